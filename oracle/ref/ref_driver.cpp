@@ -1,0 +1,182 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or shipped with the product.
+//
+// A C-ABI shim over the *reference's own* CPU HSS classes (strumpack::HSS::HSSMatrix<double>,
+// /root/reference/src/HSS/HSSMatrix.hpp:79) so that Python (ctypes) can (a) pin oracle/hss_oracle.py
+// against the real reference, (b) generate the committed fixtures in tests/golden/, and (c) time the
+// reference CPU path as bench.py's cpu_baseline (kind "reference").
+// Compiled by oracle/ref/Makefile from the sources where they lie under /root/reference; the
+// resulting library lives in oracle/_ref/ (git-ignored, travels to the GPU box as a built file).
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "HSS/HSSMatrix.hpp"
+#include "StrumpackParameters.hpp"
+#include "dense/DenseMatrix.hpp"
+#include "misc/RandomWrapper.hpp"
+
+using namespace strumpack;
+using namespace strumpack::HSS;
+
+namespace {
+struct RefHSS {
+  std::unique_ptr<HSSMatrix<double>> H;
+  int n = 0;
+};
+
+HSSOptions<double> make_opts(double rel_tol, double abs_tol, int leaf, int d0, int dd, int p,
+                             int max_rank, int algo) {
+  HSSOptions<double> o;
+  o.set_verbose(false);
+  o.set_rel_tol(rel_tol);
+  o.set_abs_tol(abs_tol);
+  o.set_leaf_size(leaf);
+  o.set_d0(d0);
+  o.set_dd(dd);
+  o.set_p(p);
+  o.set_max_rank(max_rank);
+  o.set_compression_algorithm(algo == 0 ? CompressionAlgorithm::ORIGINAL
+                                         : CompressionAlgorithm::STABLE);
+  return o;
+}
+
+double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+extern "C" {
+
+// N(0,1) draws of the reference's default generator (minstd_rand(0) + normal_distribution).
+void ref_randn(long long count, double* out) {
+  auto g = random::make_default_random_generator<double>();
+  for (long long i = 0; i < count; i++) out[i] = g->get();
+}
+
+// Toeplitz test matrix of test/test_HSS_seq.cpp:75-78 (kind 'T') and the upper-triangular
+// variant (:86-90, kind 'U'); column-major n x n into A.
+void ref_fill_test_matrix(char kind, int n, double* A) {
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < n; i++) {
+      double v = (i == j) ? 1. : 1. / (1 + std::abs(i - j));
+      if (kind == 'U' && i > j) v = 0.;
+      A[i + (size_t)j * n] = v;
+    }
+}
+
+void* ref_hss_create(int n, const double* A, int lda, double rel_tol, double abs_tol, int leaf,
+                     int d0, int dd, int p, int max_rank, int algo) {
+  auto o = make_opts(rel_tol, abs_tol, leaf, d0, dd, p, max_rank, algo);
+  DenseMatrix<double> Ad(n, n, A, lda);
+  auto* r = new RefHSS;
+  r->n = n;
+  r->H.reset(new HSSMatrix<double>(Ad, o));
+  return r;
+}
+
+void ref_hss_destroy(void* h) { delete static_cast<RefHSS*>(h); }
+int ref_hss_is_compressed(void* h) { return static_cast<RefHSS*>(h)->H->is_compressed(); }
+int ref_hss_levels(void* h) { return static_cast<RefHSS*>(h)->H->levels(); }
+int ref_hss_rank(void* h) { return static_cast<RefHSS*>(h)->H->rank(); }
+long long ref_hss_memory(void* h) { return static_cast<RefHSS*>(h)->H->memory(); }
+long long ref_hss_nonzeros(void* h) { return static_cast<RefHSS*>(h)->H->nonzeros(); }
+
+// Pre-order node table, 6 ints per node: row_offset, rows, U_rows, U_rank, V_rank, is_leaf.
+// (parsed from the reference's own print_info, HSS/HSSMatrix.cpp:333-356). Returns node count.
+int ref_hss_node_info(void* h, int* out, int cap_nodes) {
+  std::ostringstream os;
+  static_cast<RefHSS*>(h)->H->print_info(os, 0, 0);
+  std::istringstream is(os.str());
+  std::string line;
+  int cnt = 0;
+  while (std::getline(is, line)) {
+    int rk, r0, r1, c0, c1, um, ur, vm, vr;
+    char kind[32];
+    if (sscanf(line.c_str(), "SEQ rank=%d b = [%d,%d x %d,%d]  U = %d x %d V = %d x %d %31s", &rk,
+               &r0, &r1, &c0, &c1, &um, &ur, &vm, &vr, kind) == 10) {
+      if (cnt < cap_nodes) {
+        int* o = out + 6 * cnt;
+        o[0] = r0; o[1] = r1 - r0; o[2] = um; o[3] = ur; o[4] = vr;
+        o[5] = (std::strcmp(kind, "leaf") == 0);
+      }
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+void ref_hss_dense(void* h, double* out, int ld) {
+  auto D = static_cast<RefHSS*>(h)->H->dense();
+  for (std::size_t j = 0; j < D.cols(); j++)
+    std::memcpy(out + j * (size_t)ld, D.ptr(0, j), sizeof(double) * D.rows());
+}
+
+void ref_hss_mult(void* h, char trans, int nrhs, const double* B, int ldb, double* C, int ldc) {
+  auto* r = static_cast<RefHSS*>(h);
+  DenseMatrix<double> Bd(r->n, nrhs, B, ldb), Cd(r->n, nrhs);
+  r->H->mult(trans == 'N' || trans == 'n' ? Trans::N : Trans::C, Bd, Cd);
+  for (int j = 0; j < nrhs; j++)
+    std::memcpy(C + j * (size_t)ldc, Cd.ptr(0, j), sizeof(double) * r->n);
+}
+
+void ref_hss_factor(void* h) { static_cast<RefHSS*>(h)->H->factor(); }
+
+void ref_hss_solve(void* h, int nrhs, double* B, int ldb) {
+  auto* r = static_cast<RefHSS*>(h);
+  DenseMatrixWrapper<double> Bw(r->n, nrhs, B, ldb);
+  r->H->solve(Bw);
+}
+
+void ref_hss_shift(void* h, double s) { static_cast<RefHSS*>(h)->H->shift(s); }
+
+// Reference flop counters (StrumpackParameters.hpp:78-97): out[0..8] =
+// flops, update_sample, reduce_sample, ID, QR, ortho, random, ULV_factor, hss_solve.
+void ref_flops(long long* out, int reset) {
+  out[0] = params::flops; out[1] = params::update_sample_flops;
+  out[2] = params::reduce_sample_flops; out[3] = params::ID_flops; out[4] = params::QR_flops;
+  out[5] = params::ortho_flops; out[6] = params::random_flops;
+  out[7] = params::ULV_factor_flops; out[8] = params::hss_solve_flops;
+  if (reset) {
+    params::flops = 0; params::update_sample_flops = 0; params::reduce_sample_flops = 0;
+    params::ID_flops = 0; params::QR_flops = 0; params::ortho_flops = 0;
+    params::random_flops = 0; params::ULV_factor_flops = 0; params::hss_solve_flops = 0;
+  }
+}
+
+// CPU baseline: time compress / factor / solve / apply of the reference on Toeplitz T(n)
+// (nrhs right-hand sides). times[0..3] seconds; stats: rank, levels, resid ||b-H(H\b)||/||b||.
+// Returns 0 on success, 1 if compression failed.
+int ref_hss_bench_toeplitz(int n, int leaf, double rel_tol, double abs_tol, int nrhs,
+                           double* times, double* stats) {
+  DenseMatrix<double> A(n, n);
+  ref_fill_test_matrix('T', n, A.data());
+  HSSOptions<double> o;
+  o.set_verbose(false);
+  o.set_leaf_size(leaf);
+  o.set_rel_tol(rel_tol);
+  o.set_abs_tol(abs_tol);
+  double t0 = now();
+  HSSMatrix<double> H(A, o);
+  double t1 = now();
+  if (!H.is_compressed()) return 1;
+  H.factor();
+  double t2 = now();
+  DenseMatrix<double> B(n, nrhs);
+  B.random();
+  DenseMatrix<double> X(B);
+  double t3 = now();
+  H.solve(X);
+  double t4 = now();
+  auto C = H.apply(X);
+  double t5 = now();
+  C.scaled_add(-1., B);
+  times[0] = t1 - t0; times[1] = t2 - t1; times[2] = t4 - t3; times[3] = t5 - t4;
+  stats[0] = H.rank(); stats[1] = H.levels(); stats[2] = C.normF() / B.normF();
+  stats[3] = H.memory();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes loader for oracle/_ref/libstrumpack_ref.so.
+
+The library is the reference's own CPU HSS code (pghysels/STRUMPACK v8.0.0) compiled by
+oracle/ref/Makefile from the sources under /root/reference plus the thin shim
+oracle/ref/ref_driver.cpp.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libstrumpack_ref.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+        _lib = C.CDLL(_PATH, mode=C.RTLD_GLOBAL)
+        L = _lib
+        dp = C.POINTER(C.c_double)
+        L.ref_hss_create.restype = C.c_void_p
+        L.ref_hss_create.argtypes = [C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        for f in ("ref_hss_destroy", "ref_hss_factor"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = None
+        for f in ("ref_hss_is_compressed", "ref_hss_levels", "ref_hss_rank"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        for f in ("ref_hss_memory", "ref_hss_nonzeros"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_longlong
+        L.ref_hss_node_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.ref_hss_node_info.restype = C.c_int
+        L.ref_hss_dense.argtypes = [C.c_void_p, dp, C.c_int]
+        L.ref_hss_mult.argtypes = [C.c_void_p, C.c_char, C.c_int, dp, C.c_int, dp, C.c_int]
+        L.ref_hss_solve.argtypes = [C.c_void_p, C.c_int, dp, C.c_int]
+        L.ref_hss_shift.argtypes = [C.c_void_p, C.c_double]
+        L.ref_randn.argtypes = [C.c_longlong, dp]
+        L.ref_fill_test_matrix.argtypes = [C.c_char, C.c_int, dp]
+        L.ref_flops.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+        L.ref_hss_bench_toeplitz.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                             dp, dp]
+        L.ref_hss_bench_toeplitz.restype = C.c_int
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def randn(count):
+    out = np.empty(count)
+    lib().ref_randn(count, _dp(out))
+    return out
+
+
+def test_matrix(kind, n):
+    A = np.empty((n, n), order="F")
+    lib().ref_fill_test_matrix(kind.encode(), n, _dp(A))
+    return A
+
+
+class RefHSS:
+    """The reference's HSSMatrix<double>(A, opts) (HSS/HSSMatrix.cpp:50-54)."""
+
+    def __init__(self, A, rel_tol=1e-2, abs_tol=1e-8, leaf=512, d0=128, dd=64, p=10,
+                 max_rank=50000, algo="stable"):
+        A = np.asfortranarray(A, dtype=np.float64)
+        self.n = A.shape[0]
+        self.h = lib().ref_hss_create(self.n, _dp(A), A.shape[0], rel_tol, abs_tol, leaf, d0, dd,
+                                      p, max_rank, 0 if algo == "original" else 1)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_hss_destroy(self.h)
+            self.h = None
+
+    def is_compressed(self):
+        return bool(lib().ref_hss_is_compressed(self.h))
+
+    def levels(self):
+        return lib().ref_hss_levels(self.h)
+
+    def rank(self):
+        return lib().ref_hss_rank(self.h)
+
+    def memory(self):
+        return lib().ref_hss_memory(self.h)
+
+    def nonzeros(self):
+        return lib().ref_hss_nonzeros(self.h)
+
+    def node_info(self):
+        """Pre-order rows of (row_offset, rows, U_rows, U_rank, V_rank, is_leaf)."""
+        cap = 4 * self.n + 8
+        out = np.zeros((cap, 6), dtype=np.int32)
+        cnt = lib().ref_hss_node_info(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), cap)
+        return out[:cnt].copy()
+
+    def dense(self):
+        D = np.empty((self.n, self.n), order="F")
+        lib().ref_hss_dense(self.h, _dp(D), self.n)
+        return D
+
+    def mult(self, B, trans="N"):
+        B = np.asfortranarray(B, dtype=np.float64).reshape(self.n, -1, order="F")
+        Cm = np.empty_like(B, order="F")
+        lib().ref_hss_mult(self.h, trans.encode(), B.shape[1], _dp(B), self.n, _dp(Cm), self.n)
+        return Cm
+
+    def factor(self):
+        lib().ref_hss_factor(self.h)
+
+    def solve(self, B):
+        X = np.array(B, dtype=np.float64, order="F").reshape(self.n, -1, order="F")
+        lib().ref_hss_solve(self.h, X.shape[1], _dp(X), self.n)
+        return X
+
+    def shift(self, s):
+        lib().ref_hss_shift(self.h, s)
+
+
+def flops(reset=False):
+    out = (C.c_longlong * 9)()
+    lib().ref_flops(out, int(reset))
+    names = ["flops", "update_sample", "reduce_sample", "ID", "QR", "ortho", "random",
+             "ULV_factor", "hss_solve"]
+    return dict(zip(names, list(out)))
+
+
+def bench_toeplitz(n, leaf=256, rel_tol=1e-4, abs_tol=1e-8, nrhs=1):
+    times = np.zeros(4)
+    stats = np.zeros(4)
+    rc = lib().ref_hss_bench_toeplitz(n, leaf, rel_tol, abs_tol, nrhs, _dp(times), _dp(stats))
+    if rc:
+        raise RuntimeError("reference compression failed")
+    return dict(compress_s=times[0], factor_s=times[1], solve_s=times[2], apply_s=times[3],
+                rank=int(stats[0]), levels=int(stats[1]), resid=stats[2], memory=int(stats[3]))
