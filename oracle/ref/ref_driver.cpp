@@ -56,9 +56,22 @@ void ref_randn(long long count, double* out) {
   for (long long i = 0; i < count; i++) out[i] = g->get();
 }
 
-// Toeplitz test matrix of test/test_HSS_seq.cpp:75-78 (kind 'T') and the upper-triangular
-// variant (:86-90, kind 'U'); column-major n x n into A.
+// Test matrices of test/test_HSS_seq.cpp:69-105, column-major n x n into A:
+//  'T' Toeplitz (:75-78), 'U' upper-triangular Toeplitz (:86-90),
+//  'L' identity + (1/n) U V^T with U, V from DenseMatrix::random() (:92-105).
 void ref_fill_test_matrix(char kind, int n, double* A) {
+  if (kind == 'L') {
+    DenseMatrix<double> Ad(n, n);
+    Ad.eye();
+    int k = std::max(1, int(0.3 * n));
+    DenseMatrix<double> U(n, k), V(n, k);
+    U.random();
+    V.random();
+    gemm(Trans::N, Trans::C, 1. / n, U, V, 1., Ad);
+    for (int j = 0; j < n; j++)
+      std::memcpy(A + (size_t)j * n, Ad.ptr(0, j), sizeof(double) * n);
+    return;
+  }
   for (int j = 0; j < n; j++)
     for (int i = 0; i < n; i++) {
       double v = (i == j) ? 1. : 1. / (1 + std::abs(i - j));
