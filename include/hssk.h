@@ -1,0 +1,190 @@
+/* hssk.h -- thin C-ABI over the hand-written gfx950 (CDNA4) HIP kernels of the HSS engine.
+ *
+ * This layer is NOT in the reference (pghysels/STRUMPACK has no GPU path for HSS,
+ * doc/doxygen/pages/GPU_support.txt:4-6); it is the boundary "host C++ -> HIP" that SURVEY.md
+ * section 8(b) defines.  Each entry point is the device equivalent of a dense routine the
+ * reference's HSS code calls on the CPU; the reference call sites are cited per function.
+ *
+ * Conventions: every matrix pointer is a DEVICE pointer to column-major doubles; descriptor arrays
+ * are HOST arrays (the library stages them to the device); one call == one variable-size batched
+ * launch (one HSS tree level).  All functions return 0 on success, non-zero on error
+ * (hssk_last_error() gives the message) and enqueue work on the context's stream without
+ * synchronising unless stated.  Plain C types only.
+ */
+#ifndef HSSK_H
+#define HSSK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hssk_ctx hssk_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int hssk_ctx_create(hssk_ctx** ctx, int device);
+void hssk_ctx_destroy(hssk_ctx* ctx);
+void* hssk_ctx_stream(hssk_ctx* ctx); /* hipStream_t */
+int hssk_sync(hssk_ctx* ctx);
+const char* hssk_last_error(void);
+/* device memory helpers (hipMalloc/hipFree/hipMemcpy wrappers so FFI users need no HIP binding) */
+void* hssk_malloc(long long bytes);
+void hssk_free(void* dptr);
+int hssk_memcpy_h2d(hssk_ctx* ctx, void* dst, const void* src, long long bytes);
+int hssk_memcpy_d2h(hssk_ctx* ctx, void* dst, const void* src, long long bytes); /* synchronises */
+/* timing of the LAST hssk_dgemm launch on this context (HIP events on the launch stream), ms */
+float hssk_last_dgemm_ms(hssk_ctx* ctx);
+
+/* ---- generators --------------------------------------------------------------------------- */
+/* Test matrices of test/test_HSS_seq.cpp:69-91 generated in HBM: kind 'T' Toeplitz
+ * A(i,j) = i==j ? 1 : 1/(1+|i-j|), 'U' its upper triangle.  A is n x n, leading dimension lda. */
+int hssk_fill_toeplitz(hssk_ctx* ctx, double* A, int n, long long lda, char kind);
+/* N(0,1) samples, counter-based (Philox4x32-10 + Box-Muller): element (r,c) of the rows x cols
+ * panel (leading dimension ld) is a pure function of (seed, (row0+r)*stride + c).  Device
+ * replacement for DenseMatrix::random (dense/DenseMatrix.cpp:172-181) in performance runs. */
+int hssk_randn(hssk_ctx* ctx, double* P, int rows, long long cols, long long ld, int row0,
+               long long stride, unsigned long long seed);
+
+/* ---- large GEMM: the sketch  S^T = R^T op(A)   (HSS/HSSExtra.hpp:236-239) ------------------- */
+/* C(m x n) = alpha * A(m x k) * op(B) + beta * C;  op(B) = B (k x n) or B^T (B is n x k).
+ * Tuned for m <= 512 (the sample count d), n and k huge (the matrix dimension). */
+int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long long k, double alpha,
+               const double* A, long long lda, const double* B, long long ldb, double beta,
+               double* C, long long ldc);
+
+/* ---- variable-size batched GEMM on FP64 MFMA ------------------------------------------------ */
+/* C_i(m x n) = alpha * op(A_i) * op(B_i) + beta * C_i  -- every small gemm() of
+ * HSS/HSSMatrix.{compress,factor,solve,apply}.hpp (dense/DenseMatrix.cpp:935-1023). */
+typedef struct hssk_gemm_desc {
+  const double* A;
+  const double* B;
+  double* C;
+  int m, n, k;
+  int lda, ldb, ldc;
+  int transA, transB; /* 0 = N, 1 = T */
+  double alpha, beta;
+} hssk_gemm_desc;
+int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, int count);
+
+/* ---- gathers / scatters ----------------------------------------------------------------------- */
+/* dst(:, j) = src(:, idx[j]) (idx == NULL: identity) -- DenseMatrix::extract_rows in the
+ * transposed sample layout (dense/DenseMatrix.cpp:323-333), laswp (:287-297). */
+typedef struct hssk_colgather_desc {
+  const double* src;
+  double* dst;
+  const int* idx; /* device, ncols entries, or NULL */
+  int rows, ncols, lds, ldd;
+  int scatter; /* 1: dst(:, idx[j]) = src(:, j) */
+} hssk_colgather_desc;
+int hssk_gather_cols(hssk_ctx* ctx, const hssk_colgather_desc* descs, int count);
+/* dst(i, :) = src(idx[i], :)  (scatter: dst(idx[i], :) = src(i, :)); accumulate: += */
+typedef struct hssk_rowgather_desc {
+  const double* src;
+  double* dst;
+  const int* idx; /* device, nrows entries, or NULL */
+  int nrows, cols, lds, ldd;
+  int scatter, accumulate;
+} hssk_rowgather_desc;
+int hssk_gather_rows(hssk_ctx* ctx, const hssk_rowgather_desc* descs, int count);
+/* B(i,j) = A(I[i], J[j]) -- AFunctor::operator()(I,J,B) (HSS/HSSExtra.hpp:240-248).
+ * I == NULL / J == NULL: contiguous range starting at i0 / j0.  transpose: B(j,i) = ... */
+typedef struct hssk_elem_desc {
+  const double* A;
+  long long lda;
+  const int* I; /* device */
+  const int* J; /* device */
+  int i0, j0;
+  double* B;
+  int m, n, ldb, transpose;
+} hssk_elem_desc;
+int hssk_gather_elems(hssk_ctx* ctx, const hssk_elem_desc* descs, int count);
+/* dst = src^T : rows x cols (src, lds) -> cols x rows (dst, ldd) */
+typedef struct hssk_transpose_desc {
+  const double* src;
+  double* dst;
+  int rows, cols, lds, ldd;
+} hssk_transpose_desc;
+int hssk_transpose(hssk_ctx* ctx, const hssk_transpose_desc* descs, int count);
+
+/* ---- batched interpolative decomposition ------------------------------------------------------- */
+/* Truncated column-pivoted Householder QR of W (d x m, column-major, overwritten), i.e. the row ID
+ * of the m x d sample block:  DenseMatrix::ID_row -> ID_column_GEQP3 -> geqp3tol + trsm
+ * (dense/DenseMatrix.cpp:746-790, dense/lapack/dgeqp3tol.f:203-232).  Stops at the first c with
+ * |R_cc|/|R_00| <= rtol or |R_cc| <= atol; rank = min(c, max_rank).
+ * Outputs: perm[0..m) (0-based: pivoted column k is original column perm[k]); *rank; and
+ * X = R11^{-1} R12 (rank x (m-rank)) stored in W(0:rank, rank:m). */
+typedef struct hssk_id_desc {
+  double* W;
+  int ldw, d, m;
+  double rtol, atol;
+  int max_rank;
+  int* perm;    /* device, m ints */
+  int* rank;    /* device, 1 int */
+  double* work; /* device, 3*m doubles */
+} hssk_id_desc;
+int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count);
+
+/* ---- batched Householder QR ------------------------------------------------------------------- */
+/* A (rows x cols, overwritten) = Q R.  nq > 0: the first nq columns of Q are written to Q
+ * (rows x nq, ldq).  rdiag (device, 2 doubles, may be NULL) receives max|R_ii|, min|R_ii| over
+ * i < min(rows, cols).  Serves DenseMatrix::orthogonalize (geqrf+orgqr, dense/DenseMatrix.cpp:721-744)
+ * and DenseMatrix::LQ (gelqf+orglq of W0 == QR of W0^T, :693-719). */
+typedef struct hssk_qr_desc {
+  double* A;
+  int lda, rows, cols;
+  double* Q;
+  int ldq, nq;
+  double* rdiag;
+  double* work; /* device, rows + cols doubles */
+} hssk_qr_desc;
+int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
+
+/* ---- batched triangular solve / LU ------------------------------------------------------------- */
+/* B <- op(T)^{-1} B, T (n x n) triangular, B (n x nrhs)  (trsm Side::L, dense/DenseMatrix.cpp:1059-1085) */
+typedef struct hssk_trsm_desc {
+  const double* T;
+  double* B;
+  int n, nrhs, ldt, ldb;
+  int lower, transT, unit;
+} hssk_trsm_desc;
+int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count);
+/* In-place LU with partial pivoting (DenseMatrix::LU, getrf, dense/DenseMatrix.cpp:564-589);
+ * piv: device, n ints, 0-based row interchanges; info: device int (0 ok, >0 zero pivot). */
+typedef struct hssk_lu_desc {
+  double* A;
+  int n, lda;
+  int* piv;
+  int* info;
+} hssk_lu_desc;
+int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count);
+/* B <- A^{-1} B with the factors above (DenseMatrix::solve, getrs, :624-640) */
+typedef struct hssk_lusolve_desc {
+  const double* LU;
+  const int* piv;
+  double* B;
+  int n, nrhs, lda, ldb;
+} hssk_lusolve_desc;
+int hssk_getrs_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count);
+
+/* ---- small utilities --------------------------------------------------------------------------- */
+/* out[j] = sum_i P(i,j)^2 over the rows x cols panel: Frobenius norms for the stopping test
+ * (HSS/HSSMatrix.compress_stable.hpp:418,438) */
+typedef struct hssk_norm_desc {
+  const double* P;
+  int rows, cols, ld;
+  double* out; /* device, 1 double: sum of squares */
+} hssk_norm_desc;
+int hssk_sumsq_vbatched(hssk_ctx* ctx, const hssk_norm_desc* descs, int count);
+/* A(i,i) += sigma for i < n  (DenseMatrix::shift; HSS/HSSMatrix.cpp:359-365) */
+typedef struct hssk_shift_desc {
+  double* A;
+  int n, lda;
+} hssk_shift_desc;
+int hssk_shift_diag(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, double sigma);
+/* peak-rate probe: runs a dependent-free v_mfma_f64_16x16x4_f64 loop on every CU and returns the
+ * measured TFLOP/s (used by bench.py to confirm the FP64 matrix roof on the box) */
+double hssk_mfma_f64_peak_tflops(hssk_ctx* ctx, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSSK_H */

@@ -1,0 +1,41 @@
+// Device-side primitives for the gfx950 (CDNA4, wave64) kernels of the HSS engine.
+// Everything a kernel needs beyond plain C++ goes through this header: MFMA, wave shuffles,
+// launch syntax.  (tests/emu/ carries a same-named header that maps these onto a CPU fiber
+// emulator so index arithmetic and host orchestration can be unit-tested without a GPU; the
+// product is only ever built from THIS file with hipcc --offload-arch=gfx950.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define HSSK_WAVE 64
+
+typedef double hssk_d4 __attribute__((ext_vector_type(4)));
+
+// D(16x16) += A(16x4) * B(4x16), FP64 matrix core (v_mfma_f64_16x16x4_f64).
+// lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// lane l receives, in c[r], D[row = (l >> 4) + 4 r][col = l & 15].
+__device__ __forceinline__ hssk_d4 hssk_mfma_f64_16x16x4(double a, double b, hssk_d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double hssk_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int hssk_shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double hssk_shfl(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int hssk_shfl(int v, int src) { return __shfl(v, src, 64); }
+
+__device__ __forceinline__ double hssk_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double hssk_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, hssk_shfl_xor(v, o));
+  return v;
+}
+
+#define HSSK_SHARED __shared__
+#define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+
+// kernel<<<grid, block, shmem, stream>>>(args...)
+#define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__)

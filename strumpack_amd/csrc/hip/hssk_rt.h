@@ -1,0 +1,49 @@
+// Host-side runtime shim: the only place the engine touches the HIP runtime API.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#define HSSK_CHECK(call)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " +  \
+                               __FILE__ + ":" + std::to_string(__LINE__));                    \
+  } while (0)
+
+namespace hssk_rt {
+typedef hipStream_t stream_t;
+typedef hipEvent_t event_t;
+inline void* dev_malloc(size_t bytes) { void* p = nullptr; if (bytes) HSSK_CHECK(hipMalloc(&p, bytes)); return p; }
+inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+inline void* pinned_malloc(size_t bytes) { void* p = nullptr; if (bytes) HSSK_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); return p; }
+inline void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+inline void h2d(void* d, const void* h, size_t bytes, stream_t s) { if (bytes) HSSK_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s)); }
+inline void d2h(void* h, const void* d, size_t bytes, stream_t s) { if (bytes) HSSK_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s)); }
+inline void d2d(void* d, const void* s_, size_t bytes, stream_t s) { if (bytes) HSSK_CHECK(hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, s)); }
+inline void h2d_2d(void* d, size_t dpitch, const void* h, size_t hpitch, size_t width, size_t height, stream_t s) {
+  if (width && height) HSSK_CHECK(hipMemcpy2DAsync(d, dpitch, h, hpitch, width, height, hipMemcpyHostToDevice, s));
+}
+inline void d2h_2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t height, stream_t s) {
+  if (width && height) HSSK_CHECK(hipMemcpy2DAsync(h, hpitch, d, dpitch, width, height, hipMemcpyDeviceToHost, s));
+}
+inline void memset_async(void* d, int v, size_t bytes, stream_t s) { if (bytes) HSSK_CHECK(hipMemsetAsync(d, v, bytes, s)); }
+inline void sync(stream_t s) { HSSK_CHECK(hipStreamSynchronize(s)); }
+inline void check_launch() { HSSK_CHECK(hipGetLastError()); }
+inline stream_t stream_create() { stream_t s; HSSK_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
+inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+inline event_t event_create() { event_t e; HSSK_CHECK(hipEventCreate(&e)); return e; }
+inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
+inline void event_record(event_t e, stream_t s) { HSSK_CHECK(hipEventRecord(e, s)); }
+inline float event_elapsed_ms(event_t a, event_t b) { float ms = 0; HSSK_CHECK(hipEventSynchronize(b)); HSSK_CHECK(hipEventElapsedTime(&ms, a, b)); return ms; }
+inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+inline void set_device(int d) { HSSK_CHECK(hipSetDevice(d)); }
+inline bool is_device_pointer(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice;
+}
+}  // namespace hssk_rt

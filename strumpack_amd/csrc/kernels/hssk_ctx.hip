@@ -1,0 +1,72 @@
+// Context, error state and memory helpers of the hssk C-ABI (include/hssk.h).
+#include "hssk_internal.h"
+
+static thread_local std::string g_err;
+void hssk_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" {
+
+const char* hssk_last_error(void) { return g_err.c_str(); }
+
+int hssk_ctx_create(hssk_ctx** out, int device) {
+  HSSK_API_BEGIN
+  if (hssk_rt::device_count() <= device)
+    throw std::runtime_error("hssk_ctx_create: no HIP device " + std::to_string(device) +
+                             " (this library has no CPU fallback)");
+  hssk_rt::set_device(device);
+  hssk_ctx* c = new hssk_ctx;
+  c->device = device;
+  c->stream = hssk_rt::stream_create();
+  c->ring_bytes = size_t(64) << 20;
+  c->h_ring = (char*)hssk_rt::pinned_malloc(c->ring_bytes);
+  c->d_ring = (char*)hssk_rt::dev_malloc(c->ring_bytes);
+  c->ev0 = hssk_rt::event_create();
+  c->ev1 = hssk_rt::event_create();
+  *out = c;
+  HSSK_API_END
+}
+
+void hssk_ctx_destroy(hssk_ctx* c) {
+  if (!c) return;
+  try { hssk_rt::sync(c->stream); } catch (...) {}
+  hssk_rt::pinned_free(c->h_ring);
+  hssk_rt::dev_free(c->d_ring);
+  hssk_rt::dev_free(c->d_scratch);
+  hssk_rt::event_destroy(c->ev0);
+  hssk_rt::event_destroy(c->ev1);
+  hssk_rt::stream_destroy(c->stream);
+  delete c;
+}
+
+void* hssk_ctx_stream(hssk_ctx* c) { return (void*)c->stream; }
+
+int hssk_sync(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  hssk_rt::sync(c->stream);
+  HSSK_API_END
+}
+
+void* hssk_malloc(long long bytes) {
+  try { return hssk_rt::dev_malloc((size_t)bytes); } catch (const std::exception& e) { hssk_set_error(e.what()); return nullptr; }
+}
+void hssk_free(void* p) { hssk_rt::dev_free(p); }
+
+int hssk_memcpy_h2d(hssk_ctx* c, void* dst, const void* src, long long bytes) {
+  HSSK_API_BEGIN
+  hssk_rt::h2d(dst, src, (size_t)bytes, c->stream);
+  hssk_rt::sync(c->stream);  // src may be pageable: make the call synchronous for FFI safety
+  HSSK_API_END
+}
+int hssk_memcpy_d2h(hssk_ctx* c, void* dst, const void* src, long long bytes) {
+  HSSK_API_BEGIN
+  hssk_rt::d2h(dst, src, (size_t)bytes, c->stream);
+  hssk_rt::sync(c->stream);
+  HSSK_API_END
+}
+
+float hssk_last_dgemm_ms(hssk_ctx* c) {
+  if (!c->dgemm_timed) return -1.f;
+  try { return hssk_rt::event_elapsed_ms(c->ev0, c->ev1); } catch (...) { return -1.f; }
+}
+
+}  // extern "C"

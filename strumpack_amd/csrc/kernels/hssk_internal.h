@@ -1,0 +1,57 @@
+// Internal: context object shared by the kernel translation units (not part of the C-ABI).
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "hssk.h"
+#include "hssk_rt.h"
+
+struct hssk_ctx {
+  int device = 0;
+  hssk_rt::stream_t stream{};
+  // descriptor staging ring: pinned host mirror + device buffer
+  char* h_ring = nullptr;
+  char* d_ring = nullptr;
+  size_t ring_bytes = 0, ring_off = 0;
+  hssk_rt::event_t ev0{}, ev1{};
+  bool dgemm_timed = false;
+  double* d_scratch = nullptr;  // split-K partials of hssk_dgemm
+  size_t scratch_bytes = 0;
+
+  // copies `bytes` of host data into the ring and returns the device address (valid for kernels
+  // enqueued on `stream` after this call)
+  void* stage(const void* host, size_t bytes) {
+    size_t need = (bytes + 255) & ~size_t(255);
+    if (need > ring_bytes) throw std::runtime_error("hssk: descriptor batch exceeds staging ring");
+    if (ring_off + need > ring_bytes) {
+      hssk_rt::sync(stream);
+      ring_off = 0;
+    }
+    std::memcpy(h_ring + ring_off, host, bytes);
+    hssk_rt::h2d(d_ring + ring_off, h_ring + ring_off, bytes, stream);
+    void* d = d_ring + ring_off;
+    ring_off += need;
+    return d;
+  }
+  double* scratch(size_t bytes) {
+    if (bytes > scratch_bytes) {
+      hssk_rt::sync(stream);
+      hssk_rt::dev_free(d_scratch);
+      d_scratch = (double*)hssk_rt::dev_malloc(bytes);
+      scratch_bytes = bytes;
+    }
+    return d_scratch;
+  }
+};
+
+void hssk_set_error(const std::string& msg);
+
+#define HSSK_API_BEGIN try {
+#define HSSK_API_END                 \
+  return 0;                          \
+  }                                  \
+  catch (const std::exception& e) {  \
+    hssk_set_error(e.what());        \
+    return 1;                        \
+  }

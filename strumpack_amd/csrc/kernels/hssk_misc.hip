@@ -1,0 +1,294 @@
+// HBM-bound helper kernels of the HSS engine: generators, gathers/scatters, transposes, norms.
+// All are pure streaming kernels (bound: HBM / L2 bandwidth); consecutive lanes touch consecutive
+// addresses of the column-major operands wherever the access pattern allows it.
+#include "hssk_device.h"
+#include "hssk_internal.h"
+
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Toeplitz test matrix (test/test_HSS_seq.cpp:75-78, :86-90), generated in place in HBM.
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_toeplitz_kernel(double* __restrict__ A, int n, long long lda, int upper) {
+  // grid: (ceil(n/256), n): blockIdx.y = column, x covers rows -> coalesced column writes
+  int j = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int dij = i > j ? i - j : j - i;
+    double v = 1.0 / (1.0 + (double)dij);
+    if (upper && i > j) v = 0.;
+    A[i + (size_t)j * lda] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator + Box-Muller.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
+                                             unsigned k0, unsigned k1) {
+  const unsigned long long M0 = 0xD2511F53ull, M1 = 0xCD9E8D57ull;
+  unsigned long long p0 = M0 * c0, p1 = M1 * c2;
+  unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+  unsigned n1 = (unsigned)p1;
+  unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+  unsigned n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ double philox_normal(unsigned long long seed, unsigned long long ctr) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0x243F6A88u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  // two uniforms in (0,1): 53-bit mantissas
+  unsigned long long a = ((unsigned long long)c0 << 21) ^ (unsigned long long)(c1 >> 11);
+  unsigned long long b = ((unsigned long long)c2 << 21) ^ (unsigned long long)(c3 >> 11);
+  double u1 = ((double)(a & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
+  double u2 = ((double)(b & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+}
+__global__ void randn_kernel(double* __restrict__ P, int rows, long long cols, long long ld, int row0,
+                             long long stride, unsigned long long seed) {
+  long long total = (long long)rows * cols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int r = (int)(e % rows);
+    long long c = e / rows;
+    P[r + c * ld] = philox_normal(seed, (unsigned long long)(row0 + r) * (unsigned long long)stride + (unsigned long long)c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column gather / scatter: one workgroup per (problem, column chunk)
+// ------------------------------------------------------------------------------------------------
+struct Work2 {
+  int prob, chunk;
+};
+constexpr int COLS_PER_WG = 8;
+
+__global__ void gather_cols_kernel(const hssk_colgather_desc* __restrict__ descs, const Work2* __restrict__ work) {
+  const Work2 w = work[blockIdx.x];
+  const hssk_colgather_desc p = descs[w.prob];
+  int jend = min(p.ncols, (w.chunk + 1) * COLS_PER_WG);
+  for (int j = w.chunk * COLS_PER_WG; j < jend; j++) {
+    int js = p.idx ? p.idx[j] : j;
+    const double* s = p.scatter ? p.src + (size_t)j * p.lds : p.src + (size_t)js * p.lds;
+    double* d = p.scatter ? p.dst + (size_t)js * p.ldd : p.dst + (size_t)j * p.ldd;
+    for (int i = threadIdx.x; i < p.rows; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+// row gather / scatter (vectors of the apply / solve sweeps: rows = HSS node rows, cols = nrhs)
+__global__ void gather_rows_kernel(const hssk_rowgather_desc* __restrict__ descs, const Work2* __restrict__ work) {
+  const Work2 w = work[blockIdx.x];
+  const hssk_rowgather_desc p = descs[w.prob];
+  int jend = min(p.cols, (w.chunk + 1) * COLS_PER_WG);
+  for (int j = w.chunk * COLS_PER_WG; j < jend; j++) {
+    const double* s = p.src + (size_t)j * p.lds;
+    double* d = p.dst + (size_t)j * p.ldd;
+    for (int i = threadIdx.x; i < p.nrows; i += blockDim.x) {
+      int ii = p.idx ? p.idx[i] : i;
+      double v = p.scatter ? s[i] : s[ii];
+      double* o = p.scatter ? d + ii : d + i;
+      *o = p.accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+// element gather B(i,j) = A(I[i], J[j])
+__global__ void gather_elems_kernel(const hssk_elem_desc* __restrict__ descs, const Work2* __restrict__ work) {
+  const Work2 w = work[blockIdx.x];
+  const hssk_elem_desc p = descs[w.prob];
+  int jend = min(p.n, (w.chunk + 1) * COLS_PER_WG);
+  for (int j = w.chunk * COLS_PER_WG; j < jend; j++) {
+    long long gj = p.J ? p.J[j] : (p.j0 + j);
+    const double* col = p.A + (size_t)gj * p.lda;
+    for (int i = threadIdx.x; i < p.m; i += blockDim.x) {
+      long long gi = p.I ? p.I[i] : (p.i0 + i);
+      double v = col[gi];
+      if (p.transpose) p.B[j + (size_t)i * p.ldb] = v;
+      else p.B[i + (size_t)j * p.ldb] = v;
+    }
+  }
+}
+
+// transpose through a padded LDS tile: dst(c, r) = src(r, c)
+struct Work3 {
+  int prob, tr, tc;
+};
+__global__ void transpose_kernel(const hssk_transpose_desc* __restrict__ descs, const Work3* __restrict__ work) {
+  HSSK_SHARED double tile[32 * 33];
+  const Work3 w = work[blockIdx.x];
+  const hssk_transpose_desc p = descs[w.prob];
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int y = ty; y < 32; y += 8) {
+    int r = w.tr * 32 + tx, c = w.tc * 32 + y;
+    tile[y * 33 + tx] = (r < p.rows && c < p.cols) ? p.src[r + (size_t)c * p.lds] : 0.;
+  }
+  __syncthreads();
+  for (int y = ty; y < 32; y += 8) {
+    int c = w.tc * 32 + tx, r = w.tr * 32 + y;
+    if (r < p.rows && c < p.cols) p.dst[c + (size_t)r * p.ldd] = tile[tx * 33 + y];
+  }
+}
+
+// sum of squares of a panel, one workgroup per problem
+__global__ void sumsq_kernel(const hssk_norm_desc* __restrict__ descs) {
+  HSSK_SHARED double part[4];
+  const hssk_norm_desc p = descs[blockIdx.x];
+  double s = 0.;
+  long long total = (long long)p.rows * p.cols;
+  for (long long e = threadIdx.x; e < total; e += blockDim.x) {
+    int r = (int)(e % p.rows);
+    long long c = e / p.rows;
+    double v = p.P[r + c * p.ld];
+    s += v * v;
+  }
+  s = hssk_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *p.out = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void shift_diag_kernel(const hssk_shift_desc* __restrict__ descs, double sigma) {
+  const hssk_shift_desc p = descs[blockIdx.x];
+  for (int i = threadIdx.x; i < p.n; i += blockDim.x) p.A[i + (size_t)i * p.lda] += sigma;
+}
+
+// FP64 matrix-core peak probe: 4 independent accumulators per wave, no memory traffic
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  hssk_d4 c0 = {0., 0., 0., 0.}, c1 = c0, c2 = c0, c3 = c0;
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; i++) {
+    c0 = hssk_mfma_f64_16x16x4(a, b, c0);
+    c1 = hssk_mfma_f64_16x16x4(a, b, c1);
+    c2 = hssk_mfma_f64_16x16x4(a, b, c2);
+    c3 = hssk_mfma_f64_16x16x4(a, b, c3);
+  }
+  hssk_d4 s = c0 + c1 + c2 + c3;
+  if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = s[0];
+}
+
+template <class Desc, class F>
+std::vector<Work2> make_work2(const Desc* descs, int count, F ncols_of) {
+  std::vector<Work2> w;
+  for (int p = 0; p < count; p++) {
+    int nc = ncols_of(descs[p]);
+    for (int c = 0; c * COLS_PER_WG < nc; c++) w.push_back(Work2{p, c});
+  }
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hssk_fill_toeplitz(hssk_ctx* ctx, double* A, int n, long long lda, char kind) {
+  HSSK_API_BEGIN
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)std::min(64, (n + 255) / 256), (unsigned)n);
+  HSSK_LAUNCH(fill_toeplitz_kernel, grid, dim3(256), 0, ctx->stream, A, n, lda, (int)(kind == 'U'));
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_randn(hssk_ctx* ctx, double* P, int rows, long long cols, long long ld, int row0,
+               long long stride, unsigned long long seed) {
+  HSSK_API_BEGIN
+  long long total = (long long)rows * cols;
+  if (total <= 0) return 0;
+  unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 8192);
+  HSSK_LAUNCH(randn_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, rows, cols, ld, row0, stride, seed);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_gather_cols(hssk_ctx* ctx, const hssk_colgather_desc* descs, int count) {
+  HSSK_API_BEGIN
+  auto w = make_work2(descs, count, [](const hssk_colgather_desc& d) { return d.rows > 0 ? d.ncols : 0; });
+  if (w.empty()) return 0;
+  auto* dd = (const hssk_colgather_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
+  HSSK_LAUNCH(gather_cols_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_gather_rows(hssk_ctx* ctx, const hssk_rowgather_desc* descs, int count) {
+  HSSK_API_BEGIN
+  auto w = make_work2(descs, count, [](const hssk_rowgather_desc& d) { return d.nrows > 0 ? d.cols : 0; });
+  if (w.empty()) return 0;
+  auto* dd = (const hssk_rowgather_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
+  HSSK_LAUNCH(gather_rows_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_gather_elems(hssk_ctx* ctx, const hssk_elem_desc* descs, int count) {
+  HSSK_API_BEGIN
+  auto w = make_work2(descs, count, [](const hssk_elem_desc& d) { return d.m > 0 ? d.n : 0; });
+  if (w.empty()) return 0;
+  auto* dd = (const hssk_elem_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
+  HSSK_LAUNCH(gather_elems_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_transpose(hssk_ctx* ctx, const hssk_transpose_desc* descs, int count) {
+  HSSK_API_BEGIN
+  std::vector<Work3> w;
+  for (int p = 0; p < count; p++)
+    for (int tc = 0; tc * 32 < descs[p].cols; tc++)
+      for (int tr = 0; tr * 32 < descs[p].rows; tr++) w.push_back(Work3{p, tr, tc});
+  if (w.empty()) return 0;
+  auto* dd = (const hssk_transpose_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dw = (const Work3*)ctx->stage(w.data(), sizeof(Work3) * w.size());
+  HSSK_LAUNCH(transpose_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_sumsq_vbatched(hssk_ctx* ctx, const hssk_norm_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_norm_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(sumsq_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_shift_diag(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, double sigma) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_shift_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(shift_diag_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd, sigma);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+double hssk_mfma_f64_peak_tflops(hssk_ctx* ctx, int iters) {
+  try {
+    const int blocks = 256 * 8;
+    double* d = (double*)ctx->scratch(64);
+    HSSK_LAUNCH(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, 16);  // warm-up
+    hssk_rt::event_record(ctx->ev0, ctx->stream);
+    HSSK_LAUNCH(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+    hssk_rt::event_record(ctx->ev1, ctx->stream);
+    hssk_rt::check_launch();
+    float ms = hssk_rt::event_elapsed_ms(ctx->ev0, ctx->ev1);
+    ctx->dgemm_timed = false;
+    double flops = (double)blocks * 4 /*waves*/ * (double)iters * 4 /*mfma*/ * 2048.0;
+    return flops / (ms * 1e-3) * 1e-12;
+  } catch (const std::exception& e) {
+    hssk_set_error(e.what());
+    return -1.;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// Batched triangular solves and the (small) root LU of the ULV factorization.
+//
+// Reference call sites: trsm(Side::L, UpLo::L, ...) with the LQ factor L in the forward solve
+// (HSS/HSSMatrix.solve.hpp:161-162; dense/DenseMatrix.cpp:1059-1085); DenseMatrix::LU / solve =
+// getrf / getrs at the root (HSS/HSSMatrix.factor.hpp:104-106, solve.hpp:133-135;
+// dense/DenseMatrix.cpp:564-640).
+//
+// trsm: one workgroup per node; each wave owns right-hand-side columns (strided by the wave count);
+// the column being solved lives in LDS; per row step either a shuffle-reduced dot product with a
+// contiguous column of T (transposed forms) or an axpy with a contiguous column of T (plain forms),
+// so T is always read along its contiguous dimension.  Bound: latency (n dependent steps).
+// getrf: one workgroup per matrix, right-looking with partial pivoting, columns contiguous.
+#include "hssk_device.h"
+#include "hssk_internal.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int TR_THREADS = 256;
+constexpr int TR_WAVES = TR_THREADS / 64;
+
+__global__ __launch_bounds__(TR_THREADS) void trsm_kernel(const hssk_trsm_desc* __restrict__ descs) {
+  HSSK_DYN_SHARED(double, xs_all);
+  const hssk_trsm_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n, ldt = p.ldt;
+  const double* __restrict__ T = p.T;
+  double* xs = xs_all + (size_t)wave * n;
+  // effective orientation: forward substitution when (lower, N) or (upper, T)
+  const bool forward = (p.lower != 0) == (p.transT == 0);
+  for (int c0 = 0; c0 < p.nrhs; c0 += TR_WAVES) {
+    const int c = c0 + wave;
+    const bool valid = c < p.nrhs;
+    double* b = p.B + (size_t)(valid ? c : 0) * p.ldb;
+    for (int i = lane; i < n; i += 64) xs[i] = valid ? b[i] : 0.;
+    __syncthreads();
+    for (int step = 0; step < n; step++) {
+      const int i = forward ? step : n - 1 - step;
+      if (p.transT) {
+        // x_i = (x_i - sum_{l solved} T(l, i) x_l) / T(i, i): column i of T is contiguous
+        const double* tc = T + (size_t)i * ldt;
+        double s = 0.;
+        if (forward) for (int l = lane; l < i; l += 64) s += tc[l] * xs[l];
+        else for (int l = i + 1 + lane; l < n; l += 64) s += tc[l] * xs[l];
+        const double xi = xs[i];
+        s = hssk_wave_sum(s);
+        if (lane == 0) xs[i] = p.unit ? (xi - s) : (xi - s) / tc[i];
+      } else {
+        // x_i final; x_r -= T(r, i) x_i for unsolved r: column i of T is contiguous
+        const double* tc = T + (size_t)i * ldt;
+        const double xi = p.unit ? xs[i] : xs[i] / tc[i];
+        __syncthreads();  // every lane has read xs[i] before lane 0 stores the scaled value
+        if (lane == 0) xs[i] = xi;
+        if (forward) for (int r = i + 1 + lane; r < n; r += 64) xs[r] -= tc[r] * xi;
+        else for (int r = lane; r < i; r += 64) xs[r] -= tc[r] * xi;
+      }
+      __syncthreads();
+    }
+    if (valid) for (int i = lane; i < n; i += 64) b[i] = xs[i];
+    __syncthreads();
+  }
+}
+
+constexpr int LU_THREADS = 256;
+
+__global__ __launch_bounds__(LU_THREADS) void getrf_kernel(const hssk_lu_desc* __restrict__ descs) {
+  HSSK_SHARED double s_val[LU_THREADS / 64];
+  HSSK_SHARED int s_idx[LU_THREADS / 64];
+  HSSK_SHARED int s_piv;
+  const hssk_lu_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n, ld = p.lda;
+  double* __restrict__ A = p.A;
+  int info = 0;
+  for (int k = 0; k < n; k++) {
+    // pivot: first arg max_{i >= k} |A(i, k)|
+    double bv = -1.;
+    int bi = 0x7fffffff;
+    for (int i = k + tid; i < n; i += LU_THREADS) {
+      double v = fabs(A[i + (size_t)k * ld]);
+      if (v > bv) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      double ov = hssk_shfl_xor(bv, o);
+      int oi = hssk_shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_val[0];
+      int ix = s_idx[0];
+      for (int w = 1; w < LU_THREADS / 64; w++)
+        if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
+      s_piv = ix;
+      p.piv[k] = ix;
+    }
+    __syncthreads();
+    const int pv = s_piv;
+    if (pv != k)
+      for (int j = tid; j < n; j += LU_THREADS) {
+        double a = A[k + (size_t)j * ld], b = A[pv + (size_t)j * ld];
+        A[k + (size_t)j * ld] = b;
+        A[pv + (size_t)j * ld] = a;
+      }
+    __syncthreads();
+    const double akk = A[k + (size_t)k * ld];
+    if (akk == 0.) {
+      if (!info) info = k + 1;
+      __syncthreads();
+      continue;
+    }
+    const double inv = 1. / akk;
+    __syncthreads();  // everyone holds akk before the column is scaled
+    for (int i = k + 1 + tid; i < n; i += LU_THREADS) A[i + (size_t)k * ld] *= inv;
+    __syncthreads();
+    // trailing update: one column per wave, lanes along the (contiguous) column
+    const double* lk = A + (size_t)k * ld;
+    for (int j = k + 1 + wave; j < n; j += LU_THREADS / 64) {
+      double* col = A + (size_t)j * ld;
+      const double ukj = col[k];
+      for (int i = k + 1 + lane; i < n; i += 64) col[i] -= lk[i] * ukj;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *p.info = info;
+}
+
+// B <- P B (row interchanges of getrf applied in order), one thread per right-hand side
+__global__ void laswp_kernel(const hssk_lusolve_desc* __restrict__ descs) {
+  const hssk_lusolve_desc p = descs[blockIdx.x];
+  for (int c = threadIdx.x; c < p.nrhs; c += blockDim.x) {
+    double* b = p.B + (size_t)c * p.ldb;
+    for (int k = 0; k < p.n; k++) {
+      int pv = p.piv[k];
+      if (pv != k) { double t = b[k]; b[k] = b[pv]; b[pv] = t; }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  int nmax = 0;
+  for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
+  if (nmax == 0) return 0;
+  size_t shmem = sizeof(double) * (size_t)nmax * TR_WAVES;
+  if (shmem > 150 * 1024) throw std::runtime_error("hssk_trsm_vbatched: triangular block too large for LDS");
+  auto* dd = (const hssk_trsm_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(trsm_kernel, dim3((unsigned)count), dim3(TR_THREADS), shmem, ctx->stream, dd);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_lu_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_getrs_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_lusolve_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(laswp_kernel, dim3((unsigned)count), dim3(64), 0, ctx->stream, dd);
+  std::vector<hssk_trsm_desc> lo(count), up(count);
+  for (int i = 0; i < count; i++) {
+    lo[i] = hssk_trsm_desc{descs[i].LU, descs[i].B, descs[i].n, descs[i].nrhs, descs[i].lda, descs[i].ldb, 1, 0, 1};
+    up[i] = hssk_trsm_desc{descs[i].LU, descs[i].B, descs[i].n, descs[i].nrhs, descs[i].lda, descs[i].ldb, 0, 0, 0};
+  }
+  if (hssk_trsm_vbatched(ctx, lo.data(), count)) return 1;
+  if (hssk_trsm_vbatched(ctx, up.data(), count)) return 1;
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+}  // extern "C"

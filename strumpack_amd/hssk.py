@@ -1,0 +1,197 @@
+"""ctypes binding of the thin kernel-level C-ABI (include/hssk.h).
+
+Used by the parity tests and bench.py to drive individual HIP kernels; the HSS engine itself is
+native C++ (strumpack_amd/csrc/host) and calls the same entry points directly.
+"""
+import ctypes as C
+
+import numpy as np
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("transA", C.c_int), ("transB", C.c_int),
+                ("alpha", C.c_double), ("beta", C.c_double)]
+
+
+class ColGatherDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p),
+                ("rows", C.c_int), ("ncols", C.c_int), ("lds", C.c_int), ("ldd", C.c_int),
+                ("scatter", C.c_int)]
+
+
+class RowGatherDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p),
+                ("nrows", C.c_int), ("cols", C.c_int), ("lds", C.c_int), ("ldd", C.c_int),
+                ("scatter", C.c_int), ("accumulate", C.c_int)]
+
+
+class ElemDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_longlong), ("I", C.c_void_p), ("J", C.c_void_p),
+                ("i0", C.c_int), ("j0", C.c_int), ("B", C.c_void_p),
+                ("m", C.c_int), ("n", C.c_int), ("ldb", C.c_int), ("transpose", C.c_int)]
+
+
+class TransposeDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("lds", C.c_int), ("ldd", C.c_int)]
+
+
+class IdDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("d", C.c_int), ("m", C.c_int),
+                ("rtol", C.c_double), ("atol", C.c_double), ("max_rank", C.c_int),
+                ("perm", C.c_void_p), ("rank", C.c_void_p), ("work", C.c_void_p)]
+
+
+class QrDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("rows", C.c_int), ("cols", C.c_int),
+                ("Q", C.c_void_p), ("ldq", C.c_int), ("nq", C.c_int),
+                ("rdiag", C.c_void_p), ("work", C.c_void_p)]
+
+
+class TrsmDesc(C.Structure):
+    _fields_ = [("T", C.c_void_p), ("B", C.c_void_p), ("n", C.c_int), ("nrhs", C.c_int),
+                ("ldt", C.c_int), ("ldb", C.c_int), ("lower", C.c_int), ("transT", C.c_int),
+                ("unit", C.c_int)]
+
+
+class LuDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("n", C.c_int), ("lda", C.c_int), ("piv", C.c_void_p),
+                ("info", C.c_void_p)]
+
+
+class LuSolveDesc(C.Structure):
+    _fields_ = [("LU", C.c_void_p), ("piv", C.c_void_p), ("B", C.c_void_p),
+                ("n", C.c_int), ("nrhs", C.c_int), ("lda", C.c_int), ("ldb", C.c_int)]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
+                ("out", C.c_void_p)]
+
+
+class ShiftDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("n", C.c_int), ("lda", C.c_int)]
+
+
+HSSK_SYMBOLS = [
+    "hssk_ctx_create", "hssk_ctx_destroy", "hssk_ctx_stream", "hssk_sync", "hssk_last_error",
+    "hssk_malloc", "hssk_free", "hssk_memcpy_h2d", "hssk_memcpy_d2h", "hssk_last_dgemm_ms",
+    "hssk_fill_toeplitz", "hssk_randn", "hssk_dgemm", "hssk_gemm_vbatched", "hssk_gather_cols",
+    "hssk_gather_rows", "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched",
+    "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
+    "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops",
+]
+
+
+class DevArray:
+    """A device buffer with numpy-like shape metadata (column-major)."""
+
+    def __init__(self, hk, shape, dtype=np.float64):
+        self.hk, self.shape, self.dtype = hk, tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = hk.lib.hssk_malloc(max(self.nbytes, 8))
+        if not self.ptr:
+            raise MemoryError(hk.error())
+
+    def free(self):
+        if self.ptr:
+            self.hk.lib.hssk_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype, order="F")
+        if self.nbytes:
+            self.hk.check(self.hk.lib.hssk_memcpy_d2h(self.hk.ctx, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def set(self, arr):
+        a = np.asfortranarray(arr, dtype=self.dtype)
+        assert a.shape == self.shape
+        if self.nbytes:
+            self.hk.check(self.hk.lib.hssk_memcpy_h2d(self.hk.ctx, self.ptr, a.ctypes.data, self.nbytes))
+        return self
+
+    def at(self, *idx):
+        """device address of element idx (column-major)"""
+        off, stride = 0, 1
+        for i, n in zip(idx, self.shape):
+            off += i * stride
+            stride *= n
+        return self.ptr + off * self.dtype.itemsize
+
+
+class Hssk:
+    def __init__(self, path, device=0):
+        self.lib = L = C.CDLL(path)
+        L.hssk_malloc.restype = C.c_void_p
+        L.hssk_malloc.argtypes = [C.c_longlong]
+        L.hssk_free.argtypes = [C.c_void_p]
+        L.hssk_last_error.restype = C.c_char_p
+        L.hssk_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.hssk_ctx_destroy.argtypes = [C.c_void_p]
+        L.hssk_ctx_stream.restype = C.c_void_p
+        L.hssk_ctx_stream.argtypes = [C.c_void_p]
+        L.hssk_sync.argtypes = [C.c_void_p]
+        L.hssk_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.hssk_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.hssk_last_dgemm_ms.restype = C.c_float
+        L.hssk_last_dgemm_ms.argtypes = [C.c_void_p]
+        L.hssk_fill_toeplitz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_char]
+        L.hssk_randn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
+                                 C.c_int, C.c_longlong, C.c_ulonglong]
+        L.hssk_dgemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_longlong,
+                                 C.c_double, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                 C.c_double, C.c_void_p, C.c_longlong]
+        for name in ("hssk_gemm_vbatched", "hssk_gather_cols", "hssk_gather_rows",
+                     "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched", "hssk_qr_vbatched",
+                     "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
+                     "hssk_sumsq_vbatched"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        L.hssk_mfma_f64_peak_tflops.restype = C.c_double
+        L.hssk_mfma_f64_peak_tflops.argtypes = [C.c_void_p, C.c_int]
+        ctx = C.c_void_p()
+        if L.hssk_ctx_create(C.byref(ctx), device):
+            raise RuntimeError(self.error())
+        self.ctx = ctx
+
+    def error(self):
+        return self.lib.hssk_last_error().decode()
+
+    def check(self, rc):
+        if rc:
+            raise RuntimeError(self.error())
+
+    def close(self):
+        if self.ctx:
+            self.lib.hssk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        self.check(self.lib.hssk_sync(self.ctx))
+
+    def empty(self, shape, dtype=np.float64):
+        return DevArray(self, shape, dtype)
+
+    def array(self, arr, dtype=None):
+        a = np.asarray(arr)
+        d = DevArray(self, a.shape, dtype or a.dtype)
+        return d.set(a)
+
+    def batch(self, fn_name, descs):
+        if not descs:
+            return
+        arr = (type(descs[0]) * len(descs))(*descs)
+        self.check(getattr(self.lib, fn_name)(self.ctx, arr, len(descs)))

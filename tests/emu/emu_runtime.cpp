@@ -1,0 +1,175 @@
+// TEST INFRASTRUCTURE ONLY.  Fiber-based SIMT emulator: every GPU thread of a workgroup is a
+// ucontext fiber; the fibers of one workgroup run round-robin on one OS thread and switch at
+// __syncthreads()/wave-collective points; workgroups are distributed over a few OS threads.
+// Deterministic, no data races inside a workgroup; catches indexing/logic errors, not memory-model
+// ones.  Wave collectives require every live lane of the wave to participate (as on hardware with
+// a full exec mask).
+#include <ucontext.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "hssk_device.h"
+
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+namespace {
+constexpr size_t STACK = 256 * 1024;
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+};
+struct Wave {
+  int count = 0, live = 0;
+  unsigned gen = 0;
+  double buf[64], buf2[64];
+};
+struct Worker {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  int cur = 0, live = 0, bcount = 0;
+  unsigned bgen = 0;
+  const std::function<void()>* body = nullptr;
+  std::vector<char> shmem;
+  dim3 bdim;
+};
+thread_local Worker* W = nullptr;
+
+void yield() {
+  Worker* w = W;
+  swapcontext(&w->fibers[w->cur].ctx, &w->sched);
+}
+void trampoline() {
+  Worker* w = W;
+  (*w->body)();
+  Fiber& f = w->fibers[w->cur];
+  f.done = true;
+  w->live--;
+  w->waves[w->cur / 64].live--;
+  swapcontext(&f.ctx, &w->sched);
+}
+void set_tid(Worker* w, int t) {
+  threadIdx.x = t % w->bdim.x;
+  threadIdx.y = (t / w->bdim.x) % w->bdim.y;
+  threadIdx.z = t / (w->bdim.x * w->bdim.y);
+}
+void run_block(Worker* w, dim3 grid, dim3 block, unsigned bid) {
+  int T = block.x * block.y * block.z;
+  if ((int)w->fibers.size() < T) {
+    size_t old = w->fibers.size();
+    w->fibers.resize(T);
+    for (size_t i = old; i < (size_t)T; i++) w->fibers[i].stack = (char*)std::malloc(STACK);
+  }
+  w->waves.assign((T + 63) / 64, Wave());
+  for (int t = 0; t < T; t++) w->waves[t / 64].live++;
+  w->live = T; w->bcount = 0; w->bgen = 0; w->bdim = block;
+  blockIdx.x = bid % grid.x; blockIdx.y = (bid / grid.x) % grid.y; blockIdx.z = bid / (grid.x * grid.y);
+  blockDim = block; gridDim = grid;
+  for (int t = 0; t < T; t++) {
+    Fiber& f = w->fibers[t];
+    f.done = false;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STACK;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, trampoline, 0);
+  }
+  long spins = 0;
+  while (w->live > 0) {
+    for (int t = 0; t < T; t++) {
+      if (w->fibers[t].done) continue;
+      w->cur = t;
+      set_tid(w, t);
+      swapcontext(&w->sched, &w->fibers[t].ctx);
+    }
+    if (++spins > 200000000L) { std::fprintf(stderr, "emu: deadlock in block %u\n", bid); std::abort(); }
+  }
+}
+}  // namespace
+
+void* dyn_shared() { return W->shmem.data(); }
+
+void block_barrier() {
+  Worker* w = W;
+  unsigned g = w->bgen;
+  w->bcount++;
+  for (;;) {
+    if (w->bgen != g) return;
+    if (w->bcount >= w->live) { w->bcount = 0; w->bgen++; return; }
+    yield();
+    set_tid(w, w->cur);
+  }
+}
+
+static void wave_barrier(Worker* w, Wave& wv) {
+  unsigned g = wv.gen;
+  wv.count++;
+  for (;;) {
+    if (wv.gen != g) return;
+    if (wv.count >= wv.live) { wv.count = 0; wv.gen++; return; }
+    yield();
+  }
+}
+
+double wave_xchg(double v, int src_lane) {
+  Worker* w = W;
+  int t = w->cur;
+  Wave& wv = w->waves[t / 64];
+  wv.buf[t % 64] = v;
+  wave_barrier(w, wv);
+  double r = wv.buf[src_lane];
+  wave_barrier(w, wv);
+  return r;
+}
+
+hssk_d4 mfma_f64_16x16x4(double a, double b, hssk_d4 c) {
+  Worker* w = W;
+  int t = w->cur, l = t % 64;
+  Wave& wv = w->waves[t / 64];
+  wv.buf[l] = a;
+  wv.buf2[l] = b;
+  wave_barrier(w, wv);
+  int col = l & 15;
+  for (int r = 0; r < 4; r++) {
+    int row = (l >> 4) + 4 * r;
+    double s = c[r];
+    for (int k = 0; k < 4; k++) s = std::fma(wv.buf[row + 16 * k], wv.buf2[col + 16 * k], s);
+    c[r] = s;
+  }
+  wave_barrier(w, wv);
+  return c;
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+  unsigned nblocks = grid.x * grid.y * grid.z;
+  if (!nblocks) return;
+  static int nthreads = [] {
+    const char* e = std::getenv("HSSK_EMU_THREADS");
+    int n = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(n, 16));
+  }();
+  std::atomic<unsigned> next{0};
+  auto work = [&]() {
+    static thread_local Worker worker;
+    W = &worker;
+    worker.body = &body;
+    worker.shmem.assign(shmem + 64, 0);
+    for (;;) {
+      unsigned b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      run_block(&worker, grid, block, b);
+    }
+  };
+  int nt = (int)std::min<unsigned>(nthreads, nblocks);
+  if (nt <= 1) { work(); return; }
+  std::vector<std::thread> th;
+  for (int i = 0; i < nt; i++) th.emplace_back(work);
+  for (auto& t : th) t.join();
+}
+}  // namespace emu

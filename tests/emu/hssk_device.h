@@ -1,0 +1,64 @@
+// TEST INFRASTRUCTURE ONLY.  CPU stand-in for strumpack_amd/csrc/hip/hssk_device.h: lets the
+// *same kernel sources* be compiled with g++ and run on a fiber-based SIMT emulator
+// (emu_runtime.cpp) so that index arithmetic and the host orchestration can be unit-tested in the
+// GPU-less build container.  Never part of the product: libstrumpack_amd.so is built by hipcc for
+// gfx950 from csrc/hip/hssk_device.h, and the Python package refuses to load anything else.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+
+#define HSSK_WAVE 64
+#define HSSK_EMU 1
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+typedef double hssk_d4 __attribute__((vector_size(32)));
+
+namespace emu {
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void* dyn_shared();
+void block_barrier();
+double wave_xchg(double v, int src_lane);  // every live lane of the wave must call
+hssk_d4 mfma_f64_16x16x4(double a, double b, hssk_d4 c);
+}  // namespace emu
+
+inline void __syncthreads() { emu::block_barrier(); }
+
+inline hssk_d4 hssk_mfma_f64_16x16x4(double a, double b, hssk_d4 c) {
+  return emu::mfma_f64_16x16x4(a, b, c);
+}
+inline double hssk_shfl_xor(double v, int mask) {
+  return emu::wave_xchg(v, (int)((threadIdx.x & 63) ^ mask));
+}
+inline int hssk_shfl_xor(int v, int mask) { return (int)hssk_shfl_xor((double)v, mask); }
+inline double hssk_shfl(double v, int src) { return emu::wave_xchg(v, src & 63); }
+inline int hssk_shfl(int v, int src) { return (int)hssk_shfl((double)v, src); }
+inline double hssk_wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
+  return v;
+}
+using std::min;
+using std::max;
+inline double hssk_wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = std::fmax(v, hssk_shfl_xor(v, o));
+  return v;
+}
+
+#define HSSK_SHARED static thread_local
+#define HSSK_DYN_SHARED(type, name) type* name = (type*)emu::dyn_shared()
+
+#define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,258 @@
+"""Kernel-level parity cases shared by the GPU tests (product library, `-m gpu`) and the CPU tests
+(the same kernel sources on the fiber emulator, tests/emu).  Every case drives a hssk_* entry point
+of include/hssk.h and compares with numpy/LAPACK (the oracle of each dense primitive)."""
+import numpy as np
+import scipy.linalg as sla
+
+from strumpack_amd import hssk as K
+
+
+def rng(seed=0):
+    return np.random.default_rng(seed)
+
+
+def case_gemm_vbatched(hk, shapes, seed=0):
+    r = rng(seed)
+    descs, keep, expect = [], [], []
+    for (m, n, k, ta, tb, alpha, beta) in shapes:
+        A = r.standard_normal((k, m) if ta else (m, k))
+        B = r.standard_normal((n, k) if tb else (k, n))
+        Cm = r.standard_normal((m + 3, n))  # ldc = m + 3
+        dA, dB, dC = hk.array(A), hk.array(B), hk.array(Cm)
+        keep += [dA, dB, dC]
+        descs.append(K.GemmDesc(dA.ptr, dB.ptr, dC.ptr, m, n, k, max(A.shape[0], 1),
+                                max(B.shape[0], 1), m + 3, int(ta), int(tb), alpha, beta))
+        ref = Cm.copy()
+        opA = A.T if ta else A
+        opB = B.T if tb else B
+        ref[:m] = alpha * (opA @ opB) + (beta * Cm[:m] if beta != 0 else 0)
+        expect.append(ref)
+    hk.batch("hssk_gemm_vbatched", descs)
+    hk.sync()
+    for (dC, ref, sh) in zip(keep[2::3], expect, shapes):
+        got = dC.get()
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() <= 1e-12 * scale * max(sh[2], 1), f"gemm {sh}"
+
+
+def case_dgemm(hk, m, n, k, transB, alpha=1.0, beta=0.0, lda_pad=5, seed=1):
+    r = rng(seed)
+    A = r.standard_normal((m + lda_pad, k))
+    B = r.standard_normal((n + 1, k)) if transB else r.standard_normal((k + 1, n))
+    Cm = r.standard_normal((m + 2, n))
+    dA, dB, dC = hk.array(A), hk.array(B), hk.array(Cm)
+    hk.check(hk.lib.hssk_dgemm(hk.ctx, int(transB), m, n, k, alpha, dA.ptr, A.shape[0], dB.ptr,
+                               B.shape[0], beta, dC.ptr, Cm.shape[0]))
+    hk.sync()
+    opB = B[:n].T if transB else B[:k]
+    ref = Cm.copy()
+    ref[:m] = alpha * (A[:m] @ opB) + (beta * Cm[:m] if beta != 0 else 0)
+    got = dC.get()
+    assert np.abs(got - ref).max() <= 1e-13 * max(k, 1) * max(1.0, np.abs(ref).max()), \
+        f"dgemm m={m} n={n} k={k} transB={transB}"
+
+
+def case_toeplitz_randn(hk, n=70):
+    dA = hk.empty((n + 2, n))
+    dA.set(np.full((n + 2, n), -7.0))
+    for kind in ("T", "U"):
+        hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n + 2, kind.encode()))
+        hk.sync()
+        i = np.arange(n)
+        ref = 1.0 / (1.0 + np.abs(i[:, None] - i[None, :]))
+        if kind == "U":
+            ref = np.triu(ref)
+        got = dA.get()
+        assert np.array_equal(got[:n], ref) and np.all(got[n:] == -7.0)
+    rows, cols, ld = 24, 4000, 32
+    dP = hk.empty((ld, cols))
+    dP.set(np.zeros((ld, cols)))
+    hk.check(hk.lib.hssk_randn(hk.ctx, dP.ptr, rows, cols, ld, 0, cols, 42))
+    hk.sync()
+    P = dP.get()
+    assert np.all(P[rows:] == 0)
+    x = P[:rows].ravel()
+    assert abs(x.mean()) < 0.02 and abs(x.std() - 1) < 0.02 and abs((x ** 3).mean()) < 0.05
+    # counter-based: a sub-panel regenerated with a row offset reproduces the same numbers
+    dQ = hk.empty((8, cols))
+    hk.check(hk.lib.hssk_randn(hk.ctx, dQ.ptr, 8, cols, 8, 16, cols, 42))
+    hk.sync()
+    assert np.array_equal(dQ.get(), P[16:24])
+
+
+def case_gathers(hk, seed=3):
+    r = rng(seed)
+    src = r.standard_normal((37, 50))
+    idx = r.permutation(50)[:21].astype(np.int32)
+    dS, dI = hk.array(src), hk.array(idx)
+    dD = hk.array(np.zeros((40, 21)))
+    hk.batch("hssk_gather_cols", [K.ColGatherDesc(dS.ptr, dD.ptr, dI.ptr, 37, 21, 37, 40, 0)])
+    hk.sync()
+    assert np.array_equal(dD.get()[:37], src[:, idx])
+    dD2 = hk.array(np.zeros((37, 50)))
+    hk.batch("hssk_gather_cols", [K.ColGatherDesc(dD.ptr, dD2.ptr, dI.ptr, 37, 21, 40, 37, 1)])
+    hk.sync()
+    ref = np.zeros((37, 50))
+    ref[:, idx] = src[:, idx]
+    assert np.array_equal(dD2.get(), ref)
+    # rows
+    ridx = r.permutation(37)[:15].astype(np.int32)
+    dR = hk.array(ridx)
+    dE = hk.array(np.ones((15, 50)))
+    hk.batch("hssk_gather_rows", [K.RowGatherDesc(dS.ptr, dE.ptr, dR.ptr, 15, 50, 37, 15, 0, 1)])
+    hk.sync()
+    assert np.allclose(dE.get(), 1 + src[ridx])
+    dF = hk.array(np.zeros((37, 50)))
+    hk.batch("hssk_gather_rows", [K.RowGatherDesc(dE.ptr, dF.ptr, dR.ptr, 15, 50, 15, 37, 1, 0)])
+    hk.sync()
+    ref = np.zeros((37, 50))
+    ref[ridx] = 1 + src[ridx]
+    assert np.allclose(dF.get(), ref)
+    # elements
+    Ii = r.permutation(37)[:9].astype(np.int32)
+    Jj = r.permutation(50)[:13].astype(np.int32)
+    dIi, dJj = hk.array(Ii), hk.array(Jj)
+    dB = hk.array(np.zeros((9, 13)))
+    dBt = hk.array(np.zeros((13, 9)))
+    dBc = hk.array(np.zeros((10, 12)))
+    hk.batch("hssk_gather_elems", [
+        K.ElemDesc(dS.ptr, 37, dIi.ptr, dJj.ptr, 0, 0, dB.ptr, 9, 13, 9, 0),
+        K.ElemDesc(dS.ptr, 37, dIi.ptr, dJj.ptr, 0, 0, dBt.ptr, 9, 13, 13, 1),
+        K.ElemDesc(dS.ptr, 37, None, None, 5, 7, dBc.ptr, 10, 12, 10, 0)])
+    hk.sync()
+    assert np.array_equal(dB.get(), src[np.ix_(Ii, Jj)])
+    assert np.array_equal(dBt.get(), src[np.ix_(Ii, Jj)].T)
+    assert np.array_equal(dBc.get(), src[5:15, 7:19])
+    # transpose
+    dT = hk.array(np.zeros((52, 37)))
+    hk.batch("hssk_transpose", [K.TransposeDesc(dS.ptr, dT.ptr, 37, 50, 37, 52)])
+    hk.sync()
+    assert np.array_equal(dT.get()[:50], src.T)
+    # sumsq + shift
+    dO = hk.array(np.zeros(1))
+    hk.batch("hssk_sumsq_vbatched", [K.NormDesc(dS.ptr, 30, 50, 37, dO.ptr)])
+    hk.sync()
+    assert np.isclose(dO.get()[0], (src[:30] ** 2).sum())
+    sq = r.standard_normal((12, 12))
+    dQ = hk.array(sq)
+    arr = (K.ShiftDesc * 1)(K.ShiftDesc(dQ.ptr, 12, 12))
+    hk.check(hk.lib.hssk_shift_diag(hk.ctx, arr, 1, 2.5))
+    hk.sync()
+    assert np.allclose(dQ.get(), sq + 2.5 * np.eye(12))
+
+
+def _lowrank(r, d, m, rank, decay=1e-9):
+    U = r.standard_normal((d, rank))
+    V = r.standard_normal((rank, m))
+    s = np.logspace(0, np.log10(decay), rank)
+    return (U * s) @ V
+
+
+def case_id(hk, problems, seed=5):
+    """problems: list of (d, m, rtol, atol, max_rank, numerical_rank or None)"""
+    r = rng(seed)
+    descs, keep = [], []
+    for (d, m, rtol, atol, mr, nr) in problems:
+        Wm = r.standard_normal((d, m)) if nr is None else _lowrank(r, d, m, nr)
+        ld = d + 2
+        Wp = np.zeros((ld, m))
+        Wp[:d] = Wm
+        dW = hk.array(Wp)
+        dperm, drank, dwork = hk.empty((m,), np.int32), hk.empty((1,), np.int32), hk.empty((3 * m,))
+        keep.append((Wm, dW, dperm, drank))
+        keep.append(dwork)
+        descs.append(K.IdDesc(dW.ptr, ld, d, m, rtol, atol, mr, dperm.ptr, drank.ptr, dwork.ptr))
+    hk.batch("hssk_id_vbatched", descs)
+    hk.sync()
+    for (prob, (Wm, dW, dperm, drank)) in zip(problems, keep[0::2]):
+        d, m, rtol, atol, mr, nr = prob
+        rank = int(drank.get()[0])
+        perm = dperm.get()
+        assert sorted(perm.tolist()) == list(range(m)), "perm is not a permutation"
+        # reference: LAPACK QRCP with the same stopping rule (dgeqp3tol.f:225-232)
+        R, jp = sla.qr(Wm, mode="r", pivoting=True)
+        dg = np.abs(np.diag(R))
+        kk = min(d, m)
+        rr = kk
+        for c in range(kk):
+            ratio = dg[c] / dg[0] if dg[0] != 0 else np.nan
+            if ratio <= rtol or dg[c] <= atol:
+                rr = c
+                break
+        rr = min(rr, mr)
+        assert abs(rank - rr) <= (1 if rr > 0 else 0), f"rank {rank} vs LAPACK {rr} for {prob}"
+        if rank == 0:
+            continue
+        X = dW.get()[:rank, rank:]
+        # interpolation property: W[:, perm[rank:]] ~= W[:, perm[:rank]] X
+        skel = Wm[:, perm[:rank]]
+        rest = Wm[:, perm[rank:]]
+        err = np.linalg.norm(rest - skel @ X) / max(np.linalg.norm(Wm), 1e-300)
+        # residual is bounded by the first rejected pivot (times a modest growth factor)
+        bound = (max(rtol * dg[0], atol, dg[min(rank, kk - 1)]) if rank < kk else 1e-13 * dg[0]) \
+            * np.sqrt(m) * 4 / max(np.linalg.norm(Wm), 1e-300)
+        assert err <= max(bound, 1e-12), f"ID residual {err} > {bound} for {prob}"
+        assert X.size == 0 or np.abs(X).max() < 1e3
+
+
+def case_qr(hk, shapes, seed=7):
+    r = rng(seed)
+    descs, keep = [], []
+    for (rows, cols, nq) in shapes:
+        A = r.standard_normal((rows, cols))
+        dA = hk.array(A)
+        dQ = hk.empty((rows, max(nq, 1)))
+        drd, dwk = hk.empty((2,)), hk.empty((rows + cols,))
+        keep.append((A, dA, dQ, drd, dwk))
+        descs.append(K.QrDesc(dA.ptr, rows, rows, cols, dQ.ptr if nq else None, rows, nq, drd.ptr, dwk.ptr))
+    hk.batch("hssk_qr_vbatched", descs)
+    hk.sync()
+    for ((rows, cols, nq), (A, dA, dQ, drd, _)) in zip(shapes, keep):
+        k = min(rows, cols)
+        Rg = np.triu(dA.get())[:k]
+        Rl = sla.qr(A, mode="r")[0][:k]
+        # same Householder convention as LAPACK dgeqr2 -> same signs
+        assert np.allclose(Rg, Rl, atol=1e-11 * np.abs(Rl).max()), f"R mismatch {rows}x{cols}"
+        rd = drd.get()
+        assert np.isclose(rd[0], np.abs(np.diag(Rl)).max()) and np.isclose(rd[1], np.abs(np.diag(Rl)).min())
+        if nq:
+            Q = dQ.get()[:, :nq]
+            assert np.allclose(Q.T @ Q, np.eye(nq), atol=1e-12)
+            kq = min(nq, k)
+            assert np.allclose(Q[:, :kq] @ Rg[:kq, :][:, :cols] if nq >= k else Q @ Rg[:nq], A if nq >= k else Q @ Rg[:nq], atol=1e-11)
+            if nq >= k:
+                assert np.allclose(Q[:, :k] @ Rg, A, atol=1e-11 * max(1, np.abs(A).max()))
+
+
+def case_trsm_lu(hk, seed=9):
+    r = rng(seed)
+    descs, keep = [], []
+    for (n, nrhs, lower, trans, unit) in [(37, 1, 1, 0, 0), (37, 5, 0, 1, 0), (64, 3, 0, 0, 0),
+                                          (65, 2, 1, 1, 0), (20, 9, 1, 0, 1), (1, 1, 1, 0, 0),
+                                          (130, 1, 0, 1, 0)]:
+        T = r.standard_normal((n, n)) + n * np.eye(n)
+        B = r.standard_normal((n, nrhs))
+        dT, dB = hk.array(T), hk.array(B)
+        keep.append((T, B, dT, dB, lower, trans, unit))
+        descs.append(K.TrsmDesc(dT.ptr, dB.ptr, n, nrhs, n, n, lower, trans, unit))
+    hk.batch("hssk_trsm_vbatched", descs)
+    hk.sync()
+    for (T, B, dT, dB, lower, trans, unit) in keep:
+        Tt = np.tril(T) if lower else np.triu(T)
+        if unit:
+            np.fill_diagonal(Tt, 1.0)
+        ref = np.linalg.solve(Tt.T if trans else Tt, B)
+        assert np.allclose(dB.get(), ref, atol=1e-11), f"trsm lower={lower} trans={trans}"
+    for n, nrhs in [(1, 1), (45, 3), (130, 1)]:
+        A = r.standard_normal((n, n))
+        B = r.standard_normal((n, nrhs))
+        dA, dB = hk.array(A), hk.array(B)
+        dpiv, dinfo = hk.empty((n,), np.int32), hk.empty((1,), np.int32)
+        hk.batch("hssk_getrf_vbatched", [K.LuDesc(dA.ptr, n, n, dpiv.ptr, dinfo.ptr)])
+        hk.batch("hssk_getrs_vbatched", [K.LuSolveDesc(dA.ptr, dpiv.ptr, dB.ptr, n, nrhs, n, n)])
+        hk.sync()
+        assert dinfo.get()[0] == 0
+        lu, piv = sla.lu_factor(A)
+        assert np.array_equal(dpiv.get(), piv)
+        assert np.allclose(dA.get(), lu, atol=1e-11)
+        assert np.allclose(dB.get(), np.linalg.solve(A, B), atol=1e-9)

@@ -1,0 +1,53 @@
+"""CPU tests of the HIP kernel sources on the fiber emulator (small shapes): index arithmetic,
+masking, descriptor staging, wave-collective structure.  The GPU run of the same cases is
+tests/test_kernels_gpu.py."""
+import pytest
+
+import emu_lib
+import kernel_cases as KC
+from strumpack_amd import hssk as K
+
+
+@pytest.fixture(scope="module")
+def hk():
+    h = K.Hssk(emu_lib.build())
+    yield h
+    h.close()
+
+
+def test_gemm_vbatched(hk):
+    KC.case_gemm_vbatched(hk, [(5, 7, 3, 0, 0, 1.0, 0.0), (70, 33, 20, 0, 1, -1.0, 1.0),
+                               (16, 130, 17, 1, 0, 2.0, 0.5), (65, 65, 65, 1, 1, 1.0, 0.0),
+                               (3, 4, 0, 0, 0, 1.0, 2.0), (0, 4, 3, 0, 0, 1.0, 0.0)])
+
+
+@pytest.mark.parametrize("m,n,k,tb", [(192, 70, 40, 1), (100, 130, 33, 0), (16, 64, 16, 1),
+                                      (200, 65, 50, 0)])
+def test_dgemm(hk, m, n, k, tb):
+    KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
+
+
+def test_dgemm_splitk(hk):
+    KC.case_dgemm(hk, 24, 70, 3000, 1)
+
+
+def test_generators(hk):
+    KC.case_toeplitz_randn(hk)
+
+
+def test_gathers(hk):
+    KC.case_gathers(hk)
+
+
+def test_id(hk):
+    KC.case_id(hk, [(24, 40, 1e-6, 1e-12, 1000, 7), (24, 16, 1e-10, 1e-14, 1000, None),
+                    (12, 30, 1.0, 1e-10, 1000, None), (24, 40, 1e-8, 1e-12, 5, 9),
+                    (70, 20, 1e-4, 1e-10, 1000, 4), (8, 1, 1e-4, 1e-10, 1000, None)])
+
+
+def test_qr(hk):
+    KC.case_qr(hk, [(40, 12, 12), (30, 30, 30), (33, 20, 33), (10, 1, 10), (70, 10, 0)])
+
+
+def test_trsm_lu(hk):
+    KC.case_trsm_lu(hk)
