@@ -31,6 +31,15 @@ void* hssk_malloc(long long bytes);
 void hssk_free(void* dptr);
 int hssk_memcpy_h2d(hssk_ctx* ctx, void* dst, const void* src, long long bytes);
 int hssk_memcpy_d2h(hssk_ctx* ctx, void* dst, const void* src, long long bytes); /* synchronises */
+int hssk_memcpy_d2d(hssk_ctx* ctx, void* dst, const void* src, long long bytes); /* async */
+/* strided copies of `height` columns of `width` bytes (pitches in bytes); both synchronise */
+int hssk_memcpy2d_h2d(hssk_ctx* ctx, void* dst, long long dpitch, const void* src, long long spitch,
+                      long long width, long long height);
+int hssk_memcpy2d_d2h(hssk_ctx* ctx, void* dst, long long dpitch, const void* src, long long spitch,
+                      long long width, long long height);
+int hssk_memset_zero(hssk_ctx* ctx, void* dst, long long bytes); /* async */
+/* 1 if ptr is device memory of the current process (hipPointerGetAttributes) */
+int hssk_is_device_pointer(const void* ptr);
 /* timing of the LAST hssk_dgemm launch on this context (HIP events on the launch stream), ms */
 float hssk_last_dgemm_ms(hssk_ctx* ctx);
 
@@ -174,6 +183,15 @@ typedef struct hssk_norm_desc {
   double* out; /* device, 1 double: sum of squares */
 } hssk_norm_desc;
 int hssk_sumsq_vbatched(hssk_ctx* ctx, const hssk_norm_desc* descs, int count);
+/* out(perm[k], j) = k < r ? (k == j) : X(j, k - r): dense form of the interpolative basis P [I; E]
+ * with E = X^T (HSSBasisID::dense, HSS/HSSBasisID.hpp:146-153); out is m x r */
+typedef struct hssk_basis_desc {
+  const double* X; /* r x (m - r), ldx */
+  const int* perm; /* device, m ints */
+  double* out;
+  int m, r, ldx, ldo;
+} hssk_basis_desc;
+int hssk_basis_dense(hssk_ctx* ctx, const hssk_basis_desc* descs, int count);
 /* A(i,i) += sigma for i < n  (DenseMatrix::shift; HSS/HSSMatrix.cpp:359-365) */
 typedef struct hssk_shift_desc {
   double* A;

@@ -1,0 +1,98 @@
+/* structured/StructuredMatrix.h -- the C interface of the rank-structured dense solver, as bound by
+ * C / Fortran / Python users of pghysels/STRUMPACK (reference: src/structured/StructuredMatrix.h:46-602,
+ * implementation src/structured/StructuredMatrixC.cpp:83-821).  Double-precision real entry points
+ * (SP_d_struct_*), same names, argument order, ownership and 0/1 return convention.
+ *
+ * This build implements type SP_TYPE_HSS (the MI355X HSS engine); the other types return 1 with
+ * "Operation failed: ..." on stderr, exactly like a reference build configured without them.
+ * Caller buffers are HOST memory (reference rule, doc/doxygen/pages/GPU_support.txt:24-26); the
+ * SPX_* entry points at the end are extensions for operands already resident in HBM.
+ */
+#ifndef STRUCTURED_MATRIX_H
+#define STRUCTURED_MATRIX_H
+
+typedef enum {
+  SP_TYPE_HSS = 0,
+  SP_TYPE_BLR,
+  SP_TYPE_HODLR,
+  SP_TYPE_HODBF,
+  SP_TYPE_BUTTERFLY,
+  SP_TYPE_LR,
+  SP_TYPE_LOSSY,
+  SP_TYPE_LOSSLESS
+} SP_STRUCTURED_TYPE; /* reference StructuredMatrix.h:46-55 */
+
+typedef struct CSPOptions {
+  SP_STRUCTURED_TYPE type;
+  double rel_tol;
+  double abs_tol;
+  int leaf_size;
+  int max_rank;
+  int verbose;
+} CSPOptions; /* reference :68-75 */
+
+typedef void* CSPStructMat; /* reference :85 */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference :109 */
+void SP_d_struct_default_options(CSPOptions* opts);
+/* reference :137 -- frees the matrix and sets *S to NULL */
+void SP_d_struct_destroy(CSPStructMat* S);
+/* reference :163, :185, :211, :239, :265 */
+int SP_d_struct_rows(const CSPStructMat S);
+int SP_d_struct_cols(const CSPStructMat S);
+long long int SP_d_struct_memory(const CSPStructMat S);
+long long int SP_d_struct_nonzeros(const CSPStructMat S);
+int SP_d_struct_rank(const CSPStructMat S);
+/* reference :313 -- A is rows x cols column-major with leading dimension ldA, borrowed for the call */
+int SP_d_struct_from_dense(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts);
+/* reference :357 -- A(i,j) element callback */
+int SP_d_struct_from_elements(CSPStructMat* S, int rows, int cols, double A(int i, int j), const CSPOptions* opts);
+/* reference :408 -- C = op(S) B, trans in {'N','T','C'}, m columns */
+int SP_d_struct_mult(const CSPStructMat S, char trans, int m, const double* B, int ldB, double* C, int ldC);
+/* reference :474 */
+int SP_d_struct_factor(CSPStructMat S);
+/* reference :525 -- B <- S^{-1} B, in place */
+int SP_d_struct_solve(const CSPStructMat S, int nrhs, double* B, int ldB);
+/* reference :580 -- S <- S + s I (factor again afterwards) */
+int SP_d_struct_shift(CSPStructMat S, double s);
+
+/* ---- extensions (not in the reference): HSS knobs and device-resident operands ---------------- */
+/* HSSOptions beyond CSPOptions (HSS/HSSOptions.hpp:465-490); call between default_options and from_* */
+typedef struct SPXHSSOptions {
+  int d0, dd, p;
+  int compression_algorithm; /* 0 original, 1 stable */
+  int random_engine;         /* 0 minstd_rand (reference default), 1 mt19937, 2 philox (device) */
+  int random_distribution;   /* 0 normal, 1 uniform */
+} SPXHSSOptions;
+void SPX_d_struct_default_hss_options(SPXHSSOptions* h);
+/* like SP_d_struct_from_dense, with explicit HSS options (h may be NULL) */
+int SPX_d_struct_from_dense_hss(CSPStructMat* S, int rows, int cols, const double* A, int ldA,
+                                const CSPOptions* opts, const SPXHSSOptions* h);
+/* A is a DEVICE pointer (column-major, ldA); nothing is copied, A is borrowed for the call */
+int SPX_d_struct_from_dense_device(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
+                                   const CSPOptions* opts, const SPXHSSOptions* h);
+int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB,
+                             double* dC, long long ldC);
+int SPX_d_struct_solve_device(const CSPStructMat S, int nrhs, double* dB, long long ldB);
+int SPX_d_struct_levels(const CSPStructMat S);
+int SPX_d_struct_is_compressed(const CSPStructMat S);
+int SPX_d_struct_num_nodes(const CSPStructMat S);
+/* pre-order node table, 6 ints per node: row_offset, rows, U_rows, U_rank, V_rank, is_leaf */
+int SPX_d_struct_node_info(const CSPStructMat S, int* out);
+/* phase timings (s) and the algorithmic flop model; out has 24 doubles:
+ * [0] t_compress [1] t_sketch [2] t_random [3] t_tree [4] t_factor [5] t_solve [6] t_mult
+ * [7] sketch_kernel_ms [8] sketch_launches [9] rounds [10] d_final
+ * [11] f_sketch [12] f_local [13] f_reduce [14] f_id [15] f_ortho [16] f_ulv [17] f_solve
+ * [18] factor_memory_bytes */
+int SPX_d_struct_stats(const CSPStructMat S, double* out);
+/* the hssk kernel context of the matrix (include/hssk.h), for callers that share its stream */
+void* SPX_d_struct_hssk_ctx(const CSPStructMat S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRUCTURED_MATRIX_H */

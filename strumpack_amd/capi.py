@@ -1,0 +1,210 @@
+"""ctypes binding of the reference-shaped C interface (include/structured/StructuredMatrix.h):
+SP_d_struct_* plus the SPX_* device-operand extensions.  This is the binding a Python user of
+STRUMPACK's C API would write; all arithmetic happens in the native library."""
+import ctypes as C
+
+import numpy as np
+
+SP_TYPE_HSS, SP_TYPE_BLR = 0, 1
+
+
+class CSPOptions(C.Structure):
+    _fields_ = [("type", C.c_int), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
+                ("leaf_size", C.c_int), ("max_rank", C.c_int), ("verbose", C.c_int)]
+
+
+class SPXHSSOptions(C.Structure):
+    _fields_ = [("d0", C.c_int), ("dd", C.c_int), ("p", C.c_int), ("compression_algorithm", C.c_int),
+                ("random_engine", C.c_int), ("random_distribution", C.c_int)]
+
+
+SP_SYMBOLS = [
+    "SP_d_struct_default_options", "SP_d_struct_destroy", "SP_d_struct_rows", "SP_d_struct_cols",
+    "SP_d_struct_memory", "SP_d_struct_nonzeros", "SP_d_struct_rank", "SP_d_struct_from_dense",
+    "SP_d_struct_from_elements", "SP_d_struct_mult", "SP_d_struct_factor", "SP_d_struct_solve",
+    "SP_d_struct_shift",
+    "SPX_d_struct_default_hss_options", "SPX_d_struct_from_dense_hss",
+    "SPX_d_struct_from_dense_device", "SPX_d_struct_mult_device", "SPX_d_struct_solve_device",
+    "SPX_d_struct_levels", "SPX_d_struct_is_compressed", "SPX_d_struct_num_nodes",
+    "SPX_d_struct_node_info", "SPX_d_struct_stats", "SPX_d_struct_hssk_ctx",
+]
+ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
+STAT_NAMES = ["t_compress", "t_sketch", "t_random", "t_tree", "t_factor", "t_solve", "t_mult",
+              "sketch_kernel_ms", "sketch_launches", "rounds", "d_final", "f_sketch", "f_local",
+              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory"]
+
+
+def load(path):
+    L = C.CDLL(path)
+    vp, dp = C.c_void_p, C.c_void_p
+    L.SP_d_struct_default_options.argtypes = [C.POINTER(CSPOptions)]
+    L.SP_d_struct_destroy.argtypes = [C.POINTER(vp)]
+    for f in ("SP_d_struct_rows", "SP_d_struct_cols", "SP_d_struct_rank", "SPX_d_struct_levels",
+              "SPX_d_struct_is_compressed", "SPX_d_struct_num_nodes", "SP_d_struct_factor"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = C.c_int
+    for f in ("SP_d_struct_memory", "SP_d_struct_nonzeros"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = C.c_longlong
+    L.SP_d_struct_from_dense.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.POINTER(CSPOptions)]
+    L.SP_d_struct_from_elements.argtypes = [C.POINTER(vp), C.c_int, C.c_int, ELEM_CB, C.POINTER(CSPOptions)]
+    L.SP_d_struct_mult.argtypes = [vp, C.c_char, C.c_int, dp, C.c_int, dp, C.c_int]
+    L.SP_d_struct_solve.argtypes = [vp, C.c_int, dp, C.c_int]
+    L.SP_d_struct_shift.argtypes = [vp, C.c_double]
+    L.SPX_d_struct_default_hss_options.argtypes = [C.POINTER(SPXHSSOptions)]
+    L.SPX_d_struct_from_dense_hss.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int,
+                                              C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions)]
+    L.SPX_d_struct_from_dense_device.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_longlong,
+                                                 C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions)]
+    L.SPX_d_struct_mult_device.argtypes = [vp, C.c_char, C.c_int, dp, C.c_longlong, dp, C.c_longlong]
+    L.SPX_d_struct_solve_device.argtypes = [vp, C.c_int, dp, C.c_longlong]
+    L.SPX_d_struct_node_info.argtypes = [vp, C.POINTER(C.c_int)]
+    L.SPX_d_struct_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.SPX_d_struct_hssk_ctx.argtypes = [vp]
+    L.SPX_d_struct_hssk_ctx.restype = vp
+    return L
+
+
+class StructuredMatrix:
+    """HSS matrix behind the C handle CSPStructMat (structured::StructuredMatrix<double>)."""
+
+    def __init__(self, lib, handle, n):
+        self.L, self.h, self.n = lib, handle, n
+
+    # ---- construction -------------------------------------------------------------------------
+    @staticmethod
+    def options(lib, rel_tol=None, abs_tol=None, leaf_size=None, max_rank=None, verbose=False,
+                type=SP_TYPE_HSS):
+        o = CSPOptions()
+        lib.SP_d_struct_default_options(C.byref(o))
+        o.type = type
+        o.verbose = int(verbose)
+        if rel_tol is not None:
+            o.rel_tol = rel_tol
+        if abs_tol is not None:
+            o.abs_tol = abs_tol
+        if leaf_size is not None:
+            o.leaf_size = leaf_size
+        if max_rank is not None:
+            o.max_rank = max_rank
+        return o
+
+    @staticmethod
+    def hss_options(lib, d0=None, dd=None, p=None, algorithm=None, random_engine=None):
+        h = SPXHSSOptions()
+        lib.SPX_d_struct_default_hss_options(C.byref(h))
+        if d0 is not None:
+            h.d0 = d0
+        if dd is not None:
+            h.dd = dd
+        if p is not None:
+            h.p = p
+        if algorithm is not None:
+            h.compression_algorithm = {"original": 0, "stable": 1}[algorithm]
+        if random_engine is not None:
+            h.random_engine = {"linear": 0, "mersenne": 1, "philox": 2}[random_engine]
+        return h
+
+    @classmethod
+    def from_dense(cls, lib, A, opts, hss=None):
+        A = np.asfortranarray(A, dtype=np.float64)
+        h = C.c_void_p()
+        if hss is None:
+            rc = lib.SP_d_struct_from_dense(C.byref(h), A.shape[0], A.shape[1], A.ctypes.data, A.shape[0], C.byref(opts))
+        else:
+            rc = lib.SPX_d_struct_from_dense_hss(C.byref(h), A.shape[0], A.shape[1], A.ctypes.data, A.shape[0],
+                                                 C.byref(opts), C.byref(hss))
+        if rc:
+            raise RuntimeError("SP_d_struct_from_dense failed")
+        return cls(lib, h, A.shape[0])
+
+    @classmethod
+    def from_dense_device(cls, lib, dptr, n, lda, opts, hss=None):
+        h = C.c_void_p()
+        rc = lib.SPX_d_struct_from_dense_device(C.byref(h), n, n, dptr, lda, C.byref(opts),
+                                                C.byref(hss) if hss is not None else None)
+        if rc:
+            raise RuntimeError("SPX_d_struct_from_dense_device failed")
+        return cls(lib, h, n)
+
+    @classmethod
+    def from_elements(cls, lib, n, fn, opts):
+        cb = ELEM_CB(fn)
+        h = C.c_void_p()
+        if lib.SP_d_struct_from_elements(C.byref(h), n, n, cb, C.byref(opts)):
+            raise RuntimeError("SP_d_struct_from_elements failed")
+        return cls(lib, h, n)
+
+    def destroy(self):
+        if self.h:
+            self.L.SP_d_struct_destroy(C.byref(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- operations ---------------------------------------------------------------------------
+    def mult(self, B, trans="N"):
+        B = np.asfortranarray(B, dtype=np.float64).reshape(self.n, -1, order="F")
+        Cm = np.zeros_like(B, order="F")
+        if self.L.SP_d_struct_mult(self.h, trans.encode(), B.shape[1], B.ctypes.data, self.n, Cm.ctypes.data, self.n):
+            raise RuntimeError("SP_d_struct_mult failed")
+        return Cm
+
+    def factor(self):
+        if self.L.SP_d_struct_factor(self.h):
+            raise RuntimeError("SP_d_struct_factor failed")
+
+    def solve(self, B):
+        X = np.array(B, dtype=np.float64, order="F").reshape(self.n, -1, order="F")
+        if self.L.SP_d_struct_solve(self.h, X.shape[1], X.ctypes.data, self.n):
+            raise RuntimeError("SP_d_struct_solve failed")
+        return X
+
+    def shift(self, s):
+        if self.L.SP_d_struct_shift(self.h, s):
+            raise RuntimeError("SP_d_struct_shift failed")
+
+    def mult_device(self, dB, dC, nrhs, trans="N"):
+        if self.L.SPX_d_struct_mult_device(self.h, trans.encode(), nrhs, dB, self.n, dC, self.n):
+            raise RuntimeError("SPX_d_struct_mult_device failed")
+
+    def solve_device(self, dB, nrhs):
+        if self.L.SPX_d_struct_solve_device(self.h, nrhs, dB, self.n):
+            raise RuntimeError("SPX_d_struct_solve_device failed")
+
+    def dense(self):
+        return self.mult(np.eye(self.n))
+
+    # ---- introspection ------------------------------------------------------------------------
+    def rows(self):
+        return self.L.SP_d_struct_rows(self.h)
+
+    def rank(self):
+        return self.L.SP_d_struct_rank(self.h)
+
+    def memory(self):
+        return self.L.SP_d_struct_memory(self.h)
+
+    def nonzeros(self):
+        return self.L.SP_d_struct_nonzeros(self.h)
+
+    def levels(self):
+        return self.L.SPX_d_struct_levels(self.h)
+
+    def is_compressed(self):
+        return bool(self.L.SPX_d_struct_is_compressed(self.h))
+
+    def node_info(self):
+        nn = self.L.SPX_d_struct_num_nodes(self.h)
+        out = np.zeros((nn, 6), dtype=np.int32)
+        self.L.SPX_d_struct_node_info(self.h, out.ctypes.data_as(C.POINTER(C.c_int)))
+        return out
+
+    def stats(self):
+        out = (C.c_double * 24)()
+        self.L.SPX_d_struct_stats(self.h, out)
+        return dict(zip(STAT_NAMES, list(out)))

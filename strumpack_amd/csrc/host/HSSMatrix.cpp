@@ -1,0 +1,130 @@
+#include "HSSMatrix.hpp"
+
+#include <sstream>
+
+namespace strumpack {
+namespace HSS {
+
+EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
+  EngineOptions e;
+  e.rel_tol = o.rel_tol(); e.abs_tol = o.abs_tol(); e.leaf_size = o.leaf_size(); e.max_rank = o.max_rank();
+  e.d0 = o.d0(); e.dd = o.dd(); e.p = o.p();
+  e.algorithm = o.compression_algorithm() == CompressionAlgorithm::ORIGINAL ? 0 : 1;
+  e.random_engine = o.random_engine() == random::RandomEngine::LINEAR ? 0 : (o.random_engine() == random::RandomEngine::MERSENNE ? 1 : 2);
+  e.random_dist = o.random_distribution() == random::RandomDistribution::NORMAL ? 0 : 1;
+  e.verbose = o.verbose();
+  if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
+  return e;
+}
+
+HSSMatrix<double>::HSSMatrix(std::size_t m, std::size_t n, const opts_t& opts) : rows_(m), cols_(n) {
+  if (m != n) throw std::invalid_argument("HSS compression only supported for square matrices.");
+  make_engine(opts, nullptr);
+}
+HSSMatrix<double>::HSSMatrix(const structured::ClusterTree& t, const opts_t& opts) : rows_(t.size), cols_(t.size) {
+  tree_.reset(new structured::ClusterTree(t));
+  make_engine(opts, tree_.get());
+}
+HSSMatrix<double>::~HSSMatrix() {}
+
+void HSSMatrix<double>::make_engine(const opts_t& opts, const structured::ClusterTree* t) {
+  eng_.reset(new DeviceHSS(int(rows_), engine_options(opts), t));
+}
+
+void HSSMatrix<double>::compress(const DenseM_t& A, const opts_t& opts) {
+  if (A.rows() != rows_ || A.cols() != cols_) throw std::invalid_argument("compress: matrix dimensions do not match");
+  make_engine(opts, tree_.get());
+  eng_->compress_dense_host(A.data(), A.ld());
+}
+void HSSMatrix<double>::compress_device(const double* dA, long long lda, const opts_t& opts) {
+  make_engine(opts, tree_.get());
+  eng_->compress_dense_device(dA, lda);
+}
+void HSSMatrix<double>::compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts) {
+  make_engine(opts, tree_.get());
+  const int N = int(rows_);
+  // the reference hands both sample blocks to the user in one call (HSSExtra.hpp:231-239); the
+  // engine asks for the two products separately, so cache the pair
+  DenseM_t Sr_cache, Sc_cache;
+  host_mult_t hm = [&](char trans, int n, int nrhs, const double* R, int ldr, double* S, int lds) {
+    if (trans == 'N') {
+      DenseM_t Rr(n, nrhs, R, ldr), Rc(Rr);
+      Sr_cache = DenseM_t(n, nrhs);
+      Sc_cache = DenseM_t(n, nrhs);
+      Amult(Rr, Rc, Sr_cache, Sc_cache);
+    }
+    const DenseM_t& src = trans == 'N' ? Sr_cache : Sc_cache;
+    for (int j = 0; j < nrhs; j++) std::memcpy(S + (size_t)j * lds, src.ptr(0, j), sizeof(double) * n);
+  };
+  host_elem_t he = [&](int m, const int* I, int n, const int* J, double* B, int ldb) {
+    std::vector<std::size_t> Iv(I, I + m), Jv(J, J + n);
+    DenseM_t Bm(m, n);
+    Aelem(Iv, Jv, Bm);
+    for (int j = 0; j < n; j++) std::memcpy(B + (size_t)j * ldb, Bm.ptr(0, j), sizeof(double) * m);
+  };
+  (void)N;
+  eng_->compress_callbacks(hm, he);
+}
+
+std::size_t HSSMatrix<double>::memory() const { return eng_ ? std::size_t(eng_->memory()) : 0; }
+std::size_t HSSMatrix<double>::nonzeros() const { return eng_ ? std::size_t(eng_->nonzeros()) : 0; }
+std::size_t HSSMatrix<double>::rank() const { return eng_ ? std::size_t(eng_->rank()) : 0; }
+std::size_t HSSMatrix<double>::levels() const { return eng_ ? std::size_t(eng_->levels()) : 0; }
+bool HSSMatrix<double>::is_compressed() const { return eng_ && eng_->is_compressed(); }
+bool HSSMatrix<double>::leaf() const { return !eng_ || eng_->num_nodes() == 1; }
+
+void HSSMatrix<double>::mult(Trans op, const DenseM_t& x, DenseM_t& y) const {
+  apply_HSS(op, *this, x, 0., y);
+}
+DenseMatrix<double> HSSMatrix<double>::apply(const DenseM_t& b) const {
+  DenseM_t c(rows_, b.cols());
+  apply_HSS(Trans::N, *this, b, 0., c);
+  return c;
+}
+DenseMatrix<double> HSSMatrix<double>::applyC(const DenseM_t& b) const {
+  DenseM_t c(cols_, b.cols());
+  apply_HSS(Trans::C, *this, b, 0., c);
+  return c;
+}
+void HSSMatrix<double>::factor() { eng_->factor(); }
+void HSSMatrix<double>::solve(DenseM_t& b) const {
+  if (b.rows() != rows_) throw std::invalid_argument("solve: right-hand side has the wrong number of rows");
+  eng_->solve(int(b.cols()), b.data(), b.ld(), false);
+}
+void HSSMatrix<double>::shift(scalar_t sigma) { eng_->shift(sigma); }
+void HSSMatrix<double>::mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta) const {
+  eng_->mult(op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);
+}
+void HSSMatrix<double>::solve_device(int nrhs, double* db, long long ldb) const { eng_->solve(nrhs, db, ldb, true); }
+
+DenseMatrix<double> HSSMatrix<double>::dense() const {
+  // H * I in column blocks (HSSMatrix.cpp:188-260 re-expands recursively; test-only, O(N^2 r))
+  DenseM_t D(rows_, cols_);
+  const std::size_t bs = 256;
+  for (std::size_t j0 = 0; j0 < cols_; j0 += bs) {
+    std::size_t nb = std::min(bs, cols_ - j0);
+    DenseM_t E(cols_, nb);
+    for (std::size_t j = 0; j < nb; j++) E(j0 + j, j) = 1.;
+    DenseMW_t Dj(rows_, nb, D, 0, j0);
+    eng_->mult('N', int(nb), E.data(), E.ld(), Dj.data(), Dj.ld(), false, 0.);
+  }
+  return D;
+}
+
+void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
+  if (!eng_) return;
+  for (auto& nd : eng_->nodes()) {  // pre-order, same line format as HSSMatrix.cpp:344-350
+    out << "SEQ rank=0 b = [" << roff + nd.lo << "," << roff + nd.lo + nd.m << " x " << coff + nd.lo << ","
+        << coff + nd.lo + nd.m << "]  U = " << (nd.lvl ? nd.mU : 0) << " x " << nd.rU << " V = "
+        << (nd.lvl ? nd.mV : 0) << " x " << nd.rV << (nd.leaf() ? " leaf" : " non-leaf") << std::endl;
+  }
+}
+
+void apply_HSS(Trans op, const HSSMatrix<double>& A, const DenseMatrix<double>& B, double beta, DenseMatrix<double>& C) {
+  if (B.rows() != A.rows() || C.rows() != A.rows() || B.cols() != C.cols())
+    throw std::invalid_argument("apply_HSS: dimension mismatch");
+  A.engine()->mult(op == Trans::N ? 'N' : 'C', int(B.cols()), B.data(), B.ld(), C.data(), C.ld(), false, beta);
+}
+
+}  // namespace HSS
+}  // namespace strumpack

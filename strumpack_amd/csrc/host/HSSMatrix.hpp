@@ -1,0 +1,80 @@
+// HSS::HSSMatrix<double>: the reference's public HSS class (HSS/HSSMatrix.hpp:79-711) on top of the
+// device engine (hss_engine.hpp).  construct / compress / mult / apply / factor / solve / shift and
+// the introspection calls keep the reference's names, argument meaning and error behaviour; the
+// arithmetic runs in hand-written HIP kernels on the MI355X.
+#pragma once
+#include <memory>
+
+#include "HSSOptions.hpp"
+#include "StructuredMatrix.hpp"
+#include "hss_engine.hpp"
+
+namespace strumpack {
+namespace HSS {
+
+template <typename scalar_t> class HSSMatrix;
+
+template <> class HSSMatrix<double> : public structured::StructuredMatrix<double> {
+  using scalar_t = double;
+  using DenseM_t = DenseMatrix<scalar_t>;
+  using DenseMW_t = DenseMatrixWrapper<scalar_t>;
+  using opts_t = HSSOptions<scalar_t>;
+
+ public:
+  // sampling callback: Sr = A Rr, Sc = A^H Rc ; element callback: B = A(I, J)  (HSSMatrix.hpp:83-89)
+  using mult_t = std::function<void(DenseM_t& Rr, DenseM_t& Rc, DenseM_t& Sr, DenseM_t& Sc)>;
+  using elem_t = std::function<void(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseM_t& B)>;
+
+  HSSMatrix() {}
+  // compress the dense matrix A (HSS/HSSMatrix.cpp:50-54)
+  HSSMatrix(const DenseM_t& A, const opts_t& opts) : HSSMatrix(A.rows(), A.cols(), opts) { compress(A, opts); }
+  // uncompressed m x n HSS matrix with the bisection tree (HSSMatrix.cpp:56-70)
+  HSSMatrix(std::size_t m, std::size_t n, const opts_t& opts);
+  // tree given by a cluster tree (HSSMatrix.cpp:72-86)
+  HSSMatrix(const structured::ClusterTree& t, const opts_t& opts);
+  ~HSSMatrix() override;
+
+  void compress(const DenseM_t& A, const opts_t& opts);
+  void compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts);
+  // extension: A resident in HBM
+  void compress_device(const double* dA, long long lda, const opts_t& opts);
+
+  std::size_t rows() const override { return rows_; }
+  std::size_t cols() const override { return cols_; }
+  std::size_t memory() const override;
+  std::size_t nonzeros() const override;
+  std::size_t rank() const override;
+  std::size_t levels() const;
+  bool is_compressed() const;
+  bool leaf() const;
+
+  void mult(Trans op, const DenseM_t& x, DenseM_t& y) const override;
+  using structured::StructuredMatrix<double>::mult;
+  DenseM_t apply(const DenseM_t& b) const;
+  DenseM_t applyC(const DenseM_t& b) const;
+  void factor() override;
+  void solve(DenseM_t& b) const override;
+  using structured::StructuredMatrix<double>::solve;
+  void shift(scalar_t sigma) override;
+  DenseM_t dense() const;
+  void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
+
+  // device-resident operands (extension)
+  void mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta = 0.) const;
+  void solve_device(int nrhs, double* db, long long ldb) const;
+
+  DeviceHSS* engine() const { return eng_.get(); }
+  static EngineOptions engine_options(const opts_t& opts);
+
+ private:
+  void make_engine(const opts_t& opts, const structured::ClusterTree* t);
+  std::size_t rows_ = 0, cols_ = 0;
+  std::unique_ptr<structured::ClusterTree> tree_;
+  mutable std::unique_ptr<DeviceHSS> eng_;
+};
+
+// y = op(H) x + beta y   (HSS/HSSMatrix.hpp:720, HSSMatrix.cpp:419-435)
+void apply_HSS(Trans op, const HSSMatrix<double>& A, const DenseMatrix<double>& B, double beta, DenseMatrix<double>& C);
+
+}  // namespace HSS
+}  // namespace strumpack

@@ -1,0 +1,132 @@
+// Factories of the structured facade: HSS dispatch (reference structured/StructuredMatrix.cpp:54-76
+// dense, :203-273 elements, :637-651 partially matrix-free).
+#include "StructuredMatrix.hpp"
+
+#include "HSSMatrix.hpp"
+
+namespace strumpack {
+namespace structured {
+
+namespace {
+void require_hss(Type t, int rows, int cols) {
+  if (t != Type::HSS)
+    throw std::invalid_argument("Structured type " + get_name(t) + " is not available in this build (HSS hot path only).");
+  if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
+}
+HSS::HSSMatrix<double>* new_hss(int n, const StructuredOptions<double>& opts, const ClusterTree* row_tree,
+                                HSS::HSSOptions<double>& hss_opts) {
+  hss_opts = HSS::HSSOptions<double>(opts);
+  return row_tree ? new HSS::HSSMatrix<double>(*row_tree, hss_opts) : new HSS::HSSMatrix<double>(n, n, hss_opts);
+}
+}  // namespace
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_from_dense(const DenseMatrix<double>& A, const StructuredOptions<double>& opts,
+                                                               const ClusterTree* row_tree, const ClusterTree*, const admissibility_t*) {
+  require_hss(opts.type(), int(A.rows()), int(A.cols()));
+  HSS::HSSOptions<double> ho;
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new_hss(int(A.rows()), opts, row_tree, ho));
+  H->compress(A, ho);
+  return std::unique_ptr<StructuredMatrix<double>>(H.release());
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_from_dense(int rows, int cols, const double* A, int ldA,
+                                                               const StructuredOptions<double>& opts, const ClusterTree* row_tree,
+                                                               const ClusterTree* col_tree, const admissibility_t* adm) {
+  auto M = ConstDenseMatrixWrapper<double>(rows, cols, A, ldA);
+  return construct_from_dense<double>(M, opts, row_tree, col_tree, adm);
+}
+
+std::unique_ptr<StructuredMatrix<double>> construct_from_dense_device(int rows, int cols, const double* dA, long long ldA,
+                                                                      const StructuredOptions<double>& opts, const ClusterTree* row_tree) {
+  require_hss(opts.type(), rows, cols);
+  HSS::HSSOptions<double> ho;
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new_hss(rows, opts, row_tree, ho));
+  H->compress_device(dA, ldA, ho);
+  return std::unique_ptr<StructuredMatrix<double>>(H.release());
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_from_elements(int rows, int cols, const extract_block_t<double>& A,
+                                                                  const StructuredOptions<double>& opts, const ClusterTree* row_tree,
+                                                                  const ClusterTree*, const admissibility_t*, const DenseMatrix<double>*) {
+  require_hss(opts.type(), rows, cols);
+  // The reference samples A on the fly in B x B tiles (StructuredMatrix.cpp:214-262); here the tiles
+  // are evaluated once into a dense host image, which then takes the device route (N^2 doubles).
+  DenseMatrix<double> Ad(rows, cols);
+  const std::size_t B = 1024;
+  for (std::size_t j0 = 0; j0 < std::size_t(cols); j0 += B)
+    for (std::size_t i0 = 0; i0 < std::size_t(rows); i0 += B) {
+      std::size_t mb = std::min(B, rows - i0), nb = std::min(B, cols - j0);
+      std::vector<std::size_t> I(mb), J(nb);
+      for (std::size_t i = 0; i < mb; i++) I[i] = i0 + i;
+      for (std::size_t j = 0; j < nb; j++) J[j] = j0 + j;
+      DenseMatrix<double> T(mb, nb);
+      A(I, J, T);
+      for (std::size_t j = 0; j < nb; j++) std::memcpy(Ad.ptr(i0, j0 + j), T.ptr(0, j), sizeof(double) * mb);
+    }
+  return construct_from_dense<double>(Ad, opts, row_tree, nullptr, nullptr);
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_from_elements(int rows, int cols, const extract_t<double>& A,
+                                                                  const StructuredOptions<double>& opts, const ClusterTree* row_tree,
+                                                                  const ClusterTree* col_tree, const admissibility_t* adm,
+                                                                  const DenseMatrix<double>* p) {
+  extract_block_t<double> blk = [&A](const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseMatrix<double>& B) {
+    for (std::size_t j = 0; j < J.size(); j++)
+      for (std::size_t i = 0; i < I.size(); i++) B(i, j) = A(I[i], J[j]);
+  };
+  return construct_from_elements<double>(rows, cols, blk, opts, row_tree, col_tree, adm, p);
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_and_factor_from_dense(const DenseMatrix<double>& A, const StructuredOptions<double>& opts,
+                                                                          const ClusterTree* row_tree, const ClusterTree* col_tree,
+                                                                          const admissibility_t* adm) {
+  auto S = construct_from_dense<double>(A, opts, row_tree, col_tree, adm);
+  S->factor();
+  return S;
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_and_factor_from_elements(int rows, int cols, const extract_block_t<double>& A,
+                                                                             const StructuredOptions<double>& opts, const ClusterTree* row_tree,
+                                                                             const ClusterTree* col_tree, const admissibility_t* adm,
+                                                                             const DenseMatrix<double>* p) {
+  auto S = construct_from_elements<double>(rows, cols, A, opts, row_tree, col_tree, adm, p);
+  S->factor();
+  return S;
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_partially_matrix_free(int rows, int cols, const mult_t<double>& Amult,
+                                                                          const extract_block_t<double>& Aelem,
+                                                                          const StructuredOptions<double>& opts, const ClusterTree* row_tree,
+                                                                          const ClusterTree*) {
+  require_hss(opts.type(), rows, cols);
+  HSS::HSSOptions<double> ho;
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new_hss(rows, opts, row_tree, ho));
+  // adaptor of StructuredMatrix.cpp:643-647
+  auto sample = [&Amult](DenseMatrix<double>& Rr, DenseMatrix<double>& Rc, DenseMatrix<double>& Sr, DenseMatrix<double>& Sc) {
+    Amult(Trans::N, Rr, Sr);
+    Amult(Trans::C, Rc, Sc);
+  };
+  H->compress(sample, Aelem, ho);
+  return std::unique_ptr<StructuredMatrix<double>>(H.release());
+}
+
+template <>
+std::unique_ptr<StructuredMatrix<double>> construct_partially_matrix_free(int rows, int cols, const mult_t<double>& Amult,
+                                                                          const extract_t<double>& Aelem, const StructuredOptions<double>& opts,
+                                                                          const ClusterTree* row_tree, const ClusterTree* col_tree) {
+  extract_block_t<double> blk = [&Aelem](const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseMatrix<double>& B) {
+    for (std::size_t j = 0; j < J.size(); j++)
+      for (std::size_t i = 0; i < I.size(); i++) B(i, j) = Aelem(I[i], J[j]);
+  };
+  return construct_partially_matrix_free<double>(rows, cols, Amult, blk, opts, row_tree, col_tree);
+}
+
+}  // namespace structured
+}  // namespace strumpack

@@ -1,0 +1,170 @@
+// C interface SP_d_struct_* (reference structured/StructuredMatrixC.cpp:61-119 handle + error
+// convention, :83-821 entry points) and the SPX_* device-operand extensions.
+#include <iostream>
+
+#include "HSSMatrix.hpp"
+#include "StructuredMatrix.hpp"
+#include "structured/StructuredMatrix.h"
+
+using namespace strumpack;
+using namespace strumpack::structured;
+
+namespace {
+struct CStructMat {
+  std::unique_ptr<StructuredMatrix<double>> S;
+};
+inline StructuredMatrix<double>* mat(const CSPStructMat S) { return static_cast<CStructMat*>(S)->S.get(); }
+inline HSS::HSSMatrix<double>* hss(const CSPStructMat S) { return dynamic_cast<HSS::HSSMatrix<double>*>(mat(S)); }
+
+StructuredOptions<double> get_options(const CSPOptions* o) {
+  StructuredOptions<double> opts;
+  opts.set_type(Type(int(o->type)));
+  opts.set_rel_tol(o->rel_tol);
+  opts.set_abs_tol(o->abs_tol);
+  opts.set_leaf_size(o->leaf_size);
+  opts.set_max_rank(o->max_rank);
+  opts.set_verbose(o->verbose != 0);
+  return opts;
+}
+HSS::HSSOptions<double> get_hss_options(const CSPOptions* o, const SPXHSSOptions* h) {
+  HSS::HSSOptions<double> ho(get_options(o));
+  if (h) {
+    ho.set_d0(h->d0); ho.set_dd(h->dd); ho.set_p(h->p);
+    ho.set_compression_algorithm(h->compression_algorithm == 0 ? HSS::CompressionAlgorithm::ORIGINAL : HSS::CompressionAlgorithm::STABLE);
+    ho.set_random_engine(h->random_engine == 0 ? random::RandomEngine::LINEAR : (h->random_engine == 1 ? random::RandomEngine::MERSENNE : random::RandomEngine::PHILOX));
+    ho.set_random_distribution(h->random_distribution == 0 ? random::RandomDistribution::NORMAL : random::RandomDistribution::UNIFORM);
+  }
+  return ho;
+}
+#define SP_TRY try {
+#define SP_CATCH                                                      \
+  }                                                                   \
+  catch (std::exception & e) {                                        \
+    std::cerr << "Operation failed: " << e.what() << std::endl;       \
+    return 1;                                                         \
+  }                                                                   \
+  return 0;
+}  // namespace
+
+extern "C" {
+
+void SP_d_struct_default_options(CSPOptions* o) {
+  StructuredOptions<double> d;
+  o->type = SP_STRUCTURED_TYPE(int(d.type()));
+  o->rel_tol = d.rel_tol(); o->abs_tol = d.abs_tol(); o->leaf_size = d.leaf_size();
+  o->max_rank = d.max_rank(); o->verbose = d.verbose();
+}
+void SP_d_struct_destroy(CSPStructMat* S) {
+  delete static_cast<CStructMat*>(*S);
+  *S = NULL;
+}
+int SP_d_struct_rows(const CSPStructMat S) { return int(mat(S)->rows()); }
+int SP_d_struct_cols(const CSPStructMat S) { return int(mat(S)->cols()); }
+long long int SP_d_struct_memory(const CSPStructMat S) { return (long long)mat(S)->memory(); }
+long long int SP_d_struct_nonzeros(const CSPStructMat S) { return (long long)mat(S)->nonzeros(); }
+int SP_d_struct_rank(const CSPStructMat S) { return int(mat(S)->rank()); }
+
+int SP_d_struct_from_dense(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts) {
+  SP_TRY
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S = construct_from_dense<double>(rows, cols, A, ldA, get_options(opts));
+  *S = s.release();
+  SP_CATCH
+}
+int SP_d_struct_from_elements(CSPStructMat* S, int rows, int cols, double A(int i, int j), const CSPOptions* opts) {
+  SP_TRY
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  extract_t<double> f = [A](std::size_t i, std::size_t j) { return A(int(i), int(j)); };
+  s->S = construct_from_elements<double>(rows, cols, f, get_options(opts));
+  *S = s.release();
+  SP_CATCH
+}
+int SP_d_struct_mult(const CSPStructMat S, char trans, int m, const double* B, int ldB, double* C, int ldC) {
+  SP_TRY
+  mat(S)->mult(c2T(trans), m, B, ldB, C, ldC);
+  SP_CATCH
+}
+int SP_d_struct_factor(CSPStructMat S) {
+  SP_TRY
+  mat(S)->factor();
+  SP_CATCH
+}
+int SP_d_struct_solve(const CSPStructMat S, int nrhs, double* B, int ldB) {
+  SP_TRY
+  mat(S)->solve(nrhs, B, ldB);
+  SP_CATCH
+}
+int SP_d_struct_shift(CSPStructMat S, double s) {
+  SP_TRY
+  mat(S)->shift(s);
+  SP_CATCH
+}
+
+// ---- extensions ------------------------------------------------------------------------------
+void SPX_d_struct_default_hss_options(SPXHSSOptions* h) {
+  HSS::HSSOptions<double> d;
+  h->d0 = d.d0(); h->dd = d.dd(); h->p = d.p();
+  h->compression_algorithm = 1; h->random_engine = 0; h->random_distribution = 0;
+}
+int SPX_d_struct_from_dense_hss(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts,
+                                const SPXHSSOptions* h) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("SPX_d_struct_from_dense_hss requires type SP_TYPE_HSS");
+  if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
+  auto ho = get_hss_options(opts, h);
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(rows, cols, ho));
+  auto M = ConstDenseMatrixWrapper<double>(rows, cols, A, ldA);
+  H->compress(M, ho);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
+int SPX_d_struct_from_dense_device(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
+                                   const CSPOptions* opts, const SPXHSSOptions* h) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("SPX_d_struct_from_dense_device requires type SP_TYPE_HSS");
+  if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
+  auto ho = get_hss_options(opts, h);
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(rows, cols, ho));
+  H->compress_device(dA, ldA, ho);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
+int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB, double* dC, long long ldC) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->mult_device(c2T(trans), m, dB, ldB, dC, ldC);
+  SP_CATCH
+}
+int SPX_d_struct_solve_device(const CSPStructMat S, int nrhs, double* dB, long long ldB) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->solve_device(nrhs, dB, ldB);
+  SP_CATCH
+}
+int SPX_d_struct_levels(const CSPStructMat S) { return hss(S) ? int(hss(S)->levels()) : 0; }
+int SPX_d_struct_is_compressed(const CSPStructMat S) { return hss(S) ? int(hss(S)->is_compressed()) : 0; }
+int SPX_d_struct_num_nodes(const CSPStructMat S) { return hss(S) ? hss(S)->engine()->num_nodes() : 0; }
+int SPX_d_struct_node_info(const CSPStructMat S, int* out) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->engine()->node_info(out);
+  SP_CATCH
+}
+int SPX_d_struct_stats(const CSPStructMat S, double* o) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  const HSS::PhaseStats& st = hss(S)->engine()->stats();
+  o[0] = st.t_compress; o[1] = st.t_sketch; o[2] = st.t_random; o[3] = st.t_tree; o[4] = st.t_factor;
+  o[5] = st.t_solve; o[6] = st.t_mult; o[7] = st.sketch_kernel_ms; o[8] = st.sketch_launches; o[9] = st.rounds;
+  o[10] = st.d_final; o[11] = st.f_sketch; o[12] = st.f_local; o[13] = st.f_reduce; o[14] = st.f_id;
+  o[15] = st.f_ortho; o[16] = st.f_ulv; o[17] = st.f_solve; o[18] = (double)hss(S)->engine()->factor_memory();
+  for (int i = 19; i < 24; i++) o[i] = 0;
+  SP_CATCH
+}
+void* SPX_d_struct_hssk_ctx(const CSPStructMat S) { return hss(S) ? (void*)hss(S)->engine()->ctx() : nullptr; }
+
+}  // extern "C"

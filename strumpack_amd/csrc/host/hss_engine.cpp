@@ -1,0 +1,1148 @@
+// DeviceHSS implementation: level-synchronous compression / apply / ULV factor / solve on the device.
+// Reference behaviour followed (all under /root/reference/src/HSS unless noted):
+//   HSSMatrix.cpp:60-82                     tree construction
+//   HSSMatrix.compress_stable.hpp:100-442   adaptive stable compression (default)
+//   HSSMatrix.compress.hpp:100-165,300-368,524-724  original compression, local samples, reduce
+//   HSSBasisID.hpp:146-203                  interpolative basis apply / applyC / dense
+//   HSSMatrix.apply.hpp:55-220              mat-vec
+//   HSSMatrix.factor.hpp:51-147             ULV factorization
+//   HSSMatrix.solve.hpp:69-238              ULV solve
+// Sibling nodes are independent, so the reference's post-order recursion is executed here as one
+// batched kernel launch per step and tree height (cf. its own level-wise variant,
+// HSSMatrix.compress_stable.hpp:234-277).
+#include "hss_engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <random>
+#include <stdexcept>
+
+namespace strumpack {
+namespace HSS {
+
+namespace {
+inline void ck(int rc) {
+  if (rc) throw std::runtime_error(std::string("hssk: ") + hssk_last_error());
+}
+inline double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+// host random stream of the reference (misc/RandomWrapper.hpp:128-191): engine seeded with 0
+struct HostRng {
+  std::minstd_rand lin{0};
+  std::mt19937 mer{0};
+  std::normal_distribution<double> nd;
+  std::uniform_real_distribution<double> ud;
+};
+
+// bump allocator over large device chunks
+class Arena {
+ public:
+  explicit Arena(size_t chunk = size_t(64) << 20) : chunk_(chunk) {}
+  ~Arena() { reset(); }
+  void* alloc(size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 8) + 255) & ~size_t(255);
+    if (bytes > left_) {
+      size_t c = std::max(chunk_, bytes);
+      void* p = hssk_malloc((long long)c);
+      if (!p) throw std::runtime_error(std::string("device allocation failed: ") + hssk_last_error());
+      chunks_.push_back(p);
+      cur_ = (char*)p;
+      left_ = c;
+      total_ += c;
+    }
+    void* r = cur_;
+    cur_ += bytes;
+    left_ -= bytes;
+    used_ += bytes;
+    return r;
+  }
+  double* dbl(size_t count) { return (double*)alloc(sizeof(double) * count); }
+  int* ints(size_t count) { return (int*)alloc(sizeof(int) * count); }
+  void reset() {
+    for (void* p : chunks_) hssk_free(p);
+    chunks_.clear();
+    cur_ = nullptr;
+    left_ = 0;
+    total_ = used_ = 0;
+  }
+  size_t used() const { return used_; }
+
+ private:
+  size_t chunk_, left_ = 0, total_ = 0, used_ = 0;
+  char* cur_ = nullptr;
+  std::vector<void*> chunks_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// sample / element sources
+// ---------------------------------------------------------------------------------------------
+struct ElemReq {
+  const int* dI;  // device index arrays (may be null: contiguous from i0/j0)
+  const int* dJ;
+  const std::vector<int>* hI;  // host copies (for host-callback sources)
+  const std::vector<int>* hJ;
+  int i0, j0, m, n;
+  double* dB;
+  int ldb;
+};
+
+struct DeviceHSS::Source {
+  virtual ~Source() {}
+  // Srt[r0:r0+dn, :] = (A R)^T, Sct[r0:r0+dn, :] = (A^T R)^T for the sample rows [r0, r0+dn) of Rt
+  virtual void sample(DeviceHSS& H, int r0, int dn) = 0;
+  virtual void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) = 0;
+};
+
+struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
+  const double* dA;
+  long long lda;
+  DenseDeviceSource(const double* a, long long l) : dA(a), lda(l) {}
+  void sample(DeviceHSS& H, int r0, int dn) override {
+    const long long N = H.n_;
+    // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout
+    ck(hssk_dgemm(H.ctx_, 1, dn, N, N, 1.0, H.Rt_ + r0, H.dcap_, dA, lda, 0.0, H.Srt_ + r0, H.dcap_));
+    ck(hssk_sync(H.ctx_));
+    float ms = hssk_last_dgemm_ms(H.ctx_);
+    if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+    ck(hssk_dgemm(H.ctx_, 0, dn, N, N, 1.0, H.Rt_ + r0, H.dcap_, dA, lda, 0.0, H.Sct_ + r0, H.dcap_));
+    ck(hssk_sync(H.ctx_));
+    ms = hssk_last_dgemm_ms(H.ctx_);
+    if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+  }
+  void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
+    std::vector<hssk_elem_desc> d;
+    d.reserve(reqs.size());
+    for (auto& r : reqs)
+      if (r.m > 0 && r.n > 0) d.push_back(hssk_elem_desc{dA, lda, r.dI, r.dJ, r.i0, r.j0, r.dB, r.m, r.n, r.ldb, 0});
+    if (!d.empty()) ck(hssk_gather_elems(H.ctx_, d.data(), (int)d.size()));
+  }
+};
+
+struct DeviceHSS::CallbackSource : DeviceHSS::Source {
+  const host_mult_t& mult;
+  const host_elem_t& elem;
+  CallbackSource(const host_mult_t& m, const host_elem_t& e) : mult(m), elem(e) {}
+  void sample(DeviceHSS& H, int r0, int dn) override {
+    const int N = H.n_;
+    std::vector<double> Rt((size_t)dn * N), R((size_t)N * dn), S((size_t)N * dn), St((size_t)dn * N);
+    ck(hssk_memcpy2d_d2h(H.ctx_, Rt.data(), sizeof(double) * dn, H.Rt_ + r0, sizeof(double) * H.dcap_, sizeof(double) * dn, N));
+    for (int j = 0; j < N; j++) for (int i = 0; i < dn; i++) R[j + (size_t)i * N] = Rt[i + (size_t)j * dn];
+    for (int pass = 0; pass < 2; pass++) {
+      mult(pass == 0 ? 'N' : 'C', N, dn, R.data(), N, S.data(), N);
+      for (int j = 0; j < N; j++) for (int i = 0; i < dn; i++) St[i + (size_t)j * dn] = S[j + (size_t)i * N];
+      double* dst = (pass == 0 ? H.Srt_ : H.Sct_) + r0;
+      ck(hssk_memcpy2d_h2d(H.ctx_, dst, sizeof(double) * H.dcap_, St.data(), sizeof(double) * dn, sizeof(double) * dn, N));
+    }
+  }
+  void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
+    for (auto& r : reqs) {
+      if (r.m <= 0 || r.n <= 0) continue;
+      std::vector<int> I(r.m), J(r.n);
+      for (int i = 0; i < r.m; i++) I[i] = r.hI ? (*r.hI)[i] : r.i0 + i;
+      for (int j = 0; j < r.n; j++) J[j] = r.hJ ? (*r.hJ)[j] : r.j0 + j;
+      std::vector<double> B((size_t)r.m * r.n);
+      elem(r.m, I.data(), r.n, J.data(), B.data(), r.m);
+      ck(hssk_memcpy2d_h2d(H.ctx_, r.dB, sizeof(double) * r.ldb, B.data(), sizeof(double) * r.m, sizeof(double) * r.m, r.n));
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------------------------
+DeviceHSS::DeviceHSS(int n, const EngineOptions& opts, const structured::ClusterTree* tree) : n_(n), o_(opts) {
+  ck(hssk_ctx_create(&ctx_, o_.device));
+  persist_.reset(new Arena(size_t(64) << 20));
+  work_.reset(new Arena(size_t(256) << 20));
+  fact_.reset(new Arena(size_t(64) << 20));
+  build_tree(tree);
+}
+
+DeviceHSS::~DeviceHSS() {
+  if (ctx_) hssk_sync(ctx_);
+  persist_.reset();
+  work_.reset();
+  fact_.reset();
+  hssk_ctx_destroy(ctx_);
+}
+
+void DeviceHSS::build_tree(const structured::ClusterTree* tree) {
+  nodes_.clear();
+  // pre-order; HSSMatrix.cpp:60-70 (bisection while size > leaf) or :72-82 (given cluster tree)
+  std::function<int(int, int, int, int, const structured::ClusterTree*)> rec =
+      [&](int lo, int m, int lvl, int parent, const structured::ClusterTree* t) -> int {
+    int id = (int)nodes_.size();
+    nodes_.emplace_back();
+    nodes_[id].lo = lo; nodes_[id].m = m; nodes_[id].lvl = lvl; nodes_[id].parent = parent;
+    bool split = t ? !t->c.empty() : (m > o_.leaf_size);
+    if (split) {
+      int m0 = t ? t->c[0].size : m / 2;
+      int c0 = rec(lo, m0, lvl + 1, id, t ? &t->c[0] : nullptr);
+      int c1 = rec(lo + m0, m - m0, lvl + 1, id, t ? &t->c[1] : nullptr);
+      nodes_[id].c0 = c0; nodes_[id].c1 = c1;
+      nodes_[id].height = 1 + std::max(nodes_[c0].height, nodes_[c1].height);
+    }
+    return id;
+  };
+  if (tree && tree->size != n_) throw std::invalid_argument("cluster tree size does not match the matrix dimension");
+  rec(0, n_, 0, -1, tree);
+  int H = nodes_[0].height, Dp = 0;
+  for (auto& nd : nodes_) Dp = std::max(Dp, nd.lvl);
+  by_height_.assign(H + 1, {});
+  by_depth_.assign(Dp + 1, {});
+  for (int i = 0; i < (int)nodes_.size(); i++) {
+    by_height_[nodes_[i].height].push_back(i);
+    by_depth_[nodes_[i].lvl].push_back(i);
+  }
+  d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
+}
+
+bool DeviceHSS::is_compressed() const { return nodes_[0].compressed(); }
+int DeviceHSS::levels() const { return nodes_[0].height + 1; }
+int DeviceHSS::rank() const {
+  int r = 0;
+  for (auto& nd : nodes_) r = std::max(r, std::max(nd.rU, nd.rV));
+  return r;
+}
+long long DeviceHSS::nonzeros() const {
+  long long t = 0;
+  for (auto& nd : nodes_) {
+    if (nd.leaf()) t += (long long)nd.m * nd.m;
+    else t += (long long)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (long long)nodes_[nd.c1].rU * nodes_[nd.c0].rV;
+    if (nd.lvl > 0) t += (long long)nd.rU * (nd.mU - nd.rU) + nd.mU + (long long)nd.rV * (nd.mV - nd.rV) + nd.mV;
+  }
+  return t;
+}
+long long DeviceHSS::memory() const {
+  long long t = 0;
+  for (auto& nd : nodes_) {
+    if (nd.leaf()) t += 8LL * nd.m * nd.m;
+    else t += 8LL * ((long long)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (long long)nodes_[nd.c1].rU * nodes_[nd.c0].rV);
+    if (nd.lvl > 0) t += 8LL * ((long long)nd.rU * (nd.mU - nd.rU) + (long long)nd.rV * (nd.mV - nd.rV)) + 4LL * (nd.mU + nd.mV);
+  }
+  return t;
+}
+long long DeviceHSS::factor_memory() const { return (long long)fact_->used(); }
+void DeviceHSS::node_info(int* out) const {
+  for (size_t i = 0; i < nodes_.size(); i++) {
+    const Node& nd = nodes_[i];
+    int* o = out + 6 * i;
+    o[0] = nd.lo; o[1] = nd.m; o[2] = nd.lvl ? nd.mU : 0; o[3] = nd.rU; o[4] = nd.rV; o[5] = nd.leaf();
+  }
+}
+void DeviceHSS::ensure_ready(const char* what) const {
+  if (!is_compressed()) throw std::logic_error(std::string(what) + ": the HSS matrix is not compressed");
+}
+
+// ---------------------------------------------------------------------------------------------
+// compression driver
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::compress_dense_device(const double* dA, long long lda) {
+  DenseDeviceSource s(dA, lda);
+  compress(s);
+}
+void DeviceHSS::compress_dense_host(const double* A, long long lda) {
+  double* dA = (double*)hssk_malloc((long long)sizeof(double) * n_ * std::max(n_, 1));
+  if (!dA && n_) throw std::runtime_error("device allocation of the dense input failed");
+  try {
+    ck(hssk_memcpy2d_h2d(ctx_, dA, sizeof(double) * n_, A, sizeof(double) * lda, sizeof(double) * n_, n_));
+    compress_dense_device(dA, n_);
+    ck(hssk_sync(ctx_));
+  } catch (...) { hssk_free(dA); throw; }
+  hssk_free(dA);
+}
+void DeviceHSS::compress_callbacks(const host_mult_t& mult, const host_elem_t& elem) {
+  CallbackSource s(mult, elem);
+  compress(s);
+}
+
+void DeviceHSS::reset_compression() {
+  for (auto& nd : nodes_) {
+    int lo = nd.lo, m = nd.m, lvl = nd.lvl, h = nd.height, c0 = nd.c0, c1 = nd.c1, p = nd.parent;
+    nd = Node();
+    nd.lo = lo; nd.m = m; nd.lvl = lvl; nd.height = h; nd.c0 = c0; nd.c1 = c1; nd.parent = p;
+  }
+  persist_->reset();
+  work_->reset();
+  fact_->reset();
+  factored_ = false;
+  d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
+}
+
+void DeviceHSS::free_compress_workspace() {
+  ck(hssk_sync(ctx_));
+  work_->reset();
+  Rt_ = Srt_ = Sct_ = nullptr;
+  for (auto& nd : nodes_) { nd.Srt = nd.Sct = nd.Rrt = nd.Rct = nd.RrtRed = nd.RctRed = nd.Qr = nd.Qc = nullptr; nd.panels = false; }
+}
+
+void DeviceHSS::compress(Source& src) {
+  double t0 = now();
+  stats_ = PhaseStats();
+  int dcap = o_.algorithm == 0 ? o_.d0 + o_.p : o_.d0 + o_.dd;
+  dcap = std::max(16, (dcap + 15) / 16 * 16);
+  for (;;) {
+    if (compress_attempt(src, dcap)) break;
+    dcap *= 2;  // the sample capacity was too small: restart (the random stream is seeded, so the
+                // restarted run retraces the same samples and continues past the old capacity)
+    if (o_.verbose) std::cout << "# HSS compression: growing the sample capacity to " << dcap << std::endl;
+  }
+  free_compress_workspace();
+  stats_.t_compress = now() - t0;
+  stats_.t_tree = stats_.t_compress - stats_.t_sketch - stats_.t_random;
+}
+
+void DeviceHSS::fill_random(int r0, int dn) {
+  double t0 = now();
+  const long long N = n_;
+  if (o_.random_engine == 2) {
+    // device Philox: element (sample s, column c) is a pure function of (seed, s * N + c)
+    if (o_.random_dist != 0) throw std::invalid_argument("philox engine implements the normal distribution only");
+    ck(hssk_randn(ctx_, Rt_ + r0, dn, N, dcap_, r0, N, 0x5354524dull));
+  } else {
+    // reference-identical host stream: DenseMatrix::random fills the N x dn block column-major,
+    // i.e. sample by sample (dense/DenseMatrix.cpp:172-181); the generator persists across rounds
+    // (HSSMatrix.compress_stable.hpp:108-112).
+    if (r0 == 0 || !rng_) rng_.reset(new HostRng());
+    std::minstd_rand* lin = &rng_->lin;
+    std::mt19937* mer = &rng_->mer;
+    auto& nd = rng_->nd;
+    auto& ud = rng_->ud;
+    std::vector<double> buf((size_t)dn * N);
+    for (int s = 0; s < dn; s++)
+      for (long long c = 0; c < N; c++) {
+        double v;
+        if (o_.random_engine == 0) v = o_.random_dist == 0 ? nd(*lin) : ud(*lin);
+        else v = o_.random_dist == 0 ? nd(*mer) : ud(*mer);
+        buf[s + (size_t)c * dn] = v;
+      }
+    ck(hssk_memcpy2d_h2d(ctx_, Rt_ + r0, sizeof(double) * dcap_, buf.data(), sizeof(double) * dn, sizeof(double) * dn, N));
+  }
+  ck(hssk_sync(ctx_));
+  stats_.t_random += now() - t0;
+}
+
+bool DeviceHSS::compress_attempt(Source& src, int dcap) {
+  reset_compression();
+  dcap_ = dcap;
+  const size_t N = n_;
+  Rt_ = work_->dbl((size_t)dcap * N);
+  Srt_ = work_->dbl((size_t)dcap * N);
+  Sct_ = work_->dbl((size_t)dcap * N);
+  stats_.rounds = 0;
+  stats_.f_sketch = stats_.f_local = stats_.f_reduce = stats_.f_id = stats_.f_ortho = 0;
+  const bool original = (o_.algorithm == 0);
+  if (!original) {
+    // compress_stable(Amult, Aelem, opts), HSSMatrix.compress_stable.hpp:100-163
+    int d = o_.d0, dd = o_.dd;
+    while (!is_compressed()) {
+      int c = (d == o_.d0) ? 0 : d;
+      int dnew = (d == o_.d0) ? d + dd : dd;
+      if (c + dnew > dcap) return false;
+      fill_random(c, dnew);
+      double t0 = now();
+      src.sample(*this, c, dnew);
+      ck(hssk_sync(ctx_));
+      stats_.t_sketch += now() - t0;
+      stats_.f_sketch += 4.0 * (double)N * (double)N * dnew;
+      if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
+      stats_.rounds++;
+      for (auto& ids : by_height_) process_level(src, ids, d, dd, false);
+      stats_.d_final = d + dd;
+      if (!is_compressed()) {
+        d += dd;
+        dd = std::min(dd, o_.max_rank - d);
+        if (dd <= 0) break;  // cannot add samples: compression failed (is_compressed() stays false)
+      }
+    }
+  } else {
+    // compress_original, HSSMatrix.compress.hpp:100-165
+    int d_old = 0, d = o_.d0 + o_.p;
+    while (!is_compressed()) {
+      if (d > dcap) return false;
+      fill_random(d_old, d - d_old);
+      double t0 = now();
+      src.sample(*this, d_old, d - d_old);
+      ck(hssk_sync(ctx_));
+      stats_.t_sketch += now() - t0;
+      stats_.f_sketch += 4.0 * (double)N * (double)N * (d - d_old);
+      if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << " (original)" << std::endl;
+      stats_.rounds++;
+      for (auto& ids : by_height_) process_level(src, ids, d, d - d_old, true);
+      stats_.d_final = d;
+      if (!is_compressed()) {
+        d_old = d;
+        d = 2 * (d_old - o_.p) + o_.p;
+        if (d_old >= 4 * n_ + o_.p + 64) break;
+      }
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one tree height of one compression round
+//   stable:   d, dd as in compress_recursive_stable (samples [0,d+dd), new ones [d,d+dd))
+//   original: d = total samples, dd = newly added ones
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::process_level(Source& src, const std::vector<int>& ids_all, int d, int dd, bool original) {
+  const int dtot = original ? d : d + dd;
+  const int dnew0 = original ? d - dd : d;  // first new sample row
+  std::vector<int> ids;
+  for (int id : ids_all) {
+    Node& nd = nodes_[id];
+    if (!nd.leaf() && !(nodes_[nd.c0].compressed() && nodes_[nd.c1].compressed())) continue;
+    if (nd.lvl == 0 && nd.compressed()) continue;
+    ids.push_back(id);
+  }
+  if (ids.empty()) return;
+  // --- extraction of D / B01 / B10 for untouched nodes (compress_stable.hpp:171-182, 204-217)
+  std::vector<int> fresh;
+  std::vector<char> was_untouched(nodes_.size(), 0), was_compressed(nodes_.size(), 0);
+  for (int id : ids) {
+    Node& nd = nodes_[id];
+    was_untouched[id] = nd.untouched();
+    was_compressed[id] = nd.compressed();
+    if (nd.untouched()) fresh.push_back(id);
+  }
+  extract_blocks(src, fresh);
+  std::vector<int> work_ids, r0s, dns;
+  for (int id : ids) {
+    Node& nd = nodes_[id];
+    if (nd.lvl == 0) { nd.Ustate = nd.Vstate = 2; continue; }
+    if (!nd.panels) {
+      if (nd.leaf()) {
+        nd.mU = nd.mV = nd.m;
+        nd.Srt = Srt_ + (size_t)nd.lo * dcap_;
+        nd.Sct = Sct_ + (size_t)nd.lo * dcap_;
+        nd.Rrt = nd.Rct = Rt_ + (size_t)nd.lo * dcap_;
+      } else {
+        nd.mU = nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+        nd.mV = nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+        nd.Srt = work_->dbl((size_t)dcap_ * std::max(nd.mU, 1));
+        nd.Sct = work_->dbl((size_t)dcap_ * std::max(nd.mV, 1));
+        nd.Rrt = work_->dbl((size_t)dcap_ * std::max(nd.mV, 1));
+        nd.Rct = work_->dbl((size_t)dcap_ * std::max(nd.mU, 1));
+      }
+      nd.panels = true;
+    }
+    work_ids.push_back(id);
+    r0s.push_back(was_untouched[id] ? 0 : dnew0);
+    dns.push_back(was_untouched[id] ? dtot : dtot - dnew0);
+  }
+  if (work_ids.empty()) return;
+  local_samples(work_ids, r0s, dns);
+
+  // --- bases
+  std::vector<int> id_nodes, id_which, ot_nodes, ot_which;
+  for (int id : work_ids) {
+    Node& nd = nodes_[id];
+    if (was_compressed[id]) continue;
+    for (int w = 0; w < 2; w++) {
+      int st = w == 0 ? nd.Ustate : nd.Vstate;
+      if (st == 2) continue;
+      int rows = w == 0 ? nd.mU : nd.mV;
+      if (original || dtot >= o_.max_rank || dtot >= rows) { id_nodes.push_back(id); id_which.push_back(w); }
+      else { ot_nodes.push_back(id); ot_which.push_back(w); }
+    }
+  }
+  if (!ot_nodes.empty()) {
+    std::vector<char> resolved;
+    ortho_test(ot_nodes, ot_which, d, dd, resolved);
+    for (size_t i = 0; i < ot_nodes.size(); i++) {
+      if (resolved[i]) { id_nodes.push_back(ot_nodes[i]); id_which.push_back(ot_which[i]); }
+      else {
+        Node& nd = nodes_[ot_nodes[i]];
+        (ot_which[i] == 0 ? nd.Ustate : nd.Vstate) = 1;
+      }
+    }
+  }
+  run_id(id_nodes, id_which, dtot);
+  if (original) {
+    // compute_U_V_bases acceptance, HSSMatrix.compress.hpp:663-686
+    for (int id : work_ids) {
+      Node& nd = nodes_[id];
+      if (was_compressed[id]) continue;
+      bool ok = (dtot - o_.p >= o_.max_rank) || (nd.rU < dtot - o_.p && nd.rV < dtot - o_.p);
+      if (!ok) { nd.Ustate = nd.Vstate = 1; nd.rU = nd.rV = 0; nd.Ir.clear(); nd.Ic.clear(); }
+    }
+  }
+  // --- reduce (reduce_local_samples, HSSMatrix.compress.hpp:689-724)
+  std::vector<int> rd_ids, rd_r0, rd_dn;
+  for (int id : work_ids) {
+    Node& nd = nodes_[id];
+    if (!nd.compressed()) continue;
+    if (!was_compressed[id]) {
+      nd.RrtRed = work_->dbl((size_t)dcap_ * std::max(nd.rV, 1));
+      nd.RctRed = work_->dbl((size_t)dcap_ * std::max(nd.rU, 1));
+      rd_ids.push_back(id); rd_r0.push_back(0); rd_dn.push_back(dtot);
+    } else {
+      rd_ids.push_back(id); rd_r0.push_back(dnew0); rd_dn.push_back(dtot - dnew0);
+    }
+  }
+  reduce_samples(rd_ids, rd_r0, rd_dn);
+}
+
+void DeviceHSS::extract_blocks(Source& src, const std::vector<int>& ids) {
+  std::vector<ElemReq> reqs;
+  for (int id : ids) {
+    Node& nd = nodes_[id];
+    if (nd.leaf()) {
+      nd.D = persist_->dbl((size_t)nd.m * nd.m);
+      reqs.push_back(ElemReq{nullptr, nullptr, nullptr, nullptr, nd.lo, nd.lo, nd.m, nd.m, nd.D, nd.m});
+    } else {
+      Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+      nd.B01 = persist_->dbl((size_t)std::max(a.rU, 1) * std::max(b.rV, 1));
+      nd.B10 = persist_->dbl((size_t)std::max(b.rU, 1) * std::max(a.rV, 1));
+      reqs.push_back(ElemReq{a.dIr, b.dIc, &a.Ir, &b.Ic, 0, 0, a.rU, b.rV, nd.B01, std::max(a.rU, 1)});
+      reqs.push_back(ElemReq{b.dIr, a.dIc, &b.Ir, &a.Ic, 0, 0, b.rU, a.rV, nd.B10, std::max(b.rU, 1)});
+    }
+  }
+  if (!reqs.empty()) src.extract(*this, reqs);
+}
+
+// compute_local_samples (HSSMatrix.compress.hpp:524-629) on sample rows [r0, r0+dn) of each node
+void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int>& r0s, const std::vector<int>& dns) {
+  std::vector<hssk_colgather_desc> g;
+  std::vector<hssk_gemm_desc> mm;
+  for (size_t k = 0; k < ids.size(); k++) {
+    Node& nd = nodes_[ids[k]];
+    const int r0 = r0s[k], dn = dns[k];
+    if (dn <= 0) continue;
+    if (nd.leaf()) {
+      const int m = nd.m;
+      // Sr_loc -= D Rr_loc  ->  Srt -= Rt D^T ;  Sc_loc -= D^T Rc_loc  ->  Sct -= Rt D
+      mm.push_back(hssk_gemm_desc{nd.Rrt + r0, nd.D, nd.Srt + r0, dn, m, m, dcap_, m, dcap_, 0, 1, -1.0, 1.0});
+      mm.push_back(hssk_gemm_desc{nd.Rct + r0, nd.D, nd.Sct + r0, dn, m, m, dcap_, m, dcap_, 0, 0, -1.0, 1.0});
+      stats_.f_local += 4.0 * m * (double)m * dn;
+    } else {
+      Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+      // gather the children's skeleton rows (extract_rows, compress.hpp:563-566, 611-614)
+      g.push_back(hssk_colgather_desc{a.Srt + r0, nd.Srt + r0, a.permU, dn, a.rU, dcap_, dcap_, 0});
+      g.push_back(hssk_colgather_desc{b.Srt + r0, nd.Srt + r0 + (size_t)a.rU * dcap_, b.permU, dn, b.rU, dcap_, dcap_, 0});
+      g.push_back(hssk_colgather_desc{a.Sct + r0, nd.Sct + r0, a.permV, dn, a.rV, dcap_, dcap_, 0});
+      g.push_back(hssk_colgather_desc{b.Sct + r0, nd.Sct + r0 + (size_t)a.rV * dcap_, b.permV, dn, b.rV, dcap_, dcap_, 0});
+      // Sr0 -= B01 Rr1 ; Sr1 -= B10 Rr0 ; Sc0 -= B10^T Rc1 ; Sc1 -= B01^T Rc0
+      mm.push_back(hssk_gemm_desc{b.RrtRed + r0, nd.B01, nd.Srt + r0, dn, a.rU, b.rV, dcap_, std::max(a.rU, 1), dcap_, 0, 1, -1.0, 1.0});
+      mm.push_back(hssk_gemm_desc{a.RrtRed + r0, nd.B10, nd.Srt + r0 + (size_t)a.rU * dcap_, dn, b.rU, a.rV, dcap_, std::max(b.rU, 1), dcap_, 0, 1, -1.0, 1.0});
+      mm.push_back(hssk_gemm_desc{b.RctRed + r0, nd.B10, nd.Sct + r0, dn, a.rV, b.rU, dcap_, std::max(b.rU, 1), dcap_, 0, 0, -1.0, 1.0});
+      mm.push_back(hssk_gemm_desc{a.RctRed + r0, nd.B01, nd.Sct + r0 + (size_t)a.rV * dcap_, dn, b.rV, a.rU, dcap_, std::max(a.rU, 1), dcap_, 0, 0, -1.0, 1.0});
+      stats_.f_local += 4.0 * ((double)a.rU * b.rV + (double)b.rU * a.rV) * dn;
+    }
+  }
+  if (!g.empty()) ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
+  if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
+}
+
+// reduce_local_samples: Rr_loc <- V^H Rr_loc, Rc_loc <- U^H Rc_loc (HSSBasisID::applyC), transposed
+void DeviceHSS::reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0s, const std::vector<int>& dns) {
+  if (ids.empty()) return;
+  std::vector<hssk_colgather_desc> cat, g;
+  std::vector<hssk_gemm_desc> mm;
+  Arena tmp(size_t(32) << 20);
+  for (size_t k = 0; k < ids.size(); k++) {
+    Node& nd = nodes_[ids[k]];
+    const int r0 = r0s[k], dn = dns[k];
+    if (dn <= 0) continue;
+    if (!nd.leaf()) {
+      Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+      cat.push_back(hssk_colgather_desc{a.RrtRed + r0, nd.Rrt + r0, nullptr, dn, a.rV, dcap_, dcap_, 0});
+      cat.push_back(hssk_colgather_desc{b.RrtRed + r0, nd.Rrt + r0 + (size_t)a.rV * dcap_, nullptr, dn, b.rV, dcap_, dcap_, 0});
+      cat.push_back(hssk_colgather_desc{a.RctRed + r0, nd.Rct + r0, nullptr, dn, a.rU, dcap_, dcap_, 0});
+      cat.push_back(hssk_colgather_desc{b.RctRed + r0, nd.Rct + r0 + (size_t)a.rU * dcap_, nullptr, dn, b.rU, dcap_, dcap_, 0});
+    }
+    // Rr (with V): RrtRed = Rrt[:, permV[:rV]] + Rrt[:, permV[rV:]] XV^T
+    {
+      const int m = nd.mV, r = nd.rV;
+      g.push_back(hssk_colgather_desc{nd.Rrt + r0, nd.RrtRed + r0, nd.permV, dn, r, dcap_, dcap_, 0});
+      if (m > r && r > 0) {
+        double* T = tmp.dbl((size_t)dn * (m - r));
+        g.push_back(hssk_colgather_desc{nd.Rrt + r0, T, nd.permV + r, dn, m - r, dcap_, dn, 0});
+        mm.push_back(hssk_gemm_desc{T, nd.XV, nd.RrtRed + r0, dn, r, m - r, dn, r, dcap_, 0, 1, 1.0, 1.0});
+        stats_.f_reduce += 2.0 * r * (double)(m - r) * dn;
+      }
+    }
+    {
+      const int m = nd.mU, r = nd.rU;
+      g.push_back(hssk_colgather_desc{nd.Rct + r0, nd.RctRed + r0, nd.permU, dn, r, dcap_, dcap_, 0});
+      if (m > r && r > 0) {
+        double* T = tmp.dbl((size_t)dn * (m - r));
+        g.push_back(hssk_colgather_desc{nd.Rct + r0, T, nd.permU + r, dn, m - r, dcap_, dn, 0});
+        mm.push_back(hssk_gemm_desc{T, nd.XU, nd.RctRed + r0, dn, r, m - r, dn, r, dcap_, 0, 1, 1.0, 1.0});
+        stats_.f_reduce += 2.0 * r * (double)(m - r) * dn;
+      }
+    }
+  }
+  if (!cat.empty()) ck(hssk_gather_cols(ctx_, cat.data(), (int)cat.size()));
+  if (!g.empty()) ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
+  if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
+  ck(hssk_sync(ctx_));  // tmp is released on return
+}
+
+// ID of the listed (node, basis) pairs on all dtot samples; commits ranks, X, perm, index sets
+void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot) {
+  if (ids.empty()) return;
+  Arena tmp(size_t(64) << 20);
+  const size_t cnt = ids.size();
+  std::vector<hssk_colgather_desc> cp;
+  std::vector<hssk_id_desc> idd;
+  std::vector<double*> Ws(cnt, nullptr);
+  std::vector<int*> perms(cnt, nullptr);
+  size_t perm_total = 0;
+  for (size_t k = 0; k < cnt; k++) perm_total += (which[k] == 0 ? nodes_[ids[k]].mU : nodes_[ids[k]].mV);
+  int* perm_block = persist_->ints(std::max<size_t>(perm_total, 1));
+  int* rank_block = d_ranks_;
+  if (cnt > 2 * nodes_.size()) throw std::logic_error("run_id: too many problems");
+  size_t poff = 0;
+  for (size_t k = 0; k < cnt; k++) {
+    Node& nd = nodes_[ids[k]];
+    const int m = which[k] == 0 ? nd.mU : nd.mV;
+    const double* S = which[k] == 0 ? nd.Srt : nd.Sct;
+    perms[k] = perm_block + poff;
+    poff += m;
+    if (m == 0) continue;
+    double* W = tmp.dbl((size_t)dtot * m);
+    Ws[k] = W;
+    cp.push_back(hssk_colgather_desc{S, W, nullptr, dtot, m, dcap_, dtot, 0});
+    double* wk = tmp.dbl(3 * (size_t)m);
+    idd.push_back(hssk_id_desc{W, dtot, dtot, m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk});
+  }
+  if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+  if (!idd.empty()) ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
+  std::vector<int> hranks(cnt, 0), hperm(std::max<size_t>(perm_total, 1));
+  ck(hssk_memcpy_d2h(ctx_, hranks.data(), rank_block, (long long)sizeof(int) * cnt));
+  if (perm_total) ck(hssk_memcpy_d2h(ctx_, hperm.data(), perm_block, (long long)sizeof(int) * perm_total));
+  // commit
+  std::vector<hssk_elem_desc> xc;
+  poff = 0;
+  for (size_t k = 0; k < cnt; k++) {
+    Node& nd = nodes_[ids[k]];
+    const int w = which[k];
+    const int m = w == 0 ? nd.mU : nd.mV;
+    const int r = m ? hranks[k] : 0;
+    std::vector<int> perm(hperm.begin() + poff, hperm.begin() + poff + m);
+    poff += m;
+    double* X = persist_->dbl((size_t)std::max(r, 1) * std::max(m - r, 1));
+    if (r > 0 && m > r) xc.push_back(hssk_elem_desc{Ws[k], dtot, nullptr, nullptr, 0, r, X, r, m - r, r, 0});
+    // global skeleton indices (compress_stable.hpp:299-306, 334-341)
+    std::vector<int> I(r);
+    if (nd.leaf()) for (int i = 0; i < r; i++) I[i] = nd.lo + perm[i];
+    else {
+      const std::vector<int>& ia = w == 0 ? nodes_[nd.c0].Ir : nodes_[nd.c0].Ic;
+      const std::vector<int>& ib = w == 0 ? nodes_[nd.c1].Ir : nodes_[nd.c1].Ic;
+      const int r0 = (int)ia.size();
+      for (int i = 0; i < r; i++) I[i] = perm[i] < r0 ? ia[perm[i]] : ib[perm[i] - r0];
+    }
+    int* dI = persist_->ints(std::max(r, 1));
+    if (r) ck(hssk_memcpy_h2d(ctx_, dI, I.data(), (long long)sizeof(int) * r));
+    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.hpermU = perm; nd.Ir = I; nd.dIr = dI; nd.Ustate = 2; }
+    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.hpermV = perm; nd.Ic = I; nd.dIc = dI; nd.Vstate = 2; }
+    stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
+  }
+  if (!xc.empty()) ck(hssk_gather_elems(ctx_, xc.data(), (int)xc.size()));
+  ck(hssk_sync(ctx_));  // tmp (W panels) released on return
+}
+
+// update_orthogonal_basis (HSSMatrix.compress_stable.hpp:390-442) for the listed (node, basis) pairs
+void DeviceHSS::ortho_test(const std::vector<int>& ids, const std::vector<int>& which, int d, int dd,
+                           std::vector<char>& resolved) {
+  const size_t cnt = ids.size();
+  resolved.assign(cnt, 0);
+  Arena tmp(size_t(64) << 20);
+  std::vector<hssk_transpose_desc> tr;
+  std::vector<hssk_colgather_desc> cp;
+  std::vector<hssk_qr_desc> qr;
+  double* rdiag = tmp.dbl(2 * cnt);
+  std::vector<char> untouched(cnt);
+  for (size_t k = 0; k < cnt; k++) {
+    Node& nd = nodes_[ids[k]];
+    const int w = which[k];
+    const int m = w == 0 ? nd.mU : nd.mV;
+    const double* S = w == 0 ? nd.Srt : nd.Sct;
+    double*& Q = w == 0 ? nd.Qr : nd.Qc;
+    untouched[k] = (w == 0 ? nd.Ustate : nd.Vstate) == 0;
+    if (!Q) Q = work_->dbl((size_t)m * dcap_);
+    // Q(:, d:d+dd) = S(:, d:d+dd)
+    tr.push_back(hssk_transpose_desc{S + d, Q + (size_t)d * m, dd, m, dcap_, m});
+    int c2, n2;
+    if (untouched[k]) { c2 = 0; n2 = std::min(d, m); }
+    else { c2 = d - dd; n2 = std::min(dd, m - (d - dd)); }
+    double* T = tmp.dbl((size_t)m * std::max(n2, 1));
+    if (untouched[k]) tr.push_back(hssk_transpose_desc{S, T, n2, m, dcap_, m});
+    else cp.push_back(hssk_colgather_desc{Q + (size_t)c2 * m, T, nullptr, m, n2, m, m, 0});
+    double* wk = tmp.dbl((size_t)m + n2);
+    qr.push_back(hssk_qr_desc{T, m, m, n2, Q + (size_t)c2 * m, m, n2, rdiag + 2 * k, wk});
+    stats_.f_ortho += 4.0 * m * (double)n2 * n2;
+  }
+  if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+  ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
+  ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+  std::vector<double> hr(2 * cnt);
+  ck(hssk_memcpy_d2h(ctx_, hr.data(), rdiag, (long long)sizeof(double) * 2 * cnt));
+  std::vector<size_t> pend;
+  for (size_t k = 0; k < cnt; k++) {
+    Node& nd = nodes_[ids[k]];
+    const int w = which[k];
+    double r_max = hr[2 * k], r_min = hr[2 * k + 1];
+    double& r_max_0 = w == 0 ? nd.Ur_max : nd.Vr_max;
+    if (untouched[k]) r_max_0 = r_max;
+    const double atol = o_.abs_tol / nd.lvl, rtol = o_.rel_tol / nd.lvl;
+    if (std::abs(r_min) < atol || std::abs(r_min / r_max_0) < rtol) resolved[k] = 1;
+    else pend.push_back(k);
+  }
+  if (pend.empty()) return;
+  // iterated classical Gram-Schmidt of the dd new columns against Q12, norms of the first p columns
+  const int pc = std::min(dd, o_.p);
+  double* nrm = tmp.dbl(2 * pend.size());
+  std::vector<hssk_norm_desc> n0, n1;
+  std::vector<hssk_gemm_desc> g1, g2;
+  for (size_t i = 0; i < pend.size(); i++) {
+    size_t k = pend[i];
+    Node& nd = nodes_[ids[k]];
+    const int w = which[k];
+    const int m = w == 0 ? nd.mU : nd.mV;
+    double* Q = w == 0 ? nd.Qr : nd.Qc;
+    const int q12 = std::min(d, m);
+    double* Q3 = Q + (size_t)d * m;
+    double* P = tmp.dbl((size_t)q12 * dd);
+    n0.push_back(hssk_norm_desc{Q3, m, pc, m, nrm + 2 * i});
+    g1.push_back(hssk_gemm_desc{Q, Q3, P, q12, dd, m, m, m, q12, 1, 0, 1.0, 0.0});
+    g2.push_back(hssk_gemm_desc{Q, P, Q3, m, dd, q12, m, q12, m, 0, 0, -1.0, 1.0});
+    n1.push_back(hssk_norm_desc{Q3, m, pc, m, nrm + 2 * i + 1});
+    stats_.f_ortho += 8.0 * m * (double)q12 * dd;
+  }
+  ck(hssk_sumsq_vbatched(ctx_, n0.data(), (int)n0.size()));
+  for (int it = 0; it < 2; it++) {
+    ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
+    ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
+  }
+  ck(hssk_sumsq_vbatched(ctx_, n1.data(), (int)n1.size()));
+  std::vector<double> hn(2 * pend.size());
+  ck(hssk_memcpy_d2h(ctx_, hn.data(), nrm, (long long)sizeof(double) * hn.size()));
+  for (size_t i = 0; i < pend.size(); i++) {
+    size_t k = pend[i];
+    Node& nd = nodes_[ids[k]];
+    const double atol = o_.abs_tol / nd.lvl, rtol = o_.rel_tol / nd.lvl;
+    double S3 = std::sqrt(hn[2 * i]), Q3 = std::sqrt(hn[2 * i + 1]);
+    if (Q3 / std::sqrt(double(dd)) < atol || Q3 / S3 < rtol) resolved[k] = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shift
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::shift(double sigma) {
+  std::vector<hssk_shift_desc> d;
+  for (auto& nd : nodes_)
+    if (nd.leaf() && nd.D) d.push_back(hssk_shift_desc{nd.D, nd.m, nd.m});
+  if (!d.empty()) ck(hssk_shift_diag(ctx_, d.data(), (int)d.size(), sigma));
+  ck(hssk_sync(ctx_));
+  factored_ = false;  // the ULV factors are stale (examples/dense/testStructured.cpp:199)
+}
+
+// ---------------------------------------------------------------------------------------------
+// mult: apply_HSS (HSSMatrix.cpp:419-435, HSSMatrix.apply.hpp:55-220)
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
+                     bool on_device, double beta) {
+  ensure_ready("mult");
+  if (nrhs <= 0 || n_ == 0) return;
+  double t0 = now();
+  const bool T = !(trans == 'N' || trans == 'n');
+  Arena tmp(size_t(32) << 20);
+  const int N = n_;
+  const double* dx = x;
+  double* dy = y;
+  long long lx = ldx, ly = ldy;
+  if (!on_device) {
+    double* bx = tmp.dbl((size_t)N * nrhs);
+    double* by = tmp.dbl((size_t)N * nrhs);
+    ck(hssk_memcpy2d_h2d(ctx_, bx, sizeof(double) * N, x, sizeof(double) * ldx, sizeof(double) * N, nrhs));
+    if (beta != 0.0) ck(hssk_memcpy2d_h2d(ctx_, by, sizeof(double) * N, y, sizeof(double) * ldy, sizeof(double) * N, nrhs));
+    dx = bx; dy = by; lx = ly = N;
+  }
+  if (lx > 0x7fffffffLL || ly > 0x7fffffffLL) throw std::invalid_argument("mult: leading dimension too large");
+  // per-node buffers: cat (children's V^H results, rows of the "in" basis), t (U tmp2, rows of "out" basis)
+  const size_t nn = nodes_.size();
+  std::vector<double*> cat(nn, nullptr), tbuf(nn, nullptr);
+  auto rin = [&](const Node& nd) { return T ? nd.rU : nd.rV; };   // rank of the basis applied to the input
+  auto rout = [&](const Node& nd) { return T ? nd.rV : nd.rU; };
+  auto min_ = [&](const Node& nd) { return T ? nd.mU : nd.mV; };
+  auto mout = [&](const Node& nd) { return T ? nd.mV : nd.mU; };
+  for (size_t i = 0; i < nn; i++) {
+    const Node& nd = nodes_[i];
+    if (nd.leaf()) continue;
+    int ci = rin(nodes_[nd.c0]) + rin(nodes_[nd.c1]);
+    int co = rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]);
+    cat[i] = tmp.dbl((size_t)std::max(ci, 1) * nrhs);
+    tbuf[i] = tmp.dbl((size_t)std::max(co, 1) * nrhs);
+  }
+  // ---- up-sweep: tmp1 = Vin^H [..]
+  for (size_t h = 0; h < by_height_.size(); h++) {
+    std::vector<hssk_rowgather_desc> g;
+    std::vector<hssk_gemm_desc> mm;
+    for (int id : by_height_[h]) {
+      const Node& nd = nodes_[id];
+      if (nd.lvl == 0) continue;
+      const Node& pa = nodes_[nd.parent];
+      const int m = min_(nd), r = rin(nd);
+      const int* perm = T ? nd.permU : nd.permV;
+      const double* X = T ? nd.XU : nd.XV;
+      const double* src = nd.leaf() ? dx + nd.lo : cat[id];
+      const int lds = nd.leaf() ? (int)lx : std::max(m, 1);
+      const int pci = rin(nodes_[pa.c0]) + rin(nodes_[pa.c1]);
+      double* dst = cat[nd.parent] + (id == pa.c0 ? 0 : rin(nodes_[pa.c0]));
+      const int ldd = std::max(pci, 1);
+      if (r == 0) continue;
+      g.push_back(hssk_rowgather_desc{src, dst, perm, r, nrhs, lds, ldd, 0, 0});
+      if (m > r) {
+        double* Tm = tmp.dbl((size_t)(m - r) * nrhs);
+        g.push_back(hssk_rowgather_desc{src, Tm, perm + r, m - r, nrhs, lds, m - r, 0, 0});
+        mm.push_back(hssk_gemm_desc{X, Tm, dst, r, nrhs, m - r, r, m - r, ldd, 0, 0, 1.0, 1.0});
+      }
+    }
+    if (!g.empty()) ck(hssk_gather_rows(ctx_, g.data(), (int)g.size()));
+    if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
+  }
+  // ---- down-sweep by depth
+  for (size_t dpt = 0; dpt < by_depth_.size(); dpt++) {
+    std::vector<hssk_gemm_desc> m1, leafmm, innermm;  // m1: basis expansion X^T tmp2
+    std::vector<hssk_rowgather_desc> sc;
+    for (int id : by_depth_[dpt]) {
+      const Node& nd = nodes_[id];
+      const int mo = mout(nd), ro = rout(nd);
+      const int* perm = T ? nd.permV : nd.permU;
+      const double* X = T ? nd.XV : nd.XU;
+      // tmp2 of this node lives in the parent's t buffer
+      const double* tmp2 = nullptr;
+      int ld2 = 1;
+      if (nd.lvl > 0) {
+        const Node& pa = nodes_[nd.parent];
+        tmp2 = tbuf[nd.parent] + (id == pa.c0 ? 0 : rout(nodes_[pa.c0]));
+        ld2 = std::max(rout(nodes_[pa.c0]) + rout(nodes_[pa.c1]), 1);
+      }
+      double* out = nd.leaf() ? dy + nd.lo : tbuf[id];
+      // (the root has no basis, so its mU / mV are unset: size t from the children's ranks)
+      const int ldo = nd.leaf() ? (int)ly : std::max(rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]), 1);
+      const bool expand = nd.lvl > 0 && ro > 0;
+      if (nd.leaf()) {
+        // c = D b + beta c (+ U tmp2)
+        leafmm.push_back(hssk_gemm_desc{nd.D, dx + nd.lo, out, nd.m, nrhs, nd.m, nd.m, (int)lx, ldo, T ? 1 : 0, 0, 1.0, beta});
+      } else {
+        const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+        const int ri_a = rin(a), ri_b = rin(b), ro_a = rout(a), ro_b = rout(b);
+        const int lc = std::max(ri_a + ri_b, 1);
+        const double* t1a = cat[id];
+        const double* t1b = cat[id] + ri_a;
+        const double bet = expand ? 1.0 : 0.0;
+        if (!T) {  // tmp2_0 = B01 tmp1_1 ; tmp2_1 = B10 tmp1_0
+          innermm.push_back(hssk_gemm_desc{nd.B01, t1b, out, ro_a, nrhs, ri_b, std::max(ro_a, 1), lc, ldo, 0, 0, 1.0, bet});
+          innermm.push_back(hssk_gemm_desc{nd.B10, t1a, out + ro_a, ro_b, nrhs, ri_a, std::max(ro_b, 1), lc, ldo, 0, 0, 1.0, bet});
+        } else {   // tmp2_0 = B10^T tmp1_1 ; tmp2_1 = B01^T tmp1_0   (ranks: B10 is rU1 x rV0, B01 is rU0 x rV1)
+          innermm.push_back(hssk_gemm_desc{nd.B10, t1b, out, ro_a, nrhs, ri_b, std::max(ri_b, 1), lc, ldo, 1, 0, 1.0, bet});
+          innermm.push_back(hssk_gemm_desc{nd.B01, t1a, out + ro_a, ro_b, nrhs, ri_a, std::max(ri_a, 1), lc, ldo, 1, 0, 1.0, bet});
+        }
+      }
+      if (expand) {
+        // out(perm[:r]) (+)= tmp2 ; out(perm[r:]) (+)= X^T tmp2     (HSSBasisID::apply)
+        const int acc = nd.leaf() ? 1 : 0;  // leaves add onto D b; inner nodes initialise t
+        sc.push_back(hssk_rowgather_desc{tmp2, out, perm, ro, nrhs, ld2, ldo, 1, acc});
+        if (mo > ro) {
+          double* E2 = tmp.dbl((size_t)(mo - ro) * nrhs);
+          m1.push_back(hssk_gemm_desc{X, tmp2, E2, mo - ro, nrhs, ro, ro, ld2, mo - ro, 1, 0, 1.0, 0.0});
+          sc.push_back(hssk_rowgather_desc{E2, out, perm + ro, mo - ro, nrhs, mo - ro, ldo, 1, acc});
+        }
+      }
+    }
+    // order: leaves need D b before the accumulate-scatter; inner nodes need the scatter (which
+    // initialises t) before the beta = 1 coupling gemm.
+    if (!leafmm.empty()) ck(hssk_gemm_vbatched(ctx_, leafmm.data(), (int)leafmm.size()));
+    if (!m1.empty()) ck(hssk_gemm_vbatched(ctx_, m1.data(), (int)m1.size()));
+    if (!sc.empty()) ck(hssk_gather_rows(ctx_, sc.data(), (int)sc.size()));
+    if (!innermm.empty()) ck(hssk_gemm_vbatched(ctx_, innermm.data(), (int)innermm.size()));
+  }
+  if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, y, sizeof(double) * ldy, dy, sizeof(double) * N, sizeof(double) * N, nrhs));
+  ck(hssk_sync(ctx_));
+  stats_.t_mult = now() - t0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ULV factorization (HSSMatrix.factor.hpp:51-147)
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::factor() {
+  ensure_ready("factor");
+  double t0 = now();
+  ck(hssk_sync(ctx_));
+  fact_->reset();
+  stats_.f_ulv = 0;
+  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nullptr, nd.piv = nullptr;
+  const size_t nn = nodes_.size();
+  std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr);
+  for (size_t h = 0; h < by_height_.size(); h++) {
+    const std::vector<int>& ids = by_height_[h];
+    // ---- assemble Dh (mU x mU) and Vh (mU x rV)
+    std::vector<hssk_colgather_desc> cp;
+    std::vector<hssk_gemm_desc> g0, g1;
+    std::vector<hssk_basis_desc> bd;
+    Arena tmp(size_t(32) << 20);
+    for (int id : ids) {
+      Node& nd = nodes_[id];
+      const bool root = nd.lvl == 0;
+      const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+      Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
+      if (nd.leaf()) {
+        cp.push_back(hssk_colgather_desc{nd.D, Dh[id], nullptr, nd.m, nd.m, nd.m, nd.m, 0});
+      } else {
+        Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+        // D = [Dt0, B01 Vt1_1^T ; B10 Vt1_0^T, Dt1]
+        cp.push_back(hssk_colgather_desc{a.Dt, Dh[id], nullptr, a.rU, a.rU, std::max(a.rU, 1), std::max(mu, 1), 0});
+        cp.push_back(hssk_colgather_desc{b.Dt, Dh[id] + a.rU + (size_t)a.rU * mu, nullptr, b.rU, b.rU, std::max(b.rU, 1), std::max(mu, 1), 0});
+        g0.push_back(hssk_gemm_desc{nd.B01, b.Vt1, Dh[id] + (size_t)a.rU * mu, a.rU, b.rU, b.rV, std::max(a.rU, 1), std::max(b.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
+        g0.push_back(hssk_gemm_desc{nd.B10, a.Vt1, Dh[id] + a.rU, b.rU, a.rU, a.rV, std::max(b.rU, 1), std::max(a.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
+        stats_.f_ulv += 2.0 * a.rU * (double)b.rU * (a.rV + b.rV);
+      }
+      if (!root) {
+        Vh[id] = fact_->dbl((size_t)std::max(nd.mU, 1) * std::max(nd.rV, 1));
+        if (nd.leaf()) {
+          if (nd.rV) bd.push_back(hssk_basis_desc{nd.XV, nd.permV, Vh[id], nd.mV, nd.rV, nd.rV, nd.mV});
+        } else if (nd.rV) {
+          Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+          double* Vd = tmp.dbl((size_t)nd.mV * nd.rV);
+          bd.push_back(hssk_basis_desc{nd.XV, nd.permV, Vd, nd.mV, nd.rV, nd.rV, nd.mV});
+          // Vh = [Vt1_0 Vd(0:rV0, :) ; Vt1_1 Vd(rV0:, :)]
+          g1.push_back(hssk_gemm_desc{a.Vt1, Vd, Vh[id], a.rU, nd.rV, a.rV, std::max(a.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+          g1.push_back(hssk_gemm_desc{b.Vt1, Vd + a.rV, Vh[id] + a.rU, b.rU, nd.rV, b.rV, std::max(b.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+          stats_.f_ulv += 2.0 * nd.rV * ((double)a.rU * a.rV + (double)b.rU * b.rV);
+        }
+      }
+    }
+    if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+    if (!g0.empty()) ck(hssk_gemm_vbatched(ctx_, g0.data(), (int)g0.size()));
+    if (!bd.empty()) ck(hssk_basis_dense(ctx_, bd.data(), (int)bd.size()));
+    if (!g1.empty()) ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
+    // ---- eliminate
+    std::vector<hssk_elem_desc> ge;
+    std::vector<hssk_gemm_desc> g2, g3;
+    std::vector<hssk_qr_desc> qr;
+    std::vector<hssk_lu_desc> lu;
+    for (int id : ids) {
+      Node& nd = nodes_[id];
+      if (nd.lvl == 0) {
+        const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+        nd.LU = Dh[id];
+        nd.piv = (int*)fact_->alloc(sizeof(int) * (std::max(mu, 1) + 1));
+        if (mu) lu.push_back(hssk_lu_desc{nd.LU, mu, mu, nd.piv, nd.piv + mu});
+        stats_.f_ulv += 2.0 / 3.0 * mu * (double)mu * mu;
+        continue;
+      }
+      const int m = nd.mU, r = nd.rU, rv = nd.rV;
+      if (m > r) {
+        // W1 = (P^T D)(0:r, :) ; W0^T = (P^T D)(r:, :)^T - W1^T X       (factor.hpp:109-118)
+        nd.W1 = fact_->dbl((size_t)std::max(r, 1) * m);
+        nd.Rlq = fact_->dbl((size_t)m * (m - r));
+        nd.Qt = fact_->dbl((size_t)m * m);
+        nd.Vt0 = fact_->dbl((size_t)(m - r) * std::max(rv, 1));
+        nd.Vt1 = fact_->dbl((size_t)std::max(r, 1) * std::max(rv, 1));
+        nd.Dt = fact_->dbl((size_t)std::max(r, 1) * std::max(r, 1));
+        if (r) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.W1, r, m, r, 0});
+        ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU + r, nullptr, 0, 0, nd.Rlq, m - r, m, m, 1});
+        if (r) g2.push_back(hssk_gemm_desc{nd.W1, nd.XU, nd.Rlq, m, m - r, r, r, r, m, 1, 0, -1.0, 1.0});
+        // LQ(W0) == QR(W0^T): Q~ (m x m) = Q^T, R~ = L^T                  (factor.hpp:122)
+        double* wk = tmp.dbl((size_t)2 * m);
+        qr.push_back(hssk_qr_desc{nd.Rlq, m, m, m - r, nd.Qt, m, m, nullptr, wk});
+        // Vt0 = Q0 Vh = Q~(:, :m-r)^T Vh ; Vt1 = Q~(:, m-r:)^T Vh ; Dt = W1 Q1^T = W1 Q~(:, m-r:)
+        if (rv) {
+          g3.push_back(hssk_gemm_desc{nd.Qt, Vh[id], nd.Vt0, m - r, rv, m, m, m, m - r, 1, 0, 1.0, 0.0});
+          if (r) g3.push_back(hssk_gemm_desc{nd.Qt + (size_t)(m - r) * m, Vh[id], nd.Vt1, r, rv, m, m, m, r, 1, 0, 1.0, 0.0});
+        }
+        if (r) g3.push_back(hssk_gemm_desc{nd.W1, nd.Qt + (size_t)(m - r) * m, nd.Dt, r, r, m, r, m, r, 0, 0, 1.0, 0.0});
+        const double k = m - r;
+        stats_.f_ulv += 2.0 * k * r * m + (2.0 * m * k * k - 2.0 / 3.0 * k * k * k) + (4.0 * m * m * k - 2.0 * m * k * k) / 1.0 * 0.5 + 2.0 * m * m * rv + 2.0 * r * (double)r * m;
+      } else {
+        // nothing to eliminate: Dt = P^T D, Vt1 = Vh   (factor.hpp:138-141)
+        nd.Dt = fact_->dbl((size_t)std::max(m, 1) * std::max(m, 1));
+        nd.Vt1 = Vh[id];
+        if (m) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.Dt, m, m, m, 0});
+      }
+    }
+    if (!ge.empty()) ck(hssk_gather_elems(ctx_, ge.data(), (int)ge.size()));
+    if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
+    if (!qr.empty()) ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+    if (!g3.empty()) ck(hssk_gemm_vbatched(ctx_, g3.data(), (int)g3.size()));
+    if (!lu.empty()) ck(hssk_getrf_vbatched(ctx_, lu.data(), (int)lu.size()));
+    ck(hssk_sync(ctx_));  // tmp released
+  }
+  factored_ = true;
+  stats_.t_factor = now() - t0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ULV solve (HSSMatrix.solve.hpp:69-238)
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
+  ensure_ready("solve");
+  if (!factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
+  if (nrhs <= 0 || n_ == 0) return;
+  double t0 = now();
+  Arena tmp(size_t(32) << 20);
+  const int N = n_;
+  double* db = b;
+  long long lb = ldb;
+  if (!on_device) {
+    db = tmp.dbl((size_t)N * nrhs);
+    ck(hssk_memcpy2d_h2d(ctx_, db, sizeof(double) * N, b, sizeof(double) * ldb, sizeof(double) * N, nrhs));
+    lb = N;
+  }
+  if (lb > 0x7fffffffLL) throw std::invalid_argument("solve: leading dimension too large");
+  const size_t nn = nodes_.size();
+  // f: assembled right-hand side of an inner node (mU rows; children write ft1 into it);
+  // y: (mU - rU) rows; zc: children's z stacked (mV rows); xb: solution in the node's basis (mU rows)
+  std::vector<double*> f(nn, nullptr), y(nn, nullptr), zc(nn, nullptr), xb(nn, nullptr);
+  for (size_t i = 0; i < nn; i++) {
+    const Node& nd = nodes_[i];
+    const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+    const int mv = nd.leaf() ? nd.m : nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+    if (!nd.leaf()) {
+      f[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
+      zc[i] = tmp.dbl((size_t)std::max(mv, 1) * nrhs);
+    }
+    if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
+    if (!nd.leaf()) xb[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
+  }
+  // ---- forward
+  for (size_t h = 0; h < by_height_.size(); h++) {
+    std::vector<hssk_gemm_desc> ga, gb, gc, gd, ge;
+    std::vector<hssk_rowgather_desc> rg;
+    std::vector<hssk_trsm_desc> ts;
+    std::vector<hssk_lusolve_desc> ls;
+    for (int id : by_height_[h]) {
+      const Node& nd = nodes_[id];
+      if (!nd.leaf()) {
+        const int ldf = std::max(nodes_[nd.c0].rU + nodes_[nd.c1].rU, 1);
+        const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+        // f0 = ft1_0 - B01 z_1 - W1_0 (Q0_0^T y_0) ; f1 likewise (solve.hpp:88-131); ft1 already in f
+        const int lz = std::max(a.rV + c.rV, 1);
+        ga.push_back(hssk_gemm_desc{nd.B01, zc[id] + a.rV, f[id], a.rU, nrhs, c.rV, std::max(a.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
+        ga.push_back(hssk_gemm_desc{nd.B10, zc[id], f[id] + a.rU, c.rU, nrhs, a.rV, std::max(c.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
+        const Node* ch[2] = {&a, &c};
+        const int cid[2] = {nd.c0, nd.c1};
+        for (int q = 0; q < 2; q++) {
+          const Node& cn = *ch[q];
+          const int mc = cn.mU, rc = cn.rU;
+          if (mc > rc && rc > 0) {
+            double* t = tmp.dbl((size_t)mc * nrhs);
+            // t = Q0^T y = Q~(:, :mc-rc) y ; f_q -= W1 t
+            gb.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], t, mc, nrhs, mc - rc, mc, mc - rc, mc, 0, 0, 1.0, 0.0});
+            gc.push_back(hssk_gemm_desc{cn.W1, t, f[id] + (q ? a.rU : 0), rc, nrhs, mc, rc, mc, ldf, 0, 0, -1.0, 1.0});
+          }
+        }
+      }
+    }
+    if (!ga.empty()) ck(hssk_gemm_vbatched(ctx_, ga.data(), (int)ga.size()));
+    if (!gb.empty()) ck(hssk_gemm_vbatched(ctx_, gb.data(), (int)gb.size()));
+    if (!gc.empty()) ck(hssk_gemm_vbatched(ctx_, gc.data(), (int)gc.size()));
+    for (int id : by_height_[h]) {
+      const Node& nd = nodes_[id];
+      const double* fsrc = nd.leaf() ? db + nd.lo : f[id];
+      const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+      const int ldf = nd.leaf() ? (int)lb : std::max(mu, 1);
+      if (nd.lvl == 0) {
+        // x = LU^{-1} f (solve.hpp:133-135)
+        if (nd.leaf()) { if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, db + nd.lo, mu, nrhs, mu, (int)lb}); }
+        else {
+          rg.push_back(hssk_rowgather_desc{f[id], xb[id], nullptr, mu, nrhs, ldf, std::max(mu, 1), 0, 0});
+          if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, xb[id], mu, nrhs, mu, std::max(mu, 1)});
+        }
+        continue;
+      }
+      const Node& pa = nodes_[nd.parent];
+      const int m = nd.mU, r = nd.rU;
+      double* ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+      const int ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+      double* z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+      const int ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+      // f <- P^T f ; ft1 = f(0:r) ; y = L^{-1} (f(r:) - E ft1)    (solve.hpp:153-163)
+      if (r) rg.push_back(hssk_rowgather_desc{fsrc, ft1, nd.permU, r, nrhs, ldf, ldp, 0, 0});
+      if (m > r) {
+        rg.push_back(hssk_rowgather_desc{fsrc, y[id], nd.permU + r, m - r, nrhs, ldf, m - r, 0, 0});
+        if (r) gd.push_back(hssk_gemm_desc{nd.XU, ft1, y[id], m - r, nrhs, r, r, ldp, m - r, 1, 0, -1.0, 1.0});
+        ts.push_back(hssk_trsm_desc{nd.Rlq, y[id], m - r, nrhs, m, m - r, 0, 1, 0});
+      }
+      // z = V^H [z0; z1] + Vt0^H y   (leaf: z = Vt0^H y)          (solve.hpp:164-192)
+      const int rv = nd.rV;
+      if (rv) {
+        double zbeta = 0.0;
+        if (!nd.leaf()) {
+          const int mv = nd.mV;
+          rg.push_back(hssk_rowgather_desc{zc[id], z, nd.permV, rv, nrhs, std::max(mv, 1), ldz, 0, 0});
+          if (mv > rv) {
+            double* t = tmp.dbl((size_t)(mv - rv) * nrhs);
+            rg.push_back(hssk_rowgather_desc{zc[id], t, nd.permV + rv, mv - rv, nrhs, std::max(mv, 1), mv - rv, 0, 0});
+            gd.push_back(hssk_gemm_desc{nd.XV, t, z, rv, nrhs, mv - rv, rv, mv - rv, ldz, 0, 0, 1.0, 1.0});
+          }
+          zbeta = 1.0;
+        }
+        if (m > r) ge.push_back(hssk_gemm_desc{nd.Vt0, y[id], z, rv, nrhs, m - r, m - r, m - r, ldz, 1, 0, 1.0, zbeta});
+        else if (nd.leaf()) ge.push_back(hssk_gemm_desc{nd.Vt0, y[id], z, rv, nrhs, 0, 1, 1, ldz, 1, 0, 1.0, 0.0});  // z = 0
+      }
+    }
+    if (!rg.empty()) ck(hssk_gather_rows(ctx_, rg.data(), (int)rg.size()));
+    if (!gd.empty()) ck(hssk_gemm_vbatched(ctx_, gd.data(), (int)gd.size()));
+    if (!ts.empty()) ck(hssk_trsm_vbatched(ctx_, ts.data(), (int)ts.size()));
+    if (!ge.empty()) ck(hssk_gemm_vbatched(ctx_, ge.data(), (int)ge.size()));
+    if (!ls.empty()) ck(hssk_getrs_vbatched(ctx_, ls.data(), (int)ls.size()));
+  }
+  // ---- backward (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
+  for (size_t dpt = 0; dpt < by_depth_.size(); dpt++) {
+    std::vector<hssk_gemm_desc> g1, g2;
+    std::vector<hssk_rowgather_desc> cp;
+    for (int id : by_depth_[dpt]) {
+      const Node& nd = nodes_[id];
+      if (nd.leaf()) continue;
+      const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+      const int mu = a.rU + c.rU;
+      const double* x = xb[id];
+      const int ldx = std::max(mu, 1);
+      const Node* ch[2] = {&a, &c};
+      const int cid[2] = {nd.c0, nd.c1};
+      for (int q = 0; q < 2; q++) {
+        const Node& cn = *ch[q];
+        const int mc = cn.mU, rc = cn.rU;
+        const double* xpart = x + (q ? a.rU : 0);
+        double* out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+        const int ldo = cn.leaf() ? (int)lb : std::max(mc, 1);
+        if (mc > rc) {
+          g1.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], out, mc, nrhs, mc - rc, mc, mc - rc, ldo, 0, 0, 1.0, 0.0});
+          if (rc) g2.push_back(hssk_gemm_desc{cn.Qt + (size_t)(mc - rc) * mc, xpart, out, mc, nrhs, rc, mc, ldx, ldo, 0, 0, 1.0, 1.0});
+        } else if (mc) {
+          cp.push_back(hssk_rowgather_desc{xpart, out, nullptr, mc, nrhs, ldx, ldo, 0, 0});
+        }
+      }
+    }
+    if (!g1.empty()) ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
+    if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
+    if (!cp.empty()) ck(hssk_gather_rows(ctx_, cp.data(), (int)cp.size()));
+  }
+  if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
+  ck(hssk_sync(ctx_));
+  stats_.t_solve = now() - t0;
+  {
+    double fs = 0;
+    for (auto& nd : nodes_) {
+      if (nd.lvl == 0) { const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU; fs += 2.0 * mu * (double)mu; continue; }
+      const double m = nd.mU, r = nd.rU, k = m - r, rv = nd.rV;
+      fs += 2.0 * k * r + k * k + 2.0 * k * rv + 2.0 * m * m + 2.0 * k * m;
+      if (!nd.leaf()) fs += 4.0 * nodes_[nd.c0].rU * (double)nodes_[nd.c1].rV;
+    }
+    stats_.f_solve = fs * nrhs;
+  }
+}
+
+}  // namespace HSS
+}  // namespace strumpack

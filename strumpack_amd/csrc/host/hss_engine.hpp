@@ -1,0 +1,144 @@
+// DeviceHSS: the MI355X-resident HSS matrix and the level-synchronous orchestration of the hot
+// path -- randomized compression, hierarchical apply, ULV factorization and solve -- over the
+// hand-written HIP kernels of include/hssk.h (one variable-size batched launch per step and tree
+// height).  strumpack::HSS::HSSMatrix<double> (HSSMatrix.hpp) is the reference-shaped facade on top.
+//
+// Data layout in HBM
+//  * the tree is flattened on the host (pre-order node table, lists by height / depth); every node
+//    owns device blocks carved from bump arenas: D (leaf, m x m), B01 / B10 (coupling), the
+//    interpolative bases as X = R11^{-1} R12 (rank x (rows-rank), E = X^T) plus a 0-based row
+//    permutation, and the ULV factors (Q~ = Q^T, R~ = L^T, W1, Vt0; root LU);
+//  * the random samples are kept TRANSPOSED: Rt, Srt, Sct are (dcap x N) column-major, so the
+//    samples of node [lo, lo+m) form one contiguous d x m panel, the operand layout that the sketch
+//    GEMM, the per-node GEMMs and the column-pivoted QR of the ID all read contiguously.
+#pragma once
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ClusterTree.hpp"
+#include "hssk.h"
+
+namespace strumpack {
+namespace HSS {
+
+struct EngineOptions {
+  double rel_tol = 1e-2, abs_tol = 1e-8;
+  int leaf_size = 512, max_rank = 50000, d0 = 128, dd = 64, p = 10;
+  int algorithm = 1;      // 0 original, 1 stable, 2 hard restart (treated as stable)
+  int random_engine = 0;  // 0 minstd_rand, 1 mt19937 (host, reference-identical), 2 philox (device)
+  int random_dist = 0;    // 0 normal, 1 uniform
+  bool verbose = false;
+  int device = 0;
+};
+
+// host callbacks of the matrix-free / element interfaces (column-major host buffers)
+using host_mult_t = std::function<void(char trans, int n, int nrhs, const double* R, int ldr, double* S, int lds)>;
+using host_elem_t = std::function<void(int m, const int* I, int n, const int* J, double* B, int ldb)>;
+
+struct PhaseStats {
+  double t_compress = 0, t_sketch = 0, t_random = 0, t_tree = 0, t_factor = 0, t_solve = 0, t_mult = 0;
+  double sketch_kernel_ms = 0;  // sum of HIP-event durations of the sketch GEMM launches
+  int sketch_launches = 0, rounds = 0, d_final = 0;
+  // algorithmic flop model
+  double f_sketch = 0, f_local = 0, f_reduce = 0, f_id = 0, f_ortho = 0, f_ulv = 0, f_solve = 0;
+};
+
+class Arena;
+struct HostRng;
+
+class DeviceHSS {
+ public:
+  DeviceHSS(int n, const EngineOptions& opts, const structured::ClusterTree* tree = nullptr);
+  ~DeviceHSS();
+  DeviceHSS(const DeviceHSS&) = delete;
+  DeviceHSS& operator=(const DeviceHSS&) = delete;
+
+  // ---- construction (compression) ----
+  void compress_dense_device(const double* dA, long long lda);       // A resident in HBM
+  void compress_dense_host(const double* A, long long lda);          // uploads A, then the above
+  void compress_callbacks(const host_mult_t& mult, const host_elem_t& elem);  // matrix-free
+
+  // ---- operations; x/b/y are column-major, host or device (on_device) ----
+  void mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
+            bool on_device, double beta = 0.0);
+  void factor();
+  void solve(int nrhs, double* b, long long ldb, bool on_device);
+  void shift(double sigma);
+
+  // ---- introspection ----
+  int rows() const { return n_; }
+  bool is_compressed() const;
+  bool is_factored() const { return factored_; }
+  int levels() const;
+  int rank() const;
+  long long memory() const;    // bytes of the compressed representation
+  long long nonzeros() const;  // stored scalars + permutation entries
+  long long factor_memory() const;
+  int num_nodes() const { return (int)nodes_.size(); }
+  // pre-order node table, 6 ints per node: row_offset, rows, U_rows, U_rank, V_rank, is_leaf
+  void node_info(int* out) const;
+  const PhaseStats& stats() const { return stats_; }
+  hssk_ctx* ctx() const { return ctx_; }
+
+  struct Node {
+    int lo = 0, m = 0, lvl = 0, height = 0, c0 = -1, c1 = -1, parent = -1;
+    int Ustate = 0, Vstate = 0;  // 0 untouched, 1 partially compressed, 2 compressed
+    int rU = 0, rV = 0, mU = 0, mV = 0;
+    // compressed representation (device)
+    double *D = nullptr, *B01 = nullptr, *B10 = nullptr, *XU = nullptr, *XV = nullptr;
+    int *permU = nullptr, *permV = nullptr, *dIr = nullptr, *dIc = nullptr;
+    std::vector<int> hpermU, hpermV, Ir, Ic;
+    // compression workspace (device, transposed sample panels)
+    double *Srt = nullptr, *Sct = nullptr, *Rrt = nullptr, *Rct = nullptr, *RrtRed = nullptr, *RctRed = nullptr;
+    double *Qr = nullptr, *Qc = nullptr;  // orthogonal bases of the stable stopping test (mU x dcap)
+    double Ur_max = 0, Vr_max = 0;
+    bool panels = false;
+    // ULV factors (device)
+    double *Qt = nullptr, *Rlq = nullptr, *W1 = nullptr, *Vt0 = nullptr, *Dt = nullptr, *Vt1 = nullptr;
+    double* LU = nullptr;
+    int* piv = nullptr;
+    bool leaf() const { return c0 < 0; }
+    bool compressed() const { return Ustate == 2 && Vstate == 2; }
+    bool untouched() const { return Ustate == 0 && Vstate == 0; }
+  };
+  const std::vector<Node>& nodes() const { return nodes_; }
+
+ private:
+  struct Source;
+  struct DenseDeviceSource;
+  struct CallbackSource;
+
+  void build_tree(const structured::ClusterTree* tree);
+  void compress(Source& src);
+  bool compress_attempt(Source& src, int dcap);
+  void reset_compression();
+  void fill_random(int r0, int dn);
+  void process_level(Source& src, const std::vector<int>& ids, int d, int dd, bool original);
+  void extract_blocks(Source& src, const std::vector<int>& ids);
+  void local_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
+  void reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
+  void run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot);
+  void ortho_test(const std::vector<int>& ids, const std::vector<int>& which, int d, int dd,
+                  std::vector<char>& resolved);
+  void free_compress_workspace();
+  void ensure_ready(const char* what) const;
+
+  int n_;
+  EngineOptions o_;
+  hssk_ctx* ctx_ = nullptr;
+  std::vector<Node> nodes_;
+  std::vector<std::vector<int>> by_height_, by_depth_;
+  std::unique_ptr<Arena> persist_, work_, fact_;
+  // global transposed sample arrays (dcap x N)
+  double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;
+  int dcap_ = 0;
+  int* d_ranks_ = nullptr;
+  bool factored_ = false;
+  PhaseStats stats_;
+  std::shared_ptr<HostRng> rng_;
+};
+
+}  // namespace HSS
+}  // namespace strumpack

@@ -64,6 +64,32 @@ int hssk_memcpy_d2h(hssk_ctx* c, void* dst, const void* src, long long bytes) {
   HSSK_API_END
 }
 
+int hssk_memcpy_d2d(hssk_ctx* c, void* dst, const void* src, long long bytes) {
+  HSSK_API_BEGIN
+  hssk_rt::d2d(dst, src, (size_t)bytes, c->stream);
+  HSSK_API_END
+}
+int hssk_memcpy2d_h2d(hssk_ctx* c, void* dst, long long dpitch, const void* src, long long spitch,
+                      long long width, long long height) {
+  HSSK_API_BEGIN
+  hssk_rt::h2d_2d(dst, (size_t)dpitch, src, (size_t)spitch, (size_t)width, (size_t)height, c->stream);
+  hssk_rt::sync(c->stream);
+  HSSK_API_END
+}
+int hssk_memcpy2d_d2h(hssk_ctx* c, void* dst, long long dpitch, const void* src, long long spitch,
+                      long long width, long long height) {
+  HSSK_API_BEGIN
+  hssk_rt::d2h_2d(dst, (size_t)dpitch, src, (size_t)spitch, (size_t)width, (size_t)height, c->stream);
+  hssk_rt::sync(c->stream);
+  HSSK_API_END
+}
+int hssk_memset_zero(hssk_ctx* c, void* dst, long long bytes) {
+  HSSK_API_BEGIN
+  hssk_rt::memset_async(dst, 0, (size_t)bytes, c->stream);
+  HSSK_API_END
+}
+int hssk_is_device_pointer(const void* p) { return hssk_rt::is_device_pointer(p) ? 1 : 0; }
+
 float hssk_last_dgemm_ms(hssk_ctx* c) {
   if (!c->dgemm_timed) return -1.f;
   try { return hssk_rt::event_elapsed_ms(c->ev0, c->ev1); } catch (...) { return -1.f; }

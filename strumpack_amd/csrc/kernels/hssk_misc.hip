@@ -154,6 +154,16 @@ __global__ void sumsq_kernel(const hssk_norm_desc* __restrict__ descs) {
   if (threadIdx.x == 0) *p.out = part[0] + part[1] + part[2] + part[3];
 }
 
+// dense interpolative basis: out(perm[k], :) = row k of [I; X^T]
+__global__ void basis_dense_kernel(const hssk_basis_desc* __restrict__ descs) {
+  const hssk_basis_desc p = descs[blockIdx.x];
+  for (int e = threadIdx.x; e < p.m * p.r; e += blockDim.x) {
+    int k = e % p.m, j = e / p.m;
+    double v = (k < p.r) ? (k == j ? 1. : 0.) : p.X[j + (size_t)(k - p.r) * p.ldx];
+    p.out[p.perm[k] + (size_t)j * p.ldo] = v;
+  }
+}
+
 __global__ void shift_diag_kernel(const hssk_shift_desc* __restrict__ descs, double sigma) {
   const hssk_shift_desc p = descs[blockIdx.x];
   for (int i = threadIdx.x; i < p.n; i += blockDim.x) p.A[i + (size_t)i * p.lda] += sigma;
@@ -259,6 +269,15 @@ int hssk_sumsq_vbatched(hssk_ctx* ctx, const hssk_norm_desc* descs, int count) {
   if (count <= 0) return 0;
   auto* dd = (const hssk_norm_desc*)ctx->stage(descs, sizeof(*descs) * count);
   HSSK_LAUNCH(sumsq_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_basis_dense(hssk_ctx* ctx, const hssk_basis_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_basis_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(basis_dense_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd);
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -1,0 +1,68 @@
+"""GPU parity tests of the hand-written HIP kernels (product library) through the hssk C-ABI, at
+sizes representative of the HSS levels of BASELINE.json's configs."""
+import numpy as np
+import pytest
+
+import kernel_cases as KC
+from strumpack_amd import _loader
+from strumpack_amd import hssk as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hk():
+    h = K.Hssk(_loader.lib_path())
+    yield h
+    h.close()
+
+
+def test_gemm_vbatched_ragged(hk):
+    KC.case_gemm_vbatched(hk, [(5, 7, 3, 0, 0, 1.0, 0.0), (70, 33, 20, 0, 1, -1.0, 1.0),
+                               (16, 130, 17, 1, 0, 2.0, 0.5), (65, 65, 65, 1, 1, 1.0, 0.0),
+                               (3, 4, 0, 0, 0, 1.0, 2.0), (0, 4, 3, 0, 0, 1.0, 0.0)])
+
+
+def test_gemm_vbatched_hss_level_shapes(hk):
+    # leaf sample update 192 x 390 x 390, inner 192 x 31 x 28, reduce 192 x 16 x 240, ULV shapes
+    shapes = [(192, 390, 390, 0, 1, -1.0, 1.0)] * 8 + [(192, 31, 28, 0, 1, -1.0, 1.0)] * 16 + \
+             [(192, 16, 240, 0, 0, 1.0, 1.0)] * 8 + [(350, 390, 40, 1, 0, -1.0, 1.0), (40, 40, 390, 0, 1, 1.0, 0.0),
+                                                     (256, 1, 256, 0, 0, 1.0, 0.0), (256, 64, 256, 1, 0, 1.0, 0.0)]
+    KC.case_gemm_vbatched(hk, shapes, seed=11)
+
+
+@pytest.mark.parametrize("m,n,k,tb", [(192, 4096, 4096, 1), (192, 4096, 4096, 0), (64, 1000, 3001, 1),
+                                      (130, 777, 2050, 0), (200, 65, 50, 0), (16, 64, 16, 1)])
+def test_dgemm(hk, m, n, k, tb):
+    KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
+
+
+def test_generators(hk):
+    KC.case_toeplitz_randn(hk, n=700)
+
+
+def test_gathers(hk):
+    KC.case_gathers(hk)
+
+
+def test_id(hk):
+    KC.case_id(hk, [(24, 40, 1e-6, 1e-12, 1000, 7), (24, 16, 1e-10, 1e-14, 1000, None),
+                    (12, 30, 1.0, 1e-10, 1000, None), (24, 40, 1e-8, 1e-12, 5, 9),
+                    (70, 20, 1e-4, 1e-10, 1000, 4), (8, 1, 1e-4, 1e-10, 1000, None)])
+    KC.case_id(hk, [(192, 390, 1e-4, 1e-10, 50000, 40)] * 6 + [(192, 256, 1e-8, 1e-12, 50000, 60)] * 4 +
+               [(192, 54, 1e-4, 1e-10, 50000, 30)] * 8 + [(192, 300, 1e-13, 1e-15, 50000, None)], seed=21)
+
+
+def test_qr(hk):
+    KC.case_qr(hk, [(40, 12, 12), (30, 30, 30), (33, 20, 33), (10, 1, 10), (70, 10, 0)])
+    KC.case_qr(hk, [(390, 350, 390), (390, 128, 128), (256, 240, 256), (54, 24, 54)] * 2, seed=23)
+
+
+def test_trsm_lu(hk):
+    KC.case_trsm_lu(hk)
+
+
+def test_mfma_peak_probe(hk):
+    tf = hk.lib.hssk_mfma_f64_peak_tflops(hk.ctx, 20000)
+    print("FP64 MFMA probe: %.1f TFLOP/s" % tf)
+    assert tf > 20.0
