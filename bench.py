@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline workload on MI355X.
+
+One "step" = one full pass of the HSS hot path on BASELINE.json's headline configuration
+(configs[2]): randomized HSS compression + ULV factorization + ULV solve of the 100000 x 100000
+double-precision Toeplitz matrix A(i,j) = 1/(1+|i-j|) (test/test_HSS_seq.cpp:75-78), leaf 256,
+rel_tol 1e-4, d0+dd = 128+64 samples, matrix A already resident in HBM when the clock starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line (rank 0).  `value` = algorithmic GFLOP/s of compress+factor+solve (flop model of
+SURVEY.md section 8(d): 4 N^2 d for the sketch + the per-node terms) over the max-over-ranks step
+time.  `roofline` describes the dominant kernel (the sketch DGEMM, FP64 MFMA bound) with the launch
+duration measured by HIP events on the launch stream; `cpu_baseline` is the reference's own CPU HSS
+(oracle/_ref, built from /root/reference by oracle/ref/Makefile) timed on this host on a bounded
+sample (N = 16384, same options) -- the only place anything under oracle/ is used here.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # gfx950 FP64 matrix peak (MI355X spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=100000)
+    p.add_argument("--leaf", type=int, default=256)
+    p.add_argument("--rel-tol", type=float, default=1e-4)
+    p.add_argument("--nrhs", type=int, default=1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-n", type=int, default=16384)
+    return p.parse_args()
+
+
+def cpu_baseline(n, leaf, rel_tol):
+    """Reference CPU HSS (oracle/_ref) on a bounded sample of the same workload."""
+    try:
+        from oracle import ref_lib as R
+        if not R.available():
+            raise RuntimeError("oracle/_ref not built")
+        r = R.bench_toeplitz(n, leaf=leaf, rel_tol=rel_tol, abs_tol=1e-8, nrhs=1)
+        fl = R.flops(reset=True)
+        # same flop model as the GPU number: 4 N^2 d for the sketch + the reference's own counters
+        flops = 4.0 * n * n * 192 + fl["update_sample"] + fl["reduce_sample"] + fl["ID"] + fl["QR"] + \
+            fl["ortho"] + fl["ULV_factor"] + fl["hss_solve"]
+        t = r["compress_s"] + r["factor_s"] + r["solve_s"]
+        return dict(value=flops / t * 1e-9, unit="GFLOP/s", cores=os.cpu_count(), kind="reference",
+                    sample="STRUMPACK v8.0.0 CPU HSS (MKL, OpenMP), Toeplitz N=%d leaf=%d rel_tol=%g: compress %.3fs "
+                           "factor %.3fs solve %.4fs, rank %d" % (n, leaf, rel_tol, r["compress_s"], r["factor_s"],
+                                                                   r["solve_s"], r["rank"]))
+    except Exception as e:  # reference library unavailable on this host: time the numpy/LAPACK port instead
+        import numpy as np
+        from oracle import hss_oracle as O
+        n = min(n, 8192)
+        A = O.toeplitz(n)
+        t0 = time.time()
+        H = O.HSSMatrix(A, O.Options(rel_tol=rel_tol, abs_tol=1e-8, leaf_size=leaf), rgen=type(
+            "G", (), {"matrix": staticmethod(lambda r, c: np.asfortranarray(np.random.default_rng(0).standard_normal((r, c))))})())
+        H.factor()
+        H.solve(np.ones(n))
+        t = time.time() - t0
+        return dict(value=4.0 * n * n * 192 / t * 1e-9, unit="GFLOP/s", cores=os.cpu_count(), kind="port",
+                    sample="numpy/LAPACK oracle, Toeplitz N=%d (reference library unavailable: %s)" % (n, e))
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    os.environ["STRUMPACK_AMD_DEVICE"] = str(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from strumpack_amd import _loader, capi, dist as sdist
+    from strumpack_amd import hssk as K
+    L = capi.load(_loader.lib_path())
+    hk = K.Hssk(_loader.lib_path(), device=local)
+    n = a.n
+
+    # ---- inputs resident in HBM before the clock starts: dense A (column-major) and the rhs
+    dA = hk.empty((n, n))
+    hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
+    dB = hk.empty((n, a.nrhs))
+    dX = hk.empty((n, a.nrhs))
+    hk.check(hk.lib.hssk_randn(hk.ctx, dB.ptr, n, a.nrhs, n, 0, a.nrhs, 7))
+    hk.sync()
+    opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox")
+    exch = sdist.make_exchange(L, world, rank) if world > 1 else None
+
+    def step():
+        H = sdist.from_dense_device(L, dA.ptr, n, n, opts, hopts, exch)
+        H.factor()
+        hk.check(hk.lib.hssk_memcpy_d2d(hk.ctx, dX.ptr, dB.ptr, 8 * n * a.nrhs))
+        hk.sync()
+        H.solve_device(dX.ptr, a.nrhs)
+        return H
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    H = None
+    for _ in range(a.warmup):
+        if H is not None:
+            H.destroy()
+        H = step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(a.steps):
+        if H is not None:
+            H.destroy()
+        H = step()
+        stats.append(H.stats())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+
+    # ---- correctness gates reported with the number
+    import numpy as np
+    Xh = dX.get()
+    Bh = dB.get()
+    HX = H.mult(Xh)
+    resid = float(np.linalg.norm(HX - Bh) / np.linalg.norm(Bh))
+    rng = np.random.default_rng(0)
+    cols = rng.integers(0, n, 8)
+    E = np.zeros((n, 8))
+    E[cols, np.arange(8)] = 1.0
+    i = np.arange(n)
+    Ac = 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :]))
+    comp_err = float(np.linalg.norm(H.mult(E) - Ac) / np.linalg.norm(Ac))
+    ax_resid = float(np.linalg.norm(Ac.T @ Xh[:, 0] - Bh[cols, 0]) / np.linalg.norm(Bh[cols, 0]))
+
+    st = stats[-1]
+    f_total = st["f_sketch"] + st["f_local"] + st["f_reduce"] + st["f_id"] + st["f_ortho"] + st["f_ulv"] + st["f_solve"]
+    value = f_total / (ms_per_step * 1e-3) * 1e-9
+    # dominant kernel: the sketch DGEMM.  Algorithmic flops per launch = 2 d N^2 (4 N^2 d
+    # for the Sr and Sc launches together), per-rank share when the sketch is sharded.
+    d = int(st["d_final"])
+    launches = max(st["sketch_launches"], 1)
+    avg_ms = st["sketch_kernel_ms"] / launches
+    flops_per_launch = st["f_sketch"] / launches / world
+    ach = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tf) and n == 100000 and world == 1:
+        traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+    out = {
+        "metric": "hss_compress_ulv_factor_solve_gflops", "value": value, "unit": "GFLOP/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %dx%d double Toeplitz HSS, randomized compression "
+                               "(d0+dd=128+64, Philox samples), leaf=%d, rel_tol=%g, compress + ULV factor + solve (nrhs=%d)"
+                               % (n, n, a.leaf, a.rel_tol, a.nrhs),
+                   "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
+                   "parallelism": "1 GPU" if world == 1 else "sketch sharded over %d GPUs (RCCL all-gather), tree replicated" % world},
+        "phases_s": {"compress": st["t_compress"], "sketch": st["t_sketch"], "random": st["t_random"],
+                     "tree": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
+        "flops": {"sketch": st["f_sketch"], "local": st["f_local"], "reduce": st["f_reduce"], "id": st["f_id"],
+                  "ortho": st["f_ortho"], "ulv": st["f_ulv"], "solve": st["f_solve"]},
+        "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "rounds": int(st["rounds"]), "d": d},
+        "checks": {"solve_resid_H": resid, "compress_err_sampled": comp_err, "Ax_minus_b_sampled": ax_resid},
+        "roofline": {"kernel": "dgemm_kernel<192> (sketch S^T = R^T op(A), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                     "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches},
+    }
+    if rank == 0:
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.leaf, a.rel_tol)
+        elif not a.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    H.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,14 @@ int SPX_d_struct_from_dense_hss(CSPStructMat* S, int rows, int cols, const doubl
 /* A is a DEVICE pointer (column-major, ldA); nothing is copied, A is borrowed for the call */
 int SPX_d_struct_from_dense_device(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                    const CSPOptions* opts, const SPXHSSOptions* h);
+/* one process per GPU: this rank computes the sample columns of its shard, then calls
+ * exchange(user, dSrt, dSct, ld, cols_per_rank): an in-place all-gather of the equally sized, contiguous
+ * column blocks (ld * cols_per_rank doubles per rank, rank r at offset r * ld * cols_per_rank) of both
+ * device arrays -- RCCL over xGMI in production (strumpack_amd/dist.py), gloo in the CPU tests */
+typedef void (*SPXExchangeFn)(void* user, double* dSrt, double* dSct, long long ld, long long cols_per_rank);
+int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
+                                           const CSPOptions* opts, const SPXHSSOptions* h, int world, int rank,
+                                           SPXExchangeFn exchange, void* user);
 int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB,
                              double* dC, long long ldC);
 int SPX_d_struct_solve_device(const CSPStructMat S, int nrhs, double* dB, long long ldB);

@@ -133,6 +133,21 @@ int SPX_d_struct_from_dense_device(CSPStructMat* S, int rows, int cols, const do
   *S = s.release();
   SP_CATCH
 }
+int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
+                                           const CSPOptions* opts, const SPXHSSOptions* h, int world, int rank,
+                                           SPXExchangeFn exchange, void* user) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("sharded construction requires type SP_TYPE_HSS");
+  if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
+  if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("invalid world/rank");
+  auto ho = get_hss_options(opts, h);
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(rows, cols, ho));
+  H->compress_device_sharded(dA, ldA, ho, world, rank, exchange, user);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
 int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB, double* dC, long long ldC) {
   SP_TRY
   if (!hss(S)) throw std::invalid_argument("not an HSS matrix");

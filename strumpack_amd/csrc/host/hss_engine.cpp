@@ -105,15 +105,26 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
   DenseDeviceSource(const double* a, long long l) : dA(a), lda(l) {}
   void sample(DeviceHSS& H, int r0, int dn) override {
     const long long N = H.n_;
-    // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout
-    ck(hssk_dgemm(H.ctx_, 1, dn, N, N, 1.0, H.Rt_ + r0, H.dcap_, dA, lda, 0.0, H.Srt_ + r0, H.dcap_));
-    ck(hssk_sync(H.ctx_));
-    float ms = hssk_last_dgemm_ms(H.ctx_);
-    if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
-    ck(hssk_dgemm(H.ctx_, 0, dn, N, N, 1.0, H.Rt_ + r0, H.dcap_, dA, lda, 0.0, H.Sct_ + r0, H.dcap_));
-    ck(hssk_sync(H.ctx_));
-    ms = hssk_last_dgemm_ms(H.ctx_);
-    if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+    // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout.
+    // Multi-GPU: this rank computes the sample columns [j0, j1) only (rows j0:j1 of A for Sr,
+    // columns j0:j1 of A for Sc); the blocks are then all-gathered (RCCL) by the exchange hook.
+    long long j0 = 0, j1 = N;
+    if (H.o_.world > 1) { j0 = std::min(N, H.cols_per_rank_ * H.o_.rank); j1 = std::min(N, j0 + H.cols_per_rank_); }
+    const long long nloc = j1 - j0;
+    if (nloc > 0) {
+      ck(hssk_dgemm(H.ctx_, 1, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0, lda, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
+      ck(hssk_sync(H.ctx_));
+      float ms = hssk_last_dgemm_ms(H.ctx_);
+      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+      ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0 * lda, lda, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
+      ck(hssk_sync(H.ctx_));
+      ms = hssk_last_dgemm_ms(H.ctx_);
+      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+    }
+    if (H.o_.world > 1) {
+      if (!H.o_.exchange) throw std::logic_error("multi-GPU compression needs an exchange hook");
+      H.o_.exchange(H.o_.exchange_user, H.Srt_, H.Sct_, H.dcap_, H.cols_per_rank_);
+    }
   }
   void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
     std::vector<hssk_elem_desc> d;
@@ -332,9 +343,13 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
   reset_compression();
   dcap_ = dcap;
   const size_t N = n_;
+  // sample arrays; with several GPUs the column count is padded to world * cols_per_rank so that
+  // every rank's shard is one contiguous, equally sized block (in-place all-gather)
+  cols_per_rank_ = o_.world > 1 ? ((long long)N + o_.world - 1) / o_.world : (long long)N;
+  const size_t Npad = o_.world > 1 ? (size_t)cols_per_rank_ * o_.world : N;
   Rt_ = work_->dbl((size_t)dcap * N);
-  Srt_ = work_->dbl((size_t)dcap * N);
-  Sct_ = work_->dbl((size_t)dcap * N);
+  Srt_ = work_->dbl((size_t)dcap * Npad);
+  Sct_ = work_->dbl((size_t)dcap * Npad);
   stats_.rounds = 0;
   stats_.f_sketch = stats_.f_local = stats_.f_reduce = stats_.f_id = stats_.f_ortho = 0;
   const bool original = (o_.algorithm == 0);

@@ -31,6 +31,11 @@ struct EngineOptions {
   int random_dist = 0;    // 0 normal, 1 uniform
   bool verbose = false;
   int device = 0;
+  // multi-GPU: the sketch columns are sharded over `world` ranks (one process per GPU); after each
+  // sketch the column blocks are all-gathered through `exchange` (RCCL, provided by the caller)
+  int world = 1, rank = 0;
+  void (*exchange)(void* user, double* dSrt, double* dSct, long long ld, long long cols_per_rank) = nullptr;
+  void* exchange_user = nullptr;
 };
 
 // host callbacks of the matrix-free / element interfaces (column-major host buffers)
@@ -134,6 +139,7 @@ class DeviceHSS {
   // global transposed sample arrays (dcap x N)
   double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;
   int dcap_ = 0;
+  long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
   int* d_ranks_ = nullptr;
   bool factored_ = false;
   PhaseStats stats_;

@@ -1,0 +1,52 @@
+"""CPU: the product library (hipcc, gfx950) loads and exports every symbol that include/*.h
+declares -- no compute calls (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from strumpack_amd import _loader, capi, hssk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:hssk|SP_d_struct|SPX_d_struct)_\w+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_loader.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return ctypes.CDLL(_loader.lib_path())
+
+
+def test_hssk_symbols(lib):
+    names = declared("hssk.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hssk.h but not exported"
+    assert set(hssk.HSSK_SYMBOLS) <= set(names)
+
+
+def test_structured_c_api_symbols(lib):
+    names = declared(os.path.join("structured", "StructuredMatrix.h"))
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared but not exported"
+    assert set(capi.SP_SYMBOLS) <= set(names)
+
+
+def test_no_cpu_fallback(lib):
+    """Creating a context without a HIP device must fail loudly (no silent CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = ctypes.c_void_p()
+    lib.hssk_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    lib.hssk_last_error.restype = ctypes.c_char_p
+    assert lib.hssk_ctx_create(ctypes.byref(ctx), 0) != 0
+    assert b"no HIP device" in lib.hssk_last_error() or b"HIP error" in lib.hssk_last_error()

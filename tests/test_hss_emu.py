@@ -1,0 +1,26 @@
+"""CPU tests of the host engine + kernel sources on the fiber emulator (tests/emu): the whole
+compress -> mult -> factor -> solve path through the C interface, against the reference's fixtures
+and the oracle, at sizes the emulator finishes in seconds.  The GPU twin is tests/test_hss_gpu.py."""
+import pytest
+
+import emu_lib
+import hss_cases as HC
+from strumpack_amd import capi
+
+CASES = HC.golden_cases()
+SMALL = ["HSS_seq_1", "HSS_seq_3", "HSS_seq_6", "HSS_seq_8", "HSS_seq_9", "HSS_seq_10", "HSS_seq_11",
+         "HSS_seq_14", "HSS_seq_15", "HSS_seq_17", "HSS_seq_20", "HSS_seq_2"]
+
+
+@pytest.fixture(scope="module")
+def L():
+    return capi.load(emu_lib.build())
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_ctest_case(L, name):
+    HC.check_against_golden(L, CASES[name])
+
+
+def test_api_semantics(L):
+    HC.check_api_semantics(L)
