@@ -85,7 +85,9 @@ HSSK_SYMBOLS = [
     "hssk_fill_toeplitz", "hssk_randn", "hssk_dgemm", "hssk_gemm_vbatched", "hssk_gather_cols",
     "hssk_gather_rows", "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched",
     "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
-    "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops",
+    "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops", "hssk_memcpy_d2d",
+    "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
+    "hssk_basis_dense",
 ]
 
 
@@ -146,6 +148,12 @@ class Hssk:
         L.hssk_sync.argtypes = [C.c_void_p]
         L.hssk_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         L.hssk_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.hssk_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.hssk_memset_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+        for f in ("hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                      C.c_longlong, C.c_longlong]
+        L.hssk_is_device_pointer.argtypes = [C.c_void_p]
         L.hssk_last_dgemm_ms.restype = C.c_float
         L.hssk_last_dgemm_ms.argtypes = [C.c_void_p]
         L.hssk_fill_toeplitz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_char]
