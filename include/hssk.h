@@ -201,6 +201,9 @@ int hssk_shift_diag(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, doub
 /* peak-rate probe: runs a dependent-free v_mfma_f64_16x16x4_f64 loop on every CU and returns the
  * measured TFLOP/s (used by bench.py to confirm the FP64 matrix roof on the box) */
 double hssk_mfma_f64_peak_tflops(hssk_ctx* ctx, int iters);
+/* detailed probe: waves_per_simd in {1,2,4,8}, zero_data != 0 feeds zeros (DVFS check).
+ * out[0] TFLOP/s, out[1] shader cycles per MFMA per wave, out[2] effective shader clock in GHz */
+int hssk_mfma_f64_probe(hssk_ctx* ctx, int iters, int waves_per_simd, int zero_data, double* out);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 #define HSSK_WAVE 64
 
 typedef double hssk_d4 __attribute__((ext_vector_type(4)));
+typedef double hssk_d2 __attribute__((ext_vector_type(2)));
 
 // D(16x16) += A(16x4) * B(4x16), FP64 matrix core (v_mfma_f64_16x16x4_f64).
 // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
@@ -32,6 +33,10 @@ __device__ __forceinline__ double hssk_wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, hssk_shfl_xor(v, o));
   return v;
 }
+
+// shader-clock and constant-rate (100 MHz) counters, for the peak probe
+__device__ __forceinline__ long long hssk_clock() { return (long long)__builtin_readcyclecounter(); }
+__device__ __forceinline__ long long hssk_wallclock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 
 #define HSSK_SHARED __shared__
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]

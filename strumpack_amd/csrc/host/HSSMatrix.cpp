@@ -28,7 +28,12 @@ HSSMatrix<double>::HSSMatrix(const structured::ClusterTree& t, const opts_t& opt
 HSSMatrix<double>::~HSSMatrix() {}
 
 void HSSMatrix<double>::make_engine(const opts_t& opts, const structured::ClusterTree* t) {
-  eng_.reset(new DeviceHSS(int(rows_), engine_options(opts), t));
+  EngineOptions e = engine_options(opts);
+  if (eng_ && eng_->options().leaf_size == e.leaf_size && eng_->options().device == e.device) {
+    eng_->set_options(e);  // same tree: keep the engine (and its device context), new knobs
+    return;
+  }
+  eng_.reset(new DeviceHSS(int(rows_), e, t));
 }
 
 void HSSMatrix<double>::compress(const DenseM_t& A, const opts_t& opts) {

@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 
@@ -40,6 +42,44 @@ struct HostRng {
   std::uniform_real_distribution<double> ud;
 };
 
+// process-wide pool of device chunks: arenas return their chunks here instead of hipFree, so that
+// repeated constructions (solver loops, benchmarks) do not pay hipMalloc / hipFree page-table work
+class DevicePool {
+ public:
+  static DevicePool& get() { static DevicePool p; return p; }
+  void* acquire(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = free_.find(bytes);
+      if (it != free_.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); cached_ -= bytes; return p; }
+    }
+    void* p = hssk_malloc((long long)bytes);
+    if (!p) {  // memory pressure: drop the cache and retry once
+      trim();
+      p = hssk_malloc((long long)bytes);
+    }
+    return p;
+  }
+  void release(void* p, size_t bytes) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (cached_ + bytes > limit_) { hssk_free(p); return; }
+    free_[bytes].push_back(p);
+    cached_ += bytes;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& kv : free_) for (void* p : kv.second) hssk_free(p);
+    free_.clear();
+    cached_ = 0;
+  }
+  ~DevicePool() { for (auto& kv : free_) for (void* p : kv.second) hssk_free(p); }
+
+ private:
+  std::mutex mu_;
+  std::map<size_t, std::vector<void*>> free_;
+  size_t cached_ = 0, limit_ = size_t(8) << 30;
+};
+
 // bump allocator over large device chunks
 class Arena {
  public:
@@ -47,14 +87,22 @@ class Arena {
   ~Arena() { reset(); }
   void* alloc(size_t bytes) {
     bytes = (std::max<size_t>(bytes, 8) + 255) & ~size_t(255);
-    if (bytes > left_) {
-      size_t c = std::max(chunk_, bytes);
-      void* p = hssk_malloc((long long)c);
+    while (bytes > left_) {
+      // try the next chunk kept from before a rewind(), else get a new one
+      if (next_ < chunks_.size()) {
+        cur_ = (char*)chunks_[next_].first;
+        left_ = chunks_[next_].second;
+        next_++;
+        continue;
+      }
+      const size_t gran = size_t(64) << 20;
+      size_t c = (std::max(chunk_, bytes) + gran - 1) / gran * gran;
+      void* p = DevicePool::get().acquire(c);
       if (!p) throw std::runtime_error(std::string("device allocation failed: ") + hssk_last_error());
-      chunks_.push_back(p);
+      chunks_.emplace_back(p, c);
+      next_ = chunks_.size();
       cur_ = (char*)p;
       left_ = c;
-      total_ += c;
     }
     void* r = cur_;
     cur_ += bytes;
@@ -64,19 +112,19 @@ class Arena {
   }
   double* dbl(size_t count) { return (double*)alloc(sizeof(double) * count); }
   int* ints(size_t count) { return (int*)alloc(sizeof(int) * count); }
+  // forget all allocations but keep the chunks (caller guarantees the device is done with them)
+  void rewind() { next_ = 0; cur_ = nullptr; left_ = 0; used_ = 0; }
   void reset() {
-    for (void* p : chunks_) hssk_free(p);
+    for (auto& c : chunks_) DevicePool::get().release(c.first, c.second);
     chunks_.clear();
-    cur_ = nullptr;
-    left_ = 0;
-    total_ = used_ = 0;
+    rewind();
   }
   size_t used() const { return used_; }
 
  private:
-  size_t chunk_, left_ = 0, total_ = 0, used_ = 0;
+  size_t chunk_, left_ = 0, used_ = 0, next_ = 0;
   char* cur_ = nullptr;
-  std::vector<void*> chunks_;
+  std::vector<std::pair<void*, size_t>> chunks_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -172,6 +220,7 @@ DeviceHSS::DeviceHSS(int n, const EngineOptions& opts, const structured::Cluster
   persist_.reset(new Arena(size_t(64) << 20));
   work_.reset(new Arena(size_t(256) << 20));
   fact_.reset(new Arena(size_t(64) << 20));
+  tmp_.reset(new Arena(size_t(64) << 20));
   build_tree(tree);
 }
 
@@ -180,6 +229,7 @@ DeviceHSS::~DeviceHSS() {
   persist_.reset();
   work_.reset();
   fact_.reset();
+  tmp_.reset();
   hssk_ctx_destroy(ctx_);
 }
 
@@ -560,7 +610,8 @@ void DeviceHSS::reduce_samples(const std::vector<int>& ids, const std::vector<in
   if (ids.empty()) return;
   std::vector<hssk_colgather_desc> cat, g;
   std::vector<hssk_gemm_desc> mm;
-  Arena tmp(size_t(32) << 20);
+  Arena& tmp = *tmp_;
+  tmp.rewind();
   for (size_t k = 0; k < ids.size(); k++) {
     Node& nd = nodes_[ids[k]];
     const int r0 = r0s[k], dn = dns[k];
@@ -603,7 +654,8 @@ void DeviceHSS::reduce_samples(const std::vector<int>& ids, const std::vector<in
 // ID of the listed (node, basis) pairs on all dtot samples; commits ranks, X, perm, index sets
 void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot) {
   if (ids.empty()) return;
-  Arena tmp(size_t(64) << 20);
+  Arena& tmp = *tmp_;
+  tmp.rewind();
   const size_t cnt = ids.size();
   std::vector<hssk_colgather_desc> cp;
   std::vector<hssk_id_desc> idd;
@@ -635,6 +687,8 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
   if (perm_total) ck(hssk_memcpy_d2h(ctx_, hperm.data(), perm_block, (long long)sizeof(int) * perm_total));
   // commit
   std::vector<hssk_elem_desc> xc;
+  std::vector<int> idx_host;      // all skeleton index sets of this level: one upload
+  std::vector<size_t> idx_off;
   poff = 0;
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
@@ -654,14 +708,21 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
       const int r0 = (int)ia.size();
       for (int i = 0; i < r; i++) I[i] = perm[i] < r0 ? ia[perm[i]] : ib[perm[i] - r0];
     }
-    int* dI = persist_->ints(std::max(r, 1));
-    if (r) ck(hssk_memcpy_h2d(ctx_, dI, I.data(), (long long)sizeof(int) * r));
-    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.hpermU = perm; nd.Ir = I; nd.dIr = dI; nd.Ustate = 2; }
-    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.hpermV = perm; nd.Ic = I; nd.dIc = dI; nd.Vstate = 2; }
+    const size_t ioff = idx_host.size();
+    idx_host.insert(idx_host.end(), I.begin(), I.end());
+    idx_off.push_back(ioff);
+    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.hpermU = perm; nd.Ir = I; nd.Ustate = 2; }
+    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.hpermV = perm; nd.Ic = I; nd.Vstate = 2; }
     stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
   }
+  int* idx_dev = persist_->ints(std::max<size_t>(idx_host.size(), 1));
+  if (!idx_host.empty()) ck(hssk_memcpy_h2d(ctx_, idx_dev, idx_host.data(), (long long)sizeof(int) * idx_host.size()));
+  for (size_t k = 0; k < cnt; k++) {
+    Node& nd = nodes_[ids[k]];
+    (which[k] == 0 ? nd.dIr : nd.dIc) = idx_dev + idx_off[k];
+  }
   if (!xc.empty()) ck(hssk_gather_elems(ctx_, xc.data(), (int)xc.size()));
-  ck(hssk_sync(ctx_));  // tmp (W panels) released on return
+  ck(hssk_sync(ctx_));  // the W panels in tmp_ may be reused after this
 }
 
 // update_orthogonal_basis (HSSMatrix.compress_stable.hpp:390-442) for the listed (node, basis) pairs
@@ -669,7 +730,8 @@ void DeviceHSS::ortho_test(const std::vector<int>& ids, const std::vector<int>& 
                            std::vector<char>& resolved) {
   const size_t cnt = ids.size();
   resolved.assign(cnt, 0);
-  Arena tmp(size_t(64) << 20);
+  Arena& tmp = *tmp_;
+  tmp.rewind();
   std::vector<hssk_transpose_desc> tr;
   std::vector<hssk_colgather_desc> cp;
   std::vector<hssk_qr_desc> qr;
@@ -770,7 +832,8 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   if (nrhs <= 0 || n_ == 0) return;
   double t0 = now();
   const bool T = !(trans == 'N' || trans == 'n');
-  Arena tmp(size_t(32) << 20);
+  Arena& tmp = *tmp_;
+  tmp.rewind();
   const int N = n_;
   const double* dx = x;
   double* dy = y;
@@ -905,7 +968,8 @@ void DeviceHSS::factor() {
     std::vector<hssk_colgather_desc> cp;
     std::vector<hssk_gemm_desc> g0, g1;
     std::vector<hssk_basis_desc> bd;
-    Arena tmp(size_t(32) << 20);
+    Arena& tmp = *tmp_;
+    tmp.rewind();
     for (int id : ids) {
       Node& nd = nodes_[id];
       const bool root = nd.lvl == 0;
@@ -1005,7 +1069,8 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   if (!factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
   if (nrhs <= 0 || n_ == 0) return;
   double t0 = now();
-  Arena tmp(size_t(32) << 20);
+  Arena& tmp = *tmp_;
+  tmp.rewind();
   const int N = n_;
   double* db = b;
   long long lb = ldb;

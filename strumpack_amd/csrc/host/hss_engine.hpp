@@ -86,6 +86,8 @@ class DeviceHSS {
   void node_info(int* out) const;
   const PhaseStats& stats() const { return stats_; }
   hssk_ctx* ctx() const { return ctx_; }
+  const EngineOptions& options() const { return o_; }
+  void set_options(const EngineOptions& o) { o_ = o; }
 
   struct Node {
     int lo = 0, m = 0, lvl = 0, height = 0, c0 = -1, c1 = -1, parent = -1;
@@ -135,7 +137,7 @@ class DeviceHSS {
   hssk_ctx* ctx_ = nullptr;
   std::vector<Node> nodes_;
   std::vector<std::vector<int>> by_height_, by_depth_;
-  std::unique_ptr<Arena> persist_, work_, fact_;
+  std::unique_ptr<Arena> persist_, work_, fact_, tmp_;
   // global transposed sample arrays (dcap x N)
   double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;
   int dcap_ = 0;

@@ -1,7 +1,14 @@
 // Context, error state and memory helpers of the hssk C-ABI (include/hssk.h).
 #include "hssk_internal.h"
 
+#include <mutex>
+#include <vector>
+
 static thread_local std::string g_err;
+// retired contexts are kept (stream, events, 64 MB pinned + device staging rings) and handed out
+// again by hssk_ctx_create: creating pinned memory costs milliseconds, solvers create many matrices
+static std::mutex g_pool_mu;
+static std::vector<hssk_ctx*> g_pool;
 void hssk_set_error(const std::string& msg) { g_err = msg; }
 
 extern "C" {
@@ -14,6 +21,15 @@ int hssk_ctx_create(hssk_ctx** out, int device) {
     throw std::runtime_error("hssk_ctx_create: no HIP device " + std::to_string(device) +
                              " (this library has no CPU fallback)");
   hssk_rt::set_device(device);
+  {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+      if (g_pool[i]->device == device) {
+        *out = g_pool[i];
+        g_pool.erase(g_pool.begin() + i);
+        return 0;
+      }
+  }
   hssk_ctx* c = new hssk_ctx;
   c->device = device;
   c->stream = hssk_rt::stream_create();
@@ -29,6 +45,15 @@ int hssk_ctx_create(hssk_ctx** out, int device) {
 void hssk_ctx_destroy(hssk_ctx* c) {
   if (!c) return;
   try { hssk_rt::sync(c->stream); } catch (...) {}
+  {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (g_pool.size() < 8) {
+      c->ring_off = 0;
+      c->dgemm_timed = false;
+      g_pool.push_back(c);
+      return;
+    }
+  }
   hssk_rt::pinned_free(c->h_ring);
   hssk_rt::dev_free(c->d_ring);
   hssk_rt::dev_free(c->d_scratch);

@@ -23,23 +23,27 @@ namespace {
 
 constexpr int BN = 64, BK = 16;
 
-template <int BM, bool TRANSB>
-__global__ __launch_bounds__(256) void dgemm_kernel(int m, long long n, long long k, const double* __restrict__ A,
-                                                    long long lda, const double* __restrict__ B, long long ldb,
-                                                    double* __restrict__ P, long long ldp, long long pstride,
-                                                    long long kchunk) {
+// FULL = true : interior tiles -- m % BM == 0, whole BN columns, k-chunk a multiple of BK, operands
+//               16-byte aligned with even leading dimensions: unmasked 16-byte global loads.
+// FULL = false: edge tiles / unaligned operands -- masked 8-byte loads.
+template <int BM, bool TRANSB, bool FULL>
+__global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long long k, const double* __restrict__ A,
+                                                       long long lda, const double* __restrict__ B, long long ldb,
+                                                       double* __restrict__ P, long long ldp, long long pstride,
+                                                       long long kchunk, int jtile0) {
   constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
   constexpr int WM = BM / 2;       // rows per wave
   constexpr int MT = WM / 16;      // MFMA tiles per wave along M
   constexpr int NT = 2;            // 32 columns per wave
-  constexpr int A_PER_THREAD = BM * BK / 256;
+  constexpr int A_PER_THREAD = BM * BK / 256;   // doubles per thread and stage
   constexpr int B_PER_THREAD = BN * BK / 256;
+  constexpr int A2 = A_PER_THREAD / 2, B2 = B_PER_THREAD / 2;  // 16-byte pieces
   HSSK_SHARED double As[2 * BK * LDA_S];
   HSSK_SHARED double Bs[2 * BK * LDB_S];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const long long j0 = (long long)blockIdx.x * BN;
+  const long long j0 = (long long)(blockIdx.x + jtile0) * BN;
   const int i0 = blockIdx.y * BM;
   const long long kbeg = (long long)blockIdx.z * kchunk;
   const long long kend = kbeg + kchunk < k ? kbeg + kchunk : k;
@@ -51,57 +55,12 @@ __global__ __launch_bounds__(256) void dgemm_kernel(int m, long long n, long lon
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
 
-  double ra[A_PER_THREAD], rb[B_PER_THREAD];
+  const double* Ak = A + i0 + kbeg * lda;
+  const double* Bk = TRANSB ? B + j0 + kbeg * ldb : B + j0 * ldb + kbeg;
+  const long long stepA = (long long)BK * lda, stepB = TRANSB ? (long long)BK * ldb : (long long)BK;
+  const long long nst = (kend - kbeg + BK - 1) / BK;  // stages
 
-  auto load_tiles = [&](long long k0) {
-    // A tile: (i, kk) contiguous along i
-#pragma unroll
-    for (int r = 0; r < A_PER_THREAD; r++) {
-      int e = tid + 256 * r;
-      int i = e % BM, kk = e / BM;
-      long long gk = k0 + kk;
-      int gi = i0 + i;
-      ra[r] = (gi < m && gk < kend) ? A[gi + gk * lda] : 0.;
-    }
-#pragma unroll
-    for (int r = 0; r < B_PER_THREAD; r++) {
-      int e = tid + 256 * r;
-      if (TRANSB) {  // op(B)(k, j) = B(j, k): contiguous along j
-        int j = e % BN, kk = e / BN;
-        long long gk = k0 + kk, gj = j0 + j;
-        rb[r] = (gj < n && gk < kend) ? B[gj + gk * ldb] : 0.;
-      } else {       // op(B)(k, j) = B(k, j): contiguous along k
-        int kk = e % BK, j = e / BK;
-        long long gk = k0 + kk, gj = j0 + j;
-        rb[r] = (gj < n && gk < kend) ? B[gk + gj * ldb] : 0.;
-      }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    double* as = As + buf * BK * LDA_S;
-    double* bs = Bs + buf * BK * LDB_S;
-#pragma unroll
-    for (int r = 0; r < A_PER_THREAD; r++) {
-      int e = tid + 256 * r;
-      as[(e / BM) * LDA_S + (e % BM)] = ra[r];
-    }
-#pragma unroll
-    for (int r = 0; r < B_PER_THREAD; r++) {
-      int e = tid + 256 * r;
-      if (TRANSB) bs[(e / BN) * LDB_S + (e % BN)] = rb[r];
-      else bs[(e % BK) * LDB_S + (e / BK)] = rb[r];
-    }
-  };
-
-  if (kbeg < kend) {
-    load_tiles(kbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (long long k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) load_tiles(k0 + BK);
+  auto compute = [&](int buf) {
     const double* as = As + buf * BK * LDA_S;
     const double* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
@@ -117,9 +76,111 @@ __global__ __launch_bounds__(256) void dgemm_kernel(int m, long long n, long lon
         for (int b = 0; b < NT; b++)  // swapped operands: lane holds C[i = l15][j = l4 + 4r]
           acc[a][b] = hssk_mfma_f64_16x16x4(bf[b], af[a], acc[a][b]);
     }
-    if (more) store_tiles(buf ^ 1);
+  };
+
+  if (FULL) {
+    // k-invariant per-thread global offsets (32-bit, relative to the stage base) and LDS slots
+    int offA[A2], ldsA[A2], offB[B2], ldsB[B2];
+#pragma unroll
+    for (int r = 0; r < A2; r++) {
+      int e = tid + 256 * r;                  // pair index: (i2, kk) with i = 2 i2
+      int i = 2 * (e % (BM / 2)), kk = e / (BM / 2);
+      offA[r] = i + kk * (int)lda;
+      ldsA[r] = kk * LDA_S + i;
+    }
+#pragma unroll
+    for (int r = 0; r < B2; r++) {
+      int e = tid + 256 * r;
+      if (TRANSB) {  // op(B)(k,j) = B(j,k): pairs along j
+        int j = 2 * (e % (BN / 2)), kk = e / (BN / 2);
+        offB[r] = j + kk * (int)ldb;
+        ldsB[r] = kk * LDB_S + j;
+      } else {       // op(B)(k,j) = B(k,j): pairs along k
+        int kk = 2 * (e % (BK / 2)), j = e / (BK / 2);
+        offB[r] = kk + j * (int)ldb;
+        ldsB[r] = kk * LDB_S + j;
+      }
+    }
+    hssk_d2 ra[A2], rb[B2];
+    auto load = [&]() {
+#pragma unroll
+      for (int r = 0; r < A2; r++) ra[r] = *reinterpret_cast<const hssk_d2*>(Ak + offA[r]);
+#pragma unroll
+      for (int r = 0; r < B2; r++) rb[r] = *reinterpret_cast<const hssk_d2*>(Bk + offB[r]);
+    };
+    auto store = [&](int buf) {
+      double* as = As + buf * BK * LDA_S;
+      double* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+      for (int r = 0; r < A2; r++) *reinterpret_cast<hssk_d2*>(as + ldsA[r]) = ra[r];
+#pragma unroll
+      for (int r = 0; r < B2; r++) {
+        if (TRANSB) *reinterpret_cast<hssk_d2*>(bs + ldsB[r]) = rb[r];
+        else { bs[ldsB[r]] = rb[r][0]; bs[ldsB[r] + LDB_S] = rb[r][1]; }
+      }
+    };
+    load();
+    store(0);
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    for (long long st = 0; st + 1 < nst; st++) {
+      Ak += stepA; Bk += stepB;
+      load();               // prefetch stage st+1 into registers
+      compute(buf);         // MFMAs of stage st
+      store(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    compute(buf);
+  } else {
+    double ra[A_PER_THREAD], rb[B_PER_THREAD];
+    auto load = [&](long long k0) {
+#pragma unroll
+      for (int r = 0; r < A_PER_THREAD; r++) {
+        int e = tid + 256 * r;
+        int i = e % BM, kk = e / BM;
+        ra[r] = (i0 + i < m && k0 + kk < kend) ? A[i0 + i + (k0 + kk) * lda] : 0.;
+      }
+#pragma unroll
+      for (int r = 0; r < B_PER_THREAD; r++) {
+        int e = tid + 256 * r;
+        if (TRANSB) {
+          int j = e % BN, kk = e / BN;
+          rb[r] = (j0 + j < n && k0 + kk < kend) ? B[j0 + j + (k0 + kk) * ldb] : 0.;
+        } else {
+          int kk = e % BK, j = e / BK;
+          rb[r] = (j0 + j < n && k0 + kk < kend) ? B[k0 + kk + (j0 + j) * ldb] : 0.;
+        }
+      }
+    };
+    auto store = [&](int buf) {
+      double* as = As + buf * BK * LDA_S;
+      double* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+      for (int r = 0; r < A_PER_THREAD; r++) {
+        int e = tid + 256 * r;
+        as[(e / BM) * LDA_S + (e % BM)] = ra[r];
+      }
+#pragma unroll
+      for (int r = 0; r < B_PER_THREAD; r++) {
+        int e = tid + 256 * r;
+        if (TRANSB) bs[(e / BN) * LDB_S + (e % BN)] = rb[r];
+        else bs[(e % BK) * LDB_S + (e / BK)] = rb[r];
+      }
+    };
+    if (nst > 0) { load(kbeg); store(0); }
+    __syncthreads();
+    int buf = 0;
+    long long k0 = kbeg;
+    for (long long st = 0; st + 1 < nst; st++) {
+      k0 += BK;
+      load(k0);
+      compute(buf);
+      store(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    if (nst > 0) compute(buf);
   }
   // partial tile -> P (slice blockIdx.z), plain stores; the reduce kernel applies alpha/beta
   double* Pz = P + (long long)blockIdx.z * pstride;
@@ -153,14 +214,23 @@ __global__ void dgemm_reduce_kernel(int m, long long n, const double* __restrict
   }
 }
 
-template <int BM>
+template <int BM, bool FULL>
 void launch_dgemm(hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
                   long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
-                  long long kchunk) {
+                  long long kchunk, int jtile0) {
+  if (grid.x == 0) return;
   if (transB)
-    HSSK_LAUNCH((dgemm_kernel<BM, true>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
+    HSSK_LAUNCH((dgemm_kernel<BM, true, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
   else
-    HSSK_LAUNCH((dgemm_kernel<BM, false>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
+    HSSK_LAUNCH((dgemm_kernel<BM, false, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+}
+
+template <int BM>
+void launch_dgemm_split(hssk_ctx* ctx, int transB, unsigned gn_full, unsigned gn, unsigned gm, unsigned nz, int m,
+                        long long n, long long k, const double* A, long long lda, const double* B, long long ldb,
+                        double* P, long long ldp, long long pstride, long long kchunk) {
+  launch_dgemm<BM, true>(ctx, transB, dim3(gn_full, gm, nz), m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, 0);
+  launch_dgemm<BM, false>(ctx, transB, dim3(gn - gn_full, gm, nz), m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, (int)gn_full);
 }
 
 }  // namespace
@@ -194,11 +264,15 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
   long long ldp = m;
   long long pstride = ldp * n;
   double* P = ctx->scratch(sizeof(double) * (size_t)pstride * nz);
-  dim3 grid(gn, gm, (unsigned)nz);
+  // interior tiles take the unmasked 16-byte-load kernel; the ragged last column tile (and any
+  // unaligned / odd-sized problem) the masked one
+  const bool aligned = (m % BM == 0) && (k % BK == 0) && (lda % 2 == 0) && (ldb % 2 == 0) &&
+                       (((size_t)A | (size_t)B) % 16 == 0);
+  const unsigned gn_full = aligned ? (unsigned)(n / BN) : 0u;
   hssk_rt::event_record(ctx->ev0, ctx->stream);
-  if (BM == 192) launch_dgemm<192>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
-  else if (BM == 128) launch_dgemm<128>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
-  else launch_dgemm<64>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
+  if (BM == 192) launch_dgemm_split<192>(ctx, transB, gn_full, gn, gm, (unsigned)nz, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
+  else if (BM == 128) launch_dgemm_split<128>(ctx, transB, gn_full, gn, gm, (unsigned)nz, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
+  else launch_dgemm_split<64>(ctx, transB, gn_full, gn, gm, (unsigned)nz, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
   hssk_rt::event_record(ctx->ev1, ctx->stream);
   ctx->dgemm_timed = true;
   long long total = (long long)m * n;

@@ -183,6 +183,37 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
   if (s[0] + s[1] + s[2] + s[3] == -1.0) out[0] = s[0];
 }
 
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(double* out, long long* clk, int iters, double av, double bv) {
+  // 12 independent accumulators, 48 MFMAs per iteration, no memory traffic: the pure issue rate
+  hssk_d4 c[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) c[i] = hssk_d4{0., 0., 0., 0.};
+  double a0 = av * (1.0 + threadIdx.x * 1e-3), b0 = bv * (1.0 - threadIdx.x * 1e-3);
+  double a1 = a0 * 0.5, b1 = b0 * 0.25;
+  long long t0 = hssk_clock(), w0 = hssk_wallclock();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+      for (int q = 0; q < 12; q += 2) {
+        c[q] = hssk_mfma_f64_16x16x4(a0, b0, c[q]);
+        c[q + 1] = hssk_mfma_f64_16x16x4(a1, b0, c[q + 1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 12; q += 2) {
+        c[q] = hssk_mfma_f64_16x16x4(a0, b1, c[q]);
+        c[q + 1] = hssk_mfma_f64_16x16x4(a1, b1, c[q + 1]);
+      }
+    }
+  }
+  long long t1 = hssk_clock(), w1 = hssk_wallclock();
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 12; i++) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+  if (s == -1.0) out[0] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
 template <class Desc, class F>
 std::vector<Work2> make_work2(const Desc* descs, int count, F ncols_of) {
   std::vector<Work2> w;
@@ -308,6 +339,29 @@ double hssk_mfma_f64_peak_tflops(hssk_ctx* ctx, int iters) {
     hssk_set_error(e.what());
     return -1.;
   }
+}
+
+int hssk_mfma_f64_probe(hssk_ctx* ctx, int iters, int waves_per_simd, int zero_data, double* out) {
+  HSSK_API_BEGIN
+  // 256-thread blocks = 4 waves = one per SIMD; waves_per_simd blocks per CU
+  const int blocks = 256 * std::max(1, std::min(2, waves_per_simd));
+  double* d = (double*)ctx->scratch(256);
+  long long* clk = (long long*)(d + 8);
+  const double v = zero_data ? 0.0 : 0.7310585786300049;
+  HSSK_LAUNCH(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, clk, 64, v, v);
+  hssk_rt::event_record(ctx->ev0, ctx->stream);
+  HSSK_LAUNCH(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, clk, iters, v, v);
+  hssk_rt::event_record(ctx->ev1, ctx->stream);
+  hssk_rt::check_launch();
+  float ms = hssk_rt::event_elapsed_ms(ctx->ev0, ctx->ev1);
+  ctx->dgemm_timed = false;
+  long long h[2] = {0, 0};
+  hssk_rt::d2h(h, clk, sizeof(h), ctx->stream);
+  hssk_rt::sync(ctx->stream);
+  out[0] = (double)blocks * 4 * (double)iters * 48 * 2048.0 / (ms * 1e-3) * 1e-12;
+  out[1] = (double)h[0] / ((double)iters * 48);
+  out[2] = h[1] > 0 ? (double)h[0] / ((double)h[1] / 100e6) * 1e-9 : 0.;
+  HSSK_API_END
 }
 
 }  // extern "C"

@@ -87,7 +87,7 @@ HSSK_SYMBOLS = [
     "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
     "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops", "hssk_memcpy_d2d",
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
-    "hssk_basis_dense",
+    "hssk_basis_dense", "hssk_mfma_f64_probe",
 ]
 
 
@@ -170,6 +170,7 @@ class Hssk:
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         L.hssk_mfma_f64_peak_tflops.restype = C.c_double
         L.hssk_mfma_f64_peak_tflops.argtypes = [C.c_void_p, C.c_int]
+        L.hssk_mfma_f64_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         ctx = C.c_void_p()
         if L.hssk_ctx_create(C.byref(ctx), device):
             raise RuntimeError(self.error())

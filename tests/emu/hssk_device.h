@@ -26,6 +26,7 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __launch_bounds__(...)
 
 typedef double hssk_d4 __attribute__((vector_size(32)));
+typedef double hssk_d2 __attribute__((vector_size(16)));
 
 namespace emu {
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
@@ -56,6 +57,9 @@ inline double hssk_wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = std::fmax(v, hssk_shfl_xor(v, o));
   return v;
 }
+
+inline long long hssk_clock() { return 0; }
+inline long long hssk_wallclock() { return 0; }
 
 #define HSSK_SHARED static thread_local
 #define HSSK_DYN_SHARED(type, name) type* name = (type*)emu::dyn_shared()
