@@ -38,7 +38,7 @@ __device__ __forceinline__ double hssk_wave_max(double v) {
 __device__ __forceinline__ long long hssk_clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ long long hssk_wallclock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 
-#define HSSK_SHARED __shared__
+#define HSSK_SHARED __shared__ __attribute__((aligned(16)))
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
 // kernel<<<grid, block, shmem, stream>>>(args...)

@@ -13,6 +13,9 @@
 #include "hssk_device.h"
 #include "hssk_internal.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace {
 
 constexpr int QR_THREADS = 512;
@@ -94,13 +97,206 @@ __global__ __launch_bounds__(QR_THREADS) void qr_kernel(const hssk_qr_desc* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident variant: the whole panel lives in the VGPRs of one 1024-thread workgroup
+// (NW = 16 wave64; 8 for the widest panels): column j belongs to wave j % NW (local slot j / NW), row i to lane i % 64 (slot
+// i / 64), so a lane holds a[CT][RT] doubles.  A Householder step costs one LDS broadcast of the
+// reflector (double-buffered: one barrier per step) and, per owned column, RT fmas + a shuffle
+// reduction + RT fmas -- no global or L2 traffic inside the factorization, which is what bounds the
+// global-memory kernel above (the 200 KB leaf panels of a level do not fit L2, every step re-streams
+// them).  Q is formed in place like LAPACK dorg2r.  Capacity: rows <= 64 RT, max(cols, nq) <= NW CT.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void qr_reg_kernel(const hssk_qr_desc* __restrict__ descs) {
+  HSSK_SHARED double s_v[2 * 64 * RT];
+  HSSK_SHARED double s_tau[NW * CT];
+  HSSK_SHARED double s_rd[2];
+  const hssk_qr_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = p.rows, cols = p.cols, nq = p.nq;
+  const int kmax = rows < cols ? rows : cols;
+  double a[CT][RT];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const int row = lane + 64 * r, col = wave + NW * c;
+      a[c][r] = (row < rows && col < cols) ? p.A[row + (size_t)col * p.lda] : 0.;
+    }
+  // ---- factorization.  Step k = kc * NW + kw is owned by wave kw, local column slot kc; the slot
+  // loop is unrolled at compile time so that every access to the register tile is statically indexed
+#pragma clang loop unroll(full)
+  for (int kc = 0; kc < CT; kc++) {
+    for (int kw = 0; kw < NW; kw++) {
+      const int k = kc * NW + kw;
+      if (k >= kmax) break;
+      double* sv = s_v + (k & 1) * 64 * RT;
+      const int lk = k & 63, rk = k >> 6;
+      if (wave == kw) {
+        double s = 0., av = 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+          const int row = lane + 64 * r;
+          if (row > k && row < rows) s += a[kc][r] * a[kc][r];
+          if (r == rk) av = a[kc][r];
+        }
+        const double alpha = hssk_shfl(av, lk);
+        s = hssk_wave_sum(s);
+        double tau = 0., beta = alpha, scal = 1.;
+        if (s != 0.) {
+          double nrm = sqrt(alpha * alpha + s);
+          beta = alpha >= 0. ? -nrm : nrm;
+          tau = (beta - alpha) / beta;
+          scal = 1. / (alpha - beta);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+          const int row = lane + 64 * r;
+          if (row > k && row < rows) a[kc][r] *= scal;
+          sv[row] = row > k ? a[kc][r] : (row == k ? 1. : 0.);
+          if (row == k) a[kc][r] = beta;
+        }
+        if (lane == 0) {
+          s_tau[k] = tau;
+          const double ab = fabs(beta);
+          if (k == 0) { s_rd[0] = ab; s_rd[1] = ab; }
+          else { if (ab > s_rd[0]) s_rd[0] = ab; if (ab < s_rd[1]) s_rd[1] = ab; }
+        }
+      }
+      __syncthreads();
+      const double tau = s_tau[k];
+      if (tau != 0.) {
+        double vr[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) vr[r] = sv[lane + 64 * r];
+#pragma unroll
+        for (int c = kc; c < CT; c++) {
+          const int col = wave + NW * c;
+          // slots above kc hold only columns > k; in slot kc the waves after the owner do
+          if ((c > kc || wave > kw) && col < cols) {
+            double dot = 0.;
+#pragma unroll
+            for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
+            dot = hssk_wave_sum(dot) * tau;
+#pragma unroll
+            for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
+          }
+        }
+      }
+    }
+  }
+  // factored panel (R + reflectors) back to A, taus to the work array
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const int row = lane + 64 * r, col = wave + NW * c;
+      if (row < rows && col < cols) p.A[row + (size_t)col * p.lda] = a[c][r];
+    }
+  __syncthreads();
+  for (int k = tid; k < kmax; k += NW * 64) p.work[k] = s_tau[k];
+  if (p.rdiag && tid == 0) { p.rdiag[0] = kmax ? s_rd[0] : 0.; p.rdiag[1] = kmax ? s_rd[1] : 0.; }
+}
+
+// Q(:, j0 : j0 + 16 CT) = H_0 ... H_{kmax-1} I(:, same columns): every wave owns CT columns in
+// registers and applies the reflectors (read from the factored panel, L1/L2 hits) on its own --
+// no LDS, no barriers.  H_k leaves column j untouched for k > j, so the sweep starts at the last
+// column of the block.
+struct QBlock {
+  int prob, block;
+};
+template <int RT, int CT>
+__global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __restrict__ descs,
+                                                         const QBlock* __restrict__ work) {
+  const QBlock w = work[blockIdx.x];
+  const hssk_qr_desc p = descs[w.prob];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = p.rows, cols = p.cols, nq = p.nq;
+  const int kmax = rows < cols ? rows : cols;
+  const int j0 = w.block * 16 * CT;
+  const double* __restrict__ A = p.A;
+  const double* __restrict__ taus = p.work;
+  double a[CT][RT];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < RT; r++) a[c][r] = (lane + 64 * r == j0 + wave + 16 * c) ? 1. : 0.;
+  int kstart = j0 + 16 * CT - 1;
+  if (kstart > kmax - 1) kstart = kmax - 1;
+  for (int k = kstart; k >= 0; k--) {
+    const double tau = taus[k];
+    if (tau == 0.) continue;
+    double vr[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const int row = lane + 64 * r;
+      vr[r] = (row > k && row < rows) ? A[row + (size_t)k * p.lda] : (row == k ? 1. : 0.);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int col = j0 + wave + 16 * c;
+      if (col >= k && col < nq) {
+        double dot = 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
+        dot = hssk_wave_sum(dot) * tau;
+#pragma unroll
+        for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const int row = lane + 64 * r, col = j0 + wave + 16 * c;
+      if (row < rows && col < nq) p.Q[row + (size_t)col * p.ldq] = a[c][r];
+    }
+}
+
+template <int RT, int CT, int NW>
+void launch_qr_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, int count) {
+  HSSK_LAUNCH((qr_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
+}
+template <int RT, int CT>
+void launch_formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc* descs, int count) {
+  std::vector<QBlock> blocks;
+  for (int i = 0; i < count; i++)
+    for (int b = 0; b * 16 * CT < descs[i].nq; b++) blocks.push_back(QBlock{i, b});
+  if (blocks.empty()) return;
+  auto* dw = (const QBlock*)ctx->stage(blocks.data(), sizeof(QBlock) * blocks.size());
+  HSSK_LAUNCH((formq_reg_kernel<RT, CT>), dim3((unsigned)blocks.size()), dim3(1024), 0, ctx->stream, dd, dw);
+}
+
 }  // namespace
 
 extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
+  int rmax = 0, cmax = 0, qmax = 0;
+  for (int i = 0; i < count; i++) {
+    rmax = std::max(rmax, descs[i].rows);
+    cmax = std::max(cmax, descs[i].cols);
+    qmax = std::max(qmax, descs[i].nq);
+  }
   auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd);
+  // register-resident kernels when the largest panel of the batch fits (rows <= 64 RT, cols <= 16 CT);
+  // Q is then formed by a second, barrier-free launch over blocks of 16 CT columns
+  bool reg = true;
+  if (rmax <= 64 && cmax <= 64) launch_qr_reg<1, 4, 16>(ctx, dd, count);
+  else if (rmax <= 128 && cmax <= 128) launch_qr_reg<2, 8, 16>(ctx, dd, count);
+  else if (rmax <= 256 && cmax <= 128) launch_qr_reg<4, 8, 16>(ctx, dd, count);
+  else if (rmax <= 256 && cmax <= 208) launch_qr_reg<4, 26, 8>(ctx, dd, count);
+  else reg = false;
+  if (reg) {
+    if (qmax > 0) {
+      if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
+      else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
+      else launch_formq_reg<4, 8>(ctx, dd, descs, count);
+    }
+  } else {
+    HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd);
+  }
   hssk_rt::check_launch();
   HSSK_API_END
 }

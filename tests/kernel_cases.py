@@ -35,10 +35,10 @@ def case_gemm_vbatched(hk, shapes, seed=0):
         assert np.abs(got - ref).max() <= 1e-12 * scale * max(sh[2], 1), f"gemm {sh}"
 
 
-def case_dgemm(hk, m, n, k, transB, alpha=1.0, beta=0.0, lda_pad=5, seed=1):
+def case_dgemm(hk, m, n, k, transB, alpha=1.0, beta=0.0, lda_pad=5, seed=1, ldb_pad=1):
     r = rng(seed)
     A = r.standard_normal((m + lda_pad, k))
-    B = r.standard_normal((n + 1, k)) if transB else r.standard_normal((k + 1, n))
+    B = r.standard_normal((n + ldb_pad, k)) if transB else r.standard_normal((k + ldb_pad, n))
     Cm = r.standard_normal((m + 2, n))
     dA, dB, dC = hk.array(A), hk.array(B), hk.array(Cm)
     hk.check(hk.lib.hssk_dgemm(hk.ctx, int(transB), m, n, k, alpha, dA.ptr, A.shape[0], dB.ptr,

@@ -27,6 +27,13 @@ def test_dgemm(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
 
 
+@pytest.mark.parametrize("m,n,k,tb", [(192, 150, 64, 1), (192, 150, 64, 0), (64, 130, 48, 1), (128, 64, 32, 0)])
+def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
+    # even leading dimensions + 16-byte aligned operands: interior tiles take the unmasked kernel
+    KC.case_dgemm(hk, m, n, k, tb, alpha=1.0, beta=0.0, lda_pad=0, ldb_pad=0)
+    KC.case_dgemm(hk, m, n, k, tb, alpha=-1.0, beta=1.0, lda_pad=2, ldb_pad=4)
+
+
 def test_dgemm_splitk(hk):
     KC.case_dgemm(hk, 24, 70, 3000, 1)
 
@@ -47,6 +54,10 @@ def test_id(hk):
 
 def test_qr(hk):
     KC.case_qr(hk, [(40, 12, 12), (30, 30, 30), (33, 20, 33), (10, 1, 10), (70, 10, 0)])
+    KC.case_qr(hk, [(100, 128, 100), (120, 60, 120)], seed=8)       # <2,8,16>
+    KC.case_qr(hk, [(195, 128, 128)], seed=9)                       # <4,8,16>
+    KC.case_qr(hk, [(195, 160, 195), (130, 100, 130)], seed=10)     # <4,26,8>
+    KC.case_qr(hk, [(300, 40, 300)], seed=11)                       # global-memory fallback
 
 
 def test_trsm_lu(hk):

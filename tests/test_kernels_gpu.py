@@ -37,6 +37,12 @@ def test_dgemm(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
 
 
+@pytest.mark.parametrize("m,n,k,tb", [(192, 4100, 4096, 1), (192, 4100, 4096, 0), (64, 1000, 3008, 1), (128, 640, 2048, 0)])
+def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
+    KC.case_dgemm(hk, m, n, k, tb, alpha=1.0, beta=0.0, lda_pad=0, ldb_pad=0)
+    KC.case_dgemm(hk, m, n, k, tb, alpha=-1.0, beta=1.0, lda_pad=2, ldb_pad=4)
+
+
 def test_generators(hk):
     KC.case_toeplitz_randn(hk, n=700)
 
