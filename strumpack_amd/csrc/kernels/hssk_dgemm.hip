@@ -55,26 +55,35 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
 
-  const double* Ak = A + i0 + kbeg * lda;
+  const double* Ak = A + i0 + kbeg * lda;  // (advanced by the FULL-path loader)
   const double* Bk = TRANSB ? B + j0 + kbeg * ldb : B + j0 * ldb + kbeg;
   const long long stepA = (long long)BK * lda, stepB = TRANSB ? (long long)BK * ldb : (long long)BK;
   const long long nst = (kend - kbeg + BK - 1) / BK;  // stages
 
+  // MFMAs of one k-stage; the LDS fragments of sub-step ks+1 are requested before the MFMAs of
+  // sub-step ks issue, so their latency hides under the 12 x 64-cycle MFMA group
   auto compute = [&](int buf) {
-    const double* as = As + buf * BK * LDA_S;
-    const double* bs = Bs + buf * BK * LDB_S;
+    const double* as = As + buf * BK * LDA_S + wm + l15;
+    const double* bs = Bs + buf * BK * LDB_S + wn + l15;
+    double af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int a = 0; a < MT; a++) af[0][a] = as[l4 * LDA_S + a * 16];
+#pragma unroll
+    for (int b = 0; b < NT; b++) bf[0][b] = bs[l4 * LDB_S + b * 16];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      double af[MT], bf[NT];
+      const int cur = (ks >> 2) & 1, nxt = cur ^ 1;
+      if (ks + 4 < BK) {
 #pragma unroll
-      for (int a = 0; a < MT; a++) af[a] = as[(ks + l4) * LDA_S + wm + a * 16 + l15];
+        for (int a = 0; a < MT; a++) af[nxt][a] = as[(ks + 4 + l4) * LDA_S + a * 16];
 #pragma unroll
-      for (int b = 0; b < NT; b++) bf[b] = bs[(ks + l4) * LDB_S + wn + b * 16 + l15];
+        for (int b = 0; b < NT; b++) bf[nxt][b] = bs[(ks + 4 + l4) * LDB_S + b * 16];
+      }
 #pragma unroll
       for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < NT; b++)  // swapped operands: lane holds C[i = l15][j = l4 + 4r]
-          acc[a][b] = hssk_mfma_f64_16x16x4(bf[b], af[a], acc[a][b]);
+          acc[a][b] = hssk_mfma_f64_16x16x4(bf[cur][b], af[cur][a], acc[a][b]);
     }
   };
 
@@ -101,14 +110,17 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
         ldsB[r] = kk * LDB_S + j;
       }
     }
-    hssk_d2 ra[A2], rb[B2];
-    auto load = [&]() {
+    // two register sets: the global loads of stage s+2 are issued while stage s computes, so every
+    // load has two full MFMA stages (~2.5 us) to land before it is written to LDS
+    hssk_d2 ra0[A2], rb0[B2], ra1[A2], rb1[B2];
+    auto load = [&](hssk_d2 (&ra)[A2], hssk_d2 (&rb)[B2]) {
 #pragma unroll
       for (int r = 0; r < A2; r++) ra[r] = *reinterpret_cast<const hssk_d2*>(Ak + offA[r]);
 #pragma unroll
       for (int r = 0; r < B2; r++) rb[r] = *reinterpret_cast<const hssk_d2*>(Bk + offB[r]);
+      Ak += stepA; Bk += stepB;
     };
-    auto store = [&](int buf) {
+    auto store = [&](int buf, const hssk_d2 (&ra)[A2], const hssk_d2 (&rb)[B2]) {
       double* as = As + buf * BK * LDA_S;
       double* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
@@ -119,19 +131,29 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
         else { bs[ldsB[r]] = rb[r][0]; bs[ldsB[r] + LDB_S] = rb[r][1]; }
       }
     };
-    load();
-    store(0);
+    load(ra0, rb0);                      // stage 0
+    store(0, ra0, rb0);
+    if (nst > 1) load(ra1, rb1);         // stage 1
     __syncthreads();
-    int buf = 0;
-    for (long long st = 0; st + 1 < nst; st++) {
-      Ak += stepA; Bk += stepB;
-      load();               // prefetch stage st+1 into registers
-      compute(buf);         // MFMAs of stage st
-      store(buf ^ 1);
+    long long st = 0;
+    // LDS buffer of stage s is s & 1; register set of stage s is s & 1 as well
+    for (; st + 2 < nst; st += 2) {
+      load(ra0, rb0);                    // stage st+2
+      compute(0);                        // stage st
+      store(1, ra1, rb1);                // stage st+1 (loaded one full stage ago)
       __syncthreads();
-      buf ^= 1;
+      if (st + 3 < nst) load(ra1, rb1);  // stage st+3
+      compute(1);                        // stage st+1
+      store(0, ra0, rb0);                // stage st+2
+      __syncthreads();
     }
-    compute(buf);
+    // here LDS[st & 1 == 0] holds stage st; stage st+1 (if any) sits in (ra1, rb1)
+    compute(0);
+    if (st + 1 < nst) {
+      store(1, ra1, rb1);
+      __syncthreads();
+      compute(1);
+    }
   } else {
     double ra[A_PER_THREAD], rb[B_PER_THREAD];
     auto load = [&](long long k0) {
