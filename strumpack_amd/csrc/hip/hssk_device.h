@@ -38,6 +38,13 @@ __device__ __forceinline__ double hssk_wave_max(double v) {
 __device__ __forceinline__ long long hssk_clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ long long hssk_wallclock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 
+// scheduling hint: ask the backend to interleave `n` groups of {1 MFMA, 1 LDS write}
+#define HSSK_SCHED_MFMA_DSWRITE(n)                         \
+  _Pragma("unroll") for (int s_ = 0; s_ < (n); s_++) {     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     \
+  }
+
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 

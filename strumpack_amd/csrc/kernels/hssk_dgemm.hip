@@ -247,14 +247,17 @@ void launch_dgemm(hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long
     HSSK_LAUNCH((dgemm_kernel<BM, false, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
 }
 
-template <int BM>
-void launch_dgemm_split(hssk_ctx* ctx, int transB, unsigned gn_full, unsigned gn, unsigned gm, unsigned nz, int m,
-                        long long n, long long k, const double* A, long long lda, const double* B, long long ldb,
-                        double* P, long long ldp, long long pstride, long long kchunk) {
-  launch_dgemm<BM, true>(ctx, transB, dim3(gn_full, gm, nz), m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, 0);
-  launch_dgemm<BM, false>(ctx, transB, dim3(gn - gn_full, gm, nz), m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, (int)gn_full);
-}
+}  // namespace
 
+namespace {
+template <bool FULL>
+void launch_bm(int BM, hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
+               long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
+               long long kchunk, int jtile0) {
+  if (BM == 192) launch_dgemm<192, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+  else if (BM == 128) launch_dgemm<128, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+  else launch_dgemm<64, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+}
 }  // namespace
 
 extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long long k, double alpha,
@@ -262,44 +265,61 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
                           double* C, long long ldc) {
   HSSK_API_BEGIN
   if (m <= 0 || n <= 0) return 0;
-  int BM = m > 128 ? 192 : (m > 64 ? 128 : 64);
-  unsigned gm = (unsigned)((m + BM - 1) / BM);
-  unsigned gn = (unsigned)((n + BN - 1) / BN);
-  // split K so that the grid is a near-multiple of the 512 resident workgroup slots (256 CUs x 2)
-  const long long slots = 512;
-  long long tiles = (long long)gm * gn;
-  long long ksteps = (k + BK - 1) / BK;
-  int best = 1;
-  double best_eff = 0.;
-  for (int s = 1; s <= 16; s++) {
-    if (s > 1 && ksteps / s < 64) break;  // keep chunks long enough to amortise the epilogue
-    long long wgs = tiles * s;
-    long long rounds = (wgs + slots - 1) / slots;
-    double eff = (double)wgs / (double)(rounds * slots);
-    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
-  }
-  if (k <= 0) best = 1;
-  long long kchunk = ((ksteps + best - 1) / best) * BK;
-  if (kchunk <= 0) kchunk = BK;
-  int nz = (int)((k + kchunk - 1) / kchunk);
-  if (nz < 1) nz = 1;
-  long long ldp = m;
-  long long pstride = ldp * n;
-  double* P = ctx->scratch(sizeof(double) * (size_t)pstride * nz);
+  const int BM = m > 128 ? 192 : (m > 64 ? 128 : 64);
+  const unsigned gm = (unsigned)((m + BM - 1) / BM);
+  const unsigned gn = (unsigned)((n + BN - 1) / BN);
+  const long long ksteps = (k + BK - 1) / BK;
   // interior tiles take the unmasked 16-byte-load kernel; the ragged last column tile (and any
   // unaligned / odd-sized problem) the masked one
   const bool aligned = (m % BM == 0) && (k % BK == 0) && (lda % 2 == 0) && (ldb % 2 == 0) &&
                        (((size_t)A | (size_t)B) % 16 == 0);
   const unsigned gn_full = aligned ? (unsigned)(n / BN) : 0u;
+  const unsigned gn_edge = gn - gn_full;
+  // split K so that each grid is a near-multiple of the 512 resident workgroup slots (256 CUs x 2)
+  auto pick_split = [&](long long tiles) {
+    const long long slots = 512;
+    int best = 1;
+    double best_eff = 0.;
+    for (int s = 1; s <= 256; s++) {
+      if (s > 1 && ksteps / s < 24) break;  // keep chunks long enough to amortise the epilogue
+      long long wgs = tiles * s;
+      long long rounds = (wgs + slots - 1) / slots;
+      double eff = (double)wgs / (double)(rounds * slots);
+      if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+      if (wgs >= 16 * slots) break;
+    }
+    return k > 0 ? best : 1;
+  };
+  auto chunk_of = [&](int split) {
+    long long c = ((ksteps + split - 1) / split) * BK;
+    return c > 0 ? c : (long long)BK;
+  };
+  const long long ldp = m;
+  const long long n_full = (long long)gn_full * BN, n_edge = n - n_full;
+  long long kchunk_f = BK, kchunk_e = BK;
+  int nz_f = 0, nz_e = 0;
+  if (gn_full) { kchunk_f = chunk_of(pick_split((long long)gm * gn_full)); nz_f = (int)std::max<long long>(1, (k + kchunk_f - 1) / kchunk_f); }
+  if (gn_edge) { kchunk_e = chunk_of(pick_split((long long)gm * gn_edge)); nz_e = (int)std::max<long long>(1, (k + kchunk_e - 1) / kchunk_e); }
+  const long long pstride_f = ldp * n_full, pstride_e = ldp * n_edge;
+  double* P = ctx->scratch(sizeof(double) * (size_t)(pstride_f * nz_f + pstride_e * nz_e + 2));
+  double* Pf = P;
+  double* Pe = P + pstride_f * nz_f;
   hssk_rt::event_record(ctx->ev0, ctx->stream);
-  if (BM == 192) launch_dgemm_split<192>(ctx, transB, gn_full, gn, gm, (unsigned)nz, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
-  else if (BM == 128) launch_dgemm_split<128>(ctx, transB, gn_full, gn, gm, (unsigned)nz, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
-  else launch_dgemm_split<64>(ctx, transB, gn_full, gn, gm, (unsigned)nz, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk);
+  // the edge partials are laid out as if the edge columns started at 0: shift P by -n_full columns
+  if (gn_edge) launch_bm<false>(BM, ctx, transB, dim3(gn_edge, gm, (unsigned)nz_e), m, n, k, A, lda, B, ldb, Pe - n_full * ldp, ldp, pstride_e, kchunk_e, (int)gn_full);
+  if (gn_full) launch_bm<true>(BM, ctx, transB, dim3(gn_full, gm, (unsigned)nz_f), m, n, k, A, lda, B, ldb, Pf, ldp, pstride_f, kchunk_f, 0);
   hssk_rt::event_record(ctx->ev1, ctx->stream);
   ctx->dgemm_timed = true;
-  long long total = (long long)m * n;
-  unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-  HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, n, (const double*)P, ldp, pstride, nz, alpha, beta, C, ldc);
+  if (gn_full) {
+    long long total = (long long)m * n_full;
+    unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, n_full, (const double*)Pf, ldp, pstride_f, nz_f, alpha, beta, C, ldc);
+  }
+  if (gn_edge) {
+    long long total = (long long)m * n_edge;
+    unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, n_edge, (const double*)Pe, ldp, pstride_e, nz_e, alpha, beta, C + n_full * ldc, ldc);
+  }
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -223,15 +223,24 @@ __global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __r
     for (int r = 0; r < RT; r++) a[c][r] = (lane + 64 * r == j0 + wave + 16 * c) ? 1. : 0.;
   int kstart = j0 + 16 * CT - 1;
   if (kstart > kmax - 1) kstart = kmax - 1;
-  for (int k = kstart; k >= 0; k--) {
-    const double tau = taus[k];
-    if (tau == 0.) continue;
-    double vr[RT];
+  // reflector k-1 is fetched (L2) while reflector k is applied
+  double vn[RT], taun = 0.;
+  auto fetch = [&](int k) {
+    taun = k >= 0 ? taus[k] : 0.;
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       const int row = lane + 64 * r;
-      vr[r] = (row > k && row < rows) ? A[row + (size_t)k * p.lda] : (row == k ? 1. : 0.);
+      vn[r] = (k >= 0 && row > k && row < rows) ? A[row + (size_t)k * p.lda] : (row == k ? 1. : 0.);
     }
+  };
+  fetch(kstart);
+  for (int k = kstart; k >= 0; k--) {
+    const double tau = taun;
+    double vr[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) vr[r] = vn[r];
+    fetch(k - 1);
+    if (tau == 0.) continue;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
       const int col = j0 + wave + 16 * c;

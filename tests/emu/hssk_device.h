@@ -61,6 +61,8 @@ inline double hssk_wave_max(double v) {
 inline long long hssk_clock() { return 0; }
 inline long long hssk_wallclock() { return 0; }
 
+#define HSSK_SCHED_MFMA_DSWRITE(n)
+
 #define HSSK_SHARED alignas(16) static thread_local
 #define HSSK_DYN_SHARED(type, name) type* name = (type*)emu::dyn_shared()
 
