@@ -23,10 +23,31 @@ __device__ __forceinline__ int hssk_shfl_xor(int v, int mask) { return __shfl_xo
 __device__ __forceinline__ double hssk_shfl(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int hssk_shfl(int v, int src) { return __shfl(v, src, 64); }
 
+// 64-lane sum on the DPP network (no LDS crossbar): quad swaps, half-row / row mirrors, then the
+// GFX9 row broadcasts; lane 63 ends up with the total, which is read back through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double hssk_dpp_mov0(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double hssk_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
-  return v;
+  v += hssk_dpp_mov0<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += hssk_dpp_mov0<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += hssk_dpp_mov0<0x141, 0xF>(v);  // row_half_mirror
+  v += hssk_dpp_mov0<0x140, 0xF>(v);  // row_mirror      -> every lane holds its 16-lane row sum
+  v += hssk_dpp_mov0<0x142, 0xA>(v);  // row_bcast15 into rows 1, 3
+  v += hssk_dpp_mov0<0x143, 0xC>(v);  // row_bcast31 into rows 2, 3 -> lane 63 holds the total
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+// value of `v` in lane `src` (src must be wave-uniform): v_readlane, no LDS crossbar
+__device__ __forceinline__ double hssk_bcast_lane(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double hssk_wave_max(double v) {
 #pragma unroll

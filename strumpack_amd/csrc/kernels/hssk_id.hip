@@ -17,6 +17,8 @@
 #include "hssk_device.h"
 #include "hssk_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int ID_THREADS = 512;
@@ -165,13 +167,262 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
   if (tid == 0) *p.rank = rank;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident variant (same idea as qr_reg_kernel in hssk_qr.hip): the d x m sample panel lives
+// in the VGPRs of one workgroup -- column j in wave j % NW (slot j / NW), row i in lane i % 64 (slot
+// i / 64).  Columns never move: pivoting only records the order (s_perm) and a per-wave "used" mask;
+// the panel is written back once, in pivoted order, for the triangular solve.  Per Householder step:
+// one LDS hop for the pivot search, one LDS broadcast of the reflector (both double-buffered, two
+// barriers), and per owned column RT fmas + a DPP reduction + RT fmas + the dlaqp2 norm down-date.
+// The global-memory kernel above streams the whole panel (300 KB at the leaf level, > L2 for a full
+// level) from HBM/MALL on every step; here the factorization touches no memory at all.
+// Capacity: d <= 64 RT, m <= NW CT.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void id_reg_kernel(const hssk_id_desc* __restrict__ descs) {
+  HSSK_SHARED double s_v[2 * 64 * RT];
+  HSSK_SHARED double s_vn1[NW * CT];
+  HSSK_SHARED double s_vn2[NW * CT];
+  HSSK_SHARED double s_val[2 * NW];
+  HSSK_SHARED int s_idx[2 * NW];
+  HSSK_SHARED double s_tau[2];
+  HSSK_SHARED double s_r00;
+  HSSK_SHARED int s_stop;
+  HSSK_SHARED int s_perm[NW * CT];
+  HSSK_SHARED int s_pos[NW * CT];
+  const hssk_id_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = p.d, m = p.m, ld = p.ldw;
+  const int kmax = d < m ? d : m;
+  const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
+  double a[CT][RT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    const int col = wave + NW * c;
+    double s = 0.;
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const int row = lane + 64 * r;
+      a[c][r] = (row < d && col < m) ? p.W[row + (size_t)col * ld] : 0.;
+      s += a[c][r] * a[c][r];
+    }
+    s = hssk_wave_sum(s);
+    // squared partial norms: dlaqp2's down-date  vn1 *= sqrt(1 - (R_kj/vn1)^2)  is  N1 -= R_kj^2 and its
+    // cancellation guard  (1-(R/vn1)^2) (vn1/vn2)^2 <= sqrt(eps)  is  N1_new <= sqrt(eps) N2: no div / sqrt
+    if (lane == 0 && col < m) { s_vn1[col] = s; s_vn2[col] = s; }
+  }
+  if (tid == 0) { s_stop = 0; s_r00 = 0.; }
+  for (int j = tid; j < NW * CT; j += NW * 64) s_pos[j] = -1;
+  unsigned used = 0;  // bit c: local column slot c has been chosen as a pivot (wave-uniform)
+  __syncthreads();
+
+  int rank = kmax;
+  for (int k = 0; k < kmax; k++) {
+    const int pb = k & 1;
+    double* sv = s_v + pb * 64 * RT;
+    const int lk = k & 63, rk = k >> 6;
+    // ---- 1. pivot: first arg max over the unused columns
+    {
+      double bv = -1.;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int col = wave + NW * c;
+        if (col < m && !((used >> c) & 1u)) {
+          const double v = s_vn1[col];
+          if (v > bv) { bv = v; bi = col; }  // columns of a wave are visited in increasing order
+        }
+      }
+      if (lane == 0) { s_val[pb * NW + wave] = bv; s_idx[pb * NW + wave] = bi; }
+    }
+    __syncthreads();
+    double gv = s_val[pb * NW];
+    int pcol = s_idx[pb * NW];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+      const double v = s_val[pb * NW + w];
+      const int ix = s_idx[pb * NW + w];
+      if (v > gv || (v == gv && ix < pcol)) { gv = v; pcol = ix; }
+    }
+    const int wp = pcol % NW, cp = pcol / NW;
+    // ---- 2. reflector from the pivot column (dlarfg), owner wave only
+    if (wave == wp) {
+      double oc[RT];
+#pragma unroll
+      for (int r = 0; r < RT; r++) oc[r] = 0.;
+#pragma unroll
+      for (int c = 0; c < CT; c++)
+        if (c == cp) {
+#pragma unroll
+          for (int r = 0; r < RT; r++) oc[r] = a[c][r];
+        }
+      double s = 0., av = 0.;
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const int row = lane + 64 * r;
+        if (row > k && row < d) s += oc[r] * oc[r];
+        if (r == rk) av = oc[r];
+      }
+      const double alpha = hssk_bcast_lane(av, lk);
+      s = hssk_wave_sum(s);
+      double tau = 0., beta = alpha, scal = 1.;
+      if (s != 0.) {
+        double nrm = sqrt(alpha * alpha + s);
+        beta = alpha >= 0. ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scal = 1. / (alpha - beta);
+      }
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const int row = lane + 64 * r;
+        if (row > k && row < d) oc[r] *= scal;
+        sv[row] = row > k ? oc[r] : (row == k ? 1. : 0.);
+        if (row == k) oc[r] = beta;
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++)
+        if (c == cp) {
+#pragma unroll
+          for (int r = 0; r < RT; r++) a[c][r] = oc[r];
+        }
+      used |= 1u << cp;
+      if (lane == 0) {
+        s_tau[pb] = tau;
+        s_perm[k] = pcol;
+        const double ab = fabs(beta);
+        if (k == 0) s_r00 = ab;
+        const double r00 = (k == 0) ? ab : s_r00;
+        // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
+        if ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) s_stop = 1;
+      }
+    }
+    __syncthreads();
+    if (s_stop) { rank = k; break; }
+    const double tau = s_tau[pb];
+    // ---- 3. apply H to the unused columns and down-date their norms (dlaqp2)
+    double vr[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) vr[r] = sv[lane + 64 * r];
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int col = wave + NW * c;
+      if (col < m && !((used >> c) & 1u)) {
+        double dot = 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
+        // wave-shared scalars are read before the collectives; lane 0 rewrites them afterwards
+        const double n1 = s_vn1[col], n2 = s_vn2[col];
+        dot = hssk_wave_sum(dot) * tau;
+        double sel = 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+          a[c][r] -= dot * vr[r];
+          if (r == rk) sel = a[c][r];
+        }
+        const double newk = hssk_bcast_lane(sel, lk);  // R(k, col)
+        double newn1 = n1 - newk * newk;
+        newn1 = newn1 > 0. ? newn1 : 0.;
+        const int recompute = (n1 != 0.) && (newn1 <= tol3z * n2);
+        if (recompute) {
+          double s2 = 0.;
+#pragma unroll
+          for (int r = 0; r < RT; r++) {
+            const int row = lane + 64 * r;
+            if (row > k && row < d) s2 += a[c][r] * a[c][r];
+          }
+          s2 = hssk_wave_sum(s2);
+          newn1 = s2;
+          if (lane == 0) s_vn2[col] = newn1;
+        }
+        if (lane == 0) s_vn1[col] = newn1;
+      }
+    }
+  }
+  if (rank > p.max_rank) rank = p.max_rank;
+  // ---- pivoted column positions: skeleton columns first (pivot order), then the rest
+  __syncthreads();
+  if (tid == 0) {
+    for (int j = 0; j < rank; j++) s_pos[s_perm[j]] = j;
+    int next = rank;
+    for (int col = 0; col < m; col++)
+      if (s_pos[col] < 0) s_pos[col] = next++;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    const int col = wave + NW * c;
+    if (col < m) {
+      const int pos = s_pos[col];
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const int row = lane + 64 * r;
+        if (row < d) p.W[row + (size_t)pos * ld] = a[c][r];
+      }
+      if (lane == 0) p.perm[pos] = col;
+    }
+  }
+  __syncthreads();
+  // ---- X = R11^{-1} R12 in place.  rank <= 64: one column per wave, x(l) in lane l, R11 staged in
+  // LDS (reusing the reflector buffer is too small: separate array), each back-substitution step is
+  // one LDS row read + a DPP reduction.  Larger ranks: one column per thread from global memory.
+  double* __restrict__ W = p.W;
+  if (rank <= 64) {
+    HSSK_SHARED double s_R[64 * 65];
+    for (int e = tid; e < rank * rank; e += NW * 64) {
+      const int i = e % rank, l = e / rank;
+      s_R[i + l * 65] = W[i + (size_t)l * ld];
+    }
+    __syncthreads();
+    for (int j = rank + wave; j < m; j += NW) {
+      double* xcol = W + (size_t)j * ld;
+      double x = lane < rank ? xcol[lane] : 0.;
+      for (int i = rank - 1; i >= 0; i--) {
+        const double t = (lane > i && lane < rank) ? s_R[i + lane * 65] * x : 0.;
+        const double s = hssk_wave_sum(t);
+        if (lane == i) x = (x - s) / s_R[i + i * 65];
+      }
+      if (lane < rank) xcol[lane] = x;
+    }
+  } else {
+    for (int j = rank + tid; j < m; j += NW * 64) {
+      double* x = W + (size_t)j * ld;
+      for (int i = rank - 1; i >= 0; i--) {
+        double s = x[i];
+        for (int l = i + 1; l < rank; l++) s -= W[i + (size_t)l * ld] * x[l];
+        x[i] = s / W[i + (size_t)i * ld];
+      }
+    }
+  }
+  if (tid == 0) *p.rank = rank;
+}
+
+template <int RT, int CT>
+void launch_id_reg(hssk_ctx* ctx, const hssk_id_desc* dd, int count) {
+  HSSK_LAUNCH((id_reg_kernel<RT, CT, 16>), dim3((unsigned)count), dim3(1024), 0, ctx->stream, dd);
+}
+template <int RT>
+bool launch_id_reg_ct(hssk_ctx* ctx, const hssk_id_desc* dd, int count, int mmax) {
+  if (mmax <= 64) launch_id_reg<RT, 4>(ctx, dd, count);
+  else if (mmax <= 128) launch_id_reg<RT, 8>(ctx, dd, count);
+  else if (mmax <= 208) launch_id_reg<RT, 13>(ctx, dd, count);
+  else return false;
+  return true;
+}
+
 }  // namespace
 
 extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
+  int dmax = 0, mmax = 0;
+  for (int i = 0; i < count; i++) { dmax = std::max(dmax, descs[i].d); mmax = std::max(mmax, descs[i].m); }
   auto* dd = (const hssk_id_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
+  bool done = false;
+  if (dmax <= 64) done = launch_id_reg_ct<1>(ctx, dd, count, mmax);
+  else if (dmax <= 128) done = launch_id_reg_ct<2>(ctx, dd, count, mmax);
+  else if (dmax <= 192) done = launch_id_reg_ct<3>(ctx, dd, count, mmax);
+  else if (dmax <= 256) done = launch_id_reg_ct<4>(ctx, dd, count, mmax);
+  if (!done) HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
   hssk_rt::check_launch();
   HSSK_API_END
 }

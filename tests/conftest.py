@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # the bundled HIP runtime of torch must be the first one loaded (see strumpack_amd/__init__.py)
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -47,6 +47,7 @@ inline double hssk_shfl_xor(double v, int mask) {
 inline int hssk_shfl_xor(int v, int mask) { return (int)hssk_shfl_xor((double)v, mask); }
 inline double hssk_shfl(double v, int src) { return emu::wave_xchg(v, src & 63); }
 inline int hssk_shfl(int v, int src) { return (int)hssk_shfl((double)v, src); }
+inline double hssk_bcast_lane(double v, int src) { return emu::wave_xchg(v, src & 63); }
 inline double hssk_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
   return v;

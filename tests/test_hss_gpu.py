@@ -76,3 +76,39 @@ def test_full_size_properties(L, n, leaf):
     H.destroy()
     dA.free()
     hk.close()
+
+
+def test_rccl_exchange_hook_single_rank():
+    """The multi-GPU exchange hook (strumpack_amd/dist.py) on real device memory with a 1-rank RCCL
+    group: zero-copy tensor views of engine buffers + in-place all_gather_into_tensor."""
+    import ctypes as C
+    import os
+    import torch
+    import torch.distributed as dist
+    from strumpack_amd import dist as sdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        L = capi.load(_loader.lib_path())
+        hk = K.Hssk(_loader.lib_path())
+        ld, cols = 16, 50
+        a = np.arange(ld * cols, dtype=np.float64).reshape(ld, cols, order="F")
+        dS, dT = hk.array(a), hk.array(2 * a)
+        ex = sdist.make_exchange(L, 1, 0)
+        ex(None, dS.ptr, dT.ptr, ld, cols)
+        assert np.array_equal(dS.get(), a) and np.array_equal(dT.get(), 2 * a)
+        # and the sharded constructor itself with world = 1
+        n = 512
+        dA = hk.empty((n, n))
+        hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
+        hk.sync()
+        o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=64)
+        h = capi.StructuredMatrix.hss_options(L, d0=32, dd=16)
+        H = sdist.from_dense_device(L, dA.ptr, n, n, o, h, ex, world=1, rank=0)
+        assert H.is_compressed()
+        x = np.ones(n)
+        assert np.linalg.norm(H.mult(x)[:, 0] - O.toeplitz(n) @ x) / np.linalg.norm(x) < 1e-4
+    finally:
+        dist.destroy_process_group()

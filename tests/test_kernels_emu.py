@@ -50,6 +50,8 @@ def test_id(hk):
     KC.case_id(hk, [(24, 40, 1e-6, 1e-12, 1000, 7), (24, 16, 1e-10, 1e-14, 1000, None),
                     (12, 30, 1.0, 1e-10, 1000, None), (24, 40, 1e-8, 1e-12, 5, 9),
                     (70, 20, 1e-4, 1e-10, 1000, 4), (8, 1, 1e-4, 1e-10, 1000, None)])
+    KC.case_id(hk, [(192, 150, 1e-6, 1e-12, 1000, 18), (130, 100, 1e-6, 1e-12, 1000, 11)], seed=6)   # <3,13>, <3,8>
+    KC.case_id(hk, [(200, 70, 1e-6, 1e-12, 1000, 9), (48, 210, 1e-6, 1e-12, 1000, 6)], seed=7)        # <4,8>, fallback
 
 
 def test_qr(hk):
