@@ -42,6 +42,9 @@ int hssk_memset_zero(hssk_ctx* ctx, void* dst, long long bytes); /* async */
 int hssk_is_device_pointer(const void* ptr);
 /* timing of the LAST hssk_dgemm launch on this context (HIP events on the launch stream), ms */
 float hssk_last_dgemm_ms(hssk_ctx* ctx);
+/* effective shader clock (GHz) seen by workgroup 0 of the last hssk_dgemm main launch (s_memtime /
+ * s_memrealtime); 0 if unavailable.  Synchronises. */
+double hssk_last_dgemm_clock_ghz(hssk_ctx* ctx);
 
 /* ---- generators --------------------------------------------------------------------------- */
 /* Test matrices of test/test_HSS_seq.cpp:69-91 generated in HBM: kind 'T' Toeplitz

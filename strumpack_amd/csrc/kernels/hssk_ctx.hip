@@ -115,6 +115,16 @@ int hssk_memset_zero(hssk_ctx* c, void* dst, long long bytes) {
 }
 int hssk_is_device_pointer(const void* p) { return hssk_rt::is_device_pointer(p) ? 1 : 0; }
 
+double hssk_last_dgemm_clock_ghz(hssk_ctx* c) {
+  try {
+    if (!c->d_clk) return 0.;
+    long long h[2] = {0, 0};
+    hssk_rt::d2h(h, c->d_clk, sizeof(h), c->stream);
+    hssk_rt::sync(c->stream);
+    return h[1] > 0 ? (double)h[0] / ((double)h[1] / 100e6) * 1e-9 : 0.;
+  } catch (...) { return 0.; }
+}
+
 float hssk_last_dgemm_ms(hssk_ctx* c) {
   if (!c->dgemm_timed) return -1.f;
   try { return hssk_rt::event_elapsed_ms(c->ev0, c->ev1); } catch (...) { return -1.f; }

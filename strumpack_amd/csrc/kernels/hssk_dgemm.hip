@@ -30,7 +30,8 @@ template <int BM, bool TRANSB, bool FULL>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long long k, const double* __restrict__ A,
                                                        long long lda, const double* __restrict__ B, long long ldb,
                                                        double* __restrict__ P, long long ldp, long long pstride,
-                                                       long long kchunk, int jtile0) {
+                                                       long long kchunk, int jtile0, long long* __restrict__ clk) {
+  const long long t0_ = clk ? hssk_clock() : 0, w0_ = clk ? hssk_wallclock() : 0;
   constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
   constexpr int WM = BM / 2;       // rows per wave
   constexpr int MT = WM / 16;      // MFMA tiles per wave along M
@@ -216,6 +217,11 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
         long long gj = j0 + wn + b * 16 + l4 + 4 * r;
         if (gi < m && gj < n) Pz[gi + gj * ldp] = acc[a][b][r];
       }
+  // shader-clock probe (workgroup 0 only): elapsed shader cycles and 100 MHz ticks of this workgroup
+  if (clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    clk[0] = hssk_clock() - t0_;
+    clk[1] = hssk_wallclock() - w0_;
+  }
 }
 
 // C = alpha * sum_z P_z + beta * C   (fixed summation order -> deterministic)
@@ -239,12 +245,12 @@ __global__ void dgemm_reduce_kernel(int m, long long n, const double* __restrict
 template <int BM, bool FULL>
 void launch_dgemm(hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
                   long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
-                  long long kchunk, int jtile0) {
+                  long long kchunk, int jtile0, long long* clk) {
   if (grid.x == 0) return;
   if (transB)
-    HSSK_LAUNCH((dgemm_kernel<BM, true, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+    HSSK_LAUNCH((dgemm_kernel<BM, true, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
   else
-    HSSK_LAUNCH((dgemm_kernel<BM, false, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+    HSSK_LAUNCH((dgemm_kernel<BM, false, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
 }
 
 }  // namespace
@@ -253,10 +259,10 @@ namespace {
 template <bool FULL>
 void launch_bm(int BM, hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
                long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
-               long long kchunk, int jtile0) {
-  if (BM == 192) launch_dgemm<192, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
-  else if (BM == 128) launch_dgemm<128, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
-  else launch_dgemm<64, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0);
+               long long kchunk, int jtile0, long long* clk) {
+  if (BM == 192) launch_dgemm<192, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  else if (BM == 128) launch_dgemm<128, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  else launch_dgemm<64, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
 }
 }  // namespace
 
@@ -301,13 +307,15 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
   if (gn_full) { kchunk_f = chunk_of(pick_split((long long)gm * gn_full)); nz_f = (int)std::max<long long>(1, (k + kchunk_f - 1) / kchunk_f); }
   if (gn_edge) { kchunk_e = chunk_of(pick_split((long long)gm * gn_edge)); nz_e = (int)std::max<long long>(1, (k + kchunk_e - 1) / kchunk_e); }
   const long long pstride_f = ldp * n_full, pstride_e = ldp * n_edge;
-  double* P = ctx->scratch(sizeof(double) * (size_t)(pstride_f * nz_f + pstride_e * nz_e + 2));
+  double* P = ctx->scratch(sizeof(double) * (size_t)(pstride_f * nz_f + pstride_e * nz_e + 4));
+  long long* clk = (long long*)(P + pstride_f * nz_f + pstride_e * nz_e);  // clock probe of workgroup 0
   double* Pf = P;
   double* Pe = P + pstride_f * nz_f;
   hssk_rt::event_record(ctx->ev0, ctx->stream);
   // the edge partials are laid out as if the edge columns started at 0: shift P by -n_full columns
-  if (gn_edge) launch_bm<false>(BM, ctx, transB, dim3(gn_edge, gm, (unsigned)nz_e), m, n, k, A, lda, B, ldb, Pe - n_full * ldp, ldp, pstride_e, kchunk_e, (int)gn_full);
-  if (gn_full) launch_bm<true>(BM, ctx, transB, dim3(gn_full, gm, (unsigned)nz_f), m, n, k, A, lda, B, ldb, Pf, ldp, pstride_f, kchunk_f, 0);
+  if (gn_edge) launch_bm<false>(BM, ctx, transB, dim3(gn_edge, gm, (unsigned)nz_e), m, n, k, A, lda, B, ldb, Pe - n_full * ldp, ldp, pstride_e, kchunk_e, (int)gn_full, nullptr);
+  if (gn_full) launch_bm<true>(BM, ctx, transB, dim3(gn_full, gm, (unsigned)nz_f), m, n, k, A, lda, B, ldb, Pf, ldp, pstride_f, kchunk_f, 0, clk);
+  ctx->d_clk = gn_full ? clk : nullptr;
   hssk_rt::event_record(ctx->ev1, ctx->stream);
   ctx->dgemm_timed = true;
   if (gn_full) {

@@ -87,7 +87,7 @@ HSSK_SYMBOLS = [
     "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
     "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops", "hssk_memcpy_d2d",
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
-    "hssk_basis_dense", "hssk_mfma_f64_probe",
+    "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz",
 ]
 
 
@@ -154,6 +154,8 @@ class Hssk:
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                       C.c_longlong, C.c_longlong]
         L.hssk_is_device_pointer.argtypes = [C.c_void_p]
+        L.hssk_last_dgemm_clock_ghz.restype = C.c_double
+        L.hssk_last_dgemm_clock_ghz.argtypes = [C.c_void_p]
         L.hssk_last_dgemm_ms.restype = C.c_float
         L.hssk_last_dgemm_ms.argtypes = [C.c_void_p]
         L.hssk_fill_toeplitz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_char]
