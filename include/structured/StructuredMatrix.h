@@ -75,14 +75,17 @@ int SPX_d_struct_from_dense_hss(CSPStructMat* S, int rows, int cols, const doubl
 /* A is a DEVICE pointer (column-major, ldA); nothing is copied, A is borrowed for the call */
 int SPX_d_struct_from_dense_device(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                    const CSPOptions* opts, const SPXHSSOptions* h);
-/* one process per GPU: this rank computes the sample columns of its shard, then calls
- * exchange(user, dSrt, dSct, ld, cols_per_rank): an in-place all-gather of the equally sized, contiguous
- * column blocks (ld * cols_per_rank doubles per rank, rank r at offset r * ld * cols_per_rank) of both
- * device arrays -- RCCL over xGMI in production (strumpack_amd/dist.py), gloo in the CPU tests */
-typedef void (*SPXExchangeFn)(void* user, double* dSrt, double* dSct, long long ld, long long cols_per_rank);
+/* one process per GPU.  With 2^c ranks rank g owns the g-th subtree at depth c (its sketch columns,
+ * compression, ULV factors and sweeps: no communication); the top of the tree is replicated after small
+ * all-gathers of the cut nodes' reduced blocks.  allgather(user, dbuf, bytes_per_rank) must perform an
+ * IN-PLACE all-gather of the DEVICE buffer dbuf of world * bytes_per_rank bytes (rank r contributes the
+ * block at offset r * bytes_per_rank) -- RCCL over xGMI in production (strumpack_amd/dist.py), gloo in
+ * the CPU tests.  The same hook is used by factor / solve / mult of the returned matrix, so it must
+ * stay valid for the matrix' lifetime; every rank must call the same operations in the same order. */
+typedef void (*SPXAllGatherFn)(void* user, void* dbuf, long long bytes_per_rank);
 int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                            const CSPOptions* opts, const SPXHSSOptions* h, int world, int rank,
-                                           SPXExchangeFn exchange, void* user);
+                                           SPXAllGatherFn allgather, void* user);
 int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB,
                              double* dC, long long ldC);
 int SPX_d_struct_solve_device(const CSPStructMat S, int nrhs, double* dB, long long ldB);

@@ -29,7 +29,7 @@ SP_SYMBOLS = [
     "SPX_d_struct_node_info", "SPX_d_struct_stats", "SPX_d_struct_hssk_ctx",
 ]
 ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
-EXCHANGE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong)
+ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
 STAT_NAMES = ["t_compress", "t_sketch", "t_random", "t_tree", "t_factor", "t_solve", "t_mult",
               "sketch_kernel_ms", "sketch_launches", "rounds", "d_final", "f_sketch", "f_local",
               "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory"]
@@ -59,7 +59,7 @@ def load(path):
                                                  C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions)]
     L.SPX_d_struct_from_dense_device_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_longlong,
                                                          C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions),
-                                                         C.c_int, C.c_int, EXCHANGE_CB, vp]
+                                                         C.c_int, C.c_int, ALLGATHER_CB, vp]
     L.SPX_d_struct_mult_device.argtypes = [vp, C.c_char, C.c_int, dp, C.c_longlong, dp, C.c_longlong]
     L.SPX_d_struct_solve_device.argtypes = [vp, C.c_int, dp, C.c_longlong]
     L.SPX_d_struct_node_info.argtypes = [vp, C.POINTER(C.c_int)]

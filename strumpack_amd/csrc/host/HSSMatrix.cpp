@@ -46,9 +46,9 @@ void HSSMatrix<double>::compress_device(const double* dA, long long lda, const o
   eng_->compress_dense_device(dA, lda);
 }
 void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda, const opts_t& opts, int world, int rank,
-                                                void (*fn)(void*, double*, double*, long long, long long), void* user) {
+                                                void (*fn)(void*, void*, long long), void* user) {
   EngineOptions e = engine_options(opts);
-  e.world = world; e.rank = rank; e.exchange = fn; e.exchange_user = user;
+  e.world = world; e.rank = rank; e.allgather = fn; e.comm_user = user;
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
   eng_->compress_dense_device(dA, lda);
 }

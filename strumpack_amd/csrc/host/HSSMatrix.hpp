@@ -38,9 +38,10 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   void compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts);
   // extension: A resident in HBM
   void compress_device(const double* dA, long long lda, const opts_t& opts);
-  // extension: one process per GPU; sketch columns sharded over `world` ranks, blocks exchanged by `fn`
+  // extension: one process per GPU (subtree ownership below the cut level, replicated top);
+  // `allgather` is an in-place all-gather of a device buffer (RCCL)
   void compress_device_sharded(const double* dA, long long lda, const opts_t& opts, int world, int rank,
-                               void (*fn)(void*, double*, double*, long long, long long), void* user);
+                               void (*allgather)(void*, void*, long long), void* user);
 
   std::size_t rows() const override { return rows_; }
   std::size_t cols() const override { return cols_; }

@@ -135,7 +135,7 @@ int SPX_d_struct_from_dense_device(CSPStructMat* S, int rows, int cols, const do
 }
 int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                            const CSPOptions* opts, const SPXHSSOptions* h, int world, int rank,
-                                           SPXExchangeFn exchange, void* user) {
+                                           SPXAllGatherFn exchange, void* user) {
   SP_TRY
   if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("sharded construction requires type SP_TYPE_HSS");
   if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");

@@ -155,9 +155,14 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
     const long long N = H.n_;
     // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout.
     // Multi-GPU: this rank computes the sample columns [j0, j1) only (rows j0:j1 of A for Sr,
-    // columns j0:j1 of A for Sc); the blocks are then all-gathered (RCCL) by the exchange hook.
+    // columns j0:j1 of A for Sc).
     long long j0 = 0, j1 = N;
-    if (H.o_.world > 1) { j0 = std::min(N, H.cols_per_rank_ * H.o_.rank); j1 = std::min(N, j0 + H.cols_per_rank_); }
+    if (H.dist_subtree_) {           // this rank's subtree range: nothing is exchanged here
+      const Node& c = H.nodes_[H.cut_nodes_[H.o_.rank]];
+      j0 = c.lo; j1 = c.lo + c.m;
+    } else if (H.o_.world > 1) {     // fallback: equal column shards + all-gather of the samples
+      j0 = std::min(N, H.cols_per_rank_ * H.o_.rank); j1 = std::min(N, j0 + H.cols_per_rank_);
+    }
     const long long nloc = j1 - j0;
     if (nloc > 0) {
       ck(hssk_dgemm(H.ctx_, 1, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0, lda, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
@@ -169,9 +174,10 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
       ms = hssk_last_dgemm_ms(H.ctx_);
       if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
     }
-    if (H.o_.world > 1) {
-      if (!H.o_.exchange) throw std::logic_error("multi-GPU compression needs an exchange hook");
-      H.o_.exchange(H.o_.exchange_user, H.Srt_, H.Sct_, H.dcap_, H.cols_per_rank_);
+    if (H.o_.world > 1 && !H.dist_subtree_) {
+      const long long bytes = (long long)sizeof(double) * H.dcap_ * H.cols_per_rank_;
+      H.comm(H.Srt_, bytes);
+      H.comm(H.Sct_, bytes);
     }
   }
   void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
@@ -188,6 +194,7 @@ struct DeviceHSS::CallbackSource : DeviceHSS::Source {
   const host_elem_t& elem;
   CallbackSource(const host_mult_t& m, const host_elem_t& e) : mult(m), elem(e) {}
   void sample(DeviceHSS& H, int r0, int dn) override {
+    if (H.o_.world > 1) throw std::invalid_argument("the host-callback interface is single-GPU");
     const int N = H.n_;
     std::vector<double> Rt((size_t)dn * N), R((size_t)N * dn), S((size_t)N * dn), St((size_t)dn * N);
     ck(hssk_memcpy2d_d2h(H.ctx_, Rt.data(), sizeof(double) * dn, H.Rt_ + r0, sizeof(double) * H.dcap_, sizeof(double) * dn, N));
@@ -221,7 +228,9 @@ DeviceHSS::DeviceHSS(int n, const EngineOptions& opts, const structured::Cluster
   work_.reset(new Arena(size_t(256) << 20));
   fact_.reset(new Arena(size_t(64) << 20));
   tmp_.reset(new Arena(size_t(64) << 20));
+  comm_arena_.reset(new Arena(size_t(64) << 20));
   build_tree(tree);
+  setup_ownership();
 }
 
 DeviceHSS::~DeviceHSS() {
@@ -230,6 +239,7 @@ DeviceHSS::~DeviceHSS() {
   work_.reset();
   fact_.reset();
   tmp_.reset();
+  comm_arena_.reset();
   hssk_ctx_destroy(ctx_);
 }
 
@@ -262,6 +272,198 @@ void DeviceHSS::build_tree(const structured::ClusterTree* tree) {
     by_depth_[nodes_[i].lvl].push_back(i);
   }
   d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: subtree ownership.  With G = 2^c ranks and a tree that is complete down to depth c,
+// rank g owns the subtree rooted at the g-th node of depth c (sketch columns, compression, ULV
+// factors, solve / apply sweeps of that subtree: no communication); the 2^c - 1 nodes above the cut
+// are processed redundantly by every rank after one small all-gather of the cut nodes' reduced blocks
+// per phase (the reference's MPI code splits the tree the same way,
+// HSSMatrixMPI.hpp:408-414).  Otherwise (G not a power of two / shallow tree) only the sketch is
+// sharded and the whole tree is replicated.
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::setup_ownership() {
+  const size_t nn = nodes_.size();
+  owner_.assign(nn, -1);
+  cut_nodes_.clear();
+  dist_subtree_ = false;
+  const int G = o_.world;
+  if (G > 1 && (G & (G - 1)) == 0) {
+    int c = 0;
+    while ((1 << c) < G) c++;
+    std::vector<int> cut;
+    bool ok = true;
+    for (size_t i = 0; i < nn; i++) {
+      if (nodes_[i].lvl == c) cut.push_back((int)i);
+      if (nodes_[i].lvl < c && nodes_[i].leaf()) ok = false;
+    }
+    if (ok && (int)cut.size() == G) {
+      dist_subtree_ = true;
+      cut_nodes_ = cut;  // pre-order == left-to-right
+      for (size_t i = 0; i < nn; i++) {
+        if (nodes_[i].lvl < c) continue;
+        int a = (int)i;
+        while (nodes_[a].lvl > c) a = nodes_[a].parent;
+        for (int g = 0; g < G; g++) if (cut[g] == a) owner_[i] = g;
+      }
+    }
+  }
+  auto split = [&](const std::vector<std::vector<int>>& all, std::vector<std::vector<int>>& own,
+                   std::vector<std::vector<int>>& top) {
+    own.assign(all.size(), {});
+    top.assign(all.size(), {});
+    for (size_t l = 0; l < all.size(); l++)
+      for (int id : all[l]) {
+        if (!dist_subtree_) own[l].push_back(id);
+        else if (owner_[id] < 0) top[l].push_back(id);
+        else if (owner_[id] == o_.rank) own[l].push_back(id);
+      }
+  };
+  split(by_height_, own_by_height_, top_by_height_);
+  split(by_depth_, own_by_depth_, top_by_depth_);
+}
+
+void DeviceHSS::comm(void* dbuf, long long bytes_per_rank) {
+  if (o_.world <= 1) return;
+  if (!o_.allgather) throw std::logic_error("multi-GPU operation needs an all-gather hook");
+  ck(hssk_sync(ctx_));
+  o_.allgather(o_.comm_user, dbuf, bytes_per_rank);
+}
+
+// v holds world * per_rank ints; this rank's block is valid on entry, all blocks on return
+void DeviceHSS::allgather_ints(std::vector<int>& v, int per_rank) {
+  const size_t bytes = sizeof(int) * (size_t)per_rank;
+  int* d = comm_arena_->ints((size_t)per_rank * o_.world);
+  ck(hssk_memcpy_h2d(ctx_, d + (size_t)per_rank * o_.rank, v.data() + (size_t)per_rank * o_.rank, (long long)bytes));
+  comm(d, (long long)bytes);
+  ck(hssk_memcpy_d2h(ctx_, v.data(), d, (long long)(bytes * o_.world)));
+}
+
+// after the owned subtrees of a compression round: publish the cut nodes to every rank
+void DeviceHSS::exchange_cut_compress(int dtot) {
+  const int G = o_.world, me = o_.rank;
+  std::vector<int> meta(4 * (size_t)G, 0);
+  {
+    const Node& c = nodes_[cut_nodes_[me]];
+    meta[4 * me] = c.Ustate; meta[4 * me + 1] = c.Vstate; meta[4 * me + 2] = c.rU; meta[4 * me + 3] = c.rV;
+  }
+  allgather_ints(meta, 4);
+  int rmax = 0;
+  for (int g = 0; g < G; g++) {
+    Node& c = nodes_[cut_nodes_[g]];
+    if (g != me) { c.Ustate = meta[4 * g]; c.Vstate = meta[4 * g + 1]; c.rU = meta[4 * g + 2]; c.rV = meta[4 * g + 3]; }
+    if (c.compressed()) rmax = std::max(rmax, std::max(c.rU, c.rV));
+  }
+  if (rmax == 0) return;
+  // index sets (host -> all ranks)
+  std::vector<int> idx(2 * (size_t)rmax * G, 0);
+  {
+    const Node& c = nodes_[cut_nodes_[me]];
+    if (c.compressed()) {
+      std::copy(c.Ir.begin(), c.Ir.end(), idx.begin() + 2 * (size_t)rmax * me);
+      std::copy(c.Ic.begin(), c.Ic.end(), idx.begin() + 2 * (size_t)rmax * me + rmax);
+    }
+  }
+  allgather_ints(idx, 2 * rmax);
+  int* didx = work_->ints(2 * (size_t)rmax * G + rmax);
+  ck(hssk_memcpy_h2d(ctx_, didx, idx.data(), (long long)(sizeof(int) * idx.size())));
+  std::vector<int> iota(rmax);
+  for (int i = 0; i < rmax; i++) iota[i] = i;
+  int* diota = didx + 2 * (size_t)rmax * G;
+  ck(hssk_memcpy_h2d(ctx_, diota, iota.data(), (long long)(sizeof(int) * rmax)));
+  // panels: [Srt(:, Jr) | Sct(:, Jc) | RrtRed | RctRed], each dcap x rmax, leading dimension dcap
+  const size_t pan = (size_t)dcap_ * rmax, blk = 4 * pan;
+  double* buf = work_->dbl(blk * G);
+  {
+    Node& c = nodes_[cut_nodes_[me]];
+    if (c.compressed()) {
+      double* slot = buf + blk * me;
+      std::vector<hssk_colgather_desc> g;
+      g.push_back(hssk_colgather_desc{c.Srt, slot, c.permU, dtot, c.rU, dcap_, dcap_, 0});
+      g.push_back(hssk_colgather_desc{c.Sct, slot + pan, c.permV, dtot, c.rV, dcap_, dcap_, 0});
+      g.push_back(hssk_colgather_desc{c.RrtRed, slot + 2 * pan, nullptr, dtot, c.rV, dcap_, dcap_, 0});
+      g.push_back(hssk_colgather_desc{c.RctRed, slot + 3 * pan, nullptr, dtot, c.rU, dcap_, dcap_, 0});
+      ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
+    }
+  }
+  comm(buf, (long long)(sizeof(double) * blk));
+  for (int g = 0; g < G; g++) {
+    if (g == me) continue;
+    Node& c = nodes_[cut_nodes_[g]];
+    if (!c.compressed()) continue;
+    double* slot = buf + blk * g;
+    c.Srt = slot; c.Sct = slot + pan; c.RrtRed = slot + 2 * pan; c.RctRed = slot + 3 * pan;
+    c.permU = c.permV = diota;  // the received panels hold the skeleton columns only, in order
+    c.dIr = didx + 2 * (size_t)rmax * g;
+    c.dIc = c.dIr + rmax;
+    c.Ir.assign(idx.begin() + 2 * (size_t)rmax * g, idx.begin() + 2 * (size_t)rmax * g + c.rU);
+    c.Ic.assign(idx.begin() + 2 * (size_t)rmax * g + rmax, idx.begin() + 2 * (size_t)rmax * g + rmax + c.rV);
+    c.panels = true;
+  }
+}
+
+// ranks / basis sizes of every node, for introspection and buffer sizing on all ranks
+void DeviceHSS::exchange_node_table() {
+  const size_t nn = nodes_.size();
+  std::vector<int> t(4 * nn * (size_t)o_.world, 0);
+  int* mineblk = t.data() + 4 * nn * (size_t)o_.rank;
+  for (size_t i = 0; i < nn; i++)
+    if (owner_[i] == o_.rank) { mineblk[4 * i] = nodes_[i].rU; mineblk[4 * i + 1] = nodes_[i].rV; mineblk[4 * i + 2] = nodes_[i].mU; mineblk[4 * i + 3] = nodes_[i].mV; }
+  allgather_ints(t, (int)(4 * nn));
+  for (size_t i = 0; i < nn; i++) {
+    const int g = owner_[i];
+    if (g < 0 || g == o_.rank) continue;
+    const int* b = t.data() + 4 * nn * (size_t)g + 4 * i;
+    nodes_[i].rU = b[0]; nodes_[i].rV = b[1]; nodes_[i].mU = b[2]; nodes_[i].mV = b[3];
+    nodes_[i].Ustate = nodes_[i].Vstate = 2;
+  }
+}
+
+// after the owned subtrees of the ULV factorization: Dt (rU x rU) and Vt1 (rU x rV) of the cut nodes
+void DeviceHSS::exchange_cut_factor() {
+  const int G = o_.world, me = o_.rank;
+  size_t blk = 1;
+  for (int g = 0; g < G; g++) {
+    const Node& c = nodes_[cut_nodes_[g]];
+    blk = std::max(blk, (size_t)c.rU * c.rU + (size_t)c.rU * c.rV);
+  }
+  double* buf = fact_->dbl(blk * G);
+  {
+    const Node& c = nodes_[cut_nodes_[me]];
+    double* slot = buf + blk * me;
+    if (c.rU) ck(hssk_memcpy_d2d(ctx_, slot, c.Dt, (long long)(sizeof(double) * c.rU * c.rU)));
+    if (c.rU && c.rV) ck(hssk_memcpy_d2d(ctx_, slot + (size_t)c.rU * c.rU, c.Vt1, (long long)(sizeof(double) * c.rU * c.rV)));
+  }
+  comm(buf, (long long)(sizeof(double) * blk));
+  for (int g = 0; g < G; g++) {
+    if (g == me) continue;
+    Node& c = nodes_[cut_nodes_[g]];
+    c.Dt = buf + blk * g;
+    c.Vt1 = c.Dt + (size_t)c.rU * c.rU;
+  }
+}
+
+// every rank holds its own row range of dx (n x nrhs, ldx): make all ranges available everywhere
+void DeviceHSS::allgather_rows(double* dx, long long ldx, int nrhs) {
+  const int G = o_.world, me = o_.rank;
+  int mmax = 0;
+  for (int g = 0; g < G; g++) mmax = std::max(mmax, nodes_[cut_nodes_[g]].m);
+  const size_t blk = (size_t)mmax * nrhs;
+  double* buf = tmp_->dbl(blk * G);
+  const Node& c = nodes_[cut_nodes_[me]];
+  hssk_rowgather_desc pk{dx + c.lo, buf + blk * me, nullptr, c.m, nrhs, (int)ldx, mmax, 0, 0};
+  ck(hssk_gather_rows(ctx_, &pk, 1));
+  comm(buf, (long long)(sizeof(double) * blk));
+  std::vector<hssk_rowgather_desc> up;
+  for (int g = 0; g < G; g++) {
+    if (g == me) continue;
+    const Node& o = nodes_[cut_nodes_[g]];
+    up.push_back(hssk_rowgather_desc{buf + blk * g, dx + o.lo, nullptr, o.m, nrhs, mmax, (int)ldx, 0, 0});
+  }
+  if (!up.empty()) ck(hssk_gather_rows(ctx_, up.data(), (int)up.size()));
+  ck(hssk_sync(ctx_));
 }
 
 bool DeviceHSS::is_compressed() const { return nodes_[0].compressed(); }
@@ -354,7 +556,9 @@ void DeviceHSS::compress(Source& src) {
                 // restarted run retraces the same samples and continues past the old capacity)
     if (o_.verbose) std::cout << "# HSS compression: growing the sample capacity to " << dcap << std::endl;
   }
+  if (dist_subtree_) exchange_node_table();
   free_compress_workspace();
+  comm_arena_->reset();
   stats_.t_compress = now() - t0;
   stats_.t_tree = stats_.t_compress - stats_.t_sketch - stats_.t_random;
 }
@@ -418,7 +622,11 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       stats_.f_sketch += 4.0 * (double)N * (double)N * dnew;
       if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
       stats_.rounds++;
-      for (auto& ids : by_height_) process_level(src, ids, d, dd, false);
+      for (auto& ids : own_by_height_) process_level(src, ids, d, dd, false);
+      if (dist_subtree_) {
+        exchange_cut_compress(d + dd);
+        for (auto& ids : top_by_height_) process_level(src, ids, d, dd, false);
+      }
       stats_.d_final = d + dd;
       if (!is_compressed()) {
         d += dd;
@@ -439,7 +647,11 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       stats_.f_sketch += 4.0 * (double)N * (double)N * (d - d_old);
       if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << " (original)" << std::endl;
       stats_.rounds++;
-      for (auto& ids : by_height_) process_level(src, ids, d, d - d_old, true);
+      for (auto& ids : own_by_height_) process_level(src, ids, d, d - d_old, true);
+      if (dist_subtree_) {
+        exchange_cut_compress(d);
+        for (auto& ids : top_by_height_) process_level(src, ids, d, d - d_old, true);
+      }
       stats_.d_final = d;
       if (!is_compressed()) {
         d_old = d;
@@ -855,17 +1067,17 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   auto mout = [&](const Node& nd) { return T ? nd.mV : nd.mU; };
   for (size_t i = 0; i < nn; i++) {
     const Node& nd = nodes_[i];
-    if (nd.leaf()) continue;
+    if (nd.leaf() || !mine((int)i)) continue;
     int ci = rin(nodes_[nd.c0]) + rin(nodes_[nd.c1]);
     int co = rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]);
     cat[i] = tmp.dbl((size_t)std::max(ci, 1) * nrhs);
     tbuf[i] = tmp.dbl((size_t)std::max(co, 1) * nrhs);
   }
-  // ---- up-sweep: tmp1 = Vin^H [..]
-  for (size_t h = 0; h < by_height_.size(); h++) {
+  // ---- up-sweep, one height: tmp1 = Vin^H [..]
+  auto up = [&](const std::vector<int>& ids) {
     std::vector<hssk_rowgather_desc> g;
     std::vector<hssk_gemm_desc> mm;
-    for (int id : by_height_[h]) {
+    for (int id : ids) {
       const Node& nd = nodes_[id];
       if (nd.lvl == 0) continue;
       const Node& pa = nodes_[nd.parent];
@@ -887,12 +1099,12 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
     }
     if (!g.empty()) ck(hssk_gather_rows(ctx_, g.data(), (int)g.size()));
     if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
-  }
-  // ---- down-sweep by depth
-  for (size_t dpt = 0; dpt < by_depth_.size(); dpt++) {
+  };
+  // ---- down-sweep, one depth
+  auto down = [&](const std::vector<int>& ids) {
     std::vector<hssk_gemm_desc> m1, leafmm, innermm;  // m1: basis expansion X^T tmp2
     std::vector<hssk_rowgather_desc> sc;
-    for (int id : by_depth_[dpt]) {
+    for (int id : ids) {
       const Node& nd = nodes_[id];
       const int mo = mout(nd), ro = rout(nd);
       const int* perm = T ? nd.permV : nd.permU;
@@ -944,7 +1156,42 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
     if (!m1.empty()) ck(hssk_gemm_vbatched(ctx_, m1.data(), (int)m1.size()));
     if (!sc.empty()) ck(hssk_gather_rows(ctx_, sc.data(), (int)sc.size()));
     if (!innermm.empty()) ck(hssk_gemm_vbatched(ctx_, innermm.data(), (int)innermm.size()));
+  };
+  for (auto& ids : own_by_height_) up(ids);
+  if (dist_subtree_) {
+    // publish tmp1 (rin x nrhs) of the cut nodes into every rank's top buffers
+    const int G = o_.world, me = o_.rank;
+    int rm = 1;
+    for (int g = 0; g < G; g++) rm = std::max(rm, rin(nodes_[cut_nodes_[g]]));
+    const size_t blk = (size_t)rm * nrhs;
+    double* buf = tmp.dbl(blk * G);
+    auto slice = [&](int g, double*& p1, int& ld1) {
+      const int id = cut_nodes_[g];
+      const Node& pa = nodes_[nodes_[id].parent];
+      p1 = cat[nodes_[id].parent] + (id == pa.c0 ? 0 : rin(nodes_[pa.c0]));
+      ld1 = std::max(rin(nodes_[pa.c0]) + rin(nodes_[pa.c1]), 1);
+    };
+    {
+      double* p1; int ld1;
+      slice(me, p1, ld1);
+      const int r = rin(nodes_[cut_nodes_[me]]);
+      if (r) { hssk_rowgather_desc pk{p1, buf + blk * me, nullptr, r, nrhs, ld1, rm, 0, 0}; ck(hssk_gather_rows(ctx_, &pk, 1)); }
+    }
+    comm(buf, (long long)(sizeof(double) * blk));
+    std::vector<hssk_rowgather_desc> upk;
+    for (int g = 0; g < G; g++) {
+      if (g == me) continue;
+      double* p1; int ld1;
+      slice(g, p1, ld1);
+      const int r = rin(nodes_[cut_nodes_[g]]);
+      if (r) upk.push_back(hssk_rowgather_desc{buf + blk * g, p1, nullptr, r, nrhs, rm, ld1, 0, 0});
+    }
+    if (!upk.empty()) ck(hssk_gather_rows(ctx_, upk.data(), (int)upk.size()));
+    for (auto& ids : top_by_height_) up(ids);
+    for (auto& ids : top_by_depth_) down(ids);
   }
+  for (auto& ids : own_by_depth_) down(ids);
+  if (dist_subtree_) allgather_rows(dy, ly, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, y, sizeof(double) * ldy, dy, sizeof(double) * N, sizeof(double) * N, nrhs));
   ck(hssk_sync(ctx_));
   stats_.t_mult = now() - t0;
@@ -962,8 +1209,8 @@ void DeviceHSS::factor() {
   for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nullptr, nd.piv = nullptr;
   const size_t nn = nodes_.size();
   std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr);
-  for (size_t h = 0; h < by_height_.size(); h++) {
-    const std::vector<int>& ids = by_height_[h];
+  auto level = [&](const std::vector<int>& ids) {
+    if (ids.empty()) return;
     // ---- assemble Dh (mU x mU) and Vh (mU x rV)
     std::vector<hssk_colgather_desc> cp;
     std::vector<hssk_gemm_desc> g0, g1;
@@ -1056,6 +1303,11 @@ void DeviceHSS::factor() {
     if (!g3.empty()) ck(hssk_gemm_vbatched(ctx_, g3.data(), (int)g3.size()));
     if (!lu.empty()) ck(hssk_getrf_vbatched(ctx_, lu.data(), (int)lu.size()));
     ck(hssk_sync(ctx_));  // tmp released
+  };
+  for (auto& ids : own_by_height_) level(ids);
+  if (dist_subtree_) {
+    exchange_cut_factor();
+    for (auto& ids : top_by_height_) level(ids);
   }
   factored_ = true;
   stats_.t_factor = now() - t0;
@@ -1085,49 +1337,36 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   // y: (mU - rU) rows; zc: children's z stacked (mV rows); xb: solution in the node's basis (mU rows)
   std::vector<double*> f(nn, nullptr), y(nn, nullptr), zc(nn, nullptr), xb(nn, nullptr);
   for (size_t i = 0; i < nn; i++) {
+    if (!mine((int)i)) continue;
     const Node& nd = nodes_[i];
     const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
     const int mv = nd.leaf() ? nd.m : nodes_[nd.c0].rV + nodes_[nd.c1].rV;
     if (!nd.leaf()) {
       f[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
       zc[i] = tmp.dbl((size_t)std::max(mv, 1) * nrhs);
+      xb[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
     }
     if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
-    if (!nd.leaf()) xb[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
   }
-  // ---- forward
-  for (size_t h = 0; h < by_height_.size(); h++) {
+  // ---- forward, one tree height
+  auto fwd = [&](const std::vector<int>& ids) {
+    if (ids.empty()) return;
     std::vector<hssk_gemm_desc> ga, gb, gc, gd, ge;
     std::vector<hssk_rowgather_desc> rg;
     std::vector<hssk_trsm_desc> ts;
     std::vector<hssk_lusolve_desc> ls;
-    for (int id : by_height_[h]) {
+    for (int id : ids) {
       const Node& nd = nodes_[id];
-      if (!nd.leaf()) {
-        const int ldf = std::max(nodes_[nd.c0].rU + nodes_[nd.c1].rU, 1);
-        const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
-        // f0 = ft1_0 - B01 z_1 - W1_0 (Q0_0^T y_0) ; f1 likewise (solve.hpp:88-131); ft1 already in f
-        const int lz = std::max(a.rV + c.rV, 1);
-        ga.push_back(hssk_gemm_desc{nd.B01, zc[id] + a.rV, f[id], a.rU, nrhs, c.rV, std::max(a.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
-        ga.push_back(hssk_gemm_desc{nd.B10, zc[id], f[id] + a.rU, c.rU, nrhs, a.rV, std::max(c.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
-        const Node* ch[2] = {&a, &c};
-        const int cid[2] = {nd.c0, nd.c1};
-        for (int q = 0; q < 2; q++) {
-          const Node& cn = *ch[q];
-          const int mc = cn.mU, rc = cn.rU;
-          if (mc > rc && rc > 0) {
-            double* t = tmp.dbl((size_t)mc * nrhs);
-            // t = Q0^T y = Q~(:, :mc-rc) y ; f_q -= W1 t
-            gb.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], t, mc, nrhs, mc - rc, mc, mc - rc, mc, 0, 0, 1.0, 0.0});
-            gc.push_back(hssk_gemm_desc{cn.W1, t, f[id] + (q ? a.rU : 0), rc, nrhs, mc, rc, mc, ldf, 0, 0, -1.0, 1.0});
-          }
-        }
-      }
+      if (nd.leaf()) continue;
+      const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+      const int ldf = std::max(a.rU + c.rU, 1), lz = std::max(a.rV + c.rV, 1);
+      // f0 = ft1_0 - B01 z_1 ; f1 = ft1_1 - B10 z_0   (solve.hpp:88-99).  The children already wrote
+      // ft1 - W1 (Q0^T y) into f (the -W1 Q0^T y term of solve.hpp:100-131 only needs child data).
+      ga.push_back(hssk_gemm_desc{nd.B01, zc[id] + a.rV, f[id], a.rU, nrhs, c.rV, std::max(a.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
+      ga.push_back(hssk_gemm_desc{nd.B10, zc[id], f[id] + a.rU, c.rU, nrhs, a.rV, std::max(c.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
     }
     if (!ga.empty()) ck(hssk_gemm_vbatched(ctx_, ga.data(), (int)ga.size()));
-    if (!gb.empty()) ck(hssk_gemm_vbatched(ctx_, gb.data(), (int)gb.size()));
-    if (!gc.empty()) ck(hssk_gemm_vbatched(ctx_, gc.data(), (int)gc.size()));
-    for (int id : by_height_[h]) {
+    for (int id : ids) {
       const Node& nd = nodes_[id];
       const double* fsrc = nd.leaf() ? db + nd.lo : f[id];
       const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
@@ -1153,6 +1392,12 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
         rg.push_back(hssk_rowgather_desc{fsrc, y[id], nd.permU + r, m - r, nrhs, ldf, m - r, 0, 0});
         if (r) gd.push_back(hssk_gemm_desc{nd.XU, ft1, y[id], m - r, nrhs, r, r, ldp, m - r, 1, 0, -1.0, 1.0});
         ts.push_back(hssk_trsm_desc{nd.Rlq, y[id], m - r, nrhs, m, m - r, 0, 1, 0});
+        if (r) {
+          // ft1 -= W1 (Q0^T y),  Q0^T y = Q~(:, :m-r) y
+          double* t = tmp.dbl((size_t)m * nrhs);
+          gb.push_back(hssk_gemm_desc{nd.Qt, y[id], t, m, nrhs, m - r, m, m - r, m, 0, 0, 1.0, 0.0});
+          gc.push_back(hssk_gemm_desc{nd.W1, t, ft1, r, nrhs, m, r, m, ldp, 0, 0, -1.0, 1.0});
+        }
       }
       // z = V^H [z0; z1] + Vt0^H y   (leaf: z = Vt0^H y)          (solve.hpp:164-192)
       const int rv = nd.rV;
@@ -1176,13 +1421,15 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!gd.empty()) ck(hssk_gemm_vbatched(ctx_, gd.data(), (int)gd.size()));
     if (!ts.empty()) ck(hssk_trsm_vbatched(ctx_, ts.data(), (int)ts.size()));
     if (!ge.empty()) ck(hssk_gemm_vbatched(ctx_, ge.data(), (int)ge.size()));
+    if (!gb.empty()) ck(hssk_gemm_vbatched(ctx_, gb.data(), (int)gb.size()));
+    if (!gc.empty()) ck(hssk_gemm_vbatched(ctx_, gc.data(), (int)gc.size()));
     if (!ls.empty()) ck(hssk_getrs_vbatched(ctx_, ls.data(), (int)ls.size()));
-  }
-  // ---- backward (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
-  for (size_t dpt = 0; dpt < by_depth_.size(); dpt++) {
+  };
+  // ---- backward, one depth (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
+  auto bwd = [&](const std::vector<int>& ids) {
     std::vector<hssk_gemm_desc> g1, g2;
     std::vector<hssk_rowgather_desc> cp;
-    for (int id : by_depth_[dpt]) {
+    for (int id : ids) {
       const Node& nd = nodes_[id];
       if (nd.leaf()) continue;
       const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
@@ -1192,6 +1439,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
       const Node* ch[2] = {&a, &c};
       const int cid[2] = {nd.c0, nd.c1};
       for (int q = 0; q < 2; q++) {
+        if (!mine(cid[q])) continue;  // the other ranks' subtrees continue on their owners
         const Node& cn = *ch[q];
         const int mc = cn.mU, rc = cn.rU;
         const double* xpart = x + (q ? a.rU : 0);
@@ -1208,7 +1456,48 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!g1.empty()) ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
     if (!cp.empty()) ck(hssk_gather_rows(ctx_, cp.data(), (int)cp.size()));
+  };
+  for (auto& ids : own_by_height_) fwd(ids);
+  if (dist_subtree_) {
+    // publish ft1' (rU x nrhs) and z (rV x nrhs) of the cut nodes into every rank's top buffers
+    const int G = o_.world, me = o_.rank;
+    int ru = 1, rv = 1;
+    for (int g = 0; g < G; g++) { ru = std::max(ru, nodes_[cut_nodes_[g]].rU); rv = std::max(rv, nodes_[cut_nodes_[g]].rV); }
+    const size_t blk = (size_t)(ru + rv) * nrhs;
+    double* buf = tmp.dbl(blk * G);
+    auto slices = [&](int g, double*& pf, int& ldf, double*& pz, int& ldz) {
+      const int id = cut_nodes_[g];
+      const Node& pa = nodes_[nodes_[id].parent];
+      pf = f[nodes_[id].parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+      ldf = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+      pz = zc[nodes_[id].parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+      ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+    };
+    {
+      double *pf, *pz; int ldf, ldz;
+      slices(me, pf, ldf, pz, ldz);
+      const Node& c = nodes_[cut_nodes_[me]];
+      std::vector<hssk_rowgather_desc> pk;
+      if (c.rU) pk.push_back(hssk_rowgather_desc{pf, buf + blk * me, nullptr, c.rU, nrhs, ldf, ru, 0, 0});
+      if (c.rV) pk.push_back(hssk_rowgather_desc{pz, buf + blk * me + (size_t)ru * nrhs, nullptr, c.rV, nrhs, ldz, rv, 0, 0});
+      if (!pk.empty()) ck(hssk_gather_rows(ctx_, pk.data(), (int)pk.size()));
+    }
+    comm(buf, (long long)(sizeof(double) * blk));
+    std::vector<hssk_rowgather_desc> up;
+    for (int g = 0; g < G; g++) {
+      if (g == me) continue;
+      double *pf, *pz; int ldf, ldz;
+      slices(g, pf, ldf, pz, ldz);
+      const Node& c = nodes_[cut_nodes_[g]];
+      if (c.rU) up.push_back(hssk_rowgather_desc{buf + blk * g, pf, nullptr, c.rU, nrhs, ru, ldf, 0, 0});
+      if (c.rV) up.push_back(hssk_rowgather_desc{buf + blk * g + (size_t)ru * nrhs, pz, nullptr, c.rV, nrhs, rv, ldz, 0, 0});
+    }
+    if (!up.empty()) ck(hssk_gather_rows(ctx_, up.data(), (int)up.size()));
+    for (auto& ids : top_by_height_) fwd(ids);
+    for (auto& ids : top_by_depth_) bwd(ids);
   }
+  for (auto& ids : own_by_depth_) bwd(ids);
+  if (dist_subtree_) allgather_rows(db, lb, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
   ck(hssk_sync(ctx_));
   stats_.t_solve = now() - t0;

@@ -31,11 +31,12 @@ struct EngineOptions {
   int random_dist = 0;    // 0 normal, 1 uniform
   bool verbose = false;
   int device = 0;
-  // multi-GPU: the sketch columns are sharded over `world` ranks (one process per GPU); after each
-  // sketch the column blocks are all-gathered through `exchange` (RCCL, provided by the caller)
+  // multi-GPU (one process per GPU): `allgather` is an in-place all-gather of a DEVICE buffer of
+  // world * bytes_per_rank bytes (rank r contributes the block at offset r * bytes_per_rank) --
+  // RCCL over xGMI in production (strumpack_amd/dist.py), gloo in the CPU tests
   int world = 1, rank = 0;
-  void (*exchange)(void* user, double* dSrt, double* dSct, long long ld, long long cols_per_rank) = nullptr;
-  void* exchange_user = nullptr;
+  void (*allgather)(void* user, void* dbuf, long long bytes_per_rank) = nullptr;
+  void* comm_user = nullptr;
 };
 
 // host callbacks of the matrix-free / element interfaces (column-major host buffers)
@@ -131,12 +132,27 @@ class DeviceHSS {
                   std::vector<char>& resolved);
   void free_compress_workspace();
   void ensure_ready(const char* what) const;
+  // ---- multi-GPU: subtree ownership below the cut level, replicated top
+  bool mine(int id) const { return owner_[id] < 0 || owner_[id] == o_.rank; }
+  void setup_ownership();
+  void comm(void* dbuf, long long bytes_per_rank);
+  void allgather_ints(std::vector<int>& v, int per_rank);
+  void exchange_cut_compress(int dtot);
+  void exchange_node_table();
+  void exchange_cut_factor();
+  void allgather_rows(double* dx, long long ldx, int nrhs);
 
   int n_;
   EngineOptions o_;
   hssk_ctx* ctx_ = nullptr;
   std::vector<Node> nodes_;
   std::vector<std::vector<int>> by_height_, by_depth_;
+  // nodes of this rank's subtree (depth >= cut) and the replicated top (depth < cut); without
+  // subtree distribution own_* hold every node and top_* are empty
+  std::vector<std::vector<int>> own_by_height_, top_by_height_, own_by_depth_, top_by_depth_;
+  std::vector<int> owner_, cut_nodes_;
+  bool dist_subtree_ = false;
+  std::unique_ptr<Arena> comm_arena_;
   std::unique_ptr<Arena> persist_, work_, fact_, tmp_;
   // global transposed sample arrays (dcap x N)
   double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;

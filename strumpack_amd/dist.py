@@ -1,11 +1,12 @@
 """Multi-GPU glue: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
 
-The hot path shards where the flops are: rank g computes the sketch columns of its shard
-(S^T[:, cols_g] = R^T A[cols_g, :]^T and R^T A[:, cols_g], 98 % of the work, no communication), the
-shards are exchanged with ONE in-place all-gather per sample array and round (d x N doubles = 154 MB
-at N = 1e5, d = 192), and the O(N r^2) tree phase runs replicated on every rank.  The native engine
-calls back into `exchange` (SPXExchangeFn) at that point; PyTorch is only plumbing here (zero-copy
-tensor views of the engine's device arrays + the collective).
+The HSS tree is partitioned by subtree: with 2^c ranks, rank g owns the g-th subtree at depth c -- its
+rows of the sketch (98 % of the flops), its nodes' compression, ULV factors and solve / apply sweeps, all
+without communication -- and the 2^c - 1 nodes above the cut are processed redundantly by every rank
+after small all-gathers of the cut nodes' reduced blocks (r x d samples, r x r factor blocks, r x nrhs
+vectors; a few hundred KB), plus one all-gather of the solution rows.  The native engine calls back
+into `allgather` (SPXAllGatherFn: in-place all-gather of a device buffer); PyTorch is only plumbing
+here (a zero-copy tensor view of the engine's device buffer + the collective).
 """
 import ctypes as C
 
@@ -22,6 +23,20 @@ class _CudaView:
                                          "version": 2, "strides": None}
 
 
+class _CudaView32:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _tensor32(ptr, count, on_device):
+    import torch
+    if on_device:
+        return torch.as_tensor(_CudaView32(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+    buf = (C.c_int * count).from_address(int(ptr))
+    return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+
 def _tensor(ptr, count, on_device):
     import torch
     if on_device:
@@ -31,28 +46,32 @@ def _tensor(ptr, count, on_device):
 
 
 def make_exchange(lib, world, rank):
-    """Returns the SPXExchangeFn callback object (keep it alive while the matrix is constructed)."""
+    """Returns the SPXAllGatherFn callback object (keep it alive as long as the matrix lives)."""
     import torch
     import torch.distributed as dist
     lib.hssk_is_device_pointer.argtypes = [C.c_void_p]
 
-    def exchange(user, dSrt, dSct, ld, cols_per_rank):
-        shard = int(ld) * int(cols_per_rank)
-        on_dev = bool(lib.hssk_is_device_pointer(dSrt))
-        for ptr in (dSrt, dSct):
-            full = _tensor(ptr, shard * world, on_dev)
-            mine = full[rank * shard:(rank + 1) * shard]
-            if on_dev:
-                dist.all_gather_into_tensor(full, mine)
-            else:  # gloo (CPU tests): list form, copy back
-                parts = [torch.empty_like(mine) for _ in range(world)]
-                dist.all_gather(parts, mine.clone())
-                for r, prt in enumerate(parts):
-                    full[r * shard:(r + 1) * shard] = prt
+    def allgather(user, dbuf, bytes_per_rank):
+        n = int(bytes_per_rank) // 8
+        rem = int(bytes_per_rank) % 8
+        assert rem == 0 or int(bytes_per_rank) % 4 == 0
+        on_dev = bool(lib.hssk_is_device_pointer(dbuf))
+        if rem:  # int payloads of odd length: view as 4-byte words
+            full = _tensor32(dbuf, int(bytes_per_rank) // 4 * world, on_dev)
+            n = int(bytes_per_rank) // 4
+        else:
+            full = _tensor(dbuf, n * world, on_dev)
+        mine = full[rank * n:(rank + 1) * n]
         if on_dev:
+            dist.all_gather_into_tensor(full, mine)
             torch.cuda.synchronize()
+        else:  # gloo (CPU tests): list form, copy back
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine.clone())
+            for r, prt in enumerate(parts):
+                full[r * n:(r + 1) * n] = prt
 
-    return capi.EXCHANGE_CB(exchange)
+    return capi.ALLGATHER_CB(allgather)
 
 
 def from_dense_device(lib, dptr, n, lda, opts, hss, exchange_cb=None, world=None, rank=None):

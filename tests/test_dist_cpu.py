@@ -1,10 +1,12 @@
-"""N > 1 path on CPU: two processes (gloo, world_size 2) run the sharded-sketch construction on the
-emulator build and must reproduce the single-process matrix bit-for-bit."""
+"""N > 1 path on CPU: several processes (gloo) run the subtree-distributed construction / factor /
+solve / mult on the emulator build and must reproduce the single-process matrix (same ranks on every
+node, same products and solutions to rounding).  world = 2, 4: subtree ownership below the cut;
+world = 3: fallback (sharded sketch, replicated tree)."""
 import os
 import subprocess
 import sys
 
-import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
@@ -18,37 +20,52 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 L = capi.load(emu_lib.PATH)
 hk = K.Hssk(emu_lib.PATH)
-n = 203                                   # odd: the last shard is ragged
-A = O.toeplitz(n)
-dA = hk.array(A)
-o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=32)
-h = capi.StructuredMatrix.hss_options(L, d0=16, dd=8)
-ex = sdist.make_exchange(L, world, rank)
-H = sdist.from_dense_device(L, dA.ptr, n, n, o, h, ex)
-H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)   # unsharded, same process
-b = np.linspace(-1, 1, n)
-same = np.array_equal(H.node_info(), H1.node_info()) and np.array_equal(H.mult(b), H1.mult(b))
-H.factor(); x = H.solve(b)
-res = np.linalg.norm(H.mult(x) - b.reshape(-1, 1)) / np.linalg.norm(b)
-t = torch.tensor([float(same), float(res < 1e-12)])
+ok = True
+CASES = {2: [(203, 16, 16, 8, "stable"), (120, 16, 16, 8, "original")], 4: [(170, 16, 8, 8, "stable")], 3: [(110, 16, 16, 8, "stable")]}
+for (n, leaf, d0, dd, algo) in CASES[world]:
+    A = O.toeplitz(n)
+    dA = hk.array(A)
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo)
+    ex = sdist.make_exchange(L, world, rank)
+    H = sdist.from_dense_device(L, dA.ptr, n, n, o, h, ex)
+    H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)   # single-process reference
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 3))
+    same_tree = np.array_equal(H.node_info(), H1.node_info())
+    y, y1 = H.mult(B), H1.mult(B)
+    yt, yt1 = H.mult(B, "T"), H1.mult(B, "T")
+    H.factor(); H1.factor()
+    x, x1 = H.solve(B), H1.solve(B)
+    e_mult = np.linalg.norm(y - y1) / np.linalg.norm(y1)
+    e_multT = np.linalg.norm(yt - yt1) / np.linalg.norm(yt1)
+    e_solve = np.linalg.norm(x - x1) / np.linalg.norm(x1)
+    res = np.linalg.norm(H.mult(x) - B) / np.linalg.norm(B)
+    good = same_tree and e_mult < 1e-11 and e_multT < 1e-11 and e_solve < 1e-9 and res < 1e-12 and H.stats()["rounds"] == H1.stats()["rounds"]
+    if not good:
+        print("rank", rank, "case", n, leaf, algo, same_tree, e_mult, e_multT, e_solve, res, flush=True)
+    ok = ok and good
+    H.destroy(); H1.destroy()
+t = torch.tensor([float(ok)])
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 if rank == 0:
-    print("DIST_OK" if t.min().item() == 1.0 else "DIST_FAIL", H.rank(), res)
+    print("DIST_OK" if t.item() == 1.0 else "DIST_FAIL", flush=True)
 dist.destroy_process_group()
 '''
 
 
-def test_sharded_sketch_two_ranks(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 3])
+def test_distributed_hss(tmp_path, world):
     import emu_lib
     emu_lib.build()
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSSK_EMU_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + world), HSSK_EMU_THREADS="2")
     procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), WORLD_SIZE="2")
+    for r in range(world):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "DIST_OK" in outs[0], outs[0]
+    assert "DIST_OK" in outs[0], "\n".join(outs)
