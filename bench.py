@@ -34,7 +34,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=100000)
+    p.add_argument("--size", dest="n", type=int, default=100000)
     p.add_argument("--leaf", type=int, default=256)
     p.add_argument("--rel-tol", type=float, default=1e-4)
     p.add_argument("--nrhs", type=int, default=1)
@@ -83,10 +83,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if os.environ.get("STRUMPACK_AMD_SHARE_GPU"):  # functional check only: several ranks on one GPU
+        local = 0
     torch.cuda.set_device(local)
     os.environ["STRUMPACK_AMD_DEVICE"] = str(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(os.environ.get("STRUMPACK_AMD_BACKEND", "nccl"),
+                                **({"device_id": torch.device("cuda", local)} if os.environ.get("STRUMPACK_AMD_BACKEND", "nccl") == "nccl" else {}))
     from strumpack_amd import _loader, capi, dist as sdist
     from strumpack_amd import hssk as K
     L = capi.load(_loader.lib_path())
@@ -176,7 +179,7 @@ def main():
                                "(d0+dd=128+64, Philox samples), leaf=%d, rel_tol=%g, compress + ULV factor + solve (nrhs=%d)"
                                % (n, n, a.leaf, a.rel_tol, a.nrhs),
                    "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
-                   "parallelism": "1 GPU" if world == 1 else "sketch sharded over %d GPUs (RCCL all-gather), tree replicated" % world},
+                   "parallelism": "1 GPU" if world == 1 else "HSS tree partitioned by subtree over %d GPUs (sketch rows, compression, ULV, sweeps local; RCCL all-gathers of the cut-level blocks; top %d nodes replicated)" % (world, world - 1)},
         "phases_s": {"compress": st["t_compress"], "sketch": st["t_sketch"], "random": st["t_random"],
                      "tree": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
         "flops": {"sketch": st["f_sketch"], "local": st["f_local"], "reduce": st["f_reduce"], "id": st["f_id"],

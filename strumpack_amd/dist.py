@@ -9,6 +9,7 @@ into `allgather` (SPXAllGatherFn: in-place all-gather of a device buffer); PyTor
 here (a zero-copy tensor view of the engine's device buffer + the collective).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -51,7 +52,21 @@ def make_exchange(lib, world, rank):
     import torch.distributed as dist
     lib.hssk_is_device_pointer.argtypes = [C.c_void_p]
 
+    debug = bool(os.environ.get("STRUMPACK_AMD_DEBUG_COMM"))
+    counter = [0]
+
     def allgather(user, dbuf, bytes_per_rank):
+        try:
+            _allgather(dbuf, bytes_per_rank)
+        except BaseException:  # an exception cannot propagate through the C caller: fail loudly
+            import traceback
+            traceback.print_exc()
+            os._exit(3)
+
+    def _allgather(dbuf, bytes_per_rank):
+        counter[0] += 1
+        if debug:
+            print("[comm] rank %d call %d bytes_per_rank %d" % (rank, counter[0], bytes_per_rank), flush=True)
         n = int(bytes_per_rank) // 8
         rem = int(bytes_per_rank) % 8
         assert rem == 0 or int(bytes_per_rank) % 4 == 0
@@ -62,14 +77,17 @@ def make_exchange(lib, world, rank):
         else:
             full = _tensor(dbuf, n * world, on_dev)
         mine = full[rank * n:(rank + 1) * n]
-        if on_dev:
-            dist.all_gather_into_tensor(full, mine)
+        if on_dev and dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(full, mine)   # RCCL, in place
             torch.cuda.synchronize()
-        else:  # gloo (CPU tests): list form, copy back
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine.clone())
+        else:  # gloo (CPU tests, or several ranks sharing one GPU): list form through host memory
+            src = mine.cpu() if on_dev else mine.clone()
+            parts = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(parts, src)
             for r, prt in enumerate(parts):
-                full[r * n:(r + 1) * n] = prt
+                full[r * n:(r + 1) * n] = prt.to(full.device) if on_dev else prt
+            if on_dev:
+                torch.cuda.synchronize()
 
     return capi.ALLGATHER_CB(allgather)
 
