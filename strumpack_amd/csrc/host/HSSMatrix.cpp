@@ -9,7 +9,9 @@ EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
   EngineOptions e;
   e.rel_tol = o.rel_tol(); e.abs_tol = o.abs_tol(); e.leaf_size = o.leaf_size(); e.max_rank = o.max_rank();
   e.d0 = o.d0(); e.dd = o.dd(); e.p = o.p();
-  e.algorithm = o.compression_algorithm() == CompressionAlgorithm::ORIGINAL ? 0 : 1;
+  // HARD_RESTART shares the acceptance rule of ORIGINAL (compress.hpp:235-298) and differs only in
+  // re-using nothing from a failed round; it is run as ORIGINAL here
+  e.algorithm = o.compression_algorithm() == CompressionAlgorithm::STABLE ? 1 : 0;
   e.random_engine = o.random_engine() == random::RandomEngine::LINEAR ? 0 : (o.random_engine() == random::RandomEngine::MERSENNE ? 1 : 2);
   e.random_dist = o.random_distribution() == random::RandomDistribution::NORMAL ? 0 : 1;
   e.verbose = o.verbose();
@@ -122,6 +124,22 @@ DenseMatrix<double> HSSMatrix<double>::dense() const {
   }
   return D;
 }
+
+DenseMatrix<double> HSSMatrix<double>::extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const {
+  DenseM_t E(cols_, J.size()), HE(rows_, J.size()), B(I.size(), J.size());
+  for (std::size_t j = 0; j < J.size(); j++) {
+    if (J[j] >= cols_) throw std::invalid_argument("extract: column index out of range");
+    E(J[j], j) = 1.;
+  }
+  if (!J.empty()) eng_->mult('N', int(J.size()), E.data(), E.ld(), HE.data(), HE.ld(), false, 0.);
+  for (std::size_t j = 0; j < J.size(); j++)
+    for (std::size_t i = 0; i < I.size(); i++) {
+      if (I[i] >= rows_) throw std::invalid_argument("extract: row index out of range");
+      B(i, j) = HE(I[i], j);
+    }
+  return B;
+}
+double HSSMatrix<double>::get(std::size_t i, std::size_t j) const { return extract({i}, {j})(0, 0); }
 
 void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
   if (!eng_) return;

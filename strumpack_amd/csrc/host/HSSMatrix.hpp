@@ -61,6 +61,9 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   using structured::StructuredMatrix<double>::solve;
   void shift(scalar_t sigma) override;
   DenseM_t dense() const;
+  // H(I, J) and H(i, j) (reference: HSSMatrix.extract.hpp:36-104; here via |J| unit-vector products)
+  DenseM_t extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const;
+  scalar_t get(std::size_t i, std::size_t j) const;
   void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
 
   // device-resident operands (extension)

@@ -1,0 +1,111 @@
+// C++ driver over the reference-shaped classes (strumpack::HSS::HSSMatrix<double>, HSSOptions,
+// DenseMatrix): same command line, same checks and same pass/fail thresholds as the reference's
+// test/test_HSS_seq.cpp (:38-39 tolerances, :143-152 compression error, :193-233 element / sub-block
+// extraction, :235-250 ULV solve), written against this repository's headers.  Links either the product
+// library (GPU tests) or the emulator build (CPU tests).
+//   test_HSS_seq T|U|L n [--hss_leaf_size ...] [--hss_rel_tol ...] ...
+#include <cmath>
+#include <iostream>
+#include <random>
+
+#include "HSSMatrix.hpp"
+
+using namespace strumpack;
+using namespace strumpack::HSS;
+
+#define ERROR_TOLERANCE 1e2
+#define SOLVE_TOLERANCE 1e-12
+
+int main(int argc, char* argv[]) {
+  if (argc < 3) { std::cout << "usage: test_HSS_seq T|U|L n [HSS options]" << std::endl; return 2; }
+  const char prob = argv[1][0];
+  const int m = std::stoi(argv[2]);
+  HSSOptions<double> hss_opts;
+  hss_opts.set_verbose(false);
+  hss_opts.set_from_command_line(argc, argv);
+
+  DenseMatrix<double> A(m, m);
+  if (prob == 'T' || prob == 'U') {
+    for (int j = 0; j < m; j++)
+      for (int i = 0; i < m; i++) {
+        A(i, j) = (i == j) ? 1. : 1. / (1 + std::abs(i - j));
+        if (prob == 'U' && i > j) A(i, j) = 0.;
+      }
+  } else {  // 'L': identity + (1/m) U V^T, U == V from the default generator
+    const int k = std::max(1, int(0.3 * m));
+    DenseMatrix<double> U(m, k);
+    U.random();
+    A.eye();
+    for (int j = 0; j < m; j++)
+      for (int i = 0; i < m; i++) {
+        double s = 0;
+        for (int l = 0; l < k; l++) s += U(i, l) * U(j, l);
+        A(i, j) += s / m;
+      }
+  }
+  std::cout << "# tol = " << hss_opts.rel_tol() << std::endl;
+  HSSMatrix<double> H(A, hss_opts);
+  if (!H.is_compressed()) { std::cout << "# compression failed!!!!!!!!" << std::endl; return 1; }
+  std::cout << "# created H matrix of dimension " << H.rows() << " x " << H.cols() << " with " << H.levels()
+            << " levels" << std::endl << "# compression succeeded!" << std::endl;
+  std::cout << "# rank(H) = " << H.rank() << std::endl;
+  std::cout << "# memory(H) = " << H.memory() / 1e6 << " MB, " << 100. * H.memory() / A.memory() << "% of dense" << std::endl;
+
+  auto Hdense = H.dense();
+  Hdense.scaled_add(-1., A);
+  const double tol = ERROR_TOLERANCE * std::max(hss_opts.rel_tol(), hss_opts.abs_tol());
+  std::cout << "# relative error = ||A-H*I||_F/||A||_F = " << Hdense.normF() / A.normF() << std::endl;
+  if (Hdense.normF() / A.normF() > tol) { std::cout << "ERROR: compression error too big!!" << std::endl; return 1; }
+
+  // transposed product against the dense matrix
+  {
+    DenseMatrix<double> B(m, 3), C(m, 3), Cc(m, 3);
+    B.random();
+    apply_HSS(Trans::C, H, B, 0., C);
+    for (int j = 0; j < 3; j++)
+      for (int i = 0; i < m; i++) { double s = 0; for (int l = 0; l < m; l++) s += A(l, i) * B(l, j); Cc(i, j) = s; }
+    C.scaled_add(-1., Cc);
+    std::cout << "# relative error = ||H'*B-A'*B||_F/||A'*B||_F = " << C.normF() / Cc.normF() << std::endl;
+    if (C.normF() / Cc.normF() > tol) { std::cout << "ERROR: transposed product error too big!!" << std::endl; return 1; }
+  }
+
+  std::default_random_engine gen;
+  std::uniform_int_distribution<std::size_t> random_idx(0, m - 1);
+  double ex_err = 0;
+  const int iex = 5;
+  for (int i = 0; i < iex; i++) { auto r = random_idx(gen), c = random_idx(gen); ex_err += std::abs(H.get(r, c) - A(r, c)); }
+  std::cout << "# extracting individual elements, avg error = " << ex_err / iex << std::endl;
+  if (ex_err / iex > tol) { std::cout << "ERROR: extraction error too big!!" << std::endl; return 1; }
+  std::vector<std::size_t> I, J;
+  for (int i = 0; i < 8; i++) I.push_back(random_idx(gen));
+  for (int j = 0; j < 8; j++) J.push_back(random_idx(gen));
+  auto sub = H.extract(I, J);
+  DenseMatrix<double> sub_dense(8, 8);
+  for (int j = 0; j < 8; j++) for (int i = 0; i < 8; i++) sub_dense(i, j) = A(I[i], J[j]);
+  sub.scaled_add(-1., sub_dense);
+  std::cout << "# sub-matrix extraction error = " << sub.normF() / sub_dense.normF() << std::endl;
+  if (sub.normF() / sub_dense.normF() > tol) { std::cout << "ERROR: extraction error too big!!" << std::endl; return 1; }
+
+  std::cout << "# computing ULV factorization of HSS matrix .." << std::endl;
+  H.factor();
+  std::cout << "# solving linear system .." << std::endl;
+  DenseMatrix<double> B(m, 1);
+  B.random();
+  DenseMatrix<double> C(B);
+  H.solve(C);
+  auto Bcheck = H.apply(C);
+  Bcheck.scaled_add(-1., B);
+  std::cout << "# relative error = ||B-H*(H\\B)||_F/||B||_F = " << Bcheck.normF() / B.normF() << std::endl;
+  if (Bcheck.normF() / B.normF() > SOLVE_TOLERANCE) { std::cout << "ERROR: ULV solve relative error too big!!" << std::endl; return 1; }
+
+  // shift + re-factor (structured API semantics)
+  H.shift(1.5);
+  H.factor();
+  DenseMatrix<double> X(B);
+  H.solve(X);
+  auto R = H.apply(X);
+  R.scaled_add(-1., B);
+  if (R.normF() / B.normF() > SOLVE_TOLERANCE) { std::cout << "ERROR: solve after shift failed" << std::endl; return 1; }
+  std::cout << "# exiting" << std::endl;
+  return 0;
+}

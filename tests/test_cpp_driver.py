@@ -1,0 +1,58 @@
+"""The C++ driver tests/cpp/test_HSS_seq.cpp (reference-shaped classes, reference's command line and
+pass criteria) over a subset of the reference's CTest lines (test/CMakeLists.txt:57-143).
+CPU: linked against the emulator build; GPU (-m gpu): linked against the product library."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "strumpack_amd", "csrc", "host")
+SRC = os.path.join(ROOT, "tests", "cpp", "test_HSS_seq.cpp")
+
+LINES = [
+    "L 10 --hss_leaf_size 3 --hss_rel_tol 1e-5 --hss_abs_tol 1e-10 --hss_disable_sync --hss_compression_algorithm stable --hss_d0 32 --hss_dd 4",
+    "T 200 --hss_leaf_size 128 --hss_rel_tol 1 --hss_abs_tol 1e-10 --hss_disable_sync --hss_compression_algorithm stable --hss_d0 128 --hss_dd 8",
+    "U 200 --hss_leaf_size 16 --hss_rel_tol 1e-1 --hss_abs_tol 1e-10 --hss_disable_sync --hss_compression_algorithm stable --hss_d0 128 --hss_dd 4",
+    "T 10 --hss_leaf_size 16 --hss_rel_tol 1e-10 --hss_abs_tol 1e-10 --hss_enable_sync --hss_compression_algorithm original --hss_d0 128 --hss_dd 4",
+]
+GPU_LINES = LINES + [
+    "T 500 --hss_leaf_size 128 --hss_rel_tol 1e-10 --hss_abs_tol 1e-13 --hss_disable_sync --hss_compression_algorithm stable --hss_d0 16 --hss_dd 4",
+    "L 500 --hss_leaf_size 16 --hss_rel_tol 1e-10 --hss_abs_tol 1e-10 --hss_disable_sync --hss_compression_algorithm original --hss_d0 128 --hss_dd 8",
+    "T 1000 --hss_leaf_size 32 --hss_rel_tol 1e-5 --hss_abs_tol 1e-10 --hss_enable_sync --hss_compression_algorithm stable --hss_d0 8 --hss_dd 8 --hss_compression_sketch Gaussian",
+    "T 4096",
+    "T 8192 --hss_leaf_size 256 --hss_rel_tol 1e-4",
+]
+
+
+def build(libdir, libname, out):
+    cmd = ["g++", "-O2", "-std=c++17", "-I" + HOST, "-I" + os.path.join(ROOT, "include"), SRC, "-o", out,
+           "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def run(exe, line):
+    r = subprocess.run([exe] + line.split(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "# exiting" in r.stdout
+
+
+@pytest.fixture(scope="module")
+def emu_exe(tmp_path_factory):
+    import emu_lib
+    emu_lib.build()
+    return build(os.path.dirname(emu_lib.PATH), "strumpack_amd_emu", str(tmp_path_factory.mktemp("cpp") / "test_HSS_seq_emu"))
+
+
+@pytest.mark.parametrize("line", LINES)
+def test_cpp_driver_emulator(emu_exe, line):
+    run(emu_exe, line)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("line", GPU_LINES)
+def test_cpp_driver_gpu(tmp_path_factory, line):
+    from strumpack_amd import _loader
+    exe = build(os.path.dirname(_loader.lib_path()), "strumpack_amd", str(tmp_path_factory.mktemp("cpp") / "test_HSS_seq"))
+    run(exe, line)
