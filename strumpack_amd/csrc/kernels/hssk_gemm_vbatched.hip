@@ -16,6 +16,7 @@
 #include "hssk_device.h"
 #include "hssk_internal.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -127,22 +128,194 @@ __global__ void gemm_scale_kernel(const hssk_gemm_desc* __restrict__ descs, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Panel variant for the sample-update GEMMs of a level:  C(m x n) = alpha A(m x k) op(B) + beta C with
+// m = the sample count d (<= 192) -- the bulk of the batched-GEMM flops (leaf level: 2 x 192 x b x b per
+// leaf).  One workgroup owns all m rows of a 32-column tile (4 wave64 stacked along M, 48 x 32 each = 3 x 2
+// MFMA tiles), so the A panel (R^T, contiguous, 16-byte loads) is staged once per column tile and the
+// narrow tile wastes little on ragged n (b = 195 / 196 -> 7 tiles, 87 % useful columns; 64-wide: 77 %).
+// K advances 16 per stage through double-buffered LDS with a register prefetch of the next stage.
+// ------------------------------------------------------------------------------------------------
+constexpr int PBM = 192, PBN = 32, PBK = 16;
+constexpr int PLDA = PBM + 16, PLDB = PBN + 16;
+
+template <bool TRANSB>
+__global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const hssk_gemm_desc* __restrict__ descs,
+                                                            const Tile* __restrict__ tiles) {
+  HSSK_SHARED double As[2 * PBK * PLDA];
+  HSSK_SHARED double Bs[2 * PBK * PLDB];
+  const Tile t = tiles[blockIdx.x];
+  if (t.prob < 0) return;  // padding entry of the XCD-aware work list
+  const hssk_gemm_desc p = descs[t.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int j0 = t.tn * PBN;
+  const int wm = wave * 48;
+  const int m = p.m, n = p.n, k = p.k;
+  const double* __restrict__ A = p.A;
+  const double* __restrict__ B = p.B;
+
+  hssk_d4 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
+
+  // A tile: 192 x 16 doubles = 1536 pairs -> 6 per thread; pair e: rows (i, i+1), column kk
+  int offA[6], ldsA[6], kkA[6], iA[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int e = tid + 256 * r;
+    iA[r] = 2 * (e % (PBM / 2));
+    kkA[r] = e / (PBM / 2);
+    offA[r] = iA[r] + kkA[r] * p.lda;
+    ldsA[r] = kkA[r] * PLDA + iA[r];
+  }
+  // B tile: 32 x 16 doubles -> 2 per thread
+  int jB[2], kkB[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int e = tid + 256 * r;
+    if (TRANSB) { jB[r] = e % PBN; kkB[r] = e / PBN; }   // op(B)(k,j) = B(j,k): contiguous along j
+    else { kkB[r] = e % PBK; jB[r] = e / PBK; }          // op(B)(k,j) = B(k,j): contiguous along k
+  }
+  // two register sets: the loads of stage s+2 are in flight while stage s computes (the D / B blocks of a
+  // level stream from HBM: a one-stage prefetch leaves ~1.5 us of latency exposed per stage)
+  hssk_d2 ra0[6], ra1[6];
+  double rb0[2], rb1[2];
+  auto load = [&](int k0, hssk_d2 (&ra)[6], double (&rb)[2]) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const bool ok = (iA[r] < m) && (k0 + kkA[r] < k);   // m is even: a pair is inside or outside
+      ra[r] = ok ? *reinterpret_cast<const hssk_d2*>(A + (size_t)k0 * p.lda + offA[r]) : hssk_d2{0., 0.};
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int gj = j0 + jB[r], gk = k0 + kkB[r];
+      const bool ok = gj < n && gk < k;
+      rb[r] = ok ? (TRANSB ? B[gj + (size_t)gk * p.ldb] : B[gk + (size_t)gj * p.ldb]) : 0.;
+    }
+  };
+  auto store = [&](int buf, const hssk_d2 (&ra)[6], const double (&rb)[2]) {
+    double* as = As + buf * PBK * PLDA;
+    double* bs = Bs + buf * PBK * PLDB;
+#pragma unroll
+    for (int r = 0; r < 6; r++) *reinterpret_cast<hssk_d2*>(as + ldsA[r]) = ra[r];
+#pragma unroll
+    for (int r = 0; r < 2; r++) bs[kkB[r] * PLDB + jB[r]] = rb[r];
+  };
+  auto compute = [&](int buf) {
+    const double* as = As + buf * PBK * PLDA + wm + l15;
+    const double* bs = Bs + buf * PBK * PLDB + l15;
+#pragma unroll
+    for (int ks = 0; ks < PBK; ks += 4) {
+      double af[3], bf[2];
+#pragma unroll
+      for (int a = 0; a < 3; a++) af[a] = as[(ks + l4) * PLDA + a * 16];
+#pragma unroll
+      for (int b = 0; b < 2; b++) bf[b] = bs[(ks + l4) * PLDB + b * 16];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = hssk_mfma_f64_16x16x4(bf[b], af[a], acc[a][b]);
+    }
+  };
+  const int nst = (k + PBK - 1) / PBK;  // >= 1 (k > 0 for panel-eligible problems)
+  load(0, ra0, rb0);
+  store(0, ra0, rb0);
+  if (nst > 1) load(PBK, ra1, rb1);
+  __syncthreads();
+  int st = 0;
+  // LDS buffer and register set of stage s are both s & 1
+  for (; st + 2 < nst; st += 2) {
+    load((st + 2) * PBK, ra0, rb0);
+    compute(0);
+    store(1, ra1, rb1);
+    __syncthreads();
+    if (st + 3 < nst) load((st + 3) * PBK, ra1, rb1);
+    compute(1);
+    store(0, ra0, rb0);
+    __syncthreads();
+  }
+  compute(0);
+  if (st + 1 < nst) {
+    store(1, ra1, rb1);
+    __syncthreads();
+    compute(1);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = wm + a * 16 + l15;
+        const int gj = j0 + b * 16 + l4 + 4 * r;
+        if (gi < m && gj < n) {
+          double* c = p.C + gi + (size_t)gj * p.ldc;
+          double v = p.alpha * acc[a][b][r];
+          if (p.beta != 0.) v += p.beta * (*c);
+          *c = v;
+        }
+      }
+}
+
+inline bool panel_eligible(const hssk_gemm_desc& d) {
+  return d.transA == 0 && d.m > 64 && d.m <= PBM && (d.m % 2 == 0) && (d.lda % 2 == 0) &&
+         ((size_t)d.A % 16 == 0) && d.k > 0 && d.n > 0;
+}
+
 }  // namespace
 
 extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  std::vector<Tile> tiles, ztiles;
+  std::vector<Tile> tiles, ztiles, ptilesN, ptilesT;
   for (int p = 0; p < count; p++) {
     const hssk_gemm_desc& d = descs[p];
     if (d.m <= 0 || d.n <= 0) continue;
+    if (panel_eligible(d)) {
+      std::vector<Tile>& dst = d.transB ? ptilesT : ptilesN;
+      for (int tn = 0; tn * PBN < d.n; tn++) dst.push_back(Tile{p, 0, tn});
+      continue;
+    }
     int ntm = (d.m + TM - 1) / TM, ntn = (d.n + TN - 1) / TN;
     std::vector<Tile>& dst = (d.k > 0) ? tiles : ztiles;
     for (int tn = 0; tn < ntn; tn++)
       for (int tm = 0; tm < ntm; tm++) dst.push_back(Tile{p, tm, tn});
   }
-  if (tiles.empty() && ztiles.empty()) return 0;
+  if (tiles.empty() && ztiles.empty() && ptilesN.empty() && ptilesT.empty()) return 0;
   auto* d_descs = (const hssk_gemm_desc*)ctx->stage(descs, sizeof(hssk_gemm_desc) * count);
+  // XCD-aware order for the panel tiles: workgroup b runs on XCD b % 8 and every XCD has its own L2, so
+  // the column tiles of one problem (which share the 192 x k A panel) are placed on block ids that are
+  // congruent mod 8 and adjacent in time; otherwise each of them re-fetches the panel from HBM / MALL
+  auto xcd_order = [](std::vector<Tile>& v) {
+    if (v.size() < 16) return;
+    std::vector<std::vector<Tile>> lanes(8);
+    int cur = -1, lane = -1;
+    for (const Tile& t : v) {   // tiles of a problem are contiguous in v
+      if (t.prob != cur) { cur = t.prob; lane = (lane + 1) & 7; }
+      lanes[lane].push_back(t);
+    }
+    std::vector<Tile> out;
+    out.reserve(v.size() + 64);
+    size_t longest = 0;
+    for (auto& l : lanes) longest = std::max(longest, l.size());
+    for (size_t i = 0; i < longest; i++)
+      for (int x = 0; x < 8; x++)
+        out.push_back(i < lanes[x].size() ? lanes[x][i] : Tile{-1, 0, 0});  // padding keeps b % 8 == lane
+    v.swap(out);
+  };
+  xcd_order(ptilesN);
+  xcd_order(ptilesT);
+  if (!ptilesN.empty()) {
+    auto* d_tiles = (const Tile*)ctx->stage(ptilesN.data(), sizeof(Tile) * ptilesN.size());
+    HSSK_LAUNCH((gemm_panel_kernel<false>), dim3((unsigned)ptilesN.size()), dim3(256), 0, ctx->stream, d_descs, d_tiles);
+  }
+  if (!ptilesT.empty()) {
+    auto* d_tiles = (const Tile*)ctx->stage(ptilesT.data(), sizeof(Tile) * ptilesT.size());
+    HSSK_LAUNCH((gemm_panel_kernel<true>), dim3((unsigned)ptilesT.size()), dim3(256), 0, ctx->stream, d_descs, d_tiles);
+  }
   if (!tiles.empty()) {
     auto* d_tiles = (const Tile*)ctx->stage(tiles.data(), sizeof(Tile) * tiles.size());
     HSSK_LAUNCH(gemm_vbatched_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, d_descs, d_tiles);

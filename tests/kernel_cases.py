@@ -11,11 +11,11 @@ def rng(seed=0):
     return np.random.default_rng(seed)
 
 
-def case_gemm_vbatched(hk, shapes, seed=0):
+def case_gemm_vbatched(hk, shapes, seed=0, even_ld=False):
     r = rng(seed)
     descs, keep, expect = [], [], []
     for (m, n, k, ta, tb, alpha, beta) in shapes:
-        A = r.standard_normal((k, m) if ta else (m, k))
+        A = r.standard_normal((k, m) if ta else (m + (2 if even_ld else 0), k))
         B = r.standard_normal((n, k) if tb else (k, n))
         Cm = r.standard_normal((m + 3, n))  # ldc = m + 3
         dA, dB, dC = hk.array(A), hk.array(B), hk.array(Cm)
@@ -23,7 +23,7 @@ def case_gemm_vbatched(hk, shapes, seed=0):
         descs.append(K.GemmDesc(dA.ptr, dB.ptr, dC.ptr, m, n, k, max(A.shape[0], 1),
                                 max(B.shape[0], 1), m + 3, int(ta), int(tb), alpha, beta))
         ref = Cm.copy()
-        opA = A.T if ta else A
+        opA = A.T if ta else A[:m]
         opB = B.T if tb else B
         ref[:m] = alpha * (opA @ opB) + (beta * Cm[:m] if beta != 0 else 0)
         expect.append(ref)

@@ -27,6 +27,12 @@ def test_dgemm(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
 
 
+def test_gemm_vbatched_panel_path(hk):
+    # m = sample count (even, <= 192), A contiguous and aligned: the 192 x 32 panel kernel
+    KC.case_gemm_vbatched(hk, [(192, 45, 45, 0, 1, -1.0, 1.0), (192, 45, 45, 0, 0, -1.0, 1.0), (96, 33, 20, 0, 1, 1.0, 0.0),
+                               (128, 7, 50, 0, 0, 2.0, 0.5), (66, 64, 17, 0, 1, 1.0, 1.0)], seed=4, even_ld=True)
+
+
 @pytest.mark.parametrize("m,n,k,tb", [(192, 150, 64, 1), (192, 150, 64, 0), (64, 130, 48, 1), (128, 64, 32, 0)])
 def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     # even leading dimensions + 16-byte aligned operands: interior tiles take the unmasked kernel
