@@ -77,6 +77,19 @@ typedef struct hssk_gemm_desc {
 } hssk_gemm_desc;
 int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, int count);
 
+/* Fused leaf sample update (compute_local_samples, leaf branch: HSS/HSSMatrix.compress.hpp:541-545 and
+ * :591-594):  Sr -= R D^T  and  Sc -= R D  in one pass -- both products share the R panel (d x m,
+ * transposed sample layout) and the m x m leaf block D.  Requires d even, d <= 192, ldr / lds even and
+ * 16-byte aligned panels (the engine's layout); returns 2 (nothing done) otherwise. */
+typedef struct hssk_leaf_update_desc {
+  const double* R;  /* d x m */
+  const double* D;  /* m x m */
+  double* Sr;       /* d x m */
+  double* Sc;       /* d x m */
+  int d, m, ldr, ldd, lds;
+} hssk_leaf_update_desc;
+int hssk_leaf_update_vbatched(hssk_ctx* ctx, const hssk_leaf_update_desc* descs, int count);
+
 /* ---- gathers / scatters ----------------------------------------------------------------------- */
 /* dst(:, j) = src(:, idx[j]) (idx == NULL: identity) -- DenseMatrix::extract_rows in the
  * transposed sample layout (dense/DenseMatrix.cpp:323-333), laswp (:287-297). */

@@ -67,6 +67,16 @@ __device__ __forceinline__ long long hssk_wallclock() { return (long long)__buil
   }
 
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))
+
+// Global-memory accessors for pointers that arrive through a descriptor in memory: the compiler cannot infer
+// their address space and would emit FLAT loads, which also count on lgkmcnt and so serialise against every
+// LDS wait of a pipelined kernel.  These cast to address space 1 (global_load / global_store, vmcnt only).
+#define HSSK_GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ double hssk_gload(const double* p, size_t off) { return ((const double HSSK_GLOBAL_AS*)p)[off]; }
+__device__ __forceinline__ hssk_d2 hssk_gload2(const double* p, size_t off) {
+  return *(const hssk_d2 HSSK_GLOBAL_AS*)((const double HSSK_GLOBAL_AS*)p + off);
+}
+__device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { ((double HSSK_GLOBAL_AS*)p)[off] = v; }
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
 // kernel<<<grid, block, shmem, stream>>>(args...)

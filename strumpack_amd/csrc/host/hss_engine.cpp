@@ -788,6 +788,7 @@ void DeviceHSS::extract_blocks(Source& src, const std::vector<int>& ids) {
 void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int>& r0s, const std::vector<int>& dns) {
   std::vector<hssk_colgather_desc> g;
   std::vector<hssk_gemm_desc> mm;
+  std::vector<hssk_leaf_update_desc> lu;   // fused Sr / Sc update of the leaves (both share the R panel)
   for (size_t k = 0; k < ids.size(); k++) {
     Node& nd = nodes_[ids[k]];
     const int r0 = r0s[k], dn = dns[k];
@@ -795,8 +796,12 @@ void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int
     if (nd.leaf()) {
       const int m = nd.m;
       // Sr_loc -= D Rr_loc  ->  Srt -= Rt D^T ;  Sc_loc -= D^T Rc_loc  ->  Sct -= Rt D
-      mm.push_back(hssk_gemm_desc{nd.Rrt + r0, nd.D, nd.Srt + r0, dn, m, m, dcap_, m, dcap_, 0, 1, -1.0, 1.0});
-      mm.push_back(hssk_gemm_desc{nd.Rct + r0, nd.D, nd.Sct + r0, dn, m, m, dcap_, m, dcap_, 0, 0, -1.0, 1.0});
+      if (dn <= 192 && dn % 2 == 0 && r0 % 2 == 0 && nd.Rrt == nd.Rct)
+        lu.push_back(hssk_leaf_update_desc{nd.Rrt + r0, nd.D, nd.Srt + r0, nd.Sct + r0, dn, m, dcap_, m, dcap_});
+      else {
+        mm.push_back(hssk_gemm_desc{nd.Rrt + r0, nd.D, nd.Srt + r0, dn, m, m, dcap_, m, dcap_, 0, 1, -1.0, 1.0});
+        mm.push_back(hssk_gemm_desc{nd.Rct + r0, nd.D, nd.Sct + r0, dn, m, m, dcap_, m, dcap_, 0, 0, -1.0, 1.0});
+      }
       stats_.f_local += 4.0 * m * (double)m * dn;
     } else {
       Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
@@ -814,6 +819,15 @@ void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int
     }
   }
   if (!g.empty()) ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
+  if (!lu.empty()) {
+    int rc = hssk_leaf_update_vbatched(ctx_, lu.data(), (int)lu.size());
+    if (rc == 2) {  // layout not eligible for the fused kernel: two plain GEMMs per leaf
+      for (auto& u : lu) {
+        mm.push_back(hssk_gemm_desc{u.R, u.D, u.Sr, u.d, u.m, u.m, u.ldr, u.ldd, u.lds, 0, 1, -1.0, 1.0});
+        mm.push_back(hssk_gemm_desc{u.R, u.D, u.Sc, u.d, u.m, u.m, u.ldr, u.ldd, u.lds, 0, 0, -1.0, 1.0});
+      }
+    } else ck(rc);
+  }
   if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
 }
 

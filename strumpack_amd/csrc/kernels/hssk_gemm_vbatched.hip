@@ -52,16 +52,18 @@ __global__ __launch_bounds__(256) void gemm_vbatched_kernel(const hssk_gemm_desc
       for (int r = 0; r < 4; r++) {
         int i = tid & 63, kk = (tid >> 6) + 4 * r;
         int gi = i0 + i, gk = k0 + kk;
-        double v = (gi < p.m && gk < p.k) ? p.A[gi + (size_t)gk * p.lda] : 0.;
-        As[kk * LDS_LD + i] = v;
+        const bool ok = gi < p.m && gk < p.k;   // clamped address + select: no branch around the load
+        double v = hssk_gload(p.A, min(gi, p.m - 1) + (size_t)min(gk, p.k - 1) * p.lda);
+        As[kk * LDS_LD + i] = ok ? v : 0.;
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         int kk = tid & 15, i = (tid >> 4) + 16 * r;
         int gi = i0 + i, gk = k0 + kk;
-        double v = (gi < p.m && gk < p.k) ? p.A[gk + (size_t)gi * p.lda] : 0.;
-        As[kk * LDS_LD + i] = v;
+        const bool ok = gi < p.m && gk < p.k;
+        double v = hssk_gload(p.A, min(gk, p.k - 1) + (size_t)min(gi, p.m - 1) * p.lda);
+        As[kk * LDS_LD + i] = ok ? v : 0.;
       }
     }
     // ---- stage B tile: Bs[kk][j] = op(B)(k0+kk, j0+j)
@@ -70,16 +72,18 @@ __global__ __launch_bounds__(256) void gemm_vbatched_kernel(const hssk_gemm_desc
       for (int r = 0; r < 4; r++) {
         int kk = tid & 15, j = (tid >> 4) + 16 * r;
         int gj = j0 + j, gk = k0 + kk;
-        double v = (gj < p.n && gk < p.k) ? p.B[gk + (size_t)gj * p.ldb] : 0.;
-        Bs[kk * LDS_LD + j] = v;
+        const bool ok = gj < p.n && gk < p.k;
+        double v = hssk_gload(p.B, min(gk, p.k - 1) + (size_t)min(gj, p.n - 1) * p.ldb);
+        Bs[kk * LDS_LD + j] = ok ? v : 0.;
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         int j = tid & 63, kk = (tid >> 6) + 4 * r;
         int gj = j0 + j, gk = k0 + kk;
-        double v = (gj < p.n && gk < p.k) ? p.B[gj + (size_t)gk * p.ldb] : 0.;
-        Bs[kk * LDS_LD + j] = v;
+        const bool ok = gj < p.n && gk < p.k;
+        double v = hssk_gload(p.B, min(gj, p.n - 1) + (size_t)min(gk, p.k - 1) * p.ldb);
+        Bs[kk * LDS_LD + j] = ok ? v : 0.;
       }
     }
     __syncthreads();
@@ -97,21 +101,31 @@ __global__ __launch_bounds__(256) void gemm_vbatched_kernel(const hssk_gemm_desc
     }
     __syncthreads();
   }
-  // ---- epilogue
+  // ---- epilogue: all C reads of the tile are issued before the first is consumed
+  double cv[2][2][4];
+  if (p.beta != 0.) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = min(i0 + wm + a * 16 + l15, p.m - 1);
+          const int gj = min(j0 + wn + b * 16 + l4 + 4 * r, p.n - 1);
+          cv[a][b][r] = hssk_gload(p.C, gi + (size_t)gj * p.ldc);
+        }
+  }
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        int gi = i0 + wm + a * 16 + l15;
-        int gj = j0 + wn + b * 16 + l4 + 4 * r;
-        if (gi < p.m && gj < p.n) {
-          double* c = p.C + gi + (size_t)gj * p.ldc;
-          double v = p.alpha * acc[a][b][r];
-          if (p.beta != 0.) v += p.beta * (*c);
-          *c = v;
-        }
+        const int gi = i0 + wm + a * 16 + l15;
+        const int gj = j0 + wn + b * 16 + l4 + 4 * r;
+        double v = p.alpha * acc[a][b][r];
+        if (p.beta != 0.) v += p.beta * cv[a][b][r];
+        if (gi < p.m && gj < p.n) hssk_gstore(p.C, gi + (size_t)gj * p.ldc, v);
       }
 }
 
@@ -162,13 +176,12 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const hssk_gemm_desc
     for (int b = 0; b < 2; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
 
   // A tile: 192 x 16 doubles = 1536 pairs -> 6 per thread; pair e: rows (i, i+1), column kk
-  int offA[6], ldsA[6], kkA[6], iA[6];
+  int ldsA[6], kkA[6], iA[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     const int e = tid + 256 * r;
     iA[r] = 2 * (e % (PBM / 2));
     kkA[r] = e / (PBM / 2);
-    offA[r] = iA[r] + kkA[r] * p.lda;
     ldsA[r] = kkA[r] * PLDA + iA[r];
   }
   // B tile: 32 x 16 doubles -> 2 per thread
@@ -186,14 +199,18 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const hssk_gemm_desc
   auto load = [&](int k0, hssk_d2 (&ra)[6], double (&rb)[2]) {
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      const bool ok = (iA[r] < m) && (k0 + kkA[r] < k);   // m is even: a pair is inside or outside
-      ra[r] = ok ? *reinterpret_cast<const hssk_d2*>(A + (size_t)k0 * p.lda + offA[r]) : hssk_d2{0., 0.};
+      // m is even: a pair is inside or outside.  Clamped address + select keeps the load unconditional.
+      const bool ok = (iA[r] < m) && (k0 + kkA[r] < k);
+      const hssk_d2 v = hssk_gload2(A, min(iA[r], m - 2) + (size_t)min(k0 + kkA[r], k - 1) * p.lda);
+      ra[r] = ok ? v : hssk_d2{0., 0.};
     }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const int gj = j0 + jB[r], gk = k0 + kkB[r];
       const bool ok = gj < n && gk < k;
-      rb[r] = ok ? (TRANSB ? B[gj + (size_t)gk * p.ldb] : B[gk + (size_t)gj * p.ldb]) : 0.;
+      const int cj = min(gj, n - 1), ck = min(gk, k - 1);
+      const double v = TRANSB ? hssk_gload(B, cj + (size_t)ck * p.ldb) : hssk_gload(B, ck + (size_t)cj * p.ldb);
+      rb[r] = ok ? v : 0.;
     }
   };
   auto store = [&](int buf, const hssk_d2 (&ra)[6], const double (&rb)[2]) {
@@ -243,6 +260,16 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const hssk_gemm_desc
     __syncthreads();
     compute(1);
   }
+  double cv[3][2][4];
+  if (p.beta != 0.) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          cv[a][b][r] = hssk_gload(p.C, min(wm + a * 16 + l15, m - 1) + (size_t)min(j0 + b * 16 + l4 + 4 * r, n - 1) * p.ldc);
+  }
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -251,13 +278,141 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const hssk_gemm_desc
       for (int r = 0; r < 4; r++) {
         const int gi = wm + a * 16 + l15;
         const int gj = j0 + b * 16 + l4 + 4 * r;
-        if (gi < m && gj < n) {
-          double* c = p.C + gi + (size_t)gj * p.ldc;
-          double v = p.alpha * acc[a][b][r];
-          if (p.beta != 0.) v += p.beta * (*c);
-          *c = v;
-        }
+        double v = p.alpha * acc[a][b][r];
+        if (p.beta != 0.) v += p.beta * cv[a][b][r];
+        if (gi < m && gj < n) hssk_gstore(p.C, gi + (size_t)gj * p.ldc, v);
       }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused leaf sample update:  Sr(:, J) -= R D(J, :)^T  and  Sc(:, J) -= R D(:, J)  for one 32-column tile J of
+// one leaf.  Same tiling as gemm_panel_kernel, but the staged R panel feeds BOTH products (two B tiles per
+// stage), so every barrier covers 48 MFMAs per wave instead of 24 and the panel is read once, not twice.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void leaf_update_kernel(const hssk_leaf_update_desc* __restrict__ descs,
+                                                             const Tile* __restrict__ tiles) {
+  HSSK_SHARED double As[2 * PBK * PLDA];
+  HSSK_SHARED double Bs[2 * 2 * PBK * PLDB];   // [buffer][product][k][j]
+  const Tile t = tiles[blockIdx.x];
+  if (t.prob < 0) return;
+  const hssk_leaf_update_desc p = descs[t.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int j0 = t.tn * PBN;
+  const int wm = wave * 48;
+  const int d = p.d, m = p.m;
+  const double* __restrict__ A = p.R;
+  const double* __restrict__ D = p.D;
+
+  hssk_d4 acc[2][3][2];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) acc[q][a][b] = hssk_d4{0., 0., 0., 0.};
+
+  int ldsA[6], kkA[6], iA[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int e = tid + 256 * r;
+    iA[r] = 2 * (e % (PBM / 2));
+    kkA[r] = e / (PBM / 2);
+    ldsA[r] = kkA[r] * PLDA + iA[r];
+  }
+  // product 0 (Sr): op(B)(k, j) = D(j0+j, k)  -> contiguous along j ;  product 1 (Sc): D(k, j0+j) -> along k
+  int j1[2], k1[2], j2[2], k2[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int e = tid + 256 * r;
+    j1[r] = e % PBN; k1[r] = e / PBN;
+    k2[r] = e % PBK; j2[r] = e / PBK;
+  }
+  hssk_d2 ra[6];
+  double rb1[2], rb2[2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const bool ok = (iA[r] < d) && (k0 + kkA[r] < m);
+      const hssk_d2 v = hssk_gload2(A, min(iA[r], d - 2) + (size_t)min(k0 + kkA[r], m - 1) * p.ldr);
+      ra[r] = ok ? v : hssk_d2{0., 0.};
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int gj = j0 + j1[r], gk = k0 + k1[r];
+      const double v1 = hssk_gload(D, min(gj, m - 1) + (size_t)min(gk, m - 1) * p.ldd);
+      rb1[r] = (gj < m && gk < m) ? v1 : 0.;
+      const int hj = j0 + j2[r], hk = k0 + k2[r];
+      const double v2 = hssk_gload(D, min(hk, m - 1) + (size_t)min(hj, m - 1) * p.ldd);
+      rb2[r] = (hj < m && hk < m) ? v2 : 0.;
+    }
+  };
+  auto store = [&](int buf) {
+    double* as = As + buf * PBK * PLDA;
+    double* b1 = Bs + (buf * 2 + 0) * PBK * PLDB;
+    double* b2 = Bs + (buf * 2 + 1) * PBK * PLDB;
+#pragma unroll
+    for (int r = 0; r < 6; r++) *reinterpret_cast<hssk_d2*>(as + ldsA[r]) = ra[r];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      b1[k1[r] * PLDB + j1[r]] = rb1[r];
+      b2[k2[r] * PLDB + j2[r]] = rb2[r];
+    }
+  };
+  auto compute = [&](int buf) {
+    const double* as = As + buf * PBK * PLDA + wm + l15;
+    const double* b1 = Bs + (buf * 2 + 0) * PBK * PLDB + l15;
+    const double* b2 = Bs + (buf * 2 + 1) * PBK * PLDB + l15;
+#pragma unroll
+    for (int ks = 0; ks < PBK; ks += 4) {
+      double af[3], bf[2][2];
+#pragma unroll
+      for (int a = 0; a < 3; a++) af[a] = as[(ks + l4) * PLDA + a * 16];
+#pragma unroll
+      for (int b = 0; b < 2; b++) { bf[0][b] = b1[(ks + l4) * PLDB + b * 16]; bf[1][b] = b2[(ks + l4) * PLDB + b * 16]; }
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) acc[q][a][b] = hssk_mfma_f64_16x16x4(bf[q][b], af[a], acc[q][a][b]);
+    }
+  };
+  const int nst = (m + PBK - 1) / PBK;
+  load(0);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int st = 0; st + 1 < nst; st++) {
+    load((st + 1) * PBK);
+    compute(buf);
+    store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  compute(buf);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    double* C = q == 0 ? p.Sr : p.Sc;
+    double cv[3][2][4];   // every read of the tile in flight before the first is consumed
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          cv[a][b][r] = hssk_gload(C, min(wm + a * 16 + l15, d - 1) + (size_t)min(j0 + b * 16 + l4 + 4 * r, m - 1) * p.lds);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = wm + a * 16 + l15;
+          const int gj = j0 + b * 16 + l4 + 4 * r;
+          if (gi < d && gj < m) hssk_gstore(C, gi + (size_t)gj * p.lds, cv[a][b][r] - acc[q][a][b][r]);
+        }
+  }
 }
 
 inline bool panel_eligible(const hssk_gemm_desc& d) {
@@ -324,6 +479,24 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
     auto* d_tiles = (const Tile*)ctx->stage(ztiles.data(), sizeof(Tile) * ztiles.size());
     HSSK_LAUNCH(gemm_scale_kernel, dim3((unsigned)ztiles.size()), dim3(256), 0, ctx->stream, d_descs, d_tiles);
   }
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_leaf_update_vbatched(hssk_ctx* ctx, const hssk_leaf_update_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  std::vector<Tile> tiles;
+  for (int p = 0; p < count; p++) {
+    const hssk_leaf_update_desc& d = descs[p];
+    if (d.d <= 0 || d.m <= 0) continue;
+    if (d.d > PBM || (d.d % 2) || (d.ldr % 2) || ((size_t)d.R % 16)) return 2;  // caller falls back to two GEMMs
+    for (int tn = 0; tn * PBN < d.m; tn++) tiles.push_back(Tile{p, 0, tn});
+  }
+  if (tiles.empty()) return 0;
+  auto* dd = (const hssk_leaf_update_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dt = (const Tile*)ctx->stage(tiles.data(), sizeof(Tile) * tiles.size());
+  HSSK_LAUNCH(leaf_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd, dt);
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -14,6 +14,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -277,6 +278,186 @@ void launch_formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc*
   HSSK_LAUNCH((formq_reg_kernel<RT, CT>), dim3((unsigned)blocks.size()), dim3(1024), 0, ctx->stream, dd, dw);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Blocked path for panels beyond the register kernels (leaf size 512: W0^T is ~390 x 350, its Q 390 x 390).
+// Level-synchronous over the whole batch, QB columns at a time:
+//   1. qr_reg_kernel<8, 2, 16> factors the (rows - j0) x QB panel of every matrix in registers,
+//   2. larft_kernel builds the compact-WY pair of the panel, V (unit lower trapezoidal, explicit) and
+//      VT = V T  (T from the dlarft recurrence on V^T V, all in LDS), and folds the panel's max/min |R_ii|,
+//   3. two batched MFMA GEMMs apply H^T = I - V (VT)^T to the trailing columns: W = VT^T A2, A2 -= V W.
+// Q is then formed by the same two GEMMs per panel in reverse order (Q <- Q - VT (V^T Q)).
+// This turns the Level-2, latency-bound sweep of qr_kernel into Level-3 work on the matrix cores.
+// ------------------------------------------------------------------------------------------------
+constexpr int QB = 32;
+constexpr int QB_MAXROWS = 512;
+constexpr int QB_LD = QB_MAXROWS + 1;   // odd: lanes that walk along columns hit distinct LDS banks
+
+struct QPanel {
+  const double* A;   // factored panel (rows x nb, reflectors below the diagonal)
+  const double* tau;
+  double* Vc;        // out: explicit V
+  double* VT;        // out: V T
+  double* rd_panel;  // max/min |R_ii| of this panel (written by the panel kernel)
+  double* rdiag;     // running max/min of the whole matrix (may be null)
+  int lda, rows, nb, ldv, first;
+};
+
+__global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ descs) {
+  HSSK_SHARED double s_V[QB * QB_LD];
+  HSSK_SHARED double s_G[QB * QB];
+  HSSK_SHARED double s_T[QB * QB];
+  const QPanel p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = p.rows, nb = p.nb;
+  if (tid == 0 && p.rdiag) {
+    const double pm = nb ? p.rd_panel[0] : 0., pn = nb ? p.rd_panel[1] : 0.;
+    if (p.first) { p.rdiag[0] = pm; p.rdiag[1] = pn; }
+    else if (nb) {
+      if (pm > p.rdiag[0]) p.rdiag[0] = pm;
+      if (pn < p.rdiag[1]) p.rdiag[1] = pn;
+    }
+  }
+  if (nb == 0) return;
+  for (int e = tid; e < rows * nb; e += 256) {
+    const int i = e % rows, j = e / rows;
+    const double v = i < j ? 0. : (i == j ? 1. : hssk_gload(p.A, i + (size_t)j * p.lda));
+    s_V[j * QB_LD + i] = v;
+    hssk_gstore(p.Vc, i + (size_t)j * p.ldv, v);
+  }
+  for (int e = tid; e < QB * QB; e += 256) s_T[e] = 0.;
+  __syncthreads();
+  // G(a, b) = v_a . v_b for a < b  (v_b is zero above row b)
+  for (int e = tid; e < nb * nb; e += 256) {
+    const int a = e % nb, b = e / nb;
+    if (a < b) {
+      double s = 0.;
+      for (int i = b; i < rows; i++) s += s_V[a * QB_LD + i] * s_V[b * QB_LD + i];
+      s_G[a + b * QB] = s;
+    }
+  }
+  __syncthreads();
+  // dlarft, forward / columnwise:  T(0:i, i) = -tau_i T(0:i, 0:i) (V(:, 0:i)^T v_i),  T(i, i) = tau_i.
+  // Lane l owns row l of T and only ever reads its own row.
+  if (wave == 0 && lane < nb) {
+    for (int i = 0; i < nb; i++) {
+      const double ti = p.tau[i];
+      if (lane < i) {
+        double s = 0.;
+        for (int c = lane; c < i; c++) s += s_T[lane + c * QB] * s_G[c + i * QB];
+        s_T[lane + i * QB] = -ti * s;
+      } else if (lane == i) s_T[lane + i * QB] = ti;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * nb; e += 256) {
+    const int i = e % rows, j = e / rows;
+    double s = 0.;
+    for (int c = 0; c <= j; c++) s += s_V[c * QB_LD + i] * s_T[c + j * QB];
+    hssk_gstore(p.VT, i + (size_t)j * p.ldv, s);
+  }
+}
+
+struct EyeDesc {
+  double* Q;
+  int ldq, rows, nq;
+};
+__global__ void eye_kernel(const EyeDesc* __restrict__ descs) {
+  const EyeDesc p = descs[blockIdx.x];
+  for (size_t e = (size_t)blockIdx.y * blockDim.x + threadIdx.x; e < (size_t)p.rows * p.nq; e += (size_t)gridDim.y * blockDim.x) {
+    const int i = (int)(e % p.rows), j = (int)(e / p.rows);
+    hssk_gstore(p.Q, i + (size_t)j * p.ldq, i == j ? 1. : 0.);
+  }
+}
+
+void gemm_batch(hssk_ctx* ctx, std::vector<hssk_gemm_desc>& g) {
+  if (g.empty()) return;
+  if (hssk_gemm_vbatched(ctx, g.data(), (int)g.size())) throw std::runtime_error(hssk_last_error());
+}
+
+void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count) {
+  std::vector<size_t> offV(count), offW(count), offR(count);
+  size_t tot = 0;
+  int pmax = 0;
+  bool anyq = false;
+  for (int i = 0; i < count; i++) {
+    const hssk_qr_desc& d = descs[i];
+    const size_t kmax = (size_t)std::min(d.rows, d.cols);
+    offV[i] = tot; tot += 2 * (size_t)d.rows * kmax;
+    offW[i] = tot; tot += (size_t)QB * std::max(std::max(d.cols, d.nq), 1);
+    offR[i] = tot; tot += 2;
+    pmax = std::max(pmax, (int)((kmax + QB - 1) / QB));
+    anyq = anyq || d.nq > 0;
+  }
+  double* ws = ctx->scratch(sizeof(double) * tot);
+  std::vector<hssk_qr_desc> pd;
+  std::vector<QPanel> lp;
+  std::vector<hssk_gemm_desc> g1, g2;
+  for (int p = 0; p < std::max(pmax, 1); p++) {
+    pd.clear(); lp.clear(); g1.clear(); g2.clear();
+    const int j0 = p * QB;
+    for (int i = 0; i < count; i++) {
+      const hssk_qr_desc& d = descs[i];
+      const int kmax = std::min(d.rows, d.cols);
+      if (j0 >= kmax && !(p == 0 && d.rdiag)) continue;
+      const int nb = std::max(0, std::min(QB, kmax - j0)), rr = d.rows - j0;
+      double* Ap = d.A + j0 + (size_t)j0 * d.lda;
+      double* Vc = ws + offV[i] + j0 + (size_t)j0 * d.rows;
+      double* VT = Vc + (size_t)d.rows * kmax;
+      double* W = ws + offW[i];
+      double* rdp = ws + offR[i];
+      lp.push_back(QPanel{Ap, d.work + j0, Vc, VT, rdp, d.rdiag, d.lda, rr, nb, d.rows, p == 0});
+      if (nb == 0) continue;
+      pd.push_back(hssk_qr_desc{Ap, d.lda, rr, nb, nullptr, 0, 0, rdp, d.work + j0});
+      const int nt = d.cols - (j0 + nb);
+      if (nt > 0) {
+        double* A2 = Ap + (size_t)nb * d.lda;
+        g1.push_back(hssk_gemm_desc{VT, A2, W, nb, nt, rr, d.rows, d.lda, QB, 1, 0, 1.0, 0.0});
+        g2.push_back(hssk_gemm_desc{Vc, W, A2, rr, nt, nb, d.rows, QB, d.lda, 0, 0, -1.0, 1.0});
+      }
+    }
+    if (!pd.empty()) {
+      auto* dp = (const hssk_qr_desc*)ctx->stage(pd.data(), sizeof(hssk_qr_desc) * pd.size());
+      HSSK_LAUNCH((qr_reg_kernel<8, 2, 16>), dim3((unsigned)pd.size()), dim3(1024), 0, ctx->stream, dp);
+    }
+    if (!lp.empty()) {
+      auto* dl = (const QPanel*)ctx->stage(lp.data(), sizeof(QPanel) * lp.size());
+      HSSK_LAUNCH(larft_kernel, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+    }
+    gemm_batch(ctx, g1);
+    gemm_batch(ctx, g2);
+  }
+  if (!anyq) return;
+  std::vector<EyeDesc> ey;
+  for (int i = 0; i < count; i++)
+    if (descs[i].nq > 0 && descs[i].rows > 0) ey.push_back(EyeDesc{descs[i].Q, descs[i].ldq, descs[i].rows, descs[i].nq});
+  if (ey.empty()) return;
+  auto* de = (const EyeDesc*)ctx->stage(ey.data(), sizeof(EyeDesc) * ey.size());
+  HSSK_LAUNCH(eye_kernel, dim3((unsigned)ey.size(), 16), dim3(256), 0, ctx->stream, de);
+  for (int p = pmax - 1; p >= 0; p--) {
+    g1.clear(); g2.clear();
+    const int j0 = p * QB;
+    for (int i = 0; i < count; i++) {
+      const hssk_qr_desc& d = descs[i];
+      const int kmax = std::min(d.rows, d.cols);
+      if (j0 >= kmax || d.nq <= j0) continue;
+      const int nb = std::min(QB, kmax - j0), rr = d.rows - j0, cq = d.nq - j0;
+      double* Vc = ws + offV[i] + j0 + (size_t)j0 * d.rows;
+      double* VT = Vc + (size_t)d.rows * kmax;
+      double* W = ws + offW[i];
+      double* Qb = d.Q + j0 + (size_t)j0 * d.ldq;
+      g1.push_back(hssk_gemm_desc{Vc, Qb, W, nb, cq, rr, d.rows, d.ldq, QB, 1, 0, 1.0, 0.0});
+      g2.push_back(hssk_gemm_desc{VT, W, Qb, rr, cq, nb, d.rows, QB, d.ldq, 0, 0, -1.0, 1.0});
+    }
+    gemm_batch(ctx, g1);
+    gemm_batch(ctx, g2);
+  }
+}
+
+bool force_blocked() {
+  static const bool f = [] { const char* e = std::getenv("HSSK_QR_BLOCKED"); return e && e[0] == '1'; }();
+  return f;
+}
+
 }  // namespace
 
 extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count) {
@@ -287,6 +468,11 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
     rmax = std::max(rmax, descs[i].rows);
     cmax = std::max(cmax, descs[i].cols);
     qmax = std::max(qmax, descs[i].nq);
+  }
+  if (rmax <= QB_MAXROWS && (force_blocked() || rmax > 256 || cmax > 208)) {
+    qr_blocked(ctx, descs, count);
+    hssk_rt::check_launch();
+    return 0;
   }
   auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // register-resident kernels when the largest panel of the batch fits (rows <= 64 RT, cols <= 16 CT);

@@ -19,6 +19,11 @@ class GemmDesc(C.Structure):
                 ("alpha", C.c_double), ("beta", C.c_double)]
 
 
+class LeafUpdateDesc(C.Structure):
+    _fields_ = [("R", C.c_void_p), ("D", C.c_void_p), ("Sr", C.c_void_p), ("Sc", C.c_void_p),
+                ("d", C.c_int), ("m", C.c_int), ("ldr", C.c_int), ("ldd", C.c_int), ("lds", C.c_int)]
+
+
 class ColGatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p),
                 ("rows", C.c_int), ("ncols", C.c_int), ("lds", C.c_int), ("ldd", C.c_int),
@@ -87,7 +92,7 @@ HSSK_SYMBOLS = [
     "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
     "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops", "hssk_memcpy_d2d",
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
-    "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz",
+    "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched",
 ]
 
 
@@ -167,7 +172,7 @@ class Hssk:
         for name in ("hssk_gemm_vbatched", "hssk_gather_cols", "hssk_gather_rows",
                      "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched", "hssk_qr_vbatched",
                      "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
-                     "hssk_sumsq_vbatched"):
+                     "hssk_sumsq_vbatched", "hssk_leaf_update_vbatched"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         L.hssk_mfma_f64_peak_tflops.restype = C.c_double

@@ -65,6 +65,9 @@ inline long long hssk_wallclock() { return 0; }
 #define HSSK_SCHED_MFMA_DSWRITE(n)
 
 #define HSSK_SHARED alignas(16) static thread_local
+inline double hssk_gload(const double* p, size_t off) { return p[off]; }
+inline hssk_d2 hssk_gload2(const double* p, size_t off) { return *reinterpret_cast<const hssk_d2*>(p + off); }
+inline void hssk_gstore(double* p, size_t off, double v) { p[off] = v; }
 #define HSSK_DYN_SHARED(type, name) type* name = (type*)emu::dyn_shared()
 
 #define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \

@@ -35,6 +35,25 @@ def case_gemm_vbatched(hk, shapes, seed=0, even_ld=False):
         assert np.abs(got - ref).max() <= 1e-12 * scale * max(sh[2], 1), f"gemm {sh}"
 
 
+def case_leaf_update(hk, shapes, seed=12):
+    """Fused leaf sample update vs numpy: Sr -= R D^T, Sc -= R D."""
+    r = rng(seed)
+    descs, keep = [], []
+    for (d, m) in shapes:
+        R, D = r.standard_normal((d + 2, m)), r.standard_normal((m, m))
+        Sr, Sc = r.standard_normal((d + 2, m)), r.standard_normal((d + 2, m))
+        dR, dD, dSr, dSc = hk.array(R), hk.array(D), hk.array(Sr), hk.array(Sc)
+        keep.append((R, D, Sr, Sc, dSr, dSc, dR, dD, d))
+        descs.append(K.LeafUpdateDesc(dR.ptr, dD.ptr, dSr.ptr, dSc.ptr, d, m, d + 2, m, d + 2))
+    hk.batch("hssk_leaf_update_vbatched", descs)
+    hk.sync()
+    for (R, D, Sr, Sc, dSr, dSc, _, _, d) in keep:
+        er, ec = Sr.copy(), Sc.copy()
+        er[:d] -= R[:d] @ D.T
+        ec[:d] -= R[:d] @ D
+        assert np.allclose(dSr.get(), er, atol=1e-11) and np.allclose(dSc.get(), ec, atol=1e-11)
+
+
 def case_dgemm(hk, m, n, k, transB, alpha=1.0, beta=0.0, lda_pad=5, seed=1, ldb_pad=1):
     r = rng(seed)
     A = r.standard_normal((m + lda_pad, k))

@@ -27,6 +27,10 @@ def test_dgemm(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
 
 
+def test_leaf_update(hk):
+    KC.case_leaf_update(hk, [(24, 20), (192, 45), (64, 33), (2, 1)])
+
+
 def test_gemm_vbatched_panel_path(hk):
     # m = sample count (even, <= 192), A contiguous and aligned: the 192 x 32 panel kernel
     KC.case_gemm_vbatched(hk, [(192, 45, 45, 0, 1, -1.0, 1.0), (192, 45, 45, 0, 0, -1.0, 1.0), (96, 33, 20, 0, 1, 1.0, 0.0),
@@ -65,7 +69,8 @@ def test_qr(hk):
     KC.case_qr(hk, [(100, 128, 100), (120, 60, 120)], seed=8)       # <2,8,16>
     KC.case_qr(hk, [(195, 128, 128)], seed=9)                       # <4,8,16>
     KC.case_qr(hk, [(195, 160, 195), (130, 100, 130)], seed=10)     # <4,26,8>
-    KC.case_qr(hk, [(300, 40, 300)], seed=11)                       # global-memory fallback
+    KC.case_qr(hk, [(300, 40, 300), (260, 250, 260), (390, 350, 390), (300, 60, 0), (280, 300, 200)], seed=11)   # blocked (compact WY + batched GEMM)
+    KC.case_qr(hk, [(600, 20, 30)], seed=12)                        # global-memory fallback
 
 
 def test_trsm_lu(hk):

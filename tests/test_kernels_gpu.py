@@ -43,6 +43,11 @@ def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.0, beta=1.0, lda_pad=2, ldb_pad=4)
 
 
+def test_leaf_update(hk):
+    KC.case_leaf_update(hk, [(24, 20), (192, 45), (64, 33), (2, 1)])
+    KC.case_leaf_update(hk, [(192, 195), (192, 196)] * 8 + [(64, 390)], seed=13)
+
+
 def test_generators(hk):
     KC.case_toeplitz_randn(hk, n=700)
 

@@ -5,7 +5,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from strumpack_amd import _loader  # noqa: E402
 from strumpack_amd import hssk as K  # noqa: E402
 
@@ -33,3 +34,19 @@ for rep in range(5):
     hk.sync()
     dt = time.perf_counter() - t0
     print("batched sample update: %.1f us  %.2f TFLOP/s (%.1f%% of 78.6)" % (dt * 1e6, flops / dt * 1e-12, flops / dt * 1e-12 / 78.6 * 100), flush=True)
+
+# fused variant: Sr and Sc updated in one pass over the shared R panel
+Sc = hk.empty((d, N))
+hk.check(hk.lib.hssk_randn(hk.ctx, Sc.ptr, d, N, d, 0, N, 9))
+lu = []
+lo = 0
+for i, b in enumerate(sizes):
+    lu.append(K.LeafUpdateDesc(Rt.ptr + 8 * d * lo, Ds[i].ptr, St.ptr + 8 * d * lo, Sc.ptr + 8 * d * lo, d, b, d, b, d))
+    lo += b
+for rep in range(5):
+    hk.sync()
+    t0 = time.perf_counter()
+    hk.batch("hssk_leaf_update_vbatched", lu)
+    hk.sync()
+    dt = time.perf_counter() - t0
+    print("fused leaf update:     %.1f us  %.2f TFLOP/s (%.1f%% of 78.6)" % (dt * 1e6, flops / dt * 1e-12, flops / dt * 1e-12 / 78.6 * 100), flush=True)
