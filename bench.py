@@ -149,13 +149,37 @@ def main():
     HX = H.mult(Xh)
     resid = float(np.linalg.norm(HX - Bh) / np.linalg.norm(Bh))
     rng = np.random.default_rng(0)
-    cols = rng.integers(0, n, 8)
-    E = np.zeros((n, 8))
-    E[cols, np.arange(8)] = 1.0
+    nc = 64  # compression error sampled on 64 random columns
+    cols = rng.integers(0, n, nc)
+    E = np.zeros((n, nc))
+    E[cols, np.arange(nc)] = 1.0
     i = np.arange(n)
     Ac = 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :]))
     comp_err = float(np.linalg.norm(H.mult(E) - Ac) / np.linalg.norm(Ac))
     ax_resid = float(np.linalg.norm(Ac.T @ Xh[:, 0] - Bh[cols, 0]) / np.linalg.norm(Bh[cols, 0]))
+
+    # ---- apply / solve sweeps on their own (HBM-bound: every D, E, B resp. ULV block is read once per call)
+    reps = 10
+    dY = hk.empty((n, a.nrhs))
+
+    def timed(fn):
+        ts = []
+        for _ in range(reps):
+            barrier()
+            t1 = time.perf_counter()
+            fn()
+            barrier()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        if os.environ.get("STRUMPACK_AMD_BENCH_DEBUG"):
+            print(ts, file=sys.stderr)
+        return sorted(ts)[len(ts) // 2]
+
+    apply_ms = timed(lambda: H.mult_device(dB.ptr, dY.ptr, a.nrhs))
+
+    def one_solve():
+        H.solve_device(dY.ptr, a.nrhs)
+    hk.check(hk.lib.hssk_memcpy_d2d(hk.ctx, dY.ptr, dB.ptr, 8 * n * a.nrhs))
+    solve_ms = timed(one_solve)
 
     st = stats[-1]
     f_total = st["f_sketch"] + st["f_local"] + st["f_reduce"] + st["f_id"] + st["f_ortho"] + st["f_ulv"] + st["f_solve"]
@@ -165,7 +189,9 @@ def main():
     d = int(st["d_final"])
     launches = max(st["sketch_launches"], 1)
     avg_ms = st["sketch_kernel_ms"] / launches
-    flops_per_launch = st["f_sketch"] / launches / world
+    # flops of the timed launches themselves (the main grid of each sketch GEMM: whole rounds of the 512
+    # workgroup slots; the short tail / edge launches are separate kernels outside the event bracket)
+    flops_per_launch = st["sketch_kernel_flops"] / launches
     ach = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
     traffic = None
     tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -186,9 +212,13 @@ def main():
                   "ortho": st["f_ortho"], "ulv": st["f_ulv"], "solve": st["f_solve"]},
         "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "rounds": int(st["rounds"]), "d": d},
         "checks": {"solve_resid_H": resid, "compress_err_sampled": comp_err, "Ax_minus_b_sampled": ax_resid},
+        "sweeps": {"apply": {"ms": apply_ms, "bytes": H.memory() + 16.0 * n * a.nrhs,
+                             "GBps": (H.memory() + 16.0 * n * a.nrhs) / (apply_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); latency of %d dependent levels at this size" % H.levels()},
+                   "solve": {"ms": solve_ms, "bytes": st["factor_memory"] + 16.0 * n * a.nrhs,
+                             "GBps": (st["factor_memory"] + 16.0 * n * a.nrhs) / (solve_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s)"}},
         "roofline": {"kernel": "dgemm_kernel<192> (sketch S^T = R^T op(A), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches},
+                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:

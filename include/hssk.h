@@ -40,8 +40,11 @@ int hssk_memcpy2d_d2h(hssk_ctx* ctx, void* dst, long long dpitch, const void* sr
 int hssk_memset_zero(hssk_ctx* ctx, void* dst, long long bytes); /* async */
 /* 1 if ptr is device memory of the current process (hipPointerGetAttributes) */
 int hssk_is_device_pointer(const void* ptr);
-/* timing of the LAST hssk_dgemm launch on this context (HIP events on the launch stream), ms */
+/* duration (HIP events on the launch stream, ms) and algorithmic flops (2 m cols k) of the MAIN kernel launch of
+ * the last hssk_dgemm on this context -- the launch whose grid fills whole rounds of the 512 workgroup slots;
+ * the short tail / edge launches and the reduce pass are outside the bracket. */
 float hssk_last_dgemm_ms(hssk_ctx* ctx);
+double hssk_last_dgemm_flops(hssk_ctx* ctx);
 /* effective shader clock (GHz) seen by workgroup 0 of the last hssk_dgemm main launch (s_memtime /
  * s_memrealtime); 0 if unavailable.  Synchronises. */
 double hssk_last_dgemm_clock_ghz(hssk_ctx* ctx);
@@ -162,6 +165,10 @@ typedef struct hssk_qr_desc {
   double* work; /* device, rows + cols doubles */
 } hssk_qr_desc;
 int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
+/* Q(:, 0:nq) only, from panels factored by an earlier hssk_qr_vbatched call with the same A (reflectors + R)
+ * and work (taus); rdiag is not touched.  Lets the rank-adequacy test form Q only for the nodes whose
+ * R-diagonal test did not already settle (compress_stable.hpp:405-417). */
+int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
 
 /* ---- batched triangular solve / LU ------------------------------------------------------------- */
 /* B <- op(T)^{-1} B, T (n x n) triangular, B (n x nrhs)  (trsm Side::L, dense/DenseMatrix.cpp:1059-1085) */

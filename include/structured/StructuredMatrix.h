@@ -98,7 +98,7 @@ int SPX_d_struct_node_info(const CSPStructMat S, int* out);
  * [0] t_compress [1] t_sketch [2] t_random [3] t_tree [4] t_factor [5] t_solve [6] t_mult
  * [7] sketch_kernel_ms [8] sketch_launches [9] rounds [10] d_final
  * [11] f_sketch [12] f_local [13] f_reduce [14] f_id [15] f_ortho [16] f_ulv [17] f_solve
- * [18] factor_memory_bytes */
+ * [18] factor_memory_bytes [19] sketch_kernel_flops (algorithmic flops of the launches timed in [7]) */
 int SPX_d_struct_stats(const CSPStructMat S, double* out);
 /* the hssk kernel context of the matrix (include/hssk.h), for callers that share its stream */
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S);

@@ -32,7 +32,7 @@ ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
 STAT_NAMES = ["t_compress", "t_sketch", "t_random", "t_tree", "t_factor", "t_solve", "t_mult",
               "sketch_kernel_ms", "sketch_launches", "rounds", "d_final", "f_sketch", "f_local",
-              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory"]
+              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory", "sketch_kernel_flops"]
 
 
 def load(path):

@@ -177,7 +177,8 @@ int SPX_d_struct_stats(const CSPStructMat S, double* o) {
   o[5] = st.t_solve; o[6] = st.t_mult; o[7] = st.sketch_kernel_ms; o[8] = st.sketch_launches; o[9] = st.rounds;
   o[10] = st.d_final; o[11] = st.f_sketch; o[12] = st.f_local; o[13] = st.f_reduce; o[14] = st.f_id;
   o[15] = st.f_ortho; o[16] = st.f_ulv; o[17] = st.f_solve; o[18] = (double)hss(S)->engine()->factor_memory();
-  for (int i = 19; i < 24; i++) o[i] = 0;
+  o[19] = st.sketch_kernel_flops;
+  for (int i = 20; i < 24; i++) o[i] = 0;
   SP_CATCH
 }
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S) { return hss(S) ? (void*)hss(S)->engine()->ctx() : nullptr; }

@@ -168,11 +168,11 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
       ck(hssk_dgemm(H.ctx_, 1, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0, lda, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
       ck(hssk_sync(H.ctx_));
       float ms = hssk_last_dgemm_ms(H.ctx_);
-      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
       ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0 * lda, lda, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
       ck(hssk_sync(H.ctx_));
       ms = hssk_last_dgemm_ms(H.ctx_);
-      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; }
+      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
     }
     if (H.o_.world > 1 && !H.dist_subtree_) {
       const long long bytes = (long long)sizeof(double) * H.dcap_ * H.cols_per_rank_;
@@ -963,16 +963,16 @@ void DeviceHSS::ortho_test(const std::vector<int>& ids, const std::vector<int>& 
   std::vector<hssk_qr_desc> qr;
   double* rdiag = tmp.dbl(2 * cnt);
   std::vector<char> untouched(cnt);
+  // The QR of the first d sample columns only has to deliver max / min |R_ii| (DenseMatrix::orthogonalize,
+  // dense/DenseMatrix.cpp:721-744); its explicit Q is needed by the Gram-Schmidt step alone, i.e. for the nodes
+  // the R-diagonal test leaves undecided -- it is formed for those (hssk_formq_vbatched) after the read-back.
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
     const int w = which[k];
     const int m = w == 0 ? nd.mU : nd.mV;
     const double* S = w == 0 ? nd.Srt : nd.Sct;
-    double*& Q = w == 0 ? nd.Qr : nd.Qc;
+    double* Q = w == 0 ? nd.Qr : nd.Qc;
     untouched[k] = (w == 0 ? nd.Ustate : nd.Vstate) == 0;
-    if (!Q) Q = work_->dbl((size_t)m * dcap_);
-    // Q(:, d:d+dd) = S(:, d:d+dd)
-    tr.push_back(hssk_transpose_desc{S + d, Q + (size_t)d * m, dd, m, dcap_, m});
     int c2, n2;
     if (untouched[k]) { c2 = 0; n2 = std::min(d, m); }
     else { c2 = d - dd; n2 = std::min(dd, m - (d - dd)); }
@@ -980,11 +980,11 @@ void DeviceHSS::ortho_test(const std::vector<int>& ids, const std::vector<int>& 
     if (untouched[k]) tr.push_back(hssk_transpose_desc{S, T, n2, m, dcap_, m});
     else cp.push_back(hssk_colgather_desc{Q + (size_t)c2 * m, T, nullptr, m, n2, m, m, 0});
     double* wk = tmp.dbl((size_t)m + n2);
-    qr.push_back(hssk_qr_desc{T, m, m, n2, Q + (size_t)c2 * m, m, n2, rdiag + 2 * k, wk});
+    qr.push_back(hssk_qr_desc{T, m, m, n2, nullptr, m, 0, rdiag + 2 * k, wk});
     stats_.f_ortho += 4.0 * m * (double)n2 * n2;
   }
   if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
-  ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
+  if (!tr.empty()) ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
   ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
   std::vector<double> hr(2 * cnt);
   ck(hssk_memcpy_d2h(ctx_, hr.data(), rdiag, (long long)sizeof(double) * 2 * cnt));
@@ -1000,6 +1000,26 @@ void DeviceHSS::ortho_test(const std::vector<int>& ids, const std::vector<int>& 
     else pend.push_back(k);
   }
   if (pend.empty()) return;
+  // undecided nodes: Q12 block from the stored reflectors, and Q(:, d:d+dd) = S(:, d:d+dd)
+  {
+    std::vector<hssk_qr_desc> fq;
+    tr.clear();
+    for (size_t k : pend) {
+      Node& nd = nodes_[ids[k]];
+      const int w = which[k];
+      const int m = w == 0 ? nd.mU : nd.mV;
+      const double* S = w == 0 ? nd.Srt : nd.Sct;
+      double*& Q = w == 0 ? nd.Qr : nd.Qc;
+      if (!Q) Q = work_->dbl((size_t)m * dcap_);
+      const int c2 = untouched[k] ? 0 : d - dd;
+      hssk_qr_desc q = qr[k];
+      q.Q = Q + (size_t)c2 * m; q.ldq = m; q.nq = q.cols; q.rdiag = nullptr;
+      fq.push_back(q);
+      tr.push_back(hssk_transpose_desc{S + d, Q + (size_t)d * m, dd, m, dcap_, m});
+    }
+    ck(hssk_formq_vbatched(ctx_, fq.data(), (int)fq.size()));
+    ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
+  }
   // iterated classical Gram-Schmidt of the dd new columns against Q12, norms of the first p columns
   const int pc = std::min(dd, o_.p);
   double* nrm = tmp.dbl(2 * pend.size());

@@ -45,7 +45,8 @@ using host_elem_t = std::function<void(int m, const int* I, int n, const int* J,
 
 struct PhaseStats {
   double t_compress = 0, t_sketch = 0, t_random = 0, t_tree = 0, t_factor = 0, t_solve = 0, t_mult = 0;
-  double sketch_kernel_ms = 0;  // sum of HIP-event durations of the sketch GEMM launches
+  double sketch_kernel_ms = 0;  // sum of HIP-event durations of the sketch GEMM main launches
+  double sketch_kernel_flops = 0;  // algorithmic flops of those launches
   int sketch_launches = 0, rounds = 0, d_final = 0;
   // algorithmic flop model
   double f_sketch = 0, f_local = 0, f_reduce = 0, f_id = 0, f_ortho = 0, f_ulv = 0, f_solve = 0;

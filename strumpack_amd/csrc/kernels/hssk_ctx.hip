@@ -125,6 +125,8 @@ double hssk_last_dgemm_clock_ghz(hssk_ctx* c) {
   } catch (...) { return 0.; }
 }
 
+double hssk_last_dgemm_flops(hssk_ctx* c) { return c->dgemm_timed ? c->dgemm_timed_flops : 0.; }
+
 float hssk_last_dgemm_ms(hssk_ctx* c) {
   if (!c->dgemm_timed) return -1.f;
   try { return hssk_rt::event_elapsed_ms(c->ev0, c->ev1); } catch (...) { return -1.f; }

@@ -26,7 +26,8 @@ constexpr int BN = 64, BK = 16;
 // FULL = true : interior tiles -- m % BM == 0, whole BN columns, k-chunk a multiple of BK, operands
 //               16-byte aligned with even leading dimensions: unmasked 16-byte global loads.
 // FULL = false: edge tiles / unaligned operands -- masked 8-byte loads.
-template <int BM, bool TRANSB, bool FULL>
+// TAG only separates the symbol of the short tail launch from the main one (per-kernel profiles stay readable)
+template <int BM, bool TRANSB, bool FULL, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long long k, const double* __restrict__ A,
                                                        long long lda, const double* __restrict__ B, long long ldb,
                                                        double* __restrict__ P, long long ldp, long long pstride,
@@ -44,7 +45,14 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const long long j0 = (long long)(blockIdx.x + jtile0) * BN;
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so XCD x (= id % 8) is handed a
+  // contiguous range of column tiles -- neighbouring tiles share DRAM pages / L2 lines of B within one L2
+  int bx = blockIdx.x;
+  {
+    const int nx = gridDim.x, x = bx & 7, q = nx >> 3, r = nx & 7;
+    bx = x * q + (x < r ? x : r) + (bx >> 3);
+  }
+  const long long j0 = (long long)(bx + jtile0) * BN;
   const int i0 = blockIdx.y * BM;
   const long long kbeg = (long long)blockIdx.z * kchunk;
   const long long kend = kbeg + kchunk < k ? kbeg + kchunk : k;
@@ -242,27 +250,27 @@ __global__ void dgemm_reduce_kernel(int m, long long n, const double* __restrict
   }
 }
 
-template <int BM, bool FULL>
+template <int BM, bool FULL, int TAG>
 void launch_dgemm(hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
                   long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
                   long long kchunk, int jtile0, long long* clk) {
   if (grid.x == 0) return;
   if (transB)
-    HSSK_LAUNCH((dgemm_kernel<BM, true, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+    HSSK_LAUNCH((dgemm_kernel<BM, true, FULL, TAG>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
   else
-    HSSK_LAUNCH((dgemm_kernel<BM, false, FULL>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+    HSSK_LAUNCH((dgemm_kernel<BM, false, FULL, TAG>), grid, dim3(256), 0, ctx->stream, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
 }
 
 }  // namespace
 
 namespace {
-template <bool FULL>
+template <bool FULL, int TAG>
 void launch_bm(int BM, hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
                long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
                long long kchunk, int jtile0, long long* clk) {
-  if (BM == 192) launch_dgemm<192, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
-  else if (BM == 128) launch_dgemm<128, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
-  else launch_dgemm<64, FULL>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  if (BM == 192) launch_dgemm<192, FULL, TAG>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  else if (BM == 128) launch_dgemm<128, FULL, TAG>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  else launch_dgemm<64, FULL, TAG>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
 }
 }  // namespace
 
@@ -281,52 +289,89 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
                        (((size_t)A | (size_t)B) % 16 == 0);
   const unsigned gn_full = aligned ? (unsigned)(n / BN) : 0u;
   const unsigned gn_edge = gn - gn_full;
-  // split K so that each grid is a near-multiple of the 512 resident workgroup slots (256 CUs x 2)
-  auto pick_split = [&](long long tiles) {
-    const long long slots = 512;
-    int best = 1;
-    double best_eff = 0.;
-    for (int s = 1; s <= 256; s++) {
-      if (s > 1 && ksteps / s < 24) break;  // keep chunks long enough to amortise the epilogue
-      long long wgs = tiles * s;
-      long long rounds = (wgs + slots - 1) / slots;
-      double eff = (double)wgs / (double)(rounds * slots);
-      if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
-      if (wgs >= 16 * slots) break;
-    }
-    return k > 0 ? best : 1;
-  };
+  // Work decomposition.  The 256 CUs hold 512 workgroups (2 per CU); a grid that is not a multiple of 512 ends
+  // in a partly filled round.  The full tiles are therefore cut into a MAIN group whose grid (tiles x K-split s)
+  // fills r whole rounds exactly, and a short TAIL group (the remaining < 512 / s tiles) with a deeper K-split
+  // that fills one last round of short workgroups; the ragged edge tile keeps its own masked launch.  Every
+  // group writes K-partials that one deterministic reduce pass per group folds into C.
+  const long long slots = 512;
+  struct Group { long long tile0 = 0, ntiles = 0; int split = 1; long long kchunk = BK; int nz = 0; double* P = nullptr; long long cols = 0; };
   auto chunk_of = [&](int split) {
     long long c = ((ksteps + split - 1) / split) * BK;
     return c > 0 ? c : (long long)BK;
   };
-  const long long ldp = m;
-  const long long n_full = (long long)gn_full * BN, n_edge = n - n_full;
-  long long kchunk_f = BK, kchunk_e = BK;
-  int nz_f = 0, nz_e = 0;
-  if (gn_full) { kchunk_f = chunk_of(pick_split((long long)gm * gn_full)); nz_f = (int)std::max<long long>(1, (k + kchunk_f - 1) / kchunk_f); }
-  if (gn_edge) { kchunk_e = chunk_of(pick_split((long long)gm * gn_edge)); nz_e = (int)std::max<long long>(1, (k + kchunk_e - 1) / kchunk_e); }
-  const long long pstride_f = ldp * n_full, pstride_e = ldp * n_edge;
-  double* P = ctx->scratch(sizeof(double) * (size_t)(pstride_f * nz_f + pstride_e * nz_e + 4));
-  long long* clk = (long long*)(P + pstride_f * nz_f + pstride_e * nz_e);  // clock probe of workgroup 0
-  double* Pf = P;
-  double* Pe = P + pstride_f * nz_f;
-  hssk_rt::event_record(ctx->ev0, ctx->stream);
-  // the edge partials are laid out as if the edge columns started at 0: shift P by -n_full columns
-  if (gn_edge) launch_bm<false>(BM, ctx, transB, dim3(gn_edge, gm, (unsigned)nz_e), m, n, k, A, lda, B, ldb, Pe - n_full * ldp, ldp, pstride_e, kchunk_e, (int)gn_full, nullptr);
-  if (gn_full) launch_bm<true>(BM, ctx, transB, dim3(gn_full, gm, (unsigned)nz_f), m, n, k, A, lda, B, ldb, Pf, ldp, pstride_f, kchunk_f, 0, clk);
-  ctx->d_clk = gn_full ? clk : nullptr;
-  hssk_rt::event_record(ctx->ev1, ctx->stream);
-  ctx->dgemm_timed = true;
+  auto max_split = [&]() { return (int)std::max<long long>(1, std::min<long long>(256, ksteps / 24)); };
+  // split of a group that should fill (at most) one round
+  auto one_round_split = [&](long long tiles) {
+    if (tiles <= 0 || k <= 0) return 1;
+    return (int)std::max<long long>(1, std::min<long long>(max_split(), slots / tiles));
+  };
+  Group gmain, gtail, gedge;
   if (gn_full) {
-    long long total = (long long)m * n_full;
-    unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-    HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, n_full, (const double*)Pf, ldp, pstride_f, nz_f, alpha, beta, C, ldc);
+    const long long T = (long long)gm * gn_full;   // gm == 1 on the sketch path (m = d <= 192)
+    // cost model (units: one k-step of one workgroup): rounds x (steps per chunk + epilogue) + reduce traffic
+    const double epi = 3.0, red = 30.0;
+    double best = 1e300;
+    int best_s = 1;
+    long long best_main = T;
+    for (int sp = 1; sp <= std::min(max_split(), 64); sp++) {
+      const long long r = (T * sp) / slots;                       // whole rounds
+      long long tm = r > 0 ? std::min<long long>(T, (r * slots) / sp) : 0;
+      if (gm > 1) tm = T;                                          // tall outputs: no tile regrouping
+      const long long tt = T - tm;
+      double cost = 0.;
+      if (tm) cost += (double)((tm * sp + slots - 1) / slots) * ((double)(ksteps + sp - 1) / sp + epi) + red * sp * (double)tm / (double)T;
+      if (tt) {
+        const int st = one_round_split(tt);
+        cost += (double)((tt * st + slots - 1) / slots) * ((double)(ksteps + st - 1) / st + epi) + red * st * (double)tt / (double)T + 2.0;
+      }
+      if (cost < best - 1e-9) { best = cost; best_s = sp; best_main = tm; }
+    }
+    if (k <= 0) { best_s = 1; best_main = T; }
+    gmain.tile0 = 0; gmain.ntiles = gm > 1 ? gn_full : best_main; gmain.split = best_s;
+    gtail.tile0 = gmain.ntiles; gtail.ntiles = gn_full - gmain.ntiles; gtail.split = one_round_split(gtail.ntiles);
   }
-  if (gn_edge) {
-    long long total = (long long)m * n_edge;
+  gedge.tile0 = gn_full; gedge.ntiles = gn_edge; gedge.split = one_round_split((long long)gm * gn_edge);
+  const long long ldp = m;
+  size_t ptot = 0;
+  for (Group* g : {&gmain, &gtail, &gedge}) {
+    if (!g->ntiles) continue;
+    g->kchunk = chunk_of(g->split);
+    g->nz = (int)std::max<long long>(1, (k + g->kchunk - 1) / g->kchunk);
+    g->cols = std::min<long long>(n, (g->tile0 + g->ntiles) * BN) - g->tile0 * BN;
+    ptot += (size_t)ldp * g->cols * g->nz;
+  }
+  double* P = ctx->scratch(sizeof(double) * (ptot + 4));
+  long long* clk = (long long*)(P + ptot);  // clock probe of workgroup 0 of the main launch
+  {
+    double* q = P;
+    for (Group* g : {&gmain, &gtail, &gedge}) {
+      if (!g->ntiles) continue;
+      g->P = q;
+      q += (size_t)ldp * g->cols * g->nz;
+    }
+  }
+  // partials of a group are addressed by absolute column: shift its base by the group's first column
+  auto shifted = [&](const Group& g) { return g.P - g.tile0 * BN * ldp; };
+  // the timed launch (hssk_last_dgemm_ms / _flops): the main group, or whatever carries the bulk
+  const Group* timed = gmain.ntiles ? &gmain : (gtail.ntiles ? &gtail : &gedge);
+  auto bracket = [&](const Group* g, auto&& launch) {
+    if (!g->ntiles) return;
+    if (g == timed) hssk_rt::event_record(ctx->ev0, ctx->stream);
+    launch();
+    if (g == timed) hssk_rt::event_record(ctx->ev1, ctx->stream);
+  };
+  bracket(&gedge, [&] { launch_bm<false, 0>(BM, ctx, transB, dim3((unsigned)gedge.ntiles, gm, (unsigned)gedge.nz), m, n, k, A, lda, B, ldb, shifted(gedge), ldp, ldp * gedge.cols, gedge.kchunk, (int)gedge.tile0, nullptr); });
+  bracket(&gtail, [&] { launch_bm<true, 1>(BM, ctx, transB, dim3((unsigned)gtail.ntiles, gm, (unsigned)gtail.nz), m, n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)gtail.tile0, nullptr); });
+  bracket(&gmain, [&] { launch_bm<true, 0>(BM, ctx, transB, dim3((unsigned)gmain.ntiles, gm, (unsigned)gmain.nz), m, n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)gmain.tile0, clk); });
+  ctx->d_clk = gmain.ntiles ? clk : nullptr;
+  ctx->dgemm_timed = true;
+  ctx->dgemm_timed_flops = 2.0 * (double)m * (double)timed->cols * (double)k;
+  for (const Group* g : {&gmain, &gtail, &gedge}) {
+    if (!g->ntiles) continue;
+    long long total = (long long)m * g->cols;
     unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-    HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, n_edge, (const double*)Pe, ldp, pstride_e, nz_e, alpha, beta, C + n_full * ldc, ldc);
+    HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->tile0 * BN * ldc, ldc);
   }
   hssk_rt::check_launch();
   HSSK_API_END

@@ -22,7 +22,7 @@ namespace {
 constexpr int QR_THREADS = 512;
 constexpr int QR_WAVES = QR_THREADS / 64;
 
-__global__ __launch_bounds__(QR_THREADS) void qr_kernel(const hssk_qr_desc* __restrict__ descs) {
+__global__ __launch_bounds__(QR_THREADS) void qr_kernel(const hssk_qr_desc* __restrict__ descs, int qonly) {
   HSSK_SHARED double s_tau;
   const hssk_qr_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_kernel(const hssk_qr_desc* __re
   const int kmax = rows < cols ? rows : cols;
   double rmax = 0., rmin = 0.;
 
-  for (int k = 0; k < kmax; k++) {
+  for (int k = 0; k < (qonly ? 0 : kmax); k++) {
     if (wave == 0) {
       double* col = A + (size_t)k * ld;
       double s = 0.;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_kernel(const hssk_qr_desc* __re
       }
     __syncthreads();
   }
-  if (p.rdiag && tid == 0) { p.rdiag[0] = rmax; p.rdiag[1] = rmin; }
+  if (!qonly && p.rdiag && tid == 0) { p.rdiag[0] = rmax; p.rdiag[1] = rmin; }
 
   // ---- explicit Q(:, 0:nq) = H_0 H_1 ... H_{kmax-1} I(:, 0:nq)   (dorg2r)
   const int nq = p.nq;
@@ -374,7 +374,9 @@ void gemm_batch(hssk_ctx* ctx, std::vector<hssk_gemm_desc>& g) {
   if (hssk_gemm_vbatched(ctx, g.data(), (int)g.size())) throw std::runtime_error(hssk_last_error());
 }
 
-void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count) {
+// factor == false: A already holds the factored panels and work the taus (a previous factor call); only the
+// compact-WY pairs are rebuilt and Q is formed
+void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor) {
   std::vector<size_t> offV(count), offW(count), offR(count);
   size_t tot = 0;
   int pmax = 0;
@@ -398,15 +400,15 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count) {
     for (int i = 0; i < count; i++) {
       const hssk_qr_desc& d = descs[i];
       const int kmax = std::min(d.rows, d.cols);
-      if (j0 >= kmax && !(p == 0 && d.rdiag)) continue;
+      if (j0 >= kmax && !(factor && p == 0 && d.rdiag)) continue;
       const int nb = std::max(0, std::min(QB, kmax - j0)), rr = d.rows - j0;
       double* Ap = d.A + j0 + (size_t)j0 * d.lda;
       double* Vc = ws + offV[i] + j0 + (size_t)j0 * d.rows;
       double* VT = Vc + (size_t)d.rows * kmax;
       double* W = ws + offW[i];
       double* rdp = ws + offR[i];
-      lp.push_back(QPanel{Ap, d.work + j0, Vc, VT, rdp, d.rdiag, d.lda, rr, nb, d.rows, p == 0});
-      if (nb == 0) continue;
+      lp.push_back(QPanel{Ap, d.work + j0, Vc, VT, rdp, factor ? d.rdiag : nullptr, d.lda, rr, nb, d.rows, p == 0});
+      if (nb == 0 || !factor) continue;
       pd.push_back(hssk_qr_desc{Ap, d.lda, rr, nb, nullptr, 0, 0, rdp, d.work + j0});
       const int nt = d.cols - (j0 + nb);
       if (nt > 0) {
@@ -470,7 +472,7 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
     qmax = std::max(qmax, descs[i].nq);
   }
   if (rmax <= QB_MAXROWS && (force_blocked() || rmax > 256 || cmax > 208)) {
-    qr_blocked(ctx, descs, count);
+    qr_blocked(ctx, descs, count, true);
     hssk_rt::check_launch();
     return 0;
   }
@@ -490,7 +492,31 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
       else launch_formq_reg<4, 8>(ctx, dd, descs, count);
     }
   } else {
-    HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd);
+    HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd, 0);
+  }
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+// Q only, from panels factored by an earlier hssk_qr_vbatched call (A = reflectors + R, work = taus)
+extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  int rmax = 0, cmax = 0, qmax = 0;
+  for (int i = 0; i < count; i++) {
+    rmax = std::max(rmax, descs[i].rows);
+    cmax = std::max(cmax, descs[i].cols);
+    qmax = std::max(qmax, descs[i].nq);
+  }
+  if (qmax <= 0) return 0;
+  if (rmax <= QB_MAXROWS && (force_blocked() || rmax > 256)) {
+    qr_blocked(ctx, descs, count, false);
+  } else {
+    auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
+    if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
+    else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
+    else if (rmax <= 256) launch_formq_reg<4, 8>(ctx, dd, descs, count);
+    else HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd, 1);
   }
   hssk_rt::check_launch();
   HSSK_API_END

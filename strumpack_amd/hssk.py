@@ -86,13 +86,13 @@ class ShiftDesc(C.Structure):
 
 HSSK_SYMBOLS = [
     "hssk_ctx_create", "hssk_ctx_destroy", "hssk_ctx_stream", "hssk_sync", "hssk_last_error",
-    "hssk_malloc", "hssk_free", "hssk_memcpy_h2d", "hssk_memcpy_d2h", "hssk_last_dgemm_ms",
+    "hssk_malloc", "hssk_free", "hssk_memcpy_h2d", "hssk_memcpy_d2h", "hssk_last_dgemm_ms", "hssk_last_dgemm_flops",
     "hssk_fill_toeplitz", "hssk_randn", "hssk_dgemm", "hssk_gemm_vbatched", "hssk_gather_cols",
     "hssk_gather_rows", "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched",
     "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
     "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops", "hssk_memcpy_d2d",
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
-    "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched",
+    "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
 ]
 
 
@@ -163,6 +163,8 @@ class Hssk:
         L.hssk_last_dgemm_clock_ghz.argtypes = [C.c_void_p]
         L.hssk_last_dgemm_ms.restype = C.c_float
         L.hssk_last_dgemm_ms.argtypes = [C.c_void_p]
+        L.hssk_last_dgemm_flops.restype = C.c_double
+        L.hssk_last_dgemm_flops.argtypes = [C.c_void_p]
         L.hssk_fill_toeplitz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_char]
         L.hssk_randn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
                                  C.c_int, C.c_longlong, C.c_ulonglong]
@@ -172,7 +174,7 @@ class Hssk:
         for name in ("hssk_gemm_vbatched", "hssk_gather_cols", "hssk_gather_rows",
                      "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched", "hssk_qr_vbatched",
                      "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
-                     "hssk_sumsq_vbatched", "hssk_leaf_update_vbatched"):
+                     "hssk_sumsq_vbatched", "hssk_leaf_update_vbatched", "hssk_formq_vbatched"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         L.hssk_mfma_f64_peak_tflops.restype = C.c_double

@@ -243,6 +243,29 @@ def case_qr(hk, shapes, seed=7):
                 assert np.allclose(Q[:, :k] @ Rg, A, atol=1e-11 * max(1, np.abs(A).max()))
 
 
+def case_qr_lazy(hk, shapes, seed=17):
+    """Factor without Q, then hssk_formq_vbatched from the stored reflectors == Q of the one-call path."""
+    r = rng(seed)
+    d0, d1, keep = [], [], []
+    for (rows, cols, nq) in shapes:
+        A = r.standard_normal((rows, cols))
+        dA = hk.array(A)
+        dQ = hk.empty((rows, nq))
+        drd, dwk = hk.empty((2,)), hk.empty((rows + cols,))
+        keep.append((A, dA, dQ, drd, dwk))
+        d0.append(K.QrDesc(dA.ptr, rows, rows, cols, None, rows, 0, drd.ptr, dwk.ptr))
+        d1.append(K.QrDesc(dA.ptr, rows, rows, cols, dQ.ptr, rows, nq, None, dwk.ptr))
+    hk.batch("hssk_qr_vbatched", d0)
+    hk.batch("hssk_formq_vbatched", d1)
+    hk.sync()
+    for ((rows, cols, nq), (A, dA, dQ, drd, _)) in zip(shapes, keep):
+        Ql, Rl = sla.qr(A, mode="economic")
+        # LAPACK convention on both sides -> same signs
+        assert np.allclose(dQ.get()[:, :min(nq, cols)], Ql[:, :min(nq, cols)], atol=1e-11), f"lazy Q mismatch {rows}x{cols}"
+        rd = drd.get()
+        assert np.isclose(rd[0], np.abs(np.diag(Rl)).max()) and np.isclose(rd[1], np.abs(np.diag(Rl)).min())
+
+
 def case_trsm_lu(hk, seed=9):
     r = rng(seed)
     descs, keep = [], []

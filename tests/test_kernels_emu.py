@@ -73,5 +73,11 @@ def test_qr(hk):
     KC.case_qr(hk, [(600, 20, 30)], seed=12)                        # global-memory fallback
 
 
+def test_formq_from_stored_reflectors(hk):
+    KC.case_qr_lazy(hk, [(40, 12, 12), (100, 64, 64), (195, 128, 128)])   # register kernels
+    KC.case_qr_lazy(hk, [(300, 70, 70)], seed=18)                          # blocked
+    KC.case_qr_lazy(hk, [(600, 20, 20)], seed=19)                          # global-memory fallback
+
+
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)

@@ -48,6 +48,12 @@ def test_leaf_update(hk):
     KC.case_leaf_update(hk, [(192, 195), (192, 196)] * 8 + [(64, 390)], seed=13)
 
 
+def test_formq_from_stored_reflectors(hk):
+    KC.case_qr_lazy(hk, [(40, 12, 12), (100, 64, 64), (195, 128, 128)] * 3)
+    KC.case_qr_lazy(hk, [(390, 128, 128), (300, 70, 70)] * 2, seed=18)
+    KC.case_qr_lazy(hk, [(600, 20, 20)], seed=19)
+
+
 def test_generators(hk):
     KC.case_toeplitz_randn(hk, n=700)
 
