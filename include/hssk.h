@@ -45,6 +45,9 @@ int hssk_is_device_pointer(const void* ptr);
  * the short tail / edge launches and the reduce pass are outside the bracket. */
 float hssk_last_dgemm_ms(hssk_ctx* ctx);
 double hssk_last_dgemm_flops(hssk_ctx* ctx);
+/* profiling aid: per-workgroup records of that main launch, 4 long long each {start, end (100 MHz ticks), hardware id
+ * (XCC_ID << 32 | HW_ID), column tile}; returns the number of records copied (<= max_wgs).  Synchronises. */
+long long hssk_last_dgemm_trace(hssk_ctx* ctx, long long* out, long long max_wgs);
 /* effective shader clock (GHz) seen by workgroup 0 of the last hssk_dgemm main launch (s_memtime /
  * s_memrealtime); 0 if unavailable.  Synchronises. */
 double hssk_last_dgemm_clock_ghz(hssk_ctx* ctx);

@@ -58,6 +58,10 @@ __device__ __forceinline__ double hssk_wave_max(double v) {
 // shader-clock and constant-rate (100 MHz) counters, for the peak probe
 __device__ __forceinline__ long long hssk_clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ long long hssk_wallclock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
+// (XCC_ID << 32) | HW_ID: which XCD / SE / CU / SIMD this wave runs on (profiling aid)
+__device__ __forceinline__ long long hssk_hwid() {
+  return ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+}
 
 // scheduling hint: ask the backend to interleave `n` groups of {1 MFMA, 1 LDS write}
 #define HSSK_SCHED_MFMA_DSWRITE(n)                         \

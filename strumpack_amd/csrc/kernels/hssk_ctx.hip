@@ -125,6 +125,15 @@ double hssk_last_dgemm_clock_ghz(hssk_ctx* c) {
   } catch (...) { return 0.; }
 }
 
+long long hssk_last_dgemm_trace(hssk_ctx* c, long long* out, long long max_wgs) {
+  try {
+    if (!c->d_clk || c->dgemm_trace_wgs <= 0) return 0;
+    const long long nw = c->dgemm_trace_wgs < max_wgs ? c->dgemm_trace_wgs : max_wgs;
+    if (nw > 0) { hssk_rt::d2h(out, c->d_clk + 4, sizeof(long long) * 4 * nw, c->stream); hssk_rt::sync(c->stream); }
+    return nw;
+  } catch (...) { return -1; }
+}
+
 double hssk_last_dgemm_flops(hssk_ctx* c) { return c->dgemm_timed ? c->dgemm_timed_flops : 0.; }
 
 float hssk_last_dgemm_ms(hssk_ctx* c) {

@@ -18,6 +18,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -225,10 +226,17 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
         long long gj = j0 + wn + b * 16 + l4 + 4 * r;
         if (gi < m && gj < n) Pz[gi + gj * ldp] = acc[a][b][r];
       }
-  // shader-clock probe (workgroup 0 only): elapsed shader cycles and 100 MHz ticks of this workgroup
-  if (clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-    clk[0] = hssk_clock() - t0_;
-    clk[1] = hssk_wallclock() - w0_;
+  // shader-clock probe (workgroup 0: elapsed shader cycles and 100 MHz ticks) + per-workgroup trace
+  // {start tick, end tick, hw id, tile} for hssk_last_dgemm_trace
+  if (clk && threadIdx.x == 0) {
+    const long long w1 = hssk_wallclock();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+      clk[0] = hssk_clock() - t0_;
+      clk[1] = w1 - w0_;
+    }
+    const long long fid = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    long long* rec = clk + 4 + 4 * fid;
+    rec[0] = w0_; rec[1] = w1; rec[2] = hssk_hwid(); rec[3] = bx;
   }
 }
 
@@ -314,7 +322,12 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     double best = 1e300;
     int best_s = 1;
     long long best_main = T;
-    for (int sp = 1; sp <= std::min(max_split(), 64); sp++) {
+    // K-chunks of at most ~1024 stages: the workgroups running together on an XCD then stay within a window of
+    // the shared A panel (R^T, 24 KB per stage) that its 4 MB L2 can hold even though their speeds differ by
+    // +-20 % (two workgroups share a CU's MFMA pipes unevenly).  Measured at N = 1e5 (TCC_EA0_RDREQ_DRAM_32B):
+    // memory-side reads per launch 207 GB with one chunk, 123 GB with 6, 96 GB with 12; algorithmic 80 GB.
+    const int sp_min = (int)std::min<long long>(std::min(max_split(), 64), (ksteps + 1023) / 1024);
+    for (int sp = std::max(1, sp_min); sp <= std::min(max_split(), 64); sp++) {
       const long long r = (T * sp) / slots;                       // whole rounds
       long long tm = r > 0 ? std::min<long long>(T, (r * slots) / sp) : 0;
       if (gm > 1) tm = T;                                          // tall outputs: no tile regrouping
@@ -328,6 +341,12 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
       if (cost < best - 1e-9) { best = cost; best_s = sp; best_main = tm; }
     }
     if (k <= 0) { best_s = 1; best_main = T; }
+    if (const char* e = std::getenv("HSSK_DGEMM_SPLIT")) {   // tuning override: K-split of the main group
+      const int sp = std::max(1, std::min(max_split(), std::atoi(e)));
+      const long long r = (T * sp) / slots;
+      best_s = sp;
+      best_main = (gm > 1 || r == 0) ? T : std::min<long long>(T, (r * slots) / sp);
+    }
     gmain.tile0 = 0; gmain.ntiles = gm > 1 ? gn_full : best_main; gmain.split = best_s;
     gtail.tile0 = gmain.ntiles; gtail.ntiles = gn_full - gmain.ntiles; gtail.split = one_round_split(gtail.ntiles);
   }
@@ -341,7 +360,8 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     g->cols = std::min<long long>(n, (g->tile0 + g->ntiles) * BN) - g->tile0 * BN;
     ptot += (size_t)ldp * g->cols * g->nz;
   }
-  double* P = ctx->scratch(sizeof(double) * (ptot + 4));
+  const size_t ntrace = gmain.ntiles ? (size_t)gmain.ntiles * gm * gmain.nz : 0;
+  double* P = ctx->scratch(sizeof(double) * (ptot + 4 + 4 * ntrace));
   long long* clk = (long long*)(P + ptot);  // clock probe of workgroup 0 of the main launch
   {
     double* q = P;
@@ -365,6 +385,7 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
   bracket(&gtail, [&] { launch_bm<true, 1>(BM, ctx, transB, dim3((unsigned)gtail.ntiles, gm, (unsigned)gtail.nz), m, n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)gtail.tile0, nullptr); });
   bracket(&gmain, [&] { launch_bm<true, 0>(BM, ctx, transB, dim3((unsigned)gmain.ntiles, gm, (unsigned)gmain.nz), m, n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)gmain.tile0, clk); });
   ctx->d_clk = gmain.ntiles ? clk : nullptr;
+  ctx->dgemm_trace_wgs = (long long)ntrace;
   ctx->dgemm_timed = true;
   ctx->dgemm_timed_flops = 2.0 * (double)m * (double)timed->cols * (double)k;
   for (const Group* g : {&gmain, &gtail, &gedge}) {

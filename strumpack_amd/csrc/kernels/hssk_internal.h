@@ -17,6 +17,7 @@ struct hssk_ctx {
   hssk_rt::event_t ev0{}, ev1{};
   bool dgemm_timed = false;
   double dgemm_timed_flops = 0.;  // algorithmic flops of the launch bracketed by ev0 / ev1
+  long long dgemm_trace_wgs = 0;  // workgroups of the last main launch (trace records behind d_clk + 4)
   long long* d_clk = nullptr;   // device: {shader cycles, 100 MHz ticks} of workgroup 0 of the last dgemm
   double* d_scratch = nullptr;  // split-K partials of hssk_dgemm
   size_t scratch_bytes = 0;

@@ -86,7 +86,7 @@ class ShiftDesc(C.Structure):
 
 HSSK_SYMBOLS = [
     "hssk_ctx_create", "hssk_ctx_destroy", "hssk_ctx_stream", "hssk_sync", "hssk_last_error",
-    "hssk_malloc", "hssk_free", "hssk_memcpy_h2d", "hssk_memcpy_d2h", "hssk_last_dgemm_ms", "hssk_last_dgemm_flops",
+    "hssk_malloc", "hssk_free", "hssk_memcpy_h2d", "hssk_memcpy_d2h", "hssk_last_dgemm_ms", "hssk_last_dgemm_flops", "hssk_last_dgemm_trace",
     "hssk_fill_toeplitz", "hssk_randn", "hssk_dgemm", "hssk_gemm_vbatched", "hssk_gather_cols",
     "hssk_gather_rows", "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched",
     "hssk_qr_vbatched", "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
@@ -163,6 +163,8 @@ class Hssk:
         L.hssk_last_dgemm_clock_ghz.argtypes = [C.c_void_p]
         L.hssk_last_dgemm_ms.restype = C.c_float
         L.hssk_last_dgemm_ms.argtypes = [C.c_void_p]
+        L.hssk_last_dgemm_trace.restype = C.c_longlong
+        L.hssk_last_dgemm_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
         L.hssk_last_dgemm_flops.restype = C.c_double
         L.hssk_last_dgemm_flops.argtypes = [C.c_void_p]
         L.hssk_fill_toeplitz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_char]

@@ -61,6 +61,7 @@ inline double hssk_wave_max(double v) {
 
 inline long long hssk_clock() { return 0; }
 inline long long hssk_wallclock() { return 0; }
+inline long long hssk_hwid() { return 0; }
 
 #define HSSK_SCHED_MFMA_DSWRITE(n)
 
