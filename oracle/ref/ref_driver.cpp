@@ -17,6 +17,9 @@
 #include "StrumpackParameters.hpp"
 #include "dense/DenseMatrix.hpp"
 #include "misc/RandomWrapper.hpp"
+#include "kernel/KernelRegression.hpp"
+#include "clustering/Clustering.hpp"
+#include "clustering/NeighborSearch.hpp"
 
 using namespace strumpack;
 using namespace strumpack::HSS;
@@ -190,6 +193,110 @@ int ref_hss_bench_toeplitz(int n, int leaf, double rel_tol, double abs_tol, int 
   stats[0] = H.rank(); stats[1] = H.levels(); stats[2] = C.normF() / B.normF();
   stats[3] = H.memory();
   return 0;
+}
+
+
+// ---- kernel-matrix front end: HSSMatrix(kernel::Kernel&, opts), HSS/HSSMatrix.cpp:88-106 ----
+// data: d x n column-major (one point per column), copied; the reference reorders its copy while clustering.
+struct RefKernelHSS {
+  DenseMatrix<double> data;
+  std::unique_ptr<kernel::Kernel<double>> K;
+  std::unique_ptr<HSSMatrix<double>> H;
+};
+void* ref_kernel_hss_create(int n, int d, const double* data, int ktype, double h, double lambda, int p,
+                            double rel_tol, double abs_tol, int leaf, int max_rank, int clustering,
+                            int ann, int ann_iterations) {
+  auto r = new RefKernelHSS();
+  r->data = DenseMatrix<double>(d, n, data, d);
+  r->K = kernel::create_kernel<double>(ktype == 1 ? kernel::KernelType::LAPLACE : (ktype == 2 ? kernel::KernelType::ANOVA : kernel::KernelType::GAUSS), r->data, h, lambda, p);
+  HSSOptions<double> o;
+  o.set_verbose(false);
+  o.set_rel_tol(rel_tol); o.set_abs_tol(abs_tol); o.set_leaf_size(leaf); o.set_max_rank(max_rank);
+  o.set_clustering_algorithm(clustering == 0 ? ClusteringAlgorithm::NATURAL : (clustering == 2 ? ClusteringAlgorithm::KD_TREE : ClusteringAlgorithm::TWO_MEANS));
+  o.set_approximate_neighbors(ann);
+  o.set_ann_iterations(ann_iterations);
+  r->H.reset(new HSSMatrix<double>(*r->K, o));
+  return r;
+}
+void ref_kernel_hss_destroy(void* h) { delete static_cast<RefKernelHSS*>(h); }
+// the (re-ordered) data points the reference's kernel holds after construction, and its 1-based permutation
+void ref_kernel_hss_data(void* h, double* data_out, int* perm_out) {
+  auto r = static_cast<RefKernelHSS*>(h);
+  std::memcpy(data_out, r->data.data(), sizeof(double) * r->data.rows() * r->data.cols());
+  auto& pm = r->K->permutation();
+  for (std::size_t i = 0; i < pm.size(); i++) perm_out[i] = pm[i];
+}
+int ref_kernel_hss_info(void* h, long long* out) {
+  auto r = static_cast<RefKernelHSS*>(h);
+  out[0] = r->H->is_compressed(); out[1] = r->H->levels(); out[2] = r->H->rank(); out[3] = r->H->memory();
+  return 0;
+}
+int ref_kernel_hss_node_info(void* h, int* out, int cap_nodes) {
+  RefHSS t; t.H = std::move(static_cast<RefKernelHSS*>(h)->H);
+  int c = ref_hss_node_info(&t, out, cap_nodes);
+  static_cast<RefKernelHSS*>(h)->H = std::move(t.H);
+  return c;
+}
+void ref_kernel_hss_mult(void* h, int nrhs, const double* B, int ldb, double* C, int ldc) {
+  auto r = static_cast<RefKernelHSS*>(h);
+  int n = r->H->rows();
+  DenseMatrixWrapper<double> b(n, nrhs, const_cast<double*>(B), ldb), c(n, nrhs, C, ldc);
+  c.copy(r->H->apply(b));
+}
+void ref_kernel_hss_factor_solve(void* h, int nrhs, double* B, int ldb) {
+  auto r = static_cast<RefKernelHSS*>(h);
+  r->H->factor();
+  DenseMatrixWrapper<double> b(r->H->rows(), nrhs, B, ldb);
+  r->H->solve(b);
+}
+// exact kernel entries K(I, J) as the reference evaluates them on its (re-ordered) data
+void ref_kernel_eval(void* h, int ni, const int* I, int nj, const int* J, double* out) {
+  auto r = static_cast<RefKernelHSS*>(h);
+  for (int j = 0; j < nj; j++)
+    for (int i = 0; i < ni; i++) out[i + (size_t)j * ni] = r->K->eval(I[i], J[j]);
+}
+// Kernel::fit_HSS + Kernel::predict (kernel/KernelRegression.hpp:56-123), as examples/dense/KernelRegression.cpp drives them
+void ref_kernel_regression(int n, int d, const double* train, const double* labels, int m, const double* test,
+                           int ktype, double h, double lambda, int p, double rel_tol, double abs_tol, int leaf,
+                           int clustering, int ann, double* weights_out, double* prediction_out, long long* info) {
+  DenseMatrix<double> data(d, n, train, d);
+  auto K = kernel::create_kernel<double>(ktype == 1 ? kernel::KernelType::LAPLACE : (ktype == 2 ? kernel::KernelType::ANOVA : kernel::KernelType::GAUSS), data, h, lambda, p);
+  HSSOptions<double> o;
+  o.set_verbose(false);
+  o.set_rel_tol(rel_tol); o.set_abs_tol(abs_tol); o.set_leaf_size(leaf);
+  o.set_clustering_algorithm(clustering == 0 ? ClusteringAlgorithm::NATURAL : (clustering == 2 ? ClusteringAlgorithm::KD_TREE : ClusteringAlgorithm::TWO_MEANS));
+  o.set_approximate_neighbors(ann);
+  std::vector<double> lab(labels, labels + n);
+  double t0 = now();
+  auto w = K->fit_HSS(lab, o);
+  double t1 = now();
+  DenseMatrix<double> tst(d, m, test, d);
+  auto pred = K->predict(tst, w);
+  double t2 = now();
+  for (int i = 0; i < n; i++) weights_out[i] = w(i, 0);
+  for (int i = 0; i < m; i++) prediction_out[i] = pred[i];
+  info[0] = (long long)((t1 - t0) * 1e6); info[1] = (long long)((t2 - t1) * 1e6);
+}
+// binary_tree_clustering (clustering/Clustering.hpp:143-168): perm (1-based) and the leaf sizes of the tree, in order
+int ref_clustering(int n, int d, double* data_inout, int algo, int leaf, int* perm_out, int* leaf_sizes, int cap) {
+  DenseMatrix<double> p(d, n, data_inout, d);
+  std::vector<int> perm;
+  auto t = binary_tree_clustering(algo == 0 ? ClusteringAlgorithm::NATURAL : (algo == 2 ? ClusteringAlgorithm::KD_TREE : ClusteringAlgorithm::TWO_MEANS), p, perm, leaf);
+  std::memcpy(data_inout, p.data(), sizeof(double) * d * n);
+  for (int i = 0; i < n; i++) perm_out[i] = perm[i];
+  auto ls = t.template leaf_sizes<int>();
+  int c = 0;
+  for (auto s : ls) { if (c < cap) leaf_sizes[c] = s; c++; }
+  return c;
+}
+// find_approximate_neighbors (clustering/NeighborSearch.cpp:324): ann is k x n (neighbour ids of point i in column i)
+void ref_ann(int n, int d, const double* data, int iterations, int k, unsigned* ann_out, double* scores_out) {
+  DenseMatrix<double> p(d, n, data, d);
+  DenseMatrix<std::uint32_t> ann;
+  DenseMatrix<double> scores;
+  find_approximate_neighbors(p, iterations, k, ann, scores);
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < k; i++) { ann_out[i + (size_t)j * k] = ann(i, j); scores_out[i + (size_t)j * k] = scores(i, j); }
 }
 
 }  // extern "C"
