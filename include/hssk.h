@@ -96,6 +96,32 @@ typedef struct hssk_leaf_update_desc {
 } hssk_leaf_update_desc;
 int hssk_leaf_update_vbatched(hssk_ctx* ctx, const hssk_leaf_update_desc* descs, int count);
 
+/* ---- kernel matrices ---------------------------------------------------------- */
+/* A kernel matrix K(i, j) = k(x_i, x_j) + lambda [i == j] over n points x_i in R^d stored one point per column
+ * (d x n, column-major, device).  type 0: Gauss exp(-|x-y|_2^2 / (2 h^2)), 1: Laplace exp(-|x-y|_1 / h),
+ * 2: ANOVA of degree p <= 8   (kernel/Kernel.hpp:333-399; eval :122-125). */
+typedef struct hssk_kernel_spec {
+  const double* X;
+  long long n;
+  int d, type, p;
+  double h, lambda;
+} hssk_kernel_spec;
+/* out(a, b) = K(rows[a], cols[b]); rows = ri[0..nr) (device ints) or the range r0 + a when ri == NULL, same for
+ * the columns  (Kernel::operator()(I, J, B), kernel/Kernel.hpp:138-147). */
+typedef struct hssk_keval_desc {
+  const int* ri;
+  const int* ci;
+  double* out;
+  int nr, nc, ldo, r0, c0;
+} hssk_keval_desc;
+int hssk_kernel_eval_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* spec, const hssk_keval_desc* descs, int count);
+/* exact k nearest neighbours (Euclidean, the point itself excluded) of every point: out_idx is k x n (device ints,
+ * neighbours of point i in column i, unordered, -1 where n - 1 < k).  Serves the neighbour lists of
+ * HSSMatrix::compress_with_coordinates (HSS/HSSMatrix.compress_kernel.hpp:58-66).  d <= 64. */
+int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int* out_idx);
+/* pred[c] = sum_r w[r] k(x_r, t_c), c < m; T is d x m (device)   (Kernel::predict, kernel/KernelRegression.hpp:112-123) */
+int hssk_kernel_predict(hssk_ctx* ctx, const hssk_kernel_spec* spec, const double* w, const double* T, int m, double* pred);
+
 /* ---- gathers / scatters ----------------------------------------------------------------------- */
 /* dst(:, j) = src(:, idx[j]) (idx == NULL: identity) -- DenseMatrix::extract_rows in the
  * transposed sample layout (dense/DenseMatrix.cpp:323-333), laswp (:287-297). */

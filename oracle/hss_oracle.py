@@ -131,7 +131,7 @@ class Options:
 class Node:
     __slots__ = ("lo", "m", "lvl", "ch", "parent", "height", "Ustate", "Vstate", "D", "B01",
                  "B10", "UE", "Uperm", "VE", "Vperm", "Jr", "Jc", "Ir", "Ic", "Ur_max", "Vr_max",
-                 "Qr", "Qc", "ulv", "idx")
+                 "Qr", "Qc", "ulv", "idx", "cols")
 
     def __init__(self, lo, m, lvl):
         self.lo, self.m, self.lvl = lo, m, lvl
@@ -190,6 +190,49 @@ def build_tree(n, leaf_size):
 
     root = rec(0, n, 0, None)
     return root, nodes  # nodes in pre-order
+
+
+def build_tree_preorder(rows, is_leaf):
+    """Tree from a pre-order node table (rows per node, leaf flag): the cluster trees of the kernel front end are
+    not bisection trees (binary_tree_clustering, clustering/Clustering.hpp:143-168)."""
+    nodes = []
+    pos = [0]
+
+    def rec(lo, lvl, parent):
+        k = pos[0]
+        pos[0] += 1
+        nd = Node(lo, int(rows[k]), lvl)
+        nd.parent = parent
+        nd.idx = len(nodes)
+        nodes.append(nd)
+        if not is_leaf[k]:
+            a = rec(lo, lvl + 1, nd)
+            b = rec(lo + a.m, lvl + 1, nd)
+            nd.ch = [a, b]
+            nd.height = 1 + max(a.height, b.height)
+        return nd
+
+    root = rec(0, 0, None)
+    assert pos[0] == len(rows) and root.m == sum(r for r, l in zip(rows, is_leaf) if l)
+    return root, nodes
+
+
+def kernel_function(ktype, h, p=1):
+    """kernel::GaussKernel / LaplaceKernel / ANOVAKernel::eval_kernel_function (kernel/Kernel.hpp:333-399), blockwise:
+    returns f(XI, XJ) -> |I| x |J| for point blocks (rows = points)."""
+    def f(xi, xj):
+        df = xi[:, None, :] - xj[None, :, :]
+        if ktype == 0:
+            return np.exp(-(df ** 2).sum(-1) / (2.0 * h * h))
+        if ktype == 1:
+            return np.exp(-np.abs(df).sum(-1) / h)
+        t = np.exp(-(df ** 2) / (2.0 * h * h))
+        Kss = [(t ** (j + 1)).sum(-1) for j in range(p)]
+        Kpp = [np.ones(t.shape[:2])]
+        for i in range(1, p + 1):
+            Kpp.append(sum((-1.0) ** (s_ + 1) * Kpp[i - s_] * Kss[s_ - 1] for s_ in range(1, i + 1)) / i)
+        return Kpp[p]
+    return f
 
 
 # ----------------------------------------------------------------------------------------------
@@ -264,6 +307,52 @@ class HSSMatrix:
         self.d_final = 0
         if Amult is not None:
             self.compress(Amult, Aelem, rgen or MinstdNormal(0))
+
+    # -- kernel matrices: compression from coordinates, no random sketch --------------------------
+    @classmethod
+    def from_kernel(cls, X, kfun, lam, tree_rows, tree_leaf, ann, opts):
+        """HSSMatrix::compress_recursive_ann / compute_local_samples_ann / compute_U_V_bases_ann
+        (HSS/HSSMatrix.compress_kernel.hpp:84-293) for ONE neighbour count (the caller doubles it on failure, :75).
+        X: n x d points in cluster order; kfun from kernel_function(); ann: n x k neighbour ids (cluster order)."""
+        H = cls(n=X.shape[0], opts=opts)
+        H.root, H.nodes = build_tree_preorder(tree_rows, tree_leaf)
+        H.by_height = {}
+        for nd in H.nodes:
+            H.by_height.setdefault(nd.height, []).append(nd)
+
+        def K(I, J):
+            I, J = np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64)
+            return kfun(X[I], X[J]) + lam * (I[:, None] == J[None, :])
+
+        o = opts
+        for h in sorted(H.by_height):
+            for nd in H.by_height[h]:
+                lo, hi = nd.lo, nd.lo + nd.m
+                if nd.leaf:
+                    I = np.arange(lo, hi)
+                    nd.D = K(I, I)
+                    ids = ann[lo:hi].ravel()
+                else:
+                    a, b = nd.ch
+                    if not (a.compressed and b.compressed):
+                        continue
+                    nd.B01 = K(a.Ir, b.Ic)
+                    nd.B10 = nd.B01.T.copy()
+                    I = np.concatenate([a.Ir, b.Ir])
+                    ids = np.concatenate([a.cols, b.cols])
+                if nd.lvl == 0:
+                    nd.Ustate = nd.Vstate = COMPRESSED
+                    continue
+                ids = ids[(ids >= 0) & ((ids < lo) | (ids >= hi))]
+                nd.cols = np.unique(ids)                       # sorted, duplicates dropped (:197-210)
+                S = K(I, nd.cols)
+                E, perm = id_row(S, o.rel_tol / nd.lvl, o.abs_tol / nd.lvl, o.max_rank)
+                d, r = len(nd.cols), E.shape[1]
+                if not (d >= nd.m or d >= o.max_rank or r + o.p < d):   # :262-272
+                    continue
+                H._set_basis(nd, "U", E, perm)
+                H._set_basis(nd, "V", E, perm)
+        return H
 
     # -- introspection (HSS/HSSMatrix.cpp:197-331) ---------------------------------------------
     def is_compressed(self):

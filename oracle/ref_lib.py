@@ -23,7 +23,7 @@ def lib():
     global _lib
     if _lib is None:
         os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
-        _lib = C.CDLL(_PATH, mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(_PATH)   # RTLD_LOCAL: its C++ symbols share names with the product (same public API)
         L = _lib
         dp = C.POINTER(C.c_double)
         L.ref_hss_create.restype = C.c_void_p

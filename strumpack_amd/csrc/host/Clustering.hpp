@@ -1,0 +1,207 @@
+// Binary-tree clustering of point sets: the row/column ordering and the cluster tree of a kernel matrix
+// (reference: clustering/Clustering.hpp:143-168 binary_tree_clustering, clustering/KMeans.cpp,
+// clustering/KDTree.cpp, clustering/CobblePartitioning.cpp).
+//
+// Host code on purpose: it runs once per matrix over d x n doubles (n log n work) and, more importantly,
+// the reference's trees are defined through libstdc++'s std::mt19937 / std::uniform_int_distribution /
+// std::discrete_distribution / std::nth_element; using the same library calls on the same data reproduces
+// the reference's permutation exactly (tests/test_kernel_*.py compare against fixtures made by the reference).
+//
+// All partitioners have one shape -- label every point 0 / 1, move the 0-points to the front with the
+// reference's swap sequence (which also defines the order inside each half), recurse -- so only the labelling
+// differs between them.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <iostream>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "ClusterTree.hpp"
+#include "DenseMatrix.hpp"
+
+namespace strumpack {
+
+enum class ClusteringAlgorithm { NATURAL, TWO_MEANS, KD_TREE, PCA, COBBLE };
+
+inline std::string get_name(ClusteringAlgorithm c) {
+  switch (c) {
+    case ClusteringAlgorithm::NATURAL: return "natural";
+    case ClusteringAlgorithm::TWO_MEANS: return "2means";
+    case ClusteringAlgorithm::KD_TREE: return "kdtree";
+    case ClusteringAlgorithm::PCA: return "PCA";
+    case ClusteringAlgorithm::COBBLE: return "cobble";
+  }
+  return "unknown";
+}
+
+inline ClusteringAlgorithm get_clustering_algorithm(const std::string& c) {
+  if (c == "natural") return ClusteringAlgorithm::NATURAL;
+  if (c == "2means") return ClusteringAlgorithm::TWO_MEANS;
+  if (c == "kdtree") return ClusteringAlgorithm::KD_TREE;
+  if (c == "pca") return ClusteringAlgorithm::PCA;
+  if (c == "cobble") return ClusteringAlgorithm::COBBLE;
+  std::cerr << "WARNING: binary tree clustering not recognized, setting to recursive 2 means (2means)." << std::endl;
+  return ClusteringAlgorithm::TWO_MEANS;
+}
+
+namespace clustering_detail {
+
+// a d x n block of points (column = point) inside a larger column-major array
+struct Points {
+  double* x;
+  int d, n;
+  double* pt(int i) const { return x + (size_t)i * d; }
+};
+
+inline double dist2(int d, const double* a, const double* b) {  // kernel/Metrics.hpp:41-50
+  double k = 0.;
+  for (int i = 0; i < d; i++) { double t = a[i] - b[i]; k += t * t; }
+  return k;
+}
+inline double dist(int d, const double* a, const double* b) { return std::sqrt(dist2(d, a, b)); }
+
+// move the points labelled 0 to the front (swap sequence of KMeans.cpp:170-182 and the other partitioners)
+inline void group_zero_first(const Points& p, std::vector<int>& label, int n0, int* perm) {
+  int ct = 0, cj = 0;
+  for (int j = 0; j < n0; j++) {
+    while (label[cj] != 0) cj++;
+    if (cj != ct) {
+      std::swap_ranges(p.pt(cj), p.pt(cj) + p.d, p.pt(ct));
+      std::swap(perm[cj], perm[ct]);
+      label[cj] = label[ct];
+      label[ct] = 0;
+    }
+    cj++;
+    ct++;
+  }
+}
+
+// 2-means with the "random, distance-maximised" start (KMeans.cpp:44-63, 118-168)
+inline void label_two_means(const Points& p, std::vector<int>& label, int nc[2], std::mt19937& gen) {
+  const int n = p.n, d = p.d;
+  std::uniform_int_distribution<std::size_t> pick(0, n - 1);
+  const std::size_t t = pick(gen);
+  std::vector<double> w(n);
+  for (int i = 0; i < n; i++) w[i] = dist2(d, p.pt(i), p.pt((int)t));
+  std::discrete_distribution<int> far(w.begin(), w.end());
+  const int t2 = far(gen);
+  std::vector<double> c0(p.pt((int)t), p.pt((int)t) + d), c1(p.pt(t2), p.pt(t2) + d);
+  label.assign(n, 0);
+  bool changes = true;
+  for (int iter = 0; changes && iter < 100; iter++) {
+    changes = false;
+    for (int i = 0; i < n; i++) {
+      const int ci = dist(d, p.pt(i), c1.data()) < dist(d, p.pt(i), c0.data()) ? 1 : 0;
+      if (ci != label[i]) changes = true;
+      label[i] = ci;
+    }
+    nc[0] = nc[1] = 0;
+    std::fill(c0.begin(), c0.end(), 0.);
+    std::fill(c1.begin(), c1.end(), 0.);
+    for (int i = 0; i < n; i++) {
+      std::vector<double>& c = label[i] ? c1 : c0;
+      nc[label[i]]++;
+      for (int j = 0; j < d; j++) c[j] += p.pt(i)[j];
+    }
+    for (int j = 0; j < d; j++) { c0[j] /= nc[0]; c1[j] /= nc[1]; }
+  }
+}
+
+// median split along the coordinate of largest extent (KDTree.cpp:36-57, 83-95)
+inline void label_kd(const Points& p, std::vector<int>& label, int nc[2]) {
+  const int n = p.n, d = p.d;
+  std::vector<double> mx(p.pt(0), p.pt(0) + d), mn(mx);
+  for (int i = 1; i < n; i++)
+    for (int j = 0; j < d; j++) { mx[j] = std::max(p.pt(i)[j], mx[j]); mn[j] = std::min(p.pt(i)[j], mn[j]); }
+  int dim = 0;
+  double ext = mx[0] - mn[0];
+  for (int j = 1; j < d; j++)
+    if (mx[j] - mn[j] > ext) { ext = mx[j] - mn[j]; dim = j; }
+  std::vector<std::size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(),
+                   [&](const std::size_t& a, const std::size_t& b) { return p.pt((int)a)[dim] < p.pt((int)b)[dim]; });
+  nc[0] = n / 2; nc[1] = n - n / 2;
+  label.assign(n, 0);
+  for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
+}
+
+// median split by distance from the point farthest from the centroid (CobblePartitioning.cpp:36-78)
+inline void label_cobble(const Points& p, std::vector<int>& label, int nc[2]) {
+  const int n = p.n, d = p.d;
+  std::vector<double> cen(d, 0.);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < d; j++) cen[j] += p.pt(i)[j];
+  for (int j = 0; j < d; j++) cen[j] /= n;
+  int first = 0;
+  double far = -1.;
+  for (int i = 0; i < n; i++) {
+    const double dd = dist(d, p.pt(i), cen.data());
+    if (dd > far) { far = dd; first = i; }
+  }
+  std::vector<double> ds(n);
+  for (int i = 0; i < n; i++) ds[i] = dist(d, p.pt(i), p.pt(first));
+  std::vector<std::size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(),
+                   [&](const std::size_t& a, const std::size_t& b) { return ds[a] < ds[b]; });
+  nc[0] = n / 2; nc[1] = n - n / 2;
+  label.assign(n, 0);
+  for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
+}
+
+using labeller_t = std::function<void(const Points&, std::vector<int>&, int*)>;
+
+inline structured::ClusterTree recurse(const Points& p, int cluster_size, int* perm, const labeller_t& lab) {
+  structured::ClusterTree tree(p.n);
+  if (p.n < cluster_size) return tree;
+  std::vector<int> label;
+  int nc[2] = {0, 0};
+  lab(p, label, nc);
+  group_zero_first(p, label, nc[0], perm);
+  if (!nc[0] || !nc[1]) return tree;
+  tree.c.resize(2);
+  tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab);
+  tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab);
+  return tree;
+}
+
+}  // namespace clustering_detail
+
+// Reorders the points p (d x n, one point per column) in place, fills perm (1-based, LAPACK lapmt
+// convention: new column i is old column perm[i]) and returns the cluster tree.
+inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, DenseMatrix<double>& p,
+                                                      std::vector<int>& perm, std::size_t cluster_size) {
+  namespace cd = clustering_detail;
+  const int n = (int)p.cols(), d = (int)p.rows();
+  if (p.ld() != p.rows()) throw std::invalid_argument("binary_tree_clustering: points must be stored contiguously");
+  perm.resize(n);
+  std::iota(perm.begin(), perm.end(), 1);
+  cd::Points pts{p.data(), d, n};
+  switch (algo) {
+    case ClusteringAlgorithm::NATURAL: {
+      structured::ClusterTree t(n);
+      t.refine((int)cluster_size);
+      return t;
+    }
+    case ClusteringAlgorithm::PCA:
+      std::cerr << "WARNING: PCA clustering is not available in this build, using recursive 2 means." << std::endl;
+      // fall through
+    case ClusteringAlgorithm::TWO_MEANS: {
+      std::mt19937 gen(1);  // reproducible, as in the reference
+      return cd::recurse(pts, (int)cluster_size, perm.data(),
+                         [&gen](const cd::Points& q, std::vector<int>& l, int* nc) { cd::label_two_means(q, l, nc, gen); });
+    }
+    case ClusteringAlgorithm::KD_TREE:
+      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_kd);
+    case ClusteringAlgorithm::COBBLE:
+      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_cobble);
+  }
+  return structured::ClusterTree(n);
+}
+
+}  // namespace strumpack

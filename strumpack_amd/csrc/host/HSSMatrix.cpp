@@ -1,4 +1,5 @@
 #include "HSSMatrix.hpp"
+#include "Kernel.hpp"
 
 #include <sstream>
 
@@ -28,6 +29,30 @@ HSSMatrix<double>::HSSMatrix(const structured::ClusterTree& t, const opts_t& opt
   make_engine(opts, tree_.get());
 }
 HSSMatrix<double>::~HSSMatrix() {}
+
+// HSSMatrix(kernel::Kernel&, opts): HSS/HSSMatrix.cpp:88-106
+HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : rows_(K.n()), cols_(K.n()) {
+  auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size());
+  K.permute();
+  tree_.reset(new structured::ClusterTree(t));
+  eng_.reset(new DeviceHSS(int(rows_), engine_options(opts), tree_.get()));
+  compress(K, opts);
+}
+void HSSMatrix<double>::compress(const kernel::Kernel<double>& K, const opts_t& opts) {
+  compress_with_neighbors(K, opts, K.neighbors(), K.neighbor_count());
+}
+void HSSMatrix<double>::compress_with_neighbors(const kernel::Kernel<double>& K, const opts_t& opts, const int* ann, int k) {
+  if (K.n() != rows_) throw std::invalid_argument("compress: kernel size does not match");
+  if (K.device_type() < 0)
+    throw std::invalid_argument("compress(Kernel): user-defined kernel functions cannot be evaluated on the device; "
+                                "use compress(Amult, Aelem) with the kernel's element callback");
+  if (K.data().ld() != int(K.d())) throw std::invalid_argument("compress(Kernel): the point matrix must be contiguous");
+  make_engine(opts, tree_.get());
+  DeviceHSS::KernelSpec ks;
+  ks.X = K.data().data(); ks.d = int(K.d()); ks.type = K.device_type(); ks.p = K.degree();
+  ks.h = K.width(); ks.lambda = K.lambda(); ks.ann = std::min<int>(int(K.n()), opts.approximate_neighbors());
+  eng_->compress_kernel(ks, ann, k);
+}
 
 void HSSMatrix<double>::make_engine(const opts_t& opts, const structured::ClusterTree* t) {
   EngineOptions e = engine_options(opts);

@@ -10,6 +10,9 @@
 #include "hss_engine.hpp"
 
 namespace strumpack {
+namespace kernel {
+template <typename scalar_t> class Kernel;
+}
 namespace HSS {
 
 template <typename scalar_t> class HSSMatrix;
@@ -32,10 +35,16 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   HSSMatrix(std::size_t m, std::size_t n, const opts_t& opts);
   // tree given by a cluster tree (HSSMatrix.cpp:72-86)
   HSSMatrix(const structured::ClusterTree& t, const opts_t& opts);
+  // kernel matrix: clusters the points (reordering K's data), builds the tree and compresses from the point
+  // coordinates without a random sketch (HSS/HSSMatrix.cpp:88-106, HSSMatrix.compress_kernel.hpp)
+  HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts);
   ~HSSMatrix() override;
 
   void compress(const DenseM_t& A, const opts_t& opts);
   void compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts);
+  void compress(const kernel::Kernel<double>& K, const opts_t& opts);
+  // extension (tests): the neighbour lists of the first round are given (k x n, 0-based, column i = point i)
+  void compress_with_neighbors(const kernel::Kernel<double>& K, const opts_t& opts, const int* ann, int k);
   // extension: A resident in HBM
   void compress_device(const double* dA, long long lda, const opts_t& opts);
   // extension: one process per GPU (subtree ownership below the cut level, replicated top);

@@ -5,6 +5,7 @@
 #pragma once
 #include <cassert>
 
+#include "Clustering.hpp"
 #include "StructuredOptions.hpp"
 
 namespace strumpack {
@@ -49,6 +50,10 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   void set_user_defined_random(bool u) { user_defined_random_ = u; }
   void set_synchronized_compression(bool sync) { sync_ = sync; }
   void set_log_ranks(bool log_ranks) { log_ranks_ = log_ranks; }
+  // kernel-matrix construction (reference HSSOptions.hpp:258-283)
+  void set_clustering_algorithm(ClusteringAlgorithm a) { clustering_algorithm_ = a; }
+  void set_approximate_neighbors(int neighbors) { approximate_neighbors_ = neighbors; }
+  void set_ann_iterations(int iters) { assert(iters > 0); ann_iterations_ = iters; }
   int d0() const { return d0_; }
   int dd() const { return dd_; }
   int p() const { return p_; }
@@ -59,6 +64,9 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   bool user_defined_random() const { return user_defined_random_; }
   bool synchronized_compression() const { return sync_; }
   bool log_ranks() const { return log_ranks_; }
+  ClusteringAlgorithm clustering_algorithm() const { return clustering_algorithm_; }
+  int approximate_neighbors() const { return approximate_neighbors_; }
+  int ann_iterations() const { return ann_iterations_; }
 
   void set_from_command_line(int argc, const char* const* argv) override {
     using structured::detail::match_flag;
@@ -92,6 +100,9 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
       else if (match_flag(argc, argv, i, "hss_enable_sync", v, false)) set_synchronized_compression(true);
       else if (match_flag(argc, argv, i, "hss_disable_sync", v, false)) set_synchronized_compression(false);
       else if (match_flag(argc, argv, i, "hss_log_ranks", v, false)) set_log_ranks(true);
+      else if (match_flag(argc, argv, i, "hss_clustering_algorithm", v, true)) set_clustering_algorithm(get_clustering_algorithm(v));
+      else if (match_flag(argc, argv, i, "hss_approximate_neighbors", v, true)) set_approximate_neighbors(std::atoi(v.c_str()));
+      else if (match_flag(argc, argv, i, "hss_ann_iterations", v, true)) set_ann_iterations(std::atoi(v.c_str()));
       else if (match_flag(argc, argv, i, "hss_verbose", v, false) || std::string(argv[i]) == "-v") this->set_verbose(true);
       else if (match_flag(argc, argv, i, "hss_quiet", v, false) || std::string(argv[i]) == "-q") this->set_verbose(false);
     }
@@ -102,6 +113,8 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
               << ")\n#   --hss_p int (default " << p() << ")\n#   --hss_max_rank int (default " << this->max_rank()
               << ")\n#   --hss_random_distribution normal|uniform\n#   --hss_random_engine linear|mersenne|philox\n"
               << "#   --hss_compression_algorithm original|stable|hard_restart\n#   --hss_compression_sketch Gaussian\n"
+              << "#   --hss_clustering_algorithm natural|2means|kdtree|pca|cobble (default " << get_name(clustering_algorithm()) << ")\n#   --hss_approximate_neighbors int (default " << approximate_neighbors()
+              << ")\n#   --hss_ann_iterations int (default " << ann_iterations() << ")\n"
               << "#   --hss_user_defined_random  --hss_enable_sync  --hss_disable_sync  --hss_log_ranks\n#   --hss_verbose or -v   --hss_quiet or -q" << std::endl;
   }
 
@@ -118,6 +131,8 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   CompressionAlgorithm compress_algo_ = CompressionAlgorithm::STABLE;
   CompressionSketch compress_sketch_ = CompressionSketch::GAUSSIAN;
   bool user_defined_random_ = false, sync_ = false, log_ranks_ = false;
+  ClusteringAlgorithm clustering_algorithm_ = ClusteringAlgorithm::TWO_MEANS;
+  int approximate_neighbors_ = 64, ann_iterations_ = 5;
 };
 
 }  // namespace HSS

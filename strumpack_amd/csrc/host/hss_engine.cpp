@@ -884,8 +884,27 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
   tmp.rewind();
   const size_t cnt = ids.size();
   std::vector<hssk_colgather_desc> cp;
-  std::vector<hssk_id_desc> idd;
   std::vector<double*> Ws(cnt, nullptr);
+  std::vector<int> ds(cnt, dtot);
+  for (size_t k = 0; k < cnt; k++) {
+    Node& nd = nodes_[ids[k]];
+    const int m = which[k] == 0 ? nd.mU : nd.mV;
+    const double* S = which[k] == 0 ? nd.Srt : nd.Sct;
+    if (m == 0) continue;
+    Ws[k] = tmp.dbl((size_t)dtot * m);
+    cp.push_back(hssk_colgather_desc{S, Ws[k], nullptr, dtot, m, dcap_, dtot, 0});
+  }
+  if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+  id_panels(ids, which, Ws, ds);
+}
+
+// Row ID of the listed (node, basis) pairs from prepared panels W_k = S_k^T (ds[k] x m_k, contiguous, in tmp_):
+// truncated QRCP + X = R11^{-1} R12 on the device, then the commit of rank, permutation, skeleton indices.
+void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
+                          const std::vector<int>& ds) {
+  Arena& tmp = *tmp_;
+  const size_t cnt = ids.size();
+  std::vector<hssk_id_desc> idd;
   std::vector<int*> perms(cnt, nullptr);
   size_t perm_total = 0;
   for (size_t k = 0; k < cnt; k++) perm_total += (which[k] == 0 ? nodes_[ids[k]].mU : nodes_[ids[k]].mV);
@@ -896,17 +915,12 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
     const int m = which[k] == 0 ? nd.mU : nd.mV;
-    const double* S = which[k] == 0 ? nd.Srt : nd.Sct;
     perms[k] = perm_block + poff;
     poff += m;
     if (m == 0) continue;
-    double* W = tmp.dbl((size_t)dtot * m);
-    Ws[k] = W;
-    cp.push_back(hssk_colgather_desc{S, W, nullptr, dtot, m, dcap_, dtot, 0});
     double* wk = tmp.dbl(3 * (size_t)m);
-    idd.push_back(hssk_id_desc{W, dtot, dtot, m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk});
+    idd.push_back(hssk_id_desc{Ws[k], ds[k], ds[k], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk});
   }
-  if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
   if (!idd.empty()) ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
   std::vector<int> hranks(cnt, 0), hperm(std::max<size_t>(perm_total, 1));
   ck(hssk_memcpy_d2h(ctx_, hranks.data(), rank_block, (long long)sizeof(int) * cnt));
@@ -920,6 +934,7 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
     Node& nd = nodes_[ids[k]];
     const int w = which[k];
     const int m = w == 0 ? nd.mU : nd.mV;
+    const int dtot = ds[k];
     const int r = m ? hranks[k] : 0;
     std::vector<int> perm(hperm.begin() + poff, hperm.begin() + poff + m);
     poff += m;
@@ -949,6 +964,143 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
   }
   if (!xc.empty()) ck(hssk_gather_elems(ctx_, xc.data(), (int)xc.size()));
   ck(hssk_sync(ctx_));  // the W panels in tmp_ may be reused after this
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel-matrix compression from point coordinates:
+// HSSMatrix::compress_with_coordinates / compress_recursive_ann / compute_local_samples_ann /
+// compute_U_V_bases_ann (HSS/HSSMatrix.compress_kernel.hpp:50-293), level-synchronous.
+// No random sketch: the sample of a node is S = K(I, cols) with cols = the neighbours of the node's points
+// that lie outside the node (leaf) resp. the union of the children's column sets outside the node (inner),
+// I = the node's rows (leaf) resp. its children's skeleton rows; symmetric: V = U, B10 = B01^T.
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int user_k) {
+  if (o_.world > 1 && dist_subtree_) {
+    // every rank holds all points: the whole tree is built replicated (TODO(next): subtree ownership as in the sketch path)
+    dist_subtree_ = false;
+    std::fill(owner_.begin(), owner_.end(), -1);
+    own_by_height_ = by_height_; own_by_depth_ = by_depth_;
+    for (auto& v : top_by_height_) v.clear();
+    for (auto& v : top_by_depth_) v.clear();
+  }
+  double t0 = now();
+  stats_ = PhaseStats();
+  const int N = n_, dim = ks.d;
+  if (dim <= 0 || !ks.X) throw std::invalid_argument("compress_kernel: no points");
+  int k = std::min(N, std::max(1, user_ann ? user_k : ks.ann));
+  for (;;) {
+    reset_compression();
+    stats_.rounds++;
+    // points and neighbour lists
+    double* dX = work_->dbl((size_t)dim * N);
+    ck(hssk_memcpy_h2d(ctx_, dX, ks.X, (long long)sizeof(double) * dim * N));
+    hssk_kernel_spec spec{dX, N, dim, ks.type, ks.p, ks.h, ks.lambda};
+    std::vector<int> ann((size_t)k * N);
+    if (user_ann && k == user_k) std::copy(user_ann, user_ann + (size_t)k * N, ann.begin());
+    else {
+      int* dann = work_->ints((size_t)k * N);
+      ck(hssk_knn(ctx_, dX, dim, N, k, dann));
+      ck(hssk_memcpy_d2h(ctx_, ann.data(), dann, (long long)sizeof(int) * k * N));
+    }
+    std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node
+    bool failed = false;
+    const int H = (int)by_height_.size();
+    for (int h = 0; h < H && !failed; h++) {
+      const std::vector<int>& ids = by_height_[h];
+      tmp_->rewind();
+      // ---- column sets and row sets (host), one index upload per level
+      std::vector<int> hidx;
+      std::vector<size_t> roff(ids.size()), coff(ids.size());
+      std::vector<std::vector<int>> rows(ids.size());
+      for (size_t q = 0; q < ids.size(); q++) {
+        Node& nd = nodes_[ids[q]];
+        std::vector<int>& cs = cols[ids[q]];
+        const int lo = nd.lo, hi = nd.lo + nd.m;
+        if (nd.leaf()) {
+          nd.mU = nd.mV = nd.m;
+          rows[q].resize(nd.m);
+          for (int i = 0; i < nd.m; i++) rows[q][i] = lo + i;
+          if (nd.lvl > 0) {
+            cs.reserve((size_t)nd.m * k);
+            for (int i = lo; i < hi; i++)
+              for (int j = 0; j < k; j++) {
+                const int g = ann[(size_t)i * k + j];
+                if (g >= 0 && (g < lo || g >= hi)) cs.push_back(g);
+              }
+          }
+        } else {
+          Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+          nd.mU = nd.mV = a.rU + b.rU;
+          rows[q] = a.Ir;
+          rows[q].insert(rows[q].end(), b.Ir.begin(), b.Ir.end());
+          if (nd.lvl > 0)
+            for (int c : {nd.c0, nd.c1})
+              for (int g : cols[c])
+                if (g < lo || g >= hi) cs.push_back(g);
+        }
+        std::sort(cs.begin(), cs.end());
+        cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+        roff[q] = hidx.size(); hidx.insert(hidx.end(), rows[q].begin(), rows[q].end());
+        coff[q] = hidx.size(); hidx.insert(hidx.end(), cs.begin(), cs.end());
+      }
+      int* didx = tmp_->ints(std::max<size_t>(hidx.size(), 1));
+      if (!hidx.empty()) ck(hssk_memcpy_h2d(ctx_, didx, hidx.data(), (long long)sizeof(int) * hidx.size()));
+      // ---- D (leaves), B01 / B10 (inner nodes), sample panels W = K(cols, rows)  [= S^T]
+      std::vector<hssk_keval_desc> ev;
+      std::vector<hssk_transpose_desc> tr;
+      std::vector<int> idn, which;
+      std::vector<double*> Ws;
+      std::vector<int> ds;
+      for (size_t q = 0; q < ids.size(); q++) {
+        Node& nd = nodes_[ids[q]];
+        if (nd.leaf()) {
+          nd.D = persist_->dbl((size_t)nd.m * nd.m);
+          ev.push_back(hssk_keval_desc{nullptr, nullptr, nd.D, nd.m, nd.m, nd.m, nd.lo, nd.lo});
+        } else {
+          Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+          nd.B01 = persist_->dbl((size_t)std::max(a.rU, 1) * std::max(b.rV, 1));
+          nd.B10 = persist_->dbl((size_t)std::max(b.rU, 1) * std::max(a.rV, 1));
+          if (a.rU > 0 && b.rV > 0) {
+            ev.push_back(hssk_keval_desc{a.dIr, b.dIc, nd.B01, a.rU, b.rV, a.rU, 0, 0});
+            tr.push_back(hssk_transpose_desc{nd.B01, nd.B10, a.rU, b.rV, a.rU, b.rU});
+          }
+        }
+        if (nd.lvl == 0) { nd.Ustate = nd.Vstate = 2; continue; }
+        const int m = nd.mU, d = (int)cols[ids[q]].size();
+        idn.push_back(ids[q]); which.push_back(0); ds.push_back(d);
+        double* W = (m > 0 && d > 0) ? tmp_->dbl((size_t)d * m) : nullptr;
+        Ws.push_back(W);
+        if (W) ev.push_back(hssk_keval_desc{didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
+      }
+      if (!ev.empty()) ck(hssk_kernel_eval_vbatched(ctx_, &spec, ev.data(), (int)ev.size()));
+      if (!tr.empty()) ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
+      if (idn.empty()) continue;
+      // nodes with an empty column set (d == 0) get rank 0 through a 1 x m zero panel
+      for (size_t q = 0; q < idn.size(); q++)
+        if (!Ws[q] && nodes_[idn[q]].mU > 0) {
+          Ws[q] = tmp_->dbl(nodes_[idn[q]].mU);
+          ck(hssk_memset_zero(ctx_, Ws[q], (long long)sizeof(double) * nodes_[idn[q]].mU));
+          ds[q] = 1;
+        }
+      id_panels(idn, which, Ws, ds);
+      // symmetric: V = U; acceptance test of compute_U_V_bases_ann (:262-272)
+      for (size_t q = 0; q < idn.size(); q++) {
+        Node& nd = nodes_[idn[q]];
+        nd.rV = nd.rU; nd.XV = nd.XU; nd.permV = nd.permU; nd.hpermV = nd.hpermU; nd.Ic = nd.Ir; nd.dIc = nd.dIr; nd.Vstate = nd.Ustate;
+        const int d = (int)cols[idn[q]].size();
+        if (!(d >= nd.m || d >= o_.max_rank || nd.rU + o_.p < d)) failed = true;
+      }
+    }
+    ck(hssk_sync(ctx_));
+    if (!failed) break;
+    if (k >= N) throw std::runtime_error("compress_kernel: the ID did not reach the required accuracy with all points as neighbours");
+    k = std::min(2 * k, N);   // compress_with_coordinates: ann_number doubles until the tree compresses (:75)
+    if (o_.verbose) std::cout << "# HSS kernel compression: increasing the neighbour count to " << k << std::endl;
+  }
+  free_compress_workspace();
+  stats_.d_final = k;
+  stats_.t_compress = now() - t0;
+  stats_.t_tree = stats_.t_compress;
 }
 
 // update_orthogonal_basis (HSSMatrix.compress_stable.hpp:390-442) for the listed (node, basis) pairs

@@ -66,6 +66,10 @@ class DeviceHSS {
   void compress_dense_device(const double* dA, long long lda);       // A resident in HBM
   void compress_dense_host(const double* A, long long lda);          // uploads A, then the above
   void compress_callbacks(const host_mult_t& mult, const host_elem_t& elem);  // matrix-free
+  // kernel matrix over points X (host, d x n, already in tree order); user_ann (k x n, optional) replaces the
+  // device nearest-neighbour search of the first round (tests pin the compression against the reference's lists)
+  struct KernelSpec { const double* X = nullptr; int d = 0, type = 0, p = 1, ann = 64; double h = 1., lambda = 0.; };
+  void compress_kernel(const KernelSpec& ks, const int* user_ann = nullptr, int user_k = 0);
 
   // ---- operations; x/b/y are column-major, host or device (on_device) ----
   void mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
@@ -129,6 +133,8 @@ class DeviceHSS {
   void local_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
   void reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
   void run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot);
+  void id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
+                 const std::vector<int>& ds);
   void ortho_test(const std::vector<int>& ids, const std::vector<int>& which, int d, int dd,
                   std::vector<char>& resolved);
   void free_compress_workspace();

@@ -24,6 +24,16 @@ class LeafUpdateDesc(C.Structure):
                 ("d", C.c_int), ("m", C.c_int), ("ldr", C.c_int), ("ldd", C.c_int), ("lds", C.c_int)]
 
 
+class KernelSpec(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("n", C.c_longlong), ("d", C.c_int), ("type", C.c_int), ("p", C.c_int),
+                ("h", C.c_double), ("lam", C.c_double)]
+
+
+class KevalDesc(C.Structure):
+    _fields_ = [("ri", C.c_void_p), ("ci", C.c_void_p), ("out", C.c_void_p),
+                ("nr", C.c_int), ("nc", C.c_int), ("ldo", C.c_int), ("r0", C.c_int), ("c0", C.c_int)]
+
+
 class ColGatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p),
                 ("rows", C.c_int), ("ncols", C.c_int), ("lds", C.c_int), ("ldd", C.c_int),
@@ -93,6 +103,7 @@ HSSK_SYMBOLS = [
     "hssk_sumsq_vbatched", "hssk_shift_diag", "hssk_mfma_f64_peak_tflops", "hssk_memcpy_d2d",
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
     "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
+    "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict",
 ]
 
 
@@ -179,6 +190,9 @@ class Hssk:
                      "hssk_sumsq_vbatched", "hssk_leaf_update_vbatched", "hssk_formq_vbatched"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        L.hssk_kernel_eval_vbatched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.hssk_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hssk_kernel_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.hssk_mfma_f64_peak_tflops.restype = C.c_double
         L.hssk_mfma_f64_peak_tflops.argtypes = [C.c_void_p, C.c_int]
         L.hssk_mfma_f64_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]

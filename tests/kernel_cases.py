@@ -1,6 +1,8 @@
 """Kernel-level parity cases shared by the GPU tests (product library, `-m gpu`) and the CPU tests
 (the same kernel sources on the fiber emulator, tests/emu).  Every case drives a hssk_* entry point
 of include/hssk.h and compares with numpy/LAPACK (the oracle of each dense primitive)."""
+import ctypes as C
+
 import numpy as np
 import scipy.linalg as sla
 
@@ -298,3 +300,71 @@ def case_trsm_lu(hk, seed=9):
         assert np.array_equal(dpiv.get(), piv)
         assert np.allclose(dA.get(), lu, atol=1e-11)
         assert np.allclose(dB.get(), np.linalg.solve(A, B), atol=1e-9)
+
+
+# ---- kernel-matrix front end -------------------------------------------------------------------
+def kernel_np(X, I, J, ktype, h, lam, p=1):
+    """numpy restatement of kernel::Kernel::eval (kernel/Kernel.hpp:122-125, 333-399); X is n x d."""
+    xi, xj = X[I][:, None, :], X[J][None, :, :]
+    if ktype == 0:
+        K = np.exp(-((xi - xj) ** 2).sum(-1) / (2 * h * h))
+    elif ktype == 1:
+        K = np.exp(-np.abs(xi - xj).sum(-1) / h)
+    else:
+        t = np.exp(-((xi - xj) ** 2) / (2 * h * h))            # per-dimension factors
+        Kss = [(t ** (j + 1)).sum(-1) for j in range(p)]
+        Kpp = [np.ones(t.shape[:2])]
+        for i in range(1, p + 1):
+            Kpp.append(sum((-1) ** (s + 1) * Kpp[i - s] * Kss[s - 1] for s in range(1, i + 1)) / i)
+        K = Kpp[p]
+    return K + lam * (np.asarray(I)[:, None] == np.asarray(J)[None, :])
+
+
+def case_kernel_eval(hk, n=300, d=8, seed=21):
+    r = rng(seed)
+    X = r.standard_normal((n, d))
+    dX = hk.array(X.T)                      # d x n, one point per column
+    for (ktype, p) in [(0, 1), (1, 1), (2, 1), (2, 3)]:
+        spec = K.KernelSpec(dX.ptr, n, d, ktype, p, 1.3, 3.11)
+        I1, J1 = r.permutation(n)[:70].astype(np.int32), r.permutation(n)[:130].astype(np.int32)
+        J1[:5] = I1[:5]                      # a few diagonal hits
+        dI, dJ = hk.array(I1), hk.array(J1)
+        o1, o2 = hk.empty((70 + 3, 130)), hk.empty((65, 40))
+        descs = [K.KevalDesc(dI.ptr, dJ.ptr, o1.ptr, 70, 130, 73, 0, 0),
+                 K.KevalDesc(None, None, o2.ptr, 65, 40, 65, 100, 120)]   # ranges, overlapping -> diagonal entries
+        arr = (K.KevalDesc * 2)(*descs)
+        hk.check(hk.lib.hssk_kernel_eval_vbatched(hk.ctx, C.byref(spec), arr, 2))
+        hk.sync()
+        assert np.allclose(o1.get()[:70], kernel_np(X, I1, J1, ktype, 1.3, 3.11, p), rtol=1e-12, atol=1e-14)
+        assert np.allclose(o2.get(), kernel_np(X, np.arange(100, 165), np.arange(120, 160), ktype, 1.3, 3.11, p), rtol=1e-12, atol=1e-14)
+
+
+def case_knn(hk, n=500, d=8, k=10, seed=22):
+    r = rng(seed)
+    X = r.standard_normal((n, d))
+    dX = hk.array(X.T)
+    out = hk.empty((k, n), dtype=np.int32)
+    hk.check(hk.lib.hssk_knn(hk.ctx, dX.ptr, d, n, k, out.ptr))
+    hk.sync()
+    got = out.get().T                        # row i = neighbours of point i
+    D2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1).astype(np.float32)   # the kernel ranks float keys
+    np.fill_diagonal(D2, np.inf)
+    kk = min(k, n - 1)
+    for i in range(n):
+        mine = got[i][got[i] >= 0]
+        assert len(mine) == kk and len(set(mine.tolist())) == kk and i not in mine
+        kth = np.sort(D2[i])[kk - 1]
+        assert (D2[i][mine] <= kth).all()     # exactly a set of k nearest (ties at the boundary may differ)
+
+
+def case_kernel_predict(hk, n=257, m=70, d=5, seed=23):
+    r = rng(seed)
+    X, T, w = r.standard_normal((n, d)), r.standard_normal((m, d)), r.standard_normal(n)
+    dX, dT, dw, dp = hk.array(X.T), hk.array(T.T), hk.array(w), hk.empty((m,))
+    for (ktype, p) in [(0, 1), (1, 1), (2, 2)]:
+        spec = K.KernelSpec(dX.ptr, n, d, ktype, p, 0.9, 2.0)
+        hk.check(hk.lib.hssk_kernel_predict(hk.ctx, C.byref(spec), dw.ptr, dT.ptr, m, dp.ptr))
+        hk.sync()
+        Z = np.vstack([X, T])
+        Kx = kernel_np(Z, np.arange(n), n + np.arange(m), ktype, 0.9, 0.0, p)
+        assert np.allclose(dp.get(), w @ Kx, rtol=1e-11, atol=1e-12)

@@ -7,6 +7,7 @@ import re
 import pytest
 
 from strumpack_amd import _loader, capi, hssk
+from strumpack_amd import kernel as kernel_mod
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -14,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:hssk|SP_d_struct|SPX_d_struct)_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:hssk|SP_d_struct|SPX_d_struct|STRUMPACK|SPX)_\w+)\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")
@@ -38,6 +39,14 @@ def test_structured_c_api_symbols(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared but not exported"
     assert set(capi.SP_SYMBOLS) <= set(names)
+
+
+def test_kernel_c_api_symbols(lib):
+    names = declared(os.path.join("kernel", "Kernel.h"))
+    assert "STRUMPACK_kernel_fit_HSS_double" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/kernel/Kernel.h but not exported"
+    assert set(kernel_mod.KERNEL_SYMBOLS) <= set(names)
 
 
 def test_no_cpu_fallback(lib):

@@ -81,3 +81,17 @@ def test_formq_from_stored_reflectors(hk):
 
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)
+
+
+def test_kernel_matrix_entries(hk):
+    KC.case_kernel_eval(hk, n=200)
+
+
+def test_knn(hk):
+    KC.case_knn(hk, n=150, d=8, k=10)
+    KC.case_knn(hk, n=90, d=3, k=70, seed=24)     # two pages
+    KC.case_knn(hk, n=40, d=20, k=64, seed=25)    # k > n - 1
+
+
+def test_kernel_predict(hk):
+    KC.case_kernel_predict(hk)

@@ -83,3 +83,18 @@ def test_mfma_peak_probe(hk):
     tf = hk.lib.hssk_mfma_f64_peak_tflops(hk.ctx, 20000)
     print("FP64 MFMA probe: %.1f TFLOP/s" % tf)
     assert tf > 20.0
+
+
+def test_kernel_matrix_entries(hk):
+    KC.case_kernel_eval(hk, n=300)
+
+
+def test_knn(hk):
+    KC.case_knn(hk, n=2000, d=8, k=64)
+    KC.case_knn(hk, n=300, d=3, k=150, seed=24)
+    KC.case_knn(hk, n=40, d=20, k=64, seed=25)
+    KC.case_knn(hk, n=500, d=40, k=16, seed=26)
+
+
+def test_kernel_predict(hk):
+    KC.case_kernel_predict(hk)
