@@ -162,6 +162,14 @@ typedef struct hssk_transpose_desc {
 } hssk_transpose_desc;
 int hssk_transpose(hssk_ctx* ctx, const hssk_transpose_desc* descs, int count);
 
+/* dst = upper trapezoid of src (rows x cols), zeros below the diagonal: stacks the R factors of a TSQR tree */
+typedef struct hssk_triu_desc {
+  const double* src;
+  double* dst;
+  int rows, cols, lds, ldd;
+} hssk_triu_desc;
+int hssk_copy_triu(hssk_ctx* ctx, const hssk_triu_desc* descs, int count);
+
 /* ---- batched interpolative decomposition ------------------------------------------------------- */
 /* Truncated column-pivoted Householder QR of W (d x m, column-major, overwritten), i.e. the row ID
  * of the m x d sample block:  DenseMatrix::ID_row -> ID_column_GEQP3 -> geqp3tol + trsm

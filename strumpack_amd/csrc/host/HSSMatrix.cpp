@@ -1,3 +1,5 @@
+#include <chrono>
+
 #include "HSSMatrix.hpp"
 #include "Kernel.hpp"
 
@@ -32,8 +34,12 @@ HSSMatrix<double>::~HSSMatrix() {}
 
 // HSSMatrix(kernel::Kernel&, opts): HSS/HSSMatrix.cpp:88-106
 HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : rows_(K.n()), cols_(K.n()) {
+  auto tc0 = std::chrono::steady_clock::now();
   auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size());
   K.permute();
+  if (opts.verbose())
+    std::cout << "# clustering (" << get_name(opts.clustering_algorithm()) << ") time = "
+              << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count() << std::endl;
   tree_.reset(new structured::ClusterTree(t));
   eng_.reset(new DeviceHSS(int(rows_), engine_options(opts), tree_.get()));
   compress(K, opts);

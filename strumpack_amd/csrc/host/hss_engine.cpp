@@ -12,6 +12,9 @@
 // HSSMatrix.compress_stable.hpp:234-277).
 #include "hss_engine.hpp"
 
+#include <atomic>
+#include <thread>
+#include <exception>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -81,6 +84,24 @@ class DevicePool {
 };
 
 // bump allocator over large device chunks
+// run fn(0..n-1) on the host's hardware threads (used for per-node index work of a tree level)
+template <class F> void host_parallel_for(size_t n, F&& fn) {
+  const size_t nt = std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+  if (nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::mutex mu;
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++)
+    th.emplace_back([&] {
+      try {
+        for (size_t i = next++; i < n; i = next++) fn(i);
+      } catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
+    });
+  for (auto& t : th) t.join();
+  if (err) std::rethrow_exception(err);
+}
+
 class Arena {
  public:
   explicit Arena(size_t chunk = size_t(64) << 20) : chunk_(chunk) {}
@@ -898,12 +919,85 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
   id_panels(ids, which, Ws, ds);
 }
 
-// Row ID of the listed (node, basis) pairs from prepared panels W_k = S_k^T (ds[k] x m_k, contiguous, in tmp_):
-// truncated QRCP + X = R11^{-1} R12 on the device, then the commit of rank, permutation, skeleton indices.
-void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
-                          const std::vector<int>& ds) {
+// Tall panels (d >> m, the kernel-matrix path: d = thousands of sampled columns): the pivoted QR of W (d x m) only
+// depends on R of W = Q R, so W is first reduced to its m x m triangular factor by an unpivoted Householder TSQR
+// -- row chunks factored independently (register-resident / blocked batched QR), the R factors stacked pairwise
+// and re-factored until one is left -- and the ID then runs on that small panel in the register kernels.  Same
+// pivots, ranks and X = R11^{-1} R12 as the direct QRCP up to rounding; backward stable (all Householder).
+void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>& which, std::vector<double*>& Ws,
+                            std::vector<int>& ds) {
   Arena& tmp = *tmp_;
   const size_t cnt = ids.size();
+  struct Piece { double* p; int ld, rows; };
+  std::vector<std::vector<Piece>> pieces(cnt);
+  std::vector<int> ms(cnt, 0);
+  bool any = false;
+  std::vector<hssk_qr_desc> qr;
+  for (size_t k = 0; k < cnt; k++) {
+    const Node& nd = nodes_[ids[k]];
+    const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
+    ms[k] = m;
+    if (m <= 0 || m > 256 || !Ws[k] || d <= std::max(256, 2 * m)) continue;
+    const int chunk = m <= 208 ? 256 : 512;
+    for (int r0 = 0; r0 < d; r0 += chunk) {
+      const int cr = std::min(chunk, d - r0);
+      double* wk = tmp.dbl((size_t)cr + m);
+      qr.push_back(hssk_qr_desc{Ws[k] + r0, d, cr, m, nullptr, 0, 0, nullptr, wk});
+      pieces[k].push_back(Piece{Ws[k] + r0, d, std::min(cr, m)});
+    }
+    any = true;
+  }
+  if (!any) return;
+  ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+  for (;;) {
+    std::vector<hssk_triu_desc> cp;
+    qr.clear();
+    bool more = false;
+    for (size_t k = 0; k < cnt; k++) {
+      std::vector<Piece>& pc = pieces[k];
+      if (pc.size() <= 1) continue;
+      const int m = ms[k];
+      std::vector<Piece> next;
+      for (size_t i = 0; i + 1 < pc.size(); i += 2) {
+        const int rows = pc[i].rows + pc[i + 1].rows;
+        double* dst = tmp.dbl((size_t)rows * m);
+        cp.push_back(hssk_triu_desc{pc[i].p, dst, pc[i].rows, m, pc[i].ld, rows});
+        cp.push_back(hssk_triu_desc{pc[i + 1].p, dst + pc[i].rows, pc[i + 1].rows, m, pc[i + 1].ld, rows});
+        double* wk = tmp.dbl((size_t)rows + m);
+        qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk});
+        next.push_back(Piece{dst, rows, std::min(rows, m)});
+      }
+      if (pc.size() % 2) next.push_back(pc.back());
+      pc.swap(next);
+      more = more || pc.size() > 1;
+    }
+    if (cp.empty()) break;
+    ck(hssk_copy_triu(ctx_, cp.data(), (int)cp.size()));
+    ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+    if (!more) break;
+  }
+  // clean m x m (or shorter) triangular panels for the ID
+  std::vector<hssk_triu_desc> fin;
+  for (size_t k = 0; k < cnt; k++) {
+    if (pieces[k].empty()) continue;
+    const Piece& pc = pieces[k][0];
+    double* R = tmp.dbl((size_t)pc.rows * ms[k]);
+    fin.push_back(hssk_triu_desc{pc.p, R, pc.rows, ms[k], pc.ld, pc.rows});
+    Ws[k] = R;
+    ds[k] = pc.rows;
+  }
+  if (!fin.empty()) ck(hssk_copy_triu(ctx_, fin.data(), (int)fin.size()));
+}
+
+// Row ID of the listed (node, basis) pairs from prepared panels W_k = S_k^T (ds[k] x m_k, contiguous, in tmp_):
+// truncated QRCP + X = R11^{-1} R12 on the device, then the commit of rank, permutation, skeleton indices.
+void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws_in,
+                          const std::vector<int>& ds_in) {
+  Arena& tmp = *tmp_;
+  const size_t cnt = ids.size();
+  std::vector<double*> Ws(Ws_in);
+  std::vector<int> ds(ds_in);
+  tsqr_reduce(ids, which, Ws, ds);
   std::vector<hssk_id_desc> idd;
   std::vector<int*> perms(cnt, nullptr);
   size_t perm_total = 0;
@@ -995,6 +1089,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     double* dX = work_->dbl((size_t)dim * N);
     ck(hssk_memcpy_h2d(ctx_, dX, ks.X, (long long)sizeof(double) * dim * N));
     hssk_kernel_spec spec{dX, N, dim, ks.type, ks.p, ks.h, ks.lambda};
+    double tk0 = now();
     std::vector<int> ann((size_t)k * N);
     if (user_ann && k == user_k) std::copy(user_ann, user_ann + (size_t)k * N, ann.begin());
     else {
@@ -1002,17 +1097,20 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       ck(hssk_knn(ctx_, dX, dim, N, k, dann));
       ck(hssk_memcpy_d2h(ctx_, ann.data(), dann, (long long)sizeof(int) * k * N));
     }
+    stats_.t_random += now() - tk0;   // neighbour search (reported in the 'random' slot: it replaces the random sketch)
     std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node
     bool failed = false;
     const int H = (int)by_height_.size();
     for (int h = 0; h < H && !failed; h++) {
       const std::vector<int>& ids = by_height_[h];
       tmp_->rewind();
+      double tl0 = now();
       // ---- column sets and row sets (host), one index upload per level
       std::vector<int> hidx;
       std::vector<size_t> roff(ids.size()), coff(ids.size());
       std::vector<std::vector<int>> rows(ids.size());
-      for (size_t q = 0; q < ids.size(); q++) {
+      // the nodes of a level are independent: host threads build their row / column sets side by side
+      host_parallel_for(ids.size(), [&](size_t q) {
         Node& nd = nodes_[ids[q]];
         std::vector<int>& cs = cols[ids[q]];
         const int lo = nd.lo, hi = nd.lo + nd.m;
@@ -1027,24 +1125,45 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
                 const int g = ann[(size_t)i * k + j];
                 if (g >= 0 && (g < lo || g >= hi)) cs.push_back(g);
               }
+            std::sort(cs.begin(), cs.end());
+            cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
           }
         } else {
           Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
           nd.mU = nd.mV = a.rU + b.rU;
           rows[q] = a.Ir;
           rows[q].insert(rows[q].end(), b.Ir.begin(), b.Ir.end());
-          if (nd.lvl > 0)
-            for (int c : {nd.c0, nd.c1})
-              for (int g : cols[c])
-                if (g < lo || g >= hi) cs.push_back(g);
+          if (nd.lvl > 0) {
+            // union of the children's (sorted, duplicate-free) sets without the ids inside this node
+            const std::vector<int>&ca = cols[nd.c0], &cb = cols[nd.c1];
+            cs.reserve(ca.size() + cb.size());
+            size_t i = 0, j = 0;
+            auto keep = [&](int g) { if (g < lo || g >= hi) cs.push_back(g); };
+            while (i < ca.size() && j < cb.size()) {
+              if (ca[i] < cb[j]) keep(ca[i++]);
+              else if (cb[j] < ca[i]) keep(cb[j++]);
+              else { keep(ca[i]); i++; j++; }
+            }
+            while (i < ca.size()) keep(ca[i++]);
+            while (j < cb.size()) keep(cb[j++]);
+          }
         }
-        std::sort(cs.begin(), cs.end());
-        cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+      });
+      for (size_t q = 0; q < ids.size(); q++) {
+        const std::vector<int>& cs = cols[ids[q]];
         roff[q] = hidx.size(); hidx.insert(hidx.end(), rows[q].begin(), rows[q].end());
         coff[q] = hidx.size(); hidx.insert(hidx.end(), cs.begin(), cs.end());
       }
+      // the children's column sets are not needed above this level
+      if (h > 0)
+        for (int id : ids) {
+          if (nodes_[id].leaf()) continue;
+          std::vector<int>().swap(cols[nodes_[id].c0]);
+          std::vector<int>().swap(cols[nodes_[id].c1]);
+        }
       int* didx = tmp_->ints(std::max<size_t>(hidx.size(), 1));
       if (!hidx.empty()) ck(hssk_memcpy_h2d(ctx_, didx, hidx.data(), (long long)sizeof(int) * hidx.size()));
+      stats_.t_sketch += now() - tl0;   // host column-set construction (the 'sketch' slot of this path)
       // ---- D (leaves), B01 / B10 (inner nodes), sample panels W = K(cols, rows)  [= S^T]
       std::vector<hssk_keval_desc> ev;
       std::vector<hssk_transpose_desc> tr;
@@ -1100,7 +1219,10 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
   free_compress_workspace();
   stats_.d_final = k;
   stats_.t_compress = now() - t0;
-  stats_.t_tree = stats_.t_compress;
+  stats_.t_tree = stats_.t_compress - stats_.t_sketch - stats_.t_random;
+  if (o_.verbose)
+    std::cout << "# HSS kernel compression: neighbours " << stats_.t_random << " s, column sets " << stats_.t_sketch << " s, blocks + ID "
+              << stats_.t_tree << " s" << std::endl;
 }
 
 // update_orthogonal_basis (HSSMatrix.compress_stable.hpp:390-442) for the listed (node, basis) pairs

@@ -135,6 +135,7 @@ class DeviceHSS {
   void run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot);
   void id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
                  const std::vector<int>& ds);
+  void tsqr_reduce(const std::vector<int>& ids, const std::vector<int>& which, std::vector<double*>& Ws, std::vector<int>& ds);
   void ortho_test(const std::vector<int>& ids, const std::vector<int>& which, int d, int dd,
                   std::vector<char>& resolved);
   void free_compress_workspace();

@@ -117,8 +117,10 @@ constexpr int KNN_Q = 64;    // queries per workgroup (one wave)
 constexpr int KNN_C = 64;    // candidates per LDS tile
 constexpr int KNN_DMAX = 64; // largest point dimension
 
-// DM >= d: coordinates per point held in LDS (instantiated for 8 / 16 / 32 / 64 so that low-dimensional point
-// sets keep three workgroups per CU)
+// DM >= d: coordinates per point, zero padded (instantiated for 8 / 16 / 32 / 64).  The query point sits in
+// registers, the candidate tile in LDS as [candidate][coordinate] so that a wave reads one candidate's coordinates
+// as broadcast 16-byte loads; four candidates are evaluated per trip to keep several loads in flight, the
+// (rare) insertion into the LDS-resident page of the KNN_P best keys happens afterwards.
 template <int DM>
 __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X, int d, int n, int kpage,
                                                     const float* __restrict__ lb_key, const int* __restrict__ lb_idx,
@@ -126,46 +128,55 @@ __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X
                                                     int* __restrict__ ub_idx) {
   HSSK_SHARED float hk[KNN_P * KNN_Q];
   HSSK_SHARED int hi[KNN_P * KNN_Q];
-  HSSK_SHARED double xq[KNN_Q * (DM + 1)];
-  HSSK_SHARED double xc[KNN_C * (DM + 1)];
+  HSSK_SHARED double xc[KNN_C * DM];
   const int tid = threadIdx.x;
   const int q = blockIdx.x * KNN_Q + tid;
   const bool live = q < n;
-  for (int j = 0; j < d; j++) xq[tid * (DM + 1) + j] = live ? X[(size_t)q * d + j] : 0.;
+  double xq[DM];
+#pragma unroll
+  for (int j = 0; j < DM; j++) xq[j] = (live && j < d) ? X[(size_t)q * d + j] : 0.;
   for (int s = 0; s < kpage; s++) { hk[s * KNN_Q + tid] = 3.0e38f; hi[s * KNN_Q + tid] = 0x7fffffff; }
   const float lbk = lb_key ? (live ? lb_key[q] : 0.f) : -1.f;
   const int lbi = lb_idx ? (live ? lb_idx[q] : 0) : -1;
   float worst = 3.0e38f;
   int worst_i = 0x7fffffff, worst_s = 0;
-  for (int c0 = 0; c0 < n; c0 += KNN_C) {
+  auto consider = [&](float key, int g) {
+    const bool above = key > lbk || (key == lbk && g > lbi);
+    const bool better = key < worst || (key == worst && g < worst_i);
+    if (live && g != q && g < n && above && better) {
+      hk[worst_s * KNN_Q + tid] = key;
+      hi[worst_s * KNN_Q + tid] = g;
+      // new worst = lexicographic maximum of the page
+      worst = -1.f; worst_i = -1;
+      for (int s = 0; s < kpage; s++) {
+        const float k2 = hk[s * KNN_Q + tid];
+        const int i2 = hi[s * KNN_Q + tid];
+        if (k2 > worst || (k2 == worst && i2 > worst_i)) { worst = k2; worst_i = i2; worst_s = s; }
+      }
+    }
+  };
+  // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
+  // spatial neighbours, the page threshold tightens at once and later tiles rarely insert (same result set)
+  const int ntile = (n + KNN_C - 1) / KNN_C, own = (blockIdx.x * KNN_Q) / KNN_C;
+  for (int t = 0; t < ntile; t++) {
+    const int c0 = ((own + t) % ntile) * KNN_C;
     __syncthreads();
-    for (int e = tid; e < KNN_C * d; e += KNN_Q) {
-      const int pt = e / d, j = e % d;
-      xc[pt * (DM + 1) + j] = c0 + pt < n ? X[(size_t)(c0 + pt) * d + j] : 0.;
+    for (int e = tid; e < KNN_C * DM; e += KNN_Q) {
+      const int pt = e / DM, j = e % DM;
+      xc[e] = (c0 + pt < n && j < d) ? X[(size_t)(c0 + pt) * d + j] : 0.;
     }
     __syncthreads();
-    const int cend = min(KNN_C, n - c0);
-    for (int c = 0; c < cend; c++) {
-      double s2 = 0.;
-      for (int j = 0; j < d; j++) {
-        const double df = xq[tid * (DM + 1) + j] - xc[c * (DM + 1) + j];
-        s2 += df * df;
-      }
-      const float key = (float)s2;
-      const int g = c0 + c;
-      const bool above = key > lbk || (key == lbk && g > lbi);
-      const bool better = key < worst || (key == worst && g < worst_i);
-      if (live && g != q && above && better) {
-        hk[worst_s * KNN_Q + tid] = key;
-        hi[worst_s * KNN_Q + tid] = g;
-        // new worst = lexicographic maximum of the page
-        worst = -1.f; worst_i = -1;
-        for (int s = 0; s < kpage; s++) {
-          const float k2 = hk[s * KNN_Q + tid];
-          const int i2 = hi[s * KNN_Q + tid];
-          if (k2 > worst || (k2 == worst && i2 > worst_i)) { worst = k2; worst_i = i2; worst_s = s; }
+    for (int c = 0; c < KNN_C; c += 4) {
+      double s2[4] = {0., 0., 0., 0.};
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int j = 0; j < DM; j++) {
+          const double df = xq[j] - xc[(c + u) * DM + j];
+          s2[u] += df * df;
         }
-      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) consider((float)s2[u], c0 + c + u);
     }
   }
   if (!live) return;

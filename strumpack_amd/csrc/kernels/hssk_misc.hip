@@ -116,6 +116,16 @@ __global__ void gather_elems_kernel(const hssk_elem_desc* __restrict__ descs, co
   }
 }
 
+// upper-trapezoidal copy: dst(i, j) = src(i, j) for i <= j, 0 below (stacking the R factors of a TSQR tree)
+__global__ void copy_triu_kernel(const hssk_triu_desc* __restrict__ descs, const Work2* __restrict__ work) {
+  const Work2 w = work[blockIdx.x];
+  const hssk_triu_desc p = descs[w.prob];
+  const int jend = min(p.cols, (w.chunk + 1) * COLS_PER_WG);
+  for (int j = w.chunk * COLS_PER_WG; j < jend; j++)
+    for (int i = threadIdx.x; i < p.rows; i += blockDim.x)
+      hssk_gstore(p.dst, i + (size_t)j * p.ldd, i <= j ? hssk_gload(p.src, i + (size_t)j * p.lds) : 0.);
+}
+
 // transpose through a padded LDS tile: dst(c, r) = src(r, c)
 struct Work3 {
   int prob, tr, tc;
@@ -255,6 +265,17 @@ int hssk_gather_cols(hssk_ctx* ctx, const hssk_colgather_desc* descs, int count)
   auto* dd = (const hssk_colgather_desc*)ctx->stage(descs, sizeof(*descs) * count);
   auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
   HSSK_LAUNCH(gather_cols_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_copy_triu(hssk_ctx* ctx, const hssk_triu_desc* descs, int count) {
+  HSSK_API_BEGIN
+  auto w = make_work2(descs, count, [](const hssk_triu_desc& d) { return d.rows > 0 ? d.cols : 0; });
+  if (w.empty()) return 0;
+  auto* dd = (const hssk_triu_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
+  HSSK_LAUNCH(copy_triu_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
   hssk_rt::check_launch();
   HSSK_API_END
 }
