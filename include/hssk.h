@@ -115,10 +115,11 @@ typedef struct hssk_keval_desc {
   int nr, nc, ldo, r0, c0;
 } hssk_keval_desc;
 int hssk_kernel_eval_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* spec, const hssk_keval_desc* descs, int count);
-/* exact k nearest neighbours (Euclidean, the point itself excluded) of every point: out_idx is k x n (device ints,
- * neighbours of point i in column i, unordered, -1 where n - 1 < k).  Serves the neighbour lists of
+/* exact k nearest neighbours (Euclidean, the point itself excluded) of the points q0 <= i < q1 among all n points:
+ * out_idx is k x n (device ints, neighbours of point i in column i, unordered, -1 where n - 1 < k; only the columns
+ * of the query range are written -- one process per GPU searches for its own points).  Serves the neighbour lists of
  * HSSMatrix::compress_with_coordinates (HSS/HSSMatrix.compress_kernel.hpp:58-66).  d <= 64. */
-int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int* out_idx);
+int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx);
 /* pred[c] = sum_r w[r] k(x_r, t_c), c < m; T is d x m (device)   (Kernel::predict, kernel/KernelRegression.hpp:112-123) */
 int hssk_kernel_predict(hssk_ctx* ctx, const hssk_kernel_spec* spec, const double* w, const double* T, int m, double* pred);
 

@@ -86,6 +86,18 @@ typedef void (*SPXAllGatherFn)(void* user, void* dbuf, long long bytes_per_rank)
 int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                            const CSPOptions* opts, const SPXHSSOptions* h, int world, int rank,
                                            SPXAllGatherFn allgather, void* user);
+/* HSS approximation of a kernel matrix K(i, j) = k(x_i, x_j) + lambda [i == j] over n points in R^d (points: d x n,
+ * one point per column, HOST; reordered in place by the clustering, perm (n ints, may be NULL) receives the 1-based
+ * permutation: new point i = old point perm[i]).  ktype 0 Gauss, 1 Laplace, 2 ANOVA (degree p); clustering 0 natural,
+ * 1 2means, 2 kdtree, 3 pca, 4 cobble; neighbors = initial neighbour count (<= 0: default 64).  Reference:
+ * HSSMatrix(kernel::Kernel&, opts) (HSS/HSSMatrix.cpp:88-106) -- no random sketch, the samples are kernel columns
+ * chosen from nearest neighbours (HSS/HSSMatrix.compress_kernel.hpp).  The _sharded form is the one-process-per-GPU
+ * variant (same conventions as SPX_d_struct_from_dense_device_sharded; every rank passes the same points). */
+int SPX_d_struct_from_kernel(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                             const CSPOptions* opts, int clustering, int neighbors, int* perm);
+int SPX_d_struct_from_kernel_sharded(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                                     const CSPOptions* opts, int clustering, int neighbors, int* perm, int world, int rank,
+                                     SPXAllGatherFn allgather, void* user);
 int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB,
                              double* dC, long long ldC);
 int SPX_d_struct_solve_device(const CSPStructMat S, int nrhs, double* dB, long long ldB);

@@ -27,6 +27,7 @@ SP_SYMBOLS = [
     "SPX_d_struct_from_dense_device", "SPX_d_struct_from_dense_device_sharded", "SPX_d_struct_mult_device", "SPX_d_struct_solve_device",
     "SPX_d_struct_levels", "SPX_d_struct_is_compressed", "SPX_d_struct_num_nodes",
     "SPX_d_struct_node_info", "SPX_d_struct_stats", "SPX_d_struct_hssk_ctx",
+    "SPX_d_struct_from_kernel", "SPX_d_struct_from_kernel_sharded",
 ]
 ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
@@ -60,6 +61,10 @@ def load(path):
     L.SPX_d_struct_from_dense_device_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_longlong,
                                                          C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions),
                                                          C.c_int, C.c_int, ALLGATHER_CB, vp]
+    L.SPX_d_struct_from_kernel.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
+                                           C.POINTER(CSPOptions), C.c_int, C.c_int, vp]
+    L.SPX_d_struct_from_kernel_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                   C.POINTER(CSPOptions), C.c_int, C.c_int, vp, C.c_int, C.c_int, ALLGATHER_CB, vp]
     L.SPX_d_struct_mult_device.argtypes = [vp, C.c_char, C.c_int, dp, C.c_longlong, dp, C.c_longlong]
     L.SPX_d_struct_solve_device.argtypes = [vp, C.c_int, dp, C.c_longlong]
     L.SPX_d_struct_node_info.argtypes = [vp, C.POINTER(C.c_int)]

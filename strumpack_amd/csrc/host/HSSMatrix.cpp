@@ -33,7 +33,9 @@ HSSMatrix<double>::HSSMatrix(const structured::ClusterTree& t, const opts_t& opt
 HSSMatrix<double>::~HSSMatrix() {}
 
 // HSSMatrix(kernel::Kernel&, opts): HSS/HSSMatrix.cpp:88-106
-HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : rows_(K.n()), cols_(K.n()) {
+HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : HSSMatrix(K, opts, 1, 0, nullptr, nullptr) {}
+HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, int world, int rank,
+                             void (*fn)(void*, void*, long long), void* user) : rows_(K.n()), cols_(K.n()) {
   auto tc0 = std::chrono::steady_clock::now();
   auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size());
   K.permute();
@@ -41,7 +43,9 @@ HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : ro
     std::cout << "# clustering (" << get_name(opts.clustering_algorithm()) << ") time = "
               << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count() << std::endl;
   tree_.reset(new structured::ClusterTree(t));
-  eng_.reset(new DeviceHSS(int(rows_), engine_options(opts), tree_.get()));
+  EngineOptions e = engine_options(opts);
+  e.world = world; e.rank = rank; e.allgather = fn; e.comm_user = user;
+  eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
   compress(K, opts);
 }
 void HSSMatrix<double>::compress(const kernel::Kernel<double>& K, const opts_t& opts) {
@@ -63,7 +67,9 @@ void HSSMatrix<double>::compress_with_neighbors(const kernel::Kernel<double>& K,
 void HSSMatrix<double>::make_engine(const opts_t& opts, const structured::ClusterTree* t) {
   EngineOptions e = engine_options(opts);
   if (eng_ && eng_->options().leaf_size == e.leaf_size && eng_->options().device == e.device) {
-    eng_->set_options(e);  // same tree: keep the engine (and its device context), new knobs
+    const EngineOptions& cur = eng_->options();   // same tree: keep the engine (device context, process group), new knobs
+    e.world = cur.world; e.rank = cur.rank; e.allgather = cur.allgather; e.comm_user = cur.comm_user;
+    eng_->set_options(e);
     return;
   }
   eng_.reset(new DeviceHSS(int(rows_), e, t));

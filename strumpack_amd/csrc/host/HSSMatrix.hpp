@@ -38,6 +38,8 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   // kernel matrix: clusters the points (reordering K's data), builds the tree and compresses from the point
   // coordinates without a random sketch (HSS/HSSMatrix.cpp:88-106, HSSMatrix.compress_kernel.hpp)
   HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts);
+  // extension: one process per GPU (every rank holds all points; subtree ownership as in compress_device_sharded)
+  HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, int world, int rank, void (*allgather)(void*, void*, long long), void* user);
   ~HSSMatrix() override;
 
   void compress(const DenseM_t& A, const opts_t& opts);

@@ -3,6 +3,7 @@
 #include <iostream>
 
 #include "HSSMatrix.hpp"
+#include "Kernel.hpp"
 #include "StructuredMatrix.hpp"
 #include "structured/StructuredMatrix.h"
 
@@ -147,6 +148,40 @@ int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, 
   s->S.reset(H.release());
   *S = s.release();
   SP_CATCH
+}
+// HSS approximation of the kernel matrix over `points` (d x n): clusters (reordering points in place, perm 1-based),
+// builds the tree, compresses from the coordinates (HSSMatrix(kernel::Kernel&, opts), HSS/HSSMatrix.cpp:88-106)
+int SPX_d_struct_from_kernel_sharded(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                                     const CSPOptions* opts, int clustering, int neighbors, int* perm, int world, int rank,
+                                     SPXAllGatherFn allgather, void* user) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("kernel construction requires type SP_TYPE_HSS");
+  if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("invalid world/rank");
+  static const ClusteringAlgorithm algos[] = {ClusteringAlgorithm::NATURAL, ClusteringAlgorithm::TWO_MEANS, ClusteringAlgorithm::KD_TREE,
+                                              ClusteringAlgorithm::PCA, ClusteringAlgorithm::COBBLE};
+  if (clustering < 0 || clustering > 4) throw std::invalid_argument("clustering algorithm out of range");
+  auto ho = get_hss_options(opts, nullptr);
+  ho.set_clustering_algorithm(algos[clustering]);
+  if (neighbors > 0) ho.set_approximate_neighbors(neighbors);
+  DenseMatrix<double> X(d, n, points, d);
+  std::unique_ptr<kernel::Kernel<double>> K;
+  switch (ktype) {
+    case 0: K.reset(new kernel::GaussKernel<double>(X, h, lambda)); break;
+    case 1: K.reset(new kernel::LaplaceKernel<double>(X, h, lambda)); break;
+    case 2: K.reset(new kernel::ANOVAKernel<double>(X, h, lambda, p)); break;
+    default: throw std::invalid_argument("kernel type must be 0 (Gauss), 1 (Laplace) or 2 (ANOVA)");
+  }
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(*K, ho, world, rank, allgather, user));
+  std::copy(X.data(), X.data() + (size_t)d * n, points);
+  if (perm) std::copy(K->permutation().begin(), K->permutation().end(), perm);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
+int SPX_d_struct_from_kernel(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                             const CSPOptions* opts, int clustering, int neighbors, int* perm) {
+  return SPX_d_struct_from_kernel_sharded(S, n, d, points, ktype, h, lambda, p, opts, clustering, neighbors, perm, 1, 0, nullptr, nullptr);
 }
 int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB, double* dC, long long ldC) {
   SP_TRY

@@ -425,6 +425,47 @@ void DeviceHSS::exchange_cut_compress(int dtot) {
   }
 }
 
+// kernel-matrix compression: publish the cut nodes (rank, skeleton ids, column set) to every rank; returns the
+// all-ranks OR of `failed` so that every process takes the same decision about another round
+bool DeviceHSS::exchange_cut_kernel(std::vector<std::vector<int>>& cols, bool failed) {
+  const int G = o_.world, me = o_.rank;
+  std::vector<int> meta(4 * (size_t)G, 0);
+  {
+    const Node& c = nodes_[cut_nodes_[me]];
+    meta[4 * me] = c.compressed(); meta[4 * me + 1] = c.rU; meta[4 * me + 2] = (int)cols[cut_nodes_[me]].size(); meta[4 * me + 3] = failed;
+  }
+  allgather_ints(meta, 4);
+  int rmax = 0, cmax = 0;
+  bool any_failed = false;
+  for (int g = 0; g < G; g++) {
+    rmax = std::max(rmax, meta[4 * g + 1]); cmax = std::max(cmax, meta[4 * g + 2]);
+    any_failed = any_failed || meta[4 * g + 3] || !meta[4 * g];
+  }
+  if (any_failed) return true;
+  const size_t per = (size_t)rmax + cmax;
+  if (per == 0) return false;
+  std::vector<int> idx(per * G, 0);
+  {
+    const Node& c = nodes_[cut_nodes_[me]];
+    std::copy(c.Ir.begin(), c.Ir.end(), idx.begin() + per * me);
+    std::copy(cols[cut_nodes_[me]].begin(), cols[cut_nodes_[me]].end(), idx.begin() + per * me + rmax);
+  }
+  allgather_ints(idx, (int)per);
+  int* didx = work_->ints(per * G);
+  ck(hssk_memcpy_h2d(ctx_, didx, idx.data(), (long long)(sizeof(int) * idx.size())));
+  for (int g = 0; g < G; g++) {
+    if (g == me) continue;
+    Node& c = nodes_[cut_nodes_[g]];
+    c.rU = c.rV = meta[4 * g + 1];
+    c.Ustate = c.Vstate = 2;
+    c.Ir.assign(idx.begin() + per * g, idx.begin() + per * g + c.rU);
+    c.Ic = c.Ir;
+    c.dIr = c.dIc = didx + per * g;
+    cols[cut_nodes_[g]].assign(idx.begin() + per * g + rmax, idx.begin() + per * g + rmax + meta[4 * g + 2]);
+  }
+  return false;
+}
+
 // ranks / basis sizes of every node, for introspection and buffer sizing on all ranks
 void DeviceHSS::exchange_node_table() {
   const size_t nn = nodes_.size();
@@ -1069,14 +1110,6 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
 // I = the node's rows (leaf) resp. its children's skeleton rows; symmetric: V = U, B10 = B01^T.
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int user_k) {
-  if (o_.world > 1 && dist_subtree_) {
-    // every rank holds all points: the whole tree is built replicated (TODO(next): subtree ownership as in the sketch path)
-    dist_subtree_ = false;
-    std::fill(owner_.begin(), owner_.end(), -1);
-    own_by_height_ = by_height_; own_by_depth_ = by_depth_;
-    for (auto& v : top_by_height_) v.clear();
-    for (auto& v : top_by_depth_) v.clear();
-  }
   double t0 = now();
   stats_ = PhaseStats();
   const int N = n_, dim = ks.d;
@@ -1093,16 +1126,18 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     std::vector<int> ann((size_t)k * N);
     if (user_ann && k == user_k) std::copy(user_ann, user_ann + (size_t)k * N, ann.begin());
     else {
+      // one process per GPU: neighbours of this rank's own points only (its subtree's leaves are all that read them)
+      int q0 = 0, q1 = N;
+      if (dist_subtree_) { const Node& c = nodes_[cut_nodes_[o_.rank]]; q0 = c.lo; q1 = c.lo + c.m; }
       int* dann = work_->ints((size_t)k * N);
-      ck(hssk_knn(ctx_, dX, dim, N, k, dann));
-      ck(hssk_memcpy_d2h(ctx_, ann.data(), dann, (long long)sizeof(int) * k * N));
+      ck(hssk_knn(ctx_, dX, dim, N, k, q0, q1, dann));
+      ck(hssk_memcpy_d2h(ctx_, ann.data() + (size_t)k * q0, dann + (size_t)k * q0, (long long)sizeof(int) * k * (q1 - q0)));
     }
     stats_.t_random += now() - tk0;   // neighbour search (reported in the 'random' slot: it replaces the random sketch)
     std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node
     bool failed = false;
-    const int H = (int)by_height_.size();
-    for (int h = 0; h < H && !failed; h++) {
-      const std::vector<int>& ids = by_height_[h];
+    auto do_level = [&](const std::vector<int>& ids) {
+      if (ids.empty() || failed) return;
       tmp_->rewind();
       double tl0 = now();
       // ---- column sets and row sets (host), one index upload per level
@@ -1155,7 +1190,6 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         coff[q] = hidx.size(); hidx.insert(hidx.end(), cs.begin(), cs.end());
       }
       // the children's column sets are not needed above this level
-      if (h > 0)
         for (int id : ids) {
           if (nodes_[id].leaf()) continue;
           std::vector<int>().swap(cols[nodes_[id].c0]);
@@ -1193,7 +1227,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       }
       if (!ev.empty()) ck(hssk_kernel_eval_vbatched(ctx_, &spec, ev.data(), (int)ev.size()));
       if (!tr.empty()) ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
-      if (idn.empty()) continue;
+      if (idn.empty()) return;
       // nodes with an empty column set (d == 0) get rank 0 through a 1 x m zero panel
       for (size_t q = 0; q < idn.size(); q++)
         if (!Ws[q] && nodes_[idn[q]].mU > 0) {
@@ -1209,6 +1243,11 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         const int d = (int)cols[idn[q]].size();
         if (!(d >= nd.m || d >= o_.max_rank || nd.rU + o_.p < d)) failed = true;
       }
+    };
+    for (auto& ids : own_by_height_) do_level(ids);
+    if (dist_subtree_) {
+      failed = exchange_cut_kernel(cols, failed);
+      for (auto& ids : top_by_height_) do_level(ids);
     }
     ck(hssk_sync(ctx_));
     if (!failed) break;
@@ -1216,7 +1255,9 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     k = std::min(2 * k, N);   // compress_with_coordinates: ann_number doubles until the tree compresses (:75)
     if (o_.verbose) std::cout << "# HSS kernel compression: increasing the neighbour count to " << k << std::endl;
   }
+  if (dist_subtree_) exchange_node_table();
   free_compress_workspace();
+  comm_arena_->reset();
   stats_.d_final = k;
   stats_.t_compress = now() - t0;
   stats_.t_tree = stats_.t_compress - stats_.t_sketch - stats_.t_random;

@@ -146,6 +146,7 @@ class DeviceHSS {
   void comm(void* dbuf, long long bytes_per_rank);
   void allgather_ints(std::vector<int>& v, int per_rank);
   void exchange_cut_compress(int dtot);
+  bool exchange_cut_kernel(std::vector<std::vector<int>>& cols, bool failed);
   void exchange_node_table();
   void exchange_cut_factor();
   void allgather_rows(double* dx, long long ldx, int nrhs);

@@ -122,7 +122,7 @@ constexpr int KNN_DMAX = 64; // largest point dimension
 // as broadcast 16-byte loads; four candidates are evaluated per trip to keep several loads in flight, the
 // (rare) insertion into the LDS-resident page of the KNN_P best keys happens afterwards.
 template <int DM>
-__global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X, int d, int n, int kpage,
+__global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
                                                     const float* __restrict__ lb_key, const int* __restrict__ lb_idx,
                                                     int* __restrict__ out_idx, int ldo, float* __restrict__ ub_key,
                                                     int* __restrict__ ub_idx) {
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X
   HSSK_SHARED int hi[KNN_P * KNN_Q];
   HSSK_SHARED double xc[KNN_C * DM];
   const int tid = threadIdx.x;
-  const int q = blockIdx.x * KNN_Q + tid;
-  const bool live = q < n;
+  const int q = q0 + blockIdx.x * KNN_Q + tid;
+  const bool live = q < q1;
   double xq[DM];
 #pragma unroll
   for (int j = 0; j < DM; j++) xq[j] = (live && j < d) ? X[(size_t)q * d + j] : 0.;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X
   };
   // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
   // spatial neighbours, the page threshold tightens at once and later tiles rarely insert (same result set)
-  const int ntile = (n + KNN_C - 1) / KNN_C, own = (blockIdx.x * KNN_Q) / KNN_C;
+  const int ntile = (n + KNN_C - 1) / KNN_C, own = (q0 + blockIdx.x * KNN_Q) / KNN_C;
   for (int t = 0; t < ntile; t++) {
     const int c0 = ((own + t) % ntile) * KNN_C;
     __syncthreads();
@@ -267,15 +267,16 @@ extern "C" int hssk_kernel_eval_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* 
   HSSK_API_END
 }
 
-extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int* out_idx) {
+extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx) {
   HSSK_API_BEGIN
-  if (n <= 0 || k <= 0) return 0;
+  if (n <= 0 || k <= 0 || q1 <= q0) return 0;
+  if (q0 < 0 || q1 > n) throw std::invalid_argument("hssk_knn: query range outside the point set");
   if (d <= 0 || d > KNN_DMAX) throw std::invalid_argument("hssk_knn: point dimension must be in [1, 64]");
   const int pages = (k + KNN_P - 1) / KNN_P;
   // page bounds (float key + index per query), ping-pong
   float* kb = (float*)ctx->scratch(sizeof(float) * 4 * (size_t)n + 64);
   int* ib = (int*)(kb + 2 * (size_t)n);
-  const unsigned grid = (unsigned)((n + KNN_Q - 1) / KNN_Q);
+  const unsigned grid = (unsigned)((q1 - q0 + KNN_Q - 1) / KNN_Q);
   for (int pg = 0; pg < pages; pg++) {
     const int kp = std::min(KNN_P, k - pg * KNN_P);
     const float* lk = pg ? kb + (size_t)((pg - 1) & 1) * n : nullptr;
@@ -283,10 +284,10 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
     float* uk = kb + (size_t)(pg & 1) * n;
     int* ui = ib + (size_t)(pg & 1) * n;
     int* oi = out_idx + pg * KNN_P;
-    if (d <= 8) HSSK_LAUNCH((knn_kernel<8>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, kp, lk, li, oi, k, uk, ui);
-    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, kp, lk, li, oi, k, uk, ui);
-    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, kp, lk, li, oi, k, uk, ui);
-    else HSSK_LAUNCH((knn_kernel<64>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, kp, lk, li, oi, k, uk, ui);
+    if (d <= 8) HSSK_LAUNCH((knn_kernel<8>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    else HSSK_LAUNCH((knn_kernel<64>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
   }
   hssk_rt::check_launch();
   HSSK_API_END

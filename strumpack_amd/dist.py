@@ -106,3 +106,30 @@ def from_dense_device(lib, dptr, n, lda, opts, hss, exchange_cb=None, world=None
     if rc:
         raise RuntimeError("SPX_d_struct_from_dense_device_sharded failed")
     return capi.StructuredMatrix(lib, h, n)
+
+
+CLUSTERING = {"natural": 0, "2means": 1, "kdtree": 2, "pca": 3, "cobble": 4}
+KERNEL_TYPES = {"Gauss": 0, "Laplace": 1, "ANOVA": 2}
+
+
+def from_kernel(lib, X, opts, kernel="Gauss", h=1.0, lam=0.0, degree=1, clustering="2means", neighbors=64,
+                exchange_cb=None, world=None, rank=None):
+    """HSS approximation of the kernel matrix over the rows of X (n x d, host); sharded over the process group when an
+    exchange callback is given (every rank passes the same X).  Returns (matrix, points in cluster order, 1-based perm)."""
+    Xp = np.ascontiguousarray(X, dtype=np.float64).copy()
+    n, d = Xp.shape
+    perm = np.zeros(n, dtype=np.int32)
+    hnd = C.c_void_p()
+    if exchange_cb is None:
+        rc = lib.SPX_d_struct_from_kernel(C.byref(hnd), n, d, Xp.ctypes.data, KERNEL_TYPES[kernel], h, lam, degree,
+                                          C.byref(opts), CLUSTERING[clustering], neighbors, perm.ctypes.data)
+    else:
+        import torch.distributed as dist
+        world = dist.get_world_size() if world is None else world
+        rank = dist.get_rank() if rank is None else rank
+        rc = lib.SPX_d_struct_from_kernel_sharded(C.byref(hnd), n, d, Xp.ctypes.data, KERNEL_TYPES[kernel], h, lam, degree,
+                                                  C.byref(opts), CLUSTERING[clustering], neighbors, perm.ctypes.data,
+                                                  world, rank, exchange_cb, None)
+    if rc:
+        raise RuntimeError("SPX_d_struct_from_kernel failed")
+    return capi.StructuredMatrix(lib, hnd, n), Xp, perm

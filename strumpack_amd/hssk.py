@@ -191,7 +191,7 @@ class Hssk:
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         L.hssk_kernel_eval_vbatched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.hssk_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hssk_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hssk_kernel_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.hssk_mfma_f64_peak_tflops.restype = C.c_double
         L.hssk_mfma_f64_peak_tflops.argtypes = [C.c_void_p, C.c_int]

@@ -344,7 +344,8 @@ def case_knn(hk, n=500, d=8, k=10, seed=22):
     X = r.standard_normal((n, d))
     dX = hk.array(X.T)
     out = hk.empty((k, n), dtype=np.int32)
-    hk.check(hk.lib.hssk_knn(hk.ctx, dX.ptr, d, n, k, out.ptr))
+    hk.check(hk.lib.hssk_knn(hk.ctx, dX.ptr, d, n, k, 0, n // 3, out.ptr))      # two query ranges, as two ranks would
+    hk.check(hk.lib.hssk_knn(hk.ctx, dX.ptr, d, n, k, n // 3, n, out.ptr))
     hk.sync()
     got = out.get().T                        # row i = neighbours of point i
     D2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1).astype(np.float32)   # the kernel ranks float keys

@@ -46,6 +46,27 @@ for (n, leaf, d0, dd, algo) in CASES[world]:
         print("rank", rank, "case", n, leaf, algo, same_tree, e_mult, e_multT, e_solve, res, flush=True)
     ok = ok and good
     H.destroy(); H1.destroy()
+# kernel-matrix front end: subtree ownership (natural / kd trees are balanced -> cut exists), replicated otherwise
+KCASES = {2: [(130, 16, "kdtree", "Gauss")], 4: [(150, 16, "natural", "Laplace")], 3: [(90, 16, "kdtree", "Gauss")]}
+for (n, leaf, clus, kern) in KCASES[world]:
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n, 4))
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-10, leaf_size=leaf)
+    ex = sdist.make_exchange(L, world, rank)
+    H, Xp, perm = sdist.from_kernel(L, X, o, kernel=kern, h=1.5, lam=2.0, clustering=clus, neighbors=32, exchange_cb=ex)
+    H1, Xp1, perm1 = sdist.from_kernel(L, X, o, kernel=kern, h=1.5, lam=2.0, clustering=clus, neighbors=32)
+    B = rng.standard_normal((n, 2))
+    same_tree = np.array_equal(H.node_info(), H1.node_info()) and np.array_equal(perm, perm1)
+    y, y1 = H.mult(B), H1.mult(B)
+    H.factor(); H1.factor()
+    x, x1 = H.solve(B), H1.solve(B)
+    e_mult = np.linalg.norm(y - y1) / np.linalg.norm(y1)
+    e_solve = np.linalg.norm(x - x1) / np.linalg.norm(x1)
+    good = same_tree and e_mult < 1e-11 and e_solve < 1e-9 and H.is_compressed()
+    if not good:
+        print("rank", rank, "kernel case", n, leaf, clus, same_tree, e_mult, e_solve, flush=True)
+    ok = ok and good
+    H.destroy(); H1.destroy()
 t = torch.tensor([float(ok)])
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 if rank == 0:
