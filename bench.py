@@ -40,7 +40,70 @@ def parse():
     p.add_argument("--nrhs", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-n", type=int, default=16384)
+    p.add_argument("--workload", choices=["toeplitz", "kernel"], default="toeplitz",
+                   help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
+                        "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line")
     return p.parse_args()
+
+
+def kernel_workload(a, torch, dist, world, rank, local):
+    """BASELINE configs[3]: N x N Gaussian-kernel matrix (examples/dense/KernelRegression.cpp: h = 1.3, lambda = 3.11),
+    points uniform in [0,1)^8, HSS tree sharded by subtree over the ranks.  One step = clustering +
+    neighbour search + compression from coordinates + ULV factor + solve for the regression weights."""
+    import numpy as np
+    from strumpack_amd import _loader, capi, dist as sdist
+    L = capi.load(_loader.lib_path())
+    n = a.n
+    rng = np.random.default_rng(2025)
+    X = rng.random((n, 8))
+    y = np.sign((X - 0.5) @ rng.standard_normal(8)).reshape(-1, 1)
+    opts = capi.StructuredMatrix.options(L, rel_tol=1e-2, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
+    exch = sdist.make_exchange(L, world, rank) if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        H, Xp, perm = sdist.from_kernel(L, X, opts, kernel="Gauss", h=1.3, lam=3.11, clustering="cobble", neighbors=64, exchange_cb=exch)
+        H.factor()
+        w = H.solve(y[perm - 1])
+        return H, w, perm
+
+    H = None
+    for _ in range(a.warmup):
+        if H is not None:
+            H.destroy()
+        H, w, perm = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if H is not None:
+            H.destroy()
+        H, w, perm = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = H.stats()
+    resid = float(np.linalg.norm(H.mult(w) - y[perm - 1]) / np.linalg.norm(y))
+    out = {"metric": "hss_kernel_fit_points_per_s", "value": n / (elapsed / a.steps), "unit": "points/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3]: %dx%d Gaussian-kernel matrix (h=1.3, lambda=3.11) over uniform points in R^8, "
+                                  "cobble clustering, leaf=%d, rel_tol=1e-2, 64 nearest neighbours: cluster + compress + ULV factor + solve"
+                                  % (n, n, a.leaf), "n": n, "leaf": a.leaf},
+           "phases_s": {"compress": st["t_compress"], "neighbours": st["t_random"], "column_sets": st["t_sketch"],
+                        "blocks_id": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
+           "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "neighbours": int(st["d_final"])},
+           "checks": {"solve_resid_H": resid}}
+    if rank == 0:
+        print(json.dumps(out))
+    H.destroy()
 
 
 def cpu_baseline(n, leaf, rel_tol):
@@ -90,6 +153,11 @@ def main():
     if world > 1:
         dist.init_process_group(os.environ.get("STRUMPACK_AMD_BACKEND", "nccl"),
                                 **({"device_id": torch.device("cuda", local)} if os.environ.get("STRUMPACK_AMD_BACKEND", "nccl") == "nccl" else {}))
+    if a.workload == "kernel":
+        kernel_workload(a, torch, dist, world, rank, local)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from strumpack_amd import _loader, capi, dist as sdist
     from strumpack_amd import hssk as K
     L = capi.load(_loader.lib_path())

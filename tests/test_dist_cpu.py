@@ -21,7 +21,7 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 L = capi.load(emu_lib.PATH)
 hk = K.Hssk(emu_lib.PATH)
 ok = True
-CASES = {2: [(203, 16, 16, 8, "stable"), (120, 16, 16, 8, "original")], 4: [(170, 16, 8, 8, "stable")], 3: [(110, 16, 16, 8, "stable")]}
+CASES = {2: [(150, 16, 16, 8, "stable"), (90, 16, 16, 8, "original")], 4: [(140, 16, 8, 8, "stable")], 3: [(90, 16, 16, 8, "stable")]}
 for (n, leaf, d0, dd, algo) in CASES[world]:
     A = O.toeplitz(n)
     dA = hk.array(A)
@@ -47,7 +47,7 @@ for (n, leaf, d0, dd, algo) in CASES[world]:
     ok = ok and good
     H.destroy(); H1.destroy()
 # kernel-matrix front end: subtree ownership (natural / kd trees are balanced -> cut exists), replicated otherwise
-KCASES = {2: [(130, 16, "kdtree", "Gauss")], 4: [(150, 16, "natural", "Laplace")], 3: [(90, 16, "kdtree", "Gauss")]}
+KCASES = {2: [(100, 16, "kdtree", "Gauss")], 4: [(130, 16, "natural", "Laplace")], 3: [(70, 16, "kdtree", "Gauss")]}
 for (n, leaf, clus, kern) in KCASES[world]:
     rng = np.random.default_rng(11)
     X = rng.standard_normal((n, 4))
