@@ -978,8 +978,9 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
     const Node& nd = nodes_[ids[k]];
     const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
     ms[k] = m;
-    if (m <= 0 || m > 256 || !Ws[k] || d <= std::max(256, 2 * m)) continue;
-    const int chunk = m <= 208 ? 256 : 512;
+    if (m <= 0 || !Ws[k] || d <= std::max(256, 2 * m)) continue;
+    // chunk rows: register QR (<= 256 x 208), the 512-row blocked path, or the tall blocked path for wide panels
+    const int chunk = m <= 208 ? 256 : (m <= 256 ? 512 : 2 * m);
     for (int r0 = 0; r0 < d; r0 += chunk) {
       const int cr = std::min(chunk, d - r0);
       double* wk = tmp.dbl((size_t)cr + m);

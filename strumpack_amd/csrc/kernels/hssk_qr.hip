@@ -357,6 +357,51 @@ __global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ d
   }
 }
 
+// ---- tall panels (rows > QB_MAXROWS): V does not fit LDS, so the compact-WY pair is assembled from batched GEMMs:
+// make_v_kernel writes the explicit V (and folds the panel's max / min |R_ii|), G = V^T V and VT = V T are GEMMs,
+// larft_small_kernel runs the dlarft recurrence on G
+__global__ __launch_bounds__(256) void make_v_kernel(const QPanel* __restrict__ descs) {
+  const QPanel p = descs[blockIdx.x];
+  const int rows = p.rows, nb = p.nb;
+  if (blockIdx.y == 0 && threadIdx.x == 0 && p.rdiag) {
+    const double pm = nb ? p.rd_panel[0] : 0., pn = nb ? p.rd_panel[1] : 0.;
+    if (p.first) { p.rdiag[0] = pm; p.rdiag[1] = pn; }
+    else if (nb) {
+      if (pm > p.rdiag[0]) p.rdiag[0] = pm;
+      if (pn < p.rdiag[1]) p.rdiag[1] = pn;
+    }
+  }
+  for (size_t e = (size_t)blockIdx.y * blockDim.x + threadIdx.x; e < (size_t)rows * nb; e += (size_t)gridDim.y * blockDim.x) {
+    const int i = (int)(e % rows), j = (int)(e / rows);
+    hssk_gstore(p.Vc, i + (size_t)j * p.ldv, i < j ? 0. : (i == j ? 1. : hssk_gload(p.A, i + (size_t)j * p.lda)));
+  }
+}
+struct TDesc {
+  const double* G;   // nb x nb (ld QB): V^T V, upper part used
+  const double* tau;
+  double* T;         // nb x nb (ld QB)
+  int nb;
+};
+__global__ __launch_bounds__(64) void larft_small_kernel(const TDesc* __restrict__ descs) {
+  HSSK_SHARED double s_T[QB * QB];
+  const TDesc p = descs[blockIdx.x];
+  const int lane = threadIdx.x, nb = p.nb;
+  for (int e = lane; e < QB * QB; e += 64) s_T[e] = 0.;
+  __syncthreads();
+  if (lane < nb) {
+    for (int i = 0; i < nb; i++) {
+      const double ti = p.tau[i];
+      if (lane < i) {
+        double s = 0.;
+        for (int c = lane; c < i; c++) s += s_T[lane + c * QB] * p.G[c + i * QB];
+        s_T[lane + i * QB] = -ti * s;
+      } else if (lane == i) s_T[lane + i * QB] = ti;
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < QB * QB; e += 64) p.T[e] = s_T[e];
+}
+
 struct EyeDesc {
   double* Q;
   int ldq, rows, nq;
@@ -380,22 +425,25 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
   std::vector<size_t> offV(count), offW(count), offR(count);
   size_t tot = 0;
   int pmax = 0;
-  bool anyq = false;
+  bool anyq = false, tall = false;
   for (int i = 0; i < count; i++) {
     const hssk_qr_desc& d = descs[i];
     const size_t kmax = (size_t)std::min(d.rows, d.cols);
     offV[i] = tot; tot += 2 * (size_t)d.rows * kmax;
     offW[i] = tot; tot += (size_t)QB * std::max(std::max(d.cols, d.nq), 1);
-    offR[i] = tot; tot += 2;
+    offR[i] = tot; tot += 2 + 2 * QB * QB;   // panel max/min, then G and T of the tall path
     pmax = std::max(pmax, (int)((kmax + QB - 1) / QB));
     anyq = anyq || d.nq > 0;
+    tall = tall || d.rows > QB_MAXROWS;
   }
   double* ws = ctx->scratch(sizeof(double) * tot);
+  std::vector<TDesc> td;
+  std::vector<hssk_gemm_desc> gG, gVT;
   std::vector<hssk_qr_desc> pd;
   std::vector<QPanel> lp;
   std::vector<hssk_gemm_desc> g1, g2;
   for (int p = 0; p < std::max(pmax, 1); p++) {
-    pd.clear(); lp.clear(); g1.clear(); g2.clear();
+    pd.clear(); lp.clear(); g1.clear(); g2.clear(); td.clear(); gG.clear(); gVT.clear();
     const int j0 = p * QB;
     for (int i = 0; i < count; i++) {
       const hssk_qr_desc& d = descs[i];
@@ -408,6 +456,13 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
       double* W = ws + offW[i];
       double* rdp = ws + offR[i];
       lp.push_back(QPanel{Ap, d.work + j0, Vc, VT, rdp, factor ? d.rdiag : nullptr, d.lda, rr, nb, d.rows, p == 0});
+      if (tall && nb > 0) {
+        double* G = rdp + 2;
+        double* T = G + QB * QB;
+        gG.push_back(hssk_gemm_desc{Vc, Vc, G, nb, nb, rr, d.rows, d.rows, QB, 1, 0, 1.0, 0.0});
+        td.push_back(TDesc{G, d.work + j0, T, nb});
+        gVT.push_back(hssk_gemm_desc{Vc, T, VT, rr, nb, nb, d.rows, QB, d.rows, 0, 0, 1.0, 0.0});
+      }
       if (nb == 0 || !factor) continue;
       pd.push_back(hssk_qr_desc{Ap, d.lda, rr, nb, nullptr, 0, 0, rdp, d.work + j0});
       const int nt = d.cols - (j0 + nb);
@@ -419,11 +474,22 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
     }
     if (!pd.empty()) {
       auto* dp = (const hssk_qr_desc*)ctx->stage(pd.data(), sizeof(hssk_qr_desc) * pd.size());
-      HSSK_LAUNCH((qr_reg_kernel<8, 2, 16>), dim3((unsigned)pd.size()), dim3(1024), 0, ctx->stream, dp);
+      if (tall) HSSK_LAUNCH(qr_kernel, dim3((unsigned)pd.size()), dim3(QR_THREADS), 0, ctx->stream, dp, 0);   // Level-2 on a 32-column panel
+      else HSSK_LAUNCH((qr_reg_kernel<8, 2, 16>), dim3((unsigned)pd.size()), dim3(1024), 0, ctx->stream, dp);
     }
     if (!lp.empty()) {
       auto* dl = (const QPanel*)ctx->stage(lp.data(), sizeof(QPanel) * lp.size());
-      HSSK_LAUNCH(larft_kernel, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+      if (tall) {
+        HSSK_LAUNCH(make_v_kernel, dim3((unsigned)lp.size(), 8), dim3(256), 0, ctx->stream, dl);
+        gemm_batch(ctx, gG);
+        if (!td.empty()) {
+          auto* dt = (const TDesc*)ctx->stage(td.data(), sizeof(TDesc) * td.size());
+          HSSK_LAUNCH(larft_small_kernel, dim3((unsigned)td.size()), dim3(64), 0, ctx->stream, dt);
+        }
+        gemm_batch(ctx, gVT);
+      } else {
+        HSSK_LAUNCH(larft_kernel, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+      }
     }
     gemm_batch(ctx, g1);
     gemm_batch(ctx, g2);
@@ -471,7 +537,7 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
     cmax = std::max(cmax, descs[i].cols);
     qmax = std::max(qmax, descs[i].nq);
   }
-  if (rmax <= QB_MAXROWS && (force_blocked() || rmax > 256 || cmax > 208)) {
+  if (force_blocked() || rmax > 256 || cmax > 208) {
     qr_blocked(ctx, descs, count, true);
     hssk_rt::check_launch();
     return 0;
@@ -509,7 +575,7 @@ extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int
     qmax = std::max(qmax, descs[i].nq);
   }
   if (qmax <= 0) return 0;
-  if (rmax <= QB_MAXROWS && (force_blocked() || rmax > 256)) {
+  if (force_blocked() || rmax > 256) {
     qr_blocked(ctx, descs, count, false);
   } else {
     auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);

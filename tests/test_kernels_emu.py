@@ -70,13 +70,13 @@ def test_qr(hk):
     KC.case_qr(hk, [(195, 128, 128)], seed=9)                       # <4,8,16>
     KC.case_qr(hk, [(195, 160, 195), (130, 100, 130)], seed=10)     # <4,26,8>
     KC.case_qr(hk, [(300, 40, 300), (260, 250, 260), (390, 350, 390), (300, 60, 0), (280, 300, 200)], seed=11)   # blocked (compact WY + batched GEMM)
-    KC.case_qr(hk, [(600, 20, 30)], seed=12)                        # global-memory fallback
+    KC.case_qr(hk, [(600, 20, 30), (700, 90, 100), (530, 70, 0)], seed=12)   # tall blocked path (GEMM-assembled compact WY)
 
 
 def test_formq_from_stored_reflectors(hk):
     KC.case_qr_lazy(hk, [(40, 12, 12), (100, 64, 64), (195, 128, 128)])   # register kernels
     KC.case_qr_lazy(hk, [(300, 70, 70)], seed=18)                          # blocked
-    KC.case_qr_lazy(hk, [(600, 20, 20)], seed=19)                          # global-memory fallback
+    KC.case_qr_lazy(hk, [(600, 20, 20), (640, 70, 70)], seed=19)           # tall blocked path
 
 
 def test_trsm_lu(hk):

@@ -51,7 +51,7 @@ def test_leaf_update(hk):
 def test_formq_from_stored_reflectors(hk):
     KC.case_qr_lazy(hk, [(40, 12, 12), (100, 64, 64), (195, 128, 128)] * 3)
     KC.case_qr_lazy(hk, [(390, 128, 128), (300, 70, 70)] * 2, seed=18)
-    KC.case_qr_lazy(hk, [(600, 20, 20)], seed=19)
+    KC.case_qr_lazy(hk, [(600, 20, 20), (1300, 200, 200)], seed=19)
 
 
 def test_generators(hk):
@@ -73,6 +73,7 @@ def test_id(hk):
 def test_qr(hk):
     KC.case_qr(hk, [(40, 12, 12), (30, 30, 30), (33, 20, 33), (10, 1, 10), (70, 10, 0)])
     KC.case_qr(hk, [(390, 350, 390), (390, 128, 128), (256, 240, 256), (54, 24, 54)] * 2, seed=23)
+    KC.case_qr(hk, [(1400, 600, 1400), (900, 300, 0), (2100, 130, 130)], seed=24)     # tall blocked path
 
 
 def test_trsm_lu(hk):
