@@ -46,6 +46,22 @@ H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
 H1.factor()
 x1 = H1.solve(b)
 say("vs single-process: ranks equal", np.array_equal(H.node_info(), H1.node_info()), "dx %.2e" % (np.linalg.norm(x - x1) / np.linalg.norm(x1)))
+# kernel-matrix front end across the ranks (balanced kd tree -> subtree ownership)
+nk = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+X = np.random.default_rng(3).random((nk, 8))
+ok_o = capi.StructuredMatrix.options(L, rel_tol=1e-2, abs_tol=1e-8, leaf_size=256)
+t1 = time.time()
+Hk, Xp, perm = sdist.from_kernel(L, X, ok_o, kernel="Gauss", h=1.3, lam=3.11, clustering="kdtree", neighbors=64, exchange_cb=ex)
+say("kernel HSS compressed", Hk.is_compressed(), "rank", Hk.rank(), "in %.3f s" % (time.time() - t1))
+Hk.factor()
+yk = np.random.default_rng(4).standard_normal((nk, 1))
+wk = Hk.solve(yk)
+resk = np.linalg.norm(Hk.mult(wk) - yk) / np.linalg.norm(yk)
+Hk1, _, perm1 = sdist.from_kernel(L, X, ok_o, kernel="Gauss", h=1.3, lam=3.11, clustering="kdtree", neighbors=64)
+Hk1.factor()
+wk1 = Hk1.solve(yk)
+say("kernel vs single-process: ranks equal", np.array_equal(Hk.node_info(), Hk1.node_info()), "perm equal", np.array_equal(perm, perm1),
+    "dw %.2e" % (np.linalg.norm(wk - wk1) / np.linalg.norm(wk1)), "residual %.2e" % resk)
 dist.barrier()
-say("DIST_SMOKE_OK" if res < 1e-12 else "DIST_SMOKE_FAIL")
+say("DIST_SMOKE_OK" if res < 1e-12 and resk < 1e-10 else "DIST_SMOKE_FAIL")
 dist.destroy_process_group()
