@@ -78,7 +78,9 @@ def make_exchange(lib, world, rank):
             full = _tensor(dbuf, n * world, on_dev)
         mine = full[rank * n:(rank + 1) * n]
         if on_dev and dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(full, mine)   # RCCL, in place
+            # RCCL all-gather straight into the engine's buffer; the send block is a private copy (a few KB) so that
+            # input and output never alias, whatever the backend's in-place rules are
+            dist.all_gather_into_tensor(full, mine.clone())
             torch.cuda.synchronize()
         else:  # gloo (CPU tests, or several ranks sharing one GPU): list form through host memory
             src = mine.cpu() if on_dev else mine.clone()
