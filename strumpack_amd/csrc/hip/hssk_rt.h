@@ -19,6 +19,8 @@ typedef hipStream_t stream_t;
 typedef hipEvent_t event_t;
 inline void* dev_malloc(size_t bytes) { void* p = nullptr; if (bytes) HSSK_CHECK(hipMalloc(&p, bytes)); return p; }
 inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+// hipHostMalloc'ed memory is mapped into the device address space at the same address (unified addressing)
+inline bool pinned_is_device_visible() { return true; }
 inline void* pinned_malloc(size_t bytes) { void* p = nullptr; if (bytes) HSSK_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); return p; }
 inline void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 inline void h2d(void* d, const void* h, size_t bytes, stream_t s) { if (bytes) HSSK_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s)); }

@@ -1,6 +1,8 @@
 // Context, error state and memory helpers of the hssk C-ABI (include/hssk.h).
 #include "hssk_internal.h"
 
+#include <cstdlib>
+
 #include <mutex>
 #include <vector>
 
@@ -35,6 +37,8 @@ int hssk_ctx_create(hssk_ctx** out, int device) {
   c->stream = hssk_rt::stream_create();
   c->ring_bytes = size_t(64) << 20;
   c->h_ring = (char*)hssk_rt::pinned_malloc(c->ring_bytes);
+  c->zero_copy_bytes = hssk_rt::pinned_is_device_visible() ? 65536 : 0;   // measured: tree+factor+solve 13.3 -> 11.7 ms at N = 1e5
+  if (const char* e = std::getenv("HSSK_ZERO_COPY_BYTES")) c->zero_copy_bytes = (size_t)std::atoll(e);
   c->d_ring = (char*)hssk_rt::dev_malloc(c->ring_bytes);
   c->ev0 = hssk_rt::event_create();
   c->ev1 = hssk_rt::event_create();

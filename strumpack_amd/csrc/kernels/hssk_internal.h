@@ -14,6 +14,7 @@ struct hssk_ctx {
   char* h_ring = nullptr;
   char* d_ring = nullptr;
   size_t ring_bytes = 0, ring_off = 0;
+  size_t zero_copy_bytes = 0;   // descriptor arrays up to this size are read in place from the pinned ring
   hssk_rt::event_t ev0{}, ev1{};
   bool dgemm_timed = false;
   double dgemm_timed_flops = 0.;  // algorithmic flops of the launch bracketed by ev0 / ev1
@@ -32,8 +33,15 @@ struct hssk_ctx {
       ring_off = 0;
     }
     std::memcpy(h_ring + ring_off, host, bytes);
-    hssk_rt::h2d(d_ring + ring_off, h_ring + ring_off, bytes, stream);
-    void* d = d_ring + ring_off;
+    void* d;
+    if (bytes <= zero_copy_bytes) {
+      // small descriptor arrays are read by the kernel straight from the pinned host ring (it is mapped into the
+      // device address space): no copy kernel, no extra launch on the critical path of the latency-bound tree levels
+      d = h_ring + ring_off;
+    } else {
+      hssk_rt::h2d(d_ring + ring_off, h_ring + ring_off, bytes, stream);
+      d = d_ring + ring_off;
+    }
     ring_off += need;
     return d;
   }

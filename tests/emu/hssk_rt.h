@@ -12,6 +12,7 @@ typedef void* stream_t;
 typedef double* event_t;
 inline void* dev_malloc(size_t bytes) { return bytes ? std::malloc(bytes) : nullptr; }
 inline void dev_free(void* p) { std::free(p); }
+inline bool pinned_is_device_visible() { return true; }
 inline void* pinned_malloc(size_t bytes) { return bytes ? std::malloc(bytes) : nullptr; }
 inline void pinned_free(void* p) { std::free(p); }
 inline void h2d(void* d, const void* h, size_t bytes, stream_t) { if (bytes) std::memcpy(d, h, bytes); }
