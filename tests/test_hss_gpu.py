@@ -95,10 +95,13 @@ def test_rccl_exchange_hook_single_rank():
         hk = K.Hssk(_loader.lib_path())
         ld, cols = 16, 50
         a = np.arange(ld * cols, dtype=np.float64).reshape(ld, cols, order="F")
-        dS, dT = hk.array(a), hk.array(2 * a)
+        dS = hk.array(a)
         ex = sdist.make_exchange(L, 1, 0)
-        ex(None, dS.ptr, dT.ptr, ld, cols)
-        assert np.array_equal(dS.get(), a) and np.array_equal(dT.get(), 2 * a)
+        ex(None, dS.ptr, 8 * ld * cols)          # SPXAllGatherFn(user, device buffer, bytes per rank)
+        assert np.array_equal(dS.get(), a)
+        di = hk.array(np.arange(7, dtype=np.int32))
+        ex(None, di.ptr, 4 * 7)                  # int payload of odd length: 4-byte view
+        assert np.array_equal(di.get(), np.arange(7, dtype=np.int32))
         # and the sharded constructor itself with world = 1
         n = 512
         dA = hk.empty((n, n))
