@@ -281,7 +281,7 @@ void ref_kernel_regression(int n, int d, const double* train, const double* labe
 int ref_clustering(int n, int d, double* data_inout, int algo, int leaf, int* perm_out, int* leaf_sizes, int cap) {
   DenseMatrix<double> p(d, n, data_inout, d);
   std::vector<int> perm;
-  auto t = binary_tree_clustering(algo == 0 ? ClusteringAlgorithm::NATURAL : (algo == 2 ? ClusteringAlgorithm::KD_TREE : (algo == 4 ? ClusteringAlgorithm::COBBLE : ClusteringAlgorithm::TWO_MEANS)), p, perm, leaf);
+  auto t = binary_tree_clustering(algo == 0 ? ClusteringAlgorithm::NATURAL : (algo == 2 ? ClusteringAlgorithm::KD_TREE : (algo == 4 ? ClusteringAlgorithm::COBBLE : (algo == 3 ? ClusteringAlgorithm::PCA : ClusteringAlgorithm::TWO_MEANS))), p, perm, leaf);
   std::memcpy(data_inout, p.data(), sizeof(double) * d * n);
   for (int i = 0; i < n; i++) perm_out[i] = perm[i];
   auto ls = t.template leaf_sizes<int>();

@@ -154,6 +154,63 @@ inline void label_cobble(const Points& p, std::vector<int>& label, int nc[2]) {
   for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
 }
 
+// median split along the principal direction of the (uncentred) second-moment matrix p p^T, as the reference does
+// (PCAPartitioning.cpp:36-95; it takes the eigenvector from LAPACK syevx, whose sign is implementation-defined --
+// here: cyclic Jacobi on the d x d matrix, eigenvector normalised so that its largest component is positive; the
+// tree is the reference's up to mirroring of a split)
+inline void label_pca(const Points& p, std::vector<int>& label, int nc[2]) {
+  const int n = p.n, d = p.d;
+  std::vector<double> A((size_t)d * d, 0.), V((size_t)d * d, 0.);
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < d; a++)
+      for (int b = 0; b <= a; b++) A[a + (size_t)b * d] += p.pt(i)[a] * p.pt(i)[b];
+  for (int a = 0; a < d; a++) {
+    V[a + (size_t)a * d] = 1.;
+    for (int b = 0; b < a; b++) A[b + (size_t)a * d] = A[a + (size_t)b * d];
+  }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.;
+    for (int a = 0; a < d; a++)
+      for (int b = 0; b < a; b++) off += A[a + (size_t)b * d] * A[a + (size_t)b * d];
+    if (off < 1e-30) break;
+    for (int q = 1; q < d; q++)
+      for (int r = 0; r < q; r++) {
+        const double apq = A[r + (size_t)q * d];
+        if (apq == 0.) continue;
+        const double theta = (A[q + (size_t)q * d] - A[r + (size_t)r * d]) / (2. * apq);
+        const double t = (theta >= 0. ? 1. : -1.) / (std::fabs(theta) + std::sqrt(theta * theta + 1.));
+        const double c = 1. / std::sqrt(t * t + 1.), sn = t * c;
+        for (int k = 0; k < d; k++) {   // A <- A J, V <- V J
+          const double akr = A[k + (size_t)r * d], akq = A[k + (size_t)q * d];
+          A[k + (size_t)r * d] = c * akr - sn * akq; A[k + (size_t)q * d] = sn * akr + c * akq;
+          const double vkr = V[k + (size_t)r * d], vkq = V[k + (size_t)q * d];
+          V[k + (size_t)r * d] = c * vkr - sn * vkq; V[k + (size_t)q * d] = sn * vkr + c * vkq;
+        }
+        for (int k = 0; k < d; k++) {   // A <- J^T A
+          const double ark = A[r + (size_t)k * d], aqk = A[q + (size_t)k * d];
+          A[r + (size_t)k * d] = c * ark - sn * aqk; A[q + (size_t)k * d] = sn * ark + c * aqk;
+        }
+      }
+  }
+  int top = 0;
+  for (int a = 1; a < d; a++)
+    if (A[a + (size_t)a * d] > A[top + (size_t)top * d]) top = a;
+  std::vector<double> z(V.begin() + (size_t)top * d, V.begin() + (size_t)(top + 1) * d);
+  int big = 0;
+  for (int a = 1; a < d; a++)
+    if (std::fabs(z[a]) > std::fabs(z[big])) big = a;
+  if (z[big] < 0.) for (auto& v : z) v = -v;
+  std::vector<double> x(n, 0.);
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < d; a++) x[i] += p.pt(i)[a] * z[a];
+  std::vector<std::size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(), [&](const std::size_t& a, const std::size_t& b) { return x[a] < x[b]; });
+  nc[0] = n / 2; nc[1] = n - n / 2;
+  label.assign(n, 0);
+  for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
+}
+
 using labeller_t = std::function<void(const Points&, std::vector<int>&, int*)>;
 
 inline structured::ClusterTree recurse(const Points& p, int cluster_size, int* perm, const labeller_t& lab) {
@@ -189,8 +246,7 @@ inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, 
       return t;
     }
     case ClusteringAlgorithm::PCA:
-      std::cerr << "WARNING: PCA clustering is not available in this build, using recursive 2 means." << std::endl;
-      // fall through
+      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_pca);
     case ClusteringAlgorithm::TWO_MEANS: {
       std::mt19937 gen(1);  // reproducible, as in the reference
       return cd::recurse(pts, (int)cluster_size, perm.data(),

@@ -43,7 +43,7 @@ out, arrays = {}, {}
 
 # ---- clustering: permutation and leaf sizes per algorithm (full 10K set, leaf 512, and a 1000-point subset, leaf 64)
 for tag, X, leaf in (("full", train, 512), ("sub1000", train[:1000], 64)):
-    for algo, name in ((1, "2means"), (2, "kdtree"), (4, "cobble"), (0, "natural")):
+    for algo, name in ((1, "2means"), (2, "kdtree"), (4, "cobble"), (0, "natural"), (3, "pca")):
         a = np.ascontiguousarray(X).copy()
         n, d = a.shape
         perm = np.zeros(n, np.int32)
