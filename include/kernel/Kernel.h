@@ -41,6 +41,9 @@ int SPX_kernel_weights(STRUMPACKKernel K, double* w);
  * 3 pca, 4 cobble; data (d x n) is reordered in place, perm is 1-based; returns the number of leaves and writes
  * at most cap leaf sizes */
 int SPX_clustering(int n, int d, double* data, int algo, int leaf_size, int* perm, int* leaf_sizes, int cap);
+/* find_approximate_neighbors on its own (clustering/NeighborSearch.cpp:324-345, host): ann / scores are k x n, column i =
+ * the neighbours of point i, nearest first, the point itself included; scores (squared distances) may be NULL */
+int SPX_approximate_neighbors(int n, int d, const double* data, int iterations, int k, int* ann, double* scores);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,11 @@
+#include <atomic>
+#include <thread>
+#include <functional>
 #include <chrono>
 
 #include "HSSMatrix.hpp"
 #include "Kernel.hpp"
+#include "NeighborSearch.hpp"
 
 #include <sstream>
 
@@ -61,6 +65,23 @@ void HSSMatrix<double>::compress_with_neighbors(const kernel::Kernel<double>& K,
   DeviceHSS::KernelSpec ks;
   ks.X = K.data().data(); ks.d = int(K.d()); ks.type = K.device_type(); ks.p = K.degree();
   ks.h = K.width(); ks.lambda = K.lambda(); ks.ann = std::min<int>(int(K.n()), opts.approximate_neighbors());
+  if (opts.neighbor_search() == NeighborSearch::ANN) {
+    const double* X = K.data().data();
+    const std::size_t dim = K.d(), n = K.n(), iters = opts.ann_iterations();
+    ks.neighbors = [X, dim, n, iters](int kk, int* out) {
+      // leaves of a tree sample are independent: brute-force them on the host's threads
+      auto parfor = [](std::size_t cnt, const std::function<void(std::size_t)>& f) {
+        const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        std::atomic<std::size_t> next{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < std::min<std::size_t>(nt, cnt); t++)
+          th.emplace_back([&] { for (std::size_t i = next++; i < cnt; i = next++) f(i); });
+        for (auto& t : th) t.join();
+      };
+      auto L = ann_detail::search(X, dim, n, iters, (std::size_t)kk, parfor);
+      for (std::size_t i = 0; i < L.id.size(); i++) out[i] = (int)L.id[i];
+    };
+  }
   eng_->compress_kernel(ks, ann, k);
 }
 

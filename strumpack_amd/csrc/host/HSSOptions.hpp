@@ -28,6 +28,11 @@ inline std::string get_name(CompressionAlgorithm a) {
   return "unknown";
 }
 
+// neighbour search of the kernel-matrix compression (extension): EXACT = all-pairs k nearest neighbours on the device
+// (default), ANN = the reference's randomized projection-tree search on the host (identical lists, hence an HSS
+// matrix identical to the reference's)
+enum class NeighborSearch { EXACT, ANN };
+
 template <typename real_t> inline real_t default_HSS_rel_tol() { return real_t(1e-2); }
 template <typename real_t> inline real_t default_HSS_abs_tol() { return real_t(1e-8); }
 
@@ -54,6 +59,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   void set_clustering_algorithm(ClusteringAlgorithm a) { clustering_algorithm_ = a; }
   void set_approximate_neighbors(int neighbors) { approximate_neighbors_ = neighbors; }
   void set_ann_iterations(int iters) { assert(iters > 0); ann_iterations_ = iters; }
+  void set_neighbor_search(NeighborSearch s) { neighbor_search_ = s; }
   int d0() const { return d0_; }
   int dd() const { return dd_; }
   int p() const { return p_; }
@@ -67,6 +73,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   ClusteringAlgorithm clustering_algorithm() const { return clustering_algorithm_; }
   int approximate_neighbors() const { return approximate_neighbors_; }
   int ann_iterations() const { return ann_iterations_; }
+  NeighborSearch neighbor_search() const { return neighbor_search_; }
 
   void set_from_command_line(int argc, const char* const* argv) override {
     using structured::detail::match_flag;
@@ -103,6 +110,11 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
       else if (match_flag(argc, argv, i, "hss_clustering_algorithm", v, true)) set_clustering_algorithm(get_clustering_algorithm(v));
       else if (match_flag(argc, argv, i, "hss_approximate_neighbors", v, true)) set_approximate_neighbors(std::atoi(v.c_str()));
       else if (match_flag(argc, argv, i, "hss_ann_iterations", v, true)) set_ann_iterations(std::atoi(v.c_str()));
+      else if (match_flag(argc, argv, i, "hss_neighbor_search", v, true)) {
+        if (v == "exact") set_neighbor_search(NeighborSearch::EXACT);
+        else if (v == "ann") set_neighbor_search(NeighborSearch::ANN);
+        else std::cerr << "# WARNING: neighbour search not recognized, use 'exact' or 'ann'" << std::endl;
+      }
       else if (match_flag(argc, argv, i, "hss_verbose", v, false) || std::string(argv[i]) == "-v") this->set_verbose(true);
       else if (match_flag(argc, argv, i, "hss_quiet", v, false) || std::string(argv[i]) == "-q") this->set_verbose(false);
     }
@@ -114,7 +126,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
               << ")\n#   --hss_random_distribution normal|uniform\n#   --hss_random_engine linear|mersenne|philox\n"
               << "#   --hss_compression_algorithm original|stable|hard_restart\n#   --hss_compression_sketch Gaussian\n"
               << "#   --hss_clustering_algorithm natural|2means|kdtree|pca|cobble (default " << get_name(clustering_algorithm()) << ")\n#   --hss_approximate_neighbors int (default " << approximate_neighbors()
-              << ")\n#   --hss_ann_iterations int (default " << ann_iterations() << ")\n"
+              << ")\n#   --hss_ann_iterations int (default " << ann_iterations() << ")\n#   --hss_neighbor_search exact|ann (default exact: all pairs on the device)\n"
               << "#   --hss_user_defined_random  --hss_enable_sync  --hss_disable_sync  --hss_log_ranks\n#   --hss_verbose or -v   --hss_quiet or -q" << std::endl;
   }
 
@@ -133,6 +145,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   bool user_defined_random_ = false, sync_ = false, log_ranks_ = false;
   ClusteringAlgorithm clustering_algorithm_ = ClusteringAlgorithm::TWO_MEANS;
   int approximate_neighbors_ = 64, ann_iterations_ = 5;
+  NeighborSearch neighbor_search_ = NeighborSearch::EXACT;
 };
 
 }  // namespace HSS

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "HSSMatrix.hpp"
+#include "NeighborSearch.hpp"
 #include "hssk.h"
 #include "kernel/Kernel.h"
 
@@ -149,6 +150,16 @@ void STRUMPACK_kernel_predict_double(STRUMPACKKernel K, int m, double* test, dou
     auto pred = kr->K->predict(t, kr->weights);
     std::copy(pred.begin(), pred.end(), prediction);
   } catch (const std::exception& e) { report(e); }
+}
+int SPX_approximate_neighbors(int n, int d, const double* data, int iterations, int k, int* ann, double* scores) {
+  try {
+    DenseMatrix<double> p(d, n, data, d);
+    DenseMatrix<std::uint32_t> nb;
+    DenseMatrix<double> sc;
+    find_approximate_neighbors(p, iterations, k, nb, sc);
+    for (size_t i = 0; i < (size_t)k * n; i++) { ann[i] = (int)nb.data()[i]; if (scores) scores[i] = sc.data()[i]; }
+    return 0;
+  } catch (const std::exception& e) { report(e); return 1; }
 }
 int SPX_kernel_set_neighbors(STRUMPACKKernel K, int k, const int* ann) {
   auto kr = static_cast<KernelRegression*>(K);

@@ -1126,6 +1126,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     double tk0 = now();
     std::vector<int> ann((size_t)k * N);
     if (user_ann && k == user_k) std::copy(user_ann, user_ann + (size_t)k * N, ann.begin());
+    else if (ks.neighbors) ks.neighbors(k, ann.data());
     else {
       // one process per GPU: neighbours of this rank's own points only (its subtree's leaves are all that read them)
       int q0 = 0, q1 = N;

@@ -68,7 +68,14 @@ class DeviceHSS {
   void compress_callbacks(const host_mult_t& mult, const host_elem_t& elem);  // matrix-free
   // kernel matrix over points X (host, d x n, already in tree order); user_ann (k x n, optional) replaces the
   // device nearest-neighbour search of the first round (tests pin the compression against the reference's lists)
-  struct KernelSpec { const double* X = nullptr; int d = 0, type = 0, p = 1, ann = 64; double h = 1., lambda = 0.; };
+  struct KernelSpec {
+    const double* X = nullptr;
+    int d = 0, type = 0, p = 1, ann = 64;
+    double h = 1., lambda = 0.;
+    // optional host neighbour search: fills ann (k x n, ids in cluster order, -1 = none) for the given k; replaces
+    // hssk_knn in every round (the reference's randomized search, see NeighborSearch.hpp)
+    std::function<void(int k, int* ann)> neighbors;
+  };
   void compress_kernel(const KernelSpec& ks, const int* user_ann = nullptr, int user_k = 0);
 
   // ---- operations; x/b/y are column-major, host or device (on_device) ----

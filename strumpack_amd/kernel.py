@@ -8,7 +8,7 @@ import numpy as np
 KERNEL_SYMBOLS = [
     "STRUMPACK_create_kernel_double", "STRUMPACK_destroy_kernel_double", "STRUMPACK_kernel_fit_HSS_double",
     "STRUMPACK_kernel_predict_double", "SPX_kernel_fit_info", "SPX_kernel_permutation", "SPX_kernel_weights",
-    "SPX_clustering", "SPX_kernel_node_info", "SPX_kernel_set_neighbors",
+    "SPX_clustering", "SPX_kernel_node_info", "SPX_kernel_set_neighbors", "SPX_approximate_neighbors",
 ]
 KERNEL_TYPES = {"Gauss": 0, "rbf": 0, "Laplace": 1, "ANOVA": 2}
 CLUSTERING = {"natural": 0, "2means": 1, "kdtree": 2, "pca": 3, "cobble": 4}
@@ -28,6 +28,7 @@ def load(path):
     L.SPX_kernel_weights.argtypes = [vp, vp]
     L.SPX_kernel_node_info.argtypes = [vp, vp, C.c_int]
     L.SPX_kernel_set_neighbors.argtypes = [vp, C.c_int, vp]
+    L.SPX_approximate_neighbors.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     L.SPX_clustering.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int]
     return L
 
@@ -108,3 +109,13 @@ def clustering(lib, X, algo="2means", leaf_size=512):
     if c < 0:
         raise RuntimeError("SPX_clustering failed")
     return X, perm, ls[:c].copy()
+
+
+def approximate_neighbors(lib, X, k, iterations=5):
+    """find_approximate_neighbors (the reference's randomized projection-tree search, host): returns ids (n x k)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    out = np.zeros((n, k), dtype=np.int32)
+    if lib.SPX_approximate_neighbors(n, d, X.ctypes.data, iterations, k, out.ctypes.data, None):
+        raise RuntimeError("SPX_approximate_neighbors failed")
+    return out

@@ -42,6 +42,18 @@ def test_pca_clustering_matches_reference_up_to_mirroring(lib):
         assert np.array_equal(Xp, pts[perm - 1])
 
 
+@pytest.mark.parametrize("tag", ["gauss_1500", "gauss_10k"])
+def test_approximate_neighbors_match_reference(lib, tag):
+    """The host restatement of the reference's randomized neighbour search (NeighborSearch.hpp) returns the reference's
+    lists (same mt19937 stream, same sort calls); ties in a projection may differ by the rounding of a BLAS dot."""
+    J, Z = KG.golden()
+    g = J["regression_" + tag]
+    X = KG.susy()[0][:g["n"]][Z["perm_" + tag] - 1]
+    ref = Z["ann_" + tag]
+    got = KM.approximate_neighbors(lib, X, ref.shape[1])
+    assert (got == ref).mean() > 0.999, (got == ref).mean()
+
+
 @pytest.mark.parametrize("tag", ["gauss_400", "laplace_400", "anova_400"])
 def test_oracle_kernel_compression_matches_reference(tag):
     """numpy restatement of compress_recursive_ann with the reference's neighbour lists == the reference's ranks."""
