@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void kernel_eval_anova_kernel(hssk_kernel_spec
 // page q holds the KNN_P smallest keys (distance, index) above the largest key of page q-1.
 // ---------------------------------------------------------------------------------------------
 constexpr int KNN_P = 64;    // neighbours per page
-constexpr int KNN_Q = 64;    // queries per workgroup (one wave)
+
 constexpr int KNN_C = 64;    // candidates per LDS tile
 constexpr int KNN_DMAX = 64; // largest point dimension
 
@@ -121,21 +121,23 @@ constexpr int KNN_DMAX = 64; // largest point dimension
 // registers, the candidate tile in LDS as [candidate][coordinate] so that a wave reads one candidate's coordinates
 // as broadcast 16-byte loads; four candidates are evaluated per trip to keep several loads in flight, the
 // (rare) insertion into the LDS-resident page of the KNN_P best keys happens afterwards.
-template <int DM>
-__global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
+// Q queries per workgroup: Q / 64 waves share one candidate tile and -- unlike single-wave workgroups, which the
+// dispatcher packed onto one SIMD of a CU -- spread over the CU's four SIMDs.
+template <int DM, int Q>
+__global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
                                                     const float* __restrict__ lb_key, const int* __restrict__ lb_idx,
                                                     int* __restrict__ out_idx, int ldo, float* __restrict__ ub_key,
                                                     int* __restrict__ ub_idx) {
-  HSSK_SHARED float hk[KNN_P * KNN_Q];
-  HSSK_SHARED int hi[KNN_P * KNN_Q];
+  HSSK_SHARED float hk[KNN_P * Q];
+  HSSK_SHARED int hi[KNN_P * Q];
   HSSK_SHARED double xc[KNN_C * DM];
   const int tid = threadIdx.x;
-  const int q = q0 + blockIdx.x * KNN_Q + tid;
+  const int q = q0 + blockIdx.x * Q + tid;
   const bool live = q < q1;
   double xq[DM];
 #pragma unroll
   for (int j = 0; j < DM; j++) xq[j] = (live && j < d) ? X[(size_t)q * d + j] : 0.;
-  for (int s = 0; s < kpage; s++) { hk[s * KNN_Q + tid] = 3.0e38f; hi[s * KNN_Q + tid] = 0x7fffffff; }
+  for (int s = 0; s < kpage; s++) { hk[s * Q + tid] = 3.0e38f; hi[s * Q + tid] = 0x7fffffff; }
   const float lbk = lb_key ? (live ? lb_key[q] : 0.f) : -1.f;
   const int lbi = lb_idx ? (live ? lb_idx[q] : 0) : -1;
   // the page is a binary max-heap on (key, id) in this lane's LDS column: the root is the worst kept key, an
@@ -152,33 +154,48 @@ __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X
       for (;;) {
         const int l = 2 * pos + 1, r = l + 1;
         if (l >= kpage) break;
-        float kc = hk[l * KNN_Q + tid];
-        int ic = hi[l * KNN_Q + tid], c = l;
+        float kc = hk[l * Q + tid];
+        int ic = hi[l * Q + tid], c = l;
         if (r < kpage) {
-          const float kr = hk[r * KNN_Q + tid];
-          const int ir = hi[r * KNN_Q + tid];
+          const float kr = hk[r * Q + tid];
+          const int ir = hi[r * Q + tid];
           if (greater(kr, ir, kc, ic)) { kc = kr; ic = ir; c = r; }
         }
         if (!greater(kc, ic, key, g)) break;
-        hk[pos * KNN_Q + tid] = kc;
-        hi[pos * KNN_Q + tid] = ic;
+        hk[pos * Q + tid] = kc;
+        hi[pos * Q + tid] = ic;
         pos = c;
       }
-      hk[pos * KNN_Q + tid] = key;
-      hi[pos * KNN_Q + tid] = g;
+      hk[pos * Q + tid] = key;
+      hi[pos * Q + tid] = g;
       worst = hk[tid];
       worst_i = hi[tid];
     }
   };
   // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
   // spatial neighbours, the page threshold tightens at once and later tiles rarely insert (same result set)
-  const int ntile = (n + KNN_C - 1) / KNN_C, own = (q0 + blockIdx.x * KNN_Q) / KNN_C;
+  const int ntile = (n + KNN_C - 1) / KNN_C, own = (q0 + blockIdx.x * Q) / KNN_C;
   for (int t = 0; t < ntile; t++) {
-    const int c0 = ((own + t) % ntile) * KNN_C;
+    // own, own+1, own-1, own+2, own-2, ...: in cluster order index distance tracks spatial distance
+    const int off = (t + 1) >> 1;
+    const int c0 = (((t & 1) ? own + off : own - off + ntile) % ntile) * KNN_C;
     __syncthreads();
-    for (int e = tid; e < KNN_C * DM; e += KNN_Q) {
-      const int pt = e / DM, j = e % DM;
-      xc[e] = (c0 + pt < n && j < d) ? X[(size_t)(c0 + pt) * d + j] : 0.;
+    // tile load: DM independent loads per lane, all in flight together (clamped address + select instead of a
+    // branch per element, which would serialise the round trips)
+    {
+      constexpr int NL = (KNN_C * DM + Q - 1) / Q;
+      double v[NL];
+#pragma unroll
+      for (int r = 0; r < NL; r++) {
+        const int e = tid + Q * r, pt = e / DM, j = e % DM;
+        const int gp = min(c0 + pt, n - 1), gj = min(j, d - 1);
+        v[r] = hssk_gload(X, (size_t)gp * d + gj);
+      }
+#pragma unroll
+      for (int r = 0; r < NL; r++) {
+        const int e = tid + Q * r, pt = e / DM, j = e % DM;
+        if (e < KNN_C * DM) xc[e] = (c0 + pt < n && j < d) ? v[r] : 0.;
+      }
     }
     __syncthreads();
     for (int c = 0; c < KNN_C; c += 4) {
@@ -190,13 +207,28 @@ __global__ __launch_bounds__(KNN_Q) void knn_kernel(const double* __restrict__ X
           const double df = xq[j] - xc[(c + u) * DM + j];
           s2[u] += df * df;
         }
+      // branch-free acceptance test for the four candidates, ONE branch per trip into the (rare) insertion path:
+      // taken branches cost an instruction-buffer refill each, which dominated this loop
+      float key[4];
+      bool pass[4], any = false;
 #pragma unroll
-      for (int u = 0; u < 4; u++) consider((float)s2[u], c0 + c + u);
+      for (int u = 0; u < 4; u++) {
+        key[u] = (float)s2[u];
+        const int g = c0 + c + u;
+        pass[u] = live & (g != q) & (g < n) & ((key[u] > lbk) | ((key[u] == lbk) & (g > lbi))) &
+                  ((key[u] < worst) | ((key[u] == worst) & (g < worst_i)));
+        any |= pass[u];
+      }
+      if (any) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (pass[u]) consider(key[u], c0 + c + u);
+      }
     }
   }
   if (!live) return;
   for (int s = 0; s < kpage; s++) {
-    const int g = hi[s * KNN_Q + tid];
+    const int g = hi[s * Q + tid];
     out_idx[(size_t)q * ldo + s] = g == 0x7fffffff ? -1 : g;
   }
   if (ub_key) { ub_key[q] = worst; ub_idx[q] = worst_i; }
@@ -291,7 +323,7 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
   // page bounds (float key + index per query), ping-pong
   float* kb = (float*)ctx->scratch(sizeof(float) * 4 * (size_t)n + 64);
   int* ib = (int*)(kb + 2 * (size_t)n);
-  const unsigned grid = (unsigned)((q1 - q0 + KNN_Q - 1) / KNN_Q);
+
   for (int pg = 0; pg < pages; pg++) {
     const int kp = std::min(KNN_P, k - pg * KNN_P);
     const float* lk = pg ? kb + (size_t)((pg - 1) & 1) * n : nullptr;
@@ -299,10 +331,10 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
     float* uk = kb + (size_t)(pg & 1) * n;
     int* ui = ib + (size_t)(pg & 1) * n;
     int* oi = out_idx + pg * KNN_P;
-    if (d <= 8) HSSK_LAUNCH((knn_kernel<8>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
-    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
-    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
-    else HSSK_LAUNCH((knn_kernel<64>), dim3(grid), dim3(KNN_Q), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    else HSSK_LAUNCH((knn_kernel<64, 128>), dim3((unsigned)((q1 - q0 + 128 - 1) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
   }
   hssk_rt::check_launch();
   HSSK_API_END
