@@ -999,17 +999,24 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
       std::vector<Piece>& pc = pieces[k];
       if (pc.size() <= 1) continue;
       const int m = ms[k];
+      // fan-in: as many triangles as fit the register QR (256 rows) for narrow panels, pairs otherwise
+      const size_t fan = m <= 128 ? std::max<size_t>(2, 256 / std::max(m, 1)) : 2;
       std::vector<Piece> next;
-      for (size_t i = 0; i + 1 < pc.size(); i += 2) {
-        const int rows = pc[i].rows + pc[i + 1].rows;
+      for (size_t i = 0; i < pc.size(); i += fan) {
+        const size_t cntp = std::min(fan, pc.size() - i);
+        if (cntp == 1) { next.push_back(pc[i]); continue; }
+        int rows = 0;
+        for (size_t t = 0; t < cntp; t++) rows += pc[i + t].rows;
         double* dst = tmp.dbl((size_t)rows * m);
-        cp.push_back(hssk_triu_desc{pc[i].p, dst, pc[i].rows, m, pc[i].ld, rows});
-        cp.push_back(hssk_triu_desc{pc[i + 1].p, dst + pc[i].rows, pc[i + 1].rows, m, pc[i + 1].ld, rows});
+        int r0 = 0;
+        for (size_t t = 0; t < cntp; t++) {
+          cp.push_back(hssk_triu_desc{pc[i + t].p, dst + r0, pc[i + t].rows, m, pc[i + t].ld, rows});
+          r0 += pc[i + t].rows;
+        }
         double* wk = tmp.dbl((size_t)rows + m);
         qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk});
         next.push_back(Piece{dst, rows, std::min(rows, m)});
       }
-      if (pc.size() % 2) next.push_back(pc.back());
       pc.swap(next);
       more = more || pc.size() > 1;
     }
