@@ -18,6 +18,9 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <stdexcept>
+#include <vector>
 
 namespace {
 
@@ -409,6 +412,196 @@ bool launch_id_reg_ct(hssk_ctx* ctx, const hssk_id_desc* dd, int count, int mmax
   return true;
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// Wide variant for a few LARGE panels (kernel matrices with ranks in the hundreds: m up to a few thousand): the
+// same Level-2 truncated QRCP, but every Householder step of the whole batch is two launches -- idw_pivot_kernel
+// (one workgroup per matrix: pivot search, column swap, reflector, stopping test) and idw_update_kernel (MANY
+// workgroups per matrix: each wave applies the reflector to one trailing column and down-dates its norm) -- so the
+// trailing update, which is all the work, runs on the whole chip instead of one CU per matrix.  The step index is a
+// kernel argument; per-matrix state (stop flag, rank, tau, |R_00|) lives in device memory; X = R11^{-1} R12 is one
+// batched triangular solve at the end.
+// ------------------------------------------------------------------------------------------------
+struct IdwState {
+  int stop, rank;
+  double tau, r00;
+};
+constexpr int IDW_COLS = 16;   // trailing columns per workgroup of the update kernel (4 waves x 4)
+
+__global__ __launch_bounds__(256) void idw_init_kernel(const hssk_id_desc* __restrict__ descs, IdwState* __restrict__ st) {
+  const hssk_id_desc p = descs[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && tid == 0) {
+    const int kmax = p.d < p.m ? p.d : p.m;
+    st[blockIdx.y] = IdwState{kmax == 0 ? 1 : 0, kmax, 0., 0.};
+  }
+  for (int j = blockIdx.x * 4 + wave; j < p.m; j += gridDim.x * 4) {
+    double s = 0.;
+    for (int i = lane; i < p.d; i += 64) { const double v = hssk_gload(p.W, i + (size_t)j * p.ldw); s += v * v; }
+    s = hssk_wave_sum(s);
+    if (lane == 0) { p.work[j] = sqrt(s); p.work[p.m + j] = sqrt(s); p.perm[j] = j; }
+  }
+}
+
+__global__ __launch_bounds__(256) void idw_pivot_kernel(const hssk_id_desc* __restrict__ descs, IdwState* __restrict__ st, int k) {
+  HSSK_SHARED double s_val[4];
+  HSSK_SHARED int s_idx[4];
+  HSSK_SHARED int s_piv;
+  const hssk_id_desc p = descs[blockIdx.x];
+  IdwState* me = st + blockIdx.x;
+  const int kmax = p.d < p.m ? p.d : p.m;
+  if (me->stop || k >= kmax) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = p.d, m = p.m, ld = p.ldw;
+  double* vn1 = p.work;
+  double* vn2 = p.work + m;
+  double bv = -1.;
+  int bi = 0x7fffffff;
+  for (int j = k + tid; j < m; j += 256) {
+    const double v = vn1[j];
+    if (v > bv) { bv = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = hssk_shfl_xor(bv, o);
+    const int oi = hssk_shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    double v = s_val[0];
+    int ix = s_idx[0];
+    for (int w = 1; w < 4; w++)
+      if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
+    s_piv = ix;
+    if (ix != k) {
+      const int t = p.perm[k]; p.perm[k] = p.perm[ix]; p.perm[ix] = t;
+      vn1[ix] = vn1[k]; vn2[ix] = vn2[k];
+    }
+  }
+  __syncthreads();
+  const int pv = s_piv;
+  double* ck = p.W + (size_t)k * ld;
+  if (pv != k) {
+    double* cp = p.W + (size_t)pv * ld;
+    for (int i = tid; i < d; i += 256) { const double a = ck[i], b = cp[i]; ck[i] = b; cp[i] = a; }
+  }
+  __syncthreads();
+  // reflector of W[k:d, k]
+  HSSK_SHARED double s_part[4];
+  double s = 0.;
+  for (int i = k + 1 + tid; i < d; i += 256) { const double v = ck[i]; s += v * v; }
+  const double alpha = ck[k];   // read by everybody before thread 0 overwrites it
+  s = hssk_wave_sum(s);
+  if (lane == 0) s_part[wave] = s;
+  __syncthreads();
+  s = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  double tau = 0., beta = alpha, scal = 1.;
+  if (s != 0.) {
+    const double nrm = sqrt(alpha * alpha + s);
+    beta = alpha >= 0. ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    scal = 1. / (alpha - beta);
+    for (int i = k + 1 + tid; i < d; i += 256) ck[i] *= scal;
+  }
+  if (tid == 0) {
+    ck[k] = beta;
+    const double ab = fabs(beta);
+    if (k == 0) me->r00 = ab;
+    const double r00 = k == 0 ? ab : me->r00;
+    me->tau = tau;
+    if ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) { me->stop = 1; me->rank = k; }
+  }
+}
+
+__global__ __launch_bounds__(256) void idw_update_kernel(const hssk_id_desc* __restrict__ descs, const IdwState* __restrict__ st, int k) {
+  const hssk_id_desc p = descs[blockIdx.y];
+  const IdwState me = st[blockIdx.y];
+  const int kmax = p.d < p.m ? p.d : p.m;
+  if (me.stop || k >= kmax) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = p.d, m = p.m, ld = p.ldw;
+  const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
+  const double tau = me.tau;
+  double* vn1 = p.work;
+  double* vn2 = p.work + m;
+  const double* v = p.W + (size_t)k * ld;
+  const int j0 = k + 1 + blockIdx.x * IDW_COLS;
+  for (int j = j0 + wave; j < j0 + IDW_COLS && j < m; j += 4) {
+    double* col = p.W + (size_t)j * ld;
+    double s = 0.;
+    for (int i = k + 1 + lane; i < d; i += 64) s += v[i] * col[i];
+    const double ckj = col[k];
+    const double n1 = vn1[j], n2 = vn2[j];
+    s = hssk_wave_sum(s);
+    const double dot = tau * (ckj + s);
+    if (tau != 0.) for (int i = k + 1 + lane; i < d; i += 64) col[i] -= dot * v[i];
+    const double newk = ckj - dot;
+    if (lane == 0) col[k] = newk;
+    int recompute = 0;
+    double newn1 = n1;
+    if (n1 != 0.) {
+      double t = fabs(newk) / n1;
+      t = (1. + t) * (1. - t);
+      t = t > 0. ? t : 0.;
+      const double q = n1 / n2;
+      if (t * q * q <= tol3z) recompute = 1;
+      else newn1 = n1 * sqrt(t);
+    }
+    if (recompute) {
+      double s2 = 0.;
+      for (int i = k + 1 + lane; i < d; i += 64) { const double x = col[i]; s2 += x * x; }
+      s2 = hssk_wave_sum(s2);
+      newn1 = sqrt(s2);
+      if (lane == 0) vn2[j] = newn1;
+    }
+    if (lane == 0) vn1[j] = newn1;
+  }
+}
+
+int hssk_trsm_vbatched_internal(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count) { return hssk_trsm_vbatched(ctx, descs, count); }
+
+void id_wide(hssk_ctx* ctx, const hssk_id_desc* descs, const hssk_id_desc* dd, int count) {
+  int kmax = 0, mmax = 0;
+  for (int i = 0; i < count; i++) {
+    kmax = std::max(kmax, std::min(std::min(descs[i].d, descs[i].m), std::max(descs[i].max_rank, 0) + 1));
+    mmax = std::max(mmax, descs[i].m);
+  }
+  IdwState* st = (IdwState*)ctx->scratch(sizeof(IdwState) * (size_t)count + 64);
+  HSSK_LAUNCH(idw_init_kernel, dim3((unsigned)std::max(1, std::min(64, (mmax + 3) / 4)), (unsigned)count), dim3(256), 0, ctx->stream, dd, st);
+  std::vector<IdwState> hs(count);
+  const unsigned chunks = (unsigned)((mmax + IDW_COLS - 1) / IDW_COLS);
+  for (int k = 0; k < kmax; k++) {
+    HSSK_LAUNCH(idw_pivot_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd, st, k);
+    const unsigned ch = (unsigned)std::max(1, (mmax - (k + 1) + IDW_COLS - 1) / IDW_COLS);
+    HSSK_LAUNCH(idw_update_kernel, dim3(std::min(ch, chunks), (unsigned)count), dim3(256), 0, ctx->stream, dd, st, k);
+    if ((k & 63) == 63) {   // every 64 steps: has every matrix met its stopping test?
+      hssk_rt::d2h(hs.data(), st, sizeof(IdwState) * count, ctx->stream);
+      hssk_rt::sync(ctx->stream);
+      bool all = true;
+      for (auto& h : hs) all = all && h.stop;
+      if (all) break;
+    }
+  }
+  hssk_rt::d2h(hs.data(), st, sizeof(IdwState) * count, ctx->stream);
+  hssk_rt::sync(ctx->stream);
+  std::vector<hssk_trsm_desc> tr;
+  std::vector<int> ranks(count);
+  for (int i = 0; i < count; i++) {
+    int r = std::min(hs[i].rank, descs[i].max_rank);
+    r = std::max(r, 0);
+    ranks[i] = r;
+    if (r > 0 && descs[i].m > r)
+      tr.push_back(hssk_trsm_desc{descs[i].W, descs[i].W + (size_t)r * descs[i].ldw, r, descs[i].m - r, descs[i].ldw, descs[i].ldw, 0, 0, 0});
+  }
+  // ranks to the device (one int each)
+  for (int i = 0; i < count; i++) hssk_rt::h2d(descs[i].rank, &ranks[i], sizeof(int), ctx->stream);
+  hssk_rt::sync(ctx->stream);
+  if (!tr.empty() && hssk_trsm_vbatched_internal(ctx, tr.data(), (int)tr.size())) throw std::runtime_error(hssk_last_error());
+}
+
 }  // namespace
 
 extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count) {
@@ -422,7 +615,12 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
   else if (dmax <= 128) done = launch_id_reg_ct<2>(ctx, dd, count, mmax);
   else if (dmax <= 192) done = launch_id_reg_ct<3>(ctx, dd, count, mmax);
   else if (dmax <= 256) done = launch_id_reg_ct<4>(ctx, dd, count, mmax);
-  if (!done) HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
+  if (!done) {
+    // few large panels: spread every Householder step over the chip; many small ones: one workgroup each
+    static const bool force_wide = [] { const char* e = std::getenv("HSSK_ID_WIDE"); return e && e[0] == '1'; }();
+    if (force_wide || (count <= 128 && (long long)dmax * mmax >= 256LL * 512)) id_wide(ctx, descs, dd, count);
+    else HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
+  }
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -21,16 +21,22 @@ namespace {
 constexpr int TR_THREADS = 256;
 constexpr int TR_WAVES = TR_THREADS / 64;
 
-__global__ __launch_bounds__(TR_THREADS) void trsm_kernel(const hssk_trsm_desc* __restrict__ descs) {
+// one workgroup per (problem, group of TR_WAVES right-hand sides): the groups of a problem run side by side
+struct TrWork {
+  int prob, group;
+};
+__global__ __launch_bounds__(TR_THREADS) void trsm_kernel(const hssk_trsm_desc* __restrict__ descs, const TrWork* __restrict__ work) {
   HSSK_DYN_SHARED(double, xs_all);
-  const hssk_trsm_desc p = descs[blockIdx.x];
+  const TrWork wk = work[blockIdx.x];
+  const hssk_trsm_desc p = descs[wk.prob];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = p.n, ldt = p.ldt;
   const double* __restrict__ T = p.T;
   double* xs = xs_all + (size_t)wave * n;
   // effective orientation: forward substitution when (lower, N) or (upper, T)
   const bool forward = (p.lower != 0) == (p.transT == 0);
-  for (int c0 = 0; c0 < p.nrhs; c0 += TR_WAVES) {
+  {
+    const int c0 = wk.group * TR_WAVES;
     const int c = c0 + wave;
     const bool valid = c < p.nrhs;
     double* b = p.B + (size_t)(valid ? c : 0) * p.ldb;
@@ -153,8 +159,14 @@ int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count) {
   if (nmax == 0) return 0;
   size_t shmem = sizeof(double) * (size_t)nmax * TR_WAVES;
   if (shmem > 150 * 1024) throw std::runtime_error("hssk_trsm_vbatched: triangular block too large for LDS");
+  std::vector<TrWork> work;
+  for (int i = 0; i < count; i++)
+    if (descs[i].n > 0)
+      for (int g = 0; g * TR_WAVES < descs[i].nrhs; g++) work.push_back(TrWork{i, g});
+  if (work.empty()) return 0;
   auto* dd = (const hssk_trsm_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(trsm_kernel, dim3((unsigned)count), dim3(TR_THREADS), shmem, ctx->stream, dd);
+  auto* dw = (const TrWork*)ctx->stage(work.data(), sizeof(TrWork) * work.size());
+  HSSK_LAUNCH(trsm_kernel, dim3((unsigned)work.size()), dim3(TR_THREADS), shmem, ctx->stream, dd, dw);
   hssk_rt::check_launch();
   HSSK_API_END
 }
