@@ -135,6 +135,89 @@ __global__ __launch_bounds__(LU_THREADS) void getrf_kernel(const hssk_lu_desc* _
   if (tid == 0) *p.info = info;
 }
 
+// ---- blocked LU for large matrices (root of an HSS matrix with ranks in the hundreds): right-looking, LUB columns
+// per panel; the panel is factored by one workgroup (same pivoting rule as getrf_kernel, restricted to the panel's
+// columns), its row interchanges are applied to the other columns by lu_swap_kernel, U12 = L11^{-1} A12 is a batched
+// unit-lower trsm and A22 -= L21 U12 a batched MFMA GEMM.
+constexpr int LUB = 64;
+__global__ __launch_bounds__(LU_THREADS) void getrf_panel_kernel(const hssk_lu_desc* __restrict__ descs, int j0) {
+  HSSK_SHARED double s_val[LU_THREADS / 64];
+  HSSK_SHARED int s_idx[LU_THREADS / 64];
+  HSSK_SHARED int s_piv;
+  const hssk_lu_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n, ld = p.lda;
+  if (j0 >= n) return;
+  const int jend = min(n, j0 + LUB);
+  double* __restrict__ A = p.A;
+  int info = j0 == 0 ? 0 : *p.info;
+  for (int k = j0; k < jend; k++) {
+    double bv = -1.;
+    int bi = 0x7fffffff;
+    for (int i = k + tid; i < n; i += LU_THREADS) {
+      const double v = fabs(A[i + (size_t)k * ld]);
+      if (v > bv) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = hssk_shfl_xor(bv, o);
+      const int oi = hssk_shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_val[0];
+      int ix = s_idx[0];
+      for (int w = 1; w < LU_THREADS / 64; w++)
+        if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
+      s_piv = ix;
+      p.piv[k] = ix;
+    }
+    __syncthreads();
+    const int pv = s_piv;
+    if (pv != k)
+      for (int j = j0 + tid; j < jend; j += LU_THREADS) {
+        const double a = A[k + (size_t)j * ld], b = A[pv + (size_t)j * ld];
+        A[k + (size_t)j * ld] = b;
+        A[pv + (size_t)j * ld] = a;
+      }
+    __syncthreads();
+    const double akk = A[k + (size_t)k * ld];
+    if (akk == 0.) {
+      if (!info) info = k + 1;
+      __syncthreads();
+      continue;
+    }
+    const double inv = 1. / akk;
+    __syncthreads();
+    for (int i = k + 1 + tid; i < n; i += LU_THREADS) A[i + (size_t)k * ld] *= inv;
+    __syncthreads();
+    const double* lk = A + (size_t)k * ld;
+    for (int j = k + 1 + wave; j < jend; j += LU_THREADS / 64) {
+      double* col = A + (size_t)j * ld;
+      const double ukj = col[k];
+      for (int i = k + 1 + lane; i < n; i += 64) col[i] -= lk[i] * ukj;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *p.info = info;
+}
+
+// the row interchanges piv[j0 .. j0+LUB) applied to the columns outside the panel, one thread per column
+__global__ void lu_swap_kernel(const hssk_lu_desc* __restrict__ descs, int j0) {
+  const hssk_lu_desc p = descs[blockIdx.y];
+  const int n = p.n, jend = min(n, j0 + LUB);
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n - (jend - j0)) return;
+  if (c >= j0) c += jend - j0;   // skip the panel's own columns
+  double* col = p.A + (size_t)c * p.lda;
+  for (int k = j0; k < jend; k++) {
+    const int pv = p.piv[k];
+    if (pv != k) { const double t = col[k]; col[k] = col[pv]; col[pv] = t; }
+  }
+}
+
 // B <- P B (row interchanges of getrf applied in order), one thread per right-hand side
 __global__ void laswp_kernel(const hssk_lusolve_desc* __restrict__ descs) {
   const hssk_lusolve_desc p = descs[blockIdx.x];
@@ -175,7 +258,32 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
   auto* dd = (const hssk_lu_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  int nmax = 0;
+  for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
+  if (nmax <= 384) {
+    HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  } else {
+    std::vector<hssk_trsm_desc> tr;
+    std::vector<hssk_gemm_desc> gm;
+    for (int j0 = 0; j0 < nmax; j0 += LUB) {
+      HSSK_LAUNCH(getrf_panel_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd, j0);
+      HSSK_LAUNCH(lu_swap_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, ctx->stream, dd, j0);
+      tr.clear(); gm.clear();
+      for (int i = 0; i < count; i++) {
+        const hssk_lu_desc& d = descs[i];
+        const int jend = std::min(d.n, j0 + LUB), nb = jend - j0, rest = d.n - jend;
+        if (nb <= 0 || rest <= 0) continue;
+        double* A11 = d.A + j0 + (size_t)j0 * d.lda;
+        double* A12 = d.A + j0 + (size_t)jend * d.lda;
+        double* A21 = d.A + jend + (size_t)j0 * d.lda;
+        double* A22 = d.A + jend + (size_t)jend * d.lda;
+        tr.push_back(hssk_trsm_desc{A11, A12, nb, rest, d.lda, d.lda, 1, 0, 1});
+        gm.push_back(hssk_gemm_desc{A21, A12, A22, rest, rest, nb, d.lda, d.lda, d.lda, 0, 0, -1.0, 1.0});
+      }
+      if (!tr.empty() && hssk_trsm_vbatched(ctx, tr.data(), (int)tr.size())) return 1;
+      if (!gm.empty() && hssk_gemm_vbatched(ctx, gm.data(), (int)gm.size())) return 1;
+    }
+  }
   hssk_rt::check_launch();
   HSSK_API_END
 }

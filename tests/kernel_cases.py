@@ -268,7 +268,7 @@ def case_qr_lazy(hk, shapes, seed=17):
         assert np.isclose(rd[0], np.abs(np.diag(Rl)).max()) and np.isclose(rd[1], np.abs(np.diag(Rl)).min())
 
 
-def case_trsm_lu(hk, seed=9):
+def case_trsm_lu(hk, seed=9, big_lu=(450, 3)):
     r = rng(seed)
     descs, keep = [], []
     for (n, nrhs, lower, trans, unit) in [(37, 1, 1, 0, 0), (37, 5, 0, 1, 0), (64, 3, 0, 0, 0),
@@ -287,7 +287,7 @@ def case_trsm_lu(hk, seed=9):
             np.fill_diagonal(Tt, 1.0)
         ref = np.linalg.solve(Tt.T if trans else Tt, B)
         assert np.allclose(dB.get(), ref, atol=1e-11), f"trsm lower={lower} trans={trans}"
-    for n, nrhs in [(1, 1), (45, 3), (130, 1)]:
+    for n, nrhs in [(1, 1), (45, 3), (130, 1), big_lu]:     # the last one takes the blocked path (n > 384)
         A = r.standard_normal((n, n))
         B = r.standard_normal((n, nrhs))
         dA, dB = hk.array(A), hk.array(B)
@@ -298,8 +298,8 @@ def case_trsm_lu(hk, seed=9):
         assert dinfo.get()[0] == 0
         lu, piv = sla.lu_factor(A)
         assert np.array_equal(dpiv.get(), piv)
-        assert np.allclose(dA.get(), lu, atol=1e-11)
-        assert np.allclose(dB.get(), np.linalg.solve(A, B), atol=1e-9)
+        assert np.allclose(dA.get(), lu, atol=1e-9 if n > 384 else 1e-11)
+        assert np.allclose(dB.get(), np.linalg.solve(A, B), atol=1e-8 if n > 384 else 1e-9)
 
 
 # ---- kernel-matrix front end -------------------------------------------------------------------

@@ -80,6 +80,7 @@ def test_qr(hk):
 
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)
+    KC.case_trsm_lu(hk, seed=10, big_lu=(2100, 5))
 
 
 def test_mfma_peak_probe(hk):
