@@ -2,6 +2,7 @@
 #include <thread>
 #include <functional>
 #include <chrono>
+#include <fstream>
 
 #include "HSSMatrix.hpp"
 #include "Kernel.hpp"
@@ -35,6 +36,22 @@ HSSMatrix<double>::HSSMatrix(const structured::ClusterTree& t, const opts_t& opt
   make_engine(opts, tree_.get());
 }
 HSSMatrix<double>::~HSSMatrix() {}
+
+void HSSMatrix<double>::write(const std::string& fname) const {
+  if (!eng_) throw std::invalid_argument("write: empty matrix");
+  std::ofstream f(fname, std::ios::out | std::ios::trunc | std::ios::binary);
+  if (!f) throw std::runtime_error("write: cannot open " + fname);
+  eng_->save(f);
+}
+HSSMatrix<double> HSSMatrix<double>::read(const std::string& fname) {
+  std::ifstream f(fname, std::ios::in | std::ios::binary);
+  if (!f) throw std::runtime_error("read: cannot open " + fname);
+  HSSMatrix<double> H;
+  opts_t o;
+  H.eng_ = DeviceHSS::load(f, engine_options(o));
+  H.rows_ = H.cols_ = H.eng_->rows();
+  return H;
+}
 
 // HSSMatrix(kernel::Kernel&, opts): HSS/HSSMatrix.cpp:88-106
 HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : HSSMatrix(K, opts, 1, 0, nullptr, nullptr) {}

@@ -76,6 +76,12 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   DenseM_t extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const;
   scalar_t get(std::size_t i, std::size_t j) const;
   void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
+  // binary file with the compressed representation (tree, D, B, bases; not the ULV factors) and back
+  // (HSSMatrix.cpp:438-510; the file layout is this library's own, see hss_engine.cpp)
+  void write(const std::string& fname) const;
+  static HSSMatrix<double> read(const std::string& fname);
+  HSSMatrix(HSSMatrix<double>&&) = default;
+  HSSMatrix<double>& operator=(HSSMatrix<double>&&) = default;
 
   // device-resident operands (extension)
   void mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta = 0.) const;

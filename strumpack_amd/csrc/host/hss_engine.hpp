@@ -13,6 +13,7 @@
 //    GEMM, the per-node GEMMs and the column-pivoted QR of the ID all read contiguously.
 #pragma once
 #include <functional>
+#include <iosfwd>
 #include <memory>
 #include <string>
 #include <vector>
@@ -77,6 +78,10 @@ class DeviceHSS {
     std::function<void(int k, int* ann)> neighbors;
   };
   void compress_kernel(const KernelSpec& ks, const int* user_ann = nullptr, int user_k = 0);
+
+  // ---- serialization of the compressed representation (not the ULV factors): HSSMatrix::write / read ----
+  void save(std::ostream& os) const;
+  static std::unique_ptr<DeviceHSS> load(std::istream& is, const EngineOptions& opts);
 
   // ---- operations; x/b/y are column-major, host or device (on_device) ----
   void mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,

@@ -84,3 +84,24 @@ def test_kernel_regression_driver_gpu(tmp_path_factory):
     from strumpack_amd import _loader
     exe = build(os.path.dirname(_loader.lib_path()), "strumpack_amd", str(tmp_path_factory.mktemp("cpp") / "krr"), KRR_SRC)
     run_krr(exe, 10000, 78.0)
+
+
+WR_SRC = os.path.join(ROOT, "tests", "cpp", "test_write_read.cpp")
+
+
+def test_write_read_round_trip_emulator(tmp_path_factory):
+    import emu_lib
+    emu_lib.build()
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build(os.path.dirname(emu_lib.PATH), "strumpack_amd_emu", str(d / "wr_emu"), WR_SRC)
+    r = subprocess.run([exe, "200", str(d / "h.bin")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_write_read_round_trip_gpu(tmp_path_factory):
+    from strumpack_amd import _loader
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build(os.path.dirname(_loader.lib_path()), "strumpack_amd", str(d / "wr"), WR_SRC)
+    r = subprocess.run([exe, "3000", str(d / "h.bin")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
