@@ -47,7 +47,7 @@ for (n, leaf, d0, dd, algo) in CASES[world]:
     ok = ok and good
     H.destroy(); H1.destroy()
 # kernel-matrix front end: subtree ownership (natural / kd trees are balanced -> cut exists), replicated otherwise
-KCASES = {2: [(100, 16, "kdtree", "Gauss")], 4: [(130, 16, "natural", "Laplace")], 3: [(70, 16, "kdtree", "Gauss")]}
+KCASES = {2: [(100, 16, "kdtree", "Gauss")], 4: [(100, 16, "natural", "Laplace")], 3: []}
 for (n, leaf, clus, kern) in KCASES[world]:
     rng = np.random.default_rng(11)
     X = rng.standard_normal((n, 4))

@@ -76,7 +76,3 @@ def test_oracle_kernel_compression_matches_reference(tag):
 
 def test_regression_with_reference_neighbours(lib):
     KG.check_regression(KM, lib, "gauss_400", inject=True, acc_tol=0.0, rank_tol=0.0, w_tol=1e-7)
-
-
-def test_regression_anova_kdtree(lib):
-    KG.check_regression(KM, lib, "anova_400", inject=True, acc_tol=0.0, rank_tol=0.0, w_tol=1e-7)
