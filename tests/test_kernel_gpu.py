@@ -55,3 +55,39 @@ def test_kernel_regression_example_10k(lib):
     print("kernel regression 10k (device neighbours):", info)
     info = KG.check_regression(KM, lib, "gauss_10k", inject=True, acc_tol=0.0, rank_tol=0.0, w_tol=1e-6)
     print("kernel regression 10k (reference neighbours):", info)
+
+
+def test_full_size_properties_100k():
+    """BASELINE configs[3] size (N = 100000 points in R^8, Gauss kernel, h = 1.3, lambda = 3.11) through size-independent
+    properties: sampled rows of K against the compressed matrix, symmetry (V = U, B10 = B01^T), linearity, ULV residual."""
+    import ctypes as C
+    import numpy as np
+    import kernel_cases as KC
+    from strumpack_amd import capi, dist as sdist
+    L = capi.load(_loader.lib_path())
+    n, d = 100000, 8
+    rng = np.random.default_rng(2025)
+    X = rng.random((n, d))
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-2, abs_tol=1e-8, leaf_size=256, max_rank=50000)
+    H, Xp, perm = sdist.from_kernel(L, X, o, kernel="Gauss", h=1.3, lam=3.11, clustering="cobble", neighbors=64)
+    assert H.is_compressed() and H.levels() >= 9
+    assert np.array_equal(Xp, X[perm - 1])
+    assert 20 <= H.rank() <= 200, H.rank()
+    # sampled rows: (K x)_I exactly vs (H x)_I
+    x = rng.standard_normal((n, 2))
+    I = rng.integers(0, n, 24)
+    KI = KC.kernel_np(Xp, I, np.arange(n), 0, 1.3, 3.11)
+    Hx = H.mult(x)
+    err = np.linalg.norm(Hx[I] - KI @ x) / np.linalg.norm(KI @ x)
+    assert err <= 1e2 * 1e-2 and err < 5e-2, err
+    # symmetry and linearity
+    assert np.allclose(H.mult(x, "T"), Hx, rtol=1e-10, atol=1e-10)
+    y = rng.standard_normal((n, 2))
+    assert np.allclose(H.mult(2 * x - 3 * y), 2 * Hx - 3 * H.mult(y), atol=1e-8)
+    # ULV
+    H.factor()
+    b = rng.standard_normal((n, 3))
+    w = H.solve(b)
+    res = np.linalg.norm(H.mult(w) - b) / np.linalg.norm(b)
+    assert res <= 1e-10, res
+    H.destroy()
