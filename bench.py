@@ -14,7 +14,7 @@ SURVEY.md section 8(d): 4 N^2 d for the sketch + the per-node terms) over the ma
 time.  `roofline` describes the dominant kernel (the sketch DGEMM, FP64 MFMA bound) with the launch
 duration measured by HIP events on the launch stream; `cpu_baseline` is the reference's own CPU HSS
 (oracle/_ref, built from /root/reference by oracle/ref/Makefile) timed on this host on a bounded
-sample (N = 16384, same options) -- the only place anything under oracle/ is used here.
+sample (N = 32768 = BASELINE configs[1], same options) -- the only place anything under oracle/ is used here.
 """
 import argparse
 import ctypes as C
@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--rel-tol", type=float, default=1e-4)
     p.add_argument("--nrhs", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-n", type=int, default=16384)
+    p.add_argument("--cpu-n", type=int, default=32768)
     p.add_argument("--workload", choices=["toeplitz", "kernel"], default="toeplitz",
                    help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
                         "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line")
