@@ -64,11 +64,6 @@ __device__ __forceinline__ long long hssk_hwid() {
 }
 
 // scheduling hint: ask the backend to interleave `n` groups of {1 MFMA, 1 LDS write}
-#define HSSK_SCHED_MFMA_DSWRITE(n)                         \
-  _Pragma("unroll") for (int s_ = 0; s_ < (n); s_++) {     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     \
-  }
 
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))
 

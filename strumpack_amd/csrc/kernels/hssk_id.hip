@@ -561,8 +561,6 @@ __global__ __launch_bounds__(256) void idw_update_kernel(const hssk_id_desc* __r
   }
 }
 
-int hssk_trsm_vbatched_internal(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count) { return hssk_trsm_vbatched(ctx, descs, count); }
-
 void id_wide(hssk_ctx* ctx, const hssk_id_desc* descs, const hssk_id_desc* dd, int count) {
   int kmax = 0, mmax = 0;
   for (int i = 0; i < count; i++) {
@@ -599,7 +597,7 @@ void id_wide(hssk_ctx* ctx, const hssk_id_desc* descs, const hssk_id_desc* dd, i
   // ranks to the device (one int each)
   for (int i = 0; i < count; i++) hssk_rt::h2d(descs[i].rank, &ranks[i], sizeof(int), ctx->stream);
   hssk_rt::sync(ctx->stream);
-  if (!tr.empty() && hssk_trsm_vbatched_internal(ctx, tr.data(), (int)tr.size())) throw std::runtime_error(hssk_last_error());
+  if (!tr.empty() && hssk_trsm_vbatched(ctx, tr.data(), (int)tr.size())) throw std::runtime_error(hssk_last_error());
 }
 
 }  // namespace

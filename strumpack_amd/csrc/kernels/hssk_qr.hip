@@ -6,6 +6,8 @@
 // m x m Q; dense/DenseMatrix.cpp:693-719 -- the ULV factorization, HSS/HSSMatrix.factor.hpp:122):
 // the LQ of W0 is computed as the QR of W0^T, which the engine forms directly.
 //
+// qr_kernel (global memory, Level-2) now serves as the PANEL factorisation of the tall blocked path (32 columns at a
+// time, see qr_blocked); whole matrices go through the register kernels or the blocked paths.
 // Same wave64 mapping as the ID kernel: the reflector is built by one wave with shuffle reductions,
 // the trailing update gives one column to each wave, lanes stride the (contiguous) column.
 // Q is accumulated backwards (dorg2r order) in a separate rows x nq buffer.
@@ -545,20 +547,14 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
   auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // register-resident kernels when the largest panel of the batch fits (rows <= 64 RT, cols <= 16 CT);
   // Q is then formed by a second, barrier-free launch over blocks of 16 CT columns
-  bool reg = true;
   if (rmax <= 64 && cmax <= 64) launch_qr_reg<1, 4, 16>(ctx, dd, count);
   else if (rmax <= 128 && cmax <= 128) launch_qr_reg<2, 8, 16>(ctx, dd, count);
-  else if (rmax <= 256 && cmax <= 128) launch_qr_reg<4, 8, 16>(ctx, dd, count);
-  else if (rmax <= 256 && cmax <= 208) launch_qr_reg<4, 26, 8>(ctx, dd, count);
-  else reg = false;
-  if (reg) {
-    if (qmax > 0) {
-      if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
-      else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
-      else launch_formq_reg<4, 8>(ctx, dd, descs, count);
-    }
-  } else {
-    HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd, 0);
+  else if (cmax <= 128) launch_qr_reg<4, 8, 16>(ctx, dd, count);
+  else launch_qr_reg<4, 26, 8>(ctx, dd, count);   // rmax <= 256, cmax <= 208 (larger panels took the blocked path above)
+  if (qmax > 0) {
+    if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
+    else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
+    else launch_formq_reg<4, 8>(ctx, dd, descs, count);
   }
   hssk_rt::check_launch();
   HSSK_API_END
@@ -581,8 +577,7 @@ extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int
     auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
     if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
     else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
-    else if (rmax <= 256) launch_formq_reg<4, 8>(ctx, dd, descs, count);
-    else HSSK_LAUNCH(qr_kernel, dim3((unsigned)count), dim3(QR_THREADS), 0, ctx->stream, dd, 1);
+    else launch_formq_reg<4, 8>(ctx, dd, descs, count);   // rmax <= 256 (taller panels took the blocked path above)
   }
   hssk_rt::check_launch();
   HSSK_API_END

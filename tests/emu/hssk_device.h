@@ -63,7 +63,6 @@ inline long long hssk_clock() { return 0; }
 inline long long hssk_wallclock() { return 0; }
 inline long long hssk_hwid() { return 0; }
 
-#define HSSK_SCHED_MFMA_DSWRITE(n)
 
 #define HSSK_SHARED alignas(16) static thread_local
 inline double hssk_gload(const double* p, size_t off) { return p[off]; }
