@@ -63,8 +63,6 @@ __device__ __forceinline__ long long hssk_hwid() {
   return ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 }
 
-// scheduling hint: ask the backend to interleave `n` groups of {1 MFMA, 1 LDS write}
-
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))
 
 // Global-memory accessors for pointers that arrive through a descriptor in memory: the compiler cannot infer
