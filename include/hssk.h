@@ -26,6 +26,20 @@ void hssk_ctx_destroy(hssk_ctx* ctx);
 void* hssk_ctx_stream(hssk_ctx* ctx); /* hipStream_t */
 int hssk_sync(hssk_ctx* ctx);
 const char* hssk_last_error(void);
+/* ---- sweep plans ------------------------------------------------------------------------------
+ * Between hssk_plan_begin and hssk_plan_end every batched call on this context (from the calling thread) is executed
+ * AND recorded: its kernel launches with their arguments, its descriptor arrays in storage owned by the plan.
+ * hssk_plan_replay re-issues the launches on the context's stream: one launch per step, no descriptor building, no
+ * staging -- for sweeps that are repeated on the same buffers (solves with a factored matrix, mat-vecs in a Krylov
+ * loop).  Every pointer the recorded calls used must still be valid at replay.  Not for calls that synchronise or copy
+ * to the host. */
+typedef struct hssk_plan hssk_plan;
+int hssk_plan_begin(hssk_ctx* ctx, hssk_plan** plan);
+int hssk_plan_end(hssk_ctx* ctx);
+int hssk_plan_replay(hssk_ctx* ctx, hssk_plan* plan);
+void hssk_plan_destroy(hssk_plan* plan);
+int hssk_plan_size(const hssk_plan* plan);
+
 /* device memory helpers (hipMalloc/hipFree/hipMemcpy wrappers so FFI users need no HIP binding) */
 void* hssk_malloc(long long bytes);
 void hssk_free(void* dptr);

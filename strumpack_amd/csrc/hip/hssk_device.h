@@ -6,6 +6,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
+#include <vector>
+
+namespace hssk_rec {
+extern thread_local std::vector<std::function<void()>>* sink;   // non-null while a plan is being recorded
+}
+
 #define HSSK_WAVE 64
 
 typedef double hssk_d4 __attribute__((ext_vector_type(4)));
@@ -76,6 +83,11 @@ __device__ __forceinline__ hssk_d2 hssk_gload2(const double* p, size_t off) {
 __device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { ((double HSSK_GLOBAL_AS*)p)[off] = v; }
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
-// kernel<<<grid, block, shmem, stream>>>(args...)
-#define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-  hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__)
+// kernel<<<grid, block, shmem, stream>>>(args...).  While a sweep plan is being recorded on this thread
+// (hssk_plan_begin / _end, hssk_internal.h) the launch is also remembered, arguments by value, for replay.
+#define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                  \
+  do {                                                                                                        \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__);                       \
+    if (hssk_rec::sink)                                                                                       \
+      hssk_rec::sink->push_back([=]() { hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__); }); \
+  } while (0)

@@ -252,12 +252,15 @@ DeviceHSS::DeviceHSS(int n, const EngineOptions& opts, const structured::Cluster
   fact_.reset(new Arena(size_t(64) << 20));
   tmp_.reset(new Arena(size_t(64) << 20));
   comm_arena_.reset(new Arena(size_t(64) << 20));
+  plan_arena_.reset(new Arena(size_t(64) << 20));
   build_tree(tree);
   setup_ownership();
 }
 
 DeviceHSS::~DeviceHSS() {
   if (ctx_) hssk_sync(ctx_);
+  drop_plans();
+  plan_arena_.reset();
   persist_.reset();
   work_.reset();
   fact_.reset();
@@ -589,7 +592,18 @@ void DeviceHSS::compress_callbacks(const host_mult_t& mult, const host_elem_t& e
   compress(s);
 }
 
+void DeviceHSS::drop_plans() {
+  for (auto& kv : plans_) if (kv.second.plan) hssk_plan_destroy(kv.second.plan);
+  plans_.clear();
+  if (plan_arena_) plan_arena_->reset();
+}
+bool DeviceHSS::plans_enabled() const {
+  static const bool off = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_PLANS"); return e && e[0] == '1'; }();
+  return !off;
+}
+
 void DeviceHSS::reset_compression() {
+  drop_plans();
   for (auto& nd : nodes_) {
     int lo = nd.lo, m = nd.m, lvl = nd.lvl, h = nd.height, c0 = nd.c0, c1 = nd.c1, p = nd.parent;
     nd = Node();
@@ -1514,6 +1528,7 @@ void DeviceHSS::shift(double sigma) {
   if (!d.empty()) ck(hssk_shift_diag(ctx_, d.data(), (int)d.size(), sigma));
   ck(hssk_sync(ctx_));
   factored_ = false;  // the ULV factors are stale (examples/dense/testStructured.cpp:199)
+  drop_plans();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1525,8 +1540,23 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   if (nrhs <= 0 || n_ == 0) return;
   double t0 = now();
   const bool T = !(trans == 'N' || trans == 'n');
-  Arena& tmp = *tmp_;
-  tmp.rewind();
+  const bool plannable = on_device && o_.world == 1 && plans_enabled();
+  const PlanKey key{0, T ? 'T' : 'N', nrhs, (const void*)x, (void*)y, ldx, ldy, beta};
+  if (plannable) {
+    auto it = plans_.find(key);
+    if (it != plans_.end() && it->second.plan) {
+      ck(hssk_plan_replay(ctx_, it->second.plan));
+      ck(hssk_sync(ctx_));
+      stats_.t_mult = now() - t0;
+      return;
+    }
+  }
+  hssk_plan* rec = nullptr;
+  if (plannable && plans_.size() > 32) drop_plans();   // many different buffers: start over rather than grow
+  if (plannable && ++plans_[key].seen == 2) ck(hssk_plan_begin(ctx_, &rec));
+  struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
+  Arena& tmp = rec ? *plan_arena_ : *tmp_;
+  if (!rec) tmp.rewind();
   const int N = n_;
   const double* dx = x;
   double* dy = y;
@@ -1674,6 +1704,7 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   for (auto& ids : own_by_depth_) down(ids);
   if (dist_subtree_) allgather_rows(dy, ly, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, y, sizeof(double) * ldy, dy, sizeof(double) * N, sizeof(double) * N, nrhs));
+  if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
   ck(hssk_sync(ctx_));
   stats_.t_mult = now() - t0;
 }
@@ -1685,6 +1716,7 @@ void DeviceHSS::factor() {
   ensure_ready("factor");
   double t0 = now();
   ck(hssk_sync(ctx_));
+  drop_plans();   // recorded sweeps reference the old factors
   fact_->reset();
   stats_.f_ulv = 0;
   for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nullptr, nd.piv = nullptr;
@@ -1802,8 +1834,25 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   if (!factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
   if (nrhs <= 0 || n_ == 0) return;
   double t0 = now();
-  Arena& tmp = *tmp_;
-  tmp.rewind();
+  // repeated solve on the same device buffer: replay the recorded sweep (no descriptor building, no staging)
+  const bool plannable = on_device && o_.world == 1 && plans_enabled();
+  const PlanKey key{1, 'N', nrhs, (const void*)b, (void*)b, ldb, ldb, 0.};
+  if (plannable) {
+    auto it = plans_.find(key);
+    if (it != plans_.end() && it->second.plan) {
+      ck(hssk_plan_replay(ctx_, it->second.plan));
+      ck(hssk_sync(ctx_));
+      stats_.t_solve = now() - t0;
+      return;
+    }
+  }
+  hssk_plan* rec = nullptr;
+  // the first call on a buffer runs normally; the second one is recorded while it runs, later ones replay
+  if (plannable && plans_.size() > 32) drop_plans();   // many different buffers: start over rather than grow
+  if (plannable && ++plans_[key].seen == 2) ck(hssk_plan_begin(ctx_, &rec));
+  struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
+  Arena& tmp = rec ? *plan_arena_ : *tmp_;   // a recorded sweep keeps its own work vectors
+  if (!rec) tmp.rewind();
   const int N = n_;
   double* db = b;
   long long lb = ldb;
@@ -1980,6 +2029,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   for (auto& ids : own_by_depth_) bwd(ids);
   if (dist_subtree_) allgather_rows(db, lb, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
+  if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
   ck(hssk_sync(ctx_));
   stats_.t_solve = now() - t0;
   {

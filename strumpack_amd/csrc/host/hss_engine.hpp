@@ -14,6 +14,8 @@
 #pragma once
 #include <functional>
 #include <iosfwd>
+#include <map>
+#include <tuple>
 #include <memory>
 #include <string>
 #include <vector>
@@ -152,6 +154,18 @@ class DeviceHSS {
                   std::vector<char>& resolved);
   void free_compress_workspace();
   void ensure_ready(const char* what) const;
+  // sweep plans: an apply / solve repeated on the same device buffers is recorded once (hssk_plan_*) and replayed
+  struct PlanKey {
+    int op; char trans; int nrhs; const void* x; void* y; long long ldx, ldy; double beta;
+    bool operator<(const PlanKey& o) const {
+      return std::tie(op, trans, nrhs, x, y, ldx, ldy, beta) < std::tie(o.op, o.trans, o.nrhs, o.x, o.y, o.ldx, o.ldy, o.beta);
+    }
+  };
+  struct PlanEntry { int seen = 0; hssk_plan* plan = nullptr; };
+  std::map<PlanKey, PlanEntry> plans_;
+  std::unique_ptr<Arena> plan_arena_;   // work vectors of the recorded sweeps (never rewound while plans live)
+  void drop_plans();
+  bool plans_enabled() const;
   // ---- multi-GPU: subtree ownership below the cut level, replicated top
   bool mine(int id) const { return owner_[id] < 0 || owner_[id] == o_.rank; }
   void setup_ownership();

@@ -13,6 +13,8 @@ static std::mutex g_pool_mu;
 static std::vector<hssk_ctx*> g_pool;
 void hssk_set_error(const std::string& msg) { g_err = msg; }
 
+thread_local std::vector<std::function<void()>>* hssk_rec::sink = nullptr;
+
 extern "C" {
 
 const char* hssk_last_error(void) { return g_err.c_str(); }
@@ -137,6 +139,34 @@ long long hssk_last_dgemm_trace(hssk_ctx* c, long long* out, long long max_wgs) 
     return nw;
   } catch (...) { return -1; }
 }
+
+// ---- sweep plans: record a sequence of batched launches once, replay it without host-side descriptor work
+int hssk_plan_begin(hssk_ctx* c, hssk_plan** out) {
+  try {
+    if (c->recording || hssk_rec::sink) throw std::logic_error("hssk_plan_begin: a plan is already being recorded");
+    if (!hssk_rt::pinned_is_device_visible()) throw std::runtime_error("hssk_plan_begin: pinned memory is not device-visible here");
+    hssk_plan* p = new hssk_plan();
+    c->recording = p;
+    hssk_rec::sink = &p->launches;
+    *out = p;
+    return 0;
+  } catch (const std::exception& e) { hssk_set_error(e.what()); return 1; }
+}
+int hssk_plan_end(hssk_ctx* c) {
+  c->recording = nullptr;
+  hssk_rec::sink = nullptr;
+  return 0;
+}
+int hssk_plan_replay(hssk_ctx* c, hssk_plan* p) {
+  try {
+    if (c->recording) throw std::logic_error("hssk_plan_replay: cannot replay while recording");
+    for (auto& f : p->launches) f();
+    hssk_rt::check_launch();
+    return 0;
+  } catch (const std::exception& e) { hssk_set_error(e.what()); return 1; }
+}
+void hssk_plan_destroy(hssk_plan* p) { delete p; }
+int hssk_plan_size(const hssk_plan* p) { return p ? (int)p->launches.size() : 0; }
 
 double hssk_last_dgemm_flops(hssk_ctx* c) { return c->dgemm_timed ? c->dgemm_timed_flops : 0.; }
 

@@ -1,11 +1,39 @@
 // Internal: context object shared by the kernel translation units (not part of the C-ABI).
 #pragma once
+#include <functional>
+#include <vector>
+#include <algorithm>
+#include <utility>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 
 #include "hssk.h"
 #include "hssk_rt.h"
+
+namespace hssk_rec {
+extern thread_local std::vector<std::function<void()>>* sink;   // non-null while a plan is being recorded (hssk_device.h)
+}
+
+// A recorded sequence of batched launches (one apply / solve sweep) with its descriptor arrays kept in a private
+// pinned block: replaying it costs one kernel launch per step and no host-side descriptor work.
+struct hssk_plan {
+  std::vector<std::function<void()>> launches;
+  std::vector<std::pair<char*, size_t>> blocks;   // pinned, device-visible descriptor storage
+  size_t off = 0;
+  char* alloc(size_t bytes) {
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (blocks.empty() || off + need > blocks.back().second) {
+      const size_t sz = std::max<size_t>(need, size_t(1) << 20);
+      blocks.emplace_back((char*)hssk_rt::pinned_malloc(sz), sz);
+      off = 0;
+    }
+    char* p = blocks.back().first + off;
+    off += need;
+    return p;
+  }
+  ~hssk_plan() { for (auto& b : blocks) hssk_rt::pinned_free(b.first); }
+};
 
 struct hssk_ctx {
   int device = 0;
@@ -25,7 +53,13 @@ struct hssk_ctx {
 
   // copies `bytes` of host data into the ring and returns the device address (valid for kernels
   // enqueued on `stream` after this call)
+  hssk_plan* recording = nullptr;
   void* stage(const void* host, size_t bytes) {
+    if (recording) {   // descriptors of a recorded sweep live as long as the plan
+      char* p = recording->alloc(bytes);
+      std::memcpy(p, host, bytes);
+      return p;
+    }
     size_t need = (bytes + 255) & ~size_t(255);
     if (need > ring_bytes) throw std::runtime_error("hssk: descriptor batch exceeds staging ring");
     if (ring_off + need > ring_bytes) {

@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <vector>
 
 #define HSSK_WAVE 64
 #define HSSK_EMU 1
@@ -25,6 +26,9 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 
+namespace hssk_rec {
+extern thread_local std::vector<std::function<void()>>* sink;   // non-null while a plan is being recorded
+}
 typedef double hssk_d4 __attribute__((vector_size(32)));
 typedef double hssk_d2 __attribute__((vector_size(16)));
 
@@ -70,5 +74,9 @@ inline hssk_d2 hssk_gload2(const double* p, size_t off) { return *reinterpret_ca
 inline void hssk_gstore(double* p, size_t off, double v) { p[off] = v; }
 #define HSSK_DYN_SHARED(type, name) type* name = (type*)emu::dyn_shared()
 
-#define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-  emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); })
+#define HSSK_LAUNCH(kernel, grid, block, shmem, stream, ...)                                          \
+  do {                                                                                                \
+    emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); });                                  \
+    if (hssk_rec::sink)                                                                               \
+      hssk_rec::sink->push_back([=]() { emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); }); }); \
+  } while (0)

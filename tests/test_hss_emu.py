@@ -24,3 +24,10 @@ def test_ctest_case(L, name):
 
 def test_api_semantics(L):
     HC.check_api_semantics(L)
+
+
+def test_sweep_plans(L):
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(emu_lib.PATH)
+    HC.check_sweep_plans(L, hk, n=200)
+    hk.close()

@@ -28,6 +28,13 @@ def test_api_semantics(L):
     HC.check_api_semantics(L)
 
 
+def test_sweep_plans(L):
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(_loader.lib_path())
+    HC.check_sweep_plans(L, hk, n=3000)
+    hk.close()
+
+
 def test_native_code_is_loaded():
     import os
     maps = open("/proc/self/maps").read()
