@@ -249,6 +249,29 @@ typedef struct hssk_lusolve_desc {
 } hssk_lusolve_desc;
 int hssk_getrs_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count);
 
+/* ---- fused ULV solve sweeps (few right-hand sides) ------------------------------------------------
+ * One launch per tree level of HSSMatrix::solve_fwd / solve_bwd (HSS/HSSMatrix.solve.hpp:69-238); see
+ * kernels/hssk_ulv.hip for the per-node arithmetic.  nrhs <= 4 and node dimensions <= 512, otherwise the call returns 2
+ * and does nothing (the caller then issues the unfused batched calls). */
+typedef struct hssk_ulv_fwd_desc {
+  const double* fsrc;   /* m x nrhs right-hand side rows of the node (leaf: rows of b; inner: [ft1_0; ft1_1]) */
+  const double *B01, *B10, *zc; /* inner nodes: f(0:rU0) -= B01 zc(rV0:rV0+rV1), f(rU0:) -= B10 zc(0:rV0); zc = children's z stacked; leaves: NULL */
+  const int* permU;
+  const double *XU, *Rlq, *Qt, *W1, *Vt0;
+  const int* permV;     /* inner nodes only (NULL for leaves) */
+  const double* XV;
+  double *ft1, *y, *z;  /* out: r x nrhs (ld ldp), (m-r) x nrhs (ld m-r), rv x nrhs (ld ldz) */
+  int ldf, rU0, rU1, rV0, rV1, ldz_in, m, r, mv, rv, ldp, ldz;
+} hssk_ulv_fwd_desc;
+int hssk_ulv_fwd_level(hssk_ctx* ctx, const hssk_ulv_fwd_desc* descs, int count, int nrhs);
+/* out (m x nrhs, ldo) = Qt(:, 0:m-r) y + Qt(:, m-r:) xpart   (y: (m-r) x nrhs, ld m-r; xpart: r x nrhs, ldx) */
+typedef struct hssk_ulv_bwd_desc {
+  const double *Qt, *y, *xpart;
+  double* out;
+  int m, r, ldx, ldo;
+} hssk_ulv_bwd_desc;
+int hssk_ulv_bwd_level(hssk_ctx* ctx, const hssk_ulv_bwd_desc* descs, int count, int nrhs);
+
 /* ---- small utilities --------------------------------------------------------------------------- */
 /* out[j] = sum_i P(i,j)^2 over the rows x cols panel: Frobenius norms for the stopping test
  * (HSS/HSSMatrix.compress_stable.hpp:418,438) */

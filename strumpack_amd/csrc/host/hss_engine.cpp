@@ -1878,9 +1878,45 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     }
     if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
   }
+  // few right-hand sides: one fused launch per level (hssk_ulv_fwd_level / _bwd_level) instead of 7 / 3 batched ones
+  static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
+  const bool fuse = nrhs <= 4 && !no_fuse;
+  auto fwd_fused = [&](const std::vector<int>& ids) -> bool {
+    std::vector<hssk_ulv_fwd_desc> fd;
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      if (nd.lvl == 0) return false;   // the root level (LU solve) stays on the batched path
+      const Node& pa = nodes_[nd.parent];
+      hssk_ulv_fwd_desc d{};
+      d.m = nd.mU; d.r = nd.rU; d.mv = nd.leaf() ? nd.m : nd.mV; d.rv = nd.rV;
+      if (nd.leaf()) { d.fsrc = db + nd.lo; d.ldf = (int)lb; }
+      else {
+        const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+        d.fsrc = f[id]; d.ldf = std::max(a.rU + c.rU, 1);
+        d.B01 = nd.B01; d.B10 = nd.B10; d.zc = zc[id];
+        d.rU0 = a.rU; d.rU1 = c.rU; d.rV0 = a.rV; d.rV1 = c.rV; d.ldz_in = std::max(a.rV + c.rV, 1);
+        d.permV = nd.permV; d.XV = nd.XV;
+        if (!d.B01 || !d.B10) return false;
+      }
+      d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Qt = nd.Qt; d.W1 = nd.W1; d.Vt0 = nd.Vt0;
+      d.ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+      d.ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+      d.z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+      d.ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+      d.y = y[id];
+      if (d.m > d.r && (!d.y || !d.Rlq || !d.Qt)) return false;
+      fd.push_back(d);
+    }
+    if (fd.empty()) return true;
+    const int rc = hssk_ulv_fwd_level(ctx_, fd.data(), (int)fd.size(), nrhs);
+    if (rc == 2) return false;
+    ck(rc);
+    return true;
+  };
   // ---- forward, one tree height
   auto fwd = [&](const std::vector<int>& ids) {
     if (ids.empty()) return;
+    if (fuse && fwd_fused(ids)) return;
     std::vector<hssk_gemm_desc> ga, gb, gc, gd, ge;
     std::vector<hssk_rowgather_desc> rg;
     std::vector<hssk_trsm_desc> ts;
@@ -1957,6 +1993,28 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   };
   // ---- backward, one depth (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
   auto bwd = [&](const std::vector<int>& ids) {
+    if (fuse) {
+      std::vector<hssk_ulv_bwd_desc> bd;
+      for (int id : ids) {
+        const Node& nd = nodes_[id];
+        if (nd.leaf()) continue;
+        const Node& a = nodes_[nd.c0];
+        const int cid[2] = {nd.c0, nd.c1};
+        for (int q = 0; q < 2; q++) {
+          if (!mine(cid[q])) continue;
+          const Node& cn = nodes_[cid[q]];
+          if (cn.mU == 0) continue;
+          hssk_ulv_bwd_desc d{};
+          d.Qt = cn.Qt; d.y = y[cid[q]]; d.xpart = xb[id] + (q ? a.rU : 0);
+          d.out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+          d.m = cn.mU; d.r = cn.rU; d.ldx = std::max(a.rU + nodes_[nd.c1].rU, 1); d.ldo = cn.leaf() ? (int)lb : std::max(cn.mU, 1);
+          bd.push_back(d);
+        }
+      }
+      if (bd.empty()) return;
+      const int rc = hssk_ulv_bwd_level(ctx_, bd.data(), (int)bd.size(), nrhs);
+      if (rc != 2) { ck(rc); return; }
+    }
     std::vector<hssk_gemm_desc> g1, g2;
     std::vector<hssk_rowgather_desc> cp;
     for (int id : ids) {
