@@ -21,7 +21,7 @@ namespace {
 
 constexpr int UL_T = 256;      // threads per workgroup
 constexpr int UL_NR = 4;       // right-hand sides handled at once
-constexpr int UL_D = 4;        // columns of R~ per prefetch block of the substitution
+constexpr int UL_TB = 32;      // block size of the substitution y <- R~^{-T} y
 constexpr int UL_MAX = 256;    // largest node dimension (rows of a basis) the LDS vectors / register prefetch are sized for
 
 __global__ __launch_bounds__(UL_T) void ulv_fwd_kernel(const hssk_ulv_fwd_desc* __restrict__ descs, int nrhs) {
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(UL_T) void ulv_fwd_kernel(const hssk_ulv_fwd_desc* 
   HSSK_SHARED double s_y[UL_MAX * UL_NR];
   HSSK_SHARED double s_a[UL_MAX * UL_NR];    // ft1, later the stacked children z
   HSSK_SHARED double s_p[4 * UL_NR * 64];    // per-wave partial sums of the split GEMVs
+  HSSK_SHARED double s_T[UL_TB * UL_TB];      // diagonal block of R~ of the blocked substitution
   const hssk_ulv_fwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = p.m, r = p.r, q = m - r;
@@ -75,56 +76,45 @@ __global__ __launch_bounds__(UL_T) void ulv_fwd_kernel(const hssk_ulv_fwd_desc* 
       }
     }
   __syncthreads();
-  // ---- y <- R~^{-T} y : forward substitution, column i of R~ (rows 0..i) is contiguous
+  // ---- y <- R~^{-T} y, blocked: the dependent chain only ever touches a UL_TB x UL_TB diagonal block that all threads
+  // loaded into LDS at once; the coupling to the remaining rows is a parallel update with UL_TB independent loads per
+  // thread.  (An unblocked chain pays a global-memory round trip per step: it was 40 % of the sweep.)
   if (q > 0) {
-    if (wave == 0) {
-      // The substitution is a chain of q dependent steps; a global-memory round trip in each of them (~1 us) was 40 %
-      // of the sweep.  Columns of R~ are therefore fetched UL_D at a time, one block ahead of the block being reduced.
-      constexpr int PF = UL_MAX / 64;
-      double bufA[UL_D][PF], bufB[UL_D][PF], diaA[UL_D], diaB[UL_D];
-      auto fetch = [&](double (&buf)[UL_D][PF], double (&dia)[UL_D], int i0) {
-#pragma unroll
-        for (int dd = 0; dd < UL_D; dd++) {
-          const int col = i0 + dd;
-          const bool ok = col < q;
-          const size_t cb = (size_t)(ok ? col : 0) * p.m;
-          dia[dd] = ok ? hssk_gload(p.Rlq, cb + col) : 1.;
-#pragma unroll
-          for (int u = 0; u < PF; u++) {
-            const int l = lane + 64 * u;
-            const double v = hssk_gload(p.Rlq, cb + (l < col ? l : 0));
-            buf[dd][u] = (ok && l < col) ? v : 0.;
-          }
-        }
-      };
-      auto reduce = [&](const double (&buf)[UL_D][PF], const double (&dia)[UL_D], int i0) {
-#pragma unroll
-        for (int dd = 0; dd < UL_D; dd++) {
-          const int i = i0 + dd;
-          if (i >= q) break;
-          double acc[UL_NR] = {0., 0., 0., 0.};
-#pragma unroll
-          for (int u = 0; u < PF; u++) {
-            const int l = lane + 64 * u;
-            if (l < i)
-              for (int c = 0; c < nrhs; c++) acc[c] += buf[dd][u] * s_y[l + c * UL_MAX];
-          }
-          for (int c = 0; c < nrhs; c++) {
-            const double yi = s_y[i + c * UL_MAX];   // read by every lane before it is rewritten
-            const double v = hssk_wave_sum(acc[c]);
-            s_y[i + c * UL_MAX] = (yi - v) / dia[dd];   // every lane stores the same value: no lane can run ahead of the update
-          }
-        }
-      };
-      fetch(bufA, diaA, 0);
-      for (int i0 = 0; i0 < q; i0 += 2 * UL_D) {
-        fetch(bufB, diaB, i0 + UL_D);
-        reduce(bufA, diaA, i0);
-        fetch(bufA, diaA, i0 + 2 * UL_D);
-        reduce(bufB, diaB, i0 + UL_D);
+    for (int b0 = 0; b0 < q; b0 += UL_TB) {
+      const int nb = min(UL_TB, q - b0);
+      for (int e = tid; e < nb * nb; e += UL_T) {
+        const int i = e % nb, j = e / nb;
+        s_T[i + j * UL_TB] = i <= j ? hssk_gload(p.Rlq, (b0 + i) + (size_t)(b0 + j) * p.m) : 0.;
       }
+      __syncthreads();
+      if (wave == 0)
+        for (int i = 0; i < nb; i++) {
+          double acc[UL_NR] = {0., 0., 0., 0.};
+          if (lane < i) {
+            const double t = s_T[lane + i * UL_TB];
+            for (int c = 0; c < nrhs; c++) acc[c] = t * s_y[b0 + lane + c * UL_MAX];
+          }
+          const double dia = s_T[i + i * UL_TB];
+          for (int c = 0; c < nrhs; c++) {
+            const double yi = s_y[b0 + i + c * UL_MAX];   // read by every lane before it is rewritten
+            const double v = hssk_wave_sum(acc[c]);
+            s_y[b0 + i + c * UL_MAX] = (yi - v) / dia;    // every lane stores the same value: no lane can run ahead
+          }
+        }
+      __syncthreads();
+      // rows below the block: y(k) -= R~(b0:b0+nb, k)^T y(b0:b0+nb)   (column k of R~, rows b0.. contiguous)
+      for (int k = b0 + nb + tid; k < q; k += UL_T) {
+        double acc[UL_NR] = {0., 0., 0., 0.};
+        const size_t cb = (size_t)k * p.m + b0;
+#pragma unroll 8
+        for (int l = 0; l < nb; l++) {
+          const double t = hssk_gload(p.Rlq, cb + l);
+          for (int c = 0; c < nrhs; c++) acc[c] += t * s_y[b0 + l + c * UL_MAX];
+        }
+        for (int c = 0; c < nrhs; c++) s_y[k + c * UL_MAX] -= acc[c];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     for (int e = tid; e < q * nrhs; e += UL_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * UL_MAX]);
   }
   // ---- ft1 -= W1 (Q~(:, 0:q) y):  t (m) = Q~(:, :q) y  (row index contiguous),  then W1 (r x m, row index contiguous)
