@@ -235,7 +235,7 @@ inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, 
                                                       std::vector<int>& perm, std::size_t cluster_size) {
   namespace cd = clustering_detail;
   const int n = (int)p.cols(), d = (int)p.rows();
-  if (p.ld() != p.rows()) throw std::invalid_argument("binary_tree_clustering: points must be stored contiguously");
+  if (p.ld() != d) throw std::invalid_argument("binary_tree_clustering: points must be stored contiguously");
   perm.resize(n);
   std::iota(perm.begin(), perm.end(), 1);
   cd::Points pts{p.data(), d, n};

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NW * 64) void qr_reg_kernel(const hssk_qr_desc* __r
   HSSK_SHARED double s_rd[2];
   const hssk_qr_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rows = p.rows, cols = p.cols, nq = p.nq;
+  const int rows = p.rows, cols = p.cols;
   const int kmax = rows < cols ? rows : cols;
   double a[CT][RT];
 #pragma unroll
