@@ -112,6 +112,26 @@ int SPX_d_struct_node_info(const CSPStructMat S, int* out);
  * [11] f_sketch [12] f_local [13] f_reduce [14] f_id [15] f_ortho [16] f_ulv [17] f_solve
  * [18] factor_memory_bytes [19] sketch_kernel_flops (algorithmic flops of the launches timed in [7]) */
 int SPX_d_struct_stats(const CSPStructMat S, double* out);
+/* ---- Schur complement of the (0,0) block of an HSS matrix: S = H11 - H10 H00^{-1} H01 -- what the reference's sparse
+ * HSS fronts call on HSSMatrix<T> (HSS/HSSMatrix.hpp:330 partial_factor, :456 Schur_update, :459 Schur_product_direct,
+ * :465 Schur_product_indirect; HSS/HSSMatrix.Schur.hpp; use: sparse/fronts/FrontHSS.cpp:391-407, :164, :218).
+ * dims: [0] n0 [1] n1 [2] rV0 [3] mu0 [4] rV1 [5] rU0 [6] rU1;  Theta n1 x rV0, DUB01 mu0 x rV1, Phi n1 x mu0,
+ * Vhat mu0 x rV0 (host outputs, any may be NULL):  S = H11 - Theta Vhat^T Phi^T.  The factors stay in HBM for the
+ * products: Sr = S R, Sc = S^T R (direct);  Sr = Sr1 - H10 R0 - (H11 - S) R1, Sc = Sc1 - H01^T R0 - (H11 - S)^T R1
+ * (indirect).  on_device: R / S* are device pointers. */
+int SPX_d_struct_partial_factor(CSPStructMat S);
+int SPX_d_struct_schur_dims(const CSPStructMat S, int* dims);
+int SPX_d_struct_schur_update(CSPStructMat S, double* Theta, int ldT, double* DUB01, int ldD, double* Phi, int ldP,
+                              double* Vhat, int ldV);
+int SPX_d_struct_schur_product_direct(const CSPStructMat S, int c, const double* R, long long ldR, double* Sr,
+                                      long long ldSr, double* Sc, long long ldSc, int on_device);
+int SPX_d_struct_schur_product_indirect(const CSPStructMat S, int c, const double* R0, long long ldR0, const double* R1,
+                                        long long ldR1, const double* Sr1, long long ldSr1, const double* Sc1,
+                                        long long ldSc1, double* Sr, long long ldSr, double* Sc, long long ldSc,
+                                        int on_device);
+/* C = op(H_cc) B for the diagonal block of child c (HSSMatrix::child(c)->apply, HSS/HSSMatrix.hpp:194-202) */
+int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, const double* B, long long ldB, double* C,
+                            long long ldC, int on_device);
 /* the hssk kernel context of the matrix (include/hssk.h), for callers that share its stream */
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S);
 

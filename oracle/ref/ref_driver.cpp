@@ -28,6 +28,7 @@ namespace {
 struct RefHSS {
   std::unique_ptr<HSSMatrix<double>> H;
   int n = 0;
+  DenseMatrix<double> Theta, DUB01, Phi, TV;   // Schur_update results (+ what FrontHSS.cpp:396-407 derives)
 };
 
 HSSOptions<double> make_opts(double rel_tol, double abs_tol, int leaf, int d0, int dd, int p,
@@ -147,6 +148,60 @@ void ref_hss_solve(void* h, int nrhs, double* B, int ldb) {
 }
 
 void ref_hss_shift(void* h, double s) { static_cast<RefHSS*>(h)->H->shift(s); }
+
+// partial_factor + Schur_update exactly as the sparse HSS front drives them (sparse/fronts/FrontHSS.cpp:391-407).
+// dims: [0] n1 = rows of block 1, [1] Theta cols, [2] Phi cols, [3] DUB01 cols, [4] Vhat rows, [5] Vhat cols.
+// Returns 0 for a leaf root (nothing done, test_HSS_seq.cpp:252).
+int ref_hss_schur_update(void* h, int* dims) {
+  auto* r = static_cast<RefHSS*>(h);
+  for (int i = 0; i < 6; i++) dims[i] = 0;
+  if (r->H->leaf()) return 0;
+  r->H->partial_factor();
+  r->H->Schur_update(r->Theta, r->DUB01, r->Phi);
+  const DenseMatrix<double>& Vhat = r->H->child(0)->ULV().Vhat();
+  if (r->Theta.cols() < r->Phi.cols()) {
+    r->TV = DenseMatrix<double>(Vhat.cols(), r->Phi.rows());
+    gemm(Trans::C, Trans::C, 1., Vhat, r->Phi, 0., r->TV);
+  } else {
+    r->TV = DenseMatrix<double>(r->Theta.rows(), Vhat.rows());
+    gemm(Trans::N, Trans::C, 1., r->Theta, Vhat, 0., r->TV);
+  }
+  dims[0] = (int)r->H->child(1)->rows(); dims[1] = (int)r->Theta.cols(); dims[2] = (int)r->Phi.cols();
+  dims[3] = (int)r->DUB01.cols(); dims[4] = (int)Vhat.rows(); dims[5] = (int)Vhat.cols();
+  return 1;
+}
+
+// which: 0 Theta, 1 DUB01, 2 Phi, 3 Vhat; out is column-major with ld = the matrix's rows
+void ref_hss_schur_get(void* h, int which, double* out) {
+  auto* r = static_cast<RefHSS*>(h);
+  const DenseMatrix<double>* M = which == 0 ? &r->Theta : which == 1 ? &r->DUB01 : which == 2 ? &r->Phi
+                                                                       : &r->H->child(0)->ULV().Vhat();
+  for (std::size_t j = 0; j < M->cols(); j++)
+    for (std::size_t i = 0; i < M->rows(); i++) out[i + j * M->rows()] = (*M)(i, j);
+}
+
+// the low-rank update H10 H00^{-1} H01 of the Schur complement as a dense n1 x n1 matrix (FrontHSS.cpp:61-70)
+void ref_hss_schur_update_dense(void* h, double* out) {
+  auto* r = static_cast<RefHSS*>(h);
+  const std::size_t n1 = r->H->child(1)->rows();
+  DenseMatrix<double> U(n1, n1);
+  U.zero();
+  if (r->Theta.cols() < r->Phi.cols()) gemm(Trans::N, Trans::N, 1., r->Theta, r->TV, 0., U);
+  else gemm(Trans::N, Trans::C, 1., r->TV, r->Phi, 0., U);
+  for (std::size_t j = 0; j < n1; j++) std::memcpy(out + j * n1, U.ptr(0, j), sizeof(double) * n1);
+}
+
+// Sr = S R, Sc = S^T R with S = H11 - H10 H00^{-1} H01 (Schur_product_direct, as FrontHSS.cpp:218-219 calls it)
+void ref_hss_schur_product_direct(void* h, int c, const double* R, double* Sr, double* Sc) {
+  auto* r = static_cast<RefHSS*>(h);
+  const std::size_t n1 = r->H->child(1)->rows();
+  DenseMatrix<double> Rd(n1, c, R, n1), Srd(n1, c), Scd(n1, c);
+  r->H->Schur_product_direct(r->Theta, r->DUB01, r->Phi, r->TV, Rd, Srd, Scd);
+  for (int j = 0; j < c; j++) {
+    std::memcpy(Sr + j * n1, Srd.ptr(0, j), sizeof(double) * n1);
+    std::memcpy(Sc + j * n1, Scd.ptr(0, j), sizeof(double) * n1);
+  }
+}
 
 // Reference flop counters (StrumpackParameters.hpp:78-97): out[0..8] =
 // flops, update_sample, reduce_sample, ID, QR, ortho, random, ULV_factor, hss_solve.

@@ -44,6 +44,11 @@ def lib():
         L.ref_hss_mult.argtypes = [C.c_void_p, C.c_char, C.c_int, dp, C.c_int, dp, C.c_int]
         L.ref_hss_solve.argtypes = [C.c_void_p, C.c_int, dp, C.c_int]
         L.ref_hss_shift.argtypes = [C.c_void_p, C.c_double]
+        L.ref_hss_schur_update.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.ref_hss_schur_update.restype = C.c_int
+        L.ref_hss_schur_get.argtypes = [C.c_void_p, C.c_int, dp]
+        L.ref_hss_schur_update_dense.argtypes = [C.c_void_p, dp]
+        L.ref_hss_schur_product_direct.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
         L.ref_randn.argtypes = [C.c_longlong, dp]
         L.ref_fill_test_matrix.argtypes = [C.c_char, C.c_int, dp]
         L.ref_flops.argtypes = [C.POINTER(C.c_longlong), C.c_int]
@@ -127,6 +132,33 @@ class RefHSS:
 
     def shift(self, s):
         lib().ref_hss_shift(self.h, s)
+
+    # ---- Schur complement of the (0,0) block, driven as sparse/fronts/FrontHSS.cpp:391-407 does
+    def schur_update(self):
+        """partial_factor + Schur_update -> dict(Theta, DUB01, Phi, Vhat) or None for a leaf root."""
+        d = (C.c_int * 6)()
+        if not lib().ref_hss_schur_update(self.h, d):
+            return None
+        n1, tc, pc, dc, vr, vc = list(d)
+        self._n1 = n1
+        out = {}
+        for k, (name, shape) in enumerate([("Theta", (n1, tc)), ("DUB01", (pc, dc)), ("Phi", (n1, pc)), ("Vhat", (vr, vc))]):
+            M = np.zeros(shape, order="F")
+            if M.size:
+                lib().ref_hss_schur_get(self.h, k, _dp(M))
+            out[name] = M
+        return out
+
+    def schur_update_dense(self):
+        U = np.zeros((self._n1, self._n1), order="F")
+        lib().ref_hss_schur_update_dense(self.h, _dp(U))
+        return U
+
+    def schur_product_direct(self, R):
+        R = np.asfortranarray(R, dtype=np.float64).reshape(self._n1, -1, order="F")
+        Sr, Sc = np.empty_like(R, order="F"), np.empty_like(R, order="F")
+        lib().ref_hss_schur_product_direct(self.h, R.shape[1], _dp(R), _dp(Sr), _dp(Sc))
+        return Sr, Sc
 
 
 def flops(reset=False):

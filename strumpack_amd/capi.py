@@ -69,6 +69,13 @@ def load(path):
     L.SPX_d_struct_solve_device.argtypes = [vp, C.c_int, dp, C.c_longlong]
     L.SPX_d_struct_node_info.argtypes = [vp, C.POINTER(C.c_int)]
     L.SPX_d_struct_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    ll = C.c_longlong
+    L.SPX_d_struct_partial_factor.argtypes = [vp]
+    L.SPX_d_struct_schur_dims.argtypes = [vp, C.POINTER(C.c_int)]
+    L.SPX_d_struct_schur_update.argtypes = [vp, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int]
+    L.SPX_d_struct_schur_product_direct.argtypes = [vp, C.c_int, dp, ll, dp, ll, dp, ll, C.c_int]
+    L.SPX_d_struct_schur_product_indirect.argtypes = [vp, C.c_int, dp, ll, dp, ll, dp, ll, dp, ll, dp, ll, dp, ll, C.c_int]
+    L.SPX_d_struct_mult_child.argtypes = [vp, C.c_int, C.c_char, C.c_int, dp, ll, dp, ll, C.c_int]
     L.SPX_d_struct_hssk_ctx.argtypes = [vp]
     L.SPX_d_struct_hssk_ctx.restype = vp
     return L
@@ -187,6 +194,57 @@ class StructuredMatrix:
 
     def dense(self):
         return self.mult(np.eye(self.n))
+
+    # ---- Schur complement of the (0,0) block (HSSMatrix::partial_factor / Schur_update / Schur_product_*) ----
+    def partial_factor(self):
+        if self.L.SPX_d_struct_partial_factor(self.h):
+            raise RuntimeError("SPX_d_struct_partial_factor failed")
+
+    def schur_dims(self):
+        d = (C.c_int * 7)()
+        if self.L.SPX_d_struct_schur_dims(self.h, d):
+            raise RuntimeError("SPX_d_struct_schur_dims failed")
+        return dict(zip(("n0", "n1", "rV0", "mu0", "rV1", "rU0", "rU1"), list(d)))
+
+    def schur_update(self):
+        """-> Theta (n1 x rV0), DUB01 (mu0 x rV1), Phi (n1 x mu0), Vhat (mu0 x rV0)"""
+        d = self.schur_dims()
+        mk = lambda r, c: np.zeros((r, c), order="F")
+        Th, DU, Ph, Vh = mk(d["n1"], d["rV0"]), mk(d["mu0"], d["rV1"]), mk(d["n1"], d["mu0"]), mk(d["mu0"], d["rV0"])
+        ld = lambda a: max(a.shape[0], 1)
+        if self.L.SPX_d_struct_schur_update(self.h, Th.ctypes.data, ld(Th), DU.ctypes.data, ld(DU), Ph.ctypes.data, ld(Ph),
+                                            Vh.ctypes.data, ld(Vh)):
+            raise RuntimeError("SPX_d_struct_schur_update failed")
+        return Th, DU, Ph, Vh
+
+    def schur_product_direct(self, R):
+        n1 = self.schur_dims()["n1"]
+        R = np.asfortranarray(R, dtype=np.float64).reshape(n1, -1, order="F")
+        Sr, Sc = np.zeros_like(R, order="F"), np.zeros_like(R, order="F")
+        if self.L.SPX_d_struct_schur_product_direct(self.h, R.shape[1], R.ctypes.data, n1, Sr.ctypes.data, n1, Sc.ctypes.data, n1, 0):
+            raise RuntimeError("SPX_d_struct_schur_product_direct failed")
+        return Sr, Sc
+
+    def schur_product_indirect(self, R0, R1, Sr1, Sc1):
+        d = self.schur_dims()
+        n0, n1 = d["n0"], d["n1"]
+        f = lambda a, n: np.asfortranarray(a, dtype=np.float64).reshape(n, -1, order="F")
+        R0, R1, Sr1, Sc1 = f(R0, n0), f(R1, n1), f(Sr1, n1), f(Sc1, n1)
+        Sr, Sc = np.zeros_like(R1, order="F"), np.zeros_like(R1, order="F")
+        if self.L.SPX_d_struct_schur_product_indirect(self.h, R1.shape[1], R0.ctypes.data, max(n0, 1), R1.ctypes.data, n1,
+                                                      Sr1.ctypes.data, n1, Sc1.ctypes.data, n1, Sr.ctypes.data, n1,
+                                                      Sc.ctypes.data, n1, 0):
+            raise RuntimeError("SPX_d_struct_schur_product_indirect failed")
+        return Sr, Sc
+
+    def mult_child(self, child, B, trans="N"):
+        d = self.schur_dims()
+        n = d["n0"] if child == 0 else d["n1"]
+        B = np.asfortranarray(B, dtype=np.float64).reshape(n, -1, order="F")
+        Cm = np.zeros_like(B, order="F")
+        if self.L.SPX_d_struct_mult_child(self.h, child, trans.encode(), B.shape[1], B.ctypes.data, n, Cm.ctypes.data, n, 0):
+            raise RuntimeError("SPX_d_struct_mult_child failed")
+        return Cm
 
     # ---- introspection ------------------------------------------------------------------------
     def rows(self):

@@ -215,6 +215,67 @@ DenseMatrix<double> HSSMatrix<double>::extract(const std::vector<std::size_t>& I
   return B;
 }
 double HSSMatrix<double>::get(std::size_t i, std::size_t j) const { return extract({i}, {j})(0, 0); }
+void HSSMatrix<double>::extract_add(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseM_t& B) const {
+  if (B.rows() != I.size() || B.cols() != J.size()) throw std::invalid_argument("extract_add: B has the wrong shape");
+  DenseM_t E = extract(I, J);
+  for (std::size_t j = 0; j < J.size(); j++)
+    for (std::size_t i = 0; i < I.size(); i++) B(i, j) += E(i, j);
+}
+
+// ---- Schur complement of the (0,0) block (HSSMatrix.Schur.hpp) ----------------------------------------------
+void HSSMatrix<double>::partial_factor() { eng_->partial_factor(); }
+void HSSMatrix<double>::Schur_update(DenseM_t& Theta, DenseM_t& DUB01, DenseM_t& Phi) const {
+  if (leaf()) return;
+  const auto d = eng_->schur_dims();
+  Theta = DenseM_t(d.n1, d.rV0);
+  DUB01 = DenseM_t(d.mu0, d.rV1);
+  Phi = DenseM_t(d.n1, d.mu0);
+  eng_->schur_update(Theta.data(), Theta.ld(), DUB01.data(), DUB01.ld(), Phi.data(), Phi.ld(), nullptr, 1);
+}
+DenseMatrix<double> HSSMatrix<double>::Vhat() const {
+  if (leaf() || !eng_->is_partially_factored()) throw std::logic_error("Vhat: partial_factor() has not been called");
+  const auto d = eng_->schur_dims();
+  DenseM_t V(d.mu0, d.rV0);
+  const auto& a = eng_->nodes()[eng_->nodes()[0].c0];
+  if (d.mu0 && d.rV0)
+    if (hssk_memcpy2d_d2h(eng_->ctx(), V.data(), sizeof(double) * V.ld(), a.Vt0, sizeof(double) * d.mu0, sizeof(double) * d.mu0, d.rV0))
+      throw std::runtime_error(hssk_last_error());
+  return V;
+}
+void HSSMatrix<double>::Schur_product_direct(const DenseM_t& Theta, const DenseM_t& DUB01, const DenseM_t& Phi,
+                                             const DenseM_t&, const DenseM_t& R, DenseM_t& Sr, DenseM_t& Sc) const {
+  const auto d = eng_->schur_dims();
+  if (Theta.rows() != std::size_t(d.n1) || Theta.cols() != std::size_t(d.rV0) || DUB01.rows() != std::size_t(d.mu0) ||
+      DUB01.cols() != std::size_t(d.rV1) || Phi.rows() != std::size_t(d.n1) || Phi.cols() != std::size_t(d.mu0))
+    throw std::invalid_argument("Schur_product_direct: Theta / DUB01 / Phi are not the matrices returned by Schur_update");
+  if (R.rows() != std::size_t(d.n1)) throw std::invalid_argument("Schur_product_direct: R has the wrong number of rows");
+  if (Sr.rows() != R.rows() || Sr.cols() != R.cols()) Sr = DenseM_t(R.rows(), R.cols());
+  if (Sc.rows() != R.rows() || Sc.cols() != R.cols()) Sc = DenseM_t(R.rows(), R.cols());
+  eng_->schur_product_direct(int(R.cols()), R.data(), R.ld(), Sr.data(), Sr.ld(), Sc.data(), Sc.ld(), false);
+}
+void HSSMatrix<double>::Schur_product_indirect(const DenseM_t& DUB01, const DenseM_t& R0, const DenseM_t& R1,
+                                               const DenseM_t& Sr1, const DenseM_t& Sc1, DenseM_t& Sr, DenseM_t& Sc) const {
+  if (leaf()) return;
+  const auto d = eng_->schur_dims();
+  if (DUB01.rows() != std::size_t(d.mu0) || DUB01.cols() != std::size_t(d.rV1))
+    throw std::invalid_argument("Schur_product_indirect: DUB01 is not the matrix returned by Schur_update");
+  if (R0.rows() != std::size_t(d.n0) || R1.rows() != std::size_t(d.n1) || R0.cols() != R1.cols() ||
+      Sr1.rows() != R1.rows() || Sc1.rows() != R1.rows() || Sr1.cols() != R1.cols() || Sc1.cols() != R1.cols())
+    throw std::invalid_argument("Schur_product_indirect: operand shapes do not match");
+  Sr = DenseM_t(R1.rows(), R1.cols());
+  Sc = DenseM_t(R1.rows(), R1.cols());
+  eng_->schur_product_indirect(int(R1.cols()), R0.data(), R0.ld(), R1.data(), R1.ld(), Sr1.data(), Sr1.ld(), Sc1.data(),
+                               Sc1.ld(), Sr.data(), Sr.ld(), Sc.data(), Sc.ld(), false);
+}
+DenseMatrix<double> HSSMatrix<double>::apply_child(int c, Trans op, const DenseM_t& x) const {
+  if (leaf()) throw std::logic_error("apply_child: the matrix is a single leaf");
+  const auto d = eng_->schur_dims();
+  const std::size_t n = c == 0 ? d.n0 : d.n1;
+  if (x.rows() != n) throw std::invalid_argument("apply_child: x has the wrong number of rows");
+  DenseM_t y(n, x.cols());
+  eng_->mult_child(c, op == Trans::N ? 'N' : 'C', int(x.cols()), x.data(), x.ld(), y.data(), y.ld(), false);
+  return y;
+}
 
 void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
   if (!eng_) return;

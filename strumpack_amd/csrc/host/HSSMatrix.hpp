@@ -75,6 +75,28 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   // H(I, J) and H(i, j) (reference: HSSMatrix.extract.hpp:36-104; here via |J| unit-vector products)
   DenseM_t extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const;
   scalar_t get(std::size_t i, std::size_t j) const;
+  // H(I, J) added into B (HSSMatrix.hpp:430-434, extract_add)
+  void extract_add(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseM_t& B) const;
+  // ---- Schur complement of the (0,0) block, as the sparse HSS fronts use it (sparse/fronts/FrontHSS.cpp:391-407):
+  //   partial_factor(): ULV of child(0) only (HSSMatrix.hpp:330, factor.hpp:43-49)
+  //   Schur_update(Theta, DUB01, Phi): Theta = U1big B10, DUB01 = D00^{-1} U0 B01, Phi = V1big DUB01^H, so that
+  //       H11 - H10 H00^{-1} H01 = H11 - Theta Vhat^H Phi^H        (HSSMatrix.hpp:456, Schur.hpp:40-59)
+  //   Vhat(): child(0)->ULV().Vhat() (HSSExtra.hpp:191)
+  //   Schur_product_direct(...): Sr = S R, Sc = S^H R              (HSSMatrix.hpp:459, Schur.hpp:73-143)
+  //   Schur_product_indirect(...): samples of H -> samples of S    (HSSMatrix.hpp:465, Schur.hpp:145-221)
+  // The factors stay resident in HBM after Schur_update(); the matrices passed back into Schur_product_* must be the
+  // ones it returned (checked by shape) and are not uploaded again.  DUB01 / Phi / Vhat are expressed in this
+  // library's reduced unknowns of block 0, so only products such as Vhat^H DUB01 or Theta Vhat^H Phi^H compare
+  // with the reference's.
+  void partial_factor();
+  void Schur_update(DenseM_t& Theta, DenseM_t& DUB01, DenseM_t& Phi) const;
+  DenseM_t Vhat() const;
+  void Schur_product_direct(const DenseM_t& Theta, const DenseM_t& DUB01, const DenseM_t& Phi,
+                            const DenseM_t& ThetaVhatC_or_VhatCPhiC, const DenseM_t& R, DenseM_t& Sr, DenseM_t& Sc) const;
+  void Schur_product_indirect(const DenseM_t& DUB01, const DenseM_t& R0, const DenseM_t& R1, const DenseM_t& Sr1,
+                              const DenseM_t& Sc1, DenseM_t& Sr, DenseM_t& Sc) const;
+  // y = op(H_cc) x with H_cc the diagonal block of child c (child(c)->apply / applyC, HSSMatrix.hpp:194-202)
+  DenseM_t apply_child(int c, Trans op, const DenseM_t& x) const;
   void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
   // binary file with the compressed representation (tree, D, B, bases; not the ULV factors) and back
   // (HSSMatrix.cpp:438-510; the file layout is this library's own, see hss_engine.cpp)

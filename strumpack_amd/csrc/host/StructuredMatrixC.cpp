@@ -216,6 +216,50 @@ int SPX_d_struct_stats(const CSPStructMat S, double* o) {
   for (int i = 20; i < 24; i++) o[i] = 0;
   SP_CATCH
 }
+// ---- Schur complement of the (0,0) block (HSS only; HSSMatrix.Schur.hpp)
+int SPX_d_struct_partial_factor(CSPStructMat S) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->partial_factor();
+  SP_CATCH
+}
+int SPX_d_struct_schur_dims(const CSPStructMat S, int* out) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  const auto d = hss(S)->engine()->schur_dims();
+  out[0] = d.n0; out[1] = d.n1; out[2] = d.rV0; out[3] = d.mu0; out[4] = d.rV1; out[5] = d.rU0; out[6] = d.rU1;
+  SP_CATCH
+}
+int SPX_d_struct_schur_update(CSPStructMat S, double* Theta, int ldT, double* DUB01, int ldD, double* Phi, int ldP,
+                              double* Vhat, int ldV) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->engine()->schur_update(Theta, ldT, DUB01, ldD, Phi, ldP, Vhat, ldV);
+  SP_CATCH
+}
+int SPX_d_struct_schur_product_direct(const CSPStructMat S, int c, const double* R, long long ldR, double* Sr,
+                                      long long ldSr, double* Sc, long long ldSc, int on_device) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->engine()->schur_product_direct(c, R, ldR, Sr, ldSr, Sc, ldSc, on_device != 0);
+  SP_CATCH
+}
+int SPX_d_struct_schur_product_indirect(const CSPStructMat S, int c, const double* R0, long long ldR0, const double* R1,
+                                        long long ldR1, const double* Sr1, long long ldSr1, const double* Sc1,
+                                        long long ldSc1, double* Sr, long long ldSr, double* Sc, long long ldSc,
+                                        int on_device) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->engine()->schur_product_indirect(c, R0, ldR0, R1, ldR1, Sr1, ldSr1, Sc1, ldSc1, Sr, ldSr, Sc, ldSc, on_device != 0);
+  SP_CATCH
+}
+int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, const double* B, long long ldB, double* C,
+                            long long ldC, int on_device) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->engine()->mult_child(child, trans, m, B, ldB, C, ldC, on_device != 0);
+  SP_CATCH
+}
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S) { return hss(S) ? (void*)hss(S)->engine()->ctx() : nullptr; }
 
 }  // extern "C"

@@ -253,6 +253,7 @@ DeviceHSS::DeviceHSS(int n, const EngineOptions& opts, const structured::Cluster
   tmp_.reset(new Arena(size_t(64) << 20));
   comm_arena_.reset(new Arena(size_t(64) << 20));
   plan_arena_.reset(new Arena(size_t(64) << 20));
+  schur_.reset(new Arena(size_t(64) << 20));
   build_tree(tree);
   setup_ownership();
 }
@@ -266,6 +267,7 @@ DeviceHSS::~DeviceHSS() {
   fact_.reset();
   tmp_.reset();
   comm_arena_.reset();
+  schur_.reset();
   hssk_ctx_destroy(ctx_);
 }
 
@@ -1527,7 +1529,7 @@ void DeviceHSS::shift(double sigma) {
     if (nd.leaf() && nd.D) d.push_back(hssk_shift_desc{nd.D, nd.m, nd.m});
   if (!d.empty()) ck(hssk_shift_diag(ctx_, d.data(), (int)d.size(), sigma));
   ck(hssk_sync(ctx_));
-  factored_ = false;  // the ULV factors are stale (examples/dense/testStructured.cpp:199)
+  factored_ = partial_factored_ = schur_ready_ = false;  // the ULV factors are stale (examples/dense/testStructured.cpp:199)
   drop_plans();
 }
 
@@ -1536,11 +1538,20 @@ void DeviceHSS::shift(double sigma) {
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
                      bool on_device, double beta) {
+  mult_sub(0, trans, nrhs, x, ldx, y, ldy, on_device, beta);
+}
+
+// op(H_sr) x for the HSS sub-matrix rooted at node sr (sr = 0: the whole matrix; sr = a child of the root: the
+// diagonal block H00 / H11 that the reference reaches through child(c)->apply_fwd / apply_bwd, HSSMatrix.Schur.hpp:81-82).
+// x / y have rows(sr) rows.
+void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
+                         bool on_device, double beta) {
   ensure_ready("mult");
   if (nrhs <= 0 || n_ == 0) return;
+  if (sr != 0 && o_.world != 1) throw std::logic_error("mult_sub: sub-matrix products need a single-process matrix");
   double t0 = now();
   const bool T = !(trans == 'N' || trans == 'n');
-  const bool plannable = on_device && o_.world == 1 && plans_enabled();
+  const bool plannable = sr == 0 && on_device && o_.world == 1 && plans_enabled();
   const PlanKey key{0, T ? 'T' : 'N', nrhs, (const void*)x, (void*)y, ldx, ldy, beta};
   if (plannable) {
     auto it = plans_.find(key);
@@ -1557,7 +1568,8 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
   Arena& tmp = rec ? *plan_arena_ : *tmp_;
   if (!rec) tmp.rewind();
-  const int N = n_;
+  const int N = nodes_[sr].m, lo0 = nodes_[sr].lo;
+  const int sr_end = subtree_end(sr);
   const double* dx = x;
   double* dy = y;
   long long lx = ldx, ly = ldy;
@@ -1578,7 +1590,7 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   auto mout = [&](const Node& nd) { return T ? nd.mV : nd.mU; };
   for (size_t i = 0; i < nn; i++) {
     const Node& nd = nodes_[i];
-    if (nd.leaf() || !mine((int)i)) continue;
+    if (nd.leaf() || !mine((int)i) || (int)i < sr || (int)i >= sr_end) continue;
     int ci = rin(nodes_[nd.c0]) + rin(nodes_[nd.c1]);
     int co = rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]);
     cat[i] = tmp.dbl((size_t)std::max(ci, 1) * nrhs);
@@ -1590,12 +1602,12 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
     std::vector<hssk_gemm_desc> mm;
     for (int id : ids) {
       const Node& nd = nodes_[id];
-      if (nd.lvl == 0) continue;
+      if (id == sr) continue;
       const Node& pa = nodes_[nd.parent];
       const int m = min_(nd), r = rin(nd);
       const int* perm = T ? nd.permU : nd.permV;
       const double* X = T ? nd.XU : nd.XV;
-      const double* src = nd.leaf() ? dx + nd.lo : cat[id];
+      const double* src = nd.leaf() ? dx + (nd.lo - lo0) : cat[id];
       const int lds = nd.leaf() ? (int)lx : std::max(m, 1);
       const int pci = rin(nodes_[pa.c0]) + rin(nodes_[pa.c1]);
       double* dst = cat[nd.parent] + (id == pa.c0 ? 0 : rin(nodes_[pa.c0]));
@@ -1623,18 +1635,18 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
       // tmp2 of this node lives in the parent's t buffer
       const double* tmp2 = nullptr;
       int ld2 = 1;
-      if (nd.lvl > 0) {
+      if (id != sr) {
         const Node& pa = nodes_[nd.parent];
         tmp2 = tbuf[nd.parent] + (id == pa.c0 ? 0 : rout(nodes_[pa.c0]));
         ld2 = std::max(rout(nodes_[pa.c0]) + rout(nodes_[pa.c1]), 1);
       }
-      double* out = nd.leaf() ? dy + nd.lo : tbuf[id];
+      double* out = nd.leaf() ? dy + (nd.lo - lo0) : tbuf[id];
       // (the root has no basis, so its mU / mV are unset: size t from the children's ranks)
       const int ldo = nd.leaf() ? (int)ly : std::max(rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]), 1);
-      const bool expand = nd.lvl > 0 && ro > 0;
+      const bool expand = id != sr && ro > 0;
       if (nd.leaf()) {
         // c = D b + beta c (+ U tmp2)
-        leafmm.push_back(hssk_gemm_desc{nd.D, dx + nd.lo, out, nd.m, nrhs, nd.m, nd.m, (int)lx, ldo, T ? 1 : 0, 0, 1.0, beta});
+        leafmm.push_back(hssk_gemm_desc{nd.D, dx + (nd.lo - lo0), out, nd.m, nrhs, nd.m, nd.m, (int)lx, ldo, T ? 1 : 0, 0, 1.0, beta});
       } else {
         const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
         const int ri_a = rin(a), ri_b = rin(b), ro_a = rout(a), ro_b = rout(b);
@@ -1668,7 +1680,9 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
     if (!sc.empty()) ck(hssk_gather_rows(ctx_, sc.data(), (int)sc.size()));
     if (!innermm.empty()) ck(hssk_gemm_vbatched(ctx_, innermm.data(), (int)innermm.size()));
   };
-  for (auto& ids : own_by_height_) up(ids);
+  std::vector<std::vector<int>> sub_h, sub_d;
+  if (sr != 0) { sub_h = sublists(own_by_height_, sr); sub_d = sublists(own_by_depth_, sr); }
+  for (auto& ids : (sr ? sub_h : own_by_height_)) up(ids);
   if (dist_subtree_) {
     // publish tmp1 (rin x nrhs) of the cut nodes into every rank's top buffers
     const int G = o_.world, me = o_.rank;
@@ -1701,7 +1715,7 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
     for (auto& ids : top_by_height_) up(ids);
     for (auto& ids : top_by_depth_) down(ids);
   }
-  for (auto& ids : own_by_depth_) down(ids);
+  for (auto& ids : (sr ? sub_d : own_by_depth_)) down(ids);
   if (dist_subtree_) allgather_rows(dy, ly, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, y, sizeof(double) * ldy, dy, sizeof(double) * N, sizeof(double) * N, nrhs));
   if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
@@ -1712,7 +1726,18 @@ void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, doubl
 // ---------------------------------------------------------------------------------------------
 // ULV factorization (HSSMatrix.factor.hpp:51-147)
 // ---------------------------------------------------------------------------------------------
-void DeviceHSS::factor() {
+void DeviceHSS::factor() { factor_sub(0, false); }
+
+// HSSMatrix::partial_factor (HSSMatrix.factor.hpp:43-49): ULV-factor the (0,0) block only -- child(0) is eliminated as
+// the root of its own subtree -- and keep its reduced column basis Vhat (HSSFactors::Vhat(), HSSExtra.hpp:191) for
+// the Schur complement update of the (1,1) block.
+void DeviceHSS::partial_factor() {
+  if (nodes_[0].leaf()) return;
+  if (o_.world != 1) throw std::logic_error("partial_factor: needs a single-process matrix");
+  factor_sub(nodes_[0].c0, true);
+}
+
+void DeviceHSS::factor_sub(int sr, bool partial) {
   ensure_ready("factor");
   double t0 = now();
   ck(hssk_sync(ctx_));
@@ -1732,7 +1757,7 @@ void DeviceHSS::factor() {
     tmp.rewind();
     for (int id : ids) {
       Node& nd = nodes_[id];
-      const bool root = nd.lvl == 0;
+      const bool root = id == sr;
       const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
       Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
       if (nd.leaf()) {
@@ -1746,7 +1771,7 @@ void DeviceHSS::factor() {
         g0.push_back(hssk_gemm_desc{nd.B10, a.Vt1, Dh[id] + a.rU, b.rU, a.rU, a.rV, std::max(b.rU, 1), std::max(a.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
         stats_.f_ulv += 2.0 * a.rU * (double)b.rU * (a.rV + b.rV);
       }
-      if (!root) {
+      if (!root || partial) {
         Vh[id] = fact_->dbl((size_t)std::max(nd.mU, 1) * std::max(nd.rV, 1));
         if (nd.leaf()) {
           if (nd.rV) bd.push_back(hssk_basis_desc{nd.XV, nd.permV, Vh[id], nd.mV, nd.rV, nd.rV, nd.mV});
@@ -1772,9 +1797,10 @@ void DeviceHSS::factor() {
     std::vector<hssk_lu_desc> lu;
     for (int id : ids) {
       Node& nd = nodes_[id];
-      if (nd.lvl == 0) {
+      if (id == sr) {
         const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
         nd.LU = Dh[id];
+        if (partial) nd.Vt0 = Vh[id];   // Vhat: mu x rV, the column basis in the reduced unknowns
         nd.piv = (int*)fact_->alloc(sizeof(int) * (std::max(mu, 1) + 1));
         if (mu) lu.push_back(hssk_lu_desc{nd.LU, mu, mu, nd.piv, nd.piv + mu});
         stats_.f_ulv += 2.0 / 3.0 * mu * (double)mu * mu;
@@ -1817,13 +1843,301 @@ void DeviceHSS::factor() {
     if (!lu.empty()) ck(hssk_getrf_vbatched(ctx_, lu.data(), (int)lu.size()));
     ck(hssk_sync(ctx_));  // tmp released
   };
-  for (auto& ids : own_by_height_) level(ids);
+  std::vector<std::vector<int>> sub_h;
+  if (sr != 0) sub_h = sublists(own_by_height_, sr);
+  for (auto& ids : (sr ? sub_h : own_by_height_)) level(ids);
   if (dist_subtree_) {
     exchange_cut_factor();
     for (auto& ids : top_by_height_) level(ids);
   }
-  factored_ = true;
+  factored_ = sr == 0;
+  partial_factored_ = partial;
+  schur_ready_ = false;
   stats_.t_factor = now() - t0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sub-tree helpers and the Schur complement of the (0,0) block (HSSMatrix.Schur.hpp)
+// ---------------------------------------------------------------------------------------------
+int DeviceHSS::subtree_end(int sr) const {
+  int id = sr;
+  while (!nodes_[id].leaf()) id = nodes_[id].c1;
+  return id + 1;
+}
+
+std::vector<std::vector<int>> DeviceHSS::sublists(const std::vector<std::vector<int>>& lists, int sr) const {
+  const int end = subtree_end(sr);
+  std::vector<std::vector<int>> out;
+  for (auto& l : lists) {
+    std::vector<int> f;
+    for (int id : l) if (id >= sr && id < end) f.push_back(id);
+    if (!f.empty()) out.push_back(std::move(f));
+  }
+  return out;
+}
+
+void DeviceHSS::mult_child(int c, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
+                           bool on_device) {
+  if (nodes_[0].leaf()) throw std::logic_error("mult_child: the root is a leaf");
+  mult_sub(c == 0 ? nodes_[0].c0 : nodes_[0].c1, trans, nrhs, x, ldx, y, ldy, on_device, 0.0);
+}
+
+void DeviceHSS::basis_up(int sr, bool useU, const double* dA, long long lda, int c, double* dOut, int ldout, Arena& wk) {
+  if (c <= 0) return;
+  if (lda > 0x7fffffffLL) throw std::invalid_argument("basis_up: leading dimension too large");
+  const int lo0 = nodes_[sr].lo, end = subtree_end(sr);
+  auto rk = [&](const Node& nd) { return useU ? nd.rU : nd.rV; };
+  auto rows = [&](const Node& nd) { return nd.leaf() ? nd.m : rk(nodes_[nd.c0]) + rk(nodes_[nd.c1]); };
+  std::vector<double*> cat(nodes_.size(), nullptr);
+  for (int id = sr; id < end; id++)
+    if (!nodes_[id].leaf()) cat[id] = wk.dbl((size_t)std::max(rows(nodes_[id]), 1) * c);
+  for (auto& ids : sublists(by_height_, sr)) {
+    std::vector<hssk_rowgather_desc> g;
+    std::vector<hssk_gemm_desc> mm;
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      const int m = rows(nd), r = rk(nd);
+      if (r == 0) continue;
+      const int* perm = useU ? nd.permU : nd.permV;
+      const double* X = useU ? nd.XU : nd.XV;
+      const double* src = nd.leaf() ? dA + (nd.lo - lo0) : cat[id];
+      const int lds = nd.leaf() ? (int)lda : std::max(m, 1);
+      double* dst = dOut;
+      int ldd = ldout;
+      if (id != sr) {
+        const Node& pa = nodes_[nd.parent];
+        dst = cat[nd.parent] + (id == pa.c0 ? 0 : rk(nodes_[pa.c0]));
+        ldd = std::max(rows(pa), 1);
+      }
+      g.push_back(hssk_rowgather_desc{src, dst, perm, r, c, lds, ldd, 0, 0});
+      if (m > r) {
+        double* Tm = wk.dbl((size_t)(m - r) * c);
+        g.push_back(hssk_rowgather_desc{src, Tm, perm + r, m - r, c, lds, m - r, 0, 0});
+        mm.push_back(hssk_gemm_desc{X, Tm, dst, r, c, m - r, r, m - r, ldd, 0, 0, 1.0, 1.0});
+      }
+    }
+    if (!g.empty()) ck(hssk_gather_rows(ctx_, g.data(), (int)g.size()));
+    if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
+  }
+}
+
+void DeviceHSS::basis_down(int sr, bool useU, const double* dIn, int ldin, int c, double* dOut, long long ldo, Arena& wk,
+                           bool recurse) {
+  if (c <= 0) return;
+  if (ldo > 0x7fffffffLL) throw std::invalid_argument("basis_down: leading dimension too large");
+  const int lo0 = nodes_[sr].lo;
+  auto rk = [&](const Node& nd) { return useU ? nd.rU : nd.rV; };
+  auto rows = [&](const Node& nd) { return nd.leaf() ? nd.m : rk(nodes_[nd.c0]) + rk(nodes_[nd.c1]); };
+  std::vector<double*> t(nodes_.size(), nullptr);
+  std::vector<std::vector<int>> lists;
+  if (recurse) lists = sublists(by_depth_, sr);
+  else lists.push_back(std::vector<int>{sr});
+  for (auto& ids : lists) {
+    std::vector<hssk_rowgather_desc> sc;
+    std::vector<hssk_gemm_desc> mm, zero;
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      const int mo = rows(nd), r = rk(nd);
+      if (mo == 0) continue;
+      double* out;
+      int ld;
+      if (nd.leaf() || !recurse) {
+        out = dOut + (recurse ? nd.lo - lo0 : 0);
+        ld = (int)ldo;
+      } else {
+        out = t[id] = wk.dbl((size_t)mo * c);
+        ld = mo;
+      }
+      const double* in = dIn;
+      int ldi = ldin;
+      if (id != sr) {
+        const Node& pa = nodes_[nd.parent];
+        in = t[nd.parent] + (id == pa.c0 ? 0 : rk(nodes_[pa.c0]));
+        ldi = std::max(rows(pa), 1);
+      }
+      if (r == 0) {   // no basis: this block row of the product is zero (Schur.hpp:262, :269)
+        zero.push_back(hssk_gemm_desc{out, out, out, mo, c, 0, ld, 1, ld, 0, 0, 0.0, 0.0});
+        continue;
+      }
+      const int* perm = useU ? nd.permU : nd.permV;
+      const double* X = useU ? nd.XU : nd.XV;
+      // out(perm[:r]) = in ; out(perm[r:]) = X^T in      (HSSBasisID::apply)
+      sc.push_back(hssk_rowgather_desc{in, out, perm, r, c, ldi, ld, 1, 0});
+      if (mo > r) {
+        double* E2 = wk.dbl((size_t)(mo - r) * c);
+        mm.push_back(hssk_gemm_desc{X, in, E2, mo - r, c, r, r, ldi, mo - r, 1, 0, 1.0, 0.0});
+        sc.push_back(hssk_rowgather_desc{E2, out, perm + r, mo - r, c, mo - r, ld, 1, 0});
+      }
+    }
+    if (!zero.empty()) ck(hssk_gemm_vbatched(ctx_, zero.data(), (int)zero.size()));
+    if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
+    if (!sc.empty()) ck(hssk_gather_rows(ctx_, sc.data(), (int)sc.size()));
+  }
+}
+
+DeviceHSS::SchurDims DeviceHSS::schur_dims() const {
+  SchurDims d;
+  if (nodes_[0].leaf()) return d;
+  const Node &a = nodes_[nodes_[0].c0], &b = nodes_[nodes_[0].c1];
+  d.n0 = a.m; d.n1 = b.m;
+  d.rV0 = a.rV; d.rU0 = a.rU; d.rV1 = b.rV; d.rU1 = b.rU;
+  d.mu0 = a.leaf() ? a.m : nodes_[a.c0].rU + nodes_[a.c1].rU;
+  return d;
+}
+
+void DeviceHSS::schur_update(double* Theta, long long ldt, double* DUB01, long long ldd, double* Phi, long long ldp,
+                             double* Vhat, long long ldv) {
+  ensure_ready("Schur_update");
+  if (nodes_[0].leaf()) return;    // Schur.hpp:42
+  if (!partial_factored_) throw std::logic_error("Schur_update: partial_factor() has not been called");
+  const Node& root = nodes_[0];
+  const Node &a = nodes_[root.c0], &b = nodes_[root.c1];
+  const SchurDims d = schur_dims();
+  ck(hssk_sync(ctx_));
+  schur_->rewind();
+  Arena wk;
+  auto L = [](int x) { return std::max(x, 1); };
+  sDUB01_ = schur_->dbl((size_t)L(d.mu0) * L(d.rV1));
+  sTheta_ = schur_->dbl((size_t)L(d.n1) * L(d.rV0));
+  sPhi_ = schur_->dbl((size_t)L(d.n1) * L(d.mu0));
+  sVtDUB01_ = schur_->dbl((size_t)L(d.rV0) * L(d.rV1));
+  sW_ = schur_->dbl((size_t)L(d.rU1) * L(d.rV1));
+  // DUB01 = D00^{-1} (U0 B01)                                         (Schur.hpp:46-48)
+  basis_down(root.c0, true, root.B01, L(d.rU0), d.rV1, sDUB01_, L(d.mu0), wk, false);
+  if (d.mu0 && d.rV1) {
+    hssk_lusolve_desc ls{a.LU, a.piv, sDUB01_, d.mu0, d.rV1, d.mu0, L(d.mu0)};
+    ck(hssk_getrs_vbatched(ctx_, &ls, 1));
+  }
+  // Theta = U1big B10 ; Phi = V1big DUB01^T                          (Schur.hpp:52-58)
+  basis_down(root.c1, true, root.B10, L(d.rU1), d.rV0, sTheta_, L(d.n1), wk);
+  double* Dt = wk.dbl((size_t)L(d.rV1) * L(d.mu0));
+  if (d.mu0 && d.rV1) {
+    hssk_transpose_desc tr{sDUB01_, Dt, d.mu0, d.rV1, L(d.mu0), L(d.rV1)};
+    ck(hssk_transpose(ctx_, &tr, 1));
+  }
+  basis_down(root.c1, false, Dt, L(d.rV1), d.mu0, sPhi_, L(d.n1), wk);
+  // small products reused by every Schur_product_*: Vhat^T DUB01 (rV0 x rV1) and W = B10 Vhat^T DUB01 (rU1 x rV1)
+  std::vector<hssk_gemm_desc> g;
+  g.push_back(hssk_gemm_desc{a.Vt0, sDUB01_, sVtDUB01_, d.rV0, d.rV1, d.mu0, L(d.mu0), L(d.mu0), L(d.rV0), 1, 0, 1.0, 0.0});
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 1));
+  g[0] = hssk_gemm_desc{root.B10, sVtDUB01_, sW_, d.rU1, d.rV1, d.rV0, L(d.rU1), L(d.rV0), L(d.rU1), 0, 0, 1.0, 0.0};
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 1));
+  ck(hssk_sync(ctx_));
+  schur_ready_ = true;
+  auto get = [&](double* h, long long ldh, const double* dsrc, int rows, int cols) {
+    if (h && rows > 0 && cols > 0)
+      ck(hssk_memcpy2d_d2h(ctx_, h, sizeof(double) * ldh, dsrc, sizeof(double) * rows, sizeof(double) * rows, cols));
+  };
+  get(Theta, ldt, sTheta_, d.n1, d.rV0);
+  get(DUB01, ldd, sDUB01_, d.mu0, d.rV1);
+  get(Phi, ldp, sPhi_, d.n1, d.mu0);
+  get(Vhat, ldv, a.Vt0, d.mu0, d.rV0);
+}
+
+void DeviceHSS::schur_product_direct(int c, const double* R, long long ldr, double* Sr, long long ldsr, double* Sc,
+                                     long long ldsc, bool on_device) {
+  if (!schur_ready_) throw std::logic_error("Schur_product_direct: Schur_update() has not been called");
+  if (c <= 0) return;
+  const Node& root = nodes_[0];
+  const Node& a = nodes_[root.c0];
+  const SchurDims d = schur_dims();
+  Arena wk;
+  auto L = [](int x) { return std::max(x, 1); };
+  const int n1 = d.n1;
+  const double* dR = R;
+  double *dSr = Sr, *dSc = Sc;
+  long long lr = ldr, lsr = ldsr, lsc = ldsc;
+  if (!on_device) {
+    double* b = wk.dbl((size_t)n1 * c);
+    ck(hssk_memcpy2d_h2d(ctx_, b, sizeof(double) * n1, R, sizeof(double) * ldr, sizeof(double) * n1, c));
+    dR = b; dSr = wk.dbl((size_t)n1 * c); dSc = wk.dbl((size_t)n1 * c);
+    lr = lsr = lsc = n1;
+  }
+  if (lsr > 0x7fffffffLL || lsc > 0x7fffffffLL) throw std::invalid_argument("Schur_product_direct: leading dimension too large");
+  // Sr = H11 R, Sc = H11^T R; the basis products V1big^T R / U1big^T R are the forward halves of those applies
+  mult_sub(root.c1, 'N', c, dR, lr, dSr, lsr, true, 0.0);
+  mult_sub(root.c1, 'T', c, dR, lr, dSc, lsc, true, 0.0);
+  double* V1tR = wk.dbl((size_t)L(d.rV1) * c);
+  double* U1tR = wk.dbl((size_t)L(d.rU1) * c);
+  basis_up(root.c1, false, dR, lr, c, V1tR, L(d.rV1), wk);
+  basis_up(root.c1, true, dR, lr, c, U1tR, L(d.rU1), wk);
+  // Sr -= Theta (Vhat^T DUB01) (V1big^T R) ;  Sc -= Phi Vhat B10^T (U1big^T R)        (Schur.hpp:60-71)
+  double* t1 = wk.dbl((size_t)L(d.rV0) * c);
+  double* t2 = wk.dbl((size_t)L(d.rV0) * c);
+  double* t3 = wk.dbl((size_t)L(d.mu0) * c);
+  std::vector<hssk_gemm_desc> g(2);
+  g[0] = hssk_gemm_desc{sVtDUB01_, V1tR, t1, d.rV0, c, d.rV1, L(d.rV0), L(d.rV1), L(d.rV0), 0, 0, 1.0, 0.0};
+  g[1] = hssk_gemm_desc{root.B10, U1tR, t2, d.rV0, c, d.rU1, L(d.rU1), L(d.rU1), L(d.rV0), 1, 0, 1.0, 0.0};
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 2));
+  g[0] = hssk_gemm_desc{a.Vt0, t2, t3, d.mu0, c, d.rV0, L(d.mu0), L(d.rV0), L(d.mu0), 0, 0, 1.0, 0.0};
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 1));
+  g[0] = hssk_gemm_desc{sTheta_, t1, dSr, n1, c, d.rV0, L(n1), L(d.rV0), (int)lsr, 0, 0, -1.0, 1.0};
+  g[1] = hssk_gemm_desc{sPhi_, t3, dSc, n1, c, d.mu0, L(n1), L(d.mu0), (int)lsc, 0, 0, -1.0, 1.0};
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 2));
+  if (!on_device) {
+    ck(hssk_memcpy2d_d2h(ctx_, Sr, sizeof(double) * ldsr, dSr, sizeof(double) * n1, sizeof(double) * n1, c));
+    ck(hssk_memcpy2d_d2h(ctx_, Sc, sizeof(double) * ldsc, dSc, sizeof(double) * n1, sizeof(double) * n1, c));
+  }
+  ck(hssk_sync(ctx_));
+}
+
+void DeviceHSS::schur_product_indirect(int c, const double* R0, long long ldr0, const double* R1, long long ldr1,
+                                       const double* Sr1, long long ldsr1, const double* Sc1, long long ldsc1,
+                                       double* Sr, long long ldsr, double* Sc, long long ldsc, bool on_device) {
+  if (nodes_[0].leaf()) return;   // Schur.hpp:158
+  if (!schur_ready_) throw std::logic_error("Schur_product_indirect: Schur_update() has not been called");
+  if (c <= 0) return;
+  const Node& root = nodes_[0];
+  const SchurDims d = schur_dims();
+  Arena wk;
+  auto L = [](int x) { return std::max(x, 1); };
+  const int n0 = d.n0, n1 = d.n1;
+  const double *dR0 = R0, *dR1 = R1;
+  double *dSr = Sr, *dSc = Sc;
+  long long l0 = ldr0, l1 = ldr1, lsr = ldsr, lsc = ldsc;
+  auto up = [&](const double* h, long long ldh, int rows) {
+    double* b = wk.dbl((size_t)L(rows) * c);
+    if (rows) ck(hssk_memcpy2d_h2d(ctx_, b, sizeof(double) * rows, h, sizeof(double) * ldh, sizeof(double) * rows, c));
+    return b;
+  };
+  if (!on_device) {
+    dR0 = up(R0, ldr0, n0); dR1 = up(R1, ldr1, n1);
+    dSr = up(Sr1, ldsr1, n1); dSc = up(Sc1, ldsc1, n1);
+    l0 = n0; l1 = lsr = lsc = n1;
+  } else {
+    // start from Sr1 / Sc1
+    if (Sr != Sr1) { hssk_rowgather_desc cp{Sr1, Sr, nullptr, n1, c, (int)ldsr1, (int)ldsr, 0, 0}; ck(hssk_gather_rows(ctx_, &cp, 1)); }
+    if (Sc != Sc1) { hssk_rowgather_desc cp{Sc1, Sc, nullptr, n1, c, (int)ldsc1, (int)ldsc, 0, 0}; ck(hssk_gather_rows(ctx_, &cp, 1)); }
+  }
+  double* V0tR0 = wk.dbl((size_t)L(d.rV0) * c);
+  double* U0tR0 = wk.dbl((size_t)L(d.rU0) * c);
+  double* V1tR1 = wk.dbl((size_t)L(d.rV1) * c);
+  double* U1tR1 = wk.dbl((size_t)L(d.rU1) * c);
+  basis_up(root.c0, false, dR0, l0, c, V0tR0, L(d.rV0), wk);
+  basis_up(root.c0, true, dR0, l0, c, U0tR0, L(d.rU0), wk);
+  basis_up(root.c1, false, dR1, l1, c, V1tR1, L(d.rV1), wk);
+  basis_up(root.c1, true, dR1, l1, c, U1tR1, L(d.rU1), wk);
+  // P = -(B10 V0big^T R0 + W V1big^T R1)  (rU1 x c) ; Q = -(B01^T U0big^T R0 + W^T U1big^T R1)  (rV1 x c)
+  double* P = wk.dbl((size_t)L(d.rU1) * c);
+  double* Q = wk.dbl((size_t)L(d.rV1) * c);
+  std::vector<hssk_gemm_desc> g(2);
+  g[0] = hssk_gemm_desc{root.B10, V0tR0, P, d.rU1, c, d.rV0, L(d.rU1), L(d.rV0), L(d.rU1), 0, 0, -1.0, 0.0};
+  g[1] = hssk_gemm_desc{root.B01, U0tR0, Q, d.rV1, c, d.rU0, L(d.rU0), L(d.rU0), L(d.rV1), 1, 0, -1.0, 0.0};
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 2));
+  g[0] = hssk_gemm_desc{sW_, V1tR1, P, d.rU1, c, d.rV1, L(d.rU1), L(d.rV1), L(d.rU1), 0, 0, -1.0, 1.0};
+  g[1] = hssk_gemm_desc{sW_, U1tR1, Q, d.rV1, c, d.rU1, L(d.rU1), L(d.rU1), L(d.rV1), 1, 0, -1.0, 1.0};
+  ck(hssk_gemm_vbatched(ctx_, g.data(), 2));
+  // Sr = Sr1 + U1big P ; Sc = Sc1 + V1big Q                           (Schur.hpp:213-218)
+  double* E = wk.dbl((size_t)L(n1) * c);
+  basis_down(root.c1, true, P, L(d.rU1), c, E, L(n1), wk);
+  { hssk_rowgather_desc ad{E, dSr, nullptr, n1, c, L(n1), (int)lsr, 0, 1}; ck(hssk_gather_rows(ctx_, &ad, 1)); }
+  basis_down(root.c1, false, Q, L(d.rV1), c, E, L(n1), wk);
+  { hssk_rowgather_desc ad{E, dSc, nullptr, n1, c, L(n1), (int)lsc, 0, 1}; ck(hssk_gather_rows(ctx_, &ad, 1)); }
+  if (!on_device) {
+    ck(hssk_memcpy2d_d2h(ctx_, Sr, sizeof(double) * ldsr, dSr, sizeof(double) * n1, sizeof(double) * n1, c));
+    ck(hssk_memcpy2d_d2h(ctx_, Sc, sizeof(double) * ldsc, dSc, sizeof(double) * n1, sizeof(double) * n1, c));
+  }
+  ck(hssk_sync(ctx_));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -92,6 +92,28 @@ class DeviceHSS {
   void solve(int nrhs, double* b, long long ldb, bool on_device);
   void shift(double sigma);
 
+  // ---- Schur complement of the (0,0) block, H11 - H10 H00^{-1} H01 (HSSMatrix.Schur.hpp, factor.hpp:43-49);
+  //      single-process matrices with a non-leaf root.  After partial_factor() + schur_update() the factors
+  //      Theta = U1big B10 (n1 x rV0), DUB01 = D00^{-1} U0 B01 (mu0 x rV1), Phi = V1big DUB01^T (n1 x mu0) and
+  //      Vhat (mu0 x rV0) stay resident in HBM:  S = H11 - Theta Vhat^T Phi^T.
+  struct SchurDims { int n0 = 0, n1 = 0, rV0 = 0, rU0 = 0, rV1 = 0, rU1 = 0, mu0 = 0; };
+  void partial_factor();
+  bool is_partially_factored() const { return partial_factored_; }
+  SchurDims schur_dims() const;
+  // computes the factors on the device; every non-null HOST pointer receives a copy (column-major)
+  void schur_update(double* Theta, long long ldt, double* DUB01, long long ldd, double* Phi, long long ldp,
+                    double* Vhat, long long ldv);
+  // Sr = S R, Sc = S^T R  (R, Sr, Sc: n1 x c)                      (Schur_product_direct, Schur.hpp:73-143)
+  void schur_product_direct(int c, const double* R, long long ldr, double* Sr, long long ldsr, double* Sc,
+                            long long ldsc, bool on_device);
+  // Sr = Sr1 - H10 R0 - (H11 - S) R1, Sc = Sc1 - H01^T R0 - (H11 - S)^T R1   (Schur_product_indirect, :145-221):
+  // turns samples of the whole matrix into samples of the Schur complement
+  void schur_product_indirect(int c, const double* R0, long long ldr0, const double* R1, long long ldr1,
+                              const double* Sr1, long long ldsr1, const double* Sc1, long long ldsc1, double* Sr,
+                              long long ldsr, double* Sc, long long ldsc, bool on_device);
+  // rows of the (c)-th child's sub-matrix applied to x: y = op(H_cc) x  (child(c)->apply)
+  void mult_child(int c, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device);
+
   // ---- introspection ----
   int rows() const { return n_; }
   bool is_compressed() const;
@@ -154,6 +176,17 @@ class DeviceHSS {
                   std::vector<char>& resolved);
   void free_compress_workspace();
   void ensure_ready(const char* what) const;
+  // ---- sub-tree variants (node sr as the root of its own HSS matrix)
+  int subtree_end(int sr) const;   // pre-order ids [sr, end)
+  std::vector<std::vector<int>> sublists(const std::vector<std::vector<int>>& lists, int sr) const;
+  void mult_sub(int sr, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
+                bool on_device, double beta);
+  void factor_sub(int sr, bool partial);
+  // out (rank(sr) x c) = Ubig^T A or Vbig^T A  (apply_UtVt_big, Schur.hpp:223-252)
+  void basis_up(int sr, bool useU, const double* dA, long long lda, int c, double* dOut, int ldout, Arena& wk);
+  // out (rows(sr) x c) = Ubig in or Vbig in (apply_UV_big, Schur.hpp:254-323); !recurse: sr's own basis only
+  void basis_down(int sr, bool useU, const double* dIn, int ldin, int c, double* dOut, long long ldo, Arena& wk,
+                  bool recurse = true);
   // sweep plans: an apply / solve repeated on the same device buffers is recorded once (hssk_plan_*) and replayed
   struct PlanKey {
     int op; char trans; int nrhs; const void* x; void* y; long long ldx, ldy; double beta;
@@ -194,7 +227,9 @@ class DeviceHSS {
   int dcap_ = 0;
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
   int* d_ranks_ = nullptr;
-  bool factored_ = false;
+  bool factored_ = false, partial_factored_ = false, schur_ready_ = false;
+  std::unique_ptr<Arena> schur_;
+  double *sTheta_ = nullptr, *sPhi_ = nullptr, *sDUB01_ = nullptr, *sVtDUB01_ = nullptr, *sW_ = nullptr;
   PhaseStats stats_;
   std::shared_ptr<HostRng> rng_;
 };

@@ -106,6 +106,45 @@ int main(int argc, char* argv[]) {
   auto R = H.apply(X);
   R.scaled_add(-1., B);
   if (R.normF() / B.normF() > SOLVE_TOLERANCE) { std::cout << "ERROR: solve after shift failed" << std::endl; return 1; }
+
+  if (!H.leaf()) {
+    // test_HSS_seq.cpp:252-260, plus the check the reference leaves as a TODO: with H z = [0; y] the Schur
+    // complement S of the (0,0) block satisfies S z1 = y (and S^T likewise through the transposed system)
+    DenseMatrix<double> z(m, 1);
+    z.random();
+    H.partial_factor();
+    std::cout << "# Computing Schur update .." << std::endl;
+    DenseMatrix<double> Theta, Phi, DUB01;
+    H.Schur_update(Theta, DUB01, Phi);
+    const std::size_t n1 = Theta.rows(), n0 = m - n1;
+    auto Vhat = H.Vhat();
+    if (Vhat.rows() != DUB01.rows() || Vhat.cols() != Theta.cols() || Phi.cols() != DUB01.rows()) {
+      std::cout << "ERROR: Schur update shapes are inconsistent" << std::endl;
+      return 1;
+    }
+    DenseMatrix<double> z0(n0, 1), z1(n1, 1), Sr, Sc, TV;
+    for (std::size_t i = 0; i < n0; i++) z0(i, 0) = z(i, 0);
+    for (std::size_t i = 0; i < n1; i++) z1(i, 0) = z(n0 + i, 0);
+    H.Schur_product_direct(Theta, DUB01, Phi, TV, z1, Sr, Sc);
+    // samples of H and H^T at z -> samples of S at z1 (indirect), must agree with the direct product
+    auto Hz = H.apply(z), Htz = H.applyC(z);
+    DenseMatrix<double> Sr1(n1, 1), Sc1(n1, 1), Sr2, Sc2;
+    for (std::size_t i = 0; i < n1; i++) { Sr1(i, 0) = Hz(n0 + i, 0); Sc1(i, 0) = Htz(n0 + i, 0); }
+    H.Schur_product_indirect(DUB01, z0, z1, Sr1, Sc1, Sr2, Sc2);
+    Sr2.scaled_add(-1., Sr);
+    Sc2.scaled_add(-1., Sc);
+    std::cout << "# Schur products, direct vs indirect = " << Sr2.normF() / Sr.normF() << " , " << Sc2.normF() / Sc.normF() << std::endl;
+    if (Sr2.normF() > 1e-10 * Sr.normF() || Sc2.normF() > 1e-10 * Sc.normF()) { std::cout << "ERROR: Schur products disagree" << std::endl; return 1; }
+    // S^{-1} y is the lower part of H^{-1} [0; y]
+    H.factor();
+    DenseMatrix<double> rhs(m, 1);
+    for (std::size_t i = 0; i < n1; i++) rhs(n0 + i, 0) = Sr(i, 0);
+    H.solve(rhs);
+    double num = 0, den = 0;
+    for (std::size_t i = 0; i < n1; i++) { num += (rhs(n0 + i, 0) - z1(i, 0)) * (rhs(n0 + i, 0) - z1(i, 0)); den += z1(i, 0) * z1(i, 0); }
+    std::cout << "# ||S^{-1} (S z1) - z1|| / ||z1|| = " << std::sqrt(num / den) << std::endl;
+    if (std::sqrt(num / den) > 1e-9) { std::cout << "ERROR: Schur complement is not consistent with the ULV solve" << std::endl; return 1; }
+  }
   std::cout << "# exiting" << std::endl;
   return 0;
 }

@@ -22,6 +22,11 @@ def test_ctest_case(L, name):
     HC.check_against_golden(L, CASES[name])
 
 
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_8", "HSS_seq_11", "HSS_seq_14", "HSS_seq_5"])
+def test_schur_complement(L, name):
+    HC.check_schur(L, CASES[name])
+
+
 def test_api_semantics(L):
     HC.check_api_semantics(L)
 

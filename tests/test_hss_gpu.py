@@ -24,6 +24,13 @@ def test_ctest_case(L, name):
     HC.check_against_golden(L, c, compare_oracle=c["n"] <= 4096)
 
 
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_5", "HSS_seq_8", "HSS_seq_11", "HSS_seq_12",
+                                  "HSS_seq_14", "HSS_seq_22", "config1_T4096_defaults",
+                                  "config2shape_T8192_leaf256_rtol1e-4"])
+def test_schur_complement(L, name):
+    HC.check_schur(L, CASES[name], dense_check=CASES[name]["n"] <= 4096)
+
+
 def test_api_semantics(L):
     HC.check_api_semantics(L)
 
