@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--nrhs", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-n", type=int, default=32768)
+    p.add_argument("--sketch", choices=["gaussian", "sjlt"], default="gaussian",
+                   help="gaussian = the reference's default (BASELINE's metric is quoted on it); sjlt = its "
+                        "--hss_compression_sketch SJLT option (nnz = 4), a separate, HBM-bound workload")
     p.add_argument("--workload", choices=["toeplitz", "kernel"], default="toeplitz",
                    help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
                         "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line")
@@ -172,7 +175,7 @@ def main():
     hk.check(hk.lib.hssk_randn(hk.ctx, dB.ptr, n, a.nrhs, n, 0, a.nrhs, 7))
     hk.sync()
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
-    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox")
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch)
     exch = sdist.make_exchange(L, world, rank) if world > 1 else None
 
     def step():
@@ -270,9 +273,10 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %dx%d double Toeplitz HSS, randomized compression "
-                               "(d0+dd=128+64, Philox samples), leaf=%d, rel_tol=%g, compress + ULV factor + solve (nrhs=%d)"
-                               % (n, n, a.leaf, a.rel_tol, a.nrhs),
-                   "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
+                               "(d0+dd=128+64, %s), leaf=%d, rel_tol=%g, compress + ULV factor + solve (nrhs=%d)"
+                               % (n, n, "Philox samples" if a.sketch == "gaussian" else "SJLT sketch, nnz=4: NOT the configuration of BASELINE's metric",
+                                  a.leaf, a.rel_tol, a.nrhs),
+                   "sketch": a.sketch, "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
                    "parallelism": "1 GPU" if world == 1 else "HSS tree partitioned by subtree over %d GPUs (sketch rows, compression, ULV, sweeps local; RCCL all-gathers of the cut-level blocks; top %d nodes replicated)" % (world, world - 1)},
         "phases_s": {"compress": st["t_compress"], "sketch": st["t_sketch"], "random": st["t_random"],
                      "tree": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
@@ -288,6 +292,13 @@ def main():
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                      "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
+    if a.sketch == "sjlt" and st["sketch_kernel_bytes"] > 0 and avg_ms > 0:
+        # the SJLT products stream A once: algorithmic bytes per launch = 8 N^2 (per-rank share when sharded)
+        bpl = st["sketch_kernel_bytes"] / launches
+        gbs = bpl / (avg_ms * 1e-3) * 1e-9
+        out["roofline"] = {"kernel": "sjlt_n_kernel / sjlt_t_kernel (S^T = (op(A) R)^T, R with 4 entries +-1 per row)",
+                           "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                           "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches, "bytes_per_launch": bpl}
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.leaf, a.rel_tol)

@@ -185,6 +185,18 @@ typedef struct hssk_triu_desc {
 } hssk_triu_desc;
 int hssk_copy_triu(hssk_ctx* ctx, const hssk_triu_desc* descs, int count);
 
+/* ---- sparse Johnson-Lindenstrauss sketch ---------------------------------------------------------------
+ * The reference's --hss_compression_sketch SJLT (HSS/HSSMatrix.sketch.hpp; compress_stable.hpp:39-97): the sketching
+ * matrix R (K x dn) has nnz entries +-1 per row.  pat (DEVICE, nnz x K ints, K contiguous): pat[q * K + k] = column
+ * index of the q-th nonzero of row k, sign bit set for -1.
+ * hssk_sjlt_dense: Rt (dn x K, ld) = R^T as a dense block (SJLTMatrix::SJLT_to_dense, sketch.hpp:573-596).
+ * hssk_sjlt_sketch: St (dn x n_out, lds) = (op(A) R)^T with op(A) n_out x K: transA = 0: A(i, k) = A[i + k lda]
+ * (matrix_times_SJLT, sketch.hpp:611-721), transA = 1: A(k, j) = A[k + j lda] (matrixT_times_SJLT, :723-809).
+ * One pass over A (8 bytes per element), nnz LDS adds per element; nnz <= 8, dn <= 1024. */
+int hssk_sjlt_dense(hssk_ctx* ctx, double* Rt, int dn, long long K, long long ld, const int* pat, int nnz);
+int hssk_sjlt_sketch(hssk_ctx* ctx, int transA, long long n_out, long long K, const double* A, long long lda,
+                     const int* pat, int nnz, int dn, double* St, long long lds);
+
 /* ---- batched interpolative decomposition ------------------------------------------------------- */
 /* Truncated column-pivoted Householder QR of W (d x m, column-major, overwritten), i.e. the row ID
  * of the m x d sample block:  DenseMatrix::ID_row -> ID_column_GEQP3 -> geqp3tol + trsm

@@ -67,6 +67,9 @@ typedef struct SPXHSSOptions {
   int compression_algorithm; /* 0 original, 1 stable */
   int random_engine;         /* 0 minstd_rand (reference default), 1 mt19937, 2 philox (device) */
   int random_distribution;   /* 0 normal, 1 uniform */
+  /* sketching matrix (HSS/HSSOptions.hpp:110-133): 0 Gaussian, 1 SJLT (nnz entries +-1 per row); SJLT placement
+   * 0 chunk / 1 perm; nonzeros per row in the first d0 + dd columns (nnz0) and in every further dd columns (nnz) */
+  int compression_sketch, sjlt_algo, nnz0, nnz;
 } SPXHSSOptions;
 void SPX_d_struct_default_hss_options(SPXHSSOptions* h);
 /* like SP_d_struct_from_dense, with explicit HSS options (h may be NULL) */
@@ -110,7 +113,8 @@ int SPX_d_struct_node_info(const CSPStructMat S, int* out);
  * [0] t_compress [1] t_sketch [2] t_random [3] t_tree [4] t_factor [5] t_solve [6] t_mult
  * [7] sketch_kernel_ms [8] sketch_launches [9] rounds [10] d_final
  * [11] f_sketch [12] f_local [13] f_reduce [14] f_id [15] f_ortho [16] f_ulv [17] f_solve
- * [18] factor_memory_bytes [19] sketch_kernel_flops (algorithmic flops of the launches timed in [7]) */
+ * [18] factor_memory_bytes [19] sketch_kernel_flops (algorithmic flops of the launches timed in [7])
+ * [20] sketch_kernel_bytes (SJLT sketch: algorithmic HBM bytes of those launches) */
 int SPX_d_struct_stats(const CSPStructMat S, double* out);
 /* ---- Schur complement of the (0,0) block of an HSS matrix: S = H11 - H10 H00^{-1} H01 -- what the reference's sparse
  * HSS fronts call on HSSMatrix<T> (HSS/HSSMatrix.hpp:330 partial_factor, :456 Schur_update, :459 Schur_product_direct,

@@ -94,6 +94,22 @@ void* ref_hss_create(int n, const double* A, int lda, double rel_tol, double abs
   return r;
 }
 
+// the SJLT sketch (--hss_compression_sketch SJLT, test/CMakeLists.txt:145-159): the reference seeds its pattern
+// generator from the clock (HSSMatrix.sketch.hpp:266-270), so repeated calls give different matrices
+void* ref_hss_create_sjlt(int n, const double* A, int lda, double rel_tol, double abs_tol, int leaf,
+                          int d0, int dd, int algo, int perm, int nnz0, int nnz) {
+  auto o = make_opts(rel_tol, abs_tol, leaf, d0, dd, 10, 50000, algo);
+  o.set_compression_sketch(CompressionSketch::SJLT);
+  o.set_SJLT_algo(perm ? SJLTAlgo::PERM : SJLTAlgo::CHUNK);
+  o.set_nnz0(nnz0);
+  o.set_nnz(nnz);
+  DenseMatrix<double> Ad(n, n, A, lda);
+  auto* r = new RefHSS;
+  r->n = n;
+  r->H.reset(new HSSMatrix<double>(Ad, o));
+  return r;
+}
+
 void ref_hss_destroy(void* h) { delete static_cast<RefHSS*>(h); }
 int ref_hss_is_compressed(void* h) { return static_cast<RefHSS*>(h)->H->is_compressed(); }
 int ref_hss_levels(void* h) { return static_cast<RefHSS*>(h)->H->levels(); }

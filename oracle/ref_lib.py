@@ -29,6 +29,9 @@ def lib():
         L.ref_hss_create.restype = C.c_void_p
         L.ref_hss_create.argtypes = [C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_hss_create_sjlt.restype = C.c_void_p
+        L.ref_hss_create_sjlt.argtypes = [C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int]
         for f in ("ref_hss_destroy", "ref_hss_factor"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = None
@@ -78,9 +81,13 @@ class RefHSS:
     """The reference's HSSMatrix<double>(A, opts) (HSS/HSSMatrix.cpp:50-54)."""
 
     def __init__(self, A, rel_tol=1e-2, abs_tol=1e-8, leaf=512, d0=128, dd=64, p=10,
-                 max_rank=50000, algo="stable"):
+                 max_rank=50000, algo="stable", sjlt=None):
         A = np.asfortranarray(A, dtype=np.float64)
         self.n = A.shape[0]
+        if sjlt is not None:    # (algo "chunk" | "perm", nnz0, nnz): --hss_compression_sketch SJLT
+            self.h = lib().ref_hss_create_sjlt(self.n, _dp(A), A.shape[0], rel_tol, abs_tol, leaf, d0, dd,
+                                               0 if algo == "original" else 1, int(sjlt[0] == "perm"), sjlt[1], sjlt[2])
+            return
         self.h = lib().ref_hss_create(self.n, _dp(A), A.shape[0], rel_tol, abs_tol, leaf, d0, dd,
                                       p, max_rank, 0 if algo == "original" else 1)
 

@@ -15,7 +15,8 @@ class CSPOptions(C.Structure):
 
 class SPXHSSOptions(C.Structure):
     _fields_ = [("d0", C.c_int), ("dd", C.c_int), ("p", C.c_int), ("compression_algorithm", C.c_int),
-                ("random_engine", C.c_int), ("random_distribution", C.c_int)]
+                ("random_engine", C.c_int), ("random_distribution", C.c_int),
+                ("compression_sketch", C.c_int), ("sjlt_algo", C.c_int), ("nnz0", C.c_int), ("nnz", C.c_int)]
 
 
 SP_SYMBOLS = [
@@ -33,7 +34,7 @@ ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
 STAT_NAMES = ["t_compress", "t_sketch", "t_random", "t_tree", "t_factor", "t_solve", "t_mult",
               "sketch_kernel_ms", "sketch_launches", "rounds", "d_final", "f_sketch", "f_local",
-              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory", "sketch_kernel_flops"]
+              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory", "sketch_kernel_flops", "sketch_kernel_bytes"]
 
 
 def load(path):
@@ -106,7 +107,8 @@ class StructuredMatrix:
         return o
 
     @staticmethod
-    def hss_options(lib, d0=None, dd=None, p=None, algorithm=None, random_engine=None):
+    def hss_options(lib, d0=None, dd=None, p=None, algorithm=None, random_engine=None, sketch=None, sjlt_algo=None,
+                    nnz0=None, nnz=None):
         h = SPXHSSOptions()
         lib.SPX_d_struct_default_hss_options(C.byref(h))
         if d0 is not None:
@@ -119,6 +121,14 @@ class StructuredMatrix:
             h.compression_algorithm = {"original": 0, "stable": 1}[algorithm]
         if random_engine is not None:
             h.random_engine = {"linear": 0, "mersenne": 1, "philox": 2}[random_engine]
+        if sketch is not None:
+            h.compression_sketch = {"gaussian": 0, "sjlt": 1}[sketch.lower()]
+        if sjlt_algo is not None:
+            h.sjlt_algo = {"chunk": 0, "perm": 1}[sjlt_algo]
+        if nnz0 is not None:
+            h.nnz0 = nnz0
+        if nnz is not None:
+            h.nnz = nnz
         return h
 
     @classmethod

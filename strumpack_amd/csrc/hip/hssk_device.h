@@ -81,6 +81,10 @@ __device__ __forceinline__ hssk_d2 hssk_gload2(const double* p, size_t off) {
   return *(const hssk_d2 HSSK_GLOBAL_AS*)((const double HSSK_GLOBAL_AS*)p + off);
 }
 __device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { ((double HSSK_GLOBAL_AS*)p)[off] = v; }
+// LDS accumulate without a return value (ds_add_f64): lanes / waves of a workgroup summing into shared slots
+__device__ __forceinline__ void hssk_lds_add(double* p, double v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
 // kernel<<<grid, block, shmem, stream>>>(args...).  While a sweep plan is being recorded on this thread

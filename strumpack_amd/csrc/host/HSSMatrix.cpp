@@ -22,6 +22,9 @@ EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
   e.algorithm = o.compression_algorithm() == CompressionAlgorithm::STABLE ? 1 : 0;
   e.random_engine = o.random_engine() == random::RandomEngine::LINEAR ? 0 : (o.random_engine() == random::RandomEngine::MERSENNE ? 1 : 2);
   e.random_dist = o.random_distribution() == random::RandomDistribution::NORMAL ? 0 : 1;
+  e.sketch = o.compression_sketch() == CompressionSketch::SJLT ? 1 : 0;
+  e.sjlt_algo = o.SJLT_algo() == SJLTAlgo::CHUNK ? 0 : 1;
+  e.nnz0 = o.nnz0(); e.nnz = o.nnz();
   e.verbose = o.verbose();
   if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
   return e;

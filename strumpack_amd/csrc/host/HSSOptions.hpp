@@ -23,6 +23,9 @@ namespace HSS {
 
 enum class CompressionAlgorithm { ORIGINAL, STABLE, HARD_RESTART };
 enum class CompressionSketch { GAUSSIAN, SJLT };
+// how the nnz nonzeros of a row of the SJLT sketching matrix are placed (reference HSSOptions.hpp:128-133):
+// CHUNK = one in each of nnz equal column chunks, PERM = the first nnz entries of a random permutation
+enum class SJLTAlgo { CHUNK, PERM };
 inline std::string get_name(CompressionAlgorithm a) {
   switch (a) { case CompressionAlgorithm::ORIGINAL: return "original"; case CompressionAlgorithm::STABLE: return "stable"; case CompressionAlgorithm::HARD_RESTART: return "hard_restart"; }
   return "unknown";
@@ -52,6 +55,11 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   void set_random_distribution(random::RandomDistribution d) { random_distribution_ = d; }
   void set_compression_algorithm(CompressionAlgorithm a) { compress_algo_ = a; }
   void set_compression_sketch(CompressionSketch a) { compress_sketch_ = a; }
+  // SJLT sketch (reference HSSOptions.hpp:195-204, :247): nonzeros per row of the first d0+dd columns / of each
+  // further block of dd columns, and their placement
+  void set_nnz0(int nnz0) { assert(nnz0 > 0); nnz0_ = nnz0; }
+  void set_nnz(int nnz) { assert(nnz > 0); nnz_ = nnz; }
+  void set_SJLT_algo(SJLTAlgo a) { sjlt_algo_ = a; }
   void set_user_defined_random(bool u) { user_defined_random_ = u; }
   void set_synchronized_compression(bool sync) { sync_ = sync; }
   void set_log_ranks(bool log_ranks) { log_ranks_ = log_ranks; }
@@ -67,6 +75,9 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   random::RandomDistribution random_distribution() const { return random_distribution_; }
   CompressionAlgorithm compression_algorithm() const { return compress_algo_; }
   CompressionSketch compression_sketch() const { return compress_sketch_; }
+  int nnz0() const { return nnz0_; }
+  int nnz() const { return nnz_; }
+  SJLTAlgo SJLT_algo() const { return sjlt_algo_; }
   bool user_defined_random() const { return user_defined_random_; }
   bool synchronized_compression() const { return sync_; }
   bool log_ranks() const { return log_ranks_; }
@@ -102,8 +113,15 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
         else std::cerr << "# WARNING: compression algorithm not recognized, use 'original', 'stable' or 'hard_restart'" << std::endl;
       } else if (match_flag(argc, argv, i, "hss_compression_sketch", v, true)) {
         if (v == "Gaussian" || v == "gaussian") set_compression_sketch(CompressionSketch::GAUSSIAN);
-        else std::cerr << "# WARNING: only the Gaussian sketch is implemented in this build" << std::endl;
-      } else if (match_flag(argc, argv, i, "hss_user_defined_random", v, false)) set_user_defined_random(true);
+        else if (v == "SJLT" || v == "sjlt") set_compression_sketch(CompressionSketch::SJLT);
+        else std::cerr << "# WARNING: compression sketch not recognized, use 'Gaussian', or 'SJLT'." << std::endl;
+      } else if (match_flag(argc, argv, i, "hss_SJLT_algo", v, true)) {
+        if (v == "chunk") set_SJLT_algo(SJLTAlgo::CHUNK);
+        else if (v == "perm") set_SJLT_algo(SJLTAlgo::PERM);
+        else std::cerr << "# WARNING: SJLT algorithm not recognized, use 'chunk' or 'perm'." << std::endl;
+      } else if (match_flag(argc, argv, i, "hss_nnz0", v, true)) set_nnz0(std::atoi(v.c_str()));
+      else if (match_flag(argc, argv, i, "hss_nnz", v, true)) set_nnz(std::atoi(v.c_str()));
+      else if (match_flag(argc, argv, i, "hss_user_defined_random", v, false)) set_user_defined_random(true);
       else if (match_flag(argc, argv, i, "hss_enable_sync", v, false)) set_synchronized_compression(true);
       else if (match_flag(argc, argv, i, "hss_disable_sync", v, false)) set_synchronized_compression(false);
       else if (match_flag(argc, argv, i, "hss_log_ranks", v, false)) set_log_ranks(true);
@@ -124,7 +142,8 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
               << ")\n#   --hss_leaf_size int (default " << this->leaf_size() << ")\n#   --hss_d0 int (default " << d0() << ")\n#   --hss_dd int (default " << dd()
               << ")\n#   --hss_p int (default " << p() << ")\n#   --hss_max_rank int (default " << this->max_rank()
               << ")\n#   --hss_random_distribution normal|uniform\n#   --hss_random_engine linear|mersenne|philox\n"
-              << "#   --hss_compression_algorithm original|stable|hard_restart\n#   --hss_compression_sketch Gaussian\n"
+              << "#   --hss_compression_algorithm original|stable|hard_restart\n#   --hss_compression_sketch Gaussian|SJLT\n"
+              << "#   --hss_SJLT_algo chunk|perm\n#   --hss_nnz0 int (default " << nnz0() << ")\n#   --hss_nnz int (default " << nnz() << ")\n"
               << "#   --hss_clustering_algorithm natural|2means|kdtree|pca|cobble (default " << get_name(clustering_algorithm()) << ")\n#   --hss_approximate_neighbors int (default " << approximate_neighbors()
               << ")\n#   --hss_ann_iterations int (default " << ann_iterations() << ")\n#   --hss_neighbor_search exact|ann (default exact: all pairs on the device)\n"
               << "#   --hss_user_defined_random  --hss_enable_sync  --hss_disable_sync  --hss_log_ranks\n#   --hss_verbose or -v   --hss_quiet or -q" << std::endl;
@@ -142,6 +161,8 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   random::RandomDistribution random_distribution_ = random::RandomDistribution::NORMAL;
   CompressionAlgorithm compress_algo_ = CompressionAlgorithm::STABLE;
   CompressionSketch compress_sketch_ = CompressionSketch::GAUSSIAN;
+  int nnz0_ = 4, nnz_ = 4;
+  SJLTAlgo sjlt_algo_ = SJLTAlgo::CHUNK;
   bool user_defined_random_ = false, sync_ = false, log_ranks_ = false;
   ClusteringAlgorithm clustering_algorithm_ = ClusteringAlgorithm::TWO_MEANS;
   int approximate_neighbors_ = 64, ann_iterations_ = 5;

@@ -34,6 +34,10 @@ HSS::HSSOptions<double> get_hss_options(const CSPOptions* o, const SPXHSSOptions
     ho.set_compression_algorithm(h->compression_algorithm == 0 ? HSS::CompressionAlgorithm::ORIGINAL : HSS::CompressionAlgorithm::STABLE);
     ho.set_random_engine(h->random_engine == 0 ? random::RandomEngine::LINEAR : (h->random_engine == 1 ? random::RandomEngine::MERSENNE : random::RandomEngine::PHILOX));
     ho.set_random_distribution(h->random_distribution == 0 ? random::RandomDistribution::NORMAL : random::RandomDistribution::UNIFORM);
+    ho.set_compression_sketch(h->compression_sketch == 1 ? HSS::CompressionSketch::SJLT : HSS::CompressionSketch::GAUSSIAN);
+    ho.set_SJLT_algo(h->sjlt_algo == 1 ? HSS::SJLTAlgo::PERM : HSS::SJLTAlgo::CHUNK);
+    if (h->nnz0 > 0) ho.set_nnz0(h->nnz0);
+    if (h->nnz > 0) ho.set_nnz(h->nnz);
   }
   return ho;
 }
@@ -106,6 +110,7 @@ void SPX_d_struct_default_hss_options(SPXHSSOptions* h) {
   HSS::HSSOptions<double> d;
   h->d0 = d.d0(); h->dd = d.dd(); h->p = d.p();
   h->compression_algorithm = 1; h->random_engine = 0; h->random_distribution = 0;
+  h->compression_sketch = 0; h->sjlt_algo = 0; h->nnz0 = d.nnz0(); h->nnz = d.nnz();
 }
 int SPX_d_struct_from_dense_hss(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts,
                                 const SPXHSSOptions* h) {
@@ -213,7 +218,8 @@ int SPX_d_struct_stats(const CSPStructMat S, double* o) {
   o[10] = st.d_final; o[11] = st.f_sketch; o[12] = st.f_local; o[13] = st.f_reduce; o[14] = st.f_id;
   o[15] = st.f_ortho; o[16] = st.f_ulv; o[17] = st.f_solve; o[18] = (double)hss(S)->engine()->factor_memory();
   o[19] = st.sketch_kernel_flops;
-  for (int i = 20; i < 24; i++) o[i] = 0;
+  o[20] = st.sketch_kernel_bytes;
+  for (int i = 21; i < 24; i++) o[i] = 0;
   SP_CATCH
 }
 // ---- Schur complement of the (0,0) block (HSS only; HSSMatrix.Schur.hpp)

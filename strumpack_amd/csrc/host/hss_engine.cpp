@@ -41,6 +41,7 @@ inline double now() {
 
 // host random stream of the reference (misc/RandomWrapper.hpp:128-191): engine seeded with 0
 struct HostRng {
+  std::default_random_engine sj{0};   // SJLT patterns (the reference seeds its generator from the clock, sketch.hpp:266-270)
   std::minstd_rand lin{0};
   std::mt19937 mer{0};
   std::normal_distribution<double> nd;
@@ -187,7 +188,23 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
       j0 = std::min(N, H.cols_per_rank_ * H.o_.rank); j1 = std::min(N, j0 + H.cols_per_rank_);
     }
     const long long nloc = j1 - j0;
-    if (nloc > 0) {
+    // SJLT sketch: stream A once per product instead of a dense GEMM (blocks wider than the kernel's LDS tile, or
+    // STRUMPACK_AMD_SJLT_DENSE=1, multiply with the dense form of the pattern)
+    static const bool sj_dense = std::getenv("STRUMPACK_AMD_SJLT_DENSE") && std::atoi(std::getenv("STRUMPACK_AMD_SJLT_DENSE"));
+    if (nloc > 0 && H.sj_pat_ && dn <= 1024 && !sj_dense) {
+      for (int t = 0; t < 2; t++) {
+        const double* Aop = t == 0 ? dA + j0 : dA + j0 * lda;
+        double* St = (t == 0 ? H.Srt_ : H.Sct_) + r0 + j0 * H.dcap_;
+        ck(hssk_sjlt_sketch(H.ctx_, t, nloc, N, Aop, lda, H.sj_pat_, H.sj_nnz_, dn, St, H.dcap_));
+        ck(hssk_sync(H.ctx_));
+        float ms = hssk_last_dgemm_ms(H.ctx_);
+        if (ms > 0) {
+          H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++;
+          H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_);
+          H.stats_.sketch_kernel_bytes += 8.0 * (double)nloc * (double)N;
+        }
+      }
+    } else if (nloc > 0) {
       ck(hssk_dgemm(H.ctx_, 1, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0, lda, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
       ck(hssk_sync(H.ctx_));
       float ms = hssk_last_dgemm_ms(H.ctx_);
@@ -622,6 +639,7 @@ void DeviceHSS::free_compress_workspace() {
   ck(hssk_sync(ctx_));
   work_->reset();
   Rt_ = Srt_ = Sct_ = nullptr;
+  sj_pat_ = nullptr;
   for (auto& nd : nodes_) { nd.Srt = nd.Sct = nd.Rrt = nd.Rct = nd.RrtRed = nd.RctRed = nd.Qr = nd.Qc = nullptr; nd.panels = false; }
 }
 
@@ -646,7 +664,42 @@ void DeviceHSS::compress(Source& src) {
 void DeviceHSS::fill_random(int r0, int dn) {
   double t0 = now();
   const long long N = n_;
-  if (o_.random_engine == 2) {
+  sj_pat_ = nullptr;
+  if (o_.sketch == 1) {
+    // SJLT (HSSMatrix.compress_stable.hpp:39-97, HSSMatrix.sketch.hpp): every row of the N x dn block gets nnz entries
+    // +-1 -- nnz0 in the first d0 + dd columns, nnz in each further block (S.add_columns / SJLTMatrix(g, nnz, n, dnew)).
+    // CHUNK (sketch.hpp:419-441): one nonzero in each of nnz chunks of dn / nnz columns; PERM (:316-341): the first
+    // nnz entries of a random permutation of the columns (drawn here as a partial Fisher-Yates shuffle).  Only the
+    // pattern (nnz ints per row) crosses PCIe; the dense block the tree levels need is expanded on the device.
+    if (r0 == 0 || !rng_) rng_.reset(new HostRng());
+    auto& e = rng_->sj;
+    const int nnz = std::max(1, std::min(std::min(r0 == 0 ? o_.nnz0 : o_.nnz, dn), 8));
+    std::vector<int> pat((size_t)nnz * N);
+    std::uniform_int_distribution<int> sign(0, 1);
+    if (o_.sjlt_algo == 0) {
+      const int chunk = dn / nnz;
+      std::uniform_int_distribution<int> shift(0, chunk - 1);
+      for (long long k = 0; k < N; k++)
+        for (int q = 0; q < nnz; q++) {
+          const int c = shift(e) + chunk * q;
+          pat[(size_t)q * N + k] = sign(e) == 0 ? c : (c | (int)0x80000000);
+        }
+    } else {
+      std::vector<int> cols(dn);
+      for (int j = 0; j < dn; j++) cols[j] = j;
+      for (long long k = 0; k < N; k++)
+        for (int q = 0; q < nnz; q++) {
+          std::uniform_int_distribution<int> pick(q, dn - 1);
+          std::swap(cols[q], cols[pick(e)]);
+          pat[(size_t)q * N + k] = sign(e) == 0 ? cols[q] : (cols[q] | (int)0x80000000);
+        }
+    }
+    int* dp = work_->ints((size_t)nnz * N);
+    ck(hssk_memcpy_h2d(ctx_, dp, pat.data(), (long long)sizeof(int) * nnz * N));
+    ck(hssk_sjlt_dense(ctx_, Rt_ + r0, dn, N, dcap_, dp, nnz));
+    sj_pat_ = dp;
+    sj_nnz_ = nnz;
+  } else if (o_.random_engine == 2) {
     // device Philox: element (sample s, column c) is a pure function of (seed, s * N + c)
     if (o_.random_dist != 0) throw std::invalid_argument("philox engine implements the normal distribution only");
     ck(hssk_randn(ctx_, Rt_ + r0, dn, N, dcap_, r0, N, 0x5354524dull));

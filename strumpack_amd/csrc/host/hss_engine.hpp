@@ -32,6 +32,9 @@ struct EngineOptions {
   int algorithm = 1;      // 0 original, 1 stable, 2 hard restart (treated as stable)
   int random_engine = 0;  // 0 minstd_rand, 1 mt19937 (host, reference-identical), 2 philox (device)
   int random_dist = 0;    // 0 normal, 1 uniform
+  // sketching matrix: 0 Gaussian (the distribution above), 1 SJLT = nnz entries +-1 per row (HSSMatrix.sketch.hpp);
+  // sjlt_algo 0 chunk / 1 perm; nnz0 nonzeros per row in the first d0 + dd columns, nnz in every further dd
+  int sketch = 0, sjlt_algo = 0, nnz0 = 4, nnz = 4;
   bool verbose = false;
   int device = 0;
   // multi-GPU (one process per GPU): `allgather` is an in-place all-gather of a DEVICE buffer of
@@ -50,6 +53,7 @@ struct PhaseStats {
   double t_compress = 0, t_sketch = 0, t_random = 0, t_tree = 0, t_factor = 0, t_solve = 0, t_mult = 0;
   double sketch_kernel_ms = 0;  // sum of HIP-event durations of the sketch GEMM main launches
   double sketch_kernel_flops = 0;  // algorithmic flops of those launches
+  double sketch_kernel_bytes = 0;  // SJLT sketch: algorithmic HBM bytes of those launches (8 per element of A read)
   int sketch_launches = 0, rounds = 0, d_final = 0;
   // algorithmic flop model
   double f_sketch = 0, f_local = 0, f_reduce = 0, f_id = 0, f_ortho = 0, f_ulv = 0, f_solve = 0;
@@ -225,6 +229,8 @@ class DeviceHSS {
   // global transposed sample arrays (dcap x N)
   double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;
   int dcap_ = 0;
+  const int* sj_pat_ = nullptr;   // SJLT pattern of the sample block filled last (device, nnz x N)
+  int sj_nnz_ = 0;
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
   int* d_ranks_ = nullptr;
   bool factored_ = false, partial_factored_ = false, schur_ready_ = false;

@@ -104,7 +104,7 @@ HSSK_SYMBOLS = [
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
     "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
     "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict", "hssk_copy_triu",
-    "hssk_ulv_fwd_level", "hssk_ulv_bwd_level",
+    "hssk_ulv_fwd_level", "hssk_ulv_bwd_level", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
 ]
 
@@ -195,6 +195,9 @@ class Hssk:
         L.hssk_kernel_eval_vbatched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hssk_kernel_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.hssk_sjlt_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
+        L.hssk_sjlt_sketch.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_longlong,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong]
         L.hssk_mfma_f64_peak_tflops.restype = C.c_double
         L.hssk_mfma_f64_peak_tflops.argtypes = [C.c_void_p, C.c_int]
         L.hssk_mfma_f64_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]

@@ -73,6 +73,35 @@ def case_dgemm(hk, m, n, k, transB, alpha=1.0, beta=0.0, lda_pad=5, seed=1, ldb_
         f"dgemm m={m} n={n} k={k} transB={transB}"
 
 
+def case_sjlt(hk, n_out, K, dn, nnz, seed=3):
+    """hssk_sjlt_dense / hssk_sjlt_sketch against numpy: S = op(A) R for a random +-1 pattern with nnz entries per
+    row (matrix_times_SJLT / matrixT_times_SJLT / SJLT_to_dense, HSS/HSSMatrix.sketch.hpp)."""
+    r = rng(seed)
+    cols = np.stack([r.permutation(dn)[:nnz] for _ in range(K)], axis=1).astype(np.int64)   # nnz x K, distinct per row
+    neg = r.integers(0, 2, size=(nnz, K)).astype(bool)
+    pat = (cols | (neg.astype(np.int64) << 31)).astype(np.uint32).view(np.int32)
+    R = np.zeros((K, dn))
+    for q in range(nnz):
+        R[np.arange(K), cols[q]] = np.where(neg[q], -1.0, 1.0)
+    dpat = hk.array(np.ascontiguousarray(pat).reshape(-1), dtype=np.int32)
+    ld = dn + 3
+    dRt = hk.array(np.full((ld, K), -7.0))
+    hk.check(hk.lib.hssk_sjlt_dense(hk.ctx, dRt.ptr, dn, K, ld, dpat.ptr, nnz))
+    hk.sync()
+    got = dRt.get()
+    assert np.array_equal(got[:dn], R.T) and np.all(got[dn:] == -7.0)
+    for trans in (0, 1):
+        A = r.standard_normal((n_out + 2, K)) if trans == 0 else r.standard_normal((K + 2, n_out))
+        dA = hk.array(A)
+        dS = hk.array(np.full((ld, n_out), -3.0))
+        hk.check(hk.lib.hssk_sjlt_sketch(hk.ctx, trans, n_out, K, dA.ptr, A.shape[0], dpat.ptr, nnz, dn, dS.ptr, ld))
+        hk.sync()
+        ref = (A[:n_out] @ R).T if trans == 0 else (A[:K].T @ R).T
+        got = dS.get()
+        assert np.all(got[dn:] == -3.0)
+        assert np.abs(got[:dn] - ref).max() <= 1e-13 * K * max(1.0, np.abs(ref).max()), f"sjlt trans={trans}"
+
+
 def case_toeplitz_randn(hk, n=70):
     dA = hk.empty((n + 2, n))
     dA.set(np.full((n + 2, n), -7.0))

@@ -27,6 +27,11 @@ def test_schur_complement(L, name):
     HC.check_schur(L, CASES[name])
 
 
+@pytest.mark.parametrize("name", ["HSS_seq_24", "sjlt_original_T500", "sjlt_stable_U400"])
+def test_sjlt_sketch(L, name):
+    HC.check_sjlt(L, HC.sjlt_golden()[name])
+
+
 def test_api_semantics(L):
     HC.check_api_semantics(L)
 

@@ -31,6 +31,42 @@ def test_schur_complement(L, name):
     HC.check_schur(L, CASES[name], dense_check=CASES[name]["n"] <= 4096)
 
 
+@pytest.mark.parametrize("name", sorted(HC.sjlt_golden()))
+def test_sjlt_sketch(L, name):
+    HC.check_sjlt(L, HC.sjlt_golden()[name])
+
+
+def test_sjlt_sketch_full_size(L):
+    """SJLT sketch at BASELINE size with A in HBM: the streaming kernels (one pass over A per product) must give a
+    matrix as accurate as the Gaussian sketch's (test_full_size_properties)."""
+    n = 32768
+    hk = K.Hssk(_loader.lib_path())
+    dA = hk.empty((n, n))
+    hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
+    hk.sync()
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=256, max_rank=50000)
+    h = capi.StructuredMatrix.hss_options(L, sketch="sjlt")
+    H = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
+    assert H.is_compressed() and 26 <= H.rank() <= 40, H.rank()
+    st = H.stats()
+    assert st["sketch_kernel_bytes"] >= 2 * 8.0 * n * n     # both products went through the streaming kernels
+    rng = np.random.default_rng(0)
+    cols = rng.integers(0, n, 16)
+    E = np.zeros((n, 16))
+    E[cols, np.arange(16)] = 1.0
+    i = np.arange(n)
+    Acols = 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :]))
+    err = np.linalg.norm(H.mult(E) - Acols) / np.linalg.norm(Acols)
+    assert err < 2e-4, err
+    H.factor()
+    b = rng.standard_normal((n, 2))
+    X = H.solve(b)
+    assert np.linalg.norm(H.mult(X) - b) / np.linalg.norm(b) <= 1e-12
+    H.destroy()
+    dA.free()
+    hk.close()
+
+
 def test_api_semantics(L):
     HC.check_api_semantics(L)
 

@@ -96,3 +96,9 @@ def test_knn(hk):
 
 def test_kernel_predict(hk):
     KC.case_kernel_predict(hk)
+
+
+def test_sjlt(hk):
+    KC.case_sjlt(hk, n_out=45, K=300, dn=24, nnz=4)
+    KC.case_sjlt(hk, n_out=130, K=77, dn=200, nnz=2, seed=4)
+    KC.case_sjlt(hk, n_out=20, K=130, dn=600, nnz=8, seed=5)

@@ -102,3 +102,11 @@ def test_knn(hk):
 
 def test_kernel_predict(hk):
     KC.case_kernel_predict(hk)
+
+
+def test_sjlt(hk):
+    KC.case_sjlt(hk, n_out=45, K=300, dn=24, nnz=4)
+    KC.case_sjlt(hk, n_out=1000, K=3001, dn=192, nnz=4, seed=4)
+    KC.case_sjlt(hk, n_out=777, K=2050, dn=64, nnz=2, seed=5)
+    KC.case_sjlt(hk, n_out=300, K=1500, dn=300, nnz=8, seed=6)
+    KC.case_sjlt(hk, n_out=100, K=900, dn=1000, nnz=3, seed=7)
