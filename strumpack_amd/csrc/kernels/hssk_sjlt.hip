@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(SJ_T) sjlt_n_kernel(const double* __restrict__
   }
 }
 
-constexpr int SJ_LDS_DOUBLES = 8192;   // 64 KB: two workgroups per CU
+constexpr int SJ_LDS_DOUBLES = 8000;   // < 64 KB (the default dynamic LDS limit): two workgroups per CU
 
 }  // namespace
 

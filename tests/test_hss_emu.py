@@ -22,12 +22,12 @@ def test_ctest_case(L, name):
     HC.check_against_golden(L, CASES[name])
 
 
-@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_8", "HSS_seq_11", "HSS_seq_14", "HSS_seq_5"])
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_8", "HSS_seq_11", "HSS_seq_14"])
 def test_schur_complement(L, name):
     HC.check_schur(L, CASES[name])
 
 
-@pytest.mark.parametrize("name", ["HSS_seq_24", "sjlt_original_T500", "sjlt_stable_U400"])
+@pytest.mark.parametrize("name", ["sjlt_original_T500"])
 def test_sjlt_sketch(L, name):
     HC.check_sjlt(L, HC.sjlt_golden()[name])
 
