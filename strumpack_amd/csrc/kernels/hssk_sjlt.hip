@@ -16,6 +16,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace {
@@ -138,23 +139,31 @@ int hssk_sjlt_sketch(hssk_ctx* ctx, int transA, long long n_out, long long K, co
   if (n_out <= 0 || dn <= 0) return 0;
   if (nnz < 0 || nnz > SJ_NNZ_MAX) throw std::invalid_argument("hssk_sjlt_sketch: nnz out of range (max 8)");
   if (dn > 1024) throw std::invalid_argument("hssk_sjlt_sketch: more than 1024 sketch columns in one call");
+  // tuning overrides (tools/sjlt_only.py): columns per workgroup of the A^T R kernel, rows per workgroup of the A R kernel
+  auto env_int = [](const char* name) { const char* v = std::getenv(name); return v ? std::atoi(v) : 0; };
+  const int ct_req = env_int("HSSK_SJLT_CT"), rt_req = env_int("HSSK_SJLT_RT");
   hssk_rt::event_record(ctx->ev0, ctx->stream);
   if (transA) {
 #define SJ_LAUNCH_T(CT)                                                                                                   \
   HSSK_LAUNCH(sjlt_t_kernel<CT>, dim3((unsigned)((n_out + CT - 1) / CT)), dim3(SJ_T), sizeof(double) * CT * dn, ctx->stream, \
               A, lda, K, n_out, pat, nnz, dn, St, lds)
-    if (16 * dn <= SJ_LDS_DOUBLES) SJ_LAUNCH_T(16);
-    else if (8 * dn <= SJ_LDS_DOUBLES) SJ_LAUNCH_T(8);
+    int ct = 16 * dn <= SJ_LDS_DOUBLES ? 16 : (8 * dn <= SJ_LDS_DOUBLES ? 8 : 4);
+    if ((ct_req == 4 || ct_req == 8 || ct_req == 16 || ct_req == 32) && ct_req * dn <= SJ_LDS_DOUBLES) ct = ct_req;
+    if (ct == 32) SJ_LAUNCH_T(32);
+    else if (ct == 16) SJ_LAUNCH_T(16);
+    else if (ct == 8) SJ_LAUNCH_T(8);
     else SJ_LAUNCH_T(4);
 #undef SJ_LAUNCH_T
   } else {
 #define SJ_LAUNCH_N(RT)                                                                                                   \
   HSSK_LAUNCH(sjlt_n_kernel<RT>, dim3((unsigned)((n_out + RT - 1) / RT)), dim3(SJ_T), sizeof(double) * (RT + 1) * dn,      \
               ctx->stream, A, lda, K, n_out, pat, nnz, dn, St, lds)
-    if (65 * dn <= SJ_LDS_DOUBLES) SJ_LAUNCH_N(64);
-    else if (33 * dn <= SJ_LDS_DOUBLES) SJ_LAUNCH_N(32);
-    else if (17 * dn <= SJ_LDS_DOUBLES) SJ_LAUNCH_N(16);
-    else if (9 * dn <= SJ_LDS_DOUBLES) SJ_LAUNCH_N(8);
+    int rt = 65 * dn <= SJ_LDS_DOUBLES ? 64 : (33 * dn <= SJ_LDS_DOUBLES ? 32 : (17 * dn <= SJ_LDS_DOUBLES ? 16 : (9 * dn <= SJ_LDS_DOUBLES ? 8 : 4)));
+    if ((rt_req == 4 || rt_req == 8 || rt_req == 16 || rt_req == 32 || rt_req == 64) && (rt_req + 1) * dn <= SJ_LDS_DOUBLES) rt = rt_req;
+    if (rt == 64) SJ_LAUNCH_N(64);
+    else if (rt == 32) SJ_LAUNCH_N(32);
+    else if (rt == 16) SJ_LAUNCH_N(16);
+    else if (rt == 8) SJ_LAUNCH_N(8);
     else SJ_LAUNCH_N(4);
 #undef SJ_LAUNCH_N
   }
