@@ -187,12 +187,13 @@ int hssk_copy_triu(hssk_ctx* ctx, const hssk_triu_desc* descs, int count);
 
 /* ---- sparse Johnson-Lindenstrauss sketch ---------------------------------------------------------------
  * The reference's --hss_compression_sketch SJLT (HSS/HSSMatrix.sketch.hpp; compress_stable.hpp:39-97): the sketching
- * matrix R (K x dn) has nnz entries +-1 per row.  pat (DEVICE, nnz x K ints, K contiguous): pat[q * K + k] = column
- * index of the q-th nonzero of row k, sign bit set for -1.
+ * matrix R (K x dn) has nnz <= 8 entries +-1 per row.  pat (DEVICE ints, NQ = (nnz <= 4 ? 4 : 8) per row):
+ * pat[k * NQ + q] = column index of the q-th nonzero of row k, sign bit set for -1; unused entries = dn.
  * hssk_sjlt_dense: Rt (dn x K, ld) = R^T as a dense block (SJLTMatrix::SJLT_to_dense, sketch.hpp:573-596).
  * hssk_sjlt_sketch: St (dn x n_out, lds) = (op(A) R)^T with op(A) n_out x K: transA = 0: A(i, k) = A[i + k lda]
  * (matrix_times_SJLT, sketch.hpp:611-721), transA = 1: A(k, j) = A[k + j lda] (matrixT_times_SJLT, :723-809).
- * One pass over A (8 bytes per element), nnz LDS adds per element; nnz <= 8, dn <= 1024. */
+ * One pass over A (8 bytes per element), NQ LDS adds per element; dn <= 1024.  The launch is bracketed by the
+ * events behind hssk_last_dgemm_ms / _flops (2 nnz flops per element). */
 int hssk_sjlt_dense(hssk_ctx* ctx, double* Rt, int dn, long long K, long long ld, const int* pat, int nnz);
 int hssk_sjlt_sketch(hssk_ctx* ctx, int transA, long long n_out, long long K, const double* A, long long lda,
                      const int* pat, int nnz, int dn, double* St, long long lds);

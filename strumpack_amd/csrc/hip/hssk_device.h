@@ -85,6 +85,10 @@ __device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { (
 __device__ __forceinline__ void hssk_lds_add(double* p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// a value known to be the same in every lane of the wave, moved to a scalar register (loads indexed by it become s_load)
+__device__ __forceinline__ int hssk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// compile-time only: memory operations are not moved across this point
+#define HSSK_COMPILER_FENCE() __asm__ volatile("" ::: "memory")
 #define HSSK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
 // kernel<<<grid, block, shmem, stream>>>(args...).  While a sweep plan is being recorded on this thread

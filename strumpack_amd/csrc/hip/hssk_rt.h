@@ -35,6 +35,10 @@ inline void d2h_2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t 
 inline void memset_async(void* d, int v, size_t bytes, stream_t s) { if (bytes) HSSK_CHECK(hipMemsetAsync(d, v, bytes, s)); }
 inline void sync(stream_t s) { HSSK_CHECK(hipStreamSynchronize(s)); }
 inline void check_launch() { HSSK_CHECK(hipGetLastError()); }
+// dynamic LDS above the 64 KB default (gfx950: 160 KB per CU)
+template <typename K> inline void allow_dynamic_lds(K kernel, size_t bytes) {
+  HSSK_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
 inline stream_t stream_create() { stream_t s; HSSK_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
 inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
 inline event_t event_create() { event_t e; HSSK_CHECK(hipEventCreate(&e)); return e; }

@@ -674,7 +674,8 @@ void DeviceHSS::fill_random(int r0, int dn) {
     if (r0 == 0 || !rng_) rng_.reset(new HostRng());
     auto& e = rng_->sj;
     const int nnz = std::max(1, std::min(std::min(r0 == 0 ? o_.nnz0 : o_.nnz, dn), 8));
-    std::vector<int> pat((size_t)nnz * N);
+    const int nq = nnz <= 4 ? 4 : 8;            // ints per row in the device pattern (hssk.h); unused ones point at column dn
+    std::vector<int> pat((size_t)nq * N, dn);
     std::uniform_int_distribution<int> sign(0, 1);
     if (o_.sjlt_algo == 0) {
       const int chunk = dn / nnz;
@@ -682,7 +683,7 @@ void DeviceHSS::fill_random(int r0, int dn) {
       for (long long k = 0; k < N; k++)
         for (int q = 0; q < nnz; q++) {
           const int c = shift(e) + chunk * q;
-          pat[(size_t)q * N + k] = sign(e) == 0 ? c : (c | (int)0x80000000);
+          pat[(size_t)k * nq + q] = sign(e) == 0 ? c : (c | (int)0x80000000);
         }
     } else {
       std::vector<int> cols(dn);
@@ -691,11 +692,11 @@ void DeviceHSS::fill_random(int r0, int dn) {
         for (int q = 0; q < nnz; q++) {
           std::uniform_int_distribution<int> pick(q, dn - 1);
           std::swap(cols[q], cols[pick(e)]);
-          pat[(size_t)q * N + k] = sign(e) == 0 ? cols[q] : (cols[q] | (int)0x80000000);
+          pat[(size_t)k * nq + q] = sign(e) == 0 ? cols[q] : (cols[q] | (int)0x80000000);
         }
     }
-    int* dp = work_->ints((size_t)nnz * N);
-    ck(hssk_memcpy_h2d(ctx_, dp, pat.data(), (long long)sizeof(int) * nnz * N));
+    int* dp = work_->ints((size_t)nq * N);
+    ck(hssk_memcpy_h2d(ctx_, dp, pat.data(), (long long)sizeof(int) * nq * N));
     ck(hssk_sjlt_dense(ctx_, Rt_ + r0, dn, N, dcap_, dp, nnz));
     sj_pat_ = dp;
     sj_nnz_ = nnz;

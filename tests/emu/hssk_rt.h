@@ -27,6 +27,7 @@ inline void d2h_2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t 
 inline void memset_async(void* d, int v, size_t bytes, stream_t) { if (bytes) std::memset(d, v, bytes); }
 inline void sync(stream_t) {}
 inline void check_launch() {}
+template <typename K> inline void allow_dynamic_lds(K, size_t) {}
 inline stream_t stream_create() { return nullptr; }
 inline void stream_destroy(stream_t) {}
 inline event_t event_create() { return new double(0); }

@@ -79,7 +79,10 @@ def case_sjlt(hk, n_out, K, dn, nnz, seed=3):
     r = rng(seed)
     cols = np.stack([r.permutation(dn)[:nnz] for _ in range(K)], axis=1).astype(np.int64)   # nnz x K, distinct per row
     neg = r.integers(0, 2, size=(nnz, K)).astype(bool)
-    pat = (cols | (neg.astype(np.int64) << 31)).astype(np.uint32).view(np.int32)
+    nq = 4 if nnz <= 4 else 8
+    pat = np.full((K, nq), dn, dtype=np.int64)                # unused entries point at column dn
+    pat[:, :nnz] = (cols | (neg.astype(np.int64) << 31)).T
+    pat = pat.astype(np.uint32).view(np.int32)
     R = np.zeros((K, dn))
     for q in range(nnz):
         R[np.arange(K), cols[q]] = np.where(neg[q], -1.0, 1.0)

@@ -21,7 +21,10 @@ rng = np.random.default_rng(0)
 chunk = dn // nnz
 cols = (rng.integers(0, chunk, size=(nnz, n)) + chunk * np.arange(nnz)[:, None]).astype(np.int64)
 neg = rng.integers(0, 2, size=(nnz, n)).astype(np.int64)
-pat = (cols | (neg << 31)).astype(np.uint32).view(np.int32)
+nq = 4 if nnz <= 4 else 8
+pat = np.full((n, nq), dn, dtype=np.int64)
+pat[:, :nnz] = (cols | (neg << 31)).T
+pat = pat.astype(np.uint32).view(np.int32)
 dpat = hk.array(np.ascontiguousarray(pat).reshape(-1), dtype=np.int32)
 dS = hk.empty((dn, n))
 hk.sync()
@@ -37,18 +40,28 @@ def run(trans, reps=3):
     return best
 
 
-for trans, var, vals in ((1, "HSSK_SJLT_CT", (0, 4, 8, 16, 32)), (0, "HSSK_SJLT_RT", (0, 16, 32, 64))):
+def sweep(trans, var, vals, mode=None):
     for v in vals:
-        if v:
-            os.environ[var] = str(v)
-        else:
-            os.environ.pop(var, None)
+        os.environ[var] = str(v)
+        if mode is not None:
+            os.environ["HSSK_SJLT_MODE"] = str(mode)
         try:
             ms = run(trans)
-            print("trans=%d %s=%s  %.2f ms  %.0f GB/s (algorithmic, %.1f GB)" % (trans, var, v or "default", ms, gb / (ms * 1e-3), gb), flush=True)
+            print("trans=%d %s=%s mode=%s  %.2f ms  %.0f GB/s (algorithmic, %.1f GB)" % (trans, var, v, mode or 0, ms, gb / (ms * 1e-3), gb), flush=True)
         except Exception as e:  # noqa: BLE001
             print("trans=%d %s=%s failed: %s" % (trans, var, v, e), flush=True)
+        os.environ.pop("HSSK_SJLT_MODE", None)
     os.environ.pop(var, None)
+
+
+# variants: n: 0 = 16 waves x 8 loads, 1 = 8 x 16, 2 = 8 x 8, 3 = 16 x 16, -1 = small-tile kernel;  t: 0 = 16 waves, 1 = 8, 2 = 4, -1 = small
+sweep(1, "HSSK_SJLT_TV", (-1, 2, 1, 0))
+sweep(1, "HSSK_SJLT_TV", (0,), mode=1)
+sweep(1, "HSSK_SJLT_TV", (0,), mode=2)
+sweep(0, "HSSK_SJLT_NV", (-1, 3, 2, 1, 0))
+sweep(0, "HSSK_SJLT_NV", (0,), mode=1)
+sweep(0, "HSSK_SJLT_NV", (0,), mode=2)
+run(0, reps=1)   # leave the product path's result in dS for the check below
 # checksum against a column of the exact product (row sums of the pattern applied to one column of A)
 S = dS.get()
 i = np.arange(n)
