@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(NW * 64) sjlt_n_kernel(const double* __restric
 }
 
 // ---- Sc = A^T R, 64 columns per workgroup (lane = column), NW waves ----------------------------------------------
-template <int NQ, int NW, int MODE>
+// KB = rows per lane and block: 8 (one 64-byte run) or 16 (one 128-byte run)
+template <int NQ, int NW, int KB, int MODE>
 __global__ void __launch_bounds__(NW * 64) sjlt_t_kernel(const double* __restrict__ A, long long lda, long long K, long long n_out,
                                                           const int* __restrict__ pat, int dn, double* __restrict__ St, long long lds,
                                                           int aligned) {
@@ -134,25 +135,28 @@ __global__ void __launch_bounds__(NW * 64) sjlt_t_kernel(const double* __restric
   const double* a = A + (j0 + (cok ? lane : 0)) * lda;   // (columns past the end read column j0 and are not stored)
   double* my = acc + lane;
   double sink = 0.;
-  const long long step = (long long)NW * 8, kfull = aligned ? K - 7 : 0;   // blocks of 8 rows with 16-byte loads
-  long long k0 = (long long)wave * 8;
-  hssk_d2 v[4], w[4];
-  auto fetch = [&](hssk_d2 (&x)[4], long long kb) {
+  const long long step = (long long)NW * KB, kfull = aligned ? K - (KB - 1) : 0;   // full blocks use 16-byte loads
+  long long k0 = (long long)wave * KB;
+  hssk_d2 v[KB / 2], w[KB / 2];
+  auto fetch = [&](hssk_d2 (&x)[KB / 2], long long kb) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) x[t] = *reinterpret_cast<const hssk_d2*>(a + kb + 2 * t);
+    for (int t = 0; t < KB / 2; t++) x[t] = *reinterpret_cast<const hssk_d2*>(a + kb + 2 * t);
   };
-  auto update = [&](const hssk_d2 (&x)[4], long long kb) {
-    int p[8][NQ];
+  auto update = [&](const hssk_d2 (&x)[KB / 2], long long kb) {
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+    for (int h = 0; h < KB / 8; h++) {   // 8 rows at a time: their patterns fit the scalar registers
+      int p[8][NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; q++) p[t][q] = pat[(kb + t) * NQ + q];
-    HSSK_COMPILER_FENCE();
+      for (int t = 0; t < 8; t++)
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      const double y = x[t >> 1][t & 1];
+        for (int q = 0; q < NQ; q++) p[t][q] = pat[(kb + 8 * h + t) * NQ + q];
+      HSSK_COMPILER_FENCE();
 #pragma unroll
-      for (int q = 0; q < NQ; q++) sj_acc<MODE>(my + (p[t][q] & 0x7fffffff) * SJ_LD, p[t][q] < 0 ? -y : y, sink);
+      for (int t = 0; t < 8; t++) {
+        const double y = x[4 * h + (t >> 1)][t & 1];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) sj_acc<MODE>(my + (p[t][q] & 0x7fffffff) * SJ_LD, p[t][q] < 0 ? -y : y, sink);
+      }
     }
   };
   if (k0 < kfull) {
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64) sjlt_t_kernel(const double* __restric
     }
   }
   for (; k0 < K; k0 += step)   // tail (and the whole range when the columns are not 16-byte aligned)
-    for (int t = 0; t < 8 && k0 + t < K; t++) {
+    for (int t = 0; t < KB && k0 + t < K; t++) {
       const double x = a[k0 + t];
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
@@ -291,11 +295,13 @@ template <int NQ> void launch_sketch(hssk_ctx* ctx, int transA, long long n_out,
       else SJ_BIG((sjlt_n_kernel<NQ, 16, 8, 0>), 1024);
     } else {
       const int aligned = (lda % 2 == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
-      if (mode == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 1>), 1024, aligned);
-      else if (mode == 2) SJ_BIG((sjlt_t_kernel<NQ, 16, 2>), 1024, aligned);
-      else if (variant == 1) SJ_BIG((sjlt_t_kernel<NQ, 8, 0>), 512, aligned);
-      else if (variant == 2) SJ_BIG((sjlt_t_kernel<NQ, 4, 0>), 256, aligned);
-      else SJ_BIG((sjlt_t_kernel<NQ, 16, 0>), 1024, aligned);
+      if (mode == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 1>), 1024, aligned);
+      else if (mode == 2 && variant == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 8, 2>), 1024, aligned);
+      else if (mode == 2) SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 2>), 1024, aligned);
+      else if (variant == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 8, 0>), 1024, aligned);
+      else if (variant == 2) SJ_BIG((sjlt_t_kernel<NQ, 8, 16, 0>), 512, aligned);
+      else if (variant == 3) SJ_BIG((sjlt_t_kernel<NQ, 8, 8, 0>), 512, aligned);
+      else SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 0>), 1024, aligned);
     }
     return;
   }
