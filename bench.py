@@ -299,6 +299,9 @@ def main():
         out["roofline"] = {"kernel": "sjlt_n_kernel / sjlt_t_kernel (S^T = (op(A) R)^T, R with 4 entries +-1 per row)",
                            "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                            "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches, "bytes_per_launch": bpl}
+        tfs = os.path.join(ROOT, "profiles", "r01_pmc_sjlt_traffic.json")
+        if os.path.exists(tfs) and n == 100000 and world == 1:
+            out["roofline"]["traffic"] = json.load(open(tfs)).get("hbm_read_bytes_per_launch")
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.leaf, a.rel_tol)

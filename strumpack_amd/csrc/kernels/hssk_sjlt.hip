@@ -7,12 +7,12 @@
 // St is dn x n_out.  Every kernel reads its part of A exactly once and sums into an LDS tile with ds_add_f64.
 //
 //   sjlt_n_kernel  (Sr = A R):   St(:, i) = sum_k A(i, k) R(k, :).  A workgroup owns 64 consecutive rows i; each of
-//     its NW waves streams its own columns k (512-byte coalesced loads, U in flight per lane).  k is uniform over the
+//     its NW = 16 waves streams its own columns k (512-byte coalesced loads, U = 16 in flight per lane).  k is uniform over the
 //     wave, so the pattern arrives through scalar loads and the NQ updates of acc[c][lane] (row stride 65 doubles) are
 //     conflict-free.  The waves of a workgroup take different k, hence the atomic add.
 //   sjlt_t_kernel  (Sc = A^T R): St(:, j) = sum_k A(k, j) R(k, :).  A workgroup owns 64 consecutive columns j, lane = j:
-//     every lane loads 64 contiguous bytes (8 k) of its own column -- full cache lines, and the NW waves of the
-//     workgroup take adjacent 8-row blocks so a column is read in NW * 64-byte runs.  Again k is wave-uniform:
+//     every lane loads 128 contiguous bytes (16 k) of its own column -- full cache lines, and the NW = 8 waves of the
+//     workgroup take adjacent 16-row blocks so a column is read in 1 KB runs.  Again k is wave-uniform:
 //     scalar pattern loads, conflict-free acc[c][lane].
 //   sjlt_n_small_kernel / sjlt_t_small_kernel: the same sums with accumulator tiles that fit 64 KB (RT rows / CT
 //     columns per workgroup) for sketch blocks too wide for the kernels above (dn > 300).
@@ -286,22 +286,23 @@ template <int NQ> void launch_sketch(hssk_ctx* ctx, int transA, long long n_out,
     HSSK_LAUNCH(kernel, dim3(g64), dim3(threads), big, ctx->stream, A, lda, K, n_out, pat, dn, St, lds, ##__VA_ARGS__); \
   } while (0)
   if (big <= SJ_BIG_LDS_BYTES && variant >= 0) {
+    // measured at N = 1e5, dn = 192, nnz = 4 (tools/sjlt_only.py, profiles/r01_sjlt_variants.txt): A R 14.5 ms with
+    // 16 waves x 16 loads in flight (14.8 with x 8), A^T R 16.5 ms with 8 waves x 128-byte runs (17.5 with 16 waves,
+    // 21.9 with 64-byte runs)
+    constexpr int UN = NQ == 4 ? 16 : 8;   // U x NQ pattern words live in scalar registers
     if (!transA) {
-      if (mode == 1) SJ_BIG((sjlt_n_kernel<NQ, 16, 8, 1>), 1024);
-      else if (mode == 2) SJ_BIG((sjlt_n_kernel<NQ, 16, 8, 2>), 1024);
-      else if (variant == 1) SJ_BIG((sjlt_n_kernel<NQ, 8, 16, 0>), 512);
-      else if (variant == 2) SJ_BIG((sjlt_n_kernel<NQ, 8, 8, 0>), 512);
-      else if (variant == 3) SJ_BIG((sjlt_n_kernel<NQ, 16, 16, 0>), 1024);
-      else SJ_BIG((sjlt_n_kernel<NQ, 16, 8, 0>), 1024);
+      if (mode == 1) SJ_BIG((sjlt_n_kernel<NQ, 16, UN, 1>), 1024);
+      else if (mode == 2) SJ_BIG((sjlt_n_kernel<NQ, 16, UN, 2>), 1024);
+      else if (variant == 1) SJ_BIG((sjlt_n_kernel<NQ, 16, 8, 0>), 1024);
+      else if (variant == 2) SJ_BIG((sjlt_n_kernel<NQ, 8, UN, 0>), 512);
+      else SJ_BIG((sjlt_n_kernel<NQ, 16, UN, 0>), 1024);
     } else {
       const int aligned = (lda % 2 == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
-      if (mode == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 1>), 1024, aligned);
-      else if (mode == 2 && variant == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 8, 2>), 1024, aligned);
-      else if (mode == 2) SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 2>), 1024, aligned);
-      else if (variant == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 8, 0>), 1024, aligned);
-      else if (variant == 2) SJ_BIG((sjlt_t_kernel<NQ, 8, 16, 0>), 512, aligned);
-      else if (variant == 3) SJ_BIG((sjlt_t_kernel<NQ, 8, 8, 0>), 512, aligned);
-      else SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 0>), 1024, aligned);
+      if (mode == 1) SJ_BIG((sjlt_t_kernel<NQ, 8, 16, 1>), 512, aligned);
+      else if (mode == 2) SJ_BIG((sjlt_t_kernel<NQ, 8, 16, 2>), 512, aligned);
+      else if (variant == 1) SJ_BIG((sjlt_t_kernel<NQ, 16, 16, 0>), 1024, aligned);
+      else if (variant == 2) SJ_BIG((sjlt_t_kernel<NQ, 16, 8, 0>), 1024, aligned);
+      else SJ_BIG((sjlt_t_kernel<NQ, 8, 16, 0>), 512, aligned);
     }
     return;
   }

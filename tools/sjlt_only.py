@@ -54,12 +54,14 @@ def sweep(trans, var, vals, mode=None):
     os.environ.pop(var, None)
 
 
-# variants: n: 0 = 16 waves x 8 loads, 1 = 8 x 16, 2 = 8 x 8, 3 = 16 x 16, -1 = small-tile kernel
-#           t: 0 = 16 waves x 128-byte runs, 1 = 16 x 64, 2 = 8 x 128, 3 = 8 x 64, -1 = small-tile kernel
-sweep(1, "HSSK_SJLT_TV", (-1, 3, 2, 1, 0))
+# variants (hssk_sjlt.hip, launch_sketch): n: 0 = 16 waves x 16 loads, 1 = 16 x 8, 2 = 8 x 16, -1 = small-tile kernel
+#           t: 0 = 8 waves x 128-byte runs, 1 = 16 x 128, 2 = 16 x 64, -1 = small-tile kernel;  mode 1 = plain LDS
+#           read-modify-write instead of ds_add_f64, mode 2 = no LDS updates (streaming rate of the access pattern)
+sweep(1, "HSSK_SJLT_TV", (-1, 2, 1, 0))
 sweep(1, "HSSK_SJLT_TV", (0,), mode=1)
-sweep(1, "HSSK_SJLT_TV", (1, 0), mode=2)
-sweep(0, "HSSK_SJLT_NV", (3, 1, 0))
+sweep(1, "HSSK_SJLT_TV", (0,), mode=2)
+sweep(0, "HSSK_SJLT_NV", (-1, 2, 1, 0))
+sweep(0, "HSSK_SJLT_NV", (0,), mode=1)
 sweep(0, "HSSK_SJLT_NV", (0,), mode=2)
 run(0, reps=1)   # leave the product path's result in dS for the check below
 # checksum against a column of the exact product (row sums of the pattern applied to one column of A)
