@@ -292,6 +292,10 @@ def main():
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                      "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
+    if a.sketch == "sjlt":
+        # the flop model counts what is executed (2 nnz flops per element and product), so GFLOP/s is not comparable
+        # with the Gaussian run: compare ms_per_step
+        out["note"] = "SJLT sketch: value counts the executed flops (4 N^2 nnz for the sketch); compare ms_per_step with the Gaussian run"
     if a.sketch == "sjlt" and st["sketch_kernel_bytes"] > 0 and avg_ms > 0:
         # the SJLT products stream A once: algorithmic bytes per launch = 8 N^2 (per-rank share when sharded)
         bpl = st["sketch_kernel_bytes"] / launches

@@ -753,7 +753,7 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       src.sample(*this, c, dnew);
       ck(hssk_sync(ctx_));
       stats_.t_sketch += now() - t0;
-      stats_.f_sketch += 4.0 * (double)N * (double)N * dnew;
+      stats_.f_sketch += 4.0 * (double)N * (double)N * (sj_pat_ ? sj_nnz_ : dnew);   // SJLT: 2 nnz flops per element and product
       if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
       stats_.rounds++;
       for (auto& ids : own_by_height_) process_level(src, ids, d, dd, false);
@@ -778,7 +778,7 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       src.sample(*this, d_old, d - d_old);
       ck(hssk_sync(ctx_));
       stats_.t_sketch += now() - t0;
-      stats_.f_sketch += 4.0 * (double)N * (double)N * (d - d_old);
+      stats_.f_sketch += 4.0 * (double)N * (double)N * (sj_pat_ ? sj_nnz_ : d - d_old);
       if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << " (original)" << std::endl;
       stats_.rounds++;
       for (auto& ids : own_by_height_) process_level(src, ids, d, d - d_old, true);
