@@ -21,12 +21,14 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 L = capi.load(emu_lib.PATH)
 hk = K.Hssk(emu_lib.PATH)
 ok = True
-CASES = {2: [(150, 16, 16, 8, "stable"), (90, 16, 16, 8, "original")], 4: [(140, 16, 8, 8, "stable")], 3: [(90, 16, 16, 8, "stable")]}
-for (n, leaf, d0, dd, algo) in CASES[world]:
+# (n, leaf, d0, dd, algorithm, sketch): "sjlt" = the SJLT sketch through the streaming kernels on each rank's rows / columns
+CASES = {2: [(150, 16, 16, 8, "stable", "gaussian"), (90, 16, 16, 8, "original", "gaussian"), (130, 16, 16, 8, "stable", "sjlt")],
+         4: [(140, 16, 8, 8, "stable", "gaussian")], 3: [(90, 16, 16, 8, "stable", "gaussian"), (90, 16, 16, 8, "stable", "sjlt")]}
+for (n, leaf, d0, dd, algo, sketch) in CASES[world]:
     A = O.toeplitz(n)
     dA = hk.array(A)
     o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
-    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo)
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo, sketch=sketch, nnz0=3, nnz=2)
     ex = sdist.make_exchange(L, world, rank)
     H = sdist.from_dense_device(L, dA.ptr, n, n, o, h, ex)
     H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)   # single-process reference
