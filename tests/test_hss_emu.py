@@ -22,7 +22,7 @@ def test_ctest_case(L, name):
     HC.check_against_golden(L, CASES[name])
 
 
-@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_8", "HSS_seq_11", "HSS_seq_14"])
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_8", "HSS_seq_11"])
 def test_schur_complement(L, name):
     HC.check_schur(L, CASES[name])
 
