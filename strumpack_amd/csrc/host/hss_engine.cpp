@@ -1071,8 +1071,11 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
       std::vector<Piece>& pc = pieces[k];
       if (pc.size() <= 1) continue;
       const int m = ms[k];
-      // fan-in: as many triangles as fit the register QR (256 rows) for narrow panels, pairs otherwise
-      const size_t fan = m <= 128 ? std::max<size_t>(2, 256 / std::max(m, 1)) : 2;
+      // fan-in: as many triangles as fit the register QR (256 rows) for narrow panels; wider ones either pairwise
+      // (390-row blocked QR per tree level) or all at once through the tall blocked path (STRUMPACK_AMD_TSQR_FANIN)
+      static const int fan_env = std::getenv("STRUMPACK_AMD_TSQR_FANIN") ? std::atoi(std::getenv("STRUMPACK_AMD_TSQR_FANIN")) : 0;
+      const size_t fan_wide = fan_env >= 2 ? (size_t)fan_env : 2;
+      const size_t fan = m <= 128 ? std::max<size_t>(2, 256 / std::max(m, 1)) : fan_wide;
       std::vector<Piece> next;
       for (size_t i = 0; i < pc.size(); i += fan) {
         const size_t cntp = std::min(fan, pc.size() - i);
