@@ -182,6 +182,7 @@ typedef struct hssk_triu_desc {
   const double* src;
   double* dst;
   int rows, cols, lds, ldd;
+  int dstride; /* row i of src goes to row i * dstride of dst (0 or 1: contiguous): interleaves stacked triangles */
 } hssk_triu_desc;
 int hssk_copy_triu(hssk_ctx* ctx, const hssk_triu_desc* descs, int count);
 
@@ -228,6 +229,10 @@ typedef struct hssk_qr_desc {
   int ldq, nq;
   double* rdiag;
   double* work; /* device, rows + cols doubles */
+  /* stair > 0 (needs nq == 0, more than 256 rows): column j of A is zero at and below row stair * (j + 1) -- a stack
+   * of `stair` upper-triangular factors with their rows interleaved (TSQR tree).  The blocked factorisation then only
+   * touches the rows [j0, stair * (j0 + panel)) of each panel step; R is the same as for the dense sweep. */
+  int stair;
 } hssk_qr_desc;
 int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
 /* Q(:, 0:nq) only, from panels factored by an earlier hssk_qr_vbatched call with the same A (reflectors + R)

@@ -1037,6 +1037,11 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
 // -- row chunks factored independently (register-resident / blocked batched QR), the R factors stacked pairwise
 // and re-factored until one is left -- and the ID then runs on that small panel in the register kernels.  Same
 // pivots, ranks and X = R11^{-1} R12 as the direct QRCP up to rounding; backward stable (all Householder).
+static bool tsqr_staircase() {   // (read per call: the tests compare both paths in one process)
+  const char* e = std::getenv("STRUMPACK_AMD_TSQR_DENSE");
+  return !(e && std::atoi(e));
+}
+
 void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>& which, std::vector<double*>& Ws,
                             std::vector<int>& ds) {
   Arena& tmp = *tmp_;
@@ -1081,15 +1086,20 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
         const size_t cntp = std::min(fan, pc.size() - i);
         if (cntp == 1) { next.push_back(pc[i]); continue; }
         int rows = 0;
-        for (size_t t = 0; t < cntp; t++) rows += pc[i + t].rows;
+        bool full = true;   // every piece a full m x m triangle
+        for (size_t t = 0; t < cntp; t++) { rows += pc[i + t].rows; full = full && pc[i + t].rows == m; }
         double* dst = tmp.dbl((size_t)rows * m);
+        // full triangles are stacked with their rows interleaved (row r of piece t -> row cntp r + t): column j of the
+        // stack is then zero from row cntp (j + 1) on, and the blocked QR only sweeps that staircase (hssk_qr_desc::stair)
+        const bool stair = full && rows > 256 && tsqr_staircase();
         int r0 = 0;
         for (size_t t = 0; t < cntp; t++) {
-          cp.push_back(hssk_triu_desc{pc[i + t].p, dst + r0, pc[i + t].rows, m, pc[i + t].ld, rows});
+          if (stair) cp.push_back(hssk_triu_desc{pc[i + t].p, dst + t, pc[i + t].rows, m, pc[i + t].ld, rows, (int)cntp});
+          else cp.push_back(hssk_triu_desc{pc[i + t].p, dst + r0, pc[i + t].rows, m, pc[i + t].ld, rows, 1});
           r0 += pc[i + t].rows;
         }
         double* wk = tmp.dbl((size_t)rows + m);
-        qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk});
+        qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk, stair ? (int)cntp : 0});
         next.push_back(Piece{dst, rows, std::min(rows, m)});
       }
       pc.swap(next);

@@ -121,9 +121,10 @@ __global__ void copy_triu_kernel(const hssk_triu_desc* __restrict__ descs, const
   const Work2 w = work[blockIdx.x];
   const hssk_triu_desc p = descs[w.prob];
   const int jend = min(p.cols, (w.chunk + 1) * COLS_PER_WG);
+  const int st = p.dstride > 1 ? p.dstride : 1;
   for (int j = w.chunk * COLS_PER_WG; j < jend; j++)
     for (int i = threadIdx.x; i < p.rows; i += blockDim.x)
-      hssk_gstore(p.dst, i + (size_t)j * p.ldd, i <= j ? hssk_gload(p.src, i + (size_t)j * p.lds) : 0.);
+      hssk_gstore(p.dst, (size_t)i * st + (size_t)j * p.ldd, i <= j ? hssk_gload(p.src, i + (size_t)j * p.lds) : 0.);
 }
 
 // transpose through a padded LDS tile: dst(c, r) = src(r, c)

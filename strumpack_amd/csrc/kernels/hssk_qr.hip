@@ -451,7 +451,10 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
       const hssk_qr_desc& d = descs[i];
       const int kmax = std::min(d.rows, d.cols);
       if (j0 >= kmax && !(factor && p == 0 && d.rdiag)) continue;
-      const int nb = std::max(0, std::min(QB, kmax - j0)), rr = d.rows - j0;
+      const int nb = std::max(0, std::min(QB, kmax - j0));
+      // staircase input (interleaved stack of triangles): the panel's columns are zero from row stair * (j0 + nb) on
+      const int rend = (d.stair > 0 && d.nq == 0) ? std::min<long long>(d.rows, (long long)d.stair * (j0 + nb)) : d.rows;
+      const int rr = rend - j0;
       double* Ap = d.A + j0 + (size_t)j0 * d.lda;
       double* Vc = ws + offV[i] + j0 + (size_t)j0 * d.rows;
       double* VT = Vc + (size_t)d.rows * kmax;

@@ -277,6 +277,30 @@ def case_qr(hk, shapes, seed=7):
                 assert np.allclose(Q[:, :k] @ Rg, A, atol=1e-11 * max(1, np.abs(A).max()))
 
 
+def case_qr_staircase(hk, shapes, seed=27):
+    """hssk_qr_desc.stair: an interleaved stack of `fan` upper-triangular m x m factors (row r of triangle t at row
+    fan * r + t) -- the TSQR tree's input -- must give the same R as the dense sweep / LAPACK."""
+    r = rng(seed)
+    descs, keep = [], []
+    for (m, fan) in shapes:
+        rows = fan * m
+        A = np.zeros((rows, m))
+        for t in range(fan):
+            A[t::fan] = np.triu(r.standard_normal((m, m)))
+        dA = hk.array(A)
+        drd, dwk = hk.empty((2,)), hk.empty((rows + m,))
+        keep.append((A, dA, drd, dwk))
+        descs.append(K.QrDesc(dA.ptr, rows, rows, m, None, rows, 0, drd.ptr, dwk.ptr, fan))
+    hk.batch("hssk_qr_vbatched", descs)
+    hk.sync()
+    for ((m, fan), (A, dA, drd, _)) in zip(shapes, keep):
+        Rg = np.triu(dA.get())[:m]
+        Rl = sla.qr(A, mode="r")[0][:m]
+        assert np.allclose(Rg, Rl, atol=1e-11 * np.abs(Rl).max()), f"staircase R mismatch m={m} fan={fan}"
+        rd = drd.get()
+        assert np.isclose(rd[0], np.abs(np.diag(Rl)).max()) and np.isclose(rd[1], np.abs(np.diag(Rl)).min())
+
+
 def case_qr_lazy(hk, shapes, seed=17):
     """Factor without Q, then hssk_formq_vbatched from the stored reflectors == Q of the one-call path."""
     r = rng(seed)

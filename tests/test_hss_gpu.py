@@ -28,7 +28,9 @@ def test_ctest_case(L, name):
                                   "HSS_seq_14", "HSS_seq_22", "config1_T4096_defaults",
                                   "config2shape_T8192_leaf256_rtol1e-4"])
 def test_schur_complement(L, name):
-    HC.check_schur(L, CASES[name], dense_check=CASES[name]["n"] <= 4096)
+    hk = K.Hssk(_loader.lib_path())
+    HC.check_schur(L, CASES[name], dense_check=CASES[name]["n"] <= 4096, hk=hk)
+    hk.close()
 
 
 @pytest.mark.parametrize("name", sorted(HC.sjlt_golden()))

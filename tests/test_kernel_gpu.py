@@ -57,6 +57,28 @@ def test_kernel_regression_example_10k(lib):
     print("kernel regression 10k (reference neighbours):", info)
 
 
+def test_tsqr_staircase_matches_dense_sweep():
+    """The TSQR pre-reduction of tall ID panels stacks R factors with interleaved rows and factors only the staircase
+    (hssk_qr_desc.stair); the dense sweep of the same stack (STRUMPACK_AMD_TSQR_DENSE=1) must give the same matrix."""
+    import os
+    import numpy as np
+    from strumpack_amd import capi, dist as sdist
+    L = capi.load(_loader.lib_path())
+    n, d = 20000, 8
+    X = np.random.default_rng(7).random((n, d))
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-10, leaf_size=256, max_rank=50000)
+    res = []
+    for dense in ("1", "0"):
+        os.environ["STRUMPACK_AMD_TSQR_DENSE"] = dense
+        H, Xp, perm = sdist.from_kernel(L, X.copy(), o, kernel="Gauss", h=1.3, lam=3.11, clustering="kdtree", neighbors=64)
+        b = np.linspace(-1, 1, n)
+        res.append((H.node_info().copy(), H.mult(b)[:, 0]))
+        H.destroy()
+    os.environ.pop("STRUMPACK_AMD_TSQR_DENSE")
+    assert np.array_equal(res[0][0], res[1][0]), "ranks differ between the staircase and the dense TSQR sweeps"
+    assert np.linalg.norm(res[0][1] - res[1][1]) <= 1e-10 * np.linalg.norm(res[0][1])
+
+
 def test_full_size_properties_100k():
     """BASELINE configs[3] size (N = 100000 points in R^8, Gauss kernel, h = 1.3, lambda = 3.11) through size-independent
     properties: sampled rows of K against the compressed matrix, symmetry (V = U, B10 = B01^T), linearity, ULV residual."""

@@ -98,6 +98,10 @@ def test_kernel_predict(hk):
     KC.case_kernel_predict(hk)
 
 
+def test_qr_staircase(hk):
+    KC.case_qr_staircase(hk, [(140, 2), (195, 2), (70, 4), (150, 3)])
+
+
 def test_sjlt(hk):
     KC.case_sjlt(hk, n_out=45, K=300, dn=24, nnz=4)
     KC.case_sjlt(hk, n_out=130, K=77, dn=200, nnz=2, seed=4)

@@ -104,6 +104,11 @@ def test_kernel_predict(hk):
     KC.case_kernel_predict(hk)
 
 
+def test_qr_staircase(hk):
+    KC.case_qr_staircase(hk, [(195, 2), (196, 2), (140, 2), (130, 4), (200, 3), (256, 2)] * 3)
+    KC.case_qr_staircase(hk, [(300, 2), (260, 4)], seed=28)    # tall path (more than 512 rows)
+
+
 def test_sjlt(hk):
     KC.case_sjlt(hk, n_out=45, K=300, dn=24, nnz=4)
     KC.case_sjlt(hk, n_out=1000, K=3001, dn=192, nnz=4, seed=4)
