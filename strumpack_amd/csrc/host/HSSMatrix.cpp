@@ -280,6 +280,86 @@ DenseMatrix<double> HSSMatrix<double>::apply_child(int c, Trans op, const DenseM
   return y;
 }
 
+// ---- child views (HSS/HSSMatrix.hpp:194-202) ----------------------------------------------------------------
+const HSSMatrixChild* HSSMatrix<double>::child(int c) const {
+  if (leaf()) throw std::logic_error("child: the matrix is a leaf");
+  if (c != 0 && c != 1) throw std::invalid_argument("child: c must be 0 or 1");
+  const auto& root = eng_->nodes()[0];
+  const int id = c == 0 ? root.c0 : root.c1;
+  if (!ch_[c] || ch_[c]->node() != id || ch_[c]->engine() != eng_.get()) ch_[c].reset(new HSSMatrixChild(eng_.get(), id));
+  return ch_[c].get();
+}
+const HSSMatrixChild* HSSMatrixChild::child(int c) const {
+  if (leaf()) throw std::logic_error("child: the matrix is a leaf");
+  if (c != 0 && c != 1) throw std::invalid_argument("child: c must be 0 or 1");
+  const int id = c == 0 ? nd().c0 : nd().c1;
+  if (!ch_[c]) ch_[c].reset(new HSSMatrixChild(eng_, id));
+  return ch_[c].get();
+}
+void HSSMatrixChild::mult(Trans op, const DenseM_t& x, DenseM_t& y) const {
+  if (x.rows() != rows() || y.rows() != rows() || x.cols() != y.cols()) throw std::invalid_argument("mult: dimension mismatch");
+  eng_->mult_node(node_, op == Trans::N ? 'N' : 'C', int(x.cols()), x.data(), x.ld(), y.data(), y.ld(), false);
+}
+DenseMatrix<double> HSSMatrixChild::apply(const DenseM_t& b) const {
+  DenseM_t c(rows(), b.cols());
+  mult(Trans::N, b, c);
+  return c;
+}
+DenseMatrix<double> HSSMatrixChild::applyC(const DenseM_t& b) const {
+  DenseM_t c(rows(), b.cols());
+  mult(Trans::C, b, c);
+  return c;
+}
+DenseMatrix<double> HSSMatrixChild::dense() const {
+  const std::size_t n = rows(), bs = 256;
+  DenseM_t D(n, n);
+  for (std::size_t j0 = 0; j0 < n; j0 += bs) {
+    const std::size_t nb = std::min(bs, n - j0);
+    DenseM_t E(n, nb);
+    for (std::size_t j = 0; j < nb; j++) E(j0 + j, j) = 1.;
+    DenseMatrixWrapper<double> Dj(n, nb, D, 0, j0);
+    eng_->mult_node(node_, 'N', int(nb), E.data(), E.ld(), Dj.data(), Dj.ld(), false);
+  }
+  return D;
+}
+DenseMatrix<double> HSSMatrixChild::extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const {
+  const std::size_t n = rows();
+  DenseM_t E(n, J.size()), HE(n, J.size()), B(I.size(), J.size());
+  for (std::size_t j = 0; j < J.size(); j++) {
+    if (J[j] >= n) throw std::invalid_argument("extract: column index out of range");
+    E(J[j], j) = 1.;
+  }
+  if (!J.empty()) eng_->mult_node(node_, 'N', int(J.size()), E.data(), E.ld(), HE.data(), HE.ld(), false);
+  for (std::size_t j = 0; j < J.size(); j++)
+    for (std::size_t i = 0; i < I.size(); i++) {
+      if (I[i] >= n) throw std::invalid_argument("extract: row index out of range");
+      B(i, j) = HE(I[i], j);
+    }
+  return B;
+}
+void HSSMatrixChild::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
+  const int lo0 = nd().lo;
+  for (int i = node_, e = eng_->node_end(node_); i < e; i++) {
+    const auto& n = eng_->nodes()[i];
+    out << "SEQ rank=0 b = [" << roff + n.lo - lo0 << "," << roff + n.lo - lo0 + n.m << " x " << coff + n.lo - lo0 << ","
+        << coff + n.lo - lo0 + n.m << "]  U = " << n.mU << " x " << n.rU << " V = " << n.mV << " x " << n.rV
+        << (n.leaf() ? " leaf" : " non-leaf") << std::endl;
+  }
+}
+DenseMatrix<double> HSSMatrixChild::Factors::Vhat() const {
+  DeviceHSS* eng = self->eng_;
+  const auto& root = eng->nodes()[0];
+  if (root.leaf() || self->node_ != root.c0 || !eng->is_partially_factored())
+    throw std::logic_error("Vhat: only child(0) carries it, after partial_factor()");
+  const auto d = eng->schur_dims();
+  DenseM_t V(d.mu0, d.rV0);
+  const auto& a = eng->nodes()[root.c0];
+  if (d.mu0 && d.rV0)
+    if (hssk_memcpy2d_d2h(eng->ctx(), V.data(), sizeof(double) * V.ld(), a.Vt0, sizeof(double) * d.mu0, sizeof(double) * d.mu0, d.rV0))
+      throw std::runtime_error(hssk_last_error());
+  return V;
+}
+
 void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
   if (!eng_) return;
   for (auto& nd : eng_->nodes()) {  // pre-order, same line format as HSSMatrix.cpp:344-350

@@ -554,23 +554,30 @@ void DeviceHSS::allgather_rows(double* dx, long long ldx, int nrhs) {
 
 bool DeviceHSS::is_compressed() const { return nodes_[0].compressed(); }
 int DeviceHSS::levels() const { return nodes_[0].height + 1; }
-int DeviceHSS::rank() const {
+int DeviceHSS::rank() const { return rank(0); }
+long long DeviceHSS::nonzeros() const { return nonzeros(0); }
+long long DeviceHSS::memory() const { return memory(0); }
+// the same over the sub-tree of a node (HSSMatrix::child(c)->rank() ...; the node's own basis belongs to it, as in the
+// reference, where a child carries its U and V)
+int DeviceHSS::rank(int node) const {
   int r = 0;
-  for (auto& nd : nodes_) r = std::max(r, std::max(nd.rU, nd.rV));
+  for (int i = node, e = subtree_end(node); i < e; i++) r = std::max(r, std::max(nodes_[i].rU, nodes_[i].rV));
   return r;
 }
-long long DeviceHSS::nonzeros() const {
+long long DeviceHSS::nonzeros(int node) const {
   long long t = 0;
-  for (auto& nd : nodes_) {
+  for (int i = node, e = subtree_end(node); i < e; i++) {
+    const Node& nd = nodes_[i];
     if (nd.leaf()) t += (long long)nd.m * nd.m;
     else t += (long long)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (long long)nodes_[nd.c1].rU * nodes_[nd.c0].rV;
     if (nd.lvl > 0) t += (long long)nd.rU * (nd.mU - nd.rU) + nd.mU + (long long)nd.rV * (nd.mV - nd.rV) + nd.mV;
   }
   return t;
 }
-long long DeviceHSS::memory() const {
+long long DeviceHSS::memory(int node) const {
   long long t = 0;
-  for (auto& nd : nodes_) {
+  for (int i = node, e = subtree_end(node); i < e; i++) {
+    const Node& nd = nodes_[i];
     if (nd.leaf()) t += 8LL * nd.m * nd.m;
     else t += 8LL * ((long long)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (long long)nodes_[nd.c1].rU * nodes_[nd.c0].rV);
     if (nd.lvl > 0) t += 8LL * ((long long)nd.rU * (nd.mU - nd.rU) + (long long)nd.rV * (nd.mV - nd.rV)) + 4LL * (nd.mU + nd.mV);
@@ -1947,6 +1954,12 @@ void DeviceHSS::mult_child(int c, char trans, int nrhs, const double* x, long lo
                            bool on_device) {
   if (nodes_[0].leaf()) throw std::logic_error("mult_child: the root is a leaf");
   mult_sub(c == 0 ? nodes_[0].c0 : nodes_[0].c1, trans, nrhs, x, ldx, y, ldy, on_device, 0.0);
+}
+
+void DeviceHSS::mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
+                          bool on_device) {
+  if (node < 0 || node >= (int)nodes_.size()) throw std::invalid_argument("mult_node: no such node");
+  mult_sub(node, trans, nrhs, x, ldx, y, ldy, on_device, 0.0);
 }
 
 void DeviceHSS::basis_up(int sr, bool useU, const double* dA, long long lda, int c, double* dOut, int ldout, Arena& wk) {

@@ -117,6 +117,12 @@ class DeviceHSS {
                               long long ldsr, double* Sc, long long ldsc, bool on_device);
   // rows of the (c)-th child's sub-matrix applied to x: y = op(H_cc) x  (child(c)->apply)
   void mult_child(int c, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device);
+  // the same for the sub-matrix rooted at any node of the pre-order table (HSSMatrix::child(c)->child(c')...)
+  void mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device);
+  int node_end(int node) const { return subtree_end(node); }   // pre-order ids of the sub-tree: [node, node_end)
+  int rank(int node) const;
+  long long memory(int node) const;
+  long long nonzeros(int node) const;
 
   // ---- introspection ----
   int rows() const { return n_; }

@@ -135,6 +135,38 @@ int main(int argc, char* argv[]) {
     Sc2.scaled_add(-1., Sc);
     std::cout << "# Schur products, direct vs indirect = " << Sr2.normF() / Sr.normF() << " , " << Sc2.normF() / Sc.normF() << std::endl;
     if (Sr2.normF() > 1e-10 * Sr.normF() || Sc2.normF() > 1e-10 * Sc.normF()) { std::cout << "ERROR: Schur products disagree" << std::endl; return 1; }
+    // child views (HSSMatrix.hpp:194-202): blocks of H through child(c), children of children, Vhat through the view
+    {
+      auto c0 = H.child(0);
+      auto c1 = H.child(1);
+      if (c0->rows() != n0 || c1->rows() != n1 || c0->levels() + 1 > H.levels() || c1->rank() > H.rank()) {
+        std::cout << "ERROR: child views have the wrong shape" << std::endl;
+        return 1;
+      }
+      if (c0->V_rank() != Theta.cols() || c0->ULV().Vhat().rows() != Vhat.rows()) { std::cout << "ERROR: child(0) ranks" << std::endl; return 1; }
+      auto D11 = c1->dense();
+      auto Hd = H.dense();
+      double e11 = 0, n11 = 0;
+      for (std::size_t j = 0; j < n1; j++)
+        for (std::size_t i = 0; i < n1; i++) { const double df = D11(i, j) - Hd(n0 + i, n0 + j); e11 += df * df; n11 += Hd(n0 + i, n0 + j) * Hd(n0 + i, n0 + j); }
+      std::cout << "# ||child(1)->dense() - H(1,1)||_F/||H(1,1)||_F = " << std::sqrt(e11 / n11) << std::endl;
+      if (std::sqrt(e11 / n11) > 1e-13) { std::cout << "ERROR: child(1) is not the (1,1) block" << std::endl; return 1; }
+      if (!c1->leaf()) {
+        auto c10 = c1->child(0);
+        DenseMatrix<double> x(c10->rows(), 2);
+        x.random();
+        auto y = c10->apply(x);
+        double e = 0, nn = 0;
+        for (std::size_t j = 0; j < 2; j++)
+          for (std::size_t i = 0; i < c10->rows(); i++) {
+            double s = 0;
+            for (std::size_t k = 0; k < c10->rows(); k++) s += D11(i, k) * x(k, j);
+            e += (y(i, j) - s) * (y(i, j) - s); nn += s * s;
+          }
+        if (std::sqrt(e / nn) > 1e-12) { std::cout << "ERROR: child(1)->child(0)->apply" << std::endl; return 1; }
+        if (std::abs(c10->get(1 % c10->rows(), 0) - D11(1 % c10->rows(), 0)) > 1e-13) { std::cout << "ERROR: child get" << std::endl; return 1; }
+      }
+    }
     // S^{-1} y is the lower part of H^{-1} [0; y]
     H.factor();
     DenseMatrix<double> rhs(m, 1);
