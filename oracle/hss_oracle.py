@@ -94,6 +94,34 @@ class MinstdNormal:
         return flat.reshape((rows, cols), order="F")
 
 
+class SJLTGenerator:
+    """The SJLT sketching matrix of --hss_compression_sketch SJLT (HSS/HSSMatrix.sketch.hpp:260-460): every ROW of an
+    n x cols block gets nnz entries +-1 (SJLT_to_dense, :573-596, keeps them unscaled).  CHUNK (createSJLTCRS_Chunks,
+    :419-441): the columns are cut into nnz chunks of cols // nnz, one nonzero at a uniform position of each chunk,
+    sign by a fair coin.  PERM (createSJLTCRS, :316-341): the first nnz entries of a random permutation of the
+    columns.  The first block (d0 + dd columns) uses nnz0, later blocks nnz (compress_stable.hpp:62-76).  The
+    reference seeds its engine from the clock (:266-270), so only the distribution is restated, with numpy's
+    generator."""
+
+    def __init__(self, nnz0=4, nnz=4, algo="chunk", seed=0):
+        self.nnz0, self.nnz, self.algo = nnz0, nnz, algo
+        self.rng = np.random.default_rng(seed)
+        self.first = True
+
+    def matrix(self, rows, cols):
+        nnz = min(self.nnz0 if self.first else self.nnz, cols)
+        self.first = False
+        R = np.zeros((rows, cols), order="F")
+        sign = self.rng.integers(0, 2, size=(rows, nnz)) * 2.0 - 1.0
+        if self.algo == "chunk":
+            chunk = cols // nnz
+            pos = self.rng.integers(0, chunk, size=(rows, nnz)) + chunk * np.arange(nnz)[None, :]
+        else:
+            pos = np.argsort(self.rng.random((rows, cols)), axis=1)[:, :nnz]
+        R[np.arange(rows)[:, None], pos] = sign
+        return R
+
+
 # ----------------------------------------------------------------------------------------------
 # Test-problem generators of test/test_HSS_seq.cpp:69-105
 # ----------------------------------------------------------------------------------------------
@@ -595,7 +623,19 @@ class HSSMatrix:
                 d = 2 * (d_old - o.p) + o.p
 
     # -- apply: HSS/HSSMatrix.apply.hpp:55-220 ---------------------------------------------------
-    def mult(self, x, trans="N", beta=0.0, y=None):
+    def subtree(self, top):
+        """Nodes of the sub-tree of `top` in pre-order (a child of an HSS matrix is an HSS matrix, HSSMatrix.hpp:194)."""
+        out, stack = [], [top]
+        while stack:
+            nd = stack.pop()
+            out.append(nd)
+            stack.extend(reversed(nd.ch))
+        return out
+
+    def mult(self, x, trans="N", beta=0.0, y=None, top=None):
+        """op(H) x; top = a node: the diagonal block of that node (child(c)->apply, HSSMatrix.apply.hpp:55-220)."""
+        if top is not None and top is not self.root:
+            return self._mult_sub(top, x, trans)
         x = np.asarray(x, dtype=np.float64).reshape(self.n, -1)
         T = trans in ("T", "C", "t", "c")
         tmp1, tmp2 = {}, {}
@@ -636,8 +676,96 @@ class HSSMatrix:
                 tmp2[a.idx], tmp2[b.idx] = t0, t1
         return out
 
+    def _mult_sub(self, top, x, trans):
+        T = trans in ("T", "C", "t", "c")
+        x = np.asarray(x, dtype=np.float64).reshape(top.m, -1)
+        nodes = self.subtree(top)
+        tmp1, tmp2 = {}, {}
+        for nd in sorted(nodes, key=lambda q: q.height):
+            if nd is top:
+                continue
+            E, perm = (nd.UE, nd.Uperm) if T else (nd.VE, nd.Vperm)
+            b = x[nd.lo - top.lo:nd.lo - top.lo + nd.m] if nd.leaf else np.vstack([tmp1[nd.ch[0].idx], tmp1[nd.ch[1].idx]])
+            tmp1[nd.idx] = basis_applyC(E, perm, b)
+        out = np.zeros_like(x)
+        for nd in nodes:
+            E, perm = (nd.VE, nd.Vperm) if T else (nd.UE, nd.Uperm)
+            r = 0 if (E is None or nd is top) else E.shape[1]
+            lo = nd.lo - top.lo
+            if nd.leaf:
+                out[lo:lo + nd.m] += (nd.D.T if T else nd.D) @ x[lo:lo + nd.m]
+                if r:
+                    out[lo:lo + nd.m] += basis_apply(E, perm, tmp2[nd.idx])
+            else:
+                a, b = nd.ch
+                t0 = (nd.B10.T if T else nd.B01) @ tmp1[b.idx]
+                t1 = (nd.B01.T if T else nd.B10) @ tmp1[a.idx]
+                if r:
+                    t = basis_apply(E, perm, tmp2[nd.idx])
+                    ra = a.rV if T else a.rU
+                    t0, t1 = t0 + t[:ra], t1 + t[ra:]
+                tmp2[a.idx], tmp2[b.idx] = t0, t1
+        return out
+
     def dense(self):
         return self.mult(np.eye(self.n))
+
+    # -- Schur complement of the (0,0) block: HSS/HSSMatrix.Schur.hpp, factor.hpp:43-49 ---------------------------
+    def apply_UV_big(self, top, Uop=None, Vop=None):
+        """Theta = Ubig Uop, Phi = Vbig Vop over the sub-tree of `top` (apply_UV_big, Schur.hpp:254-323)."""
+        res = []
+        for op, useU in ((Uop, True), (Vop, False)):
+            if op is None:
+                res.append(None)
+                continue
+            out = np.zeros((top.m, op.shape[1]))
+            cur = {top.idx: op}
+            for nd in self.subtree(top):
+                E, perm = (nd.UE, nd.Uperm) if useU else (nd.VE, nd.Vperm)
+                t = basis_apply(E, perm, cur[nd.idx]) if E is not None and E.shape[1] and op.shape[1] else \
+                    np.zeros(((nd.Urows if useU else nd.Vrows), op.shape[1]))
+                if nd.leaf:
+                    out[nd.lo - top.lo:nd.lo - top.lo + nd.m] = t
+                else:
+                    a, b = nd.ch
+                    ra = a.rU if useU else a.rV
+                    cur[a.idx], cur[b.idx] = t[:ra], t[ra:]
+            res.append(out)
+        return res
+
+    def apply_UtVt_big(self, top, A):
+        """(Ubig^T A, Vbig^T A) over the sub-tree of `top` (apply_UtVt_big, Schur.hpp:223-252)."""
+        res = []
+        for useU in (True, False):
+            tmp = {}
+            for nd in sorted(self.subtree(top), key=lambda q: q.height):
+                E, perm = (nd.UE, nd.Uperm) if useU else (nd.VE, nd.Vperm)
+                b = A[nd.lo - top.lo:nd.lo - top.lo + nd.m] if nd.leaf else np.vstack([tmp[nd.ch[0].idx], tmp[nd.ch[1].idx]])
+                tmp[nd.idx] = basis_applyC(E, perm, b)
+            res.append(tmp[top.idx])
+        return res
+
+    def partial_factor(self):
+        """ULV of child(0) alone, as the root of its sub-tree, keeping Vhat (partial_factor, factor.hpp:43-49, :96-104,
+        :113-114)."""
+        self.factor(top=self.root.ch[0], partial=True)
+
+    def schur_update(self):
+        """-> Theta = U1big B10, DUB01 = D00^{-1} U0 B01, Phi = (D00^{-1} U0 B01 V1big^T)^T, Vhat  (Schur_update,
+        Schur.hpp:40-59; Vhat = child(0)->ULV().Vhat(), HSSExtra.hpp:191)."""
+        c0, c1 = self.root.ch
+        UB = basis_apply(c0.UE, c0.Uperm, self.root.B01) if c0.rU else np.zeros((c0.Urows, self.root.B01.shape[1]))
+        DUB01 = sla.lu_solve(c0.ulv["LU"], UB) if UB.size else UB
+        Theta, Phi = self.apply_UV_big(c1, self.root.B10, DUB01.T.copy())
+        return Theta, DUB01, Phi, c0.ulv["Vhat"]
+
+    def schur_product_direct(self, Theta, DUB01, Phi, Vhat, R):
+        """Sr = S R, Sc = S^T R with S = H11 - Theta Vhat^T Phi^T (Schur_product_direct, Schur.hpp:60-143)."""
+        c1 = self.root.ch[1]
+        U1tR, V1tR = self.apply_UtVt_big(c1, R)
+        Sr = self.mult(R, "N", top=c1) - Theta @ ((Vhat.T @ DUB01) @ V1tR)
+        Sc = self.mult(R, "T", top=c1) - Phi @ (Vhat @ (self.root.B10.T @ U1tR))
+        return Sr, Sc
 
     def shift(self, sigma):
         """HSSMatrix::shift, HSS/HSSMatrix.cpp:359-365 (ULV factors become stale)."""
@@ -647,12 +775,16 @@ class HSSMatrix:
             nd.ulv = None
 
     # -- ULV factorization: HSS/HSSMatrix.factor.hpp:51-147 -------------------------------------
-    def factor(self):
+    def factor(self, top=None, partial=False):
         work = {}
+        top = top or self.root
+        inside = {nd.idx for nd in self.subtree(top)}
         for h in sorted(self.by_height):
             for nd in self.by_height[h]:
+                if nd.idx not in inside:
+                    continue
                 f = {}
-                isroot = nd.lvl == 0
+                isroot = nd is top
                 if not nd.leaf:
                     a, b = nd.ch
                     Dt0, Vt10 = work.pop(a.idx)
@@ -663,15 +795,17 @@ class HSSMatrix:
                     Dh[a.rU:, a.rU:] = Dt1
                     Dh[:a.rU, a.rU:] = nd.B01 @ Vt11.T
                     Dh[a.rU:, :a.rU] = nd.B10 @ Vt10.T
-                    if not isroot:
+                    if not isroot or partial:
                         V = basis_dense(nd.VE, nd.Vperm)
                         Vh = np.vstack([Vt10 @ V[:a.rV], Vt11 @ V[a.rV:]])
                 else:
                     Dh = nd.D.copy()
-                    if not isroot:
+                    if not isroot or partial:
                         Vh = basis_dense(nd.VE, nd.Vperm)
                 if isroot:
                     f["LU"] = sla.lu_factor(Dh) if Dh.size else None
+                    if partial:
+                        f["Vhat"] = Vh
                 else:
                     m, r = len(nd.Uperm), nd.rU
                     PD = Dh[nd.Uperm]                                # P^T D
