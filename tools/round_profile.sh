@@ -44,3 +44,11 @@ print(json.dumps(res, indent=1))
 PY
 head -12 $out/kt/kt_kernel_stats.csv | cut -c1-160
 tail -c 1500 $out/bench_n1.json
+# the other two workloads: SJLT-sketch variant (bench, kernel summary, HBM traffic) and the kernel-matrix front end
+bash /root/repo/tools/round_profile_sjlt.sh $tag > $out/sjlt_profile.log 2>&1
+cd /root/repo
+python bench.py --workload kernel --no-cpu-baseline > $out/bench_kernel_n1.json 2> $out/bench_kernel.err
+(cd /tmp; timeout 120 rocprofv3 --kernel-trace --stats -d $out/kt_kernel -o kt --output-format csv -- python /root/repo/bench.py --workload kernel --no-cpu-baseline > $out/bench_kernel_rocprof.json 2> $out/kt_kernel.err)
+# copy into profiles/ afterwards:  bench_n1.json -> rNN_bench_n1.json, kt/kt_kernel_stats.csv -> rNN_kernel_stats_bench_n100k.csv,
+# pmc_traffic_raw.json -> rNN_pmc_traffic.json, bench_sjlt_n1.json, kt_sjlt/kt_kernel_stats.csv, pmc_sjlt_traffic.json,
+# bench_kernel_n1.json, kt_kernel/kt_kernel_stats.csv
