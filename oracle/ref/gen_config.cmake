@@ -13,7 +13,3 @@ set(STRUMPACK_VERSION_MAJOR 8)
 set(STRUMPACK_VERSION_MINOR 0)
 set(STRUMPACK_VERSION_PATCH 0)
 configure_file(${REF}/src/StrumpackConfig.h.in ${OUT}/StrumpackConfig.h)
-# Fortran name mangling of the LAPACK/BLAS in this image (MKL, gfortran-style
-# lower-case + trailing underscore); CMake's FortranCInterface would emit the same macro.
-file(WRITE ${OUT}/StrumpackFortranCInterface.h
-"#ifndef STRUMPACK_FC_HEADER_INCLUDED\n#define STRUMPACK_FC_HEADER_INCLUDED\n#define STRUMPACK_FC_GLOBAL(name,NAME) name##_\n#define STRUMPACK_FC_GLOBAL_(name,NAME) name##_\n#endif\n")
