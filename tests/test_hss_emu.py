@@ -43,5 +43,5 @@ def test_api_semantics(L):
 def test_sweep_plans(L):
     from strumpack_amd import hssk as K
     hk = K.Hssk(emu_lib.PATH)
-    HC.check_sweep_plans(L, hk, n=200)
+    HC.check_sweep_plans(L, hk, n=130)
     hk.close()
