@@ -4,11 +4,16 @@
 // Deterministic, no data races inside a workgroup; catches indexing/logic errors, not memory-model
 // ones.  Wave collectives require every live lane of the wave to participate (as on hardware with
 // a full exec mask).
+// (fortified longjmp rejects jumps between fiber stacks)
+#undef _FORTIFY_SOURCE
+#include <setjmp.h>
 #include <ucontext.h>
 
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -19,10 +24,13 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 namespace emu {
 namespace {
 constexpr size_t STACK = 256 * 1024;
+// A fiber is entered once through makecontext / setcontext; every later switch is _setjmp / _longjmp, which -- unlike
+// swapcontext -- does not save and restore the signal mask (one system call per switch).
 struct Fiber {
   ucontext_t ctx;
+  jmp_buf jb;
   char* stack = nullptr;
-  bool done = false;
+  bool done = false, started = false;
 };
 struct Wave {
   int count = 0, live = 0;
@@ -30,7 +38,7 @@ struct Wave {
   double buf[64], buf2[64];
 };
 struct Worker {
-  ucontext_t sched;
+  jmp_buf sched;
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
   int cur = 0, live = 0, bcount = 0;
@@ -43,7 +51,7 @@ thread_local Worker* W = nullptr;
 
 void yield() {
   Worker* w = W;
-  swapcontext(&w->fibers[w->cur].ctx, &w->sched);
+  if (!_setjmp(w->fibers[w->cur].jb)) _longjmp(w->sched, 1);
 }
 void trampoline() {
   Worker* w = W;
@@ -52,7 +60,7 @@ void trampoline() {
   f.done = true;
   w->live--;
   w->waves[w->cur / 64].live--;
-  swapcontext(&f.ctx, &w->sched);
+  _longjmp(w->sched, 1);
 }
 void set_tid(Worker* w, int t) {
   threadIdx.x = t % w->bdim.x;
@@ -74,6 +82,7 @@ void run_block(Worker* w, dim3 grid, dim3 block, unsigned bid) {
   for (int t = 0; t < T; t++) {
     Fiber& f = w->fibers[t];
     f.done = false;
+    f.started = false;
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack;
     f.ctx.uc_stack.ss_size = STACK;
@@ -86,7 +95,11 @@ void run_block(Worker* w, dim3 grid, dim3 block, unsigned bid) {
       if (w->fibers[t].done) continue;
       w->cur = t;
       set_tid(w, t);
-      swapcontext(&w->sched, &w->fibers[t].ctx);
+      if (!_setjmp(w->sched)) {
+        Fiber& f = w->fibers[t];
+        if (!f.started) { f.started = true; setcontext(&f.ctx); }
+        else _longjmp(f.jb, 1);
+      }
     }
     if (++spins > 200000000L) { std::fprintf(stderr, "emu: deadlock in block %u\n", bid); std::abort(); }
   }
@@ -146,6 +159,53 @@ hssk_d4 mfma_f64_16x16x4(double a, double b, hssk_d4 c) {
   return c;
 }
 
+// Persistent worker threads: the fiber stacks of a worker (256 KB per emulated thread) are allocated once and reused by
+// every launch (a fresh std::thread per launch used to allocate -- and never free -- them again).
+namespace {
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv, done;
+  const std::function<void()>* job = nullptr;
+  unsigned long gen = 0;
+  int pending = 0, size = 0;
+  void worker_loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void()>* j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        j = job;
+      }
+      (*j)();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending == 0) done.notify_all();
+      }
+    }
+  }
+  void run(const std::function<void()>& f) {
+    std::unique_lock<std::mutex> lk(m);
+    job = &f;
+    pending = size;
+    gen++;
+    cv.notify_all();
+    done.wait(lk, [&] { return pending == 0; });
+  }
+};
+Pool* pool(int n) {   // leaked on purpose: the workers wait for work until the process ends
+  static Pool* p = [n] {
+    Pool* q = new Pool;
+    q->size = n;
+    for (int i = 0; i < n; i++) std::thread([q] { q->worker_loop(); }).detach();
+    return q;
+  }();
+  return p;
+}
+std::mutex launch_mutex;   // one emulated launch at a time (several host threads may launch)
+}  // namespace
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   unsigned nblocks = grid.x * grid.y * grid.z;
   if (!nblocks) return;
@@ -155,7 +215,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     return std::max(1, std::min(n, 16));
   }();
   std::atomic<unsigned> next{0};
-  auto work = [&]() {
+  std::function<void()> work = [&]() {
     static thread_local Worker worker;
     W = &worker;
     worker.body = &body;
@@ -166,10 +226,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
       run_block(&worker, grid, block, b);
     }
   };
-  int nt = (int)std::min<unsigned>(nthreads, nblocks);
-  if (nt <= 1) { work(); return; }
-  std::vector<std::thread> th;
-  for (int i = 0; i < nt; i++) th.emplace_back(work);
-  for (auto& t : th) t.join();
+  if (nthreads <= 1 || nblocks <= 1) { work(); return; }
+  std::lock_guard<std::mutex> lk(launch_mutex);
+  pool(nthreads)->run(work);
 }
 }  // namespace emu
