@@ -8,8 +8,7 @@ import hss_cases as HC
 from strumpack_amd import capi
 
 CASES = HC.golden_cases()
-SMALL = ["HSS_seq_1", "HSS_seq_3", "HSS_seq_6", "HSS_seq_8", "HSS_seq_9", "HSS_seq_10", "HSS_seq_11",
-         "HSS_seq_14", "HSS_seq_15", "HSS_seq_17", "HSS_seq_20", "HSS_seq_2"]
+SMALL = ["HSS_seq_%d" % i for i in range(1, 23)]     # the reference's whole CTest sweep for test_HSS_seq
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +21,7 @@ def test_ctest_case(L, name):
     HC.check_against_golden(L, CASES[name])
 
 
-@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_8", "HSS_seq_11"])
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_2", "HSS_seq_5", "HSS_seq_8", "HSS_seq_11", "HSS_seq_12", "HSS_seq_14", "HSS_seq_22"])
 def test_schur_complement(L, name):
     from strumpack_amd import hssk as K
     hk = K.Hssk(emu_lib.PATH) if name == "HSS_seq_2" else None
@@ -31,7 +30,7 @@ def test_schur_complement(L, name):
         hk.close()
 
 
-@pytest.mark.parametrize("name", ["sjlt_original_T500"])
+@pytest.mark.parametrize("name", sorted(HC.sjlt_golden()))
 def test_sjlt_sketch(L, name):
     HC.check_sjlt(L, HC.sjlt_golden()[name])
 

@@ -74,5 +74,6 @@ def test_oracle_kernel_compression_matches_reference(tag):
     assert np.linalg.norm(w - wr) <= 1e-8 * np.linalg.norm(wr)
 
 
-def test_regression_with_reference_neighbours(lib):
-    KG.check_regression(KM, lib, "gauss_400", inject=True, acc_tol=0.0, rank_tol=0.0, w_tol=1e-7)
+@pytest.mark.parametrize("tag", ["gauss_400", "laplace_400", "anova_400"])
+def test_regression_with_reference_neighbours(lib, tag):
+    KG.check_regression(KM, lib, tag, inject=True, acc_tol=0.0, rank_tol=0.0, w_tol=1e-7 if tag == "gauss_400" else 1e-6)

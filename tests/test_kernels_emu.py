@@ -70,8 +70,8 @@ def test_qr(hk):
     KC.case_qr(hk, [(100, 128, 100), (120, 60, 120)], seed=8)       # <2,8,16>
     KC.case_qr(hk, [(195, 128, 128)], seed=9)                       # <4,8,16>
     KC.case_qr(hk, [(195, 160, 195), (130, 100, 130)], seed=10)     # <4,26,8>
-    KC.case_qr(hk, [(300, 40, 300), (260, 250, 260), (280, 300, 200)], seed=11)   # blocked (compact WY + batched GEMM)
-    KC.case_qr(hk, [(600, 20, 30), (530, 70, 0)], seed=12)   # tall blocked path (GEMM-assembled compact WY)
+    KC.case_qr(hk, [(300, 40, 300), (260, 250, 260), (390, 350, 390), (300, 60, 0), (280, 300, 200)], seed=11)   # blocked (compact WY + batched GEMM)
+    KC.case_qr(hk, [(600, 20, 30), (700, 90, 100), (530, 70, 0)], seed=12)   # tall blocked path (GEMM-assembled compact WY)
 
 
 def test_formq_from_stored_reflectors(hk):
@@ -99,7 +99,8 @@ def test_kernel_predict(hk):
 
 
 def test_qr_staircase(hk):
-    KC.case_qr_staircase(hk, [(140, 2), (195, 2), (70, 4), (150, 3)])
+    KC.case_qr_staircase(hk, [(140, 2), (195, 2), (196, 2), (70, 4), (150, 3), (256, 2)])
+    KC.case_qr_staircase(hk, [(300, 2), (140, 4)], seed=28)      # tall path
 
 
 def test_sjlt(hk):
