@@ -39,6 +39,7 @@ struct Wave {
 };
 struct Worker {
   jmp_buf sched;
+  ucontext_t sched_ctx;
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
   int cur = 0, live = 0, bcount = 0;
@@ -49,9 +50,19 @@ struct Worker {
 };
 thread_local Worker* W = nullptr;
 
+// -DEMU_SWAPCONTEXT (sanitizer builds, tools/asan_emu.sh): plain swapcontext switches, which the sanitizer runtime follows
+#ifdef EMU_SWAPCONTEXT
+#define EMU_TO_SCHED(w, f) swapcontext(&(f).ctx, &(w)->sched_ctx)
+#else
+#define EMU_TO_SCHED(w, f) _longjmp((w)->sched, 1)
+#endif
 void yield() {
   Worker* w = W;
+#ifdef EMU_SWAPCONTEXT
+  swapcontext(&w->fibers[w->cur].ctx, &w->sched_ctx);
+#else
   if (!_setjmp(w->fibers[w->cur].jb)) _longjmp(w->sched, 1);
+#endif
 }
 void trampoline() {
   Worker* w = W;
@@ -60,7 +71,7 @@ void trampoline() {
   f.done = true;
   w->live--;
   w->waves[w->cur / 64].live--;
-  _longjmp(w->sched, 1);
+  EMU_TO_SCHED(w, f);
 }
 void set_tid(Worker* w, int t) {
   threadIdx.x = t % w->bdim.x;
@@ -95,11 +106,15 @@ void run_block(Worker* w, dim3 grid, dim3 block, unsigned bid) {
       if (w->fibers[t].done) continue;
       w->cur = t;
       set_tid(w, t);
+#ifdef EMU_SWAPCONTEXT
+      swapcontext(&w->sched_ctx, &w->fibers[t].ctx);
+#else
       if (!_setjmp(w->sched)) {
         Fiber& f = w->fibers[t];
         if (!f.started) { f.started = true; setcontext(&f.ctx); }
         else _longjmp(f.jb, 1);
       }
+#endif
     }
     if (++spins > 200000000L) { std::fprintf(stderr, "emu: deadlock in block %u\n", bid); std::abort(); }
   }

@@ -10,13 +10,13 @@ FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -f
 mkdir -p $B && cd $B
 for f in $SRC/kernels/*.hip; do g++ $FLAGS -x c++ -c $f -o k_$(basename $f .hip).o & done
 for f in $SRC/host/*.cpp; do g++ $FLAGS -c $f -o h_$(basename $f .cpp).o & done
-g++ $FLAGS -c $ROOT/tests/emu/emu_runtime.cpp -o emu_runtime.o &
+g++ $FLAGS -DEMU_SWAPCONTEXT -c $ROOT/tests/emu/emu_runtime.cpp -o emu_runtime.o &
 wait
 g++ $FLAGS $ROOT/tests/cpp/test_HSS_seq.cpp *.o -o test_HSS_seq_asan -lpthread
 export ASAN_OPTIONS=detect_stack_use_after_return=0:detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 HSSK_EMU_THREADS=4
 while read -r line; do
   echo "== $line"
-  ./test_HSS_seq_asan $line 2>&1 | grep -E "ERROR|runtime error|AddressSanitizer|SUMMARY|# exiting"
+  timeout 900 ./test_HSS_seq_asan $line 2>&1 | grep -E "ERROR|runtime error|AddressSanitizer|SUMMARY|# exiting"
 done <<'LINES'
 U 200 --hss_leaf_size 16 --hss_rel_tol 1e-1 --hss_abs_tol 1e-10 --hss_compression_algorithm stable --hss_d0 128 --hss_dd 4
 U 300 --hss_leaf_size 32 --hss_rel_tol 1e-5 --hss_abs_tol 1e-10 --hss_compression_algorithm stable --hss_d0 16 --hss_dd 8 --hss_compression_sketch SJLT --hss_SJLT_algo perm --hss_nnz0 2 --hss_nnz 2
