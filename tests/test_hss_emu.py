@@ -35,6 +35,16 @@ def test_sjlt_sketch(L, name):
     HC.check_sjlt(L, HC.sjlt_golden()[name])
 
 
+RAGGED = [("T", 2, 1, "stable"), ("T", 3, 1, "original"), ("T", 5, 2, "stable"), ("U", 17, 3, "stable"),
+          ("T", 33, 16, "original"), ("L", 37, 5, "stable"), ("T", 64, 16, "stable"), ("U", 65, 16, "original"),
+          ("T", 127, 17, "stable"), ("T", 129, 128, "stable"), ("L", 131, 33, "original"), ("T", 257, 7, "stable")]
+
+
+@pytest.mark.parametrize("prob,n,leaf,algo", RAGGED)
+def test_ragged_sizes_vs_oracle(L, prob, n, leaf, algo):
+    HC.check_vs_oracle(L, prob, n, leaf, 1e-6, 1e-12, algo, 16, 8)
+
+
 def test_api_semantics(L):
     HC.check_api_semantics(L)
 
