@@ -267,28 +267,79 @@ typedef struct hssk_lusolve_desc {
 } hssk_lusolve_desc;
 int hssk_getrs_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count);
 
-/* ---- fused ULV solve sweeps (few right-hand sides) ------------------------------------------------
- * One launch per tree level of HSSMatrix::solve_fwd / solve_bwd (HSS/HSSMatrix.solve.hpp:69-238); see
- * kernels/hssk_ulv.hip for the per-node arithmetic.  nrhs <= 4 and node dimensions <= 512, otherwise the call returns 2
- * and does nothing (the caller then issues the unfused batched calls). */
-typedef struct hssk_ulv_fwd_desc {
+/* ---- single-launch tree sweeps (few right-hand sides) ---------------------------------------------------------
+ * The forward / backward ULV sweeps (HSS/HSSMatrix.solve.hpp:69-238) and the mat-vec up / down sweeps
+ * (HSS/HSSMatrix.apply.hpp:55-220) of a whole (sub)tree as ONE launch each: one workgroup per node, ordered so that a
+ * node only depends on lower-indexed descriptors (children before parents going up, parents before children going
+ * down); wait* name those descriptors (-1: none / produced by an earlier launch), `consumers` = how many later
+ * descriptors of the same launch wait on this one.  See kernels/hssk_sweep.hip.  nrhs <= 4 and node dimensions <= 256,
+ * otherwise the call returns 2 and does nothing (the caller issues the batched calls instead).
+ * hssk_sweep_status: non-zero if a workgroup of an earlier sweep gave up waiting (checked after a synchronisation). */
+typedef struct hssk_sweep_fwd_desc {
   const double* fsrc;   /* m x nrhs right-hand side rows of the node (leaf: rows of b; inner: [ft1_0; ft1_1]) */
-  const double *B01, *B10, *zc; /* inner nodes: f(0:rU0) -= B01 zc(rV0:rV0+rV1), f(rU0:) -= B10 zc(0:rV0); zc = children's z stacked; leaves: NULL */
+  const double *B01, *B10, *zc; /* inner nodes: f(0:rU0) -= B01 zc(rV0:), f(rU0:) -= B10 zc(0:rV0); leaves: NULL */
   const int* permU;
-  const double *XU, *Rlq, *Qt, *W1, *Vt0;
-  const int* permV;     /* inner nodes only (NULL for leaves) */
+  const double* XU;     /* r x (m - r) */
+  const double* Rlq;    /* m x (m - r): R~ = L^T in the upper triangle */
+  const double* Tinv;   /* ceil((m-r)/64) blocks of 64 x 64: inverses of the diagonal blocks of R~^T (hssk_trtri_diag_vbatched) */
+  const double* WQ;     /* r x (m - r): W1 Q~(:, 0:m-r) */
+  const double* Vt0;    /* (m - r) x rv */
+  const int* permV;     /* inner nodes only */
   const double* XV;
   double *ft1, *y, *z;  /* out: r x nrhs (ld ldp), (m-r) x nrhs (ld m-r), rv x nrhs (ld ldz) */
-  int ldf, rU0, rU1, rV0, rV1, ldz_in, m, r, mv, rv, ldp, ldz;
-} hssk_ulv_fwd_desc;
-int hssk_ulv_fwd_level(hssk_ctx* ctx, const hssk_ulv_fwd_desc* descs, int count, int nrhs);
-/* out (m x nrhs, ldo) = Qt(:, 0:m-r) y + Qt(:, m-r:) xpart   (y: (m-r) x nrhs, ld m-r; xpart: r x nrhs, ldx) */
-typedef struct hssk_ulv_bwd_desc {
+  /* the root of the factorization (LU != NULL): x = LU^{-1} f with f assembled as above (m rows), written to xroot
+   * (ld ldxr); TinvL / TinvU = inverted diagonal blocks of L and U (hssk_trtri_diag_vbatched modes 2 / 1) */
+  const double *LU, *TinvL, *TinvU;
+  const int* piv;
+  double* xroot;
+  int ldf, rU0, rU1, rV0, rV1, ldz_in, m, r, mv, rv, ldp, ldz, ldxr;
+  int wait0, wait1, consumers;
+} hssk_sweep_fwd_desc;
+int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs);
+/* out (m x nrhs, ldo) = Qt(:, 0:m-r) y + Qt(:, m-r:) xpart */
+typedef struct hssk_sweep_bwd_desc {
   const double *Qt, *y, *xpart;
   double* out;
   int m, r, ldx, ldo;
-} hssk_ulv_bwd_desc;
-int hssk_ulv_bwd_level(hssk_ctx* ctx, const hssk_ulv_bwd_desc* descs, int count, int nrhs);
+  int wait0, consumers;
+} hssk_sweep_bwd_desc;
+int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* descs, int count, int nrhs);
+/* up: dst (r x nrhs, ldd) = src(perm[0:r], :) + X src(perm[r:], :)   (HSSBasisID::applyC; X is r x (m - r)) */
+typedef struct hssk_apply_up_desc {
+  const double* src;
+  const int* perm;
+  const double* X;
+  double* dst;
+  int m, r, lds, ldd;
+  int wait0, wait1, consumers;
+} hssk_apply_up_desc;
+/* down: leaf (D != NULL): out = op(D) x + beta out + U tmp2;  inner: out = [B01 t1_1; B10 t1_0] (trans: [B10^T t1_1;
+ * B01^T t1_0]) + U tmp2, with U tmp2 = scatter through perm of [tmp2; X^T tmp2] (HSSBasisID::apply; X is ro x (mo - ro));
+ * tmp2 == NULL for the root of the sweep.  wait0 = the parent's down descriptor, wait1 / wait2 = the children's up
+ * descriptors (inner nodes); indices count the up descriptors first, then the down descriptors. */
+typedef struct hssk_apply_down_desc {
+  const double* tmp2;
+  const int* perm;
+  const double* X;
+  const double *D, *x;
+  const double *B01, *B10, *t1;
+  double* out;
+  double beta;
+  int ld2, mo, ro, m, ldx, trans, ri_a, ri_b, ro_a, ro_b, ldt1, ldo;
+  int wait0, wait1, wait2, consumers;
+} hssk_apply_down_desc;
+int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, int nup, const hssk_apply_down_desc* downs, int ndown,
+                     int nrhs);
+int hssk_sweep_status(hssk_ctx* ctx);
+/* Tinv (ceil(n/64) blocks of 64 x 64, leading dimension 64) = transposed inverses of the 64 x 64 diagonal blocks of the
+ * triangular R (n x n, ldr), zero padded; see `mode`. */
+typedef struct hssk_trtri_desc {
+  const double* R;
+  double* Tinv;
+  int n, ldr;
+  int mode; /* 0: R upper, blocks hold (R(b,b)^{-1})^T;  1: R upper, plain inverses;  2: unit lower triangle of R, plain inverses */
+} hssk_trtri_desc;
+int hssk_trtri_diag_vbatched(hssk_ctx* ctx, const hssk_trtri_desc* descs, int count);
 
 /* ---- small utilities --------------------------------------------------------------------------- */
 /* out[j] = sum_i P(i,j)^2 over the rows x cols panel: Frobenius norms for the stopping test

@@ -70,6 +70,18 @@ __device__ __forceinline__ long long hssk_hwid() {
   return ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 }
 
+
+// ---- cross-workgroup dependency flags of the single-launch tree sweeps (kernels/hssk_sweep.hip) ----------------
+// A workgroup publishes its results with a release store at agent scope (L2 write-back across XCDs included) and a
+// consumer workgroup polls with acquire loads; s_sleep keeps the polling wave off the issue ports.
+__device__ __forceinline__ int hssk_flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hssk_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int hssk_flag_sub(int* f, int v) { return __hip_atomic_fetch_sub(f, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hssk_flag_raise(int* f) { __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // error word in pinned host memory
+__device__ __forceinline__ void hssk_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void hssk_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void hssk_pause() { __builtin_amdgcn_s_sleep(2); }
+
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))
 
 // Global-memory accessors for pointers that arrive through a descriptor in memory: the compiler cannot infer

@@ -1632,6 +1632,7 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
     if (it != plans_.end() && it->second.plan) {
       ck(hssk_plan_replay(ctx_, it->second.plan));
       ck(hssk_sync(ctx_));
+      if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("mult: ") + hssk_last_error());
       stats_.t_mult = now() - t0;
       return;
     }
@@ -1754,9 +1755,84 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
     if (!sc.empty()) ck(hssk_gather_rows(ctx_, sc.data(), (int)sc.size()));
     if (!innermm.empty()) ck(hssk_gemm_vbatched(ctx_, innermm.data(), (int)innermm.size()));
   };
+  // few right-hand sides: up-sweep and down-sweep of a set of levels as ONE launch (hssk_apply_sweep: a workgroup per
+  // node and direction, dependency flags between them) instead of two to four batched launches per level
+  static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_APPLY"); return e && e[0] == '1'; }();
+  const bool fuse = nrhs <= 4 && !no_fuse;
+  typedef std::vector<std::vector<int>> Levels;
+  auto sweep = [&](const Levels* ups, const Levels* downs) -> bool {
+    std::vector<hssk_apply_up_desc> U;
+    std::vector<hssk_apply_down_desc> Dn;
+    std::vector<int> wu(nn, -1), wd(nn, -1);
+    if (ups)
+      for (auto& ids : *ups)
+        for (int id : ids) {
+          if (id == sr) continue;
+          const Node& nd = nodes_[id];
+          const Node& pa = nodes_[nd.parent];
+          hssk_apply_up_desc d{};
+          d.m = min_(nd); d.r = rin(nd);
+          d.perm = T ? nd.permU : nd.permV;
+          d.X = T ? nd.XU : nd.XV;
+          d.src = nd.leaf() ? dx + (nd.lo - lo0) : cat[id];
+          d.lds = nd.leaf() ? (int)lx : std::max(d.m, 1);
+          d.dst = cat[nd.parent] + (id == pa.c0 ? 0 : rin(nodes_[pa.c0]));
+          d.ldd = std::max(rin(nodes_[pa.c0]) + rin(nodes_[pa.c1]), 1);
+          d.wait0 = nd.leaf() ? -1 : wu[nd.c0];
+          d.wait1 = nd.leaf() ? -1 : wu[nd.c1];
+          wu[id] = (int)U.size();
+          U.push_back(d);
+        }
+    const int nup = (int)U.size();
+    if (downs)
+      for (auto& ids : *downs)
+        for (int id : ids) {
+          const Node& nd = nodes_[id];
+          hssk_apply_down_desc d{};
+          d.wait0 = d.wait1 = d.wait2 = -1;
+          if (id != sr) {
+            const Node& pa = nodes_[nd.parent];
+            d.tmp2 = tbuf[nd.parent] + (id == pa.c0 ? 0 : rout(nodes_[pa.c0]));
+            d.ld2 = std::max(rout(nodes_[pa.c0]) + rout(nodes_[pa.c1]), 1);
+            d.perm = T ? nd.permV : nd.permU;
+            d.X = T ? nd.XV : nd.XU;
+            d.mo = mout(nd); d.ro = rout(nd);
+            d.wait0 = wd[nd.parent];
+          }
+          d.trans = T ? 1 : 0;
+          if (nd.leaf()) {
+            d.D = nd.D; d.x = dx + (nd.lo - lo0); d.ldx = (int)lx; d.m = nd.m; d.beta = beta;
+            d.out = dy + (nd.lo - lo0); d.ldo = (int)ly;
+            if (!d.D) return false;
+          } else {
+            const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+            d.B01 = nd.B01; d.B10 = nd.B10; d.t1 = cat[id];
+            d.ri_a = rin(a); d.ri_b = rin(b); d.ro_a = rout(a); d.ro_b = rout(b);
+            d.ldt1 = std::max(d.ri_a + d.ri_b, 1);
+            d.out = tbuf[id]; d.ldo = std::max(d.ro_a + d.ro_b, 1);
+            d.wait1 = wu[nd.c0]; d.wait2 = wu[nd.c1];
+            if (!d.B01 || !d.B10) return false;
+          }
+          wd[id] = nup + (int)Dn.size();
+          Dn.push_back(d);
+        }
+    auto bump = [&](int w) { if (w >= 0) { if (w < nup) U[w].consumers++; else Dn[w - nup].consumers++; } };
+    for (auto& d : U) { bump(d.wait0); bump(d.wait1); }
+    for (auto& d : Dn) { bump(d.wait0); bump(d.wait1); bump(d.wait2); }
+    if (U.empty() && Dn.empty()) return true;
+    const int rc = hssk_apply_sweep(ctx_, U.data(), nup, Dn.data(), (int)Dn.size(), nrhs);
+    if (rc == 2) return false;
+    ck(rc);
+    return true;
+  };
   std::vector<std::vector<int>> sub_h, sub_d;
   if (sr != 0) { sub_h = sublists(own_by_height_, sr); sub_d = sublists(own_by_depth_, sr); }
-  for (auto& ids : (sr ? sub_h : own_by_height_)) up(ids);
+  const Levels& ups_own = sr ? sub_h : own_by_height_;
+  const Levels& downs_own = sr ? sub_d : own_by_depth_;
+  // single process: the whole product is one launch
+  const bool whole = fuse && !dist_subtree_ && sweep(&ups_own, &downs_own);
+  if (!whole && !(fuse && dist_subtree_ && sweep(&ups_own, nullptr)))
+    for (auto& ids : ups_own) up(ids);
   if (dist_subtree_) {
     // publish tmp1 (rin x nrhs) of the cut nodes into every rank's top buffers
     const int G = o_.world, me = o_.rank;
@@ -1786,14 +1862,18 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
       if (r) upk.push_back(hssk_rowgather_desc{buf + blk * g, p1, nullptr, r, nrhs, rm, ld1, 0, 0});
     }
     if (!upk.empty()) ck(hssk_gather_rows(ctx_, upk.data(), (int)upk.size()));
-    for (auto& ids : top_by_height_) up(ids);
-    for (auto& ids : top_by_depth_) down(ids);
+    if (!(fuse && sweep(&top_by_height_, &top_by_depth_))) {
+      for (auto& ids : top_by_height_) up(ids);
+      for (auto& ids : top_by_depth_) down(ids);
+    }
   }
-  for (auto& ids : (sr ? sub_d : own_by_depth_)) down(ids);
+  if (!whole && !(fuse && dist_subtree_ && sweep(nullptr, &downs_own)))
+    for (auto& ids : downs_own) down(ids);
   if (dist_subtree_) allgather_rows(dy, ly, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, y, sizeof(double) * ldy, dy, sizeof(double) * N, sizeof(double) * N, nrhs));
   if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
   ck(hssk_sync(ctx_));
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("mult: ") + hssk_last_error());
   stats_.t_mult = now() - t0;
 }
 
@@ -1818,7 +1898,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   drop_plans();   // recorded sweeps reference the old factors
   fact_->reset();
   stats_.f_ulv = 0;
-  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nullptr, nd.piv = nullptr;
+  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nullptr, nd.piv = nullptr;
   const size_t nn = nodes_.size();
   std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr);
   auto level = [&](const std::vector<int>& ids) {
@@ -1827,8 +1907,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     std::vector<hssk_colgather_desc> cp;
     std::vector<hssk_gemm_desc> g0, g1;
     std::vector<hssk_basis_desc> bd;
-    Arena& tmp = *tmp_;
-    tmp.rewind();
+    Arena& tmp = *tmp_;   // (rewound once per factorization: the levels are enqueued back to back, no host sync between them)
     for (int id : ids) {
       Node& nd = nodes_[id];
       const bool root = id == sr;
@@ -1869,6 +1948,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     std::vector<hssk_gemm_desc> g2, g3;
     std::vector<hssk_qr_desc> qr;
     std::vector<hssk_lu_desc> lu;
+    std::vector<hssk_trtri_desc> ti, tiroot;   // inverted diagonal blocks for the single-launch solve sweeps
     for (int id : ids) {
       Node& nd = nodes_[id];
       if (id == sr) {
@@ -1877,6 +1957,13 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         if (partial) nd.Vt0 = Vh[id];   // Vhat: mu x rV, the column basis in the reduced unknowns
         nd.piv = (int*)fact_->alloc(sizeof(int) * (std::max(mu, 1) + 1));
         if (mu) lu.push_back(hssk_lu_desc{nd.LU, mu, mu, nd.piv, nd.piv + mu});
+        if (mu && mu <= 256) {
+          const size_t nblk = (size_t)(mu + 63) / 64;
+          nd.Tinv = fact_->dbl(nblk * 4096);
+          nd.TinvU = fact_->dbl(nblk * 4096);
+          tiroot.push_back(hssk_trtri_desc{nd.LU, nd.Tinv, mu, mu, 2});
+          tiroot.push_back(hssk_trtri_desc{nd.LU, nd.TinvU, mu, mu, 1});
+        }
         stats_.f_ulv += 2.0 / 3.0 * mu * (double)mu * mu;
         continue;
       }
@@ -1901,6 +1988,15 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
           if (r) g3.push_back(hssk_gemm_desc{nd.Qt + (size_t)(m - r) * m, Vh[id], nd.Vt1, r, rv, m, m, m, r, 1, 0, 1.0, 0.0});
         }
         if (r) g3.push_back(hssk_gemm_desc{nd.W1, nd.Qt + (size_t)(m - r) * m, nd.Dt, r, r, m, r, m, r, 0, 0, 1.0, 0.0});
+        // derived factors of the solve sweeps: WQ = W1 Q~(:, 0:m-r) and the inverted diagonal blocks of R~^T
+        if (r) {
+          nd.WQ = fact_->dbl((size_t)r * (m - r));
+          g3.push_back(hssk_gemm_desc{nd.W1, nd.Qt, nd.WQ, r, m - r, m, r, m, r, 0, 0, 1.0, 0.0});
+        }
+        if (m <= 256) {
+          nd.Tinv = fact_->dbl((size_t)((m - r + 63) / 64) * 4096);
+          ti.push_back(hssk_trtri_desc{nd.Rlq, nd.Tinv, m - r, m, 0});
+        }
         const double k = m - r;
         stats_.f_ulv += 2.0 * k * r * m + (2.0 * m * k * k - 2.0 / 3.0 * k * k * k) + (4.0 * m * m * k - 2.0 * m * k * k) / 1.0 * 0.5 + 2.0 * m * m * rv + 2.0 * r * (double)r * m;
       } else {
@@ -1914,16 +2010,19 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
     if (!qr.empty()) ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
     if (!g3.empty()) ck(hssk_gemm_vbatched(ctx_, g3.data(), (int)g3.size()));
+    if (!ti.empty()) ck(hssk_trtri_diag_vbatched(ctx_, ti.data(), (int)ti.size()));
     if (!lu.empty()) ck(hssk_getrf_vbatched(ctx_, lu.data(), (int)lu.size()));
-    ck(hssk_sync(ctx_));  // tmp released
+    if (!tiroot.empty()) ck(hssk_trtri_diag_vbatched(ctx_, tiroot.data(), (int)tiroot.size()));
   };
   std::vector<std::vector<int>> sub_h;
   if (sr != 0) sub_h = sublists(own_by_height_, sr);
+  tmp_->rewind();
   for (auto& ids : (sr ? sub_h : own_by_height_)) level(ids);
   if (dist_subtree_) {
     exchange_cut_factor();
     for (auto& ids : top_by_height_) level(ids);
   }
+  ck(hssk_sync(ctx_));
   factored_ = sr == 0;
   partial_factored_ = partial;
   schur_ready_ = false;
@@ -2236,6 +2335,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (it != plans_.end() && it->second.plan) {
       ck(hssk_plan_replay(ctx_, it->second.plan));
       ck(hssk_sync(ctx_));
+      if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("solve: ") + hssk_last_error());
       stats_.t_solve = now() - t0;
       return;
     }
@@ -2272,37 +2372,91 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     }
     if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
   }
-  // few right-hand sides: one fused launch per level (hssk_ulv_fwd_level / _bwd_level) instead of 7 / 3 batched ones
+  // few right-hand sides: the whole forward sweep (root solve included) and the whole backward sweep are ONE launch each
+  // (hssk_ulv_fwd_sweep / _bwd_sweep: a workgroup per node, dependency flags between them) instead of 7 / 3 batched
+  // launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
   const bool fuse = nrhs <= 4 && !no_fuse;
-  auto fwd_fused = [&](const std::vector<int>& ids) -> bool {
-    std::vector<hssk_ulv_fwd_desc> fd;
-    for (int id : ids) {
-      const Node& nd = nodes_[id];
-      if (nd.lvl == 0) return false;   // the root level (LU solve) stays on the batched path
-      const Node& pa = nodes_[nd.parent];
-      hssk_ulv_fwd_desc d{};
-      d.m = nd.mU; d.r = nd.rU; d.mv = nd.leaf() ? nd.m : nd.mV; d.rv = nd.rV;
-      if (nd.leaf()) { d.fsrc = db + nd.lo; d.ldf = (int)lb; }
-      else {
-        const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
-        d.fsrc = f[id]; d.ldf = std::max(a.rU + c.rU, 1);
-        d.B01 = nd.B01; d.B10 = nd.B10; d.zc = zc[id];
-        d.rU0 = a.rU; d.rU1 = c.rU; d.rV0 = a.rV; d.rV1 = c.rV; d.ldz_in = std::max(a.rV + c.rV, 1);
-        d.permV = nd.permV; d.XV = nd.XV;
-        if (!d.B01 || !d.B10) return false;
+  typedef std::vector<std::vector<int>> Levels;
+  auto fwd_sweep = [&](const Levels& levels) -> bool {
+    std::vector<hssk_sweep_fwd_desc> fd;
+    std::vector<int> where(nn, -1);
+    for (auto& ids : levels)
+      for (int id : ids) {
+        const Node& nd = nodes_[id];
+        hssk_sweep_fwd_desc d{};
+        d.wait0 = d.wait1 = -1;
+        d.mv = nd.leaf() ? nd.m : nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+        if (nd.leaf()) { d.fsrc = db + nd.lo; d.ldf = (int)lb; }
+        else {
+          const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+          d.fsrc = f[id]; d.ldf = std::max(a.rU + c.rU, 1);
+          d.B01 = nd.B01; d.B10 = nd.B10; d.zc = zc[id];
+          d.rU0 = a.rU; d.rU1 = c.rU; d.rV0 = a.rV; d.rV1 = c.rV; d.ldz_in = std::max(a.rV + c.rV, 1);
+          d.permV = nd.permV; d.XV = nd.XV;
+          if (!d.B01 || !d.B10) return false;
+          d.wait0 = where[nd.c0]; d.wait1 = where[nd.c1];
+        }
+        if (nd.lvl == 0) {
+          // root: x = LU^{-1} f
+          d.m = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+          if (d.m == 0) continue;
+          d.LU = nd.LU; d.piv = nd.piv; d.TinvL = nd.Tinv; d.TinvU = nd.TinvU;
+          if (!d.LU || !d.TinvL || !d.TinvU) return false;
+          d.xroot = nd.leaf() ? db + nd.lo : xb[id];
+          d.ldxr = nd.leaf() ? (int)lb : std::max(d.m, 1);
+        } else {
+          const Node& pa = nodes_[nd.parent];
+          d.m = nd.mU; d.r = nd.rU; d.rv = nd.rV;
+          if (!nd.leaf()) d.mv = nd.mV;
+          d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Tinv = nd.Tinv; d.WQ = nd.WQ; d.Vt0 = nd.Vt0;
+          d.ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+          d.ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+          d.z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+          d.ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+          d.y = y[id];
+          if (d.m > d.r && (!d.y || !d.Rlq || !d.Tinv || (d.r && !d.WQ))) return false;
+        }
+        where[id] = (int)fd.size();
+        fd.push_back(d);
       }
-      d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Qt = nd.Qt; d.W1 = nd.W1; d.Vt0 = nd.Vt0;
-      d.ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
-      d.ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
-      d.z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
-      d.ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
-      d.y = y[id];
-      if (d.m > d.r && (!d.y || !d.Rlq || !d.Qt)) return false;
-      fd.push_back(d);
+    for (auto& d : fd) {
+      if (d.wait0 >= 0) fd[d.wait0].consumers++;
+      if (d.wait1 >= 0) fd[d.wait1].consumers++;
     }
     if (fd.empty()) return true;
-    const int rc = hssk_ulv_fwd_level(ctx_, fd.data(), (int)fd.size(), nrhs);
+    const int rc = hssk_ulv_fwd_sweep(ctx_, fd.data(), (int)fd.size(), nrhs);
+    if (rc == 2) return false;
+    ck(rc);
+    return true;
+  };
+  auto bwd_sweep = [&](const Levels& levels) -> bool {
+    std::vector<hssk_sweep_bwd_desc> bd;
+    std::vector<int> where(nn, -1);
+    for (auto& ids : levels)
+      for (int id : ids) {
+        const Node& nd = nodes_[id];
+        if (nd.leaf()) continue;
+        const Node& a = nodes_[nd.c0];
+        const int cid[2] = {nd.c0, nd.c1};
+        for (int q = 0; q < 2; q++) {
+          if (!mine(cid[q])) continue;
+          const Node& cn = nodes_[cid[q]];
+          if (cn.mU == 0) continue;
+          hssk_sweep_bwd_desc d{};
+          d.Qt = cn.Qt; d.y = y[cid[q]]; d.xpart = xb[id] + (q ? a.rU : 0);
+          d.out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+          d.m = cn.mU; d.r = cn.rU; d.ldx = std::max(a.rU + nodes_[nd.c1].rU, 1); d.ldo = cn.leaf() ? (int)lb : std::max(cn.mU, 1);
+          d.wait0 = where[id];
+          if (d.m > d.r && (!d.Qt || !d.y)) return false;
+          where[cid[q]] = (int)bd.size();
+          bd.push_back(d);
+        }
+      }
+    for (auto& d : bd)
+      if (d.wait0 >= 0) bd[d.wait0].consumers++;
+    if (bd.empty()) return true;
+    const int rc = hssk_ulv_bwd_sweep(ctx_, bd.data(), (int)bd.size(), nrhs);
     if (rc == 2) return false;
     ck(rc);
     return true;
@@ -2310,7 +2464,6 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   // ---- forward, one tree height
   auto fwd = [&](const std::vector<int>& ids) {
     if (ids.empty()) return;
-    if (fuse && fwd_fused(ids)) return;
     std::vector<hssk_gemm_desc> ga, gb, gc, gd, ge;
     std::vector<hssk_rowgather_desc> rg;
     std::vector<hssk_trsm_desc> ts;
@@ -2387,28 +2540,6 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   };
   // ---- backward, one depth (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
   auto bwd = [&](const std::vector<int>& ids) {
-    if (fuse) {
-      std::vector<hssk_ulv_bwd_desc> bd;
-      for (int id : ids) {
-        const Node& nd = nodes_[id];
-        if (nd.leaf()) continue;
-        const Node& a = nodes_[nd.c0];
-        const int cid[2] = {nd.c0, nd.c1};
-        for (int q = 0; q < 2; q++) {
-          if (!mine(cid[q])) continue;
-          const Node& cn = nodes_[cid[q]];
-          if (cn.mU == 0) continue;
-          hssk_ulv_bwd_desc d{};
-          d.Qt = cn.Qt; d.y = y[cid[q]]; d.xpart = xb[id] + (q ? a.rU : 0);
-          d.out = cn.leaf() ? db + cn.lo : xb[cid[q]];
-          d.m = cn.mU; d.r = cn.rU; d.ldx = std::max(a.rU + nodes_[nd.c1].rU, 1); d.ldo = cn.leaf() ? (int)lb : std::max(cn.mU, 1);
-          bd.push_back(d);
-        }
-      }
-      if (bd.empty()) return;
-      const int rc = hssk_ulv_bwd_level(ctx_, bd.data(), (int)bd.size(), nrhs);
-      if (rc != 2) { ck(rc); return; }
-    }
     std::vector<hssk_gemm_desc> g1, g2;
     std::vector<hssk_rowgather_desc> cp;
     for (int id : ids) {
@@ -2439,7 +2570,8 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
     if (!cp.empty()) ck(hssk_gather_rows(ctx_, cp.data(), (int)cp.size()));
   };
-  for (auto& ids : own_by_height_) fwd(ids);
+  if (!(fuse && fwd_sweep(own_by_height_)))
+    for (auto& ids : own_by_height_) fwd(ids);
   if (dist_subtree_) {
     // publish ft1' (rU x nrhs) and z (rV x nrhs) of the cut nodes into every rank's top buffers
     const int G = o_.world, me = o_.rank;
@@ -2475,14 +2607,18 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
       if (c.rV) up.push_back(hssk_rowgather_desc{buf + blk * g + (size_t)ru * nrhs, pz, nullptr, c.rV, nrhs, rv, ldz, 0, 0});
     }
     if (!up.empty()) ck(hssk_gather_rows(ctx_, up.data(), (int)up.size()));
-    for (auto& ids : top_by_height_) fwd(ids);
-    for (auto& ids : top_by_depth_) bwd(ids);
+    if (!(fuse && fwd_sweep(top_by_height_)))
+      for (auto& ids : top_by_height_) fwd(ids);
+    if (!(fuse && bwd_sweep(top_by_depth_)))
+      for (auto& ids : top_by_depth_) bwd(ids);
   }
-  for (auto& ids : own_by_depth_) bwd(ids);
+  if (!(fuse && bwd_sweep(own_by_depth_)))
+    for (auto& ids : own_by_depth_) bwd(ids);
   if (dist_subtree_) allgather_rows(db, lb, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
   if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
   ck(hssk_sync(ctx_));
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("solve: ") + hssk_last_error());
   stats_.t_solve = now() - t0;
   {
     double fs = 0;

@@ -156,6 +156,9 @@ class DeviceHSS {
     bool panels = false;
     // ULV factors (device)
     double *Qt = nullptr, *Rlq = nullptr, *W1 = nullptr, *Vt0 = nullptr, *Dt = nullptr, *Vt1 = nullptr;
+    // derived factors read by the single-launch solve sweeps: WQ = W1 Q~(:, 0:m-r), inverted 64 x 64 diagonal blocks of
+    // R~^T (non-root) resp. of the root's L and U
+    double *WQ = nullptr, *Tinv = nullptr, *TinvU = nullptr;
     double* LU = nullptr;
     int* piv = nullptr;
     bool leaf() const { return c0 < 0; }

@@ -63,6 +63,8 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   hssk_rt::pinned_free(c->h_ring);
   hssk_rt::dev_free(c->d_ring);
   hssk_rt::dev_free(c->d_scratch);
+  hssk_rt::dev_free(c->d_sweep_flags);
+  hssk_rt::pinned_free(c->h_sweep_err);
   hssk_rt::event_destroy(c->ev0);
   hssk_rt::event_destroy(c->ev1);
   hssk_rt::stream_destroy(c->stream);

@@ -49,6 +49,10 @@ struct hssk_ctx {
   long long dgemm_trace_wgs = 0;  // workgroups of the last main launch (trace records behind d_clk + 4)
   long long* d_clk = nullptr;   // device: {shader cycles, 100 MHz ticks} of workgroup 0 of the last dgemm
   double* d_scratch = nullptr;  // split-K partials of hssk_dgemm
+  // dependency flags of the single-launch sweeps (device, all zero between launches) and their error word (pinned)
+  int* d_sweep_flags = nullptr;
+  int* h_sweep_err = nullptr;
+  size_t sweep_cap = size_t(1) << 20;
   size_t scratch_bytes = 0;
 
   // copies `bytes` of host data into the ring and returns the device address (valid for kernels

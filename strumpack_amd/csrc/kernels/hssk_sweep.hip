@@ -1,0 +1,483 @@
+// Single-launch tree sweeps: the ULV solve (forward / backward) and the HSS mat-vec (up / down) of a whole tree in ONE
+// kernel launch each, for few right-hand sides.
+//
+// A sweep over an HSS tree is a chain of ~10 dependent levels of tiny per-node operations; launched level by level it
+// is bound by launch-to-launch latency (N = 1e5: 20 launches, 0.55 ms apply / 1.07 ms solve for 0.19 / 0.52 GB of
+// blocks).  Here every node of the sweep is one workgroup of the same launch, ordered so that a node only depends on
+// workgroups with a LOWER index (children before parents going up, parents before children going down).  A workgroup
+// polls its dependencies' flags (agent-scope acquire), does the node's arithmetic with the vectors in LDS, and
+// publishes its own flag (agent-scope release).  Workgroups are dispatched in index order (round-robin over the XCDs,
+// in order within an XCD), so the lowest-indexed unfinished workgroup is always resident and never waits on a
+// non-resident one: the scheme cannot deadlock, whatever the occupancy; a bounded spin count turns any violation of
+// that assumption into an error code instead of a hang.  Flags count pending consumers and return to zero by the end
+// of the launch, so a recorded launch (hssk_plan_*) can be replayed as is.
+//
+// Reference arithmetic: HSSMatrix::solve_fwd / solve_bwd (HSS/HSSMatrix.solve.hpp:69-238), apply_fwd / apply_bwd
+// (HSS/HSSMatrix.apply.hpp:55-220), HSSBasisID::apply / applyC (HSS/HSSBasisID.hpp:155-203).  Differences in the
+// stored factors (see DeviceHSS::factor_sub): WQ = W1 Q~(:, 0:q) is formed once at factor time, so the forward sweep
+// reads r x q instead of W1 (r x m) and Q~(:, 0:q) (m x q); the substitution with R~^T runs on 64-row blocks whose
+// diagonal blocks were inverted at factor time (Tinv), so the dependent chain is q/64 block steps, not q scalar steps.
+//
+// Per-node GEMVs are written for memory-level parallelism (the blocks stream from HBM exactly once): thread per output
+// row with 16 independent loads in flight (gemv_n), or four adjacent lanes per output column for column-contiguous
+// operands (gemv_t).
+#include "hssk_device.h"
+#include "hssk_internal.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int SW_T = 256;     // threads per workgroup
+constexpr int SW_NR = 4;      // right-hand sides handled at once
+constexpr int SW_MAX = 256;   // largest node dimension (rows of a basis)
+constexpr int SW_NB = 64;     // block size of the substitution with R~^T (hssk_trtri_diag_vbatched)
+constexpr long SW_SPIN_LIMIT = 1L << 22;
+
+// ---- dependency flags --------------------------------------------------------------------------------------------
+// wait until desc `idx` of this launch has published; the flag counts its pending consumers
+__device__ __forceinline__ void sweep_wait(int* flags, int idx, int* err) {
+  if (idx >= 0 && threadIdx.x == 0) {
+    long spins = 0;
+    while (hssk_flag_load(flags + idx) <= 0) {
+      hssk_pause();
+      if (++spins > SW_SPIN_LIMIT) { hssk_flag_raise(err); break; }
+    }
+    hssk_flag_sub(flags + idx, 1);
+  }
+}
+// call with every thread after sweep_wait(s): orders the workgroup behind thread 0's acquire
+__device__ __forceinline__ void sweep_acquire() {
+  __syncthreads();
+  hssk_fence_acquire();
+}
+// call with every thread once the node's results are stored
+__device__ __forceinline__ void sweep_publish(int* flags, int self, int consumers) {
+  hssk_fence_release();
+  __syncthreads();
+  if (consumers > 0 && threadIdx.x == 0) hssk_flag_store(flags + self, consumers);
+}
+
+// ---- workgroup GEMVs on LDS vectors (leading dimension SW_MAX per right-hand side) -----------------------------------
+enum { OP_SET = 0, OP_ADD = 1, OP_SUB = 2 };
+__device__ __forceinline__ void apply_op(double* o, double v, int op) {
+  *o = op == OP_SET ? v : (op == OP_ADD ? *o + v : *o - v);
+}
+
+// out[i] (op)= sum_{k < K} A[i + k lda] x[k],  i < M <= 256: rows contiguous.  Lanes run along the rows; with M <= 128
+// the K range is split over 2 / 4 thread groups (partials meet in s_p) so that all 256 threads have loads in flight.
+// Contains barriers: every thread of the workgroup must call.  x and out must not alias.
+__device__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
+                       double* s_p) {
+  const int tid = threadIdx.x;
+  const int M64 = max(64, (M + 63) & ~63);
+  const int P = M64 <= 64 ? 4 : (M64 <= 128 ? 2 : 1);
+  const int i = P == 1 ? tid : tid % M64, part = P == 1 ? 0 : tid / M64;
+  const int Kc = (K + P - 1) / P;
+  const int k0 = part * Kc, k1 = min(K, k0 + Kc);
+  double acc[SW_NR] = {0., 0., 0., 0.};
+  if (i < M && part < P) {
+    const double* a = A + i;
+#pragma unroll 16
+    for (int k = k0; k < k1; k++) {
+      const double t = hssk_gload(a, (size_t)k * lda);
+#pragma unroll
+      for (int c = 0; c < SW_NR; c++) acc[c] += t * x[k + c * SW_MAX];
+    }
+  }
+  if (P == 1) {
+    if (i < M)
+      for (int c = 0; c < nrhs; c++) apply_op(out + i + c * SW_MAX, acc[c], op);
+    __syncthreads();
+    return;
+  }
+  // partials: s_p[(part * SW_NR + c) * M64 + i]   (P * M64 == 256)
+  if (part < P)
+    for (int c = 0; c < nrhs; c++) s_p[(part * SW_NR + c) * M64 + i] = acc[c];
+  __syncthreads();
+  if (part == 0 && i < M)
+    for (int c = 0; c < nrhs; c++) {
+      double v = 0.;
+      for (int q = 0; q < P; q++) v += s_p[(q * SW_NR + c) * M64 + i];
+      apply_op(out + i + c * SW_MAX, v, op);
+    }
+  __syncthreads();
+}
+
+// out[j] (op)= sum_{i < K} A[i + j lda] x[i],  j < N: columns contiguous.  Four adjacent lanes share a column (each
+// a contiguous quarter of it: whole cache lines per lane), 64 columns per pass; quad reduction by shuffles.
+// Contains wave collectives and a barrier: every thread must call.  x and out must not alias.
+__device__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op) {
+  const int tid = threadIdx.x;
+  const int part = tid & 3, cj = tid >> 2;
+  const int Kc = (K + 3) >> 2;
+  const int i0 = part * Kc, i1 = min(K, i0 + Kc);
+  for (int j0 = 0; j0 < N; j0 += SW_T / 4) {
+    const int j = j0 + cj;
+    double acc[SW_NR] = {0., 0., 0., 0.};
+    if (j < N) {
+      const double* a = A + (size_t)j * lda;
+#pragma unroll 16
+      for (int i = i0; i < i1; i++) {
+        const double t = hssk_gload(a, i);
+#pragma unroll
+        for (int c = 0; c < SW_NR; c++) acc[c] += t * x[i + c * SW_MAX];
+      }
+    }
+    for (int c = 0; c < nrhs; c++) {
+      double v = acc[c];
+      v += hssk_shfl_xor(v, 1);
+      v += hssk_shfl_xor(v, 2);
+      if (part == 0 && j < N) apply_op(out + j + c * SW_MAX, v, op);
+    }
+  }
+  __syncthreads();
+}
+
+// ---- forward ULV sweep ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs,
+                                                             int* flags, int* err) {
+  HSSK_SHARED double s_f[SW_MAX * SW_NR];    // f, later z
+  HSSK_SHARED double s_y[SW_MAX * SW_NR];    // y, later the gathered children z
+  HSSK_SHARED double s_a[SW_MAX * SW_NR];    // stacked children z (inner nodes)
+  HSSK_SHARED double s_t[SW_MAX * SW_NR];    // ft1, and the block right-hand side of the substitution
+  HSSK_SHARED double s_p[SW_T * SW_NR];      // gemv_n partials
+  const hssk_sweep_fwd_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
+  const bool inner = p.B01 != nullptr;
+  sweep_wait(flags, p.wait0, err);
+  sweep_wait(flags, p.wait1, err);
+  sweep_acquire();
+  // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] - [B01 z_1; B10 z_0] (inner)
+  for (int e = tid; e < m * nrhs; e += SW_T) {
+    const int i = e % m, c = e / m;
+    s_f[i + c * SW_MAX] = hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
+  }
+  if (inner)
+    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = hssk_gload(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in);
+  __syncthreads();
+  if (inner) {
+    gemv_n(p.B01, max(p.rU0, 1), p.rU0, p.rV1, s_a + p.rV0, s_f, nrhs, OP_SUB, s_p);
+    gemv_n(p.B10, max(p.rU1, 1), p.rU1, p.rV0, s_a, s_f + p.rU0, nrhs, OP_SUB, s_p);
+  }
+  if (p.LU) {
+    // ---- root: x = U^{-1} L^{-1} P f   (DenseMatrix::solve / getrs, solve.hpp:133-135), block substitution with the
+    // inverted 64 x 64 diagonal blocks
+    if (tid < nrhs)
+      for (int i = 0; i < m; i++) {
+        const int pi = p.piv[i];
+        if (pi != i) { const double a = s_f[i + tid * SW_MAX]; s_f[i + tid * SW_MAX] = s_f[pi + tid * SW_MAX]; s_f[pi + tid * SW_MAX] = a; }
+      }
+    __syncthreads();
+    for (int b0 = 0, blk = 0; b0 < m; b0 += SW_NB, blk++) {
+      const int nb = min(SW_NB, m - b0);
+      for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+      __syncthreads();
+      gemv_n(p.TinvL + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
+      const int rest = m - b0 - nb;
+      if (rest > 0) {
+        for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+        __syncthreads();
+        gemv_n(p.LU + (b0 + nb) + (size_t)b0 * m, m, rest, nb, s_t, s_f + b0 + nb, nrhs, OP_SUB, s_p);
+      }
+    }
+    for (int blk = (m - 1) / SW_NB; blk >= 0; blk--) {
+      const int b0 = blk * SW_NB, nb = min(SW_NB, m - b0);
+      for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+      __syncthreads();
+      gemv_n(p.TinvU + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
+      if (b0 > 0) {
+        for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+        __syncthreads();
+        gemv_n(p.LU + (size_t)b0 * m, m, b0, nb, s_t, s_f, nrhs, OP_SUB, s_p);
+      }
+    }
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.xroot, (e % m) + (size_t)(e / m) * p.ldxr, s_f[(e % m) + (e / m) * SW_MAX]);
+    sweep_publish(flags, blockIdx.x, p.consumers);
+    return;
+  }
+  // ---- ft1 = f(perm[0:r]), y = f(perm[r:])
+  for (int e = tid; e < m * nrhs; e += SW_T) {
+    const int k = e % m, c = e / m;
+    const double v = s_f[p.permU[k] + c * SW_MAX];
+    if (k < r) s_t[k + c * SW_MAX] = v;
+    else s_y[(k - r) + c * SW_MAX] = v;
+  }
+  __syncthreads();
+  if (q > 0) {
+    // ---- y -= X^T ft1   (X is r x q, column k contiguous)
+    if (r > 0) gemv_t(p.XU, r, r, q, s_t, s_y, nrhs, OP_SUB);
+    // ---- y <- R~^{-T} y on 64-row blocks: y_b = Linv_b y_b, then rows below -= R~(b, below)^T y_b
+    for (int b0 = 0, blk = 0; b0 < q; b0 += SW_NB, blk++) {
+      const int nb = min(SW_NB, q - b0);
+      for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * SW_MAX] = s_y[b0 + (e % nb) + (e / nb) * SW_MAX];
+      __syncthreads();
+      gemv_n(p.Tinv + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_f, s_y + b0, nrhs, OP_SET, s_p);
+      const int rest = q - b0 - nb;
+      if (rest > 0) {
+        // column k of R~ (rows b0 .. b0+nb contiguous) for k > b0 + nb;  x = y_b (now final) copied to s_f
+        for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * SW_MAX] = s_y[b0 + (e % nb) + (e / nb) * SW_MAX];
+        __syncthreads();
+        gemv_t(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
+      }
+    }
+    for (int e = tid; e < q * nrhs; e += SW_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * SW_MAX]);
+    // ---- ft1 -= W1 (Q~(:, 0:q) y) = WQ y
+    if (r > 0) gemv_n(p.WQ, r, r, q, s_y, s_t, nrhs, OP_SUB, s_p);
+  }
+  for (int e = tid; e < r * nrhs; e += SW_T) hssk_gstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * SW_MAX]);
+  // ---- z = V^H [z_0; z_1] + Vt0^T y   (leaf: Vt0^T y)
+  if (rv > 0) {
+    for (int e = tid; e < rv * nrhs; e += SW_T) s_f[(e % rv) + (e / rv) * SW_MAX] = 0.;
+    __syncthreads();
+    if (q > 0) gemv_t(p.Vt0, q, q, rv, s_y, s_f, nrhs, OP_SET);
+    if (inner) {
+      // z(k) += zc(permV[k]) + sum_j XV(k, j) zc(permV[rv + j])   (XV is rv x (mv - rv), rows contiguous)
+      for (int e = tid; e < mv * nrhs; e += SW_T) {
+        const int k = e % mv, c = e / mv;
+        const double v = s_a[p.permV[k] + c * SW_MAX];
+        if (k < rv) s_f[k + c * SW_MAX] += v;
+        else s_y[(k - rv) + c * SW_MAX] = v;
+      }
+      __syncthreads();
+      if (mv > rv) gemv_n(p.XV, rv, rv, mv - rv, s_y, s_f, nrhs, OP_ADD, s_p);
+    }
+    for (int e = tid; e < rv * nrhs; e += SW_T) hssk_gstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_f[(e % rv) + (e / rv) * SW_MAX]);
+  }
+  sweep_publish(flags, blockIdx.x, p.consumers);
+}
+
+// ---- backward ULV sweep:  x_c = Q~(:, 0:q) y + Q~(:, q:) xpart ; m == r (nothing eliminated): x_c = xpart ------------
+__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs,
+                                                             int* flags, int* err) {
+  HSSK_SHARED double s_v[SW_MAX * SW_NR];   // [y; xpart]
+  HSSK_SHARED double s_o[SW_MAX * SW_NR];
+  HSSK_SHARED double s_p[SW_T * SW_NR];
+  const hssk_sweep_bwd_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int m = p.m, r = p.r, q = m - r;
+  // y does not depend on the parent: it is in LDS before the wait is over
+  for (int e = tid; e < q * nrhs; e += SW_T) s_v[(e % q) + (e / q) * SW_MAX] = hssk_gload(p.y, (e % q) + (size_t)(e / q) * q);
+  sweep_wait(flags, p.wait0, err);
+  sweep_acquire();
+  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = hssk_gload(p.xpart, (e % r) + (size_t)(e / r) * p.ldx);
+  __syncthreads();
+  if (q > 0) {
+    gemv_n(p.Qt, m, m, m, s_v, s_o, nrhs, OP_SET, s_p);
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_o[(e % m) + (e / m) * SW_MAX]);
+  } else {
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * SW_MAX]);
+  }
+  sweep_publish(flags, blockIdx.x, p.consumers);
+}
+
+// ---- mat-vec: up-sweep nodes [0, nup) then down-sweep nodes [nup, nup + ndown) in one launch -------------------------------
+__global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
+                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs,
+                                                           int* flags, int* err) {
+  HSSK_SHARED double s_x[SW_MAX * SW_NR];
+  HSSK_SHARED double s_g[SW_MAX * SW_NR];
+  HSSK_SHARED double s_o[SW_MAX * SW_NR];
+  HSSK_SHARED double s_p[SW_T * SW_NR];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nup) {
+    // tmp1 = V^H src = src(perm[0:r]) + X src(perm[r:])   (X is r x (m - r), rows contiguous)
+    const hssk_apply_up_desc p = ups[blockIdx.x];
+    const int m = p.m, r = p.r;
+    sweep_wait(flags, p.wait0, err);
+    sweep_wait(flags, p.wait1, err);
+    sweep_acquire();
+    for (int e = tid; e < m * nrhs; e += SW_T) {
+      const int k = e % m, c = e / m;
+      const double v = hssk_gload(p.src, p.perm[k] + (size_t)c * p.lds);
+      if (k < r) s_o[k + c * SW_MAX] = v;
+      else s_g[(k - r) + c * SW_MAX] = v;
+    }
+    __syncthreads();
+    if (m > r && r > 0) gemv_n(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p);
+    for (int e = tid; e < r * nrhs; e += SW_T) hssk_gstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
+    sweep_publish(flags, blockIdx.x, p.consumers);
+    return;
+  }
+  const hssk_apply_down_desc p = downs[blockIdx.x - nup];
+  const int mo = p.mo, ro = p.ro;
+  if (p.D) {
+    // ---- leaf: y = op(D) x + beta y + U tmp2.  op(D) x does not depend on the tree: it runs before the wait.
+    const int m = p.m;
+    for (int e = tid; e < m * nrhs; e += SW_T) s_x[(e % m) + (e / m) * SW_MAX] = hssk_gload(p.x, (e % m) + (size_t)(e / m) * p.ldx);
+    __syncthreads();
+    if (p.trans) gemv_t(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
+    else gemv_n(p.D, m, m, m, s_x, s_o, nrhs, OP_SET, s_p);
+    if (p.beta != 0.) {
+      for (int e = tid; e < m * nrhs; e += SW_T) s_o[(e % m) + (e / m) * SW_MAX] += p.beta * hssk_gload(p.out, (e % m) + (size_t)(e / m) * p.ldo);
+      __syncthreads();
+    }
+  } else {
+    // ---- inner: t = [B01 t1_1; B10 t1_0]  (transposed: [B10^T t1_1; B01^T t1_0]); t1 = the children's up-sweep results
+    sweep_wait(flags, p.wait1, err);
+    sweep_wait(flags, p.wait2, err);
+    sweep_acquire();
+    const int nt1 = p.ri_a + p.ri_b;
+    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = hssk_gload(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1);
+    for (int e = tid; e < (p.ro_a + p.ro_b) * nrhs; e += SW_T) s_o[(e % (p.ro_a + p.ro_b)) + (e / (p.ro_a + p.ro_b)) * SW_MAX] = 0.;
+    __syncthreads();
+    if (!p.trans) {   // B01 is ro_a x ri_b, B10 is ro_b x ri_a
+      if (p.ro_a > 0 && p.ri_b > 0) gemv_n(p.B01, p.ro_a, p.ro_a, p.ri_b, s_x + p.ri_a, s_o, nrhs, OP_SET, s_p);
+      if (p.ro_b > 0 && p.ri_a > 0) gemv_n(p.B10, p.ro_b, p.ro_b, p.ri_a, s_x, s_o + p.ro_a, nrhs, OP_SET, s_p);
+    } else {          // B10 is ri_b x ro_a, B01 is ri_a x ro_b
+      if (p.ro_a > 0 && p.ri_b > 0) gemv_t(p.B10, p.ri_b, p.ri_b, p.ro_a, s_x + p.ri_a, s_o, nrhs, OP_SET);
+      if (p.ro_b > 0 && p.ri_a > 0) gemv_t(p.B01, p.ri_a, p.ri_a, p.ro_b, s_x, s_o + p.ro_a, nrhs, OP_SET);
+    }
+  }
+  // ---- + U tmp2:  out(perm[k]) += tmp2(k), k < ro ;  out(perm[ro + j]) += sum_k X(k, j) tmp2(k)   (X is ro x (mo - ro))
+  if (p.tmp2 && ro > 0) {
+    sweep_wait(flags, p.wait0, err);
+    sweep_acquire();
+    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = hssk_gload(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2);
+    __syncthreads();
+    if (mo > ro) gemv_t(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET);
+    for (int e = tid; e < mo * nrhs; e += SW_T) {
+      const int k = e % mo, c = e / mo;
+      s_o[p.perm[k] + c * SW_MAX] += k < ro ? s_x[k + c * SW_MAX] : s_g[(k - ro) + c * SW_MAX];
+    }
+    __syncthreads();
+  } else if (p.wait0 >= 0) {
+    sweep_wait(flags, p.wait0, err);   // nothing to read, but the producer counted this consumer
+  }
+  const int mout = p.D ? p.m : p.ro_a + p.ro_b;
+  for (int e = tid; e < mout * nrhs; e += SW_T) hssk_gstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
+  sweep_publish(flags, blockIdx.x, p.consumers);
+}
+
+// ---- inverses of the 64 x 64 diagonal blocks of R~^T (factor time) --------------------------------------------------------
+// One wave per block: lane j back-substitutes column j of U^{-1} (U = R~(b, b), upper triangular), both matrices in LDS;
+// mode 0 stores it TRANSPOSED (Linv = U^{-T}, lower triangular, leading dimension 64) so that the sweep's y_b = Linv y_b
+// reads rows contiguously; modes 1 / 2 serve the root's LU (plain inverses of the blocks of U and of the unit lower L).
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const hssk_trtri_desc* __restrict__ descs, const int* __restrict__ blk_prob,
+                                                        const int* __restrict__ blk_idx) {
+  HSSK_SHARED double s_U[SW_NB * (SW_NB + 1)];
+  HSSK_SHARED double s_X[SW_NB * (SW_NB + 1)];
+  const hssk_trtri_desc p = descs[blk_prob[blockIdx.x]];
+  const int b = blk_idx[blockIdx.x], b0 = b * SW_NB;
+  const int nb = min(SW_NB, p.n - b0);
+  const int j = threadIdx.x;
+  for (int e = j; e < nb * nb; e += 64) {
+    const int i = e % nb, c = e / nb;
+    double v = 0.;
+    if (p.mode == 2) v = i == c ? 1. : (i < c ? hssk_gload(p.R, (b0 + c) + (size_t)(b0 + i) * p.ldr) : 0.);   // U = L^T, unit diagonal
+    else if (i <= c) v = hssk_gload(p.R, (b0 + i) + (size_t)(b0 + c) * p.ldr);
+    s_U[i + c * (SW_NB + 1)] = v;
+  }
+  for (int e = j; e < SW_NB * (SW_NB + 1); e += 64) s_X[e] = 0.;
+  __syncthreads();
+  if (j < nb) {
+    double* x = s_X + j * (SW_NB + 1);   // column j of U^{-1}
+    x[j] = 1. / s_U[j + j * (SW_NB + 1)];
+    for (int i = j - 1; i >= 0; i--) {
+      double s = 0.;
+      for (int k = i + 1; k <= j; k++) s += s_U[i + k * (SW_NB + 1)] * x[k];
+      x[i] = -s / s_U[i + i * (SW_NB + 1)];
+    }
+  }
+  __syncthreads();
+  double* out = p.Tinv + (size_t)b * SW_NB * SW_NB;
+  for (int e = j; e < SW_NB * SW_NB; e += 64) {
+    const int i = e % SW_NB, c = e / SW_NB;   // modes 0, 2: out(i, c) = Uinv(c, i);  mode 1: out(i, c) = Uinv(i, c)
+    out[e] = (i < nb && c < nb) ? (p.mode == 1 ? s_X[i + c * (SW_NB + 1)] : s_X[c + i * (SW_NB + 1)]) : 0.;
+  }
+}
+
+int* sweep_flags(hssk_ctx* ctx, int count) {
+  if ((size_t)count > ctx->sweep_cap) return nullptr;
+  if (!ctx->d_sweep_flags) {
+    ctx->d_sweep_flags = (int*)hssk_rt::dev_malloc(sizeof(int) * ctx->sweep_cap);
+    hssk_rt::memset_async(ctx->d_sweep_flags, 0, sizeof(int) * ctx->sweep_cap, ctx->stream);
+    ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64);
+    *ctx->h_sweep_err = 0;
+  }
+  return ctx->d_sweep_flags;
+}
+
+}  // namespace
+
+extern "C" int hssk_sweep_status(hssk_ctx* ctx) {
+  if (!ctx->h_sweep_err) return 0;
+  const int e = *(volatile int*)ctx->h_sweep_err;
+  if (e) {   // a dependency never arrived: flags are in an unknown state
+    try {
+      hssk_rt::sync(ctx->stream);
+      hssk_rt::memset_async(ctx->d_sweep_flags, 0, sizeof(int) * ctx->sweep_cap, ctx->stream);
+      hssk_rt::sync(ctx->stream);
+    } catch (...) {}
+    *ctx->h_sweep_err = 0;
+    hssk_set_error("hssk sweep: a workgroup timed out waiting for its dependency (in-order dispatch violated?)");
+  }
+  return e;
+}
+
+extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  if (nrhs < 1 || nrhs > SW_NR) return 2;
+  for (int i = 0; i < count; i++)
+    if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) return 2;
+  int* flags = sweep_flags(ctx, count);
+  if (!flags) return 2;
+  auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(ulv_fwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, flags, ctx->h_sweep_err);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* descs, int count, int nrhs) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  if (nrhs < 1 || nrhs > SW_NR) return 2;
+  for (int i = 0; i < count; i++)
+    if (descs[i].m > SW_MAX || descs[i].wait0 >= i) return 2;
+  int* flags = sweep_flags(ctx, count);
+  if (!flags) return 2;
+  auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(ulv_bwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, flags, ctx->h_sweep_err);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, int nup, const hssk_apply_down_desc* downs,
+                                int ndown, int nrhs) {
+  HSSK_API_BEGIN
+  if (nup + ndown <= 0) return 0;
+  if (nrhs < 1 || nrhs > SW_NR) return 2;
+  for (int i = 0; i < nup; i++)
+    if (ups[i].m > SW_MAX || ups[i].wait0 >= i || ups[i].wait1 >= i) return 2;
+  for (int i = 0; i < ndown; i++) {
+    const hssk_apply_down_desc& d = downs[i];
+    if (d.mo > SW_MAX || d.m > SW_MAX || d.ri_a + d.ri_b > SW_MAX || d.ro_a + d.ro_b > SW_MAX) return 2;
+    if (d.wait0 >= nup + i || d.wait1 >= nup + i || d.wait2 >= nup + i) return 2;
+  }
+  int* flags = sweep_flags(ctx, nup + ndown);
+  if (!flags) return 2;
+  const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
+  const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
+  HSSK_LAUNCH(apply_sweep_kernel, dim3((unsigned)(nup + ndown)), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, flags,
+              ctx->h_sweep_err);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_trtri_diag_vbatched(hssk_ctx* ctx, const hssk_trtri_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  std::vector<int> prob, idx;
+  for (int i = 0; i < count; i++)
+    for (int b = 0; b * SW_NB < descs[i].n; b++) { prob.push_back(i); idx.push_back(b); }
+  if (prob.empty()) return 0;
+  auto* dd = (const hssk_trtri_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dp = (const int*)ctx->stage(prob.data(), sizeof(int) * prob.size());
+  auto* di = (const int*)ctx->stage(idx.data(), sizeof(int) * idx.size());
+  HSSK_LAUNCH(trtri_diag_kernel, dim3((unsigned)prob.size()), dim3(64), 0, ctx->stream, dd, dp, di);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}

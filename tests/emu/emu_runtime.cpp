@@ -20,6 +20,8 @@
 #include "hssk_device.h"
 
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#include <sched.h>
+void hssk_pause() { sched_yield(); }
 
 namespace emu {
 namespace {

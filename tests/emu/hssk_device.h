@@ -68,6 +68,17 @@ inline long long hssk_wallclock() { return 0; }
 inline long long hssk_hwid() { return 0; }
 
 
+
+// cross-workgroup dependency flags (single-launch tree sweeps): workgroups of a launch are taken in index order by the
+// emulator's worker threads, so a workgroup that polls a lower-indexed one always finds it running or finished
+inline int hssk_flag_load(const int* f) { return __atomic_load_n(f, __ATOMIC_ACQUIRE); }
+inline void hssk_flag_store(int* f, int v) { __atomic_store_n(f, v, __ATOMIC_RELEASE); }
+inline int hssk_flag_sub(int* f, int v) { return __atomic_fetch_sub(f, v, __ATOMIC_ACQ_REL); }
+inline void hssk_flag_raise(int* f) { __atomic_store_n(f, 1, __ATOMIC_RELAXED); }
+inline void hssk_fence_release() { __atomic_thread_fence(__ATOMIC_RELEASE); }
+inline void hssk_fence_acquire() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+void hssk_pause();   // emu_runtime.cpp: sched_yield
+
 #define HSSK_SHARED alignas(16) static thread_local
 inline double hssk_gload(const double* p, size_t off) { return p[off]; }
 inline hssk_d2 hssk_gload2(const double* p, size_t off) { return *reinterpret_cast<const hssk_d2*>(p + off); }
