@@ -253,6 +253,7 @@ def main():
     solve_ms = timed(one_solve)
 
     st = stats[-1]
+    st2 = H.stats()
     f_total = st["f_sketch"] + st["f_local"] + st["f_reduce"] + st["f_id"] + st["f_ortho"] + st["f_ulv"] + st["f_solve"]
     value = f_total / (ms_per_step * 1e-3) * 1e-9
     # dominant kernel: the sketch DGEMM.  Algorithmic flops per launch = 2 d N^2 (4 N^2 d
@@ -284,10 +285,12 @@ def main():
                   "ortho": st["f_ortho"], "ulv": st["f_ulv"], "solve": st["f_solve"]},
         "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "rounds": int(st["rounds"]), "d": d},
         "checks": {"solve_resid_H": resid, "compress_err_sampled": comp_err, "Ax_minus_b_sampled": ax_resid},
-        "sweeps": {"apply": {"ms": apply_ms, "bytes": H.memory() + 16.0 * n * a.nrhs,
-                             "GBps": (H.memory() + 16.0 * n * a.nrhs) / (apply_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); latency of %d dependent levels at this size" % H.levels()},
-                   "solve": {"ms": solve_ms, "bytes": st["factor_memory"] + 16.0 * n * a.nrhs,
-                             "GBps": (st["factor_memory"] + 16.0 * n * a.nrhs) / (solve_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s)"}},
+        # bytes = the blocks each sweep reads, once (engine-side count: D, X, B for the mat-vec; X, R~, WQ, Vt0, B, Q~ for
+        # the solve) + the vectors in and out
+        "sweeps": {"apply": {"ms": apply_ms, "bytes": st2["b_mult"] + 16.0 * n * a.nrhs,
+                             "GBps": (st2["b_mult"] + 16.0 * n * a.nrhs) / (apply_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); one launch, %d dependent levels" % H.levels()},
+                   "solve": {"ms": solve_ms, "bytes": st2["b_solve"] + 16.0 * n * a.nrhs,
+                             "GBps": (st2["b_solve"] + 16.0 * n * a.nrhs) / (solve_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); two launches"}},
         "roofline": {"kernel": "dgemm_kernel<192> (sketch S^T = R^T op(A), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                      "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},

@@ -283,7 +283,7 @@ typedef struct hssk_sweep_fwd_desc {
   const double* Rlq;    /* m x (m - r): R~ = L^T in the upper triangle */
   const double* Tinv;   /* ceil((m-r)/64) blocks of 64 x 64: inverses of the diagonal blocks of R~^T (hssk_trtri_diag_vbatched) */
   const double* WQ;     /* r x (m - r): W1 Q~(:, 0:m-r) */
-  const double* Vt0;    /* (m - r) x rv */
+  const double* Vt0T;   /* rv x (m - r): Vt0^T, Vt0 = Q~(:, 0:m-r)^T Vhat */
   const int* permV;     /* inner nodes only */
   const double* XV;
   double *ft1, *y, *z;  /* out: r x nrhs (ld ldp), (m-r) x nrhs (ld m-r), rv x nrhs (ld ldz) */

@@ -34,7 +34,8 @@ ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
 STAT_NAMES = ["t_compress", "t_sketch", "t_random", "t_tree", "t_factor", "t_solve", "t_mult",
               "sketch_kernel_ms", "sketch_launches", "rounds", "d_final", "f_sketch", "f_local",
-              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory", "sketch_kernel_flops", "sketch_kernel_bytes"]
+              "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory", "sketch_kernel_flops", "sketch_kernel_bytes",
+              "b_solve", "b_mult"]
 
 
 def load(path):

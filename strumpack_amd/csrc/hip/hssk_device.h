@@ -71,15 +71,24 @@ __device__ __forceinline__ long long hssk_hwid() {
 }
 
 
-// ---- cross-workgroup dependency flags of the single-launch tree sweeps (kernels/hssk_sweep.hip) ----------------
-// A workgroup publishes its results with a release store at agent scope (L2 write-back across XCDs included) and a
-// consumer workgroup polls with acquire loads; s_sleep keeps the polling wave off the issue ports.
-__device__ __forceinline__ int hssk_flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void hssk_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int hssk_flag_sub(int* f, int v) { return __hip_atomic_fetch_sub(f, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
+// ---- cross-workgroup hand-off inside one launch (single-launch tree sweeps, kernels/hssk_sweep.hip) ---------------
+// The vectors one workgroup hands to another (a few hundred bytes) and the flag that announces them are written and
+// read with agent-scope RELAXED atomics: on gfx950 these are sc1 accesses served at the device coherence point, so no
+// cache-wide maintenance is needed.  (Agent-scope release / acquire FENCES would write back / invalidate the whole L2
+// of the XCD -- measured ~100 us per tree level.)  Ordering: the producer drains its stores (s_waitcnt 0) before the
+// workgroup barrier that precedes the flag store; the consumer's loads are issued after the barrier that follows the
+// poll.  s_sleep keeps the polling wave off the issue ports.
+__device__ __forceinline__ int hssk_flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hssk_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int hssk_flag_sub(int* f, int v) { return __hip_atomic_fetch_sub(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void hssk_flag_raise(int* f) { __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // error word in pinned host memory
-__device__ __forceinline__ void hssk_fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-__device__ __forceinline__ void hssk_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ double hssk_cload(const double* p, size_t off) {
+  return __longlong_as_double(__hip_atomic_load((const long long*)(p + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void hssk_cstore(double* p, size_t off, double v) {
+  __hip_atomic_store((long long*)(p + off), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hssk_drain_stores() { __builtin_amdgcn_s_waitcnt(0); }
 __device__ __forceinline__ void hssk_pause() { __builtin_amdgcn_s_sleep(2); }
 
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))

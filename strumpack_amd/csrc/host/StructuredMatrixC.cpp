@@ -219,7 +219,8 @@ int SPX_d_struct_stats(const CSPStructMat S, double* o) {
   o[15] = st.f_ortho; o[16] = st.f_ulv; o[17] = st.f_solve; o[18] = (double)hss(S)->engine()->factor_memory();
   o[19] = st.sketch_kernel_flops;
   o[20] = st.sketch_kernel_bytes;
-  for (int i = 21; i < 24; i++) o[i] = 0;
+  o[21] = st.b_solve; o[22] = st.b_mult;
+  o[23] = 0;
   SP_CATCH
 }
 // ---- Schur complement of the (0,0) block (HSS only; HSSMatrix.Schur.hpp)

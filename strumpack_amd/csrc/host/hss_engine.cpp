@@ -1875,6 +1875,16 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   ck(hssk_sync(ctx_));
   if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("mult: ") + hssk_last_error());
   stats_.t_mult = now() - t0;
+  {
+    double bm = 0;
+    for (int i = sr; i < sr_end; i++) {
+      const Node& nd = nodes_[i];
+      if (nd.leaf()) bm += (double)nd.m * nd.m;
+      else bm += (double)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (double)nodes_[nd.c1].rU * nodes_[nd.c0].rV;
+      if (i != sr) bm += (double)nd.rU * (nd.mU - nd.rU) + (double)nd.rV * (nd.mV - nd.rV);
+    }
+    stats_.b_mult = 8.0 * bm;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1898,7 +1908,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   drop_plans();   // recorded sweeps reference the old factors
   fact_->reset();
   stats_.f_ulv = 0;
-  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nullptr, nd.piv = nullptr;
+  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nd.Vt0T = nullptr, nd.piv = nullptr;
   const size_t nn = nodes_.size();
   std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr);
   auto level = [&](const std::vector<int>& ids) {
@@ -1985,6 +1995,8 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         // Vt0 = Q0 Vh = Q~(:, :m-r)^T Vh ; Vt1 = Q~(:, m-r:)^T Vh ; Dt = W1 Q1^T = W1 Q~(:, m-r:)
         if (rv) {
           g3.push_back(hssk_gemm_desc{nd.Qt, Vh[id], nd.Vt0, m - r, rv, m, m, m, m - r, 1, 0, 1.0, 0.0});
+          nd.Vt0T = fact_->dbl((size_t)rv * (m - r));   // rows contiguous for the solve sweep: Vt0^T = Vh^T Q~(:, 0:m-r)
+          g3.push_back(hssk_gemm_desc{Vh[id], nd.Qt, nd.Vt0T, rv, m - r, m, m, m, rv, 1, 0, 1.0, 0.0});
           if (r) g3.push_back(hssk_gemm_desc{nd.Qt + (size_t)(m - r) * m, Vh[id], nd.Vt1, r, rv, m, m, m, r, 1, 0, 1.0, 0.0});
         }
         if (r) g3.push_back(hssk_gemm_desc{nd.W1, nd.Qt + (size_t)(m - r) * m, nd.Dt, r, r, m, r, m, r, 0, 0, 1.0, 0.0});
@@ -2409,13 +2421,13 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
           const Node& pa = nodes_[nd.parent];
           d.m = nd.mU; d.r = nd.rU; d.rv = nd.rV;
           if (!nd.leaf()) d.mv = nd.mV;
-          d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Tinv = nd.Tinv; d.WQ = nd.WQ; d.Vt0 = nd.Vt0;
+          d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Tinv = nd.Tinv; d.WQ = nd.WQ; d.Vt0T = nd.Vt0T;
           d.ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
           d.ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
           d.z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
           d.ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
           d.y = y[id];
-          if (d.m > d.r && (!d.y || !d.Rlq || !d.Tinv || (d.r && !d.WQ))) return false;
+          if (d.m > d.r && (!d.y || !d.Rlq || !d.Tinv || (d.r && !d.WQ) || (d.rv && !d.Vt0T))) return false;
         }
         where[id] = (int)fd.size();
         fd.push_back(d);
@@ -2629,6 +2641,16 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
       if (!nd.leaf()) fs += 4.0 * nodes_[nd.c0].rU * (double)nodes_[nd.c1].rV;
     }
     stats_.f_solve = fs * nrhs;
+    // blocks read by the sweeps (fused path: X, the off-diagonal part of R~ + its inverted diagonal blocks, WQ, Vt0, B, XV
+    // going up, Q~ going down; the unfused path reads W1 and Q~(:, 0:q) instead of WQ)
+    double bs = 0;
+    for (auto& nd : nodes_) {
+      if (nd.lvl == 0) { const double mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU; bs += mu * mu; continue; }
+      const double m = nd.mU, r = nd.rU, k = m - r, rv = nd.rV;
+      bs += r * k + k * (k + 1) / 2 + (fuse ? r * k : r * m + m * k) + k * rv + m * m;
+      if (!nd.leaf()) bs += (double)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (double)nodes_[nd.c1].rU * nodes_[nd.c0].rV + rv * (nd.mV - rv);
+    }
+    stats_.b_solve = 8.0 * bs;
   }
 }
 

@@ -57,6 +57,8 @@ struct PhaseStats {
   int sketch_launches = 0, rounds = 0, d_final = 0;
   // algorithmic flop model
   double f_sketch = 0, f_local = 0, f_reduce = 0, f_id = 0, f_ortho = 0, f_ulv = 0, f_solve = 0;
+  // algorithmic HBM bytes of one solve / one mat-vec: every block the sweep reads, once (vectors not included)
+  double b_solve = 0, b_mult = 0;
 };
 
 class Arena;
@@ -156,9 +158,9 @@ class DeviceHSS {
     bool panels = false;
     // ULV factors (device)
     double *Qt = nullptr, *Rlq = nullptr, *W1 = nullptr, *Vt0 = nullptr, *Dt = nullptr, *Vt1 = nullptr;
-    // derived factors read by the single-launch solve sweeps: WQ = W1 Q~(:, 0:m-r), inverted 64 x 64 diagonal blocks of
+    // derived factors read by the single-launch solve sweeps: WQ = W1 Q~(:, 0:m-r), Vt0T = Vt0^T, inverted 64 x 64 diagonal blocks of
     // R~^T (non-root) resp. of the root's L and U
-    double *WQ = nullptr, *Tinv = nullptr, *TinvU = nullptr;
+    double *WQ = nullptr, *Tinv = nullptr, *TinvU = nullptr, *Vt0T = nullptr;
     double* LU = nullptr;
     int* piv = nullptr;
     bool leaf() const { return c0 < 0; }

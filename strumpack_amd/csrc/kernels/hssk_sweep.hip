@@ -5,8 +5,8 @@
 // is bound by launch-to-launch latency (N = 1e5: 20 launches, 0.55 ms apply / 1.07 ms solve for 0.19 / 0.52 GB of
 // blocks).  Here every node of the sweep is one workgroup of the same launch, ordered so that a node only depends on
 // workgroups with a LOWER index (children before parents going up, parents before children going down).  A workgroup
-// polls its dependencies' flags (agent-scope acquire), does the node's arithmetic with the vectors in LDS, and
-// publishes its own flag (agent-scope release).  Workgroups are dispatched in index order (round-robin over the XCDs,
+// polls its dependencies' flags, does the node's arithmetic with the vectors in LDS, and publishes its own flag; the
+// handed-over vectors and the flags are coherent (sc1) accesses, see hssk_device.h.  Workgroups are dispatched in index order (round-robin over the XCDs,
 // in order within an XCD), so the lowest-indexed unfinished workgroup is always resident and never waits on a
 // non-resident one: the scheme cannot deadlock, whatever the occupancy; a bounded spin count turns any violation of
 // that assumption into an error code instead of a hang.  Flags count pending consumers and return to zero by the end
@@ -47,14 +47,11 @@ __device__ __forceinline__ void sweep_wait(int* flags, int idx, int* err) {
     hssk_flag_sub(flags + idx, 1);
   }
 }
-// call with every thread after sweep_wait(s): orders the workgroup behind thread 0's acquire
-__device__ __forceinline__ void sweep_acquire() {
-  __syncthreads();
-  hssk_fence_acquire();
-}
-// call with every thread once the node's results are stored
+// call with every thread after sweep_wait(s): the hand-off loads (hssk_cload) of the workgroup are issued behind thread 0's poll
+__device__ __forceinline__ void sweep_acquire() { __syncthreads(); }
+// call with every thread once the node's hand-off results are stored (hssk_cstore)
 __device__ __forceinline__ void sweep_publish(int* flags, int self, int consumers) {
-  hssk_fence_release();
+  hssk_drain_stores();
   __syncthreads();
   if (consumers > 0 && threadIdx.x == 0) hssk_flag_store(flags + self, consumers);
 }
@@ -65,44 +62,72 @@ __device__ __forceinline__ void apply_op(double* o, double v, int op) {
   *o = op == OP_SET ? v : (op == OP_ADD ? *o + v : *o - v);
 }
 
-// out[i] (op)= sum_{k < K} A[i + k lda] x[k],  i < M <= 256: rows contiguous.  Lanes run along the rows; with M <= 128
-// the K range is split over 2 / 4 thread groups (partials meet in s_p) so that all 256 threads have loads in flight.
-// Contains barriers: every thread of the workgroup must call.  x and out must not alias.
+// Row-wise GEMV with per-row operands: out[i] (op)= sum_{k < K_i} a_i[k lda_i] x_i[k] for i < M, where rowop(i) names row
+// i's operands (several stacked matrices that share a stage are ONE pass, so their loads are in flight together).  Lanes
+// run along the rows (contiguous in memory); with M <= 128 the K range is split over 2 / 4 thread groups (partials meet in
+// s_p) so that all 256 threads have loads in flight; M > 256 takes further passes.  Contains barriers: every thread of the
+// workgroup must call.  x and out must not alias.
+struct RowOp {
+  const double* a;   // first element of the row
+  int lda, K;
+  const double* x;   // LDS vector (leading dimension SW_MAX per right-hand side)
+  double* o;         // LDS output element of the row (same leading dimension)
+  int op;
+};
+template <class F>
+__device__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s_p) {
+  const int tid = threadIdx.x;
+  for (int r0 = 0; r0 < Mtot || r0 == 0; r0 += SW_T) {
+    const int M = min(Mtot - r0, SW_T);
+    const int M64 = max(64, (M + 63) & ~63);
+    const int P = M64 <= 64 ? 4 : (M64 <= 128 ? 2 : 1);
+    const int i = P == 1 ? tid : tid % M64, part = P == 1 ? 0 : tid / M64;
+    double acc[SW_NR] = {0., 0., 0., 0.};
+    RowOp ro{};
+    if (i < M && part < P) {
+      ro = rowop(r0 + i);
+      const int Kc = (ro.K + P - 1) / P;
+      const int k0 = part * Kc, k1 = min(ro.K, k0 + Kc);
+#pragma unroll 16
+      for (int k = k0; k < k1; k++) {
+        const double t = hssk_gload(ro.a, (size_t)k * ro.lda);
+#pragma unroll
+        for (int c = 0; c < SW_NR; c++) acc[c] += t * ro.x[k + c * SW_MAX];
+      }
+    }
+    if (P == 1) {
+      if (i < M)
+        for (int c = 0; c < nrhs; c++) apply_op(ro.o + c * SW_MAX, acc[c], ro.op);
+      __syncthreads();
+      continue;
+    }
+    // partials: s_p[(part * SW_NR + c) * M64 + i]   (P * M64 == 256)
+    if (part < P)
+      for (int c = 0; c < nrhs; c++) s_p[(part * SW_NR + c) * M64 + i] = acc[c];
+    __syncthreads();
+    if (part == 0 && i < M)
+      for (int c = 0; c < nrhs; c++) {
+        double v = 0.;
+        for (int q = 0; q < P; q++) v += s_p[(q * SW_NR + c) * M64 + i];
+        apply_op(ro.o + c * SW_MAX, v, ro.op);
+      }
+    __syncthreads();
+  }
+}
+// out[i] (op)= sum_{k < K} A[i + k lda] x[k],  i < M
 __device__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
                        double* s_p) {
-  const int tid = threadIdx.x;
-  const int M64 = max(64, (M + 63) & ~63);
-  const int P = M64 <= 64 ? 4 : (M64 <= 128 ? 2 : 1);
-  const int i = P == 1 ? tid : tid % M64, part = P == 1 ? 0 : tid / M64;
-  const int Kc = (K + P - 1) / P;
-  const int k0 = part * Kc, k1 = min(K, k0 + Kc);
-  double acc[SW_NR] = {0., 0., 0., 0.};
-  if (i < M && part < P) {
-    const double* a = A + i;
-#pragma unroll 16
-    for (int k = k0; k < k1; k++) {
-      const double t = hssk_gload(a, (size_t)k * lda);
-#pragma unroll
-      for (int c = 0; c < SW_NR; c++) acc[c] += t * x[k + c * SW_MAX];
-    }
-  }
-  if (P == 1) {
-    if (i < M)
-      for (int c = 0; c < nrhs; c++) apply_op(out + i + c * SW_MAX, acc[c], op);
-    __syncthreads();
-    return;
-  }
-  // partials: s_p[(part * SW_NR + c) * M64 + i]   (P * M64 == 256)
-  if (part < P)
-    for (int c = 0; c < nrhs; c++) s_p[(part * SW_NR + c) * M64 + i] = acc[c];
-  __syncthreads();
-  if (part == 0 && i < M)
-    for (int c = 0; c < nrhs; c++) {
-      double v = 0.;
-      for (int q = 0; q < P; q++) v += s_p[(q * SW_NR + c) * M64 + i];
-      apply_op(out + i + c * SW_MAX, v, op);
-    }
-  __syncthreads();
+  gemv_rows(M, [=](int i) { return RowOp{A + i, lda, K, x, out + i, op}; }, nrhs, s_p);
+}
+
+// pull `count` doubles at p towards this XCD's L2 (one load per 128-byte line) while the workgroup still waits for its
+// dependencies: the dependent chain of a node then runs on L2 hits.  The values are folded into `sink` (see keep()).
+__device__ __forceinline__ void touch(const double* p, size_t count, double& sink) {
+  if (p)
+    for (size_t e = (size_t)threadIdx.x * 16; e < count; e += (size_t)SW_T * 16) sink += hssk_gload(p, e);
+}
+__device__ __forceinline__ void keep(double sink, double* s_p) {
+  if (sink == 1.234567e300) s_p[0] = sink;   // never true: keeps the prefetch loads alive
 }
 
 // out[j] (op)= sum_{i < K} A[i + j lda] x[i],  j < N: columns contiguous.  Four adjacent lanes share a column (each
@@ -138,36 +163,79 @@ __device__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, cons
 // ---- forward ULV sweep ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs,
                                                              int* flags, int* err) {
-  HSSK_SHARED double s_f[SW_MAX * SW_NR];    // f, later z
-  HSSK_SHARED double s_y[SW_MAX * SW_NR];    // y, later the gathered children z
+  HSSK_SHARED double s_f[SW_MAX * SW_NR];    // f, later the block right-hand side of the substitution
+  HSSK_SHARED double s_y[SW_MAX * SW_NR];    // zc(permV[rv:]) first, then y
   HSSK_SHARED double s_a[SW_MAX * SW_NR];    // stacked children z (inner nodes)
-  HSSK_SHARED double s_t[SW_MAX * SW_NR];    // ft1, and the block right-hand side of the substitution
-  HSSK_SHARED double s_p[SW_T * SW_NR];      // gemv_n partials
+  HSSK_SHARED double s_t[SW_MAX * SW_NR];    // ft1 (root: block right-hand side)
+  HSSK_SHARED double s_z[SW_MAX * SW_NR];    // z
+  HSSK_SHARED double s_p[SW_T * SW_NR];      // gemv partials
+  HSSK_SHARED int s_piv[SW_MAX];
   const hssk_sweep_fwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
   const bool inner = p.B01 != nullptr;
+  // ---- before the dependencies arrive: permutations into registers, the node's blocks towards L2
+  int pu = 0, pv = 0;
+  if (p.LU) { if (tid < m) s_piv[tid] = p.piv[tid]; }
+  else {
+    if (tid < m) pu = p.permU[tid];
+    if (inner && tid < mv) pv = p.permV[tid];
+  }
+  if (p.wait0 >= 0 || p.wait1 >= 0) {
+    double sink = 0.;
+    if (inner) { touch(p.B01, (size_t)p.rU0 * p.rV1, sink); touch(p.B10, (size_t)p.rU1 * p.rV0, sink); }
+    if (p.LU) {
+      touch(p.LU, (size_t)m * m, sink);
+      touch(p.TinvL, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
+      touch(p.TinvU, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
+    } else {
+      if (inner) touch(p.XV, (size_t)rv * (mv - rv), sink);
+      touch(p.XU, (size_t)r * q, sink);
+      touch(p.Tinv, (size_t)((q + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
+      if (q > SW_NB) touch(p.Rlq, (size_t)m * q, sink);
+      touch(p.WQ, (size_t)r * q, sink);
+      touch(p.Vt0T, (size_t)rv * q, sink);
+    }
+    keep(sink, s_p);
+  }
   sweep_wait(flags, p.wait0, err);
   sweep_wait(flags, p.wait1, err);
   sweep_acquire();
-  // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] - [B01 z_1; B10 z_0] (inner)
+  // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] (inner); zc = stacked children z, s_y = its rows permV[rv:] (for V^H zc)
   for (int e = tid; e < m * nrhs; e += SW_T) {
     const int i = e % m, c = e / m;
-    s_f[i + c * SW_MAX] = hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
+    s_f[i + c * SW_MAX] = hssk_cload(p.fsrc, i + (size_t)c * p.ldf);
   }
   if (inner)
-    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = hssk_gload(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in);
+    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = hssk_cload(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in);
   __syncthreads();
   if (inner) {
-    gemv_n(p.B01, max(p.rU0, 1), p.rU0, p.rV1, s_a + p.rV0, s_f, nrhs, OP_SUB, s_p);
-    gemv_n(p.B10, max(p.rU1, 1), p.rU1, p.rV0, s_a, s_f + p.rU0, nrhs, OP_SUB, s_p);
+    const bool zpart = !p.LU && rv > 0;
+    if (zpart) {
+      // s_z (= s_t2) <- zc(permV[0:rv]);  s_y <- zc(permV[rv:])
+      if (tid < mv)
+        for (int c = 0; c < nrhs; c++) {
+          const double v = s_a[pv + c * SW_MAX];
+          if (tid < rv) s_z[tid + c * SW_MAX] = v;
+          else s_y[(tid - rv) + c * SW_MAX] = v;
+        }
+      __syncthreads();
+    }
+    // one pass: f(0:rU0) -= B01 zc(rV0:), f(rU0:) -= B10 zc(0:rV0)   and   z += XV zc(permV[rv:])   (XV is rv x (mv - rv))
+    const int mz = (zpart && mv > rv) ? rv : 0;
+    const int rU0 = p.rU0;
+    gemv_rows(m + mz, [=](int i) {
+      if (i < rU0) return RowOp{p.B01 + i, max(rU0, 1), p.rV1, s_a + p.rV0, s_f + i, OP_SUB};
+      if (i < m) return RowOp{p.B10 + (i - rU0), max(p.rU1, 1), p.rV0, s_a, s_f + i, OP_SUB};
+      return RowOp{p.XV + (i - m), rv, mv - rv, s_y, s_z + (i - m), OP_ADD};
+    }, nrhs, s_p);
   }
   if (p.LU) {
     // ---- root: x = U^{-1} L^{-1} P f   (DenseMatrix::solve / getrs, solve.hpp:133-135), block substitution with the
     // inverted 64 x 64 diagonal blocks
     if (tid < nrhs)
       for (int i = 0; i < m; i++) {
-        const int pi = p.piv[i];
+        const int pi = s_piv[i];
         if (pi != i) { const double a = s_f[i + tid * SW_MAX]; s_f[i + tid * SW_MAX] = s_f[pi + tid * SW_MAX]; s_f[pi + tid * SW_MAX] = a; }
       }
     __syncthreads();
@@ -198,13 +266,15 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
     sweep_publish(flags, blockIdx.x, p.consumers);
     return;
   }
-  // ---- ft1 = f(perm[0:r]), y = f(perm[r:])
-  for (int e = tid; e < m * nrhs; e += SW_T) {
-    const int k = e % m, c = e / m;
-    const double v = s_f[p.permU[k] + c * SW_MAX];
-    if (k < r) s_t[k + c * SW_MAX] = v;
-    else s_y[(k - r) + c * SW_MAX] = v;
-  }
+  // ---- ft1 = f(perm[0:r]) -> s_t, y = f(perm[r:]) -> s_y
+  if (tid < m)
+    for (int c = 0; c < nrhs; c++) {
+      const double v = s_f[pu + c * SW_MAX];
+      if (tid < r) s_t[tid + c * SW_MAX] = v;
+      else s_y[(tid - r) + c * SW_MAX] = v;
+    }
+  if (!inner)
+    for (int e = tid; e < rv * nrhs; e += SW_T) s_z[(e % rv) + (e / rv) * SW_MAX] = 0.;
   __syncthreads();
   if (q > 0) {
     // ---- y -= X^T ft1   (X is r x q, column k contiguous)
@@ -224,28 +294,14 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
       }
     }
     for (int e = tid; e < q * nrhs; e += SW_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * SW_MAX]);
-    // ---- ft1 -= W1 (Q~(:, 0:q) y) = WQ y
-    if (r > 0) gemv_n(p.WQ, r, r, q, s_y, s_t, nrhs, OP_SUB, s_p);
+    // ---- one pass over [WQ; Vt0^T] (both (.) x q, rows contiguous):  ft1 -= WQ y   and   z += Vt0^T y
+    gemv_rows(r + rv, [=](int i) {
+      if (i < r) return RowOp{p.WQ + i, r, q, s_y, s_t + i, OP_SUB};
+      return RowOp{p.Vt0T + (i - r), rv, q, s_y, s_z + (i - r), OP_ADD};
+    }, nrhs, s_p);
   }
-  for (int e = tid; e < r * nrhs; e += SW_T) hssk_gstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * SW_MAX]);
-  // ---- z = V^H [z_0; z_1] + Vt0^T y   (leaf: Vt0^T y)
-  if (rv > 0) {
-    for (int e = tid; e < rv * nrhs; e += SW_T) s_f[(e % rv) + (e / rv) * SW_MAX] = 0.;
-    __syncthreads();
-    if (q > 0) gemv_t(p.Vt0, q, q, rv, s_y, s_f, nrhs, OP_SET);
-    if (inner) {
-      // z(k) += zc(permV[k]) + sum_j XV(k, j) zc(permV[rv + j])   (XV is rv x (mv - rv), rows contiguous)
-      for (int e = tid; e < mv * nrhs; e += SW_T) {
-        const int k = e % mv, c = e / mv;
-        const double v = s_a[p.permV[k] + c * SW_MAX];
-        if (k < rv) s_f[k + c * SW_MAX] += v;
-        else s_y[(k - rv) + c * SW_MAX] = v;
-      }
-      __syncthreads();
-      if (mv > rv) gemv_n(p.XV, rv, rv, mv - rv, s_y, s_f, nrhs, OP_ADD, s_p);
-    }
-    for (int e = tid; e < rv * nrhs; e += SW_T) hssk_gstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_f[(e % rv) + (e / rv) * SW_MAX]);
-  }
+  for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * SW_MAX]);
+  for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * SW_MAX]);
   sweep_publish(flags, blockIdx.x, p.consumers);
 }
 
@@ -258,17 +314,22 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
   const hssk_sweep_bwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r;
-  // y does not depend on the parent: it is in LDS before the wait is over
+  // the parent-independent part first: s_o = Q~(:, 0:q) y; Q~(:, q:) towards L2
   for (int e = tid; e < q * nrhs; e += SW_T) s_v[(e % q) + (e / q) * SW_MAX] = hssk_gload(p.y, (e % q) + (size_t)(e / q) * q);
-  sweep_wait(flags, p.wait0, err);
-  sweep_acquire();
-  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = hssk_gload(p.xpart, (e % r) + (size_t)(e / r) * p.ldx);
   __syncthreads();
   if (q > 0) {
-    gemv_n(p.Qt, m, m, m, s_v, s_o, nrhs, OP_SET, s_p);
-    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_o[(e % m) + (e / m) * SW_MAX]);
+    gemv_n(p.Qt, m, m, q, s_v, s_o, nrhs, OP_SET, s_p);
+    if (p.wait0 >= 0) { double sink = 0.; touch(p.Qt + (size_t)q * m, (size_t)m * r, sink); keep(sink, s_p); }
+  }
+  sweep_wait(flags, p.wait0, err);
+  sweep_acquire();
+  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = hssk_cload(p.xpart, (e % r) + (size_t)(e / r) * p.ldx);
+  __syncthreads();
+  if (q > 0) {
+    if (r > 0) gemv_n(p.Qt + (size_t)q * m, m, m, r, s_v + q, s_o, nrhs, OP_ADD, s_p);
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_o[(e % m) + (e / m) * SW_MAX]);
   } else {
-    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * SW_MAX]);
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * SW_MAX]);
   }
   sweep_publish(flags, blockIdx.x, p.consumers);
 }
@@ -286,23 +347,27 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
     // tmp1 = V^H src = src(perm[0:r]) + X src(perm[r:])   (X is r x (m - r), rows contiguous)
     const hssk_apply_up_desc p = ups[blockIdx.x];
     const int m = p.m, r = p.r;
+    const int pk = tid < m ? p.perm[tid] : 0;
+    if (p.wait0 >= 0 || p.wait1 >= 0) { double sink = 0.; touch(p.X, (size_t)r * (m - r), sink); keep(sink, s_p); }
     sweep_wait(flags, p.wait0, err);
     sweep_wait(flags, p.wait1, err);
     sweep_acquire();
-    for (int e = tid; e < m * nrhs; e += SW_T) {
-      const int k = e % m, c = e / m;
-      const double v = hssk_gload(p.src, p.perm[k] + (size_t)c * p.lds);
-      if (k < r) s_o[k + c * SW_MAX] = v;
-      else s_g[(k - r) + c * SW_MAX] = v;
-    }
+    if (tid < m)
+      for (int c = 0; c < nrhs; c++) {
+        const double v = hssk_cload(p.src, pk + (size_t)c * p.lds);
+        if (tid < r) s_o[tid + c * SW_MAX] = v;
+        else s_g[(tid - r) + c * SW_MAX] = v;
+      }
     __syncthreads();
     if (m > r && r > 0) gemv_n(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p);
-    for (int e = tid; e < r * nrhs; e += SW_T) hssk_gstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
+    for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
     sweep_publish(flags, blockIdx.x, p.consumers);
     return;
   }
   const hssk_apply_down_desc p = downs[blockIdx.x - nup];
   const int mo = p.mo, ro = p.ro;
+  const bool expand = p.tmp2 && ro > 0;
+  const int pk = (expand && tid < mo) ? p.perm[tid] : 0;
   if (p.D) {
     // ---- leaf: y = op(D) x + beta y + U tmp2.  op(D) x does not depend on the tree: it runs before the wait.
     const int m = p.m;
@@ -316,38 +381,46 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
     }
   } else {
     // ---- inner: t = [B01 t1_1; B10 t1_0]  (transposed: [B10^T t1_1; B01^T t1_0]); t1 = the children's up-sweep results
+    {
+      double sink = 0.;
+      touch(p.B01, (size_t)(p.trans ? p.ri_a * p.ro_b : p.ro_a * p.ri_b), sink);
+      touch(p.B10, (size_t)(p.trans ? p.ri_b * p.ro_a : p.ro_b * p.ri_a), sink);
+      keep(sink, s_p);
+    }
     sweep_wait(flags, p.wait1, err);
     sweep_wait(flags, p.wait2, err);
     sweep_acquire();
-    const int nt1 = p.ri_a + p.ri_b;
-    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = hssk_gload(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1);
-    for (int e = tid; e < (p.ro_a + p.ro_b) * nrhs; e += SW_T) s_o[(e % (p.ro_a + p.ro_b)) + (e / (p.ro_a + p.ro_b)) * SW_MAX] = 0.;
+    const int nt1 = p.ri_a + p.ri_b, nto = p.ro_a + p.ro_b;
+    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = hssk_cload(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1);
+    for (int e = tid; e < nto * nrhs; e += SW_T) s_o[(e % nto) + (e / nto) * SW_MAX] = 0.;
     __syncthreads();
-    if (!p.trans) {   // B01 is ro_a x ri_b, B10 is ro_b x ri_a
-      if (p.ro_a > 0 && p.ri_b > 0) gemv_n(p.B01, p.ro_a, p.ro_a, p.ri_b, s_x + p.ri_a, s_o, nrhs, OP_SET, s_p);
-      if (p.ro_b > 0 && p.ri_a > 0) gemv_n(p.B10, p.ro_b, p.ro_b, p.ri_a, s_x, s_o + p.ro_a, nrhs, OP_SET, s_p);
+    if (!p.trans) {   // B01 is ro_a x ri_b, B10 is ro_b x ri_a: one pass over the stacked rows
+      const int ro_a = p.ro_a;
+      gemv_rows(nto, [=](int i) {
+        if (i < ro_a) return RowOp{p.B01 + i, max(ro_a, 1), p.ri_b, s_x + p.ri_a, s_o + i, OP_SET};
+        return RowOp{p.B10 + (i - ro_a), max(p.ro_b, 1), p.ri_a, s_x, s_o + i, OP_SET};
+      }, nrhs, s_p);
     } else {          // B10 is ri_b x ro_a, B01 is ri_a x ro_b
       if (p.ro_a > 0 && p.ri_b > 0) gemv_t(p.B10, p.ri_b, p.ri_b, p.ro_a, s_x + p.ri_a, s_o, nrhs, OP_SET);
       if (p.ro_b > 0 && p.ri_a > 0) gemv_t(p.B01, p.ri_a, p.ri_a, p.ro_b, s_x, s_o + p.ro_a, nrhs, OP_SET);
     }
   }
   // ---- + U tmp2:  out(perm[k]) += tmp2(k), k < ro ;  out(perm[ro + j]) += sum_k X(k, j) tmp2(k)   (X is ro x (mo - ro))
-  if (p.tmp2 && ro > 0) {
+  if (expand) {
+    if (p.wait0 >= 0) { double sink = 0.; touch(p.X, (size_t)ro * (mo - ro), sink); keep(sink, s_p); }
     sweep_wait(flags, p.wait0, err);
     sweep_acquire();
-    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = hssk_gload(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2);
+    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = hssk_cload(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2);
     __syncthreads();
     if (mo > ro) gemv_t(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET);
-    for (int e = tid; e < mo * nrhs; e += SW_T) {
-      const int k = e % mo, c = e / mo;
-      s_o[p.perm[k] + c * SW_MAX] += k < ro ? s_x[k + c * SW_MAX] : s_g[(k - ro) + c * SW_MAX];
-    }
+    if (tid < mo)
+      for (int c = 0; c < nrhs; c++) s_o[pk + c * SW_MAX] += tid < ro ? s_x[tid + c * SW_MAX] : s_g[(tid - ro) + c * SW_MAX];
     __syncthreads();
   } else if (p.wait0 >= 0) {
     sweep_wait(flags, p.wait0, err);   // nothing to read, but the producer counted this consumer
   }
   const int mout = p.D ? p.m : p.ro_a + p.ro_b;
-  for (int e = tid; e < mout * nrhs; e += SW_T) hssk_gstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
+  for (int e = tid; e < mout * nrhs; e += SW_T) hssk_cstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
   sweep_publish(flags, blockIdx.x, p.consumers);
 }
 

@@ -75,8 +75,9 @@ inline int hssk_flag_load(const int* f) { return __atomic_load_n(f, __ATOMIC_ACQ
 inline void hssk_flag_store(int* f, int v) { __atomic_store_n(f, v, __ATOMIC_RELEASE); }
 inline int hssk_flag_sub(int* f, int v) { return __atomic_fetch_sub(f, v, __ATOMIC_ACQ_REL); }
 inline void hssk_flag_raise(int* f) { __atomic_store_n(f, 1, __ATOMIC_RELAXED); }
-inline void hssk_fence_release() { __atomic_thread_fence(__ATOMIC_RELEASE); }
-inline void hssk_fence_acquire() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+inline double hssk_cload(const double* p, size_t off) { double v; __atomic_load((const double*)(p + off), &v, __ATOMIC_ACQUIRE); return v; }
+inline void hssk_cstore(double* p, size_t off, double v) { __atomic_store(p + off, &v, __ATOMIC_RELEASE); }
+inline void hssk_drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 void hssk_pause();   // emu_runtime.cpp: sched_yield
 
 #define HSSK_SHARED alignas(16) static thread_local
