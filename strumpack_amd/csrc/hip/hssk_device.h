@@ -50,12 +50,24 @@ __device__ __forceinline__ double hssk_wave_sum(double v) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
+// sum over each 16-lane DPP row (lanes 16 q .. 16 q + 15); every lane of a row ends up with its row's total.
+// The register QR / ID kernels keep one matrix column per row of lanes, so a column dot product is these four DPP steps.
+__device__ __forceinline__ double hssk_row_sum(double v) {
+  v += hssk_dpp_mov0<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += hssk_dpp_mov0<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += hssk_dpp_mov0<0x141, 0xF>(v);  // row_half_mirror
+  v += hssk_dpp_mov0<0x140, 0xF>(v);  // row_mirror
+  return v;
+}
 // value of `v` in lane `src` (src must be wave-uniform): v_readlane, no LDS crossbar
 __device__ __forceinline__ double hssk_bcast_lane(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int hssk_bcast_lane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// non-zero if `pred` holds in any lane of the wave
+__device__ __forceinline__ int hssk_any(int pred) { return __any(pred); }
 __device__ __forceinline__ double hssk_wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, hssk_shfl_xor(v, o));
@@ -91,6 +103,9 @@ __device__ __forceinline__ void hssk_cstore(double* p, size_t off, double v) {
 __device__ __forceinline__ void hssk_drain_stores() { __builtin_amdgcn_s_waitcnt(0); }
 __device__ __forceinline__ void hssk_pause() { __builtin_amdgcn_s_sleep(2); }
 
+// occupancy the register allocator should plan for (workgroups of N wave64 per SIMD): the full register budget of that
+// occupancy is then available to the kernel's register tile
+#define HSSK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define HSSK_SHARED __shared__ __attribute__((aligned(16)))
 
 // Global-memory accessors for pointers that arrive through a descriptor in memory: the compiler cannot infer

@@ -171,173 +171,186 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Register-resident variant (same idea as qr_reg_kernel in hssk_qr.hip): the d x m sample panel lives
-// in the VGPRs of one workgroup -- column j in wave j % NW (slot j / NW), row i in lane i % 64 (slot
-// i / 64).  Columns never move: pivoting only records the order (s_perm) and a per-wave "used" mask;
-// the panel is written back once, in pivoted order, for the triangular solve.  Per Householder step:
-// one LDS hop for the pivot search, one LDS broadcast of the reflector (both double-buffered, two
-// barriers), and per owned column RT fmas + a DPP reduction + RT fmas + the dlaqp2 norm down-date.
-// The global-memory kernel above streams the whole panel (300 KB at the leaf level, > L2 for a full
-// level) from HBM/MALL on every step; here the factorization touches no memory at all.
-// Capacity: d <= 64 RT, m <= NW CT.
+// Register-resident variant (same layout as qr_reg_kernel in hssk_qr.hip): the d x m sample panel lives in the VGPRs of
+// one workgroup, ONE COLUMN PER 16-LANE DPP ROW -- column j belongs to row-group g = j % NC (wave g / 4, lanes 16 (g % 4)
+// .. +15), slot j / NC, with NC = 4 NW groups per workgroup; row i sits in lane i % 16 of the group, register i / 16.
+// A column dot product is then RT fmas and four in-row DPP steps (hssk_row_sum), with every lane of the group holding the
+// result: no cross-row stages, no readlane, and a wave works on four columns at once.  (The first version spread a
+// column over all 64 lanes: 6 DPP stages + a readlane per column, ~3x the instructions per Householder step.)
+// Columns never move: pivoting only records the order (s_perm) and a per-lane "used" mask; the panel is written back
+// once, in pivoted order, for the triangular solve.  The step loop is unrolled over the register index of the pivot row
+// (k = 16 rk + lk), so R(k, j) is a statically indexed register.  Per Householder step: one LDS hop for the pivot search,
+// one LDS broadcast of the reflector (both double-buffered, two barriers), and per owned column 2 RT fmas, the row sum,
+// one in-group shuffle for R(k, j) and the dlaqp2 norm down-date.
+// Capacity: d <= 16 RT, m <= 4 NW CT.
 // ------------------------------------------------------------------------------------------------
 template <int RT, int CT, int NW>
-__global__ __launch_bounds__(NW * 64) void id_reg_kernel(const hssk_id_desc* __restrict__ descs) {
-  HSSK_SHARED double s_v[2 * 64 * RT];
-  HSSK_SHARED double s_vn1[NW * CT];
-  HSSK_SHARED double s_vn2[NW * CT];
+__global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_kernel(const hssk_id_desc* __restrict__ descs) {
+  constexpr int NC = NW * 4;
+  HSSK_SHARED double s_v[2 * 16 * RT];
+  HSSK_SHARED double s_vn1[NC * CT];
+  HSSK_SHARED double s_vn2[NC * CT];
   HSSK_SHARED double s_val[2 * NW];
   HSSK_SHARED int s_idx[2 * NW];
   HSSK_SHARED double s_tau[2];
   HSSK_SHARED double s_r00;
   HSSK_SHARED int s_stop;
-  HSSK_SHARED int s_perm[NW * CT];
-  HSSK_SHARED int s_pos[NW * CT];
+  HSSK_SHARED int s_perm[NC * CT];
+  HSSK_SHARED int s_pos[NC * CT];
   const hssk_id_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, sub = lane >> 4, grp = wave * 4 + sub;
   const int d = p.d, m = p.m, ld = p.ldw;
   const int kmax = d < m ? d : m;
   const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
   double a[CT][RT];
 #pragma unroll
   for (int c = 0; c < CT; c++) {
-    const int col = wave + NW * c;
+    const int col = grp + NC * c;
     double s = 0.;
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      const int row = lane + 64 * r;
+      const int row = l16 + 16 * r;
       a[c][r] = (row < d && col < m) ? p.W[row + (size_t)col * ld] : 0.;
       s += a[c][r] * a[c][r];
     }
-    s = hssk_wave_sum(s);
+    s = hssk_row_sum(s);
     // squared partial norms: dlaqp2's down-date  vn1 *= sqrt(1 - (R_kj/vn1)^2)  is  N1 -= R_kj^2 and its
     // cancellation guard  (1-(R/vn1)^2) (vn1/vn2)^2 <= sqrt(eps)  is  N1_new <= sqrt(eps) N2: no div / sqrt
-    if (lane == 0 && col < m) { s_vn1[col] = s; s_vn2[col] = s; }
+    if (l16 == 0 && col < m) { s_vn1[col] = s; s_vn2[col] = s; }
   }
   if (tid == 0) { s_stop = 0; s_r00 = 0.; }
-  for (int j = tid; j < NW * CT; j += NW * 64) s_pos[j] = -1;
-  unsigned used = 0;  // bit c: local column slot c has been chosen as a pivot (wave-uniform)
+  for (int j = tid; j < NC * CT; j += NW * 64) s_pos[j] = -1;
+  unsigned used = 0;  // bit c: this lane's column of slot c has been chosen as a pivot (uniform over the 16 lanes of a group)
   __syncthreads();
 
   int rank = kmax;
-  for (int k = 0; k < kmax; k++) {
-    const int pb = k & 1;
-    double* sv = s_v + pb * 64 * RT;
-    const int lk = k & 63, rk = k >> 6;
-    // ---- 1. pivot: first arg max over the unused columns
-    {
-      double bv = -1.;
-      int bi = 0x7fffffff;
+  bool done = false;
+#pragma clang loop unroll(full)
+  for (int rk = 0; rk < RT; rk++) {
+    const int nlk = done ? 0 : min(16, kmax - 16 * rk);
+    for (int lk = 0; lk < nlk; lk++) {
+      const int k = rk * 16 + lk;
+      const int pb = k & 1;
+      double* sv = s_v + pb * 16 * RT;
+      // ---- 1. pivot: first arg max over the unused columns
+      {
+        double bv = -1.;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          const int col = grp + NC * c;
+          if (col < m && !((used >> c) & 1u)) {
+            const double v = s_vn1[col];
+            if (v > bv) { bv = v; bi = col; }  // the columns of a group are visited in increasing order
+          }
+        }
+        // best of the wave's four groups (bv / bi are uniform over the 16 lanes of a group)
+        double wv = hssk_bcast_lane(bv, 0);
+        int wi = hssk_bcast_lane_i(bi, 0);
+#pragma unroll
+        for (int q = 1; q < 4; q++) {
+          const double v = hssk_bcast_lane(bv, 16 * q);
+          const int ix = hssk_bcast_lane_i(bi, 16 * q);
+          if (v > wv || (v == wv && ix < wi)) { wv = v; wi = ix; }
+        }
+        if (lane == 0) { s_val[pb * NW + wave] = wv; s_idx[pb * NW + wave] = wi; }
+      }
+      __syncthreads();
+      double gv = s_val[pb * NW];
+      int pcol = s_idx[pb * NW];
+#pragma unroll
+      for (int w = 1; w < NW; w++) {
+        const double v = s_val[pb * NW + w];
+        const int ix = s_idx[pb * NW + w];
+        if (v > gv || (v == gv && ix < pcol)) { gv = v; pcol = ix; }
+      }
+      const int pg = pcol % NC, cp = pcol / NC, wp = pg >> 2, sp = pg & 3;
+      // ---- 2. reflector from the pivot column (dlarfg): the owner wave computes, the owner group commits
+      // (static loop over the slots: the pivot column is used in place, no register copy)
+      if (wave == wp) {
+        const bool own = sub == sp;
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+          if (c == cp) {
+            double s = 0.;
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+              const int row = l16 + 16 * r;
+              if (row > k && row < d) s += a[c][r] * a[c][r];
+            }
+            const double alpha = hssk_shfl(a[c][rk], (lane & 48) | lk);
+            s = hssk_row_sum(s);
+            double tau = 0., beta = alpha, scal = 1.;
+            if (s != 0.) {
+              double nrm = sqrt(alpha * alpha + s);
+              beta = alpha >= 0. ? -nrm : nrm;
+              tau = (beta - alpha) / beta;
+              scal = 1. / (alpha - beta);
+            }
+            if (own) {
+#pragma unroll
+              for (int r = 0; r < RT; r++) {
+                const int row = l16 + 16 * r;
+                if (row > k && row < d) a[c][r] *= scal;
+                sv[row] = row > k ? a[c][r] : (row == k ? 1. : 0.);
+                if (row == k) a[c][r] = beta;
+              }
+              used |= 1u << c;
+              if (l16 == 0) {
+                s_tau[pb] = tau;
+                s_perm[k] = pcol;
+                const double ab = fabs(beta);
+                if (k == 0) s_r00 = ab;
+                const double r00 = (k == 0) ? ab : s_r00;
+                // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
+                if ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) s_stop = 1;
+              }
+            }
+          }
+      }
+      __syncthreads();
+      if (s_stop) { rank = k; done = true; break; }
+      const double tau = s_tau[pb];
+      // ---- 3. apply H to the unused columns and down-date their norms (dlaqp2)
+      double vr[RT];
+#pragma unroll
+      for (int r = 0; r < RT; r++) vr[r] = sv[l16 + 16 * r];
 #pragma unroll
       for (int c = 0; c < CT; c++) {
-        const int col = wave + NW * c;
-        if (col < m && !((used >> c) & 1u)) {
-          const double v = s_vn1[col];
-          if (v > bv) { bv = v; bi = col; }  // columns of a wave are visited in increasing order
-        }
-      }
-      if (lane == 0) { s_val[pb * NW + wave] = bv; s_idx[pb * NW + wave] = bi; }
-    }
-    __syncthreads();
-    double gv = s_val[pb * NW];
-    int pcol = s_idx[pb * NW];
-#pragma unroll
-    for (int w = 1; w < NW; w++) {
-      const double v = s_val[pb * NW + w];
-      const int ix = s_idx[pb * NW + w];
-      if (v > gv || (v == gv && ix < pcol)) { gv = v; pcol = ix; }
-    }
-    const int wp = pcol % NW, cp = pcol / NW;
-    // ---- 2. reflector from the pivot column (dlarfg), owner wave only
-    if (wave == wp) {
-      double oc[RT];
-#pragma unroll
-      for (int r = 0; r < RT; r++) oc[r] = 0.;
-#pragma unroll
-      for (int c = 0; c < CT; c++)
-        if (c == cp) {
-#pragma unroll
-          for (int r = 0; r < RT; r++) oc[r] = a[c][r];
-        }
-      double s = 0., av = 0.;
-#pragma unroll
-      for (int r = 0; r < RT; r++) {
-        const int row = lane + 64 * r;
-        if (row > k && row < d) s += oc[r] * oc[r];
-        if (r == rk) av = oc[r];
-      }
-      const double alpha = hssk_bcast_lane(av, lk);
-      s = hssk_wave_sum(s);
-      double tau = 0., beta = alpha, scal = 1.;
-      if (s != 0.) {
-        double nrm = sqrt(alpha * alpha + s);
-        beta = alpha >= 0. ? -nrm : nrm;
-        tau = (beta - alpha) / beta;
-        scal = 1. / (alpha - beta);
-      }
-#pragma unroll
-      for (int r = 0; r < RT; r++) {
-        const int row = lane + 64 * r;
-        if (row > k && row < d) oc[r] *= scal;
-        sv[row] = row > k ? oc[r] : (row == k ? 1. : 0.);
-        if (row == k) oc[r] = beta;
-      }
-#pragma unroll
-      for (int c = 0; c < CT; c++)
-        if (c == cp) {
-#pragma unroll
-          for (int r = 0; r < RT; r++) a[c][r] = oc[r];
-        }
-      used |= 1u << cp;
-      if (lane == 0) {
-        s_tau[pb] = tau;
-        s_perm[k] = pcol;
-        const double ab = fabs(beta);
-        if (k == 0) s_r00 = ab;
-        const double r00 = (k == 0) ? ab : s_r00;
-        // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
-        if ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) s_stop = 1;
-      }
-    }
-    __syncthreads();
-    if (s_stop) { rank = k; break; }
-    const double tau = s_tau[pb];
-    // ---- 3. apply H to the unused columns and down-date their norms (dlaqp2)
-    double vr[RT];
-#pragma unroll
-    for (int r = 0; r < RT; r++) vr[r] = sv[lane + 64 * r];
-#pragma unroll
-    for (int c = 0; c < CT; c++) {
-      const int col = wave + NW * c;
-      if (col < m && !((used >> c) & 1u)) {
+        const int col = grp + NC * c;
+        const bool act = col < m && !((used >> c) & 1u);
         double dot = 0.;
 #pragma unroll
         for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
-        // wave-shared scalars are read before the collectives; lane 0 rewrites them afterwards
-        const double n1 = s_vn1[col], n2 = s_vn2[col];
-        dot = hssk_wave_sum(dot) * tau;
-        double sel = 0.;
+        dot = hssk_row_sum(dot) * tau;
+        if (act) {
 #pragma unroll
-        for (int r = 0; r < RT; r++) {
-          a[c][r] -= dot * vr[r];
-          if (r == rk) sel = a[c][r];
+          for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
         }
-        const double newk = hssk_bcast_lane(sel, lk);  // R(k, col)
-        double newn1 = n1 - newk * newk;
-        newn1 = newn1 > 0. ? newn1 : 0.;
-        const int recompute = (n1 != 0.) && (newn1 <= tol3z * n2);
-        if (recompute) {
+        const double newk = hssk_shfl(a[c][rk], (lane & 48) | lk);  // R(k, col)
+        double n1 = 0., n2 = 0., newn1 = 0.;
+        int recompute = 0;
+        if (act) {
+          n1 = s_vn1[col]; n2 = s_vn2[col];
+          newn1 = n1 - newk * newk;
+          newn1 = newn1 > 0. ? newn1 : 0.;
+          recompute = (n1 != 0.) && (newn1 <= tol3z * n2);
+        }
+        if (hssk_any(recompute)) {
           double s2 = 0.;
 #pragma unroll
           for (int r = 0; r < RT; r++) {
-            const int row = lane + 64 * r;
+            const int row = l16 + 16 * r;
             if (row > k && row < d) s2 += a[c][r] * a[c][r];
           }
-          s2 = hssk_wave_sum(s2);
-          newn1 = s2;
-          if (lane == 0) s_vn2[col] = newn1;
+          s2 = hssk_row_sum(s2);
+          if (recompute) {
+            newn1 = s2;
+            if (l16 == 0) s_vn2[col] = newn1;
+          }
         }
-        if (lane == 0) s_vn1[col] = newn1;
+        if (act && l16 == 0) s_vn1[col] = newn1;
       }
     }
   }
@@ -353,21 +366,21 @@ __global__ __launch_bounds__(NW * 64) void id_reg_kernel(const hssk_id_desc* __r
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < CT; c++) {
-    const int col = wave + NW * c;
+    const int col = grp + NC * c;
     if (col < m) {
       const int pos = s_pos[col];
 #pragma unroll
       for (int r = 0; r < RT; r++) {
-        const int row = lane + 64 * r;
+        const int row = l16 + 16 * r;
         if (row < d) p.W[row + (size_t)pos * ld] = a[c][r];
       }
-      if (lane == 0) p.perm[pos] = col;
+      if (l16 == 0) p.perm[pos] = col;
     }
   }
   __syncthreads();
   // ---- X = R11^{-1} R12 in place.  rank <= 64: one column per wave, x(l) in lane l, R11 staged in
-  // LDS (reusing the reflector buffer is too small: separate array), each back-substitution step is
-  // one LDS row read + a DPP reduction.  Larger ranks: one column per thread from global memory.
+  // LDS, each back-substitution step is one LDS row read + a DPP reduction.  Larger ranks: one column per thread
+  // from global memory.
   double* __restrict__ W = p.W;
   if (rank <= 64) {
     HSSK_SHARED double s_R[64 * 65];
@@ -399,15 +412,18 @@ __global__ __launch_bounds__(NW * 64) void id_reg_kernel(const hssk_id_desc* __r
   if (tid == 0) *p.rank = rank;
 }
 
-template <int RT, int CT>
+template <int RT, int CT, int NW>
 void launch_id_reg(hssk_ctx* ctx, const hssk_id_desc* dd, int count) {
-  HSSK_LAUNCH((id_reg_kernel<RT, CT, 16>), dim3((unsigned)count), dim3(1024), 0, ctx->stream, dd);
+  HSSK_LAUNCH((id_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
 }
+// panels of d <= 16 RT sample rows and up to 64 / 128 / 224 columns; 8-wave workgroups (two waves per SIMD: 256 VGPRs
+// for the register tile and the unrolled step loop; 16 waves with half the slots issue the same number of instructions
+// per SIMD and step)
 template <int RT>
 bool launch_id_reg_ct(hssk_ctx* ctx, const hssk_id_desc* dd, int count, int mmax) {
-  if (mmax <= 64) launch_id_reg<RT, 4>(ctx, dd, count);
-  else if (mmax <= 128) launch_id_reg<RT, 8>(ctx, dd, count);
-  else if (mmax <= 208) launch_id_reg<RT, 13>(ctx, dd, count);
+  if (mmax <= 64) launch_id_reg<RT, 2, 8>(ctx, dd, count);
+  else if (mmax <= 128) launch_id_reg<RT, 4, 8>(ctx, dd, count);
+  else if (mmax <= 224) launch_id_reg<RT, 7, 8>(ctx, dd, count);
   else return false;
   return true;
 }
@@ -609,10 +625,10 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
   for (int i = 0; i < count; i++) { dmax = std::max(dmax, descs[i].d); mmax = std::max(mmax, descs[i].m); }
   auto* dd = (const hssk_id_desc*)ctx->stage(descs, sizeof(*descs) * count);
   bool done = false;
-  if (dmax <= 64) done = launch_id_reg_ct<1>(ctx, dd, count, mmax);
-  else if (dmax <= 128) done = launch_id_reg_ct<2>(ctx, dd, count, mmax);
-  else if (dmax <= 192) done = launch_id_reg_ct<3>(ctx, dd, count, mmax);
-  else if (dmax <= 256) done = launch_id_reg_ct<4>(ctx, dd, count, mmax);
+  if (dmax <= 64) done = launch_id_reg_ct<4>(ctx, dd, count, mmax);
+  else if (dmax <= 128) done = launch_id_reg_ct<8>(ctx, dd, count, mmax);
+  else if (dmax <= 192) done = launch_id_reg_ct<12>(ctx, dd, count, mmax);
+  else if (dmax <= 256) done = launch_id_reg_ct<16>(ctx, dd, count, mmax);
   if (!done) {
     // few large panels: spread every Householder step over the chip; many small ones: one workgroup each
     static const bool force_wide = [] { const char* e = std::getenv("HSSK_ID_WIDE"); return e && e[0] == '1'; }();

@@ -101,21 +101,25 @@ __global__ __launch_bounds__(QR_THREADS) void qr_kernel(const hssk_qr_desc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Register-resident variant: the whole panel lives in the VGPRs of one 1024-thread workgroup
-// (NW = 16 wave64; 8 for the widest panels): column j belongs to wave j % NW (local slot j / NW), row i to lane i % 64 (slot
-// i / 64), so a lane holds a[CT][RT] doubles.  A Householder step costs one LDS broadcast of the
-// reflector (double-buffered: one barrier per step) and, per owned column, RT fmas + a shuffle
-// reduction + RT fmas -- no global or L2 traffic inside the factorization, which is what bounds the
-// global-memory kernel above (the 200 KB leaf panels of a level do not fit L2, every step re-streams
-// them).  Q is formed in place like LAPACK dorg2r.  Capacity: rows <= 64 RT, max(cols, nq) <= NW CT.
+// Register-resident variant: the whole panel lives in the VGPRs of one workgroup of NW wave64, ONE COLUMN PER 16-LANE
+// DPP ROW: column j belongs to row-group g = j % NC (wave g / 4, lanes 16 (g % 4) .. +15), slot j / NC, NC = 4 NW; row i
+// sits in lane i % 16 of the group, register i / 16, so a lane holds a[CT][RT] doubles.  A Householder step costs one LDS
+// broadcast of the reflector (double-buffered: one barrier per step) and, per owned column, RT fmas + four in-row DPP
+// steps (hssk_row_sum: every lane of the group ends up with the dot product, no readlane) + RT fmas, four columns per
+// wave at a time -- no global or L2 traffic inside the factorization, which is what bounds the global-memory kernel
+// above.  (The first version spread a column over all 64 lanes: 6 DPP stages + a readlane per column.)  The step loop is
+// unrolled over the slot and the register index of the diagonal row, so every register access is static.
+// Capacity: rows <= 16 RT, cols <= 4 NW CT.
 // ------------------------------------------------------------------------------------------------
 template <int RT, int CT, int NW>
-__global__ __launch_bounds__(NW * 64) void qr_reg_kernel(const hssk_qr_desc* __restrict__ descs) {
-  HSSK_SHARED double s_v[2 * 64 * RT];
-  HSSK_SHARED double s_tau[NW * CT];
+__global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_kernel(const hssk_qr_desc* __restrict__ descs) {
+  constexpr int NC = NW * 4, SPC = NC / 16;
+  HSSK_SHARED double s_v[2 * 16 * RT];
+  HSSK_SHARED double s_tau[NC * CT];
   HSSK_SHARED double s_rd[2];
   const hssk_qr_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, sub = lane >> 4, grp = wave * 4 + sub;
   const int rows = p.rows, cols = p.cols;
   const int kmax = rows < cols ? rows : cols;
   double a[CT][RT];
@@ -123,66 +127,71 @@ __global__ __launch_bounds__(NW * 64) void qr_reg_kernel(const hssk_qr_desc* __r
   for (int c = 0; c < CT; c++)
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      const int row = lane + 64 * r, col = wave + NW * c;
+      const int row = l16 + 16 * r, col = grp + NC * c;
       a[c][r] = (row < rows && col < cols) ? p.A[row + (size_t)col * p.lda] : 0.;
     }
-  // ---- factorization.  Step k = kc * NW + kw is owned by wave kw, local column slot kc; the slot
-  // loop is unrolled at compile time so that every access to the register tile is statically indexed
+  // ---- factorization.  Step k = 16 rk + lk is owned by group g = k % NC of slot kc = k / NC
 #pragma clang loop unroll(full)
   for (int kc = 0; kc < CT; kc++) {
-    for (int kw = 0; kw < NW; kw++) {
-      const int k = kc * NW + kw;
-      if (k >= kmax) break;
-      double* sv = s_v + (k & 1) * 64 * RT;
-      const int lk = k & 63, rk = k >> 6;
-      if (wave == kw) {
-        double s = 0., av = 0.;
+#pragma clang loop unroll(full)
+    for (int rq = 0; rq < SPC; rq++) {
+      const int rk = kc * SPC + rq < RT ? kc * SPC + rq : RT - 1;   // (static; slots beyond the last row register run no step)
+      const int nlk = kc * SPC + rq < RT ? min(16, kmax - 16 * rk) : 0;
+      for (int lk = 0; lk < nlk; lk++) {
+        const int k = 16 * rk + lk;
+        const int g = rq * 16 + lk, kw = g >> 2, ks = g & 3;
+        double* sv = s_v + (k & 1) * 16 * RT;
+        if (wave == kw) {
+          const bool own = sub == ks;
+          double s = 0.;
 #pragma unroll
-        for (int r = 0; r < RT; r++) {
-          const int row = lane + 64 * r;
-          if (row > k && row < rows) s += a[kc][r] * a[kc][r];
-          if (r == rk) av = a[kc][r];
-        }
-        const double alpha = hssk_shfl(av, lk);
-        s = hssk_wave_sum(s);
-        double tau = 0., beta = alpha, scal = 1.;
-        if (s != 0.) {
-          double nrm = sqrt(alpha * alpha + s);
-          beta = alpha >= 0. ? -nrm : nrm;
-          tau = (beta - alpha) / beta;
-          scal = 1. / (alpha - beta);
-        }
+          for (int r = 0; r < RT; r++) {
+            const int row = l16 + 16 * r;
+            if (row > k && row < rows) s += a[kc][r] * a[kc][r];
+          }
+          const double alpha = hssk_shfl(a[kc][rk], (lane & 48) | lk);
+          s = hssk_row_sum(s);
+          double tau = 0., beta = alpha, scal = 1.;
+          if (s != 0.) {
+            double nrm = sqrt(alpha * alpha + s);
+            beta = alpha >= 0. ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scal = 1. / (alpha - beta);
+          }
+          if (own) {
 #pragma unroll
-        for (int r = 0; r < RT; r++) {
-          const int row = lane + 64 * r;
-          if (row > k && row < rows) a[kc][r] *= scal;
-          sv[row] = row > k ? a[kc][r] : (row == k ? 1. : 0.);
-          if (row == k) a[kc][r] = beta;
+            for (int r = 0; r < RT; r++) {
+              const int row = l16 + 16 * r;
+              if (row > k && row < rows) a[kc][r] *= scal;
+              sv[row] = row > k ? a[kc][r] : (row == k ? 1. : 0.);
+              if (row == k) a[kc][r] = beta;
+            }
+            if (l16 == 0) {
+              s_tau[k] = tau;
+              const double ab = fabs(beta);
+              if (k == 0) { s_rd[0] = ab; s_rd[1] = ab; }
+              else { if (ab > s_rd[0]) s_rd[0] = ab; if (ab < s_rd[1]) s_rd[1] = ab; }
+            }
+          }
         }
-        if (lane == 0) {
-          s_tau[k] = tau;
-          const double ab = fabs(beta);
-          if (k == 0) { s_rd[0] = ab; s_rd[1] = ab; }
-          else { if (ab > s_rd[0]) s_rd[0] = ab; if (ab < s_rd[1]) s_rd[1] = ab; }
-        }
-      }
-      __syncthreads();
-      const double tau = s_tau[k];
-      if (tau != 0.) {
-        double vr[RT];
+        __syncthreads();
+        const double tau = s_tau[k];
+        if (tau != 0.) {
+          double vr[RT];
 #pragma unroll
-        for (int r = 0; r < RT; r++) vr[r] = sv[lane + 64 * r];
+          for (int r = 0; r < RT; r++) vr[r] = sv[l16 + 16 * r];
 #pragma unroll
-        for (int c = kc; c < CT; c++) {
-          const int col = wave + NW * c;
-          // slots above kc hold only columns > k; in slot kc the waves after the owner do
-          if ((c > kc || wave > kw) && col < cols) {
+          for (int c = kc; c < CT; c++) {
+            const int col = grp + NC * c;
+            const bool act = col > k && col < cols;
             double dot = 0.;
 #pragma unroll
             for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
-            dot = hssk_wave_sum(dot) * tau;
+            dot = hssk_row_sum(dot) * tau;
+            if (act) {
 #pragma unroll
-            for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
+              for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
+            }
           }
         }
       }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void qr_reg_kernel(const hssk_qr_desc* __r
   for (int c = 0; c < CT; c++)
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      const int row = lane + 64 * r, col = wave + NW * c;
+      const int row = l16 + 16 * r, col = grp + NC * c;
       if (row < rows && col < cols) p.A[row + (size_t)col * p.lda] = a[c][r];
     }
   __syncthreads();
@@ -201,10 +210,9 @@ __global__ __launch_bounds__(NW * 64) void qr_reg_kernel(const hssk_qr_desc* __r
   if (p.rdiag && tid == 0) { p.rdiag[0] = kmax ? s_rd[0] : 0.; p.rdiag[1] = kmax ? s_rd[1] : 0.; }
 }
 
-// Q(:, j0 : j0 + 16 CT) = H_0 ... H_{kmax-1} I(:, same columns): every wave owns CT columns in
-// registers and applies the reflectors (read from the factored panel, L1/L2 hits) on its own --
-// no LDS, no barriers.  H_k leaves column j untouched for k > j, so the sweep starts at the last
-// column of the block.
+// Q(:, j0 : j0 + 64 CT) = H_0 ... H_{kmax-1} I(:, same columns): every 16-lane group owns CT columns in registers (same
+// layout as above) and applies the reflectors (read from the factored panel, L1/L2 hits) on its own -- no LDS, no
+// barriers.  H_k leaves column j untouched for k > j, so the sweep starts at the last column of the block.
 struct QBlock {
   int prob, block;
 };
@@ -214,17 +222,18 @@ __global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __r
   const QBlock w = work[blockIdx.x];
   const hssk_qr_desc p = descs[w.prob];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, grp = wave * 4 + (lane >> 4);
   const int rows = p.rows, cols = p.cols, nq = p.nq;
   const int kmax = rows < cols ? rows : cols;
-  const int j0 = w.block * 16 * CT;
+  const int j0 = w.block * 64 * CT;
   const double* __restrict__ A = p.A;
   const double* __restrict__ taus = p.work;
   double a[CT][RT];
 #pragma unroll
   for (int c = 0; c < CT; c++)
 #pragma unroll
-    for (int r = 0; r < RT; r++) a[c][r] = (lane + 64 * r == j0 + wave + 16 * c) ? 1. : 0.;
-  int kstart = j0 + 16 * CT - 1;
+    for (int r = 0; r < RT; r++) a[c][r] = (l16 + 16 * r == j0 + grp + 64 * c) ? 1. : 0.;
+  int kstart = j0 + 64 * CT - 1;
   if (kstart > kmax - 1) kstart = kmax - 1;
   // reflector k-1 is fetched (L2) while reflector k is applied
   double vn[RT], taun = 0.;
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __r
     taun = k >= 0 ? taus[k] : 0.;
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      const int row = lane + 64 * r;
+      const int row = l16 + 16 * r;
       vn[r] = (k >= 0 && row > k && row < rows) ? A[row + (size_t)k * p.lda] : (row == k ? 1. : 0.);
     }
   };
@@ -246,12 +255,13 @@ __global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __r
     if (tau == 0.) continue;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      const int col = j0 + wave + 16 * c;
-      if (col >= k && col < nq) {
-        double dot = 0.;
+      const int col = j0 + grp + 64 * c;
+      const bool act = col >= k && col < nq;
+      double dot = 0.;
 #pragma unroll
-        for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
-        dot = hssk_wave_sum(dot) * tau;
+      for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
+      dot = hssk_row_sum(dot) * tau;
+      if (act) {
 #pragma unroll
         for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
       }
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __r
   for (int c = 0; c < CT; c++)
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      const int row = lane + 64 * r, col = j0 + wave + 16 * c;
+      const int row = l16 + 16 * r, col = j0 + grp + 64 * c;
       if (row < rows && col < nq) p.Q[row + (size_t)col * p.ldq] = a[c][r];
     }
 }
@@ -274,16 +284,23 @@ template <int RT, int CT>
 void launch_formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc* descs, int count) {
   std::vector<QBlock> blocks;
   for (int i = 0; i < count; i++)
-    for (int b = 0; b * 16 * CT < descs[i].nq; b++) blocks.push_back(QBlock{i, b});
+    for (int b = 0; b * 64 * CT < descs[i].nq; b++) blocks.push_back(QBlock{i, b});
   if (blocks.empty()) return;
   auto* dw = (const QBlock*)ctx->stage(blocks.data(), sizeof(QBlock) * blocks.size());
   HSSK_LAUNCH((formq_reg_kernel<RT, CT>), dim3((unsigned)blocks.size()), dim3(1024), 0, ctx->stream, dd, dw);
+}
+// Q of panels with up to 256 rows
+void formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc* descs, int count, int rmax) {
+  if (rmax <= 64) launch_formq_reg<4, 1>(ctx, dd, descs, count);
+  else if (rmax <= 128) launch_formq_reg<8, 1>(ctx, dd, descs, count);
+  else if (rmax <= 208) launch_formq_reg<13, 1>(ctx, dd, descs, count);
+  else launch_formq_reg<16, 1>(ctx, dd, descs, count);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Blocked path for panels beyond the register kernels (leaf size 512: W0^T is ~390 x 350, its Q 390 x 390).
 // Level-synchronous over the whole batch, QB columns at a time:
-//   1. qr_reg_kernel<8, 2, 16> factors the (rows - j0) x QB panel of every matrix in registers,
+//   1. qr_reg_kernel<32, 1, 8> factors the (rows - j0) x QB panel of every matrix in registers,
 //   2. larft_kernel builds the compact-WY pair of the panel, V (unit lower trapezoidal, explicit) and
 //      VT = V T  (T from the dlarft recurrence on V^T V, all in LDS), and folds the panel's max/min |R_ii|,
 //   3. two batched MFMA GEMMs apply H^T = I - V (VT)^T to the trailing columns: W = VT^T A2, A2 -= V W.
@@ -480,7 +497,7 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
     if (!pd.empty()) {
       auto* dp = (const hssk_qr_desc*)ctx->stage(pd.data(), sizeof(hssk_qr_desc) * pd.size());
       if (tall) HSSK_LAUNCH(qr_kernel, dim3((unsigned)pd.size()), dim3(QR_THREADS), 0, ctx->stream, dp, 0);   // Level-2 on a 32-column panel
-      else HSSK_LAUNCH((qr_reg_kernel<8, 2, 16>), dim3((unsigned)pd.size()), dim3(1024), 0, ctx->stream, dp);
+      else HSSK_LAUNCH((qr_reg_kernel<32, 1, 8>), dim3((unsigned)pd.size()), dim3(512), 0, ctx->stream, dp);
     }
     if (!lp.empty()) {
       auto* dl = (const QPanel*)ctx->stage(lp.data(), sizeof(QPanel) * lp.size());
@@ -542,23 +559,21 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
     cmax = std::max(cmax, descs[i].cols);
     qmax = std::max(qmax, descs[i].nq);
   }
-  if (force_blocked() || rmax > 256 || cmax > 208) {
+  // register-resident kernels when the largest panel of the batch fits (rows <= 16 RT, cols <= 4 NW CT; the register
+  // tile of the widest variant, 13 x 7 doubles per lane, needs the 256 VGPRs of an 8-wave workgroup)
+  if (force_blocked() || rmax > 256 || cmax > 224 || (rmax > 208 && cmax > 128)) {
     qr_blocked(ctx, descs, count, true);
     hssk_rt::check_launch();
     return 0;
   }
   auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  // register-resident kernels when the largest panel of the batch fits (rows <= 64 RT, cols <= 16 CT);
-  // Q is then formed by a second, barrier-free launch over blocks of 16 CT columns
-  if (rmax <= 64 && cmax <= 64) launch_qr_reg<1, 4, 16>(ctx, dd, count);
-  else if (rmax <= 128 && cmax <= 128) launch_qr_reg<2, 8, 16>(ctx, dd, count);
-  else if (cmax <= 128) launch_qr_reg<4, 8, 16>(ctx, dd, count);
-  else launch_qr_reg<4, 26, 8>(ctx, dd, count);   // rmax <= 256, cmax <= 208 (larger panels took the blocked path above)
-  if (qmax > 0) {
-    if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
-    else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
-    else launch_formq_reg<4, 8>(ctx, dd, descs, count);
-  }
+  if (rmax <= 64 && cmax <= 64) launch_qr_reg<4, 1, 16>(ctx, dd, count);
+  else if (rmax <= 128 && cmax <= 128) launch_qr_reg<8, 2, 16>(ctx, dd, count);
+  else if (cmax <= 128 && rmax <= 208) launch_qr_reg<13, 4, 8>(ctx, dd, count);
+  else if (cmax <= 128) launch_qr_reg<16, 4, 8>(ctx, dd, count);
+  else launch_qr_reg<13, 7, 8>(ctx, dd, count);
+  // Q is then formed by a second, barrier-free launch over blocks of 64 columns
+  if (qmax > 0) formq_reg(ctx, dd, descs, count, rmax);
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -578,9 +593,7 @@ extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int
     qr_blocked(ctx, descs, count, false);
   } else {
     auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
-    if (rmax <= 64) launch_formq_reg<1, 4>(ctx, dd, descs, count);
-    else if (rmax <= 128) launch_formq_reg<2, 8>(ctx, dd, descs, count);
-    else launch_formq_reg<4, 8>(ctx, dd, descs, count);   // rmax <= 256 (taller panels took the blocked path above)
+    formq_reg(ctx, dd, descs, count, rmax);   // rmax <= 256 (taller panels took the blocked path above)
   }
   hssk_rt::check_launch();
   HSSK_API_END

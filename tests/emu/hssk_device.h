@@ -25,6 +25,7 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define HSSK_WAVES_PER_SIMD(n)
 
 namespace hssk_rec {
 extern thread_local std::vector<std::function<void()>>* sink;   // non-null while a plan is being recorded
@@ -54,6 +55,16 @@ inline int hssk_shfl(int v, int src) { return (int)hssk_shfl((double)v, src); }
 inline double hssk_bcast_lane(double v, int src) { return emu::wave_xchg(v, src & 63); }
 inline double hssk_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
+  return v;
+}
+inline int hssk_bcast_lane_i(int v, int src) { return (int)emu::wave_xchg((double)v, src & 63); }
+inline int hssk_any(int pred) {
+  double v = pred ? 1. : 0.;
+  for (int o = 32; o > 0; o >>= 1) v = std::fmax(v, hssk_shfl_xor(v, o));
+  return v > 0.;
+}
+inline double hssk_row_sum(double v) {
+  for (int o = 8; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
   return v;
 }
 using std::min;
