@@ -45,6 +45,9 @@ void* hssk_malloc(long long bytes);
 void hssk_free(void* dptr);
 int hssk_memcpy_h2d(hssk_ctx* ctx, void* dst, const void* src, long long bytes);
 int hssk_memcpy_d2h(hssk_ctx* ctx, void* dst, const void* src, long long bytes); /* synchronises */
+/* host -> device without synchronising: src is copied into the context's pinned staging ring first, so the caller's
+ * buffer may be released on return; ordered on the context's stream like a kernel launch */
+int hssk_upload_async(hssk_ctx* ctx, void* dst, const void* src, long long bytes);
 int hssk_memcpy_d2d(hssk_ctx* ctx, void* dst, const void* src, long long bytes); /* async */
 /* strided copies of `height` columns of `width` bytes (pitches in bytes); both synchronise */
 int hssk_memcpy2d_h2d(hssk_ctx* ctx, void* dst, long long dpitch, const void* src, long long spitch,

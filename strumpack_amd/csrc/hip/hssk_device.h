@@ -59,6 +59,18 @@ __device__ __forceinline__ double hssk_row_sum(double v) {
   v += hssk_dpp_mov0<0x140, 0xF>(v);  // row_mirror
   return v;
 }
+// the same for N independent values, stage by stage: N dependent chains in flight instead of one after the other
+template <int N>
+__device__ __forceinline__ void hssk_row_sum_n(double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += hssk_dpp_mov0<0xB1, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += hssk_dpp_mov0<0x4E, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += hssk_dpp_mov0<0x141, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += hssk_dpp_mov0<0x140, 0xF>(v[i]);
+}
 // value of `v` in lane `src` (src must be wave-uniform): v_readlane, no LDS crossbar
 __device__ __forceinline__ double hssk_bcast_lane(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);

@@ -1015,7 +1015,7 @@ void DeviceHSS::reduce_samples(const std::vector<int>& ids, const std::vector<in
   if (!cat.empty()) ck(hssk_gather_cols(ctx_, cat.data(), (int)cat.size()));
   if (!g.empty()) ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
   if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
-  ck(hssk_sync(ctx_));  // tmp is released on return
+  // (tmp is reused by later launches of the same stream only: no host synchronisation needed)
 }
 
 // ID of the listed (node, basis) pairs on all dtot samples; commits ranks, X, perm, index sets
@@ -1143,9 +1143,9 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   std::vector<int*> perms(cnt, nullptr);
   size_t perm_total = 0;
   for (size_t k = 0; k < cnt; k++) perm_total += (which[k] == 0 ? nodes_[ids[k]].mU : nodes_[ids[k]].mV);
-  int* perm_block = persist_->ints(std::max<size_t>(perm_total, 1));
-  int* rank_block = d_ranks_;
-  if (cnt > 2 * nodes_.size()) throw std::logic_error("run_id: too many problems");
+  // ranks and permutations of the level in ONE device block: one read-back (one host synchronisation) per level
+  int* rank_block = persist_->ints(cnt + std::max<size_t>(perm_total, 1));
+  int* perm_block = rank_block + cnt;
   size_t poff = 0;
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
@@ -1157,9 +1157,10 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     idd.push_back(hssk_id_desc{Ws[k], ds[k], ds[k], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk});
   }
   if (!idd.empty()) ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
-  std::vector<int> hranks(cnt, 0), hperm(std::max<size_t>(perm_total, 1));
-  ck(hssk_memcpy_d2h(ctx_, hranks.data(), rank_block, (long long)sizeof(int) * cnt));
-  if (perm_total) ck(hssk_memcpy_d2h(ctx_, hperm.data(), perm_block, (long long)sizeof(int) * perm_total));
+  std::vector<int> hall(cnt + std::max<size_t>(perm_total, 1));
+  ck(hssk_memcpy_d2h(ctx_, hall.data(), rank_block, (long long)sizeof(int) * (cnt + perm_total)));
+  const int* hranks = hall.data();
+  const int* hperm = hall.data() + cnt;
   // commit
   std::vector<hssk_elem_desc> xc;
   std::vector<int> idx_host;      // all skeleton index sets of this level: one upload
@@ -1171,7 +1172,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     const int m = w == 0 ? nd.mU : nd.mV;
     const int dtot = ds[k];
     const int r = m ? hranks[k] : 0;
-    std::vector<int> perm(hperm.begin() + poff, hperm.begin() + poff + m);
+    std::vector<int> perm(hperm + poff, hperm + poff + m);
     poff += m;
     double* X = persist_->dbl((size_t)std::max(r, 1) * std::max(m - r, 1));
     if (r > 0 && m > r) xc.push_back(hssk_elem_desc{Ws[k], dtot, nullptr, nullptr, 0, r, X, r, m - r, r, 0});
@@ -1192,13 +1193,13 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
   }
   int* idx_dev = persist_->ints(std::max<size_t>(idx_host.size(), 1));
-  if (!idx_host.empty()) ck(hssk_memcpy_h2d(ctx_, idx_dev, idx_host.data(), (long long)sizeof(int) * idx_host.size()));
+  if (!idx_host.empty()) ck(hssk_upload_async(ctx_, idx_dev, idx_host.data(), (long long)sizeof(int) * idx_host.size()));
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
     (which[k] == 0 ? nd.dIr : nd.dIc) = idx_dev + idx_off[k];
   }
   if (!xc.empty()) ck(hssk_gather_elems(ctx_, xc.data(), (int)xc.size()));
-  ck(hssk_sync(ctx_));  // the W panels in tmp_ may be reused after this
+  // (no synchronisation: everything that reuses the W panels in tmp_ is enqueued behind these launches on the same stream)
 }
 
 // ---------------------------------------------------------------------------------------------

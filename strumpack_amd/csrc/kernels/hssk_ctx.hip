@@ -90,6 +90,21 @@ int hssk_memcpy_h2d(hssk_ctx* c, void* dst, const void* src, long long bytes) {
   hssk_rt::sync(c->stream);  // src may be pageable: make the call synchronous for FFI safety
   HSSK_API_END
 }
+int hssk_upload_async(hssk_ctx* c, void* dst, const void* src, long long bytes) {
+  HSSK_API_BEGIN
+  if (bytes <= 0) return 0;
+  const size_t need = ((size_t)bytes + 255) & ~size_t(255);
+  if (need > c->ring_bytes) {   // larger than the ring: plain synchronous copy
+    hssk_rt::h2d(dst, src, (size_t)bytes, c->stream);
+    hssk_rt::sync(c->stream);
+    return 0;
+  }
+  if (c->ring_off + need > c->ring_bytes) { hssk_rt::sync(c->stream); c->ring_off = 0; }
+  std::memcpy(c->h_ring + c->ring_off, src, (size_t)bytes);
+  hssk_rt::h2d(dst, c->h_ring + c->ring_off, (size_t)bytes, c->stream);
+  c->ring_off += need;
+  HSSK_API_END
+}
 int hssk_memcpy_d2h(hssk_ctx* c, void* dst, const void* src, long long bytes) {
   HSSK_API_BEGIN
   hssk_rt::d2h(dst, src, (size_t)bytes, c->stream);

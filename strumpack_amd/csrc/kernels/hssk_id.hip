@@ -316,24 +316,35 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
       double vr[RT];
 #pragma unroll
       for (int r = 0; r < RT; r++) vr[r] = sv[l16 + 16 * r];
+      // all dot products of the wave's slots first, their row sums stage by stage (independent chains in flight)
+      double dot[CT];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        double d0 = 0., d1 = 0.;
+#pragma unroll
+        for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
+        if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
+        dot[c] = d0 + d1;
+      }
+      hssk_row_sum_n(dot);
+      double newk[CT];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int col = grp + NC * c;
+        const double f = (col < m && !((used >> c) & 1u)) ? dot[c] * tau : 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
+        newk[c] = hssk_shfl(a[c][rk], (lane & 48) | lk);  // R(k, col)
+      }
 #pragma unroll
       for (int c = 0; c < CT; c++) {
         const int col = grp + NC * c;
         const bool act = col < m && !((used >> c) & 1u);
-        double dot = 0.;
-#pragma unroll
-        for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
-        dot = hssk_row_sum(dot) * tau;
-        if (act) {
-#pragma unroll
-          for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
-        }
-        const double newk = hssk_shfl(a[c][rk], (lane & 48) | lk);  // R(k, col)
         double n1 = 0., n2 = 0., newn1 = 0.;
         int recompute = 0;
         if (act) {
           n1 = s_vn1[col]; n2 = s_vn2[col];
-          newn1 = n1 - newk * newk;
+          newn1 = n1 - newk[c] * newk[c];
           newn1 = newn1 > 0. ? newn1 : 0.;
           recompute = (n1 != 0.) && (newn1 <= tol3z * n2);
         }

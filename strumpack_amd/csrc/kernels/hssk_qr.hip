@@ -180,18 +180,25 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
           double vr[RT];
 #pragma unroll
           for (int r = 0; r < RT; r++) vr[r] = sv[l16 + 16 * r];
+          // all dot products of the wave's slots first, their row sums stage by stage (independent chains in flight)
+          double dot[CT];
+#pragma unroll
+          for (int c = 0; c < CT; c++) {
+            double d0 = 0., d1 = 0.;
+            if (c >= kc) {
+#pragma unroll
+              for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
+              if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
+            }
+            dot[c] = d0 + d1;
+          }
+          hssk_row_sum_n(dot);
 #pragma unroll
           for (int c = kc; c < CT; c++) {
             const int col = grp + NC * c;
-            const bool act = col > k && col < cols;
-            double dot = 0.;
+            const double f = (col > k && col < cols) ? dot[c] * tau : 0.;
 #pragma unroll
-            for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
-            dot = hssk_row_sum(dot) * tau;
-            if (act) {
-#pragma unroll
-              for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
-            }
+            for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
           }
         }
       }
@@ -210,30 +217,31 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
   if (p.rdiag && tid == 0) { p.rdiag[0] = kmax ? s_rd[0] : 0.; p.rdiag[1] = kmax ? s_rd[1] : 0.; }
 }
 
-// Q(:, j0 : j0 + 64 CT) = H_0 ... H_{kmax-1} I(:, same columns): every 16-lane group owns CT columns in registers (same
+// Q(:, j0 : j0 + 4 NW CT) = H_0 ... H_{kmax-1} I(:, same columns): every 16-lane group owns CT columns in registers (same
 // layout as above) and applies the reflectors (read from the factored panel, L1/L2 hits) on its own -- no LDS, no
 // barriers.  H_k leaves column j untouched for k > j, so the sweep starts at the last column of the block.
 struct QBlock {
   int prob, block;
 };
-template <int RT, int CT>
-__global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __restrict__ descs,
-                                                         const QBlock* __restrict__ work) {
+template <int RT, int CT, int NW>
+__global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void formq_reg_kernel(const hssk_qr_desc* __restrict__ descs,
+                                                                                       const QBlock* __restrict__ work) {
+  constexpr int NC = NW * 4;
   const QBlock w = work[blockIdx.x];
   const hssk_qr_desc p = descs[w.prob];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, grp = wave * 4 + (lane >> 4);
   const int rows = p.rows, cols = p.cols, nq = p.nq;
   const int kmax = rows < cols ? rows : cols;
-  const int j0 = w.block * 64 * CT;
+  const int j0 = w.block * NC * CT;
   const double* __restrict__ A = p.A;
   const double* __restrict__ taus = p.work;
   double a[CT][RT];
 #pragma unroll
   for (int c = 0; c < CT; c++)
 #pragma unroll
-    for (int r = 0; r < RT; r++) a[c][r] = (l16 + 16 * r == j0 + grp + 64 * c) ? 1. : 0.;
-  int kstart = j0 + 64 * CT - 1;
+    for (int r = 0; r < RT; r++) a[c][r] = (l16 + 16 * r == j0 + grp + NC * c) ? 1. : 0.;
+  int kstart = j0 + NC * CT - 1;
   if (kstart > kmax - 1) kstart = kmax - 1;
   // reflector k-1 is fetched (L2) while reflector k is applied
   double vn[RT], taun = 0.;
@@ -253,25 +261,29 @@ __global__ __launch_bounds__(1024) void formq_reg_kernel(const hssk_qr_desc* __r
     for (int r = 0; r < RT; r++) vr[r] = vn[r];
     fetch(k - 1);
     if (tau == 0.) continue;
+    double dot[CT];
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      const int col = j0 + grp + 64 * c;
-      const bool act = col >= k && col < nq;
-      double dot = 0.;
+      double d0 = 0., d1 = 0.;
 #pragma unroll
-      for (int r = 0; r < RT; r++) dot += vr[r] * a[c][r];
-      dot = hssk_row_sum(dot) * tau;
-      if (act) {
+      for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
+      if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
+      dot[c] = d0 + d1;
+    }
+    hssk_row_sum_n(dot);
 #pragma unroll
-        for (int r = 0; r < RT; r++) a[c][r] -= dot * vr[r];
-      }
+    for (int c = 0; c < CT; c++) {
+      const int col = j0 + grp + NC * c;
+      const double f = (col >= k && col < nq) ? dot[c] * tau : 0.;
+#pragma unroll
+      for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
     }
   }
 #pragma unroll
   for (int c = 0; c < CT; c++)
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      const int row = l16 + 16 * r, col = j0 + grp + 64 * c;
+      const int row = l16 + 16 * r, col = j0 + grp + NC * c;
       if (row < rows && col < nq) p.Q[row + (size_t)col * p.ldq] = a[c][r];
     }
 }
@@ -280,21 +292,22 @@ template <int RT, int CT, int NW>
 void launch_qr_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, int count) {
   HSSK_LAUNCH((qr_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
 }
-template <int RT, int CT>
+template <int RT, int CT, int NW>
 void launch_formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc* descs, int count) {
   std::vector<QBlock> blocks;
   for (int i = 0; i < count; i++)
-    for (int b = 0; b * 64 * CT < descs[i].nq; b++) blocks.push_back(QBlock{i, b});
+    for (int b = 0; b * 4 * NW * CT < descs[i].nq; b++) blocks.push_back(QBlock{i, b});
   if (blocks.empty()) return;
   auto* dw = (const QBlock*)ctx->stage(blocks.data(), sizeof(QBlock) * blocks.size());
-  HSSK_LAUNCH((formq_reg_kernel<RT, CT>), dim3((unsigned)blocks.size()), dim3(1024), 0, ctx->stream, dd, dw);
+  HSSK_LAUNCH((formq_reg_kernel<RT, CT, NW>), dim3((unsigned)blocks.size()), dim3(NW * 64), 0, ctx->stream, dd, dw);
 }
 // Q of panels with up to 256 rows
 void formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc* descs, int count, int rmax) {
-  if (rmax <= 64) launch_formq_reg<4, 1>(ctx, dd, descs, count);
-  else if (rmax <= 128) launch_formq_reg<8, 1>(ctx, dd, descs, count);
-  else if (rmax <= 208) launch_formq_reg<13, 1>(ctx, dd, descs, count);
-  else launch_formq_reg<16, 1>(ctx, dd, descs, count);
+  // four column slots per group: four independent reflector-application chains in flight per wave
+  if (rmax <= 64) launch_formq_reg<4, 2, 8>(ctx, dd, descs, count);
+  else if (rmax <= 128) launch_formq_reg<8, 4, 8>(ctx, dd, descs, count);
+  else if (rmax <= 208) launch_formq_reg<13, 4, 8>(ctx, dd, descs, count);
+  else launch_formq_reg<16, 4, 8>(ctx, dd, descs, count);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -446,12 +446,21 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const hssk_trtri_desc* _
   for (int e = j; e < SW_NB * (SW_NB + 1); e += 64) s_X[e] = 0.;
   __syncthreads();
   if (j < nb) {
-    double* x = s_X + j * (SW_NB + 1);   // column j of U^{-1}
+    // column j of U^{-1} by back substitution; x(k) = 0 for k > j, so the inner sum runs over the same k range in every
+    // lane (independent LDS reads, four partial sums: the loop is bound by LDS throughput, not by its latency)
+    double* x = s_X + j * (SW_NB + 1);
     x[j] = 1. / s_U[j + j * (SW_NB + 1)];
-    for (int i = j - 1; i >= 0; i--) {
-      double s = 0.;
-      for (int k = i + 1; k <= j; k++) s += s_U[i + k * (SW_NB + 1)] * x[k];
-      x[i] = -s / s_U[i + i * (SW_NB + 1)];
+    for (int i = nb - 2; i >= 0; i--) {
+      double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+      int k = i + 1;
+      for (; k + 3 < nb; k += 4) {
+        s0 += s_U[i + k * (SW_NB + 1)] * x[k];
+        s1 += s_U[i + (k + 1) * (SW_NB + 1)] * x[k + 1];
+        s2 += s_U[i + (k + 2) * (SW_NB + 1)] * x[k + 2];
+        s3 += s_U[i + (k + 3) * (SW_NB + 1)] * x[k + 3];
+      }
+      for (; k < nb; k++) s0 += s_U[i + k * (SW_NB + 1)] * x[k];
+      if (i < j) x[i] = -((s0 + s1) + (s2 + s3)) / s_U[i + i * (SW_NB + 1)];
     }
   }
   __syncthreads();

@@ -67,6 +67,10 @@ inline double hssk_row_sum(double v) {
   for (int o = 8; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
   return v;
 }
+template <int N>
+inline void hssk_row_sum_n(double (&v)[N]) {
+  for (int i = 0; i < N; i++) v[i] = hssk_row_sum(v[i]);
+}
 using std::min;
 using std::max;
 inline double hssk_wave_max(double v) {
