@@ -167,19 +167,49 @@ def main():
     hk = K.Hssk(_loader.lib_path(), device=local)
     n = a.n
 
+    opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch)
+    # ---- process group.  Default for N > 1: the library's own RCCL communicator (collectives on the engine's stream) and
+    # a SHARDED operand -- every rank generates only its row block and its column block of A (2 x 80 GB / N), never the
+    # whole matrix.  STRUMPACK_AMD_BENCH_COMM=torch selects the round-1 path (replicated A, torch.distributed callback).
+    comm_mode = "single"
+    comm = exch = None
+    if world > 1:
+        comm_mode = os.environ.get("STRUMPACK_AMD_BENCH_COMM", "rccl")
+        if comm_mode == "rccl" and a.sketch == "gaussian":
+            try:
+                comm = sdist.NativeComm(L)
+                if L.SPX_comm_selftest(comm.h):
+                    raise RuntimeError("SPX_comm_selftest failed")
+                sdist.shard_range(L, n, opts, world, rank)
+            except Exception as e:   # e.g. world not a power of two: replicated operand over the callback
+                if rank == 0:
+                    print("bench: native RCCL / sharded operand unavailable (%s); using the torch callback path" % e, file=sys.stderr)
+                comm, comm_mode = None, "torch"
+        else:
+            comm_mode = "torch"
+        if comm is None:
+            exch = sdist.make_exchange(L, world, rank)
     # ---- inputs resident in HBM before the clock starts: dense A (column-major) and the rhs
-    dA = hk.empty((n, n))
-    hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
+    if comm is not None:
+        lo, hi = sdist.shard_range(L, n, opts, world, rank)
+        dAr = hk.empty((hi - lo, n))
+        dAc = hk.empty((n, hi - lo))
+        hk.check(hk.lib.hssk_fill_toeplitz_block(hk.ctx, dAr.ptr, hi - lo, n, hi - lo, lo, 0, b"T"))
+        hk.check(hk.lib.hssk_fill_toeplitz_block(hk.ctx, dAc.ptr, n, hi - lo, n, 0, lo, b"T"))
+    else:
+        dA = hk.empty((n, n))
+        hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
     dB = hk.empty((n, a.nrhs))
     dX = hk.empty((n, a.nrhs))
     hk.check(hk.lib.hssk_randn(hk.ctx, dB.ptr, n, a.nrhs, n, 0, a.nrhs, 7))
     hk.sync()
-    opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
-    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch)
-    exch = sdist.make_exchange(L, world, rank) if world > 1 else None
 
     def step():
-        H = sdist.from_dense_device(L, dA.ptr, n, n, opts, hopts, exch)
+        if comm is not None:
+            H = sdist.from_blocks_device(L, dAr.ptr, hi - lo, dAc.ptr, n, n, opts, hopts, comm=comm)
+        else:
+            H = sdist.from_dense_device(L, dA.ptr, n, n, opts, hopts, exch)
         H.factor()
         hk.check(hk.lib.hssk_memcpy_d2d(hk.ctx, dX.ptr, dB.ptr, 8 * n * a.nrhs))
         hk.sync()
@@ -278,7 +308,10 @@ def main():
                                % (n, n, "Philox samples" if a.sketch == "gaussian" else "SJLT sketch, nnz=4: NOT the configuration of BASELINE's metric",
                                   a.leaf, a.rel_tol, a.nrhs),
                    "sketch": a.sketch, "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
-                   "parallelism": "1 GPU" if world == 1 else "HSS tree partitioned by subtree over %d GPUs (sketch rows, compression, ULV, sweeps local; RCCL all-gathers of the cut-level blocks; top %d nodes replicated)" % (world, world - 1)},
+                   "parallelism": "1 GPU" if world == 1 else "HSS tree partitioned by subtree over %d GPUs (sketch rows, compression, ULV, sweeps local; RCCL all-gathers of the cut-level blocks; top %d nodes replicated)" % (world, world - 1),
+                   "comm": {"single": "none", "rccl": "native RCCL communicator inside the library, collectives on the engine's stream; operand sharded (row block + column block per rank)",
+                            "torch": "torch.distributed all-gather callback; operand replicated on every rank"}[comm_mode],
+                   "rccl_nranks": world if comm_mode == "rccl" else 0},
         "phases_s": {"compress": st["t_compress"], "sketch": st["t_sketch"], "random": st["t_random"],
                      "tree": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
         "flops": {"sketch": st["f_sketch"], "local": st["f_local"], "reduce": st["f_reduce"], "id": st["f_id"],
@@ -309,6 +342,13 @@ def main():
         tfs = os.path.join(ROOT, "profiles", "r01_pmc_sjlt_traffic.json")
         if os.path.exists(tfs) and n == 100000 and world == 1:
             out["roofline"]["traffic"] = json.load(open(tfs)).get("hbm_read_bytes_per_launch")
+    if world > 1:
+        # diagnostic step with synchronised collectives: host-visible time of the compression's collectives
+        os.environ["STRUMPACK_AMD_TIME_COMM"] = "1"
+        H.destroy()
+        H = step()
+        out["comm_s"] = {"compress_collectives_synchronised": H.stats()["t_comm"], "note": "one extra step outside the timed region, every collective bracketed by stream synchronisations"}
+        del os.environ["STRUMPACK_AMD_TIME_COMM"]
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.leaf, a.rel_tol)

@@ -73,6 +73,8 @@ double hssk_last_dgemm_clock_ghz(hssk_ctx* ctx);
 /* Test matrices of test/test_HSS_seq.cpp:69-91 generated in HBM: kind 'T' Toeplitz
  * A(i,j) = i==j ? 1 : 1/(1+|i-j|), 'U' its upper triangle.  A is n x n, leading dimension lda. */
 int hssk_fill_toeplitz(hssk_ctx* ctx, double* A, int n, long long lda, char kind);
+/* the rows x cols block of that matrix whose first entry is global (i0, j0): one rank's shard of the operand */
+int hssk_fill_toeplitz_block(hssk_ctx* ctx, double* A, int rows, int cols, long long lda, int i0, int j0, char kind);
 /* N(0,1) samples, counter-based (Philox4x32-10 + Box-Muller): element (r,c) of the rows x cols
  * panel (leading dimension ld) is a pure function of (seed, (row0+r)*stride + c).  Device
  * replacement for DenseMatrix::random (dense/DenseMatrix.cpp:172-181) in performance runs. */
@@ -170,8 +172,14 @@ typedef struct hssk_elem_desc {
   int i0, j0;
   double* B;
   int m, n, ldb, transpose;
+  /* ownership windows of a sharded operand (0, 0 = none): entries whose global row lies outside [rlo, rhi) or whose
+   * global column lies outside [clo, chi) are written as 0 and A is not read there -- every process of a multi-GPU run
+   * fills in the part of a coupling block it holds, the parts are summed over the ranks */
+  int rlo, rhi, clo, chi;
 } hssk_elem_desc;
 int hssk_gather_elems(hssk_ctx* ctx, const hssk_elem_desc* descs, int count);
+/* out[0:count) = sum over g < nslab of slabs[g * stride + (0:count)]  (partial blocks of several ranks after an all-gather) */
+int hssk_sum_slabs(hssk_ctx* ctx, const double* slabs, long long count, long long stride, int nslab, double* out);
 /* dst = src^T : rows x cols (src, lds) -> cols x rows (dst, ldd) */
 typedef struct hssk_transpose_desc {
   const double* src;

@@ -89,6 +89,40 @@ typedef void (*SPXAllGatherFn)(void* user, void* dbuf, long long bytes_per_rank)
 int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                            const CSPOptions* opts, const SPXHSSOptions* h, int world, int rank,
                                            SPXAllGatherFn allgather, void* user);
+/* ---- native process group: RCCL over xGMI, bound inside the library (no Python, no MPI needed) --------------------------
+ * Rank 0 calls SPX_comm_unique_id and hands the 128 bytes to the other ranks by any means (MPI_Bcast, a file, a socket);
+ * then every rank calls SPX_comm_create (collective; binds to the calling thread's current HIP device).  The engine issues
+ * its collectives -- in-place all-gathers of the cut nodes' reduced blocks, sums of the replicated top nodes' coupling
+ * blocks and, for a column-sharded operand, the reduction of the off-diagonal sample contributions -- on its own HIP
+ * stream, in order with its kernels.  The communicator must outlive every matrix built with it; all ranks must call the
+ * same operations in the same order. */
+typedef void* SPXComm;
+int SPX_comm_unique_id(char id[128]);
+int SPX_comm_create(SPXComm* comm, int world, int rank, const char id[128]);
+void SPX_comm_destroy(SPXComm* comm);
+/* runs the engine's three collectives (in-place all-gather, all-reduce, reduce-scatter with per-rank counts) on small
+ * device buffers and checks the results; collective; 0 = ok */
+int SPX_comm_selftest(SPXComm comm);
+int SPX_comm_size(const SPXComm comm);
+int SPX_comm_rank(const SPXComm comm);
+/* rows == columns [lo, hi) of an n x n matrix that `rank` of `world` owns (its subtree of the bisection tree for this leaf
+ * size, structured/ClusterTree.hpp:104-114): the part of the operand that rank has to hold.  Returns non-zero if the tree
+ * cannot be cut into one subtree per rank (world not a power of two, or n too small). */
+int SPX_struct_shard_range(int n, const CSPOptions* opts, int world, int rank, int* lo, int* hi);
+/* replicated operand (every rank passes the whole dA), native communicator */
+int SPX_d_struct_from_dense_device_comm(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
+                                        const CSPOptions* opts, const SPXHSSOptions* h, SPXComm comm);
+/* SHARDED operand: this rank passes only its blocks (DEVICE pointers, column-major): dArows = A(lo:hi, :) ((hi-lo) x cols,
+ * ldr) and dAcols = A(:, lo:hi) (rows x (hi-lo), ldc).  dArows may be NULL -- a column-sharded operator: the contributions
+ * A(:, cols_g) R(cols_g, :) of all ranks to Sr are then summed to the owners of the rows (reduce-scatter).  No rank ever
+ * holds the full matrix. */
+int SPX_d_struct_from_blocks_device(CSPStructMat* S, int rows, int cols, const double* dArows, long long ldr,
+                                    const double* dAcols, long long ldc, const CSPOptions* opts, const SPXHSSOptions* h,
+                                    SPXComm comm);
+/* the same over the all-gather callback (gloo in the CPU tests; the reductions are emulated with all-gathers) */
+int SPX_d_struct_from_blocks_device_cb(CSPStructMat* S, int rows, int cols, const double* dArows, long long ldr,
+                                       const double* dAcols, long long ldc, const CSPOptions* opts, const SPXHSSOptions* h,
+                                       int world, int rank, SPXAllGatherFn allgather, void* user);
 /* HSS approximation of a kernel matrix K(i, j) = k(x_i, x_j) + lambda [i == j] over n points in R^d (points: d x n,
  * one point per column, HOST; reordered in place by the clustering, perm (n ints, may be NULL) receives the 1-based
  * permutation: new point i = old point perm[i]).  ktype 0 Gauss, 1 Laplace, 2 ANOVA (degree p); clustering 0 natural,
@@ -101,6 +135,8 @@ int SPX_d_struct_from_kernel(CSPStructMat* S, int n, int d, double* points, int 
 int SPX_d_struct_from_kernel_sharded(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
                                      const CSPOptions* opts, int clustering, int neighbors, int* perm, int world, int rank,
                                      SPXAllGatherFn allgather, void* user);
+int SPX_d_struct_from_kernel_comm(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                                  const CSPOptions* opts, int clustering, int neighbors, int* perm, SPXComm comm);
 int SPX_d_struct_mult_device(const CSPStructMat S, char trans, int m, const double* dB, long long ldB,
                              double* dC, long long ldC);
 int SPX_d_struct_solve_device(const CSPStructMat S, int nrhs, double* dB, long long ldB);

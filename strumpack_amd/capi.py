@@ -29,13 +29,16 @@ SP_SYMBOLS = [
     "SPX_d_struct_levels", "SPX_d_struct_is_compressed", "SPX_d_struct_num_nodes",
     "SPX_d_struct_node_info", "SPX_d_struct_stats", "SPX_d_struct_hssk_ctx",
     "SPX_d_struct_from_kernel", "SPX_d_struct_from_kernel_sharded",
+    "SPX_comm_unique_id", "SPX_comm_create", "SPX_comm_destroy", "SPX_comm_size", "SPX_comm_rank", "SPX_comm_selftest", "SPX_struct_shard_range",
+    "SPX_d_struct_from_dense_device_comm", "SPX_d_struct_from_blocks_device", "SPX_d_struct_from_blocks_device_cb",
+    "SPX_d_struct_from_kernel_comm",
 ]
 ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
 STAT_NAMES = ["t_compress", "t_sketch", "t_random", "t_tree", "t_factor", "t_solve", "t_mult",
               "sketch_kernel_ms", "sketch_launches", "rounds", "d_final", "f_sketch", "f_local",
               "f_reduce", "f_id", "f_ortho", "f_ulv", "f_solve", "factor_memory", "sketch_kernel_flops", "sketch_kernel_bytes",
-              "b_solve", "b_mult"]
+              "b_solve", "b_mult", "t_comm"]
 
 
 def load(path):
@@ -67,6 +70,23 @@ def load(path):
                                            C.POINTER(CSPOptions), C.c_int, C.c_int, vp]
     L.SPX_d_struct_from_kernel_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
                                                    C.POINTER(CSPOptions), C.c_int, C.c_int, vp, C.c_int, C.c_int, ALLGATHER_CB, vp]
+    L.SPX_comm_unique_id.argtypes = [C.c_char_p]
+    L.SPX_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p]
+    L.SPX_comm_destroy.argtypes = [C.POINTER(vp)]
+    L.SPX_comm_destroy.restype = None
+    L.SPX_comm_selftest.argtypes = [vp]
+    L.SPX_comm_size.argtypes = [vp]
+    L.SPX_comm_rank.argtypes = [vp]
+    L.SPX_struct_shard_range.argtypes = [C.c_int, C.POINTER(CSPOptions), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.SPX_d_struct_from_dense_device_comm.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_longlong,
+                                                      C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions), vp]
+    L.SPX_d_struct_from_blocks_device.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_longlong, dp, C.c_longlong,
+                                                  C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions), vp]
+    L.SPX_d_struct_from_blocks_device_cb.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_longlong, dp, C.c_longlong,
+                                                     C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions), C.c_int, C.c_int,
+                                                     ALLGATHER_CB, vp]
+    L.SPX_d_struct_from_kernel_comm.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                C.POINTER(CSPOptions), C.c_int, C.c_int, vp, vp]
     L.SPX_d_struct_mult_device.argtypes = [vp, C.c_char, C.c_int, dp, C.c_longlong, dp, C.c_longlong]
     L.SPX_d_struct_solve_device.argtypes = [vp, C.c_int, dp, C.c_longlong]
     L.SPX_d_struct_node_info.argtypes = [vp, C.POINTER(C.c_int)]

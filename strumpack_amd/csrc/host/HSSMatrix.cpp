@@ -58,8 +58,14 @@ HSSMatrix<double> HSSMatrix<double>::read(const std::string& fname) {
 
 // HSSMatrix(kernel::Kernel&, opts): HSS/HSSMatrix.cpp:88-106
 HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts) : HSSMatrix(K, opts, 1, 0, nullptr, nullptr) {}
+static CommSpec callback_group(int world, int rank, void (*fn)(void*, void*, long long), void* user) {
+  CommSpec pg;
+  pg.world = world; pg.rank = rank; pg.allgather = fn; pg.user = user; pg.native = false;
+  return pg;
+}
 HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, int world, int rank,
-                             void (*fn)(void*, void*, long long), void* user) : rows_(K.n()), cols_(K.n()) {
+                             void (*fn)(void*, void*, long long), void* user) : HSSMatrix(K, opts, callback_group(world, rank, fn, user)) {}
+HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, const CommSpec& pg) : rows_(K.n()), cols_(K.n()) {
   auto tc0 = std::chrono::steady_clock::now();
   auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size());
   K.permute();
@@ -68,7 +74,7 @@ HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, int 
               << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count() << std::endl;
   tree_.reset(new structured::ClusterTree(t));
   EngineOptions e = engine_options(opts);
-  e.world = world; e.rank = rank; e.allgather = fn; e.comm_user = user;
+  pg.apply(e);
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
   compress(K, opts);
 }
@@ -110,6 +116,7 @@ void HSSMatrix<double>::make_engine(const opts_t& opts, const structured::Cluste
   if (eng_ && eng_->options().leaf_size == e.leaf_size && eng_->options().device == e.device) {
     const EngineOptions& cur = eng_->options();   // same tree: keep the engine (device context, process group), new knobs
     e.world = cur.world; e.rank = cur.rank; e.allgather = cur.allgather; e.comm_user = cur.comm_user;
+    e.allgather_stream = cur.allgather_stream; e.allreduce_stream = cur.allreduce_stream; e.reduce_scatter_stream = cur.reduce_scatter_stream;
     eng_->set_options(e);
     return;
   }
@@ -127,10 +134,20 @@ void HSSMatrix<double>::compress_device(const double* dA, long long lda, const o
 }
 void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda, const opts_t& opts, int world, int rank,
                                                 void (*fn)(void*, void*, long long), void* user) {
+  compress_device_sharded(dA, lda, opts, callback_group(world, rank, fn, user));
+}
+void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda, const opts_t& opts, const CommSpec& pg) {
   EngineOptions e = engine_options(opts);
-  e.world = world; e.rank = rank; e.allgather = fn; e.comm_user = user;
+  pg.apply(e);
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
   eng_->compress_dense_device(dA, lda);
+}
+void HSSMatrix<double>::compress_device_blocks(const double* dRows, long long ldr, const double* dCols, long long ldc,
+                                               const opts_t& opts, const CommSpec& pg) {
+  EngineOptions e = engine_options(opts);
+  pg.apply(e);
+  eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
+  eng_->compress_dense_device_sharded(dRows, ldr, dCols, ldc);
 }
 void HSSMatrix<double>::compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts) {
   make_engine(opts, tree_.get());

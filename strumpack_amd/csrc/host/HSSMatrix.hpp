@@ -100,6 +100,13 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   // `allgather` is an in-place all-gather of a device buffer (RCCL)
   void compress_device_sharded(const double* dA, long long lda, const opts_t& opts, int world, int rank,
                                void (*allgather)(void*, void*, long long), void* user);
+  // the same with a process group (native RCCL communicator or callback), replicated operand
+  void compress_device_sharded(const double* dA, long long lda, const opts_t& opts, const CommSpec& pg);
+  // sharded operand: this rank's row block A(lo:hi, :) (may be null: column-sharded operator) and column block
+  // A(:, lo:hi), [lo, hi) = shard_range(pg.rank)
+  void compress_device_blocks(const double* dRows, long long ldr, const double* dCols, long long ldc, const opts_t& opts,
+                              const CommSpec& pg);
+  HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, const CommSpec& pg);
 
   std::size_t rows() const override { return rows_; }
   std::size_t cols() const override { return cols_; }

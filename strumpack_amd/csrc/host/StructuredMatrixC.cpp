@@ -1,8 +1,10 @@
 // C interface SP_d_struct_* (reference structured/StructuredMatrixC.cpp:61-119 handle + error
 // convention, :83-821 entry points) and the SPX_* device-operand extensions.
+#include <cstdlib>
 #include <iostream>
 
 #include "HSSMatrix.hpp"
+#include "Comm.hpp"
 #include "Kernel.hpp"
 #include "StructuredMatrix.hpp"
 #include "structured/StructuredMatrix.h"
@@ -156,12 +158,11 @@ int SPX_d_struct_from_dense_device_sharded(CSPStructMat* S, int rows, int cols, 
 }
 // HSS approximation of the kernel matrix over `points` (d x n): clusters (reordering points in place, perm 1-based),
 // builds the tree, compresses from the coordinates (HSSMatrix(kernel::Kernel&, opts), HSS/HSSMatrix.cpp:88-106)
-int SPX_d_struct_from_kernel_sharded(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
-                                     const CSPOptions* opts, int clustering, int neighbors, int* perm, int world, int rank,
-                                     SPXAllGatherFn allgather, void* user) {
+static int from_kernel_group(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                             const CSPOptions* opts, int clustering, int neighbors, int* perm, const HSS::CommSpec& pg) {
   SP_TRY
   if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("kernel construction requires type SP_TYPE_HSS");
-  if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("invalid world/rank");
+  if (pg.world < 1 || pg.rank < 0 || pg.rank >= pg.world) throw std::invalid_argument("invalid world/rank");
   static const ClusteringAlgorithm algos[] = {ClusteringAlgorithm::NATURAL, ClusteringAlgorithm::TWO_MEANS, ClusteringAlgorithm::KD_TREE,
                                               ClusteringAlgorithm::PCA, ClusteringAlgorithm::COBBLE};
   if (clustering < 0 || clustering > 4) throw std::invalid_argument("clustering algorithm out of range");
@@ -176,9 +177,143 @@ int SPX_d_struct_from_kernel_sharded(CSPStructMat* S, int n, int d, double* poin
     case 2: K.reset(new kernel::ANOVAKernel<double>(X, h, lambda, p)); break;
     default: throw std::invalid_argument("kernel type must be 0 (Gauss), 1 (Laplace) or 2 (ANOVA)");
   }
-  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(*K, ho, world, rank, allgather, user));
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(*K, ho, pg));
   std::copy(X.data(), X.data() + (size_t)d * n, points);
   if (perm) std::copy(K->permutation().begin(), K->permutation().end(), perm);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
+static HSS::CommSpec callback_group(int world, int rank, SPXAllGatherFn fn, void* user) {
+  HSS::CommSpec pg;
+  pg.world = world; pg.rank = rank; pg.allgather = fn; pg.user = user; pg.native = false;
+  return pg;
+}
+static HSS::CommSpec native_group(SPXComm comm) {
+  if (!comm) throw std::invalid_argument("null communicator");
+  auto* c = (comm::RcclComm*)comm;
+  HSS::CommSpec pg;
+  pg.world = c->world(); pg.rank = c->rank(); pg.user = c; pg.native = true;
+  return pg;
+}
+int SPX_d_struct_from_kernel_sharded(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                                     const CSPOptions* opts, int clustering, int neighbors, int* perm, int world, int rank,
+                                     SPXAllGatherFn allgather, void* user) {
+  return from_kernel_group(S, n, d, points, ktype, h, lambda, p, opts, clustering, neighbors, perm, callback_group(world, rank, allgather, user));
+}
+int SPX_d_struct_from_kernel_comm(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
+                                  const CSPOptions* opts, int clustering, int neighbors, int* perm, SPXComm comm) {
+  SP_TRY
+  return from_kernel_group(S, n, d, points, ktype, h, lambda, p, opts, clustering, neighbors, perm, native_group(comm));
+  SP_CATCH
+}
+// ---- native process group (Comm.hpp)
+int SPX_comm_unique_id(char id[128]) {
+  SP_TRY
+  comm::RcclComm::unique_id(id);
+  SP_CATCH
+}
+int SPX_comm_create(SPXComm* out, int world, int rank, const char id[128]) {
+  SP_TRY
+  *out = new comm::RcclComm(world, rank, id);
+  SP_CATCH
+}
+void SPX_comm_destroy(SPXComm* c) {
+  if (c && *c) { delete (comm::RcclComm*)*c; *c = nullptr; }
+}
+// exercises the three collectives the engine uses on small device buffers and checks the results on every rank
+int SPX_comm_selftest(SPXComm comm) {
+  SP_TRY
+  auto* c = (comm::RcclComm*)comm;
+  if (!c) throw std::invalid_argument("null communicator");
+  const int G = c->world(), me = c->rank(), L = 1000;
+  hssk_ctx* ctx = nullptr;
+  int dev = 0;
+  if (const char* e = std::getenv("STRUMPACK_AMD_DEVICE")) dev = std::atoi(e);   // (the device the engines of this process use)
+  if (hssk_ctx_create(&ctx, dev)) throw std::runtime_error(hssk_last_error());
+  struct Guard { hssk_ctx* c; std::vector<void*> p; ~Guard() { for (void* q : p) hssk_free(q); hssk_ctx_destroy(c); } } g{ctx, {}};
+  auto dmal = [&](size_t n) { void* p = hssk_malloc((long long)(sizeof(double) * n)); if (!p) throw std::runtime_error("selftest: allocation failed"); g.p.push_back(p); return (double*)p; };
+  void* stream = hssk_ctx_stream(ctx);
+  // all-gather: block r holds r + 1 everywhere
+  std::vector<double> h((size_t)L * G, 0.), out((size_t)L * G);
+  for (int i = 0; i < L; i++) h[(size_t)L * me + i] = me + 1.;
+  double* d = dmal((size_t)L * G);
+  if (hssk_memcpy_h2d(ctx, d, h.data(), (long long)(sizeof(double) * L * G))) throw std::runtime_error(hssk_last_error());
+  c->allgather(d, (long long)sizeof(double) * L, stream);
+  if (hssk_memcpy_d2h(ctx, out.data(), d, (long long)(sizeof(double) * L * G))) throw std::runtime_error(hssk_last_error());
+  for (int r = 0; r < G; r++) for (int i = 0; i < L; i++) if (out[(size_t)L * r + i] != r + 1.) throw std::runtime_error("selftest: all-gather mismatch");
+  // all-reduce: every rank contributes rank + 1 -> G (G + 1) / 2
+  for (auto& v : h) v = me + 1.;
+  if (hssk_memcpy_h2d(ctx, d, h.data(), (long long)(sizeof(double) * L * G))) throw std::runtime_error(hssk_last_error());
+  c->allreduce_sum(d, (long long)L * G, stream);
+  if (hssk_memcpy_d2h(ctx, out.data(), d, (long long)(sizeof(double) * L * G))) throw std::runtime_error(hssk_last_error());
+  for (auto v : out) if (v != G * (G + 1) / 2.) throw std::runtime_error("selftest: all-reduce mismatch");
+  // reduce-scatter with per-rank counts: rank r receives r + 1 entries of value sum_g (g + 1) * (offset + i)
+  std::vector<long long> offs(G), cnts(G);
+  long long tot = 0;
+  for (int r = 0; r < G; r++) { offs[r] = tot; cnts[r] = r + 1; tot += r + 1; }
+  std::vector<double> hs(tot), hr(cnts[me]);
+  for (long long i = 0; i < tot; i++) hs[i] = (me + 1.) * (double)i;
+  double* ds = dmal(tot);
+  double* dr = dmal(cnts[me]);
+  if (hssk_memcpy_h2d(ctx, ds, hs.data(), (long long)(sizeof(double) * tot))) throw std::runtime_error(hssk_last_error());
+  c->reduce_scatter_sum(ds, offs.data(), cnts.data(), dr, stream);
+  if (hssk_memcpy_d2h(ctx, hr.data(), dr, (long long)(sizeof(double) * cnts[me]))) throw std::runtime_error(hssk_last_error());
+  for (long long i = 0; i < cnts[me]; i++) if (hr[i] != G * (G + 1) / 2. * (double)(offs[me] + i)) throw std::runtime_error("selftest: reduce-scatter mismatch");
+  SP_CATCH
+}
+int SPX_comm_size(const SPXComm c) { return c ? ((comm::RcclComm*)c)->world() : 1; }
+int SPX_comm_rank(const SPXComm c) { return c ? ((comm::RcclComm*)c)->rank() : 0; }
+int SPX_struct_shard_range(int n, const CSPOptions* opts, int world, int rank, int* lo, int* hi) {
+  SP_TRY
+  if (world < 1 || rank < 0 || rank >= world || (world & (world - 1))) throw std::invalid_argument("shard_range: world must be a power of two, 0 <= rank < world");
+  int c = 0;
+  while ((1 << c) < world) c++;
+  // the bisection of HSSMatrix(m, n, opts) (HSS/HSSMatrix.cpp:60-70): children of size m/2 and m - m/2 while m > leaf
+  int l = 0, m = n;
+  for (int lev = 0; lev < c; lev++) {
+    if (m <= opts->leaf_size) throw std::invalid_argument("shard_range: the tree is shallower than log2(world) levels");
+    const int m0 = m / 2;
+    if ((rank >> (c - 1 - lev)) & 1) { l += m0; m -= m0; } else m = m0;
+  }
+  *lo = l; *hi = l + m;
+  SP_CATCH
+}
+static int from_blocks(CSPStructMat* S, int rows, int cols, const double* dArows, long long ldr, const double* dAcols,
+                       long long ldc, const CSPOptions* opts, const SPXHSSOptions* h, const HSS::CommSpec& pg) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("sharded construction requires type SP_TYPE_HSS");
+  if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
+  auto ho = get_hss_options(opts, h);
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(rows, cols, ho));
+  H->compress_device_blocks(dArows, ldr, dAcols, ldc, ho, pg);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
+int SPX_d_struct_from_blocks_device(CSPStructMat* S, int rows, int cols, const double* dArows, long long ldr,
+                                    const double* dAcols, long long ldc, const CSPOptions* opts, const SPXHSSOptions* h,
+                                    SPXComm comm) {
+  SP_TRY
+  return from_blocks(S, rows, cols, dArows, ldr, dAcols, ldc, opts, h, native_group(comm));
+  SP_CATCH
+}
+int SPX_d_struct_from_blocks_device_cb(CSPStructMat* S, int rows, int cols, const double* dArows, long long ldr,
+                                       const double* dAcols, long long ldc, const CSPOptions* opts, const SPXHSSOptions* h,
+                                       int world, int rank, SPXAllGatherFn allgather, void* user) {
+  if (world < 1 || rank < 0 || rank >= world) return 1;
+  return from_blocks(S, rows, cols, dArows, ldr, dAcols, ldc, opts, h, callback_group(world, rank, allgather, user));
+}
+int SPX_d_struct_from_dense_device_comm(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
+                                        const CSPOptions* opts, const SPXHSSOptions* h, SPXComm comm) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("sharded construction requires type SP_TYPE_HSS");
+  if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
+  auto ho = get_hss_options(opts, h);
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(rows, cols, ho));
+  H->compress_device_sharded(dA, ldA, ho, native_group(comm));
   std::unique_ptr<CStructMat> s(new CStructMat);
   s->S.reset(H.release());
   *S = s.release();
@@ -220,7 +355,7 @@ int SPX_d_struct_stats(const CSPStructMat S, double* o) {
   o[19] = st.sketch_kernel_flops;
   o[20] = st.sketch_kernel_bytes;
   o[21] = st.b_solve; o[22] = st.b_mult;
-  o[23] = 0;
+  o[23] = st.t_comm;
   SP_CATCH
 }
 // ---- Schur complement of the (0,0) block (HSS only; HSSMatrix.Schur.hpp)

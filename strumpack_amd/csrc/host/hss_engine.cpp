@@ -11,6 +11,7 @@
 // batched kernel launch per step and tree height (cf. its own level-wise variant,
 // HSSMatrix.compress_stable.hpp:234-277).
 #include "hss_engine.hpp"
+#include "Comm.hpp"
 
 #include <atomic>
 #include <thread>
@@ -38,6 +39,19 @@ inline double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 }  // namespace
+
+void CommSpec::apply(EngineOptions& e) const {
+  e.world = world; e.rank = rank; e.comm_user = user;
+  e.allgather = nullptr; e.allgather_stream = nullptr; e.allreduce_stream = nullptr; e.reduce_scatter_stream = nullptr;
+  if (world <= 1) return;
+  if (native) {
+    e.allgather_stream = comm::rccl_allgather_hook;
+    e.allreduce_stream = comm::rccl_allreduce_hook;
+    e.reduce_scatter_stream = comm::rccl_reduce_scatter_hook;
+  } else {
+    e.allgather = allgather;
+  }
+}
 
 // host random stream of the reference (misc/RandomWrapper.hpp:128-191): engine seeded with 0
 struct HostRng {
@@ -229,6 +243,96 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
   }
 };
 
+// Sharded dense operand (one process per GPU, subtree ownership): this rank holds the columns [j0, j1) of its subtree
+// (n x nloc) and, optionally, the rows [j0, j1) (nloc x n) -- never the whole matrix.
+//   sketch:  Sc(j0:j1, :) = A(:, j0:j1)^H R                                   -- local
+//            Sr(j0:j1, :) = A(j0:j1, :) R                                     -- local when the row block is given, else
+//            Sr = sum_g A(:, cols_g) R(cols_g, :): every rank multiplies its column block with its rows of R and the
+//            partial N x d products are summed to the owners of the rows (reduce-scatter over xGMI, SURVEY.md 8(e)(5):
+//            the "reduce of off-diagonal contributions"; per-rank flops are the same 2 n nloc d either way)
+//   elements: blocks inside the subtree come from the column block; the coupling blocks of the replicated top nodes
+//            B01 = A(Ir_0, Ic_1) straddle the ranks: every rank fills in the rows (columns) it holds, zeros elsewhere,
+//            and the partial blocks are summed over the ranks (a few r x r blocks per top level)
+struct DeviceHSS::ShardedDenseSource : DeviceHSS::Source {
+  const double* dRows;
+  long long ldr;
+  const double* dCols;
+  long long ldc;
+  ShardedDenseSource(const double* r, long long lr, const double* c, long long lc) : dRows(r), ldr(lr), dCols(c), ldc(lc) {}
+  void sample(DeviceHSS& H, int r0, int dn) override {
+    const bool single = H.o_.world == 1;   // one rank: its "shard" is the whole operand (same code path, no collective)
+    if (!single && !H.dist_subtree_) throw std::invalid_argument("sharded operand: the tree cannot be cut into one subtree per rank (world must be a power of two and the tree complete down to that depth)");
+    if (H.sj_pat_) throw std::invalid_argument("sharded operand: the SJLT sketch needs the replicated-operand interface");
+    const long long N = H.n_;
+    const Node& c = H.nodes_[single ? 0 : H.cut_nodes_[H.o_.rank]];
+    const long long j0 = c.lo, nloc = c.m;
+    auto timed = [&] {
+      ck(hssk_sync(H.ctx_));
+      const float ms = hssk_last_dgemm_ms(H.ctx_);
+      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
+    };
+    ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dCols, ldc, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
+    timed();
+    if (dRows) {
+      ck(hssk_dgemm(H.ctx_, 1, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dRows, ldr, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
+      timed();
+    } else {
+      // P (dn x N) = R(cols, :)^T A(:, cols)^T : the contribution of this rank's columns to every row of Sr
+      H.tmp_->rewind();
+      double* P = H.tmp_->dbl((size_t)dn * N);
+      double* mineP = H.tmp_->dbl((size_t)dn * nloc);
+      ck(hssk_dgemm(H.ctx_, 1, dn, N, nloc, 1.0, H.Rt_ + r0 + j0 * H.dcap_, H.dcap_, dCols, ldc, 0.0, P, dn));
+      timed();
+      const double tc = now();
+      std::vector<long long> offs(H.o_.world), counts(H.o_.world);
+      for (int g = 0; g < H.o_.world; g++) {
+        const Node& cg = H.nodes_[single ? 0 : H.cut_nodes_[g]];
+        offs[g] = (long long)cg.lo * dn; counts[g] = (long long)cg.m * dn;
+      }
+      H.reduce_scatter_sum(P, offs, counts, mineP);
+      hssk_colgather_desc cp{mineP, H.Srt_ + r0 + j0 * H.dcap_, nullptr, dn, (int)nloc, dn, H.dcap_, 0};
+      ck(hssk_gather_cols(H.ctx_, &cp, 1));
+      ck(hssk_sync(H.ctx_));
+      H.stats_.t_comm += now() - tc;
+    }
+  }
+  void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
+    const Node& c = H.nodes_[H.o_.world == 1 ? 0 : H.cut_nodes_[H.o_.rank]];
+    const int j0 = c.lo, j1 = c.lo + c.m;
+    auto inside = [&](const std::vector<int>* h, int i0, int cnt) {
+      if (!h) return i0 >= j0 && i0 + cnt <= j1;
+      for (int i = 0; i < cnt; i++) if ((*h)[i] < j0 || (*h)[i] >= j1) return false;
+      return true;
+    };
+    std::vector<hssk_elem_desc> own, part, back;
+    size_t tot = 0;
+    for (auto& r : reqs) if (r.m > 0 && r.n > 0 && !(inside(r.hI, r.i0, r.m) && inside(r.hJ, r.j0, r.n))) tot += (size_t)r.m * r.n;
+    double* stage = tot ? H.comm_arena_->dbl(tot) : nullptr;
+    size_t off = 0;
+    for (auto& r : reqs) {
+      if (r.m <= 0 || r.n <= 0) continue;
+      if (inside(r.hI, r.i0, r.m) && inside(r.hJ, r.j0, r.n)) {
+        // column block addressed with global column indices: A'(i, j) = dCols[i + (j - j0) ldc]
+        own.push_back(hssk_elem_desc{dCols - (long long)j0 * ldc, ldc, r.dI, r.dJ, r.i0, r.j0, r.dB, r.m, r.n, r.ldb, 0, 0, 0, 0, 0});
+      } else {
+        double* T = stage + off;
+        off += (size_t)r.m * r.n;
+        if (dRows) part.push_back(hssk_elem_desc{dRows - j0, ldr, r.dI, r.dJ, r.i0, r.j0, T, r.m, r.n, r.m, 0, j0, j1, 0, 0});
+        else part.push_back(hssk_elem_desc{dCols - (long long)j0 * ldc, ldc, r.dI, r.dJ, r.i0, r.j0, T, r.m, r.n, r.m, 0, 0, 0, j0, j1});
+        back.push_back(hssk_elem_desc{T, r.m, nullptr, nullptr, 0, 0, r.dB, r.m, r.n, r.ldb, 0, 0, 0, 0, 0});
+      }
+    }
+    if (!own.empty()) ck(hssk_gather_elems(H.ctx_, own.data(), (int)own.size()));
+    if (!part.empty()) {
+      const double tc = now();
+      ck(hssk_gather_elems(H.ctx_, part.data(), (int)part.size()));
+      H.allreduce_sum(stage, (long long)tot);
+      ck(hssk_gather_elems(H.ctx_, back.data(), (int)back.size()));
+      H.stats_.t_comm += now() - tc;
+    }
+  }
+};
+
 struct DeviceHSS::CallbackSource : DeviceHSS::Source {
   const host_mult_t& mult;
   const host_elem_t& elem;
@@ -370,11 +474,66 @@ void DeviceHSS::setup_ownership() {
   split(by_depth_, own_by_depth_, top_by_depth_);
 }
 
+// STRUMPACK_AMD_TIME_COMM=1: bracket every collective with stream synchronisations and add its wall time to
+// stats().t_comm (diagnostic: the stream-ordered collectives are otherwise invisible to the host clock)
+static bool time_comm() {
+  const char* e = std::getenv("STRUMPACK_AMD_TIME_COMM");
+  return e && e[0] == '1';
+}
+
 void DeviceHSS::comm(void* dbuf, long long bytes_per_rank) {
   if (o_.world <= 1) return;
+  if (o_.allgather_stream) {   // RCCL on the engine's stream: ordered with the kernels, no host synchronisation
+    if (time_comm()) {
+      ck(hssk_sync(ctx_));
+      const double t0 = now();
+      o_.allgather_stream(o_.comm_user, dbuf, bytes_per_rank, hssk_ctx_stream(ctx_));
+      ck(hssk_sync(ctx_));
+      stats_.t_comm += now() - t0;
+      return;
+    }
+    o_.allgather_stream(o_.comm_user, dbuf, bytes_per_rank, hssk_ctx_stream(ctx_));
+    return;
+  }
   if (!o_.allgather) throw std::logic_error("multi-GPU operation needs an all-gather hook");
   ck(hssk_sync(ctx_));
   o_.allgather(o_.comm_user, dbuf, bytes_per_rank);
+}
+
+// dbuf[0:count) <- sum over the ranks
+void DeviceHSS::allreduce_sum(double* dbuf, long long count) {
+  if (o_.world <= 1 || count <= 0) return;
+  if (o_.allreduce_stream) { o_.allreduce_stream(o_.comm_user, dbuf, count, hssk_ctx_stream(ctx_)); return; }
+  // all-gather hook only: gather every rank's partial block, sum locally
+  double* slabs = comm_arena_->dbl((size_t)count * o_.world);
+  ck(hssk_memcpy_d2d(ctx_, slabs + (size_t)count * o_.rank, dbuf, (long long)sizeof(double) * count));
+  comm(slabs, (long long)sizeof(double) * count);
+  ck(hssk_sum_slabs(ctx_, slabs, count, count, o_.world, dbuf));
+}
+
+// recv[0:counts[me]) <- sum over the ranks of send[offs[me] : offs[me] + counts[me])
+void DeviceHSS::reduce_scatter_sum(const double* send, const std::vector<long long>& offs, const std::vector<long long>& counts,
+                                   double* recv) {
+  const int me = o_.rank;
+  if (o_.world <= 1) { ck(hssk_memcpy_d2d(ctx_, recv, send + offs[me], (long long)sizeof(double) * counts[me])); return; }
+  if (o_.reduce_scatter_stream) {
+    o_.reduce_scatter_stream(o_.comm_user, send, offs.data(), counts.data(), recv, hssk_ctx_stream(ctx_));
+    return;
+  }
+  // all-gather hook only: every rank publishes the slice each other rank needs (padded to the largest slice)
+  long long cmax = 0;
+  for (long long c : counts) cmax = std::max(cmax, c);
+  const int G = o_.world;
+  // slab layout: [destination g][source rank] blocks of cmax doubles; one all-gather per destination keeps the hook simple
+  double* slabs = comm_arena_->dbl((size_t)cmax * G);
+  for (int g = 0; g < G; g++) {
+    if (counts[g] <= 0) continue;
+    ck(hssk_memset_zero(ctx_, slabs + (size_t)cmax * me, (long long)sizeof(double) * cmax));
+    ck(hssk_memcpy_d2d(ctx_, slabs + (size_t)cmax * me, send + offs[g], (long long)sizeof(double) * counts[g]));
+    comm(slabs, (long long)sizeof(double) * cmax);
+    if (g == me) ck(hssk_sum_slabs(ctx_, slabs, counts[g], cmax, G, recv));
+    ck(hssk_sync(ctx_));
+  }
 }
 
 // v holds world * per_rank ints; this rank's block is valid on entry, all blocks on return
@@ -612,6 +771,18 @@ void DeviceHSS::compress_dense_host(const double* A, long long lda) {
     ck(hssk_sync(ctx_));
   } catch (...) { hssk_free(dA); throw; }
   hssk_free(dA);
+}
+void DeviceHSS::compress_dense_device_sharded(const double* dRows, long long ldr, const double* dCols, long long ldc) {
+  if (!dCols) throw std::invalid_argument("sharded operand: the column block is required");
+  ShardedDenseSource s(dRows, ldr, dCols, ldc);
+  compress(s);
+}
+bool DeviceHSS::shard_range(int rank, int& lo, int& hi) const {
+  if (o_.world == 1) { lo = 0; hi = n_; return true; }
+  if (!dist_subtree_ || rank < 0 || rank >= (int)cut_nodes_.size()) return false;
+  lo = nodes_[cut_nodes_[rank]].lo;
+  hi = lo + nodes_[cut_nodes_[rank]].m;
+  return true;
 }
 void DeviceHSS::compress_callbacks(const host_mult_t& mult, const host_elem_t& elem) {
   CallbackSource s(mult, elem);

@@ -43,6 +43,23 @@ struct EngineOptions {
   int world = 1, rank = 0;
   void (*allgather)(void* user, void* dbuf, long long bytes_per_rank) = nullptr;
   void* comm_user = nullptr;
+  // stream-ordered collectives (native RCCL, Comm.hpp): issued on the engine's own stream, no host synchronisation.
+  // When allgather_stream is null the host-synchronous `allgather` callback above is used and the two reductions are
+  // emulated with it (all-gather of the partial blocks + a local sum).
+  void (*allgather_stream)(void* user, void* dbuf, long long bytes_per_rank, void* stream) = nullptr;
+  void (*allreduce_stream)(void* user, double* buf, long long count, void* stream) = nullptr;
+  void (*reduce_scatter_stream)(void* user, const double* send, const long long* offs, const long long* counts, double* recv,
+                                void* stream) = nullptr;
+};
+
+// process group of a multi-GPU matrix: either the native RCCL communicator (Comm.hpp; collectives on the engine's stream)
+// or a host-synchronous all-gather callback (gloo in the CPU tests, torch.distributed in dist.py)
+struct CommSpec {
+  int world = 1, rank = 0;
+  void (*allgather)(void*, void*, long long) = nullptr;
+  void* user = nullptr;
+  bool native = false;   // user is a comm::RcclComm*
+  void apply(EngineOptions& e) const;
 };
 
 // host callbacks of the matrix-free / element interfaces (column-major host buffers)
@@ -51,6 +68,7 @@ using host_elem_t = std::function<void(int m, const int* I, int n, const int* J,
 
 struct PhaseStats {
   double t_compress = 0, t_sketch = 0, t_random = 0, t_tree = 0, t_factor = 0, t_solve = 0, t_mult = 0;
+  double t_comm = 0;   // host-side time spent in the collectives of the compression (multi-GPU)
   double sketch_kernel_ms = 0;  // sum of HIP-event durations of the sketch GEMM main launches
   double sketch_kernel_flops = 0;  // algorithmic flops of those launches
   double sketch_kernel_bytes = 0;  // SJLT sketch: algorithmic HBM bytes of those launches (8 per element of A read)
@@ -74,6 +92,12 @@ class DeviceHSS {
   // ---- construction (compression) ----
   void compress_dense_device(const double* dA, long long lda);       // A resident in HBM
   void compress_dense_host(const double* A, long long lda);          // uploads A, then the above
+  // multi-GPU, sharded operand: this rank holds the rows and / or the columns [lo, hi) of its subtree (shard_range()):
+  // dRows = A(lo:hi, :) ((hi-lo) x n, ldr) or null, dCols = A(:, lo:hi) (n x (hi-lo), ldc).  Without the row block
+  // the operator is column-sharded: Sr = sum_g A(:, cols_g) R(cols_g, :) is reduced over the ranks.
+  void compress_dense_device_sharded(const double* dRows, long long ldr, const double* dCols, long long ldc);
+  // rows / columns [lo, hi) owned by `rank` (its subtree below the cut); false if the tree cannot be cut for this world size
+  bool shard_range(int rank, int& lo, int& hi) const;
   void compress_callbacks(const host_mult_t& mult, const host_elem_t& elem);  // matrix-free
   // kernel matrix over points X (host, d x n, already in tree order); user_ann (k x n, optional) replaces the
   // device nearest-neighbour search of the first round (tests pin the compression against the reference's lists)
@@ -172,6 +196,7 @@ class DeviceHSS {
  private:
   struct Source;
   struct DenseDeviceSource;
+  struct ShardedDenseSource;
   struct CallbackSource;
 
   void build_tree(const structured::ClusterTree* tree);
@@ -218,6 +243,8 @@ class DeviceHSS {
   bool mine(int id) const { return owner_[id] < 0 || owner_[id] == o_.rank; }
   void setup_ownership();
   void comm(void* dbuf, long long bytes_per_rank);
+  void allreduce_sum(double* dbuf, long long count);
+  void reduce_scatter_sum(const double* send, const std::vector<long long>& offs, const std::vector<long long>& counts, double* recv);
   void allgather_ints(std::vector<int>& v, int per_rank);
   void exchange_cut_compress(int dtot);
   bool exchange_cut_kernel(std::vector<std::vector<int>>& cols, bool failed);

@@ -11,14 +11,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // Toeplitz test matrix (test/test_HSS_seq.cpp:75-78, :86-90), generated in place in HBM.
 // ------------------------------------------------------------------------------------------------
-__global__ void fill_toeplitz_kernel(double* __restrict__ A, int n, long long lda, int upper) {
-  // grid: (ceil(n/256), n): blockIdx.y = column, x covers rows -> coalesced column writes
-  int j = blockIdx.y;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+__global__ void fill_toeplitz_kernel(double* __restrict__ A, int rows, long long lda, int upper, int i0, int j0) {
+  // grid: (ceil(rows/256), cols): blockIdx.y = column, x covers rows -> coalesced column writes
+  const int jl = blockIdx.y, j = j0 + jl;
+  for (int il = blockIdx.x * blockDim.x + threadIdx.x; il < rows; il += gridDim.x * blockDim.x) {
+    const int i = i0 + il;
     int dij = i > j ? i - j : j - i;
     double v = 1.0 / (1.0 + (double)dij);
     if (upper && i > j) v = 0.;
-    A[i + (size_t)j * lda] = v;
+    A[il + (size_t)jl * lda] = v;
   }
 }
 
@@ -106,13 +107,23 @@ __global__ void gather_elems_kernel(const hssk_elem_desc* __restrict__ descs, co
   int jend = min(p.n, (w.chunk + 1) * COLS_PER_WG);
   for (int j = w.chunk * COLS_PER_WG; j < jend; j++) {
     long long gj = p.J ? p.J[j] : (p.j0 + j);
-    const double* col = p.A + (size_t)gj * p.lda;
+    const bool cin = p.chi <= p.clo || (gj >= p.clo && gj < p.chi);
+    const double* col = p.A + (long long)gj * p.lda;
     for (int i = threadIdx.x; i < p.m; i += blockDim.x) {
       long long gi = p.I ? p.I[i] : (p.i0 + i);
-      double v = col[gi];
+      const bool rin = p.rhi <= p.rlo || (gi >= p.rlo && gi < p.rhi);
+      double v = (cin && rin) ? col[gi] : 0.;
       if (p.transpose) p.B[j + (size_t)i * p.ldb] = v;
       else p.B[i + (size_t)j * p.ldb] = v;
     }
+  }
+}
+
+__global__ void sum_slabs_kernel(const double* __restrict__ slabs, long long count, long long stride, int nslab, double* __restrict__ out) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x) {
+    double s = 0.;
+    for (int g = 0; g < nslab; g++) s += slabs[(size_t)g * stride + e];
+    out[e] = s;
   }
 }
 
@@ -243,7 +254,16 @@ int hssk_fill_toeplitz(hssk_ctx* ctx, double* A, int n, long long lda, char kind
   HSSK_API_BEGIN
   if (n <= 0) return 0;
   dim3 grid((unsigned)std::min(64, (n + 255) / 256), (unsigned)n);
-  HSSK_LAUNCH(fill_toeplitz_kernel, grid, dim3(256), 0, ctx->stream, A, n, lda, (int)(kind == 'U'));
+  HSSK_LAUNCH(fill_toeplitz_kernel, grid, dim3(256), 0, ctx->stream, A, n, lda, (int)(kind == 'U'), 0, 0);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_fill_toeplitz_block(hssk_ctx* ctx, double* A, int rows, int cols, long long lda, int i0, int j0, char kind) {
+  HSSK_API_BEGIN
+  if (rows <= 0 || cols <= 0) return 0;
+  dim3 grid((unsigned)std::min(64, (rows + 255) / 256), (unsigned)cols);
+  HSSK_LAUNCH(fill_toeplitz_kernel, grid, dim3(256), 0, ctx->stream, A, rows, lda, (int)(kind == 'U'), i0, j0);
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -299,6 +319,15 @@ int hssk_gather_elems(hssk_ctx* ctx, const hssk_elem_desc* descs, int count) {
   auto* dd = (const hssk_elem_desc*)ctx->stage(descs, sizeof(*descs) * count);
   auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
   HSSK_LAUNCH(gather_elems_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_sum_slabs(hssk_ctx* ctx, const double* slabs, long long count, long long stride, int nslab, double* out) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  const unsigned nb = (unsigned)std::min<long long>((count + 255) / 256, 4096);
+  HSSK_LAUNCH(sum_slabs_kernel, dim3(nb), dim3(256), 0, ctx->stream, slabs, count, stride, nslab, out);
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -94,6 +94,64 @@ def make_exchange(lib, world, rank):
     return capi.ALLGATHER_CB(allgather)
 
 
+class NativeComm:
+    """The library's own RCCL communicator (SPX_comm_*, csrc/host/Comm.cpp): the engine issues its collectives on its own
+    HIP stream -- no Python callback, no torch synchronisation.  torch.distributed is used once, to hand rank 0's unique
+    id to the other ranks."""
+
+    def __init__(self, lib):
+        import torch.distributed as dist
+        self.lib = lib
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        box = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            if lib.SPX_comm_unique_id(buf):
+                raise RuntimeError("SPX_comm_unique_id failed")
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0)
+        self.h = C.c_void_p()
+        if lib.SPX_comm_create(C.byref(self.h), self.world, self.rank, box[0]):
+            raise RuntimeError("SPX_comm_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.SPX_comm_destroy(C.byref(self.h))
+
+
+def shard_range(lib, n, opts, world, rank):
+    """rows == columns [lo, hi) of the n x n operand that `rank` has to hold"""
+    lo, hi = C.c_int(), C.c_int()
+    if lib.SPX_struct_shard_range(n, C.byref(opts), world, rank, C.byref(lo), C.byref(hi)):
+        raise RuntimeError("SPX_struct_shard_range failed (world must be a power of two and the tree deep enough)")
+    return lo.value, hi.value
+
+
+def from_blocks_device(lib, d_rows, ldr, d_cols, ldc, n, opts, hss, comm=None, exchange_cb=None, world=None, rank=None):
+    """HSS construction from this rank's shard of the operand: row block A[lo:hi, :] (device pointer or None for a
+    column-sharded operator) and column block A[:, lo:hi]; `comm` = NativeComm, or an all-gather callback (gloo tests)."""
+    h = C.c_void_p()
+    if comm is not None:
+        rc = lib.SPX_d_struct_from_blocks_device(C.byref(h), n, n, d_rows, ldr, d_cols, ldc, C.byref(opts), C.byref(hss), comm.h)
+    else:
+        import torch.distributed as dist
+        world = dist.get_world_size() if world is None else world
+        rank = dist.get_rank() if rank is None else rank
+        rc = lib.SPX_d_struct_from_blocks_device_cb(C.byref(h), n, n, d_rows, ldr, d_cols, ldc, C.byref(opts), C.byref(hss),
+                                                    world, rank, exchange_cb, None)
+    if rc:
+        raise RuntimeError("SPX_d_struct_from_blocks_device failed")
+    return capi.StructuredMatrix(lib, h, n)
+
+
+def from_dense_device_comm(lib, dptr, n, lda, opts, hss, comm):
+    """replicated operand, native communicator"""
+    h = C.c_void_p()
+    if lib.SPX_d_struct_from_dense_device_comm(C.byref(h), n, n, dptr, lda, C.byref(opts), C.byref(hss), comm.h):
+        raise RuntimeError("SPX_d_struct_from_dense_device_comm failed")
+    return capi.StructuredMatrix(lib, h, n)
+
+
 def from_dense_device(lib, dptr, n, lda, opts, hss, exchange_cb=None, world=None, rank=None):
     """HSS construction from a device-resident dense matrix; sharded over the process group when an
     exchange callback is given."""
@@ -115,14 +173,18 @@ KERNEL_TYPES = {"Gauss": 0, "Laplace": 1, "ANOVA": 2}
 
 
 def from_kernel(lib, X, opts, kernel="Gauss", h=1.0, lam=0.0, degree=1, clustering="2means", neighbors=64,
-                exchange_cb=None, world=None, rank=None):
+                exchange_cb=None, world=None, rank=None, comm=None):
     """HSS approximation of the kernel matrix over the rows of X (n x d, host); sharded over the process group when an
-    exchange callback is given (every rank passes the same X).  Returns (matrix, points in cluster order, 1-based perm)."""
+    exchange callback or a NativeComm is given (every rank passes the same X).  Returns (matrix, points in cluster order,
+    1-based perm)."""
     Xp = np.ascontiguousarray(X, dtype=np.float64).copy()
     n, d = Xp.shape
     perm = np.zeros(n, dtype=np.int32)
     hnd = C.c_void_p()
-    if exchange_cb is None:
+    if comm is not None:
+        rc = lib.SPX_d_struct_from_kernel_comm(C.byref(hnd), n, d, Xp.ctypes.data, KERNEL_TYPES[kernel], h, lam, degree,
+                                               C.byref(opts), CLUSTERING[clustering], neighbors, perm.ctypes.data, comm.h)
+    elif exchange_cb is None:
         rc = lib.SPX_d_struct_from_kernel(C.byref(hnd), n, d, Xp.ctypes.data, KERNEL_TYPES[kernel], h, lam, degree,
                                           C.byref(opts), CLUSTERING[clustering], neighbors, perm.ctypes.data)
     else:

@@ -48,6 +48,35 @@ for (n, leaf, d0, dd, algo, sketch) in CASES[world]:
         print("rank", rank, "case", n, leaf, algo, same_tree, e_mult, e_multT, e_solve, res, flush=True)
     ok = ok and good
     H.destroy(); H1.destroy()
+# sharded operand: every rank passes only its row block + column block, or only its column block (column-sharded operator:
+# the Sr contributions are reduced over the ranks); must reproduce the single-process matrix built from the whole A
+BCASES = {2: [(120, 16, 16, 8, "stable", True), (120, 16, 16, 8, "stable", False), (75, 8, 8, 8, "original", False)],
+          4: [(140, 16, 8, 8, "stable", True), (140, 16, 8, 8, "stable", False)], 3: []}
+for (n, leaf, d0, dd, algo, with_rows) in BCASES[world]:
+    A = O.toeplitz(n) + 0.01 * np.random.default_rng(2).standard_normal((n, n))     # unsymmetric: rows and columns differ
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo)
+    lo, hi = sdist.shard_range(L, n, o, world, rank)
+    dR = hk.array(np.asfortranarray(A[lo:hi, :])) if with_rows else None
+    dC = hk.array(np.asfortranarray(A[:, lo:hi]))
+    ex = sdist.make_exchange(L, world, rank)
+    H = sdist.from_blocks_device(L, dR.ptr if with_rows else None, hi - lo, dC.ptr, n, n, o, h, exchange_cb=ex)
+    dA = hk.array(A)
+    H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
+    B = np.random.default_rng(5).standard_normal((n, 2))
+    same_tree = np.array_equal(H.node_info(), H1.node_info())
+    y, y1 = H.mult(B), H1.mult(B)
+    yt, yt1 = H.mult(B, "T"), H1.mult(B, "T")
+    H.factor(); H1.factor()
+    x, x1 = H.solve(B), H1.solve(B)
+    e_mult = np.linalg.norm(y - y1) / np.linalg.norm(y1)
+    e_multT = np.linalg.norm(yt - yt1) / np.linalg.norm(yt1)
+    e_solve = np.linalg.norm(x - x1) / np.linalg.norm(x1)
+    good = same_tree and e_mult < 1e-10 and e_multT < 1e-10 and e_solve < 1e-8
+    if not good:
+        print("rank", rank, "block case", n, leaf, algo, with_rows, same_tree, e_mult, e_multT, e_solve, flush=True)
+    ok = ok and good
+    H.destroy(); H1.destroy()
 # kernel-matrix front end: subtree ownership (natural / kd trees are balanced -> cut exists), replicated otherwise
 KCASES = {2: [(100, 16, "kdtree", "Gauss")], 4: [(100, 16, "natural", "Laplace")], 3: []}
 for (n, leaf, clus, kern) in KCASES[world]:

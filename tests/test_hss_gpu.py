@@ -1,6 +1,8 @@
 """GPU parity tests of the HSS hot path (product library, hand-written HIP kernels) through the
 reference's C interface: the reference's whole CTest sweep for test_HSS_seq against fixtures generated
 by the reference itself, BASELINE.json configs 1/2, and size-independent properties at full size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -167,3 +169,110 @@ def test_rccl_exchange_hook_single_rank():
         assert np.linalg.norm(H.mult(x)[:, 0] - O.toeplitz(n) @ x) / np.linalg.norm(x) < 1e-4
     finally:
         dist.destroy_process_group()
+
+
+def test_native_comm_and_sharded_operand_single_rank(L):
+    """The library's own RCCL communicator (SPX_comm_*) with one rank on the one GPU of the test box: the collectives'
+    self test, then the sharded-operand construction through both of its sketch paths (row block + column block; column
+    block only, i.e. the reduce-scatter route) against the plain device construction."""
+    import ctypes as C
+    import numpy as np
+    from strumpack_amd import _loader, dist as sdist, hssk as K
+    from oracle import hss_oracle as O
+    buf = C.create_string_buffer(128)
+    assert L.SPX_comm_unique_id(buf) == 0
+    h = C.c_void_p()
+    assert L.SPX_comm_create(C.byref(h), 1, 0, buf.raw) == 0
+    assert L.SPX_comm_size(h) == 1 and L.SPX_comm_rank(h) == 0
+    assert L.SPX_comm_selftest(h) == 0
+
+    class Comm:
+        pass
+    comm = Comm()
+    comm.h = h
+    hk = K.Hssk(_loader.lib_path())
+    n = 3000
+    A = O.toeplitz(n) + 0.01 * np.random.default_rng(3).standard_normal((n, n))
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=128)
+    ho = capi.StructuredMatrix.hss_options(L)
+    lo, hi = sdist.shard_range(L, n, o, 1, 0)
+    assert (lo, hi) == (0, n)
+    dA = hk.array(A)
+    H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, ho)
+    B = np.random.default_rng(4).standard_normal((n, 2))
+    y1 = H1.mult(B)
+    for with_rows in (True, False):
+        H = sdist.from_blocks_device(L, dA.ptr if with_rows else None, n, dA.ptr, n, n, o, ho, comm=comm)
+        assert np.array_equal(H.node_info(), H1.node_info())
+        assert np.linalg.norm(H.mult(B) - y1) <= 1e-10 * np.linalg.norm(y1)
+        H.factor()
+        x = H.solve(B)
+        assert np.linalg.norm(H.mult(x) - B) <= 1e-12 * np.linalg.norm(B)
+        H.destroy()
+    H1.destroy()
+    hk.close()
+    L.SPX_comm_destroy(C.byref(h))
+
+
+RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+os.environ["STRUMPACK_AMD_DEVICE"] = str(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+from strumpack_amd import _loader, capi, dist as sdist, hssk as K
+from oracle import hss_oracle as O
+L = capi.load(_loader.lib_path())
+hk = K.Hssk(_loader.lib_path(), device=rank)
+comm = sdist.NativeComm(L)
+ok = L.SPX_comm_selftest(comm.h) == 0
+n = 6000
+A = O.toeplitz(n) + 0.01 * np.random.default_rng(3).standard_normal((n, n))
+o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=128)
+ho = capi.StructuredMatrix.hss_options(L)
+lo, hi = sdist.shard_range(L, n, o, world, rank)
+dR = hk.array(np.asfortranarray(A[lo:hi, :]))
+dC = hk.array(np.asfortranarray(A[:, lo:hi]))
+dA = hk.array(A)
+H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, ho)
+B = np.random.default_rng(4).standard_normal((n, 2))
+y1 = H1.mult(B)
+H1.factor()
+x1 = H1.solve(B)
+for with_rows in (True, False):
+    H = sdist.from_blocks_device(L, dR.ptr if with_rows else None, hi - lo, dC.ptr, n, n, o, ho, comm=comm)
+    ok = ok and np.array_equal(H.node_info(), H1.node_info())
+    ok = ok and np.linalg.norm(H.mult(B) - y1) <= 1e-10 * np.linalg.norm(y1)
+    H.factor()
+    x = H.solve(B)
+    ok = ok and np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
+    H.destroy()
+Hr = sdist.from_dense_device_comm(L, dA.ptr, n, n, o, ho, comm)      # replicated operand, native collectives
+ok = ok and np.linalg.norm(Hr.mult(B) - y1) <= 1e-10 * np.linalg.norm(y1)
+t = torch.tensor([float(ok)], device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
+if rank == 0:
+    print("RCCL_OK" if t.item() == 1.0 else "RCCL_FAIL", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_native_rccl_two_ranks(tmp_path):
+    """world_size 2 over RCCL / xGMI when the box has two GPUs (skipped on the one-GPU test boxes): sharded operand, both
+    sketch paths, replicated operand, against the single-process matrix."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % {"root": root})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="2"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "RCCL_OK" in outs[0], "\n".join(outs)
