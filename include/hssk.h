@@ -55,6 +55,17 @@ int hssk_memcpy2d_h2d(hssk_ctx* ctx, void* dst, long long dpitch, const void* sr
 int hssk_memcpy2d_d2h(hssk_ctx* ctx, void* dst, long long dpitch, const void* src, long long spitch,
                       long long width, long long height);
 int hssk_memset_zero(hssk_ctx* ctx, void* dst, long long bytes); /* async */
+/* Pipelined upload of a column-major block of doubles (rows x cols, host leading dimension lds, device leading dimension
+ * ldd) on the context's COPY stream, so that it overlaps the kernels of the compute stream: pageable host memory goes
+ * through a ring of pinned bounce buffers filled by host threads (the call returns when the last piece is queued), pinned
+ * host memory is read by the DMA engines in place.  hssk_copy_fence: work enqueued on the compute stream afterwards waits
+ * for the uploads issued so far; hssk_compute_fence: uploads issued afterwards wait for the compute work enqueued so far
+ * (before a device buffer is overwritten).  Serves the streaming sampler of a host-resident operand
+ * (structured/StructuredMatrix.cpp:214-262 never stores A either). */
+int hssk_h2d_block_async(hssk_ctx* ctx, double* dst, long long ldd, const double* src, long long lds, long long rows,
+                         long long cols);
+int hssk_copy_fence(hssk_ctx* ctx);
+int hssk_compute_fence(hssk_ctx* ctx);
 /* 1 if ptr is device memory of the current process (hipPointerGetAttributes) */
 int hssk_is_device_pointer(const void* ptr);
 /* duration (HIP events on the launch stream, ms) and algorithmic flops (2 m cols k) of the MAIN kernel launch of

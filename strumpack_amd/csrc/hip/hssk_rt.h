@@ -45,6 +45,14 @@ inline event_t event_create() { event_t e; HSSK_CHECK(hipEventCreate(&e)); retur
 inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
 inline void event_record(event_t e, stream_t s) { HSSK_CHECK(hipEventRecord(e, s)); }
 inline float event_elapsed_ms(event_t a, event_t b) { float ms = 0; HSSK_CHECK(hipEventSynchronize(b)); HSSK_CHECK(hipEventElapsedTime(&ms, a, b)); return ms; }
+inline void stream_wait_event(stream_t s, event_t e) { HSSK_CHECK(hipStreamWaitEvent(s, e, 0)); }
+inline void event_sync(event_t e) { HSSK_CHECK(hipEventSynchronize(e)); }
+// host memory that the DMA engines can read directly (hipHostMalloc / hipHostRegister)
+inline bool is_pinned_host_pointer(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
 inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void set_device(int d) { HSSK_CHECK(hipSetDevice(d)); }
 inline bool is_device_pointer(const void* p) {

@@ -4,6 +4,8 @@
 #include <chrono>
 #include <fstream>
 
+#include <mutex>
+#include <exception>
 #include "HSSMatrix.hpp"
 #include "Kernel.hpp"
 #include "NeighborSearch.hpp"
@@ -173,6 +175,47 @@ void HSSMatrix<double>::compress(const mult_t& Amult, const elem_t& Aelem, const
   };
   (void)N;
   eng_->compress_callbacks(hm, he);
+}
+
+void HSSMatrix<double>::compress_from_elements(const elem_t& Aelem, const opts_t& opts) {
+  make_engine(opts, tree_.get());
+  const std::size_t N = rows_;
+  host_elem_t he = [&](int m, const int* I, int n, const int* J, double* B, int ldb) {
+    std::vector<std::size_t> Iv(I, I + m), Jv(J, J + n);
+    DenseM_t Bm(m, n);
+    Aelem(Iv, Jv, Bm);
+    for (int j = 0; j < n; j++) std::memcpy(B + (size_t)j * ldb, Bm.ptr(0, j), sizeof(double) * m);
+  };
+  // A(:, c0:c1) in 1024 x 1024 tiles, tiles in parallel on the host threads (the reference evaluates its tiles from
+  // concurrent OpenMP tasks, StructuredMatrix.cpp:226-233)
+  DeviceHSS::host_fill_t fill = [&](long long c0, long long c1, double* dst) {
+    const std::size_t T = 1024;
+    const std::size_t tr = (N + T - 1) / T, tc = (std::size_t(c1 - c0) + T - 1) / T;
+    std::atomic<std::size_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    auto work = [&] {
+      try {
+        for (std::size_t t = next++; t < tr * tc; t = next++) {
+          const std::size_t i0 = (t % tr) * T, j0 = std::size_t(c0) + (t / tr) * T;
+          const std::size_t mb = std::min(T, N - i0), nbk = std::min(T, std::size_t(c1) - j0);
+          std::vector<std::size_t> I(mb), J(nbk);
+          for (std::size_t i = 0; i < mb; i++) I[i] = i0 + i;
+          for (std::size_t j = 0; j < nbk; j++) J[j] = j0 + j;
+          DenseM_t Tm(mb, nbk);
+          Aelem(I, J, Tm);
+          for (std::size_t j = 0; j < nbk; j++) std::memcpy(dst + i0 + (j0 - std::size_t(c0) + j) * N, Tm.ptr(0, j), sizeof(double) * mb);
+        }
+      } catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
+    };
+    const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<std::size_t>(nt, tr * tc); t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+  };
+  eng_->compress_host_blocks(fill, he);
 }
 
 std::size_t HSSMatrix<double>::memory() const { return eng_ ? std::size_t(eng_->memory()) : 0; }

@@ -91,6 +91,9 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
 
   void compress(const DenseM_t& A, const opts_t& opts);
   void compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts);
+  // extension: operand given by element evaluation only -- the columns are evaluated in blocks on the host threads and
+  // streamed through the device (the reference's tile sampler, structured/StructuredMatrix.cpp:214-262)
+  void compress_from_elements(const elem_t& Aelem, const opts_t& opts);
   void compress(const kernel::Kernel<double>& K, const opts_t& opts);
   // extension (tests): the neighbour lists of the first round are given (k x n, 0-based, column i = point i)
   void compress_with_neighbors(const kernel::Kernel<double>& K, const opts_t& opts, const int* ann, int k);

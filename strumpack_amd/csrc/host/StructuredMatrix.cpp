@@ -52,21 +52,13 @@ std::unique_ptr<StructuredMatrix<double>> construct_from_elements(int rows, int 
                                                                   const StructuredOptions<double>& opts, const ClusterTree* row_tree,
                                                                   const ClusterTree*, const admissibility_t*, const DenseMatrix<double>*) {
   require_hss(opts.type(), rows, cols);
-  // The reference samples A on the fly in B x B tiles (StructuredMatrix.cpp:214-262); here the tiles
-  // are evaluated once into a dense host image, which then takes the device route (N^2 doubles).
-  DenseMatrix<double> Ad(rows, cols);
-  const std::size_t B = 1024;
-  for (std::size_t j0 = 0; j0 < std::size_t(cols); j0 += B)
-    for (std::size_t i0 = 0; i0 < std::size_t(rows); i0 += B) {
-      std::size_t mb = std::min(B, rows - i0), nb = std::min(B, cols - j0);
-      std::vector<std::size_t> I(mb), J(nb);
-      for (std::size_t i = 0; i < mb; i++) I[i] = i0 + i;
-      for (std::size_t j = 0; j < nb; j++) J[j] = j0 + j;
-      DenseMatrix<double> T(mb, nb);
-      A(I, J, T);
-      for (std::size_t j = 0; j < nb; j++) std::memcpy(Ad.ptr(i0, j0 + j), T.ptr(0, j), sizeof(double) * mb);
-    }
-  return construct_from_dense<double>(Ad, opts, row_tree, nullptr, nullptr);
+  // The reference samples A on the fly in B x B tiles and never stores it (StructuredMatrix.cpp:214-262); here the column
+  // blocks are evaluated tile by tile on the host threads and streamed through the device, uploads overlapped with the
+  // sketch GEMMs (DeviceHSS::HostBlockSource) -- no N^2 image on either side.
+  HSS::HSSOptions<double> ho;
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new_hss(rows, opts, row_tree, ho));
+  H->compress_from_elements(A, ho);
+  return std::unique_ptr<StructuredMatrix<double>>(H.release());
 }
 
 template <>

@@ -333,6 +333,93 @@ struct DeviceHSS::ShardedDenseSource : DeviceHSS::Source {
   }
 };
 
+// Host-resident operand, streamed: column blocks A(:, c0:c1) cross PCIe once per sampling round through two device
+// buffers; the upload of block b+1 (copy stream, pinned bounce buffers filled by host threads) overlaps the two sketch
+// GEMMs of block b (compute stream):
+//   Sc(c0:c1, :)  = A(:, c0:c1)^H R            -- complete for these columns
+//   Sr(:, :)     += A(:, c0:c1) R(c0:c1, :)    -- the block's contribution to every row
+// The diagonal blocks and the coupling blocks are read from the host operand afterwards (contiguous 2-D copies, resp. a
+// multi-threaded host gather of the few scattered entries + one upload).  At most 2 x n x nb doubles of A are in HBM.
+struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
+  const double* hA;        // column-major host matrix, or null when `fill` evaluates the columns
+  long long lda;
+  const host_fill_t* fill;
+  const host_elem_t* elem;
+  double* dBuf[2] = {nullptr, nullptr};
+  long long nb = 0;
+  int gen = -1;   // compression attempt the buffers were carved in (a restart resets the work arena)
+  HostBlockSource(const double* a, long long l, const host_fill_t* f, const host_elem_t* e) : hA(a), lda(l), fill(f), elem(e) {}
+  void sample(DeviceHSS& H, int r0, int dn) override {
+    if (H.o_.world > 1) throw std::invalid_argument("host-resident operands are single-GPU (use the device / sharded interfaces)");
+    // (an SJLT sketching matrix is applied in its dense form here -- Rt_ holds it, DeviceHSS::fill_random: the streaming
+    // SJLT kernels overwrite their output, the blocks of a streamed operand have to accumulate)
+    const long long N = H.n_;
+    if (gen != H.attempt_) {
+      gen = H.attempt_;
+      // ~1.5 GB per buffer (STRUMPACK_AMD_HOST_BLOCK_MB to change), whole 64-column tiles of the sketch GEMM
+      long long mb = 1536;
+      if (const char* e = std::getenv("STRUMPACK_AMD_HOST_BLOCK_MB")) mb = std::max(1LL, std::atoll(e));
+      nb = std::max<long long>(64, (mb << 20) / (8 * std::max<long long>(N, 1)) / 64 * 64);
+      nb = std::min(nb, (N + 63) / 64 * 64);
+      dBuf[0] = H.work_->dbl((size_t)N * nb);
+      dBuf[1] = H.work_->dbl((size_t)N * nb);
+    }
+    const long long nblk = (N + nb - 1) / nb;
+    std::vector<double> tmp;   // columns evaluated by `fill` (packed into the pinned ring before the call returns)
+    auto upload = [&](long long b) {
+      const long long c0 = b * nb, c1 = std::min(N, c0 + nb);
+      if (hA) ck(hssk_h2d_block_async(H.ctx_, dBuf[b & 1], N, hA + (size_t)c0 * lda, lda, N, c1 - c0));
+      else {
+        tmp.resize((size_t)N * (c1 - c0));
+        (*fill)(c0, c1, tmp.data());
+        ck(hssk_h2d_block_async(H.ctx_, dBuf[b & 1], N, tmp.data(), N, N, c1 - c0));
+      }
+    };
+    upload(0);
+    for (long long b = 0; b < nblk; b++) {
+      const long long c0 = b * nb, c1 = std::min(N, c0 + nb);
+      ck(hssk_copy_fence(H.ctx_));          // the GEMMs below wait for block b
+      if (b + 1 < nblk) {
+        ck(hssk_compute_fence(H.ctx_));     // block b+1 overwrites the buffer the GEMMs of block b-1 read
+        upload(b + 1);
+      }
+      const double* Ab = dBuf[b & 1];
+      ck(hssk_dgemm(H.ctx_, 0, dn, c1 - c0, N, 1.0, H.Rt_ + r0, H.dcap_, Ab, N, 0.0, H.Sct_ + r0 + c0 * H.dcap_, H.dcap_));
+      ck(hssk_dgemm(H.ctx_, 1, dn, N, c1 - c0, 1.0, H.Rt_ + r0 + c0 * H.dcap_, H.dcap_, Ab, N, b ? 1.0 : 0.0, H.Srt_ + r0, H.dcap_));
+    }
+    ck(hssk_sync(H.ctx_));
+  }
+  void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
+    // every requested block is compact (ldb == m): gather on the host threads into one staging image, one upload each
+    std::vector<size_t> off(reqs.size() + 1, 0);
+    for (size_t k = 0; k < reqs.size(); k++) off[k + 1] = off[k] + (size_t)std::max(reqs[k].m, 0) * std::max(reqs[k].n, 0);
+    std::vector<double> img(off.back());
+    host_parallel_for(reqs.size(), [&](size_t k) {
+      const ElemReq& r = reqs[k];
+      if (r.m <= 0 || r.n <= 0) return;
+      double* B = img.data() + off[k];
+      if (hA) {
+        for (int j = 0; j < r.n; j++) {
+          const double* col = hA + (size_t)(r.hJ ? (*r.hJ)[j] : r.j0 + j) * lda;
+          if (r.hI) for (int i = 0; i < r.m; i++) B[i + (size_t)j * r.m] = col[(*r.hI)[i]];
+          else std::memcpy(B + (size_t)j * r.m, col + r.i0, sizeof(double) * r.m);
+        }
+      } else {
+        std::vector<int> I(r.m), J(r.n);
+        for (int i = 0; i < r.m; i++) I[i] = r.hI ? (*r.hI)[i] : r.i0 + i;
+        for (int j = 0; j < r.n; j++) J[j] = r.hJ ? (*r.hJ)[j] : r.j0 + j;
+        (*elem)(r.m, I.data(), r.n, J.data(), B, r.m);
+      }
+    });
+    for (size_t k = 0; k < reqs.size(); k++) {
+      const ElemReq& r = reqs[k];
+      if (r.m <= 0 || r.n <= 0) continue;
+      if (r.ldb == r.m) ck(hssk_upload_async(H.ctx_, r.dB, img.data() + off[k], (long long)(sizeof(double) * (off[k + 1] - off[k]))));
+      else ck(hssk_memcpy2d_h2d(H.ctx_, r.dB, sizeof(double) * r.ldb, img.data() + off[k], sizeof(double) * r.m, sizeof(double) * r.m, r.n));
+    }
+  }
+};
+
 struct DeviceHSS::CallbackSource : DeviceHSS::Source {
   const host_mult_t& mult;
   const host_elem_t& elem;
@@ -763,14 +850,12 @@ void DeviceHSS::compress_dense_device(const double* dA, long long lda) {
   compress(s);
 }
 void DeviceHSS::compress_dense_host(const double* A, long long lda) {
-  double* dA = (double*)hssk_malloc((long long)sizeof(double) * n_ * std::max(n_, 1));
-  if (!dA && n_) throw std::runtime_error("device allocation of the dense input failed");
-  try {
-    ck(hssk_memcpy2d_h2d(ctx_, dA, sizeof(double) * n_, A, sizeof(double) * lda, sizeof(double) * n_, n_));
-    compress_dense_device(dA, n_);
-    ck(hssk_sync(ctx_));
-  } catch (...) { hssk_free(dA); throw; }
-  hssk_free(dA);
+  HostBlockSource s(A, lda, nullptr, nullptr);
+  compress(s);
+}
+void DeviceHSS::compress_host_blocks(const host_fill_t& fill, const host_elem_t& elem) {
+  HostBlockSource s(nullptr, 0, &fill, &elem);
+  compress(s);
 }
 void DeviceHSS::compress_dense_device_sharded(const double* dRows, long long ldr, const double* dCols, long long ldc) {
   if (!dCols) throw std::invalid_argument("sharded operand: the column block is required");
@@ -907,6 +992,7 @@ void DeviceHSS::fill_random(int r0, int dn) {
 
 bool DeviceHSS::compress_attempt(Source& src, int dcap) {
   reset_compression();
+  attempt_++;
   dcap_ = dcap;
   const size_t N = n_;
   // sample arrays; with several GPUs the column count is padded to world * cols_per_rank so that

@@ -65,6 +65,7 @@ struct CommSpec {
 // host callbacks of the matrix-free / element interfaces (column-major host buffers)
 using host_mult_t = std::function<void(char trans, int n, int nrhs, const double* R, int ldr, double* S, int lds)>;
 using host_elem_t = std::function<void(int m, const int* I, int n, const int* J, double* B, int ldb)>;
+class DeviceHSS;
 
 struct PhaseStats {
   double t_compress = 0, t_sketch = 0, t_random = 0, t_tree = 0, t_factor = 0, t_solve = 0, t_mult = 0;
@@ -91,7 +92,13 @@ class DeviceHSS {
 
   // ---- construction (compression) ----
   void compress_dense_device(const double* dA, long long lda);       // A resident in HBM
-  void compress_dense_host(const double* A, long long lda);          // uploads A, then the above
+  // A in host memory: streamed through the device in column blocks, uploads overlapped with the sketch GEMMs; the full
+  // matrix is never resident in HBM (the reference's element sampler never stores A either, StructuredMatrix.cpp:214-262)
+  void compress_dense_host(const double* A, long long lda);
+  // the same for an operand given by element evaluation: fill(c0, c1, dst) writes A(:, c0:c1) (n x (c1-c0), ld n, host),
+  // elem evaluates scattered blocks; both may be called concurrently from several host threads
+  using host_fill_t = std::function<void(long long c0, long long c1, double* dst)>;
+  void compress_host_blocks(const host_fill_t& fill, const host_elem_t& elem);
   // multi-GPU, sharded operand: this rank holds the rows and / or the columns [lo, hi) of its subtree (shard_range()):
   // dRows = A(lo:hi, :) ((hi-lo) x n, ldr) or null, dCols = A(:, lo:hi) (n x (hi-lo), ldc).  Without the row block
   // the operator is column-sharded: Sr = sum_g A(:, cols_g) R(cols_g, :) is reduced over the ranks.
@@ -196,6 +203,7 @@ class DeviceHSS {
  private:
   struct Source;
   struct DenseDeviceSource;
+  struct HostBlockSource;
   struct ShardedDenseSource;
   struct CallbackSource;
 
@@ -267,6 +275,7 @@ class DeviceHSS {
   // global transposed sample arrays (dcap x N)
   double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;
   int dcap_ = 0;
+  int attempt_ = 0;   // compression attempts so far (sources re-carve their work buffers after a restart)
   const int* sj_pat_ = nullptr;   // SJLT pattern of the sample block filled last (device, nnz x N)
   int sj_nnz_ = 0;
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)

@@ -3,7 +3,9 @@
 
 #include <cstdlib>
 
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -15,7 +17,109 @@ void hssk_set_error(const std::string& msg) { g_err = msg; }
 
 thread_local std::vector<std::function<void()>>* hssk_rec::sink = nullptr;
 
+// ---- pipelined host -> device uploads (hssk_h2d_block_async) ----------------------------------------------------------
+struct hssk_uploader {
+  static constexpr int SLOTS = 4;
+  static constexpr size_t CHUNK = size_t(64) << 20;
+  hssk_rt::stream_t copy{};
+  hssk_rt::event_t ev_copy{}, ev_compute{};
+  char* pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  hssk_rt::event_t slot_ev[SLOTS];
+  bool slot_busy[SLOTS] = {false, false, false, false};
+  int next = 0;
+  hssk_uploader() {
+    copy = hssk_rt::stream_create();
+    ev_copy = hssk_rt::event_create();
+    ev_compute = hssk_rt::event_create();
+    for (int i = 0; i < SLOTS; i++) { pinned[i] = (char*)hssk_rt::pinned_malloc(CHUNK); slot_ev[i] = hssk_rt::event_create(); }
+  }
+  ~hssk_uploader() {
+    try { hssk_rt::sync(copy); } catch (...) {}
+    for (int i = 0; i < SLOTS; i++) { hssk_rt::pinned_free(pinned[i]); hssk_rt::event_destroy(slot_ev[i]); }
+    hssk_rt::event_destroy(ev_copy);
+    hssk_rt::event_destroy(ev_compute);
+    hssk_rt::stream_destroy(copy);
+  }
+};
+static hssk_uploader* uploader(hssk_ctx* c) {
+  if (!c->uploader) c->uploader = new hssk_uploader();
+  return c->uploader;
+}
+// columns [c0, c1) of a column-major host block into a compact pinned buffer, on the host's hardware threads
+static void host_pack(char* dst, const double* src, long long lds, long long rows, long long c0, long long c1) {
+  const long long ncol = c1 - c0;
+  const size_t colb = sizeof(double) * (size_t)rows;
+  const unsigned nt = (unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(16, std::thread::hardware_concurrency()), (long long)(colb * ncol >> 22) + 1));
+  if (nt <= 1) {
+    for (long long j = 0; j < ncol; j++) std::memcpy(dst + colb * j, src + (size_t)(c0 + j) * lds, colb);
+    return;
+  }
+  // split by bytes, not by columns: a block may be one very long column
+  const size_t total = colb * (size_t)ncol, per = (total + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([=] {
+      size_t b0 = per * t, b1 = std::min(total, b0 + per);
+      while (b0 < b1) {
+        const size_t j = b0 / colb, o = b0 % colb, len = std::min(colb - o, b1 - b0);
+        std::memcpy(dst + b0, (const char*)(src + (size_t)(c0 + (long long)j) * lds) + o, len);
+        b0 += len;
+      }
+    });
+  for (auto& t : th) t.join();
+}
+
 extern "C" {
+
+int hssk_h2d_block_async(hssk_ctx* c, double* dst, long long ldd, const double* src, long long lds, long long rows,
+                         long long cols) {
+  HSSK_API_BEGIN
+  if (rows <= 0 || cols <= 0) return 0;
+  hssk_uploader* u = uploader(c);
+  const size_t colb = sizeof(double) * (size_t)rows;
+  if (hssk_rt::is_pinned_host_pointer(src)) {   // DMA straight from the caller's pinned buffer
+    hssk_rt::h2d_2d(dst, sizeof(double) * (size_t)ldd, src, sizeof(double) * (size_t)lds, colb, (size_t)cols, u->copy);
+    return 0;
+  }
+  if (colb > hssk_uploader::CHUNK) {   // columns longer than a bounce slot: pieces of one column at a time
+    for (long long j = 0; j < cols; j++)
+      for (size_t o = 0; o < colb; o += hssk_uploader::CHUNK) {
+        const size_t len = std::min(hssk_uploader::CHUNK, colb - o);
+        const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
+        if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);
+        std::memcpy(u->pinned[s], (const char*)(src + (size_t)j * lds) + o, len);
+        hssk_rt::h2d((char*)(dst + (size_t)j * ldd) + o, u->pinned[s], len, u->copy);
+        hssk_rt::event_record(u->slot_ev[s], u->copy);
+        u->slot_busy[s] = true;
+      }
+    return 0;
+  }
+  const long long cpc = std::max<long long>(1, (long long)(hssk_uploader::CHUNK / colb));   // columns per bounce slot
+  for (long long c0 = 0; c0 < cols; c0 += cpc) {
+    const long long c1 = std::min(cols, c0 + cpc);
+    const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
+    if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);   // the DMA that last read this slot has finished
+    host_pack(u->pinned[s], src, lds, rows, c0, c1);
+    hssk_rt::h2d_2d(dst + (size_t)c0 * ldd, sizeof(double) * (size_t)ldd, u->pinned[s], colb, colb, (size_t)(c1 - c0), u->copy);
+    hssk_rt::event_record(u->slot_ev[s], u->copy);
+    u->slot_busy[s] = true;
+  }
+  HSSK_API_END
+}
+int hssk_copy_fence(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  hssk_uploader* u = uploader(c);
+  hssk_rt::event_record(u->ev_copy, u->copy);
+  hssk_rt::stream_wait_event(c->stream, u->ev_copy);
+  HSSK_API_END
+}
+int hssk_compute_fence(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  hssk_uploader* u = uploader(c);
+  hssk_rt::event_record(u->ev_compute, c->stream);
+  hssk_rt::stream_wait_event(u->copy, u->ev_compute);
+  HSSK_API_END
+}
 
 const char* hssk_last_error(void) { return g_err.c_str(); }
 
@@ -63,6 +167,7 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   hssk_rt::pinned_free(c->h_ring);
   hssk_rt::dev_free(c->d_ring);
   hssk_rt::dev_free(c->d_scratch);
+  delete c->uploader;
   hssk_rt::dev_free(c->d_sweep_flags);
   hssk_rt::pinned_free(c->h_sweep_err);
   hssk_rt::event_destroy(c->ev0);

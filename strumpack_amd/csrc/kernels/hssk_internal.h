@@ -35,6 +35,7 @@ struct hssk_plan {
   ~hssk_plan() { for (auto& b : blocks) hssk_rt::pinned_free(b.first); }
 };
 
+struct hssk_uploader;
 struct hssk_ctx {
   int device = 0;
   hssk_rt::stream_t stream{};
@@ -50,6 +51,7 @@ struct hssk_ctx {
   long long* d_clk = nullptr;   // device: {shader cycles, 100 MHz ticks} of workgroup 0 of the last dgemm
   double* d_scratch = nullptr;  // split-K partials of hssk_dgemm
   // dependency flags of the single-launch sweeps (device, all zero between launches) and their error word (pinned)
+  struct hssk_uploader* uploader = nullptr;   // copy stream + pinned bounce slots of hssk_h2d_block_async (hssk_ctx.hip)
   int* d_sweep_flags = nullptr;
   int* h_sweep_err = nullptr;
   size_t sweep_cap = size_t(1) << 20;

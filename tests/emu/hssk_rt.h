@@ -36,6 +36,9 @@ inline void event_record(event_t e, stream_t) {
   *e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 inline float event_elapsed_ms(event_t a, event_t b) { return (float)(*b - *a); }
+inline void stream_wait_event(stream_t, event_t) {}
+inline void event_sync(event_t) {}
+inline bool is_pinned_host_pointer(const void*) { return false; }
 inline int device_count() { return 1; }
 inline void set_device(int) {}
 inline bool is_device_pointer(const void*) { return false; }
