@@ -43,9 +43,11 @@ def parse():
     p.add_argument("--sketch", choices=["gaussian", "sjlt"], default="gaussian",
                    help="gaussian = the reference's default (BASELINE's metric is quoted on it); sjlt = its "
                         "--hss_compression_sketch SJLT option (nnz = 4), a separate, HBM-bound workload")
-    p.add_argument("--workload", choices=["toeplitz", "kernel"], default="toeplitz",
+    p.add_argument("--workload", choices=["toeplitz", "kernel", "host"], default="toeplitz",
                    help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
-                        "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line")
+                        "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line; host = the headline "
+                        "matrix resident in HOST memory, through the reference's own entry point SP_d_struct_from_dense "
+                        "(the drop-in call: the operand crosses PCIe inside the step), reported as a secondary line")
     return p.parse_args()
 
 
@@ -109,22 +111,103 @@ def kernel_workload(a, torch, dist, world, rank, local):
     H.destroy()
 
 
-def cpu_baseline(n, leaf, rel_tol):
-    """Reference CPU HSS (oracle/_ref) on a bounded sample of the same workload."""
+def host_workload(a, L, hk):
+    """The drop-in call on the headline matrix: A lives in (pageable) host memory and goes through
+    SP_d_struct_from_dense-with-options; the engine streams it through the device in column blocks, uploads overlapped
+    with the sketch GEMMs.  One step = construct + factor + solve; the bound of the step is the PCIe upload of 8 N^2 bytes."""
+    import numpy as np
+    from strumpack_amd import capi
+    n = a.n
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        while 8.0 * n * n * 1.25 > avail and n > 8192:
+            n = int(n * 0.8) // 1024 * 1024
+    except Exception:
+        pass
+    A = np.empty((n, n), order="F")
+    slab = 4096
+    dS = hk.empty((n, slab))
+    for c0 in range(0, n, slab):   # generated on the device, brought to the host slab by slab (setup, untimed)
+        w = min(slab, n - c0)
+        hk.check(hk.lib.hssk_fill_toeplitz_block(hk.ctx, dS.ptr, n, w, n, 0, c0, b"T"))
+        A[:, c0:c0 + w] = dS.get()[:, :w]
+    del dS
+    opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox")
+    b = np.random.default_rng(7).standard_normal((n, a.nrhs))
+
+    def step():
+        H = capi.StructuredMatrix.from_dense(L, A, opts, hopts)
+        H.factor()
+        x = H.solve(b)
+        return H, x
+
+    H = None
+    for _ in range(a.warmup):
+        if H is not None:
+            H.destroy()
+        H, x = step()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if H is not None:
+            H.destroy()
+        H, x = step()
+    elapsed = (time.perf_counter() - t0) / a.steps
+    st = H.stats()
+    f_total = st["f_sketch"] + st["f_local"] + st["f_reduce"] + st["f_id"] + st["f_ortho"] + st["f_ulv"] + st["f_solve"]
+    resid = float(np.linalg.norm(H.mult(x) - b) / np.linalg.norm(b))
+    gbs = 8.0 * n * n / st["t_sketch"] * 1e-9
+    out = {"metric": "hss_compress_ulv_factor_solve_gflops", "value": f_total / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2] matrix (%dx%d double Toeplitz, leaf=%d, rel_tol=%g) resident in pageable HOST memory, "
+                                  "through the reference's entry point SP_d_struct_from_dense (+ HSS options): streamed column blocks, "
+                                  "uploads overlapped with the sketch; compress + ULV factor + solve (nrhs=%d)" % (n, n, a.leaf, a.rel_tol, a.nrhs),
+                      "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs, "operand": "host"},
+           "phases_s": {"compress": st["t_compress"], "sketch_incl_upload": st["t_sketch"], "tree": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
+           "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6},
+           "checks": {"solve_resid_H": resid},
+           "roofline": {"kernel": "host -> device stream of A (hipMemcpy2DAsync from a pinned bounce ring, copy stream)", "bound": "pcie",
+                        "achieved": gbs, "peak": 63.0, "unit": "GB/s", "frac": gbs / 63.0, "traffic": None,
+                        "bytes": 8.0 * n * n, "note": "PCIe gen5 x16 ~63 GB/s per direction; the two sketch GEMMs of a block (2.4 ms per 1.6 GB) hide behind its upload"}}
+    print(json.dumps(out))
+    H.destroy()
+
+
+def _ref_sample(R, n, leaf, rel_tol):
+    r = R.bench_toeplitz(n, leaf=leaf, rel_tol=rel_tol, abs_tol=1e-8, nrhs=1)
+    fl = R.flops(reset=True)
+    # same flop model as the GPU number: 4 N^2 d for the sketch + the reference's own counters
+    flops = 4.0 * n * n * 192 + fl["update_sample"] + fl["reduce_sample"] + fl["ID"] + fl["QR"] + \
+        fl["ortho"] + fl["ULV_factor"] + fl["hss_solve"]
+    t = r["compress_s"] + r["factor_s"] + r["solve_s"]
+    return flops / t * 1e-9, ("STRUMPACK v8.0.0 CPU HSS (MKL, OpenMP), Toeplitz N=%d leaf=%d rel_tol=%g: compress %.3fs "
+                              "factor %.3fs solve %.4fs, rank %d" % (n, leaf, rel_tol, r["compress_s"], r["factor_s"], r["solve_s"], r["rank"]))
+
+
+def cpu_baseline(n_small, leaf, rel_tol, n_full=100000):
+    """Reference CPU HSS (oracle/_ref) timed on this host: on the headline workload itself (N = n_full, the dense operand
+    is 8 N^2 bytes of host memory: ~20 s of compression on a 256-core host) when the host has the memory, and on the
+    N = n_small sample (BASELINE configs[1]) as a second point."""
     try:
         from oracle import ref_lib as R
         if not R.available():
             raise RuntimeError("oracle/_ref not built")
-        r = R.bench_toeplitz(n, leaf=leaf, rel_tol=rel_tol, abs_tol=1e-8, nrhs=1)
-        fl = R.flops(reset=True)
-        # same flop model as the GPU number: 4 N^2 d for the sketch + the reference's own counters
-        flops = 4.0 * n * n * 192 + fl["update_sample"] + fl["reduce_sample"] + fl["ID"] + fl["QR"] + \
-            fl["ortho"] + fl["ULV_factor"] + fl["hss_solve"]
-        t = r["compress_s"] + r["factor_s"] + r["solve_s"]
-        return dict(value=flops / t * 1e-9, unit="GFLOP/s", cores=os.cpu_count(), kind="reference",
-                    sample="STRUMPACK v8.0.0 CPU HSS (MKL, OpenMP), Toeplitz N=%d leaf=%d rel_tol=%g: compress %.3fs "
-                           "factor %.3fs solve %.4fs, rank %d" % (n, leaf, rel_tol, r["compress_s"], r["factor_s"],
-                                                                   r["solve_s"], r["rank"]))
+        out = dict(unit="GFLOP/s", cores=os.cpu_count(), kind="reference")
+        big = None
+        try:
+            import psutil
+            if psutil.virtual_memory().available > 8.0 * n_full * n_full * 1.6 and not os.environ.get("STRUMPACK_AMD_BENCH_SMALL_CPU"):
+                big = _ref_sample(R, n_full, leaf, rel_tol)
+        except Exception as e:   # e.g. allocation failure: keep the small sample
+            out["full_size_error"] = str(e)[:200]
+        small = _ref_sample(R, n_small, leaf, rel_tol)
+        if big:
+            out.update(value=big[0], sample=big[1], second_sample={"value": small[0], "sample": small[1]})
+        else:
+            out.update(value=small[0], sample=small[1] + " (host memory too small for the dense N=%d operand)" % n_full)
+        return out
     except Exception as e:  # reference library unavailable on this host: time the numpy/LAPACK port instead
         import numpy as np
         from oracle import hss_oracle as O
@@ -166,6 +249,11 @@ def main():
     L = capi.load(_loader.lib_path())
     hk = K.Hssk(_loader.lib_path(), device=local)
     n = a.n
+    if a.workload == "host":
+        if world > 1:
+            raise SystemExit("--workload host is the single-GPU drop-in call")
+        host_workload(a, L, hk)
+        return
 
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
     hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch)

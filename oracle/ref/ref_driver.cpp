@@ -76,6 +76,7 @@ void ref_fill_test_matrix(char kind, int n, double* A) {
       std::memcpy(A + (size_t)j * n, Ad.ptr(0, j), sizeof(double) * n);
     return;
   }
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < n; j++)
     for (int i = 0; i < n; i++) {
       double v = (i == j) ? 1. : 1. / (1 + std::abs(i - j));

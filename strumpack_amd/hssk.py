@@ -181,6 +181,13 @@ class Hssk:
         L.hssk_last_dgemm_flops.restype = C.c_double
         L.hssk_last_dgemm_flops.argtypes = [C.c_void_p]
         L.hssk_fill_toeplitz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_char]
+        L.hssk_fill_toeplitz_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_char]
+        L.hssk_sum_slabs.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p]
+        L.hssk_upload_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.hssk_h2d_block_async.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong]
+        L.hssk_copy_fence.argtypes = [C.c_void_p]
+        L.hssk_compute_fence.argtypes = [C.c_void_p]
+        L.hssk_sweep_status.argtypes = [C.c_void_p]
         L.hssk_randn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
                                  C.c_int, C.c_longlong, C.c_ulonglong]
         L.hssk_dgemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_longlong,
