@@ -139,7 +139,7 @@ class StructuredMatrix:
         if p is not None:
             h.p = p
         if algorithm is not None:
-            h.compression_algorithm = {"original": 0, "stable": 1}[algorithm]
+            h.compression_algorithm = {"original": 0, "stable": 1, "hard_restart": 2}[algorithm]
         if random_engine is not None:
             h.random_engine = {"linear": 0, "mersenne": 1, "philox": 2}[random_engine]
         if sketch is not None:

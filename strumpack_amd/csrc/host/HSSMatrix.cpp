@@ -19,9 +19,13 @@ EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
   EngineOptions e;
   e.rel_tol = o.rel_tol(); e.abs_tol = o.abs_tol(); e.leaf_size = o.leaf_size(); e.max_rank = o.max_rank();
   e.d0 = o.d0(); e.dd = o.dd(); e.p = o.p();
-  // HARD_RESTART shares the acceptance rule of ORIGINAL (compress.hpp:235-298) and differs only in
-  // re-using nothing from a failed round; it is run as ORIGINAL here
-  e.algorithm = o.compression_algorithm() == CompressionAlgorithm::STABLE ? 1 : 0;
+  // HARD_RESTART (compress.hpp:235-298): the acceptance rule of ORIGINAL, but a failed round resets every node and the
+  // next round recompresses the whole tree on all samples
+  e.algorithm = o.compression_algorithm() == CompressionAlgorithm::STABLE ? 1 : (o.compression_algorithm() == CompressionAlgorithm::HARD_RESTART ? 2 : 0);
+  // the engine draws the sketching matrix itself (host generators identical to the reference's, or Philox on the device);
+  // a random matrix filled in by the user's multiplication routine (compress_stable.hpp:126-141) would be ignored
+  if (o.user_defined_random())
+    throw std::invalid_argument("--hss_user_defined_random / set_user_defined_random(true) is not supported: the sketching matrix is drawn by the engine");
   e.random_engine = o.random_engine() == random::RandomEngine::LINEAR ? 0 : (o.random_engine() == random::RandomEngine::MERSENNE ? 1 : 2);
   e.random_dist = o.random_distribution() == random::RandomDistribution::NORMAL ? 0 : 1;
   e.sketch = o.compression_sketch() == CompressionSketch::SJLT ? 1 : 0;

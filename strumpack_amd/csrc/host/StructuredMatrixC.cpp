@@ -33,7 +33,7 @@ HSS::HSSOptions<double> get_hss_options(const CSPOptions* o, const SPXHSSOptions
   HSS::HSSOptions<double> ho(get_options(o));
   if (h) {
     ho.set_d0(h->d0); ho.set_dd(h->dd); ho.set_p(h->p);
-    ho.set_compression_algorithm(h->compression_algorithm == 0 ? HSS::CompressionAlgorithm::ORIGINAL : HSS::CompressionAlgorithm::STABLE);
+    ho.set_compression_algorithm(h->compression_algorithm == 0 ? HSS::CompressionAlgorithm::ORIGINAL : (h->compression_algorithm == 2 ? HSS::CompressionAlgorithm::HARD_RESTART : HSS::CompressionAlgorithm::STABLE));
     ho.set_random_engine(h->random_engine == 0 ? random::RandomEngine::LINEAR : (h->random_engine == 1 ? random::RandomEngine::MERSENNE : random::RandomEngine::PHILOX));
     ho.set_random_distribution(h->random_distribution == 0 ? random::RandomDistribution::NORMAL : random::RandomDistribution::UNIFORM);
     ho.set_compression_sketch(h->compression_sketch == 1 ? HSS::CompressionSketch::SJLT : HSS::CompressionSketch::GAUSSIAN);

@@ -898,10 +898,30 @@ void DeviceHSS::reset_compression() {
   d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
 }
 
+// hard restart (compress.hpp:289-294, reset()): every node back to UNTOUCHED, the first d_have sample rows of Srt_ / Sct_
+// back to what the sampling produced; the sample arrays themselves are kept
+void DeviceHSS::restart_nodes(int d_have) {
+  ck(hssk_sync(ctx_));
+  for (auto& nd : nodes_) {
+    int lo = nd.lo, m = nd.m, lvl = nd.lvl, h = nd.height, c0 = nd.c0, c1 = nd.c1, p = nd.parent;
+    nd = Node();
+    nd.lo = lo; nd.m = m; nd.lvl = lvl; nd.height = h; nd.c0 = c0; nd.c1 = c1; nd.parent = p;
+  }
+  persist_->reset();
+  d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
+  if (d_have > 0) {
+    std::vector<hssk_colgather_desc> cp;
+    const int ncols = (int)std::min<long long>(n_, 0x7fffffff);
+    cp.push_back(hssk_colgather_desc{Srt0_, Srt_, nullptr, d_have, ncols, dcap_, dcap_, 0});
+    cp.push_back(hssk_colgather_desc{Sct0_, Sct_, nullptr, d_have, ncols, dcap_, dcap_, 0});
+    ck(hssk_gather_cols(ctx_, cp.data(), 2));
+  }
+}
+
 void DeviceHSS::free_compress_workspace() {
   ck(hssk_sync(ctx_));
   work_->reset();
-  Rt_ = Srt_ = Sct_ = nullptr;
+  Rt_ = Srt_ = Sct_ = Srt0_ = Sct0_ = nullptr;
   sj_pat_ = nullptr;
   for (auto& nd : nodes_) { nd.Srt = nd.Sct = nd.Rrt = nd.Rct = nd.RrtRed = nd.RctRed = nd.Qr = nd.Qc = nullptr; nd.panels = false; }
 }
@@ -909,7 +929,7 @@ void DeviceHSS::free_compress_workspace() {
 void DeviceHSS::compress(Source& src) {
   double t0 = now();
   stats_ = PhaseStats();
-  int dcap = o_.algorithm == 0 ? o_.d0 + o_.p : o_.d0 + o_.dd;
+  int dcap = o_.algorithm != 1 ? o_.d0 + o_.p : o_.d0 + o_.dd;
   dcap = std::max(16, (dcap + 15) / 16 * 16);
   for (;;) {
     if (compress_attempt(src, dcap)) break;
@@ -936,7 +956,9 @@ void DeviceHSS::fill_random(int r0, int dn) {
     // pattern (nnz ints per row) crosses PCIe; the dense block the tree levels need is expanded on the device.
     if (r0 == 0 || !rng_) rng_.reset(new HostRng());
     auto& e = rng_->sj;
-    const int nnz = std::max(1, std::min(std::min(r0 == 0 ? o_.nnz0 : o_.nnz, dn), 8));
+    if ((r0 == 0 ? o_.nnz0 : o_.nnz) > 8)
+      throw std::invalid_argument("SJLT sketch: more than 8 nonzeros per row (--hss_nnz0 / --hss_nnz) are not supported by the device pattern");
+    const int nnz = std::max(1, std::min(r0 == 0 ? o_.nnz0 : o_.nnz, dn));
     const int nq = nnz <= 4 ? 4 : 8;            // ints per row in the device pattern (hssk.h); unused ones point at column dn
     std::vector<int> pat((size_t)nq * N, dn);
     std::uniform_int_distribution<int> sign(0, 1);
@@ -1002,9 +1024,10 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
   Rt_ = work_->dbl((size_t)dcap * N);
   Srt_ = work_->dbl((size_t)dcap * Npad);
   Sct_ = work_->dbl((size_t)dcap * Npad);
+  if (o_.algorithm == 2) { Srt0_ = work_->dbl((size_t)dcap * Npad); Sct0_ = work_->dbl((size_t)dcap * Npad); }
   stats_.rounds = 0;
   stats_.f_sketch = stats_.f_local = stats_.f_reduce = stats_.f_id = stats_.f_ortho = 0;
-  const bool original = (o_.algorithm == 0);
+  const bool original = (o_.algorithm != 1);
   if (!original) {
     // compress_stable(Amult, Aelem, opts), HSSMatrix.compress_stable.hpp:100-163
     int d = o_.d0, dd = o_.dd;
@@ -1043,7 +1066,14 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       ck(hssk_sync(ctx_));
       stats_.t_sketch += now() - t0;
       stats_.f_sketch += 4.0 * (double)N * (double)N * (sj_pat_ ? sj_nnz_ : d - d_old);
-      if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << " (original)" << std::endl;
+      if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << (o_.algorithm == 2 ? " (original, hard restart)" : " (original)") << std::endl;
+      if (o_.algorithm == 2) {   // keep the new samples as drawn
+        if (dist_subtree_ || o_.world > 1) throw std::invalid_argument("hard restart is a single-GPU option");
+        std::vector<hssk_colgather_desc> cp;
+        cp.push_back(hssk_colgather_desc{Srt_ + d_old, Srt0_ + d_old, nullptr, d - d_old, (int)N, dcap_, dcap_, 0});
+        cp.push_back(hssk_colgather_desc{Sct_ + d_old, Sct0_ + d_old, nullptr, d - d_old, (int)N, dcap_, dcap_, 0});
+        ck(hssk_gather_cols(ctx_, cp.data(), 2));
+      }
       stats_.rounds++;
       for (auto& ids : own_by_height_) process_level(src, ids, d, d - d_old, true);
       if (dist_subtree_) {
@@ -1055,6 +1085,7 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
         d_old = d;
         d = 2 * (d_old - o_.p) + o_.p;
         if (d_old >= 4 * n_ + o_.p + 64) break;
+        if (o_.algorithm == 2 && d <= dcap) restart_nodes(d_old);
       }
     }
   }
@@ -1838,12 +1869,36 @@ std::unique_ptr<DeviceHSS> DeviceHSS::load(std::istream& is, const EngineOptions
     const Rec& r = recs[i];
     if (nd.lo != r.f[0] || nd.m != r.f[1] || nd.c0 != r.f[4] || nd.c1 != r.f[5]) throw std::runtime_error("corrupt HSS file (node table)");
     nd.Ustate = r.f[7]; nd.Vstate = r.f[8]; nd.rU = r.f[9]; nd.rV = r.f[10]; nd.mU = r.f[11]; nd.mV = r.f[12];
-    if (nd.leaf()) { if (!r.D.empty()) nd.D = up_d(r.D); }
-    else { nd.B01 = up_d(r.B01); nd.B10 = up_d(r.B10); }
+    // every block is checked against the node table before it reaches the device: a truncated-but-parseable or foreign
+    // file must fail here, not as an out-of-bounds read in the first mult / factor
+    if (nd.Ustate < 0 || nd.Ustate > 2 || nd.Vstate < 0 || nd.Vstate > 2) throw std::runtime_error("corrupt HSS file (node state)");
+    if (nd.rU < 0 || nd.rV < 0 || nd.mU < 0 || nd.mV < 0 || nd.rU > nd.mU || nd.rV > nd.mV) throw std::runtime_error("corrupt HSS file (ranks)");
+    const bool used = nd.compressed() || nd.lvl == 0;   // blocks exist once the node has been processed
+    if (nd.leaf()) {
+      if (r.D.size() != (used || !r.D.empty() ? (size_t)nd.m * nd.m : 0)) throw std::runtime_error("corrupt HSS file (leaf block size)");
+      if (nd.lvl > 0 && nd.compressed() && (nd.mU != nd.m || nd.mV != nd.m)) throw std::runtime_error("corrupt HSS file (leaf basis rows)");
+      if (!r.D.empty()) nd.D = up_d(r.D);
+    } else {
+      const Rec &a = recs[nd.c0], &b = recs[nd.c1];   // (rU, rV) of the children: f[9], f[10]
+      if (used) {
+        if (r.B01.size() != (size_t)a.f[9] * b.f[10] || r.B10.size() != (size_t)b.f[9] * a.f[10])
+          throw std::runtime_error("corrupt HSS file (coupling block sizes)");
+        if (nd.lvl > 0 && (nd.mU != a.f[9] + b.f[9] || nd.mV != a.f[10] + b.f[10])) throw std::runtime_error("corrupt HSS file (basis rows)");
+      } else if (!r.B01.empty() || !r.B10.empty()) throw std::runtime_error("corrupt HSS file (coupling blocks of an untouched node)");
+      nd.B01 = up_d(r.B01); nd.B10 = up_d(r.B10);
+    }
     if (nd.lvl > 0 && nd.compressed()) {
       if ((int)r.pU.size() != nd.mU || (int)r.pV.size() != nd.mV || (int)r.Ir.size() != nd.rU || (int)r.Ic.size() != nd.rV ||
           r.XU.size() != (size_t)nd.rU * std::max(nd.mU - nd.rU, 0) || r.XV.size() != (size_t)nd.rV * std::max(nd.mV - nd.rV, 0))
         throw std::runtime_error("corrupt HSS file (basis sizes)");
+      auto is_perm = [](const std::vector<int>& p) {
+        std::vector<char> seen(p.size(), 0);
+        for (int v : p) { if (v < 0 || v >= (int)p.size() || seen[v]) return false; seen[v] = 1; }
+        return true;
+      };
+      if (!is_perm(r.pU) || !is_perm(r.pV)) throw std::runtime_error("corrupt HSS file (permutation)");
+      for (int v : r.Ir) if (v < 0 || v >= n) throw std::runtime_error("corrupt HSS file (row index set)");
+      for (int v : r.Ic) if (v < 0 || v >= n) throw std::runtime_error("corrupt HSS file (column index set)");
       nd.XU = up_d(r.XU); nd.permU = up_i(r.pU); nd.hpermU = r.pU; nd.Ir = r.Ir; nd.dIr = up_i(r.Ir);
       nd.XV = up_d(r.XV); nd.permV = up_i(r.pV); nd.hpermV = r.pV; nd.Ic = r.Ic; nd.dIc = up_i(r.Ic);
     }

@@ -29,7 +29,7 @@ namespace HSS {
 struct EngineOptions {
   double rel_tol = 1e-2, abs_tol = 1e-8;
   int leaf_size = 512, max_rank = 50000, d0 = 128, dd = 64, p = 10;
-  int algorithm = 1;      // 0 original, 1 stable, 2 hard restart (treated as stable)
+  int algorithm = 1;      // 0 original, 1 stable, 2 hard restart (original's acceptance rule; a failed round restarts every node)
   int random_engine = 0;  // 0 minstd_rand, 1 mt19937 (host, reference-identical), 2 philox (device)
   int random_dist = 0;    // 0 normal, 1 uniform
   // sketching matrix: 0 Gaussian (the distribution above), 1 SJLT = nnz entries +-1 per row (HSSMatrix.sketch.hpp);
@@ -211,6 +211,7 @@ class DeviceHSS {
   void compress(Source& src);
   bool compress_attempt(Source& src, int dcap);
   void reset_compression();
+  void restart_nodes(int d_have);
   void fill_random(int r0, int dn);
   void process_level(Source& src, const std::vector<int>& ids, int d, int dd, bool original);
   void extract_blocks(Source& src, const std::vector<int>& ids);
@@ -274,6 +275,7 @@ class DeviceHSS {
   std::unique_ptr<Arena> persist_, work_, fact_, tmp_;
   // global transposed sample arrays (dcap x N)
   double *Rt_ = nullptr, *Srt_ = nullptr, *Sct_ = nullptr;
+  double *Srt0_ = nullptr, *Sct0_ = nullptr;   // hard restart: the samples as drawn (the tree levels update Srt_ / Sct_ in place)
   int dcap_ = 0;
   int attempt_ = 0;   // compression attempts so far (sources re-carve their work buffers after a restart)
   const int* sj_pat_ = nullptr;   // SJLT pattern of the sample block filled last (device, nnz x N)

@@ -49,7 +49,7 @@ static hssk_uploader* uploader(hssk_ctx* c) {
 static void host_pack(char* dst, const double* src, long long lds, long long rows, long long c0, long long c1) {
   const long long ncol = c1 - c0;
   const size_t colb = sizeof(double) * (size_t)rows;
-  const unsigned nt = (unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(16, std::thread::hardware_concurrency()), (long long)(colb * ncol >> 22) + 1));
+  const unsigned nt = (unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(32, std::thread::hardware_concurrency()), (long long)(colb * ncol >> 22) + 1));
   if (nt <= 1) {
     for (long long j = 0; j < ncol; j++) std::memcpy(dst + colb * j, src + (size_t)(c0 + j) * lds, colb);
     return;
@@ -78,7 +78,8 @@ int hssk_h2d_block_async(hssk_ctx* c, double* dst, long long ldd, const double* 
   hssk_uploader* u = uploader(c);
   const size_t colb = sizeof(double) * (size_t)rows;
   if (hssk_rt::is_pinned_host_pointer(src)) {   // DMA straight from the caller's pinned buffer
-    hssk_rt::h2d_2d(dst, sizeof(double) * (size_t)ldd, src, sizeof(double) * (size_t)lds, colb, (size_t)cols, u->copy);
+    if (ldd == rows && lds == rows) hssk_rt::h2d(dst, src, colb * (size_t)cols, u->copy);
+    else hssk_rt::h2d_2d(dst, sizeof(double) * (size_t)ldd, src, sizeof(double) * (size_t)lds, colb, (size_t)cols, u->copy);
     return 0;
   }
   if (colb > hssk_uploader::CHUNK) {   // columns longer than a bounce slot: pieces of one column at a time
@@ -100,7 +101,10 @@ int hssk_h2d_block_async(hssk_ctx* c, double* dst, long long ldd, const double* 
     const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
     if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);   // the DMA that last read this slot has finished
     host_pack(u->pinned[s], src, lds, rows, c0, c1);
-    hssk_rt::h2d_2d(dst + (size_t)c0 * ldd, sizeof(double) * (size_t)ldd, u->pinned[s], colb, colb, (size_t)(c1 - c0), u->copy);
+    if (ldd == rows)   // contiguous on the device: one linear DMA (the rectangular copy path is markedly slower)
+      hssk_rt::h2d(dst + (size_t)c0 * ldd, u->pinned[s], colb * (size_t)(c1 - c0), u->copy);
+    else
+      hssk_rt::h2d_2d(dst + (size_t)c0 * ldd, sizeof(double) * (size_t)ldd, u->pinned[s], colb, colb, (size_t)(c1 - c0), u->copy);
     hssk_rt::event_record(u->slot_ev[s], u->copy);
     u->slot_busy[s] = true;
   }

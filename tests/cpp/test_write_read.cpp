@@ -2,7 +2,11 @@
 // applies, factors and solves like the one written.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <fstream>
 #include <iostream>
+#include <iterator>
+#include <vector>
 
 #include "HSSMatrix.hpp"
 
@@ -23,6 +27,63 @@ int main(int argc, char* argv[]) {
   if (!H.is_compressed()) { std::cout << "compression failed" << std::endl; return 1; }
   H.write(fname);
   auto G = HSS::HSSMatrix<double>::read(fname);
+  // damaged files must be refused by read() -- never loaded and then read out of bounds on the device: a truncated
+  // file, and files whose payload was altered in place (a block count, a permutation entry)
+  {
+    std::ifstream in(fname, std::ios::binary);
+    std::vector<char> img((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    in.close();
+    auto refused = [&](const std::vector<char>& bytes, const char* what) {
+      const std::string f2 = fname + ".bad";
+      { std::ofstream o(f2, std::ios::binary | std::ios::trunc); o.write(bytes.data(), (std::streamsize)bytes.size()); }
+      bool thrown = false;
+      try { auto B = HSS::HSSMatrix<double>::read(f2); } catch (const std::exception&) { thrown = true; }
+      std::remove(f2.c_str());
+      if (!thrown) std::cout << "ERROR: a corrupt file (" << what << ") was accepted" << std::endl;
+      return thrown;
+    };
+    bool ok = true;
+    ok = refused(std::vector<char>(img.begin(), img.begin() + img.size() / 2), "truncated") && ok;
+    // first node record: 16 bytes header, 13 ints node table, then the int64 element count of the D block (0 for the
+    // root of a multi-level tree), then B01's count: claim one element fewer
+    {
+      auto b = img;
+      long long cnt;
+      const size_t off = 16 + 13 * sizeof(int) + sizeof(long long);   // count of B01 of the root
+      std::memcpy(&cnt, b.data() + off, sizeof(cnt));
+      if (cnt > 1) {
+        // drop the last double of the block and fix the count: still parseable, but the size no longer matches the ranks
+        cnt -= 1;
+        std::memcpy(b.data() + off, &cnt, sizeof(cnt));
+        b.erase(b.begin() + off + sizeof(long long) + cnt * sizeof(double), b.begin() + off + sizeof(long long) + (cnt + 1) * sizeof(double));
+        ok = refused(b, "coupling block size") && ok;
+      }
+    }
+    // a permutation entry out of range: find the second node's permU block = after its D / B01 / B10 / XU blocks
+    {
+      auto b = img;
+      size_t off = 16;
+      auto skip_node = [&](size_t o, size_t* permU_off) {
+        o += 13 * sizeof(int);
+        for (int blk = 0; blk < 9; blk++) {
+          long long cnt;
+          std::memcpy(&cnt, b.data() + o, sizeof(cnt));
+          if (blk == 4 && permU_off) *permU_off = cnt > 0 ? o + sizeof(long long) : 0;
+          o += sizeof(long long) + (size_t)cnt * ((blk == 4 || blk == 5 || blk == 7 || blk == 8) ? sizeof(int) : sizeof(double));
+        }
+        return o;
+      };
+      off = skip_node(off, nullptr);
+      size_t pu = 0;
+      skip_node(off, &pu);
+      if (pu) {
+        const int badv = 1 << 28;
+        std::memcpy(b.data() + pu, &badv, sizeof(int));
+        ok = refused(b, "permutation entry") && ok;
+      }
+    }
+    if (!ok) return 1;
+  }
   std::remove(fname.c_str());
   if (G.rows() != H.rows() || G.rank() != H.rank() || G.levels() != H.levels() || G.memory() != H.memory() || !G.is_compressed()) {
     std::cout << "ERROR: header of the matrix read back differs" << std::endl;
