@@ -387,6 +387,9 @@ typedef struct hssk_shift_desc {
   int n, lda;
 } hssk_shift_desc;
 int hssk_shift_diag(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, double sigma);
+/* the same for the real 2n x 2n image [re -im; im re] (entries interleaved) of a complex matrix: adds the image of
+ * (re + i im) I, i.e. A(k,k) += re, A(2j, 2j+1) -= im, A(2j+1, 2j) += im; n (the real dimension) must be even */
+int hssk_shift_diag_cplx(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, double re, double im);
 /* peak-rate probe: runs a dependent-free v_mfma_f64_16x16x4_f64 loop on every CU and returns the
  * measured TFLOP/s (used by bench.py to confirm the FP64 matrix roof on the box) */
 double hssk_mfma_f64_peak_tflops(hssk_ctx* ctx, int iters);

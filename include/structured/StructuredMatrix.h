@@ -60,6 +60,30 @@ int SP_d_struct_solve(const CSPStructMat S, int nrhs, double* B, int ldB);
 /* reference :580 -- S <- S + s I (factor again afterwards) */
 int SP_d_struct_shift(CSPStructMat S, double s);
 
+/* ---- single precision and complex variants (reference :103-602): same conventions as SP_d_*; the handle types are
+ * distinct per precision (a matrix made by SP_z_struct_from_dense must only go to SP_z_struct_* routines).  These
+ * instantiations are carried by the double-precision MI355X engine: float is promoted to double, a complex matrix is
+ * compressed through its interleaved real image (see csrc/host/HSSMatrixPromoted.hpp), so a complex caller's vectors are
+ * used in place.  SP_?_struct_rank reports ranks in the caller's scalar type. */
+#define SPX_DECLARE_C_API(P, CT)                                                                                        \
+  void SP_##P##_struct_default_options(CSPOptions* opts);                                                               \
+  void SP_##P##_struct_destroy(CSPStructMat* S);                                                                        \
+  int SP_##P##_struct_rows(const CSPStructMat S);                                                                       \
+  int SP_##P##_struct_cols(const CSPStructMat S);                                                                       \
+  long long int SP_##P##_struct_memory(const CSPStructMat S);                                                           \
+  long long int SP_##P##_struct_nonzeros(const CSPStructMat S);                                                         \
+  int SP_##P##_struct_rank(const CSPStructMat S);                                                                       \
+  int SP_##P##_struct_from_dense(CSPStructMat* S, int rows, int cols, const CT* A, int ldA, const CSPOptions* opts);    \
+  int SP_##P##_struct_from_elements(CSPStructMat* S, int rows, int cols, CT A(int i, int j), const CSPOptions* opts);   \
+  int SP_##P##_struct_mult(const CSPStructMat S, char trans, int m, const CT* B, int ldB, CT* C, int ldC);              \
+  int SP_##P##_struct_factor(CSPStructMat S);                                                                           \
+  int SP_##P##_struct_solve(const CSPStructMat S, int nrhs, CT* B, int ldB);                                            \
+  int SP_##P##_struct_shift(CSPStructMat S, CT s);
+SPX_DECLARE_C_API(s, float)
+SPX_DECLARE_C_API(c, float _Complex)
+SPX_DECLARE_C_API(z, double _Complex)
+#undef SPX_DECLARE_C_API
+
 /* ---- extensions (not in the reference): HSS knobs and device-resident operands ---------------- */
 /* HSSOptions beyond CSPOptions (HSS/HSSOptions.hpp:465-490); call between default_options and from_* */
 typedef struct SPXHSSOptions {

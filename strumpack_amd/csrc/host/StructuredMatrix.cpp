@@ -3,6 +3,7 @@
 #include "StructuredMatrix.hpp"
 
 #include "HSSMatrix.hpp"
+#include "HSSMatrixPromoted.hpp"
 
 namespace strumpack {
 namespace structured {
@@ -119,6 +120,58 @@ std::unique_ptr<StructuredMatrix<double>> construct_partially_matrix_free(int ro
   };
   return construct_partially_matrix_free<double>(rows, cols, Amult, blk, opts, row_tree, col_tree);
 }
+
+// ---- float / complex instantiations (reference: explicit instantiations at the end of structured/StructuredMatrix.cpp);
+// computed by the double-precision device engine through HSSMatrixPromoted.hpp
+#define SPX_PROMOTED_FACTORIES(T)                                                                                          \
+  template <>                                                                                                              \
+  std::unique_ptr<StructuredMatrix<T>> construct_from_dense(const DenseMatrix<T>& A, const StructuredOptions<T>& opts,     \
+                                                            const ClusterTree* row_tree, const ClusterTree*,               \
+                                                            const admissibility_t*) {                                      \
+    if (opts.type() != Type::HSS)                                                                                          \
+      throw std::invalid_argument("Structured type " + get_name(opts.type()) + " is not available in this build (HSS hot path only)."); \
+    if (A.rows() != A.cols()) throw std::invalid_argument("HSS compression only supported for square matrices.");         \
+    HSS::HSSOptions<double> ho{to_double_options(opts)};                                                           \
+    std::unique_ptr<HSS::HSSMatrix<T>> H(row_tree ? new HSS::HSSMatrix<T>(*row_tree, ho)                                   \
+                                                  : new HSS::HSSMatrix<T>(A.rows(), A.cols(), ho));                        \
+    H->compress(A, ho);                                                                                                    \
+    return std::unique_ptr<StructuredMatrix<T>>(H.release());                                                              \
+  }                                                                                                                        \
+  template <>                                                                                                              \
+  std::unique_ptr<StructuredMatrix<T>> construct_from_dense(int rows, int cols, const T* A, int ldA,                       \
+                                                            const StructuredOptions<T>& opts, const ClusterTree* row_tree, \
+                                                            const ClusterTree* col_tree, const admissibility_t* adm) {     \
+    auto M = ConstDenseMatrixWrapper<T>(rows, cols, A, ldA);                                                               \
+    return construct_from_dense<T>(M, opts, row_tree, col_tree, adm);                                                      \
+  }                                                                                                                        \
+  template <>                                                                                                              \
+  std::unique_ptr<StructuredMatrix<T>> construct_from_elements(int rows, int cols, const extract_block_t<T>& A,            \
+                                                               const StructuredOptions<T>& opts, const ClusterTree* row_tree, \
+                                                               const ClusterTree*, const admissibility_t*,                \
+                                                               const DenseMatrix<T>*) { \
+    if (opts.type() != Type::HSS)                                                                                          \
+      throw std::invalid_argument("Structured type " + get_name(opts.type()) + " is not available in this build (HSS hot path only)."); \
+    if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");                 \
+    HSS::HSSOptions<double> ho{to_double_options(opts)};                                                           \
+    std::unique_ptr<HSS::HSSMatrix<T>> H(row_tree ? new HSS::HSSMatrix<T>(*row_tree, ho) : new HSS::HSSMatrix<T>(rows, cols, ho)); \
+    H->compress(A, ho);                                                                                                    \
+    return std::unique_ptr<StructuredMatrix<T>>(H.release());                                                              \
+  }                                                                                                                        \
+  template <>                                                                                                              \
+  std::unique_ptr<StructuredMatrix<T>> construct_from_elements(int rows, int cols, const extract_t<T>& A,                  \
+                                                               const StructuredOptions<T>& opts, const ClusterTree* row_tree, \
+                                                               const ClusterTree* col_tree, const admissibility_t* adm,   \
+                                                               const DenseMatrix<T>* p) { \
+    extract_block_t<T> blk = [&A](const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseMatrix<T>& B) { \
+      for (std::size_t j = 0; j < J.size(); j++)                                                                           \
+        for (std::size_t i = 0; i < I.size(); i++) B(i, j) = A(I[i], J[j]);                                                \
+    };                                                                                                                     \
+    return construct_from_elements<T>(rows, cols, blk, opts, row_tree, col_tree, adm, p);                                  \
+  }
+SPX_PROMOTED_FACTORIES(float)
+SPX_PROMOTED_FACTORIES(std::complex<float>)
+SPX_PROMOTED_FACTORIES(std::complex<double>)
+#undef SPX_PROMOTED_FACTORIES
 
 }  // namespace structured
 }  // namespace strumpack

@@ -1,5 +1,6 @@
 // C interface SP_d_struct_* (reference structured/StructuredMatrixC.cpp:61-119 handle + error
 // convention, :83-821 entry points) and the SPX_* device-operand extensions.
+#include <complex>
 #include <cstdlib>
 #include <iostream>
 
@@ -19,6 +20,20 @@ struct CStructMat {
 inline StructuredMatrix<double>* mat(const CSPStructMat S) { return static_cast<CStructMat*>(S)->S.get(); }
 inline HSS::HSSMatrix<double>* hss(const CSPStructMat S) { return dynamic_cast<HSS::HSSMatrix<double>*>(mat(S)); }
 
+template <typename T> struct CStructMatT {
+  std::unique_ptr<StructuredMatrix<T>> S;
+};
+template <typename T> inline StructuredMatrix<T>* matT(const CSPStructMat S) { return static_cast<CStructMatT<T>*>(S)->S.get(); }
+template <typename T> StructuredOptions<T> get_options_t(const CSPOptions* o) {
+  StructuredOptions<T> opts;
+  opts.set_type(Type(int(o->type)));
+  opts.set_rel_tol(o->rel_tol);
+  opts.set_abs_tol(o->abs_tol);
+  opts.set_leaf_size(o->leaf_size);
+  opts.set_max_rank(o->max_rank);
+  opts.set_verbose(o->verbose != 0);
+  return opts;
+}
 StructuredOptions<double> get_options(const CSPOptions* o) {
   StructuredOptions<double> opts;
   opts.set_type(Type(int(o->type)));
@@ -106,6 +121,64 @@ int SP_d_struct_shift(CSPStructMat S, double s) {
   mat(S)->shift(s);
   SP_CATCH
 }
+
+// ---- single precision and complex entry points (reference StructuredMatrix.h:103-602, StructuredMatrixC.cpp:83-821):
+// same conventions as SP_d_*; carried by the double-precision device engine (HSSMatrixPromoted.hpp)
+#define SPX_C_API(P, T, CT, TOCPP, REAL)                                                                             \
+  void SP_##P##_struct_default_options(CSPOptions* o) {                                                              \
+    StructuredOptions<T> d;                                                                                          \
+    o->type = SP_STRUCTURED_TYPE(int(d.type()));                                                                     \
+    o->rel_tol = d.rel_tol(); o->abs_tol = d.abs_tol(); o->leaf_size = d.leaf_size();                                \
+    o->max_rank = d.max_rank(); o->verbose = d.verbose();                                                            \
+  }                                                                                                                  \
+  void SP_##P##_struct_destroy(CSPStructMat* S) { delete static_cast<CStructMatT<T>*>(*S); *S = NULL; }              \
+  int SP_##P##_struct_rows(const CSPStructMat S) { return int(matT<T>(S)->rows()); }                                 \
+  int SP_##P##_struct_cols(const CSPStructMat S) { return int(matT<T>(S)->cols()); }                                 \
+  long long int SP_##P##_struct_memory(const CSPStructMat S) { return (long long)matT<T>(S)->memory(); }             \
+  long long int SP_##P##_struct_nonzeros(const CSPStructMat S) { return (long long)matT<T>(S)->nonzeros(); }         \
+  int SP_##P##_struct_rank(const CSPStructMat S) { return int(matT<T>(S)->rank()); }                                 \
+  int SP_##P##_struct_from_dense(CSPStructMat* S, int rows, int cols, const CT* A, int ldA, const CSPOptions* opts) { \
+    SP_TRY                                                                                                           \
+    std::unique_ptr<CStructMatT<T>> s(new CStructMatT<T>);                                                           \
+    s->S = construct_from_dense<T>(rows, cols, reinterpret_cast<const T*>(A), ldA, get_options_t<T>(opts));          \
+    *S = s.release();                                                                                                \
+    SP_CATCH                                                                                                         \
+  }                                                                                                                  \
+  int SP_##P##_struct_from_elements(CSPStructMat* S, int rows, int cols, CT A(int i, int j), const CSPOptions* opts) { \
+    SP_TRY                                                                                                           \
+    std::unique_ptr<CStructMatT<T>> s(new CStructMatT<T>);                                                           \
+    extract_t<T> f = [A](std::size_t i, std::size_t j) { const CT v = A(int(i), int(j)); return TOCPP(v); };         \
+    s->S = construct_from_elements<T>(rows, cols, f, get_options_t<T>(opts));                                        \
+    *S = s.release();                                                                                                \
+    SP_CATCH                                                                                                         \
+  }                                                                                                                  \
+  int SP_##P##_struct_mult(const CSPStructMat S, char trans, int m, const CT* B, int ldB, CT* C, int ldC) {          \
+    SP_TRY                                                                                                           \
+    matT<T>(S)->mult(c2T(trans), m, reinterpret_cast<const T*>(B), ldB, reinterpret_cast<T*>(C), ldC);               \
+    SP_CATCH                                                                                                         \
+  }                                                                                                                  \
+  int SP_##P##_struct_factor(CSPStructMat S) {                                                                       \
+    SP_TRY                                                                                                           \
+    matT<T>(S)->factor();                                                                                            \
+    SP_CATCH                                                                                                         \
+  }                                                                                                                  \
+  int SP_##P##_struct_solve(const CSPStructMat S, int nrhs, CT* B, int ldB) {                                        \
+    SP_TRY                                                                                                           \
+    matT<T>(S)->solve(nrhs, reinterpret_cast<T*>(B), ldB);                                                           \
+    SP_CATCH                                                                                                         \
+  }                                                                                                                  \
+  int SP_##P##_struct_shift(CSPStructMat S, CT s) {                                                                  \
+    SP_TRY                                                                                                           \
+    matT<T>(S)->shift(TOCPP(s));                                                                                     \
+    SP_CATCH                                                                                                         \
+  }
+#define SPX_ID(v) (v)
+#define SPX_CF(v) std::complex<float>(__real__(v), __imag__(v))
+#define SPX_CD(v) std::complex<double>(__real__(v), __imag__(v))
+SPX_C_API(s, float, float, SPX_ID, float)
+SPX_C_API(c, std::complex<float>, float _Complex, SPX_CF, float)
+SPX_C_API(z, std::complex<double>, double _Complex, SPX_CD, double)
+#undef SPX_C_API
 
 // ---- extensions ------------------------------------------------------------------------------
 void SPX_d_struct_default_hss_options(SPXHSSOptions* h) {

@@ -1,6 +1,7 @@
 // structured::StructuredOptions<T> and Type (reference: structured/StructuredOptions.hpp:56-162,
 // StructuredOptions.cpp:53-60).  Same setters/getters, defaults and --structured_* flags.
 #pragma once
+#include <complex>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -40,8 +41,12 @@ inline bool match_flag(int argc, const char* const* argv, int& i, const char* na
 }
 }  // namespace detail
 
+// real type of a scalar type (reference: misc/RandomWrapper.hpp RealType)
+template <typename T> struct RealType { using value_type = T; };
+template <typename R> struct RealType<std::complex<R>> { using value_type = R; };
+
 template <typename scalar_t> class StructuredOptions {
-  using real_t = scalar_t;  // only real double is instantiated in this build
+  using real_t = typename RealType<scalar_t>::value_type;
 
  public:
   StructuredOptions() {}
@@ -92,6 +97,14 @@ template <typename scalar_t> class StructuredOptions {
   int max_rank_ = 5000;
   bool verbose_ = true;
 };
+
+// the same options for the double-precision engine that carries the float / complex instantiations
+template <typename T> StructuredOptions<double> to_double_options(const StructuredOptions<T>& o) {
+  StructuredOptions<double> d(o.type());
+  d.set_rel_tol(o.rel_tol()); d.set_abs_tol(o.abs_tol()); d.set_leaf_size(o.leaf_size());
+  d.set_pivot_threshold(o.pivot_threshold()); d.set_max_rank(o.max_rank()); d.set_verbose(o.verbose());
+  return d;
+}
 
 }  // namespace structured
 }  // namespace strumpack

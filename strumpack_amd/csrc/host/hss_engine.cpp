@@ -1920,6 +1920,19 @@ void DeviceHSS::shift(double sigma) {
   drop_plans();
 }
 
+void DeviceHSS::shift_cplx(double re, double im) {
+  std::vector<hssk_shift_desc> d;
+  for (auto& nd : nodes_)
+    if (nd.leaf() && nd.D) {
+      if ((nd.lo | nd.m) & 1) throw std::logic_error("shift_cplx: leaf boundaries must be even (embedded complex matrix)");
+      d.push_back(hssk_shift_desc{nd.D, nd.m, nd.m});
+    }
+  if (!d.empty()) ck(hssk_shift_diag_cplx(ctx_, d.data(), (int)d.size(), re, im));
+  ck(hssk_sync(ctx_));
+  factored_ = partial_factored_ = schur_ready_ = false;
+  drop_plans();
+}
+
 // ---------------------------------------------------------------------------------------------
 // mult: apply_HSS (HSSMatrix.cpp:419-435, HSSMatrix.apply.hpp:55-220)
 // ---------------------------------------------------------------------------------------------

@@ -128,6 +128,8 @@ class DeviceHSS {
   void factor();
   void solve(int nrhs, double* b, long long ldb, bool on_device);
   void shift(double sigma);
+  // the matrix is the real image [re -im; im re] (interleaved) of a complex one: adds the image of (re + i im) I
+  void shift_cplx(double re, double im);
 
   // ---- Schur complement of the (0,0) block, H11 - H10 H00^{-1} H01 (HSSMatrix.Schur.hpp, factor.hpp:43-49);
   //      single-process matrices with a non-leaf root.  After partial_factor() + schur_update() the factors

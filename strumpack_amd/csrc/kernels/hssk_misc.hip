@@ -191,6 +191,17 @@ __global__ void shift_diag_kernel(const hssk_shift_desc* __restrict__ descs, dou
   for (int i = threadIdx.x; i < p.n; i += blockDim.x) p.A[i + (size_t)i * p.lda] += sigma;
 }
 
+__global__ void shift_diag_cplx_kernel(const hssk_shift_desc* __restrict__ descs, double re, double im) {
+  const hssk_shift_desc p = descs[blockIdx.x];
+  for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
+    p.A[i + (size_t)i * p.lda] += re;
+    if ((i & 1) == 0 && i + 1 < p.n) {
+      p.A[i + (size_t)(i + 1) * p.lda] -= im;
+      p.A[(i + 1) + (size_t)i * p.lda] += im;
+    }
+  }
+}
+
 // FP64 matrix-core peak probe: 4 independent accumulators per wave, no memory traffic
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
   hssk_d4 c0 = {0., 0., 0., 0.}, c1 = c0, c2 = c0, c3 = c0;
@@ -369,6 +380,15 @@ int hssk_shift_diag(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, doub
   if (count <= 0) return 0;
   auto* dd = (const hssk_shift_desc*)ctx->stage(descs, sizeof(*descs) * count);
   HSSK_LAUNCH(shift_diag_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd, sigma);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+int hssk_shift_diag_cplx(hssk_ctx* ctx, const hssk_shift_desc* descs, int count, double re, double im) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_shift_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(shift_diag_cplx_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dd, re, im);
   hssk_rt::check_launch();
   HSSK_API_END
 }

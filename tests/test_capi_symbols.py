@@ -41,6 +41,19 @@ def test_structured_c_api_symbols(lib):
     assert set(capi.SP_SYMBOLS) <= set(names)
 
 
+def test_single_precision_and_complex_c_api_symbols(lib):
+    """SP_s_ / SP_c_ / SP_z_struct_*: the names of the reference's C header (structured/StructuredMatrix.h:103-602),
+    declared through one macro in include/structured/StructuredMatrix.h"""
+    txt = open(os.path.join(ROOT, "include", "structured", "StructuredMatrix.h")).read()
+    stems = re.findall(r"SP_##P##_struct_(\w+)\(", txt)
+    assert set(stems) >= {"default_options", "destroy", "rows", "cols", "memory", "nonzeros", "rank", "from_dense",
+                          "from_elements", "mult", "factor", "solve", "shift"}
+    for p in "scz":
+        assert "SPX_DECLARE_C_API(%s," % p in txt
+        for st in set(stems):
+            assert hasattr(lib, "SP_%s_struct_%s" % (p, st)), "SP_%s_struct_%s not exported" % (p, st)
+
+
 def test_kernel_c_api_symbols(lib):
     names = declared(os.path.join("kernel", "Kernel.h"))
     assert "STRUMPACK_kernel_fit_HSS_double" in names

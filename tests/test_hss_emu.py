@@ -54,3 +54,7 @@ def test_sweep_plans(L):
     hk = K.Hssk(emu_lib.PATH)
     HC.check_sweep_plans(L, hk, n=130)
     hk.close()
+
+
+def test_float_and_complex_instantiations(L):
+    HC.check_scz(L)
