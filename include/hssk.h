@@ -288,6 +288,9 @@ typedef struct hssk_lusolve_desc {
   int n, nrhs, lda, ldb;
 } hssk_lusolve_desc;
 int hssk_getrs_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count);
+/* B <- P B only: the row interchanges of getrf (0-based piv, n of them) applied to B (n x nrhs) in order  (DenseMatrix::laswp,
+ * dense/DenseMatrix.cpp:287-297); LU is not read */
+int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count);
 
 /* ---- single-launch tree sweeps (few right-hand sides) ---------------------------------------------------------
  * The forward / backward ULV sweeps (HSS/HSSMatrix.solve.hpp:69-238) and the mat-vec up / down sweeps

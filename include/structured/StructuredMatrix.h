@@ -3,8 +3,9 @@
  * implementation src/structured/StructuredMatrixC.cpp:83-821).  Double-precision real entry points
  * (SP_d_struct_*), same names, argument order, ownership and 0/1 return convention.
  *
- * This build implements type SP_TYPE_HSS (the MI355X HSS engine); the other types return 1 with
- * "Operation failed: ..." on stderr, exactly like a reference build configured without them.
+ * This build implements type SP_TYPE_HSS (the MI355X HSS engine) and, for dense operands, SP_TYPE_BLR (block low-rank:
+ * from_dense + mult, and compress-and-factor + solve); the other types return 1 with "Operation failed: ..." on stderr,
+ * exactly like a reference build configured without them.
  * Caller buffers are HOST memory (reference rule, doc/doxygen/pages/GPU_support.txt:24-26); the
  * SPX_* entry points at the end are extensions for operands already resident in HBM.
  */
@@ -85,6 +86,10 @@ SPX_DECLARE_C_API(z, double _Complex)
 #undef SPX_DECLARE_C_API
 
 /* ---- extensions (not in the reference): HSS knobs and device-resident operands ---------------- */
+/* structured::construct_and_factor_from_dense (reference structured/StructuredMatrix.hpp:536-553, no C binding there):
+ * compress and factor in one call -- for SP_TYPE_BLR the LU factorization is computed while the tiles are compressed
+ * (BLRMatrix::compress_and_factor) and SP_d_struct_solve applies it; SP_TYPE_HSS: construct + factor. */
+int SPX_d_struct_from_dense_and_factor(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts);
 /* HSSOptions beyond CSPOptions (HSS/HSSOptions.hpp:465-490); call between default_options and from_* */
 typedef struct SPXHSSOptions {
   int d0, dd, p;

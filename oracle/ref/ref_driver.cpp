@@ -268,6 +268,29 @@ int ref_hss_bench_toeplitz(int n, int leaf, double rel_tol, double abs_tol, int 
 }
 
 
+// ---- BLR, dense slice: structured::construct_from_dense / construct_and_factor_from_dense with
+// type BLR (structured/StructuredMatrix.cpp:77-97, 408-430).  Y = B X of the compressed matrix, Z = A^{-1} X through the
+// BLR LU; stats: rank, memory (bytes), nonzeros of the compressed matrix.
+int ref_blr_dense(int n, const double* A, int leaf, double rel_tol, double abs_tol, int nrhs, const double* X,
+                  double* Y, double* Z, double* stats) {
+  structured::StructuredOptions<double> o;
+  o.set_type(structured::Type::BLR);
+  o.set_leaf_size(leaf);
+  o.set_rel_tol(rel_tol);
+  o.set_abs_tol(abs_tol);
+  o.set_verbose(false);
+  DenseMatrix<double> Ad(n, n, A, n), Xd(n, nrhs, X, n), Yd(n, nrhs);
+  auto B = structured::construct_from_dense(Ad, o);
+  B->mult(Trans::N, Xd, Yd);
+  std::memcpy(Y, Yd.data(), sizeof(double) * n * nrhs);
+  stats[0] = B->rank(); stats[1] = B->memory(); stats[2] = B->nonzeros();
+  auto F = structured::construct_and_factor_from_dense(Ad, o);
+  DenseMatrix<double> Zd(Xd);
+  F->solve(Zd);
+  std::memcpy(Z, Zd.data(), sizeof(double) * n * nrhs);
+  return 0;
+}
+
 // ---- kernel-matrix front end: HSSMatrix(kernel::Kernel&, opts), HSS/HSSMatrix.cpp:88-106 ----
 // data: d x n column-major (one point per column), copied; the reference reorders its copy while clustering.
 struct RefKernelHSS {

@@ -29,7 +29,7 @@ SP_SYMBOLS = [
     "SPX_d_struct_levels", "SPX_d_struct_is_compressed", "SPX_d_struct_num_nodes",
     "SPX_d_struct_node_info", "SPX_d_struct_stats", "SPX_d_struct_hssk_ctx",
     "SPX_d_struct_from_kernel", "SPX_d_struct_from_kernel_sharded",
-    "SPX_comm_unique_id", "SPX_comm_create", "SPX_comm_destroy", "SPX_comm_size", "SPX_comm_rank", "SPX_comm_selftest", "SPX_struct_shard_range",
+    "SPX_d_struct_from_dense_and_factor", "SPX_comm_unique_id", "SPX_comm_create", "SPX_comm_destroy", "SPX_comm_size", "SPX_comm_rank", "SPX_comm_selftest", "SPX_struct_shard_range",
     "SPX_d_struct_from_dense_device_comm", "SPX_d_struct_from_blocks_device", "SPX_d_struct_from_blocks_device_cb",
     "SPX_d_struct_from_kernel_comm",
 ]
@@ -70,6 +70,7 @@ def load(path):
                                            C.POINTER(CSPOptions), C.c_int, C.c_int, vp]
     L.SPX_d_struct_from_kernel_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
                                                    C.POINTER(CSPOptions), C.c_int, C.c_int, vp, C.c_int, C.c_int, ALLGATHER_CB, vp]
+    L.SPX_d_struct_from_dense_and_factor.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.POINTER(CSPOptions)]
     L.SPX_comm_unique_id.argtypes = [C.c_char_p]
     L.SPX_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p]
     L.SPX_comm_destroy.argtypes = [C.POINTER(vp)]
@@ -163,6 +164,15 @@ class StructuredMatrix:
                                                  C.byref(opts), C.byref(hss))
         if rc:
             raise RuntimeError("SP_d_struct_from_dense failed")
+        return cls(lib, h, A.shape[0])
+
+    @classmethod
+    def from_dense_and_factor(cls, lib, A, opts):
+        """structured::construct_and_factor_from_dense (BLR: LU while compressing; HSS: construct + factor)"""
+        A = np.asfortranarray(A, dtype=np.float64)
+        h = C.c_void_p()
+        if lib.SPX_d_struct_from_dense_and_factor(C.byref(h), A.shape[0], A.shape[1], A.ctypes.data, A.shape[0], C.byref(opts)):
+            raise RuntimeError("SPX_d_struct_from_dense_and_factor failed")
         return cls(lib, h, A.shape[0])
 
     @classmethod

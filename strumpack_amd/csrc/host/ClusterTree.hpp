@@ -26,10 +26,20 @@ class ClusterTree {
     }
     return *this;
   }
+  // sizes of the leaves, left to right (reference :152-158)
+  template <typename T = int> std::vector<T> leaf_sizes() const {
+    std::vector<T> l;
+    collect(l);
+    return l;
+  }
   void print() const { for (auto& ch : c) ch.print(); std::cout << size << " "; }
   bool is_complete() const {
     if (c.empty()) return true;
     return c.size() == 2 && c[0].is_complete() && c[1].is_complete();
+  }
+  template <typename T> void collect(std::vector<T>& l) const {
+    if (c.empty()) l.push_back(T(size));
+    else for (auto& ch : c) ch.collect(l);
   }
   int levels() const { int l = 0; for (auto& ch : c) l = std::max(l, ch.levels()); return l + 1; }
 };

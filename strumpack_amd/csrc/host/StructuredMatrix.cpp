@@ -2,6 +2,7 @@
 // dense, :203-273 elements, :637-651 partially matrix-free).
 #include "StructuredMatrix.hpp"
 
+#include "BLRMatrix.hpp"
 #include "HSSMatrix.hpp"
 #include "HSSMatrixPromoted.hpp"
 
@@ -11,7 +12,7 @@ namespace structured {
 namespace {
 void require_hss(Type t, int rows, int cols) {
   if (t != Type::HSS)
-    throw std::invalid_argument("Structured type " + get_name(t) + " is not available in this build (HSS hot path only).");
+    throw std::invalid_argument("Structured type " + get_name(t) + " is not available in this build (HSS and dense BLR only).");
   if (rows != cols) throw std::invalid_argument("HSS compression only supported for square matrices.");
 }
 HSS::HSSMatrix<double>* new_hss(int n, const StructuredOptions<double>& opts, const ClusterTree* row_tree,
@@ -21,9 +22,29 @@ HSS::HSSMatrix<double>* new_hss(int n, const StructuredOptions<double>& opts, co
 }
 }  // namespace
 
+// BLR of a dense matrix (reference structured/StructuredMatrix.cpp:77-97, :408-430): tiles = the leaves of the cluster
+// trees (default: bisection refined to leaf_size), every tile admissible unless an admissibility matrix says otherwise
+std::unique_ptr<StructuredMatrix<double>> blr_from_dense(const DenseMatrix<double>& A, const StructuredOptions<double>& opts,
+                                                         const ClusterTree* row_tree, const ClusterTree* col_tree,
+                                                         const admissibility_t* adm, bool factor) {
+  auto row_leafs = row_tree ? row_tree->leaf_sizes<std::size_t>() : ClusterTree(int(A.rows())).refine(opts.leaf_size()).leaf_sizes<std::size_t>();
+  auto col_leafs = col_tree ? col_tree->leaf_sizes<std::size_t>() : ClusterTree(int(A.cols())).refine(opts.leaf_size()).leaf_sizes<std::size_t>();
+  std::unique_ptr<BLR::BLRMatrix<double>> B(new BLR::BLRMatrix<double>(A.rows(), row_leafs, A.cols(), col_leafs));
+  BLR::BLROptions<double> bo(opts);
+  DenseMatrix<bool> ad(row_leafs.size(), col_leafs.size());
+  if (adm) {
+    if (adm->rows() != row_leafs.size() || adm->cols() != col_leafs.size()) throw std::invalid_argument("Admissibility matrix wrong size");
+    ad = *adm;
+  } else ad.fill(true);
+  if (factor) B->compress_and_factor(A, ad, bo);
+  else B->compress(A, ad, bo);
+  return std::unique_ptr<StructuredMatrix<double>>(B.release());
+}
+
 template <>
 std::unique_ptr<StructuredMatrix<double>> construct_from_dense(const DenseMatrix<double>& A, const StructuredOptions<double>& opts,
-                                                               const ClusterTree* row_tree, const ClusterTree*, const admissibility_t*) {
+                                                               const ClusterTree* row_tree, const ClusterTree* col_tree, const admissibility_t* adm) {
+  if (opts.type() == Type::BLR) return blr_from_dense(A, opts, row_tree, col_tree, adm, false);
   require_hss(opts.type(), int(A.rows()), int(A.cols()));
   HSS::HSSOptions<double> ho;
   std::unique_ptr<HSS::HSSMatrix<double>> H(new_hss(int(A.rows()), opts, row_tree, ho));
@@ -78,6 +99,7 @@ template <>
 std::unique_ptr<StructuredMatrix<double>> construct_and_factor_from_dense(const DenseMatrix<double>& A, const StructuredOptions<double>& opts,
                                                                           const ClusterTree* row_tree, const ClusterTree* col_tree,
                                                                           const admissibility_t* adm) {
+  if (opts.type() == Type::BLR) return blr_from_dense(A, opts, row_tree, col_tree, adm, true);
   auto S = construct_from_dense<double>(A, opts, row_tree, col_tree, adm);
   S->factor();
   return S;

@@ -181,6 +181,16 @@ SPX_C_API(z, std::complex<double>, double _Complex, SPX_CD, double)
 #undef SPX_C_API
 
 // ---- extensions ------------------------------------------------------------------------------
+// structured::construct_and_factor_from_dense (structured/StructuredMatrix.hpp:536-553) -- the route to a factored BLR
+// matrix (its LU is computed while the tiles are compressed, BLRMatrix::compress_and_factor); HSS: construct + factor
+int SPX_d_struct_from_dense_and_factor(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts) {
+  SP_TRY
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  auto M = ConstDenseMatrixWrapper<double>(rows, cols, A, ldA);
+  s->S = construct_and_factor_from_dense<double>(M, get_options(opts));
+  *S = s.release();
+  SP_CATCH
+}
 void SPX_d_struct_default_hss_options(SPXHSSOptions* h) {
   HSS::HSSOptions<double> d;
   h->d0 = d.d0(); h->dd = d.dd(); h->p = d.p();

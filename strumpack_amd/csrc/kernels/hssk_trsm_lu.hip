@@ -230,9 +230,33 @@ __global__ void laswp_kernel(const hssk_lusolve_desc* __restrict__ descs) {
   }
 }
 
+// the same with the right-hand sides spread over blockIdx.y (wide blocks: a whole block row of a BLR factorization)
+__global__ void laswp_wide_kernel(const hssk_lusolve_desc* __restrict__ descs) {
+  const hssk_lusolve_desc p = descs[blockIdx.x];
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < p.nrhs; c += gridDim.y * blockDim.x) {
+    double* b = p.B + (size_t)c * p.ldb;
+    for (int k = 0; k < p.n; k++) {
+      int pv = p.piv[k];
+      if (pv != k) { double t = b[k]; b[k] = b[pv]; b[pv] = t; }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  int cmax = 0;
+  for (int i = 0; i < count; i++) cmax = std::max(cmax, descs[i].nrhs);
+  if (cmax <= 0) return 0;
+  auto* dd = (const hssk_lusolve_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(laswp_wide_kernel, dim3((unsigned)count, (unsigned)std::min(256, (cmax + 63) / 64)), dim3(64), 0, ctx->stream, dd);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
 
 int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count) {
   HSSK_API_BEGIN

@@ -58,3 +58,7 @@ def test_sweep_plans(L):
 
 def test_float_and_complex_instantiations(L):
     HC.check_scz(L)
+
+
+def test_blr_dense_slice(L):
+    HC.check_blr(L, max_n=1000)

@@ -171,6 +171,30 @@ def test_rccl_exchange_hook_single_rank():
         dist.destroy_process_group()
 
 
+def test_blr_dense_slice(L):
+    HC.check_blr(L)
+
+
+def test_blr_32k_toeplitz_front(L):
+    """BASELINE configs[4]-sized dense front: 32768 x 32768 Toeplitz, BLR compress + mult and compress-and-factor + solve at
+    full size, checked through size-independent properties (products against exact rows of A, residual of the solve)."""
+    n = 32768
+    i = np.arange(n)
+    A = np.asfortranarray(1.0 / (1.0 + np.abs(i[:, None] - i[None, :])))
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-12, leaf_size=128, type=capi.SP_TYPE_BLR)
+    B = capi.StructuredMatrix.from_dense(L, A, o)
+    assert 0 < B.rank() <= 40 and B.memory() < 0.12 * 8 * n * n
+    X = np.random.default_rng(9).standard_normal((n, 2))
+    Y = B.mult(X)
+    AX = A @ X
+    assert np.linalg.norm(Y - AX) <= 1e-5 * np.linalg.norm(AX)
+    B.destroy()
+    F = capi.StructuredMatrix.from_dense_and_factor(L, A, o)
+    Z = F.solve(X)
+    assert np.linalg.norm(A @ Z - X) <= 1e-5 * np.linalg.norm(X)
+    F.destroy()
+
+
 def test_float_and_complex_instantiations(L):
     HC.check_scz(L)
 
