@@ -296,10 +296,13 @@ int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count
  * The forward / backward ULV sweeps (HSS/HSSMatrix.solve.hpp:69-238) and the mat-vec up / down sweeps
  * (HSS/HSSMatrix.apply.hpp:55-220) of a whole (sub)tree as ONE launch each: one workgroup per node, ordered so that a
  * node only depends on lower-indexed descriptors (children before parents going up, parents before children going
- * down); wait* name those descriptors (-1: none / produced by an earlier launch), `consumers` = how many later
- * descriptors of the same launch wait on this one.  See kernels/hssk_sweep.hip.  nrhs <= 4 and node dimensions <= 256,
- * otherwise the call returns 2 and does nothing (the caller issues the batched calls instead).
+ * down); wait* name those descriptors (-1: none / produced by an earlier launch) and are checked for that order.  The
+ * vectors handed from node to node (ft1 / z / x going up and down the solve, tmp1 / tmp2 of the mat-vec) live in buffers
+ * that hssk_sweep_arm fills with a sentinel beforehand; a consumer polls the words it needs until they are written.  See
+ * kernels/hssk_sweep.hip.  nrhs <= 4 and node dimensions <= 256, otherwise the calls return 2 and do nothing (the
+ * caller issues the batched calls instead).
  * hssk_sweep_status: non-zero if a workgroup of an earlier sweep gave up waiting (checked after a synchronisation). */
+int hssk_sweep_arm(hssk_ctx* ctx, double* handoff, long long count);
 typedef struct hssk_sweep_fwd_desc {
   const double* fsrc;   /* m x nrhs right-hand side rows of the node (leaf: rows of b; inner: [ft1_0; ft1_1]) */
   const double *B01, *B10, *zc; /* inner nodes: f(0:rU0) -= B01 zc(rV0:), f(rU0:) -= B10 zc(0:rV0); leaves: NULL */
@@ -318,7 +321,7 @@ typedef struct hssk_sweep_fwd_desc {
   const int* piv;
   double* xroot;
   int ldf, rU0, rU1, rV0, rV1, ldz_in, m, r, mv, rv, ldp, ldz, ldxr;
-  int wait0, wait1, consumers;
+  int wait0, wait1;
 } hssk_sweep_fwd_desc;
 int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs);
 /* out (m x nrhs, ldo) = Qt(:, 0:m-r) y + Qt(:, m-r:) xpart */
@@ -326,7 +329,7 @@ typedef struct hssk_sweep_bwd_desc {
   const double *Qt, *y, *xpart;
   double* out;
   int m, r, ldx, ldo;
-  int wait0, consumers;
+  int wait0;
 } hssk_sweep_bwd_desc;
 int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* descs, int count, int nrhs);
 /* up: dst (r x nrhs, ldd) = src(perm[0:r], :) + X src(perm[r:], :)   (HSSBasisID::applyC; X is r x (m - r)) */
@@ -336,7 +339,8 @@ typedef struct hssk_apply_up_desc {
   const double* X;
   double* dst;
   int m, r, lds, ldd;
-  int wait0, wait1, consumers;
+  int inner; /* src holds the children's results (handed over inside the launch or by an earlier one); 0: rows of x */
+  int wait0, wait1;
 } hssk_apply_up_desc;
 /* down: leaf (D != NULL): out = op(D) x + beta out + U tmp2;  inner: out = [B01 t1_1; B10 t1_0] (trans: [B10^T t1_1;
  * B01^T t1_0]) + U tmp2, with U tmp2 = scatter through perm of [tmp2; X^T tmp2] (HSSBasisID::apply; X is ro x (mo - ro));
@@ -351,7 +355,7 @@ typedef struct hssk_apply_down_desc {
   double* out;
   double beta;
   int ld2, mo, ro, m, ldx, trans, ri_a, ri_b, ro_a, ro_b, ldt1, ldo;
-  int wait0, wait1, wait2, consumers;
+  int wait0, wait1, wait2;
 } hssk_apply_down_desc;
 int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, int nup, const hssk_apply_down_desc* downs, int ndown,
                      int nrhs);

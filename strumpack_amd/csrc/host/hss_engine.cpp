@@ -1989,13 +1989,24 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   auto rout = [&](const Node& nd) { return T ? nd.rV : nd.rU; };
   auto min_ = [&](const Node& nd) { return T ? nd.mU : nd.mV; };
   auto mout = [&](const Node& nd) { return T ? nd.mV : nd.mU; };
+  // (one block: these are the vectors handed from node to node; the single-launch sweep arms the block with a sentinel)
+  size_t hand_total = 0;
   for (size_t i = 0; i < nn; i++) {
     const Node& nd = nodes_[i];
     if (nd.leaf() || !mine((int)i) || (int)i < sr || (int)i >= sr_end) continue;
-    int ci = rin(nodes_[nd.c0]) + rin(nodes_[nd.c1]);
-    int co = rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]);
-    cat[i] = tmp.dbl((size_t)std::max(ci, 1) * nrhs);
-    tbuf[i] = tmp.dbl((size_t)std::max(co, 1) * nrhs);
+    hand_total += (size_t)std::max(rin(nodes_[nd.c0]) + rin(nodes_[nd.c1]), 1) * nrhs + (size_t)std::max(rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]), 1) * nrhs;
+  }
+  double* hand = tmp.dbl(std::max<size_t>(hand_total, 1));
+  {
+    size_t off = 0;
+    for (size_t i = 0; i < nn; i++) {
+      const Node& nd = nodes_[i];
+      if (nd.leaf() || !mine((int)i) || (int)i < sr || (int)i >= sr_end) continue;
+      int ci = rin(nodes_[nd.c0]) + rin(nodes_[nd.c1]);
+      int co = rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]);
+      cat[i] = hand + off; off += (size_t)std::max(ci, 1) * nrhs;
+      tbuf[i] = hand + off; off += (size_t)std::max(co, 1) * nrhs;
+    }
   }
   // ---- up-sweep, one height: tmp1 = Vin^H [..]
   auto up = [&](const std::vector<int>& ids) {
@@ -2085,6 +2096,7 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   // node and direction, dependency flags between them) instead of two to four batched launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_APPLY"); return e && e[0] == '1'; }();
   const bool fuse = nrhs <= 4 && !no_fuse;
+  if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto sweep = [&](const Levels* ups, const Levels* downs) -> bool {
     std::vector<hssk_apply_up_desc> U;
@@ -2104,6 +2116,7 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
           d.lds = nd.leaf() ? (int)lx : std::max(d.m, 1);
           d.dst = cat[nd.parent] + (id == pa.c0 ? 0 : rin(nodes_[pa.c0]));
           d.ldd = std::max(rin(nodes_[pa.c0]) + rin(nodes_[pa.c1]), 1);
+          d.inner = nd.leaf() ? 0 : 1;
           d.wait0 = nd.leaf() ? -1 : wu[nd.c0];
           d.wait1 = nd.leaf() ? -1 : wu[nd.c1];
           wu[id] = (int)U.size();
@@ -2142,9 +2155,6 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
           wd[id] = nup + (int)Dn.size();
           Dn.push_back(d);
         }
-    auto bump = [&](int w) { if (w >= 0) { if (w < nup) U[w].consumers++; else Dn[w - nup].consumers++; } };
-    for (auto& d : U) { bump(d.wait0); bump(d.wait1); }
-    for (auto& d : Dn) { bump(d.wait0); bump(d.wait1); bump(d.wait2); }
     if (U.empty() && Dn.empty()) return true;
     const int rc = hssk_apply_sweep(ctx_, U.data(), nup, Dn.data(), (int)Dn.size(), nrhs);
     if (rc == 2) return false;
@@ -2698,23 +2708,35 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   // f: assembled right-hand side of an inner node (mU rows; children write ft1 into it);
   // y: (mU - rU) rows; zc: children's z stacked (mV rows); xb: solution in the node's basis (mU rows)
   std::vector<double*> f(nn, nullptr), y(nn, nullptr), zc(nn, nullptr), xb(nn, nullptr);
+  // (f, zc, xb are handed from node to node: carved from one block that the single-launch sweeps arm with a sentinel)
+  size_t hand_total = 0;
   for (size_t i = 0; i < nn; i++) {
-    if (!mine((int)i)) continue;
+    if (!mine((int)i) || nodes_[i].leaf()) continue;
     const Node& nd = nodes_[i];
-    const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
-    const int mv = nd.leaf() ? nd.m : nodes_[nd.c0].rV + nodes_[nd.c1].rV;
-    if (!nd.leaf()) {
-      f[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
-      zc[i] = tmp.dbl((size_t)std::max(mv, 1) * nrhs);
-      xb[i] = tmp.dbl((size_t)std::max(mu, 1) * nrhs);
+    const int mu = nodes_[nd.c0].rU + nodes_[nd.c1].rU, mv = nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+    hand_total += (size_t)(2 * std::max(mu, 1) + std::max(mv, 1)) * nrhs;
+  }
+  double* hand = tmp.dbl(std::max<size_t>(hand_total, 1));
+  {
+    size_t off = 0;
+    for (size_t i = 0; i < nn; i++) {
+      if (!mine((int)i)) continue;
+      const Node& nd = nodes_[i];
+      if (!nd.leaf()) {
+        const int mu = nodes_[nd.c0].rU + nodes_[nd.c1].rU, mv = nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+        f[i] = hand + off; off += (size_t)std::max(mu, 1) * nrhs;
+        zc[i] = hand + off; off += (size_t)std::max(mv, 1) * nrhs;
+        xb[i] = hand + off; off += (size_t)std::max(mu, 1) * nrhs;
+      }
+      if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
     }
-    if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
   }
   // few right-hand sides: the whole forward sweep (root solve included) and the whole backward sweep are ONE launch each
   // (hssk_ulv_fwd_sweep / _bwd_sweep: a workgroup per node, dependency flags between them) instead of 7 / 3 batched
   // launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
   const bool fuse = nrhs <= 4 && !no_fuse;
+  if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto fwd_sweep = [&](const Levels& levels) -> bool {
     std::vector<hssk_sweep_fwd_desc> fd;
@@ -2758,10 +2780,6 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
         where[id] = (int)fd.size();
         fd.push_back(d);
       }
-    for (auto& d : fd) {
-      if (d.wait0 >= 0) fd[d.wait0].consumers++;
-      if (d.wait1 >= 0) fd[d.wait1].consumers++;
-    }
     if (fd.empty()) return true;
     const int rc = hssk_ulv_fwd_sweep(ctx_, fd.data(), (int)fd.size(), nrhs);
     if (rc == 2) return false;
@@ -2791,8 +2809,6 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
           bd.push_back(d);
         }
       }
-    for (auto& d : bd)
-      if (d.wait0 >= 0) bd[d.wait0].consumers++;
     if (bd.empty()) return true;
     const int rc = hssk_ulv_bwd_sweep(ctx_, bd.data(), (int)bd.size(), nrhs);
     if (rc == 2) return false;

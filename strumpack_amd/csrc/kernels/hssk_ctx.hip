@@ -20,7 +20,7 @@ thread_local std::vector<std::function<void()>>* hssk_rec::sink = nullptr;
 // ---- pipelined host -> device uploads (hssk_h2d_block_async) ----------------------------------------------------------
 struct hssk_uploader {
   static constexpr int SLOTS = 4;
-  static constexpr size_t CHUNK = size_t(64) << 20;
+  static constexpr size_t CHUNK = size_t(256) << 20;   // (large pieces: a piece costs one round of host-thread start-up)
   hssk_rt::stream_t copy{};
   hssk_rt::event_t ev_copy{}, ev_compute{};
   char* pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
@@ -49,7 +49,7 @@ static hssk_uploader* uploader(hssk_ctx* c) {
 static void host_pack(char* dst, const double* src, long long lds, long long rows, long long c0, long long c1) {
   const long long ncol = c1 - c0;
   const size_t colb = sizeof(double) * (size_t)rows;
-  const unsigned nt = (unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(32, std::thread::hardware_concurrency()), (long long)(colb * ncol >> 22) + 1));
+  const unsigned nt = (unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(24, std::thread::hardware_concurrency()), (long long)(colb * ncol >> 22) + 1));
   if (nt <= 1) {
     for (long long j = 0; j < ncol; j++) std::memcpy(dst + colb * j, src + (size_t)(c0 + j) * lds, colb);
     return;
@@ -172,7 +172,6 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   hssk_rt::dev_free(c->d_ring);
   hssk_rt::dev_free(c->d_scratch);
   delete c->uploader;
-  hssk_rt::dev_free(c->d_sweep_flags);
   hssk_rt::pinned_free(c->h_sweep_err);
   hssk_rt::event_destroy(c->ev0);
   hssk_rt::event_destroy(c->ev1);

@@ -5,12 +5,12 @@
 // is bound by launch-to-launch latency (N = 1e5: 20 launches, 0.55 ms apply / 1.07 ms solve for 0.19 / 0.52 GB of
 // blocks).  Here every node of the sweep is one workgroup of the same launch, ordered so that a node only depends on
 // workgroups with a LOWER index (children before parents going up, parents before children going down).  A workgroup
-// polls its dependencies' flags, does the node's arithmetic with the vectors in LDS, and publishes its own flag; the
-// handed-over vectors and the flags are coherent (sc1) accesses, see hssk_device.h.  Workgroups are dispatched in index order (round-robin over the XCDs,
-// in order within an XCD), so the lowest-indexed unfinished workgroup is always resident and never waits on a
-// non-resident one: the scheme cannot deadlock, whatever the occupancy; a bounded spin count turns any violation of
-// that assumption into an error code instead of a hang.  Flags count pending consumers and return to zero by the end
-// of the launch, so a recorded launch (hssk_plan_*) can be replayed as is.
+// waits for the vectors its dependencies hand over (coherent sc1 accesses, see below and hssk_device.h), does the node's
+// arithmetic with the vectors in LDS, and stores its own results for the next level.  Workgroups are dispatched in
+// index order (round-robin over the XCDs, in order within an XCD), so the lowest-indexed unfinished workgroup is always
+// resident and never waits on a non-resident one: the scheme cannot deadlock, whatever the occupancy; a bounded spin
+// count turns any violation of that assumption into an error code instead of a hang.  A recorded launch (hssk_plan_*)
+// is replayed together with the small launch that re-arms the hand-off buffers.
 //
 // Reference arithmetic: HSSMatrix::solve_fwd / solve_bwd (HSS/HSSMatrix.solve.hpp:69-238), apply_fwd / apply_bwd
 // (HSS/HSSMatrix.apply.hpp:55-220), HSSBasisID::apply / applyC (HSS/HSSBasisID.hpp:155-203).  Differences in the
@@ -35,25 +35,28 @@ constexpr int SW_MAX = 256;   // largest node dimension (rows of a basis)
 constexpr int SW_NB = 64;     // block size of the substitution with R~^T (hssk_trtri_diag_vbatched)
 constexpr long SW_SPIN_LIMIT = 1L << 22;
 
-// ---- dependency flags --------------------------------------------------------------------------------------------
-// wait until desc `idx` of this launch has published; the flag counts its pending consumers
-__device__ __forceinline__ void sweep_wait(int* flags, int idx, int* err) {
-  if (idx >= 0 && threadIdx.x == 0) {
-    long spins = 0;
-    while (hssk_flag_load(flags + idx) <= 0) {
-      hssk_pause();
-      if (++spins > SW_SPIN_LIMIT) { hssk_flag_raise(err); break; }
-    }
-    hssk_flag_sub(flags + idx, 1);
+// ---- hand-off between workgroups of one launch ---------------------------------------------------------------------
+// The vectors a node hands to its parent (or children) are a few hundred bytes.  They are written with coherent stores
+// and the consumer polls THE DATA WORDS THEMSELVES: the hand-off buffers are filled with a sentinel (a NaN with a payload
+// no computation produces) by one small launch before the sweep, and a consumer thread re-reads its element until it is
+// no longer the sentinel.  One memory round trip per tree level -- the first version (data, drain, flag store; poll the
+// flag, then load the data) paid three.  No flags, no consumer counts; the bounded spin turns a violated dispatch-order
+// assumption into an error code.
+constexpr unsigned long long SW_SENTINEL = 0x7FF8DEADBEEF5EEDull;
+__device__ __forceinline__ bool is_sentinel(double v) { return hssk_bits(v) == SW_SENTINEL; }
+__device__ __forceinline__ double sweep_take(const double* p, size_t off, int* err) {
+  double v = hssk_cload(p, off);
+  long spins = 0;
+  while (is_sentinel(v)) {
+    hssk_pause();
+    if (++spins > SW_SPIN_LIMIT) { hssk_flag_raise(err); return 0.; }
+    v = hssk_cload(p, off);
   }
+  return v;
 }
-// call with every thread after sweep_wait(s): the hand-off loads (hssk_cload) of the workgroup are issued behind thread 0's poll
-__device__ __forceinline__ void sweep_acquire() { __syncthreads(); }
-// call with every thread once the node's hand-off results are stored (hssk_cstore)
-__device__ __forceinline__ void sweep_publish(int* flags, int self, int consumers) {
-  hssk_drain_stores();
-  __syncthreads();
-  if (consumers > 0 && threadIdx.x == 0) hssk_flag_store(flags + self, consumers);
+__global__ void sweep_fill_kernel(double* p, long long count) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x)
+    hssk_cstore(p, (size_t)e, hssk_from_bits(SW_SENTINEL));
 }
 
 // ---- workgroup GEMVs on LDS vectors (leading dimension SW_MAX per right-hand side) -----------------------------------
@@ -161,8 +164,7 @@ __device__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, cons
 }
 
 // ---- forward ULV sweep ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs,
-                                                             int* flags, int* err) {
+__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs, int* err) {
   HSSK_SHARED double s_f[SW_MAX * SW_NR];    // f, later the block right-hand side of the substitution
   HSSK_SHARED double s_y[SW_MAX * SW_NR];    // zc(permV[rv:]) first, then y
   HSSK_SHARED double s_a[SW_MAX * SW_NR];    // stacked children z (inner nodes)
@@ -198,16 +200,13 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
     }
     keep(sink, s_p);
   }
-  sweep_wait(flags, p.wait0, err);
-  sweep_wait(flags, p.wait1, err);
-  sweep_acquire();
-  // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] (inner); zc = stacked children z, s_y = its rows permV[rv:] (for V^H zc)
+  // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] (inner: handed over by the children); zc = stacked children z
   for (int e = tid; e < m * nrhs; e += SW_T) {
     const int i = e % m, c = e / m;
-    s_f[i + c * SW_MAX] = hssk_cload(p.fsrc, i + (size_t)c * p.ldf);
+    s_f[i + c * SW_MAX] = inner ? sweep_take(p.fsrc, i + (size_t)c * p.ldf, err) : hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
   }
   if (inner)
-    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = hssk_cload(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in);
+    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = sweep_take(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in, err);
   __syncthreads();
   if (inner) {
     const bool zpart = !p.LU && rv > 0;
@@ -263,7 +262,6 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
       }
     }
     for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.xroot, (e % m) + (size_t)(e / m) * p.ldxr, s_f[(e % m) + (e / m) * SW_MAX]);
-    sweep_publish(flags, blockIdx.x, p.consumers);
     return;
   }
   // ---- ft1 = f(perm[0:r]) -> s_t, y = f(perm[r:]) -> s_y
@@ -302,12 +300,10 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
   }
   for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * SW_MAX]);
   for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * SW_MAX]);
-  sweep_publish(flags, blockIdx.x, p.consumers);
 }
 
 // ---- backward ULV sweep:  x_c = Q~(:, 0:q) y + Q~(:, q:) xpart ; m == r (nothing eliminated): x_c = xpart ------------
-__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs,
-                                                             int* flags, int* err) {
+__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs, int* err) {
   HSSK_SHARED double s_v[SW_MAX * SW_NR];   // [y; xpart]
   HSSK_SHARED double s_o[SW_MAX * SW_NR];
   HSSK_SHARED double s_p[SW_T * SW_NR];
@@ -321,9 +317,7 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
     gemv_n(p.Qt, m, m, q, s_v, s_o, nrhs, OP_SET, s_p);
     if (p.wait0 >= 0) { double sink = 0.; touch(p.Qt + (size_t)q * m, (size_t)m * r, sink); keep(sink, s_p); }
   }
-  sweep_wait(flags, p.wait0, err);
-  sweep_acquire();
-  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = hssk_cload(p.xpart, (e % r) + (size_t)(e / r) * p.ldx);
+  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = sweep_take(p.xpart, (e % r) + (size_t)(e / r) * p.ldx, err);
   __syncthreads();
   if (q > 0) {
     if (r > 0) gemv_n(p.Qt + (size_t)q * m, m, m, r, s_v + q, s_o, nrhs, OP_ADD, s_p);
@@ -331,13 +325,11 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
   } else {
     for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * SW_MAX]);
   }
-  sweep_publish(flags, blockIdx.x, p.consumers);
 }
 
 // ---- mat-vec: up-sweep nodes [0, nup) then down-sweep nodes [nup, nup + ndown) in one launch -------------------------------
 __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
-                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs,
-                                                           int* flags, int* err) {
+                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs, int* err) {
   HSSK_SHARED double s_x[SW_MAX * SW_NR];
   HSSK_SHARED double s_g[SW_MAX * SW_NR];
   HSSK_SHARED double s_o[SW_MAX * SW_NR];
@@ -349,19 +341,16 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
     const int m = p.m, r = p.r;
     const int pk = tid < m ? p.perm[tid] : 0;
     if (p.wait0 >= 0 || p.wait1 >= 0) { double sink = 0.; touch(p.X, (size_t)r * (m - r), sink); keep(sink, s_p); }
-    sweep_wait(flags, p.wait0, err);
-    sweep_wait(flags, p.wait1, err);
-    sweep_acquire();
+    const bool handed = p.inner != 0;   // inner node: the children's results; leaf: rows of x
     if (tid < m)
       for (int c = 0; c < nrhs; c++) {
-        const double v = hssk_cload(p.src, pk + (size_t)c * p.lds);
+        const double v = handed ? sweep_take(p.src, pk + (size_t)c * p.lds, err) : hssk_gload(p.src, pk + (size_t)c * p.lds);
         if (tid < r) s_o[tid + c * SW_MAX] = v;
         else s_g[(tid - r) + c * SW_MAX] = v;
       }
     __syncthreads();
     if (m > r && r > 0) gemv_n(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p);
     for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
-    sweep_publish(flags, blockIdx.x, p.consumers);
     return;
   }
   const hssk_apply_down_desc p = downs[blockIdx.x - nup];
@@ -387,11 +376,8 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
       touch(p.B10, (size_t)(p.trans ? p.ri_b * p.ro_a : p.ro_b * p.ri_a), sink);
       keep(sink, s_p);
     }
-    sweep_wait(flags, p.wait1, err);
-    sweep_wait(flags, p.wait2, err);
-    sweep_acquire();
     const int nt1 = p.ri_a + p.ri_b, nto = p.ro_a + p.ro_b;
-    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = hssk_cload(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1);
+    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = sweep_take(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1, err);
     for (int e = tid; e < nto * nrhs; e += SW_T) s_o[(e % nto) + (e / nto) * SW_MAX] = 0.;
     __syncthreads();
     if (!p.trans) {   // B01 is ro_a x ri_b, B10 is ro_b x ri_a: one pass over the stacked rows
@@ -408,20 +394,15 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
   // ---- + U tmp2:  out(perm[k]) += tmp2(k), k < ro ;  out(perm[ro + j]) += sum_k X(k, j) tmp2(k)   (X is ro x (mo - ro))
   if (expand) {
     if (p.wait0 >= 0) { double sink = 0.; touch(p.X, (size_t)ro * (mo - ro), sink); keep(sink, s_p); }
-    sweep_wait(flags, p.wait0, err);
-    sweep_acquire();
-    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = hssk_cload(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2);
+    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = sweep_take(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2, err);
     __syncthreads();
     if (mo > ro) gemv_t(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET);
     if (tid < mo)
       for (int c = 0; c < nrhs; c++) s_o[pk + c * SW_MAX] += tid < ro ? s_x[tid + c * SW_MAX] : s_g[(tid - ro) + c * SW_MAX];
     __syncthreads();
-  } else if (p.wait0 >= 0) {
-    sweep_wait(flags, p.wait0, err);   // nothing to read, but the producer counted this consumer
   }
   const int mout = p.D ? p.m : p.ro_a + p.ro_b;
   for (int e = tid; e < mout * nrhs; e += SW_T) hssk_cstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
-  sweep_publish(flags, blockIdx.x, p.consumers);
 }
 
 // ---- inverses of the 64 x 64 diagonal blocks of R~^T (factor time) --------------------------------------------------------
@@ -471,15 +452,12 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const hssk_trtri_desc* _
   }
 }
 
-int* sweep_flags(hssk_ctx* ctx, int count) {
-  if ((size_t)count > ctx->sweep_cap) return nullptr;
-  if (!ctx->d_sweep_flags) {
-    ctx->d_sweep_flags = (int*)hssk_rt::dev_malloc(sizeof(int) * ctx->sweep_cap);
-    hssk_rt::memset_async(ctx->d_sweep_flags, 0, sizeof(int) * ctx->sweep_cap, ctx->stream);
+int* sweep_err(hssk_ctx* ctx) {
+  if (!ctx->h_sweep_err) {
     ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64);
     *ctx->h_sweep_err = 0;
   }
-  return ctx->d_sweep_flags;
+  return ctx->h_sweep_err;
 }
 
 }  // namespace
@@ -487,16 +465,21 @@ int* sweep_flags(hssk_ctx* ctx, int count) {
 extern "C" int hssk_sweep_status(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) return 0;
   const int e = *(volatile int*)ctx->h_sweep_err;
-  if (e) {   // a dependency never arrived: flags are in an unknown state
-    try {
-      hssk_rt::sync(ctx->stream);
-      hssk_rt::memset_async(ctx->d_sweep_flags, 0, sizeof(int) * ctx->sweep_cap, ctx->stream);
-      hssk_rt::sync(ctx->stream);
-    } catch (...) {}
+  if (e) {
     *ctx->h_sweep_err = 0;
-    hssk_set_error("hssk sweep: a workgroup timed out waiting for its dependency (in-order dispatch violated?)");
+    hssk_set_error("hssk sweep: a workgroup timed out waiting for the vectors of its dependency (in-order dispatch violated?)");
   }
   return e;
+}
+
+// fills the hand-off buffers of a sweep with the sentinel (must precede, on the stream, every launch that writes them)
+extern "C" int hssk_sweep_arm(hssk_ctx* ctx, double* buf, long long count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  const unsigned nb = (unsigned)std::min<long long>((count + 255) / 256, 1024);
+  HSSK_LAUNCH(sweep_fill_kernel, dim3(nb), dim3(256), 0, ctx->stream, buf, count);
+  hssk_rt::check_launch();
+  HSSK_API_END
 }
 
 extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs) {
@@ -505,10 +488,8 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   if (nrhs < 1 || nrhs > SW_NR) return 2;
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) return 2;
-  int* flags = sweep_flags(ctx, count);
-  if (!flags) return 2;
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(ulv_fwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, flags, ctx->h_sweep_err);
+  HSSK_LAUNCH(ulv_fwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -519,10 +500,8 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   if (nrhs < 1 || nrhs > SW_NR) return 2;
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) return 2;
-  int* flags = sweep_flags(ctx, count);
-  if (!flags) return 2;
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(ulv_bwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, flags, ctx->h_sweep_err);
+  HSSK_LAUNCH(ulv_bwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -539,12 +518,9 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
     if (d.mo > SW_MAX || d.m > SW_MAX || d.ri_a + d.ri_b > SW_MAX || d.ro_a + d.ro_b > SW_MAX) return 2;
     if (d.wait0 >= nup + i || d.wait1 >= nup + i || d.wait2 >= nup + i) return 2;
   }
-  int* flags = sweep_flags(ctx, nup + ndown);
-  if (!flags) return 2;
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
-  HSSK_LAUNCH(apply_sweep_kernel, dim3((unsigned)(nup + ndown)), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, flags,
-              ctx->h_sweep_err);
+  HSSK_LAUNCH(apply_sweep_kernel, dim3((unsigned)(nup + ndown)), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }

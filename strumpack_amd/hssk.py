@@ -49,7 +49,8 @@ class RowGatherDesc(C.Structure):
 class ElemDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_longlong), ("I", C.c_void_p), ("J", C.c_void_p),
                 ("i0", C.c_int), ("j0", C.c_int), ("B", C.c_void_p),
-                ("m", C.c_int), ("n", C.c_int), ("ldb", C.c_int), ("transpose", C.c_int)]
+                ("m", C.c_int), ("n", C.c_int), ("ldb", C.c_int), ("transpose", C.c_int),
+                ("rlo", C.c_int), ("rhi", C.c_int), ("clo", C.c_int), ("chi", C.c_int)]   # ownership windows (0, 0: none)
 
 
 class TransposeDesc(C.Structure):
@@ -104,7 +105,7 @@ HSSK_SYMBOLS = [
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
     "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
     "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict", "hssk_copy_triu",
-    "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_copy_fence", "hssk_compute_fence", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
+    "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_copy_fence", "hssk_compute_fence", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
 ]
 
