@@ -384,7 +384,7 @@ def main():
     flops_per_launch = st["sketch_kernel_flops"] / launches
     ach = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tf) and n == 100000 and world == 1:
         traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
     out = {
@@ -414,7 +414,9 @@ def main():
                              "GBps": (st2["b_solve"] + 16.0 * n * a.nrhs) / (solve_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); two launches"}},
         "roofline": {"kernel": "dgemm_kernel<192> (sketch S^T = R^T op(A), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
+                     "traffic": traffic,
+                     "traffic_source": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier box (tools/round_profile.sh), not a counter read of this run" if traffic else None,
+                     "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
     if a.sketch == "sjlt":
         # the flop model counts what is executed (2 nnz flops per element and product), so GFLOP/s is not comparable
@@ -427,7 +429,7 @@ def main():
         out["roofline"] = {"kernel": "sjlt_n_kernel / sjlt_t_kernel (S^T = (op(A) R)^T, R with 4 entries +-1 per row)",
                            "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                            "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches, "bytes_per_launch": bpl}
-        tfs = os.path.join(ROOT, "profiles", "r01_pmc_sjlt_traffic.json")
+        tfs = os.path.join(ROOT, "profiles", "r02_pmc_sjlt_traffic.json")
         if os.path.exists(tfs) and n == 100000 and world == 1:
             out["roofline"]["traffic"] = json.load(open(tfs)).get("hbm_read_bytes_per_launch")
     if world > 1:
