@@ -1351,9 +1351,9 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
     const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
     ms[k] = m;
     if (m <= 0 || !Ws[k] || d <= std::max(256, 2 * m)) continue;
-    // chunk rows: register QR (<= 256 rows x 128 columns, <= 208 rows x 208 columns: the 16-lanes-per-column kernels of
+    // chunk rows: register QR (<= 256 rows x 192 columns, <= 208 rows x 208 columns: the 16-lanes-per-column kernels of
     // hssk_qr.hip), the 512-row blocked path, or the tall blocked path for wide panels
-    const int chunk = m <= 128 ? 256 : (m <= 208 ? 208 : (m <= 256 ? 512 : 2 * m));
+    const int chunk = m <= 192 ? 256 : (m <= 208 ? 208 : (m <= 256 ? 512 : 2 * m));
     for (int r0 = 0; r0 < d; r0 += chunk) {
       const int cr = std::min(chunk, d - r0);
       double* wk = tmp.dbl((size_t)cr + m);

@@ -4,6 +4,8 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -45,28 +47,76 @@ static hssk_uploader* uploader(hssk_ctx* c) {
   if (!c->uploader) c->uploader = new hssk_uploader();
   return c->uploader;
 }
+// persistent host threads for the packing (a piece is packed in ~5 ms: starting threads per piece would cost as much)
+class PackPool {
+ public:
+  explicit PackPool(unsigned n) : n_(n) {
+    for (unsigned t = 0; t < n_; t++) th_.emplace_back([this, t] { loop(t); });
+  }
+  ~PackPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  unsigned size() const { return n_; }
+  // runs fn(t) for t < size() on the pool and returns when all are done
+  void run(const std::function<void(unsigned)>& fn) {
+    std::unique_lock<std::mutex> lk(mu_);
+    fn_ = &fn; pending_ = n_; gen_++;
+    cv_.notify_all();
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  void loop(unsigned t) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)>* f;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        f = fn_;
+      }
+      (*f)(t);
+      { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_all(); }
+    }
+  }
+  unsigned n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned)>* fn_ = nullptr;
+  unsigned long gen_ = 0;
+  unsigned pending_ = 0;
+  bool stop_ = false;
+};
+static PackPool& pack_pool() {
+  static PackPool p(std::max(1u, std::min(24u, std::thread::hardware_concurrency())));
+  return p;
+}
 // columns [c0, c1) of a column-major host block into a compact pinned buffer, on the host's hardware threads
 static void host_pack(char* dst, const double* src, long long lds, long long rows, long long c0, long long c1) {
   const long long ncol = c1 - c0;
   const size_t colb = sizeof(double) * (size_t)rows;
-  const unsigned nt = (unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(24, std::thread::hardware_concurrency()), (long long)(colb * ncol >> 22) + 1));
-  if (nt <= 1) {
+  const size_t total = colb * (size_t)ncol;
+  if (total < (size_t(8) << 20)) {
     for (long long j = 0; j < ncol; j++) std::memcpy(dst + colb * j, src + (size_t)(c0 + j) * lds, colb);
     return;
   }
+  PackPool& pool = pack_pool();
+  const unsigned nt = pool.size();
   // split by bytes, not by columns: a block may be one very long column
-  const size_t total = colb * (size_t)ncol, per = (total + nt - 1) / nt;
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++)
-    th.emplace_back([=] {
-      size_t b0 = per * t, b1 = std::min(total, b0 + per);
-      while (b0 < b1) {
-        const size_t j = b0 / colb, o = b0 % colb, len = std::min(colb - o, b1 - b0);
-        std::memcpy(dst + b0, (const char*)(src + (size_t)(c0 + (long long)j) * lds) + o, len);
-        b0 += len;
-      }
-    });
-  for (auto& t : th) t.join();
+  const size_t per = (total + nt - 1) / nt;
+  pool.run([=](unsigned t) {
+    size_t b0 = std::min(total, per * t), b1 = std::min(total, b0 + per);
+    while (b0 < b1) {
+      const size_t j = b0 / colb, o = b0 % colb, len = std::min(colb - o, b1 - b0);
+      std::memcpy(dst + b0, (const char*)(src + (size_t)(c0 + (long long)j) * lds) + o, len);
+      b0 += len;
+    }
+  });
 }
 
 extern "C" {

@@ -573,8 +573,8 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
     qmax = std::max(qmax, descs[i].nq);
   }
   // register-resident kernels when the largest panel of the batch fits (rows <= 16 RT, cols <= 4 NW CT; the register
-  // tile of the widest variant, 13 x 7 doubles per lane, needs the 256 VGPRs of an 8-wave workgroup)
-  if (force_blocked() || rmax > 256 || cmax > 224 || (rmax > 208 && cmax > 128)) {
+  // tiles of the widest variants, 13 x 7 and 16 x 6 doubles per lane, need the 256 VGPRs of an 8-wave workgroup)
+  if (force_blocked() || rmax > 256 || cmax > 224 || (rmax > 208 && cmax > 192)) {
     qr_blocked(ctx, descs, count, true);
     hssk_rt::check_launch();
     return 0;
@@ -584,6 +584,7 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
   else if (rmax <= 128 && cmax <= 128) launch_qr_reg<8, 2, 16>(ctx, dd, count);
   else if (cmax <= 128 && rmax <= 208) launch_qr_reg<13, 4, 8>(ctx, dd, count);
   else if (cmax <= 128) launch_qr_reg<16, 4, 8>(ctx, dd, count);
+  else if (rmax > 208) launch_qr_reg<16, 6, 8>(ctx, dd, count);   // <= 256 rows x 192 columns
   else launch_qr_reg<13, 7, 8>(ctx, dd, count);
   // Q is then formed by a second, barrier-free launch over blocks of 64 columns
   if (qmax > 0) formq_reg(ctx, dd, descs, count, rmax);
