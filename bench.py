@@ -265,14 +265,37 @@ def main():
     if world > 1:
         comm_mode = os.environ.get("STRUMPACK_AMD_BENCH_COMM", "rccl")
         if comm_mode == "rccl" and a.sketch == "gaussian":
+            # set the native path up and TRY it on a small matrix; every rank must succeed (agreement through
+            # torch.distributed), otherwise all ranks take the torch callback path together
+            ok, why = 1.0, ""
             try:
                 comm = sdist.NativeComm(L)
                 if L.SPX_comm_selftest(comm.h):
                     raise RuntimeError("SPX_comm_selftest failed")
                 sdist.shard_range(L, n, opts, world, rank)
-            except Exception as e:   # e.g. world not a power of two: replicated operand over the callback
+                nt = 4096 * world
+                ot = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=256)
+                lo_t, hi_t = sdist.shard_range(L, nt, ot, world, rank)
+                tr, tc = hk.empty((hi_t - lo_t, nt)), hk.empty((nt, hi_t - lo_t))
+                hk.check(hk.lib.hssk_fill_toeplitz_block(hk.ctx, tr.ptr, hi_t - lo_t, nt, hi_t - lo_t, lo_t, 0, b"T"))
+                hk.check(hk.lib.hssk_fill_toeplitz_block(hk.ctx, tc.ptr, nt, hi_t - lo_t, nt, 0, lo_t, b"T"))
+                hk.sync()
+                Ht = sdist.from_blocks_device(L, tr.ptr, hi_t - lo_t, tc.ptr, nt, nt, ot, hopts, comm=comm)
+                Ht.factor()
+                import numpy as np
+                bt = np.random.default_rng(1).standard_normal((nt, 1))
+                xt = Ht.solve(bt)
+                if not (np.linalg.norm(Ht.mult(xt) - bt) <= 1e-10 * np.linalg.norm(bt)):
+                    raise RuntimeError("trial solve residual too large")
+                Ht.destroy()
+                del tr, tc
+            except Exception as e:   # e.g. world not a power of two, RCCL not loadable
+                ok, why = 0.0, str(e)[:200]
+            t = torch.tensor([ok], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if t.item() < 1.0:
                 if rank == 0:
-                    print("bench: native RCCL / sharded operand unavailable (%s); using the torch callback path" % e, file=sys.stderr)
+                    print("bench: native RCCL / sharded operand unavailable on some rank (%s); using the torch callback path" % why, file=sys.stderr)
                 comm, comm_mode = None, "torch"
         else:
             comm_mode = "torch"
@@ -326,7 +349,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
