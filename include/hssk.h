@@ -299,8 +299,8 @@ int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count
  * down); wait* name those descriptors (-1: none / produced by an earlier launch) and are checked for that order.  The
  * vectors handed from node to node (ft1 / z / x going up and down the solve, tmp1 / tmp2 of the mat-vec) live in buffers
  * that hssk_sweep_arm fills with a sentinel beforehand; a consumer polls the words it needs until they are written.  See
- * kernels/hssk_sweep.hip.  nrhs <= 4 and node dimensions <= 256, otherwise the calls return 2 and do nothing (the
- * caller issues the batched calls instead).
+ * kernels/hssk_sweep.hip.  Right-hand sides are processed in groups of four (blockIdx.y); node dimensions <= 256,
+ * otherwise the calls return 2 and do nothing (the caller issues the batched calls instead).
  * hssk_sweep_status: non-zero if a workgroup of an earlier sweep gave up waiting (checked after a synchronisation). */
 int hssk_sweep_arm(hssk_ctx* ctx, double* handoff, long long count);
 typedef struct hssk_sweep_fwd_desc {

@@ -584,7 +584,9 @@ void DeviceHSS::comm(void* dbuf, long long bytes_per_rank) {
   }
   if (!o_.allgather) throw std::logic_error("multi-GPU operation needs an all-gather hook");
   ck(hssk_sync(ctx_));
-  o_.allgather(o_.comm_user, dbuf, bytes_per_rank);
+  const double t0 = now();
+  o_.allgather(o_.comm_user, dbuf, bytes_per_rank);   // (host-synchronous by contract)
+  if (time_comm()) stats_.t_comm += now() - t0;
 }
 
 // dbuf[0:count) <- sum over the ranks
@@ -2096,7 +2098,7 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   // few right-hand sides: up-sweep and down-sweep of a set of levels as ONE launch (hssk_apply_sweep: a workgroup per
   // node and direction, dependency flags between them) instead of two to four batched launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_APPLY"); return e && e[0] == '1'; }();
-  const bool fuse = nrhs <= 4 && !no_fuse;
+  const bool fuse = nrhs <= 64 && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
   if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto sweep = [&](const Levels* ups, const Levels* downs) -> bool {
@@ -2736,7 +2738,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   // (hssk_ulv_fwd_sweep / _bwd_sweep: a workgroup per node, dependency flags between them) instead of 7 / 3 batched
   // launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
-  const bool fuse = nrhs <= 4 && !no_fuse;
+  const bool fuse = nrhs <= 64 && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
   if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto fwd_sweep = [&](const Levels& levels) -> bool {
@@ -2990,7 +2992,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     for (auto& nd : nodes_) {
       if (nd.lvl == 0) { const double mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU; bs += mu * mu; continue; }
       const double m = nd.mU, r = nd.rU, k = m - r, rv = nd.rV;
-      bs += r * k + k * (k + 1) / 2 + (fuse ? r * k : r * m + m * k) + k * rv + m * m;
+      bs += r * k + k * (k + 1) / 2 + (fuse ? r * k : r * m + m * k) + k * rv + m * m;   // (per group of four right-hand sides when fused)
       if (!nd.leaf()) bs += (double)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (double)nodes_[nd.c1].rU * nodes_[nd.c0].rV + rv * (nd.mV - rv);
     }
     stats_.b_solve = 8.0 * bs;

@@ -1,5 +1,5 @@
 // Single-launch tree sweeps: the ULV solve (forward / backward) and the HSS mat-vec (up / down) of a whole tree in ONE
-// kernel launch each, for few right-hand sides.
+// kernel launch each (right-hand sides in groups of four along blockIdx.y).
 //
 // A sweep over an HSS tree is a chain of ~10 dependent levels of tiny per-node operations; launched level by level it
 // is bound by launch-to-launch latency (N = 1e5: 20 launches, 0.55 ms apply / 1.07 ms solve for 0.19 / 0.52 GB of
@@ -164,7 +164,15 @@ __device__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, cons
 }
 
 // ---- forward ULV sweep ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs, int* err) {
+// Right-hand sides beyond SW_NR: blockIdx.y walks groups of SW_NR columns.  The groups are independent chains through the
+// tree that run side by side (a 2-D grid is dispatched x-fastest, so within a group the index order still holds); each
+// group streams the blocks again, which is what bounds it (nrhs = 64: 16 x the bytes of one group).
+__device__ __forceinline__ int rhs_group(int nrhs_total, int& c0) {
+  c0 = (int)blockIdx.y * SW_NR;
+  return min(SW_NR, nrhs_total - c0);
+}
+
+__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
   HSSK_SHARED double s_f[SW_MAX * SW_NR];    // f, later the block right-hand side of the substitution
   HSSK_SHARED double s_y[SW_MAX * SW_NR];    // zc(permV[rv:]) first, then y
   HSSK_SHARED double s_a[SW_MAX * SW_NR];    // stacked children z (inner nodes)
@@ -172,9 +180,19 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
   HSSK_SHARED double s_z[SW_MAX * SW_NR];    // z
   HSSK_SHARED double s_p[SW_T * SW_NR];      // gemv partials
   HSSK_SHARED int s_piv[SW_MAX];
-  const hssk_sweep_fwd_desc p = descs[blockIdx.x];
+  hssk_sweep_fwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
+  int c0;
+  const int nrhs = rhs_group(nrhs_total, c0);
+  if (c0) {   // this group's columns of every vector
+    p.fsrc += (size_t)c0 * p.ldf;
+    if (p.zc) p.zc += (size_t)c0 * p.ldz_in;
+    if (p.ft1) p.ft1 += (size_t)c0 * p.ldp;
+    if (p.y) p.y += (size_t)c0 * q;
+    if (p.z) p.z += (size_t)c0 * p.ldz;
+    if (p.xroot) p.xroot += (size_t)c0 * p.ldxr;
+  }
   const bool inner = p.B01 != nullptr;
   // ---- before the dependencies arrive: permutations into registers, the node's blocks towards L2
   int pu = 0, pv = 0;
@@ -303,13 +321,20 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
 }
 
 // ---- backward ULV sweep:  x_c = Q~(:, 0:q) y + Q~(:, q:) xpart ; m == r (nothing eliminated): x_c = xpart ------------
-__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs, int* err) {
+__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err) {
   HSSK_SHARED double s_v[SW_MAX * SW_NR];   // [y; xpart]
   HSSK_SHARED double s_o[SW_MAX * SW_NR];
   HSSK_SHARED double s_p[SW_T * SW_NR];
-  const hssk_sweep_bwd_desc p = descs[blockIdx.x];
+  hssk_sweep_bwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r;
+  int c0;
+  const int nrhs = rhs_group(nrhs_total, c0);
+  if (c0) {
+    if (p.y) p.y += (size_t)c0 * q;
+    p.xpart += (size_t)c0 * p.ldx;
+    p.out += (size_t)c0 * p.ldo;
+  }
   // the parent-independent part first: s_o = Q~(:, 0:q) y; Q~(:, q:) towards L2
   for (int e = tid; e < q * nrhs; e += SW_T) s_v[(e % q) + (e / q) * SW_MAX] = hssk_gload(p.y, (e % q) + (size_t)(e / q) * q);
   __syncthreads();
@@ -329,15 +354,19 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
 
 // ---- mat-vec: up-sweep nodes [0, nup) then down-sweep nodes [nup, nup + ndown) in one launch -------------------------------
 __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
-                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs, int* err) {
+                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err) {
   HSSK_SHARED double s_x[SW_MAX * SW_NR];
   HSSK_SHARED double s_g[SW_MAX * SW_NR];
   HSSK_SHARED double s_o[SW_MAX * SW_NR];
   HSSK_SHARED double s_p[SW_T * SW_NR];
   const int tid = threadIdx.x;
+  int c0;
+  const int nrhs = rhs_group(nrhs_total, c0);
   if ((int)blockIdx.x < nup) {
     // tmp1 = V^H src = src(perm[0:r]) + X src(perm[r:])   (X is r x (m - r), rows contiguous)
-    const hssk_apply_up_desc p = ups[blockIdx.x];
+    hssk_apply_up_desc p = ups[blockIdx.x];
+    p.src += (size_t)c0 * p.lds;
+    p.dst += (size_t)c0 * p.ldd;
     const int m = p.m, r = p.r;
     const int pk = tid < m ? p.perm[tid] : 0;
     if (p.wait0 >= 0 || p.wait1 >= 0) { double sink = 0.; touch(p.X, (size_t)r * (m - r), sink); keep(sink, s_p); }
@@ -353,7 +382,13 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
     for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
     return;
   }
-  const hssk_apply_down_desc p = downs[blockIdx.x - nup];
+  hssk_apply_down_desc p = downs[blockIdx.x - nup];
+  if (c0) {
+    if (p.tmp2) p.tmp2 += (size_t)c0 * p.ld2;
+    if (p.x) p.x += (size_t)c0 * p.ldx;
+    if (p.t1) p.t1 += (size_t)c0 * p.ldt1;
+    p.out += (size_t)c0 * p.ldo;
+  }
   const int mo = p.mo, ro = p.ro;
   const bool expand = p.tmp2 && ro > 0;
   const int pk = (expand && tid < mo) ? p.perm[tid] : 0;
@@ -485,11 +520,11 @@ extern "C" int hssk_sweep_arm(hssk_ctx* ctx, double* buf, long long count) {
 extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  if (nrhs < 1 || nrhs > SW_NR) return 2;
+  if (nrhs < 1 || nrhs > SW_NR * 16384) return 2;
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) return 2;
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(ulv_fwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  HSSK_LAUNCH(ulv_fwd_sweep_kernel, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -497,11 +532,11 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
 extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* descs, int count, int nrhs) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  if (nrhs < 1 || nrhs > SW_NR) return 2;
+  if (nrhs < 1 || nrhs > SW_NR * 16384) return 2;
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) return 2;
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(ulv_bwd_sweep_kernel, dim3((unsigned)count), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  HSSK_LAUNCH(ulv_bwd_sweep_kernel, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -510,7 +545,7 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
                                 int ndown, int nrhs) {
   HSSK_API_BEGIN
   if (nup + ndown <= 0) return 0;
-  if (nrhs < 1 || nrhs > SW_NR) return 2;
+  if (nrhs < 1 || nrhs > SW_NR * 16384) return 2;
   for (int i = 0; i < nup; i++)
     if (ups[i].m > SW_MAX || ups[i].wait0 >= i || ups[i].wait1 >= i) return 2;
   for (int i = 0; i < ndown; i++) {
@@ -520,7 +555,8 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   }
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
-  HSSK_LAUNCH(apply_sweep_kernel, dim3((unsigned)(nup + ndown)), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  HSSK_LAUNCH(apply_sweep_kernel, dim3((unsigned)(nup + ndown), (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, du, nup,
+              dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
