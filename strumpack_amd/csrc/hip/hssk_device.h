@@ -115,6 +115,9 @@ __device__ __forceinline__ void hssk_cstore(double* p, size_t off, double v) {
 // bit patterns of doubles (sentinel test of the sweep hand-off)
 __device__ __forceinline__ unsigned long long hssk_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double hssk_from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
+__device__ __forceinline__ unsigned hssk_fbits(float v) { return __float_as_uint(v); }
+// instruction-scheduling fence: nothing is moved across it
+__device__ __forceinline__ void hssk_sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void hssk_drain_stores() { __builtin_amdgcn_s_waitcnt(0); }
 __device__ __forceinline__ void hssk_pause() { __builtin_amdgcn_s_sleep(2); }
 

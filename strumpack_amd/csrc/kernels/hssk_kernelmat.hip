@@ -114,124 +114,170 @@ __global__ __launch_bounds__(256) void kernel_eval_anova_kernel(hssk_kernel_spec
 // ---------------------------------------------------------------------------------------------
 constexpr int KNN_P = 64;    // neighbours per page
 
-constexpr int KNN_C = 64;    // candidates per LDS tile
+constexpr int KNN_TILE = 512; // coordinates per LDS tile (512 / DM candidates)
 constexpr int KNN_DMAX = 64; // largest point dimension
 
 // DM >= d: coordinates per point, zero padded (instantiated for 8 / 16 / 32 / 64).  The query point sits in
 // registers, the candidate tile in LDS as [candidate][coordinate] so that a wave reads one candidate's coordinates
-// as broadcast 16-byte loads; four candidates are evaluated per trip to keep several loads in flight, the
-// (rare) insertion into the LDS-resident page of the KNN_P best keys happens afterwards.
+// as broadcast 16-byte loads; four candidates are evaluated per trip to keep several loads in flight.
 // Q queries per workgroup: Q / 64 waves share one candidate tile and -- unlike single-wave workgroups, which the
 // dispatcher packed onto one SIMD of a CU -- spread over the CU's four SIMDs.
+//
+// Keys: (float distance^2, index) packed into one 64-bit word, distance bits high -- distances are >= 0, so the
+// unsigned order of the words IS the (distance, index) order; the acceptance test of a candidate is two 64-bit
+// compares.  The page of a query is a binary max-heap of such words in the lane's LDS column.
+//
+// Insertions are BATCHED.  A candidate that passes the test is appended to the lane's pending list (KNN_PEND slots
+// in LDS: an unconditional store + a conditional increment, no branch); the heap insertions run for the whole wave
+// when some lane's list is nearly full.  Per query an insertion is rare (~300 in 1e5 candidates), per WAVE it is not:
+// with 64 queries side by side every second trip of four candidates had some lane inserting, and the wave then ran the
+// sift-down loop with one or two lanes active (PMC of the first version at N = 1e5, profiles/r02_pmc_knn.md: VALU busy
+// 25 %, scalar 18 %, 1.4 us per trip against ~0.3 us of arithmetic).  Batched, the same loop runs with tens of lanes
+// active and ~10 x less often; the threshold of a lane (its page's worst key) is only tightened at a flush, which lets a
+// few more candidates through to the list -- they are tested again against the current threshold there.
+constexpr int KNN_PEND = 8;
+constexpr int KNN_JS = 2;    // coordinates per scheduling group of the distance loop
+typedef unsigned long long knn_key_t;
+__device__ __forceinline__ knn_key_t knn_pack(float key, int idx) { return ((knn_key_t)hssk_fbits(key) << 32) | (unsigned)idx; }
+constexpr knn_key_t KNN_EMPTY = ((knn_key_t)0x7f61b1e6u << 32) | 0x7fffffffu;   // (3.0e38f, INT_MAX): above every real key
+
 template <int DM, int Q>
 __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
-                                                    const float* __restrict__ lb_key, const int* __restrict__ lb_idx,
-                                                    int* __restrict__ out_idx, int ldo, float* __restrict__ ub_key,
-                                                    int* __restrict__ ub_idx) {
-  HSSK_SHARED float hk[KNN_P * Q];
-  HSSK_SHARED int hi[KNN_P * Q];
-  HSSK_SHARED double xc[KNN_C * DM];
+                                                    const knn_key_t* __restrict__ lb, int* __restrict__ out_idx, int ldo,
+                                                    knn_key_t* __restrict__ ub) {
+  constexpr int CT = KNN_TILE / DM;             // candidates per tile (4 KB of coordinates)
+  constexpr int U = DM <= 16 ? 4 : (DM <= 32 ? 2 : 1);   // candidates per trip (their coordinates sit in registers)
+  constexpr int NL = KNN_TILE / Q;              // tile elements per lane
+  static_assert(KNN_TILE % Q == 0 && CT % (2 * U) == 0, "tile shape");
+  HSSK_SHARED knn_key_t hh[KNN_P * Q];
+  HSSK_SHARED knn_key_t pend[KNN_PEND * Q];
+  HSSK_SHARED double xc[2 * KNN_TILE];          // two tiles: the next one is written while the current one is read
   const int tid = threadIdx.x;
   const int q = q0 + blockIdx.x * Q + tid;
   const bool live = q < q1;
   double xq[DM];
 #pragma unroll
   for (int j = 0; j < DM; j++) xq[j] = (live && j < d) ? X[(size_t)q * d + j] : 0.;
-  for (int s = 0; s < kpage; s++) { hk[s * Q + tid] = 3.0e38f; hi[s * Q + tid] = 0x7fffffff; }
-  const float lbk = lb_key ? (live ? lb_key[q] : 0.f) : -1.f;
-  const int lbi = lb_idx ? (live ? lb_idx[q] : 0) : -1;
-  // the page is a binary max-heap on (key, id) in this lane's LDS column: the root is the worst kept key, an
-  // insertion replaces it and sifts down (<= 6 levels for 64 entries) instead of re-scanning the page
-  // (measured at N = 1e5, k = 64: 103 -> 54 ms)
-  float worst = 3.0e38f;
-  int worst_i = 0x7fffffff;
-  auto greater = [](float ka, int ia, float kb, int ib) { return ka > kb || (ka == kb && ia > ib); };
-  auto consider = [&](float key, int g) {
-    const bool above = key > lbk || (key == lbk && g > lbi);
-    const bool better = key < worst || (key == worst && g < worst_i);
-    if (live && g != q && g < n && above && better) {
-      int pos = 0;
-      for (;;) {
-        const int l = 2 * pos + 1, r = l + 1;
-        if (l >= kpage) break;
-        float kc = hk[l * Q + tid];
-        int ic = hi[l * Q + tid], c = l;
-        if (r < kpage) {
-          const float kr = hk[r * Q + tid];
-          const int ir = hi[r * Q + tid];
-          if (greater(kr, ir, kc, ic)) { kc = kr; ic = ir; c = r; }
-        }
-        if (!greater(kc, ic, key, g)) break;
-        hk[pos * Q + tid] = kc;
-        hi[pos * Q + tid] = ic;
-        pos = c;
+  for (int s = 0; s < kpage; s++) hh[s * Q + tid] = KNN_EMPTY;
+  // keys of this page lie in [lo, worst): lo = the previous page's largest key + 1; a lane without a query accepts nothing
+  const knn_key_t lo = (lb && live) ? lb[q] + 1 : 0;
+  knn_key_t worst = live ? KNN_EMPTY : 0;
+  int cnt = 0;
+  // replaces the root of the heap (the worst kept key) by K and sifts it down (<= 6 levels for 64 entries)
+  auto insert = [&](knn_key_t K) {
+    int pos = 0;
+    for (;;) {
+      const int l = 2 * pos + 1, r = l + 1;
+      if (l >= kpage) break;
+      knn_key_t kc = hh[l * Q + tid];
+      int c = l;
+      if (r < kpage) {
+        const knn_key_t kr = hh[r * Q + tid];
+        if (kr > kc) { kc = kr; c = r; }
       }
-      hk[pos * Q + tid] = key;
-      hi[pos * Q + tid] = g;
-      worst = hk[tid];
-      worst_i = hi[tid];
+      if (kc <= K) break;
+      hh[pos * Q + tid] = kc;
+      pos = c;
     }
+    hh[pos * Q + tid] = K;
+    worst = hh[tid];
+  };
+  auto flush = [&]() {
+    for (int s = 0; hssk_any(s < cnt); s++)
+      if (s < cnt) {
+        const knn_key_t K = pend[s * Q + tid];
+        if (K < worst) insert(K);
+      }
+    cnt = 0;
   };
   // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
   // spatial neighbours, the page threshold tightens at once and later tiles rarely insert (same result set)
-  const int ntile = (n + KNN_C - 1) / KNN_C, own = (q0 + blockIdx.x * Q) / KNN_C;
-  for (int t = 0; t < ntile; t++) {
-    // own, own+1, own-1, own+2, own-2, ...: in cluster order index distance tracks spatial distance
+  const int ntile = (n + CT - 1) / CT, own = (q0 + blockIdx.x * Q) / CT;
+  const double inf = __builtin_huge_val();
+  // own, own+1, own-1, own+2, own-2, ...: in cluster order index distance tracks spatial distance
+  auto tile_start = [&](int t) {
     const int off = (t + 1) >> 1;
-    const int c0 = (((t & 1) ? own + off : own - off + ntile) % ntile) * KNN_C;
-    __syncthreads();
-    // tile load: DM independent loads per lane, all in flight together (clamped address + select instead of a
-    // branch per element, which would serialise the round trips)
-    {
-      constexpr int NL = (KNN_C * DM + Q - 1) / Q;
-      double v[NL];
+    return (((t & 1) ? own + off : own - off + ntile) % ntile) * CT;
+  };
+  // tile t's coordinates: NL independent global loads per lane (clamped address + select instead of a branch per
+  // element, which would serialise the round trips), issued one tile ahead of their use.  Candidates past the end
+  // of the point set get an infinite first coordinate: their key is above every threshold.
+  double v[NL];
+  auto tile_fetch = [&](int t) {
+    const int c0 = tile_start(t);
 #pragma unroll
-      for (int r = 0; r < NL; r++) {
-        const int e = tid + Q * r, pt = e / DM, j = e % DM;
-        const int gp = min(c0 + pt, n - 1), gj = min(j, d - 1);
-        v[r] = hssk_gload(X, (size_t)gp * d + gj);
-      }
-#pragma unroll
-      for (int r = 0; r < NL; r++) {
-        const int e = tid + Q * r, pt = e / DM, j = e % DM;
-        if (e < KNN_C * DM) xc[e] = (c0 + pt < n && j < d) ? v[r] : 0.;
-      }
+    for (int r = 0; r < NL; r++) {
+      const int e = tid + Q * r, pt = e / DM, j = e % DM;
+      const int gp = min(c0 + pt, n - 1), gj = min(j, d - 1);
+      const double x = hssk_gload(X, (size_t)gp * d + gj);
+      v[r] = c0 + pt < n ? (j < d ? x : 0.) : (j == 0 ? inf : 0.);
     }
+  };
+  tile_fetch(0);
+  for (int t = 0; t < ntile; t++) {
+    double* tile = xc + (t & 1) * KNN_TILE;
+#pragma unroll
+    for (int r = 0; r < NL; r++) tile[tid + Q * r] = v[r];
+    // one barrier per tile: the buffer written here was last read two tiles ago, before the previous barrier
     __syncthreads();
-    for (int c = 0; c < KNN_C; c += 4) {
-      double s2[4] = {0., 0., 0., 0.};
+    if (t + 1 < ntile) tile_fetch(t + 1);
+    const int c0 = tile_start(t);
+    // a trip: U candidates against the lane's query, their keys appended to the pending list
+    auto trip = [&](int c, const double (&b)[U][DM]) {
+      // coordinate-major: the U chains (one per candidate) advance side by side, so consecutive instructions are
+      // independent -- with one wave per SIMD a dependent FP64 instruction waits out the full pipeline latency
+      double s2[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < U; u++) s2[u] = 0.;
 #pragma unroll
-        for (int j = 0; j < DM; j++) {
-          const double df = xq[j] - xc[(c + u) * DM + j];
-          s2[u] += df * df;
+      for (int j = 0; j < DM; j += KNN_JS) {
+        double df[KNN_JS][U];
+#pragma unroll
+        for (int jj = 0; jj < KNN_JS; jj++)
+#pragma unroll
+          for (int u = 0; u < U; u++) df[jj][u] = xq[j + jj] - b[u][j + jj];
+        hssk_sched_barrier();   // (the scheduler otherwise pairs every subtraction with its dependent fma)
+#pragma unroll
+        for (int jj = 0; jj < KNN_JS; jj++) {
+#pragma unroll
+          for (int u = 0; u < U; u++) s2[u] += df[jj][u] * df[jj][u];
         }
-      // branch-free acceptance test for the four candidates, ONE branch per trip into the (rare) insertion path:
-      // taken branches cost an instruction-buffer refill each, which dominated this loop
-      float key[4];
-      bool pass[4], any = false;
+        hssk_sched_barrier();
+      }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        key[u] = (float)s2[u];
+      for (int u = 0; u < U; u++) {
         const int g = c0 + c + u;
-        pass[u] = live & (g != q) & (g < n) & ((key[u] > lbk) | ((key[u] == lbk) & (g > lbi))) &
-                  ((key[u] < worst) | ((key[u] == worst) & (g < worst_i)));
-        any |= pass[u];
+        const knn_key_t K = knn_pack((float)s2[u], g);
+        pend[cnt * Q + tid] = K;   // kept only if the candidate passes (the slot is overwritten otherwise)
+        cnt += (int)((K >= lo) & (K < worst) & (g != q));
       }
-      if (any) {
+    };
+    auto fetch = [&](int c, double (&b)[U][DM]) {
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (pass[u]) consider(key[u], c0 + c + u);
-      }
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < DM; j++) b[u][j] = tile[(c + u) * DM + j];
+    };
+    // software pipeline over the tile: the LDS reads of the next trip are in flight while this one computes (one
+    // wave per SIMD: nothing else hides their latency)
+    double b0[U][DM], b1[U][DM];
+    fetch(0, b0);
+    for (int c = 0; c < CT; c += 2 * U) {
+      fetch(c + U, b1);
+      trip(c, b0);
+      if (hssk_any(cnt > KNN_PEND - U)) flush();
+      if (c + 2 * U < CT) fetch(c + 2 * U, b0);
+      trip(c + U, b1);
+      if (hssk_any(cnt > KNN_PEND - U)) flush();
     }
   }
+  flush();
   if (!live) return;
   for (int s = 0; s < kpage; s++) {
-    const int g = hi[s * Q + tid];
-    out_idx[(size_t)q * ldo + s] = g == 0x7fffffff ? -1 : g;
+    const knn_key_t K = hh[s * Q + tid];
+    out_idx[(size_t)q * ldo + s] = K == KNN_EMPTY ? -1 : (int)(K & 0xffffffffu);
   }
-  if (ub_key) { ub_key[q] = worst; ub_idx[q] = worst_i; }
+  if (ub) ub[q] = worst;
 }
 
 // prediction[c] = sum_r w[r] k(x_r, t_c)   (no lambda: train and test points are different sets)
@@ -320,21 +366,17 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
   if (q0 < 0 || q1 > n) throw std::invalid_argument("hssk_knn: query range outside the point set");
   if (d <= 0 || d > KNN_DMAX) throw std::invalid_argument("hssk_knn: point dimension must be in [1, 64]");
   const int pages = (k + KNN_P - 1) / KNN_P;
-  // page bounds (float key + index per query), ping-pong
-  float* kb = (float*)ctx->scratch(sizeof(float) * 4 * (size_t)n + 64);
-  int* ib = (int*)(kb + 2 * (size_t)n);
-
+  // page bounds (the largest key of the previous page, per query), ping-pong
+  knn_key_t* kb = (knn_key_t*)ctx->scratch(sizeof(knn_key_t) * 2 * (size_t)n + 64);
   for (int pg = 0; pg < pages; pg++) {
     const int kp = std::min(KNN_P, k - pg * KNN_P);
-    const float* lk = pg ? kb + (size_t)((pg - 1) & 1) * n : nullptr;
-    const int* li = pg ? ib + (size_t)((pg - 1) & 1) * n : nullptr;
-    float* uk = kb + (size_t)(pg & 1) * n;
-    int* ui = ib + (size_t)(pg & 1) * n;
+    const knn_key_t* lb = pg ? kb + (size_t)((pg - 1) & 1) * n : nullptr;
+    knn_key_t* ub = kb + (size_t)(pg & 1) * n;
     int* oi = out_idx + pg * KNN_P;
-    if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
-    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
-    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
-    else HSSK_LAUNCH((knn_kernel<64, 128>), dim3((unsigned)((q1 - q0 + 128 - 1) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lk, li, oi, k, uk, ui);
+    if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 128>), dim3((unsigned)((q1 - q0 + 128 - 1) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else HSSK_LAUNCH((knn_kernel<64, 128>), dim3((unsigned)((q1 - q0 + 128 - 1) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
   }
   hssk_rt::check_launch();
   HSSK_API_END

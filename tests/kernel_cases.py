@@ -395,9 +395,10 @@ def case_kernel_eval(hk, n=300, d=8, seed=21):
         assert np.allclose(o2.get(), kernel_np(X, np.arange(100, 165), np.arange(120, 160), ktype, 1.3, 3.11, p), rtol=1e-12, atol=1e-14)
 
 
-def case_knn(hk, n=500, d=8, k=10, seed=22):
+def case_knn(hk, n=500, d=8, k=10, seed=22, lattice=False):
     r = rng(seed)
-    X = r.standard_normal((n, d))
+    # lattice: many points at exactly equal distances (and duplicates): ties are ordered by index
+    X = r.integers(0, 3, (n, d)).astype(np.float64) if lattice else r.standard_normal((n, d))
     dX = hk.array(X.T)
     out = hk.empty((k, n), dtype=np.int32)
     hk.check(hk.lib.hssk_knn(hk.ctx, dX.ptr, d, n, k, 0, n // 3, out.ptr))      # two query ranges, as two ranks would
@@ -411,7 +412,10 @@ def case_knn(hk, n=500, d=8, k=10, seed=22):
         mine = got[i][got[i] >= 0]
         assert len(mine) == kk and len(set(mine.tolist())) == kk and i not in mine
         kth = np.sort(D2[i])[kk - 1]
-        assert (D2[i][mine] <= kth).all()     # exactly a set of k nearest (ties at the boundary may differ)
+        assert (D2[i][mine] <= kth).all()     # exactly a set of k nearest
+        if lattice:                           # ... and among equal distances the smallest indices
+            order = np.lexsort((np.arange(n), D2[i]))
+            assert set(mine.tolist()) == set(order[:kk].tolist())
 
 
 def case_kernel_predict(hk, n=257, m=70, d=5, seed=23):

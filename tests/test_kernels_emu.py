@@ -92,6 +92,7 @@ def test_knn(hk):
     KC.case_knn(hk, n=150, d=8, k=10)
     KC.case_knn(hk, n=90, d=3, k=70, seed=24)     # two pages
     KC.case_knn(hk, n=40, d=20, k=64, seed=25)    # k > n - 1
+    KC.case_knn(hk, n=300, d=4, k=70, seed=26, lattice=True)   # exact ties, duplicates, two pages
 
 
 def test_kernel_predict(hk):

@@ -98,6 +98,8 @@ def test_knn(hk):
     KC.case_knn(hk, n=300, d=3, k=150, seed=24)
     KC.case_knn(hk, n=40, d=20, k=64, seed=25)
     KC.case_knn(hk, n=500, d=40, k=16, seed=26)
+    KC.case_knn(hk, n=900, d=4, k=70, seed=27, lattice=True)   # exact ties, duplicates, two pages
+    KC.case_knn(hk, n=700, d=12, k=64, seed=28)                # the 16-coordinate instantiation
 
 
 def test_kernel_predict(hk):
