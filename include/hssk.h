@@ -227,7 +227,7 @@ int hssk_sjlt_sketch(hssk_ctx* ctx, int transA, long long n_out, long long K, co
  * (dense/DenseMatrix.cpp:746-790, dense/lapack/dgeqp3tol.f:203-232).  Stops at the first c with
  * |R_cc|/|R_00| <= rtol or |R_cc| <= atol; rank = min(c, max_rank).
  * Outputs: perm[0..m) (0-based: pivoted column k is original column perm[k]); *rank; and
- * X = R11^{-1} R12 (rank x (m-rank)) stored in W(0:rank, rank:m). */
+ * X = R11^{-1} R12 (rank x (m-rank)) stored in W(0:rank, rank:m); the rest of W is left unspecified. */
 typedef struct hssk_id_desc {
   double* W;
   int ldw, d, m;
@@ -236,6 +236,9 @@ typedef struct hssk_id_desc {
   int* perm;    /* device, m ints */
   int* rank;    /* device, 1 int */
   double* work; /* device, 3*m doubles */
+  const double* src; /* NULL: the panel is in W.  Otherwise the panel is read from src (d x m, leading dimension lds, left
+                      * untouched) and W (ldw >= d) only receives the outputs -- saves the caller a copy of the samples */
+  int lds;
 } hssk_id_desc;
 int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count);
 

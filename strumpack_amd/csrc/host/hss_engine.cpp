@@ -1314,8 +1314,8 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
   Arena& tmp = *tmp_;
   tmp.rewind();
   const size_t cnt = ids.size();
-  std::vector<hssk_colgather_desc> cp;
   std::vector<double*> Ws(cnt, nullptr);
+  std::vector<const double*> srcs(cnt, nullptr);
   std::vector<int> ds(cnt, dtot);
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
@@ -1323,10 +1323,10 @@ void DeviceHSS::run_id(const std::vector<int>& ids, const std::vector<int>& whic
     const double* S = which[k] == 0 ? nd.Srt : nd.Sct;
     if (m == 0) continue;
     Ws[k] = tmp.dbl((size_t)dtot * m);
-    cp.push_back(hssk_colgather_desc{S, Ws[k], nullptr, dtot, m, dcap_, dtot, 0});
+    srcs[k] = S;
   }
-  if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
-  id_panels(ids, which, Ws, ds);
+  // (the samples stay where they are: the ID reads them in place and writes its factors to the panel in tmp_)
+  id_panels(ids, which, Ws, ds, &srcs, dcap_);
 }
 
 // Tall panels (d >> m, the kernel-matrix path: d = thousands of sampled columns): the pivoted QR of W (d x m) only
@@ -1424,11 +1424,25 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
 // Row ID of the listed (node, basis) pairs from prepared panels W_k = S_k^T (ds[k] x m_k, contiguous, in tmp_):
 // truncated QRCP + X = R11^{-1} R12 on the device, then the commit of rank, permutation, skeleton indices.
 void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws_in,
-                          const std::vector<int>& ds_in) {
+                          const std::vector<int>& ds_in, const std::vector<const double*>* srcs, int ldsrc) {
   Arena& tmp = *tmp_;
   const size_t cnt = ids.size();
   std::vector<double*> Ws(Ws_in);
   std::vector<int> ds(ds_in);
+  if (srcs) {
+    // panels that take the TSQR pre-reduction (more than 256 sample rows) are reduced in place: those need their copy
+    std::vector<hssk_colgather_desc> cp;
+    bool tall = false;
+    for (size_t k = 0; k < cnt; k++) tall = tall || ds[k] > 256;
+    if (tall) {
+      for (size_t k = 0; k < cnt; k++) {
+        const int m = which[k] == 0 ? nodes_[ids[k]].mU : nodes_[ids[k]].mV;
+        if (Ws[k] && m) cp.push_back(hssk_colgather_desc{(*srcs)[k], Ws[k], nullptr, ds[k], m, ldsrc, ds[k], 0});
+      }
+      if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+      srcs = nullptr;
+    }
+  }
   tsqr_reduce(ids, which, Ws, ds);
   std::vector<hssk_id_desc> idd;
   std::vector<int*> perms(cnt, nullptr);
@@ -1445,7 +1459,8 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     poff += m;
     if (m == 0) continue;
     double* wk = tmp.dbl(3 * (size_t)m);
-    idd.push_back(hssk_id_desc{Ws[k], ds[k], ds[k], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk});
+    idd.push_back(hssk_id_desc{Ws[k], ds[k], ds[k], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk,
+                               srcs ? (*srcs)[k] : nullptr, ldsrc});
   }
   if (!idd.empty()) ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
   std::vector<int> hall(cnt + std::max<size_t>(perm_total, 1));
@@ -1479,8 +1494,8 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     const size_t ioff = idx_host.size();
     idx_host.insert(idx_host.end(), I.begin(), I.end());
     idx_off.push_back(ioff);
-    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.hpermU = perm; nd.Ir = I; nd.Ustate = 2; }
-    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.hpermV = perm; nd.Ic = I; nd.Vstate = 2; }
+    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.hpermU = std::move(perm); nd.Ir = std::move(I); nd.Ustate = 2; }
+    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.hpermV = std::move(perm); nd.Ic = std::move(I); nd.Vstate = 2; }
     stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
   }
   int* idx_dev = persist_->ints(std::max<size_t>(idx_host.size(), 1));
@@ -2261,10 +2276,13 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
       Node& nd = nodes_[id];
       const bool root = id == sr;
       const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
-      Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
-      if (nd.leaf()) {
+      if (nd.leaf() && !root) {
+        Dh[id] = nd.D;   // only read below (the root's block is factored in place: it gets a copy)
+      } else if (nd.leaf()) {
+        Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
         cp.push_back(hssk_colgather_desc{nd.D, Dh[id], nullptr, nd.m, nd.m, nd.m, nd.m, 0});
       } else {
+        Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
         Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
         // D = [Dt0, B01 Vt1_1^T ; B10 Vt1_0^T, Dt1]
         cp.push_back(hssk_colgather_desc{a.Dt, Dh[id], nullptr, a.rU, a.rU, std::max(a.rU, 1), std::max(mu, 1), 0});

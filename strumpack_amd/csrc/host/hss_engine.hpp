@@ -221,7 +221,7 @@ class DeviceHSS {
   void reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
   void run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot);
   void id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
-                 const std::vector<int>& ds);
+                 const std::vector<int>& ds, const std::vector<const double*>* srcs = nullptr, int ldsrc = 0);
   void tsqr_reduce(const std::vector<int>& ids, const std::vector<int>& which, std::vector<double*>& Ws, std::vector<int>& ds);
   void ortho_test(const std::vector<int>& ids, const std::vector<int>& which, int d, int dd,
                   std::vector<char>& resolved);

@@ -15,6 +15,7 @@
 // Only rank+1 Householder steps are executed.  Bound: L2/LDS latency (Level-2 BLAS on a panel that
 // lives in L2); flops are negligible.
 #include "hssk_device.h"
+#include "hssk_backsub.h"
 #include "hssk_internal.h"
 
 #include <algorithm>
@@ -170,6 +171,55 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
   if (tid == 0) *p.rank = rank;
 }
 
+// X = R11^{-1} R12 in place for the panels of a register-kernel launch whose rank came out <= 64 (W holds the pivoted,
+// factored panel: R11 = W(0:rank, 0:rank), R12 the columns behind it; larger ranks were finished by id_reg_kernel
+// itself).  One workgroup per panel, one thread per column of R12 with the column in registers; R11 is staged in LDS and
+// read as broadcasts; the back substitution is unrolled over 8-row blocks (blocks at or above the rank are skipped by
+// uniform branches), so every register index is static and a column costs rank^2 / 2 fmas with no cross-lane step.
+// A launch of its own: the factorization kernel has no registers to spare next to its tile.  (The first version solved
+// inside id_reg_kernel, a column per wave and a row per lane, and paid a 64-lane reduction per row: 185 us of the
+// 390 us of a 192 x 195 leaf panel at rank 36.)
+constexpr int XS_T = 256;
+__global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_kernel(const hssk_id_desc* __restrict__ descs) {
+  constexpr int LR = HSSK_BACKSUB_LD;
+  HSSK_SHARED double s_R[64 * LR];
+  HSSK_SHARED double s_rd[64];
+  const hssk_id_desc p = descs[blockIdx.x];
+  const int rank = *p.rank, m = p.m, ld = p.ldw, nthreads = XS_T;
+  if (rank > 64 || rank <= 0) return;
+  double* __restrict__ W = p.W;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += nthreads) {
+    const int i = e & 63, l = e >> 6;
+    s_R[i + l * LR] = (i < l && l < rank) ? W[i + (size_t)l * ld] : 0.;
+  }
+  if (tid < 64) s_rd[tid] = tid < rank ? 1. / W[tid + (size_t)tid * ld] : 0.;
+  __syncthreads();
+  for (int j = rank + tid; j < m; j += nthreads) {
+    double* __restrict__ xcol = W + (size_t)j * ld;
+    double x[64];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      if (8 * b < rank) {
+#pragma unroll
+        for (int i = 8 * b; i < 8 * b + 8; i++) x[i] = i < rank ? xcol[i] : 0.;
+      } else {
+#pragma unroll
+        for (int i = 8 * b; i < 8 * b + 8; i++) x[i] = 0.;
+      }
+    }
+    hssk_backsub64(x, s_R, s_rd, rank);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      if (8 * b < rank) {
+#pragma unroll
+        for (int i = 8 * b; i < 8 * b + 8; i++)
+          if (i < rank) xcol[i] = x[i];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-resident variant (same layout as qr_reg_kernel in hssk_qr.hip): the d x m sample panel lives in the VGPRs of
 // one workgroup, ONE COLUMN PER 16-LANE DPP ROW -- column j belongs to row-group g = j % NC (wave g / 4, lanes 16 (g % 4)
@@ -203,6 +253,8 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
   const int d = p.d, m = p.m, ld = p.ldw;
   const int kmax = d < m ? d : m;
   const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
+  const double* __restrict__ in = p.src ? p.src : p.W;
+  const int ldin = p.src ? p.lds : ld;
   double a[CT][RT];
 #pragma unroll
   for (int c = 0; c < CT; c++) {
@@ -211,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       const int row = l16 + 16 * r;
-      a[c][r] = (row < d && col < m) ? p.W[row + (size_t)col * ld] : 0.;
+      a[c][r] = (row < d && col < m) ? in[row + (size_t)col * ldin] : 0.;
       s += a[c][r] * a[c][r];
     }
     s = hssk_row_sum(s);
@@ -368,11 +420,19 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
   if (rank > p.max_rank) rank = p.max_rank;
   // ---- pivoted column positions: skeleton columns first (pivot order), then the rest
   __syncthreads();
-  if (tid == 0) {
-    for (int j = 0; j < rank; j++) s_pos[s_perm[j]] = j;
-    int next = rank;
-    for (int col = 0; col < m; col++)
-      if (s_pos[col] < 0) s_pos[col] = next++;
+  for (int j = tid; j < rank; j += NW * 64) s_pos[s_perm[j]] = j;
+  __syncthreads();
+  {
+    // a column that was never a pivot goes behind the skeleton, in index order: rank + (number of such columns before it)
+    // (m <= 4 NW CT <= 64 NW: one column per thread)
+    int mine = -1;
+    if (tid < m && s_pos[tid] < 0) {
+      int c = 0;
+      for (int e = 0; e < tid; e++) c += s_pos[e] < 0;
+      mine = rank + c;
+    }
+    __syncthreads();
+    if (mine >= 0) s_pos[tid] = mine;
   }
   __syncthreads();
 #pragma unroll
@@ -380,37 +440,20 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
     const int col = grp + NC * c;
     if (col < m) {
       const int pos = s_pos[col];
+      // only R11 and R12 (the first `rank` rows) are read again: X = R11^{-1} R12, the rest of the panel is dead
 #pragma unroll
       for (int r = 0; r < RT; r++) {
         const int row = l16 + 16 * r;
-        if (row < d) p.W[row + (size_t)pos * ld] = a[c][r];
+        if (16 * r < rank && row < d) p.W[row + (size_t)pos * ld] = a[c][r];
       }
       if (l16 == 0) p.perm[pos] = col;
     }
   }
   __syncthreads();
-  // ---- X = R11^{-1} R12 in place.  rank <= 64: one column per wave, x(l) in lane l, R11 staged in
-  // LDS, each back-substitution step is one LDS row read + a DPP reduction.  Larger ranks: one column per thread
-  // from global memory.
+  // ---- X = R11^{-1} R12 in place.  rank <= 64: left to id_xsolve_kernel (the next launch).  Larger ranks: one column
+  // per thread from global memory.
   double* __restrict__ W = p.W;
-  if (rank <= 64) {
-    HSSK_SHARED double s_R[64 * 65];
-    for (int e = tid; e < rank * rank; e += NW * 64) {
-      const int i = e % rank, l = e / rank;
-      s_R[i + l * 65] = W[i + (size_t)l * ld];
-    }
-    __syncthreads();
-    for (int j = rank + wave; j < m; j += NW) {
-      double* xcol = W + (size_t)j * ld;
-      double x = lane < rank ? xcol[lane] : 0.;
-      for (int i = rank - 1; i >= 0; i--) {
-        const double t = (lane > i && lane < rank) ? s_R[i + lane * 65] * x : 0.;
-        const double s = hssk_wave_sum(t);
-        if (lane == i) x = (x - s) / s_R[i + i * 65];
-      }
-      if (lane < rank) xcol[lane] = x;
-    }
-  } else {
+  if (rank > 64) {
     for (int j = rank + tid; j < m; j += NW * 64) {
       double* x = W + (size_t)j * ld;
       for (int i = rank - 1; i >= 0; i--) {
@@ -426,6 +469,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
 template <int RT, int CT, int NW>
 void launch_id_reg(hssk_ctx* ctx, const hssk_id_desc* dd, int count) {
   HSSK_LAUNCH((id_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
+  HSSK_LAUNCH(id_xsolve_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
 }
 // panels of d <= 16 RT sample rows and up to 64 / 128 / 224 columns; 8-wave workgroups (two waves per SIMD: 256 VGPRs
 // for the register tile and the unrolled step loop; 16 waves with half the slots issue the same number of instructions
@@ -641,6 +685,11 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
   else if (dmax <= 192) done = launch_id_reg_ct<12>(ctx, dd, count, mmax);
   else if (dmax <= 256) done = launch_id_reg_ct<16>(ctx, dd, count, mmax);
   if (!done) {
+    // the in-place kernels want the panel in W
+    std::vector<hssk_colgather_desc> cp;
+    for (int i = 0; i < count; i++)
+      if (descs[i].src) cp.push_back(hssk_colgather_desc{descs[i].src, descs[i].W, nullptr, descs[i].d, descs[i].m, descs[i].lds, descs[i].ldw, 0});
+    if (!cp.empty()) { int rc = hssk_gather_cols(ctx, cp.data(), (int)cp.size()); if (rc) return rc; }
     // few large panels: spread every Householder step over the chip; many small ones: one workgroup each
     static const bool force_wide = [] { const char* e = std::getenv("HSSK_ID_WIDE"); return e && e[0] == '1'; }();
     if (force_wide || (count <= 128 && (long long)dmax * mmax >= 256LL * 512)) id_wide(ctx, descs, dd, count);

@@ -21,6 +21,7 @@
 // Per-node GEMVs are written for memory-level parallelism (the blocks stream from HBM exactly once): thread per output
 // row with 16 independent loads in flight (gemv_n), or four adjacent lanes per output column for column-contiguous
 // operands (gemv_t).
+#include "hssk_backsub.h"
 #include "hssk_device.h"
 #include "hssk_internal.h"
 
@@ -441,49 +442,42 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
 }
 
 // ---- inverses of the 64 x 64 diagonal blocks of R~^T (factor time) --------------------------------------------------------
-// One wave per block: lane j back-substitutes column j of U^{-1} (U = R~(b, b), upper triangular), both matrices in LDS;
-// mode 0 stores it TRANSPOSED (Linv = U^{-T}, lower triangular, leading dimension 64) so that the sweep's y_b = Linv y_b
-// reads rows contiguously; modes 1 / 2 serve the root's LU (plain inverses of the blocks of U and of the unit lower L).
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const hssk_trtri_desc* __restrict__ descs, const int* __restrict__ blk_prob,
-                                                        const int* __restrict__ blk_idx) {
-  HSSK_SHARED double s_U[SW_NB * (SW_NB + 1)];
-  HSSK_SHARED double s_X[SW_NB * (SW_NB + 1)];
+// One wave per block: lane j back-substitutes column j of U^{-1} (U = R~(b, b), upper triangular) in its registers
+// (hssk_backsub64: U in LDS read as broadcasts, no cross-lane step); mode 0 stores it TRANSPOSED (Linv = U^{-T}, lower
+// triangular, leading dimension 64) so that the sweep's y_b = Linv y_b reads rows contiguously; modes 1 / 2 serve the
+// root's LU (plain inverses of the blocks of U and of the unit lower L).  (The first version kept both matrices in LDS,
+// 66 KB per single-wave workgroup -- two waves per CU -- and took 0.26 ms for the leaf level of N = 1e5.)
+__global__ __launch_bounds__(64) HSSK_WAVES_PER_SIMD(1) void trtri_diag_kernel(const hssk_trtri_desc* __restrict__ descs,
+                                                                              const int* __restrict__ blk_prob,
+                                                                              const int* __restrict__ blk_idx) {
+  constexpr int LR = HSSK_BACKSUB_LD;
+  HSSK_SHARED double s_U[SW_NB * LR];
+  HSSK_SHARED double s_rd[SW_NB];
   const hssk_trtri_desc p = descs[blk_prob[blockIdx.x]];
   const int b = blk_idx[blockIdx.x], b0 = b * SW_NB;
   const int nb = min(SW_NB, p.n - b0);
   const int j = threadIdx.x;
-  for (int e = j; e < nb * nb; e += 64) {
-    const int i = e % nb, c = e / nb;
-    double v = 0.;
-    if (p.mode == 2) v = i == c ? 1. : (i < c ? hssk_gload(p.R, (b0 + c) + (size_t)(b0 + i) * p.ldr) : 0.);   // U = L^T, unit diagonal
-    else if (i <= c) v = hssk_gload(p.R, (b0 + i) + (size_t)(b0 + c) * p.ldr);
-    s_U[i + c * (SW_NB + 1)] = v;
-  }
-  for (int e = j; e < SW_NB * (SW_NB + 1); e += 64) s_X[e] = 0.;
-  __syncthreads();
-  if (j < nb) {
-    // column j of U^{-1} by back substitution; x(k) = 0 for k > j, so the inner sum runs over the same k range in every
-    // lane (independent LDS reads, four partial sums: the loop is bound by LDS throughput, not by its latency)
-    double* x = s_X + j * (SW_NB + 1);
-    x[j] = 1. / s_U[j + j * (SW_NB + 1)];
-    for (int i = nb - 2; i >= 0; i--) {
-      double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-      int k = i + 1;
-      for (; k + 3 < nb; k += 4) {
-        s0 += s_U[i + k * (SW_NB + 1)] * x[k];
-        s1 += s_U[i + (k + 1) * (SW_NB + 1)] * x[k + 1];
-        s2 += s_U[i + (k + 2) * (SW_NB + 1)] * x[k + 2];
-        s3 += s_U[i + (k + 3) * (SW_NB + 1)] * x[k + 3];
-      }
-      for (; k < nb; k++) s0 += s_U[i + k * (SW_NB + 1)] * x[k];
-      if (i < j) x[i] = -((s0 + s1) + (s2 + s3)) / s_U[i + i * (SW_NB + 1)];
-    }
-  }
-  __syncthreads();
-  double* out = p.Tinv + (size_t)b * SW_NB * SW_NB;
   for (int e = j; e < SW_NB * SW_NB; e += 64) {
-    const int i = e % SW_NB, c = e / SW_NB;   // modes 0, 2: out(i, c) = Uinv(c, i);  mode 1: out(i, c) = Uinv(i, c)
-    out[e] = (i < nb && c < nb) ? (p.mode == 1 ? s_X[i + c * (SW_NB + 1)] : s_X[c + i * (SW_NB + 1)]) : 0.;
+    const int i = e % SW_NB, c = e / SW_NB;
+    double v = 0.;
+    if (i < c && c < nb)   // strictly upper part; mode 2: U = L^T (unit diagonal)
+      v = p.mode == 2 ? hssk_gload(p.R, (b0 + c) + (size_t)(b0 + i) * p.ldr) : hssk_gload(p.R, (b0 + i) + (size_t)(b0 + c) * p.ldr);
+    s_U[i + c * LR] = v;
+  }
+  s_rd[j] = j < nb ? (p.mode == 2 ? 1. : 1. / hssk_gload(p.R, (b0 + j) + (size_t)(b0 + j) * p.ldr)) : 0.;
+  __syncthreads();
+  // column j of U^{-1}: U x = e_j
+  double x[SW_NB];
+#pragma unroll
+  for (int i = 0; i < SW_NB; i++) x[i] = (i == j && j < nb) ? 1. : 0.;
+  hssk_backsub64(x, s_U, s_rd, nb);
+  double* out = p.Tinv + (size_t)b * SW_NB * SW_NB;
+  if (p.mode == 1) {   // out(i, j) = Uinv(i, j)
+#pragma unroll
+    for (int i = 0; i < SW_NB; i++) out[i + j * SW_NB] = x[i];
+  } else {             // out(j, c) = Uinv(c, j): lanes along a row of the output
+#pragma unroll
+    for (int c = 0; c < SW_NB; c++) out[j + c * SW_NB] = x[c];
   }
 }
 

@@ -61,7 +61,8 @@ class TransposeDesc(C.Structure):
 class IdDesc(C.Structure):
     _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("d", C.c_int), ("m", C.c_int),
                 ("rtol", C.c_double), ("atol", C.c_double), ("max_rank", C.c_int),
-                ("perm", C.c_void_p), ("rank", C.c_void_p), ("work", C.c_void_p)]
+                ("perm", C.c_void_p), ("rank", C.c_void_p), ("work", C.c_void_p),
+                ("src", C.c_void_p), ("lds", C.c_int)]
 
 
 class QrDesc(C.Structure):
