@@ -66,6 +66,11 @@ int hssk_h2d_block_async(hssk_ctx* ctx, double* dst, long long ldd, const double
                          long long cols);
 int hssk_copy_fence(hssk_ctx* ctx);
 int hssk_compute_fence(hssk_ctx* ctx);
+/* The same dependency in two halves, for double-buffered streams: hssk_compute_mark(slot) remembers the compute work enqueued
+ * so far under slot (0 / 1); hssk_copy_wait(slot) makes the uploads issued afterwards wait for exactly that work (and not
+ * for compute work enqueued since) -- a no-op for a slot never marked. */
+int hssk_compute_mark(hssk_ctx* ctx, int slot);
+int hssk_copy_wait(hssk_ctx* ctx, int slot);
 /* 1 if ptr is device memory of the current process (hipPointerGetAttributes) */
 int hssk_is_device_pointer(const void* ptr);
 /* duration (HIP events on the launch stream, ms) and algorithmic flops (2 m cols k) of the MAIN kernel launch of

@@ -348,13 +348,17 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
   double* dBuf[2] = {nullptr, nullptr};
   long long nb = 0;
   int gen = -1;   // compression attempt the buffers were carved in (a restart resets the work arena)
+  // diagonal blocks of the leaves, copied out of the column blocks while they pass through the device (first sample of an
+  // attempt): extract() then serves them from here instead of gathering them from host memory again
+  std::vector<double*> dcache;   // by node id
   HostBlockSource(const double* a, long long l, const host_fill_t* f, const host_elem_t* e) : hA(a), lda(l), fill(f), elem(e) {}
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.o_.world > 1) throw std::invalid_argument("host-resident operands are single-GPU (use the device / sharded interfaces)");
     // (an SJLT sketching matrix is applied in its dense form here -- Rt_ holds it, DeviceHSS::fill_random: the streaming
     // SJLT kernels overwrite their output, the blocks of a streamed operand have to accumulate)
     const long long N = H.n_;
-    if (gen != H.attempt_) {
+    const bool first = gen != H.attempt_;
+    if (first) {
       gen = H.attempt_;
       // ~1.5 GB per buffer (STRUMPACK_AMD_HOST_BLOCK_MB to change), whole 64-column tiles of the sketch GEMM
       long long mb = 1536;
@@ -365,6 +369,12 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
       dBuf[1] = H.work_->dbl((size_t)N * nb);
     }
     const long long nblk = (N + nb - 1) / nb;
+    const bool capture = first;
+    if (capture) {
+      dcache.assign(H.nodes_.size(), nullptr);
+      for (size_t id = 0; id < H.nodes_.size(); id++)
+        if (H.nodes_[id].leaf() && H.nodes_[id].m > 0) dcache[id] = H.work_->dbl((size_t)H.nodes_[id].m * H.nodes_[id].m);
+    }
     std::vector<double> tmp;   // columns evaluated by `fill` (packed into the pinned ring before the call returns)
     auto upload = [&](long long b) {
       const long long c0 = b * nb, c1 = std::min(N, c0 + nb);
@@ -379,13 +389,30 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
     for (long long b = 0; b < nblk; b++) {
       const long long c0 = b * nb, c1 = std::min(N, c0 + nb);
       ck(hssk_copy_fence(H.ctx_));          // the GEMMs below wait for block b
-      if (b + 1 < nblk) {
-        ck(hssk_compute_fence(H.ctx_));     // block b+1 overwrites the buffer the GEMMs of block b-1 read
-        upload(b + 1);
-      }
       const double* Ab = dBuf[b & 1];
       ck(hssk_dgemm(H.ctx_, 0, dn, c1 - c0, N, 1.0, H.Rt_ + r0, H.dcap_, Ab, N, 0.0, H.Sct_ + r0 + c0 * H.dcap_, H.dcap_));
       ck(hssk_dgemm(H.ctx_, 1, dn, N, c1 - c0, 1.0, H.Rt_ + r0 + c0 * H.dcap_, H.dcap_, Ab, N, b ? 1.0 : 0.0, H.Srt_ + r0, H.dcap_));
+      if (capture) {
+        // the columns of the leaves' diagonal blocks that lie in this column block
+        std::vector<hssk_colgather_desc> dg;
+        for (size_t id = 0; id < H.nodes_.size(); id++) {
+          const Node& nd = H.nodes_[id];
+          if (!dcache[id]) continue;
+          const long long a = std::max<long long>(nd.lo, c0), e = std::min<long long>(nd.lo + nd.m, c1);
+          if (a >= e) continue;
+          dg.push_back(hssk_colgather_desc{Ab + nd.lo + (size_t)(a - c0) * N, dcache[id] + (size_t)(a - nd.lo) * nd.m, nullptr, nd.m, (int)(e - a),
+                                           (int)N, nd.m, 0});
+        }
+        if (!dg.empty()) ck(hssk_gather_cols(H.ctx_, dg.data(), (int)dg.size()));
+      }
+      // block b + 1 overwrites the buffer the work of block b - 1 read -- and only that: the upload (whose packing blocks
+      // this thread for most of its duration) is issued AFTER the GEMMs of block b, which then run under it, and it does
+      // not wait for them.  (Issued before them, every block stalled the copy stream for the 2.4 ms of its GEMMs.)
+      ck(hssk_compute_mark(H.ctx_, (int)(b & 1)));
+      if (b + 1 < nblk) {
+        ck(hssk_copy_wait(H.ctx_, (int)((b + 1) & 1)));
+        upload(b + 1);
+      }
     }
     ck(hssk_sync(H.ctx_));
   }
@@ -393,10 +420,31 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
     // every requested block is compact (ldb == m): gather on the host threads into one staging image, one upload each
     std::vector<size_t> off(reqs.size() + 1, 0);
     for (size_t k = 0; k < reqs.size(); k++) off[k + 1] = off[k] + (size_t)std::max(reqs[k].m, 0) * std::max(reqs[k].n, 0);
-    std::vector<double> img(off.back());
+    // blocks served from the device-side cache of leaf diagonal blocks
+    std::vector<const double*> hit(reqs.size(), nullptr);
+    if (!dcache.empty()) {
+      std::vector<std::pair<int, size_t>> by_lo;   // (lo, node) of the cached leaves, for the lookups below
+      for (size_t id = 0; id < H.nodes_.size(); id++) if (dcache[id]) by_lo.push_back({H.nodes_[id].lo, id});
+      std::sort(by_lo.begin(), by_lo.end());
+      std::vector<hssk_colgather_desc> cp;
+      for (size_t k = 0; k < reqs.size(); k++) {
+        const ElemReq& r = reqs[k];
+        if (r.hI || r.hJ || r.i0 != r.j0 || r.m != r.n || r.m <= 0 || gen != H.attempt_) continue;
+        auto it = std::lower_bound(by_lo.begin(), by_lo.end(), std::make_pair(r.i0, size_t(0)));
+        if (it == by_lo.end() || it->first != r.i0 || H.nodes_[it->second].m != r.m) continue;
+        hit[k] = dcache[it->second];
+        cp.push_back(hssk_colgather_desc{hit[k], r.dB, nullptr, r.m, r.n, r.m, r.ldb, 0});
+      }
+      if (!cp.empty()) ck(hssk_gather_cols(H.ctx_, cp.data(), (int)cp.size()));
+    }
+    for (size_t k = 0; k < reqs.size(); k++)
+      if (hit[k]) off[k + 1] = off[k];   // (no staging space for served requests)
+      else off[k + 1] = off[k] + (size_t)std::max(reqs[k].m, 0) * std::max(reqs[k].n, 0);
+    std::unique_ptr<double[]> img_store(new double[std::max<size_t>(off.back(), 1)]);   // (not value-initialised: every element is written)
+    struct { double* p; double* data() { return p; } } img{img_store.get()};
     host_parallel_for(reqs.size(), [&](size_t k) {
       const ElemReq& r = reqs[k];
-      if (r.m <= 0 || r.n <= 0) return;
+      if (r.m <= 0 || r.n <= 0 || hit[k]) return;
       double* B = img.data() + off[k];
       if (hA) {
         for (int j = 0; j < r.n; j++) {
@@ -413,7 +461,7 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
     });
     for (size_t k = 0; k < reqs.size(); k++) {
       const ElemReq& r = reqs[k];
-      if (r.m <= 0 || r.n <= 0) continue;
+      if (r.m <= 0 || r.n <= 0 || hit[k]) continue;
       if (r.ldb == r.m) ck(hssk_upload_async(H.ctx_, r.dB, img.data() + off[k], (long long)(sizeof(double) * (off[k + 1] - off[k]))));
       else ck(hssk_memcpy2d_h2d(H.ctx_, r.dB, sizeof(double) * r.ldb, img.data() + off[k], sizeof(double) * r.m, sizeof(double) * r.m, r.n));
     }
