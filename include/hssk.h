@@ -244,8 +244,22 @@ typedef struct hssk_id_desc {
   const double* src; /* NULL: the panel is in W.  Otherwise the panel is read from src (d x m, leading dimension lds, left
                       * untouched) and W (ldw >= d) only receives the outputs -- saves the caller a copy of the samples */
   int lds;
+  int defer_x; /* non-zero: the caller finishes with hssk_id_xsolve_vbatched once it has read the ranks (X then goes
+                * straight to its final place, and the solve is off the path to the ranks).  W(0:rank, 0:m) holds
+                * [R11 R12] on return, or already X behind R11 when hssk_id_solves_inline() says so for the batch. */
 } hssk_id_desc;
 int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count);
+/* 1: a batch with these largest dimensions is factored by kernels that always leave X in W (defer_x has no effect) */
+int hssk_id_solves_inline(int dmax, int mmax);
+/* X (rank x (m - rank), leading dimension ldx) = R11^{-1} R12 from the factored panel W (solved == 0), or a plain copy of
+ * W(0:rank, rank:m) (solved != 0: the panel already holds X). */
+typedef struct hssk_xsolve_desc {
+  const double* W;
+  int ldw, rank, m;
+  double* X;
+  int ldx, solved;
+} hssk_xsolve_desc;
+int hssk_id_xsolve_vbatched(hssk_ctx* ctx, const hssk_xsolve_desc* descs, int count);
 
 /* ---- batched Householder QR ------------------------------------------------------------------- */
 /* A (rows x cols, overwritten) = Q R.  nq > 0: the first nq columns of Q are written to Q

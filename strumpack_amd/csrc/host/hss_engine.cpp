@@ -1493,6 +1493,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   }
   tsqr_reduce(ids, which, Ws, ds);
   std::vector<hssk_id_desc> idd;
+  int id_dmax = 0, id_mmax = 0;
   std::vector<int*> perms(cnt, nullptr);
   size_t perm_total = 0;
   for (size_t k = 0; k < cnt; k++) perm_total += (which[k] == 0 ? nodes_[ids[k]].mU : nodes_[ids[k]].mV);
@@ -1507,16 +1508,20 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     poff += m;
     if (m == 0) continue;
     double* wk = tmp.dbl(3 * (size_t)m);
+    // (defer_x: X = R11^{-1} R12 is computed behind the read-back of the ranks, straight into its final place)
     idd.push_back(hssk_id_desc{Ws[k], ds[k], ds[k], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk,
-                               srcs ? (*srcs)[k] : nullptr, ldsrc});
+                               srcs ? (*srcs)[k] : nullptr, ldsrc, 1});
+    id_dmax = std::max(id_dmax, ds[k]);
+    id_mmax = std::max(id_mmax, m);
   }
   if (!idd.empty()) ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
+  const int x_solved = hssk_id_solves_inline(id_dmax, id_mmax);
   std::vector<int> hall(cnt + std::max<size_t>(perm_total, 1));
   ck(hssk_memcpy_d2h(ctx_, hall.data(), rank_block, (long long)sizeof(int) * (cnt + perm_total)));
   const int* hranks = hall.data();
   const int* hperm = hall.data() + cnt;
   // commit
-  std::vector<hssk_elem_desc> xc;
+  std::vector<hssk_xsolve_desc> xc;
   std::vector<int> idx_host;      // all skeleton index sets of this level: one upload
   std::vector<size_t> idx_off;
   poff = 0;
@@ -1529,7 +1534,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     std::vector<int> perm(hperm + poff, hperm + poff + m);
     poff += m;
     double* X = persist_->dbl((size_t)std::max(r, 1) * std::max(m - r, 1));
-    if (r > 0 && m > r) xc.push_back(hssk_elem_desc{Ws[k], dtot, nullptr, nullptr, 0, r, X, r, m - r, r, 0});
+    if (r > 0 && m > r) xc.push_back(hssk_xsolve_desc{Ws[k], dtot, r, m, X, r, x_solved});
     // global skeleton indices (compress_stable.hpp:299-306, 334-341)
     std::vector<int> I(r);
     if (nd.leaf()) for (int i = 0; i < r; i++) I[i] = nd.lo + perm[i];
@@ -1552,7 +1557,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     Node& nd = nodes_[ids[k]];
     (which[k] == 0 ? nd.dIr : nd.dIc) = idx_dev + idx_off[k];
   }
-  if (!xc.empty()) ck(hssk_gather_elems(ctx_, xc.data(), (int)xc.size()));
+  if (!xc.empty()) ck(hssk_id_xsolve_vbatched(ctx_, xc.data(), (int)xc.size()));
   // (no synchronisation: everything that reuses the W panels in tmp_ is enqueued behind these launches on the same stream)
 }
 

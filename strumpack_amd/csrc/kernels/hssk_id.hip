@@ -180,29 +180,39 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
 // inside id_reg_kernel, a column per wave and a row per lane, and paid a 64-lane reduction per row: 185 us of the
 // 390 us of a 192 x 195 leaf panel at rank 36.)
 constexpr int XS_T = 256;
-__global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_kernel(const hssk_id_desc* __restrict__ descs) {
+// body shared by the two front ends below: X (ldx) = R11^{-1} R12 of the factored panel W (ldw)
+__device__ __forceinline__ void xsolve_body(const double* W, int ld, int rank, int m, double* X, int ldx,   // (X may lie over R12)
+                                            double* s_R, double* s_rd) {
   constexpr int LR = HSSK_BACKSUB_LD;
-  HSSK_SHARED double s_R[64 * LR];
-  HSSK_SHARED double s_rd[64];
-  const hssk_id_desc p = descs[blockIdx.x];
-  const int rank = *p.rank, m = p.m, ld = p.ldw, nthreads = XS_T;
-  if (rank > 64 || rank <= 0) return;
-  double* __restrict__ W = p.W;
   const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * 64; e += nthreads) {
+  if (rank <= 0 || rank >= m) return;
+  if (rank > 64) {   // large ranks: one column per thread, straight from global memory
+    for (int j = rank + tid; j < m; j += XS_T) {
+      const double* b = W + (size_t)j * ld;
+      double* x = X + (size_t)(j - rank) * ldx;
+      for (int i = rank - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int l = i + 1; l < rank; l++) s -= W[i + (size_t)l * ld] * x[l];
+        x[i] = s / W[i + (size_t)i * ld];
+      }
+    }
+    return;
+  }
+  for (int e = tid; e < 64 * 64; e += XS_T) {
     const int i = e & 63, l = e >> 6;
     s_R[i + l * LR] = (i < l && l < rank) ? W[i + (size_t)l * ld] : 0.;
   }
   if (tid < 64) s_rd[tid] = tid < rank ? 1. / W[tid + (size_t)tid * ld] : 0.;
   __syncthreads();
-  for (int j = rank + tid; j < m; j += nthreads) {
-    double* __restrict__ xcol = W + (size_t)j * ld;
+  for (int j = rank + tid; j < m; j += XS_T) {
+    const double* bcol = W + (size_t)j * ld;
+    double* xcol = X + (size_t)(j - rank) * ldx;
     double x[64];
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       if (8 * b < rank) {
 #pragma unroll
-        for (int i = 8 * b; i < 8 * b + 8; i++) x[i] = i < rank ? xcol[i] : 0.;
+        for (int i = 8 * b; i < 8 * b + 8; i++) x[i] = i < rank ? bcol[i] : 0.;
       } else {
 #pragma unroll
         for (int i = 8 * b; i < 8 * b + 8; i++) x[i] = 0.;
@@ -218,6 +228,30 @@ __global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_kernel(
       }
     }
   }
+}
+// in place, right behind a register-kernel launch: rank from device memory, X over R12 (ranks above 64 were finished by
+// id_reg_kernel itself; panels with defer_x set are left to hssk_id_xsolve_vbatched)
+__global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_kernel(const hssk_id_desc* __restrict__ descs) {
+  HSSK_SHARED double s_R[64 * HSSK_BACKSUB_LD];
+  HSSK_SHARED double s_rd[64];
+  const hssk_id_desc p = descs[blockIdx.x];
+  const int rank = *p.rank;
+  if (rank > 64 || p.defer_x) return;
+  xsolve_body(p.W, p.ldw, rank, p.m, p.W + (size_t)rank * p.ldw, p.ldw, s_R, s_rd);
+}
+// deferred: rank and destination from the descriptor (hssk_id_xsolve_vbatched)
+__global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_to_kernel(const hssk_xsolve_desc* __restrict__ descs) {
+  HSSK_SHARED double s_R[64 * HSSK_BACKSUB_LD];
+  HSSK_SHARED double s_rd[64];
+  const hssk_xsolve_desc p = descs[blockIdx.x];
+  if (p.solved) {
+    for (int e = threadIdx.x; e < p.rank * (p.m - p.rank); e += XS_T) {
+      const int i = e % p.rank, j = e / p.rank;
+      p.X[i + (size_t)j * p.ldx] = p.W[i + (size_t)(p.rank + j) * p.ldw];
+    }
+    return;
+  }
+  xsolve_body(p.W, p.ldw, p.rank, p.m, p.X, p.ldx, s_R, s_rd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -453,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
   // ---- X = R11^{-1} R12 in place.  rank <= 64: left to id_xsolve_kernel (the next launch).  Larger ranks: one column
   // per thread from global memory.
   double* __restrict__ W = p.W;
-  if (rank > 64) {
+  if (rank > 64 && !p.defer_x) {
     for (int j = rank + tid; j < m; j += NW * 64) {
       double* x = W + (size_t)j * ld;
       for (int i = rank - 1; i >= 0; i--) {
@@ -466,10 +500,11 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
   if (tid == 0) *p.rank = rank;
 }
 
+static thread_local bool g_all_deferred = false;   // (set by hssk_id_vbatched for the launch helpers below)
 template <int RT, int CT, int NW>
 void launch_id_reg(hssk_ctx* ctx, const hssk_id_desc* dd, int count) {
   HSSK_LAUNCH((id_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
-  HSSK_LAUNCH(id_xsolve_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
+  if (!g_all_deferred) HSSK_LAUNCH(id_xsolve_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
 }
 // panels of d <= 16 RT sample rows and up to 64 / 128 / 224 columns; 8-wave workgroups (two waves per SIMD: 256 VGPRs
 // for the register tile and the unrolled step loop; 16 waves with half the slots issue the same number of instructions
@@ -680,6 +715,8 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
   for (int i = 0; i < count; i++) { dmax = std::max(dmax, descs[i].d); mmax = std::max(mmax, descs[i].m); }
   auto* dd = (const hssk_id_desc*)ctx->stage(descs, sizeof(*descs) * count);
   bool done = false;
+  g_all_deferred = true;
+  for (int i = 0; i < count; i++) g_all_deferred = g_all_deferred && descs[i].defer_x != 0;
   if (dmax <= 64) done = launch_id_reg_ct<4>(ctx, dd, count, mmax);
   else if (dmax <= 128) done = launch_id_reg_ct<8>(ctx, dd, count, mmax);
   else if (dmax <= 192) done = launch_id_reg_ct<12>(ctx, dd, count, mmax);
@@ -695,6 +732,17 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
     if (force_wide || (count <= 128 && (long long)dmax * mmax >= 256LL * 512)) id_wide(ctx, descs, dd, count);
     else HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
   }
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_id_solves_inline(int dmax, int mmax) { return (dmax <= 256 && mmax <= 224) ? 0 : 1; }
+
+extern "C" int hssk_id_xsolve_vbatched(hssk_ctx* ctx, const hssk_xsolve_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  auto* dd = (const hssk_xsolve_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  HSSK_LAUNCH(id_xsolve_to_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
   hssk_rt::check_launch();
   HSSK_API_END
 }
