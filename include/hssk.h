@@ -226,6 +226,27 @@ int hssk_sjlt_dense(hssk_ctx* ctx, double* Rt, int dn, long long K, long long ld
 int hssk_sjlt_sketch(hssk_ctx* ctx, int transA, long long n_out, long long K, const double* A, long long lda,
                      const int* pat, int nnz, int dn, double* St, long long lds);
 
+/* ---- column gather + small product ----------------------------------------------------------------- */
+/* out(i, j) = G(i, g_j) + alpha sum_{k < K} M(i, m_k) C(j, k),  i < rows, j < J.
+ * G(:, c) is column c of [G0 | G1] (G0 has gsplit columns; G0 == NULL: no gathered part), g_j = gidx ? gidx[j] : j;
+ * M(:, c) likewise of [M0 | M1] with msplit, m_k = midx ? midx[k] : k; C(j, k) = C[j csj + k csk].  All operands
+ * column-major with the rows contiguous; out must not overlap G or M.  Serves compute_local_samples / reduce_local_samples of
+ * the inner levels (HSS/HSSMatrix.compress.hpp:524-629, 689-724) as one launch each. */
+typedef struct hssk_combine_desc {
+  const double *G0, *G1;
+  int ldg, gsplit;
+  const int* gidx; /* device */
+  const double *M0, *M1;
+  int ldm, msplit;
+  const int* midx; /* device */
+  const double* C;
+  int csj, csk;
+  double alpha;
+  double* out;
+  int ldo, rows, J, K;
+} hssk_combine_desc;
+int hssk_gather_combine(hssk_ctx* ctx, const hssk_combine_desc* descs, int count);
+
 /* ---- batched interpolative decomposition ------------------------------------------------------- */
 /* Truncated column-pivoted Householder QR of W (d x m, column-major, overwritten), i.e. the row ID
  * of the m x d sample block:  DenseMatrix::ID_row -> ID_column_GEQP3 -> geqp3tol + trsm

@@ -1265,7 +1265,7 @@ void DeviceHSS::extract_blocks(Source& src, const std::vector<int>& ids) {
 
 // compute_local_samples (HSSMatrix.compress.hpp:524-629) on sample rows [r0, r0+dn) of each node
 void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int>& r0s, const std::vector<int>& dns) {
-  std::vector<hssk_colgather_desc> g;
+  std::vector<hssk_combine_desc> cb;
   std::vector<hssk_gemm_desc> mm;
   std::vector<hssk_leaf_update_desc> lu;   // fused Sr / Sc update of the leaves (both share the R panel)
   for (size_t k = 0; k < ids.size(); k++) {
@@ -1284,20 +1284,23 @@ void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int
       stats_.f_local += 4.0 * m * (double)m * dn;
     } else {
       Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
-      // gather the children's skeleton rows (extract_rows, compress.hpp:563-566, 611-614)
-      g.push_back(hssk_colgather_desc{a.Srt + r0, nd.Srt + r0, a.permU, dn, a.rU, dcap_, dcap_, 0});
-      g.push_back(hssk_colgather_desc{b.Srt + r0, nd.Srt + r0 + (size_t)a.rU * dcap_, b.permU, dn, b.rU, dcap_, dcap_, 0});
-      g.push_back(hssk_colgather_desc{a.Sct + r0, nd.Sct + r0, a.permV, dn, a.rV, dcap_, dcap_, 0});
-      g.push_back(hssk_colgather_desc{b.Sct + r0, nd.Sct + r0 + (size_t)a.rV * dcap_, b.permV, dn, b.rV, dcap_, dcap_, 0});
-      // Sr0 -= B01 Rr1 ; Sr1 -= B10 Rr0 ; Sc0 -= B10^T Rc1 ; Sc1 -= B01^T Rc0
-      mm.push_back(hssk_gemm_desc{b.RrtRed + r0, nd.B01, nd.Srt + r0, dn, a.rU, b.rV, dcap_, std::max(a.rU, 1), dcap_, 0, 1, -1.0, 1.0});
-      mm.push_back(hssk_gemm_desc{a.RrtRed + r0, nd.B10, nd.Srt + r0 + (size_t)a.rU * dcap_, dn, b.rU, a.rV, dcap_, std::max(b.rU, 1), dcap_, 0, 1, -1.0, 1.0});
-      mm.push_back(hssk_gemm_desc{b.RctRed + r0, nd.B10, nd.Sct + r0, dn, a.rV, b.rU, dcap_, std::max(b.rU, 1), dcap_, 0, 0, -1.0, 1.0});
-      mm.push_back(hssk_gemm_desc{a.RctRed + r0, nd.B01, nd.Sct + r0 + (size_t)a.rV * dcap_, dn, b.rV, a.rU, dcap_, std::max(a.rU, 1), dcap_, 0, 0, -1.0, 1.0});
+      // the children's skeleton rows (extract_rows, compress.hpp:563-566, 611-614) minus the coupling terms, one fused
+      // gather + product per block:  Sr0 = Sr_a(Jr_a) - B01 Rr1 ; Sr1 = Sr_b(Jr_b) - B10 Rr0 ;
+      //                              Sc0 = Sc_a(Jc_a) - B10^T Rc1 ; Sc1 = Sc_b(Jc_b) - B01^T Rc0       (all transposed)
+      const int none = 0x7fffffff;
+      const int l01 = std::max(a.rU, 1), l10 = std::max(b.rU, 1);
+      cb.push_back(hssk_combine_desc{a.Srt + r0, nullptr, dcap_, none, a.permU, b.RrtRed + r0, nullptr, dcap_, none, nullptr,
+                                     nd.B01, 1, l01, -1.0, nd.Srt + r0, dcap_, dn, a.rU, b.rV});
+      cb.push_back(hssk_combine_desc{b.Srt + r0, nullptr, dcap_, none, b.permU, a.RrtRed + r0, nullptr, dcap_, none, nullptr,
+                                     nd.B10, 1, l10, -1.0, nd.Srt + r0 + (size_t)a.rU * dcap_, dcap_, dn, b.rU, a.rV});
+      cb.push_back(hssk_combine_desc{a.Sct + r0, nullptr, dcap_, none, a.permV, b.RctRed + r0, nullptr, dcap_, none, nullptr,
+                                     nd.B10, l10, 1, -1.0, nd.Sct + r0, dcap_, dn, a.rV, b.rU});
+      cb.push_back(hssk_combine_desc{b.Sct + r0, nullptr, dcap_, none, b.permV, a.RctRed + r0, nullptr, dcap_, none, nullptr,
+                                     nd.B01, l01, 1, -1.0, nd.Sct + r0 + (size_t)a.rV * dcap_, dcap_, dn, b.rV, a.rU});
       stats_.f_local += 4.0 * ((double)a.rU * b.rV + (double)b.rU * a.rV) * dn;
     }
   }
-  if (!g.empty()) ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
+  if (!cb.empty()) ck(hssk_gather_combine(ctx_, cb.data(), (int)cb.size()));
   if (!lu.empty()) {
     int rc = hssk_leaf_update_vbatched(ctx_, lu.data(), (int)lu.size());
     if (rc == 2) {  // layout not eligible for the fused kernel: two plain GEMMs per leaf
@@ -1313,47 +1316,39 @@ void DeviceHSS::local_samples(const std::vector<int>& ids, const std::vector<int
 // reduce_local_samples: Rr_loc <- V^H Rr_loc, Rc_loc <- U^H Rc_loc (HSSBasisID::applyC), transposed
 void DeviceHSS::reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0s, const std::vector<int>& dns) {
   if (ids.empty()) return;
-  std::vector<hssk_colgather_desc> cat, g;
-  std::vector<hssk_gemm_desc> mm;
-  Arena& tmp = *tmp_;
-  tmp.rewind();
+  // Rr_red = Rr(Jc, :) + XV Rr(rest, :) (transposed: columns of Rrt), where Rr of an inner node is the stack of its
+  // children's reduced samples -- read in place from the two children ([a | b] with the split at a's rank), one fused
+  // gather + product per (node, side)
+  std::vector<hssk_combine_desc> cb;
+  const int none = 0x7fffffff;
   for (size_t k = 0; k < ids.size(); k++) {
     Node& nd = nodes_[ids[k]];
     const int r0 = r0s[k], dn = dns[k];
     if (dn <= 0) continue;
-    if (!nd.leaf()) {
+    const double *rr0, *rr1 = nullptr, *rc0, *rc1 = nullptr;
+    int sr = none, sc = none;
+    if (nd.leaf()) { rr0 = nd.Rrt + r0; rc0 = nd.Rct + r0; }
+    else {
       Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
-      cat.push_back(hssk_colgather_desc{a.RrtRed + r0, nd.Rrt + r0, nullptr, dn, a.rV, dcap_, dcap_, 0});
-      cat.push_back(hssk_colgather_desc{b.RrtRed + r0, nd.Rrt + r0 + (size_t)a.rV * dcap_, nullptr, dn, b.rV, dcap_, dcap_, 0});
-      cat.push_back(hssk_colgather_desc{a.RctRed + r0, nd.Rct + r0, nullptr, dn, a.rU, dcap_, dcap_, 0});
-      cat.push_back(hssk_colgather_desc{b.RctRed + r0, nd.Rct + r0 + (size_t)a.rU * dcap_, nullptr, dn, b.rU, dcap_, dcap_, 0});
-    }
-    // Rr (with V): RrtRed = Rrt[:, permV[:rV]] + Rrt[:, permV[rV:]] XV^T
-    {
-      const int m = nd.mV, r = nd.rV;
-      g.push_back(hssk_colgather_desc{nd.Rrt + r0, nd.RrtRed + r0, nd.permV, dn, r, dcap_, dcap_, 0});
-      if (m > r && r > 0) {
-        double* T = tmp.dbl((size_t)dn * (m - r));
-        g.push_back(hssk_colgather_desc{nd.Rrt + r0, T, nd.permV + r, dn, m - r, dcap_, dn, 0});
-        mm.push_back(hssk_gemm_desc{T, nd.XV, nd.RrtRed + r0, dn, r, m - r, dn, r, dcap_, 0, 1, 1.0, 1.0});
-        stats_.f_reduce += 2.0 * r * (double)(m - r) * dn;
-      }
+      rr0 = a.RrtRed + r0; rr1 = b.RrtRed + r0; sr = a.rV;
+      rc0 = a.RctRed + r0; rc1 = b.RctRed + r0; sc = a.rU;
     }
     {
-      const int m = nd.mU, r = nd.rU;
-      g.push_back(hssk_colgather_desc{nd.Rct + r0, nd.RctRed + r0, nd.permU, dn, r, dcap_, dcap_, 0});
-      if (m > r && r > 0) {
-        double* T = tmp.dbl((size_t)dn * (m - r));
-        g.push_back(hssk_colgather_desc{nd.Rct + r0, T, nd.permU + r, dn, m - r, dcap_, dn, 0});
-        mm.push_back(hssk_gemm_desc{T, nd.XU, nd.RctRed + r0, dn, r, m - r, dn, r, dcap_, 0, 1, 1.0, 1.0});
-        stats_.f_reduce += 2.0 * r * (double)(m - r) * dn;
-      }
+      const int m = nd.mV, r = nd.rV, K = (m > r && r > 0) ? m - r : 0;
+      if (r > 0)
+        cb.push_back(hssk_combine_desc{rr0, rr1, dcap_, sr, nd.permV, rr0, rr1, dcap_, sr, nd.permV + r, nd.XV, 1, r, 1.0,
+                                       nd.RrtRed + r0, dcap_, dn, r, K});
+      stats_.f_reduce += 2.0 * r * (double)K * dn;
+    }
+    {
+      const int m = nd.mU, r = nd.rU, K = (m > r && r > 0) ? m - r : 0;
+      if (r > 0)
+        cb.push_back(hssk_combine_desc{rc0, rc1, dcap_, sc, nd.permU, rc0, rc1, dcap_, sc, nd.permU + r, nd.XU, 1, r, 1.0,
+                                       nd.RctRed + r0, dcap_, dn, r, K});
+      stats_.f_reduce += 2.0 * r * (double)K * dn;
     }
   }
-  if (!cat.empty()) ck(hssk_gather_cols(ctx_, cat.data(), (int)cat.size()));
-  if (!g.empty()) ck(hssk_gather_cols(ctx_, g.data(), (int)g.size()));
-  if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
-  // (tmp is reused by later launches of the same stream only: no host synchronisation needed)
+  if (!cb.empty()) ck(hssk_gather_combine(ctx_, cb.data(), (int)cb.size()));
 }
 
 // ID of the listed (node, basis) pairs on all dtot samples; commits ranks, X, perm, index sets

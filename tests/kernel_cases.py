@@ -7,6 +7,7 @@ import numpy as np
 import scipy.linalg as sla
 
 from strumpack_amd import hssk as K
+from strumpack_amd import hssk as K_
 
 
 def rng(seed=0):
@@ -429,3 +430,36 @@ def case_kernel_predict(hk, n=257, m=70, d=5, seed=23):
         Z = np.vstack([X, T])
         Kx = kernel_np(Z, np.arange(n), n + np.arange(m), ktype, 0.9, 0.0, p)
         assert np.allclose(dp.get(), w @ Kx, rtol=1e-11, atol=1e-12)
+
+
+def case_gather_combine(hk, shapes, seed=31):
+    """hssk_gather_combine vs numpy: out = G[:, g] + alpha M[:, m] C^T with two-part sources and index lists.
+    shapes: (rows, J, K, ng0, ng1, nm0, nm1, transposed_c, with_g)"""
+    r = rng(seed)
+    descs, keep, expect = [], [], []
+    for (rows, J, K, ng0, ng1, nm0, nm1, ct, with_g) in shapes:
+        ldg, ldm, ldo = rows + 3, rows + 1, rows + 2
+        G0, G1 = r.standard_normal((ldg, ng0)), r.standard_normal((ldg, max(ng1, 1)))
+        M0, M1 = r.standard_normal((ldm, max(nm0, 1))), r.standard_normal((ldm, max(nm1, 1)))
+        gidx = r.integers(0, ng0 + ng1, J).astype(np.int32)
+        midx = r.integers(0, max(nm0 + nm1, 1), max(K, 1)).astype(np.int32)
+        Cm = r.standard_normal((K, J)) if ct else r.standard_normal((J, K))   # C(j, k) = Cm[k, j] / Cm[j, k]
+        out0 = r.standard_normal((ldo, J))
+        alpha = -1.0 if ct else 0.5
+        d = [hk.array(x) for x in (G0, G1, M0, M1)] + [hk.array(gidx), hk.array(midx), hk.array(Cm if Cm.size else np.zeros((1, 1))), hk.array(out0)]
+        keep.append(d)
+        ldc = max(Cm.shape[0], 1)
+        csj, csk = (ldc, 1) if ct else (1, ldc)
+        descs.append(K_.CombineDesc(d[0].ptr if with_g else None, d[1].ptr, ldg, ng0, d[4].ptr, d[2].ptr, d[3].ptr, ldm, nm0, d[5].ptr,
+                                    d[6].ptr, csj, csk, alpha, d[7].ptr, ldo, rows, J, K))
+        Gc = np.hstack([G0, G1[:, :ng1]])[:rows]
+        Mc = np.hstack([M0[:, :nm0], M1[:, :nm1]])[:rows] if nm0 + nm1 else np.zeros((rows, 1))
+        Cjk = Cm.T if ct else Cm
+        ref = out0.copy()
+        ref[:rows] = (Gc[:, gidx] if with_g else 0.0) + (alpha * Mc[:, midx[:K]] @ Cjk.T if K else 0.0)
+        expect.append(ref)
+    hk.batch("hssk_gather_combine", descs)
+    hk.sync()
+    for d, ref, sh in zip(keep, expect, shapes):
+        got = d[7].get()
+        assert np.abs(got - ref).max() <= 1e-12 * max(1, sh[2]), f"gather_combine {sh}"

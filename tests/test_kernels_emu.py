@@ -108,3 +108,8 @@ def test_sjlt(hk):
     KC.case_sjlt(hk, n_out=45, K=300, dn=24, nnz=4)
     KC.case_sjlt(hk, n_out=130, K=77, dn=200, nnz=2, seed=4)
     KC.case_sjlt(hk, n_out=20, K=130, dn=600, nnz=8, seed=5)
+
+
+def test_gather_combine(hk):
+    KC.case_gather_combine(hk, [(40, 5, 7, 6, 3, 4, 5, 0, 1), (70, 66, 65, 9, 0, 70, 0, 1, 1), (33, 9, 0, 5, 5, 0, 0, 0, 1),
+                                (300, 3, 130, 2, 2, 50, 90, 1, 0)])

@@ -117,3 +117,9 @@ def test_sjlt(hk):
     KC.case_sjlt(hk, n_out=777, K=2050, dn=64, nnz=2, seed=5)
     KC.case_sjlt(hk, n_out=300, K=1500, dn=300, nnz=8, seed=6)
     KC.case_sjlt(hk, n_out=100, K=900, dn=1000, nnz=3, seed=7)
+
+
+def test_gather_combine(hk):
+    KC.case_gather_combine(hk, [(40, 5, 7, 6, 3, 4, 5, 0, 1), (70, 66, 65, 9, 0, 70, 0, 1, 1), (33, 9, 0, 5, 5, 0, 0, 0, 1),
+                                (300, 3, 130, 2, 2, 50, 90, 1, 0)])
+    KC.case_gather_combine(hk, [(192, 41, 159, 100, 95, 195, 0, 0, 1), (192, 82, 41, 60, 22, 30, 11, 1, 1), (500, 130, 70, 64, 64, 40, 40, 0, 1)], seed=33)
