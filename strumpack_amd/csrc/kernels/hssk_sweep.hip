@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int SW_T = 256;     // threads per workgroup
-constexpr int SW_NR = 4;      // right-hand sides handled at once
+constexpr int SW_NR = 4;      // right-hand sides handled at once (kernels are instantiated for NR = 4 and NR = 1)
 constexpr int SW_MAX = 256;   // largest node dimension (rows of a basis)
 constexpr int SW_NB = 64;     // block size of the substitution with R~^T (hssk_trtri_diag_vbatched)
 constexpr long SW_SPIN_LIMIT = 1L << 22;
@@ -78,25 +78,70 @@ struct RowOp {
   double* o;         // LDS output element of the row (same leading dimension)
   int op;
 };
+// A thread's slice of the FIRST pass of gemv_rows (rows [0, SW_T)): row i, K range [k0, k1).  One definition for the pass
+// itself and for rows_prefetch, which loads the slice's matrix elements into registers before the vectors exist.
+constexpr int SW_GRP = 8;    // loads a thread keeps in flight in the streaming part of a pass
+constexpr int SW_PRE = 24;   // prefetched elements per thread and pass (K <= 48 with two K partitions, <= 96 with four)
+struct Pre { double v[SW_PRE]; };
+struct RowSlice { int i, part, P, M, M64, k0, k1; bool act; RowOp ro; };
 template <class F>
-__device__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s_p) {
+__device__ __forceinline__ RowSlice rows_slice(int Mtot, int r0, F rowop) {
+  RowSlice sl;
   const int tid = threadIdx.x;
-  for (int r0 = 0; r0 < Mtot || r0 == 0; r0 += SW_T) {
-    const int M = min(Mtot - r0, SW_T);
-    const int M64 = max(64, (M + 63) & ~63);
-    const int P = M64 <= 64 ? 4 : (M64 <= 128 ? 2 : 1);
-    const int i = P == 1 ? tid : tid % M64, part = P == 1 ? 0 : tid / M64;
-    double acc[SW_NR] = {0., 0., 0., 0.};
-    RowOp ro{};
-    if (i < M && part < P) {
-      ro = rowop(r0 + i);
-      const int Kc = (ro.K + P - 1) / P;
-      const int k0 = part * Kc, k1 = min(ro.K, k0 + Kc);
-#pragma unroll 16
-      for (int k = k0; k < k1; k++) {
-        const double t = hssk_gload(ro.a, (size_t)k * ro.lda);
+  sl.M = min(Mtot - r0, SW_T);
+  sl.M64 = max(64, (sl.M + 63) & ~63);
+  sl.P = sl.M64 <= 64 ? 4 : (sl.M64 <= 128 ? 2 : 1);
+  sl.i = sl.P == 1 ? tid : tid % sl.M64;
+  sl.part = sl.P == 1 ? 0 : tid / sl.M64;
+  sl.act = sl.i < sl.M && sl.part < sl.P;
+  sl.ro = RowOp{};
+  sl.k0 = sl.k1 = 0;
+  if (sl.act) {
+    sl.ro = rowop(r0 + sl.i);
+    const int Kc = (sl.ro.K + sl.P - 1) / sl.P;
+    sl.k0 = sl.part * Kc;
+    sl.k1 = min(sl.ro.K, sl.k0 + Kc);
+  }
+  return sl;
+}
+template <class F>
+__device__ __forceinline__ void rows_prefetch(int Mtot, F rowop, Pre& pre) {
+  const RowSlice sl = rows_slice(Mtot, 0, rowop);
 #pragma unroll
-        for (int c = 0; c < SW_NR; c++) acc[c] += t * ro.x[k + c * SW_MAX];
+  for (int u = 0; u < SW_PRE; u++) pre.v[u] = (sl.act && sl.k0 + u < sl.k1) ? hssk_gload(sl.ro.a, (size_t)(sl.k0 + u) * sl.ro.lda) : 0.;
+}
+template <int NR, class F>
+__device__ __forceinline__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s_p, const Pre& pre, bool use_pre) {
+  for (int r0 = 0; r0 < Mtot || r0 == 0; r0 += SW_T) {
+    const RowSlice sl = rows_slice(Mtot, r0, rowop);
+    const int M = sl.M, M64 = sl.M64, P = sl.P, i = sl.i, part = sl.part;
+    const RowOp ro = sl.ro;
+    double acc[NR] = {};
+    if (sl.act) {
+      int k = sl.k0;
+      if (use_pre && r0 == 0) {   // the first SW_PRE elements of the slice are already in registers (same order of summation)
+#pragma unroll
+        for (int u = 0; u < SW_PRE; u++) {
+          if (sl.k0 + u < sl.k1) {
+            const double t = pre.v[u];
+#pragma unroll
+            for (int c = 0; c < NR; c++) acc[c] += t * ro.x[sl.k0 + u + c * SW_MAX];
+          }
+        }
+        k = min(sl.k1, sl.k0 + SW_PRE);
+      }
+      // the rest in groups of SW_GRP predicated loads, all in flight together (a unrolled-by-n loop leaves up to n - 1
+      // iterations to a remainder loop that waits out one memory round trip per element)
+      for (; k < sl.k1; k += SW_GRP) {
+        double t[SW_GRP];
+#pragma unroll
+        for (int u = 0; u < SW_GRP; u++) t[u] = k + u < sl.k1 ? hssk_gload(ro.a, (size_t)(k + u) * ro.lda) : 0.;
+#pragma unroll
+        for (int u = 0; u < SW_GRP; u++) {
+          const int kk = min(k + u, sl.k1 - 1);
+#pragma unroll
+          for (int c = 0; c < NR; c++) acc[c] += t[u] * ro.x[kk + c * SW_MAX];
+        }
       }
     }
     if (P == 1) {
@@ -105,23 +150,33 @@ __device__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s_p) {
       __syncthreads();
       continue;
     }
-    // partials: s_p[(part * SW_NR + c) * M64 + i]   (P * M64 == 256)
+    // partials: s_p[(part * NR + c) * M64 + i]   (P * M64 == 256)
     if (part < P)
-      for (int c = 0; c < nrhs; c++) s_p[(part * SW_NR + c) * M64 + i] = acc[c];
+      for (int c = 0; c < nrhs; c++) s_p[(part * NR + c) * M64 + i] = acc[c];
     __syncthreads();
     if (part == 0 && i < M)
       for (int c = 0; c < nrhs; c++) {
         double v = 0.;
-        for (int q = 0; q < P; q++) v += s_p[(q * SW_NR + c) * M64 + i];
+        for (int q = 0; q < P; q++) v += s_p[(q * NR + c) * M64 + i];
         apply_op(ro.o + c * SW_MAX, v, ro.op);
       }
     __syncthreads();
   }
 }
 // out[i] (op)= sum_{k < K} A[i + k lda] x[k],  i < M
-__device__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
-                       double* s_p) {
-  gemv_rows(M, [=](int i) { return RowOp{A + i, lda, K, x, out + i, op}; }, nrhs, s_p);
+template <int NR>
+__device__ __forceinline__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
+                                       double* s_p, const Pre& pre, bool use_pre) {
+  gemv_rows<NR>(M, [=](int i) { return RowOp{A + i, lda, K, x, out + i, op}; }, nrhs, s_p, pre, use_pre);
+}
+template <int NR>
+__device__ __forceinline__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
+                                       double* s_p) {
+  Pre none;
+  gemv_n<NR>(A, lda, M, K, x, out, nrhs, op, s_p, none, false);
+}
+__device__ __forceinline__ void gemv_n_prefetch(const double* __restrict__ A, int lda, int M, int K, Pre& pre) {
+  rows_prefetch(M, [=](int i) { return RowOp{A + i, lda, K, nullptr, nullptr, 0}; }, pre);
 }
 
 // pull `count` doubles at p towards this XCD's L2 (one load per 128-byte line) while the workgroup still waits for its
@@ -137,21 +192,49 @@ __device__ __forceinline__ void keep(double sink, double* s_p) {
 // out[j] (op)= sum_{i < K} A[i + j lda] x[i],  j < N: columns contiguous.  Four adjacent lanes share a column (each
 // a contiguous quarter of it: whole cache lines per lane), 64 columns per pass; quad reduction by shuffles.
 // Contains wave collectives and a barrier: every thread must call.  x and out must not alias.
-__device__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op) {
+// the thread's slice of the first pass (columns [0, 64)) of gemv_t, loaded ahead
+__device__ __forceinline__ void gemv_t_prefetch(const double* __restrict__ A, int lda, int K, int N, Pre& pre) {
+  const int tid = threadIdx.x;
+  const int part = tid & 3, j = tid >> 2;
+  const int Kc = (K + 3) >> 2;
+  const int i0 = part * Kc, i1 = min(K, i0 + Kc);
+#pragma unroll
+  for (int u = 0; u < SW_PRE; u++) pre.v[u] = (j < N && i0 + u < i1) ? hssk_gload(A + (size_t)j * lda, (size_t)(i0 + u)) : 0.;
+}
+template <int NR>
+__device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op,
+                                       const Pre& pre, bool use_pre) {
   const int tid = threadIdx.x;
   const int part = tid & 3, cj = tid >> 2;
   const int Kc = (K + 3) >> 2;
   const int i0 = part * Kc, i1 = min(K, i0 + Kc);
   for (int j0 = 0; j0 < N; j0 += SW_T / 4) {
     const int j = j0 + cj;
-    double acc[SW_NR] = {0., 0., 0., 0.};
+    double acc[NR] = {};
     if (j < N) {
       const double* a = A + (size_t)j * lda;
-#pragma unroll 16
-      for (int i = i0; i < i1; i++) {
-        const double t = hssk_gload(a, i);
+      int i = i0;
+      if (use_pre && j0 == 0) {
 #pragma unroll
-        for (int c = 0; c < SW_NR; c++) acc[c] += t * x[i + c * SW_MAX];
+        for (int u = 0; u < SW_PRE; u++) {
+          if (i0 + u < i1) {
+            const double t = pre.v[u];
+#pragma unroll
+            for (int c = 0; c < NR; c++) acc[c] += t * x[i0 + u + c * SW_MAX];
+          }
+        }
+        i = min(i1, i0 + SW_PRE);
+      }
+      for (; i < i1; i += SW_GRP) {
+        double t[SW_GRP];
+#pragma unroll
+        for (int u = 0; u < SW_GRP; u++) t[u] = i + u < i1 ? hssk_gload(a, (size_t)(i + u)) : 0.;
+#pragma unroll
+        for (int u = 0; u < SW_GRP; u++) {
+          const int ii = min(i + u, i1 - 1);
+#pragma unroll
+          for (int c = 0; c < NR; c++) acc[c] += t[u] * x[ii + c * SW_MAX];
+        }
       }
     }
     for (int c = 0; c < nrhs; c++) {
@@ -164,28 +247,36 @@ __device__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, cons
   __syncthreads();
 }
 
+template <int NR>
+__device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op) {
+  Pre none;
+  gemv_t<NR>(A, lda, K, N, x, out, nrhs, op, none, false);
+}
+
 // ---- forward ULV sweep ---------------------------------------------------------------------------------------------
 // Right-hand sides beyond SW_NR: blockIdx.y walks groups of SW_NR columns.  The groups are independent chains through the
 // tree that run side by side (a 2-D grid is dispatched x-fastest, so within a group the index order still holds); each
 // group streams the blocks again, which is what bounds it (nrhs = 64: 16 x the bytes of one group).
+template <int NR>
 __device__ __forceinline__ int rhs_group(int nrhs_total, int& c0) {
-  c0 = (int)blockIdx.y * SW_NR;
-  return min(SW_NR, nrhs_total - c0);
+  c0 = (int)blockIdx.y * NR;
+  return min(NR, nrhs_total - c0);
 }
 
+template <int NR>
 __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
-  HSSK_SHARED double s_f[SW_MAX * SW_NR];    // f, later the block right-hand side of the substitution
-  HSSK_SHARED double s_y[SW_MAX * SW_NR];    // zc(permV[rv:]) first, then y
-  HSSK_SHARED double s_a[SW_MAX * SW_NR];    // stacked children z (inner nodes)
-  HSSK_SHARED double s_t[SW_MAX * SW_NR];    // ft1 (root: block right-hand side)
-  HSSK_SHARED double s_z[SW_MAX * SW_NR];    // z
-  HSSK_SHARED double s_p[SW_T * SW_NR];      // gemv partials
+  HSSK_SHARED double s_f[SW_MAX * NR];    // f, later the block right-hand side of the substitution
+  HSSK_SHARED double s_y[SW_MAX * NR];    // zc(permV[rv:]) first, then y
+  HSSK_SHARED double s_a[SW_MAX * NR];    // stacked children z (inner nodes)
+  HSSK_SHARED double s_t[SW_MAX * NR];    // ft1 (root: block right-hand side)
+  HSSK_SHARED double s_z[SW_MAX * NR];    // z
+  HSSK_SHARED double s_p[SW_T * NR];      // gemv partials
   HSSK_SHARED int s_piv[SW_MAX];
   hssk_sweep_fwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
   int c0;
-  const int nrhs = rhs_group(nrhs_total, c0);
+  const int nrhs = rhs_group<NR>(nrhs_total, c0);
   if (c0) {   // this group's columns of every vector
     p.fsrc += (size_t)c0 * p.ldf;
     if (p.zc) p.zc += (size_t)c0 * p.ldz_in;
@@ -202,20 +293,41 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
     if (tid < m) pu = p.permU[tid];
     if (inner && tid < mv) pv = p.permV[tid];
   }
+  // a node that waits for its children loads ITS OWN slices of the blocks into registers first (every thread knows which
+  // elements its passes below will read): once the vectors arrive, the dependent chain of the node runs on registers and LDS
+  // alone -- with the blocks merely pulled towards L2 every pass still paid an L2 round trip, ~14 us per tree level.
+  const bool zpart = inner && !p.LU && rv > 0;
+  const int mz = (zpart && mv > rv) ? rv : 0;
+  const int rU0 = p.rU0;
+  auto rows1 = [=](int i) {   // f(0:rU0) -= B01 zc(rV0:), f(rU0:) -= B10 zc(0:rV0)  and  z += XV zc(permV[rv:])
+    if (i < rU0) return RowOp{p.B01 + i, max(rU0, 1), p.rV1, s_a + p.rV0, s_f + i, OP_SUB};
+    if (i < m) return RowOp{p.B10 + (i - rU0), max(p.rU1, 1), p.rV0, s_a, s_f + i, OP_SUB};
+    return RowOp{p.XV + (i - m), rv, mv - rv, s_y, s_z + (i - m), OP_ADD};
+  };
+  auto rows4 = [=](int i) {   // ft1 -= WQ y  and  z += Vt0^T y
+    if (i < r) return RowOp{p.WQ + i, r, q, s_y, s_t + i, OP_SUB};
+    return RowOp{p.Vt0T + (i - r), rv, q, s_y, s_z + (i - r), OP_ADD};
+  };
+  const bool pf = inner && !p.LU;
+  Pre pre1, pre2, pre3, pre4;
+  if (pf) {
+    rows_prefetch(m + mz, rows1, pre1);
+    if (q > 0) {
+      if (r > 0) gemv_t_prefetch(p.XU, r, r, q, pre2);
+      gemv_n_prefetch(p.Tinv, SW_NB, min(SW_NB, q), min(SW_NB, q), pre3);
+      rows_prefetch(r + rv, rows4, pre4);
+    }
+  }
   if (p.wait0 >= 0 || p.wait1 >= 0) {
     double sink = 0.;
-    if (inner) { touch(p.B01, (size_t)p.rU0 * p.rV1, sink); touch(p.B10, (size_t)p.rU1 * p.rV0, sink); }
     if (p.LU) {
+      if (inner) { touch(p.B01, (size_t)p.rU0 * p.rV1, sink); touch(p.B10, (size_t)p.rU1 * p.rV0, sink); }
       touch(p.LU, (size_t)m * m, sink);
       touch(p.TinvL, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
       touch(p.TinvU, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
-    } else {
-      if (inner) touch(p.XV, (size_t)rv * (mv - rv), sink);
-      touch(p.XU, (size_t)r * q, sink);
-      touch(p.Tinv, (size_t)((q + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
-      if (q > SW_NB) touch(p.Rlq, (size_t)m * q, sink);
-      touch(p.WQ, (size_t)r * q, sink);
-      touch(p.Vt0T, (size_t)rv * q, sink);
+    } else if (q > SW_NB) {   // (the blocks behind the first 64-row step are not in the register slices)
+      touch(p.Tinv + SW_NB * SW_NB, (size_t)((q - 1) / SW_NB) * SW_NB * SW_NB, sink);
+      touch(p.Rlq, (size_t)m * q, sink);
     }
     keep(sink, s_p);
   }
@@ -228,7 +340,6 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
     for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = sweep_take(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in, err);
   __syncthreads();
   if (inner) {
-    const bool zpart = !p.LU && rv > 0;
     if (zpart) {
       // s_z (= s_t2) <- zc(permV[0:rv]);  s_y <- zc(permV[rv:])
       if (tid < mv)
@@ -240,13 +351,7 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
       __syncthreads();
     }
     // one pass: f(0:rU0) -= B01 zc(rV0:), f(rU0:) -= B10 zc(0:rV0)   and   z += XV zc(permV[rv:])   (XV is rv x (mv - rv))
-    const int mz = (zpart && mv > rv) ? rv : 0;
-    const int rU0 = p.rU0;
-    gemv_rows(m + mz, [=](int i) {
-      if (i < rU0) return RowOp{p.B01 + i, max(rU0, 1), p.rV1, s_a + p.rV0, s_f + i, OP_SUB};
-      if (i < m) return RowOp{p.B10 + (i - rU0), max(p.rU1, 1), p.rV0, s_a, s_f + i, OP_SUB};
-      return RowOp{p.XV + (i - m), rv, mv - rv, s_y, s_z + (i - m), OP_ADD};
-    }, nrhs, s_p);
+    gemv_rows<NR>(m + mz, rows1, nrhs, s_p, pre1, pf);
   }
   if (p.LU) {
     // ---- root: x = U^{-1} L^{-1} P f   (DenseMatrix::solve / getrs, solve.hpp:133-135), block substitution with the
@@ -261,23 +366,23 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
       const int nb = min(SW_NB, m - b0);
       for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
       __syncthreads();
-      gemv_n(p.TinvL + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
+      gemv_n<NR>(p.TinvL + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
       const int rest = m - b0 - nb;
       if (rest > 0) {
         for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
         __syncthreads();
-        gemv_n(p.LU + (b0 + nb) + (size_t)b0 * m, m, rest, nb, s_t, s_f + b0 + nb, nrhs, OP_SUB, s_p);
+        gemv_n<NR>(p.LU + (b0 + nb) + (size_t)b0 * m, m, rest, nb, s_t, s_f + b0 + nb, nrhs, OP_SUB, s_p);
       }
     }
     for (int blk = (m - 1) / SW_NB; blk >= 0; blk--) {
       const int b0 = blk * SW_NB, nb = min(SW_NB, m - b0);
       for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
       __syncthreads();
-      gemv_n(p.TinvU + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
+      gemv_n<NR>(p.TinvU + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
       if (b0 > 0) {
         for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
         __syncthreads();
-        gemv_n(p.LU + (size_t)b0 * m, m, b0, nb, s_t, s_f, nrhs, OP_SUB, s_p);
+        gemv_n<NR>(p.LU + (size_t)b0 * m, m, b0, nb, s_t, s_f, nrhs, OP_SUB, s_p);
       }
     }
     for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.xroot, (e % m) + (size_t)(e / m) * p.ldxr, s_f[(e % m) + (e / m) * SW_MAX]);
@@ -295,42 +400,40 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
   __syncthreads();
   if (q > 0) {
     // ---- y -= X^T ft1   (X is r x q, column k contiguous)
-    if (r > 0) gemv_t(p.XU, r, r, q, s_t, s_y, nrhs, OP_SUB);
+    if (r > 0) gemv_t<NR>(p.XU, r, r, q, s_t, s_y, nrhs, OP_SUB, pre2, pf);
     // ---- y <- R~^{-T} y on 64-row blocks: y_b = Linv_b y_b, then rows below -= R~(b, below)^T y_b
     for (int b0 = 0, blk = 0; b0 < q; b0 += SW_NB, blk++) {
       const int nb = min(SW_NB, q - b0);
       for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * SW_MAX] = s_y[b0 + (e % nb) + (e / nb) * SW_MAX];
       __syncthreads();
-      gemv_n(p.Tinv + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_f, s_y + b0, nrhs, OP_SET, s_p);
+      gemv_n<NR>(p.Tinv + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_f, s_y + b0, nrhs, OP_SET, s_p, pre3, pf && blk == 0);
       const int rest = q - b0 - nb;
       if (rest > 0) {
         // column k of R~ (rows b0 .. b0+nb contiguous) for k > b0 + nb;  x = y_b (now final) copied to s_f
         for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * SW_MAX] = s_y[b0 + (e % nb) + (e / nb) * SW_MAX];
         __syncthreads();
-        gemv_t(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
+        gemv_t<NR>(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
       }
     }
     for (int e = tid; e < q * nrhs; e += SW_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * SW_MAX]);
     // ---- one pass over [WQ; Vt0^T] (both (.) x q, rows contiguous):  ft1 -= WQ y   and   z += Vt0^T y
-    gemv_rows(r + rv, [=](int i) {
-      if (i < r) return RowOp{p.WQ + i, r, q, s_y, s_t + i, OP_SUB};
-      return RowOp{p.Vt0T + (i - r), rv, q, s_y, s_z + (i - r), OP_ADD};
-    }, nrhs, s_p);
+    gemv_rows<NR>(r + rv, rows4, nrhs, s_p, pre4, pf);
   }
   for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * SW_MAX]);
   for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * SW_MAX]);
 }
 
 // ---- backward ULV sweep:  x_c = Q~(:, 0:q) y + Q~(:, q:) xpart ; m == r (nothing eliminated): x_c = xpart ------------
+template <int NR>
 __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err) {
-  HSSK_SHARED double s_v[SW_MAX * SW_NR];   // [y; xpart]
-  HSSK_SHARED double s_o[SW_MAX * SW_NR];
-  HSSK_SHARED double s_p[SW_T * SW_NR];
+  HSSK_SHARED double s_v[SW_MAX * NR];   // [y; xpart]
+  HSSK_SHARED double s_o[SW_MAX * NR];
+  HSSK_SHARED double s_p[SW_T * NR];
   hssk_sweep_bwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r;
   int c0;
-  const int nrhs = rhs_group(nrhs_total, c0);
+  const int nrhs = rhs_group<NR>(nrhs_total, c0);
   if (c0) {
     if (p.y) p.y += (size_t)c0 * q;
     p.xpart += (size_t)c0 * p.ldx;
@@ -339,14 +442,18 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
   // the parent-independent part first: s_o = Q~(:, 0:q) y; Q~(:, q:) towards L2
   for (int e = tid; e < q * nrhs; e += SW_T) s_v[(e % q) + (e / q) * SW_MAX] = hssk_gload(p.y, (e % q) + (size_t)(e / q) * q);
   __syncthreads();
+  // (this thread's slice of Q~(:, q:) goes to registers before anything else: it is consumed after the wait)
+  const bool pf = q > 0 && r > 0 && p.wait0 >= 0;
+  Pre pre;
+  if (pf) gemv_n_prefetch(p.Qt + (size_t)q * m, m, m, r, pre);
   if (q > 0) {
-    gemv_n(p.Qt, m, m, q, s_v, s_o, nrhs, OP_SET, s_p);
-    if (p.wait0 >= 0) { double sink = 0.; touch(p.Qt + (size_t)q * m, (size_t)m * r, sink); keep(sink, s_p); }
+    gemv_n<NR>(p.Qt, m, m, q, s_v, s_o, nrhs, OP_SET, s_p);
+    if (p.wait0 >= 0 && r > SW_PRE) { double sink = 0.; touch(p.Qt + (size_t)q * m, (size_t)m * r, sink); keep(sink, s_p); }
   }
   for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = sweep_take(p.xpart, (e % r) + (size_t)(e / r) * p.ldx, err);
   __syncthreads();
   if (q > 0) {
-    if (r > 0) gemv_n(p.Qt + (size_t)q * m, m, m, r, s_v + q, s_o, nrhs, OP_ADD, s_p);
+    if (r > 0) gemv_n<NR>(p.Qt + (size_t)q * m, m, m, r, s_v + q, s_o, nrhs, OP_ADD, s_p, pre, pf);
     for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_o[(e % m) + (e / m) * SW_MAX]);
   } else {
     for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * SW_MAX]);
@@ -354,15 +461,16 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
 }
 
 // ---- mat-vec: up-sweep nodes [0, nup) then down-sweep nodes [nup, nup + ndown) in one launch -------------------------------
+template <int NR>
 __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
                                                            const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err) {
-  HSSK_SHARED double s_x[SW_MAX * SW_NR];
-  HSSK_SHARED double s_g[SW_MAX * SW_NR];
-  HSSK_SHARED double s_o[SW_MAX * SW_NR];
-  HSSK_SHARED double s_p[SW_T * SW_NR];
+  HSSK_SHARED double s_x[SW_MAX * NR];
+  HSSK_SHARED double s_g[SW_MAX * NR];
+  HSSK_SHARED double s_o[SW_MAX * NR];
+  HSSK_SHARED double s_p[SW_T * NR];
   const int tid = threadIdx.x;
   int c0;
-  const int nrhs = rhs_group(nrhs_total, c0);
+  const int nrhs = rhs_group<NR>(nrhs_total, c0);
   if ((int)blockIdx.x < nup) {
     // tmp1 = V^H src = src(perm[0:r]) + X src(perm[r:])   (X is r x (m - r), rows contiguous)
     hssk_apply_up_desc p = ups[blockIdx.x];
@@ -370,8 +478,10 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
     p.dst += (size_t)c0 * p.ldd;
     const int m = p.m, r = p.r;
     const int pk = tid < m ? p.perm[tid] : 0;
-    if (p.wait0 >= 0 || p.wait1 >= 0) { double sink = 0.; touch(p.X, (size_t)r * (m - r), sink); keep(sink, s_p); }
     const bool handed = p.inner != 0;   // inner node: the children's results; leaf: rows of x
+    const bool pf = handed && m > r && r > 0;   // (slices of the node's blocks to registers before the wait, see the solve sweeps)
+    Pre pre;
+    if (pf) gemv_n_prefetch(p.X, r, r, m - r, pre);
     if (tid < m)
       for (int c = 0; c < nrhs; c++) {
         const double v = handed ? sweep_take(p.src, pk + (size_t)c * p.lds, err) : hssk_gload(p.src, pk + (size_t)c * p.lds);
@@ -379,7 +489,7 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
         else s_g[(tid - r) + c * SW_MAX] = v;
       }
     __syncthreads();
-    if (m > r && r > 0) gemv_n(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p);
+    if (m > r && r > 0) gemv_n<NR>(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p, pre, pf);
     for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
     return;
   }
@@ -393,46 +503,50 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
   const int mo = p.mo, ro = p.ro;
   const bool expand = p.tmp2 && ro > 0;
   const int pk = (expand && tid < mo) ? p.perm[tid] : 0;
+  // (slices of the blocks that are consumed after a wait go to registers first, see the solve sweeps)
+  Pre preX;
+  const bool pfX = expand && mo > ro && p.wait0 >= 0;
+  if (pfX) gemv_t_prefetch(p.X, ro, ro, mo - ro, preX);
   if (p.D) {
     // ---- leaf: y = op(D) x + beta y + U tmp2.  op(D) x does not depend on the tree: it runs before the wait.
     const int m = p.m;
     for (int e = tid; e < m * nrhs; e += SW_T) s_x[(e % m) + (e / m) * SW_MAX] = hssk_gload(p.x, (e % m) + (size_t)(e / m) * p.ldx);
     __syncthreads();
-    if (p.trans) gemv_t(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
-    else gemv_n(p.D, m, m, m, s_x, s_o, nrhs, OP_SET, s_p);
+    if (p.trans) gemv_t<NR>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
+    else gemv_n<NR>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET, s_p);
     if (p.beta != 0.) {
       for (int e = tid; e < m * nrhs; e += SW_T) s_o[(e % m) + (e / m) * SW_MAX] += p.beta * hssk_gload(p.out, (e % m) + (size_t)(e / m) * p.ldo);
       __syncthreads();
     }
   } else {
     // ---- inner: t = [B01 t1_1; B10 t1_0]  (transposed: [B10^T t1_1; B01^T t1_0]); t1 = the children's up-sweep results
-    {
-      double sink = 0.;
-      touch(p.B01, (size_t)(p.trans ? p.ri_a * p.ro_b : p.ro_a * p.ri_b), sink);
-      touch(p.B10, (size_t)(p.trans ? p.ri_b * p.ro_a : p.ro_b * p.ri_a), sink);
-      keep(sink, s_p);
-    }
     const int nt1 = p.ri_a + p.ri_b, nto = p.ro_a + p.ro_b;
+    const int ro_a = p.ro_a;
+    auto rowsB = [=](int i) {   // B01 is ro_a x ri_b, B10 is ro_b x ri_a: one pass over the stacked rows
+      if (i < ro_a) return RowOp{p.B01 + i, max(ro_a, 1), p.ri_b, s_x + p.ri_a, s_o + i, OP_SET};
+      return RowOp{p.B10 + (i - ro_a), max(p.ro_b, 1), p.ri_a, s_x, s_o + i, OP_SET};
+    };
+    Pre preB, preB2;
+    if (!p.trans) rows_prefetch(nto, rowsB, preB);
+    else {
+      if (p.ro_a > 0 && p.ri_b > 0) gemv_t_prefetch(p.B10, p.ri_b, p.ri_b, p.ro_a, preB);
+      if (p.ro_b > 0 && p.ri_a > 0) gemv_t_prefetch(p.B01, p.ri_a, p.ri_a, p.ro_b, preB2);
+    }
     for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = sweep_take(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1, err);
     for (int e = tid; e < nto * nrhs; e += SW_T) s_o[(e % nto) + (e / nto) * SW_MAX] = 0.;
     __syncthreads();
-    if (!p.trans) {   // B01 is ro_a x ri_b, B10 is ro_b x ri_a: one pass over the stacked rows
-      const int ro_a = p.ro_a;
-      gemv_rows(nto, [=](int i) {
-        if (i < ro_a) return RowOp{p.B01 + i, max(ro_a, 1), p.ri_b, s_x + p.ri_a, s_o + i, OP_SET};
-        return RowOp{p.B10 + (i - ro_a), max(p.ro_b, 1), p.ri_a, s_x, s_o + i, OP_SET};
-      }, nrhs, s_p);
-    } else {          // B10 is ri_b x ro_a, B01 is ri_a x ro_b
-      if (p.ro_a > 0 && p.ri_b > 0) gemv_t(p.B10, p.ri_b, p.ri_b, p.ro_a, s_x + p.ri_a, s_o, nrhs, OP_SET);
-      if (p.ro_b > 0 && p.ri_a > 0) gemv_t(p.B01, p.ri_a, p.ri_a, p.ro_b, s_x, s_o + p.ro_a, nrhs, OP_SET);
+    if (!p.trans) gemv_rows<NR>(nto, rowsB, nrhs, s_p, preB, true);
+    else {            // B10 is ri_b x ro_a, B01 is ri_a x ro_b
+      if (p.ro_a > 0 && p.ri_b > 0) gemv_t<NR>(p.B10, p.ri_b, p.ri_b, p.ro_a, s_x + p.ri_a, s_o, nrhs, OP_SET, preB, true);
+      if (p.ro_b > 0 && p.ri_a > 0) gemv_t<NR>(p.B01, p.ri_a, p.ri_a, p.ro_b, s_x, s_o + p.ro_a, nrhs, OP_SET, preB2, true);
     }
   }
   // ---- + U tmp2:  out(perm[k]) += tmp2(k), k < ro ;  out(perm[ro + j]) += sum_k X(k, j) tmp2(k)   (X is ro x (mo - ro))
   if (expand) {
-    if (p.wait0 >= 0) { double sink = 0.; touch(p.X, (size_t)ro * (mo - ro), sink); keep(sink, s_p); }
+    if (p.wait0 >= 0 && mo - ro > SW_T / 4) { double sink = 0.; touch(p.X, (size_t)ro * (mo - ro), sink); keep(sink, s_p); }
     for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = sweep_take(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2, err);
     __syncthreads();
-    if (mo > ro) gemv_t(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET);
+    if (mo > ro) gemv_t<NR>(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET, preX, pfX);
     if (tid < mo)
       for (int c = 0; c < nrhs; c++) s_o[pk + c * SW_MAX] += tid < ro ? s_x[tid + c * SW_MAX] : s_g[(tid - ro) + c * SW_MAX];
     __syncthreads();
@@ -518,7 +632,9 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) return 2;
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(ulv_fwd_sweep_kernel, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
+  if (nrhs == 1) HSSK_LAUNCH(ulv_fwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(ulv_fwd_sweep_kernel<SW_NR>, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -530,7 +646,8 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) return 2;
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  HSSK_LAUNCH(ulv_bwd_sweep_kernel, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  if (nrhs == 1) HSSK_LAUNCH(ulv_bwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -549,8 +666,9 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   }
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
-  HSSK_LAUNCH(apply_sweep_kernel, dim3((unsigned)(nup + ndown), (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, du, nup,
-              dn, nrhs, sweep_err(ctx));
+  if (nrhs == 1) HSSK_LAUNCH(apply_sweep_kernel<1>, dim3((unsigned)(nup + ndown), 1u), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(apply_sweep_kernel<SW_NR>, dim3((unsigned)(nup + ndown), (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, du, nup,
+                   dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
