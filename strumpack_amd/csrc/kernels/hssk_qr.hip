@@ -218,11 +218,12 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
 }
 
 // Q(:, j0 : j0 + 4 NW CT) = H_0 ... H_{kmax-1} I(:, same columns): every 16-lane group owns CT columns in registers (same
-// layout as above) and applies the reflectors (read from the factored panel, L1/L2 hits) on its own -- no LDS, no
-// barriers.  H_k leaves column j untouched for k > j, so the sweep starts at the last column of the block.
+// layout as above) and applies the reflectors, which the workgroup stages through LDS in chunks (see the kernel).  H_k
+// leaves column j untouched for k > j, so the sweep starts at the last column of the block.
 struct QBlock {
   int prob, block;
 };
+constexpr int FQ_KC = 16;   // reflectors staged in LDS at a time (formq_reg_kernel)
 template <int RT, int CT, int NW>
 __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void formq_reg_kernel(const hssk_qr_desc* __restrict__ descs,
                                                                                        const QBlock* __restrict__ work) {
@@ -243,41 +244,72 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void formq_reg
     for (int r = 0; r < RT; r++) a[c][r] = (l16 + 16 * r == j0 + grp + NC * c) ? 1. : 0.;
   int kstart = j0 + NC * CT - 1;
   if (kstart > kmax - 1) kstart = kmax - 1;
-  // reflector k-1 is fetched (L2) while reflector k is applied
-  double vn[RT], taun = 0.;
-  auto fetch = [&](int k) {
-    taun = k >= 0 ? taus[k] : 0.;
+  // The reflectors come through LDS, FQ_KC at a time: the workgroup loads a chunk once, coalesced, one chunk ahead of its
+  // use (registers -> LDS behind a barrier per chunk), and every lane reads its rows of the current reflector from there.
+  // (The first version had each of the 4 NW lane groups fetch every reflector from global memory itself, one step ahead:
+  // 4 NW times the traffic through the vector L1 and a step that could not be shorter than one L2 / HBM round trip --
+  // 1.75 us per reflector on the 195 x 195 leaf blocks of N = 1e5, 1.1 ms for the level.)
+  constexpr int VL = 16 * RT;                       // padded reflector length
+  constexpr int NL = (FQ_KC * VL + NW * 64 - 1) / (NW * 64);   // chunk elements per thread
+  HSSK_SHARED double s_v[2 * FQ_KC * VL];
+  HSSK_SHARED double s_tau[2 * FQ_KC];
+  const int tid = threadIdx.x;
+  const int nchunk = kstart >= 0 ? kstart / FQ_KC + 1 : 0;   // chunk ch covers k = kstart - ch FQ_KC - kk, kk < FQ_KC
+  double stage[NL];
+  double stage_tau = 0.;
+  auto fetch = [&](int ch) {
 #pragma unroll
-    for (int r = 0; r < RT; r++) {
-      const int row = l16 + 16 * r;
-      vn[r] = (k >= 0 && row > k && row < rows) ? A[row + (size_t)k * p.lda] : (row == k ? 1. : 0.);
+    for (int u = 0; u < NL; u++) {
+      const int e = tid + u * NW * 64, kk = e / VL, row = e % VL;
+      const int k = kstart - ch * FQ_KC - kk;
+      double v = 0.;
+      if (e < FQ_KC * VL && k >= 0) v = (row > k && row < rows) ? hssk_gload(A, (size_t)row + (size_t)k * p.lda) : (row == k ? 1. : 0.);
+      stage[u] = v;
     }
+    if (tid < FQ_KC) { const int k = kstart - ch * FQ_KC - tid; stage_tau = k >= 0 ? taus[k] : 0.; }
   };
-  fetch(kstart);
-  for (int k = kstart; k >= 0; k--) {
-    const double tau = taun;
-    double vr[RT];
+  auto commit = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < RT; r++) vr[r] = vn[r];
-    fetch(k - 1);
-    if (tau == 0.) continue;
-    double dot[CT];
-#pragma unroll
-    for (int c = 0; c < CT; c++) {
-      double d0 = 0., d1 = 0.;
-#pragma unroll
-      for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
-      if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
-      dot[c] = d0 + d1;
+    for (int u = 0; u < NL; u++) {
+      const int e = tid + u * NW * 64;
+      if (e < FQ_KC * VL) s_v[buf * FQ_KC * VL + e] = stage[u];
     }
-    hssk_row_sum_n(dot);
+    if (tid < FQ_KC) s_tau[buf * FQ_KC + tid] = stage_tau;
+  };
+  if (nchunk > 0) { fetch(0); commit(0); }
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ch++) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) fetch(ch + 1);
+    for (int kk = 0; kk < FQ_KC; kk++) {
+      const int k = kstart - ch * FQ_KC - kk;
+      if (k < 0) break;
+      const double tau = s_tau[buf * FQ_KC + kk];
+      if (tau == 0.) continue;
+      const double* sv = s_v + (buf * FQ_KC + kk) * VL;
+      double vr[RT];
 #pragma unroll
-    for (int c = 0; c < CT; c++) {
-      const int col = j0 + grp + NC * c;
-      const double f = (col >= k && col < nq) ? dot[c] * tau : 0.;
+      for (int r = 0; r < RT; r++) vr[r] = sv[l16 + 16 * r];
+      double dot[CT];
 #pragma unroll
-      for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
+      for (int c = 0; c < CT; c++) {
+        double d0 = 0., d1 = 0.;
+#pragma unroll
+        for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
+        if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
+        dot[c] = d0 + d1;
+      }
+      hssk_row_sum_n(dot);
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int col = j0 + grp + NC * c;
+        const double f = (col >= k && col < nq) ? dot[c] * tau : 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
+      }
     }
+    if (ch + 1 < nchunk) commit(buf ^ 1);   // (the other buffer was last read in the previous chunk, before its closing barrier)
+    __syncthreads();
   }
 #pragma unroll
   for (int c = 0; c < CT; c++)
