@@ -71,14 +71,11 @@ __global__ __launch_bounds__(TR_THREADS) void trsm_kernel(const hssk_trsm_desc* 
 
 constexpr int LU_THREADS = 256;
 
-__global__ __launch_bounds__(LU_THREADS) void getrf_kernel(const hssk_lu_desc* __restrict__ descs) {
-  HSSK_SHARED double s_val[LU_THREADS / 64];
-  HSSK_SHARED int s_idx[LU_THREADS / 64];
-  HSSK_SHARED int s_piv;
-  const hssk_lu_desc p = descs[blockIdx.x];
+// One workgroup per matrix, partial pivoting (first arg max), right-looking.  W / ld: the array the steps work on -- the
+// matrix itself, or its image in LDS (getrf_lds_kernel: n <= LU_LDS_N; the six barrier-separated stages of a step then
+// wait on LDS instead of L2: the 82 x 82 root of N = 1e5 took 167 us in global memory).
+__device__ __forceinline__ int getrf_body(double* __restrict__ A, int ld, int n, int* __restrict__ piv, double* s_val, int* s_idx, int* s_piv) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = p.n, ld = p.lda;
-  double* __restrict__ A = p.A;
   int info = 0;
   for (int k = 0; k < n; k++) {
     // pivot: first arg max_{i >= k} |A(i, k)|
@@ -101,11 +98,11 @@ __global__ __launch_bounds__(LU_THREADS) void getrf_kernel(const hssk_lu_desc* _
       int ix = s_idx[0];
       for (int w = 1; w < LU_THREADS / 64; w++)
         if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
-      s_piv = ix;
-      p.piv[k] = ix;
+      *s_piv = ix;
+      piv[k] = ix;
     }
     __syncthreads();
-    const int pv = s_piv;
+    const int pv = *s_piv;
     if (pv != k)
       for (int j = tid; j < n; j += LU_THREADS) {
         double a = A[k + (size_t)j * ld], b = A[pv + (size_t)j * ld];
@@ -132,6 +129,29 @@ __global__ __launch_bounds__(LU_THREADS) void getrf_kernel(const hssk_lu_desc* _
     }
     __syncthreads();
   }
+  return info;
+}
+__global__ __launch_bounds__(LU_THREADS) void getrf_kernel(const hssk_lu_desc* __restrict__ descs) {
+  HSSK_SHARED double s_val[LU_THREADS / 64];
+  HSSK_SHARED int s_idx[LU_THREADS / 64];
+  HSSK_SHARED int s_piv;
+  const hssk_lu_desc p = descs[blockIdx.x];
+  const int info = getrf_body(p.A, p.lda, p.n, p.piv, s_val, s_idx, &s_piv);
+  if (threadIdx.x == 0) *p.info = info;
+}
+constexpr int LU_LDS_N = 128;
+__global__ __launch_bounds__(LU_THREADS) void getrf_lds_kernel(const hssk_lu_desc* __restrict__ descs) {
+  HSSK_SHARED double s_A[LU_LDS_N * (LU_LDS_N + 1)];
+  HSSK_SHARED double s_val[LU_THREADS / 64];
+  HSSK_SHARED int s_idx[LU_THREADS / 64];
+  HSSK_SHARED int s_piv;
+  const hssk_lu_desc p = descs[blockIdx.x];
+  const int n = p.n, lds = n | 1, tid = threadIdx.x;
+  for (int e = tid; e < n * n; e += LU_THREADS) s_A[(e % n) + (e / n) * lds] = p.A[(e % n) + (size_t)(e / n) * p.lda];
+  __syncthreads();
+  const int info = getrf_body(s_A, lds, n, p.piv, s_val, s_idx, &s_piv);
+  __syncthreads();
+  for (int e = tid; e < n * n; e += LU_THREADS) p.A[(e % n) + (size_t)(e / n) * p.lda] = s_A[(e % n) + (e / n) * lds];
   if (tid == 0) *p.info = info;
 }
 
@@ -285,7 +305,8 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   int nmax = 0;
   for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
   if (nmax <= 384) {
-    HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+    if (nmax <= LU_LDS_N) HSSK_LAUNCH(getrf_lds_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+    else HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
   } else {
     std::vector<hssk_trsm_desc> tr;
     std::vector<hssk_gemm_desc> gm;
