@@ -708,7 +708,19 @@ void DeviceHSS::exchange_cut_compress(int dtot) {
     }
   }
   allgather_ints(idx, 2 * rmax);
-  int* didx = work_->ints(2 * (size_t)rmax * G + rmax);
+  // the exchange buffers are carved once per compression attempt and reused by the adaptive rounds (every round re-sends
+  // the panels of all samples and re-points the remote cut nodes, so nothing of the previous round is read again); a round
+  // that needs more room -- the ranks grew -- carves a larger pair
+  const size_t need_idx = 2 * (size_t)rmax * G + rmax, need_buf = 4 * (size_t)dcap_ * rmax * G;
+  if (cut_gen_ != attempt_ || need_idx > cut_idx_cap_ || need_buf > cut_buf_cap_) {
+    const bool grow = cut_gen_ == attempt_;   // (a new attempt starts from a reset arena: the old pair is gone)
+    cut_gen_ = attempt_;
+    cut_idx_cap_ = std::max(need_idx, grow ? 2 * cut_idx_cap_ : size_t(0));
+    cut_buf_cap_ = std::max(need_buf, grow ? 2 * cut_buf_cap_ : size_t(0));
+    cut_idx_ = work_->ints(cut_idx_cap_);
+    cut_buf_ = work_->dbl(cut_buf_cap_);
+  }
+  int* didx = cut_idx_;
   ck(hssk_memcpy_h2d(ctx_, didx, idx.data(), (long long)(sizeof(int) * idx.size())));
   std::vector<int> iota(rmax);
   for (int i = 0; i < rmax; i++) iota[i] = i;
@@ -716,7 +728,7 @@ void DeviceHSS::exchange_cut_compress(int dtot) {
   ck(hssk_memcpy_h2d(ctx_, diota, iota.data(), (long long)(sizeof(int) * rmax)));
   // panels: [Srt(:, Jr) | Sct(:, Jc) | RrtRed | RctRed], each dcap x rmax, leading dimension dcap
   const size_t pan = (size_t)dcap_ * rmax, blk = 4 * pan;
-  double* buf = work_->dbl(blk * G);
+  double* buf = cut_buf_;
   {
     Node& c = nodes_[cut_nodes_[me]];
     if (c.compressed()) {

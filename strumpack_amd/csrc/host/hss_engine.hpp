@@ -280,6 +280,11 @@ class DeviceHSS {
   double *Srt0_ = nullptr, *Sct0_ = nullptr;   // hard restart: the samples as drawn (the tree levels update Srt_ / Sct_ in place)
   int dcap_ = 0;
   int attempt_ = 0;   // compression attempts so far (sources re-carve their work buffers after a restart)
+  // cut-exchange buffers of the distributed compression (exchange_cut_compress), reused across the rounds of an attempt
+  double* cut_buf_ = nullptr;
+  int* cut_idx_ = nullptr;
+  size_t cut_buf_cap_ = 0, cut_idx_cap_ = 0;
+  int cut_gen_ = -1;
   const int* sj_pat_ = nullptr;   // SJLT pattern of the sample block filled last (device, nnz x N)
   int sj_nnz_ = 0;
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
