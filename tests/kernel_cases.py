@@ -202,8 +202,10 @@ def _lowrank(r, d, m, rank, decay=1e-9):
     return (U * s) @ V
 
 
-def case_id(hk, problems, seed=5):
-    """problems: list of (d, m, rtol, atol, max_rank, numerical_rank or None)"""
+def case_id(hk, problems, seed=5, deferred=False):
+    """problems: list of (d, m, rtol, atol, max_rank, numerical_rank or None).
+    deferred: the panel is read in place from a separate source array (desc.src, left untouched) and X is computed by
+    hssk_id_xsolve_vbatched into a compact array after the ranks have been read back (desc.defer_x)."""
     r = rng(seed)
     descs, keep = [], []
     for (d, m, rtol, atol, mr, nr) in problems:
@@ -211,14 +213,40 @@ def case_id(hk, problems, seed=5):
         ld = d + 2
         Wp = np.zeros((ld, m))
         Wp[:d] = Wm
-        dW = hk.array(Wp)
         dperm, drank, dwork = hk.empty((m,), np.int32), hk.empty((1,), np.int32), hk.empty((3 * m,))
-        keep.append((Wm, dW, dperm, drank))
-        keep.append(dwork)
-        descs.append(K.IdDesc(dW.ptr, ld, d, m, rtol, atol, mr, dperm.ptr, drank.ptr, dwork.ptr))
+        if deferred:
+            lds = d + 5
+            Sp = np.full((lds, m), 7.0)
+            Sp[:d] = Wm
+            dS = hk.array(Sp)
+            dW = hk.array(np.zeros((ld, m)))
+            keep.append((Wm, dW, dperm, drank))
+            keep.append((dwork, dS, Sp))
+            descs.append(K.IdDesc(dW.ptr, ld, d, m, rtol, atol, mr, dperm.ptr, drank.ptr, dwork.ptr, dS.ptr, lds, 1))
+        else:
+            dW = hk.array(Wp)
+            keep.append((Wm, dW, dperm, drank))
+            keep.append(dwork)
+            descs.append(K.IdDesc(dW.ptr, ld, d, m, rtol, atol, mr, dperm.ptr, drank.ptr, dwork.ptr))
     hk.batch("hssk_id_vbatched", descs)
     hk.sync()
-    for (prob, (Wm, dW, dperm, drank)) in zip(problems, keep[0::2]):
+    xs = {}
+    if deferred:
+        dmax, mmax = max(p[0] for p in problems), max(p[1] for p in problems)
+        solved = int(hk.lib.hssk_id_solves_inline(dmax, mmax))
+        xd = []
+        for i, (prob, (Wm, dW, dperm, drank)) in enumerate(zip(problems, keep[0::2])):
+            assert np.array_equal(keep[2 * i + 1][1].get(), keep[2 * i + 1][2]), "the source panel was modified"
+            rank, m = int(drank.get()[0]), prob[1]
+            if rank == 0 or rank == m:
+                continue
+            dX = hk.array(np.full((rank + 1, m - rank), -3.0))
+            xs[i] = dX
+            xd.append(K.XsolveDesc(dW.ptr, prob[0] + 2, rank, m, dX.ptr, rank + 1, solved))
+        if xd:
+            hk.batch("hssk_id_xsolve_vbatched", xd)
+            hk.sync()
+    for i, (prob, (Wm, dW, dperm, drank)) in enumerate(zip(problems, keep[0::2])):
         d, m, rtol, atol, mr, nr = prob
         rank = int(drank.get()[0])
         perm = dperm.get()
@@ -237,7 +265,12 @@ def case_id(hk, problems, seed=5):
         assert abs(rank - rr) <= (1 if rr > 0 else 0), f"rank {rank} vs LAPACK {rr} for {prob}"
         if rank == 0:
             continue
-        X = dW.get()[:rank, rank:]
+        if deferred and i in xs:
+            Xf = xs[i].get()
+            assert np.all(Xf[rank:] == -3.0)
+            X = Xf[:rank]
+        else:
+            X = dW.get()[:rank, rank:]
         # interpolation property: W[:, perm[rank:]] ~= W[:, perm[:rank]] X
         skel = Wm[:, perm[:rank]]
         rest = Wm[:, perm[rank:]]

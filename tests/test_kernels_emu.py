@@ -62,6 +62,8 @@ def test_id(hk):
                     (70, 20, 1e-4, 1e-10, 1000, 4), (8, 1, 1e-4, 1e-10, 1000, None)])
     KC.case_id(hk, [(192, 150, 1e-6, 1e-12, 1000, 18), (130, 100, 1e-6, 1e-12, 1000, 11)], seed=6)   # <3,13>, <3,8>
     KC.case_id(hk, [(200, 70, 1e-6, 1e-12, 1000, 9), (48, 210, 1e-6, 1e-12, 1000, 6)], seed=7)        # <4,8>, fallback
+    KC.case_id(hk, [(192, 150, 1e-6, 1e-12, 1000, 18), (64, 40, 1e-6, 1e-12, 1000, 7), (100, 90, 1e-9, 1e-14, 1000, 80)], seed=9, deferred=True)   # in-place source, deferred X (rank 80: the large-rank branch)
+    KC.case_id(hk, [(48, 260, 1e-6, 1e-12, 1000, 6)], seed=10, deferred=True)   # a batch the in-place kernels take: X is copied
     KC.case_id(hk, [(600, 260, 1e-6, 1e-12, 1000, 40), (520, 300, 1e-8, 1e-12, 25, 60)], seed=8)      # wide (multi-workgroup) path
 
 

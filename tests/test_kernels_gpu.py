@@ -69,6 +69,8 @@ def test_id(hk):
     KC.case_id(hk, [(192, 390, 1e-4, 1e-10, 50000, 40)] * 6 + [(192, 256, 1e-8, 1e-12, 50000, 60)] * 4 +
                [(192, 54, 1e-4, 1e-10, 50000, 30)] * 8 + [(192, 300, 1e-13, 1e-15, 50000, None)], seed=21)
     # wide (multi-workgroup) path: a few large panels
+    KC.case_id(hk, [(192, 195, 1e-4, 1e-10, 50000, 36)] * 5 + [(192, 82, 1e-6, 1e-12, 50000, 40), (100, 90, 1e-9, 1e-14, 1000, 80)], seed=23, deferred=True)
+    KC.case_id(hk, [(48, 260, 1e-6, 1e-12, 1000, 6)], seed=24, deferred=True)
     KC.case_id(hk, [(600, 260, 1e-6, 1e-12, 1000, 40), (1500, 1200, 1e-8, 1e-12, 50000, 500), (900, 1000, 1e-6, 1e-12, 200, 400)], seed=22)
 
 
