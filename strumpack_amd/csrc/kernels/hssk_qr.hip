@@ -12,6 +12,7 @@
 // the trailing update gives one column to each wave, lanes stride the (contiguous) column.
 // Q is accumulated backwards (dorg2r order) in a separate rows x nq buffer.
 // Bound: L2 latency/bandwidth (Level-2 BLAS on an L2-resident panel).
+#include "hssk_backsub.h"
 #include "hssk_device.h"
 #include "hssk_internal.h"
 
@@ -354,7 +355,6 @@ void formq_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, const hssk_qr_desc* descs,
 // ------------------------------------------------------------------------------------------------
 constexpr int QB = 32;
 constexpr int QB_MAXROWS = 512;
-constexpr int QB_LD = QB_MAXROWS + 1;   // odd: lanes that walk along columns hit distinct LDS banks
 
 struct QPanel {
   const double* A;   // factored panel (rows x nb, reflectors below the diagonal)
@@ -366,12 +366,21 @@ struct QPanel {
   int lda, rows, nb, ldv, first;
 };
 
+// MAXR: largest panel height of the batch the LDS image of V is sized for (256 rows: two workgroups per CU).
+// Three stages, each measured on 224-row panels (stamps; before -> after): G = V^T V 32 -> ~10 us (four partial sums per
+// product: a single chain waits out an LDS round trip per term); T 23 -> ~2 us -- T^{-1} is KNOWN, the strict upper
+// triangle of V^T V with 1 / tau on the diagonal, so column j of T is one register back substitution per lane
+// (hssk_backsub64; the dlarft recurrence ran 32 dependent steps on one wave); V T 14 -> ~5 us (four products per pass).
+template <int MAXR>
 __global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ descs) {
-  HSSK_SHARED double s_V[QB * QB_LD];
-  HSSK_SHARED double s_G[QB * QB];
+  constexpr int LDV = MAXR + 1;   // odd: lanes that walk along columns hit distinct LDS banks
+  constexpr int LR = HSSK_BACKSUB_LD;
+  HSSK_SHARED double s_V[QB * LDV];
+  HSSK_SHARED double s_G[QB * LR];   // strict upper triangle of V^T V (order nb <= 32: hssk_backsub64 reads no further)
+  HSSK_SHARED double s_rd[64];
   HSSK_SHARED double s_T[QB * QB];
   const QPanel p = descs[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int rows = p.rows, nb = p.nb;
   if (tid == 0 && p.rdiag) {
     const double pm = nb ? p.rd_panel[0] : 0., pn = nb ? p.rd_panel[1] : 0.;
@@ -385,39 +394,57 @@ __global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ d
   for (int e = tid; e < rows * nb; e += 256) {
     const int i = e % rows, j = e / rows;
     const double v = i < j ? 0. : (i == j ? 1. : hssk_gload(p.A, i + (size_t)j * p.lda));
-    s_V[j * QB_LD + i] = v;
+    s_V[j * LDV + i] = v;
     hssk_gstore(p.Vc, i + (size_t)j * p.ldv, v);
   }
-  for (int e = tid; e < QB * QB; e += 256) s_T[e] = 0.;
+  for (int e = tid; e < QB * LR; e += 256) s_G[e] = 0.;
+  // (tau_i == 0: H_i = I, row and column i of T are zero -- a zero "reciprocal" does that in the back substitution)
+  if (tid < 64) s_rd[tid] = tid < nb ? p.tau[tid] : 0.;
   __syncthreads();
-  // G(a, b) = v_a . v_b for a < b  (v_b is zero above row b)
-  for (int e = tid; e < nb * nb; e += 256) {
-    const int a = e % nb, b = e / nb;
-    if (a < b) {
-      double s = 0.;
-      for (int i = b; i < rows; i++) s += s_V[a * QB_LD + i] * s_V[b * QB_LD + i];
-      s_G[a + b * QB] = s;
+  // G(a, b) = v_a . v_b for a < b  (v_b is zero above row b): pair e of the nb (nb - 1) / 2, four partial sums
+  for (int e = tid; e < nb * (nb - 1) / 2; e += 256) {
+    int b = 1, rem = e;
+    while (rem >= b) { rem -= b; b++; }   // e = b (b - 1) / 2 + a
+    const int a2 = rem;
+    const double* va = s_V + a2 * LDV;
+    const double* vb = s_V + b * LDV;
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+    int i = b;
+    for (; i + 3 < rows; i += 4) {
+      s0 += va[i] * vb[i];
+      s1 += va[i + 1] * vb[i + 1];
+      s2 += va[i + 2] * vb[i + 2];
+      s3 += va[i + 3] * vb[i + 3];
+    }
+    for (; i < rows; i++) s0 += va[i] * vb[i];
+    s_G[a2 + b * LR] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  // T = (striu(G) + diag(1 / tau))^{-1}: lane j of the first wave solves for column j
+  if (tid < 64) {
+    double x[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) x[i] = (i == tid && tid < nb) ? 1. : 0.;
+    hssk_backsub64(x, s_G, s_rd, nb);
+    if (tid < QB) {
+#pragma unroll
+      for (int i = 0; i < QB; i++) s_T[i + tid * QB] = x[i];
     }
   }
   __syncthreads();
-  // dlarft, forward / columnwise:  T(0:i, i) = -tau_i T(0:i, 0:i) (V(:, 0:i)^T v_i),  T(i, i) = tau_i.
-  // Lane l owns row l of T and only ever reads its own row.
-  if (wave == 0 && lane < nb) {
-    for (int i = 0; i < nb; i++) {
-      const double ti = p.tau[i];
-      if (lane < i) {
-        double s = 0.;
-        for (int c = lane; c < i; c++) s += s_T[lane + c * QB] * s_G[c + i * QB];
-        s_T[lane + i * QB] = -ti * s;
-      } else if (lane == i) s_T[lane + i * QB] = ti;
+  // VT = V T: entry (i, j) = sum_{c <= j} V(i, c) T(c, j); four columns j per pass and thread
+  for (int e = tid; e < rows * (QB / 4); e += 256) {
+    const int i = e % rows, j0 = 4 * (e / rows);
+    if (j0 >= nb) continue;
+    double s[4] = {0., 0., 0., 0.};
+    for (int c = 0; c < min(nb, j0 + 4); c++) {
+      const double v = s_V[c * LDV + i];
+#pragma unroll
+      for (int u = 0; u < 4; u++) s[u] += v * s_T[c + (j0 + u) * QB];   // (T is upper triangular: zero for c > j)
     }
-  }
-  __syncthreads();
-  for (int e = tid; e < rows * nb; e += 256) {
-    const int i = e % rows, j = e / rows;
-    double s = 0.;
-    for (int c = 0; c <= j; c++) s += s_V[c * QB_LD + i] * s_T[c + j * QB];
-    hssk_gstore(p.VT, i + (size_t)j * p.ldv, s);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (j0 + u < nb) hssk_gstore(p.VT, i + (size_t)(j0 + u) * p.ldv, s[u]);
   }
 }
 
@@ -555,7 +582,10 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
         }
         gemm_batch(ctx, gVT);
       } else {
-        HSSK_LAUNCH(larft_kernel, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+        int lrmax = 0;
+        for (auto& q : lp) lrmax = std::max(lrmax, q.rows);
+        if (lrmax <= 256) HSSK_LAUNCH(larft_kernel<256>, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+        else HSSK_LAUNCH(larft_kernel<QB_MAXROWS>, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
       }
     }
     gemm_batch(ctx, g1);
