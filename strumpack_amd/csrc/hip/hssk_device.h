@@ -59,6 +59,20 @@ __device__ __forceinline__ double hssk_row_sum(double v) {
   v += hssk_dpp_mov0<0x140, 0xF>(v);  // row_mirror
   return v;
 }
+// first arg max over each 16-lane DPP row: on return every lane of a row holds the largest v of the row and the smallest idx
+// among the lanes that held it (the exchanges are symmetric, so all lanes take the same decisions)
+template <int CTRL>
+__device__ __forceinline__ void hssk_argmax_step(double& v, int& idx) {
+  const double ov = hssk_dpp_mov0<CTRL, 0xF>(v);
+  const int oi = __builtin_amdgcn_update_dpp(0, idx, CTRL, 0xF, 0xF, false);
+  if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
+__device__ __forceinline__ void hssk_row_argmax(double& v, int& idx) {
+  hssk_argmax_step<0xB1>(v, idx);    // quad_perm [1,0,3,2]
+  hssk_argmax_step<0x4E>(v, idx);    // quad_perm [2,3,0,1]
+  hssk_argmax_step<0x141>(v, idx);   // row_half_mirror
+  hssk_argmax_step<0x140>(v, idx);   // row_mirror
+}
 // the same for N independent values, stage by stage: N dependent chains in flight instead of one after the other
 template <int N>
 __device__ __forceinline__ void hssk_row_sum_n(double (&v)[N]) {

@@ -343,14 +343,12 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
         if (lane == 0) { s_val[pb * NW + wave] = wv; s_idx[pb * NW + wave] = wi; }
       }
       __syncthreads();
-      double gv = s_val[pb * NW];
-      int pcol = s_idx[pb * NW];
-#pragma unroll
-      for (int w = 1; w < NW; w++) {
-        const double v = s_val[pb * NW + w];
-        const int ix = s_idx[pb * NW + w];
-        if (v > gv || (v == gv && ix < pcol)) { gv = v; pcol = ix; }
-      }
+      // best of the NW wave candidates: every 16-lane row loads them (lane l takes candidate l mod NW) and reduces on the
+      // DPP network -- four exchange steps instead of a serial scan of NW LDS values in every lane
+      static_assert(NW == 8 || NW == 16, "one candidate per lane of a 16-lane row");
+      double gv = s_val[pb * NW + (lane & (NW - 1))];
+      int pcol = s_idx[pb * NW + (lane & (NW - 1))];
+      hssk_row_argmax(gv, pcol);
       const int pg = pcol % NC, cp = pcol / NC, wp = pg >> 2, sp = pg & 3;
       // ---- 2. reflector from the pivot column (dlarfg): the owner wave computes, the owner group commits
       // (static loop over the slots: the pivot column is used in place, no register copy)

@@ -68,6 +68,13 @@ inline double hssk_row_sum(double v) {
   for (int o = 8; o > 0; o >>= 1) v += hssk_shfl_xor(v, o);
   return v;
 }
+inline void hssk_row_argmax(double& v, int& idx) {
+  for (int o = 8; o > 0; o >>= 1) {
+    const double ov = hssk_shfl_xor(v, o);
+    const int oi = hssk_shfl_xor(idx, o);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
 template <int N>
 inline void hssk_row_sum_n(double (&v)[N]) {
   for (int i = 0; i < N; i++) v[i] = hssk_row_sum(v[i]);
