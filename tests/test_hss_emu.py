@@ -45,6 +45,11 @@ def test_ragged_sizes_vs_oracle(L, prob, n, leaf, algo):
     HC.check_vs_oracle(L, prob, n, leaf, 1e-6, 1e-12, algo, 16, 8)
 
 
+def test_many_samples_vs_oracle(L):
+    # more than 256 sample rows: the ID panels take the TSQR pre-reduction (copied out of the samples, not read in place)
+    HC.check_vs_oracle(L, "T", 300, 64, 1e-6, 1e-12, "stable", 260, 16)
+
+
 def test_api_semantics(L):
     HC.check_api_semantics(L)
 
