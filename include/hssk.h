@@ -298,6 +298,12 @@ typedef struct hssk_qr_desc {
    * of `stair` upper-triangular factors with their rows interleaved (TSQR tree).  The blocked factorisation then only
    * touches the rows [j0, stair * (j0 + panel)) of each panel step; R is the same as for the dense sweep. */
   int stair;
+  /* early exit for callers that only want the R-diagonal TEST of the stable stopping criterion (rdiag set, nq == 0): the
+   * factorisation stops at the first step k with |R_kk| < stop_abs or |R_kk| < stop_rel * max_{i<=k} |R_ii|, and rdiag then
+   * holds that prefix maximum and |R_kk|.  Since the maximum over all of the diagonal can only be larger, "min / max below the
+   * tolerance" is decided exactly as by the full factorisation (which runs when no step qualifies); A and work are left
+   * incomplete after an early exit.  0 / 0: never.  Honoured by the register kernels, ignored (full sweep) elsewhere. */
+  double stop_rel, stop_abs;
 } hssk_qr_desc;
 int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
 /* Q(:, 0:nq) only, from panels factored by an earlier hssk_qr_vbatched call with the same A (reflectors + R)

@@ -1763,7 +1763,17 @@ void DeviceHSS::ortho_test(const std::vector<int>& ids, const std::vector<int>& 
     if (untouched[k]) tr.push_back(hssk_transpose_desc{S, T, n2, m, dcap_, m});
     else cp.push_back(hssk_colgather_desc{Q + (size_t)c2 * m, T, nullptr, m, n2, m, m, 0});
     double* wk = tmp.dbl((size_t)m + n2);
-    qr.push_back(hssk_qr_desc{T, m, m, n2, nullptr, m, 0, rdiag + 2 * k, wk});
+    // the R-diagonal test below only needs to know whether SOME |R_ii| falls under the tolerance: the factorisation may stop
+    // at the first one that does (hssk_qr_desc.stop_rel; the 1 - 1e-12 keeps the device's product form on the safe side of the
+    // host's quotient form).  A node the test leaves undecided has run the full factorisation, which formq then uses.
+    {
+      const double atol = o_.abs_tol / nd.lvl, rtol = o_.rel_tol / nd.lvl;
+      const double r0 = w == 0 ? nd.Ur_max : nd.Vr_max;
+      hssk_qr_desc q{T, m, m, n2, nullptr, m, 0, rdiag + 2 * k, wk, 0, 0., 0.};
+      if (untouched[k]) { q.stop_rel = rtol * (1. - 1e-12); q.stop_abs = atol; }
+      else q.stop_abs = std::max(atol, rtol * std::abs(r0) * (1. - 1e-12));
+      qr.push_back(q);
+    }
     stats_.f_ortho += 4.0 * m * (double)n2 * n2;
   }
   if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));

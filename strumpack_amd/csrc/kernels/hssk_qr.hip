@@ -118,11 +118,15 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
   HSSK_SHARED double s_v[2 * 16 * RT];
   HSSK_SHARED double s_tau[NC * CT];
   HSSK_SHARED double s_rd[2];
+  HSSK_SHARED int s_stop;
   const hssk_qr_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, sub = lane >> 4, grp = wave * 4 + sub;
   const int rows = p.rows, cols = p.cols;
   const int kmax = rows < cols ? rows : cols;
+  const bool may_stop = p.rdiag && p.nq == 0 && (p.stop_rel > 0. || p.stop_abs > 0.);
+  if (tid == 0) s_stop = 0;
+  bool done = false;
   double a[CT][RT];
 #pragma unroll
   for (int c = 0; c < CT; c++)
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
 #pragma clang loop unroll(full)
     for (int rq = 0; rq < SPC; rq++) {
       const int rk = kc * SPC + rq < RT ? kc * SPC + rq : RT - 1;   // (static; slots beyond the last row register run no step)
-      const int nlk = kc * SPC + rq < RT ? min(16, kmax - 16 * rk) : 0;
+      const int nlk = (kc * SPC + rq < RT && !done) ? min(16, kmax - 16 * rk) : 0;
       for (int lk = 0; lk < nlk; lk++) {
         const int k = 16 * rk + lk;
         const int g = rq * 16 + lk, kw = g >> 2, ks = g & 3;
@@ -172,10 +176,13 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
               const double ab = fabs(beta);
               if (k == 0) { s_rd[0] = ab; s_rd[1] = ab; }
               else { if (ab > s_rd[0]) s_rd[0] = ab; if (ab < s_rd[1]) s_rd[1] = ab; }
+              // (the R-diagonal test is settled: see hssk_qr_desc.stop_rel)
+              if (may_stop && (ab < p.stop_abs || ab < p.stop_rel * s_rd[0])) s_stop = 1;
             }
           }
         }
         __syncthreads();
+        if (may_stop && s_stop) { done = true; break; }
         const double tau = s_tau[k];
         if (tau != 0.) {
           double vr[RT];

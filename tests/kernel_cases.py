@@ -496,3 +496,31 @@ def case_gather_combine(hk, shapes, seed=31):
     for d, ref, sh in zip(keep, expect, shapes):
         got = d[7].get()
         assert np.abs(got - ref).max() <= 1e-12 * max(1, sh[2]), f"gather_combine {sh}"
+
+
+def case_qr_early_exit(hk, shapes, seed=41):
+    """hssk_qr_desc.stop_rel / stop_abs: the R-diagonal test stops at the first |R_kk| under the tolerance and reports the
+    prefix maximum and that |R_kk| -- the values of the full factorisation at that step.  shapes: (rows, cols, stop_rel)"""
+    r = rng(seed)
+    descs, keep = [], []
+    for (rows, cols, srel) in shapes:
+        k = min(rows, cols)
+        U, _ = np.linalg.qr(r.standard_normal((rows, k)))
+        V, _ = np.linalg.qr(r.standard_normal((cols, k)))
+        A = (U * 10.0 ** (-np.arange(k) / 4.0)) @ V.T      # singular values decay by 10 every four
+        dA, drd, dwk = hk.array(A), hk.array(np.zeros(2)), hk.empty((rows + cols,))
+        keep.append((A, dA, drd, dwk, srel))
+        descs.append(K.QrDesc(dA.ptr, rows, rows, cols, None, rows, 0, drd.ptr, dwk.ptr, 0, srel, 0.0))
+    hk.batch("hssk_qr_vbatched", descs)
+    hk.sync()
+    for (A, dA, drd, dwk, srel) in keep:
+        dg = np.abs(np.diag(np.linalg.qr(A, mode="r")))
+        pm = np.maximum.accumulate(dg)
+        hit = np.nonzero(dg < srel * pm)[0]
+        rd = drd.get()
+        if srel > 0 and len(hit):
+            k0 = hit[0]
+            assert abs(rd[0] - pm[k0]) <= 1e-12 * pm[k0] and rd[1] <= dg[k0] * (1 + 1e-9) + 1e-300, (rd, pm[k0], dg[k0])
+            assert rd[1] < srel * rd[0]
+        else:
+            assert abs(rd[0] - dg.max()) <= 1e-12 * dg.max() and abs(rd[1] - dg.min()) <= 1e-6 * dg.max()

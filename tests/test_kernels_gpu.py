@@ -125,3 +125,7 @@ def test_gather_combine(hk):
     KC.case_gather_combine(hk, [(40, 5, 7, 6, 3, 4, 5, 0, 1), (70, 66, 65, 9, 0, 70, 0, 1, 1), (33, 9, 0, 5, 5, 0, 0, 0, 1),
                                 (300, 3, 130, 2, 2, 50, 90, 1, 0)])
     KC.case_gather_combine(hk, [(192, 41, 159, 100, 95, 195, 0, 0, 1), (192, 82, 41, 60, 22, 30, 11, 1, 1), (500, 130, 70, 64, 64, 40, 40, 0, 1)], seed=33)
+
+
+def test_qr_early_exit(hk):
+    KC.case_qr_early_exit(hk, [(195, 192, 1e-4), (195, 128, 1e-6), (64, 48, 1e-3), (100, 60, 0.0), (120, 100, 1e-30)])
