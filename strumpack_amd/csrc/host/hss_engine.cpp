@@ -2410,7 +2410,6 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         nd.W1 = fact_->dbl((size_t)std::max(r, 1) * m);
         nd.Rlq = fact_->dbl((size_t)m * (m - r));
         nd.Qt = fact_->dbl((size_t)m * m);
-        nd.Vt0 = fact_->dbl((size_t)(m - r) * std::max(rv, 1));
         nd.Vt1 = fact_->dbl((size_t)std::max(r, 1) * std::max(rv, 1));
         nd.Dt = fact_->dbl((size_t)std::max(r, 1) * std::max(r, 1));
         if (r) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.W1, r, m, r, 0});
@@ -2419,10 +2418,10 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         // LQ(W0) == QR(W0^T): Q~ (m x m) = Q^T, R~ = L^T                  (factor.hpp:122)
         double* wk = tmp.dbl((size_t)2 * m);
         qr.push_back(hssk_qr_desc{nd.Rlq, m, m, m - r, nd.Qt, m, m, nullptr, wk});
-        // Vt0 = Q0 Vh = Q~(:, :m-r)^T Vh ; Vt1 = Q~(:, m-r:)^T Vh ; Dt = W1 Q1^T = W1 Q~(:, m-r:)
+        // Vt0 = Q0 Vh = Q~(:, :m-r)^T Vh, kept TRANSPOSED (Vt0^T = Vh^T Q~(:, 0:m-r): rows contiguous for the solve sweep; the
+        // per-level solve reads the same array) ; Vt1 = Q~(:, m-r:)^T Vh ; Dt = W1 Q1^T = W1 Q~(:, m-r:)
         if (rv) {
-          g3.push_back(hssk_gemm_desc{nd.Qt, Vh[id], nd.Vt0, m - r, rv, m, m, m, m - r, 1, 0, 1.0, 0.0});
-          nd.Vt0T = fact_->dbl((size_t)rv * (m - r));   // rows contiguous for the solve sweep: Vt0^T = Vh^T Q~(:, 0:m-r)
+          nd.Vt0T = fact_->dbl((size_t)rv * (m - r));
           g3.push_back(hssk_gemm_desc{Vh[id], nd.Qt, nd.Vt0T, rv, m - r, m, m, m, rv, 1, 0, 1.0, 0.0});
           if (r) g3.push_back(hssk_gemm_desc{nd.Qt + (size_t)(m - r) * m, Vh[id], nd.Vt1, r, rv, m, m, m, r, 1, 0, 1.0, 0.0});
         }
@@ -2971,8 +2970,8 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
           }
           zbeta = 1.0;
         }
-        if (m > r) ge.push_back(hssk_gemm_desc{nd.Vt0, y[id], z, rv, nrhs, m - r, m - r, m - r, ldz, 1, 0, 1.0, zbeta});
-        else if (nd.leaf()) ge.push_back(hssk_gemm_desc{nd.Vt0, y[id], z, rv, nrhs, 0, 1, 1, ldz, 1, 0, 1.0, 0.0});  // z = 0
+        if (m > r && rv > 0) ge.push_back(hssk_gemm_desc{nd.Vt0T, y[id], z, rv, nrhs, m - r, rv, m - r, ldz, 0, 0, 1.0, zbeta});   // z (+)= Vt0^T y
+        else if (nd.leaf()) ge.push_back(hssk_gemm_desc{z, z, z, rv, nrhs, 0, 1, 1, ldz, 0, 0, 1.0, 0.0});  // z = 0
       }
     }
     if (!rg.empty()) ck(hssk_gather_rows(ctx_, rg.data(), (int)rg.size()));
