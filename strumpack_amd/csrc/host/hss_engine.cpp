@@ -14,6 +14,8 @@
 #include "Comm.hpp"
 
 #include <atomic>
+#include <functional>
+#include <condition_variable>
 #include <thread>
 #include <exception>
 #include <algorithm>
@@ -101,21 +103,73 @@ class DevicePool {
 };
 
 // bump allocator over large device chunks
-// run fn(0..n-1) on the host's hardware threads (used for per-node index work of a tree level)
+// run fn(0..n-1) on the host's hardware threads (per-node index work of a tree level, host-side gathers).  The threads
+// are persistent: a level's work is a few hundred microseconds, starting up to 32 threads per call cost more than that
+// (the tree phase of the host-operand path: 13 ms, half of it thread start-up).
+class HostPool {
+ public:
+  static HostPool& get() { static HostPool p; return p; }
+  // runs body() on every worker and on the caller; returns when all are done.  One job at a time: a second caller
+  // (another matrix on another thread) finds the pool busy and runs its loop alone.
+  bool run(const std::function<void()>& body) {
+    std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
+    if (!own.owns_lock() || th_.empty()) return false;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      body_ = &body; pending_ = th_.size(); gen_++;
+    }
+    cv_.notify_all();
+    body();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    body_ = nullptr;
+    return true;
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+
+ private:
+  HostPool() {
+    const unsigned n = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    for (unsigned t = 1; t < n; t++) th_.emplace_back([this] { loop(); });
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void()>* f;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        f = body_;
+      }
+      (*f)();
+      { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_all(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex owner_, mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void()>* body_ = nullptr;
+  unsigned long gen_ = 0;
+  size_t pending_ = 0;
+  bool stop_ = false;
+};
 template <class F> void host_parallel_for(size_t n, F&& fn) {
-  const size_t nt = std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
-  if (nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+  if (n <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
   std::atomic<size_t> next{0};
   std::exception_ptr err;
   std::mutex mu;
-  std::vector<std::thread> th;
-  for (size_t t = 0; t < nt; t++)
-    th.emplace_back([&] {
-      try {
-        for (size_t i = next++; i < n; i = next++) fn(i);
-      } catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
-    });
-  for (auto& t : th) t.join();
+  const std::function<void()> body = [&] {
+    try {
+      for (size_t i = next++; i < n; i = next++) fn(i);
+    } catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
+  };
+  if (!HostPool::get().run(body)) body();
   if (err) std::rethrow_exception(err);
 }
 
