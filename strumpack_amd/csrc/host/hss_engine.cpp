@@ -1581,10 +1581,12 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   ck(hssk_memcpy_d2h(ctx_, hall.data(), rank_block, (long long)sizeof(int) * (cnt + perm_total)));
   const int* hranks = hall.data();
   const int* hperm = hall.data() + cnt;
-  // commit
+  // commit, in the order that puts the device back to work first: (A) ranks -> final places of X -> the X solves are
+  // launched; (B) the host-side bookkeeping (permutations, global skeleton indices: vectors per node) while they run;
+  // then the one index upload of the level
   std::vector<hssk_xsolve_desc> xc;
-  std::vector<int> idx_host;      // all skeleton index sets of this level: one upload
-  std::vector<size_t> idx_off;
+  std::vector<size_t> idx_off(cnt), perm_off(cnt);
+  size_t idx_total = 0;
   poff = 0;
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
@@ -1592,10 +1594,24 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     const int m = w == 0 ? nd.mU : nd.mV;
     const int dtot = ds[k];
     const int r = m ? hranks[k] : 0;
-    std::vector<int> perm(hperm + poff, hperm + poff + m);
+    perm_off[k] = poff;
     poff += m;
+    idx_off[k] = idx_total;
+    idx_total += r;
     double* X = persist_->dbl((size_t)std::max(r, 1) * std::max(m - r, 1));
     if (r > 0 && m > r) xc.push_back(hssk_xsolve_desc{Ws[k], dtot, r, m, X, r, x_solved});
+    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.Ustate = 2; }
+    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.Vstate = 2; }
+    stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
+  }
+  if (!xc.empty()) ck(hssk_id_xsolve_vbatched(ctx_, xc.data(), (int)xc.size()));
+  std::vector<int> idx_host(std::max<size_t>(idx_total, 1));   // all skeleton index sets of this level: one upload
+  auto book = [&](size_t k) {
+    Node& nd = nodes_[ids[k]];
+    const int w = which[k];
+    const int m = w == 0 ? nd.mU : nd.mV;
+    const int r = w == 0 ? nd.rU : nd.rV;
+    std::vector<int> perm(hperm + perm_off[k], hperm + perm_off[k] + m);
     // global skeleton indices (compress_stable.hpp:299-306, 334-341)
     std::vector<int> I(r);
     if (nd.leaf()) for (int i = 0; i < r; i++) I[i] = nd.lo + perm[i];
@@ -1605,20 +1621,18 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       const int r0 = (int)ia.size();
       for (int i = 0; i < r; i++) I[i] = perm[i] < r0 ? ia[perm[i]] : ib[perm[i] - r0];
     }
-    const size_t ioff = idx_host.size();
-    idx_host.insert(idx_host.end(), I.begin(), I.end());
-    idx_off.push_back(ioff);
-    if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.hpermU = std::move(perm); nd.Ir = std::move(I); nd.Ustate = 2; }
-    else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.hpermV = std::move(perm); nd.Ic = std::move(I); nd.Vstate = 2; }
-    stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
-  }
-  int* idx_dev = persist_->ints(std::max<size_t>(idx_host.size(), 1));
-  if (!idx_host.empty()) ck(hssk_upload_async(ctx_, idx_dev, idx_host.data(), (long long)sizeof(int) * idx_host.size()));
+    std::copy(I.begin(), I.end(), idx_host.begin() + idx_off[k]);
+    if (w == 0) { nd.hpermU = std::move(perm); nd.Ir = std::move(I); }
+    else { nd.hpermV = std::move(perm); nd.Ic = std::move(I); }
+  };
+  // (on this thread: waking the host pool costs ~100 us, as much as the widest level's bookkeeping itself -- measured)
+  for (size_t k = 0; k < cnt; k++) book(k);
+  int* idx_dev = persist_->ints(std::max<size_t>(idx_total, 1));
+  if (idx_total) ck(hssk_upload_async(ctx_, idx_dev, idx_host.data(), (long long)sizeof(int) * idx_total));
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
     (which[k] == 0 ? nd.dIr : nd.dIc) = idx_dev + idx_off[k];
   }
-  if (!xc.empty()) ck(hssk_id_xsolve_vbatched(ctx_, xc.data(), (int)xc.size()));
   // (no synchronisation: everything that reuses the W panels in tmp_ is enqueued behind these launches on the same stream)
 }
 
