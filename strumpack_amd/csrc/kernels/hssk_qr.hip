@@ -654,6 +654,8 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
   else if (cmax <= 128 && rmax <= 208) launch_qr_reg<13, 4, 8>(ctx, dd, count);
   else if (cmax <= 128) launch_qr_reg<16, 4, 8>(ctx, dd, count);
   else if (rmax > 208) launch_qr_reg<16, 6, 8>(ctx, dd, count);   // <= 256 rows x 192 columns
+  else if (cmax <= 160) launch_qr_reg<13, 5, 8>(ctx, dd, count);   // (a step costs per column slot: the 195 x ~160 ULV panels of N = 1e5 need five or
+  else if (cmax <= 192) launch_qr_reg<13, 6, 8>(ctx, dd, count);   //  six, not seven)
   else launch_qr_reg<13, 7, 8>(ctx, dd, count);
   // Q is then formed by a second, barrier-free launch over blocks of 64 columns
   if (qmax > 0) formq_reg(ctx, dd, descs, count, rmax);
