@@ -1285,7 +1285,11 @@ void DeviceHSS::process_level(Source& src, const std::vector<int>& ids_all, int 
       }
     }
   }
+  // (the host-side bookkeeping of the ID -- index sets, permutations -- is finished behind the launches of the sample
+  // reduction below, which only need what is on the device; the ORIGINAL algorithm inspects and resets ranks first)
+  defer_book_ = !original;
   run_id(id_nodes, id_which, dtot);
+  defer_book_ = false;
   if (original) {
     // compute_U_V_bases acceptance, HSSMatrix.compress.hpp:663-686
     for (int id : work_ids) {
@@ -1309,6 +1313,7 @@ void DeviceHSS::process_level(Source& src, const std::vector<int>& ids_all, int 
     }
   }
   reduce_samples(rd_ids, rd_r0, rd_dn);
+  finish_id_bookkeeping();
 }
 
 void DeviceHSS::extract_blocks(Source& src, const std::vector<int>& ids) {
@@ -1605,13 +1610,29 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
   }
   if (!xc.empty()) ck(hssk_id_xsolve_vbatched(ctx_, xc.data(), (int)xc.size()));
+  book_.ids = ids; book_.which = which; book_.hall = std::move(hall);
+  book_.idx_off = std::move(idx_off); book_.perm_off = std::move(perm_off);
+  book_.cnt = cnt; book_.idx_total = idx_total; book_.active = true;
+  if (!defer_book_) finish_id_bookkeeping();
+  // (no synchronisation: everything that reuses the W panels in tmp_ is enqueued behind these launches on the same stream)
+}
+
+// Second half of id_panels' commit: permutations and global skeleton indices of the level on the host (vectors per node),
+// the one index upload of the level.  Nothing on the device waits for it except the next level's block extraction.
+void DeviceHSS::finish_id_bookkeeping() {
+  if (!book_.active) return;
+  book_.active = false;
+  const std::vector<int>&ids = book_.ids, &which = book_.which;
+  const size_t cnt = book_.cnt, idx_total = book_.idx_total;
+  const int* hperm = book_.hall.data() + cnt;
   std::vector<int> idx_host(std::max<size_t>(idx_total, 1));   // all skeleton index sets of this level: one upload
-  auto book = [&](size_t k) {
+  // (on this thread: waking the host pool costs ~100 us, as much as the widest level's bookkeeping itself -- measured)
+  for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
     const int w = which[k];
     const int m = w == 0 ? nd.mU : nd.mV;
     const int r = w == 0 ? nd.rU : nd.rV;
-    std::vector<int> perm(hperm + perm_off[k], hperm + perm_off[k] + m);
+    std::vector<int> perm(hperm + book_.perm_off[k], hperm + book_.perm_off[k] + m);
     // global skeleton indices (compress_stable.hpp:299-306, 334-341)
     std::vector<int> I(r);
     if (nd.leaf()) for (int i = 0; i < r; i++) I[i] = nd.lo + perm[i];
@@ -1621,19 +1642,16 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       const int r0 = (int)ia.size();
       for (int i = 0; i < r; i++) I[i] = perm[i] < r0 ? ia[perm[i]] : ib[perm[i] - r0];
     }
-    std::copy(I.begin(), I.end(), idx_host.begin() + idx_off[k]);
+    std::copy(I.begin(), I.end(), idx_host.begin() + book_.idx_off[k]);
     if (w == 0) { nd.hpermU = std::move(perm); nd.Ir = std::move(I); }
     else { nd.hpermV = std::move(perm); nd.Ic = std::move(I); }
-  };
-  // (on this thread: waking the host pool costs ~100 us, as much as the widest level's bookkeeping itself -- measured)
-  for (size_t k = 0; k < cnt; k++) book(k);
+  }
   int* idx_dev = persist_->ints(std::max<size_t>(idx_total, 1));
   if (idx_total) ck(hssk_upload_async(ctx_, idx_dev, idx_host.data(), (long long)sizeof(int) * idx_total));
   for (size_t k = 0; k < cnt; k++) {
     Node& nd = nodes_[ids[k]];
-    (which[k] == 0 ? nd.dIr : nd.dIc) = idx_dev + idx_off[k];
+    (which[k] == 0 ? nd.dIr : nd.dIc) = idx_dev + book_.idx_off[k];
   }
-  // (no synchronisation: everything that reuses the W panels in tmp_ is enqueued behind these launches on the same stream)
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -220,6 +220,15 @@ class DeviceHSS {
   void local_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
   void reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
   void run_id(const std::vector<int>& ids, const std::vector<int>& which, int dtot);
+  // host-side half of an ID commit, finished behind the next launches (see id_panels / finish_id_bookkeeping)
+  struct PendingBook {
+    std::vector<int> ids, which, hall;
+    std::vector<size_t> idx_off, perm_off;
+    size_t cnt = 0, idx_total = 0;
+    bool active = false;
+  } book_;
+  bool defer_book_ = false;
+  void finish_id_bookkeeping();
   void id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
                  const std::vector<int>& ds, const std::vector<const double*>* srcs = nullptr, int ldsrc = 0);
   void tsqr_reduce(const std::vector<int>& ids, const std::vector<int>& which, std::vector<double*>& Ws, std::vector<int>& ds);
