@@ -441,8 +441,10 @@ def main():
                    "comm": {"single": "none", "rccl": "native RCCL communicator inside the library, collectives on the engine's stream; operand sharded (row block + column block per rank)",
                             "torch": "torch.distributed all-gather callback; operand replicated on every rank"}[comm_mode],
                    "rccl_nranks": world if comm_mode == "rccl" else 0},
-        "phases_s": {"compress": st["t_compress"], "sketch": st["t_sketch"], "random": st["t_random"],
-                     "tree": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
+        # per-phase wall times: the median over the timed steps (a single step's host-side phases are noisy)
+        "phases_s": {name: sorted(s_[key] for s_ in stats)[len(stats) // 2]
+                     for name, key in (("compress", "t_compress"), ("sketch", "t_sketch"), ("random", "t_random"),
+                                       ("tree", "t_tree"), ("factor", "t_factor"), ("solve", "t_solve"))},
         "flops": {"sketch": st["f_sketch"], "local": st["f_local"], "reduce": st["f_reduce"], "id": st["f_id"],
                   "ortho": st["f_ortho"], "ulv": st["f_ulv"], "solve": st["f_solve"]},
         "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "rounds": int(st["rounds"]), "d": d},

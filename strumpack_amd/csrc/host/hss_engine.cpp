@@ -2463,9 +2463,10 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
       }
     }
     if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
-    if (!g0.empty()) ck(hssk_gemm_vbatched(ctx_, g0.data(), (int)g0.size()));
     if (!bd.empty()) ck(hssk_basis_dense(ctx_, bd.data(), (int)bd.size()));
-    if (!g1.empty()) ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
+    // (the coupling products into Dh and the products that build Vh are independent of each other: one batched launch)
+    g0.insert(g0.end(), g1.begin(), g1.end());
+    if (!g0.empty()) ck(hssk_gemm_vbatched(ctx_, g0.data(), (int)g0.size()));
     // ---- eliminate
     std::vector<hssk_elem_desc> ge;
     std::vector<hssk_gemm_desc> g2, g3;
