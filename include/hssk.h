@@ -247,6 +247,23 @@ typedef struct hssk_combine_desc {
 } hssk_combine_desc;
 int hssk_gather_combine(hssk_ctx* ctx, const hssk_combine_desc* descs, int count);
 
+/* ---- first step of the ULV elimination of a node (HSS/HSSMatrix.factor.hpp:109-118) ------------------------- */
+/* W1 (r x m, ldw) = (P^T D)(0:r, :) and W0t (m x (m - r), ldt) = (P^T D)(r:, :)^T - W1^T X, with P^T the row permutation
+ * perm (device, m ints: row k of P^T D is row perm[k] of D) and X (r x (m - r), ldx) of the node's row ID.  m <= 256 (return
+ * code 2 beyond: the caller composes the step from hssk_gather_elems and hssk_gemm_vbatched). */
+typedef struct hssk_ulvsplit_desc {
+  const double* D;
+  int ldd, m, r;
+  const int* perm;
+  const double* X;
+  int ldx;
+  double* W1;
+  int ldw;
+  double* W0t;
+  int ldt;
+} hssk_ulvsplit_desc;
+int hssk_ulv_split(hssk_ctx* ctx, const hssk_ulvsplit_desc* descs, int count);
+
 /* ---- batched interpolative decomposition ------------------------------------------------------- */
 /* Truncated column-pivoted Householder QR of W (d x m, column-major, overwritten), i.e. the row ID
  * of the m x d sample block:  DenseMatrix::ID_row -> ID_column_GEQP3 -> geqp3tol + trsm

@@ -2469,6 +2469,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     if (!g0.empty()) ck(hssk_gemm_vbatched(ctx_, g0.data(), (int)g0.size()));
     // ---- eliminate
     std::vector<hssk_elem_desc> ge;
+    std::vector<hssk_ulvsplit_desc> us;
     std::vector<hssk_gemm_desc> g2, g3;
     std::vector<hssk_qr_desc> qr;
     std::vector<hssk_lu_desc> lu;
@@ -2499,9 +2500,13 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         nd.Qt = fact_->dbl((size_t)m * m);
         nd.Vt1 = fact_->dbl((size_t)std::max(r, 1) * std::max(rv, 1));
         nd.Dt = fact_->dbl((size_t)std::max(r, 1) * std::max(r, 1));
-        if (r) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.W1, r, m, r, 0});
-        ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU + r, nullptr, 0, 0, nd.Rlq, m - r, m, m, 1});
-        if (r) g2.push_back(hssk_gemm_desc{nd.W1, nd.XU, nd.Rlq, m, m - r, r, r, r, m, 1, 0, -1.0, 1.0});
+        if (m <= 256) {   // one fused launch (hssk_ulv_split); larger blocks: two row gathers and a product
+          us.push_back(hssk_ulvsplit_desc{Dh[id], m, m, r, nd.permU, nd.XU, std::max(r, 1), nd.W1, std::max(r, 1), nd.Rlq, m});
+        } else {
+          if (r) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.W1, r, m, r, 0});
+          ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU + r, nullptr, 0, 0, nd.Rlq, m - r, m, m, 1});
+          if (r) g2.push_back(hssk_gemm_desc{nd.W1, nd.XU, nd.Rlq, m, m - r, r, r, r, m, 1, 0, -1.0, 1.0});
+        }
         // LQ(W0) == QR(W0^T): Q~ (m x m) = Q^T, R~ = L^T                  (factor.hpp:122)
         double* wk = tmp.dbl((size_t)2 * m);
         qr.push_back(hssk_qr_desc{nd.Rlq, m, m, m - r, nd.Qt, m, m, nullptr, wk});
@@ -2531,6 +2536,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         if (m) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.Dt, m, m, m, 0});
       }
     }
+    if (!us.empty()) ck(hssk_ulv_split(ctx_, us.data(), (int)us.size()));
     if (!ge.empty()) ck(hssk_gather_elems(ctx_, ge.data(), (int)ge.size()));
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
     if (!qr.empty()) ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));

@@ -524,3 +524,31 @@ def case_qr_early_exit(hk, shapes, seed=41):
             assert rd[1] < srel * rd[0]
         else:
             assert abs(rd[0] - dg.max()) <= 1e-12 * dg.max() and abs(rd[1] - dg.min()) <= 1e-6 * dg.max()
+
+
+def case_ulv_split(hk, shapes, seed=51):
+    """hssk_ulv_split vs numpy.  shapes: (m, r)"""
+    r_ = rng(seed)
+    descs, keep = [], []
+    for (m, r) in shapes:
+        q = m - r
+        D = r_.standard_normal((m + 3, m))
+        perm = r_.permutation(m).astype(np.int32)
+        X = r_.standard_normal((max(r, 1) + 1, max(q, 1)))
+        W1 = np.full((max(r, 1) + 2, m), -5.0)
+        W0t = np.full((m + 1, max(q, 1)), -6.0)
+        d = [hk.array(D), hk.array(perm), hk.array(X), hk.array(W1), hk.array(W0t)]
+        keep.append((D, perm, X, d, m, r))
+        descs.append(K.UlvSplitDesc(d[0].ptr, m + 3, m, r, d[1].ptr, d[2].ptr, max(r, 1) + 1, d[3].ptr, max(r, 1) + 2, d[4].ptr, m + 1))
+    hk.batch("hssk_ulv_split", descs)
+    hk.sync()
+    for (D, perm, X, d, m, r) in keep:
+        q = m - r
+        PD = D[:m][perm]
+        w1 = PD[:r]
+        w0t = PD[r:].T - w1.T @ X[:r, :q]
+        g1, g0 = d[3].get(), d[4].get()
+        assert np.array_equal(g1[:r], w1) and np.all(g1[r:] == -5.0)
+        if q:
+            assert np.abs(g0[:m, :q] - w0t).max() <= 1e-12 * max(1.0, np.abs(w0t).max()) * max(r, 1)
+        assert np.all(g0[m:] == -6.0)

@@ -130,3 +130,8 @@ def test_gather_combine(hk):
 
 def test_qr_early_exit(hk):
     KC.case_qr_early_exit(hk, [(195, 192, 1e-4), (195, 128, 1e-6), (64, 48, 1e-3), (100, 60, 0.0), (120, 100, 1e-30)])
+
+
+def test_ulv_split(hk):
+    KC.case_ulv_split(hk, [(40, 7), (33, 33), (70, 0), (82, 41), (5, 2)])
+    KC.case_ulv_split(hk, [(195, 36), (196, 30), (256, 100)] * 3, seed=53)
