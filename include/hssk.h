@@ -323,6 +323,16 @@ typedef struct hssk_qr_desc {
   double stop_rel, stop_abs;
 } hssk_qr_desc;
 int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
+/* R1 (m x m, upper triangle, updated in place) <- R of the QR factorisation of [triu(R1); triu(R2)]: the merge step of a
+ * TSQR tree.  Only the upper triangles are read (whatever else the arrays hold -- the reflectors of an earlier factorisation --
+ * is ignored) and only the upper triangle of R1 is written.  m <= 224 (return code 2 beyond). */
+typedef struct hssk_tpqr_desc {
+  double* R1;
+  int ld1;
+  const double* R2;
+  int ld2, m;
+} hssk_tpqr_desc;
+int hssk_tpqr_vbatched(hssk_ctx* ctx, const hssk_tpqr_desc* descs, int count);
 /* Q(:, 0:nq) only, from panels factored by an earlier hssk_qr_vbatched call with the same A (reflectors + R)
  * and work (taus); rdiag is not touched.  Lets the rank-adequacy test form Q only for the nodes whose
  * R-diagonal test did not already settle (compress_stable.hpp:405-417). */

@@ -1480,8 +1480,12 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
   }
   if (!any) return;
   ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+  // pairs of full triangles are merged by hssk_tpqr_vbatched: in place over the first one, no stacking, one launch per tree
+  // level (STRUMPACK_AMD_TSQR_PAIRS=0 or STRUMPACK_AMD_TSQR_DENSE=1: the stacked blocked QR below for everything)
+  static const bool pairs_off = [] { const char* e = std::getenv("STRUMPACK_AMD_TSQR_PAIRS"); return e && e[0] == '0'; }();
   for (;;) {
     std::vector<hssk_triu_desc> cp;
+    std::vector<hssk_tpqr_desc> tp;
     qr.clear();
     bool more = false;
     for (size_t k = 0; k < cnt; k++) {
@@ -1500,6 +1504,11 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
         int rows = 0;
         bool full = true;   // every piece a full m x m triangle
         for (size_t t = 0; t < cntp; t++) { rows += pc[i + t].rows; full = full && pc[i + t].rows == m; }
+        if (cntp == 2 && full && m <= 224 && !pairs_off && tsqr_staircase()) {
+          tp.push_back(hssk_tpqr_desc{pc[i].p, pc[i].ld, pc[i + 1].p, pc[i + 1].ld, m});
+          next.push_back(pc[i]);
+          continue;
+        }
         double* dst = tmp.dbl((size_t)rows * m);
         // full triangles are stacked with their rows interleaved (row r of piece t -> row cntp r + t): column j of the
         // stack is then zero from row cntp (j + 1) on, and the blocked QR only sweeps that staircase (hssk_qr_desc::stair)
@@ -1517,9 +1526,12 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
       pc.swap(next);
       more = more || pc.size() > 1;
     }
-    if (cp.empty()) break;
-    ck(hssk_copy_triu(ctx_, cp.data(), (int)cp.size()));
-    ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+    if (cp.empty() && tp.empty()) break;
+    if (!tp.empty()) ck(hssk_tpqr_vbatched(ctx_, tp.data(), (int)tp.size()));
+    if (!cp.empty()) {
+      ck(hssk_copy_triu(ctx_, cp.data(), (int)cp.size()));
+      ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
+    }
     if (!more) break;
   }
   // clean m x m (or shorter) triangular panels for the ID

@@ -328,6 +328,116 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void formq_reg
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// QR of a PAIR of upper triangular factors stacked on top of each other, [R1; R2] = Q R (both m x m), the merge step of the
+// TSQR tree (DeviceHSS::tsqr_reduce).  The structure does most of the work: the reflector of step k couples row k of R1
+// with column k of R2 (rows 0..k) and nothing else, so
+//   * R2 lives in the registers of the workgroup in the layout of qr_reg_kernel (one column per 16-lane row; its zeros
+//     below the diagonal make every row mask unnecessary),
+//   * R1 is never loaded as a matrix: step k reads its row k (one element per column, fetched one step ahead) and writes
+//     it back as row k of R -- R1 is updated in place, R2 is only read,
+//   * a step is one reflector generation on the owner group, one LDS broadcast, one barrier and the update of the columns
+//     behind k: (2/3) m^3 flops per pair where the dense sweep of the 2m x m stack spends (10/3) m^3.
+// One launch per tree level instead of a triangle copy and four launches per 32-column panel step of the blocked QR
+// (the kernel-matrix workload at N = 1e5: ~33 ms of its 140 in those).  Capacity: m <= 16 RT rows, m <= 4 NW CT columns.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int CT, int NW>
+__global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void tpqr_reg_kernel(const hssk_tpqr_desc* __restrict__ descs) {
+  constexpr int NC = NW * 4;
+  // column slot c holds columns < NC (c + 1) of an upper triangular matrix: only the first RC(c) row registers can be non-zero
+  // (they are the only ones allocated: every loop below is unrolled with these bounds)
+#define RC(c) ((NC * ((c) + 1) + 15) / 16 < RT ? (NC * ((c) + 1) + 15) / 16 : RT)
+  HSSK_SHARED double s_v[2 * 16 * RT];
+  HSSK_SHARED double s_tau[2];
+  HSSK_SHARED double s_t[2 * NC * CT];   // rows k, k + 1 of R1 (double-buffered: row k + 1 is staged during step k)
+  const hssk_tpqr_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, sub = lane >> 4, grp = wave * 4 + sub;
+  const int m = p.m;
+  double* __restrict__ R1 = p.R1;
+  double a[CT][RT];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < RC(c); r++) {
+      const int row = l16 + 16 * r, col = grp + NC * c;
+      a[c][r] = (row <= col && col < m) ? p.R2[row + (size_t)col * p.ld2] : 0.;
+    }
+  // R1(k, k) is fetched one step ahead into a register (the owner needs it first thing); row k as a whole is staged in LDS
+  // during step k - 1 (thread j loads R1(k, j)) and read behind the barrier of step k.  No step writes a row but its own.
+  double alpha_next = m > 0 ? hssk_gload(R1, 0) : 0.;
+  if (tid < m) s_t[tid] = hssk_gload(R1, (size_t)tid * p.ld1);
+#pragma clang loop unroll(full)
+  for (int kc = 0; kc < CT; kc++) {
+    const int ng = min(NC, m - NC * kc);   // steps whose column sits in slot kc
+    for (int g = 0; g < ng; g++) {
+      const int k = NC * kc + g, kw = g >> 2, ks = g & 3;
+      double* sv = s_v + (k & 1) * 16 * RT;
+      const double alpha = alpha_next;
+      const double* st = s_t + (k & 1) * NC * CT;
+      const double trow = (k + 1 < m && tid > k && tid < m) ? hssk_gload(R1, (size_t)(k + 1) + (size_t)tid * p.ld1) : 0.;   // row k + 1, for the next step
+      alpha_next = k + 1 < m ? hssk_gload(R1, (size_t)(k + 1) + (size_t)(k + 1) * p.ld1) : 0.;
+      if (wave == kw) {
+        // reflector from [R1(k, k); R2(0:k, k)]
+        double s = 0.;
+#pragma unroll
+        for (int r = 0; r < RC(kc); r++) s += a[kc][r] * a[kc][r];
+        s = hssk_row_sum(s);
+        double tau = 0., beta = alpha, scal = 1.;
+        if (s != 0.) {
+          const double nrm = sqrt(alpha * alpha + s);
+          beta = alpha >= 0. ? -nrm : nrm;
+          tau = (beta - alpha) / beta;
+          scal = 1. / (alpha - beta);
+        }
+        if (sub == ks) {
+#pragma unroll
+          for (int r = 0; r < RC(kc); r++) {
+            a[kc][r] *= scal;
+            sv[l16 + 16 * r] = a[kc][r];
+          }
+          if (l16 == 0) {
+            s_tau[k & 1] = tau;
+            hssk_gstore(R1, (size_t)k + (size_t)k * p.ld1, beta);
+          }
+        }
+      }
+      __syncthreads();
+      const double tau = s_tau[k & 1];
+      if (tau != 0.) {
+        double vr[RT];   // (the reflector of a column of slot kc is zero beyond its first RC(kc) row registers)
+#pragma unroll
+        for (int r = 0; r < RC(kc); r++) vr[r] = sv[l16 + 16 * r];
+        double dot[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          double d0 = 0., d1 = 0.;
+          if (c >= kc) {
+#pragma unroll
+            for (int r = 0; r + 1 < RC(kc); r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
+            if (RC(kc) & 1) d0 += vr[RC(kc) - 1] * a[c][RC(kc) - 1];
+          }
+          dot[c] = d0 + d1;
+        }
+        hssk_row_sum_n(dot);
+#pragma unroll
+        for (int c = kc; c < CT; c++) {
+          const int col = grp + NC * c;
+          if (col > k && col < m) {
+            const double tc = st[col];
+            const double f = (dot[c] + tc) * tau;   // w = R1(k, col) + v . R2(:, col)
+#pragma unroll
+            for (int r = 0; r < RC(kc); r++) a[c][r] -= f * vr[r];
+            if (l16 == 0) hssk_gstore(R1, (size_t)k + (size_t)col * p.ld1, tc - f);
+          }
+        }
+      }
+      if (tid < m) s_t[((k + 1) & 1) * NC * CT + tid] = trow;   // (read behind the next step's barrier)
+    }
+  }
+}
+#undef RC
+
 template <int RT, int CT, int NW>
 void launch_qr_reg(hssk_ctx* ctx, const hssk_qr_desc* dd, int count) {
   HSSK_LAUNCH((qr_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
@@ -680,6 +790,25 @@ extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int
     auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
     formq_reg(ctx, dd, descs, count, rmax);   // rmax <= 256 (taller panels took the blocked path above)
   }
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_tpqr_vbatched(hssk_ctx* ctx, const hssk_tpqr_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  int mmax = 0;
+  for (int i = 0; i < count; i++) {
+    if (descs[i].m < 0 || descs[i].ld1 < descs[i].m || descs[i].ld2 < descs[i].m) return 2;
+    mmax = std::max(mmax, descs[i].m);
+  }
+  if (mmax == 0) return 0;
+  if (mmax > 224) return 2;   // (beyond the register tile: the caller stacks the triangles and calls hssk_qr_vbatched)
+  auto* dd = (const hssk_tpqr_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  if (mmax <= 64) HSSK_LAUNCH((tpqr_reg_kernel<4, 2, 8>), dim3((unsigned)count), dim3(512), 0, ctx->stream, dd);
+  else if (mmax <= 128) HSSK_LAUNCH((tpqr_reg_kernel<8, 4, 8>), dim3((unsigned)count), dim3(512), 0, ctx->stream, dd);
+  else if (mmax <= 208) HSSK_LAUNCH((tpqr_reg_kernel<13, 7, 8>), dim3((unsigned)count), dim3(512), 0, ctx->stream, dd);
+  else HSSK_LAUNCH((tpqr_reg_kernel<14, 7, 8>), dim3((unsigned)count), dim3(512), 0, ctx->stream, dd);
   hssk_rt::check_launch();
   HSSK_API_END
 }

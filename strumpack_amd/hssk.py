@@ -77,6 +77,10 @@ class UlvSplitDesc(C.Structure):
                 ("X", C.c_void_p), ("ldx", C.c_int), ("W1", C.c_void_p), ("ldw", C.c_int), ("W0t", C.c_void_p), ("ldt", C.c_int)]
 
 
+class TpqrDesc(C.Structure):
+    _fields_ = [("R1", C.c_void_p), ("ld1", C.c_int), ("R2", C.c_void_p), ("ld2", C.c_int), ("m", C.c_int)]
+
+
 class XsolveDesc(C.Structure):
     _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("rank", C.c_int), ("m", C.c_int),
                 ("X", C.c_void_p), ("ldx", C.c_int), ("solved", C.c_int)]
@@ -124,7 +128,7 @@ HSSK_SYMBOLS = [
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
     "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
     "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict", "hssk_copy_triu",
-    "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
+    "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
 ]
 
@@ -219,7 +223,7 @@ class Hssk:
                      "hssk_gather_elems", "hssk_transpose", "hssk_id_vbatched", "hssk_qr_vbatched",
                      "hssk_trsm_vbatched", "hssk_getrf_vbatched", "hssk_getrs_vbatched",
                      "hssk_sumsq_vbatched", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
-                     "hssk_id_xsolve_vbatched", "hssk_gather_combine", "hssk_ulv_split"):
+                     "hssk_id_xsolve_vbatched", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_id_solves_inline.argtypes = [C.c_int, C.c_int]
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]

@@ -552,3 +552,27 @@ def case_ulv_split(hk, shapes, seed=51):
         if q:
             assert np.abs(g0[:m, :q] - w0t).max() <= 1e-12 * max(1.0, np.abs(w0t).max()) * max(r, 1)
         assert np.all(g0[m:] == -6.0)
+
+
+def case_tpqr(hk, sizes, seed=61):
+    """hssk_tpqr_vbatched vs numpy: R of [triu(R1); triu(R2)] in place over R1 (signs of the rows are free: R^T R is compared,
+    and the magnitudes of the diagonal)."""
+    r = rng(seed)
+    descs, keep = [], []
+    for m in sizes:
+        A1, A2 = r.standard_normal((m + 2, m)), r.standard_normal((m + 5, m))   # below the diagonals: junk that must be ignored
+        d1, d2 = hk.array(A1), hk.array(A2)
+        keep.append((A1, A2, d1, d2, m))
+        descs.append(K.TpqrDesc(d1.ptr, m + 2, d2.ptr, m + 5, m))
+    hk.batch("hssk_tpqr_vbatched", descs)
+    hk.sync()
+    for (A1, A2, d1, d2, m) in keep:
+        S = np.vstack([np.triu(A1[:m]), np.triu(A2[:m])])
+        Rref = np.linalg.qr(S, mode="r")
+        got = d1.get()
+        R = np.triu(got[:m])
+        assert np.array_equal(np.tril(got[:m], -1), np.tril(A1[:m], -1)) and np.array_equal(got[m:], A1[m:]), "wrote outside the upper triangle"
+        assert np.array_equal(d2.get(), A2), "R2 was modified"
+        scale = np.abs(Rref).max()
+        assert np.abs(R.T @ R - Rref.T @ Rref).max() <= 1e-12 * scale * scale * m
+        assert np.abs(np.abs(np.diag(R)) - np.abs(np.diag(Rref))).max() <= 1e-11 * scale

@@ -123,3 +123,7 @@ def test_qr_early_exit(hk):
 
 def test_ulv_split(hk):
     KC.case_ulv_split(hk, [(40, 7), (33, 33), (70, 0), (82, 41), (5, 2)])
+
+
+def test_tpqr(hk):
+    KC.case_tpqr(hk, [1, 5, 33, 64, 70, 130])

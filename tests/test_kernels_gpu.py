@@ -135,3 +135,8 @@ def test_qr_early_exit(hk):
 def test_ulv_split(hk):
     KC.case_ulv_split(hk, [(40, 7), (33, 33), (70, 0), (82, 41), (5, 2)])
     KC.case_ulv_split(hk, [(195, 36), (196, 30), (256, 100)] * 3, seed=53)
+
+
+def test_tpqr(hk):
+    KC.case_tpqr(hk, [1, 5, 33, 64, 70, 130])
+    KC.case_tpqr(hk, [195, 196, 106, 208, 224, 209] * 2, seed=63)
