@@ -141,24 +141,32 @@ typedef unsigned long long knn_key_t;
 __device__ __forceinline__ knn_key_t knn_pack(float key, int idx) { return ((knn_key_t)hssk_fbits(key) << 32) | (unsigned)idx; }
 constexpr knn_key_t KNN_EMPTY = ((knn_key_t)0x7f61b1e6u << 32) | 0x7fffffffu;   // (3.0e38f, INT_MAX): above every real key
 
-template <int DM, int Q>
+// LQ lanes per query: each of them takes every LQ-th candidate of a trip and keeps its own pending list; the page (heap) of
+// the query is shared.  LQ = 1 is the layout described above.  LQ = 4 quarters the LDS footprint per wave (16 queries: 8 KB
+// of heaps), so several waves share a SIMD and cover each other's LDS and FP64 latencies -- with one query per lane the
+// 128 KB of heaps per 256 queries left ONE wave per SIMD, which issues one instruction per 4-cycle slot whatever its type
+// (profiles/r02_pmc_knn.md).  The price is paid in the flush, which takes the LQ lane groups of a query in turn.
+template <int DM, int Q, int LQ>
 __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
                                                     const knn_key_t* __restrict__ lb, int* __restrict__ out_idx, int ldo,
                                                     knn_key_t* __restrict__ ub) {
-  constexpr int CT = KNN_TILE / DM;             // candidates per tile (4 KB of coordinates)
-  constexpr int U = DM <= 16 ? 4 : (DM <= 32 ? 2 : 1);   // candidates per trip (their coordinates sit in registers)
-  constexpr int NL = KNN_TILE / Q;              // tile elements per lane
-  static_assert(KNN_TILE % Q == 0 && CT % (2 * U) == 0, "tile shape");
-  HSSK_SHARED knn_key_t hh[KNN_P * Q];
+  constexpr int TILE = KNN_TILE * LQ;           // coordinates per tile: a tile lasts as many trips whatever LQ
+  constexpr int CT = TILE / DM;                 // candidates per tile
+  constexpr int U = DM <= 16 ? 4 : (DM <= 32 ? 2 : 1);   // candidates per lane and trip (their coordinates sit in registers)
+  constexpr int NL = TILE / Q;                  // tile elements per lane
+  constexpr int NQ = Q / LQ;                    // queries per workgroup
+  constexpr int TRIP = U * LQ;                  // candidates per trip
+  static_assert(TILE % Q == 0 && CT % (2 * TRIP) == 0 && Q % LQ == 0 && 64 % LQ == 0, "tile shape");
+  HSSK_SHARED knn_key_t hh[KNN_P * NQ];
   HSSK_SHARED knn_key_t pend[KNN_PEND * Q];
-  HSSK_SHARED double xc[2 * KNN_TILE];          // two tiles: the next one is written while the current one is read
-  const int tid = threadIdx.x;
-  const int q = q0 + blockIdx.x * Q + tid;
+  HSSK_SHARED double xc[2 * TILE];          // two tiles: the next one is written while the current one is read
+  const int tid = threadIdx.x, ql = tid / LQ, part = tid % LQ;
+  const int q = q0 + blockIdx.x * NQ + ql;
   const bool live = q < q1;
   double xq[DM];
 #pragma unroll
   for (int j = 0; j < DM; j++) xq[j] = (live && j < d) ? X[(size_t)q * d + j] : 0.;
-  for (int s = 0; s < kpage; s++) hh[s * Q + tid] = KNN_EMPTY;
+  for (int s = part; s < kpage; s += LQ) hh[s * NQ + ql] = KNN_EMPTY;
   // keys of this page lie in [lo, worst): lo = the previous page's largest key + 1; a lane without a query accepts nothing
   const knn_key_t lo = (lb && live) ? lb[q] + 1 : 0;
   knn_key_t worst = live ? KNN_EMPTY : 0;
@@ -169,30 +177,38 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
     for (;;) {
       const int l = 2 * pos + 1, r = l + 1;
       if (l >= kpage) break;
-      knn_key_t kc = hh[l * Q + tid];
+      knn_key_t kc = hh[l * NQ + ql];
       int c = l;
       if (r < kpage) {
-        const knn_key_t kr = hh[r * Q + tid];
+        const knn_key_t kr = hh[r * NQ + ql];
         if (kr > kc) { kc = kr; c = r; }
       }
       if (kc <= K) break;
-      hh[pos * Q + tid] = kc;
+      hh[pos * NQ + ql] = kc;
       pos = c;
     }
-    hh[pos * Q + tid] = K;
-    worst = hh[tid];
+    hh[pos * NQ + ql] = K;
+    worst = hh[ql];
   };
+  // the lanes of a query take turns (they sit in one wave: LDS operations of a wave execute in order, so a turn sees the
+  // heap its predecessor left); within a turn all queries of the wave insert side by side
   auto flush = [&]() {
-    for (int s = 0; hssk_any(s < cnt); s++)
-      if (s < cnt) {
-        const knn_key_t K = pend[s * Q + tid];
-        if (K < worst) insert(K);
-      }
+#pragma unroll
+    for (int turn = 0; turn < LQ; turn++) {
+      if (LQ > 1 && live) worst = hh[ql];
+      for (int s = 0; hssk_any(part == turn && s < cnt); s++)
+        if (part == turn && s < cnt) {
+          const knn_key_t K = pend[s * Q + tid];
+          if (K < worst) insert(K);
+        }
+    }
+    if (LQ > 1 && live) worst = hh[ql];
     cnt = 0;
   };
+  if (LQ > 1) __syncthreads();   // (the heaps are initialised by all lanes of a query)
   // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
   // spatial neighbours, the page threshold tightens at once and later tiles rarely insert (same result set)
-  const int ntile = (n + CT - 1) / CT, own = (q0 + blockIdx.x * Q) / CT;
+  const int ntile = (n + CT - 1) / CT, own = (q0 + blockIdx.x * NQ) / CT;
   const double inf = __builtin_huge_val();
   // own, own+1, own-1, own+2, own-2, ...: in cluster order index distance tracks spatial distance
   auto tile_start = [&](int t) {
@@ -215,17 +231,17 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
   };
   tile_fetch(0);
   for (int t = 0; t < ntile; t++) {
-    double* tile = xc + (t & 1) * KNN_TILE;
+    double* tile = xc + (t & 1) * TILE;
 #pragma unroll
     for (int r = 0; r < NL; r++) tile[tid + Q * r] = v[r];
     // one barrier per tile: the buffer written here was last read two tiles ago, before the previous barrier
     __syncthreads();
     if (t + 1 < ntile) tile_fetch(t + 1);
     const int c0 = tile_start(t);
-    // a trip: U candidates against the lane's query, their keys appended to the pending list
+    // a trip: U candidates per lane (candidate c + u LQ + part: the LQ lanes of a query read neighbouring candidates, whose
+    // 64-byte records fall on different LDS banks) against the lane's query, their keys appended to the pending list
     auto trip = [&](int c, const double (&b)[U][DM]) {
-      // coordinate-major: the U chains (one per candidate) advance side by side, so consecutive instructions are
-      // independent -- with one wave per SIMD a dependent FP64 instruction waits out the full pipeline latency
+      // coordinate-major: the U chains (one per candidate) advance side by side, so consecutive instructions are independent
       double s2[U];
 #pragma unroll
       for (int u = 0; u < U; u++) s2[u] = 0.;
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int g = c0 + c + u;
+        const int g = c0 + c + u * LQ + part;
         const knn_key_t K = knn_pack((float)s2[u], g);
         pend[cnt * Q + tid] = K;   // kept only if the candidate passes (the slot is overwritten otherwise)
         cnt += (int)((K >= lo) & (K < worst) & (g != q));
@@ -256,28 +272,38 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int j = 0; j < DM; j++) b[u][j] = tile[(c + u) * DM + j];
+        for (int j = 0; j < DM; j++) b[u][j] = tile[(c + u * LQ + part) * DM + j];
     };
-    // software pipeline over the tile: the LDS reads of the next trip are in flight while this one computes (one
-    // wave per SIMD: nothing else hides their latency)
-    double b0[U][DM], b1[U][DM];
-    fetch(0, b0);
-    for (int c = 0; c < CT; c += 2 * U) {
-      fetch(c + U, b1);
-      trip(c, b0);
-      if (hssk_any(cnt > KNN_PEND - U)) flush();
-      if (c + 2 * U < CT) fetch(c + 2 * U, b0);
-      trip(c + U, b1);
-      if (hssk_any(cnt > KNN_PEND - U)) flush();
+    if (LQ == 1) {
+      // software pipeline over the tile: the LDS reads of the next trip are in flight while this one computes (one
+      // wave per SIMD: nothing else hides their latency)
+      double b0[U][DM], b1[U][DM];
+      fetch(0, b0);
+      for (int c = 0; c < CT; c += 2 * TRIP) {
+        fetch(c + TRIP, b1);
+        trip(c, b0);
+        if (hssk_any(cnt > KNN_PEND - U)) flush();
+        if (c + 2 * TRIP < CT) fetch(c + 2 * TRIP, b0);
+        trip(c + TRIP, b1);
+        if (hssk_any(cnt > KNN_PEND - U)) flush();
+      }
+    } else {
+      // (several waves per SIMD: they cover each other, and the second register set is better spent on occupancy)
+      double b0[U][DM];
+      for (int c = 0; c < CT; c += TRIP) {
+        fetch(c, b0);
+        trip(c, b0);
+        if (hssk_any(cnt > KNN_PEND - U)) flush();
+      }
     }
   }
   flush();
   if (!live) return;
-  for (int s = 0; s < kpage; s++) {
-    const knn_key_t K = hh[s * Q + tid];
+  for (int s = part; s < kpage; s += LQ) {
+    const knn_key_t K = hh[s * NQ + ql];
     out_idx[(size_t)q * ldo + s] = K == KNN_EMPTY ? -1 : (int)(K & 0xffffffffu);
   }
-  if (ub) ub[q] = worst;
+  if (ub && part == 0) ub[q] = worst;
 }
 
 // prediction[c] = sum_r w[r] k(x_r, t_c)   (no lambda: train and test points are different sets)
@@ -373,10 +399,14 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
     const knn_key_t* lb = pg ? kb + (size_t)((pg - 1) & 1) * n : nullptr;
     knn_key_t* ub = kb + (size_t)(pg & 1) * n;
     int* oi = out_idx + pg * KNN_P;
-    if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256>), dim3((unsigned)((q1 - q0 + 256 - 1) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 128>), dim3((unsigned)((q1 - q0 + 128 - 1) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else HSSK_LAUNCH((knn_kernel<64, 128>), dim3((unsigned)((q1 - q0 + 128 - 1) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    // (queries per workgroup: threads / lanes per query)
+    static const bool lq1 = [] { const char* e = std::getenv("HSSK_KNN_LQ"); return e && e[0] == '1'; }();
+    const int nqr = q1 - q0;
+    if (d <= 8 && !lq1) HSSK_LAUNCH((knn_kernel<8, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256, 1>), dim3((unsigned)((nqr + 255) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else HSSK_LAUNCH((knn_kernel<64, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
   }
   hssk_rt::check_launch();
   HSSK_API_END
