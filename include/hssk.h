@@ -321,6 +321,9 @@ typedef struct hssk_qr_desc {
    * tolerance" is decided exactly as by the full factorisation (which runs when no step qualifies); A and work are left
    * incomplete after an early exit.  0 / 0: never.  Honoured by the register kernels, ignored (full sweep) elsewhere. */
   double stop_rel, stop_abs;
+  /* r_only != 0 (nq == 0): only R is wanted -- the register kernels then write back the upper triangle alone (the reflectors
+   * and the taus are dropped: half the stores of a TSQR chunk); ignored elsewhere. */
+  int r_only;
 } hssk_qr_desc;
 int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int count);
 /* R1 (m x m, upper triangle, updated in place) <- R of the QR factorisation of [triu(R1); triu(R2)]: the merge step of a

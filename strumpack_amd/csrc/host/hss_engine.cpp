@@ -1473,7 +1473,7 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
     for (int r0 = 0; r0 < d; r0 += chunk) {
       const int cr = std::min(chunk, d - r0);
       double* wk = tmp.dbl((size_t)cr + m);
-      qr.push_back(hssk_qr_desc{Ws[k] + r0, d, cr, m, nullptr, 0, 0, nullptr, wk});
+      qr.push_back(hssk_qr_desc{Ws[k] + r0, d, cr, m, nullptr, 0, 0, nullptr, wk, 0, 0., 0., 1});   // (only R is read again)
       pieces[k].push_back(Piece{Ws[k] + r0, d, std::min(cr, m)});
     }
     any = true;
@@ -1520,7 +1520,7 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
           r0 += pc[i + t].rows;
         }
         double* wk = tmp.dbl((size_t)rows + m);
-        qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk, stair ? (int)cntp : 0});
+        qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk, stair ? (int)cntp : 0, 0., 0., 1});
         next.push_back(Piece{dst, rows, std::min(rows, m)});
       }
       pc.swap(next);
@@ -1720,14 +1720,28 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
           rows[q].resize(nd.m);
           for (int i = 0; i < nd.m; i++) rows[q][i] = lo + i;
           if (nd.lvl > 0) {
-            cs.reserve((size_t)nd.m * k);
+            // sorted, duplicate-free ids outside the node: marked in a bitmap over the point set and read back in order
+            // (m k ~ 1e4 ids per leaf: cheaper than sorting them)
+            std::vector<unsigned long long> bits(((size_t)N + 63) / 64, 0ULL);
+            size_t marked = 0;
             for (int i = lo; i < hi; i++)
               for (int j = 0; j < k; j++) {
                 const int g = ann[(size_t)i * k + j];
-                if (g >= 0 && (g < lo || g >= hi)) cs.push_back(g);
+                if (g >= 0 && (g < lo || g >= hi)) {
+                  unsigned long long& wd = bits[(size_t)g >> 6];
+                  const unsigned long long b = 1ULL << (g & 63);
+                  marked += !(wd & b);
+                  wd |= b;
+                }
               }
-            std::sort(cs.begin(), cs.end());
-            cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+            cs.reserve(marked);
+            for (size_t wi = 0; wi < bits.size(); wi++) {
+              unsigned long long wd = bits[wi];
+              while (wd) {
+                cs.push_back((int)(wi * 64 + (size_t)__builtin_ctzll(wd)));
+                wd &= wd - 1;
+              }
+            }
           }
         } else {
           Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];

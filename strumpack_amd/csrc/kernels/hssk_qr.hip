@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
   const int l16 = lane & 15, sub = lane >> 4, grp = wave * 4 + sub;
   const int rows = p.rows, cols = p.cols;
   const int kmax = rows < cols ? rows : cols;
+  const bool r_only = p.r_only != 0 && p.nq == 0;
   const bool may_stop = p.rdiag && p.nq == 0 && (p.stop_rel > 0. || p.stop_abs > 0.);
   if (tid == 0) s_stop = 0;
   bool done = false;
@@ -218,10 +219,11 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       const int row = l16 + 16 * r, col = grp + NC * c;
-      if (row < rows && col < cols) p.A[row + (size_t)col * p.lda] = a[c][r];
+      if (row < rows && col < cols && (!r_only || row <= col)) p.A[row + (size_t)col * p.lda] = a[c][r];
     }
   __syncthreads();
-  for (int k = tid; k < kmax; k += NW * 64) p.work[k] = s_tau[k];
+  if (!r_only)
+    for (int k = tid; k < kmax; k += NW * 64) p.work[k] = s_tau[k];
   if (p.rdiag && tid == 0) { p.rdiag[0] = kmax ? s_rd[0] : 0.; p.rdiag[1] = kmax ? s_rd[1] : 0.; }
 }
 

@@ -90,7 +90,7 @@ class QrDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("rows", C.c_int), ("cols", C.c_int),
                 ("Q", C.c_void_p), ("ldq", C.c_int), ("nq", C.c_int),
                 ("rdiag", C.c_void_p), ("work", C.c_void_p), ("stair", C.c_int),
-                ("stop_rel", C.c_double), ("stop_abs", C.c_double)]
+                ("stop_rel", C.c_double), ("stop_abs", C.c_double), ("r_only", C.c_int)]
 
 
 class TrsmDesc(C.Structure):
