@@ -13,6 +13,7 @@
 #include "hss_engine.hpp"
 #include "Comm.hpp"
 
+#include <unistd.h>
 #include <atomic>
 #include <functional>
 #include <condition_variable>
@@ -112,6 +113,7 @@ class HostPool {
   // runs body() on every worker and on the caller; returns when all are done.  One job at a time: a second caller
   // (another matrix on another thread) finds the pool busy and runs its loop alone.
   bool run(const std::function<void()>& body) {
+    if (getpid() != pid_) return false;   // (a forked child has the pool object but not its threads: it works alone)
     std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
     if (!own.owns_lock() || th_.empty()) return false;
     {
@@ -126,13 +128,14 @@ class HostPool {
     return true;
   }
   ~HostPool() {
+    if (getpid() != pid_) { for (auto& t : th_) t.detach(); return; }
     { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
 
  private:
-  HostPool() {
+  HostPool() : pid_(getpid()) {
     const unsigned n = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     for (unsigned t = 1; t < n; t++) th_.emplace_back([this] { loop(); });
   }
@@ -151,6 +154,7 @@ class HostPool {
       { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_all(); }
     }
   }
+  const pid_t pid_;
   std::vector<std::thread> th_;
   std::mutex owner_, mu_;
   std::condition_variable cv_, done_;
