@@ -358,10 +358,12 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
         for (int c = 0; c < CT; c++)
           if (c == cp) {
             double s = 0.;
+            // (row registers before the pivot row's are above it, those behind it below; only register rk needs a lane test.
+            // Rows beyond d hold zeros.)
 #pragma unroll
             for (int r = 0; r < RT; r++) {
-              const int row = l16 + 16 * r;
-              if (row > k && row < d) s += a[c][r] * a[c][r];
+              if (r > rk) s += a[c][r] * a[c][r];
+              else if (r == rk && l16 > lk) s += a[c][r] * a[c][r];
             }
             const double alpha = hssk_shfl(a[c][rk], (lane & 48) | lk);
             s = hssk_row_sum(s);
@@ -376,9 +378,13 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
 #pragma unroll
               for (int r = 0; r < RT; r++) {
                 const int row = l16 + 16 * r;
-                if (row > k && row < d) a[c][r] *= scal;
-                sv[row] = row > k ? a[c][r] : (row == k ? 1. : 0.);
-                if (row == k) a[c][r] = beta;
+                if (r < rk) sv[row] = 0.;
+                else if (r > rk) { a[c][r] *= scal; sv[row] = a[c][r]; }
+                else {
+                  if (l16 > lk) a[c][r] *= scal;
+                  sv[row] = l16 > lk ? a[c][r] : (l16 == lk ? 1. : 0.);
+                  if (l16 == lk) a[c][r] = beta;
+                }
               }
               used |= 1u << c;
               if (l16 == 0) {
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
 #pragma unroll
           for (int r = 0; r < RT; r++) {
             const int row = l16 + 16 * r;
-            if (row > k && row < d) s2 += a[c][r] * a[c][r];
+            if (r > rk || (r == rk && l16 > lk)) s2 += a[c][r] * a[c][r];
           }
           s2 = hssk_row_sum(s2);
           if (recompute) {

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
 #pragma unroll
           for (int r = 0; r < RT; r++) {
             const int row = l16 + 16 * r;
-            if (row > k && row < rows) s += a[kc][r] * a[kc][r];
+            if (r > rk || (r == rk && l16 > lk)) s += a[kc][r] * a[kc][r];   // (static in r: rows beyond `rows` hold zeros)
           }
           const double alpha = hssk_shfl(a[kc][rk], (lane & 48) | lk);
           s = hssk_row_sum(s);
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
 #pragma unroll
             for (int r = 0; r < RT; r++) {
               const int row = l16 + 16 * r;
-              if (row > k && row < rows) a[kc][r] *= scal;
-              sv[row] = row > k ? a[kc][r] : (row == k ? 1. : 0.);
-              if (row == k) a[kc][r] = beta;
+              if (r > rk || (r == rk && l16 > lk)) a[kc][r] *= scal;
+              sv[row] = r < rk ? 0. : (r > rk ? a[kc][r] : (l16 > lk ? a[kc][r] : (l16 == lk ? 1. : 0.)));
+              if (r == rk && l16 == lk) a[kc][r] = beta;
             }
             if (l16 == 0) {
               s_tau[k] = tau;
