@@ -576,3 +576,25 @@ def case_tpqr(hk, sizes, seed=61):
         scale = np.abs(Rref).max()
         assert np.abs(R.T @ R - Rref.T @ Rref).max() <= 1e-12 * scale * scale * m
         assert np.abs(np.abs(np.diag(R)) - np.abs(np.diag(Rref))).max() <= 1e-11 * scale
+
+
+def case_qr_r_only(hk, shapes, seed=71):
+    """hssk_qr_desc.r_only: the upper triangle of the factored panel equals the one of the full factorisation; the register
+    kernels leave what is below it alone.  shapes: (rows, cols)"""
+    r = rng(seed)
+    full, ronly, keep = [], [], []
+    for (rows, cols) in shapes:
+        A = r.standard_normal((rows, cols))
+        d1, d2 = hk.array(A), hk.array(A)
+        w1, w2 = hk.empty((rows + cols,)), hk.empty((rows + cols,))
+        keep.append((A, d1, d2, w1, w2))
+        full.append(K.QrDesc(d1.ptr, rows, rows, cols, None, rows, 0, None, w1.ptr, 0, 0.0, 0.0, 0))
+        ronly.append(K.QrDesc(d2.ptr, rows, rows, cols, None, rows, 0, None, w2.ptr, 0, 0.0, 0.0, 1))
+    hk.batch("hssk_qr_vbatched", full)
+    hk.batch("hssk_qr_vbatched", ronly)
+    hk.sync()
+    for (A, d1, d2, w1, w2) in keep:
+        F, R = d1.get(), d2.get()
+        assert np.array_equal(np.triu(F), np.triu(R))
+        low = np.tril(R, -1)
+        assert np.array_equal(low, np.tril(A, -1)) or np.array_equal(low, np.tril(F, -1))   # untouched, or the full write-back

@@ -127,3 +127,7 @@ def test_ulv_split(hk):
 
 def test_tpqr(hk):
     KC.case_tpqr(hk, [1, 5, 33, 64, 70, 130])
+
+
+def test_qr_r_only(hk):
+    KC.case_qr_r_only(hk, [(60, 40), (128, 100), (208, 195), (256, 120), (300, 64)])
