@@ -1005,6 +1005,8 @@ bool DeviceHSS::plans_enabled() const {
 }
 
 void DeviceHSS::reset_compression() {
+  book_ = PendingBook();   // (a compression that threw may have left an ID commit half done)
+  defer_book_ = false;
   drop_plans();
   for (auto& nd : nodes_) {
     int lo = nd.lo, m = nd.m, lvl = nd.lvl, h = nd.height, c0 = nd.c0, c1 = nd.c1, p = nd.parent;
