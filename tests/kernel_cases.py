@@ -598,3 +598,22 @@ def case_qr_r_only(hk, shapes, seed=71):
         assert np.array_equal(np.triu(F), np.triu(R))
         low = np.tril(R, -1)
         assert np.array_equal(low, np.tril(A, -1)) or np.array_equal(low, np.tril(F, -1))   # untouched, or the full write-back
+
+
+def case_contract_codes(hk):
+    """Return code 2 (caller composes the step from other entry points) of the size-limited kernels, and empty work."""
+    import ctypes as C_
+    d = hk.array(np.zeros((300, 300)))
+    i = hk.array(np.arange(300, dtype=np.int32))
+
+    def rc(fn, desc):
+        arr = (type(desc) * 1)(desc)
+        return getattr(hk.lib, fn)(hk.ctx, arr, 1)
+    assert rc("hssk_ulv_split", K.UlvSplitDesc(d.ptr, 300, 257, 10, i.ptr, d.ptr, 10, d.ptr, 10, d.ptr, 257)) == 2
+    assert rc("hssk_ulv_split", K.UlvSplitDesc(d.ptr, 300, 0, 0, i.ptr, d.ptr, 1, d.ptr, 1, d.ptr, 1)) == 0
+    assert rc("hssk_tpqr_vbatched", K.TpqrDesc(d.ptr, 300, d.ptr, 300, 225)) == 2
+    assert rc("hssk_tpqr_vbatched", K.TpqrDesc(d.ptr, 300, d.ptr, 300, 0)) == 0
+    # a combine with nothing to write, and one whose product has no operand
+    assert rc("hssk_gather_combine", K.CombineDesc(d.ptr, None, 300, 300, None, None, None, 300, 300, None, None, 1, 1, 1.0, d.ptr, 300, 0, 5, 3)) == 0
+    assert rc("hssk_gather_combine", K.CombineDesc(d.ptr, None, 300, 300, None, None, None, 300, 300, None, None, 1, 1, 1.0, d.ptr, 300, 4, 5, 3)) == 2
+    hk.sync()

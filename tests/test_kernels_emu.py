@@ -131,3 +131,7 @@ def test_tpqr(hk):
 
 def test_qr_r_only(hk):
     KC.case_qr_r_only(hk, [(60, 40), (128, 100), (208, 195), (256, 120), (300, 64)])
+
+
+def test_contract_codes(hk):
+    KC.case_contract_codes(hk)
