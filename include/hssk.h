@@ -64,6 +64,10 @@ int hssk_memset_zero(hssk_ctx* ctx, void* dst, long long bytes); /* async */
  * (structured/StructuredMatrix.cpp:214-262 never stores A either). */
 int hssk_h2d_block_async(hssk_ctx* ctx, double* dst, long long ldd, const double* src, long long lds, long long rows,
                          long long cols);
+/* The same for a block of `cols` columns of `width` bytes each (pitches in bytes): operands of the other scalar types, which
+ * cross the link in their own format (hssk_expand_image). */
+int hssk_h2d_bytes_async(hssk_ctx* ctx, void* dst, long long dpitch, const void* src, long long spitch, long long width,
+                         long long cols);
 int hssk_copy_fence(hssk_ctx* ctx);
 int hssk_compute_fence(hssk_ctx* ctx);
 /* The same dependency in two halves, for double-buffered streams: hssk_compute_mark(slot) remembers the compute work enqueued
@@ -169,6 +173,15 @@ typedef struct hssk_colgather_desc {
   int scatter; /* 1: dst(:, idx[j]) = src(:, j) */
 } hssk_colgather_desc;
 int hssk_gather_cols(hssk_ctx* ctx, const hssk_colgather_desc* descs, int count);
+/* Real double-precision image of a column-major block (rows x cols scalars, leading dimension lds scalars) of another scalar
+ * type, already on the device (the float / complex instantiations of the reference, HSS/HSSMatrix.cpp:513-516, are carried by
+ * the double-precision engine):
+ *   HSSK_DT_F32: dst(i, j) = (double) src(i, j)                                          -- dst is rows x cols;
+ *   HSSK_DT_C32 / HSSK_DT_C64: dst(2i + a, 2j + b) = [re -im; im re](a, b) of src(i, j)     -- dst is 2 rows x 2 cols.
+ * ldd in doubles.  Compute stream. */
+enum { HSSK_DT_F64 = 0, HSSK_DT_F32 = 1, HSSK_DT_C32 = 2, HSSK_DT_C64 = 3 };
+int hssk_expand_image(hssk_ctx* ctx, double* dst, long long ldd, const void* src, long long lds, long long rows, long long cols,
+                      int dtype);
 /* dst(i, :) = src(idx[i], :)  (scatter: dst(idx[i], :) = src(i, :)); accumulate: += */
 typedef struct hssk_rowgather_desc {
   const double* src;

@@ -134,6 +134,10 @@ void HSSMatrix<double>::compress(const DenseM_t& A, const opts_t& opts) {
   make_engine(opts, tree_.get());
   eng_->compress_dense_host(A.data(), A.ld());
 }
+void HSSMatrix<double>::compress_image(const void* A, std::size_t lda, int dtype, const opts_t& opts) {
+  make_engine(opts, tree_.get());
+  eng_->compress_dense_host_typed(A, (long long)lda, dtype);
+}
 void HSSMatrix<double>::compress_device(const double* dA, long long lda, const opts_t& opts) {
   make_engine(opts, tree_.get());
   eng_->compress_dense_device(dA, lda);

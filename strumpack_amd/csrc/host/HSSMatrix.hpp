@@ -90,6 +90,9 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   ~HSSMatrix() override;
 
   void compress(const DenseM_t& A, const opts_t& opts);
+  // extension (HSSMatrixPromoted.hpp): this matrix is the real image of a host matrix of another scalar type (dtype =
+  // HSSK_DT_F32 / _C32 / _C64, lda in scalars)
+  void compress_image(const void* A, std::size_t lda, int dtype, const opts_t& opts);
   void compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts);
   // extension: operand given by element evaluation only -- the columns are evaluated in blocks on the host threads and
   // streamed through the device (the reference's tile sampler, structured/StructuredMatrix.cpp:214-262)

@@ -9,7 +9,9 @@
 //                       ordering a complex vector IS its real image in memory (re, im, re, im ...), so mult / solve
 //                       operate on the caller's complex buffers in place; Ahat^T is the image of A^H.  Column 2j of
 //                       Ahat is column j of A viewed as reals, column 2j+1 the image of i A(:, j): the operand is
-//                       streamed through the device block by block (DeviceHSS::HostBlockSource), never stored;
+//                       streamed through the device block by block IN ITS OWN FORMAT (half the bytes of the image, a
+//                       quarter for complex<float>; a float matrix half the bytes of its promotion) and expanded there
+//                       (hssk_expand_image, DeviceHSS::HostBlockSource), never stored;
 //   complex<float>   -> promoted to complex<double>.
 // Cost of the embedding against a native complex engine: 2x the stored reals and ~2x the flops at equal accuracy
 // (4 real multiplications per complex one either way, but the sketch carries 2r instead of r columns).
@@ -48,9 +50,9 @@ template <typename T> class HSSMatrixPromoted : public structured::StructuredMat
 
   void compress(const DenseM_t& A, const opts_t& opts) {
     if (A.rows() != rows_ || A.cols() != cols_) throw std::invalid_argument("compress: matrix dimensions do not match");
-    const T* a = A.data();
-    const std::size_t lda = A.ld();
-    compress_elements_raw([a, lda](std::size_t i, std::size_t j) { return a[i + lda * j]; }, opts);
+    // the operand crosses the link in its own format and is expanded to its image on the device
+    const int dtype = std::is_same<T, float>::value ? 1 : std::is_same<T, std::complex<float>>::value ? 2 : 3;   // HSSK_DT_*
+    H_->compress_image(A.data(), A.ld(), dtype, scaled(opts));
   }
   void compress(const elem_t& Aelem, const opts_t& opts) {
     // block evaluation of the image from block evaluations of A
@@ -176,14 +178,6 @@ template <typename T> class HSSMatrixPromoted : public structured::StructuredMat
     structured::ClusterTree base = t ? *t : bisect(int(rows_), o.leaf_size());
     H_.reset(new HSSMatrix<double>(doubled(base), scaled(o)));
   }
-  template <class F> void compress_elements_raw(F a, const opts_t& opts) {
-    typename HSSMatrix<double>::elem_t img = [a](const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseMatrix<double>& B) {
-      for (std::size_t j = 0; j < J.size(); j++)
-        for (std::size_t i = 0; i < I.size(); i++) B(i, j) = image(a(I[i] / W, J[j] / W), I[i] % W, J[j] % W);
-    };
-    H_->compress_from_elements(img, scaled(opts));
-  }
-
   std::size_t rows_ = 0, cols_ = 0;
   std::unique_ptr<HSSMatrix<double>> H_;
 };

@@ -114,8 +114,11 @@ class HostPool {
   // (another matrix on another thread) finds the pool busy and runs its loop alone.
   bool run(const std::function<void()>& body) {
     if (getpid() != pid_) return false;   // (a forked child has the pool object but not its threads: it works alone)
+    static thread_local bool inside = false;   // a loop started from inside a pool job runs on its own thread
+    if (inside) return false;
     std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
     if (!own.owns_lock() || th_.empty()) return false;
+    struct Mark { bool& f; Mark(bool& x) : f(x) { f = true; } ~Mark() { f = false; } } mark(inside);
     {
       std::lock_guard<std::mutex> g(mu_);
       body_ = &body; pending_ = th_.size(); gen_++;
@@ -398,33 +401,63 @@ struct DeviceHSS::ShardedDenseSource : DeviceHSS::Source {
 //   Sr(:, :)     += A(:, c0:c1) R(c0:c1, :)    -- the block's contribution to every row
 // The diagonal blocks and the coupling blocks are read from the host operand afterwards (contiguous 2-D copies, resp. a
 // multi-threaded host gather of the few scattered entries + one upload).  At most 2 x n x nb doubles of A are in HBM.
+// An operand of another scalar type (float, complex<float>, complex<double>: `dtype`, the reference's other instantiations,
+// HSS/HSSMatrix.cpp:513-516) crosses the link in ITS format -- half / a quarter of the bytes of its double-precision real image --
+// into two staging buffers; hssk_expand_image writes the image of a block (interleaved [re -im; im re] for complex scalars,
+// HSSMatrixPromoted.hpp) into the one block buffer the GEMMs read.
 struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
-  const double* hA;        // column-major host matrix, or null when `fill` evaluates the columns
-  long long lda;
+  const void* hA;          // column-major host matrix (scalars of `dtype`), or null when `fill` evaluates the columns
+  long long lda;           // in scalars
+  int dtype = HSSK_DT_F64;
   const host_fill_t* fill;
   const host_elem_t* elem;
   double* dBuf[2] = {nullptr, nullptr};
+  double* dNat[2] = {nullptr, nullptr};   // staging of the native blocks (dtype != HSSK_DT_F64)
   long long nb = 0;
   int gen = -1;   // compression attempt the buffers were carved in (a restart resets the work arena)
   // diagonal blocks of the leaves, copied out of the column blocks while they pass through the device (first sample of an
   // attempt): extract() then serves them from here instead of gathering them from host memory again
   std::vector<double*> dcache;   // by node id
-  HostBlockSource(const double* a, long long l, const host_fill_t* f, const host_elem_t* e) : hA(a), lda(l), fill(f), elem(e) {}
+  HostBlockSource(const void* a, long long l, const host_fill_t* f, const host_elem_t* e, int dt = HSSK_DT_F64)
+      : hA(a), lda(l), dtype(dt), fill(f), elem(e) {}
+  long long reals() const { return dtype == HSSK_DT_C32 || dtype == HSSK_DT_C64 ? 2 : 1; }   // image rows per scalar row
+  size_t esize() const { return dtype == HSSK_DT_F32 ? 4 : dtype == HSSK_DT_C64 ? 16 : 8; }
+  // entry (I, J) of the image
+  double image_at(size_t I, size_t J) const {
+    switch (dtype) {
+      case HSSK_DT_F32: return (double)((const float*)hA)[I + J * (size_t)lda];
+      case HSSK_DT_C32: {
+        const float* z = (const float*)hA + 2 * (I / 2 + (J / 2) * (size_t)lda);
+        return (I & 1) == (J & 1) ? (double)z[0] : ((I & 1) ? (double)z[1] : -(double)z[1]);
+      }
+      case HSSK_DT_C64: {
+        const double* z = (const double*)hA + 2 * (I / 2 + (J / 2) * (size_t)lda);
+        return (I & 1) == (J & 1) ? z[0] : ((I & 1) ? z[1] : -z[1]);
+      }
+      default: return ((const double*)hA)[I + J * (size_t)lda];
+    }
+  }
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.o_.world > 1) throw std::invalid_argument("host-resident operands are single-GPU (use the device / sharded interfaces)");
     // (an SJLT sketching matrix is applied in its dense form here -- Rt_ holds it, DeviceHSS::fill_random: the streaming
     // SJLT kernels overwrite their output, the blocks of a streamed operand have to accumulate)
     const long long N = H.n_;
+    const bool typed = hA && dtype != HSSK_DT_F64;
+    const long long W = typed ? reals() : 1, ns = N / W;   // scalar rows
+    if (typed && N % W) throw std::logic_error("image dimension of a complex operand must be even");
     const bool first = gen != H.attempt_;
     if (first) {
       gen = H.attempt_;
-      // ~1.5 GB per buffer (STRUMPACK_AMD_HOST_BLOCK_MB to change), whole 64-column tiles of the sketch GEMM
-      long long mb = 1536;
-      if (const char* e = std::getenv("STRUMPACK_AMD_HOST_BLOCK_MB")) mb = std::max(1LL, std::atoll(e));
-      nb = std::max<long long>(64, (mb << 20) / (8 * std::max<long long>(N, 1)) / 64 * 64);
+      // ~1.5 GB per buffer (STRUMPACK_AMD_HOST_BLOCK_MB, or _KB for small operands, to change), whole 64-column tiles of the
+      // sketch GEMM
+      long long bytes = 1536LL << 20;
+      if (const char* e = std::getenv("STRUMPACK_AMD_HOST_BLOCK_MB")) bytes = std::max(1LL, std::atoll(e)) << 20;
+      if (const char* e = std::getenv("STRUMPACK_AMD_HOST_BLOCK_KB")) bytes = std::max(1LL, std::atoll(e)) << 10;
+      nb = std::max<long long>(64, bytes / (8 * std::max<long long>(N, 1)) / 64 * 64);
       nb = std::min(nb, (N + 63) / 64 * 64);
       dBuf[0] = H.work_->dbl((size_t)N * nb);
-      dBuf[1] = H.work_->dbl((size_t)N * nb);
+      if (!typed) dBuf[1] = H.work_->dbl((size_t)N * nb);
+      else for (int k = 0; k < 2; k++) dNat[k] = H.work_->dbl(((size_t)ns * (size_t)(nb / W) * esize() + 7) / 8);
     }
     const long long nblk = (N + nb - 1) / nb;
     const bool capture = first;
@@ -436,7 +469,10 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
     std::vector<double> tmp;   // columns evaluated by `fill` (packed into the pinned ring before the call returns)
     auto upload = [&](long long b) {
       const long long c0 = b * nb, c1 = std::min(N, c0 + nb);
-      if (hA) ck(hssk_h2d_block_async(H.ctx_, dBuf[b & 1], N, hA + (size_t)c0 * lda, lda, N, c1 - c0));
+      if (typed)   // (c0 and c1 are even: nb is a multiple of 64, N = 2 ns)
+        ck(hssk_h2d_bytes_async(H.ctx_, dNat[b & 1], (long long)(ns * esize()), (const char*)hA + (size_t)(c0 / W) * lda * esize(),
+                                (long long)(lda * esize()), (long long)(ns * esize()), (c1 - c0) / W));
+      else if (hA) ck(hssk_h2d_block_async(H.ctx_, dBuf[b & 1], N, (const double*)hA + (size_t)c0 * lda, lda, N, c1 - c0));
       else {
         tmp.resize((size_t)N * (c1 - c0));
         (*fill)(c0, c1, tmp.data());
@@ -447,7 +483,12 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
     for (long long b = 0; b < nblk; b++) {
       const long long c0 = b * nb, c1 = std::min(N, c0 + nb);
       ck(hssk_copy_fence(H.ctx_));          // the GEMMs below wait for block b
-      const double* Ab = dBuf[b & 1];
+      const double* Ab = typed ? dBuf[0] : dBuf[b & 1];
+      if (typed) {
+        // the image of block b (behind the GEMMs of block b - 1 in stream order); its staging buffer is free from here on
+        ck(hssk_expand_image(H.ctx_, dBuf[0], N, dNat[b & 1], ns, ns, (c1 - c0) / W, dtype));
+        ck(hssk_compute_mark(H.ctx_, (int)(b & 1)));
+      }
       ck(hssk_dgemm(H.ctx_, 0, dn, c1 - c0, N, 1.0, H.Rt_ + r0, H.dcap_, Ab, N, 0.0, H.Sct_ + r0 + c0 * H.dcap_, H.dcap_));
       ck(hssk_dgemm(H.ctx_, 1, dn, N, c1 - c0, 1.0, H.Rt_ + r0 + c0 * H.dcap_, H.dcap_, Ab, N, b ? 1.0 : 0.0, H.Srt_ + r0, H.dcap_));
       if (capture) {
@@ -466,7 +507,7 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
       // block b + 1 overwrites the buffer the work of block b - 1 read -- and only that: the upload (whose packing blocks
       // this thread for most of its duration) is issued AFTER the GEMMs of block b, which then run under it, and it does
       // not wait for them.  (Issued before them, every block stalled the copy stream for the 2.4 ms of its GEMMs.)
-      ck(hssk_compute_mark(H.ctx_, (int)(b & 1)));
+      if (!typed) ck(hssk_compute_mark(H.ctx_, (int)(b & 1)));
       if (b + 1 < nblk) {
         ck(hssk_copy_wait(H.ctx_, (int)((b + 1) & 1)));
         upload(b + 1);
@@ -504,9 +545,14 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
       const ElemReq& r = reqs[k];
       if (r.m <= 0 || r.n <= 0 || hit[k]) return;
       double* B = img.data() + off[k];
-      if (hA) {
+      if (hA && dtype != HSSK_DT_F64) {
         for (int j = 0; j < r.n; j++) {
-          const double* col = hA + (size_t)(r.hJ ? (*r.hJ)[j] : r.j0 + j) * lda;
+          const size_t J = (size_t)(r.hJ ? (*r.hJ)[j] : r.j0 + j);
+          for (int i = 0; i < r.m; i++) B[i + (size_t)j * r.m] = image_at((size_t)(r.hI ? (*r.hI)[i] : r.i0 + i), J);
+        }
+      } else if (hA) {
+        for (int j = 0; j < r.n; j++) {
+          const double* col = (const double*)hA + (size_t)(r.hJ ? (*r.hJ)[j] : r.j0 + j) * lda;
           if (r.hI) for (int i = 0; i < r.m; i++) B[i + (size_t)j * r.m] = col[(*r.hI)[i]];
           else std::memcpy(B + (size_t)j * r.m, col + r.i0, sizeof(double) * r.m);
         }
@@ -971,6 +1017,11 @@ void DeviceHSS::compress_dense_device(const double* dA, long long lda) {
 }
 void DeviceHSS::compress_dense_host(const double* A, long long lda) {
   HostBlockSource s(A, lda, nullptr, nullptr);
+  compress(s);
+}
+void DeviceHSS::compress_dense_host_typed(const void* A, long long lda, int dtype) {
+  if (dtype != HSSK_DT_F32 && dtype != HSSK_DT_C32 && dtype != HSSK_DT_C64) throw std::invalid_argument("compress_dense_host_typed: unknown scalar type");
+  HostBlockSource s(A, lda, nullptr, nullptr, dtype);
   compress(s);
 }
 void DeviceHSS::compress_host_blocks(const host_fill_t& fill, const host_elem_t& elem) {

@@ -95,6 +95,9 @@ class DeviceHSS {
   // A in host memory: streamed through the device in column blocks, uploads overlapped with the sketch GEMMs; the full
   // matrix is never resident in HBM (the reference's element sampler never stores A either, StructuredMatrix.cpp:214-262)
   void compress_dense_host(const double* A, long long lda);
+  // A holds scalars of another type (HSSK_DT_F32 / _C32 / _C64, lda in scalars); this matrix is its real image (n() = rows for
+  // float, 2 x rows for complex scalars): the operand is uploaded in its own format and expanded on the device
+  void compress_dense_host_typed(const void* A, long long lda, int dtype);
   // the same for an operand given by element evaluation: fill(c0, c1, dst) writes A(:, c0:c1) (n x (c1-c0), ld n, host),
   // elem evaluates scattered blocks; both may be called concurrently from several host threads
   using host_fill_t = std::function<void(long long c0, long long c1, double* dst)>;

@@ -102,13 +102,13 @@ static PackPool& pack_pool() {
   static PackPool p(std::max(1u, std::min(24u, std::thread::hardware_concurrency())));
   return p;
 }
-// columns [c0, c1) of a column-major host block into a compact pinned buffer, on the host's hardware threads
-static void host_pack(char* dst, const double* src, long long lds, long long rows, long long c0, long long c1) {
+// columns [c0, c1) (colb bytes each, spitch bytes apart) of a column-major host block into a compact pinned buffer, on the
+// host's hardware threads
+static void host_pack(char* dst, const char* src, size_t spitch, size_t colb, long long c0, long long c1) {
   const long long ncol = c1 - c0;
-  const size_t colb = sizeof(double) * (size_t)rows;
   const size_t total = colb * (size_t)ncol;
   if (total < (size_t(8) << 20)) {
-    for (long long j = 0; j < ncol; j++) std::memcpy(dst + colb * j, src + (size_t)(c0 + j) * lds, colb);
+    for (long long j = 0; j < ncol; j++) std::memcpy(dst + colb * j, src + (size_t)(c0 + j) * spitch, colb);
     return;
   }
   PackPool& pool = pack_pool();
@@ -119,10 +119,54 @@ static void host_pack(char* dst, const double* src, long long lds, long long row
     size_t b0 = std::min(total, per * t), b1 = std::min(total, b0 + per);
     while (b0 < b1) {
       const size_t j = b0 / colb, o = b0 % colb, len = std::min(colb - o, b1 - b0);
-      std::memcpy(dst + b0, (const char*)(src + (size_t)(c0 + (long long)j) * lds) + o, len);
+      std::memcpy(dst + b0, src + (size_t)(c0 + (long long)j) * spitch + o, len);
       b0 += len;
     }
   });
+}
+// `cols` columns of `colb` bytes from host memory (pinned: DMA in place; pageable: the runtime's staged copy for a contiguous
+// source, else the pinned bounce ring) to the device, on the copy stream
+static void h2d_bytes(hssk_ctx* c, char* dst, size_t dpitch, const char* src, size_t spitch, size_t colb, long long cols) {
+  hssk_uploader* u = uploader(c);
+  if (hssk_rt::is_pinned_host_pointer(src)) {   // DMA straight from the caller's pinned buffer
+    if (dpitch == colb && spitch == colb) hssk_rt::h2d(dst, src, colb * (size_t)cols, u->copy);
+    else hssk_rt::h2d_2d(dst, dpitch, src, spitch, colb, (size_t)cols, u->copy);
+    return;
+  }
+  // A contiguous pageable source goes through the runtime's own staged copy: measured at N = 1e5 (80 GB) 56.4 GB/s against
+  // 52-53 GB/s for the packing pool below (the link gives a pinned buffer 57.6 GB/s); the call returns when the source has
+  // been staged, which the caller's loop allows for (HostBlockSource::sample).  HSSK_H2D_DIRECT=0 forces the pool.
+  static const bool direct = [] { const char* e = std::getenv("HSSK_H2D_DIRECT"); return !(e && e[0] == '0'); }();
+  if (direct && dpitch == colb && spitch == colb) {
+    hssk_rt::h2d(dst, src, colb * (size_t)cols, u->copy);
+    return;
+  }
+  if (colb > hssk_uploader::CHUNK) {   // columns longer than a bounce slot: pieces of one column at a time
+    for (long long j = 0; j < cols; j++)
+      for (size_t o = 0; o < colb; o += hssk_uploader::CHUNK) {
+        const size_t len = std::min(hssk_uploader::CHUNK, colb - o);
+        const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
+        if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);
+        std::memcpy(u->pinned[s], src + (size_t)j * spitch + o, len);
+        hssk_rt::h2d(dst + (size_t)j * dpitch + o, u->pinned[s], len, u->copy);
+        hssk_rt::event_record(u->slot_ev[s], u->copy);
+        u->slot_busy[s] = true;
+      }
+    return;
+  }
+  const long long cpc = std::max<long long>(1, (long long)(hssk_uploader::CHUNK / colb));   // columns per bounce slot
+  for (long long c0 = 0; c0 < cols; c0 += cpc) {
+    const long long c1 = std::min(cols, c0 + cpc);
+    const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
+    if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);   // the DMA that last read this slot has finished
+    host_pack(u->pinned[s], src, spitch, colb, c0, c1);
+    if (dpitch == colb)   // contiguous on the device: one linear DMA (the rectangular copy path is markedly slower)
+      hssk_rt::h2d(dst + (size_t)c0 * dpitch, u->pinned[s], colb * (size_t)(c1 - c0), u->copy);
+    else
+      hssk_rt::h2d_2d(dst + (size_t)c0 * dpitch, dpitch, u->pinned[s], colb, colb, (size_t)(c1 - c0), u->copy);
+    hssk_rt::event_record(u->slot_ev[s], u->copy);
+    u->slot_busy[s] = true;
+  }
 }
 
 extern "C" {
@@ -131,47 +175,14 @@ int hssk_h2d_block_async(hssk_ctx* c, double* dst, long long ldd, const double* 
                          long long cols) {
   HSSK_API_BEGIN
   if (rows <= 0 || cols <= 0) return 0;
-  hssk_uploader* u = uploader(c);
-  const size_t colb = sizeof(double) * (size_t)rows;
-  if (hssk_rt::is_pinned_host_pointer(src)) {   // DMA straight from the caller's pinned buffer
-    if (ldd == rows && lds == rows) hssk_rt::h2d(dst, src, colb * (size_t)cols, u->copy);
-    else hssk_rt::h2d_2d(dst, sizeof(double) * (size_t)ldd, src, sizeof(double) * (size_t)lds, colb, (size_t)cols, u->copy);
-    return 0;
-  }
-  // A contiguous pageable source goes through the runtime's own staged copy: measured at N = 1e5 (80 GB) 56.4 GB/s against
-  // 52-53 GB/s for the packing pool below (the link gives a pinned buffer 57.6 GB/s); the call returns when the source has
-  // been staged, which the caller's loop allows for (HostBlockSource::sample).  HSSK_H2D_DIRECT=0 forces the pool.
-  static const bool direct = [] { const char* e = std::getenv("HSSK_H2D_DIRECT"); return !(e && e[0] == '0'); }();
-  if (direct && ldd == rows && lds == rows) {
-    hssk_rt::h2d(dst, src, colb * (size_t)cols, u->copy);
-    return 0;
-  }
-  if (colb > hssk_uploader::CHUNK) {   // columns longer than a bounce slot: pieces of one column at a time
-    for (long long j = 0; j < cols; j++)
-      for (size_t o = 0; o < colb; o += hssk_uploader::CHUNK) {
-        const size_t len = std::min(hssk_uploader::CHUNK, colb - o);
-        const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
-        if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);
-        std::memcpy(u->pinned[s], (const char*)(src + (size_t)j * lds) + o, len);
-        hssk_rt::h2d((char*)(dst + (size_t)j * ldd) + o, u->pinned[s], len, u->copy);
-        hssk_rt::event_record(u->slot_ev[s], u->copy);
-        u->slot_busy[s] = true;
-      }
-    return 0;
-  }
-  const long long cpc = std::max<long long>(1, (long long)(hssk_uploader::CHUNK / colb));   // columns per bounce slot
-  for (long long c0 = 0; c0 < cols; c0 += cpc) {
-    const long long c1 = std::min(cols, c0 + cpc);
-    const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
-    if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);   // the DMA that last read this slot has finished
-    host_pack(u->pinned[s], src, lds, rows, c0, c1);
-    if (ldd == rows)   // contiguous on the device: one linear DMA (the rectangular copy path is markedly slower)
-      hssk_rt::h2d(dst + (size_t)c0 * ldd, u->pinned[s], colb * (size_t)(c1 - c0), u->copy);
-    else
-      hssk_rt::h2d_2d(dst + (size_t)c0 * ldd, sizeof(double) * (size_t)ldd, u->pinned[s], colb, colb, (size_t)(c1 - c0), u->copy);
-    hssk_rt::event_record(u->slot_ev[s], u->copy);
-    u->slot_busy[s] = true;
-  }
+  h2d_bytes(c, (char*)dst, sizeof(double) * (size_t)ldd, (const char*)src, sizeof(double) * (size_t)lds, sizeof(double) * (size_t)rows, cols);
+  HSSK_API_END
+}
+int hssk_h2d_bytes_async(hssk_ctx* c, void* dst, long long dpitch, const void* src, long long spitch, long long width, long long cols) {
+  HSSK_API_BEGIN
+  if (width <= 0 || cols <= 0) return 0;
+  if (dpitch < width || spitch < width) return 2;
+  h2d_bytes(c, (char*)dst, (size_t)dpitch, (const char*)src, (size_t)spitch, (size_t)width, cols);
   HSSK_API_END
 }
 int hssk_copy_fence(hssk_ctx* c) {

@@ -119,6 +119,22 @@ __global__ void gather_elems_kernel(const hssk_elem_desc* __restrict__ descs, co
   }
 }
 
+// real image of a block of another scalar type (hssk_expand_image): grid (row chunks, columns), a thread per scalar
+template <typename R, bool CPLX>
+__global__ void expand_image_kernel(double* __restrict__ dst, long long ldd, const R* __restrict__ src, long long lds, long long rows) {
+  const long long j = blockIdx.y;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long long)gridDim.x * blockDim.x) {
+    if (!CPLX) {
+      dst[i + j * ldd] = (double)src[i + j * lds];
+    } else {
+      const double re = (double)src[2 * (i + j * lds)], im = (double)src[2 * (i + j * lds) + 1];
+      double* c0 = dst + 2 * i + 2 * j * ldd;
+      c0[0] = re; c0[1] = im;
+      c0[ldd] = -im; c0[ldd + 1] = re;
+    }
+  }
+}
+
 __global__ void sum_slabs_kernel(const double* __restrict__ slabs, long long count, long long stride, int nslab, double* __restrict__ out) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x) {
     double s = 0.;
@@ -432,6 +448,26 @@ int hssk_mfma_f64_probe(hssk_ctx* ctx, int iters, int waves_per_simd, int zero_d
   out[0] = (double)blocks * 4 * (double)iters * 48 * 2048.0 / (ms * 1e-3) * 1e-12;
   out[1] = (double)h[0] / ((double)iters * 48);
   out[2] = h[1] > 0 ? (double)h[0] / ((double)h[1] / 100e6) * 1e-9 : 0.;
+  HSSK_API_END
+}
+
+int hssk_expand_image(hssk_ctx* ctx, double* dst, long long ldd, const void* src, long long lds, long long rows, long long cols,
+                      int dtype) {
+  HSSK_API_BEGIN
+  if (rows <= 0 || cols <= 0) return 0;
+  if (dtype != HSSK_DT_F32 && dtype != HSSK_DT_C32 && dtype != HSSK_DT_C64) return 2;
+  if (lds < rows || ldd < (dtype == HSSK_DT_F32 ? rows : 2 * rows)) return 2;
+  for (long long c0 = 0; c0 < cols; c0 += 65535) {   // (grid.y limit)
+    const long long nc = std::min<long long>(65535, cols - c0);
+    dim3 grid((unsigned)std::min<long long>(256, (rows + 255) / 256), (unsigned)nc);
+    if (dtype == HSSK_DT_F32)
+      HSSK_LAUNCH((expand_image_kernel<float, false>), grid, dim3(256), 0, ctx->stream, dst + c0 * ldd, ldd, (const float*)src + c0 * lds, lds, rows);
+    else if (dtype == HSSK_DT_C32)
+      HSSK_LAUNCH((expand_image_kernel<float, true>), grid, dim3(256), 0, ctx->stream, dst + 2 * c0 * ldd, ldd, (const float*)src + 2 * c0 * lds, lds, rows);
+    else
+      HSSK_LAUNCH((expand_image_kernel<double, true>), grid, dim3(256), 0, ctx->stream, dst + 2 * c0 * ldd, ldd, (const double*)src + 2 * c0 * lds, lds, rows);
+    hssk_rt::check_launch();
+  }
   HSSK_API_END
 }
 

@@ -128,7 +128,7 @@ HSSK_SYMBOLS = [
     "hssk_memcpy2d_h2d", "hssk_memcpy2d_d2h", "hssk_memset_zero", "hssk_is_device_pointer",
     "hssk_basis_dense", "hssk_mfma_f64_probe", "hssk_last_dgemm_clock_ghz", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
     "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict", "hssk_copy_triu",
-    "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
+    "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_h2d_bytes_async", "hssk_expand_image", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
 ]
 
@@ -211,6 +211,8 @@ class Hssk:
         L.hssk_h2d_block_async.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong]
         L.hssk_copy_fence.argtypes = [C.c_void_p]
         L.hssk_compute_fence.argtypes = [C.c_void_p]
+        L.hssk_h2d_bytes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong]
+        L.hssk_expand_image.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]
         L.hssk_compute_mark.argtypes = [C.c_void_p, C.c_int]
         L.hssk_copy_wait.argtypes = [C.c_void_p, C.c_int]
         L.hssk_sweep_status.argtypes = [C.c_void_p]

@@ -65,5 +65,9 @@ def test_float_and_complex_instantiations(L):
     HC.check_scz(L)
 
 
+def test_host_operand_streamed_in_blocks(L):
+    HC.check_host_stream_blocks(L)
+
+
 def test_blr_dense_slice(L):
     HC.check_blr(L, max_n=1000)

@@ -204,6 +204,10 @@ def test_float_and_complex_instantiations(L):
     HC.check_scz(L)
 
 
+def test_host_operand_streamed_in_blocks(L):
+    HC.check_host_stream_blocks(L)
+
+
 def test_native_comm_and_sharded_operand_single_rank(L):
     """The library's own RCCL communicator (SPX_comm_*) with one rank on the one GPU of the test box: the collectives'
     self test, then the sharded-operand construction through both of its sketch paths (row block + column block; column
