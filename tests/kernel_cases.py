@@ -617,3 +617,38 @@ def case_contract_codes(hk):
     assert rc("hssk_gather_combine", K.CombineDesc(d.ptr, None, 300, 300, None, None, None, 300, 300, None, None, 1, 1, 1.0, d.ptr, 300, 0, 5, 3)) == 0
     assert rc("hssk_gather_combine", K.CombineDesc(d.ptr, None, 300, 300, None, None, None, 300, 300, None, None, 1, 1, 1.0, d.ptr, 300, 4, 5, 3)) == 2
     hk.sync()
+
+
+def case_expand_image(hk):
+    """hssk_expand_image: double-precision real image of float / complex blocks with padded leading dimensions, through the
+    byte-oriented upload (hssk_h2d_bytes_async) of a strided host block."""
+    rng = np.random.default_rng(11)
+    rows, cols, lds, ldd = 37, 9, 41, 83
+    for dt, code in ((np.float32, 1), (np.complex64, 2), (np.complex128, 3)):
+        host = rng.standard_normal((lds + 2, cols)).astype(dt)
+        if code > 1:
+            host = (host + 1j * rng.standard_normal(host.shape)).astype(dt)
+        host = np.asfortranarray(host)
+        w = 2 if code > 1 else 1
+        es = np.dtype(dt).itemsize
+        src = hk.empty((lds, cols), dt)
+        # rows [1, rows + 1) of the host block: pitch (lds + 2) scalars on the host, lds scalars on the device
+        hk.check(hk.lib.hssk_h2d_bytes_async(hk.ctx, src.ptr, lds * es, host.ctypes.data + es, (lds + 2) * es, rows * es, cols))
+        hk.check(hk.lib.hssk_copy_fence(hk.ctx))
+        dst = hk.array(np.full((ldd, w * cols), 5.0))
+        hk.check(hk.lib.hssk_expand_image(hk.ctx, dst.ptr, ldd, src.ptr, lds, rows, cols, code))
+        hk.sync()
+        got = dst.get()
+        Z = host[1:rows + 1]
+        if code == 1:
+            want = Z.astype(np.float64)
+        else:
+            want = np.zeros((2 * rows, 2 * cols))
+            want[0::2, 0::2], want[1::2, 0::2] = Z.real, Z.imag
+            want[0::2, 1::2], want[1::2, 1::2] = -Z.imag, Z.real
+        assert np.array_equal(got[:w * rows], want)
+        assert np.all(got[w * rows:] == 5.0)
+        assert hk.lib.hssk_expand_image(hk.ctx, dst.ptr, w * rows - 1, src.ptr, lds, rows, cols, code) == 2
+    assert hk.lib.hssk_expand_image(hk.ctx, dst.ptr, ldd, src.ptr, lds, rows, cols, 0) == 2
+    assert hk.lib.hssk_expand_image(hk.ctx, dst.ptr, ldd, src.ptr, lds, 0, cols, 1) == 0
+    assert hk.lib.hssk_h2d_bytes_async(hk.ctx, src.ptr, 8, host.ctypes.data, 16, 12, 2) == 2

@@ -135,3 +135,7 @@ def test_qr_r_only(hk):
 
 def test_contract_codes(hk):
     KC.case_contract_codes(hk)
+
+
+def test_expand_image(hk):
+    KC.case_expand_image(hk)
