@@ -2,6 +2,7 @@
 #include "hssk_internal.h"
 
 #include <cstdlib>
+#include <unistd.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -56,10 +57,11 @@ static hssk_uploader* uploader(hssk_ctx* c) {
 // persistent host threads for the packing (a piece is packed in ~5 ms: starting threads per piece would cost as much)
 class PackPool {
  public:
-  explicit PackPool(unsigned n) : n_(n) {
+  explicit PackPool(unsigned n) : n_(n), pid_(getpid()) {
     for (unsigned t = 0; t < n_; t++) th_.emplace_back([this, t] { loop(t); });
   }
   ~PackPool() {
+    if (getpid() != pid_) { for (auto& t : th_) t.detach(); return; }   // (a forked child has the object but not the threads)
     { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
     cv_.notify_all();
     for (auto& t : th_) t.join();
@@ -67,6 +69,8 @@ class PackPool {
   unsigned size() const { return n_; }
   // runs fn(t) for t < size() on the pool and returns when all are done
   void run(const std::function<void(unsigned)>& fn) {
+    if (getpid() != pid_) { for (unsigned t = 0; t < n_; t++) fn(t); return; }   // forked child: the caller does the work
+    std::lock_guard<std::mutex> own(owner_);   // one job at a time (contexts on several host threads share the pool)
     std::unique_lock<std::mutex> lk(mu_);
     fn_ = &fn; pending_ = n_; gen_++;
     cv_.notify_all();
@@ -90,8 +94,9 @@ class PackPool {
     }
   }
   unsigned n_;
+  const pid_t pid_;
   std::vector<std::thread> th_;
-  std::mutex mu_;
+  std::mutex mu_, owner_;
   std::condition_variable cv_, done_;
   const std::function<void(unsigned)>* fn_ = nullptr;
   unsigned long gen_ = 0;

@@ -652,3 +652,34 @@ def case_expand_image(hk):
     assert hk.lib.hssk_expand_image(hk.ctx, dst.ptr, ldd, src.ptr, lds, rows, cols, 0) == 2
     assert hk.lib.hssk_expand_image(hk.ctx, dst.ptr, ldd, src.ptr, lds, 0, cols, 1) == 0
     assert hk.lib.hssk_h2d_bytes_async(hk.ctx, src.ptr, 8, host.ctypes.data, 16, 12, 2) == 2
+
+
+def case_upload_two_threads(hk):
+    """Two contexts on two host threads upload strided pageable blocks at the same time: the packing threads behind the
+    bounce ring are shared by all contexts of the process and take one job at a time."""
+    import threading
+    hk2 = K.Hssk(hk.lib._name)
+    rows, cols, pad = 1100, 1100, 3          # 9.7 MB per block: above the size that goes to the packing threads
+    errs = []
+
+    def work(h, seed):
+        try:
+            rng = np.random.default_rng(seed)
+            dst = h.empty((rows, cols))
+            for it in range(4):
+                src = np.asfortranarray(rng.standard_normal((rows + pad, cols)))
+                h.check(h.lib.hssk_h2d_block_async(h.ctx, dst.ptr, rows, src.ctypes.data + 8, rows + pad, rows, cols))
+                h.check(h.lib.hssk_copy_fence(h.ctx))
+                h.sync()
+                if not np.array_equal(dst.get(), src[1:rows + 1]):
+                    errs.append("thread %d, upload %d: wrong data" % (seed, it))
+            dst.free()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(h, k)) for k, h in enumerate((hk, hk2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    hk2.close()
+    assert not errs, errs

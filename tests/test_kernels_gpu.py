@@ -152,3 +152,7 @@ def test_contract_codes(hk):
 
 def test_expand_image(hk):
     KC.case_expand_image(hk)
+
+
+def test_upload_two_threads(hk):
+    KC.case_upload_two_threads(hk)
