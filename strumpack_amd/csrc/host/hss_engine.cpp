@@ -1100,6 +1100,7 @@ void DeviceHSS::free_compress_workspace() {
 }
 
 void DeviceHSS::compress(Source& src) {
+  OpGuard op_guard(op_mu_);
   double t0 = now();
   stats_ = PhaseStats();
   int dcap = o_.algorithm != 1 ? o_.d0 + o_.p : o_.d0 + o_.dd;
@@ -1732,6 +1733,7 @@ void DeviceHSS::finish_id_bookkeeping() {
 // I = the node's rows (leaf) resp. its children's skeleton rows; symmetric: V = U, B10 = B01^T.
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int user_k) {
+  OpGuard op_guard(op_mu_);
   double t0 = now();
   stats_ = PhaseStats();
   const int N = n_, dim = ks.d;
@@ -2168,6 +2170,7 @@ std::unique_ptr<DeviceHSS> DeviceHSS::load(std::istream& is, const EngineOptions
 // shift
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::shift(double sigma) {
+  OpGuard op_guard(op_mu_);
   std::vector<hssk_shift_desc> d;
   for (auto& nd : nodes_)
     if (nd.leaf() && nd.D) d.push_back(hssk_shift_desc{nd.D, nd.m, nd.m});
@@ -2178,6 +2181,7 @@ void DeviceHSS::shift(double sigma) {
 }
 
 void DeviceHSS::shift_cplx(double re, double im) {
+  OpGuard op_guard(op_mu_);
   std::vector<hssk_shift_desc> d;
   for (auto& nd : nodes_)
     if (nd.leaf() && nd.D) {
@@ -2195,6 +2199,7 @@ void DeviceHSS::shift_cplx(double re, double im) {
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
                      bool on_device, double beta) {
+  OpGuard op_guard(op_mu_);
   mult_sub(0, trans, nrhs, x, ldx, y, ldy, on_device, beta);
 }
 
@@ -2489,12 +2494,14 @@ void DeviceHSS::factor() { factor_sub(0, false); }
 // the root of its own subtree -- and keep its reduced column basis Vhat (HSSFactors::Vhat(), HSSExtra.hpp:191) for
 // the Schur complement update of the (1,1) block.
 void DeviceHSS::partial_factor() {
+  OpGuard op_guard(op_mu_);
   if (nodes_[0].leaf()) return;
   if (o_.world != 1) throw std::logic_error("partial_factor: needs a single-process matrix");
   factor_sub(nodes_[0].c0, true);
 }
 
 void DeviceHSS::factor_sub(int sr, bool partial) {
+  OpGuard op_guard(op_mu_);
   ensure_ready("factor");
   double t0 = now();
   ck(hssk_sync(ctx_));
@@ -2665,12 +2672,14 @@ std::vector<std::vector<int>> DeviceHSS::sublists(const std::vector<std::vector<
 
 void DeviceHSS::mult_child(int c, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
                            bool on_device) {
+  OpGuard op_guard(op_mu_);
   if (nodes_[0].leaf()) throw std::logic_error("mult_child: the root is a leaf");
   mult_sub(c == 0 ? nodes_[0].c0 : nodes_[0].c1, trans, nrhs, x, ldx, y, ldy, on_device, 0.0);
 }
 
 void DeviceHSS::mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
                           bool on_device) {
+  OpGuard op_guard(op_mu_);
   if (node < 0 || node >= (int)nodes_.size()) throw std::invalid_argument("mult_node: no such node");
   mult_sub(node, trans, nrhs, x, ldx, y, ldy, on_device, 0.0);
 }
@@ -2780,6 +2789,7 @@ DeviceHSS::SchurDims DeviceHSS::schur_dims() const {
 
 void DeviceHSS::schur_update(double* Theta, long long ldt, double* DUB01, long long ldd, double* Phi, long long ldp,
                              double* Vhat, long long ldv) {
+  OpGuard op_guard(op_mu_);
   ensure_ready("Schur_update");
   if (nodes_[0].leaf()) return;    // Schur.hpp:42
   if (!partial_factored_) throw std::logic_error("Schur_update: partial_factor() has not been called");
@@ -2829,6 +2839,7 @@ void DeviceHSS::schur_update(double* Theta, long long ldt, double* DUB01, long l
 
 void DeviceHSS::schur_product_direct(int c, const double* R, long long ldr, double* Sr, long long ldsr, double* Sc,
                                      long long ldsc, bool on_device) {
+  OpGuard op_guard(op_mu_);
   if (!schur_ready_) throw std::logic_error("Schur_product_direct: Schur_update() has not been called");
   if (c <= 0) return;
   const Node& root = nodes_[0];
@@ -2877,6 +2888,7 @@ void DeviceHSS::schur_product_direct(int c, const double* R, long long ldr, doub
 void DeviceHSS::schur_product_indirect(int c, const double* R0, long long ldr0, const double* R1, long long ldr1,
                                        const double* Sr1, long long ldsr1, const double* Sc1, long long ldsc1,
                                        double* Sr, long long ldsr, double* Sc, long long ldsc, bool on_device) {
+  OpGuard op_guard(op_mu_);
   if (nodes_[0].leaf()) return;   // Schur.hpp:158
   if (!schur_ready_) throw std::logic_error("Schur_product_indirect: Schur_update() has not been called");
   if (c <= 0) return;
@@ -2937,6 +2949,7 @@ void DeviceHSS::schur_product_indirect(int c, const double* R0, long long ldr0, 
 // ULV solve (HSSMatrix.solve.hpp:69-238)
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
+  OpGuard op_guard(op_mu_);
   ensure_ready("solve");
   if (!factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
   if (nrhs <= 0 || n_ == 0) return;

@@ -17,6 +17,7 @@
 #include <map>
 #include <tuple>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -176,6 +177,10 @@ class DeviceHSS {
   void node_info(int* out) const;
   const PhaseStats& stats() const { return stats_; }
   hssk_ctx* ctx() const { return ctx_; }
+  // Operations on ONE matrix from several host threads take turns (the reference's mult / solve are const and safe to call
+  // concurrently, HSSMatrixBase.hpp:273 and the per-call work objects of apply / solve; here every operation uses the
+  // matrix's stream and work arenas).  Different matrices run concurrently.
+  using OpGuard = std::lock_guard<std::recursive_mutex>;
   const EngineOptions& options() const { return o_; }
   void set_options(const EngineOptions& o) { o_ = o; }
 
@@ -206,6 +211,7 @@ class DeviceHSS {
   const std::vector<Node>& nodes() const { return nodes_; }
 
  private:
+  mutable std::recursive_mutex op_mu_;
   struct Source;
   struct DenseDeviceSource;
   struct HostBlockSource;

@@ -204,6 +204,10 @@ def test_float_and_complex_instantiations(L):
     HC.check_scz(L)
 
 
+def test_concurrent_operations_on_one_matrix(L):
+    HC.check_concurrent_ops(L)
+
+
 def test_host_operand_streamed_in_blocks(L):
     HC.check_host_stream_blocks(L)
 
