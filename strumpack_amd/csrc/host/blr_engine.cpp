@@ -144,6 +144,7 @@ void DeviceBLR::compress_tiles(const std::vector<std::pair<int, int>>& ij, const
 }
 
 void DeviceBLR::compress_host(const double* A, long long lda, const char* adm) {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   const double t0 = now();
   load(A, lda, false);
   // (hssk_h2d_block_async runs on the copy stream; the fence in load() orders the kernels below behind it)
@@ -160,6 +161,7 @@ void DeviceBLR::compress_host(const double* A, long long lda, const char* adm) {
   t_compress = now() - t0;
 }
 void DeviceBLR::compress_device(const double* dA, long long lda, const char* adm) {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   const double t0 = now();
   load(dA, lda, true);
   for (int j = 0; j < colblocks(); j++) {
@@ -176,10 +178,12 @@ void DeviceBLR::compress_device(const double* dA, long long lda, const char* adm
 }
 
 void DeviceBLR::compress_and_factor_host(const double* A, long long lda, const char* adm) {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   load(A, lda, false);
   factor_rl(adm);
 }
 void DeviceBLR::compress_and_factor_device(const double* dA, long long lda, const char* adm) {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   load(dA, lda, true);
   factor_rl(adm);
 }
@@ -280,6 +284,7 @@ void DeviceBLR::factor_rl(const char* adm) {
 // y = op(B) x.  Tiles are visited in rounds s: round s pairs block row i with block column (i + s) mod cb (transposed: the
 // other way round), so the outputs of one round are distinct and its tiles are two batched GEMMs.
 void DeviceBLR::mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   if (!compressed_ || factored_) throw std::logic_error("BLR mult: needs a compressed, unfactored matrix (construct_from_dense)");
   if (nrhs <= 0) return;
   const bool T = !(trans == 'N' || trans == 'n');
@@ -318,6 +323,7 @@ void DeviceBLR::mult(char trans, int nrhs, const double* x, long long ldx, doubl
 // BLRMatrix::solve (BLRMatrix.hpp:118-122): x <- P x, block forward substitution with the unit lower factor, block
 // backward substitution with the upper factor
 void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   if (!factored_) throw std::logic_error("BLR solve: the matrix has not been factored (construct_and_factor_from_dense)");
   if (nrhs <= 0 || n_ == 0) return;
   const int rb = rowblocks();
@@ -378,6 +384,7 @@ void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
 }
 
 void DeviceBLR::dense(double* A, long long lda) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
   if (!compressed_ || factored_) throw std::logic_error("BLR dense: needs a compressed, unfactored matrix");
   Arena2& tmp = *tmp_;
   tmp.rewind();

@@ -19,6 +19,7 @@
 // T ~ T(:, J) [I X] P^T spans the same subspace as Q R P^T with the same stopping rule, so U = T(:, J), V = P [I; X^T].
 #pragma once
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "hssk.h"
@@ -79,6 +80,7 @@ class DeviceBLR {
   void compress_tiles(const std::vector<std::pair<int, int>>& ij, const char* adm);
   void factor_rl(const char* adm);
 
+  mutable std::recursive_mutex op_mu_;
   int m_, n_;
   std::vector<int> roff_, coff_;
   BLREngineOptions o_;
