@@ -258,6 +258,39 @@ __global__ void dgemm_reduce_kernel(int m, long long n, const double* __restrict
   }
 }
 
+// The same for FEW output elements with MANY partials (the ragged edge tile of the sketch: 192 x 32 elements, 256 partials --
+// a thread per element walked them one dependent-latency step at a time, 104 us at N = 1e5): 16 elements x 16 z-lanes per
+// workgroup, every lane sums its partials z = lane, lane + 16, ... , the 16 lane sums are added in lane order (fixed
+// summation order -> deterministic).
+__global__ void dgemm_reduce_wide_kernel(int m, long long n, const double* __restrict__ P, long long ldp,
+                                         long long pstride, int nz, double alpha, double beta,
+                                         double* __restrict__ C, long long ldc) {
+  HSSK_SHARED double s_part[256];
+  const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const long long total = (long long)m * n;
+  for (long long e0 = (long long)blockIdx.x * 16; e0 < total; e0 += (long long)gridDim.x * 16) {
+    const long long e = e0 + el;
+    const int i = (int)(e % m);
+    const long long j = e / m;
+    double s = 0.;
+    if (e < total) {
+      const double* p = P + i + j * ldp;
+      for (int z = zl; z < nz; z += 16) s += p[z * pstride];
+    }
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (zl == 0 && e < total) {
+      double t = 0.;
+      for (int q = 0; q < 16; q++) t += s_part[el + 16 * q];
+      double* c = C + i + j * ldc;
+      double v = alpha * t;
+      if (beta != 0.) v += beta * (*c);
+      *c = v;
+    }
+    __syncthreads();
+  }
+}
+
 template <int BM, bool FULL, int TAG>
 void launch_dgemm(hssk_ctx* ctx, int transB, dim3 grid, int m, long long n, long long k, const double* A,
                   long long lda, const double* B, long long ldb, double* P, long long ldp, long long pstride,
@@ -392,7 +425,10 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     if (!g->ntiles) continue;
     long long total = (long long)m * g->cols;
     unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-    HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->tile0 * BN * ldc, ldc);
+    if (g->nz >= 32 && total <= 65536)   // too few elements to hide the latency of a serial walk over the partials
+      HSSK_LAUNCH(dgemm_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->tile0 * BN * ldc, ldc);
+    else
+      HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->tile0 * BN * ldc, ldc);
   }
   hssk_rt::check_launch();
   HSSK_API_END

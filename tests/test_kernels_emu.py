@@ -48,6 +48,12 @@ def test_dgemm_splitk(hk):
     KC.case_dgemm(hk, 24, 70, 3000, 1)
 
 
+def test_dgemm_deep_split_edge_tile(hk):
+    # a ragged edge tile with >= 32 K-partials: the wide reduce (16 elements x 16 z-lanes per workgroup)
+    KC.case_dgemm(hk, 64, 72, 12800, 1, alpha=-1.5, beta=0.5, lda_pad=0, ldb_pad=0)
+    KC.case_dgemm(hk, 30, 5, 13000, 0, alpha=1.0, beta=0.0)
+
+
 def test_generators(hk):
     KC.case_toeplitz_randn(hk)
 

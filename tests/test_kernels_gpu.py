@@ -37,6 +37,12 @@ def test_dgemm(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.5, beta=0.5)
 
 
+def test_dgemm_deep_split_edge_tile(hk):
+    # a ragged edge tile with >= 32 K-partials: the wide reduce (16 elements x 16 z-lanes per workgroup)
+    KC.case_dgemm(hk, 192, 96, 100000, 1, alpha=-1.5, beta=0.5, lda_pad=0, ldb_pad=0)
+    KC.case_dgemm(hk, 30, 5, 13000, 0, alpha=1.0, beta=0.0)
+
+
 @pytest.mark.parametrize("m,n,k,tb", [(192, 4100, 4096, 1), (192, 4100, 4096, 0), (64, 1000, 3008, 1), (128, 640, 2048, 0)])
 def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=1.0, beta=0.0, lda_pad=0, ldb_pad=0)
