@@ -2511,6 +2511,9 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nd.Vt0T = nullptr, nd.piv = nullptr;
   const size_t nn = nodes_.size();
   std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr);
+  // inverted diagonal blocks for the single-launch solve sweeps: nothing in the factorization reads them, so the
+  // descriptors of all levels are collected and take ONE launch at the end (a launch per level was 10-20 us each)
+  std::vector<hssk_trtri_desc> ti;
   auto level = [&](const std::vector<int>& ids) {
     if (ids.empty()) return;
     // ---- assemble Dh (mU x mU) and Vh (mU x rV)
@@ -2563,7 +2566,6 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     std::vector<hssk_gemm_desc> g2, g3;
     std::vector<hssk_qr_desc> qr;
     std::vector<hssk_lu_desc> lu;
-    std::vector<hssk_trtri_desc> ti, tiroot;   // inverted diagonal blocks for the single-launch solve sweeps
     for (int id : ids) {
       Node& nd = nodes_[id];
       if (id == sr) {
@@ -2576,8 +2578,8 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
           const size_t nblk = (size_t)(mu + 63) / 64;
           nd.Tinv = fact_->dbl(nblk * 4096);
           nd.TinvU = fact_->dbl(nblk * 4096);
-          tiroot.push_back(hssk_trtri_desc{nd.LU, nd.Tinv, mu, mu, 2});
-          tiroot.push_back(hssk_trtri_desc{nd.LU, nd.TinvU, mu, mu, 1});
+          ti.push_back(hssk_trtri_desc{nd.LU, nd.Tinv, mu, mu, 2});
+          ti.push_back(hssk_trtri_desc{nd.LU, nd.TinvU, mu, mu, 1});
         }
         stats_.f_ulv += 2.0 / 3.0 * mu * (double)mu * mu;
         continue;
@@ -2631,9 +2633,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
     if (!qr.empty()) ck(hssk_qr_vbatched(ctx_, qr.data(), (int)qr.size()));
     if (!g3.empty()) ck(hssk_gemm_vbatched(ctx_, g3.data(), (int)g3.size()));
-    if (!ti.empty()) ck(hssk_trtri_diag_vbatched(ctx_, ti.data(), (int)ti.size()));
     if (!lu.empty()) ck(hssk_getrf_vbatched(ctx_, lu.data(), (int)lu.size()));
-    if (!tiroot.empty()) ck(hssk_trtri_diag_vbatched(ctx_, tiroot.data(), (int)tiroot.size()));
   };
   std::vector<std::vector<int>> sub_h;
   if (sr != 0) sub_h = sublists(own_by_height_, sr);
@@ -2643,6 +2643,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     exchange_cut_factor();
     for (auto& ids : top_by_height_) level(ids);
   }
+  if (!ti.empty()) ck(hssk_trtri_diag_vbatched(ctx_, ti.data(), (int)ti.size()));
   ck(hssk_sync(ctx_));
   factored_ = sr == 0;
   partial_factored_ = partial;
