@@ -2514,6 +2514,21 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   // inverted diagonal blocks for the single-launch solve sweeps: nothing in the factorization reads them, so the
   // descriptors of all levels are collected and take ONE launch at the end (a launch per level was 10-20 us each)
   std::vector<hssk_trtri_desc> ti;
+  // A node's reduced block Dt (rU x rU) is written by its products straight into the diagonal block of the PARENT's Dh
+  // (allocated here, ahead of the parent's level): no copy launch per level.  The cut nodes of a distributed tree keep a
+  // compact Dt of their own -- it travels through exchange_cut_factor().
+  std::vector<char> is_cut(nn, 0);
+  if (dist_subtree_) for (int c : cut_nodes_) is_cut[c] = 1;
+  auto dt_slot = [&](int id, int r, int& ld) -> double* {
+    const Node& nd = nodes_[id];
+    if (nd.parent < 0 || is_cut[id]) { ld = std::max(r, 1); return fact_->dbl((size_t)ld * ld); }
+    const Node& pa = nodes_[nd.parent];
+    const int mu = nodes_[pa.c0].rU + nodes_[pa.c1].rU;
+    ld = std::max(mu, 1);
+    if (!Dh[nd.parent]) Dh[nd.parent] = fact_->dbl((size_t)ld * ld);
+    const int off = id == pa.c0 ? 0 : nodes_[pa.c0].rU;
+    return Dh[nd.parent] + off + (size_t)off * ld;
+  };
   auto level = [&](const std::vector<int>& ids) {
     if (ids.empty()) return;
     // ---- assemble Dh (mU x mU) and Vh (mU x rV)
@@ -2531,11 +2546,14 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
         cp.push_back(hssk_colgather_desc{nd.D, Dh[id], nullptr, nd.m, nd.m, nd.m, nd.m, 0});
       } else {
-        Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
         Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
-        // D = [Dt0, B01 Vt1_1^T ; B10 Vt1_0^T, Dt1]
-        cp.push_back(hssk_colgather_desc{a.Dt, Dh[id], nullptr, a.rU, a.rU, std::max(a.rU, 1), std::max(mu, 1), 0});
-        cp.push_back(hssk_colgather_desc{b.Dt, Dh[id] + a.rU + (size_t)a.rU * mu, nullptr, b.rU, b.rU, std::max(b.rU, 1), std::max(mu, 1), 0});
+        // D = [Dt0, B01 Vt1_1^T ; B10 Vt1_0^T, Dt1]; the diagonal blocks are already in place (dt_slot) unless the children
+        // are cut nodes
+        if (!Dh[id]) {
+          Dh[id] = fact_->dbl((size_t)std::max(mu, 1) * std::max(mu, 1));
+          cp.push_back(hssk_colgather_desc{a.Dt, Dh[id], nullptr, a.rU, a.rU, std::max(a.rU, 1), std::max(mu, 1), 0});
+          cp.push_back(hssk_colgather_desc{b.Dt, Dh[id] + a.rU + (size_t)a.rU * mu, nullptr, b.rU, b.rU, std::max(b.rU, 1), std::max(mu, 1), 0});
+        }
         g0.push_back(hssk_gemm_desc{nd.B01, b.Vt1, Dh[id] + (size_t)a.rU * mu, a.rU, b.rU, b.rV, std::max(a.rU, 1), std::max(b.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
         g0.push_back(hssk_gemm_desc{nd.B10, a.Vt1, Dh[id] + a.rU, b.rU, a.rU, a.rV, std::max(b.rU, 1), std::max(a.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
         stats_.f_ulv += 2.0 * a.rU * (double)b.rU * (a.rV + b.rV);
@@ -2591,7 +2609,8 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         nd.Rlq = fact_->dbl((size_t)m * (m - r));
         nd.Qt = fact_->dbl((size_t)m * m);
         nd.Vt1 = fact_->dbl((size_t)std::max(r, 1) * std::max(rv, 1));
-        nd.Dt = fact_->dbl((size_t)std::max(r, 1) * std::max(r, 1));
+        int ldt = 1;
+        nd.Dt = dt_slot(id, r, ldt);
         if (m <= 256) {   // one fused launch (hssk_ulv_split); larger blocks: two row gathers and a product
           us.push_back(hssk_ulvsplit_desc{Dh[id], m, m, r, nd.permU, nd.XU, std::max(r, 1), nd.W1, std::max(r, 1), nd.Rlq, m});
         } else {
@@ -2609,7 +2628,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
           g3.push_back(hssk_gemm_desc{Vh[id], nd.Qt, nd.Vt0T, rv, m - r, m, m, m, rv, 1, 0, 1.0, 0.0});
           if (r) g3.push_back(hssk_gemm_desc{nd.Qt + (size_t)(m - r) * m, Vh[id], nd.Vt1, r, rv, m, m, m, r, 1, 0, 1.0, 0.0});
         }
-        if (r) g3.push_back(hssk_gemm_desc{nd.W1, nd.Qt + (size_t)(m - r) * m, nd.Dt, r, r, m, r, m, r, 0, 0, 1.0, 0.0});
+        if (r) g3.push_back(hssk_gemm_desc{nd.W1, nd.Qt + (size_t)(m - r) * m, nd.Dt, r, r, m, r, m, ldt, 0, 0, 1.0, 0.0});
         // derived factors of the solve sweeps: WQ = W1 Q~(:, 0:m-r) and the inverted diagonal blocks of R~^T
         if (r) {
           nd.WQ = fact_->dbl((size_t)r * (m - r));
@@ -2623,9 +2642,10 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         stats_.f_ulv += 2.0 * k * r * m + (2.0 * m * k * k - 2.0 / 3.0 * k * k * k) + (4.0 * m * m * k - 2.0 * m * k * k) / 1.0 * 0.5 + 2.0 * m * m * rv + 2.0 * r * (double)r * m;
       } else {
         // nothing to eliminate: Dt = P^T D, Vt1 = Vh   (factor.hpp:138-141)
-        nd.Dt = fact_->dbl((size_t)std::max(m, 1) * std::max(m, 1));
+        int ldt = 1;
+        nd.Dt = dt_slot(id, m, ldt);
         nd.Vt1 = Vh[id];
-        if (m) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.Dt, m, m, m, 0});
+        if (m) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.Dt, m, m, ldt, 0});
       }
     }
     if (!us.empty()) ck(hssk_ulv_split(ctx_, us.data(), (int)us.size()));
