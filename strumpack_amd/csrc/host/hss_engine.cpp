@@ -2510,7 +2510,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   stats_.f_ulv = 0;
   for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nd.Vt0T = nullptr, nd.piv = nullptr;
   const size_t nn = nodes_.size();
-  std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr);
+  std::vector<double*> Dh(nn, nullptr), Vh(nn, nullptr), Vd(nn, nullptr);
   // inverted diagonal blocks for the single-launch solve sweeps: nothing in the factorization reads them, so the
   // descriptors of all levels are collected and take ONE launch at the end (a launch per level was 10-20 us each)
   std::vector<hssk_trtri_desc> ti;
@@ -2534,7 +2534,6 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     // ---- assemble Dh (mU x mU) and Vh (mU x rV)
     std::vector<hssk_colgather_desc> cp;
     std::vector<hssk_gemm_desc> g0, g1;
-    std::vector<hssk_basis_desc> bd;
     Arena& tmp = *tmp_;   // (rewound once per factorization: the levels are enqueued back to back, no host sync between them)
     for (int id : ids) {
       Node& nd = nodes_[id];
@@ -2558,23 +2557,15 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
         g0.push_back(hssk_gemm_desc{nd.B10, a.Vt1, Dh[id] + a.rU, b.rU, a.rU, a.rV, std::max(b.rU, 1), std::max(a.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
         stats_.f_ulv += 2.0 * a.rU * (double)b.rU * (a.rV + b.rV);
       }
-      if (!root || partial) {
-        Vh[id] = fact_->dbl((size_t)std::max(nd.mU, 1) * std::max(nd.rV, 1));
-        if (nd.leaf()) {
-          if (nd.rV) bd.push_back(hssk_basis_desc{nd.XV, nd.permV, Vh[id], nd.mV, nd.rV, nd.rV, nd.mV});
-        } else if (nd.rV) {
-          Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
-          double* Vd = tmp.dbl((size_t)nd.mV * nd.rV);
-          bd.push_back(hssk_basis_desc{nd.XV, nd.permV, Vd, nd.mV, nd.rV, nd.rV, nd.mV});
-          // Vh = [Vt1_0 Vd(0:rV0, :) ; Vt1_1 Vd(rV0:, :)]
-          g1.push_back(hssk_gemm_desc{a.Vt1, Vd, Vh[id], a.rU, nd.rV, a.rV, std::max(a.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
-          g1.push_back(hssk_gemm_desc{b.Vt1, Vd + a.rV, Vh[id] + a.rU, b.rU, nd.rV, b.rV, std::max(b.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
-          stats_.f_ulv += 2.0 * nd.rV * ((double)a.rU * a.rV + (double)b.rU * b.rV);
-        }
+      if ((!root || partial) && !nd.leaf() && nd.rV) {
+        Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+        // Vh = [Vt1_0 Vd(0:rV0, :) ; Vt1_1 Vd(rV0:, :)]   (Vd: the node's dense column basis, formed ahead of the levels)
+        g1.push_back(hssk_gemm_desc{a.Vt1, Vd[id], Vh[id], a.rU, nd.rV, a.rV, std::max(a.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+        g1.push_back(hssk_gemm_desc{b.Vt1, Vd[id] + a.rV, Vh[id] + a.rU, b.rU, nd.rV, b.rV, std::max(b.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+        stats_.f_ulv += 2.0 * nd.rV * ((double)a.rU * a.rV + (double)b.rU * b.rV);
       }
     }
     if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
-    if (!bd.empty()) ck(hssk_basis_dense(ctx_, bd.data(), (int)bd.size()));
     // (the coupling products into Dh and the products that build Vh are independent of each other: one batched launch)
     g0.insert(g0.end(), g1.begin(), g1.end());
     if (!g0.empty()) ck(hssk_gemm_vbatched(ctx_, g0.data(), (int)g0.size()));
@@ -2658,6 +2649,25 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   std::vector<std::vector<int>> sub_h;
   if (sr != 0) sub_h = sublists(own_by_height_, sr);
   tmp_->rewind();
+  {
+    // the dense column bases [I; X^T] in row order (leaves: straight into Vh; inner nodes: Vd, multiplied by the children's
+    // Vt1 at the node's level) depend on the compression only: one launch for the whole tree instead of one per level
+    std::vector<hssk_basis_desc> bd;
+    auto prep = [&](const std::vector<int>& ids) {
+      for (int id : ids) {
+        const Node& nd = nodes_[id];
+        if (id == sr && !partial) continue;
+        Vh[id] = fact_->dbl((size_t)std::max(nd.mU, 1) * std::max(nd.rV, 1));
+        if (!nd.rV) continue;
+        double* out = Vh[id];
+        if (!nd.leaf()) out = Vd[id] = tmp_->dbl((size_t)nd.mV * nd.rV);
+        bd.push_back(hssk_basis_desc{nd.XV, nd.permV, out, nd.mV, nd.rV, nd.rV, nd.mV});
+      }
+    };
+    for (auto& ids : (sr ? sub_h : own_by_height_)) prep(ids);
+    if (dist_subtree_) for (auto& ids : top_by_height_) prep(ids);
+    if (!bd.empty()) ck(hssk_basis_dense(ctx_, bd.data(), (int)bd.size()));
+  }
   for (auto& ids : (sr ? sub_h : own_by_height_)) level(ids);
   if (dist_subtree_) {
     exchange_cut_factor();
