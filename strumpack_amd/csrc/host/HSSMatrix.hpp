@@ -161,7 +161,7 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   const HSSMatrixChild* child(int c) const;
   void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
   // binary file with the compressed representation (tree, D, B, bases; not the ULV factors) and back
-  // (HSSMatrix.cpp:438-510; the file layout is this library's own, see hss_engine.cpp)
+  // (HSSMatrix.cpp:438-510; the file layout is this library's own, see hss_io.cpp)
   void write(const std::string& fname) const;
   static HSSMatrix<double> read(const std::string& fname);
   HSSMatrix(HSSMatrix<double>&&) = default;

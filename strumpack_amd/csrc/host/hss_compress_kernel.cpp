@@ -1,0 +1,189 @@
+// DeviceHSS: compression of a kernel matrix from point coordinates.
+#include "hss_engine_internal.hpp"
+
+namespace strumpack {
+namespace HSS {
+
+// ---------------------------------------------------------------------------------------------
+// Kernel-matrix compression from point coordinates:
+// HSSMatrix::compress_with_coordinates / compress_recursive_ann / compute_local_samples_ann /
+// compute_U_V_bases_ann (HSS/HSSMatrix.compress_kernel.hpp:50-293), level-synchronous.
+// No random sketch: the sample of a node is S = K(I, cols) with cols = the neighbours of the node's points
+// that lie outside the node (leaf) resp. the union of the children's column sets outside the node (inner),
+// I = the node's rows (leaf) resp. its children's skeleton rows; symmetric: V = U, B10 = B01^T.
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int user_k) {
+  OpGuard op_guard(op_mu_);
+  double t0 = now();
+  stats_ = PhaseStats();
+  const int N = n_, dim = ks.d;
+  if (dim <= 0 || !ks.X) throw std::invalid_argument("compress_kernel: no points");
+  int k = std::min(N, std::max(1, user_ann ? user_k : ks.ann));
+  for (;;) {
+    reset_compression();
+    stats_.rounds++;
+    // points and neighbour lists
+    double* dX = work_->dbl((size_t)dim * N);
+    ck(hssk_memcpy_h2d(ctx_, dX, ks.X, (long long)sizeof(double) * dim * N));
+    hssk_kernel_spec spec{dX, N, dim, ks.type, ks.p, ks.h, ks.lambda};
+    double tk0 = now();
+    std::vector<int> ann((size_t)k * N);
+    if (user_ann && k == user_k) std::copy(user_ann, user_ann + (size_t)k * N, ann.begin());
+    else if (ks.neighbors) ks.neighbors(k, ann.data());
+    else {
+      // one process per GPU: neighbours of this rank's own points only (its subtree's leaves are all that read them)
+      int q0 = 0, q1 = N;
+      if (dist_subtree_) { const Node& c = nodes_[cut_nodes_[o_.rank]]; q0 = c.lo; q1 = c.lo + c.m; }
+      int* dann = work_->ints((size_t)k * N);
+      ck(hssk_knn(ctx_, dX, dim, N, k, q0, q1, dann));
+      ck(hssk_memcpy_d2h(ctx_, ann.data() + (size_t)k * q0, dann + (size_t)k * q0, (long long)sizeof(int) * k * (q1 - q0)));
+    }
+    stats_.t_random += now() - tk0;   // neighbour search (reported in the 'random' slot: it replaces the random sketch)
+    std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node
+    bool failed = false;
+    auto do_level = [&](const std::vector<int>& ids) {
+      if (ids.empty() || failed) return;
+      tmp_->rewind();
+      double tl0 = now();
+      // ---- column sets and row sets (host), one index upload per level
+      std::vector<int> hidx;
+      std::vector<size_t> roff(ids.size()), coff(ids.size());
+      std::vector<std::vector<int>> rows(ids.size());
+      // the nodes of a level are independent: host threads build their row / column sets side by side
+      host_parallel_for(ids.size(), [&](size_t q) {
+        Node& nd = nodes_[ids[q]];
+        std::vector<int>& cs = cols[ids[q]];
+        const int lo = nd.lo, hi = nd.lo + nd.m;
+        if (nd.leaf()) {
+          nd.mU = nd.mV = nd.m;
+          rows[q].resize(nd.m);
+          for (int i = 0; i < nd.m; i++) rows[q][i] = lo + i;
+          if (nd.lvl > 0) {
+            // sorted, duplicate-free ids outside the node: marked in a bitmap over the point set and read back in order
+            // (m k ~ 1e4 ids per leaf: cheaper than sorting them)
+            std::vector<unsigned long long> bits(((size_t)N + 63) / 64, 0ULL);
+            size_t marked = 0;
+            for (int i = lo; i < hi; i++)
+              for (int j = 0; j < k; j++) {
+                const int g = ann[(size_t)i * k + j];
+                if (g >= 0 && (g < lo || g >= hi)) {
+                  unsigned long long& wd = bits[(size_t)g >> 6];
+                  const unsigned long long b = 1ULL << (g & 63);
+                  marked += !(wd & b);
+                  wd |= b;
+                }
+              }
+            cs.reserve(marked);
+            for (size_t wi = 0; wi < bits.size(); wi++) {
+              unsigned long long wd = bits[wi];
+              while (wd) {
+                cs.push_back((int)(wi * 64 + (size_t)__builtin_ctzll(wd)));
+                wd &= wd - 1;
+              }
+            }
+          }
+        } else {
+          Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+          nd.mU = nd.mV = a.rU + b.rU;
+          rows[q] = a.Ir;
+          rows[q].insert(rows[q].end(), b.Ir.begin(), b.Ir.end());
+          if (nd.lvl > 0) {
+            // union of the children's (sorted, duplicate-free) sets without the ids inside this node
+            const std::vector<int>&ca = cols[nd.c0], &cb = cols[nd.c1];
+            cs.reserve(ca.size() + cb.size());
+            size_t i = 0, j = 0;
+            auto keep = [&](int g) { if (g < lo || g >= hi) cs.push_back(g); };
+            while (i < ca.size() && j < cb.size()) {
+              if (ca[i] < cb[j]) keep(ca[i++]);
+              else if (cb[j] < ca[i]) keep(cb[j++]);
+              else { keep(ca[i]); i++; j++; }
+            }
+            while (i < ca.size()) keep(ca[i++]);
+            while (j < cb.size()) keep(cb[j++]);
+          }
+        }
+      });
+      for (size_t q = 0; q < ids.size(); q++) {
+        const std::vector<int>& cs = cols[ids[q]];
+        roff[q] = hidx.size(); hidx.insert(hidx.end(), rows[q].begin(), rows[q].end());
+        coff[q] = hidx.size(); hidx.insert(hidx.end(), cs.begin(), cs.end());
+      }
+      // the children's column sets are not needed above this level
+        for (int id : ids) {
+          if (nodes_[id].leaf()) continue;
+          std::vector<int>().swap(cols[nodes_[id].c0]);
+          std::vector<int>().swap(cols[nodes_[id].c1]);
+        }
+      int* didx = tmp_->ints(std::max<size_t>(hidx.size(), 1));
+      if (!hidx.empty()) ck(hssk_memcpy_h2d(ctx_, didx, hidx.data(), (long long)sizeof(int) * hidx.size()));
+      stats_.t_sketch += now() - tl0;   // host column-set construction (the 'sketch' slot of this path)
+      // ---- D (leaves), B01 / B10 (inner nodes), sample panels W = K(cols, rows)  [= S^T]
+      std::vector<hssk_keval_desc> ev;
+      std::vector<hssk_transpose_desc> tr;
+      std::vector<int> idn, which;
+      std::vector<double*> Ws;
+      std::vector<int> ds;
+      for (size_t q = 0; q < ids.size(); q++) {
+        Node& nd = nodes_[ids[q]];
+        if (nd.leaf()) {
+          nd.D = persist_->dbl((size_t)nd.m * nd.m);
+          ev.push_back(hssk_keval_desc{nullptr, nullptr, nd.D, nd.m, nd.m, nd.m, nd.lo, nd.lo});
+        } else {
+          Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+          nd.B01 = persist_->dbl((size_t)std::max(a.rU, 1) * std::max(b.rV, 1));
+          nd.B10 = persist_->dbl((size_t)std::max(b.rU, 1) * std::max(a.rV, 1));
+          if (a.rU > 0 && b.rV > 0) {
+            ev.push_back(hssk_keval_desc{a.dIr, b.dIc, nd.B01, a.rU, b.rV, a.rU, 0, 0});
+            tr.push_back(hssk_transpose_desc{nd.B01, nd.B10, a.rU, b.rV, a.rU, b.rU});
+          }
+        }
+        if (nd.lvl == 0) { nd.Ustate = nd.Vstate = 2; continue; }
+        const int m = nd.mU, d = (int)cols[ids[q]].size();
+        idn.push_back(ids[q]); which.push_back(0); ds.push_back(d);
+        double* W = (m > 0 && d > 0) ? tmp_->dbl((size_t)d * m) : nullptr;
+        Ws.push_back(W);
+        if (W) ev.push_back(hssk_keval_desc{didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
+      }
+      if (!ev.empty()) ck(hssk_kernel_eval_vbatched(ctx_, &spec, ev.data(), (int)ev.size()));
+      if (!tr.empty()) ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
+      if (idn.empty()) return;
+      // nodes with an empty column set (d == 0) get rank 0 through a 1 x m zero panel
+      for (size_t q = 0; q < idn.size(); q++)
+        if (!Ws[q] && nodes_[idn[q]].mU > 0) {
+          Ws[q] = tmp_->dbl(nodes_[idn[q]].mU);
+          ck(hssk_memset_zero(ctx_, Ws[q], (long long)sizeof(double) * nodes_[idn[q]].mU));
+          ds[q] = 1;
+        }
+      id_panels(idn, which, Ws, ds);
+      // symmetric: V = U; acceptance test of compute_U_V_bases_ann (:262-272)
+      for (size_t q = 0; q < idn.size(); q++) {
+        Node& nd = nodes_[idn[q]];
+        nd.rV = nd.rU; nd.XV = nd.XU; nd.permV = nd.permU; nd.hpermV = nd.hpermU; nd.Ic = nd.Ir; nd.dIc = nd.dIr; nd.Vstate = nd.Ustate;
+        const int d = (int)cols[idn[q]].size();
+        if (!(d >= nd.m || d >= o_.max_rank || nd.rU + o_.p < d)) failed = true;
+      }
+    };
+    for (auto& ids : own_by_height_) do_level(ids);
+    if (dist_subtree_) {
+      failed = exchange_cut_kernel(cols, failed);
+      for (auto& ids : top_by_height_) do_level(ids);
+    }
+    ck(hssk_sync(ctx_));
+    if (!failed) break;
+    if (k >= N) throw std::runtime_error("compress_kernel: the ID did not reach the required accuracy with all points as neighbours");
+    k = std::min(2 * k, N);   // compress_with_coordinates: ann_number doubles until the tree compresses (:75)
+    if (o_.verbose) std::cout << "# HSS kernel compression: increasing the neighbour count to " << k << std::endl;
+  }
+  if (dist_subtree_) exchange_node_table();
+  free_compress_workspace();
+  comm_arena_->reset();
+  stats_.d_final = k;
+  stats_.t_compress = now() - t0;
+  stats_.t_tree = stats_.t_compress - stats_.t_sketch - stats_.t_random;
+  if (o_.verbose)
+    std::cout << "# HSS kernel compression: neighbours " << stats_.t_random << " s, column sets " << stats_.t_sketch << " s, blocks + ID "
+              << stats_.t_tree << " s" << std::endl;
+}
+
+}  // namespace HSS
+}  // namespace strumpack

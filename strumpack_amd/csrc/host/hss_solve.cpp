@@ -1,0 +1,338 @@
+// DeviceHSS: ULV solve (HSSMatrix.solve.hpp:69-238).
+#include "hss_engine_internal.hpp"
+
+namespace strumpack {
+namespace HSS {
+
+// ---------------------------------------------------------------------------------------------
+// ULV solve (HSSMatrix.solve.hpp:69-238)
+// ---------------------------------------------------------------------------------------------
+void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
+  OpGuard op_guard(op_mu_);
+  ensure_ready("solve");
+  if (!factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
+  if (nrhs <= 0 || n_ == 0) return;
+  double t0 = now();
+  // repeated solve on the same device buffer: replay the recorded sweep (no descriptor building, no staging)
+  const bool plannable = on_device && o_.world == 1 && plans_enabled();
+  const PlanKey key{1, 'N', nrhs, (const void*)b, (void*)b, ldb, ldb, 0.};
+  if (plannable) {
+    auto it = plans_.find(key);
+    if (it != plans_.end() && it->second.plan) {
+      ck(hssk_plan_replay(ctx_, it->second.plan));
+      ck(hssk_sync(ctx_));
+      if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("solve: ") + hssk_last_error());
+      stats_.t_solve = now() - t0;
+      return;
+    }
+  }
+  hssk_plan* rec = nullptr;
+  // the first call on a buffer runs normally; the second one is recorded while it runs, later ones replay
+  if (plannable && plans_.size() > 32) drop_plans();   // many different buffers: start over rather than grow
+  if (plannable && ++plans_[key].seen == 2) ck(hssk_plan_begin(ctx_, &rec));
+  struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
+  Arena& tmp = rec ? *plan_arena_ : *tmp_;   // a recorded sweep keeps its own work vectors
+  if (!rec) tmp.rewind();
+  const int N = n_;
+  double* db = b;
+  long long lb = ldb;
+  if (!on_device) {
+    db = tmp.dbl((size_t)N * nrhs);
+    ck(hssk_memcpy2d_h2d(ctx_, db, sizeof(double) * N, b, sizeof(double) * ldb, sizeof(double) * N, nrhs));
+    lb = N;
+  }
+  if (lb > 0x7fffffffLL) throw std::invalid_argument("solve: leading dimension too large");
+  const size_t nn = nodes_.size();
+  // f: assembled right-hand side of an inner node (mU rows; children write ft1 into it);
+  // y: (mU - rU) rows; zc: children's z stacked (mV rows); xb: solution in the node's basis (mU rows)
+  std::vector<double*> f(nn, nullptr), y(nn, nullptr), zc(nn, nullptr), xb(nn, nullptr);
+  // (f, zc, xb are handed from node to node: carved from one block that the single-launch sweeps arm with a sentinel)
+  size_t hand_total = 0;
+  for (size_t i = 0; i < nn; i++) {
+    if (!mine((int)i) || nodes_[i].leaf()) continue;
+    const Node& nd = nodes_[i];
+    const int mu = nodes_[nd.c0].rU + nodes_[nd.c1].rU, mv = nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+    hand_total += (size_t)(2 * std::max(mu, 1) + std::max(mv, 1)) * nrhs;
+  }
+  double* hand = tmp.dbl(std::max<size_t>(hand_total, 1));
+  {
+    size_t off = 0;
+    for (size_t i = 0; i < nn; i++) {
+      if (!mine((int)i)) continue;
+      const Node& nd = nodes_[i];
+      if (!nd.leaf()) {
+        const int mu = nodes_[nd.c0].rU + nodes_[nd.c1].rU, mv = nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+        f[i] = hand + off; off += (size_t)std::max(mu, 1) * nrhs;
+        zc[i] = hand + off; off += (size_t)std::max(mv, 1) * nrhs;
+        xb[i] = hand + off; off += (size_t)std::max(mu, 1) * nrhs;
+      }
+      if (nd.lvl > 0 && nd.mU > nd.rU) y[i] = tmp.dbl((size_t)(nd.mU - nd.rU) * nrhs);
+    }
+  }
+  // few right-hand sides: the whole forward sweep (root solve included) and the whole backward sweep are ONE launch each
+  // (hssk_ulv_fwd_sweep / _bwd_sweep: a workgroup per node, dependency flags between them) instead of 7 / 3 batched
+  // launches per level
+  static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
+  const bool fuse = nrhs <= 64 && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
+  if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
+  typedef std::vector<std::vector<int>> Levels;
+  auto fwd_sweep = [&](const Levels& levels) -> bool {
+    std::vector<hssk_sweep_fwd_desc> fd;
+    std::vector<int> where(nn, -1);
+    for (auto& ids : levels)
+      for (int id : ids) {
+        const Node& nd = nodes_[id];
+        hssk_sweep_fwd_desc d{};
+        d.wait0 = d.wait1 = -1;
+        d.mv = nd.leaf() ? nd.m : nodes_[nd.c0].rV + nodes_[nd.c1].rV;
+        if (nd.leaf()) { d.fsrc = db + nd.lo; d.ldf = (int)lb; }
+        else {
+          const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+          d.fsrc = f[id]; d.ldf = std::max(a.rU + c.rU, 1);
+          d.B01 = nd.B01; d.B10 = nd.B10; d.zc = zc[id];
+          d.rU0 = a.rU; d.rU1 = c.rU; d.rV0 = a.rV; d.rV1 = c.rV; d.ldz_in = std::max(a.rV + c.rV, 1);
+          d.permV = nd.permV; d.XV = nd.XV;
+          if (!d.B01 || !d.B10) return false;
+          d.wait0 = where[nd.c0]; d.wait1 = where[nd.c1];
+        }
+        if (nd.lvl == 0) {
+          // root: x = LU^{-1} f
+          d.m = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+          if (d.m == 0) continue;
+          d.LU = nd.LU; d.piv = nd.piv; d.TinvL = nd.Tinv; d.TinvU = nd.TinvU;
+          if (!d.LU || !d.TinvL || !d.TinvU) return false;
+          d.xroot = nd.leaf() ? db + nd.lo : xb[id];
+          d.ldxr = nd.leaf() ? (int)lb : std::max(d.m, 1);
+        } else {
+          const Node& pa = nodes_[nd.parent];
+          d.m = nd.mU; d.r = nd.rU; d.rv = nd.rV;
+          if (!nd.leaf()) d.mv = nd.mV;
+          d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Tinv = nd.Tinv; d.WQ = nd.WQ; d.Vt0T = nd.Vt0T;
+          d.ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+          d.ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+          d.z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+          d.ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+          d.y = y[id];
+          if (d.m > d.r && (!d.y || !d.Rlq || !d.Tinv || (d.r && !d.WQ) || (d.rv && !d.Vt0T))) return false;
+        }
+        where[id] = (int)fd.size();
+        fd.push_back(d);
+      }
+    if (fd.empty()) return true;
+    const int rc = hssk_ulv_fwd_sweep(ctx_, fd.data(), (int)fd.size(), nrhs);
+    if (rc == 2) return false;
+    ck(rc);
+    return true;
+  };
+  auto bwd_sweep = [&](const Levels& levels) -> bool {
+    std::vector<hssk_sweep_bwd_desc> bd;
+    std::vector<int> where(nn, -1);
+    for (auto& ids : levels)
+      for (int id : ids) {
+        const Node& nd = nodes_[id];
+        if (nd.leaf()) continue;
+        const Node& a = nodes_[nd.c0];
+        const int cid[2] = {nd.c0, nd.c1};
+        for (int q = 0; q < 2; q++) {
+          if (!mine(cid[q])) continue;
+          const Node& cn = nodes_[cid[q]];
+          if (cn.mU == 0) continue;
+          hssk_sweep_bwd_desc d{};
+          d.Qt = cn.Qt; d.y = y[cid[q]]; d.xpart = xb[id] + (q ? a.rU : 0);
+          d.out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+          d.m = cn.mU; d.r = cn.rU; d.ldx = std::max(a.rU + nodes_[nd.c1].rU, 1); d.ldo = cn.leaf() ? (int)lb : std::max(cn.mU, 1);
+          d.wait0 = where[id];
+          if (d.m > d.r && (!d.Qt || !d.y)) return false;
+          where[cid[q]] = (int)bd.size();
+          bd.push_back(d);
+        }
+      }
+    if (bd.empty()) return true;
+    const int rc = hssk_ulv_bwd_sweep(ctx_, bd.data(), (int)bd.size(), nrhs);
+    if (rc == 2) return false;
+    ck(rc);
+    return true;
+  };
+  // ---- forward, one tree height
+  auto fwd = [&](const std::vector<int>& ids) {
+    if (ids.empty()) return;
+    std::vector<hssk_gemm_desc> ga, gb, gc, gd, ge;
+    std::vector<hssk_rowgather_desc> rg;
+    std::vector<hssk_trsm_desc> ts;
+    std::vector<hssk_lusolve_desc> ls;
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      if (nd.leaf()) continue;
+      const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+      const int ldf = std::max(a.rU + c.rU, 1), lz = std::max(a.rV + c.rV, 1);
+      // f0 = ft1_0 - B01 z_1 ; f1 = ft1_1 - B10 z_0   (solve.hpp:88-99).  The children already wrote
+      // ft1 - W1 (Q0^T y) into f (the -W1 Q0^T y term of solve.hpp:100-131 only needs child data).
+      ga.push_back(hssk_gemm_desc{nd.B01, zc[id] + a.rV, f[id], a.rU, nrhs, c.rV, std::max(a.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
+      ga.push_back(hssk_gemm_desc{nd.B10, zc[id], f[id] + a.rU, c.rU, nrhs, a.rV, std::max(c.rU, 1), lz, ldf, 0, 0, -1.0, 1.0});
+    }
+    if (!ga.empty()) ck(hssk_gemm_vbatched(ctx_, ga.data(), (int)ga.size()));
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      const double* fsrc = nd.leaf() ? db + nd.lo : f[id];
+      const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
+      const int ldf = nd.leaf() ? (int)lb : std::max(mu, 1);
+      if (nd.lvl == 0) {
+        // x = LU^{-1} f (solve.hpp:133-135)
+        if (nd.leaf()) { if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, db + nd.lo, mu, nrhs, mu, (int)lb}); }
+        else {
+          rg.push_back(hssk_rowgather_desc{f[id], xb[id], nullptr, mu, nrhs, ldf, std::max(mu, 1), 0, 0});
+          if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, xb[id], mu, nrhs, mu, std::max(mu, 1)});
+        }
+        continue;
+      }
+      const Node& pa = nodes_[nd.parent];
+      const int m = nd.mU, r = nd.rU;
+      double* ft1 = f[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+      const int ldp = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+      double* z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+      const int ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+      // f <- P^T f ; ft1 = f(0:r) ; y = L^{-1} (f(r:) - E ft1)    (solve.hpp:153-163)
+      if (r) rg.push_back(hssk_rowgather_desc{fsrc, ft1, nd.permU, r, nrhs, ldf, ldp, 0, 0});
+      if (m > r) {
+        rg.push_back(hssk_rowgather_desc{fsrc, y[id], nd.permU + r, m - r, nrhs, ldf, m - r, 0, 0});
+        if (r) gd.push_back(hssk_gemm_desc{nd.XU, ft1, y[id], m - r, nrhs, r, r, ldp, m - r, 1, 0, -1.0, 1.0});
+        ts.push_back(hssk_trsm_desc{nd.Rlq, y[id], m - r, nrhs, m, m - r, 0, 1, 0});
+        if (r) {
+          // ft1 -= W1 (Q0^T y),  Q0^T y = Q~(:, :m-r) y
+          double* t = tmp.dbl((size_t)m * nrhs);
+          gb.push_back(hssk_gemm_desc{nd.Qt, y[id], t, m, nrhs, m - r, m, m - r, m, 0, 0, 1.0, 0.0});
+          gc.push_back(hssk_gemm_desc{nd.W1, t, ft1, r, nrhs, m, r, m, ldp, 0, 0, -1.0, 1.0});
+        }
+      }
+      // z = V^H [z0; z1] + Vt0^H y   (leaf: z = Vt0^H y)          (solve.hpp:164-192)
+      const int rv = nd.rV;
+      if (rv) {
+        double zbeta = 0.0;
+        if (!nd.leaf()) {
+          const int mv = nd.mV;
+          rg.push_back(hssk_rowgather_desc{zc[id], z, nd.permV, rv, nrhs, std::max(mv, 1), ldz, 0, 0});
+          if (mv > rv) {
+            double* t = tmp.dbl((size_t)(mv - rv) * nrhs);
+            rg.push_back(hssk_rowgather_desc{zc[id], t, nd.permV + rv, mv - rv, nrhs, std::max(mv, 1), mv - rv, 0, 0});
+            gd.push_back(hssk_gemm_desc{nd.XV, t, z, rv, nrhs, mv - rv, rv, mv - rv, ldz, 0, 0, 1.0, 1.0});
+          }
+          zbeta = 1.0;
+        }
+        if (m > r && rv > 0) ge.push_back(hssk_gemm_desc{nd.Vt0T, y[id], z, rv, nrhs, m - r, rv, m - r, ldz, 0, 0, 1.0, zbeta});   // z (+)= Vt0^T y
+        else if (nd.leaf()) ge.push_back(hssk_gemm_desc{z, z, z, rv, nrhs, 0, 1, 1, ldz, 0, 0, 1.0, 0.0});  // z = 0
+      }
+    }
+    if (!rg.empty()) ck(hssk_gather_rows(ctx_, rg.data(), (int)rg.size()));
+    if (!gd.empty()) ck(hssk_gemm_vbatched(ctx_, gd.data(), (int)gd.size()));
+    if (!ts.empty()) ck(hssk_trsm_vbatched(ctx_, ts.data(), (int)ts.size()));
+    if (!ge.empty()) ck(hssk_gemm_vbatched(ctx_, ge.data(), (int)ge.size()));
+    if (!gb.empty()) ck(hssk_gemm_vbatched(ctx_, gb.data(), (int)gb.size()));
+    if (!gc.empty()) ck(hssk_gemm_vbatched(ctx_, gc.data(), (int)gc.size()));
+    if (!ls.empty()) ck(hssk_getrs_vbatched(ctx_, ls.data(), (int)ls.size()));
+  };
+  // ---- backward, one depth (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
+  auto bwd = [&](const std::vector<int>& ids) {
+    std::vector<hssk_gemm_desc> g1, g2;
+    std::vector<hssk_rowgather_desc> cp;
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      if (nd.leaf()) continue;
+      const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+      const int mu = a.rU + c.rU;
+      const double* x = xb[id];
+      const int ldx = std::max(mu, 1);
+      const Node* ch[2] = {&a, &c};
+      const int cid[2] = {nd.c0, nd.c1};
+      for (int q = 0; q < 2; q++) {
+        if (!mine(cid[q])) continue;  // the other ranks' subtrees continue on their owners
+        const Node& cn = *ch[q];
+        const int mc = cn.mU, rc = cn.rU;
+        const double* xpart = x + (q ? a.rU : 0);
+        double* out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+        const int ldo = cn.leaf() ? (int)lb : std::max(mc, 1);
+        if (mc > rc) {
+          g1.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], out, mc, nrhs, mc - rc, mc, mc - rc, ldo, 0, 0, 1.0, 0.0});
+          if (rc) g2.push_back(hssk_gemm_desc{cn.Qt + (size_t)(mc - rc) * mc, xpart, out, mc, nrhs, rc, mc, ldx, ldo, 0, 0, 1.0, 1.0});
+        } else if (mc) {
+          cp.push_back(hssk_rowgather_desc{xpart, out, nullptr, mc, nrhs, ldx, ldo, 0, 0});
+        }
+      }
+    }
+    if (!g1.empty()) ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
+    if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
+    if (!cp.empty()) ck(hssk_gather_rows(ctx_, cp.data(), (int)cp.size()));
+  };
+  if (!(fuse && fwd_sweep(own_by_height_)))
+    for (auto& ids : own_by_height_) fwd(ids);
+  if (dist_subtree_) {
+    // publish ft1' (rU x nrhs) and z (rV x nrhs) of the cut nodes into every rank's top buffers
+    const int G = o_.world, me = o_.rank;
+    int ru = 1, rv = 1;
+    for (int g = 0; g < G; g++) { ru = std::max(ru, nodes_[cut_nodes_[g]].rU); rv = std::max(rv, nodes_[cut_nodes_[g]].rV); }
+    const size_t blk = (size_t)(ru + rv) * nrhs;
+    double* buf = tmp.dbl(blk * G);
+    auto slices = [&](int g, double*& pf, int& ldf, double*& pz, int& ldz) {
+      const int id = cut_nodes_[g];
+      const Node& pa = nodes_[nodes_[id].parent];
+      pf = f[nodes_[id].parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rU);
+      ldf = std::max(nodes_[pa.c0].rU + nodes_[pa.c1].rU, 1);
+      pz = zc[nodes_[id].parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
+      ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
+    };
+    {
+      double *pf, *pz; int ldf, ldz;
+      slices(me, pf, ldf, pz, ldz);
+      const Node& c = nodes_[cut_nodes_[me]];
+      std::vector<hssk_rowgather_desc> pk;
+      if (c.rU) pk.push_back(hssk_rowgather_desc{pf, buf + blk * me, nullptr, c.rU, nrhs, ldf, ru, 0, 0});
+      if (c.rV) pk.push_back(hssk_rowgather_desc{pz, buf + blk * me + (size_t)ru * nrhs, nullptr, c.rV, nrhs, ldz, rv, 0, 0});
+      if (!pk.empty()) ck(hssk_gather_rows(ctx_, pk.data(), (int)pk.size()));
+    }
+    comm(buf, (long long)(sizeof(double) * blk));
+    std::vector<hssk_rowgather_desc> up;
+    for (int g = 0; g < G; g++) {
+      if (g == me) continue;
+      double *pf, *pz; int ldf, ldz;
+      slices(g, pf, ldf, pz, ldz);
+      const Node& c = nodes_[cut_nodes_[g]];
+      if (c.rU) up.push_back(hssk_rowgather_desc{buf + blk * g, pf, nullptr, c.rU, nrhs, ru, ldf, 0, 0});
+      if (c.rV) up.push_back(hssk_rowgather_desc{buf + blk * g + (size_t)ru * nrhs, pz, nullptr, c.rV, nrhs, rv, ldz, 0, 0});
+    }
+    if (!up.empty()) ck(hssk_gather_rows(ctx_, up.data(), (int)up.size()));
+    if (!(fuse && fwd_sweep(top_by_height_)))
+      for (auto& ids : top_by_height_) fwd(ids);
+    if (!(fuse && bwd_sweep(top_by_depth_)))
+      for (auto& ids : top_by_depth_) bwd(ids);
+  }
+  if (!(fuse && bwd_sweep(own_by_depth_)))
+    for (auto& ids : own_by_depth_) bwd(ids);
+  if (dist_subtree_) allgather_rows(db, lb, nrhs);
+  if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
+  if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
+  ck(hssk_sync(ctx_));
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("solve: ") + hssk_last_error());
+  stats_.t_solve = now() - t0;
+  {
+    double fs = 0;
+    for (auto& nd : nodes_) {
+      if (nd.lvl == 0) { const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU; fs += 2.0 * mu * (double)mu; continue; }
+      const double m = nd.mU, r = nd.rU, k = m - r, rv = nd.rV;
+      fs += 2.0 * k * r + k * k + 2.0 * k * rv + 2.0 * m * m + 2.0 * k * m;
+      if (!nd.leaf()) fs += 4.0 * nodes_[nd.c0].rU * (double)nodes_[nd.c1].rV;
+    }
+    stats_.f_solve = fs * nrhs;
+    // blocks read by the sweeps (fused path: X, the off-diagonal part of R~ + its inverted diagonal blocks, WQ, Vt0, B, XV
+    // going up, Q~ going down; the unfused path reads W1 and Q~(:, 0:q) instead of WQ)
+    double bs = 0;
+    for (auto& nd : nodes_) {
+      if (nd.lvl == 0) { const double mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU; bs += mu * mu; continue; }
+      const double m = nd.mU, r = nd.rU, k = m - r, rv = nd.rV;
+      bs += r * k + k * (k + 1) / 2 + (fuse ? r * k : r * m + m * k) + k * rv + m * m;   // (per group of four right-hand sides when fused)
+      if (!nd.leaf()) bs += (double)nodes_[nd.c0].rU * nodes_[nd.c1].rV + (double)nodes_[nd.c1].rU * nodes_[nd.c0].rV + rv * (nd.mV - rv);
+    }
+    stats_.b_solve = 8.0 * bs;
+  }
+}
+
+}  // namespace HSS
+}  // namespace strumpack
