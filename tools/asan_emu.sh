@@ -24,3 +24,6 @@ T 260 --hss_leaf_size 32 --hss_rel_tol 1e-6 --hss_compression_algorithm original
 L 10 --hss_leaf_size 3 --hss_rel_tol 1e-5 --hss_abs_tol 1e-10 --hss_d0 32 --hss_dd 4
 T 1 --hss_leaf_size 16
 LINES
+# the Python-driven cases (kernel level + C interface) on the same objects as a shared library
+g++ -shared -fsanitize=address,undefined -o libstrumpack_amd_emu_asan.so k_*.o h_*.o emu_runtime.o -lpthread
+LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) timeout 2400 python $ROOT/tools/asan_emu_cases.py $B/libstrumpack_amd_emu_asan.so 2>&1 | grep -E "ok$|ERROR|runtime error|AddressSanitizer|SUMMARY|Traceback|Error"
