@@ -337,15 +337,22 @@ struct DeviceHSS::CallbackSource : DeviceHSS::Source {
   CallbackSource(const host_mult_t& m, const host_elem_t& e) : mult(m), elem(e) {}
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.o_.world > 1) throw std::invalid_argument("the host-callback interface is single-GPU");
+    // The user multiplies column-major N x dn blocks (AFunctor / Amult of the reference, HSSExtra.hpp:231-239); the
+    // samples live transposed on the device (dn x N rows of Rt / Srt / Sct).  The transposes run on the device; the host
+    // sees contiguous blocks only.
     const int N = H.n_;
-    std::vector<double> Rt((size_t)dn * N), R((size_t)N * dn), S((size_t)N * dn), St((size_t)dn * N);
-    ck(hssk_memcpy2d_d2h(H.ctx_, Rt.data(), sizeof(double) * dn, H.Rt_ + r0, sizeof(double) * H.dcap_, sizeof(double) * dn, N));
-    for (int j = 0; j < N; j++) for (int i = 0; i < dn; i++) R[j + (size_t)i * N] = Rt[i + (size_t)j * dn];
+    if (N == 0 || dn == 0) return;
+    double* dT = H.tmp_->dbl((size_t)N * dn);   // N x dn, column-major
+    std::vector<double> R((size_t)N * dn), S((size_t)N * dn);
+    hssk_transpose_desc t{H.Rt_ + r0, dT, dn, N, H.dcap_, N};
+    ck(hssk_transpose(H.ctx_, &t, 1));
+    ck(hssk_memcpy_d2h(H.ctx_, R.data(), dT, (long long)(sizeof(double) * R.size())));   // (synchronous)
     for (int pass = 0; pass < 2; pass++) {
       mult(pass == 0 ? 'N' : 'C', N, dn, R.data(), N, S.data(), N);
-      for (int j = 0; j < N; j++) for (int i = 0; i < dn; i++) St[i + (size_t)j * dn] = S[j + (size_t)i * N];
-      double* dst = (pass == 0 ? H.Srt_ : H.Sct_) + r0;
-      ck(hssk_memcpy2d_h2d(H.ctx_, dst, sizeof(double) * H.dcap_, St.data(), sizeof(double) * dn, sizeof(double) * dn, N));
+      ck(hssk_memcpy_h2d(H.ctx_, dT, S.data(), (long long)(sizeof(double) * S.size())));
+      hssk_transpose_desc b{dT, (pass == 0 ? H.Srt_ : H.Sct_) + r0, N, dn, N, H.dcap_};
+      ck(hssk_transpose(H.ctx_, &b, 1));
+      ck(hssk_sync(H.ctx_));   // dT is reused by the next pass
     }
   }
   void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {

@@ -177,6 +177,32 @@ int main(int argc, char* argv[]) {
     std::cout << "# ||S^{-1} (S z1) - z1|| / ||z1|| = " << std::sqrt(num / den) << std::endl;
     if (std::sqrt(num / den) > 1e-9) { std::cout << "ERROR: Schur complement is not consistent with the ULV solve" << std::endl; return 1; }
   }
+  // partially matrix-free construction: compress(Amult, Aelem, opts) (HSS/HSSMatrix.cpp:173-186) -- the user multiplies the
+  // random blocks and evaluates elements; same sketching matrix, so the result is the matrix compressed from A itself
+  if (m > 1 && m <= 600) {
+    HSSMatrix<double>::mult_t Amult = [&](DenseMatrix<double>& Rr, DenseMatrix<double>& Rc, DenseMatrix<double>& Sr, DenseMatrix<double>& Sc) {
+      const std::size_t d = Rr.cols();
+      for (std::size_t c = 0; c < d; c++)
+        for (int i = 0; i < m; i++) {
+          double sr = 0, sc = 0;
+          for (int l = 0; l < m; l++) { sr += A(i, l) * Rr(l, c); sc += A(l, i) * Rc(l, c); }
+          Sr(i, c) = sr; Sc(i, c) = sc;
+        }
+    };
+    HSSMatrix<double>::elem_t Aelem = [&](const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseMatrix<double>& B) {
+      for (std::size_t j = 0; j < J.size(); j++)
+        for (std::size_t i = 0; i < I.size(); i++) B(i, j) = A(I[i], J[j]);
+    };
+    HSSMatrix<double> Hf(m, m, hss_opts);
+    Hf.compress(Amult, Aelem, hss_opts);
+    if (!Hf.is_compressed()) { std::cout << "# matrix-free compression failed!!!!!!!!" << std::endl; return 1; }
+    auto Hfd = Hf.dense();
+    Hfd.scaled_add(-1., A);
+    std::cout << "# matrix-free: rank " << Hf.rank() << ", relative error = " << Hfd.normF() / A.normF() << std::endl;
+    if (Hfd.normF() / A.normF() > tol) { std::cout << "ERROR: matrix-free compression error too big!!" << std::endl; return 1; }
+    if (std::abs(double(Hf.rank()) - double(H.rank())) > 1) { std::cout << "ERROR: matrix-free rank differs!!" << std::endl; return 1; }
+  }
+
   std::cout << "# exiting" << std::endl;
   return 0;
 }
