@@ -128,19 +128,30 @@ void DeviceHSS::fill_random(int r0, int dn) {
     // i.e. sample by sample (dense/DenseMatrix.cpp:172-181); the generator persists across rounds
     // (HSSMatrix.compress_stable.hpp:108-112).
     if (r0 == 0 || !rng_) rng_.reset(new HostRng());
-    std::minstd_rand* lin = &rng_->lin;
-    std::mt19937* mer = &rng_->mer;
-    auto& nd = rng_->nd;
-    auto& ud = rng_->ud;
-    std::vector<double> buf((size_t)dn * N);
-    for (int s = 0; s < dn; s++)
-      for (long long c = 0; c < N; c++) {
-        double v;
-        if (o_.random_engine == 0) v = o_.random_dist == 0 ? nd(*lin) : ud(*lin);
-        else v = o_.random_dist == 0 ? nd(*mer) : ud(*mer);
-        buf[s + (size_t)c * dn] = v;
-      }
-    ck(hssk_memcpy2d_h2d(ctx_, Rt_ + r0, sizeof(double) * dcap_, buf.data(), sizeof(double) * dn, sizeof(double) * dn, N));
+    if (o_.random_engine == 0 && o_.random_dist == 0 && N > 0 && dn > 0) {
+      // the default (minstd_rand + normal): the same stream bit for bit, generated on all host threads (LinearNormal.hpp);
+      // the N x dn block is uploaded as it is drawn and transposed into the sample rows on the device
+      std::vector<double> blk((size_t)dn * N);
+      rng_->linnorm.fill(blk.data(), blk.size(), [](std::size_t n, const std::function<void(std::size_t)>& fn) { host_parallel_for(n, fn); });
+      double* dT = tmp_->dbl((size_t)dn * N);
+      ck(hssk_memcpy_h2d(ctx_, dT, blk.data(), (long long)(sizeof(double) * blk.size())));
+      hssk_transpose_desc t{dT, Rt_ + r0, (int)N, dn, (int)N, dcap_};
+      ck(hssk_transpose(ctx_, &t, 1));
+    } else {
+      std::minstd_rand* lin = &rng_->lin;
+      std::mt19937* mer = &rng_->mer;
+      auto& nd = rng_->nd;
+      auto& ud = rng_->ud;
+      std::vector<double> buf((size_t)dn * N);
+      for (int s = 0; s < dn; s++)
+        for (long long c = 0; c < N; c++) {
+          double v;
+          if (o_.random_engine == 0) v = o_.random_dist == 0 ? nd(*lin) : ud(*lin);
+          else v = o_.random_dist == 0 ? nd(*mer) : ud(*mer);
+          buf[s + (size_t)c * dn] = v;
+        }
+      ck(hssk_memcpy2d_h2d(ctx_, Rt_ + r0, sizeof(double) * dcap_, buf.data(), sizeof(double) * dn, sizeof(double) * dn, N));
+    }
   }
   ck(hssk_sync(ctx_));
   stats_.t_random += now() - t0;

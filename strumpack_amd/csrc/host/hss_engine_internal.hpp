@@ -4,6 +4,7 @@
 #pragma once
 #include "hss_engine.hpp"
 #include "Comm.hpp"
+#include "LinearNormal.hpp"
 
 #include <unistd.h>
 #include <atomic>
@@ -37,6 +38,7 @@ inline double now() {
 struct HostRng {
   std::default_random_engine sj{0};   // SJLT patterns (the reference seeds its generator from the clock, sketch.hpp:266-270)
   std::minstd_rand lin{0};
+  LinearNormal linnorm{0};   // lin under a normal distribution (the default), generated on all host threads
   std::mt19937 mer{0};
   std::normal_distribution<double> nd;
   std::uniform_real_distribution<double> ud;
