@@ -77,6 +77,13 @@ int hssk_compute_mark(hssk_ctx* ctx, int slot);
 int hssk_copy_wait(hssk_ctx* ctx, int slot);
 /* 1 if ptr is device memory of the current process (hipPointerGetAttributes) */
 int hssk_is_device_pointer(const void* ptr);
+/* Device-clock stopwatches on the compute stream: hssk_watch_start / _stop bracket the launches in between with HIP events
+ * (any number of start / stop pairs per stopwatch); hssk_watch_read_ms synchronises, returns the summed duration of
+ * stopwatch `id` (0 .. 7) in ms, writes the number of pairs to *pairs (may be NULL) and clears it.  This is how bench.py
+ * times one kind of kernel inside a timed region without a host synchronisation per launch. */
+int hssk_watch_start(hssk_ctx* ctx, int id);
+int hssk_watch_stop(hssk_ctx* ctx, int id);
+double hssk_watch_read_ms(hssk_ctx* ctx, int id, int* pairs);
 /* duration (HIP events on the launch stream, ms) and algorithmic flops (2 m cols k) of the MAIN kernel launch of
  * the last hssk_dgemm on this context -- the launch whose grid fills whole rounds of the 512 workgroup slots;
  * the short tail / edge launches and the reduce pass are outside the bracket. */

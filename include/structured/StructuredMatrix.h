@@ -201,6 +201,40 @@ int SPX_d_struct_schur_product_indirect(const CSPStructMat S, int c, const doubl
 /* C = op(H_cc) B for the diagonal block of child c (HSSMatrix::child(c)->apply, HSS/HSSMatrix.hpp:194-202) */
 int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, const double* B, long long ldB, double* C,
                             long long ldC, int on_device);
+/* ---- BLR frontal matrix: partial factorization of F = [F11 F12; F21 F22] -- what the reference's sparse BLR fronts call,
+ * BLR::BLRMatrix<T>::construct_and_partial_factor(A11, A12, A21, A22, B11, B12, B21, tiles1, tiles2, admissible, opts)
+ * (BLR/BLRMatrix.hpp:186-194, BLR/BLRMatrix.cpp:740-1037, algorithm RL = its default; batched GPU precedent
+ * BLR/BLRMatrix.GPU.cpp:71-262; caller sparse/fronts/FrontBLR.cpp:329-432).  F11 is dsep x dsep with row / column clusters
+ * tiles1 (ntiles1 sizes summing to dsep), F12 dsep x dupd and F21 dupd x dsep with clusters tiles2 on the update side.
+ * Per block step: LU of the diagonal tile, truncated-RRQR compression of the block row of [F11 F12] and of the block column
+ * of [F11; F21] (tolerances / max_rank from opts; F11 tiles per `admissible`, ntiles1 x ntiles1 column-major chars, NULL =
+ * every off-diagonal tile; F12 / F21 tiles always), triangular solves on the factors, Schur update of everything that
+ * trails -- including F22 <- F22 - F21 F11^{-1} F12, which stays dense.  Operands are column-major.
+ *   _factor:        HOST operands; F22 (may be NULL: taken as zero) is overwritten with the Schur complement.
+ *   _factor_device: DEVICE operands, borrowed for the call and left untouched; the Schur complement stays in HBM
+ *                   (SPX_d_blr_front_schur_device / SPX_d_blr_front_schur).
+ * Solve phases of a front (FrontBLR.cpp:525-570, BLRMatrix::trsmLNU_gemm / gemm_trsmUNN):
+ *   _forward:  bsep <- L11^{-1} P bsep,  bupd <- bupd - B21 bsep;      _backward:  ysep <- U11^{-1} (ysep - B12 yupd).
+ * _tile_ranks: (ntiles1 + ntiles2)^2 ints, column-major over the tiles of the whole front: rank of a U V^T tile, -1 dense.
+ * _stats: 12 doubles: [0] seconds of the factorization, [1..4] device ms of LU / compression / triangular solves / Schur
+ *   GEMMs (only with SPX_d_blr_front_time_phases(1) set before the call, else 0), [5] flops of the Schur GEMMs, [6] all
+ *   flops, [7..9] stored scalars of B11 / B12 / B21, [10] largest tile rank, [11] launches of the Schur GEMM phase. */
+typedef void* SPXBLRFront;
+int SPX_d_blr_front_factor(SPXBLRFront* F, int dsep, int dupd, const double* F11, int ld11, const double* F12, int ld12,
+                           const double* F21, int ld21, double* F22, int ld22, int ntiles1, const int* tiles1, int ntiles2,
+                           const int* tiles2, const char* admissible, const CSPOptions* opts);
+int SPX_d_blr_front_factor_device(SPXBLRFront* F, int dsep, int dupd, const double* dF11, long long ld11, const double* dF12,
+                                  long long ld12, const double* dF21, long long ld21, const double* dF22, long long ld22,
+                                  int ntiles1, const int* tiles1, int ntiles2, const int* tiles2, const char* admissible,
+                                  const CSPOptions* opts);
+void SPX_d_blr_front_time_phases(int on);
+int SPX_d_blr_front_forward(const SPXBLRFront F, int nrhs, double* bsep, int ldb, double* bupd, int ldu);
+int SPX_d_blr_front_backward(const SPXBLRFront F, int nrhs, double* ysep, int ldy, const double* yupd, int ldu);
+int SPX_d_blr_front_schur(const SPXBLRFront F, double* F22, int ld22);
+const double* SPX_d_blr_front_schur_device(const SPXBLRFront F, long long* ld);
+int SPX_d_blr_front_tile_ranks(const SPXBLRFront F, int* out);
+int SPX_d_blr_front_stats(const SPXBLRFront F, double* out);
+void SPX_d_blr_front_destroy(SPXBLRFront* F);
 /* the hssk kernel context of the matrix (include/hssk.h), for callers that share its stream */
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S);
 

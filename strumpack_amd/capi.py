@@ -32,6 +32,9 @@ SP_SYMBOLS = [
     "SPX_d_struct_from_dense_and_factor", "SPX_comm_unique_id", "SPX_comm_create", "SPX_comm_destroy", "SPX_comm_size", "SPX_comm_rank", "SPX_comm_selftest", "SPX_struct_shard_range",
     "SPX_d_struct_from_dense_device_comm", "SPX_d_struct_from_blocks_device", "SPX_d_struct_from_blocks_device_cb",
     "SPX_d_struct_from_kernel_comm",
+    "SPX_d_blr_front_factor", "SPX_d_blr_front_factor_device", "SPX_d_blr_front_time_phases", "SPX_d_blr_front_forward",
+    "SPX_d_blr_front_backward", "SPX_d_blr_front_schur", "SPX_d_blr_front_schur_device", "SPX_d_blr_front_tile_ranks",
+    "SPX_d_blr_front_stats", "SPX_d_blr_front_destroy",
 ]
 ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
@@ -101,7 +104,125 @@ def load(path):
     L.SPX_d_struct_mult_child.argtypes = [vp, C.c_int, C.c_char, C.c_int, dp, ll, dp, ll, C.c_int]
     L.SPX_d_struct_hssk_ctx.argtypes = [vp]
     L.SPX_d_struct_hssk_ctx.restype = vp
+    ip = C.POINTER(C.c_int)
+    L.SPX_d_blr_front_factor.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int,
+                                         C.c_int, ip, C.c_int, ip, C.c_char_p, C.POINTER(CSPOptions)]
+    L.SPX_d_blr_front_factor_device.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, ll, dp, ll, dp, ll, dp, ll,
+                                                C.c_int, ip, C.c_int, ip, C.c_char_p, C.POINTER(CSPOptions)]
+    L.SPX_d_blr_front_time_phases.argtypes = [C.c_int]
+    L.SPX_d_blr_front_time_phases.restype = None
+    L.SPX_d_blr_front_forward.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
+    L.SPX_d_blr_front_backward.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
+    L.SPX_d_blr_front_schur.argtypes = [vp, dp, C.c_int]
+    L.SPX_d_blr_front_schur_device.argtypes = [vp, C.POINTER(ll)]
+    L.SPX_d_blr_front_schur_device.restype = vp
+    L.SPX_d_blr_front_tile_ranks.argtypes = [vp, ip]
+    L.SPX_d_blr_front_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.SPX_d_blr_front_destroy.argtypes = [C.POINTER(vp)]
+    L.SPX_d_blr_front_destroy.restype = None
     return L
+
+
+class BLRFront:
+    """Partially factored BLR frontal matrix [F11 F12; F21 F22] behind the handle SPXBLRFront
+    (BLR::BLRMatrix<double>::construct_and_partial_factor of the reference, BLR/BLRMatrix.cpp:740)."""
+    STAT_NAMES = ["t_factor", "ms_lu", "ms_compress", "ms_trsm", "ms_schur", "f_schur", "f_total", "nnz11", "nnz12", "nnz21",
+                  "max_rank", "schur_launches"]
+
+    def __init__(self, lib, handle, dsep, dupd, nt1, nt2):
+        self.L, self.h, self.dsep, self.dupd, self.nt1, self.nt2 = lib, handle, dsep, dupd, nt1, nt2
+
+    @staticmethod
+    def _tiles(t):
+        a = np.ascontiguousarray(t, dtype=np.int32)
+        return a, a.ctypes.data_as(C.POINTER(C.c_int))
+
+    @staticmethod
+    def _adm(adm, nt1):
+        if adm is None:
+            return None
+        a = np.asfortranarray(np.asarray(adm).astype(np.int8).reshape(nt1, nt1))
+        return a.tobytes(order="F")
+
+    @classmethod
+    def factor(cls, lib, F11, F12, F21, F22, tiles1, tiles2, opts, admissible=None):
+        """host operands; returns (front, Schur complement F22 - F21 F11^{-1} F12)"""
+        ds, du = F11.shape[0], (F12.shape[1] if F12 is not None else 0)
+        f = lambda a: None if a is None else np.asfortranarray(a, dtype=np.float64)
+        F11, F12, F21 = f(F11), f(F12), f(F21)
+        S = np.array(F22, dtype=np.float64, order="F") if F22 is not None else np.zeros((du, du), order="F")
+        t1, p1 = cls._tiles(tiles1)
+        t2, p2 = cls._tiles(tiles2)
+        ptr = lambda a: a.ctypes.data if a is not None and a.size else None
+        h = C.c_void_p()
+        if lib.SPX_d_blr_front_factor(C.byref(h), ds, du, ptr(F11), max(ds, 1), ptr(F12), max(ds, 1), ptr(F21), max(du, 1),
+                                      ptr(S), max(du, 1), len(t1), p1, len(t2), p2, cls._adm(admissible, len(t1)), C.byref(opts)):
+            raise RuntimeError("SPX_d_blr_front_factor failed")
+        return cls(lib, h, ds, du, len(t1), len(t2)), S
+
+    @classmethod
+    def factor_device(cls, lib, dsep, dupd, dF11, ld11, dF12, ld12, dF21, ld21, dF22, ld22, tiles1, tiles2, opts, admissible=None):
+        t1, p1 = cls._tiles(tiles1)
+        t2, p2 = cls._tiles(tiles2)
+        h = C.c_void_p()
+        if lib.SPX_d_blr_front_factor_device(C.byref(h), dsep, dupd, dF11, ld11, dF12, ld12, dF21, ld21, dF22, ld22,
+                                             len(t1), p1, len(t2), p2, cls._adm(admissible, len(t1)), C.byref(opts)):
+            raise RuntimeError("SPX_d_blr_front_factor_device failed")
+        return cls(lib, h, dsep, dupd, len(t1), len(t2))
+
+    def forward(self, bsep, bupd=None):
+        bs = np.array(bsep, dtype=np.float64, order="F").reshape(self.dsep, -1, order="F")
+        bu = np.array(bupd, dtype=np.float64, order="F").reshape(self.dupd, -1, order="F") if self.dupd else None
+        if self.L.SPX_d_blr_front_forward(self.h, bs.shape[1], bs.ctypes.data, max(self.dsep, 1),
+                                          bu.ctypes.data if bu is not None else None, max(self.dupd, 1)):
+            raise RuntimeError("SPX_d_blr_front_forward failed")
+        return bs, bu
+
+    def backward(self, ysep, yupd=None):
+        ys = np.array(ysep, dtype=np.float64, order="F").reshape(self.dsep, -1, order="F")
+        yu = np.asfortranarray(yupd, dtype=np.float64).reshape(self.dupd, -1, order="F") if self.dupd else None
+        if self.L.SPX_d_blr_front_backward(self.h, ys.shape[1], ys.ctypes.data, max(self.dsep, 1),
+                                           yu.ctypes.data if yu is not None else None, max(self.dupd, 1)):
+            raise RuntimeError("SPX_d_blr_front_backward failed")
+        return ys
+
+    def solve11(self, b):
+        """B11 \\ b: forward and backward phases with an empty update part"""
+        ys, _ = self.forward(b, np.zeros((self.dupd, np.asarray(b).reshape(self.dsep, -1).shape[1])) if self.dupd else None)
+        return self.backward(ys, np.zeros((self.dupd, ys.shape[1])) if self.dupd else None)
+
+    def schur(self):
+        S = np.zeros((self.dupd, self.dupd), order="F")
+        if self.dupd and self.L.SPX_d_blr_front_schur(self.h, S.ctypes.data, self.dupd):
+            raise RuntimeError("SPX_d_blr_front_schur failed")
+        return S
+
+    def schur_device(self):
+        ld = C.c_longlong()
+        return self.L.SPX_d_blr_front_schur_device(self.h, C.byref(ld)), ld.value
+
+    def tile_ranks(self):
+        nt = self.nt1 + self.nt2
+        out = np.zeros((nt, nt), dtype=np.int32, order="F")
+        if self.L.SPX_d_blr_front_tile_ranks(self.h, out.ctypes.data_as(C.POINTER(C.c_int))):
+            raise RuntimeError("SPX_d_blr_front_tile_ranks failed")
+        return out
+
+    def stats(self):
+        out = (C.c_double * 12)()
+        self.L.SPX_d_blr_front_stats(self.h, out)
+        return dict(zip(self.STAT_NAMES, list(out)))
+
+    def destroy(self):
+        if self.h:
+            self.L.SPX_d_blr_front_destroy(C.byref(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class StructuredMatrix:

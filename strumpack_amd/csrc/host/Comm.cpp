@@ -41,10 +41,14 @@ const Api& api() {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names)
       if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    std::string why;   // dlerror() hands out its message once: take it right behind the failing dlopen
     if (!h)
-      for (const char* n : names)
+      for (const char* n : names) {
         if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) { err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        const char* e = dlerror();
+        if (e && why.empty()) why = e;
+      }
+    if (!h) { err = "cannot load librccl: " + (why.empty() ? std::string("?") : why); return; }
     auto sym = [&](const char* s) -> void* {
       void* p = dlsym(h, s);
       if (!p && err.empty()) err = std::string("librccl lacks ") + s;

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <iostream>
 
+#include "BLRMatrix.hpp"
 #include "HSSMatrix.hpp"
 #include "Comm.hpp"
 #include "Kernel.hpp"
@@ -485,6 +486,98 @@ int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, 
   hss(S)->engine()->mult_child(child, trans, m, B, ldB, C, ldC, on_device != 0);
   SP_CATCH
 }
+// ---- BLR frontal matrix (BLRMatrix::construct_and_partial_factor, BLR/BLRMatrix.cpp:740-1037) -------------------------
+namespace {
+bool g_blr_time_phases = false;
+std::unique_ptr<BLR::DeviceBLR> make_front(int dsep, int dupd, int nt1, const int* t1, int nt2, const int* t2, const CSPOptions* opts) {
+  if (dsep < 0 || dupd < 0 || nt1 < 0 || nt2 < 0 || (nt1 && !t1) || (nt2 && !t2)) throw std::invalid_argument("BLR front: bad dimensions");
+  std::vector<int> tiles(t1, t1 + nt1);
+  tiles.insert(tiles.end(), t2, t2 + nt2);
+  long long s1 = 0, s2 = 0;
+  for (int i = 0; i < nt1; i++) { if (t1[i] < 0) throw std::invalid_argument("BLR front: negative tile size"); s1 += t1[i]; }
+  for (int i = 0; i < nt2; i++) { if (t2[i] < 0) throw std::invalid_argument("BLR front: negative tile size"); s2 += t2[i]; }
+  if (s1 != dsep || s2 != dupd) throw std::invalid_argument("BLR front: the tile sizes do not add up to dsep / dupd");
+  BLR::BLREngineOptions e;
+  BLR::BLROptions<double> d;
+  e.rel_tol = opts ? opts->rel_tol : d.rel_tol();
+  e.abs_tol = opts ? opts->abs_tol : d.abs_tol();
+  e.max_rank = opts ? opts->max_rank : d.max_rank();
+  e.verbose = opts && opts->verbose;
+  if (const char* dv = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(dv);
+  std::unique_ptr<BLR::DeviceBLR> f(new BLR::DeviceBLR(dsep + dupd, tiles, dsep + dupd, tiles, e));
+  f->time_phases = g_blr_time_phases;
+  return f;
+}
+inline BLR::DeviceBLR* front(const SPXBLRFront F) {
+  if (!F) throw std::invalid_argument("BLR front: null handle");
+  return static_cast<BLR::DeviceBLR*>(F);
+}
+}  // namespace
+void SPX_d_blr_front_time_phases(int on) { g_blr_time_phases = on != 0; }
+int SPX_d_blr_front_factor(SPXBLRFront* F, int dsep, int dupd, const double* F11, int ld11, const double* F12, int ld12,
+                           const double* F21, int ld21, double* F22, int ld22, int ntiles1, const int* tiles1, int ntiles2,
+                           const int* tiles2, const char* admissible, const CSPOptions* opts) {
+  SP_TRY
+  auto f = make_front(dsep, dupd, ntiles1, tiles1, ntiles2, tiles2, opts);
+  f->partial_factor_host(ntiles1, F11, ld11, F12, ld12, F21, ld21, F22, ld22, admissible);
+  if (F22 && dupd > 0) f->schur_host(F22, ld22);
+  *F = f.release();
+  SP_CATCH
+}
+int SPX_d_blr_front_factor_device(SPXBLRFront* F, int dsep, int dupd, const double* dF11, long long ld11, const double* dF12,
+                                  long long ld12, const double* dF21, long long ld21, const double* dF22, long long ld22,
+                                  int ntiles1, const int* tiles1, int ntiles2, const int* tiles2, const char* admissible,
+                                  const CSPOptions* opts) {
+  SP_TRY
+  auto f = make_front(dsep, dupd, ntiles1, tiles1, ntiles2, tiles2, opts);
+  f->partial_factor_device(ntiles1, dF11, ld11, dF12, ld12, dF21, ld21, dF22, ld22, admissible);
+  *F = f.release();
+  SP_CATCH
+}
+int SPX_d_blr_front_forward(const SPXBLRFront F, int nrhs, double* bsep, int ldb, double* bupd, int ldu) {
+  SP_TRY
+  front(F)->front_forward(nrhs, bsep, ldb, bupd, ldu);
+  SP_CATCH
+}
+int SPX_d_blr_front_backward(const SPXBLRFront F, int nrhs, double* ysep, int ldy, const double* yupd, int ldu) {
+  SP_TRY
+  front(F)->front_backward(nrhs, ysep, ldy, yupd, ldu);
+  SP_CATCH
+}
+int SPX_d_blr_front_schur(const SPXBLRFront F, double* F22, int ld22) {
+  SP_TRY
+  front(F)->schur_host(F22, ld22);
+  SP_CATCH
+}
+const double* SPX_d_blr_front_schur_device(const SPXBLRFront F, long long* ld) {
+  if (!F) return nullptr;
+  auto* f = static_cast<BLR::DeviceBLR*>(F);
+  if (ld) *ld = f->schur_ld();
+  return f->upd_rows() > 0 ? f->schur_device() : nullptr;
+}
+int SPX_d_blr_front_tile_ranks(const SPXBLRFront F, int* out) {
+  SP_TRY
+  front(F)->tile_ranks(out);
+  SP_CATCH
+}
+int SPX_d_blr_front_stats(const SPXBLRFront F, double* out) {
+  SP_TRY
+  auto* f = front(F);
+  long long nz[3];
+  f->front_nonzeros(nz);
+  out[0] = f->t_factor;
+  for (int p = 0; p < 4; p++) out[1 + p] = f->phase_ms[p];
+  out[5] = f->f_schur; out[6] = f->f_total;
+  out[7] = (double)nz[0]; out[8] = (double)nz[1]; out[9] = (double)nz[2];
+  out[10] = f->rank(); out[11] = f->schur_launches;
+  SP_CATCH
+}
+void SPX_d_blr_front_destroy(SPXBLRFront* F) {
+  if (!F) return;
+  delete static_cast<BLR::DeviceBLR*>(*F);
+  *F = nullptr;
+}
+
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S) { return hss(S) ? (void*)hss(S)->engine()->ctx() : nullptr; }
 
 }  // extern "C"

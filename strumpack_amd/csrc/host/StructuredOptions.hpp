@@ -23,7 +23,7 @@ inline std::string get_name(Type a) {
 template <typename real_t> inline real_t default_structured_rel_tol() { return real_t(1e-4); }
 template <typename real_t> inline real_t default_structured_abs_tol() { return real_t(1e-10); }
 template <> inline float default_structured_rel_tol() { return 1e-2f; }
-template <> inline float default_structured_abs_tol() { return 1e-6f; }
+template <> inline float default_structured_abs_tol() { return 1e-5f; }   // structured/StructuredOptions.hpp:52-54
 
 namespace detail {
 // "--name value" / "--name=value" scanner shared by the option classes (the reference uses

@@ -72,23 +72,43 @@ DeviceBLR::~DeviceBLR() {
   hssk_ctx_destroy(ctx_);
 }
 
-void DeviceBLR::load(const double* A, long long lda, bool on_device) {
+void DeviceBLR::alloc_array() {
   if (dA_) { hssk_free(dA_); dA_ = nullptr; }
   ld_ = std::max(m_, 1);
   dA_ = (double*)hssk_malloc((long long)sizeof(double) * ld_ * std::max(n_, 1));
   if (!dA_) throw std::runtime_error("BLR: device allocation of the operand failed");
-  if (on_device) {
-    hssk_colgather_desc cp{A, dA_, nullptr, m_, n_, (int)lda, (int)ld_, 0};
-    if (lda > 0x7fffffffLL) throw std::invalid_argument("BLR: leading dimension too large");
-    ck(hssk_gather_cols(ctx_, &cp, 1));
-  } else {
-    ck(hssk_h2d_block_async(ctx_, dA_, ld_, A, lda, m_, n_));
-    ck(hssk_copy_fence(ctx_));
-  }
   store_->rewind();
   tiles_.assign(tiles_.size(), Tile());
   dpiv_ = store_->ints((size_t)std::max(m_, 1) + rowblocks() + 1);
   compressed_ = factored_ = false;
+  nsteps_ = 0;
+}
+
+// rows x cols block of the working array at (r0, c0) from a host or device source (null: zeros)
+void DeviceBLR::put_block(int r0, int c0, int rows, int cols, const double* src, long long lds, bool on_device) {
+  if (rows <= 0 || cols <= 0) return;
+  double* dst = dA_ + r0 + (size_t)c0 * ld_;
+  if (!src) {
+    if (rows == ld_) { ck(hssk_memset_zero(ctx_, dst, (long long)sizeof(double) * ld_ * cols)); return; }
+    hssk_gemm_desc z{dst, dst, dst, rows, cols, 0, (int)ld_, (int)ld_, (int)ld_, 0, 0, 0.0, 0.0};   // C = 0 * C
+    ck(hssk_gemm_vbatched(ctx_, &z, 1));
+    return;
+  }
+  if (lds < rows) throw std::invalid_argument("BLR: leading dimension smaller than the block");
+  if (on_device) {
+    if (lds > 0x7fffffffLL) throw std::invalid_argument("BLR: leading dimension too large");
+    hssk_colgather_desc cp{src, dst, nullptr, rows, cols, (int)lds, (int)ld_, 0};
+    ck(hssk_gather_cols(ctx_, &cp, 1));
+  } else {
+    ck(hssk_h2d_block_async(ctx_, dst, ld_, src, lds, rows, cols));
+  }
+}
+
+void DeviceBLR::load(const double* A, long long lda, bool on_device) {
+  alloc_array();
+  put_block(0, 0, m_, n_, A, lda, on_device);
+  // (hssk_h2d_block_async runs on the copy stream; the fence orders the kernels that follow behind it)
+  if (!on_device) ck(hssk_copy_fence(ctx_));
 }
 
 // Truncated RRQR of the listed tiles (batched).  A tile whose rank does not pay (r (m + n) > m n, BLRMatrix.cpp:568) or
@@ -179,37 +199,103 @@ void DeviceBLR::compress_device(const double* dA, long long lda, const char* adm
 
 void DeviceBLR::compress_and_factor_host(const double* A, long long lda, const char* adm) {
   std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
+  if (m_ != n_ || roff_ != coff_) throw std::invalid_argument("BLR factorization needs a square matrix with the same clusters for rows and columns");
   load(A, lda, false);
-  factor_rl(adm);
+  factor_rl(adm, rowblocks());
 }
 void DeviceBLR::compress_and_factor_device(const double* dA, long long lda, const char* adm) {
   std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
+  if (m_ != n_ || roff_ != coff_) throw std::invalid_argument("BLR factorization needs a square matrix with the same clusters for rows and columns");
   load(dA, lda, true);
-  factor_rl(adm);
+  factor_rl(adm, rowblocks());
 }
 
-// BLRMatrix::compress_and_factor, algorithm RL (BLRMatrix.cpp:114-175), one block step = a handful of batched launches
-void DeviceBLR::factor_rl(const char* adm) {
-  if (m_ != n_ || roff_ != coff_) throw std::invalid_argument("BLR factorization needs a square matrix with the same clusters for rows and columns");
+// BLRMatrix::construct_and_partial_factor (BLRMatrix.cpp:740-1037, RL): the front [F11 F12; F21 F22] is ONE working array, so
+// the elimination of the separator is the block LU above stopped after sep_blocks steps: the block row of a step runs through
+// F11 and F12, its block column through F11 and F21, and the trailing update reaches the rest of F11, F12, F21 and all of F22.
+void DeviceBLR::partial_factor(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12,
+                               const double* F21, long long ld21, const double* F22, long long ld22, const char* adm11,
+                               bool on_device) {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
+  if (m_ != n_ || roff_ != coff_) throw std::invalid_argument("BLR front: needs the same clusters for rows and columns");
+  const int rb = rowblocks();
+  if (sep_blocks < 0 || sep_blocks > rb) throw std::invalid_argument("BLR front: number of separator tiles out of range");
+  const int ds = roff_[sep_blocks], du = m_ - ds;
+  if (ds > 0 && !F11) throw std::invalid_argument("BLR front: no F11");
+  alloc_array();
+  put_block(0, 0, ds, ds, F11, ld11, on_device);
+  put_block(0, ds, ds, du, F12, ld12, on_device);
+  put_block(ds, 0, du, ds, F21, ld21, on_device);
+  put_block(ds, ds, du, du, F22, ld22, on_device);
+  if (!on_device) ck(hssk_copy_fence(ctx_));
+  // admissibility of the whole front: F11 as given (all but the diagonal when null), F12 / F21 always (BLRMatrix.cpp:818-845)
+  std::vector<char> adm((size_t)rb * rb, 1);
+  if (adm11)
+    for (int j = 0; j < sep_blocks; j++)
+      for (int i = 0; i < sep_blocks; i++) adm[(size_t)i + (size_t)j * rb] = adm11[(size_t)i + (size_t)j * sep_blocks];
+  factor_rl(adm.data(), sep_blocks);
+}
+void DeviceBLR::partial_factor_host(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12,
+                                    const double* F21, long long ld21, const double* F22, long long ld22, const char* adm11) {
+  partial_factor(sep_blocks, F11, ld11, F12, ld12, F21, ld21, F22, ld22, adm11, false);
+}
+void DeviceBLR::partial_factor_device(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12,
+                                      const double* F21, long long ld21, const double* F22, long long ld22, const char* adm11) {
+  partial_factor(sep_blocks, F11, ld11, F12, ld12, F21, ld21, F22, ld22, adm11, true);
+}
+
+void DeviceBLR::schur_host(double* F22, long long ld) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);
+  if (!factored_) throw std::logic_error("BLR front: not factored");
+  const int du = upd_rows();
+  if (du <= 0) return;
+  if (!F22 || ld < du) throw std::invalid_argument("BLR front: bad output for the Schur complement");
+  ck(hssk_memcpy2d_d2h(ctx_, F22, sizeof(double) * ld, blk(nsteps_, nsteps_), sizeof(double) * ld_, sizeof(double) * du, du));
+}
+
+void DeviceBLR::tile_ranks(int* out) const {
+  for (int j = 0; j < colblocks(); j++)
+    for (int i = 0; i < rowblocks(); i++) {
+      const Tile& t = tile(i, j);
+      out[(size_t)i + (size_t)j * rowblocks()] = (t.r >= 0 && t.lowrank) ? t.r : -1;
+    }
+}
+
+// BLRMatrix::compress_and_factor, algorithm RL (BLRMatrix.cpp:114-175), one block step = a handful of batched launches;
+// stopped after `nsteps` block steps it is the partial factorization of a front (BLRMatrix.cpp:740-1037)
+void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   const double t0 = now();
   const int rb = rowblocks();
   int* info = dpiv_ + m_;
+  for (double& p : phase_ms) p = 0;
+  f_schur = f_total = 0;
+  schur_launches = 0;
+  // phases on the device clock (time_phases): stopwatches 0..3 of the context bracket the launches of each phase
+  auto watch = [&](int id, bool start) {
+    if (!time_phases) return;
+    ck(start ? hssk_watch_start(ctx_, id) : hssk_watch_stop(ctx_, id));
+  };
   std::vector<char> adm_nd;   // the diagonal is never compressed
   if (adm) adm_nd.assign(adm, adm + (size_t)rb * rb); else adm_nd.assign((size_t)rb * rb, 1);
   for (int i = 0; i < rb; i++) adm_nd[(size_t)i + (size_t)i * rb] = 0;
-  for (int i = 0; i < rb; i++) {
+  for (int i = 0; i < nsteps; i++) {
     tmp_->rewind();
     const int mi = tm(i);
     // ---- LU of the diagonal tile, in place
     hssk_lu_desc lu{blk(i, i), mi, (int)ld_, dpiv_ + roff_[i], info + i};
+    watch(0, true);
     if (mi) ck(hssk_getrf_vbatched(ctx_, &lu, 1));
+    watch(0, false);
+    f_total += (2.0 / 3.0) * mi * (double)mi * mi;
     if (i + 1 == rb) break;
     // ---- compress the block row and the block column of this step from the running Schur complement
     std::vector<std::pair<int, int>> ij;
     for (int j = i + 1; j < rb; j++) { ij.emplace_back(i, j); ij.emplace_back(j, i); }
     // the U factors of the block row are carved side by side in one m_i x R panel (used as ONE operand below and in the
     // backward solve); their ranks are not known yet: reserve the dense bound and trim the view afterwards
+    watch(1, true);
     compress_tiles(ij, adm_nd.data());
+    watch(1, false);
     int R = 0;
     for (int j = i + 1; j < rb; j++) R += tile(i, j).r;
     double* Ucat = store_->dbl((size_t)mi * std::max(R, 1));
@@ -225,6 +311,7 @@ void DeviceBLR::factor_rl(const char* adm) {
       if (!mv.empty()) ck(hssk_gather_cols(ctx_, mv.data(), (int)mv.size()));
     }
     // ---- block row: U <- L^{-1} P U (all tiles at once: the panel);  block column: V <- U_ii^{-T} V
+    watch(2, true);
     if (R > 0 && mi > 0) {
       hssk_lusolve_desc sw{blk(i, i), dpiv_ + roff_[i], Ucat, mi, R, (int)ld_, mi};
       ck(hssk_laswp_vbatched(ctx_, &sw, 1));
@@ -238,7 +325,10 @@ void DeviceBLR::factor_rl(const char* adm) {
         if (t.r > 0 && mi > 0) tu.push_back(hssk_trsm_desc{blk(i, i), t.V, mi, t.r, (int)ld_, mi, 0, 1, 0});
       }
       if (!tu.empty()) ck(hssk_trsm_vbatched(ctx_, tu.data(), (int)tu.size()));
+      for (auto& d : tu) f_total += (double)d.n * d.n * d.nrhs;
+      f_total += (double)mi * mi * R;
     }
+    watch(2, false);
     // ---- Schur update of the trailing array, always into full rank (BLRMatrix.cpp:160-175):
     //   A_kj -= U_ki (V_ki^T U_ij) V_ij^T  for k, j > i, as three batched GEMMs over the block column / row:
     //   G_k = V_ki^T [U_i,i+1 .. U_i,rb)  (r_ki x R);  T(k rows, :) = U_ki G_k;  A(i+1:, j cols) -= T(:, R_j) V_ij^T
@@ -267,15 +357,24 @@ void DeviceBLR::factor_rl(const char* adm) {
                                       nrest, nj, (int)ld_, 0, 1, -1.0, 1.0});
         off += t.r;
       }
+      watch(3, true);
       if (!gG.empty()) ck(hssk_gemm_vbatched(ctx_, gG.data(), (int)gG.size()));
       if (!gT.empty()) ck(hssk_gemm_vbatched(ctx_, gT.data(), (int)gT.size()));
       if (!gF.empty()) ck(hssk_gemm_vbatched(ctx_, gF.data(), (int)gF.size()));
+      watch(3, false);
+      schur_launches += (!gG.empty()) + (!gT.empty()) + (!gF.empty());
+      for (auto* gl : {&gG, &gT, &gF})
+        for (auto& d : *gl) f_schur += 2.0 * d.m * (double)d.n * d.k;
     }
   }
+  f_total += f_schur;
+  if (time_phases)
+    for (int p = 0; p < 4; p++) phase_ms[p] = hssk_watch_read_ms(ctx_, p, nullptr);
   ck(hssk_sync(ctx_));
-  std::vector<int> hinfo(rb);
+  nsteps_ = nsteps;
+  std::vector<int> hinfo(rb, 0);
   ck(hssk_memcpy_d2h(ctx_, hinfo.data(), info, (long long)sizeof(int) * rb));
-  for (int i = 0; i < rb; i++)
+  for (int i = 0; i < nsteps; i++)
     if (hinfo[i] > 0) throw std::runtime_error("BLR factorization: zero pivot in diagonal tile " + std::to_string(i));
   compressed_ = factored_ = true;
   t_factor = now() - t0;
@@ -320,25 +419,23 @@ void DeviceBLR::mult(char trans, int nrhs, const double* x, long long ldx, doubl
   ck(hssk_memcpy2d_d2h(ctx_, y, sizeof(double) * ldy, dy, sizeof(double) * nout, sizeof(double) * nout, nrhs));
 }
 
-// BLRMatrix::solve (BLRMatrix.hpp:118-122): x <- P x, block forward substitution with the unit lower factor, block
-// backward substitution with the upper factor
-void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
-  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
-  if (!factored_) throw std::logic_error("BLR solve: the matrix has not been factored (construct_and_factor_from_dense)");
-  if (nrhs <= 0 || n_ == 0) return;
+// largest summed rank of a block row / block column of the eliminated steps (size of the sweeps' scratch vector)
+int DeviceBLR::rmax() const {
   const int rb = rowblocks();
-  Arena2& tmp = *tmp_;
-  tmp.rewind();
-  double* X = tmp.dbl((size_t)n_ * nrhs);
-  ck(hssk_memcpy2d_h2d(ctx_, X, sizeof(double) * n_, b, sizeof(double) * ldb, sizeof(double) * n_, nrhs));
   int Rmax = 1;
-  for (int i = 0; i < rb; i++) {
+  for (int i = 0; i < nsteps_; i++) {
     int R = 0, C = 0;
-    for (int j = i + 1; j < rb; j++) { R += tile(i, j).r; C += tile(j, i).r; }
+    for (int j = i + 1; j < rb; j++) { R += std::max(tile(i, j).r, 0); C += std::max(tile(j, i).r, 0); }
     Rmax = std::max(Rmax, std::max(R, C));
   }
-  double* t = tmp.dbl((size_t)Rmax * nrhs);
-  for (int i = 0; i < rb; i++) {
+  return Rmax;
+}
+
+// block forward substitution over the eliminated steps, X (n_ x nrhs, device): x_i <- L_ii^{-1} P_i x_i, then
+// x_k -= U_ki (V_ki^T x_i) for every block row k below -- the rest of the separator AND the update rows (B21)
+void DeviceBLR::fwd(double* X, int nrhs, double* t, int Rmax) const {
+  const int rb = rowblocks();
+  for (int i = 0; i < nsteps_; i++) {
     const int mi = tm(i);
     if (!mi) continue;
     double* Xi = X + roff_[i];
@@ -358,7 +455,13 @@ void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
     if (!g1.empty()) ck(hssk_gemm_vbatched(ctx_, g1.data(), (int)g1.size()));
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
   }
-  for (int i = rb - 1; i >= 0; i--) {
+}
+
+// block backward substitution over the eliminated steps: x_i <- U_ii^{-1} (x_i - sum_{j > i} U_ij V_ij^T x_j), j through the
+// rest of the separator and the update columns (B12)
+void DeviceBLR::bwd(double* X, int nrhs, double* t, int Rmax) const {
+  const int rb = rowblocks();
+  for (int i = nsteps_ - 1; i >= 0; i--) {
     const int mi = tm(i);
     if (!mi) continue;
     double* Xi = X + roff_[i];
@@ -380,7 +483,61 @@ void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
     hssk_trsm_desc tu{blk(i, i), Xi, mi, nrhs, (int)ld_, n_, 0, 0, 0};
     ck(hssk_trsm_vbatched(ctx_, &tu, 1));
   }
+}
+
+// BLRMatrix::solve (BLRMatrix.hpp:118-122): x <- P x, block forward substitution with the unit lower factor, block
+// backward substitution with the upper factor
+void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);   // operations on one matrix take turns
+  if (!factored_) throw std::logic_error("BLR solve: the matrix has not been factored (construct_and_factor_from_dense)");
+  if (nsteps_ != rowblocks()) throw std::logic_error("BLR solve: the matrix is a partially factored front (use front_forward / front_backward)");
+  if (nrhs <= 0 || n_ == 0) return;
+  Arena2& tmp = *tmp_;
+  tmp.rewind();
+  double* X = tmp.dbl((size_t)n_ * nrhs);
+  ck(hssk_memcpy2d_h2d(ctx_, X, sizeof(double) * n_, b, sizeof(double) * ldb, sizeof(double) * n_, nrhs));
+  const int Rmax = rmax();
+  double* t = tmp.dbl((size_t)Rmax * nrhs);
+  fwd(X, nrhs, t, Rmax);
+  bwd(X, nrhs, t, Rmax);
   ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, X, sizeof(double) * n_, sizeof(double) * n_, nrhs));
+}
+
+// FrontBLR::fwd_solve_phase2 (FrontBLR.cpp:525-547): bsep <- L11^{-1} P bsep, bupd <- bupd - B21 bsep
+void DeviceBLR::front_forward(int nrhs, double* bsep, long long ldb, double* bupd, long long ldu) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);
+  if (!factored_) throw std::logic_error("BLR front: not factored");
+  const int ds = sep_rows(), du = upd_rows();
+  if (nrhs <= 0 || ds == 0) return;
+  if (du > 0 && !bupd) throw std::invalid_argument("BLR front: no update part of the right-hand side");
+  Arena2& tmp = *tmp_;
+  tmp.rewind();
+  double* X = tmp.dbl((size_t)n_ * nrhs);
+  ck(hssk_memcpy2d_h2d(ctx_, X, sizeof(double) * n_, bsep, sizeof(double) * ldb, sizeof(double) * ds, nrhs));
+  if (du > 0) ck(hssk_memcpy2d_h2d(ctx_, X + ds, sizeof(double) * n_, bupd, sizeof(double) * ldu, sizeof(double) * du, nrhs));
+  const int Rmax = rmax();
+  double* t = tmp.dbl((size_t)Rmax * nrhs);
+  fwd(X, nrhs, t, Rmax);
+  ck(hssk_memcpy2d_d2h(ctx_, bsep, sizeof(double) * ldb, X, sizeof(double) * n_, sizeof(double) * ds, nrhs));
+  if (du > 0) ck(hssk_memcpy2d_d2h(ctx_, bupd, sizeof(double) * ldu, X + ds, sizeof(double) * n_, sizeof(double) * du, nrhs));
+}
+
+// FrontBLR::bwd_solve_phase1 (FrontBLR.cpp:550-570): ysep <- U11^{-1} (ysep - B12 yupd)
+void DeviceBLR::front_backward(int nrhs, double* ysep, long long ldy, const double* yupd, long long ldu) const {
+  std::lock_guard<std::recursive_mutex> op_guard(op_mu_);
+  if (!factored_) throw std::logic_error("BLR front: not factored");
+  const int ds = sep_rows(), du = upd_rows();
+  if (nrhs <= 0 || ds == 0) return;
+  if (du > 0 && !yupd) throw std::invalid_argument("BLR front: no update part of the solution");
+  Arena2& tmp = *tmp_;
+  tmp.rewind();
+  double* X = tmp.dbl((size_t)n_ * nrhs);
+  ck(hssk_memcpy2d_h2d(ctx_, X, sizeof(double) * n_, ysep, sizeof(double) * ldy, sizeof(double) * ds, nrhs));
+  if (du > 0) ck(hssk_memcpy2d_h2d(ctx_, X + ds, sizeof(double) * n_, yupd, sizeof(double) * ldu, sizeof(double) * du, nrhs));
+  const int Rmax = rmax();
+  double* t = tmp.dbl((size_t)Rmax * nrhs);
+  bwd(X, nrhs, t, Rmax);
+  ck(hssk_memcpy2d_d2h(ctx_, ysep, sizeof(double) * ldy, X, sizeof(double) * n_, sizeof(double) * ds, nrhs));
 }
 
 void DeviceBLR::dense(double* A, long long lda) const {
@@ -415,6 +572,17 @@ long long DeviceBLR::nonzeros() const {
       else nz += (long long)t.r * (tm(i) + tn(j));
     }
   return nz;
+}
+void DeviceBLR::front_nonzeros(long long out[3]) const {
+  out[0] = out[1] = out[2] = 0;
+  const int rb = rowblocks(), ns = nsteps_;
+  for (int j = 0; j < rb; j++)
+    for (int i = 0; i < rb; i++) {
+      if (i >= ns && j >= ns) continue;   // F22: not part of the factors
+      const Tile& t = tile(i, j);
+      const long long nz = (t.r < 0 || !t.lowrank) ? (long long)tm(i) * tn(j) : (long long)t.r * (tm(i) + tn(j));
+      out[(i < ns && j < ns) ? 0 : (i < ns ? 1 : 2)] += nz;
+    }
 }
 long long DeviceBLR::memory() const { return nonzeros() * (long long)sizeof(double); }
 

@@ -50,6 +50,35 @@ class DeviceBLR {
   void compress_and_factor_host(const double* A, long long lda, const char* adm);
   void compress_and_factor_device(const double* dA, long long lda, const char* adm);
 
+  // ---- frontal matrix [F11 F12; F21 F22] of a multifrontal factorization (BLRMatrix::construct_and_partial_factor,
+  // BLRMatrix.cpp:740-1037, algorithm RL; batched precedent BLRMatrix.GPU.cpp:71-262; caller sparse/fronts/FrontBLR.cpp:329-432).
+  // The matrix of this object is the whole front: clusters = the separator's tiles followed by the update tiles; the first
+  // `sep_blocks` block steps are eliminated -- LU of the diagonal tile, compression of the block row of [F11 F12] and of the
+  // block column of [F11; F21] (F11 tiles per `adm11`, sep_blocks x sep_blocks column-major, null = all but the diagonal;
+  // F12 / F21 tiles always), triangular solves on the factors, Schur update of the trailing part of F11, F12, F21 AND of
+  // F22 <- F22 - F21 F11^{-1} F12, which stays a dense array.  Any of F12 / F21 / F22 may be null when the front has no update part.
+  void partial_factor_host(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12,
+                           const double* F21, long long ld21, const double* F22, long long ld22, const char* adm11);
+  void partial_factor_device(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12,
+                             const double* F21, long long ld21, const double* F22, long long ld22, const char* adm11);
+  int sep_rows() const { return roff_[nsteps_]; }
+  int upd_rows() const { return m_ - roff_[nsteps_]; }
+  int sep_blocks() const { return nsteps_; }
+  // the Schur complement F22 - F21 F11^{-1} F12 (upd_rows() square): copy to the host / in place in HBM (column-major, schur_ld())
+  void schur_host(double* F22, long long ld) const;
+  const double* schur_device() const { return dA_ ? blk(nsteps_, nsteps_) : nullptr; }
+  long long schur_ld() const { return ld_; }
+  // the two solve phases of a front (FrontBLR.cpp:525-570; BLRMatrix::trsmLNU_gemm / gemm_trsmUNN, BLRMatrix.cpp:1552-1665):
+  //   forward:  bsep <- L11^{-1} P bsep;  bupd <- bupd - B21 bsep          backward:  ysep <- U11^{-1} (ysep - B12 yupd)
+  // host vectors; bupd / yupd may be null when the front has no update part
+  void front_forward(int nrhs, double* bsep, long long ldb, double* bupd, long long ldu) const;
+  void front_backward(int nrhs, double* ysep, long long ldy, const double* yupd, long long ldu) const;
+  // ranks of all tiles, rowblocks() x colblocks() column-major: >= 0 rank of a U V^T tile, -1 dense (diagonal, not
+  // admissible, rank does not pay, or the untouched F22 part)
+  void tile_ranks(int* out) const;
+  // stored scalars of B11 / B12 / B21 of a front (the reference's F11blr_ / F12blr_ / F21blr_ .nonzeros())
+  void front_nonzeros(long long out[3]) const;
+
   void mult(char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy) const;   // host vectors
   void solve(int nrhs, double* b, long long ldb) const;                                             // host, in place
   void dense(double* A, long long lda) const;   // host image of the compressed (not factored) matrix
@@ -63,6 +92,12 @@ class DeviceBLR {
   long long memory() const;     // bytes of the representation
   long long nonzeros() const;   // stored scalars
   double t_compress = 0, t_factor = 0;
+  // phases of the last factorization on the device clock (ms) and its algorithmic flops: [0] LU of the diagonal tiles,
+  // [1] tile compression, [2] triangular solves, [3] Schur-update GEMMs; f_schur = flops of [3]
+  double phase_ms[4] = {0, 0, 0, 0};
+  double f_schur = 0, f_total = 0;
+  int schur_launches = 0;
+  bool time_phases = false;
 
  private:
   struct Tile {
@@ -76,9 +111,16 @@ class DeviceBLR {
   int tn(int j) const { return coff_[j + 1] - coff_[j]; }
   double* blk(int i, int j) const { return dA_ + roff_[i] + (size_t)coff_[j] * ld_; }
   void load(const double* A, long long lda, bool on_device);
+  void alloc_array();
+  void put_block(int r0, int c0, int rows, int cols, const double* src, long long lds, bool on_device);
+  void partial_factor(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12, const double* F21,
+                      long long ld21, const double* F22, long long ld22, const char* adm11, bool on_device);
+  void fwd(double* X, int nrhs, double* t, int Rmax) const;
+  void bwd(double* X, int nrhs, double* t, int Rmax) const;
+  int rmax() const;
   // truncated RRQR of the listed tiles of the array (batched), results into tiles_
   void compress_tiles(const std::vector<std::pair<int, int>>& ij, const char* adm);
-  void factor_rl(const char* adm);
+  void factor_rl(const char* adm, int nsteps);
 
   mutable std::recursive_mutex op_mu_;
   int m_, n_;
@@ -91,6 +133,7 @@ class DeviceBLR {
   std::vector<Tile> tiles_;
   std::unique_ptr<Arena2> store_, tmp_;
   bool compressed_ = false, factored_ = false;
+  int nsteps_ = 0;   // eliminated block steps (== rowblocks() for a full factorization)
 };
 
 }  // namespace BLR

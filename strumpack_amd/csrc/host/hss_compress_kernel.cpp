@@ -38,6 +38,11 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       ck(hssk_knn(ctx_, dX, dim, N, k, q0, q1, dann));
       ck(hssk_memcpy_d2h(ctx_, ann.data() + (size_t)k * q0, dann + (size_t)k * q0, (long long)sizeof(int) * k * (q1 - q0)));
     }
+    if ((user_ann && k == user_k) || ks.neighbors) {
+      // lists that come from the caller index the bitmaps below: an id outside [0, N) must not reach them (negative = no neighbour)
+      for (size_t q = 0; q < ann.size(); q++)
+        if (ann[q] >= N) throw std::invalid_argument("compress_kernel: neighbour id " + std::to_string(ann[q]) + " is not a point (n = " + std::to_string(N) + ")");
+    }
     stats_.t_random += now() - tk0;   // neighbour search (reported in the 'random' slot: it replaces the random sketch)
     std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node
     bool failed = false;

@@ -18,10 +18,25 @@ template <class T> void put(std::ostream& os, const T* p, size_t n) {
   os.write((const char*)&c, sizeof(c));
   if (n) os.write((const char*)p, sizeof(T) * n);
 }
-template <class T> std::vector<T> get(std::istream& is) {
+// bytes left in the stream behind the read position (-1: not seekable, no bound available)
+long long bytes_left(std::istream& is) {
+  const std::istream::pos_type here = is.tellg();
+  if (here == std::istream::pos_type(-1)) return -1;
+  is.seekg(0, std::ios::end);
+  const std::istream::pos_type end = is.tellg();
+  is.seekg(here);
+  if (!is || end == std::istream::pos_type(-1)) { is.clear(); is.seekg(here); return -1; }
+  return (long long)(end - here);
+}
+// a block: (int64 count, payload).  The count is checked against what the stream still holds (and against `cap`, what the
+// header allows for this block) BEFORE anything is allocated: a corrupt or foreign file must end as "corrupt HSS file",
+// not as a multi-terabyte allocation
+template <class T> std::vector<T> get(std::istream& is, long long cap = (1LL << 40)) {
   long long c = -1;
   is.read((char*)&c, sizeof(c));
-  if (!is || c < 0 || c > (1LL << 40)) throw std::runtime_error("HSS file is truncated or corrupt");
+  if (!is || c < 0 || c > cap) throw std::runtime_error("HSS file is truncated or corrupt");
+  const long long left = bytes_left(is);
+  if (left >= 0 && c > left / (long long)sizeof(T)) throw std::runtime_error("HSS file is truncated or corrupt");
   std::vector<T> v((size_t)c);
   if (c) is.read((char*)v.data(), sizeof(T) * (size_t)c);
   if (!is) throw std::runtime_error("HSS file is truncated");
@@ -75,9 +90,11 @@ std::unique_ptr<DeviceHSS> DeviceHSS::load(std::istream& is, const EngineOptions
   for (auto& r : recs) {
     is.read((char*)r.f, sizeof(r.f));
     if (!is) throw std::runtime_error("HSS file is truncated");
-    r.D = get<double>(is); r.B01 = get<double>(is); r.B10 = get<double>(is);
-    r.XU = get<double>(is); r.pU = get<int>(is); r.Ir = get<int>(is);
-    r.XV = get<double>(is); r.pV = get<int>(is); r.Ic = get<int>(is);
+    // every block is bounded by the header's matrix size: doubles by n^2 (a node's D, B, X), ints by n
+    const long long cap_d = (long long)n * (long long)n, cap_i = n;
+    r.D = get<double>(is, cap_d); r.B01 = get<double>(is, cap_d); r.B10 = get<double>(is, cap_d);
+    r.XU = get<double>(is, cap_d); r.pU = get<int>(is, cap_i); r.Ir = get<int>(is, cap_i);
+    r.XV = get<double>(is, cap_d); r.pV = get<int>(is, cap_i); r.Ic = get<int>(is, cap_i);
   }
   // cluster tree from the node table (children follow their parent in pre-order)
   std::function<structured::ClusterTree(int)> tree_of = [&](int i) {

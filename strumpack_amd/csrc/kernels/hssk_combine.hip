@@ -116,7 +116,7 @@ extern "C" int hssk_gather_combine(hssk_ctx* ctx, const hssk_combine_desc* descs
     return n;
   };
   for (int p = 0; p < count; p++)
-    if (descs[p].rows > 0 && descs[p].J > 0 && descs[p].K > 0 && (!descs[p].M0 || !descs[p].C)) return 2;
+    if (descs[p].rows > 0 && descs[p].J > 0 && descs[p].K > 0 && (!descs[p].M0 || !descs[p].C)) HSSK_UNSUPPORTED("product without its operands");
   const int jb = items(64, nullptr) >= 512 ? 64 : 16;
   std::vector<GcWork> work;
   if (items(jb, &work) == 0) return 0;

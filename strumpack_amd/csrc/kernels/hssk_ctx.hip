@@ -38,11 +38,25 @@ struct hssk_uploader {
     ev_compute = hssk_rt::event_create();
     ev_mark[0] = hssk_rt::event_create();
     ev_mark[1] = hssk_rt::event_create();
-    for (int i = 0; i < SLOTS; i++) { pinned[i] = (char*)hssk_rt::pinned_malloc(CHUNK); slot_ev[i] = hssk_rt::event_create(); }
+    for (int i = 0; i < SLOTS; i++) slot_ev[i] = hssk_rt::event_create();
+  }
+  // the bounce slots (4 x 256 MiB of pinned host memory) exist only while the packing path of h2d_bytes uses them: taken on
+  // first use, given back when the context is retired (a pooled context keeps its streams and events, not the slots)
+  char* slot(int s) {
+    if (!pinned[s]) pinned[s] = (char*)hssk_rt::pinned_malloc(CHUNK);
+    return pinned[s];
+  }
+  void release_slots() {
+    try { hssk_rt::sync(copy); } catch (...) {}
+    for (int i = 0; i < SLOTS; i++) {
+      if (pinned[i]) hssk_rt::pinned_free(pinned[i]);
+      pinned[i] = nullptr;
+      slot_busy[i] = false;
+    }
   }
   ~hssk_uploader() {
     try { hssk_rt::sync(copy); } catch (...) {}
-    for (int i = 0; i < SLOTS; i++) { hssk_rt::pinned_free(pinned[i]); hssk_rt::event_destroy(slot_ev[i]); }
+    for (int i = 0; i < SLOTS; i++) { if (pinned[i]) hssk_rt::pinned_free(pinned[i]); hssk_rt::event_destroy(slot_ev[i]); }
     hssk_rt::event_destroy(ev_copy);
     hssk_rt::event_destroy(ev_compute);
     hssk_rt::event_destroy(ev_mark[0]);
@@ -152,8 +166,8 @@ static void h2d_bytes(hssk_ctx* c, char* dst, size_t dpitch, const char* src, si
         const size_t len = std::min(hssk_uploader::CHUNK, colb - o);
         const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
         if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);
-        std::memcpy(u->pinned[s], src + (size_t)j * spitch + o, len);
-        hssk_rt::h2d(dst + (size_t)j * dpitch + o, u->pinned[s], len, u->copy);
+        std::memcpy(u->slot(s), src + (size_t)j * spitch + o, len);
+        hssk_rt::h2d(dst + (size_t)j * dpitch + o, u->slot(s), len, u->copy);
         hssk_rt::event_record(u->slot_ev[s], u->copy);
         u->slot_busy[s] = true;
       }
@@ -164,11 +178,11 @@ static void h2d_bytes(hssk_ctx* c, char* dst, size_t dpitch, const char* src, si
     const long long c1 = std::min(cols, c0 + cpc);
     const int s = u->next; u->next = (s + 1) % hssk_uploader::SLOTS;
     if (u->slot_busy[s]) hssk_rt::event_sync(u->slot_ev[s]);   // the DMA that last read this slot has finished
-    host_pack(u->pinned[s], src, spitch, colb, c0, c1);
+    host_pack(u->slot(s), src, spitch, colb, c0, c1);
     if (dpitch == colb)   // contiguous on the device: one linear DMA (the rectangular copy path is markedly slower)
-      hssk_rt::h2d(dst + (size_t)c0 * dpitch, u->pinned[s], colb * (size_t)(c1 - c0), u->copy);
+      hssk_rt::h2d(dst + (size_t)c0 * dpitch, u->slot(s), colb * (size_t)(c1 - c0), u->copy);
     else
-      hssk_rt::h2d_2d(dst + (size_t)c0 * dpitch, dpitch, u->pinned[s], colb, colb, (size_t)(c1 - c0), u->copy);
+      hssk_rt::h2d_2d(dst + (size_t)c0 * dpitch, dpitch, u->slot(s), colb, colb, (size_t)(c1 - c0), u->copy);
     hssk_rt::event_record(u->slot_ev[s], u->copy);
     u->slot_busy[s] = true;
   }
@@ -186,7 +200,7 @@ int hssk_h2d_block_async(hssk_ctx* c, double* dst, long long ldd, const double* 
 int hssk_h2d_bytes_async(hssk_ctx* c, void* dst, long long dpitch, const void* src, long long spitch, long long width, long long cols) {
   HSSK_API_BEGIN
   if (width <= 0 || cols <= 0) return 0;
-  if (dpitch < width || spitch < width) return 2;
+  if (dpitch < width || spitch < width) HSSK_UNSUPPORTED("pitch smaller than the row width");
   h2d_bytes(c, (char*)dst, (size_t)dpitch, (const char*)src, (size_t)spitch, (size_t)width, cols);
   HSSK_API_END
 }
@@ -255,6 +269,7 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   {
     std::lock_guard<std::mutex> g(g_pool_mu);
     if (g_pool.size() < 8) {
+      if (c->uploader) c->uploader->release_slots();
       c->ring_off = 0;
       c->dgemm_timed = false;
       g_pool.push_back(c);
@@ -266,6 +281,8 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   hssk_rt::dev_free(c->d_scratch);
   delete c->uploader;
   hssk_rt::pinned_free(c->h_sweep_err);
+  for (auto& w : c->watch) for (auto& p : w) { hssk_rt::event_destroy(p.first); hssk_rt::event_destroy(p.second); }
+  for (auto e : c->watch_free) hssk_rt::event_destroy(e);
   hssk_rt::event_destroy(c->ev0);
   hssk_rt::event_destroy(c->ev1);
   hssk_rt::stream_destroy(c->stream);
@@ -273,6 +290,47 @@ void hssk_ctx_destroy(hssk_ctx* c) {
 }
 
 void* hssk_ctx_stream(hssk_ctx* c) { return (void*)c->stream; }
+
+static hssk_rt::event_t watch_event(hssk_ctx* c) {
+  if (c->watch_free.empty()) return hssk_rt::event_create();
+  hssk_rt::event_t e = c->watch_free.back();
+  c->watch_free.pop_back();
+  return e;
+}
+int hssk_watch_start(hssk_ctx* c, int id) {
+  HSSK_API_BEGIN
+  if (id < 0 || id >= 8) throw std::invalid_argument("hssk_watch_start: id out of range");
+  if (c->watch_open[id]) throw std::logic_error("hssk_watch_start: stopwatch is already running");
+  hssk_rt::event_t a = watch_event(c), b = watch_event(c);
+  hssk_rt::event_record(a, c->stream);
+  c->watch[id].emplace_back(a, b);
+  c->watch_open[id] = true;
+  HSSK_API_END
+}
+int hssk_watch_stop(hssk_ctx* c, int id) {
+  HSSK_API_BEGIN
+  if (id < 0 || id >= 8 || !c->watch_open[id]) throw std::logic_error("hssk_watch_stop: stopwatch is not running");
+  hssk_rt::event_record(c->watch[id].back().second, c->stream);
+  c->watch_open[id] = false;
+  HSSK_API_END
+}
+double hssk_watch_read_ms(hssk_ctx* c, int id, int* pairs) {
+  if (pairs) *pairs = 0;
+  if (!c || id < 0 || id >= 8) return 0.;
+  try {
+    if (c->watch_open[id]) { hssk_rt::event_record(c->watch[id].back().second, c->stream); c->watch_open[id] = false; }
+    hssk_rt::sync(c->stream);
+    double ms = 0.;
+    for (auto& p : c->watch[id]) {
+      ms += hssk_rt::event_elapsed_ms(p.first, p.second);
+      c->watch_free.push_back(p.first);
+      c->watch_free.push_back(p.second);
+    }
+    if (pairs) *pairs = (int)c->watch[id].size();
+    c->watch[id].clear();
+    return ms;
+  } catch (const std::exception& e) { hssk_set_error(e.what()); return -1.; }
+}
 
 int hssk_sync(hssk_ctx* c) {
   HSSK_API_BEGIN

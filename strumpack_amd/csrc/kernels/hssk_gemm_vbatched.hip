@@ -490,7 +490,7 @@ extern "C" int hssk_leaf_update_vbatched(hssk_ctx* ctx, const hssk_leaf_update_d
   for (int p = 0; p < count; p++) {
     const hssk_leaf_update_desc& d = descs[p];
     if (d.d <= 0 || d.m <= 0) continue;
-    if (d.d > PBM || (d.d % 2) || (d.ldr % 2) || ((size_t)d.R % 16)) return 2;  // caller falls back to two GEMMs
+    if (d.d > PBM || (d.d % 2) || (d.ldr % 2) || ((size_t)d.R % 16)) HSSK_UNSUPPORTED("panel shape outside the fused leaf update");  // caller falls back to two GEMMs
     for (int tn = 0; tn * PBN < d.m; tn++) tiles.push_back(Tile{p, 0, tn});
   }
   if (tiles.empty()) return 0;

@@ -54,6 +54,10 @@ struct hssk_ctx {
   struct hssk_uploader* uploader = nullptr;   // copy stream + pinned bounce slots of hssk_h2d_block_async (hssk_ctx.hip)
   int* d_sweep_flags = nullptr;
   int* h_sweep_err = nullptr;
+  // stopwatches (hssk_watch_*): recorded event pairs per id, recycled through a free list
+  std::vector<std::pair<hssk_rt::event_t, hssk_rt::event_t>> watch[8];
+  std::vector<hssk_rt::event_t> watch_free;
+  bool watch_open[8] = {false, false, false, false, false, false, false, false};
   size_t sweep_cap = size_t(1) << 20;
   size_t scratch_bytes = 0;
 
@@ -98,6 +102,9 @@ struct hssk_ctx {
 
 void hssk_set_error(const std::string& msg);
 
+// "this entry point does not take these operands" (status 2): callers with a fallback path test for 2, the others go
+// through ck() and must find a message, never a stale one
+#define HSSK_UNSUPPORTED(msg) do { hssk_set_error(std::string(__func__) + ": " + (msg)); return 2; } while (0)
 #define HSSK_API_BEGIN try {
 #define HSSK_API_END                 \
   return 0;                          \

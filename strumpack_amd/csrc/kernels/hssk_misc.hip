@@ -455,8 +455,8 @@ int hssk_expand_image(hssk_ctx* ctx, double* dst, long long ldd, const void* src
                       int dtype) {
   HSSK_API_BEGIN
   if (rows <= 0 || cols <= 0) return 0;
-  if (dtype != HSSK_DT_F32 && dtype != HSSK_DT_C32 && dtype != HSSK_DT_C64) return 2;
-  if (lds < rows || ldd < (dtype == HSSK_DT_F32 ? rows : 2 * rows)) return 2;
+  if (dtype != HSSK_DT_F32 && dtype != HSSK_DT_C32 && dtype != HSSK_DT_C64) HSSK_UNSUPPORTED("unknown scalar type");
+  if (lds < rows || ldd < (dtype == HSSK_DT_F32 ? rows : 2 * rows)) HSSK_UNSUPPORTED("leading dimension smaller than the block");
   for (long long c0 = 0; c0 < cols; c0 += 65535) {   // (grid.y limit)
     const long long nc = std::min<long long>(65535, cols - c0);
     dim3 grid((unsigned)std::min<long long>(256, (rows + 255) / 256), (unsigned)nc);

@@ -801,11 +801,11 @@ extern "C" int hssk_tpqr_vbatched(hssk_ctx* ctx, const hssk_tpqr_desc* descs, in
   if (count <= 0) return 0;
   int mmax = 0;
   for (int i = 0; i < count; i++) {
-    if (descs[i].m < 0 || descs[i].ld1 < descs[i].m || descs[i].ld2 < descs[i].m) return 2;
+    if (descs[i].m < 0 || descs[i].ld1 < descs[i].m || descs[i].ld2 < descs[i].m) HSSK_UNSUPPORTED("bad triangle descriptor");
     mmax = std::max(mmax, descs[i].m);
   }
   if (mmax == 0) return 0;
-  if (mmax > 224) return 2;   // (beyond the register tile: the caller stacks the triangles and calls hssk_qr_vbatched)
+  if (mmax > 224) HSSK_UNSUPPORTED("triangles beyond 224 columns");   // (beyond the register tile: the caller stacks the triangles and calls hssk_qr_vbatched)
   auto* dd = (const hssk_tpqr_desc*)ctx->stage(descs, sizeof(*descs) * count);
   if (mmax <= 64) HSSK_LAUNCH((tpqr_reg_kernel<4, 2, 8>), dim3((unsigned)count), dim3(512), 0, ctx->stream, dd);
   else if (mmax <= 128) HSSK_LAUNCH((tpqr_reg_kernel<8, 4, 8>), dim3((unsigned)count), dim3(512), 0, ctx->stream, dd);

@@ -628,9 +628,9 @@ extern "C" int hssk_sweep_arm(hssk_ctx* ctx, double* buf, long long count) {
 extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  if (nrhs < 1 || nrhs > SW_NR * 16384) return 2;
+  if (nrhs < 1 || nrhs > SW_NR * 16384) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   for (int i = 0; i < count; i++)
-    if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) return 2;
+    if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
   if (nrhs == 1) HSSK_LAUNCH(ulv_fwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -642,9 +642,9 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
 extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* descs, int count, int nrhs) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  if (nrhs < 1 || nrhs > SW_NR * 16384) return 2;
+  if (nrhs < 1 || nrhs > SW_NR * 16384) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   for (int i = 0; i < count; i++)
-    if (descs[i].m > SW_MAX || descs[i].wait0 >= i) return 2;
+    if (descs[i].m > SW_MAX || descs[i].wait0 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   if (nrhs == 1) HSSK_LAUNCH(ulv_bwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -656,13 +656,13 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
                                 int ndown, int nrhs) {
   HSSK_API_BEGIN
   if (nup + ndown <= 0) return 0;
-  if (nrhs < 1 || nrhs > SW_NR * 16384) return 2;
+  if (nrhs < 1 || nrhs > SW_NR * 16384) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   for (int i = 0; i < nup; i++)
-    if (ups[i].m > SW_MAX || ups[i].wait0 >= i || ups[i].wait1 >= i) return 2;
+    if (ups[i].m > SW_MAX || ups[i].wait0 >= i || ups[i].wait1 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   for (int i = 0; i < ndown; i++) {
     const hssk_apply_down_desc& d = downs[i];
-    if (d.mo > SW_MAX || d.m > SW_MAX || d.ri_a + d.ri_b > SW_MAX || d.ro_a + d.ro_b > SW_MAX) return 2;
-    if (d.wait0 >= nup + i || d.wait1 >= nup + i || d.wait2 >= nup + i) return 2;
+    if (d.mo > SW_MAX || d.m > SW_MAX || d.ri_a + d.ri_b > SW_MAX || d.ro_a + d.ro_b > SW_MAX) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
+    if (d.wait0 >= nup + i || d.wait1 >= nup + i || d.wait2 >= nup + i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   }
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;

@@ -89,7 +89,7 @@ extern "C" int hssk_ulv_split(hssk_ctx* ctx, const hssk_ulvsplit_desc* descs, in
   for (int p = 0; p < count; p++) {
     const hssk_ulvsplit_desc& d = descs[p];
     if (d.m <= 0) continue;
-    if (d.m > US_MMAX || d.r < 0 || d.r > d.m) return 2;   // (larger blocks: the caller's gathers + GEMM)
+    if (d.m > US_MMAX || d.r < 0 || d.r > d.m) HSSK_UNSUPPORTED("block beyond the LDS tile");   // (larger blocks: the caller's gathers + GEMM)
     for (int cb = 0; cb * US_C < d.m; cb++) work.push_back(UsWork{p, cb});
   }
   if (work.empty()) return 0;
