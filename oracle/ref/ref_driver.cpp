@@ -20,6 +20,7 @@
 #include "kernel/KernelRegression.hpp"
 #include "clustering/Clustering.hpp"
 #include "clustering/NeighborSearch.hpp"
+#include "BLR/BLRMatrix.hpp"
 
 using namespace strumpack;
 using namespace strumpack::HSS;
@@ -288,6 +289,55 @@ int ref_blr_dense(int n, const double* A, int leaf, double rel_tol, double abs_t
   DenseMatrix<double> Zd(Xd);
   F->solve(Zd);
   std::memcpy(Z, Zd.data(), sizeof(double) * n * nrhs);
+  return 0;
+}
+
+// ---- BLR frontal matrix (BASELINE configs[4]): BLRMatrix<double>::construct_and_partial_factor
+// (BLR/BLRMatrix.cpp:740-1037) on [F11 F12; F21 F22] exactly as sparse/fronts/FrontBLR.cpp:419-432 calls it (default
+// options: RRQR tiles, algorithm RL), followed by the two solve phases of the front (FrontBLR.cpp:525-570).
+//   F22: in = the assembled update block, out = the Schur complement.  adm: nt1 x nt1 column-major (null: weak
+//   admissibility -- every off-diagonal tile).  ranks: (nt1 + nt2)^2 column-major over the tiles of the whole front,
+//   rank of a low-rank tile, -1 dense, -2 the F22 part.  bsep / bupd: forward phase in place; ysep: backward phase in
+//   place with yupd.  stats: [0] seconds, [1..3] nonzeros of B11 / B12 / B21, [4] largest rank of the three.
+int ref_blr_front(int dsep, int dupd, const double* F11, const double* F12, const double* F21, double* F22, int nt1,
+                  const int* tiles1, int nt2, const int* tiles2, const char* adm, double rel_tol, double abs_tol, int nrhs,
+                  double* bsep, double* bupd, double* ysep, const double* yupd, int* ranks, double* stats) {
+  using BLRM = BLR::BLRMatrix<double>;
+  BLR::BLROptions<double> o;
+  o.set_rel_tol(rel_tol);
+  o.set_abs_tol(abs_tol);
+  o.set_verbose(false);
+  std::vector<std::size_t> t1(tiles1, tiles1 + nt1), t2(tiles2, tiles2 + nt2);
+  DenseMatrix<bool> A(nt1, nt1);
+  for (int j = 0; j < nt1; j++)
+    for (int i = 0; i < nt1; i++) A(i, j) = adm ? adm[i + (size_t)j * nt1] != 0 : (i != j);
+  DenseMatrix<double> A11(dsep, dsep, F11, dsep), A12(dsep, dupd, F12, std::max(dsep, 1)), A21(dupd, dsep, F21, std::max(dupd, 1));
+  DenseMatrixWrapper<double> A22(dupd, dupd, F22, std::max(dupd, 1));
+  BLRM B11, B12, B21;
+  double t0 = now();
+  BLRM::construct_and_partial_factor(A11, A12, A21, A22, B11, B12, B21, t1, t2, A, o);
+  stats[0] = now() - t0;
+  stats[1] = B11.nonzeros(); stats[2] = B12.nonzeros(); stats[3] = B21.nonzeros();
+  stats[4] = std::max(B11.rank(), std::max(B12.rank(), B21.rank()));
+  const int nt = nt1 + nt2;
+  for (int j = 0; j < nt; j++)
+    for (int i = 0; i < nt; i++) {
+      int r = -2;
+      const BLR::BLRTile<double>* t = nullptr;
+      if (i < nt1 && j < nt1) t = &B11.tile(i, j);
+      else if (i < nt1) t = &B12.tile(i, j - nt1);
+      else if (j < nt1) t = &B21.tile(i - nt1, j);
+      if (t) r = t->is_low_rank() ? (int)t->rank() : -1;
+      ranks[i + (size_t)j * nt] = r;
+    }
+  if (nrhs > 0) {
+    DenseMatrixWrapper<double> bl(dsep, nrhs, bsep, std::max(dsep, 1)), bu(dupd, nrhs, bupd, std::max(dupd, 1));
+    bl.laswp(B11.piv(), true);
+    BLRM::trsmLNU_gemm(B11, B21, bl, bu, 0);
+    DenseMatrixWrapper<double> yl(dsep, nrhs, ysep, std::max(dsep, 1));
+    DenseMatrix<double> yu(dupd, nrhs, yupd, std::max(dupd, 1));
+    BLRM::gemm_trsmUNN(B11, B12, yl, yu, 0);
+  }
   return 0;
 }
 

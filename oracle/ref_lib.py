@@ -184,3 +184,30 @@ def bench_toeplitz(n, leaf=256, rel_tol=1e-4, abs_tol=1e-8, nrhs=1):
         raise RuntimeError("reference compression failed")
     return dict(compress_s=times[0], factor_s=times[1], solve_s=times[2], apply_s=times[3],
                 rank=int(stats[0]), levels=int(stats[1]), resid=stats[2], memory=int(stats[3]))
+
+
+def blr_front(F11, F12, F21, F22, tiles1, tiles2, rel_tol, abs_tol, adm=None, bsep=None, bupd=None, ysep=None, yupd=None):
+    """the reference's BLRMatrix::construct_and_partial_factor on [F11 F12; F21 F22] (ref_driver.cpp: ref_blr_front) and
+    the front's two solve phases -> dict(S = Schur complement, ranks, stats, bsep, bupd (forward), ysep (backward))"""
+    L = lib()
+    vp = C.c_void_p
+    L.ref_blr_front.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.c_char_p, C.c_double, C.c_double,
+                                C.c_int, vp, vp, vp, vp, vp, vp]
+    L.ref_blr_front.restype = C.c_int
+    ds, du = F11.shape[0], F12.shape[1]
+    f = lambda a: np.array(a, dtype=np.float64, order="F")
+    A11, A12, A21, S = f(F11), f(F12), f(F21), f(F22)
+    t1, t2 = np.ascontiguousarray(tiles1, dtype=np.int32), np.ascontiguousarray(tiles2, dtype=np.int32)
+    nt = len(t1) + len(t2)
+    ranks = np.zeros((nt, nt), dtype=np.int32, order="F")
+    stats = np.zeros(8)
+    nrhs = 0 if bsep is None else np.asarray(bsep).reshape(ds, -1).shape[1]
+    mk = lambda a, n: f(np.asarray(a).reshape(n, nrhs, order="F")) if a is not None and n else np.zeros((n, max(nrhs, 1)), order="F")
+    bs, bu, ys, yu = mk(bsep, ds), mk(bupd, du), mk(ysep, ds), mk(yupd, du)
+    admb = None if adm is None else np.asfortranarray(np.asarray(adm).astype(np.int8)).tobytes(order="F")
+    ptr = lambda a: a.ctypes.data if a.size else None
+    rc = L.ref_blr_front(ds, du, ptr(A11), ptr(A12), ptr(A21), ptr(S), len(t1), t1.ctypes.data, len(t2), ptr(t2), admb,
+                         rel_tol, abs_tol, nrhs, ptr(bs), ptr(bu), ptr(ys), ptr(yu), ranks.ctypes.data, stats.ctypes.data)
+    if rc:
+        raise RuntimeError("ref_blr_front failed")
+    return dict(S=S, ranks=ranks, stats=stats, bsep=bs, bupd=bu, ysep=ys)

@@ -172,7 +172,7 @@ class BLRFront:
 
     def forward(self, bsep, bupd=None):
         bs = np.array(bsep, dtype=np.float64, order="F").reshape(self.dsep, -1, order="F")
-        bu = np.array(bupd, dtype=np.float64, order="F").reshape(self.dupd, -1, order="F") if self.dupd else None
+        bu = np.array(bupd, dtype=np.float64, order="F").reshape(self.dupd, bs.shape[1], order="F") if self.dupd else None
         if self.L.SPX_d_blr_front_forward(self.h, bs.shape[1], bs.ctypes.data, max(self.dsep, 1),
                                           bu.ctypes.data if bu is not None else None, max(self.dupd, 1)):
             raise RuntimeError("SPX_d_blr_front_forward failed")
@@ -180,7 +180,7 @@ class BLRFront:
 
     def backward(self, ysep, yupd=None):
         ys = np.array(ysep, dtype=np.float64, order="F").reshape(self.dsep, -1, order="F")
-        yu = np.asfortranarray(yupd, dtype=np.float64).reshape(self.dupd, -1, order="F") if self.dupd else None
+        yu = np.asfortranarray(yupd, dtype=np.float64).reshape(self.dupd, ys.shape[1], order="F") if self.dupd else None
         if self.L.SPX_d_blr_front_backward(self.h, ys.shape[1], ys.ctypes.data, max(self.dsep, 1),
                                            yu.ctypes.data if yu is not None else None, max(self.dupd, 1)):
             raise RuntimeError("SPX_d_blr_front_backward failed")
