@@ -43,11 +43,15 @@ def parse():
     p.add_argument("--sketch", choices=["gaussian", "sjlt"], default="gaussian",
                    help="gaussian = the reference's default (BASELINE's metric is quoted on it); sjlt = its "
                         "--hss_compression_sketch SJLT option (nnz = 4), a separate, HBM-bound workload")
-    p.add_argument("--workload", choices=["toeplitz", "kernel", "host"], default="toeplitz",
+    p.add_argument("--front-n", type=int, default=64, help="blr_front: the separator is an n x n plane (dsep = n^2, dupd = 2 n^2)")
+    p.add_argument("--front-leaf", type=int, default=256, help="blr_front: tile size (the reference's BLR default)")
+    p.add_argument("--workload", choices=["toeplitz", "kernel", "host", "blr_front"], default="toeplitz",
                    help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
                         "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line; host = the headline "
                         "matrix resident in HOST memory, through the reference's own entry point SP_d_struct_from_dense "
-                        "(the drop-in call: the operand crosses PCIe inside the step), reported as a secondary line")
+                        "(the drop-in call: the operand crosses PCIe inside the step), reported as a secondary line; blr_front = "
+                        "BASELINE configs[4]'s kernel: BLR partial factorization (batched LU) of an exact frontal matrix of the 3D "
+                        "7-point Poisson problem, operands resident in HBM, reported as a secondary line")
     return p.parse_args()
 
 
@@ -193,6 +197,96 @@ def host_workload(a, L, hk):
     H.destroy()
 
 
+def blr_front_workload(a, L, hk, torch):
+    """BASELINE configs[4]'s device kernel: the reference factors a 3D Poisson problem with BLR-compressed fronts; the
+    multifrontal driver (METIS ordering, assembly tree) is out of scope, the per-front work
+    BLRMatrix::construct_and_partial_factor (BLR/BLRMatrix.cpp:740, GPU precedent BLRMatrix.GPU.cpp:71-262) is what runs
+    here, on an exact front of that problem (tests/blr_fronts.py: separator = an n x n plane, update part = the two
+    planes that bound the eliminated slab), operands in HBM.  One step = partial factorization + forward / backward
+    solve phase of the front with one right-hand side."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import blr_fronts as BF
+    from strumpack_amd import capi
+    n, leaf = a.front_n, a.front_leaf
+
+    def mm(A, B):   # setup only: the closed-form blocks are products with the 2D sine basis
+        return (torch.from_numpy(np.ascontiguousarray(A)).cuda() @ torch.from_numpy(np.ascontiguousarray(B)).cuda()).cpu().numpy()
+    fr = BF.poisson_front(n, 8, 8, leaf, matmul=mm)
+    torch.cuda.empty_cache()
+    ds, du = fr["F11"].shape[0], fr["F12"].shape[1]
+    nF = float(np.sqrt(sum(np.linalg.norm(fr[k]) ** 2 for k in ("F11", "F12", "F21"))))
+    rtol, atol = 1e-4, 1e-12 * nF      # BLROptions defaults; abs_tol scaled by the front's norm (FrontBLR.cpp:424-429)
+    o = capi.StructuredMatrix.options(L, rel_tol=rtol, abs_tol=atol, type=capi.SP_TYPE_BLR)
+    d = {k: hk.array(fr[k]) for k in ("F11", "F12", "F21", "F22")}
+    rng = np.random.default_rng(5)
+    b, bu = rng.standard_normal((ds, 1)), rng.standard_normal((du, 1))
+    hk.sync()
+    L.SPX_d_blr_front_time_phases(1)
+
+    def step():
+        F = capi.BLRFront.factor_device(L, ds, du, d["F11"].ptr, ds, d["F12"].ptr, ds, d["F21"].ptr, du, d["F22"].ptr, du,
+                                        fr["tiles1"], fr["tiles2"], o)
+        ys, yu = F.forward(b, bu)
+        x = F.backward(ys, np.zeros_like(bu))
+        return F, x
+
+    F = None
+    for _ in range(a.warmup):
+        if F is not None:
+            F.destroy()
+        F, x = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sts = []
+    for _ in range(a.steps):
+        if F is not None:
+            F.destroy()
+        F, x = step()
+        sts.append(F.stats())
+    torch.cuda.synchronize()
+    elapsed = (time.perf_counter() - t0) / a.steps
+    st = sts[-1]
+    med = lambda k: sorted(s_[k] for s_ in sts)[len(sts) // 2]
+    S = F.schur()
+    Sx = BF.dense_schur(fr)
+    err = lambda p, q: float(np.linalg.norm(p - q) / np.linalg.norm(q))
+    rk = F.tile_ranks()
+    lr = rk[rk >= 0]
+    ach = st["f_schur"] / (med("ms_schur") * 1e-3) * 1e-12 if med("ms_schur") > 0 else 0.0
+    out = {"metric": "blr_front_partial_factor_gflops", "value": st["f_total"] / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4] kernel: BLR partial factorization (RL, RRQR tiles, rel_tol 1e-4, tiles of %d) of an exact "
+                                  "3D 7-point Poisson front: separator %dx%d plane (dsep=%d), update part dupd=%d, operands in HBM; "
+                                  "+ forward / backward solve phase, 1 rhs" % (leaf, n, n, ds, du),
+                      "dsep": ds, "dupd": du, "tiles": [len(fr["tiles1"]), len(fr["tiles2"])], "leaf": leaf, "rel_tol": rtol},
+           "phases_ms": {"factor_wall": med("t_factor") * 1e3, "lu_diag": med("ms_lu"), "compress_tiles": med("ms_compress"),
+                         "trsm": med("ms_trsm"), "schur_gemm": med("ms_schur")},
+           "flops": {"schur_gemm": st["f_schur"], "total": st["f_total"]},
+           "blr": {"max_rank": int(st["max_rank"]), "mean_rank": float(lr.mean()) if lr.size else 0.0,
+                   "nnz": [st["nnz11"], st["nnz12"], st["nnz21"]], "dense_nnz": [ds * ds, ds * du, du * ds]},
+           "checks": {"schur_err_vs_dense": err(S, Sx), "B11_solve_resid": err(fr["F11"] @ x, b)},
+           "roofline": {"kernel": "gemm_vbatched_kernel (the three batched GEMMs of a block step's Schur update, v_mfma_f64_16x16x4_f64)",
+                        "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                        "traffic": None, "phase_ms": med("ms_schur"), "launches_per_step": int(st["schur_launches"]),
+                        "flops_per_step": st["f_schur"],
+                        "note": "HIP events on the engine's stream around the Schur-update launches of every block step (hssk_watch_*), summed over the step"}}
+    if not a.no_cpu_baseline:
+        try:
+            from oracle import ref_lib as R
+            if not R.available():
+                raise RuntimeError("oracle/_ref not built")
+            ref = R.blr_front(fr["F11"], fr["F12"], fr["F21"], fr["F22"], fr["tiles1"], fr["tiles2"], rtol, atol)
+            out["cpu_baseline"] = {"value": st["f_total"] / ref["stats"][0] * 1e-9, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "reference",
+                                   "sample": "STRUMPACK v8.0.0 BLRMatrix::construct_and_partial_factor (CPU, MKL + OpenMP tasks) on the same front: "
+                                             "%.3f s, max rank %d (same flop count as the GPU line)" % (ref["stats"][0], int(ref["stats"][4]))}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": str(e)[:200]}
+    print(json.dumps(out))
+    F.destroy()
+
+
 def _ref_sample(R, n, leaf, rel_tol):
     r = R.bench_toeplitz(n, leaf=leaf, rel_tol=rel_tol, abs_tol=1e-8, nrhs=1)
     fl = R.flops(reset=True)
@@ -271,6 +365,11 @@ def main():
         if world > 1:
             raise SystemExit("--workload host is the single-GPU drop-in call")
         host_workload(a, L, hk)
+        return
+    if a.workload == "blr_front":
+        if world > 1:
+            raise SystemExit("--workload blr_front: fronts are independent, run one per GPU (replicas only)")
+        blr_front_workload(a, L, hk, torch)
         return
 
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)

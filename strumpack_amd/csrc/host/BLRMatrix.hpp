@@ -12,11 +12,36 @@
 namespace strumpack {
 namespace BLR {
 
-// the subset of BLR/BLROptions.hpp:100-140 that the dense path reads (defaults as there: RRQR tiles, algorithm RL)
+// BLR/BLROptions.hpp:46-146: the options the dense and the frontal paths read.  Defaults as there: rel_tol 1e-4, abs_tol
+// 1e-12, leaf_size 256, max_rank 5000, RRQR tiles, weak admissibility, factorization algorithm RL.  RL with RRQR tiles is the
+// variant built here; selecting another one is refused where it would be used, not silently replaced.
+enum class LowRankAlgorithm { RRQR, ACA, BACA };
+enum class Admissibility { STRONG, WEAK };
+enum class BLRFactorAlgorithm { COLWISE, RL, LL, COMB, STAR };
 template <typename scalar_t> class BLROptions : public structured::StructuredOptions<scalar_t> {
  public:
-  BLROptions() : structured::StructuredOptions<scalar_t>(structured::Type::BLR) {}
-  BLROptions(const structured::StructuredOptions<scalar_t>& o) : structured::StructuredOptions<scalar_t>(o) {}
+  BLROptions() : structured::StructuredOptions<scalar_t>(structured::Type::BLR) {
+    this->set_rel_tol(1e-4);
+    this->set_abs_tol(1e-12);
+    this->set_leaf_size(256);
+    this->set_max_rank(5000);
+  }
+  BLROptions(const structured::StructuredOptions<scalar_t>& o) : structured::StructuredOptions<scalar_t>(o) { this->set_type(structured::Type::BLR); }
+  void set_low_rank_algorithm(LowRankAlgorithm a) { lr_algo_ = a; }
+  void set_admissibility(Admissibility a) { adm_ = a; }
+  void set_BLR_factor_algorithm(BLRFactorAlgorithm a) { blr_algo_ = a; }
+  LowRankAlgorithm low_rank_algorithm() const { return lr_algo_; }
+  Admissibility admissibility() const { return adm_; }
+  BLRFactorAlgorithm BLR_factor_algorithm() const { return blr_algo_; }
+  void check_supported() const {
+    if (lr_algo_ != LowRankAlgorithm::RRQR) throw std::invalid_argument("BLR: only RRQR tile compression is available (ACA / BACA are not)");
+    if (blr_algo_ != BLRFactorAlgorithm::RL) throw std::invalid_argument("BLR: only the RL factorization algorithm is available (LL / COMB / STAR / COLWISE are not)");
+  }
+
+ private:
+  LowRankAlgorithm lr_algo_ = LowRankAlgorithm::RRQR;
+  Admissibility adm_ = Admissibility::WEAK;
+  BLRFactorAlgorithm blr_algo_ = BLRFactorAlgorithm::RL;
 };
 
 template <typename scalar_t> class BLRMatrix;
@@ -27,14 +52,84 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
   using Opts_t = BLROptions<double>;
   using adm_t = DenseMatrix<bool>;
 
+  BLRMatrix() {}
   BLRMatrix(std::size_t m, const std::vector<std::size_t>& rowtiles, std::size_t n, const std::vector<std::size_t>& coltiles)
       : m_(m), n_(n), rt_(rowtiles.begin(), rowtiles.end()), ct_(coltiles.begin(), coltiles.end()) {}
 
   std::size_t rows() const override { return m_; }
   std::size_t cols() const override { return n_; }
-  std::size_t memory() const override { return eng_ ? std::size_t(eng_->memory()) : 0; }
-  std::size_t nonzeros() const override { return eng_ ? std::size_t(eng_->nonzeros()) : 0; }
-  std::size_t rank() const override { return eng_ ? std::size_t(eng_->rank()) : 0; }
+  std::size_t memory() const override { return nonzeros() * sizeof(double); }
+  std::size_t nonzeros() const override {
+    if (!eng_) return 0;
+    if (!part_) return std::size_t(eng_->nonzeros());
+    long long nz[3];
+    eng_->front_nonzeros(nz);
+    return std::size_t(nz[part_ - 1]);
+  }
+  std::size_t rank() const override {
+    if (!eng_) return 0;
+    if (!part_) return std::size_t(eng_->rank());
+    // largest rank among this block's tiles of the front
+    const int nt = eng_->rowblocks(), ns = eng_->sep_blocks();
+    std::vector<int> rk((std::size_t)nt * nt);
+    eng_->tile_ranks(rk.data());
+    int r = 0;
+    for (int j = 0; j < nt; j++)
+      for (int i = 0; i < nt; i++) {
+        const int blk = (i < ns && j < ns) ? 1 : (i < ns ? 2 : (j < ns ? 3 : 0));
+        if (blk == part_) r = std::max(r, rk[(std::size_t)i + (std::size_t)j * nt]);
+      }
+    return std::size_t(r);
+  }
+
+  // ---- frontal matrices: BLRMatrix::construct_and_partial_factor(A11, A12, A21, A22, B11, B12, B21, tiles1, tiles2,
+  // admissible, opts) (BLR/BLRMatrix.hpp:186-194, BLR/BLRMatrix.cpp:740-1037; caller sparse/fronts/FrontBLR.cpp:419-432).
+  // As in the reference A22 is overwritten with the Schur complement A22 - A21 A11^{-1} A12 and A11 / A12 / A21 are
+  // released.  B11, B12, B21 come back as three views of ONE device-resident factorization (the elimination works on the
+  // whole front as one array); they serve the calls the front's solve makes -- piv(), trsmLNU_gemm, gemm_trsmUNN
+  // (FrontBLR.cpp:525-570) -- plus rows / cols / rank / nonzeros / memory.
+  static void construct_and_partial_factor(DenseM_t& A11, DenseM_t& A12, DenseM_t& A21, DenseM_t& A22, BLRMatrix<double>& B11,
+                                           BLRMatrix<double>& B12, BLRMatrix<double>& B21, const std::vector<std::size_t>& tiles1,
+                                           const std::vector<std::size_t>& tiles2, const adm_t& admissible, const Opts_t& opts) {
+    opts.check_supported();
+    const std::size_t ds = A11.rows(), du = A12.cols();
+    if (A11.cols() != ds || A12.rows() != ds || A21.rows() != du || A21.cols() != ds || (du && (A22.rows() != du || A22.cols() != du)))
+      throw std::invalid_argument("construct_and_partial_factor: the four blocks do not form a square front");
+    if (admissible.rows() != tiles1.size() || admissible.cols() != tiles1.size()) throw std::invalid_argument("Admissibility matrix wrong size");
+    std::vector<int> tiles(tiles1.begin(), tiles1.end());
+    tiles.insert(tiles.end(), tiles2.begin(), tiles2.end());
+    BLREngineOptions e;
+    e.rel_tol = opts.rel_tol(); e.abs_tol = opts.abs_tol(); e.max_rank = opts.max_rank(); e.verbose = opts.verbose();
+    if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
+    std::shared_ptr<DeviceBLR> eng(new DeviceBLR(int(ds + du), tiles, int(ds + du), tiles, e));
+    std::vector<char> adm(tiles1.size() * tiles1.size());
+    for (std::size_t j = 0; j < tiles1.size(); j++)
+      for (std::size_t i = 0; i < tiles1.size(); i++) adm[i + j * tiles1.size()] = admissible(i, j) ? 1 : 0;
+    eng->partial_factor_host(int(tiles1.size()), A11.data(), A11.ld(), du ? A12.data() : nullptr, A12.ld(), du ? A21.data() : nullptr,
+                             A21.ld(), du ? A22.data() : nullptr, A22.ld(), adm.data());
+    if (du) eng->schur_host(A22.data(), A22.ld());
+    B11 = BLRMatrix<double>(ds, tiles1, ds, tiles1);
+    B12 = BLRMatrix<double>(ds, tiles1, du, tiles2);
+    B21 = BLRMatrix<double>(du, tiles2, ds, tiles1);
+    B11.eng_ = B12.eng_ = B21.eng_ = eng;
+    B11.part_ = 1; B12.part_ = 2; B21.part_ = 3;
+    // the row interchanges are applied inside the forward phase (trsmLNU_gemm); piv() is the identity in LAPACK's
+    // convention, so that the reference's call sequence `bloc.laswp(F11.piv(), true); trsmLNU_gemm(...)` is unchanged
+    B11.piv_.resize(ds);
+    for (std::size_t i = 0; i < ds; i++) B11.piv_[i] = int(i) + 1;
+    A11.clear(); A12.clear(); A21.clear();
+  }
+  const std::vector<int>& piv() const { return piv_; }
+  // B1 <- L11^{-1} P B1,  B2 <- B2 - F2 B1   with F1 = B11, F2 = B21 of one front  (BLRMatrix.cpp:1552-1608)
+  static void trsmLNU_gemm(const BLRMatrix<double>& F1, const BLRMatrix<double>& F2, DenseM_t& B1, DenseM_t& B2, int /*task_depth*/) {
+    same_front(F1, 1, F2, 3);
+    F1.eng_->front_forward(int(B1.cols()), B1.data(), B1.ld(), F2.rows() ? B2.data() : nullptr, B2.ld());
+  }
+  // B1 <- U11^{-1} (B1 - F2 B2)   with F1 = B11, F2 = B12 of one front  (BLRMatrix.cpp:1610-1665)
+  static void gemm_trsmUNN(const BLRMatrix<double>& F1, const BLRMatrix<double>& F2, DenseM_t& B1, DenseM_t& B2, int /*task_depth*/) {
+    same_front(F1, 1, F2, 2);
+    F1.eng_->front_backward(int(B1.cols()), B1.data(), B1.ld(), F2.cols() ? B2.data() : nullptr, B2.ld());
+  }
   std::size_t rowblocks() const { return rt_.size(); }
   std::size_t colblocks() const { return ct_.size(); }
 
@@ -57,6 +152,15 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
   using structured::StructuredMatrix<double>::mult;
   void solve(DenseM_t& b) const override {
     need();
+    if (part_ == 1) {   // B11 of a front: B11 \ b = the two solve phases with an empty update part
+      const int du = eng_->upd_rows();
+      DenseM_t z(du, b.cols());
+      eng_->front_forward(int(b.cols()), b.data(), b.ld(), du ? z.data() : nullptr, z.ld());
+      z.zero();
+      eng_->front_backward(int(b.cols()), b.data(), b.ld(), du ? z.data() : nullptr, z.ld());
+      return;
+    }
+    if (part_) throw std::logic_error("BLR solve: only the separator block B11 of a front can be solved with");
     eng_->solve(int(b.cols()), b.data(), b.ld());
   }
   using structured::StructuredMatrix<double>::solve;
@@ -70,11 +174,16 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
 
  private:
   void need() const { if (!eng_) throw std::logic_error("BLR matrix has not been compressed"); }
+  static void same_front(const BLRMatrix<double>& a, int pa, const BLRMatrix<double>& b, int pb) {
+    if (!a.eng_ || a.eng_ != b.eng_ || a.part_ != pa || b.part_ != pb)
+      throw std::invalid_argument("BLR front: the two blocks do not come from one construct_and_partial_factor call");
+  }
   void make(const Opts_t& o) {
     BLREngineOptions e;
     e.rel_tol = o.rel_tol(); e.abs_tol = o.abs_tol(); e.max_rank = o.max_rank(); e.verbose = o.verbose();
     if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
     eng_.reset(new DeviceBLR(int(m_), rt_, int(n_), ct_, e));
+    part_ = 0;
   }
   std::vector<char> flags(const adm_t& a) const {
     if (a.rows() != rt_.size() || a.cols() != ct_.size()) throw std::invalid_argument("Admissibility matrix wrong size");
@@ -85,7 +194,9 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
   }
   std::size_t m_, n_;
   std::vector<int> rt_, ct_;
-  std::unique_ptr<DeviceBLR> eng_;
+  std::shared_ptr<DeviceBLR> eng_;
+  int part_ = 0;            // 0: a matrix of its own; 1 / 2 / 3: B11 / B12 / B21 of a front
+  std::vector<int> piv_;
 };
 
 }  // namespace BLR

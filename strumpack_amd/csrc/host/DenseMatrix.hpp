@@ -7,15 +7,23 @@
 #include <cassert>
 #include <cmath>
 #include <cstddef>
+#include <complex>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <random>
 #include <string>
 #include <vector>
+#if defined(_OPENMP)
+#include <omp.h>   // (the reference's headers bring it in; its drivers call omp_get_max_threads())
+#endif
 
 namespace strumpack {
 
 enum class Trans : char { N = 'N', C = 'C', T = 'T' };
+enum class Side : char { L = 'L', R = 'R' };
+enum class UpLo : char { U = 'U', L = 'L' };
+enum class Diag : char { U = 'U', N = 'N' };
 inline Trans c2T(char op) {
   switch (op) {
     case 'n': case 'N': return Trans::N;
@@ -90,6 +98,64 @@ template <typename scalar_t> class DenseMatrix {
   double norm() const { return normF(); }
   std::size_t memory() const { return sizeof(scalar_t) * rows_ * cols_; }
   std::size_t nonzeros() const { return rows_ * cols_; }
+  // B = (*this)(I, J)  (dense/DenseMatrix.hpp:551)
+  DenseMatrix<scalar_t> extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const {
+    DenseMatrix<scalar_t> B(I.size(), J.size());
+    for (std::size_t j = 0; j < J.size(); j++)
+      for (std::size_t i = 0; i < I.size(); i++) {
+        assert(I[i] < rows_ && J[j] < cols_);
+        B(i, j) = (*this)(I[i], J[j]);
+      }
+    return B;
+  }
+  DenseMatrix<scalar_t> extract_rows(const std::vector<std::size_t>& I) const {
+    DenseMatrix<scalar_t> B(I.size(), cols_);
+    for (std::size_t j = 0; j < cols_; j++)
+      for (std::size_t i = 0; i < I.size(); i++) B(i, j) = (*this)(I[i], j);
+    return B;
+  }
+  DenseMatrix<scalar_t> extract_cols(const std::vector<std::size_t>& J) const {
+    DenseMatrix<scalar_t> B(rows_, J.size());
+    for (std::size_t j = 0; j < J.size(); j++)
+      for (std::size_t i = 0; i < rows_; i++) B(i, j) = (*this)(i, J[j]);
+    return B;
+  }
+  DenseMatrix<scalar_t> transpose() const {
+    DenseMatrix<scalar_t> T(cols_, rows_);
+    for (std::size_t j = 0; j < cols_; j++)
+      for (std::size_t i = 0; i < rows_; i++) T(j, i) = (*this)(i, j);
+    return T;
+  }
+  // keeps the leading min(rows, m) x min(cols, n) block (dense/DenseMatrix.hpp: resize)
+  void resize(std::size_t m, std::size_t n) {
+    DenseMatrix<scalar_t> T(m, n);
+    for (std::size_t j = 0; j < std::min(cols_, n); j++)
+      for (std::size_t i = 0; i < std::min(rows_, m); i++) T(i, j) = (*this)(i, j);
+    *this = std::move(T);
+  }
+  DenseMatrix<scalar_t>& scale(scalar_t alpha) {
+    for (std::size_t j = 0; j < cols_; j++) for (std::size_t i = 0; i < rows_; i++) (*this)(i, j) *= alpha;
+    return *this;
+  }
+  DenseMatrix<scalar_t>& add(const DenseMatrix<scalar_t>& B) { return scaled_add(scalar_t(1.), B); }
+  DenseMatrix<scalar_t>& sub(const DenseMatrix<scalar_t>& B) { return scaled_add(scalar_t(-1.), B); }
+  // the row interchanges of getrf (1-based LAPACK pivots), applied forwards or backwards (dense/DenseMatrix.cpp:287-297)
+  void laswp(const std::vector<int>& P, bool fwd) {
+    const long long n = (long long)P.size();
+    for (long long q = 0; q < n; q++) {
+      const long long k = fwd ? q : n - 1 - q;
+      const std::size_t p = std::size_t(P[k] - 1);
+      if (p != std::size_t(k))
+        for (std::size_t j = 0; j < cols_; j++) std::swap((*this)(k, j), (*this)(p, j));
+    }
+  }
+  void print_to_file(const std::string& name, const std::string& filename, int width = 8) const {
+    std::ofstream f(filename);
+    f.precision(width + 8);
+    f << name << " = [" << std::endl;
+    for (std::size_t i = 0; i < rows_; i++) { for (std::size_t j = 0; j < cols_; j++) f << (*this)(i, j) << "  "; f << std::endl; }
+    f << "];" << std::endl;
+  }
   void print(const std::string& name = "A") const {
     std::cout << name << " = [  % " << rows_ << "x" << cols_ << ", ld=" << ld_ << std::endl;
     for (std::size_t i = 0; i < rows_; i++) { for (std::size_t j = 0; j < cols_; j++) std::cout << (*this)(i, j) << "  "; std::cout << std::endl; }
@@ -127,6 +193,114 @@ template <typename scalar_t> class DenseMatrixWrapper : public DenseMatrix<scala
 template <typename scalar_t>
 DenseMatrixWrapper<scalar_t> ConstDenseMatrixWrapper(std::size_t m, std::size_t n, const scalar_t* D, std::size_t ld) {
   return DenseMatrixWrapper<scalar_t>(m, n, const_cast<scalar_t*>(D), ld);
+}
+
+// ---- BLAS-shaped free functions on DenseMatrix (dense/DenseMatrix.hpp:1346-1400): C = alpha op(A) op(B) + beta C etc.
+// Host loops (these are the caller-side helpers of tests and examples, not the hot path); a double-precision gemm above
+// ~0.5 GFLOP is carried to the MI355X by the library (strumpack_amd_dense_gemm: batched MFMA GEMM of include/hssk.h).
+extern "C" int strumpack_amd_dense_gemm(char ta, char tb, int m, int n, int k, double alpha, const double* A, int lda,
+                                        const double* B, int ldb, double beta, double* C, int ldc);
+namespace detail {
+template <typename T> inline T conj_if(T v, bool) { return v; }
+template <typename R> inline std::complex<R> conj_if(std::complex<R> v, bool c) { return c ? std::conj(v) : v; }
+template <typename scalar_t> inline scalar_t opel(const DenseMatrix<scalar_t>& A, Trans t, std::size_t i, std::size_t j) {
+  return t == Trans::N ? A(i, j) : conj_if(A(j, i), t == Trans::C);
+}
+template <typename scalar_t>
+void gemm_host(Trans ta, Trans tb, scalar_t alpha, const DenseMatrix<scalar_t>& a, const DenseMatrix<scalar_t>& b, scalar_t beta,
+               DenseMatrix<scalar_t>& c) {
+  const std::size_t m = c.rows(), n = c.cols(), k = ta == Trans::N ? a.cols() : a.rows();
+  for (std::size_t j = 0; j < n; j++) {
+    for (std::size_t i = 0; i < m; i++) c(i, j) = beta == scalar_t(0.) ? scalar_t(0.) : beta * c(i, j);
+    for (std::size_t l = 0; l < k; l++) {
+      const scalar_t blj = alpha * opel(b, tb, l, j);
+      if (blj == scalar_t(0.)) continue;
+      if (ta == Trans::N) for (std::size_t i = 0; i < m; i++) c(i, j) += a(i, l) * blj;
+      else for (std::size_t i = 0; i < m; i++) c(i, j) += opel(a, ta, i, l) * blj;
+    }
+  }
+}
+}  // namespace detail
+template <typename scalar_t>
+void gemm(Trans ta, Trans tb, scalar_t alpha, const DenseMatrix<scalar_t>& a, const DenseMatrix<scalar_t>& b, scalar_t beta,
+          DenseMatrix<scalar_t>& c, int /*depth*/ = 0) {
+  assert((ta == Trans::N ? a.rows() : a.cols()) == c.rows() && (tb == Trans::N ? b.cols() : b.rows()) == c.cols());
+  detail::gemm_host(ta, tb, alpha, a, b, beta, c);
+}
+inline void gemm(Trans ta, Trans tb, double alpha, const DenseMatrix<double>& a, const DenseMatrix<double>& b, double beta,
+                 DenseMatrix<double>& c, int /*depth*/ = 0) {
+  const std::size_t m = c.rows(), n = c.cols(), k = ta == Trans::N ? a.cols() : a.rows();
+  assert((ta == Trans::N ? a.rows() : a.cols()) == m && (tb == Trans::N ? b.cols() : b.rows()) == n);
+  if (2.0 * double(m) * double(n) * double(k) >= 5e8 &&
+      strumpack_amd_dense_gemm(ta == Trans::N ? 'N' : 'T', tb == Trans::N ? 'N' : 'T', int(m), int(n), int(k), alpha, a.data(), a.ld(),
+                               b.data(), b.ld(), beta, c.data(), c.ld()) == 0)
+    return;
+  detail::gemm_host(ta, tb, alpha, a, b, beta, c);
+}
+template <typename scalar_t>
+void gemv(Trans ta, scalar_t alpha, const DenseMatrix<scalar_t>& a, const DenseMatrix<scalar_t>& x, scalar_t beta,
+          DenseMatrix<scalar_t>& y, int /*depth*/ = 0) {
+  detail::gemm_host(ta, Trans::N, alpha, a, x, beta, y);
+}
+// b <- alpha op(a)^{-1} b (Side::L) or alpha b op(a)^{-1} (Side::R), a triangular (dense/DenseMatrix.cpp:1059-1085)
+template <typename scalar_t>
+void trsm(Side s, UpLo ul, Trans ta, Diag d, scalar_t alpha, const DenseMatrix<scalar_t>& a, DenseMatrix<scalar_t>& b, int /*depth*/ = 0) {
+  const std::size_t n = a.rows();
+  // effective triangle of op(a): transposing flips it
+  const bool lower = (ul == UpLo::L) != (ta != Trans::N);
+  auto A = [&](std::size_t i, std::size_t j) { return detail::opel(a, ta, i, j); };
+  b.scale(alpha);
+  if (s == Side::L) {
+    for (std::size_t c = 0; c < b.cols(); c++) {
+      if (lower)
+        for (std::size_t i = 0; i < n; i++) {
+          scalar_t v = b(i, c);
+          for (std::size_t l = 0; l < i; l++) v -= A(i, l) * b(l, c);
+          b(i, c) = d == Diag::U ? v : v / A(i, i);
+        }
+      else
+        for (std::size_t q = n; q-- > 0;) {
+          scalar_t v = b(q, c);
+          for (std::size_t l = q + 1; l < n; l++) v -= A(q, l) * b(l, c);
+          b(q, c) = d == Diag::U ? v : v / A(q, q);
+        }
+    }
+  } else {   // x op(a) = b, row by row: x(r, j) = (b(r, j) - sum_l x(r, l) op(a)(l, j)) / op(a)(j, j)
+    for (std::size_t r = 0; r < b.rows(); r++) {
+      if (lower)   // x(r, j) depends on l > j
+        for (std::size_t j = n; j-- > 0;) {
+          scalar_t v = b(r, j);
+          for (std::size_t l = j + 1; l < n; l++) v -= b(r, l) * A(l, j);
+          b(r, j) = d == Diag::U ? v : v / A(j, j);
+        }
+      else
+        for (std::size_t j = 0; j < n; j++) {
+          scalar_t v = b(r, j);
+          for (std::size_t l = 0; l < j; l++) v -= b(r, l) * A(l, j);
+          b(r, j) = d == Diag::U ? v : v / A(j, j);
+        }
+    }
+  }
+}
+template <typename scalar_t>
+void trsv(UpLo ul, Trans ta, Diag d, const DenseMatrix<scalar_t>& a, DenseMatrix<scalar_t>& b, int depth = 0) {
+  trsm(Side::L, ul, ta, d, scalar_t(1.), a, b, depth);
+}
+template <typename scalar_t> DenseMatrix<scalar_t> vconcat(const DenseMatrix<scalar_t>& a, const DenseMatrix<scalar_t>& b) {
+  assert(a.cols() == b.cols());
+  DenseMatrix<scalar_t> t(a.rows() + b.rows(), a.cols());
+  for (std::size_t j = 0; j < a.cols(); j++) {
+    for (std::size_t i = 0; i < a.rows(); i++) t(i, j) = a(i, j);
+    for (std::size_t i = 0; i < b.rows(); i++) t(a.rows() + i, j) = b(i, j);
+  }
+  return t;
+}
+template <typename scalar_t> DenseMatrix<scalar_t> hconcat(const DenseMatrix<scalar_t>& a, const DenseMatrix<scalar_t>& b) {
+  assert(a.rows() == b.rows());
+  DenseMatrix<scalar_t> t(a.rows(), a.cols() + b.cols());
+  for (std::size_t j = 0; j < a.cols(); j++) for (std::size_t i = 0; i < a.rows(); i++) t(i, j) = a(i, j);
+  for (std::size_t j = 0; j < b.cols(); j++) for (std::size_t i = 0; i < a.rows(); i++) t(i, a.cols() + j) = b(i, j);
+  return t;
 }
 
 }  // namespace strumpack

@@ -22,10 +22,8 @@ EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
   // HARD_RESTART (compress.hpp:235-298): the acceptance rule of ORIGINAL, but a failed round resets every node and the
   // next round recompresses the whole tree on all samples
   e.algorithm = o.compression_algorithm() == CompressionAlgorithm::STABLE ? 1 : (o.compression_algorithm() == CompressionAlgorithm::HARD_RESTART ? 2 : 0);
-  // the engine draws the sketching matrix itself (host generators identical to the reference's, or Philox on the device);
-  // a random matrix filled in by the user's multiplication routine (compress_stable.hpp:126-141) would be ignored
-  if (o.user_defined_random())
-    throw std::invalid_argument("--hss_user_defined_random / set_user_defined_random(true) is not supported: the sketching matrix is drawn by the engine");
+  // (user_defined_random -- the random block filled in by the user's multiplication routine, compress_stable.hpp:126-141 --
+  // only has a meaning for compress(Amult, Aelem), which switches it on; the other constructors never call back for samples)
   e.random_engine = o.random_engine() == random::RandomEngine::LINEAR ? 0 : (o.random_engine() == random::RandomEngine::MERSENNE ? 1 : 2);
   e.random_dist = o.random_distribution() == random::RandomDistribution::NORMAL ? 0 : 1;
   e.sketch = o.compression_sketch() == CompressionSketch::SJLT ? 1 : 0;
@@ -47,6 +45,7 @@ HSSMatrix<double>::HSSMatrix(const structured::ClusterTree& t, const opts_t& opt
 HSSMatrix<double>::~HSSMatrix() {}
 
 void HSSMatrix<double>::write(const std::string& fname) const {
+  owner("write");
   if (!eng_) throw std::invalid_argument("write: empty matrix");
   std::ofstream f(fname, std::ios::out | std::ios::trunc | std::ios::binary);
   if (!f) throw std::runtime_error("write: cannot open " + fname);
@@ -118,6 +117,7 @@ void HSSMatrix<double>::compress_with_neighbors(const kernel::Kernel<double>& K,
 }
 
 void HSSMatrix<double>::make_engine(const opts_t& opts, const structured::ClusterTree* t) {
+  owner("compress");
   EngineOptions e = engine_options(opts);
   if (eng_ && eng_->options().leaf_size == e.leaf_size && eng_->options().device == e.device) {
     const EngineOptions& cur = eng_->options();   // same tree: keep the engine (device context, process group), new knobs
@@ -147,6 +147,7 @@ void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda,
   compress_device_sharded(dA, lda, opts, callback_group(world, rank, fn, user));
 }
 void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda, const opts_t& opts, const CommSpec& pg) {
+  owner("compress");
   EngineOptions e = engine_options(opts);
   pg.apply(e);
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
@@ -154,6 +155,7 @@ void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda,
 }
 void HSSMatrix<double>::compress_device_blocks(const double* dRows, long long ldr, const double* dCols, long long ldc,
                                                const opts_t& opts, const CommSpec& pg) {
+  owner("compress");
   EngineOptions e = engine_options(opts);
   pg.apply(e);
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
@@ -162,6 +164,33 @@ void HSSMatrix<double>::compress_device_blocks(const double* dRows, long long ld
 void HSSMatrix<double>::compress(const mult_t& Amult, const elem_t& Aelem, const opts_t& opts) {
   make_engine(opts, tree_.get());
   const int N = int(rows_);
+  if (opts.user_defined_random()) {
+    struct Flag {   // on for this call only, whatever way it ends
+      DeviceHSS* h;
+      explicit Flag(DeviceHSS* h_) : h(h_) { EngineOptions e = h->options(); e.user_random = true; h->set_options(e); }
+      ~Flag() { EngineOptions e = h->options(); e.user_random = false; h->set_options(e); }
+    } flag(eng_.get());
+    // Amult fills Rr and Rc as well as Sr and Sc (the sparse HSS fronts sample their children this way,
+    // sparse/fronts/FrontHSS.cpp:367-385).  The engine keeps ONE random block for the row and the column samples, as every
+    // caller in the reference does (Rc is a copy of Rr); distinct blocks are refused rather than silently merged.
+    host_sample_t us = [&](int n, int nrhs, double* R, double* Sr, double* Sc) {
+      DenseMW_t Rr(n, nrhs, R, n), Srw(n, nrhs, Sr, n), Scw(n, nrhs, Sc, n);
+      DenseM_t Rc(n, nrhs);
+      Rr.zero();
+      Amult(Rr, Rc, Srw, Scw);
+      for (int j = 0; j < nrhs; j++)
+        for (int i = 0; i < n; i++)
+          if (Rc(i, j) != Rr(i, j)) throw std::invalid_argument("user_defined_random: Rr and Rc must be the same random block");
+    };
+    host_elem_t he0 = [&](int m, const int* I, int n, const int* J, double* B, int ldb) {
+      std::vector<std::size_t> Iv(I, I + m), Jv(J, J + n);
+      DenseM_t Bm(m, n);
+      Aelem(Iv, Jv, Bm);
+      for (int j = 0; j < n; j++) std::memcpy(B + (size_t)j * ldb, Bm.ptr(0, j), sizeof(double) * m);
+    };
+    eng_->compress_callbacks_user_random(us, he0);
+    return;
+  }
   // the reference hands both sample blocks to the user in one call (HSSExtra.hpp:231-239); the
   // engine asks for the two products separately, so cache the pair
   DenseM_t Sr_cache, Sc_cache;
@@ -226,12 +255,30 @@ void HSSMatrix<double>::compress_from_elements(const elem_t& Aelem, const opts_t
   eng_->compress_host_blocks(fill, he);
 }
 
-std::size_t HSSMatrix<double>::memory() const { return eng_ ? std::size_t(eng_->memory()) : 0; }
-std::size_t HSSMatrix<double>::nonzeros() const { return eng_ ? std::size_t(eng_->nonzeros()) : 0; }
-std::size_t HSSMatrix<double>::rank() const { return eng_ ? std::size_t(eng_->rank()) : 0; }
-std::size_t HSSMatrix<double>::levels() const { return eng_ ? std::size_t(eng_->levels()) : 0; }
-bool HSSMatrix<double>::is_compressed() const { return eng_ && eng_->is_compressed(); }
-bool HSSMatrix<double>::leaf() const { return !eng_ || eng_->num_nodes() == 1; }
+std::size_t HSSMatrix<double>::memory() const {
+  if (veng_) return std::size_t(veng_->memory(vnode_));
+  return eng_ ? std::size_t(eng_->memory()) : 0;
+}
+std::size_t HSSMatrix<double>::nonzeros() const {
+  if (veng_) return std::size_t(veng_->nonzeros(vnode_));
+  return eng_ ? std::size_t(eng_->nonzeros()) : 0;
+}
+std::size_t HSSMatrix<double>::rank() const {
+  if (veng_) return std::size_t(veng_->rank(vnode_));
+  return eng_ ? std::size_t(eng_->rank()) : 0;
+}
+std::size_t HSSMatrix<double>::levels() const {
+  if (veng_) return std::size_t(veng_->nodes()[vnode_].height + 1);
+  return eng_ ? std::size_t(eng_->levels()) : 0;
+}
+bool HSSMatrix<double>::is_compressed() const {
+  if (veng_) return veng_->nodes()[vnode_].compressed();
+  return eng_ && eng_->is_compressed();
+}
+bool HSSMatrix<double>::leaf() const {
+  if (veng_) return veng_->nodes()[vnode_].leaf();
+  return !eng_ || eng_->num_nodes() == 1;
+}
 
 void HSSMatrix<double>::mult(Trans op, const DenseM_t& x, DenseM_t& y) const {
   apply_HSS(op, *this, x, 0., y);
@@ -246,16 +293,18 @@ DenseMatrix<double> HSSMatrix<double>::applyC(const DenseM_t& b) const {
   apply_HSS(Trans::C, *this, b, 0., c);
   return c;
 }
-void HSSMatrix<double>::factor() { eng_->factor(); }
+void HSSMatrix<double>::factor() { owner("factor"); eng_->factor(); }
 void HSSMatrix<double>::solve(DenseM_t& b) const {
+  owner("solve");
   if (b.rows() != rows_) throw std::invalid_argument("solve: right-hand side has the wrong number of rows");
   eng_->solve(int(b.cols()), b.data(), b.ld(), false);
 }
-void HSSMatrix<double>::shift(scalar_t sigma) { eng_->shift(sigma); }
+void HSSMatrix<double>::shift(scalar_t sigma) { owner("shift"); eng_->shift(sigma); }
 void HSSMatrix<double>::mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta) const {
-  eng_->mult(op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);
+  if (veng_) veng_->mult_node(vnode_, op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);
+  else eng_->mult(op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);
 }
-void HSSMatrix<double>::solve_device(int nrhs, double* db, long long ldb) const { eng_->solve(nrhs, db, ldb, true); }
+void HSSMatrix<double>::solve_device(int nrhs, double* db, long long ldb) const { owner("solve"); eng_->solve(nrhs, db, ldb, true); }
 
 DenseMatrix<double> HSSMatrix<double>::dense() const {
   // H * I in column blocks (HSSMatrix.cpp:188-260 re-expands recursively; test-only, O(N^2 r))
@@ -266,7 +315,7 @@ DenseMatrix<double> HSSMatrix<double>::dense() const {
     DenseM_t E(cols_, nb);
     for (std::size_t j = 0; j < nb; j++) E(j0 + j, j) = 1.;
     DenseMW_t Dj(rows_, nb, D, 0, j0);
-    eng_->mult('N', int(nb), E.data(), E.ld(), Dj.data(), Dj.ld(), false, 0.);
+    apply_HSS(Trans::N, *this, E, 0., Dj);
   }
   return D;
 }
@@ -277,7 +326,7 @@ DenseMatrix<double> HSSMatrix<double>::extract(const std::vector<std::size_t>& I
     if (J[j] >= cols_) throw std::invalid_argument("extract: column index out of range");
     E(J[j], j) = 1.;
   }
-  if (!J.empty()) eng_->mult('N', int(J.size()), E.data(), E.ld(), HE.data(), HE.ld(), false, 0.);
+  if (!J.empty()) apply_HSS(Trans::N, *this, E, 0., HE);
   for (std::size_t j = 0; j < J.size(); j++)
     for (std::size_t i = 0; i < I.size(); i++) {
       if (I[i] >= rows_) throw std::invalid_argument("extract: row index out of range");
@@ -294,8 +343,9 @@ void HSSMatrix<double>::extract_add(const std::vector<std::size_t>& I, const std
 }
 
 // ---- Schur complement of the (0,0) block (HSSMatrix.Schur.hpp) ----------------------------------------------
-void HSSMatrix<double>::partial_factor() { eng_->partial_factor(); }
+void HSSMatrix<double>::partial_factor() { owner("partial_factor"); eng_->partial_factor(); }
 void HSSMatrix<double>::Schur_update(DenseM_t& Theta, DenseM_t& DUB01, DenseM_t& Phi) const {
+  owner("Schur_update");
   if (leaf()) return;
   const auto d = eng_->schur_dims();
   Theta = DenseM_t(d.n1, d.rV0);
@@ -304,6 +354,7 @@ void HSSMatrix<double>::Schur_update(DenseM_t& Theta, DenseM_t& DUB01, DenseM_t&
   eng_->schur_update(Theta.data(), Theta.ld(), DUB01.data(), DUB01.ld(), Phi.data(), Phi.ld(), nullptr, 1);
 }
 DenseMatrix<double> HSSMatrix<double>::Vhat() const {
+  owner("Vhat");
   if (leaf() || !eng_->is_partially_factored()) throw std::logic_error("Vhat: partial_factor() has not been called");
   const auto d = eng_->schur_dims();
   DenseM_t V(d.mu0, d.rV0);
@@ -315,6 +366,7 @@ DenseMatrix<double> HSSMatrix<double>::Vhat() const {
 }
 void HSSMatrix<double>::Schur_product_direct(const DenseM_t& Theta, const DenseM_t& DUB01, const DenseM_t& Phi,
                                              const DenseM_t&, const DenseM_t& R, DenseM_t& Sr, DenseM_t& Sc) const {
+  owner("Schur_product_direct");
   const auto d = eng_->schur_dims();
   if (Theta.rows() != std::size_t(d.n1) || Theta.cols() != std::size_t(d.rV0) || DUB01.rows() != std::size_t(d.mu0) ||
       DUB01.cols() != std::size_t(d.rV1) || Phi.rows() != std::size_t(d.n1) || Phi.cols() != std::size_t(d.mu0))
@@ -326,6 +378,7 @@ void HSSMatrix<double>::Schur_product_direct(const DenseM_t& Theta, const DenseM
 }
 void HSSMatrix<double>::Schur_product_indirect(const DenseM_t& DUB01, const DenseM_t& R0, const DenseM_t& R1,
                                                const DenseM_t& Sr1, const DenseM_t& Sc1, DenseM_t& Sr, DenseM_t& Sc) const {
+  owner("Schur_product_indirect");
   if (leaf()) return;
   const auto d = eng_->schur_dims();
   if (DUB01.rows() != std::size_t(d.mu0) || DUB01.cols() != std::size_t(d.rV1))
@@ -339,6 +392,7 @@ void HSSMatrix<double>::Schur_product_indirect(const DenseM_t& DUB01, const Dens
                                Sc1.ld(), Sr.data(), Sr.ld(), Sc.data(), Sc.ld(), false);
 }
 DenseMatrix<double> HSSMatrix<double>::apply_child(int c, Trans op, const DenseM_t& x) const {
+  owner("apply_child");
   if (leaf()) throw std::logic_error("apply_child: the matrix is a single leaf");
   const auto d = eng_->schur_dims();
   const std::size_t n = c == 0 ? d.n0 : d.n1;
@@ -349,75 +403,29 @@ DenseMatrix<double> HSSMatrix<double>::apply_child(int c, Trans op, const DenseM
 }
 
 // ---- child views (HSS/HSSMatrix.hpp:194-202) ----------------------------------------------------------------
-const HSSMatrixChild* HSSMatrix<double>::child(int c) const {
+HSSMatrix<double>::HSSMatrix(DeviceHSS* parent_engine, int node) : veng_(parent_engine), vnode_(node) {
+  if (!parent_engine || node < 0 || node >= parent_engine->num_nodes()) throw std::invalid_argument("HSSMatrix view: no such node");
+  rows_ = cols_ = parent_engine->nodes()[node].m;
+}
+const HSSMatrix<double>* HSSMatrix<double>::child(int c) const {
   if (leaf()) throw std::logic_error("child: the matrix is a leaf");
   if (c != 0 && c != 1) throw std::invalid_argument("child: c must be 0 or 1");
-  const auto& root = eng_->nodes()[0];
+  DeviceHSS* e = engine();
+  const auto& root = e->nodes()[vnode_];
   const int id = c == 0 ? root.c0 : root.c1;
-  if (!ch_[c] || ch_[c]->node() != id || ch_[c]->engine() != eng_.get()) ch_[c].reset(new HSSMatrixChild(eng_.get(), id));
+  if (!ch_[c] || ch_[c]->vnode_ != id || ch_[c]->veng_ != e) ch_[c].reset(new HSSMatrix<double>(e, id));
   return ch_[c].get();
 }
-const HSSMatrixChild* HSSMatrixChild::child(int c) const {
-  if (leaf()) throw std::logic_error("child: the matrix is a leaf");
-  if (c != 0 && c != 1) throw std::invalid_argument("child: c must be 0 or 1");
-  const int id = c == 0 ? nd().c0 : nd().c1;
-  if (!ch_[c]) ch_[c].reset(new HSSMatrixChild(eng_, id));
-  return ch_[c].get();
-}
-void HSSMatrixChild::mult(Trans op, const DenseM_t& x, DenseM_t& y) const {
-  if (x.rows() != rows() || y.rows() != rows() || x.cols() != y.cols()) throw std::invalid_argument("mult: dimension mismatch");
-  eng_->mult_node(node_, op == Trans::N ? 'N' : 'C', int(x.cols()), x.data(), x.ld(), y.data(), y.ld(), false);
-}
-DenseMatrix<double> HSSMatrixChild::apply(const DenseM_t& b) const {
-  DenseM_t c(rows(), b.cols());
-  mult(Trans::N, b, c);
-  return c;
-}
-DenseMatrix<double> HSSMatrixChild::applyC(const DenseM_t& b) const {
-  DenseM_t c(rows(), b.cols());
-  mult(Trans::C, b, c);
-  return c;
-}
-DenseMatrix<double> HSSMatrixChild::dense() const {
-  const std::size_t n = rows(), bs = 256;
-  DenseM_t D(n, n);
-  for (std::size_t j0 = 0; j0 < n; j0 += bs) {
-    const std::size_t nb = std::min(bs, n - j0);
-    DenseM_t E(n, nb);
-    for (std::size_t j = 0; j < nb; j++) E(j0 + j, j) = 1.;
-    DenseMatrixWrapper<double> Dj(n, nb, D, 0, j0);
-    eng_->mult_node(node_, 'N', int(nb), E.data(), E.ld(), Dj.data(), Dj.ld(), false);
-  }
-  return D;
-}
-DenseMatrix<double> HSSMatrixChild::extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const {
-  const std::size_t n = rows();
-  DenseM_t E(n, J.size()), HE(n, J.size()), B(I.size(), J.size());
-  for (std::size_t j = 0; j < J.size(); j++) {
-    if (J[j] >= n) throw std::invalid_argument("extract: column index out of range");
-    E(J[j], j) = 1.;
-  }
-  if (!J.empty()) eng_->mult_node(node_, 'N', int(J.size()), E.data(), E.ld(), HE.data(), HE.ld(), false);
-  for (std::size_t j = 0; j < J.size(); j++)
-    for (std::size_t i = 0; i < I.size(); i++) {
-      if (I[i] >= n) throw std::invalid_argument("extract: row index out of range");
-      B(i, j) = HE(I[i], j);
-    }
-  return B;
-}
-void HSSMatrixChild::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
-  const int lo0 = nd().lo;
-  for (int i = node_, e = eng_->node_end(node_); i < e; i++) {
-    const auto& n = eng_->nodes()[i];
-    out << "SEQ rank=0 b = [" << roff + n.lo - lo0 << "," << roff + n.lo - lo0 + n.m << " x " << coff + n.lo - lo0 << ","
-        << coff + n.lo - lo0 + n.m << "]  U = " << n.mU << " x " << n.rU << " V = " << n.mV << " x " << n.rV
-        << (n.leaf() ? " leaf" : " non-leaf") << std::endl;
-  }
-}
-DenseMatrix<double> HSSMatrixChild::Factors::Vhat() const {
-  DeviceHSS* eng = self->eng_;
+HSSMatrix<double>* HSSMatrix<double>::child(int c) { return const_cast<HSSMatrix<double>*>(static_cast<const HSSMatrix<double>*>(this)->child(c)); }
+std::size_t HSSMatrix<double>::U_rank() const { return engine() ? engine()->nodes()[vnode_].rU : 0; }
+std::size_t HSSMatrix<double>::V_rank() const { return engine() ? engine()->nodes()[vnode_].rV : 0; }
+std::size_t HSSMatrix<double>::U_rows() const { return engine() && engine()->nodes()[vnode_].lvl ? engine()->nodes()[vnode_].mU : 0; }
+std::size_t HSSMatrix<double>::V_rows() const { return engine() && engine()->nodes()[vnode_].lvl ? engine()->nodes()[vnode_].mV : 0; }
+DenseMatrix<double> HSSMatrix<double>::Factors::Vhat() const {
+  DeviceHSS* eng = self->engine();
+  if (!eng) throw std::logic_error("Vhat: empty matrix");
   const auto& root = eng->nodes()[0];
-  if (root.leaf() || self->node_ != root.c0 || !eng->is_partially_factored())
+  if (root.leaf() || self->vnode_ != root.c0 || !eng->is_partially_factored())
     throw std::logic_error("Vhat: only child(0) carries it, after partial_factor()");
   const auto d = eng->schur_dims();
   DenseM_t V(d.mu0, d.rV0);
@@ -429,10 +437,13 @@ DenseMatrix<double> HSSMatrixChild::Factors::Vhat() const {
 }
 
 void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::size_t coff) const {
-  if (!eng_) return;
-  for (auto& nd : eng_->nodes()) {  // pre-order, same line format as HSSMatrix.cpp:344-350
-    out << "SEQ rank=0 b = [" << roff + nd.lo << "," << roff + nd.lo + nd.m << " x " << coff + nd.lo << ","
-        << coff + nd.lo + nd.m << "]  U = " << (nd.lvl ? nd.mU : 0) << " x " << nd.rU << " V = "
+  const DeviceHSS* e = engine();
+  if (!e) return;
+  const int lo0 = e->nodes()[vnode_].lo;
+  for (int i = vnode_, end = e->node_end(vnode_); i < end; i++) {  // pre-order, same line format as HSSMatrix.cpp:344-350
+    const auto& nd = e->nodes()[i];
+    out << "SEQ rank=0 b = [" << roff + nd.lo - lo0 << "," << roff + nd.lo - lo0 + nd.m << " x " << coff + nd.lo - lo0 << ","
+        << coff + nd.lo - lo0 + nd.m << "]  U = " << (nd.lvl ? nd.mU : 0) << " x " << nd.rU << " V = "
         << (nd.lvl ? nd.mV : 0) << " x " << nd.rV << (nd.leaf() ? " leaf" : " non-leaf") << std::endl;
   }
 }
@@ -440,7 +451,8 @@ void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::siz
 void apply_HSS(Trans op, const HSSMatrix<double>& A, const DenseMatrix<double>& B, double beta, DenseMatrix<double>& C) {
   if (B.rows() != A.rows() || C.rows() != A.rows() || B.cols() != C.cols())
     throw std::invalid_argument("apply_HSS: dimension mismatch");
-  A.engine()->mult(op == Trans::N ? 'N' : 'C', int(B.cols()), B.data(), B.ld(), C.data(), C.ld(), false, beta);
+  if (A.is_view()) A.engine()->mult_node(A.node(), op == Trans::N ? 'N' : 'C', int(B.cols()), B.data(), B.ld(), C.data(), C.ld(), false, beta);
+  else A.engine()->mult(op == Trans::N ? 'N' : 'C', int(B.cols()), B.data(), B.ld(), C.data(), C.ld(), false, beta);
 }
 
 }  // namespace HSS

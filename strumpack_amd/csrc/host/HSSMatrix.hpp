@@ -17,53 +17,6 @@ namespace HSS {
 
 template <typename scalar_t> class HSSMatrix;
 
-// HSSMatrix::child(c) (HSS/HSSMatrix.hpp:194-202): "a child of an HSS matrix is itself an HSS matrix".  Here a child is
-// a read-only view of a node of the parent's device-resident tree: the introspection and apply calls of the
-// reference's HSSMatrix on the diagonal block of that node, children of children included.  Views stay valid as long
-// as the parent is neither destroyed nor re-compressed.
-class HSSMatrixChild {
-  using DenseM_t = DenseMatrix<double>;
-
- public:
-  HSSMatrixChild(DeviceHSS* eng, int node) : eng_(eng), node_(node) {}
-  std::size_t rows() const { return nd().m; }
-  std::size_t cols() const { return nd().m; }
-  std::pair<std::size_t, std::size_t> dims() const { return {rows(), cols()}; }
-  bool leaf() const { return nd().leaf(); }
-  bool is_compressed() const { return nd().compressed(); }
-  std::size_t levels() const { return nd().height + 1; }
-  std::size_t rank() const { return eng_->rank(node_); }
-  std::size_t memory() const { return eng_->memory(node_); }
-  std::size_t nonzeros() const { return eng_->nonzeros(node_); }
-  // the node's own bases (HSSMatrixBase.hpp:346-349)
-  std::size_t U_rank() const { return nd().rU; }
-  std::size_t V_rank() const { return nd().rV; }
-  std::size_t U_rows() const { return nd().mU; }
-  std::size_t V_rows() const { return nd().mV; }
-  const HSSMatrixChild* child(int c) const;
-  void mult(Trans op, const DenseM_t& x, DenseM_t& y) const;
-  DenseM_t apply(const DenseM_t& b) const;
-  DenseM_t applyC(const DenseM_t& b) const;
-  DenseM_t dense() const;
-  DenseM_t extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const;
-  double get(std::size_t i, std::size_t j) const { return extract({i}, {j})(0, 0); }
-  void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
-  // child(0)->ULV().Vhat() after partial_factor() (HSSExtra.hpp:191, sparse/fronts/FrontHSS.cpp:395)
-  struct Factors {
-    const HSSMatrixChild* self;
-    DenseM_t Vhat() const;
-  };
-  Factors ULV() const { return Factors{this}; }
-  int node() const { return node_; }
-  const DeviceHSS* engine() const { return eng_; }
-
- private:
-  const DeviceHSS::Node& nd() const { return eng_->nodes()[node_]; }
-  DeviceHSS* eng_;
-  int node_;
-  mutable std::unique_ptr<HSSMatrixChild> ch_[2];
-};
-
 template <> class HSSMatrix<double> : public structured::StructuredMatrix<double> {
   using scalar_t = double;
   using DenseM_t = DenseMatrix<scalar_t>;
@@ -76,6 +29,12 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   using elem_t = std::function<void(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseM_t& B)>;
 
   HSSMatrix() {}
+  // HSSMatrix::child(c) (HSS/HSSMatrix.hpp:194-202): "a child of an HSS matrix is itself an HSS matrix".  Here a child is
+  // an HSSMatrix that VIEWS a node of its parent's device-resident tree: introspection, mult / apply / applyC, dense,
+  // extract / get, print_info and child() of the view work on the diagonal block of that node; compressing, factoring or
+  // solving with a child on its own is not offered (logic_error) -- the ULV factors belong to the whole tree.  Views stay
+  // valid as long as the parent is neither destroyed nor re-compressed.
+  HSSMatrix(DeviceHSS* parent_engine, int node);
   // compress the dense matrix A (HSS/HSSMatrix.cpp:50-54)
   HSSMatrix(const DenseM_t& A, const opts_t& opts) : HSSMatrix(A.rows(), A.cols(), opts) { compress(A, opts); }
   // uncompressed m x n HSS matrix with the bisection tree (HSSMatrix.cpp:56-70)
@@ -157,8 +116,23 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
                               const DenseM_t& Sc1, DenseM_t& Sr, DenseM_t& Sc) const;
   // y = op(H_cc) x with H_cc the diagonal block of child c (child(c)->apply / applyC, HSSMatrix.hpp:194-202)
   DenseM_t apply_child(int c, Trans op, const DenseM_t& x) const;
-  // read-only view of child c (0 or 1; the matrix must not be a leaf), children of children through the view
-  const HSSMatrixChild* child(int c) const;
+  // child c (0 or 1; the matrix must not be a leaf) as an HSS matrix that views this one's tree (see the view constructor)
+  const HSSMatrix<double>* child(int c) const;
+  HSSMatrix<double>* child(int c);
+  // the root node's own bases (HSSMatrixBase.hpp:346-349): zero for a root, the node's ranks for a child
+  std::size_t U_rank() const;
+  std::size_t V_rank() const;
+  std::size_t U_rows() const;
+  std::size_t V_rows() const;
+  std::pair<std::size_t, std::size_t> dims() const { return {rows(), cols()}; }
+  // ULV().Vhat() (HSSExtra.hpp:191): on child(0) after the parent's partial_factor() (sparse/fronts/FrontHSS.cpp:395)
+  struct Factors {
+    const HSSMatrix<double>* self;
+    DenseM_t Vhat() const;
+  };
+  Factors ULV() const { return Factors{this}; }
+  bool is_view() const { return veng_ != nullptr; }
+  int node() const { return vnode_; }
   void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
   // binary file with the compressed representation (tree, D, B, bases; not the ULV factors) and back
   // (HSSMatrix.cpp:438-510; the file layout is this library's own, see hss_io.cpp)
@@ -171,7 +145,7 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   void mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta = 0.) const;
   void solve_device(int nrhs, double* db, long long ldb) const;
 
-  DeviceHSS* engine() const { return eng_.get(); }
+  DeviceHSS* engine() const { return eng_ ? eng_.get() : veng_; }
   static EngineOptions engine_options(const opts_t& opts);
 
  private:
@@ -179,7 +153,10 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   std::size_t rows_ = 0, cols_ = 0;
   std::unique_ptr<structured::ClusterTree> tree_;
   mutable std::unique_ptr<DeviceHSS> eng_;
-  mutable std::unique_ptr<HSSMatrixChild> ch_[2];
+  DeviceHSS* veng_ = nullptr;   // view: the parent's engine ...
+  int vnode_ = 0;               // ... and the node this matrix is rooted at (0: the whole tree)
+  void owner(const char* what) const { if (veng_) throw std::logic_error(std::string(what) + ": not offered on a child view (the operation belongs to the whole HSS tree)"); }
+  mutable std::unique_ptr<HSSMatrix<double>> ch_[2];
 };
 
 // y = op(H) x + beta y   (HSS/HSSMatrix.hpp:720, HSSMatrix.cpp:419-435)

@@ -79,6 +79,7 @@ void DeviceHSS::compress(Source& src) {
 }
 
 void DeviceHSS::fill_random(int r0, int dn) {
+  if (o_.user_random) { sj_pat_ = nullptr; return; }   // the source's sample() delivers the random block with the products
   double t0 = now();
   const long long N = n_;
   sj_pat_ = nullptr;

@@ -36,6 +36,9 @@ struct EngineOptions {
   // sketching matrix: 0 Gaussian (the distribution above), 1 SJLT = nnz entries +-1 per row (HSSMatrix.sketch.hpp);
   // sjlt_algo 0 chunk / 1 perm; nnz0 nonzeros per row in the first d0 + dd columns, nnz in every further dd
   int sketch = 0, sjlt_algo = 0, nnz0 = 4, nnz = 4;
+  // the caller's multiplication routine also FILLS the random block (HSSOptions::user_defined_random,
+  // HSSMatrix.compress_stable.hpp:110-141; sparse/fronts/FrontHSS.cpp:383-385): nothing is drawn here
+  bool user_random = false;
   bool verbose = false;
   int device = 0;
   // multi-GPU (one process per GPU): `allgather` is an in-place all-gather of a DEVICE buffer of
@@ -65,6 +68,8 @@ struct CommSpec {
 
 // host callbacks of the matrix-free / element interfaces (column-major host buffers)
 using host_mult_t = std::function<void(char trans, int n, int nrhs, const double* R, int ldr, double* S, int lds)>;
+// user_random: one call per sampling round; the callee fills R (n x nrhs, the random block: Rr == Rc) and both products
+using host_sample_t = std::function<void(int n, int nrhs, double* R, double* Sr, double* Sc)>;
 using host_elem_t = std::function<void(int m, const int* I, int n, const int* J, double* B, int ldb)>;
 class DeviceHSS;
 
@@ -110,6 +115,7 @@ class DeviceHSS {
   // rows / columns [lo, hi) owned by `rank` (its subtree below the cut); false if the tree cannot be cut for this world size
   bool shard_range(int rank, int& lo, int& hi) const;
   void compress_callbacks(const host_mult_t& mult, const host_elem_t& elem);  // matrix-free
+  void compress_callbacks_user_random(const host_sample_t& sample, const host_elem_t& elem);
   // kernel matrix over points X (host, d x n, already in tree order); user_ann (k x n, optional) replaces the
   // device nearest-neighbour search of the first round (tests pin the compression against the reference's lists)
   struct KernelSpec {
@@ -157,7 +163,8 @@ class DeviceHSS {
   // rows of the (c)-th child's sub-matrix applied to x: y = op(H_cc) x  (child(c)->apply)
   void mult_child(int c, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device);
   // the same for the sub-matrix rooted at any node of the pre-order table (HSSMatrix::child(c)->child(c')...)
-  void mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device);
+  void mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device,
+                 double beta = 0.0);
   int node_end(int node) const { return subtree_end(node); }   // pre-order ids of the sub-tree: [node, node_end)
   int rank(int node) const;
   long long memory(int node) const;

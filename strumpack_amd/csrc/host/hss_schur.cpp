@@ -32,10 +32,10 @@ void DeviceHSS::mult_child(int c, char trans, int nrhs, const double* x, long lo
 }
 
 void DeviceHSS::mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
-                          bool on_device) {
+                          bool on_device, double beta) {
   OpGuard op_guard(op_mu_);
   if (node < 0 || node >= (int)nodes_.size()) throw std::invalid_argument("mult_node: no such node");
-  mult_sub(node, trans, nrhs, x, ldx, y, ldy, on_device, 0.0);
+  mult_sub(node, trans, nrhs, x, ldx, y, ldy, on_device, beta);
 }
 
 void DeviceHSS::basis_up(int sr, bool useU, const double* dA, long long lda, int c, double* dOut, int ldout, Arena& wk) {

@@ -332,11 +332,30 @@ struct DeviceHSS::HostBlockSource : DeviceHSS::Source {
 };
 
 struct DeviceHSS::CallbackSource : DeviceHSS::Source {
-  const host_mult_t& mult;
+  const host_mult_t* mult;
+  const host_sample_t* usample = nullptr;   // user_defined_random: the callee fills the random block as well
   const host_elem_t& elem;
-  CallbackSource(const host_mult_t& m, const host_elem_t& e) : mult(m), elem(e) {}
+  CallbackSource(const host_mult_t& m, const host_elem_t& e) : mult(&m), elem(e) {}
+  CallbackSource(const host_sample_t& s, const host_elem_t& e) : mult(nullptr), usample(&s), elem(e) {}
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.o_.world > 1) throw std::invalid_argument("the host-callback interface is single-GPU");
+    if (usample) {
+      // compress_stable.hpp:126-141 with user_defined_random: Amult(Rr_new, Rc_new, Sr_new, Sc_new) fills all four blocks
+      const int N = H.n_;
+      if (N == 0 || dn == 0) return;
+      std::vector<double> R((size_t)N * dn), Sr((size_t)N * dn), Sc((size_t)N * dn);
+      (*usample)(N, dn, R.data(), Sr.data(), Sc.data());
+      double* dT = H.tmp_->dbl((size_t)N * dn);
+      const double* src[3] = {R.data(), Sr.data(), Sc.data()};
+      double* dst[3] = {H.Rt_ + r0, H.Srt_ + r0, H.Sct_ + r0};
+      for (int q = 0; q < 3; q++) {
+        ck(hssk_memcpy_h2d(H.ctx_, dT, src[q], (long long)(sizeof(double) * (size_t)N * dn)));
+        hssk_transpose_desc b{dT, dst[q], N, dn, N, H.dcap_};
+        ck(hssk_transpose(H.ctx_, &b, 1));
+        ck(hssk_sync(H.ctx_));   // dT is reused
+      }
+      return;
+    }
     // The user multiplies column-major N x dn blocks (AFunctor / Amult of the reference, HSSExtra.hpp:231-239); the
     // samples live transposed on the device (dn x N rows of Rt / Srt / Sct).  The transposes run on the device; the host
     // sees contiguous blocks only.
@@ -348,7 +367,7 @@ struct DeviceHSS::CallbackSource : DeviceHSS::Source {
     ck(hssk_transpose(H.ctx_, &t, 1));
     ck(hssk_memcpy_d2h(H.ctx_, R.data(), dT, (long long)(sizeof(double) * R.size())));   // (synchronous)
     for (int pass = 0; pass < 2; pass++) {
-      mult(pass == 0 ? 'N' : 'C', N, dn, R.data(), N, S.data(), N);
+      (*mult)(pass == 0 ? 'N' : 'C', N, dn, R.data(), N, S.data(), N);
       ck(hssk_memcpy_h2d(H.ctx_, dT, S.data(), (long long)(sizeof(double) * S.size())));
       hssk_transpose_desc b{dT, (pass == 0 ? H.Srt_ : H.Sct_) + r0, N, dn, N, H.dcap_};
       ck(hssk_transpose(H.ctx_, &b, 1));
@@ -399,6 +418,11 @@ bool DeviceHSS::shard_range(int rank, int& lo, int& hi) const {
   lo = nodes_[cut_nodes_[rank]].lo;
   hi = lo + nodes_[cut_nodes_[rank]].m;
   return true;
+}
+void DeviceHSS::compress_callbacks_user_random(const host_sample_t& sample, const host_elem_t& elem) {
+  if (!o_.user_random) throw std::logic_error("compress_callbacks_user_random: the engine was not built with user_random");
+  CallbackSource s(sample, elem);
+  compress(s);
 }
 void DeviceHSS::compress_callbacks(const host_mult_t& mult, const host_elem_t& elem) {
   CallbackSource s(mult, elem);

@@ -201,6 +201,38 @@ int main(int argc, char* argv[]) {
     std::cout << "# matrix-free: rank " << Hf.rank() << ", relative error = " << Hfd.normF() / A.normF() << std::endl;
     if (Hfd.normF() / A.normF() > tol) { std::cout << "ERROR: matrix-free compression error too big!!" << std::endl; return 1; }
     if (std::abs(double(Hf.rank()) - double(H.rank())) > 1) { std::cout << "ERROR: matrix-free rank differs!!" << std::endl; return 1; }
+    // user_defined_random (HSSOptions.hpp:289, compress_stable.hpp:110-141; the sparse HSS fronts' indirect sampling,
+    // sparse/fronts/FrontHSS.cpp:383-385): the multiplication routine ALSO fills the random block.  Filled with the
+    // reference's default stream, the compression retraces the one above (same ranks); SJLT would draw its own pattern
+    if (hss_opts.compression_sketch() == CompressionSketch::GAUSSIAN) {
+      auto uo = hss_opts;
+      uo.set_user_defined_random(true);
+      std::minstd_rand eng(0);
+      std::normal_distribution<double> nd;
+      int calls = 0;
+      HSSMatrix<double>::mult_t Umult = [&](DenseMatrix<double>& Rr, DenseMatrix<double>& Rc, DenseMatrix<double>& Sr, DenseMatrix<double>& Sc) {
+        calls++;
+        for (std::size_t c = 0; c < Rr.cols(); c++)
+          for (int i = 0; i < m; i++) Rr(i, c) = nd(eng);
+        Rc.copy(Rr);
+        Amult(Rr, Rc, Sr, Sc);
+      };
+      HSSMatrix<double> Hu(m, m, uo);
+      Hu.compress(Umult, Aelem, uo);
+      if (!Hu.is_compressed() || calls == 0) { std::cout << "# user-random compression failed!!!!!!!!" << std::endl; return 1; }
+      auto Hud = Hu.dense();
+      Hud.scaled_add(-1., A);
+      std::cout << "# user-defined random: rank " << Hu.rank() << ", relative error = " << Hud.normF() / A.normF() << std::endl;
+      if (Hud.normF() / A.normF() > tol) { std::cout << "ERROR: user-random compression error too big!!" << std::endl; return 1; }
+      if (hss_opts.random_engine() == random::RandomEngine::LINEAR && Hu.rank() != Hf.rank()) { std::cout << "ERROR: user-random rank differs!!" << std::endl; return 1; }
+      // distinct Rr / Rc are refused, not silently merged
+      HSSMatrix<double>::mult_t Bad = [&](DenseMatrix<double>& Rr, DenseMatrix<double>& Rc, DenseMatrix<double>& Sr, DenseMatrix<double>& Sc) {
+        Rr.fill(1.); Rc.fill(2.); Sr.zero(); Sc.zero();
+      };
+      bool refused = false;
+      try { HSSMatrix<double> Hb(m, m, uo); Hb.compress(Bad, Aelem, uo); } catch (const std::invalid_argument&) { refused = true; }
+      if (!refused) { std::cout << "ERROR: distinct Rr / Rc accepted" << std::endl; return 1; }
+    }
   }
 
   std::cout << "# exiting" << std::endl;

@@ -113,3 +113,80 @@ def test_write_read_round_trip_gpu(tmp_path_factory):
     exe = build(os.path.dirname(_loader.lib_path()), "strumpack_amd", str(d / "wr"), WR_SRC)
     r = subprocess.run([exe, "3000", str(d / "h.bin")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
+
+
+# ---- the reference's OWN drivers, compiled unmodified from where they lie (build container only: /root/reference does not
+# exist on the GPU box) against include/{dense,HSS,structured,kernel,misc}/*.hpp and linked with the emulator library ----
+REF = "/root/reference"
+REF_LINES = [
+    "T 1000",
+    "T 200 --hss_leaf_size 128 --hss_rel_tol 1 --hss_abs_tol 1e-10 --hss_disable_sync --hss_compression_algorithm stable --hss_d0 128 --hss_dd 8",
+    "L 300 --hss_leaf_size 16 --hss_rel_tol 1e-10 --hss_abs_tol 1e-10 --hss_compression_algorithm original --hss_d0 128 --hss_dd 8",
+    "U 500 --hss_leaf_size 32 --hss_rel_tol 1e-5 --hss_abs_tol 1e-10 --hss_enable_sync --hss_compression_algorithm stable --hss_d0 16 --hss_dd 8",
+]
+
+
+def build_ref(src, out, libdir, libname):
+    cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+           "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+@pytest.fixture(scope="module")
+def ref_exe(tmp_path_factory):
+    if not os.path.exists(os.path.join(REF, "test", "test_HSS_seq.cpp")):
+        pytest.skip("the reference tree is only present in the build container")
+    import emu_lib
+    emu_lib.build()
+    return build_ref(os.path.join(REF, "test", "test_HSS_seq.cpp"), str(tmp_path_factory.mktemp("cpp") / "ref_test_HSS_seq"),
+                     os.path.dirname(emu_lib.PATH), "strumpack_amd_emu")
+
+
+@pytest.mark.parametrize("line", REF_LINES)
+def test_reference_own_driver_unmodified(ref_exe, line):
+    """/root/reference/test/test_HSS_seq.cpp itself -- HSSMatrix(A, opts), child(c)->apply, apply_HSS on a child, get, extract,
+    DenseMatrix::extract, free gemm, factor / solve, partial_factor / Schur_update -- with its own pass criteria"""
+    run(ref_exe, line)
+
+
+def test_reference_kernel_regression_example_unmodified(tmp_path_factory):
+    """/root/reference/examples/dense/KernelRegression.cpp itself on a prefix of its shipped data set"""
+    src = os.path.join(REF, "examples", "dense", "KernelRegression.cpp")
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is only present in the build container")
+    import emu_lib
+    emu_lib.build()
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build_ref(src, str(d / "ref_krr"), os.path.dirname(emu_lib.PATH), "strumpack_amd_emu")
+    for part, cnt in (("train", 300), ("train_label", 300), ("test", 100), ("test_label", 100)):
+        with open(KRR_DATA + "_%s.csv" % part) as f, open(str(d / ("s_%s.csv" % part)), "w") as g:
+            g.writelines(f.readlines()[:cnt])
+    r = subprocess.run([exe, str(d / "s"), "8", "1.3", "3.11", "1", "Gauss", "test", "--hss_leaf_size", "64", "--hss_quiet"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    score = [ln for ln in r.stdout.splitlines() if "prediction score" in ln]
+    assert score and float(score[0].split(":")[1].strip().rstrip("%")) >= 70.0, r.stdout[-500:]
+
+
+BLRF_SRC = os.path.join(ROOT, "tests", "cpp", "test_BLR_front.cpp")
+
+
+def test_blr_front_cpp_emulator(tmp_path_factory):
+    """BLRMatrix<double>::construct_and_partial_factor / trsmLNU_gemm / gemm_trsmUNN with the reference's signatures, driven
+    as sparse/fronts/FrontBLR.cpp drives them"""
+    import emu_lib
+    emu_lib.build()
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build_ref(BLRF_SRC, str(d / "blr_front_emu"), os.path.dirname(emu_lib.PATH), "strumpack_amd_emu")
+    r = subprocess.run([exe, "96", "16"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_blr_front_cpp_gpu(tmp_path_factory):
+    from strumpack_amd import _loader
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build_ref(BLRF_SRC, str(d / "blr_front"), os.path.dirname(_loader.lib_path()), "strumpack_amd")
+    r = subprocess.run([exe, "1500", "128"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
