@@ -96,6 +96,58 @@ void* ref_hss_create(int n, const double* A, int lda, double rel_tol, double abs
   return r;
 }
 
+// The Toeplitz matrix T(n) of test_HSS_seq.cpp:75-78 WITHOUT storing it: HSSMatrix(n, n, opts) + compress(Amult, Aelem, opts)
+// (HSS/HSSMatrix.cpp:173-186; the route structured::construct_partially_matrix_free takes, structured/StructuredMatrix.cpp:
+// 637-651) -- BASELINE configs[2] (N = 100000) needs 80 GB as a dense operand, this needs N x d buffers.  The products
+// Sr = T Rr, Sc = T^T Rc are formed tile by tile (tiles generated on the fly, dgemm per tile), O(N^2 d) like the dense route;
+// the random blocks come from the same default generator, so the compression is the one HSSMatrix(A, opts) performs.
+void* ref_hss_create_toeplitz_matfree(int n, double rel_tol, double abs_tol, int leaf, int d0, int dd, int p, int max_rank, int algo) {
+  auto o = make_opts(rel_tol, abs_tol, leaf, d0, dd, p, max_rank, algo);
+  auto* r = new RefHSS;
+  r->n = n;
+  auto Amult = [n](DenseMatrix<double>& Rr, DenseMatrix<double>& Rc, DenseMatrix<double>& Sr, DenseMatrix<double>& Sc) {
+    const int B = 1024, nt = (n + B - 1) / B, d = (int)Rr.cols();
+    bool same = true;
+    for (int j = 0; j < d && same; j++)
+      for (int i = 0; i < n; i++) if (Rr(i, j) != Rc(i, j)) { same = false; break; }
+    Sr.zero();
+    if (!same) Sc.zero();
+#pragma omp parallel
+    {
+      DenseMatrix<double> T(B, B);
+#pragma omp for schedule(dynamic)
+      for (int ti = 0; ti < nt; ti++) {
+        const int i0 = ti * B, mi = std::min(B, n - i0);
+        for (int tj = 0; tj < nt; tj++) {
+          const int j0 = tj * B, nj = std::min(B, n - j0);
+          for (int j = 0; j < nj; j++)
+            for (int i = 0; i < mi; i++) {
+              const int df = std::abs((i0 + i) - (j0 + j));
+              T(i, j) = df ? 1. / (1 + df) : 1.;
+            }
+          DenseMatrixWrapper<double> Tw(mi, nj, T, 0, 0), Rj(nj, d, Rr, j0, 0), Si(mi, d, Sr, i0, 0);
+          gemm(Trans::N, Trans::N, 1., Tw, Rj, 1., Si, params::task_recursion_cutoff_level);
+          if (!same) {   // T is symmetric: T^T Rc = T Rc
+            DenseMatrixWrapper<double> Rcj(nj, d, Rc, j0, 0), Sci(mi, d, Sc, i0, 0);
+            gemm(Trans::N, Trans::N, 1., Tw, Rcj, 1., Sci, params::task_recursion_cutoff_level);
+          }
+        }
+      }
+    }
+    if (same) Sc.copy(Sr);
+  };
+  auto Aelem = [](const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseMatrix<double>& Bm) {
+    for (std::size_t j = 0; j < J.size(); j++)
+      for (std::size_t i = 0; i < I.size(); i++) {
+        const long long df = std::llabs((long long)I[i] - (long long)J[j]);
+        Bm(i, j) = df ? 1. / (1 + df) : 1.;
+      }
+  };
+  r->H.reset(new HSSMatrix<double>(n, n, o));
+  r->H->compress(Amult, Aelem, o);
+  return r;
+}
+
 // the SJLT sketch (--hss_compression_sketch SJLT, test/CMakeLists.txt:145-159): the reference seeds its pattern
 // generator from the clock (HSSMatrix.sketch.hpp:266-270), so repeated calls give different matrices
 void* ref_hss_create_sjlt(int n, const double* A, int lda, double rel_tol, double abs_tol, int leaf,

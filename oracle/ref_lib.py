@@ -91,6 +91,17 @@ class RefHSS:
         self.h = lib().ref_hss_create(self.n, _dp(A), A.shape[0], rel_tol, abs_tol, leaf, d0, dd,
                                       p, max_rank, 0 if algo == "original" else 1)
 
+    @classmethod
+    def toeplitz_matfree(cls, n, rel_tol=1e-2, abs_tol=1e-8, leaf=512, d0=128, dd=64, p=10, max_rank=50000, algo="stable"):
+        """T(n) of test_HSS_seq.cpp through compress(Amult, Aelem): never stores the n x n matrix (ref_driver.cpp)"""
+        L = lib()
+        L.ref_hss_create_toeplitz_matfree.restype = C.c_void_p
+        L.ref_hss_create_toeplitz_matfree.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        self = cls.__new__(cls)
+        self.n = n
+        self.h = L.ref_hss_create_toeplitz_matfree(n, rel_tol, abs_tol, leaf, d0, dd, p, max_rank, 0 if algo == "original" else 1)
+        return self
+
     def __del__(self):
         if getattr(self, "h", None):
             lib().ref_hss_destroy(self.h)

@@ -176,7 +176,8 @@ class DeviceHSS {
   bool is_factored() const { return factored_; }
   int levels() const;
   int rank() const;
-  long long memory() const;    // bytes of the compressed representation
+  static constexpr long long kRefNodeBytes = 592;   // sizeof(HSS::HSSMatrix<double>) of the reference (see memory(int))
+  long long memory() const;    // bytes of the compressed representation (+ kRefNodeBytes per node, as the reference counts)
   long long nonzeros() const;  // stored scalars + permutation entries
   long long factor_memory() const;
   int num_nodes() const { return (int)nodes_.size(); }

@@ -93,45 +93,83 @@ def test_native_code_is_loaded():
     assert "libstrumpack_amd.so" in maps and os.path.exists(_loader.LIB_PATH)
 
 
-@pytest.mark.parametrize("n,leaf", [(32768, 256), (100000, 256)])
-def test_full_size_properties(L, n, leaf):
-    """BASELINE.json configs 2 and 3 with A generated in HBM: ranks in the reference's range,
-    sampled compression error, ULV residual <= 1e-12, linearity and transpose consistency."""
+def fullsize_golden():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hss_fullsize_golden.json")) as f:
+        return {c["name"]: c for c in json.load(f)["cases"]}
+
+
+@pytest.mark.parametrize("name", ["config2_T32768_leaf256", "config3_T100000_leaf256", "config2_T32768_leaf512", "config3_T100000_leaf512"])
+def test_full_size_against_reference(L, name):
+    """BASELINE.json configs[1] / configs[2] AT FULL SIZE against the reference run at the same size
+    (tests/golden/make_golden_fullsize.py: HSSMatrix(A, opts) at N = 32768, compress(Amult, Aelem) with an O(N^2) Toeplitz
+    product at N = 100000): A generated in HBM, the reference's default random stream (engine "linear"), then every node's
+    rank, levels, memory / nonzeros, ||H b||, ||H^T b||, ||x|| for the reference's b, sampled error, ULV residual."""
+    c = fullsize_golden()[name]
+    n, leaf = c["n"], c["leaf_size"]
     hk = K.Hssk(_loader.lib_path())
     dA = hk.empty((n, n))
     hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
     hk.sync()
-    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=leaf, max_rank=50000)
-    h = capi.StructuredMatrix.hss_options(L, random_engine="philox")
+    o = capi.StructuredMatrix.options(L, rel_tol=c["rel_tol"], abs_tol=c["abs_tol"], leaf_size=leaf, max_rank=50000)
+    h = capi.StructuredMatrix.hss_options(L, d0=c["d0"], dd=c["dd"], random_engine="linear")
     H = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
-    assert H.is_compressed()
-    # reference: rank 31 at N = 32768 (BASELINE.md), ~40 expected at 1e5; +-15 %
-    lo, hi = (26, 36) if n == 32768 else (30, 52)
-    assert lo <= H.rank() <= hi, H.rank()
-    assert H.levels() == (8 if n == 32768 else 10)
-    rng = np.random.default_rng(0)
-    cols = rng.integers(0, n, 16)
-    E = np.zeros((n, 16))
-    E[cols, np.arange(16)] = 1.0
+    assert H.is_compressed() and H.levels() == c["levels"]
+    ni, ref = H.node_info(), np.array(c["nodes"])
+    assert np.array_equal(ni[:, [0, 1, 5]], ref[:, [0, 1, 5]]), "tree shape differs from the reference"
+    dr = np.abs(ni[:, 3] - ref[:, 3]) + np.abs(ni[:, 4] - ref[:, 4])
+    assert dr.max() <= 1 and (dr > 0).mean() <= 0.05, f"node ranks differ from the reference: {int(dr.sum())} over {len(dr)} nodes"
+    assert abs(H.rank() - c["rank"]) <= 1
+    HC.check_memory(H, c, ni, ref)
+    b = HC.randn(n)
+    assert np.isclose(np.linalg.norm(H.mult(b)), c["mult_b_norm"], rtol=1e-5)
+    assert np.isclose(np.linalg.norm(H.mult(b, "T")), c["multT_b_norm"], rtol=1e-5)
+    cols = np.random.default_rng(0).integers(0, n, 64)
+    E = np.zeros((n, 64))
+    E[cols, np.arange(64)] = 1.0
     HE = H.mult(E)
     i = np.arange(n)
-    Acols = 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :]))
+    Acols = np.where(i[:, None] == cols[None, :], 1.0, 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :])))
     err = np.linalg.norm(HE - Acols) / np.linalg.norm(Acols)
-    assert err <= 1e2 * 1e-4 and err < 2e-4, err
-    # transpose consistency: (H^T e_j)_i == (H e_i)_j on the sampled block
+    assert err <= 1e2 * c["rel_tol"] and err <= 1.1 * c["rel_err_sampled"] + 1e-12, (err, c["rel_err_sampled"])
+    # transpose consistency on the sampled block, linearity
     HtE = H.mult(E, "T")
     assert np.allclose(HE[cols], HtE[cols].T, atol=1e-12)
-    # linearity
+    rng = np.random.default_rng(1)
     x, y = rng.standard_normal(n), rng.standard_normal(n)
     assert np.allclose(H.mult(2 * x - 3 * y)[:, 0], 2 * H.mult(x)[:, 0] - 3 * H.mult(y)[:, 0], atol=1e-9)
     H.factor()
-    b = rng.standard_normal((n, 3))
-    X = H.solve(b)
-    res = np.linalg.norm(H.mult(X) - b) / np.linalg.norm(b)
-    assert res <= 1e-12, res
+    xs = H.solve(b)[:, 0]
+    assert np.linalg.norm(H.mult(xs)[:, 0] - b) <= 1e-12 * np.linalg.norm(b)
+    assert np.isclose(np.linalg.norm(xs), c["x_norm"], rtol=1e-6)
+    assert np.allclose(xs[:64], np.array(c["x_head"]), rtol=1e-6, atol=1e-9)
     # the solution of the compressed system solves the dense one to O(rel_tol)
-    r1 = np.linalg.norm(Acols.T @ X[:, 0] - b[cols, 0]) / np.linalg.norm(b[cols, 0])
-    assert r1 < 1e-2, r1
+    assert np.linalg.norm(Acols.T @ xs - b[cols]) <= 1e-2 * np.linalg.norm(b[cols])
+    H.destroy()
+    dA.free()
+    hk.close()
+
+
+def test_full_size_philox_sketch_same_quality(L):
+    """the bench's configuration (Philox samples drawn on the device instead of the host stream): not bit-comparable with the
+    reference, held to its rank within 15 % and its sampled error"""
+    c = fullsize_golden()["config3_T100000_leaf256"]
+    n = c["n"]
+    hk = K.Hssk(_loader.lib_path())
+    dA = hk.empty((n, n))
+    hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
+    hk.sync()
+    o = capi.StructuredMatrix.options(L, rel_tol=c["rel_tol"], abs_tol=c["abs_tol"], leaf_size=c["leaf_size"], max_rank=50000)
+    H = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, capi.StructuredMatrix.hss_options(L, random_engine="philox"))
+    assert H.is_compressed() and H.levels() == c["levels"] and abs(H.rank() - c["rank"]) <= 0.15 * c["rank"]
+    assert abs(H.memory() - c["memory"]) <= 0.03 * c["memory"]
+    cols = np.random.default_rng(0).integers(0, n, 64)
+    E = np.zeros((n, 64))
+    E[cols, np.arange(64)] = 1.0
+    i = np.arange(n)
+    Acols = np.where(i[:, None] == cols[None, :], 1.0, 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :])))
+    err = np.linalg.norm(H.mult(E) - Acols) / np.linalg.norm(Acols)
+    assert err <= 1.5 * c["rel_err_sampled"], (err, c["rel_err_sampled"])
     H.destroy()
     dA.free()
     hk.close()
