@@ -265,8 +265,31 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   if (sr != 0) { sub_h = sublists(own_by_height_, sr); sub_d = sublists(own_by_depth_, sr); }
   const Levels& ups_own = sr ? sub_h : own_by_height_;
   const Levels& downs_own = sr ? sub_d : own_by_depth_;
+  // Many right-hand sides (hybrid): the single-launch sweep works on groups of four right-hand sides, each group streaming
+  // the blocks again -- at nrhs = 64 that is 16 passes over the leaves' diagonal blocks, 88 % of all bytes.  The LEAF level
+  // therefore runs as batched MFMA GEMMs over all right-hand sides at once (every block read once), and only the inner
+  // levels -- small blocks, a chain of dependent levels -- stay in the single launch; the leaves' results reach it through
+  // the hand-off buffers like any child's (a value that is already there is taken without waiting).
+  bool whole = false;
+  if (fuse && !dist_subtree_ && nrhs >= hybrid_nrhs() && !ups_own.empty() && ups_own.size() > 1) {
+    Levels up_in(ups_own.begin() + 1, ups_own.end()), down_in;
+    for (auto& ids : downs_own) {
+      std::vector<int> v;
+      for (int id : ids) if (!nodes_[id].leaf()) v.push_back(id);
+      down_in.push_back(std::move(v));
+    }
+    up(ups_own[0]);
+    if (sweep(&up_in, &down_in)) {
+      down(ups_own[0]);
+      whole = true;
+    } else {   // (a node beyond the sweep's limits: the batched launches for the rest as well)
+      for (auto& ids : up_in) up(ids);
+      for (auto& ids : downs_own) down(ids);
+      whole = true;
+    }
+  }
   // single process: the whole product is one launch
-  const bool whole = fuse && !dist_subtree_ && sweep(&ups_own, &downs_own);
+  if (!whole) whole = fuse && !dist_subtree_ && sweep(&ups_own, &downs_own);
   if (!whole && !(fuse && dist_subtree_ && sweep(&ups_own, nullptr)))
     for (auto& ids : ups_own) up(ids);
   if (dist_subtree_) {

@@ -33,6 +33,12 @@ inline void ck(int rc) {
 inline double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// right-hand sides from which mult / solve run their LEAF level as batched MFMA GEMMs over all right-hand sides and only
+// the inner levels as the single-launch sweep (STRUMPACK_AMD_HYBRID_NRHS overrides; a value above 64 switches it off)
+inline int hybrid_nrhs() {
+  static const int v = [] { const char* e = std::getenv("STRUMPACK_AMD_HYBRID_NRHS"); return e ? std::atoi(e) : 12; }();
+  return v;
+}
 
 // host random stream of the reference (misc/RandomWrapper.hpp:128-191): engine seeded with 0
 struct HostRng {

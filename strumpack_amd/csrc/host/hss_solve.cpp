@@ -124,7 +124,8 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     ck(rc);
     return true;
   };
-  auto bwd_sweep = [&](const Levels& levels) -> bool {
+  // mode 0: every child; 1: inner children only (the leaves are finished by bwd(.., 2)); 2: (batched form only) leaf children
+  auto bwd_sweep = [&](const Levels& levels, int mode) -> bool {
     std::vector<hssk_sweep_bwd_desc> bd;
     std::vector<int> where(nn, -1);
     for (auto& ids : levels)
@@ -137,6 +138,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
           if (!mine(cid[q])) continue;
           const Node& cn = nodes_[cid[q]];
           if (cn.mU == 0) continue;
+          if (mode == 1 && cn.leaf()) continue;
           hssk_sweep_bwd_desc d{};
           d.Qt = cn.Qt; d.y = y[cid[q]]; d.xpart = xb[id] + (q ? a.rU : 0);
           d.out = cn.leaf() ? db + cn.lo : xb[cid[q]];
@@ -154,9 +156,11 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     return true;
   };
   // ---- forward, one tree height
-  auto fwd = [&](const std::vector<int>& ids) {
+  auto fwd = [&](const std::vector<int>& ids, bool blocked = false) {
     if (ids.empty()) return;
     std::vector<hssk_gemm_desc> ga, gb, gc, gd, ge;
+    std::vector<std::vector<hssk_gemm_desc>> sub;         // block substitution: stage 2 b = diagonal block b, 2 b + 1 = rows below
+    std::vector<std::vector<hssk_rowgather_desc>> cpb;    // copies of y_b in front of stage 2 b
     std::vector<hssk_rowgather_desc> rg;
     std::vector<hssk_trsm_desc> ts;
     std::vector<hssk_lusolve_desc> ls;
@@ -196,8 +200,27 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
       if (m > r) {
         rg.push_back(hssk_rowgather_desc{fsrc, y[id], nd.permU + r, m - r, nrhs, ldf, m - r, 0, 0});
         if (r) gd.push_back(hssk_gemm_desc{nd.XU, ft1, y[id], m - r, nrhs, r, r, ldp, m - r, 1, 0, -1.0, 1.0});
-        ts.push_back(hssk_trsm_desc{nd.Rlq, y[id], m - r, nrhs, m, m - r, 0, 1, 0});
-        if (r) {
+        if (blocked && nd.Tinv) {
+          // y <- R~^{-T} y on 64-row blocks with the diagonal blocks inverted at factor time: q / 64 pairs of GEMMs over
+          // all right-hand sides instead of q dependent steps per group of four
+          const int q = m - r;
+          for (int b0 = 0, blk = 0; b0 < q; b0 += 64, blk++) {
+            const int nb = std::min(64, q - b0);
+            if ((int)sub.size() <= 2 * blk + 1) sub.resize(2 * blk + 2);
+            double* t = tmp.dbl((size_t)nb * nrhs);
+            cpb.resize(sub.size());
+            cpb[2 * blk].push_back(hssk_rowgather_desc{y[id] + b0, t, nullptr, nb, nrhs, q, nb, 0, 0});
+            sub[2 * blk].push_back(hssk_gemm_desc{nd.Tinv + (size_t)blk * 64 * 64, t, y[id] + b0, nb, nrhs, nb, 64, nb, q, 0, 0, 1.0, 0.0});
+            const int rest = q - b0 - nb;
+            if (rest > 0)   // rows below -= R~(b, below)^T y_b
+              sub[2 * blk + 1].push_back(hssk_gemm_desc{nd.Rlq + b0 + (size_t)(b0 + nb) * m, y[id] + b0, y[id] + b0 + nb, rest, nrhs, nb, m, q, q, 1, 0, -1.0, 1.0});
+          }
+        } else {
+          ts.push_back(hssk_trsm_desc{nd.Rlq, y[id], m - r, nrhs, m, m - r, 0, 1, 0});
+        }
+        if (r && nd.WQ) {
+          gc.push_back(hssk_gemm_desc{nd.WQ, y[id], ft1, r, nrhs, m - r, r, m - r, ldp, 0, 0, -1.0, 1.0});   // ft1 -= WQ y
+        } else if (r) {
           // ft1 -= W1 (Q0^T y),  Q0^T y = Q~(:, :m-r) y
           double* t = tmp.dbl((size_t)m * nrhs);
           gb.push_back(hssk_gemm_desc{nd.Qt, y[id], t, m, nrhs, m - r, m, m - r, m, 0, 0, 1.0, 0.0});
@@ -225,13 +248,17 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!rg.empty()) ck(hssk_gather_rows(ctx_, rg.data(), (int)rg.size()));
     if (!gd.empty()) ck(hssk_gemm_vbatched(ctx_, gd.data(), (int)gd.size()));
     if (!ts.empty()) ck(hssk_trsm_vbatched(ctx_, ts.data(), (int)ts.size()));
+    for (size_t st = 0; st < sub.size(); st++) {
+      if (st < cpb.size() && !cpb[st].empty()) ck(hssk_gather_rows(ctx_, cpb[st].data(), (int)cpb[st].size()));
+      if (!sub[st].empty()) ck(hssk_gemm_vbatched(ctx_, sub[st].data(), (int)sub[st].size()));
+    }
     if (!ge.empty()) ck(hssk_gemm_vbatched(ctx_, ge.data(), (int)ge.size()));
     if (!gb.empty()) ck(hssk_gemm_vbatched(ctx_, gb.data(), (int)gb.size()));
     if (!gc.empty()) ck(hssk_gemm_vbatched(ctx_, gc.data(), (int)gc.size()));
     if (!ls.empty()) ck(hssk_getrs_vbatched(ctx_, ls.data(), (int)ls.size()));
   };
   // ---- backward, one depth (solve.hpp:199-238): x_c = Q_c^H [y_c ; x(part)] = Q~(:, :mc-rc) y_c + Q~(:, mc-rc:) xpart
-  auto bwd = [&](const std::vector<int>& ids) {
+  auto bwd = [&](const std::vector<int>& ids, int mode = 0) {
     std::vector<hssk_gemm_desc> g1, g2;
     std::vector<hssk_rowgather_desc> cp;
     for (int id : ids) {
@@ -246,6 +273,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
       for (int q = 0; q < 2; q++) {
         if (!mine(cid[q])) continue;  // the other ranks' subtrees continue on their owners
         const Node& cn = *ch[q];
+        if ((mode == 1 && cn.leaf()) || (mode == 2 && !cn.leaf())) continue;
         const int mc = cn.mU, rc = cn.rU;
         const double* xpart = x + (q ? a.rU : 0);
         double* out = cn.leaf() ? db + cn.lo : xb[cid[q]];
@@ -262,7 +290,18 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!g2.empty()) ck(hssk_gemm_vbatched(ctx_, g2.data(), (int)g2.size()));
     if (!cp.empty()) ck(hssk_gather_rows(ctx_, cp.data(), (int)cp.size()));
   };
-  if (!(fuse && fwd_sweep(own_by_height_)))
+  // many right-hand sides (hybrid, see mult_sub): the leaf level as batched MFMA GEMMs over all right-hand sides (the
+  // blocks of the leaves -- X, R~, WQ, Vt0, Q~: most of the bytes -- read once), the inner levels in the single launches
+  const bool hybrid = fuse && !dist_subtree_ && nrhs >= hybrid_nrhs() && own_by_height_.size() > 1;
+  bool fwd_done = false;
+  if (hybrid) {
+    Levels inner(own_by_height_.begin() + 1, own_by_height_.end());
+    fwd(own_by_height_[0], true);
+    if (!fwd_sweep(inner))
+      for (auto& ids : inner) fwd(ids);
+    fwd_done = true;
+  }
+  if (!fwd_done && !(fuse && fwd_sweep(own_by_height_)))
     for (auto& ids : own_by_height_) fwd(ids);
   if (dist_subtree_) {
     // publish ft1' (rU x nrhs) and z (rV x nrhs) of the cut nodes into every rank's top buffers
@@ -301,10 +340,16 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!up.empty()) ck(hssk_gather_rows(ctx_, up.data(), (int)up.size()));
     if (!(fuse && fwd_sweep(top_by_height_)))
       for (auto& ids : top_by_height_) fwd(ids);
-    if (!(fuse && bwd_sweep(top_by_depth_)))
+    if (!(fuse && bwd_sweep(top_by_depth_, 0)))
       for (auto& ids : top_by_depth_) bwd(ids);
   }
-  if (!(fuse && bwd_sweep(own_by_depth_)))
+  if (hybrid) {
+    if (!bwd_sweep(own_by_depth_, 1))
+      for (auto& ids : own_by_depth_) bwd(ids, 1);
+    std::vector<int> parents;   // the leaves' parents, whatever their depth: one batch
+    for (auto& ids : own_by_depth_) parents.insert(parents.end(), ids.begin(), ids.end());
+    bwd(parents, 2);
+  } else if (!(fuse && bwd_sweep(own_by_depth_, 0)))
     for (auto& ids : own_by_depth_) bwd(ids);
   if (dist_subtree_) allgather_rows(db, lb, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));

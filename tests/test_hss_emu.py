@@ -73,5 +73,9 @@ def test_host_operand_streamed_in_blocks(L):
     HC.check_host_stream_blocks(L)
 
 
+def test_multi_rhs_hybrid_sweeps(L):
+    HC.check_multi_rhs(L, n=500, leaf=32, nrhs_list=(5, 13, 64))
+
+
 def test_blr_dense_slice(L):
     HC.check_blr(L, max_n=1000)

@@ -175,6 +175,11 @@ def test_full_size_philox_sketch_same_quality(L):
     hk.close()
 
 
+def test_multi_rhs_hybrid_sweeps(L):
+    HC.check_multi_rhs(L, n=4000, leaf=128, nrhs_list=(5, 13, 64))
+    HC.check_multi_rhs(L, n=3001, leaf=256, nrhs_list=(12, 64))
+
+
 def test_rccl_exchange_hook_single_rank():
     """The multi-GPU exchange hook (strumpack_amd/dist.py) on real device memory with a 1-rank RCCL
     group: zero-copy tensor views of engine buffers + in-place all_gather_into_tensor."""
