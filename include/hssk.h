@@ -77,6 +77,10 @@ int hssk_compute_mark(hssk_ctx* ctx, int slot);
 int hssk_copy_wait(hssk_ctx* ctx, int slot);
 /* 1 if ptr is device memory of the current process (hipPointerGetAttributes) */
 int hssk_is_device_pointer(const void* ptr);
+/* Two contexts = two streams of the same device: the work enqueued on `waiter` from now on starts after everything enqueued so
+ * far on `on` has finished (an event recorded on `on`'s stream, waited for by `waiter`'s).  Nothing blocks on the host.  This is how
+ * a BLR block step factors its diagonal tile next to the compression of its block row and column. */
+int hssk_stream_wait(hssk_ctx* waiter, hssk_ctx* on);
 /* Device-clock stopwatches on the compute stream: hssk_watch_start / _stop bracket the launches in between with HIP events
  * (any number of start / stop pairs per stopwatch); hssk_watch_read_ms synchronises, returns the summed duration of
  * stopwatch `id` (0 .. 7) in ms, writes the number of pairs to *pairs (may be NULL) and clears it.  This is how bench.py

@@ -216,9 +216,10 @@ int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, 
  * Solve phases of a front (FrontBLR.cpp:525-570, BLRMatrix::trsmLNU_gemm / gemm_trsmUNN):
  *   _forward:  bsep <- L11^{-1} P bsep,  bupd <- bupd - B21 bsep;      _backward:  ysep <- U11^{-1} (ysep - B12 yupd).
  * _tile_ranks: (ntiles1 + ntiles2)^2 ints, column-major over the tiles of the whole front: rank of a U V^T tile, -1 dense.
- * _stats: 12 doubles: [0] seconds of the factorization, [1..4] device ms of LU / compression / triangular solves / Schur
+ * _stats: 16 doubles: [0] seconds of the factorization, [1..4] device ms of LU / compression / triangular solves / Schur
  *   GEMMs (only with SPX_d_blr_front_time_phases(1) set before the call, else 0), [5] flops of the Schur GEMMs, [6] all
- *   flops, [7..9] stored scalars of B11 / B12 / B21, [10] largest tile rank, [11] launches of the Schur GEMM phase. */
+ *   flops, [7..9] stored scalars of B11 / B12 / B21, [10] largest tile rank, [11] launches of the Schur GEMM phase, [12] algorithmic bytes of the Schur GEMMs (operands once,
+ *   the updated block read and written), [13..15] reserved. */
 typedef void* SPXBLRFront;
 int SPX_d_blr_front_factor(SPXBLRFront* F, int dsep, int dupd, const double* F11, int ld11, const double* F12, int ld12,
                            const double* F21, int ld21, double* F22, int ld22, int ntiles1, const int* tiles1, int ntiles2,

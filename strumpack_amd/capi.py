@@ -127,7 +127,7 @@ class BLRFront:
     """Partially factored BLR frontal matrix [F11 F12; F21 F22] behind the handle SPXBLRFront
     (BLR::BLRMatrix<double>::construct_and_partial_factor of the reference, BLR/BLRMatrix.cpp:740)."""
     STAT_NAMES = ["t_factor", "ms_lu", "ms_compress", "ms_trsm", "ms_schur", "f_schur", "f_total", "nnz11", "nnz12", "nnz21",
-                  "max_rank", "schur_launches"]
+                  "max_rank", "schur_launches", "b_schur", "_r13", "_r14", "_r15"]
 
     def __init__(self, lib, handle, dsep, dupd, nt1, nt2):
         self.L, self.h, self.dsep, self.dupd, self.nt1, self.nt2 = lib, handle, dsep, dupd, nt1, nt2
@@ -209,7 +209,7 @@ class BLRFront:
         return out
 
     def stats(self):
-        out = (C.c_double * 12)()
+        out = (C.c_double * 16)()
         self.L.SPX_d_blr_front_stats(self.h, out)
         return dict(zip(self.STAT_NAMES, list(out)))
 

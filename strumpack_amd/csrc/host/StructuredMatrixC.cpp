@@ -569,7 +569,7 @@ int SPX_d_blr_front_stats(const SPXBLRFront F, double* out) {
   for (int p = 0; p < 4; p++) out[1 + p] = f->phase_ms[p];
   out[5] = f->f_schur; out[6] = f->f_total;
   out[7] = (double)nz[0]; out[8] = (double)nz[1]; out[9] = (double)nz[2];
-  out[10] = f->rank(); out[11] = f->schur_launches;
+  out[10] = f->rank(); out[11] = f->schur_launches; out[12] = f->b_schur;
   SP_CATCH
 }
 void SPX_d_blr_front_destroy(SPXBLRFront* F) {

@@ -65,6 +65,7 @@ DeviceBLR::DeviceBLR(int m, const std::vector<int>& rowtiles, int n, const std::
 }
 
 DeviceBLR::~DeviceBLR() {
+  if (ctx2_) { hssk_sync(ctx2_); hssk_ctx_destroy(ctx2_); }
   if (ctx_) hssk_sync(ctx_);
   store_.reset();
   tmp_.reset();
@@ -137,7 +138,9 @@ void DeviceBLR::compress_tiles(const std::vector<std::pair<int, int>>& ij, const
     W[k] = tmp.dbl((size_t)m * n);
     perm[k] = tmp.ints(n);
     cp.push_back(hssk_colgather_desc{blk(i, j), W[k], nullptr, m, n, (int)ld_, m, 0});
-    idd.push_back(hssk_id_desc{W[k], m, m, n, o_.rel_tol, o_.abs_tol, o_.max_rank, perm[k], ranks + k, tmp.dbl(3 * (size_t)n)});
+    // a tile is kept dense as soon as r (m + n) > m n (BLRMatrix.cpp:568): the factorization may stop one step beyond that rank
+    const int rpay = (int)std::min<long long>(((long long)m * n) / (m + n) + 1, (long long)o_.max_rank);
+    idd.push_back(hssk_id_desc{W[k], m, m, n, o_.rel_tol, o_.abs_tol, rpay, perm[k], ranks + k, tmp.dbl(3 * (size_t)n)});
   }
   std::vector<int> hr(cnt, 0);
   if (!idd.empty()) {
@@ -268,7 +271,10 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   const int rb = rowblocks();
   int* info = dpiv_ + m_;
   for (double& p : phase_ms) p = 0;
-  f_schur = f_total = 0;
+  static const bool one_stream = [] { const char* e = std::getenv("STRUMPACK_AMD_BLR_ONE_STREAM"); return e && e[0] == '1'; }();
+  const bool two_streams = !one_stream;
+  if (two_streams && !ctx2_) ck(hssk_ctx_create(&ctx2_, o_.device));
+  f_schur = f_total = b_schur = 0;
   schur_launches = 0;
   // phases on the device clock (time_phases): stopwatches 0..3 of the context bracket the launches of each phase
   auto watch = [&](int id, bool start) {
@@ -281,13 +287,16 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   for (int i = 0; i < nsteps; i++) {
     tmp_->rewind();
     const int mi = tm(i);
-    // ---- LU of the diagonal tile, in place
+    // ---- LU of the diagonal tile, in place -- on the second stream: the compression below neither reads the tile nor
+    // waits for its factors (both only need the Schur update of the previous step); the triangular solves join the two
     hssk_lu_desc lu{blk(i, i), mi, (int)ld_, dpiv_ + roff_[i], info + i};
+    hssk_ctx* lctx = (two_streams && !time_phases) ? ctx2_ : ctx_;
+    if (lctx != ctx_) ck(hssk_stream_wait(lctx, ctx_));
     watch(0, true);
-    if (mi) ck(hssk_getrf_vbatched(ctx_, &lu, 1));
+    if (mi) ck(hssk_getrf_vbatched(lctx, &lu, 1));
     watch(0, false);
     f_total += (2.0 / 3.0) * mi * (double)mi * mi;
-    if (i + 1 == rb) break;
+    if (i + 1 == rb) { if (lctx != ctx_) ck(hssk_stream_wait(ctx_, lctx)); break; }
     // ---- compress the block row and the block column of this step from the running Schur complement
     std::vector<std::pair<int, int>> ij;
     for (int j = i + 1; j < rb; j++) { ij.emplace_back(i, j); ij.emplace_back(j, i); }
@@ -311,6 +320,7 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
       if (!mv.empty()) ck(hssk_gather_cols(ctx_, mv.data(), (int)mv.size()));
     }
     // ---- block row: U <- L^{-1} P U (all tiles at once: the panel);  block column: V <- U_ii^{-T} V
+    if (lctx != ctx_) ck(hssk_stream_wait(ctx_, lctx));
     watch(2, true);
     if (R > 0 && mi > 0) {
       hssk_lusolve_desc sw{blk(i, i), dpiv_ + roff_[i], Ucat, mi, R, (int)ld_, mi};
@@ -364,7 +374,10 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
       watch(3, false);
       schur_launches += (!gG.empty()) + (!gT.empty()) + (!gF.empty());
       for (auto* gl : {&gG, &gT, &gF})
-        for (auto& d : *gl) f_schur += 2.0 * d.m * (double)d.n * d.k;
+        for (auto& d : *gl) {
+          f_schur += 2.0 * d.m * (double)d.n * d.k;
+          b_schur += 8.0 * ((double)d.m * d.k + (double)d.k * d.n + (d.beta != 0.0 ? 2.0 : 1.0) * d.m * (double)d.n);
+        }
     }
   }
   f_total += f_schur;

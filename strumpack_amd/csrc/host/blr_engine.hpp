@@ -96,6 +96,7 @@ class DeviceBLR {
   // [1] tile compression, [2] triangular solves, [3] Schur-update GEMMs; f_schur = flops of [3]
   double phase_ms[4] = {0, 0, 0, 0};
   double f_schur = 0, f_total = 0;
+  double b_schur = 0;   // algorithmic bytes of the Schur-update GEMMs (operands once, the updated block read and written)
   int schur_launches = 0;
   bool time_phases = false;
 
@@ -127,6 +128,7 @@ class DeviceBLR {
   std::vector<int> roff_, coff_;
   BLREngineOptions o_;
   hssk_ctx* ctx_ = nullptr;
+  hssk_ctx* ctx2_ = nullptr;   // second stream: the diagonal tile's LU runs next to the compression of its block row / column
   double* dA_ = nullptr;   // n x n working array / diagonal tiles
   long long ld_ = 0;
   int* dpiv_ = nullptr;    // pivots of the diagonal tiles (0-based, local), rows() ints

@@ -259,6 +259,7 @@ int hssk_ctx_create(hssk_ctx** out, int device) {
   c->d_ring = (char*)hssk_rt::dev_malloc(c->ring_bytes);
   c->ev0 = hssk_rt::event_create();
   c->ev1 = hssk_rt::event_create();
+  c->ev_sync = hssk_rt::event_create();
   *out = c;
   HSSK_API_END
 }
@@ -279,11 +280,13 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   hssk_rt::pinned_free(c->h_ring);
   hssk_rt::dev_free(c->d_ring);
   hssk_rt::dev_free(c->d_scratch);
+  hssk_rt::dev_free(c->d_aux);
   delete c->uploader;
   hssk_rt::pinned_free(c->h_sweep_err);
   for (auto& w : c->watch) for (auto& p : w) { hssk_rt::event_destroy(p.first); hssk_rt::event_destroy(p.second); }
   for (auto e : c->watch_free) hssk_rt::event_destroy(e);
   hssk_rt::event_destroy(c->ev0);
+  hssk_rt::event_destroy(c->ev_sync);
   hssk_rt::event_destroy(c->ev1);
   hssk_rt::stream_destroy(c->stream);
   delete c;
@@ -291,6 +294,14 @@ void hssk_ctx_destroy(hssk_ctx* c) {
 
 void* hssk_ctx_stream(hssk_ctx* c) { return (void*)c->stream; }
 
+int hssk_stream_wait(hssk_ctx* waiter, hssk_ctx* on) {
+  HSSK_API_BEGIN
+  if (!waiter || !on) throw std::invalid_argument("hssk_stream_wait: null context");
+  if (waiter == on) return 0;
+  hssk_rt::event_record(on->ev_sync, on->stream);
+  hssk_rt::stream_wait_event(waiter->stream, on->ev_sync);
+  HSSK_API_END
+}
 static hssk_rt::event_t watch_event(hssk_ctx* c) {
   if (c->watch_free.empty()) return hssk_rt::event_create();
   hssk_rt::event_t e = c->watch_free.back();

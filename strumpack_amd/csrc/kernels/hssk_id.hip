@@ -40,7 +40,8 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
   double* __restrict__ W = p.W;
   double* vn1 = p.work;
   double* vn2 = p.work + m;
-  const int kmax = d < m ? d : m;
+  // (steps beyond max_rank cannot change the result: the rank is cut there anyway -- a BLR tile stops at the rank that no longer pays)
+  const int kmax = min(d < m ? d : m, p.max_rank > 0 ? p.max_rank : 0);
   const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
 
   for (int j = tid; j < m; j += ID_THREADS) p.perm[j] = j;
@@ -171,6 +172,200 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
   if (tid == 0) *p.rank = rank;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming variant for panels beyond the register kernels (more than 224 columns or 256 rows: leaf size 512 -- 192 x 391
+// sample panels --, 256 x 256 BLR tiles): the panel stays in global memory (L2 / MALL resident: 0.3 - 1 MB), one 16-wave
+// workgroup per panel.  Same truncated QRCP as id_kernel, organised for memory-level parallelism: id_kernel walks the
+// trailing columns one at a time per wave -- load, reduce, load again, store: two dependent round trips per column, 50 us
+// per Householder step on a 256 x 256 tile --; here a wave takes G columns at once, all their elements (its lane's RL rows
+// of each) in flight together and kept in registers between the dot product and the update (one read and one write of the
+// trailing panel per step), the G reductions interleaved on the DPP network, the Householder vector held in registers for
+// the whole step.  Pivot search, column swap and reflector are one wave's work between two barriers.  The triangular
+// solve X = R11^{-1} R12 is a launch of its own (id_xsolve_all_kernel: 64 registers per thread next to this kernel's
+// tile would spill).
+// Capacity: d <= 64 RL (RL = 4 or 8), m <= IDS_MMAX.
+// ------------------------------------------------------------------------------------------------
+constexpr int IDS_T = 1024;
+constexpr int IDS_W = IDS_T / 64;
+constexpr int IDS_MMAX = 2048;
+template <int RL>
+__global__ __launch_bounds__(IDS_T) void id_stream_kernel(const hssk_id_desc* __restrict__ descs) {
+  constexpr int G = 32 / RL;   // columns a wave keeps in flight (32 doubles of panel per lane)
+  HSSK_SHARED double s_v[64 * RL];
+  HSSK_SHARED double s_vn1[IDS_MMAX];
+  HSSK_SHARED double s_vn2[IDS_MMAX];
+  HSSK_SHARED double s_tau, s_r00;
+  HSSK_SHARED int s_stop;
+
+  const hssk_id_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = p.d, m = p.m, ld = p.ldw;
+  double* __restrict__ W = p.W;
+  // (steps beyond max_rank cannot change the result: the rank is cut there anyway -- a BLR tile stops at the rank that no longer pays)
+  const int kmax = min(d < m ? d : m, p.max_rank > 0 ? p.max_rank : 0);
+  const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
+
+  for (int j = tid; j < m; j += IDS_T) p.perm[j] = j;
+  // exact column norms (BLASLAPACKWrapper.hpp:579-591), G columns per wave at a time
+  for (int j0 = wave * G; j0 < m; j0 += IDS_W * G) {
+    double a[G][RL];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int t = 0; t < RL; t++) {
+        const int i = lane + 64 * t;
+        a[g][t] = (j0 + g < m && i < d) ? hssk_gload(W, i + (size_t)(j0 + g) * ld) : 0.;
+      }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      double sq = 0.;
+#pragma unroll
+      for (int t = 0; t < RL; t++) sq += a[g][t] * a[g][t];
+      sq = hssk_wave_sum(sq);
+      if (lane == 0 && j0 + g < m) { s_vn1[j0 + g] = sqrt(sq); s_vn2[j0 + g] = sqrt(sq); }
+    }
+  }
+  if (tid == 0) { s_stop = 0; s_r00 = 0.; }
+  __syncthreads();
+
+  int rank = kmax;
+  for (int k = 0; k < kmax; k++) {
+    const int tk = k >> 6, lk = k & 63;
+    if (wave == 0) {
+      // ---- 1. pivot = first arg max_{j >= k} vn1[j]
+      double bv = -1.;
+      int bi = 0x7fffffff;
+      for (int j = k + lane; j < m; j += 64) {
+        const double v = s_vn1[j];
+        if (v > bv) { bv = v; bi = j; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = hssk_shfl_xor(bv, o);
+        const int oi = hssk_shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      const int pv = bi;
+      // ---- 2. swap columns k <-> pv (the new column k stays in registers for the reflector)
+      double ck[RL], cp[RL];
+#pragma unroll
+      for (int t = 0; t < RL; t++) {
+        const int i = lane + 64 * t;
+        cp[t] = i < d ? hssk_gload(W, i + (size_t)pv * ld) : 0.;
+        ck[t] = (pv != k && i < d) ? hssk_gload(W, i + (size_t)k * ld) : 0.;
+      }
+      if (pv != k) {
+#pragma unroll
+        for (int t = 0; t < RL; t++) {
+          const int i = lane + 64 * t;
+          if (i < d) hssk_gstore(W, i + (size_t)pv * ld, ck[t]);
+        }
+        if (lane == 0) {
+          const int tp = p.perm[k]; p.perm[k] = p.perm[pv]; p.perm[pv] = tp;
+          s_vn1[pv] = s_vn1[k]; s_vn2[pv] = s_vn2[k];   // (entries k are dead after this step)
+        }
+      }
+      // ---- 3. Householder reflector of the pivot column's rows k .. d (dlarfg)
+      double sq = 0., alpha_l = 0.;
+#pragma unroll
+      for (int t = 0; t < RL; t++) {
+        const int i = lane + 64 * t;
+        if (i > k) sq += cp[t] * cp[t];
+        if (i == k) alpha_l = cp[t];
+      }
+      sq = hssk_wave_sum(sq);
+      const double alpha = hssk_bcast_lane(alpha_l, lk);
+      double tau = 0., beta = alpha, scal = 0.;
+      if (sq != 0.) {
+        const double nrm = sqrt(alpha * alpha + sq);
+        beta = alpha >= 0. ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scal = 1. / (alpha - beta);
+      }
+#pragma unroll
+      for (int t = 0; t < RL; t++) {
+        const int i = lane + 64 * t;
+        const double vi = i < k ? 0. : (i == k ? 1. : cp[t] * scal);   // (sq == 0: the rows below are zero already)
+        s_v[i] = i < d ? vi : 0.;
+        // column k of the panel: R(0:k, k) as it was, R(k, k) = beta, the reflector below (not read again)
+        if (i < d) hssk_gstore(W, i + (size_t)k * ld, i < k ? cp[t] : (i == k ? beta : vi));
+      }
+      if (lane == 0) {
+        s_tau = tau;
+        const double ab = fabs(beta);
+        if (k == 0) s_r00 = ab;
+        const double r00 = (k == 0) ? ab : s_r00;
+        // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
+        if ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) s_stop = 1;
+      }
+    }
+    __syncthreads();
+    if (s_stop) { rank = k; break; }
+    const double tau = s_tau;
+    // ---- 4. apply H = I - tau v v^T to the columns j > k (rows k .. d), 5. down-date their norms
+    double vr[RL];
+#pragma unroll
+    for (int t = 0; t < RL; t++) vr[t] = s_v[lane + 64 * t];
+    for (int j0 = k + 1 + wave * G; j0 < m; j0 += IDS_W * G) {
+      double a[G][RL];
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int t = 0; t < RL; t++) {
+          const int i = lane + 64 * t;
+          a[g][t] = (t >= tk && j0 + g < m && i >= k && i < d) ? hssk_gload(W, i + (size_t)(j0 + g) * ld) : 0.;
+        }
+      double dot[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        dot[g] = 0.;
+#pragma unroll
+        for (int t = 0; t < RL; t++) dot[g] += vr[t] * a[g][t];
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) dot[g] = tau * hssk_wave_sum(dot[g]);
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        double sq = 0., newk_l = 0.;
+#pragma unroll
+        for (int t = 0; t < RL; t++) {
+          const int i = lane + 64 * t;
+          a[g][t] -= dot[g] * vr[t];
+          if (t >= tk && j0 + g < m && i >= k && i < d) hssk_gstore(W, i + (size_t)(j0 + g) * ld, a[g][t]);
+          if (i > k) sq += a[g][t] * a[g][t];
+          if (i == k) newk_l = a[g][t];
+        }
+        if (j0 + g < m) {   // (wave-uniform)
+          const int j = j0 + g;
+          // (scalars shared by the wave are read BEFORE the collective; lane 0 rewrites them after it)
+          const double n1 = s_vn1[j], n2 = s_vn2[j];
+          const double newk = hssk_bcast_lane(newk_l, lk);
+          // dlaqp2 norm down-date
+          int recompute = 0;
+          double newn1 = n1;
+          if (n1 != 0.) {
+            double tt = fabs(newk) / n1;
+            tt = (1. + tt) * (1. - tt);
+            tt = tt > 0. ? tt : 0.;
+            const double q = n1 / n2;
+            const double t2 = tt * q * q;
+            if (t2 <= tol3z) recompute = 1;
+            else newn1 = n1 * sqrt(tt);
+          }
+          if (recompute) {  // wave-uniform: every lane evaluated the same scalars; the updated rows are still in registers
+            newn1 = sqrt(hssk_wave_sum(sq));
+            if (lane == 0) s_vn2[j] = newn1;
+          }
+          if (lane == 0) s_vn1[j] = newn1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (rank > p.max_rank) rank = p.max_rank;
+  if (tid == 0) *p.rank = rank;
+}
+
 // X = R11^{-1} R12 in place for the panels of a register-kernel launch whose rank came out <= 64 (W holds the pivoted,
 // factored panel: R11 = W(0:rank, 0:rank), R12 the columns behind it; larger ranks were finished by id_reg_kernel
 // itself).  One workgroup per panel, one thread per column of R12 with the column in registers; R11 is staged in LDS and
@@ -186,14 +381,50 @@ __device__ __forceinline__ void xsolve_body(const double* W, int ld, int rank, i
   constexpr int LR = HSSK_BACKSUB_LD;
   const int tid = threadIdx.x;
   if (rank <= 0 || rank >= m) return;
-  if (rank > 64) {   // large ranks: one column per thread, straight from global memory
-    for (int j = rank + tid; j < m; j += XS_T) {
-      const double* b = W + (size_t)j * ld;
-      double* x = X + (size_t)(j - rank) * ldx;
-      for (int i = rank - 1; i >= 0; i--) {
-        double s = b[i];
-        for (int l = i + 1; l < rank; l++) s -= W[i + (size_t)l * ld] * x[l];
-        x[i] = s / W[i + (size_t)i * ld];
+  if (rank > 64) {
+    // large ranks (BLR tiles next to the diagonal, kernel matrices): block rows of 64 from the bottom.  A thread owns a
+    // column of X; per block row it subtracts the rows already solved -- the 64 x 64 pieces of R11 staged in LDS and read
+    // as broadcasts, the solved entries read back from the thread's own column -- and finishes with the register back
+    // substitution on the diagonal block.  (The first version ran the whole substitution from global memory, a scalar
+    // load per multiply: a rank-127 tile cost more than its factorization.)
+    const int nblk = (rank + 63) / 64;
+    for (int jp = 0; jp < m - rank; jp += XS_T) {   // (uniform trip count: the stagings below contain barriers)
+      const int j = rank + jp + tid;
+      const bool act = j < m;
+      const double* bcol = W + (size_t)(act ? j : rank) * ld;
+      double* xcol = X + (size_t)(act ? j - rank : 0) * ldx;
+      for (int b = nblk - 1; b >= 0; b--) {
+        const int i0 = 64 * b, nb = min(64, rank - i0);
+        double x[64];
+#pragma unroll
+        for (int i = 0; i < 64; i++) x[i] = (act && i < nb) ? bcol[i0 + i] : 0.;
+        for (int lc = i0 + 64; lc < rank; lc += 64) {
+          const int nl = min(64, rank - lc);
+          __syncthreads();
+          for (int e = tid; e < 64 * 64; e += XS_T) {
+            const int i = e & 63, l = e >> 6;
+            s_R[i + l * LR] = (i < nb && l < nl) ? W[(i0 + i) + (size_t)(lc + l) * ld] : 0.;
+          }
+          __syncthreads();
+          for (int l = 0; l < nl; l++) {
+            const double xl = act ? xcol[lc + l] : 0.;
+#pragma unroll
+            for (int i = 0; i < 64; i++) x[i] -= s_R[i + l * LR] * xl;
+          }
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += XS_T) {
+          const int i = e & 63, l = e >> 6;
+          s_R[i + l * LR] = (i < l && l < nb) ? W[(i0 + i) + (size_t)(i0 + l) * ld] : 0.;
+        }
+        if (tid < 64) s_rd[tid] = tid < nb ? 1. / W[(i0 + tid) + (size_t)(i0 + tid) * ld] : 0.;
+        __syncthreads();
+        hssk_backsub64(x, s_R, s_rd, nb);
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < 64; i++)
+            if (i < nb) xcol[i0 + i] = x[i];
+        }
       }
     }
     return;
@@ -238,6 +469,13 @@ __global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_kernel(
   const int rank = *p.rank;
   if (rank > 64 || p.defer_x) return;
   xsolve_body(p.W, p.ldw, rank, p.m, p.W + (size_t)rank * p.ldw, p.ldw, s_R, s_rd);
+}
+// behind id_stream_kernel: every rank, always in place (hssk_id_solves_inline() == 1 for these shapes)
+__global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_all_kernel(const hssk_id_desc* __restrict__ descs) {
+  HSSK_SHARED double s_R[64 * HSSK_BACKSUB_LD];
+  HSSK_SHARED double s_rd[64];
+  const hssk_id_desc p = descs[blockIdx.x];
+  xsolve_body(p.W, p.ldw, *p.rank, p.m, p.W + (size_t)(*p.rank) * p.ldw, p.ldw, s_R, s_rd);
 }
 // deferred: rank and destination from the descriptor (hssk_id_xsolve_vbatched)
 __global__ __launch_bounds__(XS_T) HSSK_WAVES_PER_SIMD(2) void id_xsolve_to_kernel(const hssk_xsolve_desc* __restrict__ descs) {
@@ -734,8 +972,13 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
     if (!cp.empty()) { int rc = hssk_gather_cols(ctx, cp.data(), (int)cp.size()); if (rc) return rc; }
     // few large panels: spread every Householder step over the chip; many small ones: one workgroup each
     static const bool force_wide = [] { const char* e = std::getenv("HSSK_ID_WIDE"); return e && e[0] == '1'; }();
+    static const bool no_stream = [] { const char* e = std::getenv("HSSK_ID_NO_STREAM"); return e && e[0] == '1'; }();   // (A/B: the first global-memory kernel)
     if (force_wide || (count <= 128 && (long long)dmax * mmax >= 256LL * 512)) id_wide(ctx, descs, dd, count);
-    else HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
+    else if (dmax <= 512 && mmax <= IDS_MMAX && !no_stream) {
+      if (dmax <= 256) HSSK_LAUNCH(id_stream_kernel<4>, dim3((unsigned)count), dim3(IDS_T), 0, ctx->stream, dd);
+      else HSSK_LAUNCH(id_stream_kernel<8>, dim3((unsigned)count), dim3(IDS_T), 0, ctx->stream, dd);
+      HSSK_LAUNCH(id_xsolve_all_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
+    } else HSSK_LAUNCH(id_kernel, dim3((unsigned)count), dim3(ID_THREADS), 0, ctx->stream, dd);
   }
   hssk_rt::check_launch();
   HSSK_API_END

@@ -45,6 +45,7 @@ struct hssk_ctx {
   size_t ring_bytes = 0, ring_off = 0;
   size_t zero_copy_bytes = 0;   // descriptor arrays up to this size are read in place from the pinned ring
   hssk_rt::event_t ev0{}, ev1{};
+  hssk_rt::event_t ev_sync{};   // hssk_stream_wait: recorded on this context's stream, waited for by another's
   bool dgemm_timed = false;
   double dgemm_timed_flops = 0.;  // algorithmic flops of the launch bracketed by ev0 / ev1
   long long dgemm_trace_wgs = 0;  // workgroups of the last main launch (trace records behind d_clk + 4)
@@ -88,6 +89,19 @@ struct hssk_ctx {
     }
     ring_off += need;
     return d;
+  }
+  // second work buffer (blocked triangular solves: inverted diagonal blocks + a copy of the block being solved); separate from
+  // `scratch`, whose contents a caller may still need
+  double* d_aux = nullptr;
+  size_t aux_bytes = 0;
+  double* aux(size_t bytes) {
+    if (bytes > aux_bytes) {
+      hssk_rt::sync(stream);
+      hssk_rt::dev_free(d_aux);
+      d_aux = (double*)hssk_rt::dev_malloc(bytes);
+      aux_bytes = bytes;
+    }
+    return d_aux;
   }
   double* scratch(size_t bytes) {
     if (bytes > scratch_bytes) {

@@ -14,6 +14,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -155,6 +156,171 @@ __global__ __launch_bounds__(LU_THREADS) void getrf_lds_kernel(const hssk_lu_des
   if (tid == 0) *p.info = info;
 }
 
+// ---- blocked LU of one matrix by ONE workgroup, 128 < n <= 512 (diagonal tiles of a BLR factorization, HSS roots with
+// ranks in the hundreds).  getrf_kernel above runs every elimination step on the matrix in global memory with six
+// barriers and one column per wave at a time: 4.6 ms for a 256 x 256 tile -- the longest kernel of a BLR block step.
+// Here the current 32-column panel (rows j0 .. n) lives in LDS: a step is an LDS arg max, an LDS row swap and an LDS
+// rank-1 update of at most 31 columns (three barriers, ~1 us); the row interchange of the columns OUTSIDE the panel is
+// issued by one thread per column while the panel is updated (the same thread owns a column in every step, so its
+// exchanges stay ordered).  Column k of the panel is kept unscaled until the panel is done (no read / write hazard inside
+// a step; 1 / pivot in s_inv).  The trailing matrix is then updated from the LDS panel, 64 columns at a time:
+// U12 = L11^{-1} A12 with a column per thread in registers, A22 -= L21 U12 with rows along the lanes (coalesced).
+// Same pivoting rule as getrf_kernel (first arg max), same results up to the order of the updates.
+constexpr int LUW_T = 512;
+constexpr int LUW_NB = 32;
+constexpr int LUW_NMAX = 512;
+constexpr int LUW_CH = 64;   // trailing columns per pass
+__global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __restrict__ descs) {
+  HSSK_DYN_SHARED(double, s_dyn);
+  HSSK_SHARED double s_val[LUW_T / 64];
+  HSSK_SHARED int s_idx[LUW_T / 64];
+  HSSK_SHARED double s_inv[LUW_NB];
+  HSSK_SHARED int s_src[LUW_NMAX];        // row that ends up in position r after the panel's interchanges
+  HSSK_SHARED int s_aff[2 * LUW_NB];      // the positions that change
+  HSSK_SHARED int s_naff;
+  const hssk_lu_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n, lda = p.lda;
+  double* __restrict__ A = p.A;
+  int info = 0;
+  for (int j0 = 0; j0 < n; j0 += LUW_NB) {
+    const int nb = min(LUW_NB, n - j0), mp = n - j0, LP = mp | 1, jend = j0 + nb;
+    double* s_P = s_dyn;                              // mp x nb panel, leading dimension LP
+    double* s_U = s_dyn + (size_t)LP * LUW_NB;        // nb x LUW_CH block of U12, leading dimension LUW_NB + 1
+    for (int e = tid; e < mp * nb; e += LUW_T) s_P[(e % mp) + (e / mp) * LP] = hssk_gload(A, (size_t)(j0 + e % mp) + (size_t)(j0 + e / mp) * lda);
+    for (int e = tid; e < mp; e += LUW_T) s_src[e] = e;
+    __syncthreads();
+    for (int k = 0; k < nb; k++) {
+      // ---- pivot: first arg max_{i >= k} |P(i, k)|  (one row per thread: mp <= 512)
+      double bv = -1.;
+      int bi = 0x7fffffff;
+      if (k + tid < mp) { bv = fabs(s_P[(k + tid) + k * LP]); bi = k + tid; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = hssk_shfl_xor(bv, o);
+        const int oi = hssk_shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+      __syncthreads();
+      double v = s_val[0];
+      int pv = s_idx[0];
+      for (int w = 1; w < LUW_T / 64; w++)
+        if (s_val[w] > v || (s_val[w] == v && s_idx[w] < pv)) { v = s_val[w]; pv = s_idx[w]; }
+      if (tid == 0) {
+        p.piv[j0 + k] = j0 + pv;
+        const int t = s_src[k]; s_src[k] = s_src[pv]; s_src[pv] = t;   // (the columns outside the panel follow once per panel)
+      }
+      // ---- row interchange inside the panel
+      if (pv != k && tid < nb) { const double a = s_P[k + tid * LP]; s_P[k + tid * LP] = s_P[pv + tid * LP]; s_P[pv + tid * LP] = a; }
+      __syncthreads();
+      const double akk = s_P[k + k * LP];
+      if (akk == 0.) {
+        if (!info) info = j0 + k + 1;
+        if (tid == 0) s_inv[k] = 0.;
+      } else {
+        const double inv = 1. / akk;
+        if (tid == 0) s_inv[k] = inv;
+        // ---- rank-1 update of the panel's columns k+1 .. nb (column k itself stays unscaled for now)
+        const int rw = mp - k - 1, cw = nb - k - 1;
+        for (int e = tid; e < rw * cw; e += LUW_T) {
+          const int i = k + 1 + e % rw, j = k + 1 + e / rw;
+          s_P[i + j * LP] -= s_P[i + k * LP] * inv * s_P[k + j * LP];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- L = P(:, k) / pivot below the diagonal; panel back to global memory
+    for (int e = tid; e < mp * nb; e += LUW_T) {
+      const int i = e % mp, j = e / mp;
+      double val = s_P[i + j * LP];
+      if (i > j) { val *= s_inv[j]; s_P[i + j * LP] = val; }
+      hssk_gstore(A, (size_t)(j0 + i) + (size_t)(j0 + j) * lda, val);
+    }
+    // ---- the panel's row interchanges on the columns outside it, all at once: the positions that changed (at most 2 nb)
+    // are read -- every thread its share of (position, column) pairs, into registers -- and, behind a barrier, written.
+    // (Exchanging two rows per elimination step in global memory cost two dependent round trips per step: the barrier's
+    // fence waits for them -- 5 us per step against 1 us of LDS work.)
+    if (tid == 0) {
+      int na = 0;
+      for (int r = 0; r < mp && na < 2 * LUW_NB; r++)
+        if (s_src[r] != r) s_aff[na++] = r;
+      s_naff = na;
+    }
+    __syncthreads();
+    {
+      const int na = s_naff, nco = n - nb;
+      constexpr int PER = (2 * LUW_NB * (LUW_NMAX - 1) + LUW_T - 1) / LUW_T;   // pairs per thread at most
+      double val[PER];
+      // (consecutive threads take consecutive affected rows of one column: the rows lie within the panel's row range)
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const int e = tid + q * LUW_T;
+        val[q] = 0.;
+        if (e < na * nco) {
+          const int a = e % na, c = e / na, col = c < j0 ? c : c + nb;
+          val[q] = hssk_gload(A, (size_t)(j0 + s_src[s_aff[a]]) + (size_t)col * lda);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const int e = tid + q * LUW_T;
+        if (e < na * nco) {
+          const int a = e % na, c = e / na, col = c < j0 ? c : c + nb;
+          hssk_gstore(A, (size_t)(j0 + s_aff[a]) + (size_t)col * lda, val[q]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- trailing matrix, LUW_CH columns at a time
+    constexpr int LU_ = LUW_NB + 1;
+    for (int c0 = jend; c0 < n; c0 += LUW_CH) {
+      const int nc = min(LUW_CH, n - c0);
+      for (int e = tid; e < nb * nc; e += LUW_T) s_U[(e % nb) + (e / nb) * LU_] = hssk_gload(A, (size_t)(j0 + e % nb) + (size_t)(c0 + e / nb) * lda);
+      __syncthreads();
+      if (tid < nc) {   // U12(:, c) = L11^{-1} A12(:, c): the column in registers, L11 read as broadcasts
+        double u[LUW_NB];
+#pragma unroll
+        for (int i = 0; i < LUW_NB; i++) u[i] = i < nb ? s_U[i + tid * LU_] : 0.;
+#pragma unroll
+        for (int l = 0; l < LUW_NB; l++) {
+          if (l < nb) {
+#pragma unroll
+            for (int i = l + 1; i < LUW_NB; i++)
+              if (i < nb) u[i] -= s_P[i + l * LP] * u[l];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < LUW_NB; i++)
+          if (i < nb) { s_U[i + tid * LU_] = u[i]; hssk_gstore(A, (size_t)(j0 + i) + (size_t)(c0 + tid) * lda, u[i]); }
+      }
+      __syncthreads();
+      // A22(:, c0 .. c0+nc) -= L21 U12: rows along the lanes, a thread takes 16 columns of its row
+      const int rws = mp - nb;
+      constexpr int RG = LUW_T / (LUW_CH / 16);   // rows per pass
+      for (int ip = 0; ip < rws; ip += RG) {
+        const int i = ip + tid % RG, cg = (tid / RG) * 16;
+        if (i < rws && cg < nc) {
+          double acc[16];
+#pragma unroll
+          for (int c = 0; c < 16; c++) acc[c] = cg + c < nc ? hssk_gload(A, (size_t)(jend + i) + (size_t)(c0 + cg + c) * lda) : 0.;
+          for (int l = 0; l < nb; l++) {
+            const double lil = s_P[(nb + i) + l * LP];
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc[c] -= lil * s_U[l + (cg + c) * LU_];
+          }
+#pragma unroll
+          for (int c = 0; c < 16; c++)
+            if (cg + c < nc) hssk_gstore(A, (size_t)(jend + i) + (size_t)(c0 + cg + c) * lda, acc[c]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *p.info = info;
+}
+
 // ---- blocked LU for large matrices (root of an HSS matrix with ranks in the hundreds): right-looking, LUB columns
 // per panel; the panel is factored by one workgroup (same pivoting rule as getrf_kernel, restricted to the panel's
 // columns), its row interchanges are applied to the other columns by lu_swap_kernel, U12 = L11^{-1} A12 is a batched
@@ -278,9 +444,93 @@ int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count
   HSSK_API_END
 }
 
-int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count) {
+// Large triangles with many right-hand sides (the triangular solves of a BLR block step: a 256 x 256 diagonal tile against
+// the few hundred columns of a block row's U factors, or against every V factor of a block column): the substitution kernel
+// below walks n dependent steps per group of four right-hand sides -- 0.29 ms per call for n = 256.  Blocked instead, as in
+// the ULV sweeps: the 64 x 64 diagonal blocks are inverted once (hssk_trtri_diag_vbatched) and the solve becomes
+// ceil(n / 64) block steps of two batched MFMA GEMMs over ALL right-hand sides -- X_b = inv(T_bb) B_b, then the remaining
+// block rows -= T(rest, b) X_b.  Forms taken: unit lower, upper, transposed upper (the ones the factorizations use);
+// everything else stays with the substitution kernel.
+static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, std::vector<char>& done) {
+  constexpr int NB = 64;
+  struct Tri { const double* T; int n, ldt, lower, transT, unit; size_t off; };
+  std::vector<Tri> tris;            // distinct triangles (a block column's V factors all meet the same diagonal tile)
+  std::vector<int> tri_of(count, -1);
+  size_t inv_doubles = 0, tmp_doubles = 0;
+  for (int i = 0; i < count; i++) {
+    const hssk_trsm_desc& d = descs[i];
+    const bool form = (d.lower && !d.transT && d.unit) || (!d.lower && !d.unit);
+    if (!form || d.n < 2 * NB || d.nrhs < 8) continue;
+    int t = -1;
+    for (size_t q = 0; q < tris.size(); q++)
+      if (tris[q].T == d.T && tris[q].n == d.n && tris[q].ldt == d.ldt && tris[q].lower == d.lower && tris[q].transT == d.transT && tris[q].unit == d.unit) { t = (int)q; break; }
+    if (t < 0) {
+      t = (int)tris.size();
+      tris.push_back(Tri{d.T, d.n, d.ldt, d.lower, d.transT, d.unit, inv_doubles});
+      inv_doubles += (size_t)((d.n + NB - 1) / NB) * NB * NB;
+    }
+    tri_of[i] = t;
+    tmp_doubles += (size_t)NB * d.nrhs;
+  }
+  if (tris.empty()) return false;
+  double* aux = ctx->aux(sizeof(double) * (inv_doubles + tmp_doubles));
+  double* tmp0 = aux + inv_doubles;
+  std::vector<hssk_trtri_desc> ti;
+  for (auto& t : tris) ti.push_back(hssk_trtri_desc{t.T, aux + t.off, t.n, t.ldt, t.lower ? 2 : 1});
+  if (hssk_trtri_diag_vbatched(ctx, ti.data(), (int)ti.size())) throw std::runtime_error(hssk_last_error());
+  int nblk_max = 0;
+  for (auto& t : tris) nblk_max = std::max(nblk_max, (t.n + NB - 1) / NB);
+  std::vector<hssk_rowgather_desc> cp;
+  std::vector<hssk_gemm_desc> g1, g2;
+  for (int s = 0; s < nblk_max; s++) {
+    cp.clear(); g1.clear(); g2.clear();
+    size_t toff = 0;
+    for (int i = 0; i < count; i++) {
+      if (tri_of[i] < 0) continue;
+      const hssk_trsm_desc& d = descs[i];
+      const Tri& t = tris[tri_of[i]];
+      double* tmp = tmp0 + toff;
+      toff += (size_t)NB * d.nrhs;
+      const int nblk = (d.n + NB - 1) / NB;
+      if (s >= nblk) continue;
+      // the effective triangle of op(T): lower (forward, blocks first to last) or upper (backward, last to first)
+      const bool fwd = d.lower || d.transT;
+      const int b = fwd ? s : nblk - 1 - s, b0 = b * NB, nb = std::min(NB, d.n - b0), end = b0 + nb;
+      const double* Ti = aux + t.off + (size_t)b * NB * NB;
+      double* Bb = d.B + b0;
+      cp.push_back(hssk_rowgather_desc{Bb, tmp, nullptr, nb, d.nrhs, d.ldb, nb, 0, 0});
+      // X_b = inv(op(T)_bb) B_b: the blocks hold plain inverses of T_bb; a transposed solve multiplies by their transposes
+      g1.push_back(hssk_gemm_desc{Ti, tmp, Bb, nb, d.nrhs, nb, NB, nb, d.ldb, d.transT ? 1 : 0, 0, 1.0, 0.0});
+      if (fwd && end < d.n) {
+        // rows below -= op(T)(end:n, b0:end) X_b:  lower T: T(end:n, b0:end);  transposed upper: T(b0:end, end:n)^T
+        if (d.lower) g2.push_back(hssk_gemm_desc{d.T + end + (size_t)b0 * d.ldt, Bb, d.B + end, d.n - end, d.nrhs, nb, d.ldt, d.ldb, d.ldb, 0, 0, -1.0, 1.0});
+        else g2.push_back(hssk_gemm_desc{d.T + b0 + (size_t)end * d.ldt, Bb, d.B + end, d.n - end, d.nrhs, nb, d.ldt, d.ldb, d.ldb, 1, 0, -1.0, 1.0});
+      } else if (!fwd && b0 > 0) {
+        // rows above -= T(0:b0, b0:end) X_b
+        g2.push_back(hssk_gemm_desc{d.T + (size_t)b0 * d.ldt, Bb, d.B, b0, d.nrhs, nb, d.ldt, d.ldb, d.ldb, 0, 0, -1.0, 1.0});
+      }
+    }
+    if (!cp.empty() && hssk_gather_rows(ctx, cp.data(), (int)cp.size())) throw std::runtime_error(hssk_last_error());
+    if (!g1.empty() && hssk_gemm_vbatched(ctx, g1.data(), (int)g1.size())) throw std::runtime_error(hssk_last_error());
+    if (!g2.empty() && hssk_gemm_vbatched(ctx, g2.data(), (int)g2.size())) throw std::runtime_error(hssk_last_error());
+  }
+  for (int i = 0; i < count; i++) done[i] = tri_of[i] >= 0;
+  return true;
+}
+
+int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs_in, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
+  static const bool no_blocked = [] { const char* e = std::getenv("HSSK_TRSM_NO_BLOCKED"); return e && e[0] == '1'; }();   // (A/B)
+  std::vector<char> done(count, 0);
+  std::vector<hssk_trsm_desc> rest;
+  const hssk_trsm_desc* descs = descs_in;
+  if (!no_blocked && trsm_blocked(ctx, descs_in, count, done)) {
+    for (int i = 0; i < count; i++) if (!done[i]) rest.push_back(descs_in[i]);
+    if (rest.empty()) { hssk_rt::check_launch(); return 0; }
+    descs = rest.data();
+    count = (int)rest.size();
+  }
   int nmax = 0;
   for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
   if (nmax == 0) return 0;
@@ -304,9 +554,15 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   auto* dd = (const hssk_lu_desc*)ctx->stage(descs, sizeof(*descs) * count);
   int nmax = 0;
   for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
-  if (nmax <= 384) {
-    if (nmax <= LU_LDS_N) HSSK_LAUNCH(getrf_lds_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
-    else HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  static const bool no_wg = [] { const char* e = std::getenv("HSSK_LU_NO_WG"); return e && e[0] == '1'; }();   // (A/B: the first kernel)
+  if (nmax <= LU_LDS_N) {
+    HSSK_LAUNCH(getrf_lds_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  } else if (nmax <= LUW_NMAX && !no_wg) {
+    const size_t shmem = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * LUW_CH);
+    hssk_rt::allow_dynamic_lds(getrf_wg_kernel, shmem);
+    HSSK_LAUNCH(getrf_wg_kernel, dim3((unsigned)count), dim3(LUW_T), shmem, ctx->stream, dd);
+  } else if (nmax <= 384) {
+    HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
   } else {
     std::vector<hssk_trsm_desc> tr;
     std::vector<hssk_gemm_desc> gm;

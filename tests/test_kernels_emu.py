@@ -71,6 +71,11 @@ def test_id(hk):
     KC.case_id(hk, [(192, 150, 1e-6, 1e-12, 1000, 18), (64, 40, 1e-6, 1e-12, 1000, 7), (100, 90, 1e-9, 1e-14, 1000, 80)], seed=9, deferred=True)   # in-place source, deferred X (rank 80: the large-rank branch)
     KC.case_id(hk, [(48, 260, 1e-6, 1e-12, 1000, 6)], seed=10, deferred=True)   # a batch the in-place kernels take: X is copied
     KC.case_id(hk, [(600, 260, 1e-6, 1e-12, 1000, 40), (520, 300, 1e-8, 1e-12, 25, 60)], seed=8)      # wide (multi-workgroup) path
+    # streaming kernel (panels beyond the register tiles): 4 / 8 rows per lane, ranks below and above 64 (blocked X solve),
+    # a panel that never meets its tolerance, max_rank cut-off, deferred X on such a batch
+    KC.case_id(hk, [(96, 250, 1e-6, 1e-12, 1000, 12), (130, 230, 1e-8, 1e-13, 1000, 70), (64, 300, 1e-6, 1e-12, 9, 20)], seed=12)
+    KC.case_id(hk, [(300, 120, 1e-6, 1e-12, 1000, 30), (270, 240, 1e-9, 1e-14, 1000, 150), (260, 100, 1e-13, 1e-16, 1000, None)], seed=13)
+    KC.case_id(hk, [(100, 240, 1e-6, 1e-12, 1000, 70)], seed=14, deferred=True)
 
 
 def test_qr(hk):

@@ -77,6 +77,9 @@ def test_id(hk):
     # wide (multi-workgroup) path: a few large panels
     KC.case_id(hk, [(192, 195, 1e-4, 1e-10, 50000, 36)] * 5 + [(192, 82, 1e-6, 1e-12, 50000, 40), (100, 90, 1e-9, 1e-14, 1000, 80)], seed=23, deferred=True)
     KC.case_id(hk, [(48, 260, 1e-6, 1e-12, 1000, 6)], seed=24, deferred=True)
+    # streaming kernel: BLR tiles (256 x 256, ranks 13 .. 127), leaf-512 sample panels (192 x 391), more than 256 rows
+    KC.case_id(hk, [(256, 256, 1e-4, 1e-12, 5000, 13)] * 6 + [(256, 256, 1e-4, 1e-12, 5000, 127), (200, 256, 1e-6, 1e-12, 5000, 70)] +
+               [(192, 391, 1e-4, 1e-10, 50000, 41)] * 4 + [(400, 300, 1e-8, 1e-13, 5000, 90), (512, 512, 1e-6, 1e-12, 300, 200)], seed=25)
     KC.case_id(hk, [(600, 260, 1e-6, 1e-12, 1000, 40), (1500, 1200, 1e-8, 1e-12, 50000, 500), (900, 1000, 1e-6, 1e-12, 200, 400)], seed=22)
 
 
@@ -89,7 +92,7 @@ def test_qr(hk):
 
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)
-    KC.case_trsm_lu(hk, seed=10, big_lu=(2100, 5))
+    KC.case_trsm_lu(hk, seed=10, big_lu=(2100, 5), extra_lu=[(384, 3), (391, 1), (512, 2)])
 
 
 def test_mfma_peak_probe(hk):
