@@ -26,6 +26,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -257,14 +258,19 @@ __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, in
 // Right-hand sides beyond SW_NR: blockIdx.y walks groups of SW_NR columns.  The groups are independent chains through the
 // tree that run side by side (a 2-D grid is dispatched x-fastest, so within a group the index order still holds); each
 // group streams the blocks again, which is what bounds it (nrhs = 64: 16 x the bytes of one group).
+// (few groups: side by side along blockIdx.y as described; many -- the inner levels of the hybrid many-right-hand-side path,
+// hss_apply.cpp / hss_solve.cpp --: ONE workgroup per node walks the groups in turn.  Side by side, sixteen groups of a
+// 9-level tree cost sixteen latency chains one after the other -- a group's workgroups hold the slots while they wait --:
+// 0.9 ms for the inner levels of N = 1e5 at nrhs = 64.  In turn, the chain is paid once and the levels pipeline: a parent
+// works on group g while its children are on g + 1.)
 template <int NR>
-__device__ __forceinline__ int rhs_group(int nrhs_total, int& c0) {
-  c0 = (int)blockIdx.y * NR;
+__device__ __forceinline__ int rhs_group(int nrhs_total, int group, int& c0) {
+  c0 = group * NR;
   return min(NR, nrhs_total - c0);
 }
 
 template <int NR>
-__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
+__device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err, int group) {
   HSSK_SHARED double s_f[SW_MAX * NR];    // f, later the block right-hand side of the substitution
   HSSK_SHARED double s_y[SW_MAX * NR];    // zc(permV[rv:]) first, then y
   HSSK_SHARED double s_a[SW_MAX * NR];    // stacked children z (inner nodes)
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
   int c0;
-  const int nrhs = rhs_group<NR>(nrhs_total, c0);
+  const int nrhs = rhs_group<NR>(nrhs_total, group, c0);
   if (c0) {   // this group's columns of every vector
     p.fsrc += (size_t)c0 * p.ldf;
     if (p.zc) p.zc += (size_t)c0 * p.ldz_in;
@@ -423,9 +429,17 @@ __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fw
   for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * SW_MAX]);
 }
 
+template <int NR>
+__global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
+  for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
+    ulv_fwd_body<NR>(descs, nrhs_total, err, g);
+    __syncthreads();   // (the LDS vectors are reused by the next group)
+  }
+}
+
 // ---- backward ULV sweep:  x_c = Q~(:, 0:q) y + Q~(:, q:) xpart ; m == r (nothing eliminated): x_c = xpart ------------
 template <int NR>
-__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err) {
+__device__ __forceinline__ void ulv_bwd_body(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err, int group) {
   HSSK_SHARED double s_v[SW_MAX * NR];   // [y; xpart]
   HSSK_SHARED double s_o[SW_MAX * NR];
   HSSK_SHARED double s_p[SW_T * NR];
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r;
   int c0;
-  const int nrhs = rhs_group<NR>(nrhs_total, c0);
+  const int nrhs = rhs_group<NR>(nrhs_total, group, c0);
   if (c0) {
     if (p.y) p.y += (size_t)c0 * q;
     p.xpart += (size_t)c0 * p.ldx;
@@ -460,17 +474,25 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bw
   }
 }
 
+template <int NR>
+__global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err) {
+  for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
+    ulv_bwd_body<NR>(descs, nrhs_total, err, g);
+    __syncthreads();
+  }
+}
+
 // ---- mat-vec: up-sweep nodes [0, nup) then down-sweep nodes [nup, nup + ndown) in one launch -------------------------------
 template <int NR>
-__global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
-                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err) {
+__device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict__ ups, int nup,
+                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err, int group) {
   HSSK_SHARED double s_x[SW_MAX * NR];
   HSSK_SHARED double s_g[SW_MAX * NR];
   HSSK_SHARED double s_o[SW_MAX * NR];
   HSSK_SHARED double s_p[SW_T * NR];
   const int tid = threadIdx.x;
   int c0;
-  const int nrhs = rhs_group<NR>(nrhs_total, c0);
+  const int nrhs = rhs_group<NR>(nrhs_total, group, c0);
   if ((int)blockIdx.x < nup) {
     // tmp1 = V^H src = src(perm[0:r]) + X src(perm[r:])   (X is r x (m - r), rows contiguous)
     hssk_apply_up_desc p = ups[blockIdx.x];
@@ -555,6 +577,15 @@ __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_d
   for (int e = tid; e < mout * nrhs; e += SW_T) hssk_cstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
 }
 
+template <int NR>
+__global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
+                                                           const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err) {
+  for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
+    apply_body<NR>(ups, nup, downs, nrhs_total, err, g);
+    __syncthreads();
+  }
+}
+
 // ---- inverses of the 64 x 64 diagonal blocks of R~^T (factor time) --------------------------------------------------------
 // One wave per block: lane j back-substitutes column j of U^{-1} (U = R~(b, b), upper triangular) in its registers
 // (hssk_backsub64: U in LDS read as broadcasts, no cross-lane step); mode 0 stores it TRANSPOSED (Linv = U^{-T}, lower
@@ -595,6 +626,13 @@ __global__ __launch_bounds__(64) HSSK_WAVES_PER_SIMD(1) void trtri_diag_kernel(c
   }
 }
 
+// groups of right-hand sides along blockIdx.y: side by side up to two groups, in turn inside the workgroups beyond
+// (HSSK_SWEEP_GROUPS_Y overrides the limit)
+unsigned groups_y(int nrhs) {
+  static const int lim = [] { const char* e = std::getenv("HSSK_SWEEP_GROUPS_Y"); return e ? std::max(1, std::atoi(e)) : 2; }();
+  const int g = (nrhs + SW_NR - 1) / SW_NR;
+  return (unsigned)(g <= lim ? g : 1);
+}
 int* sweep_err(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) {
     ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64);
@@ -634,7 +672,7 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
   if (nrhs == 1) HSSK_LAUNCH(ulv_fwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(ulv_fwd_sweep_kernel<SW_NR>, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(ulv_fwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -647,7 +685,7 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   if (nrhs == 1) HSSK_LAUNCH(ulv_bwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -667,7 +705,7 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
   if (nrhs == 1) HSSK_LAUNCH(apply_sweep_kernel<1>, dim3((unsigned)(nup + ndown), 1u), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(apply_sweep_kernel<SW_NR>, dim3((unsigned)(nup + ndown), (unsigned)((nrhs + SW_NR - 1) / SW_NR)), dim3(SW_T), 0, ctx->stream, du, nup,
+  else HSSK_LAUNCH(apply_sweep_kernel<SW_NR>, dim3((unsigned)(nup + ndown), groups_y(nrhs)), dim3(SW_T), 0, ctx->stream, du, nup,
                    dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
