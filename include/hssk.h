@@ -473,6 +473,29 @@ typedef struct hssk_trtri_desc {
 } hssk_trtri_desc;
 int hssk_trtri_diag_vbatched(hssk_ctx* ctx, const hssk_trtri_desc* descs, int count);
 
+/* ---- sub-block extraction by tree traversal (HSSMatrix::extract / extract_add, HSS/HSSMatrix.extract.hpp:36-104) -------------
+ * nodes: DEVICE array, the matrix's nodes in pre-order (the sub-tree of `root` is what is extracted from; row / column
+ * indices are global: lo of a node is its first row).  iperm* are the inverses of the interpolative bases' permutations
+ * (row q of U = P [I; E] is row iperm[q] of [I; E]).  rows / cols: all requested indices, concatenated over the requests
+ * (device); block b takes rows [ri0, ri0 + ni) and cols [cj0, cj0 + nj) of those lists and writes (accumulate: adds to) its
+ * ni x nj result at out (device, leading dimension ldo).  pair_off: prefix sums of ni * nj (nblocks + 1 entries, device).
+ * work: (nrows + ncols) * maxdepth * rmax doubles (device); rmax >= every rank, maxdepth > the depth of every leaf. */
+typedef struct hssk_tree_node {
+  int lo, m, c0, c1;
+  int rU, rV, mU, mV;
+  const double *XU, *XV;      /* r x (m - r), leading dimension r */
+  const int *ipermU, *ipermV; /* mU / mV ints */
+  const double *B01, *B10, *D;
+} hssk_tree_node;
+typedef struct hssk_extract_block {
+  int ri0, ni, cj0, nj;
+  double* out;
+  int ldo;
+} hssk_extract_block;
+int hssk_hss_extract(hssk_ctx* ctx, const hssk_tree_node* nodes, int root, int rmax, int maxdepth, const int* rows, int nrows,
+                     const int* cols, int ncols, const hssk_extract_block* blocks, const long long* pair_off, int nblocks,
+                     long long npairs, int accumulate, double* work);
+
 /* ---- small utilities --------------------------------------------------------------------------- */
 /* out[j] = sum_i P(i,j)^2 over the rows x cols panel: Frobenius norms for the stopping test
  * (HSS/HSSMatrix.compress_stable.hpp:418,438) */

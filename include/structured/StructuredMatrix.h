@@ -201,6 +201,12 @@ int SPX_d_struct_schur_product_indirect(const CSPStructMat S, int c, const doubl
 /* C = op(H_cc) B for the diagonal block of child c (HSSMatrix::child(c)->apply, HSS/HSSMatrix.hpp:194-202) */
 int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, const double* B, long long ldB, double* C,
                             long long ldC, int on_device);
+/* ---- sub-block extraction (HSS::HSSMatrix<T>::extract / extract_add, HSS/HSSMatrix.hpp:418-434, HSS/HSSMatrix.extract.hpp:36-104):
+ * nb requests in one call, by tree traversal on the device.  rows / cols: the requests' 0-based index lists concatenated,
+ * roff / coff: their prefix sums (nb + 1 entries); block b = H(rows[roff[b] .. roff[b+1]), cols[coff[b] .. coff[b+1])) goes to
+ * out[b] (column-major, leading dimension ldo[b]); add != 0: is added to it.  on_device: out[b] are device pointers. */
+int SPX_d_struct_extract_blocks(const CSPStructMat S, int nb, const int* rows, const int* roff, const int* cols, const int* coff,
+                                double* const* out, const int* ldo, int add, int on_device);
 /* ---- BLR frontal matrix: partial factorization of F = [F11 F12; F21 F22] -- what the reference's sparse BLR fronts call,
  * BLR::BLRMatrix<T>::construct_and_partial_factor(A11, A12, A21, A22, B11, B12, B21, tiles1, tiles2, admissible, opts)
  * (BLR/BLRMatrix.hpp:186-194, BLR/BLRMatrix.cpp:740-1037, algorithm RL = its default; batched GPU precedent

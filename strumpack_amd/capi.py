@@ -32,6 +32,7 @@ SP_SYMBOLS = [
     "SPX_d_struct_from_dense_and_factor", "SPX_comm_unique_id", "SPX_comm_create", "SPX_comm_destroy", "SPX_comm_size", "SPX_comm_rank", "SPX_comm_selftest", "SPX_struct_shard_range",
     "SPX_d_struct_from_dense_device_comm", "SPX_d_struct_from_blocks_device", "SPX_d_struct_from_blocks_device_cb",
     "SPX_d_struct_from_kernel_comm",
+    "SPX_d_struct_extract_blocks",
     "SPX_d_blr_front_factor", "SPX_d_blr_front_factor_device", "SPX_d_blr_front_time_phases", "SPX_d_blr_front_forward",
     "SPX_d_blr_front_backward", "SPX_d_blr_front_schur", "SPX_d_blr_front_schur_device", "SPX_d_blr_front_tile_ranks",
     "SPX_d_blr_front_stats", "SPX_d_blr_front_destroy",
@@ -105,6 +106,7 @@ def load(path):
     L.SPX_d_struct_hssk_ctx.argtypes = [vp]
     L.SPX_d_struct_hssk_ctx.restype = vp
     ip = C.POINTER(C.c_int)
+    L.SPX_d_struct_extract_blocks.argtypes = [vp, C.c_int, ip, ip, ip, ip, C.POINTER(C.c_void_p), ip, C.c_int, C.c_int]
     L.SPX_d_blr_front_factor.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int,
                                          C.c_int, ip, C.c_int, ip, C.c_char_p, C.POINTER(CSPOptions)]
     L.SPX_d_blr_front_factor_device.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, ll, dp, ll, dp, ll, dp, ll,
@@ -356,6 +358,22 @@ class StructuredMatrix:
 
     def dense(self):
         return self.mult(np.eye(self.n))
+
+    def extract_blocks(self, I, J, add_to=None):
+        """[H(I[b], J[b]) for b]: HSSMatrix::extract of a batch of requests by tree traversal on the device (one call);
+        add_to: list of arrays that are incremented instead (extract_add)"""
+        nb = len(I)
+        ia = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        r, c = ia(np.concatenate([ia(x) for x in I]) if nb else []), ia(np.concatenate([ia(x) for x in J]) if nb else [])
+        roff, coff = ia(np.cumsum([0] + [len(x) for x in I])), ia(np.cumsum([0] + [len(x) for x in J]))
+        out = [np.asfortranarray(a, dtype=np.float64) for a in add_to] if add_to is not None else \
+            [np.zeros((len(I[b]), len(J[b])), order="F") for b in range(nb)]
+        ptrs = (C.c_void_p * max(nb, 1))(*[o.ctypes.data for o in out])
+        ldo = ia([max(o.shape[0], 1) for o in out])
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        if self.L.SPX_d_struct_extract_blocks(self.h, nb, ip(r), ip(roff), ip(c), ip(coff), ptrs, ip(ldo), int(add_to is not None), 0):
+            raise RuntimeError("SPX_d_struct_extract_blocks failed")
+        return out
 
     # ---- Schur complement of the (0,0) block (HSSMatrix::partial_factor / Schur_update / Schur_product_*) ----
     def partial_factor(self):

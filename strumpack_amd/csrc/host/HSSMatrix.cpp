@@ -320,18 +320,28 @@ DenseMatrix<double> HSSMatrix<double>::dense() const {
   return D;
 }
 
+// H(I, J) (HSSMatrix.extract.hpp:36-104).  Small requests -- the sub-blocks a front's assembly asks for -- walk the tree on the
+// device (DeviceHSS::extract_blocks: O(r^2 (|I| + |J|) log N)); requests that cover a large part of the matrix (dense()
+// through extract, whole block rows) are cheaper as |J| products with the matrix
 DenseMatrix<double> HSSMatrix<double>::extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const {
-  DenseM_t E(cols_, J.size()), HE(rows_, J.size()), B(I.size(), J.size());
-  for (std::size_t j = 0; j < J.size(); j++) {
-    if (J[j] >= cols_) throw std::invalid_argument("extract: column index out of range");
-    E(J[j], j) = 1.;
+  DenseM_t B(I.size(), J.size());
+  for (std::size_t i = 0; i < I.size(); i++) if (I[i] >= rows_) throw std::invalid_argument("extract: row index out of range");
+  for (std::size_t j = 0; j < J.size(); j++) if (J[j] >= cols_) throw std::invalid_argument("extract: column index out of range");
+  if (I.empty() || J.empty()) return B;
+  DeviceHSS* e = engine();
+  if (e->extract_by_traversal_ok(vnode_, (long long)I.size(), (long long)J.size())) {
+    std::vector<int> r(I.begin(), I.end()), c(J.begin(), J.end());
+    const int roff[2] = {0, (int)r.size()}, coff[2] = {0, (int)c.size()};
+    double* out = B.data();
+    const int ld = B.ld();
+    e->extract_blocks(vnode_, 1, r.data(), roff, c.data(), coff, &out, &ld, false, false);
+    return B;
   }
-  if (!J.empty()) apply_HSS(Trans::N, *this, E, 0., HE);
+  DenseM_t E(cols_, J.size()), HE(rows_, J.size());
+  for (std::size_t j = 0; j < J.size(); j++) E(J[j], j) = 1.;
+  apply_HSS(Trans::N, *this, E, 0., HE);
   for (std::size_t j = 0; j < J.size(); j++)
-    for (std::size_t i = 0; i < I.size(); i++) {
-      if (I[i] >= rows_) throw std::invalid_argument("extract: row index out of range");
-      B(i, j) = HE(I[i], j);
-    }
+    for (std::size_t i = 0; i < I.size(); i++) B(i, j) = HE(I[i], j);
   return B;
 }
 double HSSMatrix<double>::get(std::size_t i, std::size_t j) const { return extract({i}, {j})(0, 0); }
@@ -340,6 +350,24 @@ void HSSMatrix<double>::extract_add(const std::vector<std::size_t>& I, const std
   DenseM_t E = extract(I, J);
   for (std::size_t j = 0; j < J.size(); j++)
     for (std::size_t i = 0; i < I.size(); i++) B(i, j) += E(i, j);
+}
+// a batch of requests in one pair of launches (extension): B[b] (+)= H(I[b], J[b])
+void HSSMatrix<double>::extract_blocks(const std::vector<std::vector<std::size_t>>& I, const std::vector<std::vector<std::size_t>>& J,
+                                       std::vector<DenseM_t>& B, bool add) const {
+  if (I.size() != J.size()) throw std::invalid_argument("extract_blocks: as many row sets as column sets");
+  const int nb = (int)I.size();
+  if (!add) { B.clear(); for (int b = 0; b < nb; b++) B.emplace_back(I[b].size(), J[b].size()); }
+  if ((int)B.size() != nb) throw std::invalid_argument("extract_blocks: one output per request");
+  std::vector<int> r, c, roff(nb + 1, 0), coff(nb + 1, 0), ld(nb);
+  std::vector<double*> out(nb);
+  for (int b = 0; b < nb; b++) {
+    if (B[b].rows() != I[b].size() || B[b].cols() != J[b].size()) throw std::invalid_argument("extract_blocks: output of the wrong shape");
+    r.insert(r.end(), I[b].begin(), I[b].end());
+    c.insert(c.end(), J[b].begin(), J[b].end());
+    roff[b + 1] = (int)r.size(); coff[b + 1] = (int)c.size();
+    out[b] = B[b].data(); ld[b] = B[b].ld();
+  }
+  if (nb) engine()->extract_blocks(vnode_, nb, r.data(), roff.data(), c.data(), coff.data(), out.data(), ld.data(), false, add);
 }
 
 // ---- Schur complement of the (0,0) block (HSSMatrix.Schur.hpp) ----------------------------------------------

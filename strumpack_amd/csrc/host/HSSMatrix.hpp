@@ -91,11 +91,14 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   using structured::StructuredMatrix<double>::solve;
   void shift(scalar_t sigma) override;
   DenseM_t dense() const;
-  // H(I, J) and H(i, j) (reference: HSSMatrix.extract.hpp:36-104; here via |J| unit-vector products)
+  // H(I, J) and H(i, j) (reference: HSSMatrix.extract.hpp:36-104): tree traversal on the device
   DenseM_t extract(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J) const;
   scalar_t get(std::size_t i, std::size_t j) const;
   // H(I, J) added into B (HSSMatrix.hpp:430-434, extract_add)
   void extract_add(const std::vector<std::size_t>& I, const std::vector<std::size_t>& J, DenseM_t& B) const;
+  // extension: many requests in one pair of kernel launches, B[b] = H(I[b], J[b]) (add: B[b] += ...)
+  void extract_blocks(const std::vector<std::vector<std::size_t>>& I, const std::vector<std::vector<std::size_t>>& J,
+                      std::vector<DenseM_t>& B, bool add = false) const;
   // ---- Schur complement of the (0,0) block, as the sparse HSS fronts use it (sparse/fronts/FrontHSS.cpp:391-407):
   //   partial_factor(): ULV of child(0) only (HSSMatrix.hpp:330, factor.hpp:43-49)
   //   Schur_update(Theta, DUB01, Phi): Theta = U1big B10, DUB01 = D00^{-1} U0 B01, Phi = V1big DUB01^H, so that

@@ -486,6 +486,14 @@ int SPX_d_struct_mult_child(const CSPStructMat S, int child, char trans, int m, 
   hss(S)->engine()->mult_child(child, trans, m, B, ldB, C, ldC, on_device != 0);
   SP_CATCH
 }
+int SPX_d_struct_extract_blocks(const CSPStructMat S, int nb, const int* rows, const int* roff, const int* cols, const int* coff,
+                                double* const* out, const int* ldo, int add, int on_device) {
+  SP_TRY
+  if (!hss(S)) throw std::invalid_argument("not an HSS matrix");
+  hss(S)->engine()->extract_blocks(0, nb, rows, roff, cols, coff, out, ldo, on_device != 0, add != 0);
+  SP_CATCH
+}
+
 // ---- BLR frontal matrix (BLRMatrix::construct_and_partial_factor, BLR/BLRMatrix.cpp:740-1037) -------------------------
 namespace {
 bool g_blr_time_phases = false;

@@ -25,6 +25,7 @@ void DeviceHSS::reset_compression() {
     nd.lo = lo; nd.m = m; nd.lvl = lvl; nd.height = h; nd.c0 = c0; nd.c1 = c1; nd.parent = p;
   }
   persist_->reset();
+  dev_tree_ = nullptr;
   work_->reset();
   fact_->reset();
   factored_ = false;
@@ -41,6 +42,7 @@ void DeviceHSS::restart_nodes(int d_have) {
     nd.lo = lo; nd.m = m; nd.lvl = lvl; nd.height = h; nd.c0 = c0; nd.c1 = c1; nd.parent = p;
   }
   persist_->reset();
+  dev_tree_ = nullptr;
   d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
   if (d_have > 0) {
     std::vector<hssk_colgather_desc> cp;

@@ -165,6 +165,14 @@ class DeviceHSS {
   // the same for the sub-matrix rooted at any node of the pre-order table (HSSMatrix::child(c)->child(c')...)
   void mult_node(int node, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy, bool on_device,
                  double beta = 0.0);
+  // H(I_b, J_b) for a batch of requests by tree traversal (HSSMatrix::extract / extract_add, HSS/HSSMatrix.extract.hpp:36-104):
+  // rows / cols = the requests' index lists concatenated (local to the sub-matrix rooted at `node`), roff / coff their prefix
+  // sums (nb + 1 entries); out[b] (leading dimension ldo[b]) receives -- add: is incremented by -- block b; host or device
+  // pointers.  One pair of launches for the whole batch, O(r^2 (|I| + |J|) log N + r^2 |I| |J|) per request.
+  void extract_blocks(int node, int nb, const int* rows, const int* roff, const int* cols, const int* coff, double* const* out,
+                      const int* ldo, bool on_device, bool add);
+  // whether a request of ni x nj entries is cheaper by traversal than by nj products with the matrix
+  bool extract_by_traversal_ok(int node, long long ni, long long nj) const;
   int node_end(int node) const { return subtree_end(node); }   // pre-order ids of the sub-tree: [node, node_end)
   int rank(int node) const;
   long long memory(int node) const;
@@ -317,6 +325,10 @@ class DeviceHSS {
   int* d_ranks_ = nullptr;
   bool factored_ = false, partial_factored_ = false, schur_ready_ = false;
   std::unique_ptr<Arena> schur_;
+  // device-resident node table of the extraction kernels (persist arena; rebuilt after a compression)
+  void ensure_dev_tree();
+  const hssk_tree_node* dev_tree_ = nullptr;
+  int ex_rmax_ = 1, ex_depth_ = 1;
   double *sTheta_ = nullptr, *sPhi_ = nullptr, *sDUB01_ = nullptr, *sVtDUB01_ = nullptr, *sW_ = nullptr;
   PhaseStats stats_;
   std::shared_ptr<HostRng> rng_;

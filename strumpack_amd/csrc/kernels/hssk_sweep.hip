@@ -26,6 +26,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -626,12 +627,22 @@ __global__ __launch_bounds__(64) HSSK_WAVES_PER_SIMD(1) void trtri_diag_kernel(c
   }
 }
 
-// groups of right-hand sides along blockIdx.y: side by side up to two groups, in turn inside the workgroups beyond
-// (HSSK_SWEEP_GROUPS_Y overrides the limit)
-unsigned groups_y(int nrhs) {
-  static const int lim = [] { const char* e = std::getenv("HSSK_SWEEP_GROUPS_Y"); return e ? std::max(1, std::atoi(e)) : 2; }();
+// groups of right-hand sides along blockIdx.y: side by side, or in turn inside the workgroups (one workgroup per node).
+// Measured at N = 1e5, nrhs = 64, inner levels only (profiles/r03_sweeps_nrhs64.md): mat-vec 0.90 ms side by side, 0.44 ms in
+// turn; backward solve 0.19 / 0.17 ms; the forward solve -- the longest chain per node -- 0.45 ms side by side, 0.68 ms in turn.
+// which: 0 mat-vec, 1 forward, 2 backward.  HSSK_SWEEP_GROUPS_Y = "a,f,b" overrides the three limits.
+unsigned groups_y(int nrhs, int which) {
+  static int lim[3] = {2, 1 << 20, 2};
+  static const bool init = [] {
+    if (const char* e = std::getenv("HSSK_SWEEP_GROUPS_Y")) {
+      int a = lim[0], f = lim[1], b = lim[2];
+      if (std::sscanf(e, "%d,%d,%d", &a, &f, &b) >= 1) { lim[0] = std::max(1, a); lim[1] = std::max(1, f); lim[2] = std::max(1, b); }
+    }
+    return true;
+  }();
+  (void)init;
   const int g = (nrhs + SW_NR - 1) / SW_NR;
-  return (unsigned)(g <= lim ? g : 1);
+  return (unsigned)(g <= lim[which] ? g : 1);
 }
 int* sweep_err(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) {
@@ -672,7 +683,7 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
   if (nrhs == 1) HSSK_LAUNCH(ulv_fwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(ulv_fwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(ulv_fwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs, 1)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -685,7 +696,7 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   if (nrhs == 1) HSSK_LAUNCH(ulv_bwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs, 2)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -705,7 +716,7 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
   if (nrhs == 1) HSSK_LAUNCH(apply_sweep_kernel<1>, dim3((unsigned)(nup + ndown), 1u), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(apply_sweep_kernel<SW_NR>, dim3((unsigned)(nup + ndown), groups_y(nrhs)), dim3(SW_T), 0, ctx->stream, du, nup,
+  else HSSK_LAUNCH(apply_sweep_kernel<SW_NR>, dim3((unsigned)(nup + ndown), groups_y(nrhs, 0)), dim3(SW_T), 0, ctx->stream, du, nup,
                    dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
     const int nb = min(LUW_NB, n - j0), mp = n - j0, LP = mp | 1, jend = j0 + nb;
     double* s_P = s_dyn;                              // mp x nb panel, leading dimension LP
     double* s_U = s_dyn + (size_t)LP * LUW_NB;        // nb x LUW_CH block of U12, leading dimension LUW_NB + 1
-    for (int e = tid; e < mp * nb; e += LUW_T) s_P[(e % mp) + (e / mp) * LP] = hssk_gload(A, (size_t)(j0 + e % mp) + (size_t)(j0 + e / mp) * lda);
+    for (int j = 0; j < nb; j++)
+      for (int i = tid; i < mp; i += LUW_T) s_P[i + j * LP] = hssk_gload(A, (size_t)(j0 + i) + (size_t)(j0 + j) * lda);
     for (int e = tid; e < mp; e += LUW_T) s_src[e] = e;
     __syncthreads();
     for (int k = 0; k < nb; k++) {
@@ -222,21 +223,23 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
         const double inv = 1. / akk;
         if (tid == 0) s_inv[k] = inv;
         // ---- rank-1 update of the panel's columns k+1 .. nb (column k itself stays unscaled for now)
-        const int rw = mp - k - 1, cw = nb - k - 1;
-        for (int e = tid; e < rw * cw; e += LUW_T) {
-          const int i = k + 1 + e % rw, j = k + 1 + e / rw;
-          s_P[i + j * LP] -= s_P[i + k * LP] * inv * s_P[k + j * LP];
+        // (a row per thread -- mp <= 512 --, the columns in a loop: no index divisions, the pivot row read as broadcasts)
+        const int i = k + 1 + tid;
+        if (i < mp) {
+          const double li = s_P[i + k * LP] * inv;
+#pragma unroll 4
+          for (int j = k + 1; j < nb; j++) s_P[i + j * LP] -= li * s_P[k + j * LP];
         }
       }
       __syncthreads();
     }
     // ---- L = P(:, k) / pivot below the diagonal; panel back to global memory
-    for (int e = tid; e < mp * nb; e += LUW_T) {
-      const int i = e % mp, j = e / mp;
-      double val = s_P[i + j * LP];
-      if (i > j) { val *= s_inv[j]; s_P[i + j * LP] = val; }
-      hssk_gstore(A, (size_t)(j0 + i) + (size_t)(j0 + j) * lda, val);
-    }
+    for (int j = 0; j < nb; j++)
+      for (int i = tid; i < mp; i += LUW_T) {
+        double val = s_P[i + j * LP];
+        if (i > j) { val *= s_inv[j]; s_P[i + j * LP] = val; }
+        hssk_gstore(A, (size_t)(j0 + i) + (size_t)(j0 + j) * lda, val);
+      }
     // ---- the panel's row interchanges on the columns outside it, all at once: the positions that changed (at most 2 nb)
     // are read -- every thread its share of (position, column) pairs, into registers -- and, behind a barrier, written.
     // (Exchanging two rows per elimination step in global memory cost two dependent round trips per step: the barrier's
@@ -460,7 +463,7 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
   for (int i = 0; i < count; i++) {
     const hssk_trsm_desc& d = descs[i];
     const bool form = (d.lower && !d.transT && d.unit) || (!d.lower && !d.unit);
-    if (!form || d.n < 2 * NB || d.nrhs < 8) continue;
+    if (!form || d.n < 2 * NB || d.nrhs < 1) continue;   // (a 128-step substitution costs more than the block's inverse, whatever the number of right-hand sides)
     int t = -1;
     for (size_t q = 0; q < tris.size(); q++)
       if (tris[q].T == d.T && tris[q].n == d.n && tris[q].ldt == d.ldt && tris[q].lower == d.lower && tris[q].transT == d.transT && tris[q].unit == d.unit) { t = (int)q; break; }

@@ -175,6 +175,62 @@ def test_full_size_philox_sketch_same_quality(L):
     hk.close()
 
 
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_4", "HSS_seq_5", "HSS_seq_11", "HSS_seq_12", "HSS_seq_14", "HSS_seq_22",
+                                  "config1_T4096_defaults", "config2shape_T8192_leaf256_rtol1e-4"])
+def test_extract_by_tree_traversal(L, name):
+    HC.check_extract(L, CASES[name])
+
+
+def test_extract_thousand_blocks_full_size(L):
+    """1000 random 8 x 8 blocks of the N = 100000 matrix in one call: against products with unit vectors on a sample, and
+    the device path (outputs resident in HBM) timed -- the assembly of a front asks for blocks like these"""
+    import ctypes as C
+    import time
+    n = 100000
+    hk = K.Hssk(_loader.lib_path())
+    dA = hk.empty((n, n))
+    hk.check(hk.lib.hssk_fill_toeplitz(hk.ctx, dA.ptr, n, n, b"T"))
+    hk.sync()
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=256, max_rank=50000)
+    H = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, capi.StructuredMatrix.hss_options(L, random_engine="philox"))
+    dA.free()
+    rng = np.random.default_rng(4)
+    nb = 1000
+    I = [rng.integers(0, n, 8) for _ in range(nb)]
+    J = [rng.integers(0, n, 8) for _ in range(nb)]
+    out = H.extract_blocks(I, J)
+    # reference on 16 of the requests: columns of H through products with unit vectors
+    for b in range(0, nb, 64):
+        E = np.zeros((n, 8))
+        E[J[b], np.arange(8)] = 1.0
+        # (repeated column indices: the unit vectors add up; compare column by column instead)
+        for q in range(8):
+            e = np.zeros((n, 1))
+            e[J[b][q]] = 1.0
+            col = H.mult(e)[:, 0]
+            assert np.abs(out[b][:, q] - col[I[b]]).max() <= 1e-12
+    # device outputs: the two launches plus the index upload
+    ia = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+    r, c = ia(np.concatenate(I)), ia(np.concatenate(J))
+    roff, coff = ia(np.arange(nb + 1) * 8), ia(np.arange(nb + 1) * 8)
+    dout = hk.empty((64, nb))
+    ptrs = (C.c_void_p * nb)(*[dout.ptr + 8 * 64 * b for b in range(nb)])
+    ldo = ia([8] * nb)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        assert L.SPX_d_struct_extract_blocks(H.h, nb, ip(r), ip(roff), ip(c), ip(coff), ptrs, ip(ldo), 0, 1) == 0
+        ts.append((time.perf_counter() - t0) * 1e3)
+    got = dout.get()
+    for b in range(0, nb, 97):
+        assert np.array_equal(got[:, b].reshape(8, 8, order="F"), out[b])
+    print("extract 1000 8x8 blocks at N = 1e5: %.2f ms (best of 5: %s)" % (min(ts), ["%.2f" % t for t in ts]))
+    assert min(ts) < 5.0, ts
+    H.destroy()
+    hk.close()
+
+
 def test_multi_rhs_hybrid_sweeps(L):
     HC.check_multi_rhs(L, n=4000, leaf=128, nrhs_list=(5, 13, 64))
     HC.check_multi_rhs(L, n=3001, leaf=256, nrhs_list=(12, 64))
