@@ -271,7 +271,11 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   // levels -- small blocks, a chain of dependent levels -- stay in the single launch; the leaves' results reach it through
   // the hand-off buffers like any child's (a value that is already there is taken without waiting).
   bool whole = false;
-  if (fuse && !dist_subtree_ && nrhs >= hybrid_nrhs() && !ups_own.empty() && ups_own.size() > 1) {
+  // (also whenever the leaves are beyond the sweep kernels' 256 rows -- leaf size 512 --: their level as batched launches, the
+  // inner levels, whose nodes are small, still in the single launch instead of two to four launches per level)
+  bool big_leaves = false;
+  for (int id : ups_own.empty() ? std::vector<int>() : ups_own[0]) big_leaves = big_leaves || nodes_[id].m > 256;
+  if (fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && !ups_own.empty() && ups_own.size() > 1) {
     Levels up_in(ups_own.begin() + 1, ups_own.end()), down_in;
     for (auto& ids : downs_own) {
       std::vector<int> v;

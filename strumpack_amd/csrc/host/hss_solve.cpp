@@ -292,7 +292,10 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   };
   // many right-hand sides (hybrid, see mult_sub): the leaf level as batched MFMA GEMMs over all right-hand sides (the
   // blocks of the leaves -- X, R~, WQ, Vt0, Q~: most of the bytes -- read once), the inner levels in the single launches
-  const bool hybrid = fuse && !dist_subtree_ && nrhs >= hybrid_nrhs() && own_by_height_.size() > 1;
+  bool big_leaves = false;   // (leaves beyond the sweep kernels' 256 rows -- leaf size 512 -- take the same route for any nrhs)
+  if (!own_by_height_.empty())
+    for (int id : own_by_height_[0]) big_leaves = big_leaves || nodes_[id].m > 256;
+  const bool hybrid = fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && own_by_height_.size() > 1;
   bool fwd_done = false;
   if (hybrid) {
     Levels inner(own_by_height_.begin() + 1, own_by_height_.end());

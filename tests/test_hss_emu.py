@@ -45,6 +45,12 @@ def test_ragged_sizes_vs_oracle(L, prob, n, leaf, algo):
     HC.check_vs_oracle(L, prob, n, leaf, 1e-6, 1e-12, algo, 16, 8)
 
 
+def test_leaves_beyond_256_rows_vs_oracle(L):
+    # leaf size above the register / single-launch kernels' 256 rows (the reference's default leaf size is 512): streaming
+    # ID, blocked QR, leaf level of the sweeps as batched launches with the inner levels in the single launch
+    HC.check_vs_oracle(L, "T", 640, 320, 1e-6, 1e-12, "stable", 32, 16)
+
+
 def test_many_samples_vs_oracle(L):
     # more than 256 sample rows: the ID panels take the TSQR pre-reduction (copied out of the samples, not read in place)
     HC.check_vs_oracle(L, "T", 300, 64, 1e-6, 1e-12, "stable", 260, 16)
