@@ -110,6 +110,15 @@ def kernel_workload(a, torch, dist, world, rank, local):
                         "blocks_id": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
            "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "neighbours": int(st["d_final"])},
            "checks": {"solve_resid_H": resid}}
+    # dominant kernel of this workload: the exact nearest-neighbour search (knn_kernel: FP32 distance evaluations on the vector
+    # units, 3 flops per coordinate and candidate), HIP events on the engine's stream around its launches (hssk_watch_*)
+    if st["sketch_launches"] > 0 and st["sketch_kernel_ms"] > 0:
+        ach = st["sketch_kernel_flops"] / (st["sketch_kernel_ms"] * 1e-3) * 1e-12
+        out["roofline"] = {"kernel": "knn_kernel (exact %d nearest neighbours of every point, FP32 distances)" % int(st["d_final"]), "bound": "valu_fp32",
+                           "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                           "avg_launch_ms": st["sketch_kernel_ms"] / st["sketch_launches"], "launches_per_step": int(st["sketch_launches"]),
+                           "flops_per_launch": st["sketch_kernel_flops"] / st["sketch_launches"],
+                           "note": "3 d N^2 flops per search; the kernel is bound by its per-query top-k heaps in LDS (profiles/r02_pmc_knn.md), not by the distance arithmetic"}
     if rank == 0:
         print(json.dumps(out))
     H.destroy()
@@ -299,6 +308,44 @@ def blr_front_workload(a, L, hk, torch):
             out["cpu_baseline"] = {"error": str(e)[:200]}
     print(json.dumps(out))
     F.destroy()
+
+
+def measure_traffic(argv_extra, kernel_match, out_dir=None):
+    """HBM traffic of the dominant kernel from counter passes of THIS command: rocprofv3 --kernel-trace --pmc <counter> in
+    separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), one step each, parsed per kernel.
+    gfx950 correction of the guide: FETCH_SIZE (KB) tallies the 128-byte requests of a wide streaming read at 64 B -> x 2.
+    Returns bytes per launch of the kernels whose name contains `kernel_match` (mean over those launches), or None when
+    rocprofv3 is not available / a pass fails -- never a constant from another run."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe or os.environ.get("STRUMPACK_AMD_BENCH_INNER") or os.environ.get("STRUMPACK_AMD_BENCH_NO_PMC"):
+        return None
+    res = {}
+    tmp = out_dir or tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, STRUMPACK_AMD_BENCH_INNER="1", TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + argv_extra
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not fs:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(fs[0])) if kernel_match in row["Kernel_Name"]]
+            if not vals:
+                return None
+            res[counter] = sum(vals) / len(vals) * 1024.0     # KB -> bytes per launch
+    except Exception:
+        return None
+    finally:
+        if not out_dir:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"read_bytes": 2.0 * res["FETCH_SIZE"], "write_bytes": res["WRITE_SIZE"], "bytes": 2.0 * res["FETCH_SIZE"] + res["WRITE_SIZE"]}
 
 
 def _ref_sample(R, n, leaf, rel_tol):
@@ -537,10 +584,16 @@ def main():
     # workgroup slots; the short tail / edge launches are separate kernels outside the event bracket)
     flops_per_launch = st["sketch_kernel_flops"] / launches
     ach = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(tf) and n == 100000 and world == 1:
-        traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+    # HBM bytes of the dominant kernel's launches, from counter passes of this very command (None without rocprofv3)
+    traffic = tsrc = None
+    if rank == 0 and world == 1 and a.sketch == "gaussian" and not os.environ.get("STRUMPACK_AMD_BENCH_INNER"):
+        extra = ["--size", str(n), "--leaf", str(a.leaf), "--rel-tol", str(a.rel_tol), "--nrhs", str(a.nrhs)]
+        tmain = measure_traffic(extra, "true, 0>")   # the MAIN launches of the sketch: dgemm_kernel<192, (transposed), full tiles, group 0>
+        if tmain is not None:
+            traffic = tmain["bytes"]
+            tsrc = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (one step each), main launches of "
+                    "dgemm_kernel<192, ., true, 0>: read %.1f GB (FETCH_SIZE x 2, the guide's gfx950 correction) + written %.2f GB per launch"
+                    % (tmain["read_bytes"] * 1e-9, tmain["write_bytes"] * 1e-9))
     out = {
         "metric": "hss_compress_ulv_factor_solve_gflops", "value": value, "unit": "GFLOP/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -571,7 +624,7 @@ def main():
         "roofline": {"kernel": "dgemm_kernel<192> (sketch S^T = R^T op(A), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                      "traffic": traffic,
-                     "traffic_source": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier box (tools/round_profile.sh), not a counter read of this run" if traffic else None,
+                     "traffic_source": tsrc, "algorithmic_bytes_per_launch": 8.0 * st["sketch_kernel_flops"] / launches / (2.0 * d) + 8.0 * d * n if d else None,
                      "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
     if a.sketch == "sjlt":

@@ -35,7 +35,18 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       int q0 = 0, q1 = N;
       if (dist_subtree_) { const Node& c = nodes_[cut_nodes_[o_.rank]]; q0 = c.lo; q1 = c.lo + c.m; }
       int* dann = work_->ints((size_t)k * N);
+      // (the search kernel on the device clock: bench.py --workload kernel reports it against the FP32 vector roof --
+      //  3 flops per coordinate and candidate: subtract, multiply, add)
+      ck(hssk_watch_start(ctx_, 7));
       ck(hssk_knn(ctx_, dX, dim, N, k, q0, q1, dann));
+      ck(hssk_watch_stop(ctx_, 7));
+      {
+        int pairs = 0;
+        const double ms = hssk_watch_read_ms(ctx_, 7, &pairs);
+        stats_.sketch_kernel_ms += ms;
+        stats_.sketch_kernel_flops += 3.0 * dim * (double)N * (double)(q1 - q0);
+        stats_.sketch_launches += pairs;
+      }
       ck(hssk_memcpy_d2h(ctx_, ann.data() + (size_t)k * q0, dann + (size_t)k * q0, (long long)sizeof(int) * k * (q1 - q0)));
     }
     if ((user_ann && k == user_k) || ks.neighbors) {
