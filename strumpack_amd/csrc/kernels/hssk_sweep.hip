@@ -430,8 +430,12 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
   for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * SW_MAX]);
 }
 
-template <int NR>
+// LOOP: the groups of right-hand sides in turn inside the workgroup (many groups); otherwise one group per workgroup along
+// blockIdx.y -- the few-right-hand-side form keeps the straight-line body (the loop and its closing barrier cost the
+// single-vector solve 15 percent)
+template <int NR, bool LOOP>
 __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
+  if (!LOOP) { ulv_fwd_body<NR>(descs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
     ulv_fwd_body<NR>(descs, nrhs_total, err, g);
     __syncthreads();   // (the LDS vectors are reused by the next group)
@@ -475,8 +479,12 @@ __device__ __forceinline__ void ulv_bwd_body(const hssk_sweep_bwd_desc* __restri
   }
 }
 
-template <int NR>
+// LOOP: the groups of right-hand sides in turn inside the workgroup (many groups); otherwise one group per workgroup along
+// blockIdx.y -- the few-right-hand-side form keeps the straight-line body (the loop and its closing barrier cost the
+// single-vector solve 15 percent)
+template <int NR, bool LOOP>
 __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err) {
+  if (!LOOP) { ulv_bwd_body<NR>(descs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
     ulv_bwd_body<NR>(descs, nrhs_total, err, g);
     __syncthreads();
@@ -578,9 +586,10 @@ __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict_
   for (int e = tid; e < mout * nrhs; e += SW_T) hssk_cstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
 }
 
-template <int NR>
+template <int NR, bool LOOP>
 __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
                                                            const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err) {
+  if (!LOOP) { apply_body<NR>(ups, nup, downs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
     apply_body<NR>(ups, nup, downs, nrhs_total, err, g);
     __syncthreads();
@@ -682,8 +691,10 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
     if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
-  if (nrhs == 1) HSSK_LAUNCH(ulv_fwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(ulv_fwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs, 1)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  const unsigned gy = groups_y(nrhs, 1);
+  if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, false>), dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, false>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, true>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -695,8 +706,10 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
-  if (nrhs == 1) HSSK_LAUNCH(ulv_bwd_sweep_kernel<1>, dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(ulv_bwd_sweep_kernel<SW_NR>, dim3((unsigned)count, groups_y(nrhs, 2)), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  const unsigned gy = groups_y(nrhs, 2);
+  if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, false>), dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, false>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, true>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -715,9 +728,10 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   }
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
-  if (nrhs == 1) HSSK_LAUNCH(apply_sweep_kernel<1>, dim3((unsigned)(nup + ndown), 1u), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH(apply_sweep_kernel<SW_NR>, dim3((unsigned)(nup + ndown), groups_y(nrhs, 0)), dim3(SW_T), 0, ctx->stream, du, nup,
-                   dn, nrhs, sweep_err(ctx));
+  const unsigned gy = groups_y(nrhs, 0);
+  if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, false>), dim3((unsigned)(nup + ndown), 1u), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, false>), dim3((unsigned)(nup + ndown), gy), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else HSSK_LAUNCH((apply_sweep_kernel<SW_NR, true>), dim3((unsigned)(nup + ndown), gy), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
