@@ -19,20 +19,27 @@ extern thread_local std::vector<std::function<void()>>* sink;   // non-null whil
 // pinned block: replaying it costs one kernel launch per step and no host-side descriptor work.
 struct hssk_plan {
   std::vector<std::function<void()>> launches;
-  std::vector<std::pair<char*, size_t>> blocks;   // pinned, device-visible descriptor storage
+  // descriptor storage of the recorded launches: DEVICE memory, with a pinned shadow the descriptors are staged through (one
+  // stream-ordered copy per table while the plan is recorded).  The first version kept the tables in pinned host memory and
+  // let the kernels read them in place: every replayed launch then fetched its descriptors across PCIe -- ~15 us on each of
+  // the batched launches of a many-right-hand-side sweep, and the first microseconds of every workgroup of the single-launch
+  // sweeps.
+  struct Block { char* dev; char* shadow; size_t size; };
+  std::vector<Block> blocks;
   size_t off = 0;
-  char* alloc(size_t bytes) {
+  char* alloc(size_t bytes, char** shadow) {
     const size_t need = (bytes + 255) & ~size_t(255);
-    if (blocks.empty() || off + need > blocks.back().second) {
+    if (blocks.empty() || off + need > blocks.back().size) {
       const size_t sz = std::max<size_t>(need, size_t(1) << 20);
-      blocks.emplace_back((char*)hssk_rt::pinned_malloc(sz), sz);
+      blocks.push_back(Block{(char*)hssk_rt::dev_malloc(sz), (char*)hssk_rt::pinned_malloc(sz), sz});
       off = 0;
     }
-    char* p = blocks.back().first + off;
+    char* p = blocks.back().dev + off;
+    *shadow = blocks.back().shadow + off;
     off += need;
     return p;
   }
-  ~hssk_plan() { for (auto& b : blocks) hssk_rt::pinned_free(b.first); }
+  ~hssk_plan() { for (auto& b : blocks) { hssk_rt::dev_free(b.dev); hssk_rt::pinned_free(b.shadow); } }
 };
 
 struct hssk_uploader;
@@ -66,9 +73,11 @@ struct hssk_ctx {
   // enqueued on `stream` after this call)
   hssk_plan* recording = nullptr;
   void* stage(const void* host, size_t bytes) {
-    if (recording) {   // descriptors of a recorded sweep live as long as the plan
-      char* p = recording->alloc(bytes);
-      std::memcpy(p, host, bytes);
+    if (recording) {   // descriptors of a recorded sweep live as long as the plan, in device memory
+      char* shadow = nullptr;
+      char* p = recording->alloc(bytes, &shadow);
+      std::memcpy(shadow, host, bytes);
+      hssk_rt::h2d(p, shadow, bytes, stream);
       return p;
     }
     size_t need = (bytes + 255) & ~size_t(255);

@@ -36,6 +36,11 @@ constexpr int SW_T = 256;     // threads per workgroup
 constexpr int SW_NR = 4;      // right-hand sides handled at once (kernels are instantiated for NR = 4 and NR = 1)
 constexpr int SW_MAX = 256;   // largest node dimension (rows of a basis)
 constexpr int SW_NB = 64;     // block size of the substitution with R~^T (hssk_trtri_diag_vbatched)
+// wide instantiation for many right-hand sides on small nodes (the inner levels of the hybrid path, hss_apply.cpp /
+// hss_solve.cpp): sixteen right-hand sides per pass, node dimensions up to 128 -- a quarter of the passes (and of their
+// barrier-separated stages) through every node; LDS 112 KB for the forward sweep
+constexpr int SW_NRW = 16;
+constexpr int SW_MAXW = 128;
 constexpr long SW_SPIN_LIMIT = 1L << 22;
 
 // ---- hand-off between workgroups of one launch ---------------------------------------------------------------------
@@ -62,7 +67,7 @@ __global__ void sweep_fill_kernel(double* p, long long count) {
     hssk_cstore(p, (size_t)e, hssk_from_bits(SW_SENTINEL));
 }
 
-// ---- workgroup GEMVs on LDS vectors (leading dimension SW_MAX per right-hand side) -----------------------------------
+// ---- workgroup GEMVs on LDS vectors (leading dimension LDV per right-hand side) -----------------------------------
 enum { OP_SET = 0, OP_ADD = 1, OP_SUB = 2 };
 __device__ __forceinline__ void apply_op(double* o, double v, int op) {
   *o = op == OP_SET ? v : (op == OP_ADD ? *o + v : *o - v);
@@ -76,7 +81,7 @@ __device__ __forceinline__ void apply_op(double* o, double v, int op) {
 struct RowOp {
   const double* a;   // first element of the row
   int lda, K;
-  const double* x;   // LDS vector (leading dimension SW_MAX per right-hand side)
+  const double* x;   // LDS vector (leading dimension LDV per right-hand side)
   double* o;         // LDS output element of the row (same leading dimension)
   int op;
 };
@@ -112,7 +117,7 @@ __device__ __forceinline__ void rows_prefetch(int Mtot, F rowop, Pre& pre) {
 #pragma unroll
   for (int u = 0; u < SW_PRE; u++) pre.v[u] = (sl.act && sl.k0 + u < sl.k1) ? hssk_gload(sl.ro.a, (size_t)(sl.k0 + u) * sl.ro.lda) : 0.;
 }
-template <int NR, class F>
+template <int NR, int LDV, class F>
 __device__ __forceinline__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s_p, const Pre& pre, bool use_pre) {
   for (int r0 = 0; r0 < Mtot || r0 == 0; r0 += SW_T) {
     const RowSlice sl = rows_slice(Mtot, r0, rowop);
@@ -127,7 +132,7 @@ __device__ __forceinline__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s
           if (sl.k0 + u < sl.k1) {
             const double t = pre.v[u];
 #pragma unroll
-            for (int c = 0; c < NR; c++) acc[c] += t * ro.x[sl.k0 + u + c * SW_MAX];
+            for (int c = 0; c < NR; c++) acc[c] += t * ro.x[sl.k0 + u + c * LDV];
           }
         }
         k = min(sl.k1, sl.k0 + SW_PRE);
@@ -142,13 +147,13 @@ __device__ __forceinline__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s
         for (int u = 0; u < SW_GRP; u++) {
           const int kk = min(k + u, sl.k1 - 1);
 #pragma unroll
-          for (int c = 0; c < NR; c++) acc[c] += t[u] * ro.x[kk + c * SW_MAX];
+          for (int c = 0; c < NR; c++) acc[c] += t[u] * ro.x[kk + c * LDV];
         }
       }
     }
     if (P == 1) {
       if (i < M)
-        for (int c = 0; c < nrhs; c++) apply_op(ro.o + c * SW_MAX, acc[c], ro.op);
+        for (int c = 0; c < nrhs; c++) apply_op(ro.o + c * LDV, acc[c], ro.op);
       __syncthreads();
       continue;
     }
@@ -160,22 +165,22 @@ __device__ __forceinline__ void gemv_rows(int Mtot, F rowop, int nrhs, double* s
       for (int c = 0; c < nrhs; c++) {
         double v = 0.;
         for (int q = 0; q < P; q++) v += s_p[(q * NR + c) * M64 + i];
-        apply_op(ro.o + c * SW_MAX, v, ro.op);
+        apply_op(ro.o + c * LDV, v, ro.op);
       }
     __syncthreads();
   }
 }
 // out[i] (op)= sum_{k < K} A[i + k lda] x[k],  i < M
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
                                        double* s_p, const Pre& pre, bool use_pre) {
-  gemv_rows<NR>(M, [=](int i) { return RowOp{A + i, lda, K, x, out + i, op}; }, nrhs, s_p, pre, use_pre);
+  gemv_rows<NR, LDV>(M, [=](int i) { return RowOp{A + i, lda, K, x, out + i, op}; }, nrhs, s_p, pre, use_pre);
 }
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void gemv_n(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
                                        double* s_p) {
   Pre none;
-  gemv_n<NR>(A, lda, M, K, x, out, nrhs, op, s_p, none, false);
+  gemv_n<NR, LDV>(A, lda, M, K, x, out, nrhs, op, s_p, none, false);
 }
 __device__ __forceinline__ void gemv_n_prefetch(const double* __restrict__ A, int lda, int M, int K, Pre& pre) {
   rows_prefetch(M, [=](int i) { return RowOp{A + i, lda, K, nullptr, nullptr, 0}; }, pre);
@@ -203,7 +208,7 @@ __device__ __forceinline__ void gemv_t_prefetch(const double* __restrict__ A, in
 #pragma unroll
   for (int u = 0; u < SW_PRE; u++) pre.v[u] = (j < N && i0 + u < i1) ? hssk_gload(A + (size_t)j * lda, (size_t)(i0 + u)) : 0.;
 }
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op,
                                        const Pre& pre, bool use_pre) {
   const int tid = threadIdx.x;
@@ -222,7 +227,7 @@ __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, in
           if (i0 + u < i1) {
             const double t = pre.v[u];
 #pragma unroll
-            for (int c = 0; c < NR; c++) acc[c] += t * x[i0 + u + c * SW_MAX];
+            for (int c = 0; c < NR; c++) acc[c] += t * x[i0 + u + c * LDV];
           }
         }
         i = min(i1, i0 + SW_PRE);
@@ -235,7 +240,7 @@ __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, in
         for (int u = 0; u < SW_GRP; u++) {
           const int ii = min(i + u, i1 - 1);
 #pragma unroll
-          for (int c = 0; c < NR; c++) acc[c] += t[u] * x[ii + c * SW_MAX];
+          for (int c = 0; c < NR; c++) acc[c] += t[u] * x[ii + c * LDV];
         }
       }
     }
@@ -243,16 +248,16 @@ __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, in
       double v = acc[c];
       v += hssk_shfl_xor(v, 1);
       v += hssk_shfl_xor(v, 2);
-      if (part == 0 && j < N) apply_op(out + j + c * SW_MAX, v, op);
+      if (part == 0 && j < N) apply_op(out + j + c * LDV, v, op);
     }
   }
   __syncthreads();
 }
 
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op) {
   Pre none;
-  gemv_t<NR>(A, lda, K, N, x, out, nrhs, op, none, false);
+  gemv_t<NR, LDV>(A, lda, K, N, x, out, nrhs, op, none, false);
 }
 
 // ---- forward ULV sweep ---------------------------------------------------------------------------------------------
@@ -270,15 +275,17 @@ __device__ __forceinline__ int rhs_group(int nrhs_total, int group, int& c0) {
   return min(NR, nrhs_total - c0);
 }
 
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err, int group) {
-  HSSK_SHARED double s_f[SW_MAX * NR];    // f, later the block right-hand side of the substitution
-  HSSK_SHARED double s_y[SW_MAX * NR];    // zc(permV[rv:]) first, then y
-  HSSK_SHARED double s_a[SW_MAX * NR];    // stacked children z (inner nodes)
-  HSSK_SHARED double s_t[SW_MAX * NR];    // ft1 (root: block right-hand side)
-  HSSK_SHARED double s_z[SW_MAX * NR];    // z
-  HSSK_SHARED double s_p[SW_T * NR];      // gemv partials
-  HSSK_SHARED int s_piv[SW_MAX];
+  // (LDS carved from the launch's dynamic allocation: the NR = 16 instantiation needs more than the 64 KB static limit)
+  HSSK_DYN_SHARED(double, s_dyn);
+  double* s_f = s_dyn;                 // f, later the block right-hand side of the substitution
+  double* s_y = s_f + LDV * NR;        // zc(permV[rv:]) first, then y
+  double* s_a = s_y + LDV * NR;        // stacked children z (inner nodes)
+  double* s_t = s_a + LDV * NR;        // ft1 (root: block right-hand side)
+  double* s_z = s_t + LDV * NR;        // z
+  double* s_p = s_z + LDV * NR;        // gemv partials (SW_T * NR)
+  int* s_piv = (int*)(s_p + SW_T * NR);   // LDV ints
   hssk_sweep_fwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
@@ -341,24 +348,24 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
   // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] (inner: handed over by the children); zc = stacked children z
   for (int e = tid; e < m * nrhs; e += SW_T) {
     const int i = e % m, c = e / m;
-    s_f[i + c * SW_MAX] = inner ? sweep_take(p.fsrc, i + (size_t)c * p.ldf, err) : hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
+    s_f[i + c * LDV] = inner ? sweep_take(p.fsrc, i + (size_t)c * p.ldf, err) : hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
   }
   if (inner)
-    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * SW_MAX] = sweep_take(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in, err);
+    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * LDV] = sweep_take(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in, err);
   __syncthreads();
   if (inner) {
     if (zpart) {
       // s_z (= s_t2) <- zc(permV[0:rv]);  s_y <- zc(permV[rv:])
       if (tid < mv)
         for (int c = 0; c < nrhs; c++) {
-          const double v = s_a[pv + c * SW_MAX];
-          if (tid < rv) s_z[tid + c * SW_MAX] = v;
-          else s_y[(tid - rv) + c * SW_MAX] = v;
+          const double v = s_a[pv + c * LDV];
+          if (tid < rv) s_z[tid + c * LDV] = v;
+          else s_y[(tid - rv) + c * LDV] = v;
         }
       __syncthreads();
     }
     // one pass: f(0:rU0) -= B01 zc(rV0:), f(rU0:) -= B10 zc(0:rV0)   and   z += XV zc(permV[rv:])   (XV is rv x (mv - rv))
-    gemv_rows<NR>(m + mz, rows1, nrhs, s_p, pre1, pf);
+    gemv_rows<NR, LDV>(m + mz, rows1, nrhs, s_p, pre1, pf);
   }
   if (p.LU) {
     // ---- root: x = U^{-1} L^{-1} P f   (DenseMatrix::solve / getrs, solve.hpp:133-135), block substitution with the
@@ -366,88 +373,89 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
     if (tid < nrhs)
       for (int i = 0; i < m; i++) {
         const int pi = s_piv[i];
-        if (pi != i) { const double a = s_f[i + tid * SW_MAX]; s_f[i + tid * SW_MAX] = s_f[pi + tid * SW_MAX]; s_f[pi + tid * SW_MAX] = a; }
+        if (pi != i) { const double a = s_f[i + tid * LDV]; s_f[i + tid * LDV] = s_f[pi + tid * LDV]; s_f[pi + tid * LDV] = a; }
       }
     __syncthreads();
     for (int b0 = 0, blk = 0; b0 < m; b0 += SW_NB, blk++) {
       const int nb = min(SW_NB, m - b0);
-      for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+      for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * LDV] = s_f[b0 + (e % nb) + (e / nb) * LDV];
       __syncthreads();
-      gemv_n<NR>(p.TinvL + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
+      gemv_n<NR, LDV>(p.TinvL + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
       const int rest = m - b0 - nb;
       if (rest > 0) {
-        for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+        for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * LDV] = s_f[b0 + (e % nb) + (e / nb) * LDV];
         __syncthreads();
-        gemv_n<NR>(p.LU + (b0 + nb) + (size_t)b0 * m, m, rest, nb, s_t, s_f + b0 + nb, nrhs, OP_SUB, s_p);
+        gemv_n<NR, LDV>(p.LU + (b0 + nb) + (size_t)b0 * m, m, rest, nb, s_t, s_f + b0 + nb, nrhs, OP_SUB, s_p);
       }
     }
     for (int blk = (m - 1) / SW_NB; blk >= 0; blk--) {
       const int b0 = blk * SW_NB, nb = min(SW_NB, m - b0);
-      for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+      for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * LDV] = s_f[b0 + (e % nb) + (e / nb) * LDV];
       __syncthreads();
-      gemv_n<NR>(p.TinvU + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
+      gemv_n<NR, LDV>(p.TinvU + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_t, s_f + b0, nrhs, OP_SET, s_p);
       if (b0 > 0) {
-        for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * SW_MAX] = s_f[b0 + (e % nb) + (e / nb) * SW_MAX];
+        for (int e = tid; e < nb * nrhs; e += SW_T) s_t[(e % nb) + (e / nb) * LDV] = s_f[b0 + (e % nb) + (e / nb) * LDV];
         __syncthreads();
-        gemv_n<NR>(p.LU + (size_t)b0 * m, m, b0, nb, s_t, s_f, nrhs, OP_SUB, s_p);
+        gemv_n<NR, LDV>(p.LU + (size_t)b0 * m, m, b0, nb, s_t, s_f, nrhs, OP_SUB, s_p);
       }
     }
-    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.xroot, (e % m) + (size_t)(e / m) * p.ldxr, s_f[(e % m) + (e / m) * SW_MAX]);
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_gstore(p.xroot, (e % m) + (size_t)(e / m) * p.ldxr, s_f[(e % m) + (e / m) * LDV]);
     return;
   }
   // ---- ft1 = f(perm[0:r]) -> s_t, y = f(perm[r:]) -> s_y
   if (tid < m)
     for (int c = 0; c < nrhs; c++) {
-      const double v = s_f[pu + c * SW_MAX];
-      if (tid < r) s_t[tid + c * SW_MAX] = v;
-      else s_y[(tid - r) + c * SW_MAX] = v;
+      const double v = s_f[pu + c * LDV];
+      if (tid < r) s_t[tid + c * LDV] = v;
+      else s_y[(tid - r) + c * LDV] = v;
     }
   if (!inner)
-    for (int e = tid; e < rv * nrhs; e += SW_T) s_z[(e % rv) + (e / rv) * SW_MAX] = 0.;
+    for (int e = tid; e < rv * nrhs; e += SW_T) s_z[(e % rv) + (e / rv) * LDV] = 0.;
   __syncthreads();
   if (q > 0) {
     // ---- y -= X^T ft1   (X is r x q, column k contiguous)
-    if (r > 0) gemv_t<NR>(p.XU, r, r, q, s_t, s_y, nrhs, OP_SUB, pre2, pf);
+    if (r > 0) gemv_t<NR, LDV>(p.XU, r, r, q, s_t, s_y, nrhs, OP_SUB, pre2, pf);
     // ---- y <- R~^{-T} y on 64-row blocks: y_b = Linv_b y_b, then rows below -= R~(b, below)^T y_b
     for (int b0 = 0, blk = 0; b0 < q; b0 += SW_NB, blk++) {
       const int nb = min(SW_NB, q - b0);
-      for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * SW_MAX] = s_y[b0 + (e % nb) + (e / nb) * SW_MAX];
+      for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * LDV] = s_y[b0 + (e % nb) + (e / nb) * LDV];
       __syncthreads();
-      gemv_n<NR>(p.Tinv + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_f, s_y + b0, nrhs, OP_SET, s_p, pre3, pf && blk == 0);
+      gemv_n<NR, LDV>(p.Tinv + (size_t)blk * SW_NB * SW_NB, SW_NB, nb, nb, s_f, s_y + b0, nrhs, OP_SET, s_p, pre3, pf && blk == 0);
       const int rest = q - b0 - nb;
       if (rest > 0) {
         // column k of R~ (rows b0 .. b0+nb contiguous) for k > b0 + nb;  x = y_b (now final) copied to s_f
-        for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * SW_MAX] = s_y[b0 + (e % nb) + (e / nb) * SW_MAX];
+        for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * LDV] = s_y[b0 + (e % nb) + (e / nb) * LDV];
         __syncthreads();
-        gemv_t<NR>(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
+        gemv_t<NR, LDV>(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
       }
     }
-    for (int e = tid; e < q * nrhs; e += SW_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * SW_MAX]);
+    for (int e = tid; e < q * nrhs; e += SW_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * LDV]);
     // ---- one pass over [WQ; Vt0^T] (both (.) x q, rows contiguous):  ft1 -= WQ y   and   z += Vt0^T y
-    gemv_rows<NR>(r + rv, rows4, nrhs, s_p, pre4, pf);
+    gemv_rows<NR, LDV>(r + rv, rows4, nrhs, s_p, pre4, pf);
   }
-  for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * SW_MAX]);
-  for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * SW_MAX]);
+  for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * LDV]);
+  for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * LDV]);
 }
 
 // LOOP: the groups of right-hand sides in turn inside the workgroup (many groups); otherwise one group per workgroup along
 // blockIdx.y -- the few-right-hand-side form keeps the straight-line body (the loop and its closing barrier cost the
 // single-vector solve 15 percent)
-template <int NR, bool LOOP>
+template <int NR, int LDV, bool LOOP>
 __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
-  if (!LOOP) { ulv_fwd_body<NR>(descs, nrhs_total, err, (int)blockIdx.y); return; }
+  if (!LOOP) { ulv_fwd_body<NR, LDV>(descs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
-    ulv_fwd_body<NR>(descs, nrhs_total, err, g);
+    ulv_fwd_body<NR, LDV>(descs, nrhs_total, err, g);
     __syncthreads();   // (the LDS vectors are reused by the next group)
   }
 }
 
 // ---- backward ULV sweep:  x_c = Q~(:, 0:q) y + Q~(:, q:) xpart ; m == r (nothing eliminated): x_c = xpart ------------
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void ulv_bwd_body(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err, int group) {
-  HSSK_SHARED double s_v[SW_MAX * NR];   // [y; xpart]
-  HSSK_SHARED double s_o[SW_MAX * NR];
-  HSSK_SHARED double s_p[SW_T * NR];
+  HSSK_DYN_SHARED(double, s_dyn);
+  double* s_v = s_dyn;                 // [y; xpart]
+  double* s_o = s_v + LDV * NR;
+  double* s_p = s_o + LDV * NR;
   hssk_sweep_bwd_desc p = descs[blockIdx.x];
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r;
@@ -459,46 +467,47 @@ __device__ __forceinline__ void ulv_bwd_body(const hssk_sweep_bwd_desc* __restri
     p.out += (size_t)c0 * p.ldo;
   }
   // the parent-independent part first: s_o = Q~(:, 0:q) y; Q~(:, q:) towards L2
-  for (int e = tid; e < q * nrhs; e += SW_T) s_v[(e % q) + (e / q) * SW_MAX] = hssk_gload(p.y, (e % q) + (size_t)(e / q) * q);
+  for (int e = tid; e < q * nrhs; e += SW_T) s_v[(e % q) + (e / q) * LDV] = hssk_gload(p.y, (e % q) + (size_t)(e / q) * q);
   __syncthreads();
   // (this thread's slice of Q~(:, q:) goes to registers before anything else: it is consumed after the wait)
   const bool pf = q > 0 && r > 0 && p.wait0 >= 0;
   Pre pre;
   if (pf) gemv_n_prefetch(p.Qt + (size_t)q * m, m, m, r, pre);
   if (q > 0) {
-    gemv_n<NR>(p.Qt, m, m, q, s_v, s_o, nrhs, OP_SET, s_p);
+    gemv_n<NR, LDV>(p.Qt, m, m, q, s_v, s_o, nrhs, OP_SET, s_p);
     if (p.wait0 >= 0 && r > SW_PRE) { double sink = 0.; touch(p.Qt + (size_t)q * m, (size_t)m * r, sink); keep(sink, s_p); }
   }
-  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * SW_MAX] = sweep_take(p.xpart, (e % r) + (size_t)(e / r) * p.ldx, err);
+  for (int e = tid; e < r * nrhs; e += SW_T) s_v[q + (e % r) + (e / r) * LDV] = sweep_take(p.xpart, (e % r) + (size_t)(e / r) * p.ldx, err);
   __syncthreads();
   if (q > 0) {
-    if (r > 0) gemv_n<NR>(p.Qt + (size_t)q * m, m, m, r, s_v + q, s_o, nrhs, OP_ADD, s_p, pre, pf);
-    for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_o[(e % m) + (e / m) * SW_MAX]);
+    if (r > 0) gemv_n<NR, LDV>(p.Qt + (size_t)q * m, m, m, r, s_v + q, s_o, nrhs, OP_ADD, s_p, pre, pf);
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_o[(e % m) + (e / m) * LDV]);
   } else {
-    for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * SW_MAX]);
+    for (int e = tid; e < m * nrhs; e += SW_T) hssk_cstore(p.out, (e % m) + (size_t)(e / m) * p.ldo, s_v[(e % m) + (e / m) * LDV]);
   }
 }
 
 // LOOP: the groups of right-hand sides in turn inside the workgroup (many groups); otherwise one group per workgroup along
 // blockIdx.y -- the few-right-hand-side form keeps the straight-line body (the loop and its closing barrier cost the
 // single-vector solve 15 percent)
-template <int NR, bool LOOP>
+template <int NR, int LDV, bool LOOP>
 __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_kernel(const hssk_sweep_bwd_desc* __restrict__ descs, int nrhs_total, int* err) {
-  if (!LOOP) { ulv_bwd_body<NR>(descs, nrhs_total, err, (int)blockIdx.y); return; }
+  if (!LOOP) { ulv_bwd_body<NR, LDV>(descs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
-    ulv_bwd_body<NR>(descs, nrhs_total, err, g);
+    ulv_bwd_body<NR, LDV>(descs, nrhs_total, err, g);
     __syncthreads();
   }
 }
 
 // ---- mat-vec: up-sweep nodes [0, nup) then down-sweep nodes [nup, nup + ndown) in one launch -------------------------------
-template <int NR>
+template <int NR, int LDV>
 __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict__ ups, int nup,
                                            const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err, int group) {
-  HSSK_SHARED double s_x[SW_MAX * NR];
-  HSSK_SHARED double s_g[SW_MAX * NR];
-  HSSK_SHARED double s_o[SW_MAX * NR];
-  HSSK_SHARED double s_p[SW_T * NR];
+  HSSK_DYN_SHARED(double, s_dyn);
+  double* s_x = s_dyn;
+  double* s_g = s_x + LDV * NR;
+  double* s_o = s_g + LDV * NR;
+  double* s_p = s_o + LDV * NR;
   const int tid = threadIdx.x;
   int c0;
   const int nrhs = rhs_group<NR>(nrhs_total, group, c0);
@@ -516,12 +525,12 @@ __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict_
     if (tid < m)
       for (int c = 0; c < nrhs; c++) {
         const double v = handed ? sweep_take(p.src, pk + (size_t)c * p.lds, err) : hssk_gload(p.src, pk + (size_t)c * p.lds);
-        if (tid < r) s_o[tid + c * SW_MAX] = v;
-        else s_g[(tid - r) + c * SW_MAX] = v;
+        if (tid < r) s_o[tid + c * LDV] = v;
+        else s_g[(tid - r) + c * LDV] = v;
       }
     __syncthreads();
-    if (m > r && r > 0) gemv_n<NR>(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p, pre, pf);
-    for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * SW_MAX]);
+    if (m > r && r > 0) gemv_n<NR, LDV>(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p, pre, pf);
+    for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * LDV]);
     return;
   }
   hssk_apply_down_desc p = downs[blockIdx.x - nup];
@@ -541,12 +550,12 @@ __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict_
   if (p.D) {
     // ---- leaf: y = op(D) x + beta y + U tmp2.  op(D) x does not depend on the tree: it runs before the wait.
     const int m = p.m;
-    for (int e = tid; e < m * nrhs; e += SW_T) s_x[(e % m) + (e / m) * SW_MAX] = hssk_gload(p.x, (e % m) + (size_t)(e / m) * p.ldx);
+    for (int e = tid; e < m * nrhs; e += SW_T) s_x[(e % m) + (e / m) * LDV] = hssk_gload(p.x, (e % m) + (size_t)(e / m) * p.ldx);
     __syncthreads();
-    if (p.trans) gemv_t<NR>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
-    else gemv_n<NR>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET, s_p);
+    if (p.trans) gemv_t<NR, LDV>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
+    else gemv_n<NR, LDV>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET, s_p);
     if (p.beta != 0.) {
-      for (int e = tid; e < m * nrhs; e += SW_T) s_o[(e % m) + (e / m) * SW_MAX] += p.beta * hssk_gload(p.out, (e % m) + (size_t)(e / m) * p.ldo);
+      for (int e = tid; e < m * nrhs; e += SW_T) s_o[(e % m) + (e / m) * LDV] += p.beta * hssk_gload(p.out, (e % m) + (size_t)(e / m) * p.ldo);
       __syncthreads();
     }
   } else {
@@ -563,35 +572,35 @@ __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict_
       if (p.ro_a > 0 && p.ri_b > 0) gemv_t_prefetch(p.B10, p.ri_b, p.ri_b, p.ro_a, preB);
       if (p.ro_b > 0 && p.ri_a > 0) gemv_t_prefetch(p.B01, p.ri_a, p.ri_a, p.ro_b, preB2);
     }
-    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * SW_MAX] = sweep_take(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1, err);
-    for (int e = tid; e < nto * nrhs; e += SW_T) s_o[(e % nto) + (e / nto) * SW_MAX] = 0.;
+    for (int e = tid; e < nt1 * nrhs; e += SW_T) s_x[(e % nt1) + (e / nt1) * LDV] = sweep_take(p.t1, (e % nt1) + (size_t)(e / nt1) * p.ldt1, err);
+    for (int e = tid; e < nto * nrhs; e += SW_T) s_o[(e % nto) + (e / nto) * LDV] = 0.;
     __syncthreads();
-    if (!p.trans) gemv_rows<NR>(nto, rowsB, nrhs, s_p, preB, true);
+    if (!p.trans) gemv_rows<NR, LDV>(nto, rowsB, nrhs, s_p, preB, true);
     else {            // B10 is ri_b x ro_a, B01 is ri_a x ro_b
-      if (p.ro_a > 0 && p.ri_b > 0) gemv_t<NR>(p.B10, p.ri_b, p.ri_b, p.ro_a, s_x + p.ri_a, s_o, nrhs, OP_SET, preB, true);
-      if (p.ro_b > 0 && p.ri_a > 0) gemv_t<NR>(p.B01, p.ri_a, p.ri_a, p.ro_b, s_x, s_o + p.ro_a, nrhs, OP_SET, preB2, true);
+      if (p.ro_a > 0 && p.ri_b > 0) gemv_t<NR, LDV>(p.B10, p.ri_b, p.ri_b, p.ro_a, s_x + p.ri_a, s_o, nrhs, OP_SET, preB, true);
+      if (p.ro_b > 0 && p.ri_a > 0) gemv_t<NR, LDV>(p.B01, p.ri_a, p.ri_a, p.ro_b, s_x, s_o + p.ro_a, nrhs, OP_SET, preB2, true);
     }
   }
   // ---- + U tmp2:  out(perm[k]) += tmp2(k), k < ro ;  out(perm[ro + j]) += sum_k X(k, j) tmp2(k)   (X is ro x (mo - ro))
   if (expand) {
     if (p.wait0 >= 0 && mo - ro > SW_T / 4) { double sink = 0.; touch(p.X, (size_t)ro * (mo - ro), sink); keep(sink, s_p); }
-    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * SW_MAX] = sweep_take(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2, err);
+    for (int e = tid; e < ro * nrhs; e += SW_T) s_x[(e % ro) + (e / ro) * LDV] = sweep_take(p.tmp2, (e % ro) + (size_t)(e / ro) * p.ld2, err);
     __syncthreads();
-    if (mo > ro) gemv_t<NR>(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET, preX, pfX);
+    if (mo > ro) gemv_t<NR, LDV>(p.X, ro, ro, mo - ro, s_x, s_g, nrhs, OP_SET, preX, pfX);
     if (tid < mo)
-      for (int c = 0; c < nrhs; c++) s_o[pk + c * SW_MAX] += tid < ro ? s_x[tid + c * SW_MAX] : s_g[(tid - ro) + c * SW_MAX];
+      for (int c = 0; c < nrhs; c++) s_o[pk + c * LDV] += tid < ro ? s_x[tid + c * LDV] : s_g[(tid - ro) + c * LDV];
     __syncthreads();
   }
   const int mout = p.D ? p.m : p.ro_a + p.ro_b;
-  for (int e = tid; e < mout * nrhs; e += SW_T) hssk_cstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * SW_MAX]);
+  for (int e = tid; e < mout * nrhs; e += SW_T) hssk_cstore(p.out, (e % mout) + (size_t)(e / mout) * p.ldo, s_o[(e % mout) + (e / mout) * LDV]);
 }
 
-template <int NR, bool LOOP>
+template <int NR, int LDV, bool LOOP>
 __global__ __launch_bounds__(SW_T) void apply_sweep_kernel(const hssk_apply_up_desc* __restrict__ ups, int nup,
                                                            const hssk_apply_down_desc* __restrict__ downs, int nrhs_total, int* err) {
-  if (!LOOP) { apply_body<NR>(ups, nup, downs, nrhs_total, err, (int)blockIdx.y); return; }
+  if (!LOOP) { apply_body<NR, LDV>(ups, nup, downs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
-    apply_body<NR>(ups, nup, downs, nrhs_total, err, g);
+    apply_body<NR, LDV>(ups, nup, downs, nrhs_total, err, g);
     __syncthreads();
   }
 }
@@ -653,6 +662,10 @@ unsigned groups_y(int nrhs, int which) {
   const int g = (nrhs + SW_NR - 1) / SW_NR;
   return (unsigned)(g <= lim[which] ? g : 1);
 }
+bool wide_ok(int nrhs, int dmax) {
+  static const bool off = [] { const char* e = std::getenv("HSSK_SWEEP_NO_WIDE"); return e && e[0] == '1'; }();
+  return !off && nrhs >= SW_NRW && dmax <= SW_MAXW;
+}
 int* sweep_err(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) {
     ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64);
@@ -691,10 +704,17 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
     if (descs[i].m > SW_MAX || descs[i].mv > SW_MAX || descs[i].m < 0 || descs[i].wait0 >= i || descs[i].wait1 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_fwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
+  int dmax = 0;
+  for (int i = 0; i < count; i++) dmax = std::max(dmax, std::max(descs[i].m, descs[i].mv));
   const unsigned gy = groups_y(nrhs, 1);
-  if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, false>), dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, false>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, true>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)5 * ldv * nr + (size_t)SW_T * nr) + sizeof(int) * (size_t)ldv; };
+  if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if (wide_ok(nrhs, dmax)) {
+    // many right-hand sides, small nodes (the inner levels of the hybrid path): sixteen right-hand sides per pass
+    hssk_rt::allow_dynamic_lds(ulv_fwd_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
+    HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3((unsigned)count, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, dd, nrhs, sweep_err(ctx));
+  } else HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, true>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -706,10 +726,16 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   for (int i = 0; i < count; i++)
     if (descs[i].m > SW_MAX || descs[i].wait0 >= i) HSSK_UNSUPPORTED("operands beyond the single-launch sweep");
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  int dmax = 0;
+  for (int i = 0; i < count; i++) dmax = std::max(dmax, descs[i].m);
   const unsigned gy = groups_y(nrhs, 2);
-  if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, false>), dim3((unsigned)count, 1u), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, false>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, true>), dim3((unsigned)count, gy), dim3(SW_T), 0, ctx->stream, dd, nrhs, sweep_err(ctx));
+  auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)2 * ldv * nr + (size_t)SW_T * nr); };
+  if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if (wide_ok(nrhs, dmax)) {
+    hssk_rt::allow_dynamic_lds(ulv_bwd_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
+    HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3((unsigned)count, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, dd, nrhs, sweep_err(ctx));
+  } else HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, true>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -728,10 +754,18 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   }
   const hssk_apply_up_desc* du = nup ? (const hssk_apply_up_desc*)ctx->stage(ups, sizeof(*ups) * nup) : nullptr;
   const hssk_apply_down_desc* dn = ndown ? (const hssk_apply_down_desc*)ctx->stage(downs, sizeof(*downs) * ndown) : nullptr;
+  int dmax = 0;
+  for (int i = 0; i < nup; i++) dmax = std::max(dmax, ups[i].m);
+  for (int i = 0; i < ndown; i++) dmax = std::max(dmax, std::max(std::max(downs[i].mo, downs[i].m), std::max(downs[i].ri_a + downs[i].ri_b, downs[i].ro_a + downs[i].ro_b)));
   const unsigned gy = groups_y(nrhs, 0);
-  if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, false>), dim3((unsigned)(nup + ndown), 1u), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, false>), dim3((unsigned)(nup + ndown), gy), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else HSSK_LAUNCH((apply_sweep_kernel<SW_NR, true>), dim3((unsigned)(nup + ndown), gy), dim3(SW_T), 0, ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  const unsigned nwg = (unsigned)(nup + ndown);
+  auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)3 * ldv * nr + (size_t)SW_T * nr); };
+  if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, SW_MAX, false>), dim3(nwg, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, false>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else if (wide_ok(nrhs, dmax)) {
+    hssk_rt::allow_dynamic_lds(apply_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
+    HSSK_LAUNCH((apply_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3(nwg, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  } else HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, true>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
   hssk_rt::check_launch();
   HSSK_API_END
 }
