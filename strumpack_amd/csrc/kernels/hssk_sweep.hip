@@ -709,7 +709,7 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   const unsigned gy = groups_y(nrhs, 1);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)5 * ldv * nr + (size_t)SW_T * nr) + sizeof(int) * (size_t)ldv; };
   if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax)) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
   else if (wide_ok(nrhs, dmax)) {
     // many right-hand sides, small nodes (the inner levels of the hybrid path): sixteen right-hand sides per pass
     hssk_rt::allow_dynamic_lds(ulv_fwd_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
@@ -731,7 +731,7 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   const unsigned gy = groups_y(nrhs, 2);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)2 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax)) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
   else if (wide_ok(nrhs, dmax)) {
     hssk_rt::allow_dynamic_lds(ulv_bwd_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
     HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3((unsigned)count, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -761,7 +761,7 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   const unsigned nwg = (unsigned)(nup + ndown);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)3 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, SW_MAX, false>), dim3(nwg, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, false>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax)) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, false>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
   else if (wide_ok(nrhs, dmax)) {
     hssk_rt::allow_dynamic_lds(apply_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
     HSSK_LAUNCH((apply_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3(nwg, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
