@@ -662,9 +662,18 @@ unsigned groups_y(int nrhs, int which) {
   const int g = (nrhs + SW_NR - 1) / SW_NR;
   return (unsigned)(g <= lim[which] ? g : 1);
 }
-bool wide_ok(int nrhs, int dmax) {
-  static const bool off = [] { const char* e = std::getenv("HSSK_SWEEP_NO_WIDE"); return e && e[0] == '1'; }();
-  return !off && nrhs >= SW_NRW && dmax <= SW_MAXW;
+// which: 0 mat-vec, 1 forward, 2 backward.  Measured at N = 1e5, nrhs = 64, inner levels (profiles/r03_sweeps_nrhs64.md):
+// mat-vec 0.44 ms (four right-hand sides per pass, in turn) -> 0.30 ms wide; backward 0.17 -> 0.12 ms; the forward sweep --
+// the longest chain of dependent stages per node -- is fastest with its sixteen groups of four SIDE BY SIDE (0.44 ms; 0.56 ms
+// wide, 0.68 ms in turn), so it keeps that form.  HSSK_SWEEP_WIDE = "a,f,b" (0 / 1 each) overrides.
+bool wide_ok(int nrhs, int dmax, int which) {
+  static int on[3] = {1, 0, 1};
+  static const bool init = [] {
+    if (const char* e = std::getenv("HSSK_SWEEP_WIDE")) std::sscanf(e, "%d,%d,%d", &on[0], &on[1], &on[2]);
+    return true;
+  }();
+  (void)init;
+  return on[which] && nrhs >= SW_NRW && dmax <= SW_MAXW;
 }
 int* sweep_err(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) {
@@ -709,8 +718,8 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   const unsigned gy = groups_y(nrhs, 1);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)5 * ldv * nr + (size_t)SW_T * nr) + sizeof(int) * (size_t)ldv; };
   if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax)) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if (wide_ok(nrhs, dmax)) {
+  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax, 1)) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if (wide_ok(nrhs, dmax, 1)) {
     // many right-hand sides, small nodes (the inner levels of the hybrid path): sixteen right-hand sides per pass
     hssk_rt::allow_dynamic_lds(ulv_fwd_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
     HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3((unsigned)count, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -731,8 +740,8 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   const unsigned gy = groups_y(nrhs, 2);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)2 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax)) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
-  else if (wide_ok(nrhs, dmax)) {
+  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax, 2)) HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if (wide_ok(nrhs, dmax, 2)) {
     hssk_rt::allow_dynamic_lds(ulv_bwd_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
     HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3((unsigned)count, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, dd, nrhs, sweep_err(ctx));
   } else HSSK_LAUNCH((ulv_bwd_sweep_kernel<SW_NR, SW_MAX, true>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -761,8 +770,8 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   const unsigned nwg = (unsigned)(nup + ndown);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)3 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, SW_MAX, false>), dim3(nwg, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax)) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, false>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
-  else if (wide_ok(nrhs, dmax)) {
+  else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax, 0)) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, false>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
+  else if (wide_ok(nrhs, dmax, 0)) {
     hssk_rt::allow_dynamic_lds(apply_sweep_kernel<SW_NRW, SW_MAXW, true>, lds(SW_NRW, SW_MAXW));
     HSSK_LAUNCH((apply_sweep_kernel<SW_NRW, SW_MAXW, true>), dim3(nwg, 1u), dim3(SW_T), lds(SW_NRW, SW_MAXW), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
   } else HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, true>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
