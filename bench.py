@@ -403,11 +403,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # TEST HARNESS ONLY (tests/test_dist_cpu.py): STRUMPACK_AMD_BENCH_DRYRUN_LIB names the CPU emulator build of the library;
+    # the run then exercises this file's argument / rendezvous / sharding / reduction path with gloo on a tiny matrix and
+    # prints its line with "dry_run": true and no value -- it measures nothing and is never what the driver runs.
+    dry = os.environ.get("STRUMPACK_AMD_BENCH_DRYRUN_LIB")
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    if os.environ.get("STRUMPACK_AMD_SHARE_GPU"):  # functional check only: several ranks on one GPU
+    if os.environ.get("STRUMPACK_AMD_SHARE_GPU") or dry:  # functional check only: several ranks on one GPU
         local = 0
-    torch.cuda.set_device(local)
+    if dry:
+        os.environ["STRUMPACK_AMD_BACKEND"] = "gloo"
+        os.environ["STRUMPACK_AMD_BENCH_NO_PMC"] = "1"
+        torch.cuda.synchronize = lambda *a_, **k_: None
+    else:
+        torch.cuda.set_device(local)
     os.environ["STRUMPACK_AMD_DEVICE"] = str(local)
     if world > 1:
         dist.init_process_group(os.environ.get("STRUMPACK_AMD_BACKEND", "nccl"),
@@ -419,8 +428,9 @@ def main():
         return
     from strumpack_amd import _loader, capi, dist as sdist
     from strumpack_amd import hssk as K
-    L = capi.load(_loader.lib_path())
-    hk = K.Hssk(_loader.lib_path(), device=local)
+    libpath = dry or _loader.lib_path()
+    L = capi.load(libpath)
+    hk = K.Hssk(libpath, device=local)
     n = a.n
     if a.workload == "host":
         if world > 1:
@@ -627,6 +637,9 @@ def main():
                      "traffic_source": tsrc, "algorithmic_bytes_per_launch": 8.0 * st["sketch_kernel_flops"] / launches / (2.0 * d) + 8.0 * d * n if d else None,
                      "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
+    if dry:
+        out["dry_run"] = True
+        out["value"] = None
     if a.sketch == "sjlt":
         # the flop model counts what is executed (2 nnz flops per element and product), so GFLOP/s is not comparable
         # with the Gaussian run: compare ms_per_step

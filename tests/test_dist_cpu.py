@@ -121,3 +121,26 @@ def test_distributed_hss(tmp_path, world):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DIST_OK" in outs[0], "\n".join(outs)
+
+
+@pytest.mark.parametrize("world", [2])
+def test_bench_rendezvous_dry_run(world):
+    """bench.py launched exactly as the driver launches its multi-GPU run (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W), on the emulator build
+    with gloo (STRUMPACK_AMD_BENCH_DRYRUN_LIB): argument handling, rendezvous, the native-communicator trial and its agreed
+    fall-back, operand sharding, the timed loop's barriers and the max-over-ranks reduction, one JSON line from rank 0."""
+    import json
+    import emu_lib
+    emu_lib.build()
+    env = dict(os.environ, STRUMPACK_AMD_BENCH_DRYRUN_LIB=emu_lib.PATH, HSSK_EMU_THREADS="2", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29571 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--size", "1500", "--leaf", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == world and d["steps"] == 1 and d["warmup"] == 1
+    assert d["metric"] == "hss_compress_ulv_factor_solve_gflops" and d["config"]["n"] == 1500
+    assert d["checks"]["solve_resid_H"] < 1e-10 and d["hss"]["levels"] >= 3
