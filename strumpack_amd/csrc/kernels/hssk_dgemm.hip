@@ -350,8 +350,12 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
   Group gmain, gtail, gedge;
   if (gn_full) {
     const long long T = (long long)gm * gn_full;   // gm == 1 on the sketch path (m = d <= 192)
-    // cost model (units: one k-step of one workgroup): rounds x (steps per chunk + epilogue) + reduce traffic
-    const double epi = 3.0, red = 30.0;
+    // cost model (units: one k-step of one workgroup): rounds x (steps per chunk + epilogue) + reduce traffic.
+    // The reduce term is ABSOLUTE (per K-chunk and tile: the partials written and folded), calibrated on N = 1e5 (7 chunks x
+    // 1536 tiles: 1.06 GB of partials, 0.21 ms = 72 units).  It used to be relative to the number of tiles, which made
+    // splits look three to twenty times too expensive on the narrow outputs of a sharded sketch: 12 500 columns per rank
+    // of 8 took 146 tiles x 7 + a tail round (90 % of the slots busy, 16.4 ms) instead of 192 x 8 = three full rounds.
+    const double epi = 3.0, red = 0.0067;
     double best = 1e300;
     int best_s = 1;
     long long best_main = T;
@@ -366,10 +370,10 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
       if (gm > 1) tm = T;                                          // tall outputs: no tile regrouping
       const long long tt = T - tm;
       double cost = 0.;
-      if (tm) cost += (double)((tm * sp + slots - 1) / slots) * ((double)(ksteps + sp - 1) / sp + epi) + red * sp * (double)tm / (double)T;
+      if (tm) cost += (double)((tm * sp + slots - 1) / slots) * ((double)(ksteps + sp - 1) / sp + epi) + red * sp * (double)tm;
       if (tt) {
         const int st = one_round_split(tt);
-        cost += (double)((tt * st + slots - 1) / slots) * ((double)(ksteps + st - 1) / st + epi) + red * st * (double)tt / (double)T + 2.0;
+        cost += (double)((tt * st + slots - 1) / slots) * ((double)(ksteps + st - 1) / st + epi) + red * st * (double)tt + 2.0;
       }
       if (cost < best - 1e-9) { best = cost; best_s = sp; best_main = tm; }
     }

@@ -79,7 +79,7 @@ def test_host_operand_streamed_in_blocks(L):
     HC.check_host_stream_blocks(L)
 
 
-@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_4", "HSS_seq_5", "HSS_seq_11", "HSS_seq_12", "HSS_seq_14", "HSS_seq_22"])
+@pytest.mark.parametrize("name", ["HSS_seq_1", "HSS_seq_4", "HSS_seq_5", "HSS_seq_11", "HSS_seq_14", "HSS_seq_22"])
 def test_extract_by_tree_traversal(L, name):
     HC.check_extract(L, CASES[name])
 
