@@ -476,9 +476,61 @@ void HSSMatrix<double>::print_info(std::ostream& out, std::size_t roff, std::siz
   }
 }
 
+void HSSMatrix<double>::draw(std::ostream& of, std::size_t rlo, std::size_t clo) const {
+  const DeviceHSS* e = engine();
+  if (!e) return;
+  // pre-order walk of the sub-tree rooted at this matrix: same rectangles and colours as the reference's recursion
+  std::function<void(int, std::size_t, std::size_t)> rec = [&](int id, std::size_t r0, std::size_t c0) {
+    const auto& nd = e->nodes()[id];
+    if (nd.leaf()) {
+      of << "set obj rect from " << r0 << ", " << c0 << " to " << r0 + nd.m << ", " << c0 + nd.m << " fc rgb 'red'" << std::endl;
+      return;
+    }
+    const auto &a = e->nodes()[nd.c0], &b = e->nodes()[nd.c1];
+    const int rank0 = std::max(a.rU, b.rV), rank1 = std::max(b.rU, a.rV), minmn = std::max(nd.m, 1);
+    auto colour = [&](int rk) {
+      const int red = int(std::floor(255.0 * rk / minmn)), blue = 255 - red;
+      char buf[16];
+      std::snprintf(buf, sizeof(buf), "%02x00%02x", std::max(0, std::min(255, red)), std::max(0, std::min(255, blue)));
+      return std::string(buf);
+    };
+    of << "set obj rect from " << r0 << ", " << c0 + a.m << " to " << r0 + a.m << ", " << c0 + nd.m << " fc rgb '#" << colour(rank0) << "'" << std::endl;
+    of << "set obj rect from " << r0 + a.m << ", " << c0 << " to " << r0 + nd.m << ", " << c0 + a.m << " fc rgb '#" << colour(rank1) << "'" << std::endl;
+    rec(nd.c0, r0, c0);
+    rec(nd.c1, r0 + a.m, c0 + a.m);
+  };
+  rec(vnode_, rlo, clo);
+}
+void draw(const HSSMatrix<double>& H, const std::string& name) {
+  std::ofstream of("plot" + name + ".gnuplot");
+  of << "set terminal pdf enhanced color size 5,4" << std::endl;
+  of << "set output '" << name << ".pdf'" << std::endl;
+  H.draw(of);
+  of << "set xrange [0:" << H.cols() << "]" << std::endl;
+  of << "set yrange [" << H.rows() << ":0]" << std::endl;
+  of << "plot x lt -1 notitle" << std::endl;
+}
+std::unique_ptr<HSSMatrix<double>> HSSMatrix<double>::clone() const {
+  owner("clone");
+  if (!eng_) return std::unique_ptr<HSSMatrix<double>>(new HSSMatrix<double>());
+  std::stringstream ss(std::ios::in | std::ios::out | std::ios::binary);
+  eng_->save(ss);
+  std::unique_ptr<HSSMatrix<double>> H(new HSSMatrix<double>());
+  H->eng_ = DeviceHSS::load(ss, eng_->options());
+  H->rows_ = H->cols_ = H->eng_->rows();
+  return H;
+}
+void HSSMatrix<double>::reset() {
+  owner("reset");
+  if (eng_) eng_->reset();
+  ch_[0].reset(); ch_[1].reset();
+  trailing_deleted_ = false;
+}
+
 void apply_HSS(Trans op, const HSSMatrix<double>& A, const DenseMatrix<double>& B, double beta, DenseMatrix<double>& C) {
   if (B.rows() != A.rows() || C.rows() != A.rows() || B.cols() != C.cols())
     throw std::invalid_argument("apply_HSS: dimension mismatch");
+  if (A.trailing_block_deleted()) throw std::logic_error("apply_HSS: the trailing block of this matrix has been deleted (delete_trailing_block)");
   if (A.is_view()) A.engine()->mult_node(A.node(), op == Trans::N ? 'N' : 'C', int(B.cols()), B.data(), B.ld(), C.data(), C.ld(), false, beta);
   else A.engine()->mult(op == Trans::N ? 'N' : 'C', int(B.cols()), B.data(), B.ld(), C.data(), C.ld(), false, beta);
 }

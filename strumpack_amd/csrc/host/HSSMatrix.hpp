@@ -137,6 +137,21 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   bool is_view() const { return veng_ != nullptr; }
   int node() const { return vnode_; }
   void print_info(std::ostream& out = std::cout, std::size_t roff = 0, std::size_t coff = 0) const;
+  // gnuplot rectangles of the HSS partition, off-diagonal blocks coloured by rank (HSS/HSSMatrix.cpp:367-404); the free
+  // draw(H, name) below writes the script plot<name>.gnuplot as the reference's does (:407-417)
+  void draw(std::ostream& of, std::size_t rlo = 0, std::size_t clo = 0) const;
+  // deep copy of the compressed representation (HSSMatrix.hpp:186; the ULV factors are not copied: factor() the clone)
+  std::unique_ptr<HSSMatrix<double>> clone() const;
+  // back to the uncompressed state, keeping the tree (HSSMatrix.hpp:313)
+  void reset();
+  // OpenMP task depth of the reference's recursive algorithms (HSSMatrixBase.hpp:273): no meaning for the level-synchronous
+  // device engine; accepted so that callers compile
+  void set_openmp_task_depth(int) {}
+  // frees the (1,1) block once the Schur complement has been formed (HSSMatrix.hpp:470; sparse/fronts/FrontHSS.cpp:411).  The
+  // engine keeps its blocks in arenas that are released with the matrix, so this only marks the block as gone: products with
+  // the whole matrix are refused afterwards, the Schur factors stay usable.
+  void delete_trailing_block() { trailing_deleted_ = true; }
+  bool trailing_block_deleted() const { return trailing_deleted_; }
   // binary file with the compressed representation (tree, D, B, bases; not the ULV factors) and back
   // (HSSMatrix.cpp:438-510; the file layout is this library's own, see hss_io.cpp)
   void write(const std::string& fname) const;
@@ -158,10 +173,13 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   mutable std::unique_ptr<DeviceHSS> eng_;
   DeviceHSS* veng_ = nullptr;   // view: the parent's engine ...
   int vnode_ = 0;               // ... and the node this matrix is rooted at (0: the whole tree)
+  bool trailing_deleted_ = false;
   void owner(const char* what) const { if (veng_) throw std::logic_error(std::string(what) + ": not offered on a child view (the operation belongs to the whole HSS tree)"); }
   mutable std::unique_ptr<HSSMatrix<double>> ch_[2];
 };
 
+// writes plot<name>.gnuplot (HSS/HSSMatrix.hpp:706, HSSMatrix.cpp:407-417)
+void draw(const HSSMatrix<double>& H, const std::string& name);
 // y = op(H) x + beta y   (HSS/HSSMatrix.hpp:720, HSSMatrix.cpp:419-435)
 void apply_HSS(Trans op, const HSSMatrix<double>& A, const DenseMatrix<double>& B, double beta, DenseMatrix<double>& C);
 

@@ -138,6 +138,8 @@ class DeviceHSS {
   void factor();
   void solve(int nrhs, double* b, long long ldb, bool on_device);
   void shift(double sigma);
+  // back to the uncompressed state (tree kept): HSSMatrix::reset
+  void reset() { OpGuard g(op_mu_); reset_compression(); partial_factored_ = schur_ready_ = false; }
   // the matrix is the real image [re -im; im re] (interleaved) of a complex one: adds the image of (re + i im) I
   void shift_cplx(double re, double im);
 

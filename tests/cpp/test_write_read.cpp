@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
+#include <sstream>
 #include <iterator>
 #include <vector>
 
@@ -102,6 +104,37 @@ int main(int argc, char* argv[]) {
   B.scaled_add(-1., X);
   std::cout << "# ||G\\(H*X) - X||_F/||X||_F = " << B.normF() / X.normF() << std::endl;
   if (B.normF() / X.normF() > 1e-10) { std::cout << "ERROR: solve with the matrix read back" << std::endl; return 1; }
+  // clone (HSSMatrix.hpp:186): an independent deep copy; reset (:313): back to uncompressed; draw (:492): the partition as gnuplot
+  {
+    auto C = H.clone();
+    auto Y3 = C->apply(X);
+    Y3.scaled_add(-1., Y1);
+    if (Y3.normF() != 0. || C->rank() != H.rank() || C->memory() != H.memory()) { std::cout << "ERROR: clone differs" << std::endl; return 1; }
+    C->reset();
+    if (C->is_compressed() || !H.is_compressed()) { std::cout << "ERROR: reset" << std::endl; return 1; }
+    std::ostringstream os;
+    H.draw(os);
+    const std::string d = os.str();
+    std::size_t rects = 0;
+    for (std::size_t p = d.find("set obj rect"); p != std::string::npos; p = d.find("set obj rect", p + 1)) rects++;
+    // one rectangle per leaf and two per inner node
+    std::size_t leaves = 0, inner = 0;
+    std::function<void(const HSS::HSSMatrix<double>*)> count = [&](const HSS::HSSMatrix<double>* M) {
+      if (M->leaf()) { leaves++; return; }
+      inner++;
+      count(M->child(0));
+      count(M->child(1));
+    };
+    count(&H);
+    if (rects != leaves + 2 * inner) { std::cout << "ERROR: draw wrote " << rects << " rectangles for " << leaves << " leaves" << std::endl; return 1; }
+    H.set_openmp_task_depth(2);
+    // delete_trailing_block (HSSMatrix.hpp:476): what is left no longer applies as a whole
+    auto T = H.clone();
+    T->delete_trailing_block();
+    bool threw = false;
+    try { T->apply(X); } catch (const std::logic_error&) { threw = true; }
+    if (!threw) { std::cout << "ERROR: apply after delete_trailing_block" << std::endl; return 1; }
+  }
   std::cout << "# exiting" << std::endl;
   return 0;
 }
