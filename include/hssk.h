@@ -463,6 +463,8 @@ typedef struct hssk_apply_down_desc {
 int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, int nup, const hssk_apply_down_desc* downs, int ndown,
                      int nrhs);
 int hssk_sweep_status(hssk_ctx* ctx);
+/* number of sweeps this process issued in the many-right-hand-side matrix-core form (kernels/hssk_sweep_mma.h) */
+long long hssk_sweep_mma_launches(void);
 /* Tinv (ceil(n/64) blocks of 64 x 64, leading dimension 64) = transposed inverses of the 64 x 64 diagonal blocks of the
  * triangular R (n x n, ldr), zero padded; see `mode`. */
 typedef struct hssk_trtri_desc {

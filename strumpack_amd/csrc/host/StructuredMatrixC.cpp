@@ -495,6 +495,7 @@ int SPX_d_struct_extract_blocks(const CSPStructMat S, int nb, const int* rows, c
 }
 
 // ---- BLR frontal matrix (BLRMatrix::construct_and_partial_factor, BLR/BLRMatrix.cpp:740-1037) -------------------------
+extern "C++" {
 namespace {
 bool g_blr_time_phases = false;
 std::unique_ptr<BLR::DeviceBLR> make_front(int dsep, int dupd, int nt1, const int* t1, int nt2, const int* t2, const CSPOptions* opts) {
@@ -521,6 +522,7 @@ inline BLR::DeviceBLR* front(const SPXBLRFront F) {
   return static_cast<BLR::DeviceBLR*>(F);
 }
 }  // namespace
+}  // extern "C++"
 void SPX_d_blr_front_time_phases(int on) { g_blr_time_phases = on != 0; }
 int SPX_d_blr_front_factor(SPXBLRFront* F, int dsep, int dupd, const double* F11, int ld11, const double* F12, int ld12,
                            const double* F21, int ld21, double* F22, int ld22, int ntiles1, const int* tiles1, int ntiles2,

@@ -195,7 +195,7 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   // few right-hand sides: up-sweep and down-sweep of a set of levels as ONE launch (hssk_apply_sweep: a workgroup per
   // node and direction, dependency flags between them) instead of two to four batched launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_APPLY"); return e && e[0] == '1'; }();
-  const bool fuse = nrhs <= 64 && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
+  const bool fuse = nrhs <= fuse_max_nrhs() && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
   if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto sweep = [&](const Levels* ups, const Levels* downs) -> bool {

@@ -40,6 +40,13 @@ inline int hybrid_nrhs() {
   return v;
 }
 
+// most right-hand sides mult / solve still run through the single-launch sweeps (in groups of 64 inside the launch); beyond,
+// the batched launches per level (STRUMPACK_AMD_FUSE_MAX_NRHS overrides)
+inline int fuse_max_nrhs() {
+  static const int v = [] { const char* e = std::getenv("STRUMPACK_AMD_FUSE_MAX_NRHS"); return e ? std::atoi(e) : 256; }();
+  return v;
+}
+
 // host random stream of the reference (misc/RandomWrapper.hpp:128-191): engine seeded with 0
 struct HostRng {
   std::default_random_engine sj{0};   // SJLT patterns (the reference seeds its generator from the clock, sketch.hpp:266-270)

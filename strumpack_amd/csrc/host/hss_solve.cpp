@@ -73,7 +73,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   // (hssk_ulv_fwd_sweep / _bwd_sweep: a workgroup per node, dependency flags between them) instead of 7 / 3 batched
   // launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
-  const bool fuse = nrhs <= 64 && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
+  const bool fuse = nrhs <= fuse_max_nrhs() && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
   if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto fwd_sweep = [&](const Levels& levels) -> bool {

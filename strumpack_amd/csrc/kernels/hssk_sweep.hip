@@ -26,6 +26,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -675,6 +676,8 @@ bool wide_ok(int nrhs, int dmax, int which) {
   (void)init;
   return on[which] && nrhs >= SW_NRW && dmax <= SW_MAXW;
 }
+#include "hssk_sweep_mma.h"
+
 int* sweep_err(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) {
     ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64);
@@ -684,6 +687,8 @@ int* sweep_err(hssk_ctx* ctx) {
 }
 
 }  // namespace
+
+extern "C" long long hssk_sweep_mma_launches(void) { return mma_launches; }
 
 extern "C" int hssk_sweep_status(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) return 0;
@@ -715,6 +720,29 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   // (a single right-hand side runs the NR = 1 instantiation: a quarter of the LDS reads and fmas of every pass)
   int dmax = 0;
   for (int i = 0; i < count; i++) dmax = std::max(dmax, std::max(descs[i].m, descs[i].mv));
+  if (mma_min_nrhs() > 0 && nrhs >= mma_min_nrhs()) {
+    // many right-hand sides: the node arithmetic on the matrix cores, 64 right-hand sides per pass (hssk_sweep_mma.h)
+    int rows = 0;
+    for (int i = 0; i < count; i++) {
+      const FwdRows R = mm_fwd_rows(descs[i].m, descs[i].r, descs[i].mv, descs[i].rv, descs[i].LU != nullptr);
+      rows = std::max(rows, R.f + R.y + R.a + R.t + R.z);
+    }
+    if (const int nc = mma_width(nrhs, rows, 2 * SW_T)) {
+      const size_t bytes = mma_lds_bytes(nc, rows, 2 * SW_T);
+      mma_launches++;
+      auto go = [&](auto kernel) {
+        hssk_rt::allow_dynamic_lds(kernel, bytes);
+        const int ng = mma_groups(nrhs, nc);
+        HSSK_LAUNCH(kernel, dim3((unsigned)count * ng), dim3(SW_T), bytes, ctx->stream, dd, nrhs, ng, sweep_err(ctx));
+      };
+      if (nc == 64) go(ulv_fwd_sweep_mma_kernel<64>);
+      else if (nc == 32) go(ulv_fwd_sweep_mma_kernel<32>);
+      else go(ulv_fwd_sweep_mma_kernel<16>);
+      hssk_rt::check_launch();
+      return 0;
+    }
+  }
+  if (nrhs > 64) HSSK_UNSUPPORTED("more than 64 right-hand sides on nodes beyond the matrix-core sweep");
   const unsigned gy = groups_y(nrhs, 1);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)5 * ldv * nr + (size_t)SW_T * nr) + sizeof(int) * (size_t)ldv; };
   if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -737,6 +765,23 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   auto* dd = (const hssk_sweep_bwd_desc*)ctx->stage(descs, sizeof(*descs) * count);
   int dmax = 0;
   for (int i = 0; i < count; i++) dmax = std::max(dmax, descs[i].m);
+  if (mma_min_nrhs() > 0 && nrhs >= mma_min_nrhs()) {
+    if (const int nc = mma_width(nrhs, 2 * std::max(dmax, 1), 0)) {
+      const size_t bytes = mma_lds_bytes(nc, 2 * std::max(dmax, 1), 0);
+      mma_launches++;
+      auto go = [&](auto kernel) {
+        hssk_rt::allow_dynamic_lds(kernel, bytes);
+        const int ng = mma_groups(nrhs, nc);
+        HSSK_LAUNCH(kernel, dim3((unsigned)count * ng), dim3(SW_T), bytes, ctx->stream, dd, nrhs, ng, sweep_err(ctx));
+      };
+      if (nc == 64) go(ulv_bwd_sweep_mma_kernel<64>);
+      else if (nc == 32) go(ulv_bwd_sweep_mma_kernel<32>);
+      else go(ulv_bwd_sweep_mma_kernel<16>);
+      hssk_rt::check_launch();
+      return 0;
+    }
+  }
+  if (nrhs > 64) HSSK_UNSUPPORTED("more than 64 right-hand sides on nodes beyond the matrix-core sweep");
   const unsigned gy = groups_y(nrhs, 2);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)2 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -766,8 +811,34 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
   int dmax = 0;
   for (int i = 0; i < nup; i++) dmax = std::max(dmax, ups[i].m);
   for (int i = 0; i < ndown; i++) dmax = std::max(dmax, std::max(std::max(downs[i].mo, downs[i].m), std::max(downs[i].ri_a + downs[i].ri_b, downs[i].ro_a + downs[i].ro_b)));
-  const unsigned gy = groups_y(nrhs, 0);
   const unsigned nwg = (unsigned)(nup + ndown);
+  if (mma_min_nrhs() > 0 && nrhs >= mma_min_nrhs()) {
+    int rows = 0;
+    bool ok = true;
+    for (int i = 0; i < nup; i++) rows = std::max(rows, std::max(ups[i].m, 1));
+    for (int i = 0; i < ndown; i++) {
+      const hssk_apply_down_desc& d = downs[i];
+      if (d.D) { ok = false; break; }   // (leaves: the batched launches of the many-right-hand-side path, or the vector form)
+      rows = std::max(rows, mm_apply_down_rows(d.ri_a + d.ri_b, d.ro, d.ro_a + d.ro_b, d.mo));
+    }
+    const int nc = ok ? mma_width(nrhs, rows, SW_T) : 0;
+    if (nc) {
+      const size_t bytes = mma_lds_bytes(nc, rows, SW_T);
+      mma_launches++;
+      auto go = [&](auto kernel) {
+        hssk_rt::allow_dynamic_lds(kernel, bytes);
+        const int ng = mma_groups(nrhs, nc);
+        HSSK_LAUNCH(kernel, dim3(nwg * ng), dim3(SW_T), bytes, ctx->stream, du, nup, dn, nrhs, ng, sweep_err(ctx));
+      };
+      if (nc == 64) go(apply_sweep_mma_kernel<64>);
+      else if (nc == 32) go(apply_sweep_mma_kernel<32>);
+      else go(apply_sweep_mma_kernel<16>);
+      hssk_rt::check_launch();
+      return 0;
+    }
+  }
+  if (nrhs > 64) HSSK_UNSUPPORTED("more than 64 right-hand sides on nodes beyond the matrix-core sweep");
+  const unsigned gy = groups_y(nrhs, 0);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)3 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, SW_MAX, false>), dim3(nwg, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));
   else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax, 0)) HSSK_LAUNCH((apply_sweep_kernel<SW_NR, SW_MAX, false>), dim3(nwg, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));

@@ -85,7 +85,13 @@ def test_extract_by_tree_traversal(L, name):
 
 
 def test_multi_rhs_hybrid_sweeps(L):
-    HC.check_multi_rhs(L, n=500, leaf=32, nrhs_list=(5, 13, 64))
+    HC.check_multi_rhs(L, n=500, leaf=32, nrhs_list=(5, 13, 20, 64, 100))
+
+
+def test_multi_rhs_matrix_core_sweeps_rank_56(L):
+    """inner nodes of 112 rows and rank 56: more 16-row tiles per stage than a wave prefetches, more k-steps than a tile
+    prefetches, and vectors that only fit the LDS as 32-wide rows (kernels/hssk_sweep_mma.h)"""
+    HC.check_multi_rhs(L, leaf=128, nrhs_list=(40, 70), A=HC.low_rank_plus_identity(1024, 56), d0=96)
 
 
 def test_blr_dense_slice(L):
