@@ -80,6 +80,13 @@ int hssk_is_device_pointer(const void* ptr);
 /* Two contexts = two streams of the same device: the work enqueued on `waiter` from now on starts after everything enqueued so
  * far on `on` has finished (an event recorded on `on`'s stream, waited for by `waiter`'s).  Nothing blocks on the host.  This is how
  * a BLR block step factors its diagonal tile next to the compression of its block row and column. */
+/* Side stream of a context: launches issued between hssk_side_begin and hssk_side_end go to a second stream that first
+ * waits for everything issued on the main stream so far; hssk_side_join makes the main stream wait for them.  For work
+ * that does not depend on what the main stream does meanwhile (the leaves' D x of a mat-vec next to the tree sweep).
+ * Recorded plans (hssk_plan_*) replay the same routing. */
+int hssk_side_begin(hssk_ctx* ctx);
+int hssk_side_end(hssk_ctx* ctx);
+int hssk_side_join(hssk_ctx* ctx);
 int hssk_stream_wait(hssk_ctx* waiter, hssk_ctx* on);
 /* Device-clock stopwatches on the compute stream: hssk_watch_start / _stop bracket the launches in between with HIP events
  * (any number of start / stop pairs per stopwatch); hssk_watch_read_ms synchronises, returns the summed duration of
@@ -459,10 +466,16 @@ typedef struct hssk_apply_down_desc {
   double beta;
   int ld2, mo, ro, m, ldx, trans, ri_a, ri_b, ro_a, ro_b, ldt1, ldo;
   int wait0, wait1, wait2;
+  int acc; /* matrix-core form only: a leaf whose op(D) x + beta out is already in `out` (D == NULL, no t1): out += U tmp2 */
 } hssk_apply_down_desc;
 int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, int nup, const hssk_apply_down_desc* downs, int ndown,
                      int nrhs);
 int hssk_sweep_status(hssk_ctx* ctx);
+/* While set, the three sweeps return 2 (nothing issued) for operands their matrix-core form (kernels/hssk_sweep_mma.h: at
+ * least hssk_sweep_mma_min_nrhs() right-hand sides, node vectors that fit the LDS) does not take, instead of running the
+ * vector form: callers with a better alternative for that case (batched launches per level) ask first. */
+int hssk_sweep_require_mma(hssk_ctx* ctx, int on);
+int hssk_sweep_mma_min_nrhs(void);
 /* number of sweeps this process issued in the many-right-hand-side matrix-core form (kernels/hssk_sweep_mma.h) */
 long long hssk_sweep_mma_launches(void);
 /* Tinv (ceil(n/64) blocks of 64 x 64, leading dimension 64) = transposed inverses of the 64 x 64 diagonal blocks of the

@@ -136,7 +136,9 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
     if (!mm.empty()) ck(hssk_gemm_vbatched(ctx_, mm.data(), (int)mm.size()));
   };
   // ---- down-sweep, one depth
-  auto down = [&](const std::vector<int>& ids) {
+  // part: 0 everything; 1 only the leaves' op(D) x + beta y (independent of the tree: it can run next to the sweeps, on the side
+  // stream); 2 everything but that
+  auto down = [&](const std::vector<int>& ids, int part = 0) {
     std::vector<hssk_gemm_desc> m1, leafmm, innermm;  // m1: basis expansion X^T tmp2
     std::vector<hssk_rowgather_desc> sc;
     for (int id : ids) {
@@ -156,9 +158,11 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
       // (the root has no basis, so its mU / mV are unset: size t from the children's ranks)
       const int ldo = nd.leaf() ? (int)ly : std::max(rout(nodes_[nd.c0]) + rout(nodes_[nd.c1]), 1);
       const bool expand = id != sr && ro > 0;
+      if (part == 1 && !nd.leaf()) continue;
       if (nd.leaf()) {
         // c = D b + beta c (+ U tmp2)
-        leafmm.push_back(hssk_gemm_desc{nd.D, dx + (nd.lo - lo0), out, nd.m, nrhs, nd.m, nd.m, (int)lx, ldo, T ? 1 : 0, 0, 1.0, beta});
+        if (part != 2) leafmm.push_back(hssk_gemm_desc{nd.D, dx + (nd.lo - lo0), out, nd.m, nrhs, nd.m, nd.m, (int)lx, ldo, T ? 1 : 0, 0, 1.0, beta});
+        if (part == 1) continue;
       } else {
         const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
         const int ri_a = rin(a), ri_b = rin(b), ro_a = rout(a), ro_b = rout(b);
@@ -198,7 +202,8 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
   const bool fuse = nrhs <= fuse_max_nrhs() && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
   if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
-  auto sweep = [&](const Levels* ups, const Levels* downs) -> bool {
+  // leaf_acc: the leaves of `downs` only add U tmp2 onto what is in y (their op(D) x is already there)
+  auto sweep = [&](const Levels* ups, const Levels* downs, bool leaf_acc = false) -> bool {
     std::vector<hssk_apply_up_desc> U;
     std::vector<hssk_apply_down_desc> Dn;
     std::vector<int> wu(nn, -1), wd(nn, -1);
@@ -239,7 +244,10 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
             d.wait0 = wd[nd.parent];
           }
           d.trans = T ? 1 : 0;
-          if (nd.leaf()) {
+          if (nd.leaf() && leaf_acc) {
+            d.acc = 1; d.m = nd.m;
+            d.out = dy + (nd.lo - lo0); d.ldo = (int)ly;
+          } else if (nd.leaf()) {
             d.D = nd.D; d.x = dx + (nd.lo - lo0); d.ldx = (int)lx; d.m = nd.m; d.beta = beta;
             d.out = dy + (nd.lo - lo0); d.ldo = (int)ly;
             if (!d.D) return false;
@@ -282,13 +290,37 @@ void DeviceHSS::mult_sub(int sr, char trans, int nrhs, const double* x, long lon
       for (int id : ids) if (!nodes_[id].leaf()) v.push_back(id);
       down_in.push_back(std::move(v));
     }
-    up(ups_own[0]);
-    if (sweep(&up_in, &down_in)) {
-      down(ups_own[0]);
-      whole = true;
-    } else {   // (a node beyond the sweep's limits: the batched launches for the rest as well)
-      for (auto& ids : up_in) up(ids);
-      for (auto& ids : downs_own) down(ids);
+    // The leaves' op(D) x -- most of the bytes and flops of the product, and independent of the tree -- goes to the side stream,
+    // next to the sweeps; what is left of the leaves' step is y += U tmp2.
+    static const bool no_side = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
+    const bool side = !no_side;
+    if (side) {
+      ck(hssk_side_begin(ctx_));
+      struct End { hssk_ctx* c; ~End() { hssk_side_end(c); } } end{ctx_};
+      down(ups_own[0], 1);
+    }
+    const int rest = side ? 2 : 0;
+    if (side && nrhs >= hssk_sweep_mma_min_nrhs() && !big_leaves) {
+      // matrix-core form (kernels/hssk_sweep_mma.h): every level, the leaves included, in the one launch; the leaves' y += U tmp2
+      // as a second launch behind the side stream's op(D) x
+      struct Req { hssk_ctx* c; Req(hssk_ctx* c_) : c(c_) { hssk_sweep_require_mma(c, 1); } ~Req() { hssk_sweep_require_mma(c, 0); } } req(ctx_);
+      if (sweep(&ups_own, &down_in)) {
+        ck(hssk_side_join(ctx_));
+        Levels leaf_level{ups_own[0]};
+        if (!sweep(nullptr, &leaf_level, true)) down(ups_own[0], rest);
+        whole = true;
+      }
+    }
+    if (!whole) {
+      up(ups_own[0]);
+      if (sweep(&up_in, &down_in)) {
+        if (side) ck(hssk_side_join(ctx_));
+        down(ups_own[0], rest);
+      } else {   // (a node beyond the sweep's limits: the batched launches for the rest as well)
+        for (auto& ids : up_in) up(ids);
+        if (side) ck(hssk_side_join(ctx_));
+        for (auto& ids : downs_own) down(ids, rest);
+      }
       whole = true;
     }
   }

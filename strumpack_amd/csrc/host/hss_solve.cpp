@@ -273,15 +273,17 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
       for (int q = 0; q < 2; q++) {
         if (!mine(cid[q])) continue;  // the other ranks' subtrees continue on their owners
         const Node& cn = *ch[q];
-        if ((mode == 1 && cn.leaf()) || (mode == 2 && !cn.leaf())) continue;
+        // mode 1: inner children only; 2: leaves only; 3: leaves only, the part that needs no parent (Q~(:, 0:q) y); 4: leaves
+        // only, the rest
+        if ((mode == 1 && cn.leaf()) || (mode >= 2 && !cn.leaf())) continue;
         const int mc = cn.mU, rc = cn.rU;
         const double* xpart = x + (q ? a.rU : 0);
         double* out = cn.leaf() ? db + cn.lo : xb[cid[q]];
         const int ldo = cn.leaf() ? (int)lb : std::max(mc, 1);
         if (mc > rc) {
-          g1.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], out, mc, nrhs, mc - rc, mc, mc - rc, ldo, 0, 0, 1.0, 0.0});
-          if (rc) g2.push_back(hssk_gemm_desc{cn.Qt + (size_t)(mc - rc) * mc, xpart, out, mc, nrhs, rc, mc, ldx, ldo, 0, 0, 1.0, 1.0});
-        } else if (mc) {
+          if (mode != 4) g1.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], out, mc, nrhs, mc - rc, mc, mc - rc, ldo, 0, 0, 1.0, 0.0});
+          if (rc && mode != 3) g2.push_back(hssk_gemm_desc{cn.Qt + (size_t)(mc - rc) * mc, xpart, out, mc, nrhs, rc, mc, ldx, ldo, 0, 0, 1.0, 1.0});
+        } else if (mc && mode != 3) {
           cp.push_back(hssk_rowgather_desc{xpart, out, nullptr, mc, nrhs, ldx, ldo, 0, 0});
         }
       }
@@ -297,9 +299,28 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     for (int id : own_by_height_[0]) big_leaves = big_leaves || nodes_[id].m > 256;
   const bool hybrid = fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && own_by_height_.size() > 1;
   bool fwd_done = false;
+  static const bool no_side = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
+  const bool side = hybrid && !no_side;
+  std::vector<int> leaf_parents;   // the leaves' parents, whatever their depth: one batch
+  if (hybrid)
+    for (auto& ids : own_by_depth_) leaf_parents.insert(leaf_parents.end(), ids.begin(), ids.end());
   if (hybrid) {
     Levels inner(own_by_height_.begin() + 1, own_by_height_.end());
-    fwd(own_by_height_[0], true);
+    // the leaf level: one launch in the matrix-core form of the sweep when it takes the leaves (kernels/hssk_sweep_mma.h),
+    // else batched launches over all right-hand sides
+    bool leaves_done = false;
+    if (nrhs >= hssk_sweep_mma_min_nrhs() && !big_leaves) {
+      struct Req { hssk_ctx* c; Req(hssk_ctx* c_) : c(c_) { hssk_sweep_require_mma(c, 1); } ~Req() { hssk_sweep_require_mma(c, 0); } } req(ctx_);
+      Levels leaf_level{own_by_height_[0]};
+      leaves_done = fwd_sweep(leaf_level);
+    }
+    if (!leaves_done) fwd(own_by_height_[0], true);
+    if (side) {
+      // the leaves' Q~(:, 0:q) y -- most of the backward step, and independent of the levels above -- next to the inner levels
+      ck(hssk_side_begin(ctx_));
+      struct End { hssk_ctx* c; ~End() { hssk_side_end(c); } } end{ctx_};
+      bwd(leaf_parents, 3);
+    }
     if (!fwd_sweep(inner))
       for (auto& ids : inner) fwd(ids);
     fwd_done = true;
@@ -349,9 +370,8 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   if (hybrid) {
     if (!bwd_sweep(own_by_depth_, 1))
       for (auto& ids : own_by_depth_) bwd(ids, 1);
-    std::vector<int> parents;   // the leaves' parents, whatever their depth: one batch
-    for (auto& ids : own_by_depth_) parents.insert(parents.end(), ids.begin(), ids.end());
-    bwd(parents, 2);
+    if (side) ck(hssk_side_join(ctx_));
+    bwd(leaf_parents, side ? 4 : 2);
   } else if (!(fuse && bwd_sweep(own_by_depth_, 0)))
     for (auto& ids : own_by_depth_) bwd(ids);
   if (dist_subtree_) allgather_rows(db, lb, nrhs);

@@ -287,6 +287,7 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   for (auto e : c->watch_free) hssk_rt::event_destroy(e);
   hssk_rt::event_destroy(c->ev0);
   hssk_rt::event_destroy(c->ev_sync);
+  if (c->side_made) { hssk_rt::event_destroy(c->ev_fork); hssk_rt::event_destroy(c->ev_join); hssk_rt::stream_destroy(c->side); }
   hssk_rt::event_destroy(c->ev1);
   hssk_rt::stream_destroy(c->stream);
   delete c;
@@ -300,6 +301,48 @@ int hssk_stream_wait(hssk_ctx* waiter, hssk_ctx* on) {
   if (waiter == on) return 0;
   hssk_rt::event_record(on->ev_sync, on->stream);
   hssk_rt::stream_wait_event(waiter->stream, on->ev_sync);
+  HSSK_API_END
+}
+// ---- side stream: launches between _begin and _end go to a second stream that first waits for everything issued on the
+// main stream so far; _join makes the main stream wait for them.  Recorded plans replay the same routing.
+int hssk_side_begin(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  if (c->on_side) throw std::logic_error("hssk_side_begin: already on the side stream");
+  if (!c->side_made) {
+    c->side = hssk_rt::stream_create();
+    c->ev_fork = hssk_rt::event_create();
+    c->ev_join = hssk_rt::event_create();
+    c->side_made = true;
+  }
+  auto f = [c]() {
+    hssk_rt::event_record(c->ev_fork, c->stream);
+    hssk_rt::stream_wait_event(c->side, c->ev_fork);
+    c->main_saved = c->stream;
+    c->stream = c->side;
+    c->on_side = true;
+  };
+  f();
+  if (hssk_rec::sink) hssk_rec::sink->push_back(f);
+  HSSK_API_END
+}
+int hssk_side_end(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  if (!c->on_side) throw std::logic_error("hssk_side_end: not on the side stream");
+  auto f = [c]() { c->stream = c->main_saved; c->on_side = false; };
+  f();
+  if (hssk_rec::sink) hssk_rec::sink->push_back(f);
+  HSSK_API_END
+}
+int hssk_side_join(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  if (c->on_side) throw std::logic_error("hssk_side_join: still on the side stream");
+  if (!c->side_made) return 0;
+  auto f = [c]() {
+    hssk_rt::event_record(c->ev_join, c->side);
+    hssk_rt::stream_wait_event(c->stream, c->ev_join);
+  };
+  f();
+  if (hssk_rec::sink) hssk_rec::sink->push_back(f);
   HSSK_API_END
 }
 static hssk_rt::event_t watch_event(hssk_ctx* c) {

@@ -17,6 +17,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -45,48 +46,43 @@ __global__ __launch_bounds__(256) void gemm_vbatched_kernel(const hssk_gemm_desc
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
 
-  for (int k0 = 0; k0 < p.k; k0 += TK) {
-    // ---- stage A tile: As[kk][i] = op(A)(i0+i, k0+kk)
-    if (!p.transA) {
+  // The next K stage's operands are loaded into registers while the matrix cores work on the current one (the blocks of a
+  // level stream from HBM: without the prefetch every stage exposes a memory round trip -- the 256 x 256 x 64 products of the
+  // leaf level of a 64-right-hand-side mat-vec ran at 24 TFLOP/s).
+  double ra[4], rb[4];
+  auto fetch = [&](int k0) {
+    // A tile: As[kk][i] = op(A)(i0+i, k0+kk);  B tile: Bs[kk][j] = op(B)(k0+kk, j0+j)   (clamped address + select: no branch
+    // around the loads)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int i = tid & 63, kk = (tid >> 6) + 4 * r;
-        int gi = i0 + i, gk = k0 + kk;
-        const bool ok = gi < p.m && gk < p.k;   // clamped address + select: no branch around the load
-        double v = hssk_gload(p.A, min(gi, p.m - 1) + (size_t)min(gk, p.k - 1) * p.lda);
-        As[kk * LDS_LD + i] = ok ? v : 0.;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int kk = tid & 15, i = (tid >> 4) + 16 * r;
-        int gi = i0 + i, gk = k0 + kk;
-        const bool ok = gi < p.m && gk < p.k;
-        double v = hssk_gload(p.A, min(gk, p.k - 1) + (size_t)min(gi, p.m - 1) * p.lda);
-        As[kk * LDS_LD + i] = ok ? v : 0.;
-      }
+    for (int r = 0; r < 4; r++) {
+      const int i = p.transA ? (tid >> 4) + 16 * r : (tid & 63), kk = p.transA ? (tid & 15) : (tid >> 6) + 4 * r;
+      const int gi = i0 + i, gk = k0 + kk;
+      const bool ok = gi < p.m && gk < p.k;
+      const double v = p.transA ? hssk_gload(p.A, min(gk, p.k - 1) + (size_t)min(gi, p.m - 1) * p.lda)
+                                : hssk_gload(p.A, min(gi, p.m - 1) + (size_t)min(gk, p.k - 1) * p.lda);
+      ra[r] = ok ? v : 0.;
     }
-    // ---- stage B tile: Bs[kk][j] = op(B)(k0+kk, j0+j)
-    if (!p.transB) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int kk = tid & 15, j = (tid >> 4) + 16 * r;
-        int gj = j0 + j, gk = k0 + kk;
-        const bool ok = gj < p.n && gk < p.k;
-        double v = hssk_gload(p.B, min(gk, p.k - 1) + (size_t)min(gj, p.n - 1) * p.ldb);
-        Bs[kk * LDS_LD + j] = ok ? v : 0.;
-      }
-    } else {
+    for (int r = 0; r < 4; r++) {
+      const int j = p.transB ? (tid & 63) : (tid >> 4) + 16 * r, kk = p.transB ? (tid >> 6) + 4 * r : (tid & 15);
+      const int gj = j0 + j, gk = k0 + kk;
+      const bool ok = gj < p.n && gk < p.k;
+      const double v = p.transB ? hssk_gload(p.B, min(gj, p.n - 1) + (size_t)min(gk, p.k - 1) * p.ldb)
+                                : hssk_gload(p.B, min(gk, p.k - 1) + (size_t)min(gj, p.n - 1) * p.ldb);
+      rb[r] = ok ? v : 0.;
+    }
+  };
+  if (p.k > 0) fetch(0);
+  for (int k0 = 0; k0 < p.k; k0 += TK) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int j = tid & 63, kk = (tid >> 6) + 4 * r;
-        int gj = j0 + j, gk = k0 + kk;
-        const bool ok = gj < p.n && gk < p.k;
-        double v = hssk_gload(p.B, min(gj, p.n - 1) + (size_t)min(gk, p.k - 1) * p.ldb);
-        Bs[kk * LDS_LD + j] = ok ? v : 0.;
-      }
+    for (int r = 0; r < 4; r++) {
+      const int i = p.transA ? (tid >> 4) + 16 * r : (tid & 63), kk = p.transA ? (tid & 15) : (tid >> 6) + 4 * r;
+      As[kk * LDS_LD + i] = ra[r];
+      const int j = p.transB ? (tid & 63) : (tid >> 4) + 16 * r, kb = p.transB ? (tid >> 6) + 4 * r : (tid & 15);
+      Bs[kb * LDS_LD + j] = rb[r];
     }
     __syncthreads();
+    if (k0 + TK < p.k) fetch(k0 + TK);
 #pragma unroll
     for (int ks = 0; ks < TK; ks += 4) {
       const double a0 = As[(ks + l4) * LDS_LD + wm + l15];
@@ -420,15 +416,112 @@ inline bool panel_eligible(const hssk_gemm_desc& d) {
          ((size_t)d.A % 16 == 0) && d.k > 0 && d.n > 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Tall variant for C(m x n) = alpha op(A) B + beta C with FEW columns (n <= 64) and a B block that fits the LDS
+// (k <= 256): the leaf-level products of a mat-vec / solve with many right-hand sides (D x, Q~ y: 256 x 256 blocks
+// against 64 columns).  The 64 x 64 tiles above stage both operands through LDS one K stage at a time and reach
+// 24 TFLOP/s on those shapes; here B is loaded into LDS once ([k][65]: conflict-free for the transposing load and
+// for the MFMA operand reads), a workgroup owns TALL_M rows of C and each wave streams the A fragments of its
+// 16-row tiles straight from global memory into registers, TALL_CH k-steps ahead, against all four 16-column
+// tiles of B.  The MFMA takes the B fragment first, so a lane holds C[i = l & 15][j = (l >> 4) + 4 r]: sixteen
+// lanes store sixteen consecutive rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int TALL_T = 1024, TALL_M = 256, TALL_N = 64, TALL_LDB = TALL_N + 1, TALL_CH = 16, TALL_KMAX = 256;
+
+__global__ __launch_bounds__(TALL_T) void gemm_tall_kernel(const hssk_gemm_desc* __restrict__ descs, const Tile* __restrict__ tiles) {
+  HSSK_DYN_SHARED(double, Bs);
+  const Tile t = tiles[blockIdx.x];
+  const hssk_gemm_desc p = descs[t.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = hssk_uniform(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int m = p.m, n = p.n, k = p.k;
+  // B -> LDS (lanes along k: contiguous in memory), zero beyond column n
+  {
+    const int cs = TALL_T / k, kk = tid % k, jq = tid / k;   // k <= 256: cs >= 4 columns per pass
+    if (jq < cs)
+      for (int j = jq; j < TALL_N; j += 8 * cs) {   // eight loads in flight (one at a time: a memory round trip per column)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = hssk_gload(p.B, (size_t)kk + (size_t)min(j + u * cs, n - 1) * p.ldb);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (j + u * cs < TALL_N) Bs[kk * TALL_LDB + j + u * cs] = j + u * cs < n ? v[u] : 0.;
+      }
+  }
+  __syncthreads();
+  const int nks = (k + 3) >> 2;
+  const int nch = hssk_uniform((nks + TALL_CH - 1) / TALL_CH);
+  const int r0 = t.tm * TALL_M;
+  for (int tl = wave; tl * 16 < TALL_M && r0 + tl * 16 < m; tl += TALL_T / 64) {
+    const int i = r0 + tl * 16 + l15;
+    // A fragment element, indices clamped into the block: no branch around the load and no select behind it (either makes the
+    // compiler wait for the load long before the matrix cores need it).  Rows beyond m are never stored; k-steps beyond k
+    // multiply by zeros read in place of B.
+    auto aload = [&](int kk) -> double {
+      const int ic = min(i, m - 1), kc = min(kk, k - 1);
+      return p.transA ? hssk_gload(p.A, (size_t)kc + (size_t)ic * p.lda) : hssk_gload(p.A, (size_t)ic + (size_t)kc * p.lda);
+    };
+    hssk_d4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) acc[ct] = hssk_d4{0., 0., 0., 0.};
+    auto chunk = [&](int k0, const double (&a)[TALL_CH]) {
+#pragma unroll
+      for (int u = 0; u < TALL_CH; u++) {
+        const int kk = k0 + 4 * u;
+        const double* xr = Bs + min(kk, k - 1) * TALL_LDB + l15;
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) acc[ct] = hssk_mfma_f64_16x16x4(kk < k ? xr[ct * 16] : 0., a[u], acc[ct]);
+      }
+    };
+    // two register sets in turn: the fragments of the next chunk are in flight while the matrix cores work on the current one
+    double a0[TALL_CH], a1[TALL_CH];
+#pragma unroll
+    for (int u = 0; u < TALL_CH; u++) a0[u] = aload(4 * u + l4);
+    for (int c = 0; c < nch; c += 2) {
+      const int k0 = 4 * TALL_CH * c + l4;
+#pragma unroll
+      for (int u = 0; u < TALL_CH; u++) a1[u] = aload(k0 + 4 * TALL_CH + 4 * u);
+      chunk(k0, a0);
+#pragma unroll
+      for (int u = 0; u < TALL_CH; u++) a0[u] = aload(k0 + 8 * TALL_CH + 4 * u);
+      chunk(k0 + 4 * TALL_CH, a1);   // (beyond k: zeros on the B side)
+    }
+    if (i < m) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int j = ct * 16 + l4 + 4 * r;
+          if (j < n) {
+            double v = p.alpha * acc[ct][r];
+            if (p.beta != 0.) v += p.beta * hssk_gload(p.C, (size_t)i + (size_t)j * p.ldc);
+            hssk_gstore(p.C, (size_t)i + (size_t)j * p.ldc, v);
+          }
+        }
+    }
+  }
+}
+bool tall_eligible(const hssk_gemm_desc& d) {
+  static const bool off = [] { const char* e = std::getenv("HSSK_GEMM_NO_TALL"); return e && e[0] == '1'; }();
+  return !off && !d.transB && d.n > 16 && d.n <= TALL_N && d.k >= 32 && d.k <= TALL_KMAX && d.m >= 96;
+}
+
 }  // namespace
 
 extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  std::vector<Tile> tiles, ztiles, ptilesN, ptilesT;
+  std::vector<Tile> tiles, ztiles, ptilesN, ptilesT, ttiles;
+  int kmax_tall = 0;
   for (int p = 0; p < count; p++) {
     const hssk_gemm_desc& d = descs[p];
     if (d.m <= 0 || d.n <= 0) continue;
+    if (tall_eligible(d)) {
+      for (int tm = 0; tm * TALL_M < d.m; tm++) ttiles.push_back(Tile{p, tm, 0});
+      kmax_tall = std::max(kmax_tall, d.k);
+      continue;
+    }
     if (panel_eligible(d)) {
       std::vector<Tile>& dst = d.transB ? ptilesT : ptilesN;
       for (int tn = 0; tn * PBN < d.n; tn++) dst.push_back(Tile{p, 0, tn});
@@ -439,7 +532,7 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
     for (int tn = 0; tn < ntn; tn++)
       for (int tm = 0; tm < ntm; tm++) dst.push_back(Tile{p, tm, tn});
   }
-  if (tiles.empty() && ztiles.empty() && ptilesN.empty() && ptilesT.empty()) return 0;
+  if (tiles.empty() && ztiles.empty() && ptilesN.empty() && ptilesT.empty() && ttiles.empty()) return 0;
   auto* d_descs = (const hssk_gemm_desc*)ctx->stage(descs, sizeof(hssk_gemm_desc) * count);
   // XCD-aware order for the panel tiles: workgroup b runs on XCD b % 8 and every XCD has its own L2, so
   // the column tiles of one problem (which share the 192 x k A panel) are placed on block ids that are
@@ -470,6 +563,12 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
   if (!ptilesT.empty()) {
     auto* d_tiles = (const Tile*)ctx->stage(ptilesT.data(), sizeof(Tile) * ptilesT.size());
     HSSK_LAUNCH((gemm_panel_kernel<true>), dim3((unsigned)ptilesT.size()), dim3(256), 0, ctx->stream, d_descs, d_tiles);
+  }
+  if (!ttiles.empty()) {
+    auto* d_tiles = (const Tile*)ctx->stage(ttiles.data(), sizeof(Tile) * ttiles.size());
+    const size_t lds = sizeof(double) * (size_t)kmax_tall * TALL_LDB;
+    hssk_rt::allow_dynamic_lds(gemm_tall_kernel, lds);
+    HSSK_LAUNCH(gemm_tall_kernel, dim3((unsigned)ttiles.size()), dim3(TALL_T), lds, ctx->stream, d_descs, d_tiles);
   }
   if (!tiles.empty()) {
     auto* d_tiles = (const Tile*)ctx->stage(tiles.data(), sizeof(Tile) * tiles.size());

@@ -53,6 +53,11 @@ struct hssk_ctx {
   size_t zero_copy_bytes = 0;   // descriptor arrays up to this size are read in place from the pinned ring
   hssk_rt::event_t ev0{}, ev1{};
   hssk_rt::event_t ev_sync{};   // hssk_stream_wait: recorded on this context's stream, waited for by another's
+  // side stream (hssk_side_begin / _end / _join): work that does not depend on what the main stream is doing
+  hssk_rt::stream_t side{}, main_saved{};
+  hssk_rt::event_t ev_fork{}, ev_join{};
+  bool on_side = false, side_made = false;
+  bool require_mma = false;   // hssk_sweep_require_mma: the sweeps refuse (code 2) what their matrix-core form cannot take
   bool dgemm_timed = false;
   double dgemm_timed_flops = 0.;  // algorithmic flops of the launch bracketed by ev0 / ev1
   long long dgemm_trace_wgs = 0;  // workgroups of the last main launch (trace records behind d_clk + 4)

@@ -190,8 +190,16 @@ __device__ __forceinline__ void gemv_n_prefetch(const double* __restrict__ A, in
 // pull `count` doubles at p towards this XCD's L2 (one load per 128-byte line) while the workgroup still waits for its
 // dependencies: the dependent chain of a node then runs on L2 hits.  The values are folded into `sink` (see keep()).
 __device__ __forceinline__ void touch(const double* p, size_t count, double& sink) {
+  // (eight lines per thread in flight: a loop that folds each value into `sink` as it arrives waits out one memory round trip
+  //  per line)
   if (p)
-    for (size_t e = (size_t)threadIdx.x * 16; e < count; e += (size_t)SW_T * 16) sink += hssk_gload(p, e);
+    for (size_t e = (size_t)threadIdx.x * 16; e < count; e += (size_t)SW_T * 16 * 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const size_t x = e + (size_t)u * SW_T * 16; t[u] = x < count ? hssk_gload(p, x) : 0.; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) sink += t[u];
+    }
 }
 __device__ __forceinline__ void keep(double sink, double* s_p) {
   if (sink == 1.234567e300) s_p[0] = sink;   // never true: keeps the prefetch loads alive
@@ -689,6 +697,8 @@ int* sweep_err(hssk_ctx* ctx) {
 }  // namespace
 
 extern "C" long long hssk_sweep_mma_launches(void) { return mma_launches; }
+extern "C" int hssk_sweep_mma_min_nrhs(void) { return mma_min_nrhs() > 0 ? mma_min_nrhs() : 1 << 30; }
+extern "C" int hssk_sweep_require_mma(hssk_ctx* ctx, int on) { ctx->require_mma = on != 0; return 0; }
 
 extern "C" int hssk_sweep_status(hssk_ctx* ctx) {
   if (!ctx->h_sweep_err) return 0;
@@ -724,25 +734,33 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
     // many right-hand sides: the node arithmetic on the matrix cores, 64 right-hand sides per pass (hssk_sweep_mma.h)
     int rows = 0;
     for (int i = 0; i < count; i++) {
-      const FwdRows R = mm_fwd_rows(descs[i].m, descs[i].r, descs[i].mv, descs[i].rv, descs[i].LU != nullptr);
+      const FwdRows R = mm_fwd_rows(descs[i].m, descs[i].r, descs[i].mv, descs[i].rv, descs[i].LU != nullptr, descs[i].B01 != nullptr);
       rows = std::max(rows, R.f + R.y + R.a + R.t + R.z);
     }
-    if (const int nc = mma_width(nrhs, rows, 2 * SW_T)) {
+    if (const int nc = mma_width(nrhs, rows, 2 * SW_T, dmax)) {
       const size_t bytes = mma_lds_bytes(nc, rows, 2 * SW_T);
       mma_launches++;
+      // (launches with large nodes -- the leaf level -- take more waves per workgroup: the LDS leaves room for one workgroup
+      //  per CU, and one wave per SIMD keeps the FP64 matrix pipe at a third of its rate; HSSK_SWEEP_MMA_T_BIG overrides)
+      static const int tb_big = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_T_BIG"); const int v = e ? std::atoi(e) : 512; return (v == 512 || v == 1024) ? v : SW_T; }();
+      const int tb = (dmax >= 160 && nc <= 32) ? tb_big : SW_T;
       auto go = [&](auto kernel) {
         hssk_rt::allow_dynamic_lds(kernel, bytes);
         const int ng = mma_groups(nrhs, nc);
-        HSSK_LAUNCH(kernel, dim3((unsigned)count * ng), dim3(SW_T), bytes, ctx->stream, dd, nrhs, ng, sweep_err(ctx));
+        HSSK_LAUNCH(kernel, dim3((unsigned)count * ng), dim3((unsigned)tb), bytes, ctx->stream, dd, nrhs, ng, sweep_err(ctx));
       };
-      if (nc == 64) go(ulv_fwd_sweep_mma_kernel<64>);
-      else if (nc == 32) go(ulv_fwd_sweep_mma_kernel<32>);
-      else go(ulv_fwd_sweep_mma_kernel<16>);
+      if (tb == 1024 && nc == 32) go(ulv_fwd_sweep_mma_kernel<32, 1024>);
+      else if (tb == 1024 && nc == 16) go(ulv_fwd_sweep_mma_kernel<16, 1024>);
+      else if (tb == 512 && nc == 32) go(ulv_fwd_sweep_mma_kernel<32, 512>);
+      else if (tb == 512 && nc == 16) go(ulv_fwd_sweep_mma_kernel<16, 512>);
+      else if (nc == 64) go(ulv_fwd_sweep_mma_kernel<64, SW_T>);
+      else if (nc == 32) go(ulv_fwd_sweep_mma_kernel<32, SW_T>);
+      else go(ulv_fwd_sweep_mma_kernel<16, SW_T>);
       hssk_rt::check_launch();
       return 0;
     }
   }
-  if (nrhs > 64) HSSK_UNSUPPORTED("more than 64 right-hand sides on nodes beyond the matrix-core sweep");
+  if (nrhs > 64 || ctx->require_mma) HSSK_UNSUPPORTED("operands beyond the matrix-core sweep");
   const unsigned gy = groups_y(nrhs, 1);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)5 * ldv * nr + (size_t)SW_T * nr) + sizeof(int) * (size_t)ldv; };
   if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -766,7 +784,7 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
   int dmax = 0;
   for (int i = 0; i < count; i++) dmax = std::max(dmax, descs[i].m);
   if (mma_min_nrhs() > 0 && nrhs >= mma_min_nrhs()) {
-    if (const int nc = mma_width(nrhs, 2 * std::max(dmax, 1), 0)) {
+    if (const int nc = mma_width(nrhs, 2 * std::max(dmax, 1), 0, dmax)) {
       const size_t bytes = mma_lds_bytes(nc, 2 * std::max(dmax, 1), 0);
       mma_launches++;
       auto go = [&](auto kernel) {
@@ -781,7 +799,7 @@ extern "C" int hssk_ulv_bwd_sweep(hssk_ctx* ctx, const hssk_sweep_bwd_desc* desc
       return 0;
     }
   }
-  if (nrhs > 64) HSSK_UNSUPPORTED("more than 64 right-hand sides on nodes beyond the matrix-core sweep");
+  if (nrhs > 64 || ctx->require_mma) HSSK_UNSUPPORTED("operands beyond the matrix-core sweep");
   const unsigned gy = groups_y(nrhs, 2);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)2 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((ulv_bwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
@@ -819,9 +837,9 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
     for (int i = 0; i < ndown; i++) {
       const hssk_apply_down_desc& d = downs[i];
       if (d.D) { ok = false; break; }   // (leaves: the batched launches of the many-right-hand-side path, or the vector form)
-      rows = std::max(rows, mm_apply_down_rows(d.ri_a + d.ri_b, d.ro, d.ro_a + d.ro_b, d.mo));
+      rows = std::max(rows, mm_apply_down_rows(d.ri_a + d.ri_b, d.ro, d.ro_a + d.ro_b, d.mo, d.acc));
     }
-    const int nc = ok ? mma_width(nrhs, rows, SW_T) : 0;
+    const int nc = ok ? mma_width(nrhs, rows, SW_T, 0) : 0;
     if (nc) {
       const size_t bytes = mma_lds_bytes(nc, rows, SW_T);
       mma_launches++;
@@ -837,7 +855,9 @@ extern "C" int hssk_apply_sweep(hssk_ctx* ctx, const hssk_apply_up_desc* ups, in
       return 0;
     }
   }
-  if (nrhs > 64) HSSK_UNSUPPORTED("more than 64 right-hand sides on nodes beyond the matrix-core sweep");
+  if (nrhs > 64 || ctx->require_mma) HSSK_UNSUPPORTED("operands beyond the matrix-core sweep");
+  for (int i = 0; i < ndown; i++)
+    if (downs[i].acc) HSSK_UNSUPPORTED("accumulating leaves are served by the matrix-core sweep only");
   const unsigned gy = groups_y(nrhs, 0);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)3 * ldv * nr + (size_t)SW_T * nr); };
   if (nrhs == 1) HSSK_LAUNCH((apply_sweep_kernel<1, SW_MAX, false>), dim3(nwg, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, du, nup, dn, nrhs, sweep_err(ctx));

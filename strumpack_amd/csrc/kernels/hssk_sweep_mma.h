@@ -16,8 +16,12 @@
 // right-hand sides per pass: NC = 64, or 32 / 16 when the node's vectors would not fit the LDS as 64-wide rows (and for fewer
 // right-hand sides); an LDS row is NC + 1 doubles
 #define MM_LDR (NC + 1)
+#define MM_T ((int)blockDim.x)   /* threads of the workgroup: 256, or more waves for the launches with large nodes */
 #define MM_NC NC
-constexpr int MM_CH = 4;          // k-steps (of 4) per chunk of the pipelined tile loop
+// k-steps (of 4) per chunk of the pipelined tile loop: 4 for the 16-wide form (small nodes: K = 41 is three chunks); 8 for the
+// wider forms, which serve the launches with large nodes (the leaves: their blocks stream from HBM and a wave needs more
+// loads in flight)
+#define MM_CH (NC == 16 ? 4 : 8)
 constexpr int MM_GRP = 8;         // hand-off loads a thread keeps in flight
 constexpr size_t MM_LDS_BYTES = 160 * 1024 - 512;   // what a workgroup may take
 // out (M x nc) (op)= op(A) x:  A is M x K (lda) or, trans, K x M (lda) applied transposed; x, out: LDS row blocks
@@ -28,15 +32,28 @@ struct MatOp {
   int op, trans;
 };
 
+// A fragment element (i, k) of an operation, indices clamped into the block (no branch around the load, no select behind it:
+// either would make the compiler wait for the load long before the matrix cores need it).  Rows beyond M give rows of the
+// result that are never stored; steps beyond K are cancelled on the other operand (see mm_tile).  Only called with M, K > 0.
 __device__ __forceinline__ double mm_aload(const MatOp& o, int i, int k) {
-  if (i >= o.M || k >= o.K) return 0.;
-  return o.trans ? hssk_gload(o.A, (size_t)k + (size_t)i * o.lda) : hssk_gload(o.A, (size_t)i + (size_t)k * o.lda);
+  const int ic = min(i, o.M - 1), kc = min(k, o.K - 1);
+  return o.trans ? hssk_gload(o.A, (size_t)kc + (size_t)ic * o.lda) : hssk_gload(o.A, (size_t)ic + (size_t)kc * o.lda);
 }
 // one 16-row tile against the NC / 16 column tiles of the right-hand sides (all of them: columns beyond the last right-hand
-// side hold whatever the LDS held and are never stored).  Wave collective: the whole wave calls.  Rows k >= K of the operand
-// are read as row K - 1 (the A fragment is zero there), so nothing outside the operand block reaches the sums.  The k loop
-// runs on chunks of MM_CH k-steps, the next chunk's A fragment in flight while the matrix cores work on the current one
-// (no conditional MFMAs: the compiler copies the whole accumulator tuple around each of them).
+// side hold whatever the LDS held and are never stored).  Wave collective: the whole wave calls.  The k loop runs on chunks
+// of MM_CH k-steps with two register sets in turn: the A fragments of the next chunk are in flight while the matrix cores
+// work on the current one, and nothing but the MFMAs themselves reads them.  (No conditional MFMAs -- the compiler copies
+// the whole accumulator tuple around each --, k-steps beyond K multiply by zeros read in place of the right-hand sides.)
+template <int NC>
+__device__ __forceinline__ void mm_chunk(const MatOp& o, const double* xb, int k0, const double (&a)[MM_CH], hssk_d4 (&acc)[NC / 16]) {
+#pragma unroll
+  for (int u = 0; u < MM_CH; u++) {
+    const int k = k0 + 4 * u;
+    const double* xr = xb + min(k, o.K - 1) * MM_LDR;
+#pragma unroll
+    for (int ct = 0; ct < NC / 16; ct++) acc[ct] = hssk_mfma_f64_16x16x4(a[u], k < o.K ? xr[ct * 16] : 0., acc[ct]);
+  }
+}
 template <int NC>
 __device__ __forceinline__ void mm_tile(const MatOp& o, int i0) {
   HSSK_DYN_SHARED(double, S);
@@ -48,21 +65,21 @@ __device__ __forceinline__ void mm_tile(const MatOp& o, int i0) {
   const int i = i0 + n;
   const int nch = hssk_uniform((o.K + 4 * MM_CH - 1) / (4 * MM_CH));
   const double* xb = S + o.x + n;
-  double a[MM_CH], an[MM_CH];
+  if (nch > 0) {   // (K == 0: nothing to load, and no address to clamp to)
+    double a0[MM_CH], a1[MM_CH];
 #pragma unroll
-  for (int u = 0; u < MM_CH; u++) a[u] = mm_aload(o, i, 4 * u + kq);
-  for (int c = 0; c < nch; c++) {
-    const int k0 = 4 * MM_CH * c + kq;
+    for (int u = 0; u < MM_CH; u++) a0[u] = mm_aload(o, i, 4 * u + kq);
+    for (int c = 0; c < nch; c += 2) {
+      const int k0 = 4 * MM_CH * c + kq;
 #pragma unroll
-    for (int u = 0; u < MM_CH; u++) an[u] = mm_aload(o, i, k0 + 4 * MM_CH + 4 * u);
+      for (int u = 0; u < MM_CH; u++) a1[u] = mm_aload(o, i, k0 + 4 * MM_CH + 4 * u);
+      mm_chunk<NC>(o, xb, k0, a0, acc);
+      if (c + 1 < nch) {
 #pragma unroll
-    for (int u = 0; u < MM_CH; u++) {
-      const double* xr = xb + min(k0 + 4 * u, o.K - 1) * MM_LDR;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ct++) acc[ct] = hssk_mfma_f64_16x16x4(a[u], xr[ct * 16], acc[ct]);
+        for (int u = 0; u < MM_CH; u++) a0[u] = mm_aload(o, i, k0 + 8 * MM_CH + 4 * u);
+        mm_chunk<NC>(o, xb, k0 + 4 * MM_CH, a1, acc);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < MM_CH; u++) a[u] = an[u];
   }
   double* ob = S + o.o + n;
 #pragma unroll
@@ -79,21 +96,33 @@ __device__ __forceinline__ void mm_tile(const MatOp& o, int i0) {
 template <int NC, int NOPS>
 __device__ __forceinline__ void mm_stage(const MatOp (&ops)[NOPS]) {
   const int wave = hssk_uniform((int)(threadIdx.x >> 6));   // (a scalar: the tile's operands stay in scalar registers)
+  const int nw = MM_T >> 6;   // waves (a power of two)
   int t0 = 0;   // tiles of the operations before this one
 #pragma unroll
   for (int j = 0; j < NOPS; j++) {
     const int nt = (ops[j].M + 15) >> 4;
-    for (int lt = (wave - t0) & 3; lt < nt; lt += 4) mm_tile<NC>(ops[j], lt * 16);
+    for (int lt = (wave - t0) & (nw - 1); lt < nt; lt += nw) mm_tile<NC>(ops[j], lt * 16);
     t0 += nt;
   }
   __syncthreads();
 }
 // pulls the operands of a stage towards this XCD's L2 while the workgroup still waits for its dependencies
+__device__ __forceinline__ void mm_touch_block(const double* p, size_t count, double& sink) {
+  if (!p) return;
+  const size_t T = blockDim.x;
+  for (size_t e = (size_t)threadIdx.x * 16; e < count; e += T * 16 * 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const size_t x = e + (size_t)u * T * 16; t[u] = x < count ? hssk_gload(p, x) : 0.; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) sink += t[u];
+  }
+}
 template <int NOPS>
 __device__ __forceinline__ void mm_touch(const MatOp (&ops)[NOPS], double& sink) {
 #pragma unroll
   for (int j = 0; j < NOPS; j++)
-    if (ops[j].M > 0 && ops[j].K > 0) touch(ops[j].A, (size_t)ops[j].lda * ((ops[j].trans ? ops[j].M : ops[j].K) - 1) + (ops[j].trans ? ops[j].K : ops[j].M), sink);
+    if (ops[j].M > 0 && ops[j].K > 0) mm_touch_block(ops[j].A, (size_t)ops[j].lda * ((ops[j].trans ? ops[j].M : ops[j].K) - 1) + (ops[j].trans ? ops[j].K : ops[j].M), sink);
 }
 
 // LDS row block (rows x nc) <- column-major global block (leading dimension ld), rows through `perm` (LDS or global ints)
@@ -103,7 +132,7 @@ template <int NC, bool HANDED>
 __device__ __forceinline__ void mm_take(const double* src, size_t ld, int rows, int nc, double* dst, const int* perm, int* err) {
   if (rows <= 0) return;
   const int tid = threadIdx.x;
-  const int cs = SW_T / rows;   // rows <= SW_T
+  const int cs = MM_T / rows;   // rows <= MM_T
   const int i = tid % rows, cq = tid / rows;
   if (cq >= cs) return;
   const size_t ri = perm ? (size_t)perm[i] : (size_t)i;
@@ -141,7 +170,7 @@ template <int NC, bool COHERENT>
 __device__ __forceinline__ void mm_put(double* dst, size_t ld, int rows, int nc, const double* src) {
   if (rows <= 0) return;
   const int tid = threadIdx.x;
-  const int cs = SW_T / rows;
+  const int cs = MM_T / rows;
   const int i = tid % rows, cq = tid / rows;
   if (cq >= cs) return;
   for (int c = cq; c < nc; c += cs) {
@@ -153,7 +182,7 @@ __device__ __forceinline__ void mm_put(double* dst, size_t ld, int rows, int nc,
 // LDS -> LDS: dst rows [0, rows) <- src rows [r0, r0 + rows)  (lanes along the right-hand sides)
 template <int NC>
 __device__ __forceinline__ void mm_copy(double* dst, const double* src, int rows, int nc) {
-  for (int e = threadIdx.x; e < rows * MM_NC; e += SW_T) {
+  for (int e = threadIdx.x; e < rows * MM_NC; e += MM_T) {
     const int c = e % NC, i = e / NC;
     if (c < nc) dst[(size_t)i * MM_LDR + c] = src[(size_t)i * MM_LDR + c];
   }
@@ -161,13 +190,14 @@ __device__ __forceinline__ void mm_copy(double* dst, const double* src, int rows
 
 // ---- LDS budgets (rows of MM_LDR doubles) of the three bodies: the host checks them, the kernels lay their blocks out by them
 struct FwdRows { int f, y, a, t, z; };
-__host__ __device__ inline FwdRows mm_fwd_rows(int m, int r, int mv, int rv, bool root) {
+__host__ __device__ inline FwdRows mm_fwd_rows(int m, int r, int mv, int rv, bool root, bool inner) {
   FwdRows R;
   const int q = m - r;
+  if (!inner) mv = rv;   // (a leaf has no children's z: nothing to stack, nothing beyond its own z)
   R.f = m > 1 ? m : 1;
   R.y = (mv - rv > q ? mv - rv : q);
   if (R.y < 1) R.y = 1;
-  R.a = mv > 1 ? mv : 1;
+  R.a = (inner && mv > 1) ? mv : 1;
   R.t = root ? (m < SW_NB ? m : SW_NB) : r;
   if (R.t < 1) R.t = 1;
   R.z = rv > 1 ? rv : 1;
@@ -181,7 +211,7 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   const int tid = threadIdx.x;
   const int m = p.m, r = p.r, q = m - r, rv = p.rv, mv = p.mv;
   const bool root = p.LU != nullptr;
-  const FwdRows R = mm_fwd_rows(m, r, mv, rv, root);
+  const FwdRows R = mm_fwd_rows(m, r, mv, rv, root, p.B01 != nullptr);
   // (row blocks by their offsets into the workgroup's LDS: the stages address them through s_dyn itself, so the compiler
   //  emits LDS instructions, not flat ones)
   const int o_f = 0;                        // f, later the block right-hand side of the substitution
@@ -215,18 +245,18 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   const MatOp ops2[1] = {{p.XU, max(r, 1), (q > 0 && r > 0) ? q : 0, r, o_t, o_y, OP_SUB, 1}};
   // ft1 -= WQ y  and  z += Vt0^T y
   const MatOp ops4[2] = {{p.WQ, max(r, 1), q > 0 ? r : 0, q, o_y, o_t, OP_SUB, 0}, {p.Vt0T, max(rv, 1), q > 0 ? rv : 0, q, o_y, o_z, OP_ADD, 0}};
-  if (p.wait0 >= 0 || p.wait1 >= 0) {
+  {   // (leaves too: their blocks come from HBM, and the stages below would meet them one memory round trip at a time)
     double sink = 0.;
     mm_touch(ops1, sink);
     if (root) {
-      touch(p.LU, (size_t)m * m, sink);
-      touch(p.TinvL, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
-      touch(p.TinvU, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
+      mm_touch_block(p.LU, (size_t)m * m, sink);
+      mm_touch_block(p.TinvL, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
+      mm_touch_block(p.TinvU, (size_t)((m + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
     } else if (q > 0) {
       mm_touch(ops2, sink);
       mm_touch(ops4, sink);
-      touch(p.Tinv, (size_t)((q + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
-      if (q > SW_NB) touch(p.Rlq, (size_t)m * q, sink);
+      mm_touch_block(p.Tinv, (size_t)((q + SW_NB - 1) / SW_NB) * SW_NB * SW_NB, sink);
+      if (q > SW_NB) mm_touch_block(p.Rlq, (size_t)m * q, sink);
     }
     keep(sink, s_f);
   }
@@ -239,7 +269,7 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   if (inner) {
     if (zpart) {
       // s_z <- zc(permV[0:rv]);  s_y <- zc(permV[rv:])
-      for (int e = tid; e < mv * MM_NC; e += SW_T) {
+      for (int e = tid; e < mv * MM_NC; e += MM_T) {
         const int c = e % NC, i = e / NC;
         if (c < nc) {
           const double v = s_a[(size_t)s_pv[i] * MM_LDR + c];
@@ -290,7 +320,7 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
     return;
   }
   // ---- ft1 = f(perm[0:r]) -> s_t, y = f(perm[r:]) -> s_y
-  for (int e = tid; e < m * MM_NC; e += SW_T) {
+  for (int e = tid; e < m * MM_NC; e += MM_T) {
     const int c = e % NC, i = e / NC;
     if (c < nc) {
       const double v = s_f[(size_t)s_pu[i] * MM_LDR + c];
@@ -299,7 +329,7 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
     }
   }
   if (!inner)
-    for (int e = tid; e < rv * MM_NC; e += SW_T) s_z[(size_t)(e / NC) * MM_LDR + (e % NC)] = 0.;
+    for (int e = tid; e < rv * MM_NC; e += MM_T) s_z[(size_t)(e / NC) * MM_LDR + (e % NC)] = 0.;
   __syncthreads();
   if (q > 0) {
     if (r > 0) mm_stage<NC>(ops2);
@@ -325,8 +355,8 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   mm_put<NC, true>(p.z, (size_t)p.ldz, rv, nc, s_z);
 }
 
-template <int NC>
-__global__ __launch_bounds__(SW_T) HSSK_WAVES_PER_SIMD(2) void ulv_fwd_sweep_mma_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int ngroups, int* err) {
+template <int NC, int TB>
+__global__ __launch_bounds__(TB) void ulv_fwd_sweep_mma_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int ngroups, int* err) {
   const int node = blockIdx.x / ngroups;
   for (int g = blockIdx.x % ngroups; g * MM_NC < nrhs_total; g += ngroups) {
     ulv_fwd_body_mma<NC>(descs, node, nrhs_total, err, g);
@@ -351,7 +381,7 @@ __device__ __forceinline__ void ulv_bwd_body_mma(const hssk_sweep_bwd_desc* __re
   }
   const MatOp oy[1] = {{p.Qt, max(m, 1), q > 0 ? m : 0, q, o_v, o_o, OP_SET, 0}};
   const MatOp ox[1] = {{p.Qt + (size_t)q * m, max(m, 1), (q > 0 && r > 0) ? m : 0, r, o_v + q * MM_LDR, o_o, OP_ADD, 0}};
-  if (p.wait0 >= 0) { double sink = 0.; mm_touch(ox, sink); keep(sink, s_v); }
+  { double sink = 0.; mm_touch(oy, sink); mm_touch(ox, sink); keep(sink, s_v); }
   // the parent-independent part first
   mm_take<NC, false>(p.y, (size_t)q, q, nc, s_v, nullptr, err);
   __syncthreads();
@@ -374,9 +404,9 @@ __global__ __launch_bounds__(SW_T) void ulv_bwd_sweep_mma_kernel(const hssk_swee
 }
 
 // ---- mat-vec (inner nodes; the leaves of a many-right-hand-side product run as batched launches)
-__host__ __device__ inline int mm_apply_down_rows(int nt1, int ro, int nto, int mo) {
+__host__ __device__ inline int mm_apply_down_rows(int nt1, int ro, int nto, int mo, int acc) {
   const int x = nt1 > ro ? nt1 : ro;
-  return (x > 1 ? x : 1) + (nto > mo ? nto : mo) + (mo - ro > 1 ? mo - ro : 1);
+  return (x > 1 ? x : 1) + (acc ? 0 : (nto > mo ? nto : mo)) + (mo - ro > 1 ? mo - ro : 1);
 }
 template <int NC>
 __device__ __forceinline__ void apply_body_mma(const hssk_apply_up_desc* __restrict__ ups, int nup,
@@ -394,7 +424,7 @@ __device__ __forceinline__ void apply_body_mma(const hssk_apply_up_desc* __restr
     double* s_o = s_dyn;                                 // rows [0, r): src(perm[0:r]); rows [r, m): src(perm[r:])
     const MatOp ou[1] = {{p.X, max(r, 1), (m > r && r > 0) ? r : 0, m - r, r * MM_LDR, 0, OP_ADD, 0}};
     const bool handed = p.inner != 0;
-    if (handed) { double sink = 0.; mm_touch(ou, sink); keep(sink, s_o); }
+    { double sink = 0.; mm_touch(ou, sink); keep(sink, s_o); }
     if (handed) mm_take<NC, true>(p.src, (size_t)p.lds, m, nc, s_o, p.perm, err);
     else mm_take<NC, false>(p.src, (size_t)p.lds, m, nc, s_o, p.perm, err);
     __syncthreads();
@@ -413,7 +443,7 @@ __device__ __forceinline__ void apply_body_mma(const hssk_apply_up_desc* __restr
   const int nt1 = p.ri_a + p.ri_b, nto = p.ro_a + p.ro_b;
   const int o_x = 0;                                          // t1, later tmp2
   const int o_o = o_x + max(max(nt1, ro), 1) * MM_LDR;        // the node's result (nto rows; mo == nto below the root)
-  const int o_g = o_o + max(nto, mo) * MM_LDR;                // X^T tmp2
+  const int o_g = o_o + (p.acc ? 0 : max(nto, mo)) * MM_LDR;  // X^T tmp2
   double *s_x = s_dyn + o_x, *s_o = s_dyn + o_o, *s_g = s_dyn + o_g;
   int* s_perm = (int*)(s_g + (size_t)max(mo - ro, 1) * MM_LDR);
   if (expand && tid < mo) s_perm[tid] = p.perm[tid];
@@ -425,6 +455,23 @@ __device__ __forceinline__ void apply_body_mma(const hssk_apply_up_desc* __restr
               : MatOp{p.B10, max(p.ro_b, 1), p.ro_b, p.ri_a, o_x, o_o + p.ro_a * MM_LDR, OP_SET, 0}};
   const MatOp oX[1] = {{p.X, max(ro, 1), (expand && mo > ro) ? mo - ro : 0, ro, o_x, o_g, OP_SET, 1}};
   { double sink = 0.; mm_touch(oB, sink); mm_touch(oX, sink); keep(sink, s_x); }
+  if (p.acc) {
+    // a leaf whose op(D) x + beta y is already in `out` (a batched launch next to the sweep): out += U tmp2 in place
+    if (expand) {
+      mm_take<NC, true>(p.tmp2, (size_t)p.ld2, ro, nc, s_x, nullptr, err);
+      __syncthreads();
+      if (mo > ro) mm_stage<NC>(oX);
+      const int cs = MM_T / mo, i = tid % mo, cq = tid / mo;   // mo <= MM_T
+      if (cq < cs) {
+        const size_t row = (size_t)s_perm[i];
+        for (int c = cq; c < nc; c += cs) {
+          const double v = i < ro ? s_x[(size_t)i * MM_LDR + c] : s_g[(size_t)(i - ro) * MM_LDR + c];
+          hssk_gstore(p.out, row + (size_t)c * p.ldo, hssk_gload(p.out, row + (size_t)c * p.ldo) + v);
+        }
+      }
+    }
+    return;
+  }
   mm_take<NC, true>(p.t1, (size_t)p.ldt1, nt1, nc, s_x, nullptr, err);
   __syncthreads();
   mm_stage<NC>(oB);
@@ -433,7 +480,7 @@ __device__ __forceinline__ void apply_body_mma(const hssk_apply_up_desc* __restr
     mm_take<NC, true>(p.tmp2, (size_t)p.ld2, ro, nc, s_x, nullptr, err);
     __syncthreads();
     if (mo > ro) mm_stage<NC>(oX);
-    for (int e = tid; e < mo * MM_NC; e += SW_T) {
+    for (int e = tid; e < mo * MM_NC; e += MM_T) {
       const int c = e % NC, i = e / NC;
       if (c < nc) s_o[(size_t)s_perm[i] * MM_LDR + c] += i < ro ? s_x[(size_t)i * MM_LDR + c] : s_g[(size_t)(i - ro) * MM_LDR + c];
     }
@@ -468,9 +515,13 @@ size_t mma_lds_bytes(int nc, int rows, int ints) { return sizeof(double) * (size
 // index = node * groups + group: every group of a child still precedes every group of its parent, and the groups of a level
 // fill the chip together instead of one chain after the other).  HSSK_SWEEP_MMA_NC = 16 / 32 / 64 overrides the width,
 // HSSK_SWEEP_MMA_GROUPS the number of groups side by side (further groups in turn inside the workgroups).
-int mma_width(int nrhs, int rows, int ints) {
+int mma_width(int nrhs, int rows, int ints, int dmax) {
   static const int want = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_NC"); return e ? std::atoi(e) : 16; }();
-  for (int nc = (want == 64 || want == 32) ? want : 16; nc >= 16; nc /= 2) {
+  // (launches with large nodes -- the leaf level --: every group of right-hand sides streams the node's blocks again, so wider
+  //  groups; HSSK_SWEEP_MMA_NC_BIG overrides)
+  static const int want_big = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_NC_BIG"); return e ? std::atoi(e) : 32; }();
+  const int w = dmax >= 160 ? want_big : want;
+  for (int nc = (w == 64 || w == 32) ? w : 16; nc >= 16; nc /= 2) {
     if (nc >= 2 * nrhs && nc > 16) continue;
     if (mma_lds_bytes(nc, rows, ints) <= MM_LDS_BYTES) return nc;
   }
@@ -482,4 +533,6 @@ int mma_groups(int nrhs, int nc) {
 }
 
 #undef MM_LDR
+#undef MM_T
+#undef MM_CH
 #undef MM_NC

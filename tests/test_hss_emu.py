@@ -88,6 +88,12 @@ def test_multi_rhs_hybrid_sweeps(L):
     HC.check_multi_rhs(L, n=500, leaf=32, nrhs_list=(5, 13, 20, 64, 100))
 
 
+def test_multi_rhs_matrix_core_sweeps_large_leaves(L):
+    """leaves of 200 rows: the leaf level is its own launch of the matrix-core forward sweep, with 1024 threads per workgroup
+    and 32 right-hand sides per pass"""
+    HC.check_multi_rhs(L, n=800, leaf=200, nrhs_list=(20, 40))
+
+
 def test_multi_rhs_matrix_core_sweeps_rank_56(L):
     """inner nodes of 112 rows and rank 56: more 16-row tiles per stage than a wave prefetches, more k-steps than a tile
     prefetches, and vectors that only fit the LDS as 32-wide rows (kernels/hssk_sweep_mma.h)"""

@@ -37,6 +37,13 @@ def test_gemm_vbatched_panel_path(hk):
                                (128, 7, 50, 0, 0, 2.0, 0.5), (66, 64, 17, 0, 1, 1.0, 1.0)], seed=4, even_ld=True)
 
 
+def test_gemm_vbatched_tall_path(hk):
+    # few columns, B resident in the LDS, 128-row blocks of C per workgroup (the leaf-level products of a mat-vec / solve with
+    # many right-hand sides): ragged rows and columns, either form of A, beta, k not a multiple of the chunk
+    KC.case_gemm_vbatched(hk, [(256, 64, 256, 0, 0, 1.0, 0.0), (200, 40, 215, 0, 0, -1.0, 1.0), (130, 17, 33, 1, 0, 2.0, 0.5),
+                               (96, 64, 100, 1, 0, 1.0, 1.0), (97, 20, 64, 0, 0, 1.0, 0.0)], seed=7)
+
+
 @pytest.mark.parametrize("m,n,k,tb", [(192, 150, 64, 1), (192, 150, 64, 0), (64, 130, 48, 1), (128, 64, 32, 0)])
 def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     # even leading dimensions + 16-byte aligned operands: interior tiles take the unmasked kernel

@@ -31,6 +31,12 @@ def test_gemm_vbatched_hss_level_shapes(hk):
     KC.case_gemm_vbatched(hk, shapes, seed=11)
 
 
+def test_gemm_vbatched_tall_path(hk):
+    # few columns, B resident in the LDS (leaf-level products with many right-hand sides)
+    KC.case_gemm_vbatched(hk, [(256, 64, 256, 0, 0, 1.0, 0.0)] * 40 + [(200, 40, 215, 0, 0, -1.0, 1.0), (130, 17, 33, 1, 0, 2.0, 0.5),
+                               (96, 64, 100, 1, 0, 1.0, 1.0), (97, 20, 64, 0, 0, 1.0, 0.0), (256, 64, 215, 0, 0, 1.0, 0.0)], seed=7)
+
+
 @pytest.mark.parametrize("m,n,k,tb", [(192, 4096, 4096, 1), (192, 4096, 4096, 0), (64, 1000, 3001, 1),
                                       (130, 777, 2050, 0), (200, 65, 50, 0), (16, 64, 16, 1)])
 def test_dgemm(hk, m, n, k, tb):
