@@ -293,18 +293,27 @@ DenseMatrix<double> HSSMatrix<double>::applyC(const DenseM_t& b) const {
   apply_HSS(Trans::C, *this, b, 0., c);
   return c;
 }
-void HSSMatrix<double>::factor() { owner("factor"); eng_->factor(); }
+// (a child view: the ULV factors of its subtree with the child as the root -- "a child of an HSS matrix is itself an HSS
+//  matrix", HSSMatrix.hpp:194-202.  They live in the nodes, as the reference's ULV_ members do: factoring the whole matrix
+//  afterwards replaces them, and the other way round.)
+void HSSMatrix<double>::factor() {
+  if (veng_) veng_->factor_node(vnode_);
+  else eng_->factor();
+}
 void HSSMatrix<double>::solve(DenseM_t& b) const {
-  owner("solve");
   if (b.rows() != rows_) throw std::invalid_argument("solve: right-hand side has the wrong number of rows");
-  eng_->solve(int(b.cols()), b.data(), b.ld(), false);
+  if (veng_) veng_->solve_node(vnode_, int(b.cols()), b.data(), b.ld(), false);
+  else eng_->solve(int(b.cols()), b.data(), b.ld(), false);
 }
 void HSSMatrix<double>::shift(scalar_t sigma) { owner("shift"); eng_->shift(sigma); }
 void HSSMatrix<double>::mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta) const {
   if (veng_) veng_->mult_node(vnode_, op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);
   else eng_->mult(op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);
 }
-void HSSMatrix<double>::solve_device(int nrhs, double* db, long long ldb) const { owner("solve"); eng_->solve(nrhs, db, ldb, true); }
+void HSSMatrix<double>::solve_device(int nrhs, double* db, long long ldb) const {
+  if (veng_) veng_->solve_node(vnode_, nrhs, db, ldb, true);
+  else eng_->solve(nrhs, db, ldb, true);
+}
 
 DenseMatrix<double> HSSMatrix<double>::dense() const {
   // H * I in column blocks (HSSMatrix.cpp:188-260 re-expands recursively; test-only, O(N^2 r))

@@ -93,10 +93,11 @@ void DeviceHSS::fill_random(int r0, int dn) {
     // pattern (nnz ints per row) crosses PCIe; the dense block the tree levels need is expanded on the device.
     if (r0 == 0 || !rng_) rng_.reset(new HostRng());
     auto& e = rng_->sj;
-    if ((r0 == 0 ? o_.nnz0 : o_.nnz) > 8)
-      throw std::invalid_argument("SJLT sketch: more than 8 nonzeros per row (--hss_nnz0 / --hss_nnz) are not supported by the device pattern");
     const int nnz = std::max(1, std::min(r0 == 0 ? o_.nnz0 : o_.nnz, dn));
-    const int nq = nnz <= 4 ? 4 : 8;            // ints per row in the device pattern (hssk.h); unused ones point at column dn
+    // the device pattern holds up to 8 entries per row (hssk.h); denser sketching matrices (--hss_nnz0 / --hss_nnz > 8) keep the
+    // same distribution but travel as the dense N x dn block and take the dense sketch products
+    const bool dense_pat = nnz > 8;
+    const int nq = dense_pat ? nnz : (nnz <= 4 ? 4 : 8);   // ints per row; unused ones point at column dn
     std::vector<int> pat((size_t)nq * N, dn);
     std::uniform_int_distribution<int> sign(0, 1);
     if (o_.sjlt_algo == 0) {
@@ -116,6 +117,19 @@ void DeviceHSS::fill_random(int r0, int dn) {
           std::swap(cols[q], cols[pick(e)]);
           pat[(size_t)k * nq + q] = sign(e) == 0 ? cols[q] : (cols[q] | (int)0x80000000);
         }
+    }
+    if (dense_pat) {
+      std::vector<double> buf((size_t)dn * N, 0.);
+      host_parallel_for((size_t)N, [&](size_t k) {
+        for (int q = 0; q < nnz; q++) {
+          const int p = pat[k * nq + q];
+          buf[(size_t)(p & 0x7fffffff) + k * dn] = p < 0 ? -1. : 1.;
+        }
+      });
+      ck(hssk_memcpy2d_h2d(ctx_, Rt_ + r0, sizeof(double) * dcap_, buf.data(), sizeof(double) * dn, sizeof(double) * dn, N));
+      ck(hssk_sync(ctx_));
+      stats_.t_random += now() - t0;
+      return;
     }
     int* dp = work_->ints((size_t)nq * N);
     ck(hssk_memcpy_h2d(ctx_, dp, pat.data(), (long long)sizeof(int) * nq * N));

@@ -149,6 +149,12 @@ class DeviceHSS {
   //      Vhat (mu0 x rV0) stay resident in HBM:  S = H11 - Theta Vhat^T Phi^T.
   struct SchurDims { int n0 = 0, n1 = 0, rV0 = 0, rU0 = 0, rV1 = 0, rU1 = 0, mu0 = 0; };
   void partial_factor();
+  // A node's diagonal block as an HSS matrix of its own (HSSMatrix::child(c)->factor() / ->solve(b), HSSMatrix.hpp:194-202):
+  // ULV factors of the subtree with the node as root.  They share the node storage with the factors of the whole matrix (as
+  // the reference's per-node ULV_ members do): factoring a child replaces them, and the other way round.
+  void factor_node(int node) { factor_sub(node, false); }
+  void solve_node(int node, int nrhs, double* b, long long ldb, bool on_device) { solve_sub(node, nrhs, b, ldb, on_device); }
+  bool node_is_factored(int node) const { return node == 0 ? factored_ : sub_factored_ == node; }
   bool is_partially_factored() const { return partial_factored_; }
   SchurDims schur_dims() const;
   // computes the factors on the device; every non-null HOST pointer receives a copy (column-major)
@@ -269,6 +275,7 @@ class DeviceHSS {
   void mult_sub(int sr, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
                 bool on_device, double beta);
   void factor_sub(int sr, bool partial);
+  void solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device);
   // out (rank(sr) x c) = Ubig^T A or Vbig^T A  (apply_UtVt_big, Schur.hpp:223-252)
   void basis_up(int sr, bool useU, const double* dA, long long lda, int c, double* dOut, int ldout, Arena& wk);
   // out (rows(sr) x c) = Ubig in or Vbig in (apply_UV_big, Schur.hpp:254-323); !recurse: sr's own basis only
@@ -326,6 +333,7 @@ class DeviceHSS {
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
   int* d_ranks_ = nullptr;
   bool factored_ = false, partial_factored_ = false, schur_ready_ = false;
+  int sub_factored_ = -1;   // node whose subtree was ULV-factored as a matrix of its own (factor_node), -1: none
   std::unique_ptr<Arena> schur_;
   // device-resident node table of the extraction kernels (persist arena; rebuilt after a compression)
   void ensure_dev_tree();

@@ -195,6 +195,7 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
   if (!ti.empty()) ck(hssk_trtri_diag_vbatched(ctx_, ti.data(), (int)ti.size()));
   ck(hssk_sync(ctx_));
   factored_ = sr == 0;
+  sub_factored_ = (sr != 0 && !partial) ? sr : -1;
   partial_factored_ = partial;
   schur_ready_ = false;
   stats_.t_factor = now() - t0;

@@ -7,15 +7,26 @@ namespace HSS {
 // ---------------------------------------------------------------------------------------------
 // ULV solve (HSSMatrix.solve.hpp:69-238)
 // ---------------------------------------------------------------------------------------------
-void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
+void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) { solve_sub(0, nrhs, b, ldb, on_device); }
+
+// sr != 0: the subtree of node sr as a matrix of its own (factor_node): rows of b = the node's rows
+void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device) {
   OpGuard op_guard(op_mu_);
   ensure_ready("solve");
-  if (!factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
-  if (nrhs <= 0 || n_ == 0) return;
+  if (sr < 0 || sr >= (int)nodes_.size()) throw std::invalid_argument("solve: no such node");
+  if (sr == 0 && !factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
+  if (sr != 0 && sub_factored_ != sr) throw std::logic_error("solve: this child has not been factored (or a later factorization replaced its factors)");
+  if (sr != 0 && o_.world != 1) throw std::logic_error("solve: a child on its own needs a single-process matrix");
+  if (nrhs <= 0 || nodes_[sr].m == 0) return;
+  const int lo0 = nodes_[sr].lo;
+  std::vector<std::vector<int>> sub_h, sub_d;
+  if (sr != 0) { sub_h = sublists(own_by_height_, sr); sub_d = sublists(own_by_depth_, sr); }
+  const std::vector<std::vector<int>>& own_by_height_ = sr ? sub_h : this->own_by_height_;
+  const std::vector<std::vector<int>>& own_by_depth_ = sr ? sub_d : this->own_by_depth_;
   double t0 = now();
   // repeated solve on the same device buffer: replay the recorded sweep (no descriptor building, no staging)
   const bool plannable = on_device && o_.world == 1 && plans_enabled();
-  const PlanKey key{1, 'N', nrhs, (const void*)b, (void*)b, ldb, ldb, 0.};
+  const PlanKey key{1 + 4 * sr, 'N', nrhs, (const void*)b, (void*)b, ldb, ldb, 0.};
   if (plannable) {
     auto it = plans_.find(key);
     if (it != plans_.end() && it->second.plan) {
@@ -33,7 +44,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
   struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
   Arena& tmp = rec ? *plan_arena_ : *tmp_;   // a recorded sweep keeps its own work vectors
   if (!rec) tmp.rewind();
-  const int N = n_;
+  const int N = nodes_[sr].m;
   double* db = b;
   long long lb = ldb;
   if (!on_device) {
@@ -85,7 +96,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
         hssk_sweep_fwd_desc d{};
         d.wait0 = d.wait1 = -1;
         d.mv = nd.leaf() ? nd.m : nodes_[nd.c0].rV + nodes_[nd.c1].rV;
-        if (nd.leaf()) { d.fsrc = db + nd.lo; d.ldf = (int)lb; }
+        if (nd.leaf()) { d.fsrc = db + (nd.lo - lo0); d.ldf = (int)lb; }
         else {
           const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
           d.fsrc = f[id]; d.ldf = std::max(a.rU + c.rU, 1);
@@ -95,13 +106,13 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
           if (!d.B01 || !d.B10) return false;
           d.wait0 = where[nd.c0]; d.wait1 = where[nd.c1];
         }
-        if (nd.lvl == 0) {
+        if (id == sr) {
           // root: x = LU^{-1} f
           d.m = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
           if (d.m == 0) continue;
           d.LU = nd.LU; d.piv = nd.piv; d.TinvL = nd.Tinv; d.TinvU = nd.TinvU;
           if (!d.LU || !d.TinvL || !d.TinvU) return false;
-          d.xroot = nd.leaf() ? db + nd.lo : xb[id];
+          d.xroot = nd.leaf() ? db + (nd.lo - lo0) : xb[id];
           d.ldxr = nd.leaf() ? (int)lb : std::max(d.m, 1);
         } else {
           const Node& pa = nodes_[nd.parent];
@@ -141,7 +152,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
           if (mode == 1 && cn.leaf()) continue;
           hssk_sweep_bwd_desc d{};
           d.Qt = cn.Qt; d.y = y[cid[q]]; d.xpart = xb[id] + (q ? a.rU : 0);
-          d.out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+          d.out = cn.leaf() ? db + (cn.lo - lo0) : xb[cid[q]];
           d.m = cn.mU; d.r = cn.rU; d.ldx = std::max(a.rU + nodes_[nd.c1].rU, 1); d.ldo = cn.leaf() ? (int)lb : std::max(cn.mU, 1);
           d.wait0 = where[id];
           if (d.m > d.r && (!d.Qt || !d.y)) return false;
@@ -177,12 +188,12 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
     if (!ga.empty()) ck(hssk_gemm_vbatched(ctx_, ga.data(), (int)ga.size()));
     for (int id : ids) {
       const Node& nd = nodes_[id];
-      const double* fsrc = nd.leaf() ? db + nd.lo : f[id];
+      const double* fsrc = nd.leaf() ? db + (nd.lo - lo0) : f[id];
       const int mu = nd.leaf() ? nd.m : nodes_[nd.c0].rU + nodes_[nd.c1].rU;
       const int ldf = nd.leaf() ? (int)lb : std::max(mu, 1);
-      if (nd.lvl == 0) {
+      if (id == sr) {
         // x = LU^{-1} f (solve.hpp:133-135)
-        if (nd.leaf()) { if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, db + nd.lo, mu, nrhs, mu, (int)lb}); }
+        if (nd.leaf()) { if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, db + (nd.lo - lo0), mu, nrhs, mu, (int)lb}); }
         else {
           rg.push_back(hssk_rowgather_desc{f[id], xb[id], nullptr, mu, nrhs, ldf, std::max(mu, 1), 0, 0});
           if (mu) ls.push_back(hssk_lusolve_desc{nd.LU, nd.piv, xb[id], mu, nrhs, mu, std::max(mu, 1)});
@@ -278,7 +289,7 @@ void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) {
         if ((mode == 1 && cn.leaf()) || (mode >= 2 && !cn.leaf())) continue;
         const int mc = cn.mU, rc = cn.rU;
         const double* xpart = x + (q ? a.rU : 0);
-        double* out = cn.leaf() ? db + cn.lo : xb[cid[q]];
+        double* out = cn.leaf() ? db + (cn.lo - lo0) : xb[cid[q]];
         const int ldo = cn.leaf() ? (int)lb : std::max(mc, 1);
         if (mc > rc) {
           if (mode != 4) g1.push_back(hssk_gemm_desc{cn.Qt, y[cid[q]], out, mc, nrhs, mc - rc, mc, mc - rc, ldo, 0, 0, 1.0, 0.0});

@@ -167,6 +167,33 @@ int main(int argc, char* argv[]) {
         if (std::abs(c10->get(1 % c10->rows(), 0) - D11(1 % c10->rows(), 0)) > 1e-13) { std::cout << "ERROR: child get" << std::endl; return 1; }
       }
     }
+    // a child factored and solved as a matrix of its own: child(1)->solve(b) is D11^{-1} b, with D11 the compressed (1,1) block
+    {
+      auto c1 = H.child(1);
+      auto D11 = c1->dense();
+      DenseMatrix<double> xs(n1, 3), bs(n1, 3);
+      xs.random();
+      gemm(Trans::N, Trans::N, 1., D11, xs, 0., bs);
+      c1->factor();
+      c1->solve(bs);
+      bs.scaled_add(-1., xs);
+      std::cout << "# ||child(1)^{-1} (D11 x) - x||_F/||x||_F = " << bs.normF() / xs.normF() << std::endl;
+      if (bs.normF() > 1e-9 * xs.normF()) { std::cout << "ERROR: child(1)->factor() / solve()" << std::endl; return 1; }
+      if (!c1->leaf()) {   // a grandchild, and the whole matrix refuses to solve on the child's factors
+        auto c10 = c1->child(0);
+        auto D = c10->dense();
+        DenseMatrix<double> x2(c10->rows(), 1), b2(c10->rows(), 1);
+        x2.random();
+        gemm(Trans::N, Trans::N, 1., D, x2, 0., b2);
+        c10->factor();
+        c10->solve(b2);
+        b2.scaled_add(-1., x2);
+        if (b2.normF() > 1e-9 * x2.normF()) { std::cout << "ERROR: child(1)->child(0)->factor() / solve()" << std::endl; return 1; }
+        bool threw = false;
+        try { DenseMatrix<double> t(n1, 1); c1->solve(t); } catch (const std::logic_error&) { threw = true; }
+        if (!threw) { std::cout << "ERROR: child(1)->solve() on the factors of its child" << std::endl; return 1; }
+      }
+    }
     // S^{-1} y is the lower part of H^{-1} [0; y]
     H.factor();
     DenseMatrix<double> rhs(m, 1);

@@ -23,6 +23,9 @@ CASES = [
     ("HSS_seq_26", "T", 1000, 32, 1e-5, 1e-10, "stable", 8, 8, "perm", 4, 4),
     ("sjlt_original_T500", "T", 500, 16, 1e-8, 1e-12, "original", 32, 16, "chunk", 4, 4),
     ("sjlt_stable_U400", "U", 400, 16, 1e-6, 1e-10, "stable", 32, 8, "perm", 3, 2),
+    # more than 8 nonzeros per row: beyond the device pattern (dense block instead)
+    ("sjlt_dense_T600", "T", 600, 32, 1e-6, 1e-10, "stable", 48, 16, "chunk", 12, 10),
+    ("sjlt_dense_perm_T600", "T", 600, 32, 1e-6, 1e-10, "stable", 48, 16, "perm", 16, 9),
 ]
 REPS = 8
 
