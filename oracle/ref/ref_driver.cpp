@@ -6,6 +6,7 @@
 // reference CPU path as bench.py's cpu_baseline (kind "reference").
 // Compiled by oracle/ref/Makefile from the sources where they lie under /root/reference; the
 // resulting library lives in oracle/_ref/ (git-ignored, travels to the GPU box as a built file).
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <iostream>
@@ -359,6 +360,13 @@ int ref_blr_front(int dsep, int dupd, const double* F11, const double* F12, cons
   o.set_rel_tol(rel_tol);
   o.set_abs_tol(abs_tol);
   o.set_verbose(false);
+  // REF_BLR_ALGO = LL / COMB / STAR: the reference's other factorization variants (default RL)
+  if (const char* e = std::getenv("REF_BLR_ALGO")) {
+    const std::string a(e);
+    if (a == "LL") o.set_BLR_factor_algorithm(BLR::BLRFactorAlgorithm::LL);
+    else if (a == "COMB") o.set_BLR_factor_algorithm(BLR::BLRFactorAlgorithm::COMB);
+    else if (a == "STAR") o.set_BLR_factor_algorithm(BLR::BLRFactorAlgorithm::STAR);
+  }
   std::vector<std::size_t> t1(tiles1, tiles1 + nt1), t2(tiles2, tiles2 + nt2);
   DenseMatrix<bool> A(nt1, nt1);
   for (int j = 0; j < nt1; j++)

@@ -35,7 +35,11 @@ template <typename scalar_t> class BLROptions : public structured::StructuredOpt
   BLRFactorAlgorithm BLR_factor_algorithm() const { return blr_algo_; }
   void check_supported() const {
     if (lr_algo_ != LowRankAlgorithm::RRQR) throw std::invalid_argument("BLR: only RRQR tile compression is available (ACA / BACA are not)");
-    if (blr_algo_ != BLRFactorAlgorithm::RL) throw std::invalid_argument("BLR: only the RL factorization algorithm is available (LL / COMB / STAR / COLWISE are not)");
+    // LL applies the same dense ("always into full rank") Schur updates as RL, in left-looking order, and compresses every tile at
+    // the same point (BLR/BLRMatrix.cpp:838-990): the same factors up to the order of the sums, so it runs the RL engine.  COMB /
+    // STAR accumulate and recompress low-rank updates (LUAR, :991-1140) -- different tile ranks -- and are not available.
+    if (blr_algo_ != BLRFactorAlgorithm::RL && blr_algo_ != BLRFactorAlgorithm::LL)
+      throw std::invalid_argument("BLR: the RL and LL factorization algorithms are available (COMB / STAR / COLWISE are not)");
   }
 
  private:

@@ -94,6 +94,20 @@ int main(int argc, char* argv[]) {
     BLRMatrix<double>::construct_and_partial_factor(C11, C12, C21, C22, B11, B12, B21, tiles1, tiles2, adm, o2);
   } catch (const std::invalid_argument&) { refused = true; }
   if (!refused) { std::cout << "ERROR: unsupported algorithm accepted" << std::endl; return 1; }
+  // LL: the same dense Schur updates in left-looking order, every tile compressed at the same point (the reference's LL and RL
+  // runs agree to the last bit on these fronts): accepted, same results
+  {
+    BLROptions<double> o3;
+    o3.set_rel_tol(1e-6);
+    o3.set_BLR_factor_algorithm(BLRFactorAlgorithm::LL);
+    DenseMatrix<double> C11(F11), C12(F12), C21(F21), C22(F22);
+    BLRMatrix<double> L11, L12, L21;
+    BLRMatrix<double>::construct_and_partial_factor(C11, C12, C21, C22, L11, L12, L21, tiles1, tiles2, adm, o3);
+    DenseMatrix<double> x3(b);
+    L11.solve(x3);
+    x3.scaled_add(-1., t);
+    if (x3.normF() > 1e-6 * t.normF()) { std::cout << "ERROR: LL variant" << std::endl; return 1; }
+  }
   std::cout << "# exiting" << std::endl;
   return 0;
 }
