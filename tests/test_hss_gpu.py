@@ -233,7 +233,12 @@ def test_extract_thousand_blocks_full_size(L):
 
 def test_multi_rhs_hybrid_sweeps(L):
     HC.check_multi_rhs(L, n=4000, leaf=128, nrhs_list=(5, 13, 64))
-    HC.check_multi_rhs(L, n=3001, leaf=256, nrhs_list=(12, 64))
+    HC.check_multi_rhs(L, n=3001, leaf=256, nrhs_list=(12, 20, 64, 100, 300))
+
+
+def test_multi_rhs_matrix_core_sweeps_rank_56(L):
+    """inner nodes of 112 rows and rank 56: vectors that only fit the LDS as 32-wide rows (kernels/hssk_sweep_mma.h)"""
+    HC.check_multi_rhs(L, leaf=128, nrhs_list=(40, 70), A=HC.low_rank_plus_identity(2048, 56), d0=96)
 
 
 def test_rccl_exchange_hook_single_rank():
