@@ -740,14 +740,19 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
     if (const int nc = mma_width(nrhs, rows, 2 * SW_T, dmax)) {
       const size_t bytes = mma_lds_bytes(nc, rows, 2 * SW_T);
       mma_launches++;
-      // (launches with large nodes -- the leaf level -- take more waves per workgroup: the LDS leaves room for one workgroup
-      //  per CU, and one wave per SIMD keeps the FP64 matrix pipe at a third of its rate; HSSK_SWEEP_MMA_T_BIG overrides)
-      static const int tb_big = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_T_BIG"); const int v = e ? std::atoi(e) : 512; return (v == 512 || v == 1024) ? v : SW_T; }();
+      // (HSSK_SWEEP_MMA_T_BIG = 512 / 1024: more waves per workgroup for the launches with large nodes -- the leaf level.
+      //  Measured at N = 1e5, nrhs = 64: solve 0.54 ms with 256 threads, 0.63 with 512, 0.69 with 1024: the stages of a node are
+      //  a dependent chain, and their barriers cost more with more waves than the extra tiles in flight bring)
+      static const int tb_big = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_T_BIG"); const int v = e ? std::atoi(e) : SW_T; return (v == 512 || v == 1024) ? v : SW_T; }();
       const int tb = (dmax >= 160 && nc <= 32) ? tb_big : SW_T;
+      bool leaves_only = true;
+      for (int i = 0; i < count; i++) leaves_only = leaves_only && !descs[i].B01 && descs[i].wait0 < 0 && descs[i].wait1 < 0;
       auto go = [&](auto kernel) {
         hssk_rt::allow_dynamic_lds(kernel, bytes);
         const int ng = mma_groups(nrhs, nc);
-        HSSK_LAUNCH(kernel, dim3((unsigned)count * ng), dim3((unsigned)tb), bytes, ctx->stream, dd, nrhs, ng, sweep_err(ctx));
+        const int xcd = (leaves_only && ng > 1 && count >= 8) ? 1 : 0;
+        const unsigned grid = xcd ? (unsigned)((count + 7) / 8) * 8u * (unsigned)ng : (unsigned)count * (unsigned)ng;
+        HSSK_LAUNCH(kernel, dim3(grid), dim3((unsigned)tb), bytes, ctx->stream, dd, count, nrhs, ng, xcd, sweep_err(ctx));
       };
       if (tb == 1024 && nc == 32) go(ulv_fwd_sweep_mma_kernel<32, 1024>);
       else if (tb == 1024 && nc == 16) go(ulv_fwd_sweep_mma_kernel<16, 1024>);

@@ -190,9 +190,20 @@ __device__ __forceinline__ void mm_copy(double* dst, const double* src, int rows
 
 // ---- LDS budgets (rows of MM_LDR doubles) of the three bodies: the host checks them, the kernels lay their blocks out by them
 struct FwdRows { int f, y, a, t, z; };
+// A leaf below the root takes the slim layout: its right-hand-side rows go straight through permU into [ft1; y] (no block for f,
+// none for the children's z), and f only names the 64-row block buffer of the substitution -- 300 rows instead of 550 for a
+// 195-row leaf of rank 41: three workgroups per CU at 16 right-hand sides per pass.
 __host__ __device__ inline FwdRows mm_fwd_rows(int m, int r, int mv, int rv, bool root, bool inner) {
   FwdRows R;
   const int q = m - r;
+  if (!inner && !root) {
+    R.t = r;
+    R.y = q;
+    R.z = rv > 1 ? rv : 1;
+    R.f = q < SW_NB ? (q > 1 ? q : 1) : SW_NB;
+    R.a = 1;   // (unused; keeps the sum an upper bound when r == 0)
+    return R;
+  }
   if (!inner) mv = rv;   // (a leaf has no children's z: nothing to stack, nothing beyond its own z)
   R.f = m > 1 ? m : 1;
   R.y = (mv - rv > q ? mv - rv : q);
@@ -214,13 +225,15 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   const FwdRows R = mm_fwd_rows(m, r, mv, rv, root, p.B01 != nullptr);
   // (row blocks by their offsets into the workgroup's LDS: the stages address them through s_dyn itself, so the compiler
   //  emits LDS instructions, not flat ones)
-  const int o_f = 0;                        // f, later the block right-hand side of the substitution
-  const int o_y = o_f + R.f * MM_LDR;       // zc(permV[rv:]) first, then y
-  const int o_a = o_y + R.y * MM_LDR;       // stacked children z (inner nodes)
-  const int o_t = o_a + R.a * MM_LDR;       // ft1 (root: block right-hand side)
-  const int o_z = o_t + R.t * MM_LDR;       // z
+  const bool slim = p.B01 == nullptr && !root;   // (mm_fwd_rows: [ft1; y], z, block buffer)
+  const int o_f = slim ? (R.t + R.y + R.z) * MM_LDR : 0;   // f, later the block right-hand side of the substitution
+  const int o_y = slim ? R.t * MM_LDR : o_f + R.f * MM_LDR;   // zc(permV[rv:]) first, then y
+  const int o_a = slim ? o_f : o_y + R.y * MM_LDR;          // stacked children z (inner nodes)
+  const int o_t = slim ? 0 : o_a + R.a * MM_LDR;            // ft1 (root: block right-hand side)
+  const int o_z = slim ? (R.t + R.y) * MM_LDR : o_t + R.t * MM_LDR;   // z
+  const int o_end = slim ? o_f + (R.f + R.a) * MM_LDR : o_z + R.z * MM_LDR;
   double *s_f = s_dyn + o_f, *s_y = s_dyn + o_y, *s_a = s_dyn + o_a, *s_t = s_dyn + o_t, *s_z = s_dyn + o_z;
-  int* s_pu = (int*)(s_z + (size_t)R.z * MM_LDR);   // permU or the root's pivots (m), then permV (mv)
+  int* s_pu = (int*)(s_dyn + o_end);   // permU or the root's pivots (m), then permV (mv)
   int* s_pv = s_pu + max(m, 1);
   const int c0 = group * MM_NC;
   const int nc = min(MM_NC, nrhs_total - c0);
@@ -264,6 +277,9 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   if (inner) {
     mm_take<NC, true>(p.fsrc, (size_t)p.ldf, m, nc, s_f, nullptr, err);
     mm_take<NC, true>(p.zc, (size_t)p.ldz_in, mv, nc, s_a, nullptr, err);
+  } else if (slim) {
+    __syncthreads();   // (permU is in LDS)
+    mm_take<NC, false>(p.fsrc, (size_t)p.ldf, m, nc, s_t, s_pu, err);   // rows through permU: [ft1; y] in place
   } else mm_take<NC, false>(p.fsrc, (size_t)p.ldf, m, nc, s_f, nullptr, err);
   __syncthreads();
   if (inner) {
@@ -320,7 +336,7 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
     return;
   }
   // ---- ft1 = f(perm[0:r]) -> s_t, y = f(perm[r:]) -> s_y
-  for (int e = tid; e < m * MM_NC; e += MM_T) {
+  for (int e = tid; e < (slim ? 0 : m * MM_NC); e += MM_T) {
     const int c = e % NC, i = e / NC;
     if (c < nc) {
       const double v = s_f[(size_t)s_pu[i] * MM_LDR + c];
@@ -355,10 +371,15 @@ __device__ __forceinline__ void ulv_fwd_body_mma(const hssk_sweep_fwd_desc* __re
   mm_put<NC, true>(p.z, (size_t)p.ldz, rv, nc, s_z);
 }
 
+// xcd != 0 (a launch of leaves only: no dependencies between its workgroups): the groups of a node sit on workgroup ids that
+// are congruent mod 8 and adjacent in time -- workgroup b runs on XCD b % 8 and every XCD has its own L2, so the groups,
+// which stream the same blocks, fetch them from HBM once; the grid is padded to a multiple of 8 x groups.
 template <int NC, int TB>
-__global__ __launch_bounds__(TB) void ulv_fwd_sweep_mma_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int ngroups, int* err) {
-  const int node = blockIdx.x / ngroups;
-  for (int g = blockIdx.x % ngroups; g * MM_NC < nrhs_total; g += ngroups) {
+__global__ __launch_bounds__(TB) void ulv_fwd_sweep_mma_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int count, int nrhs_total, int ngroups, int xcd, int* err) {
+  const int b = blockIdx.x;
+  const int node = xcd ? (b / (8 * ngroups)) * 8 + (b & 7) : b / ngroups;
+  if (node >= count) return;
+  for (int g = xcd ? (b >> 3) % ngroups : b % ngroups; g * MM_NC < nrhs_total; g += ngroups) {
     ulv_fwd_body_mma<NC>(descs, node, nrhs_total, err, g);
     __syncthreads();
   }
@@ -519,7 +540,7 @@ int mma_width(int nrhs, int rows, int ints, int dmax) {
   static const int want = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_NC"); return e ? std::atoi(e) : 16; }();
   // (launches with large nodes -- the leaf level --: every group of right-hand sides streams the node's blocks again, so wider
   //  groups; HSSK_SWEEP_MMA_NC_BIG overrides)
-  static const int want_big = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_NC_BIG"); return e ? std::atoi(e) : 32; }();
+  static const int want_big = [] { const char* e = std::getenv("HSSK_SWEEP_MMA_NC_BIG"); return e ? std::atoi(e) : 16; }();
   const int w = dmax >= 160 ? want_big : want;
   for (int nc = (w == 64 || w == 32) ? w : 16; nc >= 16; nc /= 2) {
     if (nc >= 2 * nrhs && nc > 16) continue;

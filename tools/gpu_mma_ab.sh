@@ -10,10 +10,10 @@ PY
 }
 export STRUMPACK_AMD_BENCH_NO_PMC=1
 run default A=1
-run t512 HSSK_SWEEP_MMA_T_BIG=512
+run default_again A=1
+run big32 HSSK_SWEEP_MMA_NC_BIG=32
 run t256 HSSK_SWEEP_MMA_T_BIG=256
-run big16_t512 HSSK_SWEEP_MMA_NC_BIG=16 HSSK_SWEEP_MMA_T_BIG=512
-run big16_t1024 HSSK_SWEEP_MMA_NC_BIG=16 HSSK_SWEEP_MMA_T_BIG=1024
+run t1024 HSSK_SWEEP_MMA_T_BIG=1024
 run notall HSSK_GEMM_NO_TALL=1
 timeout 600 python -m pytest tests/test_hss_gpu.py tests/test_kernels_gpu.py -x -q -k "multi_rhs or gemm" > $out/pytest.log 2>&1; tail -3 $out/pytest.log
 cd /tmp; export TMPDIR=/tmp
