@@ -69,6 +69,25 @@ int main(int argc, char* argv[]) {
     if (C.normF() / Cc.normF() > tol) { std::cout << "ERROR: transposed product error too big!!" << std::endl; return 1; }
   }
 
+  // C = H B + beta C with many right-hand sides (the leaves' D B + beta C runs next to the tree sweep, on a side stream):
+  // against the same product column by column
+  {
+    const int nb = 20;
+    DenseMatrix<double> B(m, nb), C(m, nb), C1(m, nb);
+    B.random();
+    C.random();
+    C1.copy(C);
+    apply_HSS(Trans::N, H, B, -0.5, C);
+    for (int j = 0; j < nb; j++) {
+      DenseMatrix<double> bj(m, 1), cj(m, 1);
+      for (int i = 0; i < m; i++) { bj(i, 0) = B(i, j); cj(i, 0) = C1(i, j); }
+      apply_HSS(Trans::N, H, bj, -0.5, cj);
+      for (int i = 0; i < m; i++) C1(i, j) = cj(i, 0);
+    }
+    C.scaled_add(-1., C1);
+    if (C.normF() > 1e-12 * C1.normF()) { std::cout << "ERROR: H B + beta C with 20 right-hand sides: " << C.normF() / C1.normF() << std::endl; return 1; }
+  }
+
   std::default_random_engine gen;
   std::uniform_int_distribution<std::size_t> random_idx(0, m - 1);
   double ex_err = 0;
