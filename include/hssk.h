@@ -80,6 +80,22 @@ int hssk_is_device_pointer(const void* ptr);
 /* Two contexts = two streams of the same device: the work enqueued on `waiter` from now on starts after everything enqueued so
  * far on `on` has finished (an event recorded on `on`'s stream, waited for by `waiter`'s).  Nothing blocks on the host.  This is how
  * a BLR block step factors its diagonal tile next to the compression of its block row and column. */
+/* Batched adaptive cross approximation A (m x n, lda) ~ U V^T of dense tiles, one workgroup per tile
+ * (adaptive_cross_approximation, dense/ACA.cpp:41-118: the tile compression of BLR matrices under --blr_low_rank_algorithm ACA).
+ * U (m x rank, ldu) and V (n x rank, ldv) need room for min(m, n, max_rank) columns; row0 = the first row (the reference
+ * draws it from a default-seeded std::mt19937); m, n <= 2048. */
+typedef struct hssk_aca_desc {
+  const double* A;
+  int lda, m, n;
+  double rtol, atol;
+  int max_rank, row0;
+  double* U;
+  int ldu;
+  double* V;
+  int ldv;
+  int* rank; /* out (device) */
+} hssk_aca_desc;
+int hssk_aca_vbatched(hssk_ctx* ctx, const hssk_aca_desc* descs, int count);
 /* Side stream of a context: launches issued between hssk_side_begin and hssk_side_end go to a second stream that first
  * waits for everything issued on the main stream so far; hssk_side_join makes the main stream wait for them.  For work
  * that does not depend on what the main stream does meanwhile (the leaves' D x of a mat-vec next to the tree sweep).

@@ -235,6 +235,9 @@ int SPX_d_blr_front_factor_device(SPXBLRFront* F, int dsep, int dupd, const doub
                                   int ntiles1, const int* tiles1, int ntiles2, const int* tiles2, const char* admissible,
                                   const CSPOptions* opts);
 void SPX_d_blr_front_time_phases(int on);
+/* tile compression of the BLR fronts made through this interface afterwards (the reference's BLROptions::set_low_rank_algorithm,
+ * which its C options struct does not carry): 0 RRQR (truncated pivoted QR, the default), 1 ACA; returns non-zero for others */
+int SPX_blr_low_rank_algorithm(int algo);
 int SPX_d_blr_front_forward(const SPXBLRFront F, int nrhs, double* bsep, int ldb, double* bupd, int ldu);
 int SPX_d_blr_front_backward(const SPXBLRFront F, int nrhs, double* ysep, int ldy, const double* yupd, int ldu);
 int SPX_d_blr_front_schur(const SPXBLRFront F, double* F22, int ld22);

@@ -367,6 +367,12 @@ int ref_blr_front(int dsep, int dupd, const double* F11, const double* F12, cons
     else if (a == "COMB") o.set_BLR_factor_algorithm(BLR::BLRFactorAlgorithm::COMB);
     else if (a == "STAR") o.set_BLR_factor_algorithm(BLR::BLRFactorAlgorithm::STAR);
   }
+  // REF_BLR_LRA = ACA / BACA: the tile compression (default RRQR)
+  if (const char* e = std::getenv("REF_BLR_LRA")) {
+    const std::string a(e);
+    if (a == "ACA") o.set_low_rank_algorithm(BLR::LowRankAlgorithm::ACA);
+    else if (a == "BACA") o.set_low_rank_algorithm(BLR::LowRankAlgorithm::BACA);
+  }
   std::vector<std::size_t> t1(tiles1, tiles1 + nt1), t2(tiles2, tiles2 + nt2);
   DenseMatrix<bool> A(nt1, nt1);
   for (int j = 0; j < nt1; j++)

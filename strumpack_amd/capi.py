@@ -33,7 +33,7 @@ SP_SYMBOLS = [
     "SPX_d_struct_from_dense_device_comm", "SPX_d_struct_from_blocks_device", "SPX_d_struct_from_blocks_device_cb",
     "SPX_d_struct_from_kernel_comm",
     "SPX_d_struct_extract_blocks",
-    "SPX_d_blr_front_factor", "SPX_d_blr_front_factor_device", "SPX_d_blr_front_time_phases", "SPX_d_blr_front_forward",
+    "SPX_d_blr_front_factor", "SPX_d_blr_front_factor_device", "SPX_d_blr_front_time_phases", "SPX_blr_low_rank_algorithm", "SPX_d_blr_front_forward",
     "SPX_d_blr_front_backward", "SPX_d_blr_front_schur", "SPX_d_blr_front_schur_device", "SPX_d_blr_front_tile_ranks",
     "SPX_d_blr_front_stats", "SPX_d_blr_front_destroy",
 ]
@@ -113,6 +113,8 @@ def load(path):
                                                 C.c_int, ip, C.c_int, ip, C.c_char_p, C.POINTER(CSPOptions)]
     L.SPX_d_blr_front_time_phases.argtypes = [C.c_int]
     L.SPX_d_blr_front_time_phases.restype = None
+    L.SPX_blr_low_rank_algorithm.argtypes = [C.c_int]
+    L.SPX_blr_low_rank_algorithm.restype = C.c_int
     L.SPX_d_blr_front_forward.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
     L.SPX_d_blr_front_backward.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
     L.SPX_d_blr_front_schur.argtypes = [vp, dp, C.c_int]

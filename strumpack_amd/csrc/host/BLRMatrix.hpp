@@ -34,7 +34,8 @@ template <typename scalar_t> class BLROptions : public structured::StructuredOpt
   Admissibility admissibility() const { return adm_; }
   BLRFactorAlgorithm BLR_factor_algorithm() const { return blr_algo_; }
   void check_supported() const {
-    if (lr_algo_ != LowRankAlgorithm::RRQR) throw std::invalid_argument("BLR: only RRQR tile compression is available (ACA / BACA are not)");
+    if (lr_algo_ != LowRankAlgorithm::RRQR && lr_algo_ != LowRankAlgorithm::ACA)
+      throw std::invalid_argument("BLR: RRQR and ACA tile compression are available (BACA is not)");
     // LL applies the same dense ("always into full rank") Schur updates as RL, in left-looking order, and compresses every tile at
     // the same point (BLR/BLRMatrix.cpp:838-990): the same factors up to the order of the sums, so it runs the RL engine.  COMB /
     // STAR accumulate and recompress low-rank updates (LUAR, :991-1140) -- different tile ranks -- and are not available.
@@ -104,6 +105,7 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
     tiles.insert(tiles.end(), tiles2.begin(), tiles2.end());
     BLREngineOptions e;
     e.rel_tol = opts.rel_tol(); e.abs_tol = opts.abs_tol(); e.max_rank = opts.max_rank(); e.verbose = opts.verbose();
+    e.lr_algo = opts.low_rank_algorithm() == LowRankAlgorithm::ACA ? 1 : 0;
     if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
     std::shared_ptr<DeviceBLR> eng(new DeviceBLR(int(ds + du), tiles, int(ds + du), tiles, e));
     std::vector<char> adm(tiles1.size() * tiles1.size());
@@ -185,6 +187,7 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
   void make(const Opts_t& o) {
     BLREngineOptions e;
     e.rel_tol = o.rel_tol(); e.abs_tol = o.abs_tol(); e.max_rank = o.max_rank(); e.verbose = o.verbose();
+    e.lr_algo = o.low_rank_algorithm() == LowRankAlgorithm::ACA ? 1 : 0;
     if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
     eng_.reset(new DeviceBLR(int(m_), rt_, int(n_), ct_, e));
     part_ = 0;

@@ -498,6 +498,7 @@ int SPX_d_struct_extract_blocks(const CSPStructMat S, int nb, const int* rows, c
 extern "C++" {
 namespace {
 bool g_blr_time_phases = false;
+int g_blr_low_rank_algorithm = 0;   // SPX_blr_low_rank_algorithm: what the BLR fronts made through this interface compress their tiles with
 std::unique_ptr<BLR::DeviceBLR> make_front(int dsep, int dupd, int nt1, const int* t1, int nt2, const int* t2, const CSPOptions* opts) {
   if (dsep < 0 || dupd < 0 || nt1 < 0 || nt2 < 0 || (nt1 && !t1) || (nt2 && !t2)) throw std::invalid_argument("BLR front: bad dimensions");
   std::vector<int> tiles(t1, t1 + nt1);
@@ -511,6 +512,7 @@ std::unique_ptr<BLR::DeviceBLR> make_front(int dsep, int dupd, int nt1, const in
   e.rel_tol = opts ? opts->rel_tol : d.rel_tol();
   e.abs_tol = opts ? opts->abs_tol : d.abs_tol();
   e.max_rank = opts ? opts->max_rank : d.max_rank();
+  e.lr_algo = g_blr_low_rank_algorithm;
   e.verbose = opts && opts->verbose;
   if (const char* dv = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(dv);
   std::unique_ptr<BLR::DeviceBLR> f(new BLR::DeviceBLR(dsep + dupd, tiles, dsep + dupd, tiles, e));
@@ -524,6 +526,11 @@ inline BLR::DeviceBLR* front(const SPXBLRFront F) {
 }  // namespace
 }  // extern "C++"
 void SPX_d_blr_front_time_phases(int on) { g_blr_time_phases = on != 0; }
+int SPX_blr_low_rank_algorithm(int algo) {
+  if (algo != 0 && algo != 1) return 1;   // 0 RRQR, 1 ACA (BLR::LowRankAlgorithm; BACA is not available)
+  g_blr_low_rank_algorithm = algo;
+  return 0;
+}
 int SPX_d_blr_front_factor(SPXBLRFront* F, int dsep, int dupd, const double* F11, int ld11, const double* F12, int ld12,
                            const double* F21, int ld21, double* F22, int ld22, int ntiles1, const int* tiles1, int ntiles2,
                            const int* tiles2, const char* admissible, const CSPOptions* opts) {

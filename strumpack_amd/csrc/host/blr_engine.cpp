@@ -1,6 +1,7 @@
 // DeviceBLR implementation (see blr_engine.hpp for the reference behaviour it follows).
 #include "blr_engine.hpp"
 
+#include <random>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -143,6 +144,54 @@ void DeviceBLR::compress_tiles(const std::vector<std::pair<int, int>>& ij, const
     idd.push_back(hssk_id_desc{W[k], m, m, n, o_.rel_tol, o_.abs_tol, rpay, perm[k], ranks + k, tmp.dbl(3 * (size_t)n)});
   }
   std::vector<int> hr(cnt, 0);
+  if (o_.lr_algo == 1) {
+    // adaptive cross approximation (BLR/LRTile.cpp:66-74 -> dense/ACA.cpp:41-118): U and V straight from rows and columns of
+    // the tile in the array; the factors that pay (rank (m + n) <= m n) are copied to their place
+    std::vector<hssk_aca_desc> ad;
+    std::vector<double*> Ua(cnt, nullptr), Va(cnt, nullptr);
+    std::vector<int> rcap(cnt, 0);
+    for (size_t k = 0; k < cnt; k++) {
+      if (!want[k]) continue;
+      const int i = ij[k].first, j = ij[k].second, m = tm(i), n = tn(j);
+      const int rpay = (int)std::min<long long>(std::min<long long>(((long long)m * n) / (m + n) + 1, (long long)o_.max_rank), std::min(m, n));
+      rcap[k] = std::max(rpay, 1);
+      Ua[k] = tmp.dbl((size_t)m * rcap[k]);
+      Va[k] = tmp.dbl((size_t)n * rcap[k]);
+      // the reference's first row: a default-seeded std::mt19937 drawn on [0, m) (ACA.cpp:55-57)
+      std::mt19937 mt;
+      std::uniform_int_distribution<int> rgen(0, m - 1);
+      ad.push_back(hssk_aca_desc{blk(i, j), (int)ld_, m, n, o_.rel_tol, o_.abs_tol, rcap[k], rgen(mt), Ua[k], m, Va[k], n, ranks + k});
+    }
+    if (!ad.empty()) {
+      ck(hssk_aca_vbatched(ctx_, ad.data(), (int)ad.size()));
+      ck(hssk_memcpy_d2h(ctx_, hr.data(), ranks, (long long)sizeof(int) * cnt));
+    }
+    std::vector<hssk_colgather_desc> cu;
+    for (size_t k = 0; k < cnt; k++) {
+      const int i = ij[k].first, j = ij[k].second, m = tm(i), n = tn(j);
+      Tile& t = tile(i, j);
+      const int r = want[k] ? hr[k] : n;
+      t.lowrank = want[k] && (long long)r * (m + n) <= (long long)m * n;
+      t.r = t.lowrank ? r : n;
+      if (!t.U) t.U = store_->dbl((size_t)m * t.r);
+      t.V = store_->dbl((size_t)n * t.r);
+      if (t.lowrank) {
+        if (t.r > 0 && m > 0) cu.push_back(hssk_colgather_desc{Ua[k], t.U, nullptr, m, t.r, m, m, 0});
+        if (t.r > 0 && n > 0) cu.push_back(hssk_colgather_desc{Va[k], t.V, nullptr, n, t.r, n, n, 0});
+      } else {   // kept dense: U = the tile, V = I
+        if (m > 0 && n > 0) cu.push_back(hssk_colgather_desc{blk(i, j), t.U, nullptr, m, n, (int)ld_, m, 0});
+      }
+    }
+    if (!cu.empty()) ck(hssk_gather_cols(ctx_, cu.data(), (int)cu.size()));
+    std::vector<hssk_basis_desc> eye;
+    for (size_t k = 0; k < cnt; k++) {
+      const int i = ij[k].first, j = ij[k].second, n = tn(j);
+      Tile& t = tile(i, j);
+      if (!t.lowrank && t.r > 0 && n > 0) eye.push_back(hssk_basis_desc{nullptr, diota, t.V, n, t.r, tm(i), n});
+    }
+    if (!eye.empty()) ck(hssk_basis_dense(ctx_, eye.data(), (int)eye.size()));
+    return;
+  }
   if (!idd.empty()) {
     ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
     ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));

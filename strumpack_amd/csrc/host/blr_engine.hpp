@@ -32,6 +32,7 @@ struct BLREngineOptions {
   int max_rank = 5000;
   int device = 0;
   bool verbose = false;
+  int lr_algo = 0;   // tile compression: 0 truncated pivoted QR (RRQR), 1 adaptive cross approximation (ACA)
 };
 
 class Arena2;

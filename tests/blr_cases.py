@@ -20,6 +20,7 @@ CASES = {
     "p64_unsym_strong": (64, 6, 10, 256, "left", True, "strong", 1e-6, "gpu"),
 }
 NRHS = 3
+ACA_CASES = ("p16_weak", "p12_unsym_strong", "p40_weak")   # also recorded with ACA tile compression
 
 
 def build_case(name):
@@ -87,6 +88,40 @@ def check_front(L, name, G=None):
     assert err(fr["F11"] @ x, fr["bsep"]) <= max(3 * float(G[name + "_x11_resid"]), 10 * rtol)
     F.destroy()
     return st
+
+
+def check_front_aca(L, name, G=None):
+    """the same front with ACA tile compression (SPX_blr_low_rank_algorithm(1); C++: BLROptions::set_low_rank_algorithm):
+    the reference's ACA takes its first row from a default-seeded std::mt19937 and is deterministic from there, so the tile
+    ranks are the reference's (a different pivot after a rounding tie is allowed on a few tiles) and the Schur complement and
+    the solve phases agree to the compression tolerance"""
+    G = G if G is not None else golden()
+    fr = build_case(name)
+    rtol = fr["rel_tol"]
+    o = capi.StructuredMatrix.options(L, rel_tol=rtol, abs_tol=fr["abs_tol"], type=capi.SP_TYPE_BLR)
+    assert L.SPX_blr_low_rank_algorithm(2) != 0      # BACA: refused
+    assert L.SPX_blr_low_rank_algorithm(1) == 0
+    try:
+        F, S = capi.BLRFront.factor(L, fr["F11"], fr["F12"], fr["F21"], fr["F22"], fr["tiles1"], fr["tiles2"], o, admissible=fr["adm"])
+    finally:
+        L.SPX_blr_low_rank_algorithm(0)
+    nt1, nt = len(fr["tiles1"]), len(fr["tiles1"]) + len(fr["tiles2"])
+    rk, rref = F.tile_ranks(), G[name + "_aca_ranks"]
+    part = np.ones((nt, nt), dtype=bool)
+    part[nt1:, nt1:] = False
+    assert np.array_equal(rk[part] < 0, rref[part] < 0), (name, "dense / low-rank decisions differ")
+    lr = part & (rref >= 0)
+    diff = np.abs(rk[lr] - rref[lr])
+    assert (diff > 0).mean() <= 0.1 and diff.max(initial=0) <= max(2, int(0.15 * rref[lr].max(initial=1))), (name, (diff > 0).mean(), diff.max())
+    # ACA is less accurate than the pivoted QR at the same tolerance (the reference's own Schur complement error says how much)
+    tol = max(10 * rtol, 3 * float(G[name + "_aca_Serr"]))
+    assert err(S @ fr["R"], G[name + "_aca_SR"]) <= tol
+    assert abs(np.linalg.norm(S) - G[name + "_aca_Snorm"]) <= tol * G[name + "_aca_Snorm"]
+    assert err(S, BF.dense_schur(fr)) <= max(3 * float(G[name + "_aca_Serr"]), 10 * rtol)
+    fs, fu = F.forward(fr["bsep"], fr["bupd"])
+    assert err(fs, G[name + "_aca_fwd_sep"]) <= tol and err(fu, G[name + "_aca_fwd_upd"]) <= tol
+    assert err(F.backward(fr["ysep"], fr["yupd"]), G[name + "_aca_bwd_sep"]) <= tol
+    F.destroy()
 
 
 def check_front_api(L):

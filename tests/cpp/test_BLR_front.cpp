@@ -94,6 +94,27 @@ int main(int argc, char* argv[]) {
     BLRMatrix<double>::construct_and_partial_factor(C11, C12, C21, C22, B11, B12, B21, tiles1, tiles2, adm, o2);
   } catch (const std::invalid_argument&) { refused = true; }
   if (!refused) { std::cout << "ERROR: unsupported algorithm accepted" << std::endl; return 1; }
+  // ACA tile compression (BLROptions::set_low_rank_algorithm): accepted, accurate to its tolerance; BACA is refused
+  {
+    BLROptions<double> o4;
+    o4.set_rel_tol(1e-8);
+    o4.set_low_rank_algorithm(LowRankAlgorithm::ACA);
+    DenseMatrix<double> C11(F11), C12(F12), C21(F21), C22(F22);
+    BLRMatrix<double> A11, A12, A21;
+    BLRMatrix<double>::construct_and_partial_factor(C11, C12, C21, C22, A11, A12, A21, tiles1, tiles2, adm, o4);
+    DenseMatrix<double> x4(b);
+    A11.solve(x4);
+    x4.scaled_add(-1., t);
+    std::cout << "# ACA tiles, B11 \\ b against the dense solve: " << x4.normF() / t.normF() << std::endl;
+    if (x4.normF() > 1e-5 * t.normF()) { std::cout << "ERROR: ACA variant" << std::endl; return 1; }
+    bool refused_baca = false;
+    try {
+      o4.set_low_rank_algorithm(LowRankAlgorithm::BACA);
+      DenseMatrix<double> E11(F11), E12(F12), E21(F21), E22(F22);
+      BLRMatrix<double>::construct_and_partial_factor(E11, E12, E21, E22, A11, A12, A21, tiles1, tiles2, adm, o4);
+    } catch (const std::invalid_argument&) { refused_baca = true; }
+    if (!refused_baca) { std::cout << "ERROR: BACA accepted" << std::endl; return 1; }
+  }
   // LL: the same dense Schur updates in left-looking order, every tile compressed at the same point (the reference's LL and RL
   // runs agree to the last bit on these fronts): accepted, same results
   {
