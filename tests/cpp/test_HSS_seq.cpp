@@ -190,9 +190,14 @@ int main(int argc, char* argv[]) {
     {
       auto c1 = H.child(1);
       auto D11 = c1->dense();
-      DenseMatrix<double> xs(n1, 3), bs(n1, 3);
+      DenseMatrix<double> xs(n1, 20), bs(n1, 20);   // (20 columns: the many-right-hand-side forms of the sweeps, on a subtree)
       xs.random();
       gemm(Trans::N, Trans::N, 1., D11, xs, 0., bs);
+      {
+        auto ys = c1->apply(xs);
+        ys.scaled_add(-1., bs);
+        if (ys.normF() > 1e-12 * bs.normF()) { std::cout << "ERROR: child(1)->apply with 20 columns" << std::endl; return 1; }
+      }
       c1->factor();
       c1->solve(bs);
       bs.scaled_add(-1., xs);

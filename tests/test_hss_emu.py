@@ -64,6 +64,7 @@ def test_sweep_plans(L):
     from strumpack_amd import hssk as K
     hk = K.Hssk(emu_lib.PATH)
     HC.check_sweep_plans(L, hk, n=130)
+    HC.check_sweep_plans(L, hk, n=130, nrhs=20)
     hk.close()
 
 

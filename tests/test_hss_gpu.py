@@ -84,6 +84,7 @@ def test_sweep_plans(L):
     from strumpack_amd import hssk as K
     hk = K.Hssk(_loader.lib_path())
     HC.check_sweep_plans(L, hk, n=3000)
+    HC.check_sweep_plans(L, hk, n=3000, nrhs=20)
     hk.close()
 
 
