@@ -33,6 +33,9 @@ inline Trans c2T(char op) {
   }
 }
 
+template <typename T> inline T conj_of(const T& v) { return v; }
+template <typename T> inline std::complex<T> conj_of(const std::complex<T>& v) { return std::conj(v); }
+
 template <typename scalar_t> class DenseMatrix {
  public:
   DenseMatrix() {}
@@ -125,6 +128,119 @@ template <typename scalar_t> class DenseMatrix {
     for (std::size_t j = 0; j < cols_; j++)
       for (std::size_t i = 0; i < rows_; i++) T(j, i) = (*this)(i, j);
     return T;
+  }
+  // (real scalars: the plain transpose; complex: conjugated -- dense/DenseMatrix.hpp:431-436)
+  DenseMatrix<scalar_t> conj_transpose() const {
+    DenseMatrix<scalar_t> T(cols_, rows_);
+    conj_transpose(T);
+    return T;
+  }
+  void conj_transpose(DenseMatrix<scalar_t>& X) const {
+    assert(X.rows() == cols_ && X.cols() == rows_);
+    for (std::size_t j = 0; j < cols_; j++)
+      for (std::size_t i = 0; i < rows_; i++) X(j, i) = conj_of((*this)(i, j));
+  }
+  // this = alpha this + B; rows scaled / divided by D (dense/DenseMatrix.cpp:463-541)
+  DenseMatrix<scalar_t>& scale_and_add(scalar_t alpha, const DenseMatrix<scalar_t>& B, int = 0) {
+    assert(B.rows() == rows_ && B.cols() == cols_);
+    for (std::size_t j = 0; j < cols_; j++) for (std::size_t i = 0; i < rows_; i++) (*this)(i, j) = alpha * (*this)(i, j) + B(i, j);
+    return *this;
+  }
+  DenseMatrix<scalar_t>& scale_rows(const std::vector<scalar_t>& D, int = 0) { assert(D.size() == rows_); return scale_rows(D.data()); }
+  DenseMatrix<scalar_t>& scale_rows(const scalar_t* D, int = 0) {
+    for (std::size_t j = 0; j < cols_; j++) for (std::size_t i = 0; i < rows_; i++) (*this)(i, j) *= D[i];
+    return *this;
+  }
+  DenseMatrix<scalar_t>& div_rows(const std::vector<scalar_t>& D, int = 0) {
+    for (std::size_t j = 0; j < cols_; j++) for (std::size_t i = 0; i < rows_; i++) (*this)(i, j) /= D[i];
+    return *this;
+  }
+  // A(i, i) += sigma; counts of exact zeros / of entries that are not normal numbers (dense/DenseMatrix.cpp:813-860)
+  void shift(scalar_t sigma) { for (std::size_t i = 0; i < std::min(rows_, cols_); i++) (*this)(i, i) += sigma; }
+  std::size_t zeros() const {
+    std::size_t nz = 0;
+    for (std::size_t j = 0; j < cols_; j++) for (std::size_t i = 0; i < rows_; i++) nz += (*this)(i, j) == scalar_t(0.);
+    return nz;
+  }
+  std::size_t subnormals() const {
+    std::size_t ns = 0;
+    for (std::size_t j = 0; j < cols_; j++)
+      for (std::size_t i = 0; i < rows_; i++) ns += !std::isnormal(std::real((*this)(i, j))) && !std::isnormal(std::imag((*this)(i, j)));
+    return ns;
+  }
+  // largest column sum / row sum of absolute values (lange '1' / 'I')
+  auto norm1() const {
+    decltype(std::abs(scalar_t())) nrm = 0;
+    for (std::size_t j = 0; j < cols_; j++) { decltype(nrm) s = 0; for (std::size_t i = 0; i < rows_; i++) s += std::abs((*this)(i, j)); nrm = std::max(nrm, s); }
+    return nrm;
+  }
+  auto normI() const {
+    std::vector<decltype(std::abs(scalar_t()))> s(rows_, 0);
+    for (std::size_t j = 0; j < cols_; j++) for (std::size_t i = 0; i < rows_; i++) s[i] += std::abs((*this)(i, j));
+    decltype(std::abs(scalar_t())) nrm = 0;
+    for (auto v : s) nrm = std::max(nrm, v);
+    return nrm;
+  }
+  // row / column permutations of LAPACK's lapmr / lapmt (1-based P; forward: row P(i) moves to row i), dense/DenseMatrix.cpp:300-309
+  void lapmr(const std::vector<int>& P, bool fwd) {
+    if (!rows_ || !cols_) return;
+    DenseMatrix<scalar_t> T(*this);
+    for (std::size_t i = 0; i < rows_; i++)
+      for (std::size_t j = 0; j < cols_; j++) {
+        if (fwd) (*this)(i, j) = T(std::size_t(P[i] - 1), j);
+        else (*this)(std::size_t(P[i] - 1), j) = T(i, j);
+      }
+  }
+  void lapmt(const std::vector<int>& P, bool fwd) {
+    if (!rows_ || !cols_) return;
+    DenseMatrix<scalar_t> T(*this);
+    for (std::size_t j = 0; j < cols_; j++)
+      for (std::size_t i = 0; i < rows_; i++) {
+        if (fwd) (*this)(i, j) = T(i, std::size_t(P[j] - 1));
+        else (*this)(i, std::size_t(P[j] - 1)) = T(i, j);
+      }
+  }
+  // LU with partial pivoting in place (getrf: 1-based pivots for laswp; returns the first zero pivot's column + 1, else 0) and
+  // the solves with it (dense/DenseMatrix.hpp:702-790).  Host loops: the blocks a caller factors here are small -- the
+  // engines factor theirs on the device.
+  int LU(std::vector<int>& piv, int = 0) {
+    assert(rows_ == cols_);
+    const std::size_t n = rows_;
+    piv.assign(n, 0);
+    int info = 0;
+    for (std::size_t k = 0; k < n; k++) {
+      std::size_t p = k;
+      for (std::size_t i = k + 1; i < n; i++) if (std::abs((*this)(i, k)) > std::abs((*this)(p, k))) p = i;
+      piv[k] = int(p) + 1;
+      if ((*this)(p, k) == scalar_t(0.)) { if (!info) info = int(k) + 1; continue; }
+      if (p != k) for (std::size_t j = 0; j < n; j++) std::swap((*this)(k, j), (*this)(p, j));
+      const scalar_t d = scalar_t(1.) / (*this)(k, k);
+      for (std::size_t i = k + 1; i < n; i++) (*this)(i, k) *= d;
+      for (std::size_t j = k + 1; j < n; j++) {
+        const scalar_t u = (*this)(k, j);
+        if (u != scalar_t(0.)) for (std::size_t i = k + 1; i < n; i++) (*this)(i, j) -= (*this)(i, k) * u;
+      }
+    }
+    return info;
+  }
+  std::vector<int> LU(int = 0) {
+    std::vector<int> piv;
+    if (int info = LU(piv)) std::cerr << "ERROR: LU factorization failed with info=" << info << std::endl;
+    return piv;
+  }
+  void solve_LU_in_place(DenseMatrix<scalar_t>& b, const std::vector<int>& piv, int = 0) const {
+    assert(rows_ == cols_ && b.rows() == rows_ && piv.size() >= rows_);
+    const std::size_t n = rows_;
+    b.laswp(piv, true);
+    for (std::size_t c = 0; c < b.cols(); c++) {
+      for (std::size_t k = 0; k < n; k++) { const scalar_t v = b(k, c); if (v != scalar_t(0.)) for (std::size_t i = k + 1; i < n; i++) b(i, c) -= (*this)(i, k) * v; }
+      for (std::size_t k = n; k-- > 0;) { b(k, c) /= (*this)(k, k); const scalar_t v = b(k, c); for (std::size_t i = 0; i < k; i++) b(i, c) -= (*this)(i, k) * v; }
+    }
+  }
+  DenseMatrix<scalar_t> solve(const DenseMatrix<scalar_t>& b, const std::vector<int>& piv, int = 0) const {
+    DenseMatrix<scalar_t> x(b);
+    solve_LU_in_place(x, piv);
+    return x;
   }
   // keeps the leading min(rows, m) x min(cols, n) block (dense/DenseMatrix.hpp: resize)
   void resize(std::size_t m, std::size_t n) {

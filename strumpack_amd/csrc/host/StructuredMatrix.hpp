@@ -51,7 +51,37 @@ template <typename scalar_t> class StructuredMatrix {
     solve(B);
   }
   virtual void shift(scalar_t s) { throw std::invalid_argument("Operation shift not supported for this type."); }
+  // 1-d block row distribution of the MPI formats (structured/StructuredMatrix.hpp:262-320): the formats built here are
+  // sequential objects (one process per GPU shares a matrix through the C interface, not through this class), so the local
+  // range accessors throw like the reference's defaults and dist() is the single block {0, rows()}
+  virtual std::size_t local_rows() const { throw std::invalid_argument("1d block row distribution not supported for this format."); }
+  virtual std::size_t begin_row() const { throw std::invalid_argument("1d block row distribution not supported for this format."); }
+  virtual std::size_t end_row() const { throw std::invalid_argument("1d block row distribution not supported for this format."); }
+  virtual const std::vector<int>& dist() const {
+    dist_ = {0, int(rows())};
+    return dist_;
+  }
+  virtual const std::vector<int>& rdist() const { return dist(); }
+  virtual const std::vector<int>& cdist() const { return dist(); }
+
+ private:
+  mutable std::vector<int> dist_;
 };
+
+// (structured/StructuredMatrix.cpp:572-605: HSS and BLR do not support matrix-free compression -- std::invalid_argument, as in
+//  the reference; the formats that do, HODLR / HODBF / BUTTERFLY / LR, are out of scope)
+template <typename scalar_t>
+std::unique_ptr<StructuredMatrix<scalar_t>> construct_matrix_free(int rows, int cols, const mult_t<scalar_t>& Amult,
+                                                                  const StructuredOptions<scalar_t>& opts,
+                                                                  const ClusterTree* row_tree = nullptr,
+                                                                  const ClusterTree* col_tree = nullptr) {
+  (void)rows; (void)cols; (void)Amult; (void)row_tree; (void)col_tree;
+  switch (opts.type()) {
+    case Type::HSS: throw std::invalid_argument("Type HSS does not support matrix-free compression.");
+    case Type::BLR: throw std::invalid_argument("Type BLR does not support matrix-free compression.");
+    default: throw std::invalid_argument("construct_matrix_free: this structured format is not part of this library (HSS and BLR are)");
+  }
+}
 
 template <typename scalar_t>
 std::unique_ptr<StructuredMatrix<scalar_t>> construct_from_dense(

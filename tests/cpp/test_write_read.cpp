@@ -128,6 +128,46 @@ int main(int argc, char* argv[]) {
     count(&H);
     if (rects != leaves + 2 * inner) { std::cout << "ERROR: draw wrote " << rects << " rectangles for " << leaves << " leaves" << std::endl; return 1; }
     H.set_openmp_task_depth(2);
+    // StructuredMatrix interface defaults (structured/StructuredMatrix.hpp:262-320, StructuredMatrix.cpp:572-605)
+    const structured::StructuredMatrix<double>& SM = H;
+    if (SM.dist().size() != 2 || SM.dist()[1] != int(H.rows()) || SM.rdist() != SM.cdist()) { std::cout << "ERROR: dist()" << std::endl; return 1; }
+    bool t1 = false, t2 = false;
+    try { (void)SM.local_rows(); } catch (const std::invalid_argument&) { t1 = true; }
+    try {
+      structured::StructuredOptions<double> so;
+      so.set_type(structured::Type::HSS);
+      structured::mult_t<double> mf = [](Trans, const DenseMatrix<double>&, DenseMatrix<double>&) {};
+      structured::construct_matrix_free<double>(10, 10, mf, so);
+    } catch (const std::invalid_argument&) { t2 = true; }
+    if (!t1 || !t2) { std::cout << "ERROR: StructuredMatrix defaults" << std::endl; return 1; }
+    // DenseMatrix utilities of the reference's class (dense/DenseMatrix.hpp): LU / solve, norms, permutations
+    {
+      const int q = 7;
+      DenseMatrix<double> M(q, q), xq(q, 2), bq(q, 2);
+      M.random(); xq.random();
+      M.shift(3.);
+      gemm(Trans::N, Trans::N, 1., M, xq, 0., bq);
+      DenseMatrix<double> F(M);
+      auto pv = F.LU();
+      auto sol = F.solve(bq, pv);
+      sol.scaled_add(-1., xq);
+      if (sol.normF() > 1e-12 * xq.normF()) { std::cout << "ERROR: DenseMatrix LU / solve" << std::endl; return 1; }
+      auto Mt = M.conj_transpose();
+      if (std::abs(M.norm1() - Mt.normI()) > 1e-14 * M.norm1() || M.zeros() != 0 || M.subnormals() != 0) { std::cout << "ERROR: DenseMatrix norms" << std::endl; return 1; }
+      std::vector<int> P = {3, 1, 2, 7, 6, 5, 4};
+      DenseMatrix<double> R1(M);
+      R1.lapmr(P, true);
+      for (int i = 0; i < q; i++) if (R1(i, 2) != M(P[i] - 1, 2)) { std::cout << "ERROR: lapmr" << std::endl; return 1; }
+      R1.lapmr(P, false);
+      R1.lapmt(P, true);
+      R1.lapmt(P, false);
+      R1.scaled_add(-1., M);
+      if (R1.normF() != 0.) { std::cout << "ERROR: lapmr / lapmt round trip" << std::endl; return 1; }
+      DenseMatrix<double> S1(M);
+      S1.scale_and_add(2., M);
+      S1.scaled_add(-3., M);
+      if (S1.normF() > 1e-13 * M.normF()) { std::cout << "ERROR: scale_and_add" << std::endl; return 1; }
+    }
     // delete_trailing_block (HSSMatrix.hpp:476): what is left no longer applies as a whole
     auto T = H.clone();
     T->delete_trailing_block();
