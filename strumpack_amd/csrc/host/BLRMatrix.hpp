@@ -177,6 +177,15 @@ template <> class BLRMatrix<double> : public structured::StructuredMatrix<double
     return A;
   }
   const DeviceBLR* engine() const { return eng_.get(); }
+  // the tile partition (BLR/BLRMatrix.hpp: rowblocks / colblocks / tilerows / tilecols / tileroff / tilecoff / maxtile*)
+  std::size_t rowblocks() const { return rt_.size(); }
+  std::size_t colblocks() const { return ct_.size(); }
+  std::size_t tilerows(std::size_t i) const { return std::size_t(rt_.at(i)); }
+  std::size_t tilecols(std::size_t j) const { return std::size_t(ct_.at(j)); }
+  std::size_t tileroff(std::size_t i) const { std::size_t o = 0; for (std::size_t k = 0; k < i; k++) o += std::size_t(rt_.at(k)); return o; }
+  std::size_t tilecoff(std::size_t j) const { std::size_t o = 0; for (std::size_t k = 0; k < j; k++) o += std::size_t(ct_.at(k)); return o; }
+  std::size_t maxtilerows() const { int m = 0; for (int t : rt_) m = std::max(m, t); return std::size_t(m); }
+  std::size_t maxtilecols() const { int m = 0; for (int t : ct_) m = std::max(m, t); return std::size_t(m); }
 
  private:
   void need() const { if (!eng_) throw std::logic_error("BLR matrix has not been compressed"); }
