@@ -90,6 +90,36 @@ def check_front(L, name, G=None):
     return st
 
 
+def check_front_schedules(L, name, G=None):
+    """Star / Comb (LUAR) are other schedules of the same factorization; selected, they run the RL schedule here
+    (BLRMatrix.hpp).  The result must sit inside RL's own tolerances of the reference's Star and Comb runs: same dense /
+    low-rank decisions, tile ranks at most 15 % (at least 2) apart on at most 5 % of the tiles, Schur complement and solve
+    phases equal to 10 x the compression tolerance."""
+    G = G if G is not None else golden()
+    fr = build_case(name)
+    rtol = fr["rel_tol"]
+    o = capi.StructuredMatrix.options(L, rel_tol=rtol, abs_tol=fr["abs_tol"], type=capi.SP_TYPE_BLR)
+    F, S = capi.BLRFront.factor(L, fr["F11"], fr["F12"], fr["F21"], fr["F22"], fr["tiles1"], fr["tiles2"], o, admissible=fr["adm"])
+    nt1, nt = len(fr["tiles1"]), len(fr["tiles1"]) + len(fr["tiles2"])
+    rk = F.tile_ranks()
+    part = np.ones((nt, nt), dtype=bool)
+    part[nt1:, nt1:] = False
+    fs, fu = F.forward(fr["bsep"], fr["bupd"])
+    ys = F.backward(fr["ysep"], fr["yupd"])
+    for algo in ("star", "comb"):
+        k = name + "_" + algo
+        rref = G[k + "_ranks"]
+        assert np.array_equal(rk[part] < 0, rref[part] < 0), (k, "dense / low-rank decisions differ")
+        lr = part & (rref >= 0)
+        diff = np.abs(rk[lr] - rref[lr])
+        assert diff.max(initial=0) <= max(2, int(0.15 * rref[lr].max(initial=1))) and (diff > 0).mean() <= 0.05, (k, diff.max(), (diff > 0).mean())
+        assert err(S @ fr["R"], G[k + "_SR"]) <= 10 * rtol
+        assert abs(np.linalg.norm(S) - G[k + "_Snorm"]) <= 10 * rtol * G[k + "_Snorm"]
+        assert err(fs, G[k + "_fwd_sep"]) <= 10 * rtol and err(fu, G[k + "_fwd_upd"]) <= 10 * rtol
+        assert err(ys, G[k + "_bwd_sep"]) <= 10 * rtol
+    F.destroy()
+
+
 def check_front_aca(L, name, G=None):
     """the same front with ACA tile compression (SPX_blr_low_rank_algorithm(1); C++: BLROptions::set_low_rank_algorithm):
     the reference's ACA takes its first row from a default-seeded std::mt19937 and is deterministic from there, so the tile

@@ -85,15 +85,29 @@ int main(int argc, char* argv[]) {
   B11.solve(x2);
   x2.scaled_add(-1., t);
   if (x2.normF() > 1e-6 * t.normF()) { std::cout << "ERROR: B11.solve" << std::endl; return 1; }
-  // a variant that is not built is refused
+  // a variant that is not built is refused; Star (a different schedule of the same factorization: BLRMatrix.hpp) is accepted
   bool refused = false;
   try {
     BLROptions<double> o2;
-    o2.set_BLR_factor_algorithm(BLRFactorAlgorithm::STAR);
+    o2.set_BLR_factor_algorithm(BLRFactorAlgorithm::COLWISE);
     DenseMatrix<double> C11(F11), C12(F12), C21(F21), C22(F22);
     BLRMatrix<double>::construct_and_partial_factor(C11, C12, C21, C22, B11, B12, B21, tiles1, tiles2, adm, o2);
   } catch (const std::invalid_argument&) { refused = true; }
   if (!refused) { std::cout << "ERROR: unsupported algorithm accepted" << std::endl; return 1; }
+  {
+    BLROptions<double> o2;
+    o2.set_rel_tol(1e-6);
+    const char* args[] = {"test", "--blr_factor_algorithm", "Star", "--blr_compression_kernel", "full"};
+    o2.set_from_command_line(5, args);
+    if (o2.BLR_factor_algorithm() != BLRFactorAlgorithm::STAR || o2.compression_kernel() != CompressionKernel::FULL) { std::cout << "ERROR: --blr_* flags" << std::endl; return 1; }
+    DenseMatrix<double> C11(F11), C12(F12), C21(F21), C22(F22);
+    BLRMatrix<double> S11, S12, S21;
+    BLRMatrix<double>::construct_and_partial_factor(C11, C12, C21, C22, S11, S12, S21, tiles1, tiles2, adm, o2);
+    DenseMatrix<double> xs(b);
+    S11.solve(xs);
+    xs.scaled_add(-1., t);
+    if (xs.normF() > 1e-6 * t.normF()) { std::cout << "ERROR: Star variant" << std::endl; return 1; }
+  }
   // ACA tile compression (BLROptions::set_low_rank_algorithm): accepted, accurate to its tolerance; BACA is refused
   {
     BLROptions<double> o4;

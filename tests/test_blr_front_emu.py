@@ -25,6 +25,11 @@ def test_front_aca_against_reference(L, name):
     BC.check_front_aca(L, name)
 
 
+@pytest.mark.parametrize("name", ("p16_weak", "p12_unsym_strong"))
+def test_front_against_reference_star_and_comb(L, name):
+    BC.check_front_schedules(L, name)
+
+
 def test_front_api(L):
     BC.check_front_api(L)
 

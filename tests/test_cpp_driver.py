@@ -150,6 +150,36 @@ def test_reference_own_driver_unmodified(ref_exe, line):
     run(ref_exe, line)
 
 
+# the reference's BLR CTest lines (test/CMakeLists.txt:162-184)
+REF_BLR_LINES = [
+    "300 --blr_factor_algorithm RL",
+    "300 --blr_factor_algorithm LL",
+    "300 --blr_factor_algorithm Star --blr_compression_kernel full",
+    "300 --blr_factor_algorithm Star --blr_compression_kernel half",
+    "300 --blr_factor_algorithm Comb --blr_compression_kernel full",
+    "300 --blr_factor_algorithm Comb --blr_compression_kernel half",
+    "700 --blr_leaf_size 64 --blr_rel_tol 1e-6 --blr_low_rank_algorithm ACA",
+]
+
+
+@pytest.fixture(scope="module")
+def ref_blr_exe(tmp_path_factory):
+    if not os.path.exists(os.path.join(REF, "test", "test_BLR_seq.cpp")):
+        pytest.skip("the reference tree is only present in the build container")
+    import emu_lib
+    emu_lib.build()
+    return build_ref(os.path.join(REF, "test", "test_BLR_seq.cpp"), str(tmp_path_factory.mktemp("cpp") / "ref_test_BLR_seq"),
+                     os.path.dirname(emu_lib.PATH), "strumpack_amd_emu")
+
+
+@pytest.mark.parametrize("line", REF_BLR_LINES)
+def test_reference_own_blr_driver_unmodified(ref_blr_exe, line):
+    """/root/reference/test/test_BLR_seq.cpp itself -- BLROptions::set_from_command_line, ClusterTree::leaf_sizes,
+    BLRMatrix(m, tiles, m, tiles), compress_and_factor, solve -- with its own pass criterion, on its six CTest lines (Star and
+    Comb run the RL schedule here: BLRMatrix.hpp) and one more with ACA tiles"""
+    run(ref_blr_exe, line)
+
+
 def test_reference_kernel_regression_example_unmodified(tmp_path_factory):
     """/root/reference/examples/dense/KernelRegression.cpp itself on a prefix of its shipped data set"""
     src = os.path.join(REF, "examples", "dense", "KernelRegression.cpp")
