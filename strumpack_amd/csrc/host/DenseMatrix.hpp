@@ -10,6 +10,7 @@
 #include <complex>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <random>
 #include <string>
@@ -43,6 +44,10 @@ template <typename scalar_t> class DenseMatrix {
     data_ = new scalar_t[ld_ * std::max<std::size_t>(1, n)]();
   }
   // copy of an m x n block with leading dimension ld
+  // (element by element from a function, dense/DenseMatrix.hpp:131-133)
+  DenseMatrix(std::size_t m, std::size_t n, const std::function<scalar_t(std::size_t, std::size_t)>& A) : DenseMatrix(m, n) {
+    for (std::size_t j = 0; j < n; j++) for (std::size_t i = 0; i < m; i++) (*this)(i, j) = A(i, j);
+  }
   DenseMatrix(std::size_t m, std::size_t n, const scalar_t* D, std::size_t ld) : DenseMatrix(m, n) {
     for (std::size_t j = 0; j < n; j++) std::memcpy(data_ + j * ld_, D + j * ld, sizeof(scalar_t) * m);
   }
@@ -357,6 +362,23 @@ template <typename scalar_t>
 void gemv(Trans ta, scalar_t alpha, const DenseMatrix<scalar_t>& a, const DenseMatrix<scalar_t>& x, scalar_t beta,
           DenseMatrix<scalar_t>& y, int /*depth*/ = 0) {
   detail::gemm_host(ta, Trans::N, alpha, a, x, beta, y);
+}
+// y <- alpha op(a) x + beta y on strided vectors (dense/DenseMatrix.hpp: gemv with raw pointers)
+template <typename scalar_t>
+void gemv(Trans ta, scalar_t alpha, const DenseMatrix<scalar_t>& a, const scalar_t* x, int incx, scalar_t beta, scalar_t* y, int incy,
+          int /*depth*/ = 0) {
+  const std::size_t m = a.rows(), n = a.cols();
+  const std::size_t ny = ta == Trans::N ? m : n, nx = ta == Trans::N ? n : m;
+  for (std::size_t i = 0; i < ny; i++) y[i * incy] = beta == scalar_t(0.) ? scalar_t(0.) : beta * y[i * incy];
+  if (ta == Trans::N) {
+    for (std::size_t j = 0; j < nx; j++) { const scalar_t t = alpha * x[j * incx]; for (std::size_t i = 0; i < m; i++) y[i * incy] += a(i, j) * t; }
+  } else {
+    for (std::size_t j = 0; j < ny; j++) {
+      scalar_t t = 0;
+      for (std::size_t i = 0; i < m; i++) t += (ta == Trans::C ? conj_of(a(i, j)) : a(i, j)) * x[i * incx];
+      y[j * incy] += alpha * t;
+    }
+  }
 }
 // b <- alpha op(a)^{-1} b (Side::L) or alpha b op(a)^{-1} (Side::R), a triangular (dense/DenseMatrix.cpp:1059-1085)
 template <typename scalar_t>

@@ -72,7 +72,25 @@ std::unique_ptr<StructuredMatrix<double>> construct_from_dense_device(int rows, 
 template <>
 std::unique_ptr<StructuredMatrix<double>> construct_from_elements(int rows, int cols, const extract_block_t<double>& A,
                                                                   const StructuredOptions<double>& opts, const ClusterTree* row_tree,
-                                                                  const ClusterTree*, const admissibility_t*, const DenseMatrix<double>*) {
+                                                                  const ClusterTree* col_tree, const admissibility_t* adm, const DenseMatrix<double>*) {
+  if (opts.type() == Type::BLR) {
+    // BLRMatrix::compress(Aelem, adm, opts) (StructuredMatrix.cpp:274-295, BLR/BLRMatrix.cpp:102-111) evaluates every tile in
+    // full before it compresses it: here the tiles of a block column are evaluated on the host threads into the dense image
+    // and the dense route takes over
+    DenseMatrix<double> D(rows, cols);
+    const int bs = std::max(1, opts.leaf_size());
+    std::vector<std::size_t> I(rows);
+    for (int i = 0; i < rows; i++) I[i] = std::size_t(i);
+    for (int j0 = 0; j0 < cols; j0 += bs) {
+      const int nb = std::min(bs, cols - j0);
+      std::vector<std::size_t> J(nb);
+      for (int j = 0; j < nb; j++) J[j] = std::size_t(j0 + j);
+      DenseMatrix<double> B(rows, nb);
+      A(I, J, B);
+      for (int j = 0; j < nb; j++) for (int i = 0; i < rows; i++) D(i, j0 + j) = B(i, j);
+    }
+    return blr_from_dense(D, opts, row_tree, col_tree, adm, false);
+  }
   require_hss(opts.type(), rows, cols);
   // The reference samples A on the fly in B x B tiles and never stores it (StructuredMatrix.cpp:214-262); here the column
   // blocks are evaluated tile by tile on the host threads and streamed through the device, uploads overlapped with the
@@ -119,7 +137,9 @@ template <>
 std::unique_ptr<StructuredMatrix<double>> construct_partially_matrix_free(int rows, int cols, const mult_t<double>& Amult,
                                                                           const extract_block_t<double>& Aelem,
                                                                           const StructuredOptions<double>& opts, const ClusterTree* row_tree,
-                                                                          const ClusterTree*) {
+                                                                          const ClusterTree* col_tree) {
+  // (StructuredMatrix.cpp:651-652: BLR has no use for the product and is built from the elements)
+  if (opts.type() == Type::BLR) return construct_from_elements<double>(rows, cols, Aelem, opts, row_tree, col_tree, nullptr, nullptr);
   require_hss(opts.type(), rows, cols);
   HSS::HSSOptions<double> ho;
   std::unique_ptr<HSS::HSSMatrix<double>> H(new_hss(rows, opts, row_tree, ho));

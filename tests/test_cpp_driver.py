@@ -180,6 +180,29 @@ def test_reference_own_blr_driver_unmodified(ref_blr_exe, line):
     run(ref_blr_exe, line)
 
 
+def test_reference_structured_example_unmodified(tmp_path_factory):
+    """/root/reference/examples/dense/testStructured.cpp itself: the structured:: interface over all construction routes
+    (dense, elements, blocks, partially matrix-free), factor / solve, shift, and the compressed matrix as the preconditioner of
+    iterative::GMRes / BiCGStab; BLR stops at factor() and LOSSY / LOSSLESS at construction with the exceptions the example
+    itself catches (the reference's BLR has no factor() behind this interface either)"""
+    src = os.path.join(REF, "examples", "dense", "testStructured.cpp")
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is only present in the build container")
+    import emu_lib
+    emu_lib.build()
+    exe = build_ref(src, str(tmp_path_factory.mktemp("cpp") / "ref_testStructured"), os.path.dirname(emu_lib.PATH), "strumpack_amd_emu")
+    r = subprocess.run([exe, "300", "--structured_leaf_size", "64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    import re
+    assert out.count("HSS\n") == 5 and "HSS failed" not in out          # five HSS constructions, all carried through
+    assert out.count("BLR\n") == 3 and out.count("BLR failed: Operation factor not supported") == 3   # (one per try block)
+    errs = [float(x) for x in re.findall(r"\|\|X-A\\\(A\*X\)\|\|_F/\|\|X\|\|_F = (\S+)", out)]
+    assert len(errs) == 10 and max(errs) < 1e-8, errs                    # GMRes and BiCGStab with each HSS matrix as preconditioner
+    comp = [float(x) for x in re.findall(r"\|\|A-H\|\|_F/\|\|A\|\|_F = (\S+)", out)]
+    assert comp and max(comp) < 1e-3, comp
+
+
 def test_reference_kernel_regression_example_unmodified(tmp_path_factory):
     """/root/reference/examples/dense/KernelRegression.cpp itself on a prefix of its shipped data set"""
     src = os.path.join(REF, "examples", "dense", "KernelRegression.cpp")
