@@ -3,6 +3,7 @@ pass criteria) over a subset of the reference's CTest lines (test/CMakeLists.txt
 CPU: linked against the emulator build; GPU (-m gpu): linked against the product library."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -220,6 +221,28 @@ def test_reference_kernel_regression_example_unmodified(tmp_path_factory):
     assert r.returncode == 0, r.stdout + r.stderr
     score = [ln for ln in r.stdout.splitlines() if "prediction score" in ln]
     assert score and float(score[0].split(":")[1].strip().rstrip("%")) >= 70.0, r.stdout[-500:]
+
+
+def test_reference_python_example_unmodified(tmp_path_factory):
+    """/root/reference/examples/dense/KernelRegression.py itself: `import STRUMPACKKernel as sp` resolves to
+    include/python/STRUMPACKKernel.py (the reference installs its module under the same name), the scikit-learn style classifier
+    on this library -- here on the emulator build and a prefix of the example's data set"""
+    src = os.path.join(REF, "examples", "dense", "KernelRegression.py")
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is only present in the build container")
+    import emu_lib
+    emu_lib.build()
+    d = tmp_path_factory.mktemp("py")
+    for part, cnt in (("train", 300), ("train_label", 300), ("test", 100), ("test_label", 100)):
+        with open(KRR_DATA + "_%s.csv" % part) as f, open(str(d / ("s_%s.csv" % part)), "w") as g:
+            g.writelines(f.readlines()[:cnt])
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "include", "python"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "run_with_emulator.py"), emu_lib.PATH, src, str(d / "s"), "1.3", "3.11", "1",
+                        "--hss_leaf_size", "64", "--hss_quiet"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    q = [ln for ln in r.stdout.splitlines() if "HSS KernelRR quality" in ln]
+    assert q and float(q[0].split("=")[1].strip().rstrip("%")) >= 70.0, r.stdout[-500:]
 
 
 BLRF_SRC = os.path.join(ROOT, "tests", "cpp", "test_BLR_front.cpp")
