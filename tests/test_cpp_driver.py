@@ -223,6 +223,26 @@ def test_reference_kernel_regression_example_unmodified(tmp_path_factory):
     assert score and float(score[0].split(":")[1].strip().rstrip("%")) >= 70.0, r.stdout[-500:]
 
 
+def test_reference_c_example_unmodified(tmp_path_factory):
+    """/root/reference/examples/dense/dstructured.c itself (plain C against include/structured/StructuredMatrix.h):
+    SP_d_struct_default_options, _from_elements, _mult, _factor, _solve, _destroy"""
+    src = os.path.join(REF, "examples", "dense", "dstructured.c")
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is only present in the build container")
+    import emu_lib
+    emu_lib.build()
+    exe = str(tmp_path_factory.mktemp("c") / "ref_dstructured")
+    libdir = os.path.dirname(emu_lib.PATH)
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + libdir, "-lstrumpack_amd_emu",
+                    "-Wl,-rpath," + libdir, "-lm"], check=True)
+    r = subprocess.run([exe, "500"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import re
+    comp = float(re.search(r"\|\|T-H\|\|_F/\|\|T\|\|_F = (\S+)", r.stdout).group(1))
+    sol = float(re.search(r"\|\|X-H\\\(H\*X\)\|\|_F/\|\|X\|\|_F = (\S+)", r.stdout).group(1))
+    assert comp < 1e-6 and sol < 1e-10, r.stdout          # (rel_tol 1e-8 in the example)
+
+
 def test_reference_python_example_unmodified(tmp_path_factory):
     """/root/reference/examples/dense/KernelRegression.py itself: `import STRUMPACKKernel as sp` resolves to
     include/python/STRUMPACKKernel.py (the reference installs its module under the same name), the scikit-learn style classifier
