@@ -305,6 +305,24 @@ void HSSMatrix<double>::solve(DenseM_t& b) const {
   if (veng_) veng_->solve_node(vnode_, int(b.cols()), b.data(), b.ld(), false);
   else eng_->solve(int(b.cols()), b.data(), b.ld(), false);
 }
+void HSSMatrix<double>::forward_solve(WorkSolve<double>& w, const DenseM_t& b, bool partial) const {
+  DeviceHSS* e = engine();
+  if (!e) throw std::logic_error("forward_solve: empty matrix");
+  if (b.rows() != rows_) throw std::invalid_argument("forward_solve: right-hand side has the wrong number of rows");
+  const auto& nd = e->nodes()[vnode_];
+  const std::size_t mu = nd.leaf() ? std::size_t(nd.m) : std::size_t(e->nodes()[nd.c0].rU + e->nodes()[nd.c1].rU);
+  w.x = DenseM_t(mu, b.cols());
+  w.reduced_rhs = partial ? DenseM_t(std::size_t(nd.rV), b.cols()) : DenseM_t();
+  e->forward_solve_node(vnode_, w.state_, int(b.cols()), b.data(), b.ld(), partial, w.x.data(), w.x.ld(),
+                        partial ? w.reduced_rhs.data() : nullptr, w.reduced_rhs.ld());
+}
+void HSSMatrix<double>::backward_solve(WorkSolve<double>& w, DenseM_t& x) const {
+  DeviceHSS* e = engine();
+  if (!e) throw std::logic_error("backward_solve: empty matrix");
+  if (x.rows() != rows_ || int(x.cols()) != w.state_.nrhs) throw std::invalid_argument("backward_solve: the solution block has the wrong shape");
+  e->backward_solve_node(vnode_, w.state_, w.x.data(), w.x.ld(), x.data(), x.ld());
+  w.x = DenseM_t();
+}
 void HSSMatrix<double>::shift(scalar_t sigma) { owner("shift"); eng_->shift(sigma); }
 void HSSMatrix<double>::mult_device(Trans op, int nrhs, const double* dx, long long ldx, double* dy, long long ldy, double beta) const {
   if (veng_) veng_->mult_node(vnode_, op == Trans::N ? 'N' : 'C', nrhs, dx, ldx, dy, ldy, true, beta);

@@ -17,6 +17,19 @@ namespace HSS {
 
 template <typename scalar_t> class HSSMatrix;
 
+// HSS::WorkSolve (HSS/HSSExtra.hpp): what travels from forward_solve to backward_solve.  x is the solution in the reduced
+// unknowns of the root of the call and reduced_rhs (partial solves) = Vhat^* x + V^* [z_0; z_1]: the two members a sparse front
+// reads and updates between the halves (sparse/fronts/FrontHSS.cpp:458-493); the vectors of the nodes below stay on the device.
+template <typename scalar_t> class WorkSolve;
+template <> class WorkSolve<double> {
+ public:
+  DenseMatrix<double> x, reduced_rhs;
+
+ private:
+  friend class HSSMatrix<double>;
+  mutable SolveWork state_;
+};
+
 template <> class HSSMatrix<double> : public structured::StructuredMatrix<double> {
   using scalar_t = double;
   using DenseM_t = DenseMatrix<scalar_t>;
@@ -110,6 +123,11 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   // ones it returned (checked by shape) and are not uploaded again.  DUB01 / Phi / Vhat are expressed in this
   // library's reduced unknowns of block 0, so only products such as Vhat^H DUB01 or Theta Vhat^H Phi^H compare
   // with the reference's.
+  // the two halves of solve(b) (HSSMatrix.hpp:360-376).  partial: after the parent's partial_factor(), on child(0) -- the root
+  // of the call keeps its column basis and w.reduced_rhs is formed for the front's update part; w.x may be changed between
+  // the two calls (the front subtracts Phi^* y_upd).
+  void forward_solve(WorkSolve<double>& w, const DenseM_t& b, bool partial) const;
+  void backward_solve(WorkSolve<double>& w, DenseM_t& x) const;
   void partial_factor();
   void Schur_update(DenseM_t& Theta, DenseM_t& DUB01, DenseM_t& Phi) const;
   DenseM_t Vhat() const;

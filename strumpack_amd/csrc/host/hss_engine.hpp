@@ -89,6 +89,21 @@ struct PhaseStats {
 class Arena;
 struct HostRng;
 
+class Arena;
+// state between the forward and the backward half of a split solve (HSS::WorkSolve): device vectors of every node of the
+// subtree in an arena of their own
+struct SolveWork {
+  std::shared_ptr<Arena> arena;
+  std::vector<double*> f, y, zc, xb;
+  double* db = nullptr;
+  int nrhs = 0, sr = -1;
+  bool valid = false, partial = false;
+  // host buffers of the call in progress
+  double* xroot = nullptr;
+  double* reduced = nullptr;
+  long long ldx = 0, ldr = 0;
+};
+
 class DeviceHSS {
  public:
   DeviceHSS(int n, const EngineOptions& opts, const structured::ClusterTree* tree = nullptr);
@@ -155,6 +170,10 @@ class DeviceHSS {
   void factor_node(int node) { factor_sub(node, false); }
   void solve_node(int node, int nrhs, double* b, long long ldb, bool on_device) { solve_sub(node, nrhs, b, ldb, on_device); }
   bool node_is_factored(int node) const { return node == 0 ? factored_ : sub_factored_ == node; }
+  // the two halves of a solve (HSSMatrix::forward_solve / backward_solve): hss_solve.cpp
+  void forward_solve_node(int node, struct SolveWork& w, int nrhs, const double* b, long long ldb, bool partial, double* xroot,
+                          long long ldx, double* reduced, long long ldr);
+  void backward_solve_node(int node, struct SolveWork& w, const double* xroot, long long ldx, double* x, long long ldxo);
   bool is_partially_factored() const { return partial_factored_; }
   SchurDims schur_dims() const;
   // computes the factors on the device; every non-null HOST pointer receives a copy (column-major)
@@ -275,7 +294,7 @@ class DeviceHSS {
   void mult_sub(int sr, char trans, int nrhs, const double* x, long long ldx, double* y, long long ldy,
                 bool on_device, double beta);
   void factor_sub(int sr, bool partial);
-  void solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device);
+  void solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device, int phase = 0, struct SolveWork* ws = nullptr);
   // out (rank(sr) x c) = Ubig^T A or Vbig^T A  (apply_UtVt_big, Schur.hpp:223-252)
   void basis_up(int sr, bool useU, const double* dA, long long lda, int c, double* dOut, int ldout, Arena& wk);
   // out (rows(sr) x c) = Ubig in or Vbig in (apply_UV_big, Schur.hpp:254-323); !recurse: sr's own basis only

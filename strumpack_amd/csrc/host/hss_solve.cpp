@@ -9,13 +9,35 @@ namespace HSS {
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::solve(int nrhs, double* b, long long ldb, bool on_device) { solve_sub(0, nrhs, b, ldb, on_device); }
 
+// HSSMatrix::forward_solve / backward_solve (HSS/HSSMatrix.solve.hpp:52-66): the two halves of a solve with the state between
+// them (HSS::WorkSolve) in `w`.  Forward: the elimination sweep up to the root's solve, x_root out (w.x of the reference);
+// partial (the matrix was partial_factor()ed and `node` is child 0, or node was factored on its own): also
+// reduced_rhs = Vhat^* x_root + V^* [z_0; z_1] (solve.hpp:139-154), what a sparse front subtracts Theta times from its update
+// part (sparse/fronts/FrontHSS.cpp:458-461).  Backward: x_root in (the front has subtracted Phi^* y_upd from it, :489-493),
+// the solution of the node's rows out.
+void DeviceHSS::forward_solve_node(int node, SolveWork& w, int nrhs, const double* b, long long ldb, bool partial, double* xroot,
+                                   long long ldx, double* reduced, long long ldr) {
+  w.partial = partial;
+  w.xroot = xroot; w.ldx = ldx; w.reduced = reduced; w.ldr = ldr;
+  solve_sub(node, nrhs, const_cast<double*>(b), ldb, false, 1, &w);
+}
+void DeviceHSS::backward_solve_node(int node, SolveWork& w, const double* xroot, long long ldx, double* x, long long ldxo) {
+  if (!w.valid || w.sr != node) throw std::logic_error("backward_solve: no forward_solve of this matrix went before");
+  w.xroot = const_cast<double*>(xroot); w.ldx = ldx;
+  solve_sub(node, w.nrhs, x, ldxo, false, 2, &w);
+}
+
 // sr != 0: the subtree of node sr as a matrix of its own (factor_node): rows of b = the node's rows
-void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device) {
+// phase 0: the whole solve; 1: forward half, state kept in *ws; 2: backward half from *ws
+void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device, int phase, SolveWork* ws) {
   OpGuard op_guard(op_mu_);
   ensure_ready("solve");
   if (sr < 0 || sr >= (int)nodes_.size()) throw std::invalid_argument("solve: no such node");
   if (sr == 0 && !factored_) throw std::logic_error("solve: factor() has not been called (or shift() invalidated the factors)");
-  if (sr != 0 && sub_factored_ != sr) throw std::logic_error("solve: this child has not been factored (or a later factorization replaced its factors)");
+  const bool partial_root = partial_factored_ && !nodes_[0].leaf() && sr == nodes_[0].c0;   // child 0 after partial_factor()
+  if (sr != 0 && sub_factored_ != sr && !(phase != 0 && partial_root))
+    throw std::logic_error("solve: this child has not been factored (or a later factorization replaced its factors)");
+  if (phase != 0 && (!ws || o_.world != 1)) throw std::logic_error("forward_solve / backward_solve: need a work object and a single-process matrix");
   if (sr != 0 && o_.world != 1) throw std::logic_error("solve: a child on its own needs a single-process matrix");
   if (nrhs <= 0 || nodes_[sr].m == 0) return;
   const int lo0 = nodes_[sr].lo;
@@ -42,12 +64,17 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   if (plannable && plans_.size() > 32) drop_plans();   // many different buffers: start over rather than grow
   if (plannable && ++plans_[key].seen == 2) ck(hssk_plan_begin(ctx_, &rec));
   struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
-  Arena& tmp = rec ? *plan_arena_ : *tmp_;   // a recorded sweep keeps its own work vectors
-  if (!rec) tmp.rewind();
+  if (phase == 1) {   // the state of a split solve lives in its own arena until the backward half has run
+    ws->arena.reset(new Arena());
+    ws->valid = false;
+  }
+  Arena& tmp = phase ? *ws->arena : (rec ? *plan_arena_ : *tmp_);   // a recorded sweep keeps its own work vectors
+  if (!rec && !phase) tmp.rewind();
   const int N = nodes_[sr].m;
   double* db = b;
   long long lb = ldb;
-  if (!on_device) {
+  if (phase == 2) { db = ws->db; lb = N; }
+  else if (!on_device) {
     db = tmp.dbl((size_t)N * nrhs);
     ck(hssk_memcpy2d_h2d(ctx_, db, sizeof(double) * N, b, sizeof(double) * ldb, sizeof(double) * N, nrhs));
     lb = N;
@@ -56,17 +83,20 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   const size_t nn = nodes_.size();
   // f: assembled right-hand side of an inner node (mU rows; children write ft1 into it);
   // y: (mU - rU) rows; zc: children's z stacked (mV rows); xb: solution in the node's basis (mU rows)
-  std::vector<double*> f(nn, nullptr), y(nn, nullptr), zc(nn, nullptr), xb(nn, nullptr);
+  std::vector<double*> f_(nn, nullptr), y_(nn, nullptr), zc_(nn, nullptr), xb_(nn, nullptr);
+  if (phase == 1) { ws->f = f_; ws->y = y_; ws->zc = zc_; ws->xb = xb_; }
+  std::vector<double*>&f = phase ? ws->f : f_, &y = phase ? ws->y : y_, &zc = phase ? ws->zc : zc_, &xb = phase ? ws->xb : xb_;
   // (f, zc, xb are handed from node to node: carved from one block that the single-launch sweeps arm with a sentinel)
   size_t hand_total = 0;
+  if (phase != 2)
   for (size_t i = 0; i < nn; i++) {
     if (!mine((int)i) || nodes_[i].leaf()) continue;
     const Node& nd = nodes_[i];
     const int mu = nodes_[nd.c0].rU + nodes_[nd.c1].rU, mv = nodes_[nd.c0].rV + nodes_[nd.c1].rV;
     hand_total += (size_t)(2 * std::max(mu, 1) + std::max(mv, 1)) * nrhs;
   }
-  double* hand = tmp.dbl(std::max<size_t>(hand_total, 1));
-  {
+  double* hand = phase == 2 ? nullptr : tmp.dbl(std::max<size_t>(hand_total, 1));
+  if (phase != 2) {
     size_t off = 0;
     for (size_t i = 0; i < nn; i++) {
       if (!mine((int)i)) continue;
@@ -85,7 +115,7 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   // launches per level
   static const bool no_fuse = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_FUSED_SOLVE"); return e && e[0] == '1'; }();
   const bool fuse = nrhs <= fuse_max_nrhs() && !no_fuse;   // (more right-hand sides: the batched MFMA launches per level)
-  if (fuse) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
+  if (fuse && phase != 2) ck(hssk_sweep_arm(ctx_, hand, (long long)hand_total));
   typedef std::vector<std::vector<int>> Levels;
   auto fwd_sweep = [&](const Levels& levels) -> bool {
     std::vector<hssk_sweep_fwd_desc> fd;
@@ -309,13 +339,13 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   if (!own_by_height_.empty())
     for (int id : own_by_height_[0]) big_leaves = big_leaves || nodes_[id].m > 256;
   const bool hybrid = fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && own_by_height_.size() > 1;
-  bool fwd_done = false;
+  bool fwd_done = phase == 2;   // (the backward half: the forward sweep ran in forward_solve)
   static const bool no_side = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
-  const bool side = hybrid && !no_side;
+  const bool side = hybrid && !no_side && phase == 0;   // (a split solve keeps every launch on the main stream)
   std::vector<int> leaf_parents;   // the leaves' parents, whatever their depth: one batch
   if (hybrid)
     for (auto& ids : own_by_depth_) leaf_parents.insert(leaf_parents.end(), ids.begin(), ids.end());
-  if (hybrid) {
+  if (hybrid && phase != 2) {
     Levels inner(own_by_height_.begin() + 1, own_by_height_.end());
     // the leaf level: one launch in the matrix-core form of the sweep when it takes the leaves (kernels/hssk_sweep_mma.h),
     // else batched launches over all right-hand sides
@@ -378,6 +408,52 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
     if (!(fuse && bwd_sweep(top_by_depth_, 0)))
       for (auto& ids : top_by_depth_) bwd(ids);
   }
+  if (phase == 1) {
+    // ---- forward half: x_root (and the reduced right-hand side of a partial solve) to the host, the state stays in *ws
+    const Node& rt = nodes_[sr];
+    const int mu = rt.leaf() ? rt.m : nodes_[rt.c0].rU + nodes_[rt.c1].rU;
+    const double* dxr = rt.leaf() ? db : xb[sr];
+    const long long ldr_dev = rt.leaf() ? lb : std::max(mu, 1);
+    if (mu && ws->xroot) ck(hssk_memcpy2d_d2h(ctx_, ws->xroot, sizeof(double) * ws->ldx, dxr, sizeof(double) * ldr_dev, sizeof(double) * mu, nrhs));
+    if (ws->partial && ws->reduced) {
+      // reduced_rhs = Vhat^* x_root + V^* [z_0; z_1]   (HSSMatrix.solve.hpp:139-154; Vhat = the root's Vt0 of a partial factorization)
+      const int rv = rt.rV;
+      if (sr == 0) throw std::logic_error("forward_solve: a partial solve needs a node with a column basis (child 0 of the root)");
+      if (rv) {
+        if (!rt.Vt0) throw std::logic_error("forward_solve: partial, but the factorization kept no Vhat (partial_factor() first)");
+        double* red = tmp.dbl((size_t)rv * nrhs);
+        if (mu) {
+          hssk_gemm_desc g{rt.Vt0, dxr, red, rv, nrhs, mu, std::max(rt.mU, 1), (int)ldr_dev, rv, 1, 0, 1.0, 0.0};
+          ck(hssk_gemm_vbatched(ctx_, &g, 1));
+        } else ck(hssk_memset_zero(ctx_, red, (long long)sizeof(double) * rv * nrhs));
+        if (!rt.leaf()) {
+          const int mv = rt.mV;
+          hssk_rowgather_desc r0{zc[sr], red, rt.permV, rv, nrhs, std::max(mv, 1), rv, 0, 1};
+          ck(hssk_gather_rows(ctx_, &r0, 1));
+          if (mv > rv) {
+            double* t = tmp.dbl((size_t)(mv - rv) * nrhs);
+            hssk_rowgather_desc r1{zc[sr], t, rt.permV + rv, mv - rv, nrhs, std::max(mv, 1), mv - rv, 0, 0};
+            ck(hssk_gather_rows(ctx_, &r1, 1));
+            hssk_gemm_desc g{rt.XV, t, red, rv, nrhs, mv - rv, rv, mv - rv, rv, 0, 0, 1.0, 1.0};
+            ck(hssk_gemm_vbatched(ctx_, &g, 1));
+          }
+        }
+        ck(hssk_memcpy2d_d2h(ctx_, ws->reduced, sizeof(double) * ws->ldr, red, sizeof(double) * rv, sizeof(double) * rv, nrhs));
+      }
+    }
+    ck(hssk_sync(ctx_));
+    if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("forward_solve: ") + hssk_last_error());
+    ws->db = db; ws->nrhs = nrhs; ws->sr = sr; ws->valid = true;
+    return;
+  }
+  if (phase == 2) {
+    // ---- backward half: the caller's x_root (possibly updated) back into the root's slot
+    const Node& rt = nodes_[sr];
+    const int mu = rt.leaf() ? rt.m : nodes_[rt.c0].rU + nodes_[rt.c1].rU;
+    double* dxr = rt.leaf() ? db : xb[sr];
+    const long long ldr_dev = rt.leaf() ? lb : std::max(mu, 1);
+    if (mu) ck(hssk_memcpy2d_h2d(ctx_, dxr, sizeof(double) * ldr_dev, ws->xroot, sizeof(double) * ws->ldx, sizeof(double) * mu, nrhs));
+  }
   if (hybrid) {
     if (!bwd_sweep(own_by_depth_, 1))
       for (auto& ids : own_by_depth_) bwd(ids, 1);
@@ -389,6 +465,7 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
   if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
   ck(hssk_sync(ctx_));
+  if (phase == 2) { ws->arena.reset(); ws->valid = false; }
   if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("solve: ") + hssk_last_error());
   stats_.t_solve = now() - t0;
   {

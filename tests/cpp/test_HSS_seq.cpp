@@ -125,6 +125,14 @@ int main(int argc, char* argv[]) {
   auto R = H.apply(X);
   R.scaled_add(-1., B);
   if (R.normF() / B.normF() > SOLVE_TOLERANCE) { std::cout << "ERROR: solve after shift failed" << std::endl; return 1; }
+  {   // the same solve in its two halves (HSSMatrix.hpp:360-376)
+    WorkSolve<double> w;
+    DenseMatrix<double> X2(B.rows(), B.cols());
+    H.forward_solve(w, B, false);
+    H.backward_solve(w, X2);
+    X2.scaled_add(-1., X);
+    if (X2.normF() > 1e-13 * X.normF()) { std::cout << "ERROR: forward_solve + backward_solve differ from solve" << std::endl; return 1; }
+  }
 
   if (!H.leaf()) {
     // test_HSS_seq.cpp:252-260, plus the check the reference leaves as a TODO: with H z = [0; y] the Schur
@@ -154,6 +162,42 @@ int main(int argc, char* argv[]) {
     Sc2.scaled_add(-1., Sc);
     std::cout << "# Schur products, direct vs indirect = " << Sr2.normF() / Sr.normF() << " , " << Sc2.normF() / Sc.normF() << std::endl;
     if (Sr2.normF() > 1e-10 * Sr.normF() || Sc2.normF() > 1e-10 * Sc.normF()) { std::cout << "ERROR: Schur products disagree" << std::endl; return 1; }
+    // the solve of a sparse front on top of the partial factorization (sparse/fronts/FrontHSS.cpp:446-501): forward half on
+    // child(0) with partial = true, the update part through Theta and the dense Schur complement, Phi^* y_upd off the reduced
+    // solution, backward half -- [x0; x1] then solves the compressed system H x = b
+    {
+      auto c0 = H.child(0);
+      auto c1 = H.child(1);
+      const int nb = 3;
+      DenseMatrix<double> bf(m, nb), b0(n0, nb), b1(n1, nb);
+      bf.random();
+      for (int j = 0; j < nb; j++) {
+        for (std::size_t i = 0; i < n0; i++) b0(i, j) = bf(i, j);
+        for (std::size_t i = 0; i < n1; i++) b1(i, j) = bf(n0 + i, j);
+      }
+      WorkSolve<double> w;
+      c0->forward_solve(w, b0, true);
+      if (w.reduced_rhs.rows() != Theta.cols() || w.x.rows() != Phi.cols()) { std::cout << "ERROR: forward_solve shapes" << std::endl; return 1; }
+      gemm(Trans::N, Trans::N, -1., Theta, w.reduced_rhs, 1., b1);                 // b_upd -= Theta reduced_rhs
+      auto S = c1->dense();                                                        // S = H11 - Theta Vhat^* Phi^*
+      DenseMatrix<double> VP(Vhat.cols(), Phi.rows());
+      gemm(Trans::C, Trans::C, 1., Vhat, Phi, 0., VP);
+      gemm(Trans::N, Trans::N, -1., Theta, VP, 1., S);
+      auto pv = S.LU();
+      auto x1 = S.solve(b1, pv);
+      gemm(Trans::C, Trans::N, -1., Phi, x1, 1., w.x);                             // x_root -= Phi^* y_upd
+      DenseMatrix<double> x0(n0, nb);
+      c0->backward_solve(w, x0);
+      DenseMatrix<double> xf(m, nb);
+      for (int j = 0; j < nb; j++) {
+        for (std::size_t i = 0; i < n0; i++) xf(i, j) = x0(i, j);
+        for (std::size_t i = 0; i < n1; i++) xf(n0 + i, j) = x1(i, j);
+      }
+      auto rf = H.apply(xf);
+      rf.scaled_add(-1., bf);
+      std::cout << "# front solve on the partial factorization: ||H x - b||_F/||b||_F = " << rf.normF() / bf.normF() << std::endl;
+      if (rf.normF() > 1e-9 * bf.normF()) { std::cout << "ERROR: forward_solve / backward_solve with a partial factorization" << std::endl; return 1; }
+    }
     // child views (HSSMatrix.hpp:194-202): blocks of H through child(c), children of children, Vhat through the view
     {
       auto c0 = H.child(0);
