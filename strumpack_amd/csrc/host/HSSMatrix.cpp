@@ -305,6 +305,39 @@ void HSSMatrix<double>::solve(DenseM_t& b) const {
   if (veng_) veng_->solve_node(vnode_, int(b.cols()), b.data(), b.ld(), false);
   else eng_->solve(int(b.cols()), b.data(), b.ld(), false);
 }
+std::size_t HSSMatrix<double>::factor_nonzeros() const {
+  DeviceHSS* e = engine();
+  if (!e) return 0;
+  const auto& nd = e->nodes();
+  const bool whole = e->node_is_factored(0);
+  const bool partial = e->is_partially_factored() && !nd[0].leaf();
+  // the node the factorization in place is rooted at: the whole tree, child 0 (partial_factor), or a child factored on its own
+  int root = -1;
+  if (whole) root = 0;
+  else if (partial) root = nd[0].c0;
+  else for (std::size_t i = 1; i < nd.size(); i++) if (e->node_is_factored(int(i))) root = int(i);
+  if (root < 0) return 0;
+  std::size_t nnz = 0;
+  std::function<void(int, bool)> walk = [&](int i, bool counted) {   // counted: inside the factored subtree
+    const auto& n = nd[i];
+    const bool in = counted || i == root;
+    if (in) {
+      if (i == root) {
+        const std::size_t mu = n.leaf() ? std::size_t(n.m) : std::size_t(nd[n.c0].rU + nd[n.c1].rU);
+        nnz += mu * mu + (partial && !whole ? mu * std::size_t(n.rV) : 0);
+      } else if (n.mU > n.rU) {
+        const std::size_t m = n.mU, r = n.rU, q = m - r, rv = n.rV;
+        nnz += q * q + q * rv + r * m + m * m;
+      }
+    }
+    if (!n.leaf()) { walk(n.c0, in); walk(n.c1, in); }
+  };
+  // (a view reports the factors below its own node)
+  std::function<bool(int, int)> below = [&](int i, int a) { while (i > 0 && i != a) i = nd[i].parent; return i == a; };
+  if (vnode_ != 0 && !below(root, vnode_) && !below(vnode_, root)) return 0;
+  walk(below(root, vnode_) ? vnode_ : vnode_, below(vnode_, root) && vnode_ != root);
+  return nnz;
+}
 void HSSMatrix<double>::forward_solve(WorkSolve<double>& w, const DenseM_t& b, bool partial) const {
   DeviceHSS* e = engine();
   if (!e) throw std::logic_error("forward_solve: empty matrix");

@@ -126,6 +126,9 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   // the two halves of solve(b) (HSSMatrix.hpp:360-376).  partial: after the parent's partial_factor(), on child(0) -- the root
   // of the call keeps its column basis and w.reduced_rhs is formed for the front's update part; w.x may be changed between
   // the two calls (the front subtracts Phi^* y_upd).
+  // scalars of the ULV factors as the reference counts them (HSSMatrixBase.cpp:73-78, HSSExtra.hpp:183-186: L, Vt0, W1, Q of
+  // every eliminated node, D of the root): 0 before factor()
+  std::size_t factor_nonzeros() const;
   void forward_solve(WorkSolve<double>& w, const DenseM_t& b, bool partial) const;
   void backward_solve(WorkSolve<double>& w, DenseM_t& x) const;
   void partial_factor();

@@ -128,6 +128,23 @@ int main(int argc, char* argv[]) {
     count(&H);
     if (rects != leaves + 2 * inner) { std::cout << "ERROR: draw wrote " << rects << " rectangles for " << leaves << " leaves" << std::endl; return 1; }
     H.set_openmp_task_depth(2);
+    // factor_nonzeros (HSSMatrixBase.hpp:177): L, Vt0, W1, Q of the eliminated nodes + D of the root, from the node table
+    {
+      std::size_t want = 0;
+      std::function<void(const HSS::HSSMatrix<double>*, bool)> cnt = [&](const HSS::HSSMatrix<double>* M, bool root) {
+        if (root) { const std::size_t mu = M->leaf() ? M->rows() : M->child(0)->U_rank() + M->child(1)->U_rank(); want += mu * mu; }
+        else if (M->U_rows() > M->U_rank()) {
+          const std::size_t mm = M->U_rows(), r = M->U_rank(), q = mm - r;
+          want += q * q + q * M->V_rank() + r * mm + mm * mm;
+        }
+        if (!M->leaf()) { cnt(M->child(0), false); cnt(M->child(1), false); }
+      };
+      auto Fc = H.clone();
+      if (Fc->factor_nonzeros() != 0) { std::cout << "ERROR: factor_nonzeros before factor()" << std::endl; return 1; }
+      Fc->factor();
+      cnt(Fc.get(), true);
+      if (Fc->factor_nonzeros() != want || want == 0) { std::cout << "ERROR: factor_nonzeros " << Fc->factor_nonzeros() << " vs " << want << std::endl; return 1; }
+    }
     // StructuredMatrix interface defaults (structured/StructuredMatrix.hpp:262-320, StructuredMatrix.cpp:572-605)
     const structured::StructuredMatrix<double>& SM = H;
     if (SM.dist().size() != 2 || SM.dist()[1] != int(H.rows()) || SM.rdist() != SM.cdist()) { std::cout << "ERROR: dist()" << std::endl; return 1; }
