@@ -43,6 +43,10 @@ for (n, leaf, d0, dd, algo, sketch) in CASES[world]:
     e_multT = np.linalg.norm(yt - yt1) / np.linalg.norm(yt1)
     e_solve = np.linalg.norm(x - x1) / np.linalg.norm(x1)
     res = np.linalg.norm(H.mult(x) - B) / np.linalg.norm(B)
+    # twenty right-hand sides: the matrix-core forms of the sweeps on the rank's subtree and on the replicated top
+    B20 = rng.standard_normal((n, 20))
+    e_mult = max(e_mult, np.linalg.norm(H.mult(B20) - H1.mult(B20)) / np.linalg.norm(B20))
+    e_solve = max(e_solve, np.linalg.norm(H.solve(B20) - H1.solve(B20)) / np.linalg.norm(B20))
     good = same_tree and e_mult < 1e-11 and e_multT < 1e-11 and e_solve < 1e-9 and res < 1e-12 and H.stats()["rounds"] == H1.stats()["rounds"]
     if not good:
         print("rank", rank, "case", n, leaf, algo, same_tree, e_mult, e_multT, e_solve, res, flush=True)
