@@ -332,10 +332,12 @@ std::size_t HSSMatrix<double>::factor_nonzeros() const {
     }
     if (!n.leaf()) { walk(n.c0, in); walk(n.c1, in); }
   };
-  // (a view reports the factors below its own node)
-  std::function<bool(int, int)> below = [&](int i, int a) { while (i > 0 && i != a) i = nd[i].parent; return i == a; };
-  if (vnode_ != 0 && !below(root, vnode_) && !below(vnode_, root)) return 0;
-  walk(below(root, vnode_) ? vnode_ : vnode_, below(vnode_, root) && vnode_ != root);
+  // a view reports the factors of its own nodes: the factored subtree lies inside the view (count from its root on), the view
+  // lies inside the factored subtree (every node of the view counts), or they are disjoint
+  auto below = [&](int i, int a) { while (i > 0 && i != a) i = nd[i].parent; return i == a; };   // is a an ancestor of (or equal to) i
+  const bool view_inside = below(vnode_, root) && vnode_ != root;
+  if (!below(root, vnode_) && !view_inside) return 0;
+  walk(vnode_, view_inside);
   return nnz;
 }
 void HSSMatrix<double>::forward_solve(WorkSolve<double>& w, const DenseM_t& b, bool partial) const {

@@ -43,8 +43,9 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   const int lo0 = nodes_[sr].lo;
   std::vector<std::vector<int>> sub_h, sub_d;
   if (sr != 0) { sub_h = sublists(own_by_height_, sr); sub_d = sublists(own_by_depth_, sr); }
-  const std::vector<std::vector<int>>& own_by_height_ = sr ? sub_h : this->own_by_height_;
-  const std::vector<std::vector<int>>& own_by_depth_ = sr ? sub_d : this->own_by_depth_;
+  // the levels of the solve: the whole tree's, or those of the subtree below sr
+  const std::vector<std::vector<int>>& lv_height = sr ? sub_h : own_by_height_;
+  const std::vector<std::vector<int>>& lv_depth = sr ? sub_d : own_by_depth_;
   double t0 = now();
   // repeated solve on the same device buffer: replay the recorded sweep (no descriptor building, no staging)
   const bool plannable = on_device && o_.world == 1 && plans_enabled();
@@ -336,26 +337,26 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   // many right-hand sides (hybrid, see mult_sub): the leaf level as batched MFMA GEMMs over all right-hand sides (the
   // blocks of the leaves -- X, R~, WQ, Vt0, Q~: most of the bytes -- read once), the inner levels in the single launches
   bool big_leaves = false;   // (leaves beyond the sweep kernels' 256 rows -- leaf size 512 -- take the same route for any nrhs)
-  if (!own_by_height_.empty())
-    for (int id : own_by_height_[0]) big_leaves = big_leaves || nodes_[id].m > 256;
-  const bool hybrid = fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && own_by_height_.size() > 1;
+  if (!lv_height.empty())
+    for (int id : lv_height[0]) big_leaves = big_leaves || nodes_[id].m > 256;
+  const bool hybrid = fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && lv_height.size() > 1;
   bool fwd_done = phase == 2;   // (the backward half: the forward sweep ran in forward_solve)
   static const bool no_side = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
   const bool side = hybrid && !no_side && phase == 0;   // (a split solve keeps every launch on the main stream)
   std::vector<int> leaf_parents;   // the leaves' parents, whatever their depth: one batch
   if (hybrid)
-    for (auto& ids : own_by_depth_) leaf_parents.insert(leaf_parents.end(), ids.begin(), ids.end());
+    for (auto& ids : lv_depth) leaf_parents.insert(leaf_parents.end(), ids.begin(), ids.end());
   if (hybrid && phase != 2) {
-    Levels inner(own_by_height_.begin() + 1, own_by_height_.end());
+    Levels inner(lv_height.begin() + 1, lv_height.end());
     // the leaf level: one launch in the matrix-core form of the sweep when it takes the leaves (kernels/hssk_sweep_mma.h),
     // else batched launches over all right-hand sides
     bool leaves_done = false;
     if (nrhs >= hssk_sweep_mma_min_nrhs() && !big_leaves) {
       struct Req { hssk_ctx* c; Req(hssk_ctx* c_) : c(c_) { hssk_sweep_require_mma(c, 1); } ~Req() { hssk_sweep_require_mma(c, 0); } } req(ctx_);
-      Levels leaf_level{own_by_height_[0]};
+      Levels leaf_level{lv_height[0]};
       leaves_done = fwd_sweep(leaf_level);
     }
-    if (!leaves_done) fwd(own_by_height_[0], true);
+    if (!leaves_done) fwd(lv_height[0], true);
     if (side) {
       // the leaves' Q~(:, 0:q) y -- most of the backward step, and independent of the levels above -- next to the inner levels
       ck(hssk_side_begin(ctx_));
@@ -366,8 +367,8 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
       for (auto& ids : inner) fwd(ids);
     fwd_done = true;
   }
-  if (!fwd_done && !(fuse && fwd_sweep(own_by_height_)))
-    for (auto& ids : own_by_height_) fwd(ids);
+  if (!fwd_done && !(fuse && fwd_sweep(lv_height)))
+    for (auto& ids : lv_height) fwd(ids);
   if (dist_subtree_) {
     // publish ft1' (rU x nrhs) and z (rV x nrhs) of the cut nodes into every rank's top buffers
     const int G = o_.world, me = o_.rank;
@@ -455,12 +456,12 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
     if (mu) ck(hssk_memcpy2d_h2d(ctx_, dxr, sizeof(double) * ldr_dev, ws->xroot, sizeof(double) * ws->ldx, sizeof(double) * mu, nrhs));
   }
   if (hybrid) {
-    if (!bwd_sweep(own_by_depth_, 1))
-      for (auto& ids : own_by_depth_) bwd(ids, 1);
+    if (!bwd_sweep(lv_depth, 1))
+      for (auto& ids : lv_depth) bwd(ids, 1);
     if (side) ck(hssk_side_join(ctx_));
     bwd(leaf_parents, side ? 4 : 2);
-  } else if (!(fuse && bwd_sweep(own_by_depth_, 0)))
-    for (auto& ids : own_by_depth_) bwd(ids);
+  } else if (!(fuse && bwd_sweep(lv_depth, 0)))
+    for (auto& ids : lv_depth) bwd(ids);
   if (dist_subtree_) allgather_rows(db, lb, nrhs);
   if (!on_device) ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, db, sizeof(double) * N, sizeof(double) * N, nrhs));
   if (rec) { ck(hssk_plan_end(ctx_)); guard.done = true; plans_[key].plan = rec; }
