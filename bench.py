@@ -45,6 +45,8 @@ def parse():
                         "--hss_compression_sketch SJLT option (nnz = 4), a separate, HBM-bound workload")
     p.add_argument("--front-n", type=int, default=64, help="blr_front: the separator is an n x n plane (dsep = n^2, dupd = 2 n^2)")
     p.add_argument("--front-leaf", type=int, default=256, help="blr_front: tile size (the reference's BLR default)")
+    p.add_argument("--front-lra", choices=["rrqr", "aca"], default="rrqr",
+                   help="blr_front: tile compression (--blr_low_rank_algorithm; the reference's default and BASELINE's: RRQR)")
     p.add_argument("--workload", choices=["toeplitz", "kernel", "host", "blr_front"], default="toeplitz",
                    help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
                         "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line; host = the headline "
@@ -227,6 +229,8 @@ def blr_front_workload(a, L, hk, torch):
     nF = float(np.sqrt(sum(np.linalg.norm(fr[k]) ** 2 for k in ("F11", "F12", "F21"))))
     rtol, atol = 1e-4, 1e-12 * nF      # BLROptions defaults; abs_tol scaled by the front's norm (FrontBLR.cpp:424-429)
     o = capi.StructuredMatrix.options(L, rel_tol=rtol, abs_tol=atol, type=capi.SP_TYPE_BLR)
+    if L.SPX_blr_low_rank_algorithm(1 if a.front_lra == "aca" else 0):
+        raise SystemExit("SPX_blr_low_rank_algorithm failed")
     d = {k: hk.array(fr[k]) for k in ("F11", "F12", "F21", "F22")}
     rng = np.random.default_rng(5)
     b, bu = rng.standard_normal((ds, 1)), rng.standard_normal((du, 1))
@@ -279,7 +283,7 @@ def blr_front_workload(a, L, hk, torch):
     out = {"metric": "blr_front_partial_factor_gflops", "value": st["f_total"] / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[4] kernel: BLR partial factorization (RL, RRQR tiles, rel_tol 1e-4, tiles of %d) of an exact "
+           "config": {"workload": "BASELINE configs[4] kernel: BLR partial factorization (RL, " + a.front_lra.upper() + " tiles, rel_tol 1e-4, tiles of %d) of an exact "
                                   "3D 7-point Poisson front: separator %dx%d plane (dsep=%d), update part dupd=%d, operands in HBM; "
                                   "+ forward / backward solve phase, 1 rhs" % (leaf, n, n, ds, du),
                       "dsep": ds, "dupd": du, "tiles": [len(fr["tiles1"]), len(fr["tiles2"])], "leaf": leaf, "rel_tol": rtol},
