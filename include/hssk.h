@@ -334,6 +334,9 @@ typedef struct hssk_id_desc {
                 * [R11 R12] on return, or already X behind R11 when hssk_id_solves_inline() says so for the batch. */
 } hssk_id_desc;
 int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count);
+/* batches this process factored with several workgroups per panel (id_group_kernel: panels of 129..256 rows and up to 512
+ * columns beyond the single-workgroup register kernels); tests assert that the path was taken */
+long long hssk_id_group_launches(void);
 /* 1: a batch with these largest dimensions is factored by kernels that always leave X in W (defer_x has no effect) */
 int hssk_id_solves_inline(int dmax, int mmax);
 /* X (rank x (m - rank), leading dimension ldx) = R11^{-1} R12 from the factored panel W (solved == 0), or a plain copy of

@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <stdexcept>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -743,6 +745,292 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_reg_ke
 }
 
 static thread_local bool g_all_deferred = false;   // (set by hssk_id_vbatched for the launch helpers below)
+// ------------------------------------------------------------------------------------------------
+// id_group_kernel: the register kernel above for panels that do not fit the registers of ONE workgroup (256 x 256 BLR tiles,
+// the 192 x 391 sample panels of leaf size 512): H = 2 or 4 workgroups of 16 waves share a panel, each keeps its slice of
+// the columns in registers for the whole factorization (the streaming kernel reads and writes the trailing panel through L2
+// every step: 19 us per step on a 256 x 256 tile).  Per Householder step the workgroups exchange two small messages through
+// device memory: their best pivot candidates (value, column), then -- from the owner of the pivot column -- the reflector,
+// tau, |R_kk| and the stopping flag.  Every word of a message is written once with a coherent store and polled by its reader
+// until it is no longer the sentinel the buffer was armed with (hssk_sweep_arm; one memory round trip per message, ~0.65 us
+// across XCDs); step k has words of its own, so nothing is ever reset.  The workgroups of a panel are adjacent in the launch:
+// in-order dispatch leaves at most the group at the dispatch frontier incomplete while all earlier groups are resident and
+// finish, so a waiting workgroup is never starved; a bounded spin count turns a violation into an error code.
+// Same decisions as id_reg_kernel (squared norms, first arg max with the smaller column index on ties, dlaqp2 down-date with
+// its cancellation guard, the dgeqp3tol stopping rule), same outputs ([R11 R12] in the first `rank` rows at the pivoted column
+// positions, perm, rank).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long IDG_SENTINEL = 0x7FF8DEADBEEF5EEDull;   // (the pattern hssk_sweep_arm writes)
+constexpr long IDG_SPIN_LIMIT = 1L << 17;   // (~30 ms of polling: a partner that is merely not resident yet arrives within microseconds)
+__device__ __forceinline__ double idg_take(const double* p, size_t off, int* err) {
+  double v = hssk_cload(p, off);
+  long spins = 0;
+  while (hssk_bits(v) == IDG_SENTINEL) {
+    hssk_pause();
+    if (++spins > IDG_SPIN_LIMIT) { hssk_flag_raise(err); return 0.; }
+    v = hssk_cload(p, off);
+  }
+  return v;
+}
+template <int RT, int H> constexpr int idg_step_words() { return 2 * H + 16 * RT + 3; }
+
+template <int RT, int CT, int NW, int H>
+__global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_kernel(const hssk_id_desc* __restrict__ descs, double* __restrict__ xch,
+                                                                              int kcap, int* err) {
+  static_assert(NW == 8 || NW == 16, "one pivot candidate per lane of a 16-lane row");
+  constexpr int NC = NW * 4, HC = NC * CT, NT = NW * 64;   // HC: columns a workgroup holds
+  constexpr int SW = idg_step_words<RT, H>();
+  HSSK_SHARED double s_v[16 * RT];
+  HSSK_SHARED double s_vn1[HC];
+  HSSK_SHARED double s_vn2[HC];
+  HSSK_SHARED double s_val[NW];
+  HSSK_SHARED int s_idx[NW];
+  HSSK_SHARED double s_oval[H];
+  HSSK_SHARED double s_oidx[H];
+  HSSK_SHARED double s_msg[3];   // tau, stop, |R_kk|
+  HSSK_SHARED double s_r00;
+  HSSK_SHARED int s_perm[H * HC];
+  HSSK_SHARED int s_pos[H * HC];
+  const int panel = blockIdx.x / H, h = blockIdx.x % H;
+  const hssk_id_desc p = descs[panel];
+  double* xw = xch + (size_t)panel * kcap * SW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, sub = lane >> 4, grp = wave * 4 + sub;
+  const int d = p.d, m = p.m, ld = p.ldw;
+  const int kmax = min(min(d < m ? d : m, p.max_rank > 0 ? p.max_rank : 0), kcap);
+  const double tol3z = 1.4901161193847656e-08;  // sqrt(eps)
+  const double* __restrict__ in = p.src ? p.src : p.W;
+  const int ldin = p.src ? p.lds : ld;
+  const int c0 = h * HC;   // first column of this workgroup's slice
+  double a[CT][RT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    const int lc = grp + NC * c, col = c0 + lc;
+    double s = 0.;
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const int row = l16 + 16 * r;
+      a[c][r] = (row < d && col < m) ? hssk_gload(in, row + (size_t)col * ldin) : 0.;
+      s += a[c][r] * a[c][r];
+    }
+    s = hssk_row_sum(s);
+    if (l16 == 0) { s_vn1[lc] = s; s_vn2[lc] = s; }
+  }
+  if (tid == 0) s_r00 = 0.;
+  unsigned used = 0;
+  __syncthreads();
+
+  int rank = kmax;
+  bool done = false;
+#pragma clang loop unroll(full)
+  for (int rk = 0; rk < RT; rk++) {
+    const int nlk = done ? 0 : min(16, kmax - 16 * rk);
+    for (int lk = 0; lk < nlk; lk++) {
+      const int k = rk * 16 + lk;
+      double* xs = xw + (size_t)k * SW;   // this step's words: [H values][H columns][16 RT reflector rows][tau, stop, |R_kk|]
+      // ---- 1. pivot: this workgroup's first arg max over its unused columns ...
+      {
+        double bv = -1.;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          const int lc = grp + NC * c, col = c0 + lc;
+          if (col < m && !((used >> c) & 1u)) {
+            const double v = s_vn1[lc];
+            if (v > bv) { bv = v; bi = col; }
+          }
+        }
+        double wv = hssk_bcast_lane(bv, 0);
+        int wi = hssk_bcast_lane_i(bi, 0);
+#pragma unroll
+        for (int q = 1; q < 4; q++) {
+          const double v = hssk_bcast_lane(bv, 16 * q);
+          const int ix = hssk_bcast_lane_i(bi, 16 * q);
+          if (v > wv || (v == wv && ix < wi)) { wv = v; wi = ix; }
+        }
+        if (lane == 0) { s_val[wave] = wv; s_idx[wave] = wi; }
+      }
+      __syncthreads();
+      double gv = s_val[lane & (NW - 1)];
+      int pcol = s_idx[lane & (NW - 1)];
+      hssk_row_argmax(gv, pcol);
+      // ... published by two lanes of wave 0, the others' taken by wave 1: lane q < H the value of workgroup q, lane H + q its
+      // column.  (Store and poll must not share a wave: the compiler is free to run the polling lanes of a divergent wave to
+      // completion before the storing ones, and two workgroups doing that wait for each other forever.)
+      if (tid < 2) hssk_cstore(xs, (size_t)(tid * H + h), tid ? (double)pcol : gv);
+      if (wave == 1 && lane < 2 * H) {
+        const int q = lane % H;
+        const bool isidx = lane >= H;
+        const double got = q == h ? (isidx ? (double)pcol : gv) : idg_take(xs, (size_t)lane, err);
+        if (isidx) s_oidx[q] = got; else s_oval[q] = got;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < H; q++) {
+        const double v = s_oval[q];
+        const int ix = (int)s_oidx[q];
+        if (q != h && (v > gv || (v == gv && ix < pcol))) { gv = v; pcol = ix; }
+      }
+      const int owner = pcol / HC, lp = pcol - owner * HC;
+      const int pg = lp % NC, cp = lp / NC, wp = pg >> 2, sp = pg & 3;
+      // ---- 2. reflector from the pivot column (dlarfg): its owner computes and publishes it
+      if (h == owner) {
+        if (wave == wp) {
+          const bool own = sub == sp;
+#pragma unroll
+          for (int c = 0; c < CT; c++)
+            if (c == cp) {
+              double s = 0.;
+#pragma unroll
+              for (int r = 0; r < RT; r++) {
+                if (r > rk) s += a[c][r] * a[c][r];
+                else if (r == rk && l16 > lk) s += a[c][r] * a[c][r];
+              }
+              const double alpha = hssk_shfl(a[c][rk], (lane & 48) | lk);
+              s = hssk_row_sum(s);
+              double tau = 0., beta = alpha, scal = 1.;
+              if (s != 0.) {
+                double nrm = sqrt(alpha * alpha + s);
+                beta = alpha >= 0. ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scal = 1. / (alpha - beta);
+              }
+              if (own) {
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                  const int row = l16 + 16 * r;
+                  double vrow;
+                  if (r < rk) vrow = 0.;
+                  else if (r > rk) { a[c][r] *= scal; vrow = a[c][r]; }
+                  else {
+                    if (l16 > lk) a[c][r] *= scal;
+                    vrow = l16 > lk ? a[c][r] : (l16 == lk ? 1. : 0.);
+                    if (l16 == lk) a[c][r] = beta;
+                  }
+                  s_v[row] = vrow;
+                  hssk_cstore(xs, (size_t)(2 * H + row), vrow);
+                }
+                used |= 1u << c;
+                if (l16 == 0) {
+                  const double ab = fabs(beta);
+                  const double r00 = (k == 0) ? ab : s_r00;
+                  // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
+                  const double stop = ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) ? 1. : 0.;
+                  s_msg[0] = tau; s_msg[1] = stop; s_msg[2] = ab;
+                  hssk_cstore(xs, (size_t)(2 * H + 16 * RT), tau);
+                  hssk_cstore(xs, (size_t)(2 * H + 16 * RT + 1), stop);
+                  hssk_cstore(xs, (size_t)(2 * H + 16 * RT + 2), ab);
+                }
+              }
+            }
+        }
+      } else {
+        // the other workgroups take it word by word
+        if (tid < 16 * RT) s_v[tid] = idg_take(xs, (size_t)(2 * H + tid), err);
+        else if (tid < 16 * RT + 3) s_msg[tid - 16 * RT] = idg_take(xs, (size_t)(2 * H + tid), err);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        if (k == 0) s_r00 = s_msg[2];
+        s_perm[k] = pcol;
+      }
+      if (s_msg[1] != 0.) { rank = k; done = true; __syncthreads(); break; }
+      const double tau = s_msg[0];
+      // ---- 3. apply H to this workgroup's unused columns and down-date their norms (dlaqp2)
+      double vr[RT];
+#pragma unroll
+      for (int r = 0; r < RT; r++) vr[r] = s_v[l16 + 16 * r];
+      // all dot products of the wave's slots first, their row sums stage by stage (independent chains in flight)
+      double dot[CT];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        double d0 = 0., d1 = 0.;
+#pragma unroll
+        for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
+        if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
+        dot[c] = d0 + d1;
+      }
+      hssk_row_sum_n(dot);
+      double newk[CT];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int col = c0 + grp + NC * c;
+        const double f = (col < m && !((used >> c) & 1u)) ? dot[c] * tau : 0.;
+#pragma unroll
+        for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
+        newk[c] = hssk_shfl(a[c][rk], (lane & 48) | lk);  // R(k, col)
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const int lc = grp + NC * c, col = c0 + lc;
+        const bool act = col < m && !((used >> c) & 1u);
+        double n1 = 0., n2 = 0., newn1 = 0.;
+        int recompute = 0;
+        if (act) {
+          n1 = s_vn1[lc]; n2 = s_vn2[lc];
+          newn1 = n1 - newk[c] * newk[c];
+          newn1 = newn1 > 0. ? newn1 : 0.;
+          recompute = (n1 != 0.) && (newn1 <= tol3z * n2);
+        }
+        if (hssk_any(recompute)) {
+          double s2 = 0.;
+#pragma unroll
+          for (int r = 0; r < RT; r++)
+            if (r > rk || (r == rk && l16 > lk)) s2 += a[c][r] * a[c][r];
+          s2 = hssk_row_sum(s2);
+          if (recompute) {
+            newn1 = s2;
+            if (l16 == 0) s_vn2[lc] = newn1;
+          }
+        }
+        if (act && l16 == 0) s_vn1[lc] = newn1;
+      }
+      __syncthreads();   // (the step's LDS words are rewritten by the next one)
+    }
+  }
+  // ---- pivoted column positions: skeleton columns first (pivot order), then the rest in index order (every workgroup works
+  // the whole table out: the pivots of all steps are known to all)
+  __syncthreads();
+  for (int j = tid; j < H * HC; j += NT) s_pos[j] = -1;
+  __syncthreads();
+  for (int j = tid; j < rank; j += NT) s_pos[s_perm[j]] = j;
+  __syncthreads();
+  {
+    // a column that was never a pivot goes behind the skeleton, in index order: rank + (number of such columns before it);
+    // m <= H HC: up to H columns per thread, the new positions committed after everybody has counted
+    int mine[H];
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+      const int col = tid + q * NT;
+      mine[q] = -1;
+      if (col < m && s_pos[col] < 0) {
+        int c = 0;
+        for (int e = 0; e < col; e++) c += s_pos[e] < 0;
+        mine[q] = rank + c;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < H; q++)
+      if (mine[q] >= 0) s_pos[tid + q * NT] = mine[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    const int col = c0 + grp + NC * c;
+    if (col < m) {
+      const int pos = s_pos[col];
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const int row = l16 + 16 * r;
+        if (16 * r < rank && row < d) hssk_gstore(p.W, row + (size_t)pos * ld, a[c][r]);
+      }
+      if (l16 == 0) p.perm[pos] = col;
+    }
+  }
+  if (h == 0 && tid == 0) *p.rank = rank;
+}
+
 template <int RT, int CT, int NW>
 void launch_id_reg(hssk_ctx* ctx, const hssk_id_desc* dd, int count) {
   HSSK_LAUNCH((id_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
@@ -951,6 +1239,9 @@ void id_wide(hssk_ctx* ctx, const hssk_id_desc* descs, const hssk_id_desc* dd, i
 
 }  // namespace
 
+static std::atomic<long long> g_group_launches{0};
+extern "C" long long hssk_id_group_launches(void) { return g_group_launches; }
+
 extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
@@ -965,6 +1256,39 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
   else if (dmax <= 192) done = launch_id_reg_ct<12>(ctx, dd, count, mmax);
   else if (dmax <= 256) done = launch_id_reg_ct<16>(ctx, dd, count, mmax);
   if (!done) {
+    // panels of up to 256 rows and 512 columns: two or four workgroups per panel, its columns in their registers (id_group_kernel)
+    static const bool no_group = [] { const char* e = std::getenv("HSSK_ID_NO_GROUP"); return e && e[0] == '1'; }();
+    bool group_ok = !no_group && dmax > 128 && dmax <= 256 && mmax <= 512 && count >= 1;
+#ifdef HSSK_EMU
+    {   // (the emulator runs a launch's workgroups on a pool of host threads: the workgroups of a panel must be able to run together)
+      const char* e = std::getenv("HSSK_EMU_THREADS");
+      const int nt = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+      group_ok = group_ok && std::min(nt, 16) >= 4;
+    }
+#endif
+    if (group_ok) {
+      const int H = mmax <= 256 ? 2 : 4;
+      const int RTv = dmax <= 192 ? 12 : 16;
+      int kcap = 1;
+      for (int i = 0; i < count; i++) kcap = std::max(kcap, std::min(std::min(descs[i].d, descs[i].m), std::max(descs[i].max_rank, 0)));
+      const int sw = 2 * H + 16 * RTv + 3;
+      const size_t words = (size_t)count * kcap * sw;
+      double* xch = ctx->aux(sizeof(double) * words);
+      { int rc = hssk_sweep_arm(ctx, xch, (long long)words); if (rc) return rc; }
+      if (!ctx->h_sweep_err) { ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64); *ctx->h_sweep_err = 0; }
+      int* err = ctx->h_sweep_err;
+      // (eight waves per workgroup, 128 columns each: the tile takes 128 of a lane's 256 registers; sixteen waves with half the
+      //  columns each spill -- 232 bytes per lane at 256 rows)
+      const dim3 grid((unsigned)count * H), block(512);
+      g_group_launches++;
+      if (RTv == 16 && H == 2) HSSK_LAUNCH((id_group_kernel<16, 4, 8, 2>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
+      else if (RTv == 16) HSSK_LAUNCH((id_group_kernel<16, 4, 8, 4>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
+      else if (H == 2) HSSK_LAUNCH((id_group_kernel<12, 4, 8, 2>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
+      else HSSK_LAUNCH((id_group_kernel<12, 4, 8, 4>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
+      HSSK_LAUNCH(id_xsolve_all_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
+      hssk_rt::check_launch();
+      return 0;
+    }
     // the in-place kernels want the panel in W
     std::vector<hssk_colgather_desc> cp;
     for (int i = 0; i < count; i++)

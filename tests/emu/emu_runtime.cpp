@@ -21,7 +21,6 @@
 
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #include <sched.h>
-void hssk_pause() { sched_yield(); }
 
 namespace emu {
 namespace {
@@ -66,6 +65,17 @@ void yield() {
   if (!_setjmp(w->fibers[w->cur].jb)) _longjmp(w->sched, 1);
 #endif
 }
+}  // namespace
+}  // namespace emu
+// a polling lane gives way to the other workgroups (OS threads) AND to the other lanes of its own workgroup: on the device the
+// waves of a workgroup progress independently, so a wave may poll for a word whose store another wave of a partner workgroup
+// has yet to issue
+void hssk_pause() {
+  sched_yield();
+  emu::yield();
+}
+namespace emu {
+namespace {
 void trampoline() {
   Worker* w = W;
   (*w->body)();

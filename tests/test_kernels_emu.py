@@ -83,6 +83,17 @@ def test_id(hk):
     KC.case_id(hk, [(96, 250, 1e-6, 1e-12, 1000, 12), (130, 230, 1e-8, 1e-13, 1000, 70), (64, 300, 1e-6, 1e-12, 9, 20)], seed=12)
     KC.case_id(hk, [(300, 120, 1e-6, 1e-12, 1000, 30), (270, 240, 1e-9, 1e-14, 1000, 150), (260, 100, 1e-13, 1e-16, 1000, None)], seed=13)
     KC.case_id(hk, [(100, 240, 1e-6, 1e-12, 1000, 70)], seed=14, deferred=True)
+    # two / four workgroups per panel with its columns in their registers (id_group_kernel): 256 x 256 tiles (BLR), the 192 x 391
+    # sample panels of leaf size 512, ranks below and above 64, a max_rank cut-off, a full-rank panel, deferred X from a source
+    import ctypes
+    hk.lib.hssk_id_group_launches.restype = ctypes.c_longlong
+    g0 = hk.lib.hssk_id_group_launches()
+    KC.case_id(hk, [(256, 256, 1e-6, 1e-12, 1000, 30), (200, 250, 1e-8, 1e-13, 1000, 100), (256, 256, 1e-6, 1e-12, 129, None)], seed=15)
+    KC.case_id(hk, [(192, 391, 1e-6, 1e-12, 1000, 40), (150, 500, 1e-6, 1e-12, 12, 60)], seed=16)
+    KC.case_id(hk, [(256, 240, 1e-6, 1e-12, 1000, 20), (140, 256, 1e-6, 1e-12, 1000, 5)], seed=17, deferred=True)
+    import os
+    if (os.cpu_count() or 1) >= 4 and "HSSK_ID_NO_GROUP" not in os.environ and "HSSK_EMU_THREADS" not in os.environ:
+        assert hk.lib.hssk_id_group_launches() == g0 + 3
 
 
 def test_qr(hk):

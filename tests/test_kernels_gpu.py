@@ -87,6 +87,17 @@ def test_id(hk):
     KC.case_id(hk, [(256, 256, 1e-4, 1e-12, 5000, 13)] * 6 + [(256, 256, 1e-4, 1e-12, 5000, 127), (200, 256, 1e-6, 1e-12, 5000, 70)] +
                [(192, 391, 1e-4, 1e-10, 50000, 41)] * 4 + [(400, 300, 1e-8, 1e-13, 5000, 90), (512, 512, 1e-6, 1e-12, 300, 200)], seed=25)
     KC.case_id(hk, [(600, 260, 1e-6, 1e-12, 1000, 40), (1500, 1200, 1e-8, 1e-12, 50000, 500), (900, 1000, 1e-6, 1e-12, 200, 400)], seed=22)
+    # several workgroups per panel, its columns in their registers (id_group_kernel): a BLR block row's worth of 256 x 256 tiles
+    # (more workgroups than CUs: the groups at the dispatch frontier wait for their partners), leaf-512 sample panels
+    import ctypes
+    hk.lib.hssk_id_group_launches.restype = ctypes.c_longlong
+    g0 = hk.lib.hssk_id_group_launches()
+    KC.case_id(hk, [(256, 256, 1e-4, 1e-12, 129, 13)] * 150 + [(256, 256, 1e-4, 1e-12, 129, 127), (200, 250, 1e-6, 1e-12, 129, 70), (256, 256, 1e-6, 1e-12, 129, None)], seed=26)
+    KC.case_id(hk, [(192, 391, 1e-4, 1e-10, 50000, 41)] * 100 + [(150, 500, 1e-6, 1e-12, 12, 60)], seed=27)
+    KC.case_id(hk, [(256, 240, 1e-6, 1e-12, 1000, 20), (140, 256, 1e-6, 1e-12, 1000, 5)] * 3, seed=28, deferred=True)
+    import os
+    if "HSSK_ID_NO_GROUP" not in os.environ:
+        assert hk.lib.hssk_id_group_launches() >= g0 + 3
 
 
 def test_qr(hk):
