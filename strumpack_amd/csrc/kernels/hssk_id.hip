@@ -773,6 +773,15 @@ __device__ __forceinline__ double idg_take(const double* p, size_t off, int* err
   return v;
 }
 template <int RT, int H> constexpr int idg_step_words() { return 2 * H + 16 * RT + 3; }
+// a[rk] of a register array, rk a wave-uniform run-time value: a one-hot combination (the weights are scalar selects, one
+// fma per entry).  A chain of compare-selects is folded by the compiler into ONE load at a computed address, which moves the
+// whole array from registers to scratch memory.
+template <int RT> __device__ __forceinline__ double idg_pick(const double (&a)[RT], int rk) {
+  double v = 0.;
+#pragma unroll
+  for (int r = 0; r < RT; r++) v = fma(a[r], r == rk ? 1. : 0., v);
+  return v;
+}
 
 template <int RT, int CT, int NW, int H>
 __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_kernel(const hssk_id_desc* __restrict__ descs, double* __restrict__ xch,
@@ -821,13 +830,19 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
   __syncthreads();
 
   int rank = kmax;
-  bool done = false;
-#pragma clang loop unroll(full)
-  for (int rk = 0; rk < RT; rk++) {
-    const int nlk = done ? 0 : min(16, kmax - 16 * rk);
-    for (int lk = 0; lk < nlk; lk++) {
-      const int k = rk * 16 + lk;
+#ifdef IDG_TIMING
+  long long tacc[5] = {0, 0, 0, 0, 0};
+#endif
+  // (one copy of the step for every 16-row register block `rk` -- the register kernel's form -- costs 2800 instructions per
+  //  block and, at 256 rows, 350 bytes of spills per lane: 11.4 us per step.  Here rk is a run-time value: the entries of row
+  //  k are picked out of the lane's RT registers of a column with compare-selects.)
+  {
+    for (int k = 0; k < kmax; k++) {
+      const int rk = k >> 4, lk = k & 15;
       double* xs = xw + (size_t)k * SW;   // this step's words: [H values][H columns][16 RT reflector rows][tau, stop, |R_kk|]
+#ifdef IDG_TIMING
+      long long tq0 = hssk_wallclock();
+#endif
       // ---- 1. pivot: this workgroup's first arg max over its unused columns ...
       {
         double bv = -1.;
@@ -851,6 +866,9 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         if (lane == 0) { s_val[wave] = wv; s_idx[wave] = wi; }
       }
       __syncthreads();
+#ifdef IDG_TIMING
+      long long tq1 = hssk_wallclock();
+#endif
       double gv = s_val[lane & (NW - 1)];
       int pcol = s_idx[lane & (NW - 1)];
       hssk_row_argmax(gv, pcol);
@@ -865,6 +883,9 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         if (isidx) s_oidx[q] = got; else s_oval[q] = got;
       }
       __syncthreads();
+#ifdef IDG_TIMING
+      long long tq2 = hssk_wallclock();
+#endif
 #pragma unroll
       for (int q = 0; q < H; q++) {
         const double v = s_oval[q];
@@ -876,53 +897,62 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
       // ---- 2. reflector from the pivot column (dlarfg): its owner computes and publishes it
       if (h == owner) {
         if (wave == wp) {
+          // (the pivot column's slot cp is a run-time value: its entries are picked out of the lane's slots with compare-selects,
+          //  the new column is put back the same way -- one copy of the row loop instead of one per slot)
           const bool own = sub == sp;
+          // (the pivot column is picked out of the slots twice -- for its norm, then for the reflector -- rather than kept in RT
+          //  more registers between the two passes)
+          const auto pick = [&](int r) {
+            double v = 0.;
 #pragma unroll
-          for (int c = 0; c < CT; c++)
-            if (c == cp) {
-              double s = 0.;
+            for (int c = 0; c < CT; c++) v = fma(a[c][r], c == cp ? 1. : 0., v);
+            return v;
+          };
+          double s = 0., arow = 0.;
 #pragma unroll
-              for (int r = 0; r < RT; r++) {
-                if (r > rk) s += a[c][r] * a[c][r];
-                else if (r == rk && l16 > lk) s += a[c][r] * a[c][r];
-              }
-              const double alpha = hssk_shfl(a[c][rk], (lane & 48) | lk);
-              s = hssk_row_sum(s);
-              double tau = 0., beta = alpha, scal = 1.;
-              if (s != 0.) {
-                double nrm = sqrt(alpha * alpha + s);
-                beta = alpha >= 0. ? -nrm : nrm;
-                tau = (beta - alpha) / beta;
-                scal = 1. / (alpha - beta);
-              }
-              if (own) {
+          for (int r = 0; r < RT; r++) {
+            const bool below = r > rk || (r == rk && l16 > lk);
+            const double v = pick(r);
+            s += below ? v * v : 0.;
+            arow = fma(v, r == rk ? 1. : 0., arow);
+          }
+          const double alpha = hssk_shfl(arow, (lane & 48) | lk);
+          s = hssk_row_sum(s);
+          double tau = 0., beta = alpha, scal = 1.;
+          if (s != 0.) {
+            double nrm = sqrt(alpha * alpha + s);
+            beta = alpha >= 0. ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scal = 1. / (alpha - beta);
+          }
 #pragma unroll
-                for (int r = 0; r < RT; r++) {
-                  const int row = l16 + 16 * r;
-                  double vrow;
-                  if (r < rk) vrow = 0.;
-                  else if (r > rk) { a[c][r] *= scal; vrow = a[c][r]; }
-                  else {
-                    if (l16 > lk) a[c][r] *= scal;
-                    vrow = l16 > lk ? a[c][r] : (l16 == lk ? 1. : 0.);
-                    if (l16 == lk) a[c][r] = beta;
-                  }
-                  s_v[row] = vrow;
-                  hssk_cstore(xs, (size_t)(2 * H + row), vrow);
-                }
-                used |= 1u << c;
-                if (l16 == 0) {
-                  const double ab = fabs(beta);
-                  const double r00 = (k == 0) ? ab : s_r00;
-                  // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
-                  const double stop = ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) ? 1. : 0.;
-                  s_msg[0] = tau; s_msg[1] = stop; s_msg[2] = ab;
-                  hssk_cstore(xs, (size_t)(2 * H + 16 * RT), tau);
-                  hssk_cstore(xs, (size_t)(2 * H + 16 * RT + 1), stop);
-                  hssk_cstore(xs, (size_t)(2 * H + 16 * RT + 2), ab);
-                }
-              }
+          for (int r = 0; r < RT; r++) {
+            const bool below = r > rk || (r == rk && l16 > lk);
+            const bool diag = r == rk && l16 == lk;
+            const double v = pick(r);
+            const double scaled = v * scal;
+            const double vrow = below ? scaled : (diag ? 1. : 0.);
+            const double anew = below ? scaled : (diag ? beta : v);
+            if (own) {
+              s_v[l16 + 16 * r] = vrow;
+              hssk_cstore(xs, (size_t)(2 * H + l16 + 16 * r), vrow);
             }
+#pragma unroll
+            for (int c = 0; c < CT; c++) a[c][r] = (own && c == cp) ? anew : a[c][r];
+          }
+          if (own) {
+            used |= 1u << cp;
+            if (l16 == 0) {
+              const double ab = fabs(beta);
+              const double r00 = (k == 0) ? ab : s_r00;
+              // dgeqp3tol.f:225-232 (0/0 is NaN -> false, then the absolute test decides)
+              const double stop = ((r00 != 0. && ab / r00 <= p.rtol) || ab <= p.atol) ? 1. : 0.;
+              s_msg[0] = tau; s_msg[1] = stop; s_msg[2] = ab;
+              hssk_cstore(xs, (size_t)(2 * H + 16 * RT), tau);
+              hssk_cstore(xs, (size_t)(2 * H + 16 * RT + 1), stop);
+              hssk_cstore(xs, (size_t)(2 * H + 16 * RT + 2), ab);
+            }
+          }
         }
       } else {
         // the other workgroups take it word by word
@@ -930,35 +960,56 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         else if (tid < 16 * RT + 3) s_msg[tid - 16 * RT] = idg_take(xs, (size_t)(2 * H + tid), err);
       }
       __syncthreads();
+#ifdef IDG_TIMING
+      long long tq3 = hssk_wallclock();
+#endif
       if (tid == 0) {
         if (k == 0) s_r00 = s_msg[2];
         s_perm[k] = pcol;
       }
-      if (s_msg[1] != 0.) { rank = k; done = true; __syncthreads(); break; }
+      if (s_msg[1] != 0.) { rank = k; __syncthreads(); break; }
       const double tau = s_msg[0];
       // ---- 3. apply H to this workgroup's unused columns and down-date their norms (dlaqp2)
-      double vr[RT];
-#pragma unroll
-      for (int r = 0; r < RT; r++) vr[r] = s_v[l16 + 16 * r];
-      // all dot products of the wave's slots first, their row sums stage by stage (independent chains in flight)
+      // all dot products of the wave's slots first, their row sums stage by stage (independent chains in flight).  The reflector
+      // is read from the LDS in both passes (a compiler fence between them): 2 RT registers less across the row sums, which at
+      // RT = 16 are the difference between a register tile and spills
       double dot[CT];
+      {
+        double d0[CT], d1[CT];
 #pragma unroll
-      for (int c = 0; c < CT; c++) {
-        double d0 = 0., d1 = 0.;
+        for (int c = 0; c < CT; c++) d0[c] = d1[c] = 0.;
 #pragma unroll
-        for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
-        if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
-        dot[c] = d0 + d1;
+        for (int r = 0; r + 1 < RT; r += 2) {
+          const double v0 = s_v[l16 + 16 * r], v1 = s_v[l16 + 16 * (r + 1)];
+#pragma unroll
+          for (int c = 0; c < CT; c++) { d0[c] += v0 * a[c][r]; d1[c] += v1 * a[c][r + 1]; }
+        }
+        if (RT & 1) {
+          const double v0 = s_v[l16 + 16 * (RT - 1)];
+#pragma unroll
+          for (int c = 0; c < CT; c++) d0[c] += v0 * a[c][RT - 1];
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++) dot[c] = d0[c] + d1[c];
       }
+      HSSK_COMPILER_FENCE();
       hssk_row_sum_n(dot);
       double newk[CT];
+      {
+        double f[CT];
 #pragma unroll
-      for (int c = 0; c < CT; c++) {
-        const int col = c0 + grp + NC * c;
-        const double f = (col < m && !((used >> c) & 1u)) ? dot[c] * tau : 0.;
+        for (int c = 0; c < CT; c++) {
+          const int col = c0 + grp + NC * c;
+          f[c] = (col < m && !((used >> c) & 1u)) ? dot[c] * tau : 0.;
+        }
 #pragma unroll
-        for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
-        newk[c] = hssk_shfl(a[c][rk], (lane & 48) | lk);  // R(k, col)
+        for (int r = 0; r < RT; r++) {
+          const double v = s_v[l16 + 16 * r];
+#pragma unroll
+          for (int c = 0; c < CT; c++) a[c][r] -= f[c] * v;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++) newk[c] = hssk_shfl(idg_pick<RT>(a[c], rk), (lane & 48) | lk);  // R(k, col)
       }
 #pragma unroll
       for (int c = 0; c < CT; c++) {
@@ -986,8 +1037,17 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         if (act && l16 == 0) s_vn1[lc] = newn1;
       }
       __syncthreads();   // (the step's LDS words are rewritten by the next one)
+#ifdef IDG_TIMING
+      if (tid == 0) {
+        const long long tq4 = hssk_wallclock();
+        tacc[0] += tq1 - tq0; tacc[1] += tq2 - tq1; tacc[2] += tq3 - tq2; tacc[3] += tq4 - tq3; tacc[4] += (h == owner);
+      }
+#endif
     }
   }
+#ifdef IDG_TIMING
+  if (tid == 0) for (int q = 0; q < 5; q++) p.work[8 * h + q] = (double)tacc[q];
+#endif
   // ---- pivoted column positions: skeleton columns first (pivot order), then the rest in index order (every workgroup works
   // the whole table out: the pivots of all steps are known to all)
   __syncthreads();
