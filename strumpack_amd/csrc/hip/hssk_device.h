@@ -153,6 +153,8 @@ __device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { (
 __device__ __forceinline__ void hssk_lds_add(double* p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// a slot counter in the LDS: returns the value before the increment
+__device__ __forceinline__ int hssk_lds_inc(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // a value known to be the same in every lane of the wave, moved to a scalar register (loads indexed by it become s_load)
 __device__ __forceinline__ int hssk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // compile-time only: memory operations are not moved across this point

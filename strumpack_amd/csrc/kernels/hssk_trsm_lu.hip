@@ -183,6 +183,12 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
   const int n = p.n, lda = p.lda;
   double* __restrict__ A = p.A;
   int info = 0;
+#ifdef LUW_TIMING
+  long long tacc[5] = {0, 0, 0, 0, 0}, tq = hssk_wallclock();
+#define LUW_STAMP(q) { __syncthreads(); const long long t_ = hssk_wallclock(); tacc[q] += t_ - tq; tq = t_; }
+#else
+#define LUW_STAMP(q)
+#endif
   for (int j0 = 0; j0 < n; j0 += LUW_NB) {
     const int nb = min(LUW_NB, n - j0), mp = n - j0, LP = mp | 1, jend = j0 + nb;
     double* s_P = s_dyn;                              // mp x nb panel, leading dimension LP
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       for (int i = tid; i < mp; i += LUW_T) s_P[i + j * LP] = hssk_gload(A, (size_t)(j0 + i) + (size_t)(j0 + j) * lda);
     for (int e = tid; e < mp; e += LUW_T) s_src[e] = e;
     __syncthreads();
+    LUW_STAMP(0)
     for (int k = 0; k < nb; k++) {
       // ---- pivot: first arg max_{i >= k} |P(i, k)|  (one row per thread: mp <= 512)
       double bv = -1.;
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       }
       __syncthreads();
     }
+    LUW_STAMP(1)
     // ---- L = P(:, k) / pivot below the diagonal; panel back to global memory
     for (int j = 0; j < nb; j++)
       for (int i = tid; i < mp; i += LUW_T) {
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       }
     }
     __syncthreads();
+    LUW_STAMP(2)
     // ---- trailing matrix, LUW_CH columns at a time
     constexpr int LU_ = LUW_NB + 1;
     for (int c0 = jend; c0 < n; c0 += LUW_CH) {
@@ -316,6 +325,192 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
 #pragma unroll
           for (int c = 0; c < 16; c++)
             if (cg + c < nc) hssk_gstore(A, (size_t)(jend + i) + (size_t)(c0 + cg + c) * lda, acc[c]);
+        }
+      }
+      __syncthreads();
+    }
+    LUW_STAMP(3)
+  }
+#ifdef LUW_TIMING
+  if (tid == 0 && blockIdx.x == 0) printf("getrf_wg n %d: us  panel load %.1f  steps %.1f  write-back + interchange %.1f  trailing %.1f\n", n, tacc[0] / 100., tacc[1] / 100., tacc[2] / 100., tacc[3] / 100.);
+#endif
+  if (tid == 0) *p.info = info;
+}
+
+// ---- second form of the one-workgroup LU (the diagonal tile of a BLR block step is ONE matrix: its LU is a serial chain on
+// one CU while the rest of the chip compresses tiles -- 1.48 ms for a 256 x 256 tile with getrf_wg_kernel: 0.61 ms in the 256
+// elimination steps (2.4 us each: three barriers around LDS read-modify-writes), 0.68 ms in the trailing updates (17 LDS reads
+// per 16 fmas), 0.21 ms in the panel's write-back and row interchanges (a serial scan of the permutation by one lane)).
+//  * a thread holds ITS ROW of the 32-column panel in registers for the panel's 32 steps; rows never move: a thread keeps the
+//    POSITION of its row in the interchanged order (dgetf2's swap of rows k and p exchanges two positions), the arg max breaks
+//    ties by position -- the same pivots as the swapping kernel --, the pivot row is broadcast through 32 LDS words and the
+//    rank-1 update is 31 - k fmas on registers: two barriers per step;
+//  * the rows go back to global memory (and into the LDS, for the trailing update) at their positions; the threads whose
+//    position changed -- at most 64 -- list themselves with an LDS counter, and the interchange of the other columns is the
+//    gather / barrier / scatter of getrf_wg_kernel over that list;
+//  * U12 = L11^{-1} A12 with a column per thread, for all trailing columns at once when n <= 256 (LDS: 66 KB panel + 59 KB
+//    U12), 64 at a time above; A22 -= L21 U12 on the matrix cores: a wave owns 16-row blocks of A22, the lanes hold the
+//    TRANSPOSED 16 x 16 accumulator (D = (-U12^T) L21^T: a lane's four entries lie in one row of A22 per register and the 16
+//    lanes of a quarter-wave in 16 consecutive rows: 128-byte segments of the column-major tile).
+// Same pivoting rule and results as getrf_wg_kernel up to the order of the updates.  HSSK_LU_WG_V1=1 selects the first form.
+constexpr int LUW_CHW_SMALL = 224;   // trailing columns per pass, n <= 256 (all of them)
+template <int T>
+__global__ __launch_bounds__(T) void getrf_wg2_kernel(const hssk_lu_desc* __restrict__ descs, int chw) {
+  HSSK_DYN_SHARED(double, s_dyn);
+  HSSK_SHARED double s_val[T / 64];
+  HSSK_SHARED int s_idx[T / 64];
+  HSSK_SHARED double s_row[LUW_NB];
+  HSSK_SHARED int s_affd[2 * LUW_NB];   // positions that receive another row ...
+  HSSK_SHARED int s_affs[2 * LUW_NB];   // ... and the position that row had before the panel
+  HSSK_SHARED int s_naff;
+  constexpr int NW = T / 64, LU_ = LUW_NB + 1;
+  const hssk_lu_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n, lda = p.lda;
+  double* __restrict__ A = p.A;
+  int info = 0;
+  for (int j0 = 0; j0 < n; j0 += LUW_NB) {
+    const int nb = min(LUW_NB, n - j0), mp = n - j0, LP = mp | 1, jend = j0 + nb;
+    double* s_P = s_dyn;                              // mp x nb panel in position order, leading dimension LP
+    double* s_U = s_dyn + (size_t)LP * LUW_NB;        // nb x chw block of U12, leading dimension LUW_NB + 1
+    const bool has = tid < mp;
+    double a[LUW_NB];
+#pragma unroll
+    for (int j = 0; j < LUW_NB; j++) a[j] = (has && j < nb) ? hssk_gload(A, (size_t)(j0 + tid) + (size_t)(j0 + j) * lda) : 0.;
+    int pos = tid;
+    if (tid == 0) s_naff = 0;
+#pragma unroll
+    for (int k = 0; k < LUW_NB; k++) {
+      if (k < nb) {
+        // ---- pivot: first arg max over the positions >= k
+        double bv = (has && pos >= k) ? fabs(a[k]) : -1.;
+        int bi = (has && pos >= k) ? pos : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const double ov = hssk_shfl_xor(bv, o);
+          const int oi = hssk_shfl_xor(bi, o);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+        __syncthreads();
+        double v = s_val[0];
+        int pp = s_idx[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++)
+          if (s_val[w] > v || (s_val[w] == v && s_idx[w] < pp)) { v = s_val[w]; pp = s_idx[w]; }
+        // ---- the rows at positions k and pp exchange positions; the pivot row goes out through the LDS
+        const bool ispiv = has && pos == pp;
+        if (has && pos == k) pos = pp;
+        else if (ispiv) pos = k;
+        if (ispiv) {
+#pragma unroll
+          for (int j = k; j < LUW_NB; j++) s_row[j] = a[j];
+          p.piv[j0 + k] = j0 + pp;
+        }
+        __syncthreads();
+        const double akk = s_row[k];
+        if (akk == 0.) {
+          if (!info) info = j0 + k + 1;
+        } else if (has && pos > k) {
+          const double l = a[k] * (1. / akk);
+          a[k] = l;
+#pragma unroll
+          for (int j = k + 1; j < LUW_NB; j++) a[j] -= l * s_row[j];
+        }
+      }
+    }
+    // ---- rows to their positions: LDS (trailing update) and global memory; who moved
+    if (has) {
+#pragma unroll
+      for (int j = 0; j < LUW_NB; j++)
+        if (j < nb) {
+          s_P[pos + j * LP] = a[j];
+          hssk_gstore(A, (size_t)(j0 + pos) + (size_t)(j0 + j) * lda, a[j]);
+        }
+      if (pos != tid) {
+        const int slot = hssk_lds_inc(&s_naff);
+        s_affd[slot] = pos;
+        s_affs[slot] = tid;
+      }
+    }
+    __syncthreads();
+    // ---- the panel's row interchanges on the columns outside it: gather into registers, barrier, scatter
+    {
+      const int na = s_naff, nco = n - nb;
+      constexpr int NMAXT = T == 256 ? 256 : LUW_NMAX;
+      constexpr int PER = (2 * LUW_NB * (NMAXT - 1) + T - 1) / T;
+      double val[PER];
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const int e = tid + q * T;
+        val[q] = 0.;
+        if (e < na * nco) {
+          const int ai = e % na, c = e / na, col = c < j0 ? c : c + nb;
+          val[q] = hssk_gload(A, (size_t)(j0 + s_affs[ai]) + (size_t)col * lda);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const int e = tid + q * T;
+        if (e < na * nco) {
+          const int ai = e % na, c = e / na, col = c < j0 ? c : c + nb;
+          hssk_gstore(A, (size_t)(j0 + s_affd[ai]) + (size_t)col * lda, val[q]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- trailing matrix, chw columns at a time
+    const int rws = mp - nb;
+    for (int c0 = jend; c0 < n; c0 += chw) {
+      const int nc = min(chw, n - c0);
+      for (int e = tid; e < nb * nc; e += T) s_U[(e % nb) + (e / nb) * LU_] = hssk_gload(A, (size_t)(j0 + e % nb) + (size_t)(c0 + e / nb) * lda);
+      __syncthreads();
+      for (int c = tid; c < nc; c += T) {   // U12(:, c) = L11^{-1} A12(:, c): the column in registers, L11 read as broadcasts
+        double u[LUW_NB];
+#pragma unroll
+        for (int i = 0; i < LUW_NB; i++) u[i] = i < nb ? s_U[i + c * LU_] : 0.;
+#pragma unroll
+        for (int l = 0; l < LUW_NB; l++) {
+          if (l < nb) {
+#pragma unroll
+            for (int i = l + 1; i < LUW_NB; i++)
+              if (i < nb) u[i] -= s_P[i + l * LP] * u[l];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < LUW_NB; i++)
+          if (i < nb) { s_U[i + c * LU_] = u[i]; hssk_gstore(A, (size_t)(j0 + i) + (size_t)(c0 + c) * lda, u[i]); }
+      }
+      __syncthreads();
+      // A22(:, c0 .. c0+nc) -= L21 U12 on the matrix cores (transposed accumulator, see above)
+      if (rws > 0) {
+        const int y = lane & 15, kq = lane >> 4;
+        const int nrt = (rws + 15) / 16, nct = (nc + 15) / 16;
+        for (int ti = wave; ti < nrt; ti += NW) {
+          const int row = ti * 16 + y, rowc = min(row, rws - 1);
+          double bl[LUW_NB / 4];
+#pragma unroll
+          for (int kk = 0; kk < LUW_NB / 4; kk++) bl[kk] = kq + 4 * kk < nb ? s_P[(nb + rowc) + (kq + 4 * kk) * LP] : 0.;
+          for (int tj = 0; tj < nct; tj++) {
+            const int xc = min(tj * 16 + y, nc - 1);
+            hssk_d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int col = tj * 16 + kq + 4 * r;
+              acc[r] = (row < rws && col < nc) ? hssk_gload(A, (size_t)(jend + row) + (size_t)(c0 + col) * lda) : 0.;
+            }
+#pragma unroll
+            for (int kk = 0; kk < LUW_NB / 4; kk++) {
+              const double au = kq + 4 * kk < nb ? -s_U[(kq + 4 * kk) + xc * LU_] : 0.;
+              acc = hssk_mfma_f64_16x16x4(au, bl[kk], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int col = tj * 16 + kq + 4 * r;
+              if (row < rws && col < nc) hssk_gstore(A, (size_t)(jend + row) + (size_t)(c0 + col) * lda, acc[r]);
+            }
+          }
         }
       }
       __syncthreads();
@@ -558,8 +753,19 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   int nmax = 0;
   for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
   static const bool no_wg = [] { const char* e = std::getenv("HSSK_LU_NO_WG"); return e && e[0] == '1'; }();   // (A/B: the first kernel)
+  static const bool wg_v1 = [] { const char* e = std::getenv("HSSK_LU_WG_V1"); return e && e[0] == '1'; }();   // (A/B: the first one-workgroup form)
   if (nmax <= LU_LDS_N) {
     HSSK_LAUNCH(getrf_lds_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  } else if (nmax <= LUW_NMAX && !no_wg && !wg_v1) {
+    const int chw = nmax <= 256 ? LUW_CHW_SMALL : LUW_CH;
+    const size_t shmem = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * chw);
+    if (nmax <= 256) {
+      hssk_rt::allow_dynamic_lds(getrf_wg2_kernel<256>, shmem);
+      HSSK_LAUNCH(getrf_wg2_kernel<256>, dim3((unsigned)count), dim3(256), shmem, ctx->stream, dd, chw);
+    } else {
+      hssk_rt::allow_dynamic_lds(getrf_wg2_kernel<512>, shmem);
+      HSSK_LAUNCH(getrf_wg2_kernel<512>, dim3((unsigned)count), dim3(512), shmem, ctx->stream, dd, chw);
+    }
   } else if (nmax <= LUW_NMAX && !no_wg) {
     const size_t shmem = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * LUW_CH);
     hssk_rt::allow_dynamic_lds(getrf_wg_kernel, shmem);

@@ -112,6 +112,7 @@ inline double hssk_gload(const double* p, size_t off) { return p[off]; }
 inline hssk_d2 hssk_gload2(const double* p, size_t off) { return *reinterpret_cast<const hssk_d2*>(p + off); }
 inline void hssk_gstore(double* p, size_t off, double v) { p[off] = v; }
 inline void hssk_lds_add(double* p, double v) { *p += v; }   // fibers are cooperative: a plain update is atomic
+inline int hssk_lds_inc(int* p) { return (*p)++; }
 inline int hssk_uniform(int v) { return v; }
 // compile-time only: memory operations are not moved across this point
 #define HSSK_COMPILER_FENCE() __asm__ volatile("" ::: "memory")

@@ -397,6 +397,29 @@ def case_trsm_lu(hk, seed=9, big_lu=(600, 3), extra_lu=()):
         assert np.array_equal(dpiv.get(), piv)
         assert np.allclose(dA.get(), lu, atol=1e-9 if n > 128 else 1e-11)
         assert np.allclose(dB.get(), np.linalg.solve(A, B), atol=1e-8 if n > 128 else 1e-9)
+    # equal pivot candidates (small integer entries: the eliminations stay exact for a while, ties are real) -- the first one in
+    # the interchanged order wins, as in dgetf2 --, and a matrix with a zero column (info = its index + 1, factors as LAPACK's)
+    for n in [140, 256] + [e[0] for e in extra_lu]:
+        A = r.integers(1, 3, size=(n, n)).astype(float) * r.choice([-1.0, 1.0], size=(n, n))
+        dA, dpiv, dinfo = hk.array(A), hk.empty((n,), np.int32), hk.empty((1,), np.int32)
+        hk.batch("hssk_getrf_vbatched", [K.LuDesc(dA.ptr, n, n, dpiv.ptr, dinfo.ptr)])
+        hk.sync()
+        lu, piv = sla.lu_factor(A)
+        assert np.array_equal(dpiv.get(), piv), f"pivots with ties, n={n}"
+        assert np.allclose(dA.get(), lu, atol=1e-9 * np.abs(lu).max())
+    for n in [150]:
+        A = r.standard_normal((n, n))
+        A[:, 40] = 0.0
+        dA, dpiv, dinfo = hk.array(A), hk.empty((n,), np.int32), hk.empty((1,), np.int32)
+        hk.batch("hssk_getrf_vbatched", [K.LuDesc(dA.ptr, n, n, dpiv.ptr, dinfo.ptr)])
+        hk.sync()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lu, piv = sla.lu_factor(A)
+        assert dinfo.get()[0] == 41
+        assert np.array_equal(dpiv.get(), piv)
+        assert np.allclose(dA.get(), lu, atol=1e-9)
 
 
 # ---- kernel-matrix front end -------------------------------------------------------------------

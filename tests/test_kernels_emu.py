@@ -91,9 +91,11 @@ def test_id(hk):
     KC.case_id(hk, [(256, 256, 1e-6, 1e-12, 1000, 30), (200, 250, 1e-8, 1e-13, 1000, 100), (256, 256, 1e-6, 1e-12, 129, None)], seed=15)
     KC.case_id(hk, [(192, 391, 1e-6, 1e-12, 1000, 40), (150, 500, 1e-6, 1e-12, 12, 60)], seed=16)
     KC.case_id(hk, [(256, 240, 1e-6, 1e-12, 1000, 20), (140, 256, 1e-6, 1e-12, 1000, 5)], seed=17, deferred=True)
+    KC.case_id(hk, [(250, 400, 1e-6, 1e-12, 1000, 90), (130, 300, 1e-6, 1e-12, 40, 60)], seed=18)        # 256 rows, four workgroups
+    KC.case_id(hk, [(160, 250, 1e-6, 1e-12, 1000, 45), (129, 129, 1e-6, 1e-12, 1000, None)], seed=19)   # 192 rows, two workgroups
     import os
     if (os.cpu_count() or 1) >= 4 and "HSSK_ID_NO_GROUP" not in os.environ and "HSSK_EMU_THREADS" not in os.environ:
-        assert hk.lib.hssk_id_group_launches() == g0 + 3
+        assert hk.lib.hssk_id_group_launches() == g0 + 5
 
 
 def test_qr(hk):
@@ -113,6 +115,7 @@ def test_formq_from_stored_reflectors(hk):
 
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)
+    KC.case_trsm_lu(hk, seed=11, big_lu=(530, 2), extra_lu=[(300, 2), (391, 1), (512, 1)])   # 512-lane form: 64 trailing columns per pass
 
 
 def test_kernel_matrix_entries(hk):

@@ -95,9 +95,12 @@ def test_id(hk):
     KC.case_id(hk, [(256, 256, 1e-4, 1e-12, 129, 13)] * 150 + [(256, 256, 1e-4, 1e-12, 129, 127), (200, 250, 1e-6, 1e-12, 129, 70), (256, 256, 1e-6, 1e-12, 129, None)], seed=26)
     KC.case_id(hk, [(192, 391, 1e-4, 1e-10, 50000, 41)] * 100 + [(150, 500, 1e-6, 1e-12, 12, 60)], seed=27)
     KC.case_id(hk, [(256, 240, 1e-6, 1e-12, 1000, 20), (140, 256, 1e-6, 1e-12, 1000, 5)] * 3, seed=28, deferred=True)
+    # the other two instantiations: 256 rows x 512 columns on four workgroups, 192 rows x 256 columns on two
+    KC.case_id(hk, [(250, 400, 1e-6, 1e-12, 1000, 90), (256, 512, 1e-8, 1e-13, 1000, 150), (130, 300, 1e-6, 1e-12, 40, 60)] * 4, seed=29)
+    KC.case_id(hk, [(160, 250, 1e-6, 1e-12, 1000, 45), (192, 256, 1e-9, 1e-14, 1000, 100), (129, 129, 1e-6, 1e-12, 1000, None)] * 4, seed=30)
     import os
     if "HSSK_ID_NO_GROUP" not in os.environ:
-        assert hk.lib.hssk_id_group_launches() >= g0 + 3
+        assert hk.lib.hssk_id_group_launches() >= g0 + 5
 
 
 def test_qr(hk):
