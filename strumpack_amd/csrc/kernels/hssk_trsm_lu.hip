@@ -642,6 +642,82 @@ int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count
   HSSK_API_END
 }
 
+// ---- the blocked solve of trsm_blocked below as ONE launch (triangles of up to 512 rows): a workgroup takes 16 right-hand
+// sides, keeps their n x 16 block in the LDS for the whole solve and walks the ceil(n / 64) block steps itself -- X_b =
+// inv(op(T)_bb) B_b (the inverted diagonal blocks of hssk_trtri_diag_vbatched), then the remaining block rows -= op(T)(rest, b)
+// X_b, both on the matrix cores with the right-hand sides as the 16 columns of the tile.  The multi-launch form spends three
+// launches per block step (copy of B_b, two batched GEMMs): 13 launches of 5 - 15 us for a 256 x 256 tile whatever the number
+// of right-hand sides -- 0.43 ms of a BLR block step's 2.6 ms, and 0.11 ms per tile of a front's forward / backward solve
+// with one right-hand side.  T is read from L2 (512 KB at most, shared by the workgroups of a launch).
+struct TfWork {
+  int prob, group;
+  size_t inv_off;   // the triangle's inverted diagonal blocks in the aux buffer (doubles)
+};
+constexpr int TF_T = 256, TF_NB = 64, TF_NMAX = 512;
+__global__ __launch_bounds__(TF_T) void trsm_fused_kernel(const hssk_trsm_desc* __restrict__ descs, const TfWork* __restrict__ work,
+                                                          const double* __restrict__ aux) {
+  HSSK_DYN_SHARED(double, s_x);   // (round-up of n to 64) x 16 right-hand sides, leading dimension ldx
+  const TfWork wk = work[blockIdx.x];
+  const hssk_trsm_desc p = descs[wk.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int y = lane & 15, kq = lane >> 4;
+  const int n = p.n, ldt = p.ldt, nblk = (n + TF_NB - 1) / TF_NB, npad = nblk * TF_NB, ldx = npad + 1;
+  const double* __restrict__ T = p.T;
+  const int c0 = wk.group * 16, nc = min(16, p.nrhs - c0);
+  for (int e = tid; e < npad * 16; e += TF_T) {
+    const int i = e % npad, c = e / npad;
+    s_x[i + c * ldx] = (i < n && c < nc) ? hssk_gload(p.B, (size_t)i + (size_t)(c0 + c) * p.ldb) : 0.;
+  }
+  __syncthreads();
+  const bool fwd = p.lower || p.transT;   // the effective triangle of op(T): lower (blocks first to last) or upper (last to first)
+  for (int s = 0; s < nblk; s++) {
+    const int b = fwd ? s : nblk - 1 - s, b0 = b * TF_NB;
+    const double* __restrict__ Ti = aux + wk.inv_off + (size_t)b * TF_NB * TF_NB;   // plain inverse of T_bb, zero padded, ld 64
+    // ---- X_b = inv(op(T)_bb) B_b: a wave per 16 rows of the block
+    {
+      double av[TF_NB / 4];
+#pragma unroll
+      for (int kk = 0; kk < TF_NB / 4; kk++) {
+        const int i = wave * 16 + y, k = kq + 4 * kk;
+        av[kk] = hssk_gload(Ti, p.transT ? (size_t)k + (size_t)i * TF_NB : (size_t)i + (size_t)k * TF_NB);
+      }
+      hssk_d4 acc = {0., 0., 0., 0.};
+#pragma unroll
+      for (int kk = 0; kk < TF_NB / 4; kk++) acc = hssk_mfma_f64_16x16x4(av[kk], s_x[(b0 + kq + 4 * kk) + y * ldx], acc);
+      __syncthreads();   // (every wave has read all of B_b)
+#pragma unroll
+      for (int r = 0; r < 4; r++) s_x[(b0 + wave * 16 + kq + 4 * r) + y * ldx] = acc[r];
+      __syncthreads();
+    }
+    // ---- the block rows still to come -= op(T)(rows, b) X_b: 16-row tiles over the waves
+    const int r_lo = fwd ? b0 + TF_NB : 0, r_hi = fwd ? n : b0;   // rows [r_lo, r_hi)
+    const int ntile = r_hi > r_lo ? (r_hi - r_lo + 15) / 16 : 0;
+    for (int t = wave; t < ntile; t += TF_T / 64) {
+      const int row = r_lo + t * 16 + y, rowc = min(row, n - 1);
+      double av[TF_NB / 4];
+#pragma unroll
+      for (int kk = 0; kk < TF_NB / 4; kk++) {
+        const int k = b0 + kq + 4 * kk, kc = min(k, n - 1);
+        // op(T)(row, k): lower / upper, not transposed: T(row, k); transposed upper: T(k, row)
+        const double v = hssk_gload(T, p.transT ? (size_t)kc + (size_t)rowc * ldt : (size_t)rowc + (size_t)kc * ldt);
+        av[kk] = (k < n && row < n) ? -v : 0.;
+      }
+      hssk_d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = s_x[(r_lo + t * 16 + kq + 4 * r) + y * ldx];
+#pragma unroll
+      for (int kk = 0; kk < TF_NB / 4; kk++) acc = hssk_mfma_f64_16x16x4(av[kk], s_x[(b0 + kq + 4 * kk) + y * ldx], acc);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s_x[(r_lo + t * 16 + kq + 4 * r) + y * ldx] = acc[r];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < n * nc; e += TF_T) {
+    const int i = e % n, c = e / n;
+    hssk_gstore(p.B, (size_t)i + (size_t)(c0 + c) * p.ldb, s_x[i + c * ldx]);
+  }
+}
+
 // Large triangles with many right-hand sides (the triangular solves of a BLR block step: a 256 x 256 diagonal tile against
 // the few hundred columns of a block row's U factors, or against every V factor of a block column): the substitution kernel
 // below walks n dependent steps per group of four right-hand sides -- 0.29 ms per call for n = 256.  Blocked instead, as in
@@ -676,8 +752,26 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
   std::vector<hssk_trtri_desc> ti;
   for (auto& t : tris) ti.push_back(hssk_trtri_desc{t.T, aux + t.off, t.n, t.ldt, t.lower ? 2 : 1});
   if (hssk_trtri_diag_vbatched(ctx, ti.data(), (int)ti.size())) throw std::runtime_error(hssk_last_error());
-  int nblk_max = 0;
-  for (auto& t : tris) nblk_max = std::max(nblk_max, (t.n + NB - 1) / NB);
+  int nblk_max = 0, n_max = 0;
+  for (auto& t : tris) { nblk_max = std::max(nblk_max, (t.n + NB - 1) / NB); n_max = std::max(n_max, t.n); }
+  static const bool no_fused = [] { const char* e = std::getenv("HSSK_TRSM_NO_FUSED"); return e && e[0] == '1'; }();   // (A/B: one launch per block step and stage)
+  if (n_max <= TF_NMAX && !no_fused) {
+    // all block steps in one launch: a workgroup per 16 right-hand sides
+    std::vector<hssk_trsm_desc> sel;
+    std::vector<TfWork> work;
+    for (int i = 0; i < count; i++) {
+      if (tri_of[i] < 0) continue;
+      for (int g = 0; g * 16 < descs[i].nrhs; g++) work.push_back(TfWork{(int)sel.size(), g, tris[tri_of[i]].off});
+      sel.push_back(descs[i]);
+    }
+    auto* dd = (const hssk_trsm_desc*)ctx->stage(sel.data(), sizeof(hssk_trsm_desc) * sel.size());
+    auto* dw = (const TfWork*)ctx->stage(work.data(), sizeof(TfWork) * work.size());
+    const size_t shmem = sizeof(double) * 16 * (size_t)(nblk_max * NB + 1);
+    hssk_rt::allow_dynamic_lds(trsm_fused_kernel, shmem);
+    HSSK_LAUNCH(trsm_fused_kernel, dim3((unsigned)work.size()), dim3(TF_T), shmem, ctx->stream, dd, dw, (const double*)aux);
+    for (int i = 0; i < count; i++) done[i] = tri_of[i] >= 0;
+    return true;
+  }
   std::vector<hssk_rowgather_desc> cp;
   std::vector<hssk_gemm_desc> g1, g2;
   for (int s = 0; s < nblk_max; s++) {

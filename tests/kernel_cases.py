@@ -366,7 +366,10 @@ def case_trsm_lu(hk, seed=9, big_lu=(600, 3), extra_lu=()):
                                           (130, 1, 0, 1, 0),
                                           # blocked form (inverted 64 x 64 diagonal blocks + batched GEMMs): unit lower, upper,
                                           # transposed upper; ragged last block; a form that stays with the substitution kernel
-                                          (256, 40, 1, 0, 1), (256, 33, 0, 0, 0), (200, 24, 0, 1, 0), (150, 16, 1, 1, 0), (129, 8, 0, 0, 0)]:
+                                          (256, 40, 1, 0, 1), (256, 33, 0, 0, 0), (200, 24, 0, 1, 0), (150, 16, 1, 1, 0), (129, 8, 0, 0, 0),
+                                          # (up to 512 rows all block steps are one launch, a workgroup per 16 right-hand sides)
+                                          (512, 17, 1, 0, 1), (300, 1, 0, 0, 0), (450, 5, 0, 1, 0), (130, 1, 1, 0, 1),
+                                          (640, 20, 0, 0, 0)]:
         T = r.standard_normal((n, n)) + n * np.eye(n)
         if unit and n > 64:   # a unit triangle as the solves meet it: the L of an LU with partial pivoting (|L_ij| <= 1)
             T = sla.lu_factor(r.standard_normal((n, n)))[0]
@@ -397,16 +400,24 @@ def case_trsm_lu(hk, seed=9, big_lu=(600, 3), extra_lu=()):
         assert np.array_equal(dpiv.get(), piv)
         assert np.allclose(dA.get(), lu, atol=1e-9 if n > 128 else 1e-11)
         assert np.allclose(dB.get(), np.linalg.solve(A, B), atol=1e-8 if n > 128 else 1e-9)
-    # equal pivot candidates (small integer entries: the eliminations stay exact for a while, ties are real) -- the first one in
-    # the interchanged order wins, as in dgetf2 --, and a matrix with a zero column (info = its index + 1, factors as LAPACK's)
+    # equal pivot candidates: entries +-1, +-2 -- the first two elimination steps are exact in floating point (multipliers 1/2
+    # and 1, then multiples of 1/2), so their ties are real and the first candidate in the interchanged order must win, as in
+    # dgetf2; later steps round (ties there are resolved by the order of the updates, LAPACK's own differs between versions):
+    # the factorization is checked as one -- P A = L U, |L| <= 1
     for n in [140, 256] + [e[0] for e in extra_lu]:
         A = r.integers(1, 3, size=(n, n)).astype(float) * r.choice([-1.0, 1.0], size=(n, n))
         dA, dpiv, dinfo = hk.array(A), hk.empty((n,), np.int32), hk.empty((1,), np.int32)
         hk.batch("hssk_getrf_vbatched", [K.LuDesc(dA.ptr, n, n, dpiv.ptr, dinfo.ptr)])
         hk.sync()
         lu, piv = sla.lu_factor(A)
-        assert np.array_equal(dpiv.get(), piv), f"pivots with ties, n={n}"
-        assert np.allclose(dA.get(), lu, atol=1e-9 * np.abs(lu).max())
+        got, gp = dA.get(), dpiv.get()
+        assert np.array_equal(gp[:2], piv[:2]), f"pivots with ties, n={n}"
+        PA = A.copy()
+        for i, pi in enumerate(gp):
+            PA[[i, pi]] = PA[[pi, i]]
+        Lf, Uf = np.tril(got, -1) + np.eye(n), np.triu(got)
+        assert np.abs(Lf).max() <= 1.0 + 1e-14
+        assert np.allclose(Lf @ Uf, PA, atol=1e-10 * np.abs(Uf).max()), f"P A = L U, n={n}"
     for n in [150]:
         A = r.standard_normal((n, n))
         A[:, 40] = 0.0
