@@ -398,6 +398,9 @@ typedef struct hssk_trsm_desc {
   double* B;
   int n, nrhs, ldt, ldb;
   int lower, transT, unit;
+  const double* Tinv;   /* optional (may be NULL): the inverted 64 x 64 diagonal blocks of T as hssk_trtri_diag_vbatched leaves them
+                         * (mode 2 for a unit lower T, mode 1 for an upper T), for callers that solve with the same triangle
+                         * more than once -- the blocked forms (n >= 128) then skip the inversion */
 } hssk_trsm_desc;
 int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count);
 /* In-place LU with partial pivoting (DenseMatrix::LU, getrf, dense/DenseMatrix.cpp:564-589);

@@ -333,6 +333,8 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   std::vector<char> adm_nd;   // the diagonal is never compressed
   if (adm) adm_nd.assign(adm, adm + (size_t)rb * rb); else adm_nd.assign((size_t)rb * rb, 1);
   for (int i = 0; i < rb; i++) adm_nd[(size_t)i + (size_t)i * rb] = 0;
+  invL_.assign(rb, nullptr);
+  invU_.assign(rb, nullptr);
   for (int i = 0; i < nsteps; i++) {
     tmp_->rewind();
     const int mi = tm(i);
@@ -343,6 +345,16 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
     if (lctx != ctx_) ck(hssk_stream_wait(lctx, ctx_));
     watch(0, true);
     if (mi) ck(hssk_getrf_vbatched(lctx, &lu, 1));
+    if (mi >= 128) {
+      // the inverted diagonal blocks of the tile's L and U, once: this step's two triangular solves and every later solve
+      // phase with the tile take them from here (hssk_trsm_desc::Tinv) instead of inverting per call
+      const size_t per = (size_t)((mi + 63) / 64) * 64 * 64;
+      double* inv = store_->dbl(2 * per);
+      hssk_trtri_desc tt[2] = {{blk(i, i), inv, mi, (int)ld_, 2}, {blk(i, i), inv + per, mi, (int)ld_, 1}};
+      ck(hssk_trtri_diag_vbatched(lctx, tt, 2));
+      invL_[i] = inv;
+      invU_[i] = inv + per;
+    }
     watch(0, false);
     f_total += (2.0 / 3.0) * mi * (double)mi * mi;
     if (i + 1 == rb) { if (lctx != ctx_) ck(hssk_stream_wait(ctx_, lctx)); break; }
@@ -374,14 +386,14 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
     if (R > 0 && mi > 0) {
       hssk_lusolve_desc sw{blk(i, i), dpiv_ + roff_[i], Ucat, mi, R, (int)ld_, mi};
       ck(hssk_laswp_vbatched(ctx_, &sw, 1));
-      hssk_trsm_desc tl{blk(i, i), Ucat, mi, R, (int)ld_, mi, 1, 0, 1};
+      hssk_trsm_desc tl{blk(i, i), Ucat, mi, R, (int)ld_, mi, 1, 0, 1, invL_[i]};
       ck(hssk_trsm_vbatched(ctx_, &tl, 1));
     }
     {
       std::vector<hssk_trsm_desc> tu;
       for (int k = i + 1; k < rb; k++) {
         Tile& t = tile(k, i);
-        if (t.r > 0 && mi > 0) tu.push_back(hssk_trsm_desc{blk(i, i), t.V, mi, t.r, (int)ld_, mi, 0, 1, 0});
+        if (t.r > 0 && mi > 0) tu.push_back(hssk_trsm_desc{blk(i, i), t.V, mi, t.r, (int)ld_, mi, 0, 1, 0, invU_[i]});
       }
       if (!tu.empty()) ck(hssk_trsm_vbatched(ctx_, tu.data(), (int)tu.size()));
       for (auto& d : tu) f_total += (double)d.n * d.n * d.nrhs;
@@ -503,7 +515,7 @@ void DeviceBLR::fwd(double* X, int nrhs, double* t, int Rmax) const {
     double* Xi = X + roff_[i];
     hssk_lusolve_desc sw{blk(i, i), dpiv_ + roff_[i], Xi, mi, nrhs, (int)ld_, n_};
     ck(hssk_laswp_vbatched(ctx_, &sw, 1));
-    hssk_trsm_desc tl{blk(i, i), Xi, mi, nrhs, (int)ld_, n_, 1, 0, 1};
+    hssk_trsm_desc tl{blk(i, i), Xi, mi, nrhs, (int)ld_, n_, 1, 0, 1, invL_[i]};
     ck(hssk_trsm_vbatched(ctx_, &tl, 1));
     std::vector<hssk_gemm_desc> g1, g2;
     int off = 0;
@@ -542,7 +554,7 @@ void DeviceBLR::bwd(double* X, int nrhs, double* t, int Rmax) const {
       hssk_gemm_desc g2{Ucat, t, Xi, mi, nrhs, R, mi, Rmax, n_, 0, 0, -1.0, 1.0};
       ck(hssk_gemm_vbatched(ctx_, &g2, 1));
     }
-    hssk_trsm_desc tu{blk(i, i), Xi, mi, nrhs, (int)ld_, n_, 0, 0, 0};
+    hssk_trsm_desc tu{blk(i, i), Xi, mi, nrhs, (int)ld_, n_, 0, 0, 0, invU_[i]};
     ck(hssk_trsm_vbatched(ctx_, &tu, 1));
   }
 }

@@ -133,6 +133,7 @@ class DeviceBLR {
   double* dA_ = nullptr;   // n x n working array / diagonal tiles
   long long ld_ = 0;
   int* dpiv_ = nullptr;    // pivots of the diagonal tiles (0-based, local), rows() ints
+  std::vector<const double*> invL_, invU_;   // per block step: inverted 64 x 64 diagonal blocks of the tile's L and U (tiles of >= 128 rows; else null)
   std::vector<Tile> tiles_;
   std::unique_ptr<Arena2> store_, tmp_;
   bool compressed_ = false, factored_ = false;

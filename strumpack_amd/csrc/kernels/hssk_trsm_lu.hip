@@ -651,11 +651,10 @@ int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count
 // with one right-hand side.  T is read from L2 (512 KB at most, shared by the workgroups of a launch).
 struct TfWork {
   int prob, group;
-  size_t inv_off;   // the triangle's inverted diagonal blocks in the aux buffer (doubles)
+  const double* inv;   // the triangle's inverted diagonal blocks (the call's aux buffer, or the caller's)
 };
 constexpr int TF_T = 256, TF_NB = 64, TF_NMAX = 512;
-__global__ __launch_bounds__(TF_T) void trsm_fused_kernel(const hssk_trsm_desc* __restrict__ descs, const TfWork* __restrict__ work,
-                                                          const double* __restrict__ aux) {
+__global__ __launch_bounds__(TF_T) void trsm_fused_kernel(const hssk_trsm_desc* __restrict__ descs, const TfWork* __restrict__ work) {
   HSSK_DYN_SHARED(double, s_x);   // (round-up of n to 64) x 16 right-hand sides, leading dimension ldx
   const TfWork wk = work[blockIdx.x];
   const hssk_trsm_desc p = descs[wk.prob];
@@ -672,7 +671,7 @@ __global__ __launch_bounds__(TF_T) void trsm_fused_kernel(const hssk_trsm_desc* 
   const bool fwd = p.lower || p.transT;   // the effective triangle of op(T): lower (blocks first to last) or upper (last to first)
   for (int s = 0; s < nblk; s++) {
     const int b = fwd ? s : nblk - 1 - s, b0 = b * TF_NB;
-    const double* __restrict__ Ti = aux + wk.inv_off + (size_t)b * TF_NB * TF_NB;   // plain inverse of T_bb, zero padded, ld 64
+    const double* __restrict__ Ti = wk.inv + (size_t)b * TF_NB * TF_NB;   // plain inverse of T_bb, zero padded, ld 64
     // ---- X_b = inv(op(T)_bb) B_b: a wave per 16 rows of the block
     {
       double av[TF_NB / 4];
@@ -727,7 +726,7 @@ __global__ __launch_bounds__(TF_T) void trsm_fused_kernel(const hssk_trsm_desc* 
 // everything else stays with the substitution kernel.
 static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, std::vector<char>& done) {
   constexpr int NB = 64;
-  struct Tri { const double* T; int n, ldt, lower, transT, unit; size_t off; };
+  struct Tri { const double* T; int n, ldt, lower, transT, unit; size_t off; const double* given; const double* inv; };
   std::vector<Tri> tris;            // distinct triangles (a block column's V factors all meet the same diagonal tile)
   std::vector<int> tri_of(count, -1);
   size_t inv_doubles = 0, tmp_doubles = 0;
@@ -737,11 +736,11 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
     if (!form || d.n < 2 * NB || d.nrhs < 1) continue;   // (a 128-step substitution costs more than the block's inverse, whatever the number of right-hand sides)
     int t = -1;
     for (size_t q = 0; q < tris.size(); q++)
-      if (tris[q].T == d.T && tris[q].n == d.n && tris[q].ldt == d.ldt && tris[q].lower == d.lower && tris[q].transT == d.transT && tris[q].unit == d.unit) { t = (int)q; break; }
+      if (tris[q].T == d.T && tris[q].n == d.n && tris[q].ldt == d.ldt && tris[q].lower == d.lower && tris[q].transT == d.transT && tris[q].unit == d.unit && tris[q].given == d.Tinv) { t = (int)q; break; }
     if (t < 0) {
       t = (int)tris.size();
-      tris.push_back(Tri{d.T, d.n, d.ldt, d.lower, d.transT, d.unit, inv_doubles});
-      inv_doubles += (size_t)((d.n + NB - 1) / NB) * NB * NB;
+      tris.push_back(Tri{d.T, d.n, d.ldt, d.lower, d.transT, d.unit, inv_doubles, d.Tinv, nullptr});
+      if (!d.Tinv) inv_doubles += (size_t)((d.n + NB - 1) / NB) * NB * NB;
     }
     tri_of[i] = t;
     tmp_doubles += (size_t)NB * d.nrhs;
@@ -750,8 +749,11 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
   double* aux = ctx->aux(sizeof(double) * (inv_doubles + tmp_doubles));
   double* tmp0 = aux + inv_doubles;
   std::vector<hssk_trtri_desc> ti;
-  for (auto& t : tris) ti.push_back(hssk_trtri_desc{t.T, aux + t.off, t.n, t.ldt, t.lower ? 2 : 1});
-  if (hssk_trtri_diag_vbatched(ctx, ti.data(), (int)ti.size())) throw std::runtime_error(hssk_last_error());
+  for (auto& t : tris) {
+    t.inv = t.given ? t.given : aux + t.off;
+    if (!t.given) ti.push_back(hssk_trtri_desc{t.T, aux + t.off, t.n, t.ldt, t.lower ? 2 : 1});
+  }
+  if (!ti.empty() && hssk_trtri_diag_vbatched(ctx, ti.data(), (int)ti.size())) throw std::runtime_error(hssk_last_error());
   int nblk_max = 0, n_max = 0;
   for (auto& t : tris) { nblk_max = std::max(nblk_max, (t.n + NB - 1) / NB); n_max = std::max(n_max, t.n); }
   static const bool no_fused = [] { const char* e = std::getenv("HSSK_TRSM_NO_FUSED"); return e && e[0] == '1'; }();   // (A/B: one launch per block step and stage)
@@ -761,14 +763,14 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
     std::vector<TfWork> work;
     for (int i = 0; i < count; i++) {
       if (tri_of[i] < 0) continue;
-      for (int g = 0; g * 16 < descs[i].nrhs; g++) work.push_back(TfWork{(int)sel.size(), g, tris[tri_of[i]].off});
+      for (int g = 0; g * 16 < descs[i].nrhs; g++) work.push_back(TfWork{(int)sel.size(), g, tris[tri_of[i]].inv});
       sel.push_back(descs[i]);
     }
     auto* dd = (const hssk_trsm_desc*)ctx->stage(sel.data(), sizeof(hssk_trsm_desc) * sel.size());
     auto* dw = (const TfWork*)ctx->stage(work.data(), sizeof(TfWork) * work.size());
     const size_t shmem = sizeof(double) * 16 * (size_t)(nblk_max * NB + 1);
     hssk_rt::allow_dynamic_lds(trsm_fused_kernel, shmem);
-    HSSK_LAUNCH(trsm_fused_kernel, dim3((unsigned)work.size()), dim3(TF_T), shmem, ctx->stream, dd, dw, (const double*)aux);
+    HSSK_LAUNCH(trsm_fused_kernel, dim3((unsigned)work.size()), dim3(TF_T), shmem, ctx->stream, dd, dw);
     for (int i = 0; i < count; i++) done[i] = tri_of[i] >= 0;
     return true;
   }
@@ -788,7 +790,7 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
       // the effective triangle of op(T): lower (forward, blocks first to last) or upper (backward, last to first)
       const bool fwd = d.lower || d.transT;
       const int b = fwd ? s : nblk - 1 - s, b0 = b * NB, nb = std::min(NB, d.n - b0), end = b0 + nb;
-      const double* Ti = aux + t.off + (size_t)b * NB * NB;
+      const double* Ti = t.inv + (size_t)b * NB * NB;
       double* Bb = d.B + b0;
       cp.push_back(hssk_rowgather_desc{Bb, tmp, nullptr, nb, d.nrhs, d.ldb, nb, 0, 0});
       // X_b = inv(op(T)_bb) B_b: the blocks hold plain inverses of T_bb; a transposed solve multiplies by their transposes

@@ -96,7 +96,7 @@ class QrDesc(C.Structure):
 class TrsmDesc(C.Structure):
     _fields_ = [("T", C.c_void_p), ("B", C.c_void_p), ("n", C.c_int), ("nrhs", C.c_int),
                 ("ldt", C.c_int), ("ldb", C.c_int), ("lower", C.c_int), ("transT", C.c_int),
-                ("unit", C.c_int)]
+                ("unit", C.c_int), ("Tinv", C.c_void_p)]
 
 
 class LuDesc(C.Structure):
