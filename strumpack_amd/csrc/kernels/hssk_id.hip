@@ -1327,8 +1327,11 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
     }
 #endif
     if (group_ok) {
-      const int H = mmax <= 256 ? 2 : 4;
       const int RTv = dmax <= 192 ? 12 : 16;
+      // 256 x 256 tiles: three workgroups of 96 columns hold the tile without spills (6.5 us per step against 9.4 with two of
+      // 128) -- as long as all of them are resident at once (one 8-wave workgroup of 240 registers per CU, 256 CUs)
+      static const bool no_h3 = [] { const char* e = std::getenv("HSSK_ID_GROUP_NO_H3"); return e && e[0] == '1'; }();
+      const int H = mmax <= 256 ? ((RTv == 16 && count * 3 <= 256 && !no_h3) ? 3 : 2) : 4;
       int kcap = 1;
       for (int i = 0; i < count; i++) kcap = std::max(kcap, std::min(std::min(descs[i].d, descs[i].m), std::max(descs[i].max_rank, 0)));
       const int sw = 2 * H + 16 * RTv + 3;
@@ -1341,7 +1344,8 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
       //  columns each spill -- 232 bytes per lane at 256 rows)
       const dim3 grid((unsigned)count * H), block(512);
       g_group_launches++;
-      if (RTv == 16 && H == 2) HSSK_LAUNCH((id_group_kernel<16, 4, 8, 2>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
+      if (RTv == 16 && H == 3) HSSK_LAUNCH((id_group_kernel<16, 3, 8, 3>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
+      else if (RTv == 16 && H == 2) HSSK_LAUNCH((id_group_kernel<16, 4, 8, 2>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
       else if (RTv == 16) HSSK_LAUNCH((id_group_kernel<16, 4, 8, 4>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
       else if (H == 2) HSSK_LAUNCH((id_group_kernel<12, 4, 8, 2>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
       else HSSK_LAUNCH((id_group_kernel<12, 4, 8, 4>), grid, block, 0, ctx->stream, dd, xch, kcap, err);
