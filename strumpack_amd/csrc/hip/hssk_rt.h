@@ -53,6 +53,12 @@ inline bool is_pinned_host_pointer(const void* p) {
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeHost;
 }
+// compute units of the current device (256 on an MI355X in SPX mode, 32 per partition in CPX mode)
+inline int cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  return n > 0 ? n : 256;
+}
 inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void set_device(int d) { HSSK_CHECK(hipSetDevice(d)); }
 inline bool is_device_pointer(const void* p) {

@@ -1328,10 +1328,11 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
 #endif
     if (group_ok) {
       const int RTv = dmax <= 192 ? 12 : 16;
-      // 256 x 256 tiles: three workgroups of 96 columns hold the tile without spills (6.5 us per step against 9.4 with two of
-      // 128) -- as long as all of them are resident at once (one 8-wave workgroup of 240 registers per CU, 256 CUs)
+      // 256 x 256 tiles: three workgroups of 96 columns hold the tile without spills (5.4 us per step against 10 with two of
+      // 128) -- as long as all of them are resident at once (one 8-wave workgroup of 240 registers per CU)
       static const bool no_h3 = [] { const char* e = std::getenv("HSSK_ID_GROUP_NO_H3"); return e && e[0] == '1'; }();
-      const int H = mmax <= 256 ? ((RTv == 16 && count * 3 <= 256 && !no_h3) ? 3 : 2) : 4;
+      static const int cus = hssk_rt::cu_count();
+      const int H = mmax <= 256 ? ((RTv == 16 && count * 3 <= cus && !no_h3) ? 3 : 2) : 4;
       int kcap = 1;
       for (int i = 0; i < count; i++) kcap = std::max(kcap, std::min(std::min(descs[i].d, descs[i].m), std::max(descs[i].max_rank, 0)));
       const int sw = 2 * H + 16 * RTv + 3;

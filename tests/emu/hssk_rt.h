@@ -39,6 +39,7 @@ inline float event_elapsed_ms(event_t a, event_t b) { return (float)(*b - *a); }
 inline void stream_wait_event(stream_t, event_t) {}
 inline void event_sync(event_t) {}
 inline bool is_pinned_host_pointer(const void*) { return false; }
+inline int cu_count() { return 256; }
 inline int device_count() { return 1; }
 inline void set_device(int) {}
 inline bool is_device_pointer(const void*) { return false; }
