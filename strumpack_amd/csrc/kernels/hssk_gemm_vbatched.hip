@@ -502,6 +502,77 @@ __global__ __launch_bounds__(TALL_T) void gemm_tall_kernel(const hssk_gemm_desc*
     }
   }
 }
+// ---- products with at most four columns (mat-vec shaped: the solve phases of a BLR front with one right-hand side -- V^T x
+// and U t per low-rank tile --, the dense leaf products of an HSS mat-vec / solve at leaf sizes beyond the single-launch
+// sweep).  The MFMA tile kernel spends a 64 x 64 tile's staging and its K loop of barriers on them: 38 - 44 us per launch for
+// the tiles of a BLR block column, 212 us for the 196 leaf blocks of N = 1e5 at leaf 512 (411 MB: 1.9 TB/s).  Here the
+// columns of op(B) sit in the LDS (k <= 1024) and A streams once: not transposed, a thread per row of C (coalesced along
+// the rows, the vector entries read as LDS broadcasts); transposed, a wave per row of C (the lanes along the contiguous
+// column of A, a wave sum per output).
+constexpr int GV_T = 256, GV_N = 4, GV_K = 1024, GV_ROWS_T = 64;
+__global__ __launch_bounds__(GV_T) void gemv_small_kernel(const hssk_gemm_desc* __restrict__ descs, const Tile* __restrict__ tiles) {
+  HSSK_SHARED double s_x[GV_K * GV_N];
+  const Tile t = tiles[blockIdx.x];
+  const hssk_gemm_desc p = descs[t.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = p.m, n = p.n, k = p.k;
+  for (int e = tid; e < k * GV_N; e += GV_T) {
+    const int kk = e % k, c = e / k;
+    s_x[kk + c * GV_K] = c < n ? hssk_gload(p.B, p.transB ? (size_t)c + (size_t)kk * p.ldb : (size_t)kk + (size_t)c * p.ldb) : 0.;
+  }
+  __syncthreads();
+  if (!p.transA) {
+    const int row = t.tm * GV_T + tid;
+    if (row >= m) return;
+    double acc[GV_N] = {0., 0., 0., 0.};
+    int kk = 0;
+    for (; kk + 8 <= k; kk += 8) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = hssk_gload(p.A, (size_t)row + (size_t)(kk + u) * p.lda);
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int c = 0; c < GV_N; c++) acc[c] += a[u] * s_x[kk + u + c * GV_K];
+    }
+    for (; kk < k; kk++) {
+      const double a = hssk_gload(p.A, (size_t)row + (size_t)kk * p.lda);
+#pragma unroll
+      for (int c = 0; c < GV_N; c++) acc[c] += a * s_x[kk + c * GV_K];
+    }
+#pragma unroll
+    for (int c = 0; c < GV_N; c++)
+      if (c < n) {
+        const size_t o = (size_t)row + (size_t)c * p.ldc;
+        hssk_gstore(p.C, o, p.beta == 0. ? p.alpha * acc[c] : p.alpha * acc[c] + p.beta * hssk_gload(p.C, o));
+      }
+  } else {
+    for (int jj = wave; jj < GV_ROWS_T; jj += GV_T / 64) {
+      const int j = t.tm * GV_ROWS_T + jj;
+      if (j >= m) break;
+      double acc[GV_N] = {0., 0., 0., 0.};
+      for (int kk = lane; kk < k; kk += 64) {
+        const double a = hssk_gload(p.A, (size_t)kk + (size_t)j * p.lda);
+#pragma unroll
+        for (int c = 0; c < GV_N; c++) acc[c] += a * s_x[kk + c * GV_K];
+      }
+#pragma unroll
+      for (int c = 0; c < GV_N; c++) acc[c] = hssk_wave_sum(acc[c]);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < GV_N; c++)
+          if (c < n) {
+            const size_t o = (size_t)j + (size_t)c * p.ldc;
+            hssk_gstore(p.C, o, p.beta == 0. ? p.alpha * acc[c] : p.alpha * acc[c] + p.beta * hssk_gload(p.C, o));
+          }
+      }
+    }
+  }
+}
+bool gemv_eligible(const hssk_gemm_desc& d) {
+  static const bool off = [] { const char* e = std::getenv("HSSK_GEMM_NO_GEMV"); return e && e[0] == '1'; }();
+  return !off && d.n <= GV_N && d.k >= 1 && d.k <= GV_K;
+}
 bool tall_eligible(const hssk_gemm_desc& d) {
   static const bool off = [] { const char* e = std::getenv("HSSK_GEMM_NO_TALL"); return e && e[0] == '1'; }();
   return !off && !d.transB && d.n > 16 && d.n <= TALL_N && d.k >= 32 && d.k <= TALL_KMAX && d.m >= 96;
@@ -512,11 +583,16 @@ bool tall_eligible(const hssk_gemm_desc& d) {
 extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
-  std::vector<Tile> tiles, ztiles, ptilesN, ptilesT, ttiles;
+  std::vector<Tile> tiles, ztiles, ptilesN, ptilesT, ttiles, vtiles;
   int kmax_tall = 0;
   for (int p = 0; p < count; p++) {
     const hssk_gemm_desc& d = descs[p];
     if (d.m <= 0 || d.n <= 0) continue;
+    if (gemv_eligible(d)) {
+      const int per = d.transA ? GV_ROWS_T : GV_T;
+      for (int tm = 0; tm * per < d.m; tm++) vtiles.push_back(Tile{p, tm, 0});
+      continue;
+    }
     if (tall_eligible(d)) {
       for (int tm = 0; tm * TALL_M < d.m; tm++) ttiles.push_back(Tile{p, tm, 0});
       kmax_tall = std::max(kmax_tall, d.k);
@@ -532,7 +608,7 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
     for (int tn = 0; tn < ntn; tn++)
       for (int tm = 0; tm < ntm; tm++) dst.push_back(Tile{p, tm, tn});
   }
-  if (tiles.empty() && ztiles.empty() && ptilesN.empty() && ptilesT.empty() && ttiles.empty()) return 0;
+  if (tiles.empty() && ztiles.empty() && ptilesN.empty() && ptilesT.empty() && ttiles.empty() && vtiles.empty()) return 0;
   auto* d_descs = (const hssk_gemm_desc*)ctx->stage(descs, sizeof(hssk_gemm_desc) * count);
   // XCD-aware order for the panel tiles: workgroup b runs on XCD b % 8 and every XCD has its own L2, so
   // the column tiles of one problem (which share the 192 x k A panel) are placed on block ids that are
@@ -563,6 +639,10 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
   if (!ptilesT.empty()) {
     auto* d_tiles = (const Tile*)ctx->stage(ptilesT.data(), sizeof(Tile) * ptilesT.size());
     HSSK_LAUNCH((gemm_panel_kernel<true>), dim3((unsigned)ptilesT.size()), dim3(256), 0, ctx->stream, d_descs, d_tiles);
+  }
+  if (!vtiles.empty()) {
+    auto* d_tiles = (const Tile*)ctx->stage(vtiles.data(), sizeof(Tile) * vtiles.size());
+    HSSK_LAUNCH(gemv_small_kernel, dim3((unsigned)vtiles.size()), dim3(GV_T), 0, ctx->stream, d_descs, d_tiles);
   }
   if (!ttiles.empty()) {
     auto* d_tiles = (const Tile*)ctx->stage(ttiles.data(), sizeof(Tile) * ttiles.size());

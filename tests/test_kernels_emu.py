@@ -44,6 +44,15 @@ def test_gemm_vbatched_tall_path(hk):
                                (96, 64, 100, 1, 0, 1.0, 1.0), (97, 20, 64, 0, 0, 1.0, 0.0)], seed=7)
 
 
+def test_gemm_vbatched_few_columns(hk):
+    # at most four columns, k <= 1024: the vector entries in the LDS, A streamed once (gemv_small_kernel): a thread per row of
+    # C (A not transposed) or a wave per row (transposed), either form of B, beta, ragged blocks; k beyond the LDS copy and
+    # five columns stay with the tile kernel
+    KC.case_gemm_vbatched(hk, [(300, 1, 256, 0, 0, 1.0, 0.0), (13, 1, 256, 1, 0, 1.0, 0.0), (256, 1, 13, 0, 0, -1.0, 1.0),
+                               (70, 4, 1000, 1, 0, 2.0, 0.5), (513, 3, 77, 0, 1, 1.0, 1.0), (100, 2, 130, 1, 1, -1.5, 0.0),
+                               (5, 1, 1, 0, 0, 1.0, 0.0), (40, 3, 1100, 0, 0, 1.0, 0.0), (40, 5, 64, 0, 0, 1.0, 0.0)], seed=9)
+
+
 @pytest.mark.parametrize("m,n,k,tb", [(192, 150, 64, 1), (192, 150, 64, 0), (64, 130, 48, 1), (128, 64, 32, 0)])
 def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     # even leading dimensions + 16-byte aligned operands: interior tiles take the unmasked kernel

@@ -74,6 +74,13 @@ def test_gathers(hk):
     KC.case_gathers(hk)
 
 
+def test_gemm_vbatched_few_columns(hk):
+    # gemv_small_kernel: the shapes of a BLR front's solve phases (V^T x, U t per tile) and of leaf-512 dense products
+    KC.case_gemm_vbatched(hk, [(256, 1, 13, 0, 0, -1.0, 1.0)] * 40 + [(13, 1, 256, 1, 0, 1.0, 0.0)] * 40 + [(512, 1, 512, 0, 0, 1.0, 0.0)] * 20 +
+                          [(512, 2, 512, 1, 0, 1.0, 1.0)] * 20 + [(300, 4, 1000, 1, 0, 2.0, 0.5), (513, 3, 77, 0, 1, 1.0, 1.0), (100, 2, 130, 1, 1, -1.5, 0.0),
+                           (5, 1, 1, 0, 0, 1.0, 0.0), (40, 3, 1100, 0, 0, 1.0, 0.0), (40, 5, 64, 0, 0, 1.0, 0.0)], seed=9)
+
+
 def test_id(hk):
     KC.case_id(hk, [(24, 40, 1e-6, 1e-12, 1000, 7), (24, 16, 1e-10, 1e-14, 1000, None),
                     (12, 30, 1.0, 1e-10, 1000, None), (24, 40, 1e-8, 1e-12, 5, 9),
