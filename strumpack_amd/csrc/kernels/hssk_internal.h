@@ -89,6 +89,10 @@ struct hssk_ctx {
     if (need > ring_bytes) throw std::runtime_error("hssk: descriptor batch exceeds staging ring");
     if (ring_off + need > ring_bytes) {
       hssk_rt::sync(stream);
+      if (side_made) {   // (launches on the other stream of the pair may still read their descriptors)
+        hssk_rt::sync(side);
+        if (on_side) hssk_rt::sync(main_saved);
+      }
       ring_off = 0;
     }
     std::memcpy(h_ring + ring_off, host, bytes);
