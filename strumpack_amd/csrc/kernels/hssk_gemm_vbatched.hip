@@ -507,7 +507,7 @@ __global__ __launch_bounds__(TALL_T) void gemm_tall_kernel(const hssk_gemm_desc*
 // sweep).  The MFMA tile kernel spends a 64 x 64 tile's staging and its K loop of barriers on them: 38 - 44 us per launch for
 // the tiles of a BLR block column, 212 us for the 196 leaf blocks of N = 1e5 at leaf 512 (411 MB: 1.9 TB/s).  Here the
 // columns of op(B) sit in the LDS (k <= 1024) and A streams once: not transposed, a thread per row of C (coalesced along
-// the rows, the vector entries read as LDS broadcasts); transposed, a wave per row of C (the lanes along the contiguous
+// the rows, the waves of a workgroup along k, the vector entries read as LDS broadcasts); transposed, a wave per row of C (the lanes along the contiguous
 // column of A, a wave sum per output).
 constexpr int GV_T = 256, GV_N = 4, GV_K = 1024, GV_ROWS_T = 64;
 __global__ __launch_bounds__(GV_T) void gemv_small_kernel(const hssk_gemm_desc* __restrict__ descs, const Tile* __restrict__ tiles) {
@@ -522,30 +522,44 @@ __global__ __launch_bounds__(GV_T) void gemv_small_kernel(const hssk_gemm_desc* 
   }
   __syncthreads();
   if (!p.transA) {
-    const int row = t.tm * GV_T + tid;
-    if (row >= m) return;
+    // 64 rows of C per workgroup, a lane per row; the four waves take a quarter of k each (one long product -- the U panel of
+    // a BLR block row against its stacked V^T x, k ~ 600 -- is then 19 batches of eight loads per lane instead of 75) and
+    // meet in the LDS
+    HSSK_SHARED double s_red[GV_T / 64][GV_N][64];
+    const int row = t.tm * 64 + lane;
+    const int kq = (k + GV_T / 64 - 1) / (GV_T / 64), k0 = wave * kq, k1 = min(k, k0 + kq);
     double acc[GV_N] = {0., 0., 0., 0.};
-    int kk = 0;
-    for (; kk + 8 <= k; kk += 8) {
-      double a[8];
+    if (row < m) {
+      int kk = k0;
+      for (; kk + 8 <= k1; kk += 8) {
+        double a[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = hssk_gload(p.A, (size_t)row + (size_t)(kk + u) * p.lda);
+        for (int u = 0; u < 8; u++) a[u] = hssk_gload(p.A, (size_t)row + (size_t)(kk + u) * p.lda);
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+        for (int u = 0; u < 8; u++)
 #pragma unroll
-        for (int c = 0; c < GV_N; c++) acc[c] += a[u] * s_x[kk + u + c * GV_K];
-    }
-    for (; kk < k; kk++) {
-      const double a = hssk_gload(p.A, (size_t)row + (size_t)kk * p.lda);
-#pragma unroll
-      for (int c = 0; c < GV_N; c++) acc[c] += a * s_x[kk + c * GV_K];
-    }
-#pragma unroll
-    for (int c = 0; c < GV_N; c++)
-      if (c < n) {
-        const size_t o = (size_t)row + (size_t)c * p.ldc;
-        hssk_gstore(p.C, o, p.beta == 0. ? p.alpha * acc[c] : p.alpha * acc[c] + p.beta * hssk_gload(p.C, o));
+          for (int c = 0; c < GV_N; c++) acc[c] += a[u] * s_x[kk + u + c * GV_K];
       }
+      for (; kk < k1; kk++) {
+        const double a = hssk_gload(p.A, (size_t)row + (size_t)kk * p.lda);
+#pragma unroll
+        for (int c = 0; c < GV_N; c++) acc[c] += a * s_x[kk + c * GV_K];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < GV_N; c++) s_red[wave][c][lane] = acc[c];
+    __syncthreads();
+    if (wave == 0 && row < m) {
+#pragma unroll
+      for (int c = 0; c < GV_N; c++)
+        if (c < n) {
+          double v = s_red[0][c][lane];
+#pragma unroll
+          for (int w = 1; w < GV_T / 64; w++) v += s_red[w][c][lane];
+          const size_t o = (size_t)row + (size_t)c * p.ldc;
+          hssk_gstore(p.C, o, p.beta == 0. ? p.alpha * v : p.alpha * v + p.beta * hssk_gload(p.C, o));
+        }
+    }
   } else {
     for (int jj = wave; jj < GV_ROWS_T; jj += GV_T / 64) {
       const int j = t.tm * GV_ROWS_T + jj;
@@ -589,7 +603,7 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
     const hssk_gemm_desc& d = descs[p];
     if (d.m <= 0 || d.n <= 0) continue;
     if (gemv_eligible(d)) {
-      const int per = d.transA ? GV_ROWS_T : GV_T;
+      const int per = 64;   // rows of C per workgroup, either form (GV_ROWS_T)
       for (int tm = 0; tm * per < d.m; tm++) vtiles.push_back(Tile{p, tm, 0});
       continue;
     }
