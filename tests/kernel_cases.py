@@ -358,6 +358,31 @@ def case_qr_lazy(hk, shapes, seed=17):
         assert np.isclose(rd[0], np.abs(np.diag(Rl)).max()) and np.isclose(rd[1], np.abs(np.diag(Rl)).min())
 
 
+def case_laswp(hk, shapes, seed=31):
+    """hssk_laswp_vbatched: B <- P B, the row interchanges of a getrf applied in order (shapes: (n, nrhs)); up to 1024 rows
+    every row replays the interchanges on its index and the rows move in one pass, above that column by column"""
+    r = rng(seed)
+    descs, keep = [], []
+    for (n, nrhs) in shapes:
+        piv = np.array([int(r.integers(k, n)) for k in range(n)], dtype=np.int32)
+        if n > 3:
+            piv[1] = 1            # an interchange with itself
+            piv[2] = n - 1
+        ldb = n + 3
+        B = r.standard_normal((ldb, nrhs))
+        dB, dpiv = hk.array(B), hk.array(piv)
+        keep.append((B, piv, dB, dpiv, n))
+        descs.append(K.LuSolveDesc(None, dpiv.ptr, dB.ptr, n, nrhs, n, ldb))
+    hk.batch("hssk_laswp_vbatched", descs)
+    hk.sync()
+    for (B, piv, dB, dpiv, n) in keep:
+        ref = B.copy()
+        for k in range(n):
+            if piv[k] != k:
+                ref[[k, piv[k]]] = ref[[piv[k], k]]
+        assert np.array_equal(dB.get(), ref), f"laswp n={n}"
+
+
 def case_trsm_lu(hk, seed=9, big_lu=(600, 3), extra_lu=()):
     r = rng(seed)
     descs, keep = [], []

@@ -122,6 +122,10 @@ def test_formq_from_stored_reflectors(hk):
     KC.case_qr_lazy(hk, [(600, 20, 20), (640, 70, 70)], seed=19)           # tall blocked path
 
 
+def test_laswp(hk):
+    KC.case_laswp(hk, [(256, 1), (200, 70), (5, 3), (1, 1), (513, 9), (1024, 2), (1100, 3)])
+
+
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)
     KC.case_trsm_lu(hk, seed=11, big_lu=(530, 2), extra_lu=[(300, 2), (391, 1), (512, 1)])   # 512-lane form: 64 trailing columns per pass

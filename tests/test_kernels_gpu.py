@@ -117,6 +117,10 @@ def test_qr(hk):
     KC.case_qr(hk, [(195, 159, 195), (208, 160, 0), (200, 180, 200), (196, 161, 196)], seed=25)   # five- and seven-slot register variants
 
 
+def test_laswp(hk):
+    KC.case_laswp(hk, [(256, 1), (256, 600), (200, 70), (5, 3), (1, 1), (513, 9), (1024, 130), (1100, 3)])
+
+
 def test_trsm_lu(hk):
     KC.case_trsm_lu(hk)
     KC.case_trsm_lu(hk, seed=10, big_lu=(2100, 5), extra_lu=[(384, 3), (391, 1), (512, 2)])
