@@ -99,6 +99,10 @@ class TrsmDesc(C.Structure):
                 ("unit", C.c_int), ("Tinv", C.c_void_p)]
 
 
+class TrtriDesc(C.Structure):
+    _fields_ = [("R", C.c_void_p), ("Tinv", C.c_void_p), ("n", C.c_int), ("ldr", C.c_int), ("mode", C.c_int)]
+
+
 class LuDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("n", C.c_int), ("lda", C.c_int), ("piv", C.c_void_p),
                 ("info", C.c_void_p)]

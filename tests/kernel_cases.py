@@ -358,6 +358,57 @@ def case_qr_lazy(hk, shapes, seed=17):
         assert np.isclose(rd[0], np.abs(np.diag(Rl)).max()) and np.isclose(rd[1], np.abs(np.diag(Rl)).min())
 
 
+def case_random_shapes(hk, seed, rounds=3):
+    """Seeded random shapes through the kernels of round 3 that choose their form by size: the cooperative ID (129 .. 256 rows,
+    up to 512 columns: two / three / four workgroups per panel), products with at most four columns, the one-workgroup LU
+    (checked as a factorization: P A = L U, |L| <= 1, LAPACK's pivots unless the matrix is degenerate), blocked triangular
+    solves with and without the caller's inverted diagonal blocks."""
+    r = rng(seed)
+    for it in range(rounds):
+        probs = []
+        for _ in range(int(r.integers(1, 4))):
+            d, m = int(r.integers(129, 257)), int(r.integers(2, 513))
+            nr = int(r.integers(1, min(d, m) + 1)) if r.random() < 0.8 else None
+            mr = int(r.choice([1000, 1000, int(r.integers(1, 200))]))
+            probs.append((d, m, float(10.0 ** r.integers(-12, -2)), 1e-14, mr, nr))
+        case_id(hk, probs, seed=seed * 100 + it, deferred=bool(r.random() < 0.3))
+        cases = [(int(r.integers(1, 700)), int(r.integers(1, 5)), int(r.integers(1, 1025)), int(r.integers(0, 2)), int(r.integers(0, 2)),
+                  float(r.choice([1.0, -1.0, 2.5])), float(r.choice([0.0, 1.0, 0.5]))) for _ in range(6)]
+        case_gemm_vbatched(hk, cases, seed=seed * 100 + 50 + it)
+        # LU
+        n = int(r.integers(129, 513))
+        A = r.standard_normal((n, n))
+        if it % 3 == 1:
+            A *= 10.0 ** r.uniform(-6, 6, size=(n, 1))
+        dA, dpiv, dinfo = hk.array(A), hk.empty((n,), np.int32), hk.empty((1,), np.int32)
+        hk.batch("hssk_getrf_vbatched", [K.LuDesc(dA.ptr, n, n, dpiv.ptr, dinfo.ptr)])
+        hk.sync()
+        got, gp = dA.get(), dpiv.get()
+        PA = A.copy()
+        for i, pi in enumerate(gp):
+            PA[[i, pi]] = PA[[pi, i]]
+        Lf, Uf = np.tril(got, -1) + np.eye(n), np.triu(got)
+        assert np.abs(Lf).max() <= 1.0 + 1e-12 and np.allclose(Lf @ Uf, PA, atol=1e-10 * max(1.0, np.abs(Uf).max())), f"LU n={n}"
+        assert np.array_equal(gp, sla.lu_factor(A)[1]), f"LU pivots n={n}"
+        # blocked triangular solve, with / without given inverses
+        n, nrhs = int(r.integers(128, 513)), int(r.integers(1, 50))
+        lower, trans, unit = [(1, 0, 1), (0, 0, 0), (0, 1, 0)][it % 3]
+        T = sla.lu_factor(r.standard_normal((n, n)))[0] if unit else r.standard_normal((n, n)) + n * np.eye(n)
+        B = r.standard_normal((n, nrhs))
+        dT, dB = hk.array(T), hk.array(B)
+        dinv = None
+        if it % 2:
+            dinv = hk.empty((((n + 63) // 64) * 4096,))
+            hk.batch("hssk_trtri_diag_vbatched", [K.TrtriDesc(dT.ptr, dinv.ptr, n, n, 2 if lower else 1)])
+        hk.batch("hssk_trsm_vbatched", [K.TrsmDesc(dT.ptr, dB.ptr, n, nrhs, n, n, lower, trans, unit, dinv.ptr if dinv is not None else None)])
+        hk.sync()
+        Tt = np.tril(T) if lower else np.triu(T)
+        if unit:
+            np.fill_diagonal(Tt, 1.0)
+        ref = np.linalg.solve(Tt.T if trans else Tt, B)
+        assert np.allclose(dB.get(), ref, atol=1e-10 * max(1.0, np.abs(ref).max())), f"trsm n={n} nrhs={nrhs} form={(lower, trans, unit)}"
+
+
 def case_laswp(hk, shapes, seed=31):
     """hssk_laswp_vbatched: B <- P B, the row interchanges of a getrf applied in order (shapes: (n, nrhs)); up to 1024 rows
     every row replays the interchanges on its index and the rows move in one pass, above that column by column"""

@@ -122,6 +122,11 @@ def test_formq_from_stored_reflectors(hk):
     KC.case_qr_lazy(hk, [(600, 20, 20), (640, 70, 70)], seed=19)           # tall blocked path
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_shapes(hk, seed):
+    KC.case_random_shapes(hk, seed, rounds=3)
+
+
 def test_laswp(hk):
     KC.case_laswp(hk, [(256, 1), (200, 70), (5, 3), (1, 1), (513, 9), (1024, 2), (1100, 3)])
 

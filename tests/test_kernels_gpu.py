@@ -117,6 +117,11 @@ def test_qr(hk):
     KC.case_qr(hk, [(195, 159, 195), (208, 160, 0), (200, 180, 200), (196, 161, 196)], seed=25)   # five- and seven-slot register variants
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_shapes(hk, seed):
+    KC.case_random_shapes(hk, seed, rounds=4)
+
+
 def test_laswp(hk):
     KC.case_laswp(hk, [(256, 1), (256, 600), (200, 70), (5, 3), (1, 1), (513, 9), (1024, 130), (1100, 3)])
 
