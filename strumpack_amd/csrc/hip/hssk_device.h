@@ -149,6 +149,28 @@ __device__ __forceinline__ hssk_d2 hssk_gload2(const double* p, size_t off) {
   return *(const hssk_d2 HSSK_GLOBAL_AS*)((const double HSSK_GLOBAL_AS*)p + off);
 }
 __device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { ((double HSSK_GLOBAL_AS*)p)[off] = v; }
+// ---- asynchronous global -> LDS copies (global_load_lds_dwordx4, "LDS DMA") -------------------------------------
+// Every lane names 16 bytes of global memory; lane l's piece lands at lds_base + 16 l (lds_base wave-uniform: it
+// travels in M0), without passing through registers.  The copy counts on vmcnt and nothing else orders it against
+// LDS reads: the issuing wave waits (hssk_wait_glds<N>: at most N of ITS copies still in flight), then a workgroup
+// barrier, then the reads.  hssk_wg_barrier is the bare s_barrier (__syncthreads would drain every counter).
+// (Written as an asm statement: through __builtin_amdgcn_global_load_lds the compiler's wait-count pass books the copy as
+// a FLAT access that may touch the LDS, after which every wait it places in front of an LDS read's consumer is a full
+// lgkmcnt(0) instead of the counted one -- the pipelined fragment reads of the sketch kernel then stall on the newest
+// read instead of the oldest.  M0 is the compiler's: saved and restored inside the statement.)
+__device__ __forceinline__ void hssk_glds16(const double* gsrc, double* lds_base) {
+  unsigned keep;
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base;
+  __asm__ volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void hssk_wait_glds() {   // s_waitcnt vmcnt(N) lgkmcnt(0)
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0070);
+}
+__device__ __forceinline__ void hssk_wg_barrier() { __builtin_amdgcn_s_barrier(); }
+// an index the compiler may not reason about (keeps two LDS reads from being fused into one half-rate ds_read2_b64)
+__device__ __forceinline__ int hssk_opaque(int v) { __asm__ volatile("" : "+v"(v)); return v; }
 // LDS accumulate without a return value (ds_add_f64): lanes / waves of a workgroup summing into shared slots
 __device__ __forceinline__ void hssk_lds_add(double* p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -39,6 +39,16 @@ inline void check_launch() { HSSK_CHECK(hipGetLastError()); }
 template <typename K> inline void allow_dynamic_lds(K kernel, size_t bytes) {
   HSSK_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
+// largest LDS allocation one workgroup can get (static + dynamic; gfx950: 160 KB, gfx90a / gfx942: 64 KB)
+inline size_t max_lds_per_workgroup() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 65536; }
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return 65536; }
+  }
+  return n > 0 ? (size_t)n : 65536;
+}
 inline stream_t stream_create() { stream_t s; HSSK_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
 inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
 inline event_t event_create() { event_t e; HSSK_CHECK(hipEventCreate(&e)); return e; }

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -240,6 +241,202 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
   }
 }
 
+// ---- second form of the interior tiles (round 4): BM x 128 tile on EIGHT waves, operands by LDS DMA ------------------
+// What the first form left on the table (main launches at 0.85 of the FP64 MFMA roof): every stage a wave issued 8 global
+// loads into registers, 8 LDS stores, a drain of both counters and a barrier in front of LDS reads whose latency only
+// the other workgroup of the CU could cover.  Here
+//  * one workgroup of 8 waves (2 x 4, 96 x 32 each at BM = 192) owns the CU and a BM x 128 tile: the shared A panel
+//    (R^T) is read from L2 once per 128 columns instead of once per 64;
+//  * the operands go global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write, no address VALU in
+//    the loop) into a ring of THREE stages: the copy of stage s+3 is issued right after the barrier that ends the reads
+//    of stage s and has two whole stages (~5 us) to land;
+//  * one bare s_barrier per stage, placed BEFORE the last k-step's MFMAs of the stage (its fragments are already in
+//    registers): after the barrier a wave still has 12 MFMAs to issue while the first fragments of the next stage come
+//    back from the LDS, so the matrix pipe never waits for an LDS round trip;
+//  * an LDS DMA writes lane-linear (base + 16 lane), so the layout is chosen on the SOURCE side: j- / i-contiguous
+//    operands as [64-wide block][k][64] images with the two k rows a 32-lane read group touches in different bank
+//    halves (column ^ 16 (k & 1)); a k-contiguous operand (B not transposed) as a [j][16 k] image whose 16-byte k
+//    pairs sit at pair ^ ((j >> 1) & 7) -- both conflict-free for ds_read_b64.  The k index a lane group l4 feeds to
+//    MFMA sub-step s is pi(s, l4) = 2 s + (l4 & 1) + 8 (l4 >> 1) for BOTH operands (any bijection does: the sum over
+//    k is what it is), which is what lets one 16-byte piece of the k-contiguous operand serve two lane groups.
+template <int MBLK, bool TRANSB, int TAG = 0>
+__global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k, const double* __restrict__ A, long long lda,
+                                                        const double* __restrict__ B, long long ldb,
+                                                        double* __restrict__ P, long long ldp, long long pstride,
+                                                        long long kchunk, int jtile0, long long* __restrict__ clk) {
+  const long long t0_ = clk ? hssk_clock() : 0, w0_ = clk ? hssk_wallclock() : 0;
+  constexpr int BM = 64 * MBLK, BN2 = 128;
+  constexpr int WM = BM / 2, MT = WM / 16, NT = 2;
+  constexpr int A_DBL = BM * BK, B_DBL = BN2 * BK, SLOT = A_DBL + B_DBL;   // doubles per ring stage
+  constexpr int NCH = MBLK + 2;                                            // 1 KB copies per wave and stage
+  HSSK_DYN_SHARED(double, lds);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = hssk_uniform(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int bx = blockIdx.x;
+  {  // XCD-aware tile order (see dgemm_kernel)
+    const int nx = gridDim.x, x = bx & 7, q = nx >> 3, r = nx & 7;
+    bx = x * q + (x < r ? x : r) + (bx >> 3);
+  }
+  const long long j0 = (long long)(bx + jtile0) * BN2;
+  const int i0 = blockIdx.y * BM;
+  const long long kbeg = (long long)blockIdx.z * kchunk;
+  const long long kend = kbeg + kchunk < k ? kbeg + kchunk : k;
+  const int nst = (int)((kend - kbeg) / BK);   // whole stages (the host only sends aligned chunks here)
+  const int wm = (wave & 1) * WM, wn = (wave >> 1) * 32;
+
+  // ---- copy side: wave w moves the k rows {2w, 2w+1} of every 64-wide block (i- / j-contiguous operands), or the
+  // eight j rows 8 c .. 8 c + 7 of chunk c = w, w + 8 (k-contiguous operand)
+  const int kk = lane >> 5, pos = 2 * (lane & 31);
+  const double* srcA = A + i0 + (pos ^ (16 * kk)) + (kbeg + 2 * wave + kk) * lda;
+  const long long stepA = (long long)BK * lda;
+  const double* srcB[2];
+  long long stepB;
+  if (TRANSB) {
+    srcB[0] = B + j0 + (pos ^ (16 * kk)) + (kbeg + 2 * wave + kk) * ldb;
+    srcB[1] = srcB[0] + 64;
+    stepB = (long long)BK * ldb;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int j = 8 * (wave + 8 * r) + (lane >> 3), q = lane & 7;
+      srcB[r] = B + (j0 + j) * ldb + kbeg + 2 * (q ^ ((j >> 1) & 7));
+    }
+    stepB = BK;
+  }
+  // copy number c (0 .. NCH-1) of a stage: the A blocks first, then the two B pieces.  The stage is clamped: copies past the
+  // chunk re-read its last stage into a slot nobody reads any more
+  auto copy_one = [&](int stage, int slot, int c) {
+    const int sc = stage < nst ? stage : nst - 1;
+    double* base = lds + slot * SLOT;
+    if (c < MBLK) hssk_glds16(srcA + sc * stepA + 64 * c, base + c * 1024 + wave * 128);
+    else if (TRANSB) hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (c - MBLK) * 1024 + wave * 128);
+    else hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (wave + 8 * (c - MBLK)) * 128);
+  };
+  auto copy_stage = [&](int stage, int slot) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) copy_one(stage, slot, c);
+  };
+
+  // ---- fragment side: offsets (doubles, within a stage) of this lane's operand words for sub-step 0; sub-step s adds
+  // 128 (two k rows) in the [k][64] images, and moves to pair (s ^ h) in the [j][16 k] image
+  int offA[MT], offB[NT][4];
+#pragma unroll
+  for (int a = 0; a < MT; a++) {
+    const int il = wm + a * 16 + l15;
+    offA[a] = hssk_opaque((il >> 6) * 1024 + ((l4 & 1) + 8 * (l4 >> 1)) * 64 + ((il & 63) ^ (16 * (l4 & 1))));
+  }
+#pragma unroll
+  for (int b = 0; b < NT; b++) {
+    const int jl = wn + b * 16 + l15;
+    if (TRANSB) {
+      const int o = hssk_opaque(A_DBL + (jl >> 6) * 1024 + ((l4 & 1) + 8 * (l4 >> 1)) * 64 + ((jl & 63) ^ (16 * (l4 & 1))));
+#pragma unroll
+      for (int s = 0; s < 4; s++) offB[b][s] = o + s * 128;
+    } else {
+      const int h = (jl >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 4; s++) offB[b][s] = hssk_opaque(A_DBL + jl * 16 + 2 * ((s + 4 * (l4 >> 1)) ^ h) + (l4 & 1));
+    }
+  }
+
+  hssk_d4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
+  double af[2][MT], bf[2][NT];
+  auto frags = [&](int slot, int s, int set) {
+    const double* base = lds + slot * SLOT;
+#pragma unroll
+    for (int a = 0; a < MT; a++) af[set][a] = base[offA[a] + s * 128];
+#pragma unroll
+    for (int b = 0; b < NT; b++) bf[set][b] = base[offB[b][s]];
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)  // swapped operands: lane holds C[i = l15][j = l4 + 4r]
+        acc[a][b] = hssk_mfma_f64_16x16x4(bf[set][b], af[set][a], acc[a][b]);
+  };
+  // one stage out of ring slot S; on entry the fragments of its sub-step 0 are in set 0
+  auto stage = [&](int st, auto slot_tag) {
+    constexpr int S = decltype(slot_tag)::value;
+    // (scheduling fences: left alone, the compiler hoists the reads of later sub-steps, fuses them into half-rate
+    // ds_read2st64_b64 pairs and then waits for ALL of them in front of the next MFMA)
+    frags(S, 1, 1);
+    hssk_sched_barrier();
+    mfmas(0);
+    hssk_sched_barrier();
+    frags(S, 2, 0);
+    hssk_sched_barrier();
+    mfmas(1);
+    hssk_sched_barrier();
+    frags(S, 3, 1);
+    hssk_sched_barrier();
+    mfmas(0);
+    hssk_sched_barrier();
+    // stage st+1 has landed (this wave's pieces; the barrier makes it everyone's), every read of stage st has returned
+    hssk_wait_glds<NCH>();
+    hssk_wg_barrier();
+    hssk_sched_barrier();
+    // the last sub-step's MFMAs (fragments already in registers) carry the issue of the next stage's first fragment reads
+    // and of the copies of stage st+3 into the slot just released: one copy behind each pair of MFMAs
+#pragma unroll
+    for (int a = 0; a < MT; a++) {
+#pragma unroll
+      for (int b = 0; b < NT; b++) acc[a][b] = hssk_mfma_f64_16x16x4(bf[1][b], af[1][a], acc[a][b]);
+      hssk_sched_barrier();
+      if (a == 0) frags((S + 1) % 3, 0, 0);
+      else if (a - 1 < NCH) copy_one(st + 3, S, a - 1);
+      hssk_sched_barrier();
+    }
+#pragma unroll
+    for (int c = MT - 1; c < NCH; c++) copy_one(st + 3, S, c);
+    hssk_sched_barrier();
+  };
+
+  if (nst > 0) {
+    copy_stage(0, 0);
+    copy_stage(1, 1);
+    copy_stage(2, 2);
+    hssk_wait_glds<2 * NCH>();
+    hssk_wg_barrier();
+    frags(0, 0, 0);
+    int st = 0;
+    for (; st + 3 <= nst; st += 3) {
+      stage(st, std::integral_constant<int, 0>());
+      stage(st + 1, std::integral_constant<int, 1>());
+      stage(st + 2, std::integral_constant<int, 2>());
+    }
+    if (st < nst) stage(st, std::integral_constant<int, 0>());
+    if (st + 1 < nst) stage(st + 1, std::integral_constant<int, 1>());
+    hssk_wait_glds<0>();   // the clamped copies of the last stages still target this workgroup's LDS
+  }
+  double* Pz = P + (long long)blockIdx.z * pstride;
+#pragma unroll
+  for (int a = 0; a < MT; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = i0 + wm + a * 16 + l15;
+        const long long gj = j0 + wn + b * 16 + l4 + 4 * r;
+        Pz[gi + gj * ldp] = acc[a][b][r];
+      }
+  if (clk && threadIdx.x == 0) {
+    const long long w1 = hssk_wallclock();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+      clk[0] = hssk_clock() - t0_;
+      clk[1] = w1 - w0_;
+    }
+    const long long fid = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    long long* rec = clk + 4 + 4 * fid;
+    rec[0] = w0_; rec[1] = w1; rec[2] = hssk_hwid(); rec[3] = bx;
+  }
+}
+
 // C = alpha * sum_z P_z + beta * C   (fixed summation order -> deterministic)
 __global__ void dgemm_reduce_kernel(int m, long long n, const double* __restrict__ P, long long ldp,
                                     long long pstride, int nz, double alpha, double beta,
@@ -313,6 +510,52 @@ void launch_bm(int BM, hssk_ctx* ctx, int transB, dim3 grid, int m, long long n,
   else if (BM == 128) launch_dgemm<128, FULL, TAG>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
   else launch_dgemm<64, FULL, TAG>(ctx, transB, grid, m, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
 }
+
+// the eight-wave LDS-DMA form (sketch_kernel): BM = 64 MBLK rows, 128 columns per workgroup, three ring stages
+constexpr int BN2 = 128;
+inline size_t sketch_lds_bytes(int mblk) { return sizeof(double) * 3 * (size_t)(64 * mblk + BN2) * BK; }
+template <int MBLK, int TAG>
+void launch_sketch_m(hssk_ctx* ctx, int transB, dim3 grid, long long n, long long k, const double* A, long long lda,
+                     const double* B, long long ldb, double* P, long long ldp, long long pstride, long long kchunk,
+                     int jtile0, long long* clk) {
+  const size_t shm = sketch_lds_bytes(MBLK);
+  if (transB) {
+    HSSK_LAUNCH((sketch_kernel<MBLK, true, TAG>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  } else {
+    HSSK_LAUNCH((sketch_kernel<MBLK, false, TAG>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  }
+}
+// asks the runtime for the ring's LDS once per instantiation; false where the device cannot give it (the caller then keeps
+// the four-wave form, which needs 74 KB at most)
+template <int MBLK>
+bool sketch_prepare_m() {
+  static const bool ok = [] {
+    try {
+      const size_t b = sketch_lds_bytes(MBLK);
+      if (b > hssk_rt::max_lds_per_workgroup()) return false;
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 0>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 0>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 1>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 1>, b);
+      return true;
+    } catch (const std::exception&) {
+      return false;
+    }
+  }();
+  return ok;
+}
+inline bool sketch_prepare(int BM) {
+  return BM == 192 ? sketch_prepare_m<3>() : (BM == 128 ? sketch_prepare_m<2>() : sketch_prepare_m<1>());
+}
+template <int TAG>
+void launch_sketch(int BM, hssk_ctx* ctx, int transB, dim3 grid, long long n, long long k, const double* A, long long lda,
+                   const double* B, long long ldb, double* P, long long ldp, long long pstride, long long kchunk,
+                   int jtile0, long long* clk) {
+  if (grid.x == 0) return;
+  if (BM == 192) launch_sketch_m<3, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  else if (BM == 128) launch_sketch_m<2, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  else launch_sketch_m<1, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+}
 }  // namespace
 
 extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long long k, double alpha,
@@ -322,21 +565,27 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
   if (m <= 0 || n <= 0) return 0;
   const int BM = m > 128 ? 192 : (m > 64 ? 128 : 64);
   const unsigned gm = (unsigned)((m + BM - 1) / BM);
-  const unsigned gn = (unsigned)((n + BN - 1) / BN);
   const long long ksteps = (k + BK - 1) / BK;
-  // interior tiles take the unmasked 16-byte-load kernel; the ragged last column tile (and any
-  // unaligned / odd-sized problem) the masked one
+  // interior tiles take an unmasked kernel; the ragged last columns (and any unaligned / odd-sized problem) the masked one
   const bool aligned = (m % BM == 0) && (k % BK == 0) && (lda % 2 == 0) && (ldb % 2 == 0) &&
                        (((size_t)A | (size_t)B) % 16 == 0);
-  const unsigned gn_full = aligned ? (unsigned)(n / BN) : 0u;
-  const unsigned gn_edge = gn - gn_full;
-  // Work decomposition.  The 256 CUs hold 512 workgroups (2 per CU); a grid that is not a multiple of 512 ends
-  // in a partly filled round.  The full tiles are therefore cut into a MAIN group whose grid (tiles x K-split s)
-  // fills r whole rounds exactly, and a short TAIL group (the remaining < 512 / s tiles) with a deeper K-split
-  // that fills one last round of short workgroups; the ragged edge tile keeps its own masked launch.  Every
+  // Interior tiles: the eight-wave LDS-DMA form (BM x 128 per workgroup, ONE workgroup per CU) where the device has the
+  // LDS for its three ring stages (120 KB at BM = 192; gfx950: 160 KB per workgroup), else the four-wave form (BM x 64,
+  // two workgroups per CU).  HSSK_DGEMM_V1=1 forces the latter (A/B runs).
+  static const int cus = hssk_rt::cu_count();
+  const bool force_v1 = [] { const char* e = std::getenv("HSSK_DGEMM_V1"); return e && std::atoi(e) != 0; }();
+  const bool v2 = aligned && !force_v1 && k > 0 && n >= BN2 && sketch_prepare(BM);
+  const int BNt = v2 ? BN2 : BN;
+  const unsigned gn_full = aligned ? (unsigned)(n / BNt) : 0u;
+  const long long edge_col0 = (long long)gn_full * BNt;                       // the masked kernel starts here (64-column tiles)
+  const unsigned gn_edge = (unsigned)((n - edge_col0 + BN - 1) / BN);
+  // Work decomposition.  The CUs hold `slots` workgroups (two four-wave ones per CU, or one eight-wave one); a grid that is
+  // not a multiple of that ends in a partly filled round.  The full tiles are therefore cut into a MAIN group whose grid
+  // (tiles x K-split s) fills r whole rounds exactly, and a short TAIL group (the remaining < slots / s tiles) with a
+  // deeper K-split that fills one last round of short workgroups; the ragged edge keeps its own masked launch.  Every
   // group writes K-partials that one deterministic reduce pass per group folds into C.
-  const long long slots = 512;
-  struct Group { long long tile0 = 0, ntiles = 0; int split = 1; long long kchunk = BK; int nz = 0; double* P = nullptr; long long cols = 0; };
+  const long long slots = v2 ? cus : 2LL * cus;
+  struct Group { long long col0 = 0, ntiles = 0; int split = 1; long long kchunk = BK; int nz = 0; double* P = nullptr; long long cols = 0; };
   auto chunk_of = [&](int split) {
     long long c = ((ksteps + split - 1) / split) * BK;
     return c > 0 ? c : (long long)BK;
@@ -352,10 +601,10 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     const long long T = (long long)gm * gn_full;   // gm == 1 on the sketch path (m = d <= 192)
     // cost model (units: one k-step of one workgroup): rounds x (steps per chunk + epilogue) + reduce traffic.
     // The reduce term is ABSOLUTE (per K-chunk and tile: the partials written and folded), calibrated on N = 1e5 (7 chunks x
-    // 1536 tiles: 1.06 GB of partials, 0.21 ms = 72 units).  It used to be relative to the number of tiles, which made
-    // splits look three to twenty times too expensive on the narrow outputs of a sharded sketch: 12 500 columns per rank
-    // of 8 took 146 tiles x 7 + a tail round (90 % of the slots busy, 16.4 ms) instead of 192 x 8 = three full rounds.
-    const double epi = 3.0, red = 0.0067;
+    // 1536 tiles of 64 columns: 1.06 GB of partials, 0.21 ms = 72 units).  It used to be relative to the number of tiles,
+    // which made splits look three to twenty times too expensive on the narrow outputs of a sharded sketch: 12 500 columns
+    // per rank of 8 took 146 tiles x 7 + a tail round (90 % of the slots busy, 16.4 ms) instead of 192 x 8 = three full rounds.
+    const double epi = 3.0, red = 0.0067 * (BNt / BN);
     double best = 1e300;
     int best_s = 1;
     long long best_main = T;
@@ -384,17 +633,16 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
       best_s = sp;
       best_main = (gm > 1 || r == 0) ? T : std::min<long long>(T, (r * slots) / sp);
     }
-    gmain.tile0 = 0; gmain.ntiles = gm > 1 ? gn_full : best_main; gmain.split = best_s;
-    gtail.tile0 = gmain.ntiles; gtail.ntiles = gn_full - gmain.ntiles; gtail.split = one_round_split(gtail.ntiles);
+    gmain.col0 = 0; gmain.ntiles = gm > 1 ? gn_full : best_main; gmain.split = best_s; gmain.cols = gmain.ntiles * BNt;
+    gtail.col0 = gmain.cols; gtail.ntiles = gn_full - gmain.ntiles; gtail.split = one_round_split(gtail.ntiles); gtail.cols = gtail.ntiles * BNt;
   }
-  gedge.tile0 = gn_full; gedge.ntiles = gn_edge; gedge.split = one_round_split((long long)gm * gn_edge);
+  gedge.col0 = edge_col0; gedge.ntiles = gn_edge; gedge.split = one_round_split((long long)gm * gn_edge); gedge.cols = n - edge_col0;
   const long long ldp = m;
   size_t ptot = 0;
   for (Group* g : {&gmain, &gtail, &gedge}) {
     if (!g->ntiles) continue;
     g->kchunk = chunk_of(g->split);
     g->nz = (int)std::max<long long>(1, (k + g->kchunk - 1) / g->kchunk);
-    g->cols = std::min<long long>(n, (g->tile0 + g->ntiles) * BN) - g->tile0 * BN;
     ptot += (size_t)ldp * g->cols * g->nz;
   }
   const size_t ntrace = gmain.ntiles ? (size_t)gmain.ntiles * gm * gmain.nz : 0;
@@ -409,7 +657,7 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     }
   }
   // partials of a group are addressed by absolute column: shift its base by the group's first column
-  auto shifted = [&](const Group& g) { return g.P - g.tile0 * BN * ldp; };
+  auto shifted = [&](const Group& g) { return g.P - g.col0 * ldp; };
   // the timed launch (hssk_last_dgemm_ms / _flops): the main group, or whatever carries the bulk
   const Group* timed = gmain.ntiles ? &gmain : (gtail.ntiles ? &gtail : &gedge);
   auto bracket = [&](const Group* g, auto&& launch) {
@@ -418,9 +666,15 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     launch();
     if (g == timed) hssk_rt::event_record(ctx->ev1, ctx->stream);
   };
-  bracket(&gedge, [&] { launch_bm<false, 0>(BM, ctx, transB, dim3((unsigned)gedge.ntiles, gm, (unsigned)gedge.nz), m, n, k, A, lda, B, ldb, shifted(gedge), ldp, ldp * gedge.cols, gedge.kchunk, (int)gedge.tile0, nullptr); });
-  bracket(&gtail, [&] { launch_bm<true, 1>(BM, ctx, transB, dim3((unsigned)gtail.ntiles, gm, (unsigned)gtail.nz), m, n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)gtail.tile0, nullptr); });
-  bracket(&gmain, [&] { launch_bm<true, 0>(BM, ctx, transB, dim3((unsigned)gmain.ntiles, gm, (unsigned)gmain.nz), m, n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)gmain.tile0, clk); });
+  auto grid_of = [&](const Group& g) { return dim3((unsigned)g.ntiles, gm, (unsigned)g.nz); };
+  bracket(&gedge, [&] { launch_bm<false, 0>(BM, ctx, transB, grid_of(gedge), m, n, k, A, lda, B, ldb, shifted(gedge), ldp, ldp * gedge.cols, gedge.kchunk, (int)(gedge.col0 / BN), nullptr); });
+  if (v2) {
+    bracket(&gtail, [&] { launch_sketch<1>(BM, ctx, transB, grid_of(gtail), n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)(gtail.col0 / BN2), nullptr); });
+    bracket(&gmain, [&] { launch_sketch<0>(BM, ctx, transB, grid_of(gmain), n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)(gmain.col0 / BN2), clk); });
+  } else {
+    bracket(&gtail, [&] { launch_bm<true, 1>(BM, ctx, transB, grid_of(gtail), m, n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)(gtail.col0 / BN), nullptr); });
+    bracket(&gmain, [&] { launch_bm<true, 0>(BM, ctx, transB, grid_of(gmain), m, n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)(gmain.col0 / BN), clk); });
+  }
   ctx->d_clk = gmain.ntiles ? clk : nullptr;
   ctx->dgemm_trace_wgs = (long long)ntrace;
   ctx->dgemm_timed = true;
@@ -430,9 +684,9 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     long long total = (long long)m * g->cols;
     unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
     if (g->nz >= 32 && total <= 65536)   // too few elements to hide the latency of a serial walk over the partials
-      HSSK_LAUNCH(dgemm_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->tile0 * BN * ldc, ldc);
+      HSSK_LAUNCH(dgemm_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
     else
-      HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->tile0 * BN * ldc, ldc);
+      HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
   }
   hssk_rt::check_launch();
   HSSK_API_END

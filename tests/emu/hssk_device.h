@@ -111,6 +111,11 @@ void hssk_pause();   // emu_runtime.cpp: sched_yield
 inline double hssk_gload(const double* p, size_t off) { return p[off]; }
 inline hssk_d2 hssk_gload2(const double* p, size_t off) { return *reinterpret_cast<const hssk_d2*>(p + off); }
 inline void hssk_gstore(double* p, size_t off, double v) { p[off] = v; }
+// asynchronous global -> LDS copies: immediate on the emulator (lane l's 16 bytes land at lds_base + 16 l)
+inline void hssk_glds16(const double* gsrc, double* lds_base) { std::memcpy(lds_base + 2 * (threadIdx.x & 63), gsrc, 16); }
+template <int N> inline void hssk_wait_glds() {}
+inline void hssk_wg_barrier() { emu::block_barrier(); }
+inline int hssk_opaque(int v) { return v; }
 inline void hssk_lds_add(double* p, double v) { *p += v; }   // fibers are cooperative: a plain update is atomic
 inline int hssk_lds_inc(int* p) { return (*p)++; }
 inline int hssk_uniform(int v) { return v; }

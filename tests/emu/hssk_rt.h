@@ -28,6 +28,7 @@ inline void memset_async(void* d, int v, size_t bytes, stream_t) { if (bytes) st
 inline void sync(stream_t) {}
 inline void check_launch() {}
 template <typename K> inline void allow_dynamic_lds(K, size_t) {}
+inline size_t max_lds_per_workgroup() { return 160 * 1024; }
 inline stream_t stream_create() { return nullptr; }
 inline void stream_destroy(stream_t) {}
 inline event_t event_create() { return new double(0); }

@@ -60,6 +60,16 @@ def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.0, beta=1.0, lda_pad=2, ldb_pad=4)
 
 
+@pytest.mark.parametrize("m,n,k,tb", [(192, 260, 16, 1), (192, 260, 16, 0), (192, 128, 32, 1), (128, 300, 160, 0),
+                                      (64, 256, 48, 1), (64, 256, 80, 0), (192, 390, 112, 0), (192, 384, 3200, 1)])
+def test_dgemm_lds_dma_form(hk, m, n, k, tb):
+    # the eight-wave form of the interior tiles (BM x 128 per workgroup, operands by LDS DMA into a ring of three stages):
+    # one, two, many stages per chunk (ring wrap-around, clamped copies), all three heights, both operand images, ragged
+    # rest columns through the masked kernel, several K-chunks
+    KC.case_dgemm(hk, m, n, k, tb, alpha=1.0, beta=0.0, lda_pad=0, ldb_pad=0)
+    KC.case_dgemm(hk, m, n, k, tb, alpha=-0.5, beta=2.0, lda_pad=4, ldb_pad=2)
+
+
 def test_dgemm_splitk(hk):
     KC.case_dgemm(hk, 24, 70, 3000, 1)
 

@@ -55,6 +55,14 @@ def test_dgemm_aligned_fast_path(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-1.0, beta=1.0, lda_pad=2, ldb_pad=4)
 
 
+@pytest.mark.parametrize("m,n,k,tb", [(192, 260, 16, 1), (192, 260, 16, 0), (192, 128, 32, 1), (128, 3000, 1600, 0),
+                                      (64, 2560, 4800, 1), (64, 256, 80, 0), (192, 33000, 20000, 0), (192, 33000, 20000, 1)])
+def test_dgemm_lds_dma_form(hk, m, n, k, tb):
+    # the eight-wave form of the interior tiles (BM x 128 per workgroup, operands by LDS DMA into a ring of three stages)
+    KC.case_dgemm(hk, m, n, k, tb, alpha=1.0, beta=0.0, lda_pad=0, ldb_pad=0)
+    KC.case_dgemm(hk, m, n, k, tb, alpha=-0.5, beta=2.0, lda_pad=4, ldb_pad=2)
+
+
 def test_leaf_update(hk):
     KC.case_leaf_update(hk, [(24, 20), (192, 45), (64, 33), (2, 1)])
     KC.case_leaf_update(hk, [(192, 195), (192, 196)] * 8 + [(64, 390)], seed=13)
