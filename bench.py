@@ -318,10 +318,11 @@ def measure_traffic(argv_extra, kernel_match, out_dir=None):
     """HBM traffic of the dominant kernel from counter passes of THIS command: rocprofv3 --kernel-trace --pmc <counter> in
     separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), one step each, parsed per kernel.
     gfx950 correction of the guide: FETCH_SIZE (KB) tallies the 128-byte requests of a wide streaming read at 64 B -> x 2.
-    Returns bytes per launch of the kernels whose name contains `kernel_match` (mean over those launches), or None when
+    Returns bytes per launch of the kernels whose name matches the regular expression `kernel_match` (mean over those launches), or None when
     rocprofv3 is not available / a pass fails -- never a constant from another run."""
     import csv
     import glob
+    import re
     import shutil
     import subprocess
     import tempfile
@@ -340,7 +341,7 @@ def measure_traffic(argv_extra, kernel_match, out_dir=None):
             fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not fs:
                 return None
-            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(fs[0])) if kernel_match in row["Kernel_Name"]]
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(fs[0])) if re.search(kernel_match, row["Kernel_Name"])]
             if not vals:
                 return None
             res[counter] = sum(vals) / len(vals) * 1024.0     # KB -> bytes per launch
@@ -418,6 +419,7 @@ def main():
     if dry:
         os.environ["STRUMPACK_AMD_BACKEND"] = "gloo"
         os.environ["STRUMPACK_AMD_BENCH_NO_PMC"] = "1"
+        os.environ.setdefault("STRUMPACK_AMD_BENCH_COMM", "auto")   # (no RCCL on the emulator: the agreed fall-back is what is exercised)
         torch.cuda.synchronize = lambda *a_, **k_: None
     else:
         torch.cuda.set_device(local)
@@ -456,6 +458,9 @@ def main():
     comm = exch = None
     if world > 1:
         comm_mode = os.environ.get("STRUMPACK_AMD_BENCH_COMM", "rccl")
+        auto_comm = comm_mode == "auto"
+        if auto_comm:
+            comm_mode = "rccl"
         if comm_mode == "rccl" and a.sketch == "gaussian":
             # set the native path up and TRY it on a small matrix; every rank must succeed (agreement through
             # torch.distributed), otherwise all ranks take the torch callback path together
@@ -486,6 +491,14 @@ def main():
             t = torch.tensor([ok], device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if t.item() < 1.0:
+                # No silent fallback: a line that says "rccl" must have run on RCCL with one rank per GPU.  The torch
+                # callback path is taken only when asked for (STRUMPACK_AMD_BENCH_COMM=torch, or =auto: RCCL if it works).
+                if not auto_comm:
+                    if rank == 0:
+                        print("bench: native RCCL / sharded operand unavailable on some rank (%s); refusing to fall back "
+                              "(STRUMPACK_AMD_BENCH_COMM=auto or =torch selects the torch callback path)" % why, file=sys.stderr)
+                    dist.destroy_process_group()
+                    raise SystemExit(3)
                 if rank == 0:
                     print("bench: native RCCL / sharded operand unavailable on some rank (%s); using the torch callback path" % why, file=sys.stderr)
                 comm, comm_mode = None, "torch"
@@ -602,11 +615,12 @@ def main():
     traffic = tsrc = None
     if rank == 0 and world == 1 and a.sketch == "gaussian" and not os.environ.get("STRUMPACK_AMD_BENCH_INNER"):
         extra = ["--size", str(n), "--leaf", str(a.leaf), "--rel-tol", str(a.rel_tol), "--nrhs", str(a.nrhs)]
-        tmain = measure_traffic(extra, "true, 0>")   # the MAIN launches of the sketch: dgemm_kernel<192, (transposed), full tiles, group 0>
+        # the MAIN launches of both sketch products: sketch_kernel<rows / 64, transposed?, group 0>
+        tmain = measure_traffic(extra, r"sketch_kernel<\d, (true|false), 0>")
         if tmain is not None:
             traffic = tmain["bytes"]
             tsrc = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (one step each), main launches of "
-                    "dgemm_kernel<192, ., true, 0>: read %.1f GB (FETCH_SIZE x 2, the guide's gfx950 correction) + written %.2f GB per launch"
+                    "sketch_kernel<3, ., 0>: read %.1f GB (FETCH_SIZE x 2, the guide's gfx950 correction) + written %.2f GB per launch"
                     % (tmain["read_bytes"] * 1e-9, tmain["write_bytes"] * 1e-9))
     out = {
         "metric": "hss_compress_ulv_factor_solve_gflops", "value": value, "unit": "GFLOP/s", "n_gpus": world,
@@ -635,7 +649,7 @@ def main():
                              "GBps": (st2["b_mult"] + 16.0 * n * a.nrhs) / (apply_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); one launch, %d dependent levels" % H.levels()},
                    "solve": {"ms": solve_ms, "bytes": st2["b_solve"] + 16.0 * n * a.nrhs,
                              "GBps": (st2["b_solve"] + 16.0 * n * a.nrhs) / (solve_ms * 1e-3) * 1e-9, "bound": "hbm (8000 GB/s); two launches"}},
-        "roofline": {"kernel": "dgemm_kernel<192> (sketch S^T = R^T op(A), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+        "roofline": {"kernel": "sketch_kernel<3> (sketch S^T = R^T op(A): 192 x 128 tiles on 8 waves, operands by LDS DMA, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                      "traffic": traffic,
                      "traffic_source": tsrc, "algorithmic_bytes_per_launch": 8.0 * st["sketch_kernel_flops"] / launches / (2.0 * d) + 8.0 * d * n if d else None,

@@ -69,6 +69,8 @@ inline int cu_count() {
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
   return n > 0 ? n : 256;
 }
+// workgroups of one launch that are certain to be resident together (kernels whose workgroups wait for each other)
+inline int coresident_workgroups() { return cu_count(); }
 inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void set_device(int d) { HSSK_CHECK(hipSetDevice(d)); }
 inline bool is_device_pointer(const void* p) {

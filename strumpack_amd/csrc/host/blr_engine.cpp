@@ -196,6 +196,8 @@ void DeviceBLR::compress_tiles(const std::vector<std::pair<int, int>>& ij, const
     ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
     ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
     ck(hssk_memcpy_d2h(ctx_, hr.data(), ranks, (long long)sizeof(int) * cnt));
+    // (the cooperative ID's workgroups poll each other with a bounded spin; a timeout must not pass as a rank)
+    if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("BLR tile compression: ") + hssk_last_error());
   }
   std::vector<hssk_colgather_desc> gu;
   std::vector<hssk_basis_desc> bv;

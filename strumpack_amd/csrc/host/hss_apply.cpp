@@ -14,7 +14,7 @@ void DeviceHSS::shift(double sigma) {
     if (nd.leaf() && nd.D) d.push_back(hssk_shift_desc{nd.D, nd.m, nd.m});
   if (!d.empty()) ck(hssk_shift_diag(ctx_, d.data(), (int)d.size(), sigma));
   ck(hssk_sync(ctx_));
-  factored_ = partial_factored_ = schur_ready_ = false;  // the ULV factors are stale (examples/dense/testStructured.cpp:199)
+  invalidate_factors();  // the ULV factors are stale (examples/dense/testStructured.cpp:199)
   drop_plans();
 }
 
@@ -28,7 +28,7 @@ void DeviceHSS::shift_cplx(double re, double im) {
     }
   if (!d.empty()) ck(hssk_shift_diag_cplx(ctx_, d.data(), (int)d.size(), re, im));
   ck(hssk_sync(ctx_));
-  factored_ = partial_factored_ = schur_ready_ = false;
+  invalidate_factors();
   drop_plans();
 }
 

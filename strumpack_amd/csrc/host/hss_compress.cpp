@@ -28,7 +28,7 @@ void DeviceHSS::reset_compression() {
   dev_tree_ = nullptr;
   work_->reset();
   fact_->reset();
-  factored_ = false;
+  invalidate_factors();
   d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
 }
 
@@ -43,6 +43,7 @@ void DeviceHSS::restart_nodes(int d_have) {
   }
   persist_->reset();
   dev_tree_ = nullptr;
+  invalidate_factors();
   d_ranks_ = persist_->ints(2 * nodes_.size() + 2);
   if (d_have > 0) {
     std::vector<hssk_colgather_desc> cp;
@@ -642,6 +643,8 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   const int x_solved = hssk_id_solves_inline(id_dmax, id_mmax);
   std::vector<int> hall(cnt + std::max<size_t>(perm_total, 1));
   ck(hssk_memcpy_d2h(ctx_, hall.data(), rank_block, (long long)sizeof(int) * (cnt + perm_total)));
+  // (the cooperative ID's workgroups poll each other with a bounded spin; a timeout must not pass as a rank)
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("compress: interpolative decomposition: ") + hssk_last_error());
   const int* hranks = hall.data();
   const int* hperm = hall.data() + cnt;
   // commit, in the order that puts the device back to work first: (A) ranks -> final places of X -> the X solves are

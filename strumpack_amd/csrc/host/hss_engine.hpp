@@ -154,7 +154,7 @@ class DeviceHSS {
   void solve(int nrhs, double* b, long long ldb, bool on_device);
   void shift(double sigma);
   // back to the uncompressed state (tree kept): HSSMatrix::reset
-  void reset() { OpGuard g(op_mu_); reset_compression(); partial_factored_ = schur_ready_ = false; }
+  void reset() { OpGuard g(op_mu_); reset_compression(); }
   // the matrix is the real image [re -im; im re] (interleaved) of a complex one: adds the image of (re + i im) I
   void shift_cplx(double re, double im);
 
@@ -352,6 +352,9 @@ class DeviceHSS {
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
   int* d_ranks_ = nullptr;
   bool factored_ = false, partial_factored_ = false, schur_ready_ = false;
+  // every way the ULV factors die (shift, recompression, restart, reset): the whole matrix's, a child's (factor_node) and
+  // the partial factorization with its Schur factors go together -- a later solve / solve_node / Schur_update must refuse
+  void invalidate_factors() { factored_ = partial_factored_ = schur_ready_ = false; sub_factored_ = -1; }
   int sub_factored_ = -1;   // node whose subtree was ULV-factored as a matrix of its own (factor_node), -1: none
   std::unique_ptr<Arena> schur_;
   // device-resident node table of the extraction kernels (persist arena; rebuilt after a compression)

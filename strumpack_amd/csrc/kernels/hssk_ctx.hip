@@ -354,7 +354,14 @@ static hssk_rt::event_t watch_event(hssk_ctx* c) {
 int hssk_watch_start(hssk_ctx* c, int id) {
   HSSK_API_BEGIN
   if (id < 0 || id >= 8) throw std::invalid_argument("hssk_watch_start: id out of range");
-  if (c->watch_open[id]) throw std::logic_error("hssk_watch_start: stopwatch is already running");
+  if (c->watch_open[id]) {
+    // left open by a caller that threw between start and stop: the interval is dropped, the stopwatch starts over
+    auto p = c->watch[id].back();
+    c->watch[id].pop_back();
+    c->watch_free.push_back(p.first);
+    c->watch_free.push_back(p.second);
+    c->watch_open[id] = false;
+  }
   hssk_rt::event_t a = watch_event(c), b = watch_event(c);
   hssk_rt::event_record(a, c->stream);
   c->watch[id].emplace_back(a, b);

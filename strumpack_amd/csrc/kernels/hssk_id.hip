@@ -1319,13 +1319,9 @@ extern "C" int hssk_id_vbatched(hssk_ctx* ctx, const hssk_id_desc* descs, int co
     // panels of up to 256 rows and 512 columns: two or four workgroups per panel, its columns in their registers (id_group_kernel)
     static const bool no_group = [] { const char* e = std::getenv("HSSK_ID_NO_GROUP"); return e && e[0] == '1'; }();
     bool group_ok = !no_group && dmax > 128 && dmax <= 256 && mmax <= 512 && count >= 1;
-#ifdef HSSK_EMU
-    {   // (the emulator runs a launch's workgroups on a pool of host threads: the workgroups of a panel must be able to run together)
-      const char* e = std::getenv("HSSK_EMU_THREADS");
-      const int nt = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
-      group_ok = group_ok && std::min(nt, 16) >= 4;
-    }
-#endif
+    // (the workgroups of a panel poll each other: as many as share a panel must be able to run together -- any GPU; the
+    // test emulator with its pool of host threads answers for itself)
+    group_ok = group_ok && hssk_rt::coresident_workgroups() >= 4;
     if (group_ok) {
       const int RTv = dmax <= 192 ? 12 : 16;
       // 256 x 256 tiles: three workgroups of 96 columns hold the tile without spills (5.4 us per step against 10 with two of

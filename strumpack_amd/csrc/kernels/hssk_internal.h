@@ -112,9 +112,17 @@ struct hssk_ctx {
   // `scratch`, whose contents a caller may still need
   double* d_aux = nullptr;
   size_t aux_bytes = 0;
+  // every stream of the context idle: a buffer about to be freed may still be read by launches on the side stream
+  void sync_all() {
+    hssk_rt::sync(stream);
+    if (side_made) {
+      hssk_rt::sync(side);
+      if (on_side) hssk_rt::sync(main_saved);
+    }
+  }
   double* aux(size_t bytes) {
     if (bytes > aux_bytes) {
-      hssk_rt::sync(stream);
+      sync_all();
       hssk_rt::dev_free(d_aux);
       d_aux = (double*)hssk_rt::dev_malloc(bytes);
       aux_bytes = bytes;
@@ -123,7 +131,7 @@ struct hssk_ctx {
   }
   double* scratch(size_t bytes) {
     if (bytes > scratch_bytes) {
-      hssk_rt::sync(stream);
+      sync_all();
       hssk_rt::dev_free(d_scratch);
       d_scratch = (double*)hssk_rt::dev_malloc(bytes);
       scratch_bytes = bytes;

@@ -794,7 +794,15 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
     tmp_doubles += (size_t)NB * d.nrhs;
   }
   if (tris.empty()) return false;
-  double* aux = ctx->aux(sizeof(double) * (inv_doubles + tmp_doubles));
+  // While a plan is being recorded the launches below keep these addresses for every replay, and ctx->aux() frees and
+  // reallocates when a later call needs more (more right-hand sides): the recorded plan gets storage of its own instead.
+  double* aux;
+  if (ctx->recording) {
+    char* shadow = nullptr;
+    aux = (double*)ctx->recording->alloc(sizeof(double) * (inv_doubles + tmp_doubles), &shadow);
+  } else {
+    aux = ctx->aux(sizeof(double) * (inv_doubles + tmp_doubles));
+  }
   double* tmp0 = aux + inv_doubles;
   std::vector<hssk_trtri_desc> ti;
   for (auto& t : tris) {

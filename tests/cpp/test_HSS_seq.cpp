@@ -262,6 +262,16 @@ int main(int argc, char* argv[]) {
         if (!threw) { std::cout << "ERROR: child(1)->solve() on the factors of its child" << std::endl; return 1; }
       }
     }
+    // a shift kills the factors of a child as it kills the whole matrix's: solving on them afterwards is refused
+    {
+      auto c1 = H.child(1);
+      c1->factor();
+      H.shift(0.25);
+      bool threw = false;
+      try { DenseMatrix<double> t(n1, 1); c1->solve(t); } catch (const std::logic_error&) { threw = true; }
+      H.shift(-0.25);
+      if (!threw) { std::cout << "ERROR: child(1)->solve() on factors from before a shift" << std::endl; return 1; }
+    }
     // S^{-1} y is the lower part of H^{-1} [0; y]
     H.factor();
     DenseMatrix<double> rhs(m, 1);

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE ONLY.  CPU stand-in for strumpack_amd/csrc/hip/hssk_rt.h ("device" memory
 // is host memory, streams are no-ops).  See hssk_device.h in this directory.
 #pragma once
+#include <thread>
+#include <cstdlib>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +43,12 @@ inline void stream_wait_event(stream_t, event_t) {}
 inline void event_sync(event_t) {}
 inline bool is_pinned_host_pointer(const void*) { return false; }
 inline int cu_count() { return 256; }
+// the emulator runs a launch's workgroups on a pool of host threads (emu_runtime.cpp: at most 16)
+inline int coresident_workgroups() {
+  const char* e = std::getenv("HSSK_EMU_THREADS");
+  const int nt = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+  return nt < 16 ? nt : 16;
+}
 inline int device_count() { return 1; }
 inline void set_device(int) {}
 inline bool is_device_pointer(const void*) { return false; }

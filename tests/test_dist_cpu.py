@@ -148,3 +148,20 @@ def test_bench_rendezvous_dry_run(world):
     assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == world and d["steps"] == 1 and d["warmup"] == 1
     assert d["metric"] == "hss_compress_ulv_factor_solve_gflops" and d["config"]["n"] == 1500
     assert d["checks"]["solve_resid_H"] < 1e-10 and d["hss"]["levels"] >= 3
+
+
+def test_bench_refuses_silent_fallback():
+    """With the default process group (the library's RCCL communicator) a multi-rank bench run must not fall back to the torch
+    callback path on its own: where RCCL cannot be set up (here: the emulator build, gloo) every rank exits non-zero and no
+    line is printed -- a SCALE run can then never report a fall-back as RCCL."""
+    import emu_lib
+    emu_lib.build()
+    env = dict(os.environ, STRUMPACK_AMD_BENCH_DRYRUN_LIB=emu_lib.PATH, HSSK_EMU_THREADS="2", OMP_NUM_THREADS="2",
+               STRUMPACK_AMD_BENCH_COMM="rccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--size", "1500", "--leaf", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+    assert "refusing to fall back" in r.stderr + r.stdout
