@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--front-leaf", type=int, default=256, help="blr_front: tile size (the reference's BLR default)")
     p.add_argument("--front-lra", choices=["rrqr", "aca"], default="rrqr",
                    help="blr_front: tile compression (--blr_low_rank_algorithm; the reference's default and BASELINE's: RRQR)")
+    p.add_argument("--operand", choices=["resident", "generated"], default="resident",
+                   help="toeplitz workload: 'resident' = A stored in HBM before the clock starts (BASELINE's configuration); 'generated' = A "
+                        "is the library's Toeplitz formula, evaluated inside the sketch kernel and never stored (SPX_d_struct_from_generator)")
     p.add_argument("--workload", choices=["toeplitz", "kernel", "host", "blr_front"], default="toeplitz",
                    help="toeplitz = BASELINE configs[2] (headline, default); kernel = configs[3]: Gaussian-kernel matrix over "
                         "synthetic points in R^8 (kernel ridge regression fit), reported as a secondary line; host = the headline "
@@ -507,7 +510,11 @@ def main():
         if comm is None:
             exch = sdist.make_exchange(L, world, rank)
     # ---- inputs resident in HBM before the clock starts: dense A (column-major) and the rhs
-    if comm is not None:
+    generated = a.operand == "generated"
+    if generated:
+        if a.sketch != "gaussian":
+            raise SystemExit("--operand generated: the SJLT sketch streams a stored matrix")
+    elif comm is not None:
         lo, hi = sdist.shard_range(L, n, opts, world, rank)
         dAr = hk.empty((hi - lo, n))
         dAc = hk.empty((n, hi - lo))
@@ -522,7 +529,9 @@ def main():
     hk.sync()
 
     def step():
-        if comm is not None:
+        if generated:   # the operand is the library's Toeplitz formula: evaluated inside the sketch kernel on every rank
+            H = sdist.from_generator(L, n, 1, opts, hopts, comm=comm, exchange_cb=exch)
+        elif comm is not None:
             H = sdist.from_blocks_device(L, dAr.ptr, hi - lo, dAc.ptr, n, n, opts, hopts, comm=comm)
         else:
             H = sdist.from_dense_device(L, dA.ptr, n, n, opts, hopts, exch)
@@ -614,9 +623,9 @@ def main():
     # HBM bytes of the dominant kernel's launches, from counter passes of this very command (None without rocprofv3)
     traffic = tsrc = None
     if rank == 0 and world == 1 and a.sketch == "gaussian" and not os.environ.get("STRUMPACK_AMD_BENCH_INNER"):
-        extra = ["--size", str(n), "--leaf", str(a.leaf), "--rel-tol", str(a.rel_tol), "--nrhs", str(a.nrhs)]
+        extra = ["--size", str(n), "--leaf", str(a.leaf), "--rel-tol", str(a.rel_tol), "--nrhs", str(a.nrhs), "--operand", a.operand]
         # the MAIN launches of both sketch products: sketch_kernel<rows / 64, transposed?, group 0>
-        tmain = measure_traffic(extra, r"sketch_kernel<\d, (true|false), 0>")
+        tmain = measure_traffic(extra, r"sketch_kernel<\d, (true|false), 0, (true|false)>")
         if tmain is not None:
             traffic = tmain["bytes"]
             tsrc = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (one step each), main launches of "
@@ -631,8 +640,11 @@ def main():
                                % (n, n, "Philox samples" if a.sketch == "gaussian" else "SJLT sketch, nnz=4: NOT the configuration of BASELINE's metric",
                                   a.leaf, a.rel_tol, a.nrhs),
                    "sketch": a.sketch, "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
+                   "operand": ("generated: A is the library's Toeplitz formula, its tiles evaluated inside the sketch kernel -- never stored "
+                               "(SPX_d_struct_from_generator; bitwise the compression of the stored matrix); NOT BASELINE's configuration, which holds A in HBM"
+                               if generated else "resident in HBM before the clock starts"),
                    "parallelism": "1 GPU" if world == 1 else "HSS tree partitioned by subtree over %d GPUs (sketch rows, compression, ULV, sweeps local; RCCL all-gathers of the cut-level blocks; top %d nodes replicated)" % (world, world - 1),
-                   "comm": {"single": "none", "rccl": "native RCCL communicator inside the library, collectives on the engine's stream; operand sharded (row block + column block per rank)",
+                   "comm": {"single": "none", "rccl": "native RCCL communicator inside the library, collectives on the engine's stream; operand " + ("generated on every rank" if generated else "sharded (row block + column block per rank)"),
                             "torch": "torch.distributed all-gather callback; operand replicated on every rank"}[comm_mode],
                    "rccl_nranks": world if comm_mode == "rccl" else 0},
         # per-phase wall times: the median over the timed steps (a single step's host-side phases are noisy)
@@ -652,7 +664,7 @@ def main():
         "roofline": {"kernel": "sketch_kernel<3> (sketch S^T = R^T op(A): 192 x 128 tiles on 8 waves, operands by LDS DMA, v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                      "traffic": traffic,
-                     "traffic_source": tsrc, "algorithmic_bytes_per_launch": 8.0 * st["sketch_kernel_flops"] / launches / (2.0 * d) + 8.0 * d * n if d else None,
+                     "traffic_source": tsrc, "algorithmic_bytes_per_launch": ((16.0 * d * n if generated else 8.0 * st["sketch_kernel_flops"] / launches / (2.0 * d) + 8.0 * d * n) if d else None),
                      "avg_launch_ms": avg_ms, "launches_per_step": launches, "flops_per_launch": flops_per_launch},
     }
     if dry:

@@ -142,6 +142,26 @@ int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long long k, doubl
                const double* A, long long lda, const double* B, long long ldb, double beta,
                double* C, long long ldc);
 
+/* ---- operands given by a formula: the matrix is never stored ---------------------------------
+ * (the reference's counterpart: the blocked sampler that evaluates tiles of an element routine on the fly,
+ * structured/StructuredMatrix.cpp:214-262; here the tiles are evaluated INSIDE the sketch kernel, straight into the LDS
+ * image the matrix cores read, so the sketch of a generated matrix moves no N x N bytes at all.)
+ * kind HSSK_GEN_TOEPLITZ: G(i,j) = 1/(1+|i-j|) (test/test_HSS_seq.cpp:75-78); HSSK_GEN_TOEPLITZ_UPPER: its upper triangle
+ * (:86-90) -- bit for bit the entries hssk_fill_toeplitz writes. */
+#define HSSK_GEN_TOEPLITZ 1
+#define HSSK_GEN_TOEPLITZ_UPPER 2
+typedef struct hssk_gen {
+  int kind, reserved;
+  double p[4]; /* parameters of later kinds */
+} hssk_gen;
+/* hssk_dgemm with op(B)(kk, j) = transG ? G(j0 + j, kk) : G(kk, j0 + j), kk in [0, k), j in [0, n): same tiles, same
+ * K-split and summation order as hssk_dgemm on the stored matrix -- the results are bitwise those of the dense route. */
+int hssk_sketch_gen(hssk_ctx* ctx, const hssk_gen* g, int transG, int m, long long n, long long k, long long j0, double alpha,
+                    const double* A, long long lda, double beta, double* C, long long ldc);
+/* A(il, jl) = trans ? G(j0 + jl, i0 + il) : G(i0 + il, j0 + jl) for a rows x cols block (leading dimension lda) */
+int hssk_gen_fill(hssk_ctx* ctx, const hssk_gen* g, double* A, long long rows, long long cols, long long lda, long long i0,
+                  long long j0, int trans);
+
 /* ---- variable-size batched GEMM on FP64 MFMA ------------------------------------------------ */
 /* C_i(m x n) = alpha * op(A_i) * op(B_i) + beta * C_i  -- every small gemm() of
  * HSS/HSSMatrix.{compress,factor,solve,apply}.hpp (dense/DenseMatrix.cpp:935-1023). */
@@ -241,6 +261,8 @@ typedef struct hssk_elem_desc {
   int rlo, rhi, clo, chi;
 } hssk_elem_desc;
 int hssk_gather_elems(hssk_ctx* ctx, const hssk_elem_desc* descs, int count);
+/* B(i,j) = G(I[i], J[j]): hssk_gather_elems with the matrix replaced by the formula (descs[].A / lda are ignored) */
+int hssk_gen_elems(hssk_ctx* ctx, const hssk_gen* g, const hssk_elem_desc* descs, int count);
 /* out[0:count) = sum over g < nslab of slabs[g * stride + (0:count)]  (partial blocks of several ranks after an all-gather) */
 int hssk_sum_slabs(hssk_ctx* ctx, const double* slabs, long long count, long long stride, int nslab, double* out);
 /* dst = src^T : rows x cols (src, lds) -> cols x rows (dst, ldd) */

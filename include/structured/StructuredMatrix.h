@@ -141,6 +141,15 @@ int SPX_struct_shard_range(int n, const CSPOptions* opts, int world, int rank, i
 /* replicated operand (every rank passes the whole dA), native communicator */
 int SPX_d_struct_from_dense_device_comm(CSPStructMat* S, int rows, int cols, const double* dA, long long ldA,
                                         const CSPOptions* opts, const SPXHSSOptions* h, SPXComm comm);
+/* The matrix is one of the library's FORMULAS (kind: HSSK_GEN_TOEPLITZ = 1, 1/(1+|i-j|), the reference's test matrix;
+ * HSSK_GEN_TOEPLITZ_UPPER = 2, its upper triangle): it is never stored -- the sketch kernel evaluates the tiles of the
+ * operand it multiplies (the reference's blocked sampler over an element routine, structured/StructuredMatrix.cpp:214-262,
+ * moved into the GEMM), scattered entries come from the formula.  Bit for bit the matrix SPX_d_struct_from_dense_device
+ * builds from the stored operand.  _comm / _sharded: one process per GPU, no operand shards at all. */
+int SPX_d_struct_from_generator(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h);
+int SPX_d_struct_from_generator_comm(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h, SPXComm comm);
+int SPX_d_struct_from_generator_sharded(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h,
+                                        int world, int rank, SPXAllGatherFn allgather, void* user);
 /* SHARDED operand: this rank passes only its blocks (DEVICE pointers, column-major): dArows = A(lo:hi, :) ((hi-lo) x cols,
  * ldr) and dAcols = A(:, lo:hi) (rows x (hi-lo), ldc).  dArows may be NULL -- a column-sharded operator: the contributions
  * A(:, cols_g) R(cols_g, :) of all ranks to Sr are then summed to the owners of the rows (reduce-scatter).  No rank ever

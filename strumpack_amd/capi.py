@@ -32,6 +32,7 @@ SP_SYMBOLS = [
     "SPX_d_struct_from_dense_and_factor", "SPX_comm_unique_id", "SPX_comm_create", "SPX_comm_destroy", "SPX_comm_size", "SPX_comm_rank", "SPX_comm_selftest", "SPX_struct_shard_range",
     "SPX_d_struct_from_dense_device_comm", "SPX_d_struct_from_blocks_device", "SPX_d_struct_from_blocks_device_cb",
     "SPX_d_struct_from_kernel_comm",
+    "SPX_d_struct_from_generator", "SPX_d_struct_from_generator_comm", "SPX_d_struct_from_generator_sharded",
     "SPX_d_struct_extract_blocks",
     "SPX_d_blr_front_factor", "SPX_d_blr_front_factor_device", "SPX_d_blr_front_time_phases", "SPX_blr_low_rank_algorithm", "SPX_d_blr_front_forward",
     "SPX_d_blr_front_backward", "SPX_d_blr_front_schur", "SPX_d_blr_front_schur_device", "SPX_d_blr_front_tile_ranks",
@@ -92,6 +93,10 @@ def load(path):
                                                      ALLGATHER_CB, vp]
     L.SPX_d_struct_from_kernel_comm.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_int,
                                                 C.POINTER(CSPOptions), C.c_int, C.c_int, vp, vp]
+    L.SPX_d_struct_from_generator.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions)]
+    L.SPX_d_struct_from_generator_comm.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions), vp]
+    L.SPX_d_struct_from_generator_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(CSPOptions), C.POINTER(SPXHSSOptions),
+                                                      C.c_int, C.c_int, ALLGATHER_CB, vp]
     L.SPX_d_struct_mult_device.argtypes = [vp, C.c_char, C.c_int, dp, C.c_longlong, dp, C.c_longlong]
     L.SPX_d_struct_solve_device.argtypes = [vp, C.c_int, dp, C.c_longlong]
     L.SPX_d_struct_node_info.argtypes = [vp, C.POINTER(C.c_int)]
@@ -307,6 +312,14 @@ class StructuredMatrix:
                                                 C.byref(hss) if hss is not None else None)
         if rc:
             raise RuntimeError("SPX_d_struct_from_dense_device failed")
+        return cls(lib, h, n)
+
+    @classmethod
+    def from_generator(cls, lib, n, kind, opts, hss=None):
+        """the matrix is one of the library's formulas (kind 1: Toeplitz 1/(1+|i-j|), 2: its upper triangle): never stored"""
+        h = C.c_void_p()
+        if lib.SPX_d_struct_from_generator(C.byref(h), n, kind, C.byref(opts), C.byref(hss) if hss is not None else None):
+            raise RuntimeError("SPX_d_struct_from_generator failed")
         return cls(lib, h, n)
 
     @classmethod

@@ -132,6 +132,12 @@ __device__ __forceinline__ double hssk_from_bits(unsigned long long b) { return 
 __device__ __forceinline__ unsigned hssk_fbits(float v) { return __float_as_uint(v); }
 // instruction-scheduling fence: nothing is moved across it
 __device__ __forceinline__ void hssk_sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
+// request to the instruction scheduler: the next `n` instructions of class MASK of this scheduling region go here
+// (__builtin_amdgcn_sched_group_barrier; classes: matrix core, vector ALU incl. transcendental, LDS write)
+#define HSSK_SG_MFMA 0x008
+#define HSSK_SG_VALU 0x002
+#define HSSK_SG_DSWRITE 0x200
+template <int MASK, int N> __device__ __forceinline__ void hssk_sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }
 __device__ __forceinline__ void hssk_drain_stores() { __builtin_amdgcn_s_waitcnt(0); }
 __device__ __forceinline__ void hssk_pause() { __builtin_amdgcn_s_sleep(2); }
 

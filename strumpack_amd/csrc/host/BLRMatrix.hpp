@@ -57,7 +57,8 @@ template <typename scalar_t> class BLROptions : public structured::StructuredOpt
   //    same point (BLR/BLRMatrix.cpp:838-990) -- the reference's own RL and LL runs agree bit for bit on the test fronts.
   //  * COMB / STAR (LUAR, :991-1140) schedule the SAME factorization differently: the low-rank updates of a tile are
   //    accumulated and recompressed before they are subtracted (a cache optimisation of the CPU code; the compression kernel
-  //    option picks the recompression).  Here they run the RL schedule -- dense updates are what the matrix cores are fast
+  //    option picks the recompression).  Here they run the RL schedule, and SAY SO (a warning on stderr, once per process:
+  //    check_supported) -- dense updates are what the matrix cores are fast
   //    at -- and the result sits inside the spread the reference's own variants show against each other (tile ranks up
   //    to 2 apart on ~3 % of the tiles of the test fronts, Schur complements equal to the tolerance): fixtures of the
   //    reference's STAR and COMB runs are checked with RL's tolerances (tests/blr_cases.py).  COLWISE (the fronts'
@@ -67,6 +68,16 @@ template <typename scalar_t> class BLROptions : public structured::StructuredOpt
       throw std::invalid_argument("BLR: RRQR and ACA tile compression are available (BACA is not)");
     if (blr_algo_ == BLRFactorAlgorithm::COLWISE)
       throw std::invalid_argument("BLR: the COLWISE factorization mode is not available (RL, LL, Comb and Star are)");
+    if (blr_algo_ == BLRFactorAlgorithm::COMB || blr_algo_ == BLRFactorAlgorithm::STAR) {
+      // said out loud, once per process: the selection changes nothing here
+      static bool told = false;
+      if (!told) {
+        told = true;
+        std::cerr << "# WARNING: --blr_factor_algorithm " << (blr_algo_ == BLRFactorAlgorithm::COMB ? "Comb" : "Star")
+                  << ": the accumulate-and-recompress (LUAR) schedule is not built for the GPU; the factorization runs with dense\n"
+                  << "#          Schur updates (the RL / LL result, inside the reference's own spread between its variants).\n";
+      }
+    }
   }
   // --blr_* flags of the reference (BLR/BLROptions.cpp:78-197)
   void set_from_command_line(int argc, const char* const* argv) override {

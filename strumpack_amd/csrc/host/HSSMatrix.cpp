@@ -153,6 +153,19 @@ void HSSMatrix<double>::compress_device_sharded(const double* dA, long long lda,
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
   eng_->compress_dense_device(dA, lda);
 }
+void HSSMatrix<double>::compress_generator(int kind, const opts_t& opts) {
+  make_engine(opts, tree_.get());
+  hssk_gen g{kind, 0, {0., 0., 0., 0.}};
+  eng_->compress_generator(g);
+}
+void HSSMatrix<double>::compress_generator(int kind, const opts_t& opts, const CommSpec& pg) {
+  owner("compress");
+  EngineOptions e = engine_options(opts);
+  pg.apply(e);
+  eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
+  hssk_gen g{kind, 0, {0., 0., 0., 0.}};
+  eng_->compress_generator(g);
+}
 void HSSMatrix<double>::compress_device_blocks(const double* dRows, long long ldr, const double* dCols, long long ldc,
                                                const opts_t& opts, const CommSpec& pg) {
   owner("compress");

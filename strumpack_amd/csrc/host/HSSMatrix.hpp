@@ -84,6 +84,10 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   // A(:, lo:hi), [lo, hi) = shard_range(pg.rank)
   void compress_device_blocks(const double* dRows, long long ldr, const double* dCols, long long ldc, const opts_t& opts,
                               const CommSpec& pg);
+  // extension: the matrix is one of the library's formulas (hssk_gen kinds, include/hssk.h) -- never stored; with a process
+  // group every rank evaluates what its subtree needs (no operand shards, no exchange beyond the cut nodes')
+  void compress_generator(int kind, const opts_t& opts);
+  void compress_generator(int kind, const opts_t& opts, const CommSpec& pg);
   HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, const CommSpec& pg);
 
   std::size_t rows() const override { return rows_; }

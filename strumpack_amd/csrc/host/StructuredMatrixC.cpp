@@ -403,6 +403,32 @@ int SPX_d_struct_from_dense_device_comm(CSPStructMat* S, int rows, int cols, con
   *S = s.release();
   SP_CATCH
 }
+// the matrix is a formula of the library's (hssk_gen kinds): never stored, on one rank or, with a communicator, on many
+static int from_generator(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h, const HSS::CommSpec* pg) {
+  SP_TRY
+  if (opts->type != SP_TYPE_HSS) throw std::invalid_argument("SPX_d_struct_from_generator requires type SP_TYPE_HSS");
+  if (kind != HSSK_GEN_TOEPLITZ && kind != HSSK_GEN_TOEPLITZ_UPPER) throw std::invalid_argument("SPX_d_struct_from_generator: unknown generator kind");
+  auto ho = get_hss_options(opts, h);
+  std::unique_ptr<HSS::HSSMatrix<double>> H(new HSS::HSSMatrix<double>(n, n, ho));
+  if (pg) H->compress_generator(kind, ho, *pg);
+  else H->compress_generator(kind, ho);
+  std::unique_ptr<CStructMat> s(new CStructMat);
+  s->S.reset(H.release());
+  *S = s.release();
+  SP_CATCH
+}
+int SPX_d_struct_from_generator(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h) {
+  return from_generator(S, n, kind, opts, h, nullptr);
+}
+int SPX_d_struct_from_generator_comm(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h, SPXComm comm) {
+  const HSS::CommSpec pg = native_group(comm);
+  return from_generator(S, n, kind, opts, h, &pg);
+}
+int SPX_d_struct_from_generator_sharded(CSPStructMat* S, int n, int kind, const CSPOptions* opts, const SPXHSSOptions* h,
+                                        int world, int rank, SPXAllGatherFn allgather, void* user) {
+  const HSS::CommSpec pg = callback_group(world, rank, allgather, user);
+  return from_generator(S, n, kind, opts, h, &pg);
+}
 int SPX_d_struct_from_kernel(CSPStructMat* S, int n, int d, double* points, int ktype, double h, double lambda, int p,
                              const CSPOptions* opts, int clustering, int neighbors, int* perm) {
   return SPX_d_struct_from_kernel_sharded(S, n, d, points, ktype, h, lambda, p, opts, clustering, neighbors, perm, 1, 0, nullptr, nullptr);

@@ -62,6 +62,7 @@ DeviceBLR::DeviceBLR(int m, const std::vector<int>& rowtiles, int n, const std::
   ck(hssk_ctx_create(&ctx_, o_.device));
   store_.reset(new Arena2(size_t(256) << 20));
   tmp_.reset(new Arena2(size_t(256) << 20));
+  blk_.reset(new Arena2(size_t(256) << 20));
   tiles_.assign((size_t)rowblocks() * colblocks(), Tile());
 }
 
@@ -70,6 +71,7 @@ DeviceBLR::~DeviceBLR() {
   if (ctx_) hssk_sync(ctx_);
   store_.reset();
   tmp_.reset();
+  blk_.reset();
   if (dA_) hssk_free(dA_);
   hssk_ctx_destroy(ctx_);
 }
@@ -337,6 +339,14 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   for (int i = 0; i < rb; i++) adm_nd[(size_t)i + (size_t)i * rb] = 0;
   invL_.assign(rb, nullptr);
   invU_.assign(rb, nullptr);
+  // look-ahead of the Schur updates (below): block steps per deferred update of the trailing array; 1 = every step updates
+  // everything (the right-looking schedule as written)
+  const int la = [] { const char* e = std::getenv("STRUMPACK_AMD_BLR_LOOKAHEAD"); return e ? std::max(1, std::atoi(e)) : 8; }();
+  const bool defer = la > 1;
+  struct Pending { int p; double* T; int ldT; std::vector<int> off; };   // step, its product T_p (rows > p), column offset of tile (p, j) at [j - p - 1]
+  std::vector<Pending> pend;
+  int b0 = 0, b1 = std::min(la, nsteps);
+  blk_->rewind();
   for (int i = 0; i < nsteps; i++) {
     tmp_->rewind();
     const int mi = tm(i);
@@ -405,9 +415,18 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
     // ---- Schur update of the trailing array, always into full rank (BLRMatrix.cpp:160-175):
     //   A_kj -= U_ki (V_ki^T U_ij) V_ij^T  for k, j > i, as three batched GEMMs over the block column / row:
     //   G_k = V_ki^T [U_i,i+1 .. U_i,rb)  (r_ki x R);  T(k rows, :) = U_ki G_k;  A(i+1:, j cols) -= T(:, R_j) V_ij^T
+    // Applied step by step, the last product reads and writes the WHOLE trailing array once per block step (16 bytes per
+    // 2 r flops at tile rank r: HBM-bound, and most of a large front's time).  The steps are therefore taken in blocks of
+    // `la` (look-ahead): inside a block a step updates at once only what the block's own later steps need -- the block
+    // columns (i, b1) in full and the block rows (i, b1) of the other columns -- and keeps T_i; after the block's last step
+    // the rest of the array (rows and columns >= b1) receives all `la` updates in ONE product per block column,
+    // A(b1:, j) -= [T_b0(:, R_b0,j) | ... | T_b1-1(:, R_b1-1,j)] [V_b0,j | ... | V_b1-1,j]^T: read and written once per block,
+    // with an inner dimension la times as long (the same sums in another order: left-looking inside the trailing part).
+    if (i == b1) { b0 = b1; b1 = std::min(b0 + la, nsteps); }
+    (void)b0;
     const int nrest = m_ - roff_[i + 1];
     if (R > 0 && nrest > 0) {
-      double* T = tmp_->dbl((size_t)nrest * R);
+      double* T = (defer ? blk_ : tmp_)->dbl((size_t)nrest * R);
       std::vector<hssk_gemm_desc> gG, gT, gF;
       for (int k = i + 1; k < rb; k++) {
         Tile& t = tile(k, i);
@@ -421,15 +440,20 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
           gT.push_back(hssk_gemm_desc{Trow, Trow, Trow, mk, R, 0, nrest, nrest, nrest, 0, 0, 0.0, 0.0});   // zero block
         }
       }
+      const int rows_now = defer ? roff_[b1] - roff_[i + 1] : nrest;   // rows of the columns >= b1 that cannot wait
+      Pending pd{i, T, nrest, {}};
       int off = 0;
       for (int j = i + 1; j < rb; j++) {
         Tile& t = tile(i, j);
         const int nj = tn(j);
-        if (t.r > 0 && nj > 0)
-          gF.push_back(hssk_gemm_desc{T + (size_t)off * nrest, t.V, dA_ + roff_[i + 1] + (size_t)coff_[j] * ld_, nrest, nj, t.r,
+        const int rows = (!defer || j < b1) ? nrest : rows_now;
+        if (t.r > 0 && nj > 0 && rows > 0)
+          gF.push_back(hssk_gemm_desc{T + (size_t)off * nrest, t.V, dA_ + roff_[i + 1] + (size_t)coff_[j] * ld_, rows, nj, t.r,
                                       nrest, nj, (int)ld_, 0, 1, -1.0, 1.0});
+        pd.off.push_back(off);
         off += t.r;
       }
+      if (defer) pend.push_back(std::move(pd));
       watch(3, true);
       if (!gG.empty()) ck(hssk_gemm_vbatched(ctx_, gG.data(), (int)gG.size()));
       if (!gT.empty()) ck(hssk_gemm_vbatched(ctx_, gT.data(), (int)gT.size()));
@@ -442,6 +466,42 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
           b_schur += 8.0 * ((double)d.m * d.k + (double)d.k * d.n + (d.beta != 0.0 ? 2.0 : 1.0) * d.m * (double)d.n);
         }
     }
+    if (defer && i + 1 == b1) {
+      // ---- the block's deferred updates: rows and columns >= b1
+      const int r0 = roff_[b1], nrows = m_ - r0;
+      std::vector<hssk_colgather_desc> cp;
+      std::vector<hssk_gemm_desc> gD;
+      if (nrows > 0)
+        for (int j = b1; j < rb; j++) {
+          const int nj = tn(j);
+          int K = 0;
+          for (auto& q : pend) K += tile(q.p, j).r;
+          if (K <= 0 || nj <= 0) continue;
+          double* Tcat = blk_->dbl((size_t)nrows * K);
+          double* Vcat = blk_->dbl((size_t)nj * K);
+          int col = 0;
+          for (auto& q : pend) {
+            const Tile& t = tile(q.p, j);
+            if (t.r <= 0) continue;
+            cp.push_back(hssk_colgather_desc{q.T + (r0 - roff_[q.p + 1]) + (size_t)q.off[j - q.p - 1] * q.ldT, Tcat + (size_t)col * nrows, nullptr,
+                                             nrows, t.r, q.ldT, nrows, 0});
+            cp.push_back(hssk_colgather_desc{t.V, Vcat + (size_t)col * nj, nullptr, nj, t.r, nj, nj, 0});
+            col += t.r;
+          }
+          gD.push_back(hssk_gemm_desc{Tcat, Vcat, dA_ + r0 + (size_t)coff_[j] * ld_, nrows, nj, K, nrows, nj, (int)ld_, 0, 1, -1.0, 1.0});
+        }
+      watch(3, true);
+      if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+      if (!gD.empty()) ck(hssk_gemm_vbatched(ctx_, gD.data(), (int)gD.size()));
+      watch(3, false);
+      schur_launches += !gD.empty();
+      for (auto& d : gD) {
+        f_schur += 2.0 * d.m * (double)d.n * d.k;
+        b_schur += 8.0 * (3.0 * (double)d.m * d.k + 3.0 * (double)d.k * d.n + 2.0 * d.m * (double)d.n);   // (the gathered operands: read, written, read)
+      }
+      pend.clear();
+      blk_->rewind();
+    }
   }
   f_total += f_schur;
   if (time_phases)
@@ -453,6 +513,7 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   for (int i = 0; i < nsteps; i++)
     if (hinfo[i] > 0) throw std::runtime_error("BLR factorization: zero pivot in diagonal tile " + std::to_string(i));
   compressed_ = factored_ = true;
+  blk_.reset(new Arena2(size_t(256) << 20));   // (the block products of a large front are gigabytes: not kept)
   t_factor = now() - t0;
 }
 

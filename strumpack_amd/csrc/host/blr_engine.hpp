@@ -135,7 +135,7 @@ class DeviceBLR {
   int* dpiv_ = nullptr;    // pivots of the diagonal tiles (0-based, local), rows() ints
   std::vector<const double*> invL_, invU_;   // per block step: inverted 64 x 64 diagonal blocks of the tile's L and U (tiles of >= 128 rows; else null)
   std::vector<Tile> tiles_;
-  std::unique_ptr<Arena2> store_, tmp_;
+  std::unique_ptr<Arena2> store_, tmp_, blk_;   // blk_: products kept for a block of steps (deferred Schur updates, factor_rl)
   bool compressed_ = false, factored_ = false;
   int nsteps_ = 0;   // eliminated block steps (== rowblocks() for a full factorization)
 };

@@ -127,6 +127,10 @@ class DeviceHSS {
   // dRows = A(lo:hi, :) ((hi-lo) x n, ldr) or null, dCols = A(:, lo:hi) (n x (hi-lo), ldc).  Without the row block
   // the operator is column-sharded: Sr = sum_g A(:, cols_g) R(cols_g, :) is reduced over the ranks.
   void compress_dense_device_sharded(const double* dRows, long long ldr, const double* dCols, long long ldc);
+  // A given by one of the library's formulas (hssk_gen, include/hssk.h): never stored, on any number of ranks -- the sketch
+  // kernel evaluates its tiles of the operand itself, scattered entries come from the formula (the reference's blocked
+  // sampler over an element routine, structured/StructuredMatrix.cpp:214-262, taken to its end)
+  void compress_generator(const hssk_gen& g);
   // rows / columns [lo, hi) owned by `rank` (its subtree below the cut); false if the tree cannot be cut for this world size
   bool shard_range(int rank, int& lo, int& hi) const;
   void compress_callbacks(const host_mult_t& mult, const host_elem_t& elem);  // matrix-free
@@ -260,6 +264,7 @@ class DeviceHSS {
   struct HostBlockSource;
   struct ShardedDenseSource;
   struct CallbackSource;
+  struct GeneratorSource;
 
   void build_tree(const structured::ClusterTree* tree);
   void compress(Source& src);

@@ -387,9 +387,57 @@ struct DeviceHSS::CallbackSource : DeviceHSS::Source {
   }
 };
 
+// Operand given by a formula (hssk_gen): nothing is stored, on one rank or many.  Sampling = the sketch GEMM whose second
+// operand is evaluated inside the kernel (same ranges, stats and collectives as the dense operand resident in HBM, whose
+// results it reproduces bit for bit); scattered entries = the formula at the requested indices.
+struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
+  hssk_gen g;
+  explicit GeneratorSource(const hssk_gen& g_) : g(g_) {}
+  void sample(DeviceHSS& H, int r0, int dn) override {
+    if (H.sj_pat_) throw std::invalid_argument("generated operand: the SJLT sketch streams a stored matrix; use the Gaussian sketch");
+    const long long N = H.n_;
+    long long j0 = 0, j1 = N;
+    if (H.dist_subtree_) {
+      const Node& c = H.nodes_[H.cut_nodes_[H.o_.rank]];
+      j0 = c.lo; j1 = c.lo + c.m;
+    } else if (H.o_.world > 1) {
+      j0 = std::min(N, H.cols_per_rank_ * H.o_.rank); j1 = std::min(N, j0 + H.cols_per_rank_);
+    }
+    const long long nloc = j1 - j0;
+    auto timed = [&] {
+      ck(hssk_sync(H.ctx_));
+      const float ms = hssk_last_dgemm_ms(H.ctx_);
+      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
+    };
+    if (nloc > 0) {
+      // Sr(j0:j1, :) = A(j0:j1, :) R  ->  op(G)(k, j) = G(j0 + j, k);   Sc(j0:j1, :) = A(:, j0:j1)^T R  ->  op(G)(k, j) = G(k, j0 + j)
+      ck(hssk_sketch_gen(H.ctx_, &g, 1, dn, nloc, N, j0, 1.0, H.Rt_ + r0, H.dcap_, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
+      timed();
+      ck(hssk_sketch_gen(H.ctx_, &g, 0, dn, nloc, N, j0, 1.0, H.Rt_ + r0, H.dcap_, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
+      timed();
+    }
+    if (H.o_.world > 1 && !H.dist_subtree_) {
+      const long long bytes = (long long)sizeof(double) * H.dcap_ * H.cols_per_rank_;
+      H.comm(H.Srt_, bytes);
+      H.comm(H.Sct_, bytes);
+    }
+  }
+  void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) override {
+    std::vector<hssk_elem_desc> d;
+    d.reserve(reqs.size());
+    for (auto& r : reqs)
+      if (r.m > 0 && r.n > 0) d.push_back(hssk_elem_desc{nullptr, 0, r.dI, r.dJ, r.i0, r.j0, r.dB, r.m, r.n, r.ldb, 0});
+    if (!d.empty()) ck(hssk_gen_elems(H.ctx_, &g, d.data(), (int)d.size()));
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // compression driver
 // ---------------------------------------------------------------------------------------------
+void DeviceHSS::compress_generator(const hssk_gen& g) {
+  GeneratorSource s(g);
+  compress(s);
+}
 void DeviceHSS::compress_dense_device(const double* dA, long long lda) {
   DenseDeviceSource s(dA, lda);
   compress(s);

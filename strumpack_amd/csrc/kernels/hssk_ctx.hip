@@ -273,6 +273,16 @@ void hssk_ctx_destroy(hssk_ctx* c) {
       if (c->uploader) c->uploader->release_slots();
       c->ring_off = 0;
       c->dgemm_timed = false;
+      // a context abandoned in the middle of something (an exception between a stopwatch's start and stop, or inside a
+      // side-stream section) goes back to the pool in its neutral state
+      if (c->on_side) { c->stream = c->main_saved; c->on_side = false; }
+      for (int i = 0; i < 8; i++) {
+        for (auto& p : c->watch[i]) { c->watch_free.push_back(p.first); c->watch_free.push_back(p.second); }
+        c->watch[i].clear();
+        c->watch_open[i] = false;
+      }
+      c->recording = nullptr;
+      c->require_mma = false;
       g_pool.push_back(c);
       return;
     }
@@ -281,6 +291,7 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   hssk_rt::dev_free(c->d_ring);
   hssk_rt::dev_free(c->d_scratch);
   hssk_rt::dev_free(c->d_aux);
+  hssk_rt::dev_free(c->d_gen);
   delete c->uploader;
   hssk_rt::pinned_free(c->h_sweep_err);
   for (auto& w : c->watch) for (auto& p : w) { hssk_rt::event_destroy(p.first); hssk_rt::event_destroy(p.second); }

@@ -16,6 +16,7 @@
 // second kernel reduces them in fixed order) so that the workgroup count fills 256 CUs evenly.
 #include "hssk_device.h"
 #include "hssk_internal.h"
+#include "hssk_gen.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -259,16 +260,25 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
 //    pairs sit at pair ^ ((j >> 1) & 7) -- both conflict-free for ds_read_b64.  The k index a lane group l4 feeds to
 //    MFMA sub-step s is pi(s, l4) = 2 s + (l4 & 1) + 8 (l4 >> 1) for BOTH operands (any bijection does: the sum over
 //    k is what it is), which is what lets one 16-byte piece of the k-contiguous operand serve two lane groups.
-template <int MBLK, bool TRANSB, int TAG = 0>
+//  * GEN: op(B) is not in memory at all -- it is a formula (hssk_gen) of the DIFFERENCE of its indices, G(i, j) = tau(i - j)
+//    (the Toeplitz kinds): the 16 x 128 tile of a stage holds only 143 distinct values, tau on a run of consecutive differences.
+//    That run is the B "image": one entry each for the first 143 threads of the workgroup, evaluated two stages ahead under
+//    the MFMAs, and a lane reads its operand word for (k, j) at position k + 127 - j of the run (a 32-lane read group covers
+//    17 consecutive words: conflict-free).  Only the A panel still travels.  Same tiles, stages and summation order as the
+//    stored operand -- the results are bitwise equal.  (The FP64 vector instructions of the evaluation run on the same
+//    units as the FP64 MFMA: with every thread evaluating its four entries of the full tile the kernel lost 17 %.)
+template <int MBLK, bool TRANSB, int TAG = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k, const double* __restrict__ A, long long lda,
                                                         const double* __restrict__ B, long long ldb,
                                                         double* __restrict__ P, long long ldp, long long pstride,
-                                                        long long kchunk, int jtile0, long long* __restrict__ clk) {
+                                                        long long kchunk, int jtile0, long long* __restrict__ clk,
+                                                        hssk_gen gen, long long jg0) {
   const long long t0_ = clk ? hssk_clock() : 0, w0_ = clk ? hssk_wallclock() : 0;
   constexpr int BM = 64 * MBLK, BN2 = 128;
   constexpr int WM = BM / 2, MT = WM / 16, NT = 2;
   constexpr int A_DBL = BM * BK, B_DBL = BN2 * BK, SLOT = A_DBL + B_DBL;   // doubles per ring stage
-  constexpr int NCH = MBLK + 2;                                            // 1 KB copies per wave and stage
+  constexpr int NCH = GEN ? MBLK : MBLK + 2;                               // 1 KB copies per wave and stage
+  constexpr bool KJ_IMAGE = TRANSB && !GEN;                                // B image [block][k][64] (else [j][16 k], or the run)
   HSSK_DYN_SHARED(double, lds);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = hssk_uniform(tid >> 6);
@@ -290,9 +300,10 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
   const int kk = lane >> 5, pos = 2 * (lane & 31);
   const double* srcA = A + i0 + (pos ^ (16 * kk)) + (kbeg + 2 * wave + kk) * lda;
   const long long stepA = (long long)BK * lda;
-  const double* srcB[2];
-  long long stepB;
-  if (TRANSB) {
+  const double* srcB[2] = {nullptr, nullptr};
+  long long stepB = 0;
+  if (GEN) {
+  } else if (TRANSB) {
     srcB[0] = B + j0 + (pos ^ (16 * kk)) + (kbeg + 2 * wave + kk) * ldb;
     srcB[1] = srcB[0] + 64;
     stepB = (long long)BK * ldb;
@@ -310,8 +321,21 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     const int sc = stage < nst ? stage : nst - 1;
     double* base = lds + slot * SLOT;
     if (c < MBLK) hssk_glds16(srcA + sc * stepA + 64 * c, base + c * 1024 + wave * 128);
+    else if (GEN) {}
     else if (TRANSB) hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (c - MBLK) * 1024 + wave * 128);
     else hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (wave + 8 * (c - MBLK)) * 128);
+  };
+  // generated operand: thread e < 143 owns entry e of the stage's run, tau(d0 + e) with d0 = (first k of the stage) - (last
+  // column of the tile) -- the difference k - j of tile position (k, j) is d0 + k + 127 - j; transposed, the formula takes
+  // the negated difference.  Threads 143 .. 159 fill the pad; the stage is clamped like the copies.
+  constexpr int GEN_RUN = 160;
+  const int gen_e = tid < GEN_RUN ? tid : GEN_RUN - 1;
+  const int gen_d = (int)kbeg - ((int)(jg0 + j0) + 127) + gen_e;
+  auto gen_one = [&](int stage, int slot) {
+    if (!GEN) return;
+    const int sc = stage < nst ? stage : nst - 1;
+    const int d = gen_d + sc * BK;
+    lds[slot * SLOT + A_DBL + gen_e] = TRANSB ? hssk_gen_eval(gen, 0, d) : hssk_gen_eval(gen, d, 0);
   };
   auto copy_stage = [&](int stage, int slot) {
 #pragma unroll
@@ -329,7 +353,11 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
   for (int b = 0; b < NT; b++) {
     const int jl = wn + b * 16 + l15;
-    if (TRANSB) {
+    if (GEN) {
+      const int o = hssk_opaque(A_DBL + (l4 & 1) + 8 * (l4 >> 1) + 127 - jl);
+#pragma unroll
+      for (int s = 0; s < 4; s++) offB[b][s] = o + 2 * s;
+    } else if (KJ_IMAGE) {
       const int o = hssk_opaque(A_DBL + (jl >> 6) * 1024 + ((l4 & 1) + 8 * (l4 >> 1)) * 64 + ((jl & 63) ^ (16 * (l4 & 1))));
 #pragma unroll
       for (int s = 0; s < 4; s++) offB[b][s] = o + s * 128;
@@ -360,14 +388,30 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
       for (int b = 0; b < NT; b++)  // swapped operands: lane holds C[i = l15][j = l4 + 4r]
         acc[a][b] = hssk_mfma_f64_16x16x4(bf[set][b], af[set][a], acc[a][b]);
   };
+  // twelve MFMAs and, for a generated operand, one entry of the tile two stages ahead, interleaved by the compiler on request
+  auto mfmas_gen = [&](int set, int stage2, int slot2) {
+    mfmas(set);
+    if (GEN) {
+      gen_one(stage2, slot2);
+#pragma unroll
+      for (int g = 0; g < MT * NT; g++) {
+        hssk_sched_group<HSSK_SG_MFMA, 1>();
+        hssk_sched_group<HSSK_SG_VALU, 3>();
+      }
+    }
+  };
   // one stage out of ring slot S; on entry the fragments of its sub-step 0 are in set 0
   auto stage = [&](int st, auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
     // (scheduling fences: left alone, the compiler hoists the reads of later sub-steps, fuses them into half-rate
     // ds_read2st64_b64 pairs and then waits for ALL of them in front of the next MFMA)
+    // A generated operand's run is evaluated two stages ahead of its use (slot S + 2 was released by the previous barrier
+    // and is read after the next one), by the first three waves only, its ~20 vector instructions dealt out between the
+    // MFMAs of the first sub-step
     frags(S, 1, 1);
     hssk_sched_barrier();
-    mfmas(0);
+    if (GEN && wave < 3) mfmas_gen(0, st + 2, (S + 2) % 3);
+    else mfmas(0);
     hssk_sched_barrier();
     frags(S, 2, 0);
     hssk_sched_barrier();
@@ -401,6 +445,8 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     copy_stage(0, 0);
     copy_stage(1, 1);
     copy_stage(2, 2);
+    gen_one(0, 0);   // (stage st evaluates the run of stage st + 2)
+    gen_one(1, 1);
     hssk_wait_glds<2 * NCH>();
     hssk_wg_barrier();
     frags(0, 0, 0);
@@ -517,12 +563,15 @@ inline size_t sketch_lds_bytes(int mblk) { return sizeof(double) * 3 * (size_t)(
 template <int MBLK, int TAG>
 void launch_sketch_m(hssk_ctx* ctx, int transB, dim3 grid, long long n, long long k, const double* A, long long lda,
                      const double* B, long long ldb, double* P, long long ldp, long long pstride, long long kchunk,
-                     int jtile0, long long* clk) {
+                     int jtile0, long long* clk, const hssk_gen* gen, long long jg0) {
   const size_t shm = sketch_lds_bytes(MBLK);
-  if (transB) {
-    HSSK_LAUNCH((sketch_kernel<MBLK, true, TAG>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  const hssk_gen g0{0, 0, {0., 0., 0., 0.}};
+  if (gen) {
+    if (transB) HSSK_LAUNCH((sketch_kernel<MBLK, true, TAG, true>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, *gen, jg0);
+    else HSSK_LAUNCH((sketch_kernel<MBLK, false, TAG, true>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, *gen, jg0);
   } else {
-    HSSK_LAUNCH((sketch_kernel<MBLK, false, TAG>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+    if (transB) HSSK_LAUNCH((sketch_kernel<MBLK, true, TAG, false>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, g0, jg0);
+    else HSSK_LAUNCH((sketch_kernel<MBLK, false, TAG, false>), grid, dim3(512), shm, ctx->stream, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, g0, jg0);
   }
 }
 // asks the runtime for the ring's LDS once per instantiation; false where the device cannot give it (the caller then keeps
@@ -533,10 +582,14 @@ bool sketch_prepare_m() {
     try {
       const size_t b = sketch_lds_bytes(MBLK);
       if (b > hssk_rt::max_lds_per_workgroup()) return false;
-      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 0>, b);
-      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 0>, b);
-      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 1>, b);
-      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 1>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 0, false>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 0, false>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 1, false>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 1, false>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 0, true>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 0, true>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, true, 1, true>, b);
+      hssk_rt::allow_dynamic_lds(sketch_kernel<MBLK, false, 1, true>, b);
       return true;
     } catch (const std::exception&) {
       return false;
@@ -550,31 +603,43 @@ inline bool sketch_prepare(int BM) {
 template <int TAG>
 void launch_sketch(int BM, hssk_ctx* ctx, int transB, dim3 grid, long long n, long long k, const double* A, long long lda,
                    const double* B, long long ldb, double* P, long long ldp, long long pstride, long long kchunk,
-                   int jtile0, long long* clk) {
+                   int jtile0, long long* clk, const hssk_gen* gen, long long jg0) {
   if (grid.x == 0) return;
-  if (BM == 192) launch_sketch_m<3, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
-  else if (BM == 128) launch_sketch_m<2, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
-  else launch_sketch_m<1, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk);
+  if (BM == 192) launch_sketch_m<3, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, gen, jg0);
+  else if (BM == 128) launch_sketch_m<2, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, gen, jg0);
+  else launch_sketch_m<1, TAG>(ctx, transB, grid, n, k, A, lda, B, ldb, P, ldp, pstride, kchunk, jtile0, clk, gen, jg0);
 }
 }  // namespace
 
-extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long long k, double alpha,
-                          const double* A, long long lda, const double* B, long long ldb, double beta,
-                          double* C, long long ldc) {
-  HSSK_API_BEGIN
-  if (m <= 0 || n <= 0) return 0;
+// gen != nullptr: op(B)(kk, j) = transB ? G(jg0 + j, kk) : G(kk, jg0 + j) is evaluated inside the kernel (B, ldb unused)
+static void dgemm_impl(hssk_ctx* ctx, int transB, int m, long long n, long long k, double alpha, const double* A, long long lda,
+                       const double* B, long long ldb, const hssk_gen* gen, long long jg0, double beta, double* C, long long ldc) {
+  if (m <= 0 || n <= 0) return;
   const int BM = m > 128 ? 192 : (m > 64 ? 128 : 64);
   const unsigned gm = (unsigned)((m + BM - 1) / BM);
   const long long ksteps = (k + BK - 1) / BK;
   // interior tiles take an unmasked kernel; the ragged last columns (and any unaligned / odd-sized problem) the masked one
-  const bool aligned = (m % BM == 0) && (k % BK == 0) && (lda % 2 == 0) && (ldb % 2 == 0) &&
-                       (((size_t)A | (size_t)B) % 16 == 0);
+  const bool aligned = (m % BM == 0) && (k % BK == 0) && (lda % 2 == 0) && (gen || ldb % 2 == 0) &&
+                       (((size_t)A | (gen ? (size_t)0 : (size_t)B)) % 16 == 0);
   // Interior tiles: the eight-wave LDS-DMA form (BM x 128 per workgroup, ONE workgroup per CU) where the device has the
   // LDS for its three ring stages (120 KB at BM = 192; gfx950: 160 KB per workgroup), else the four-wave form (BM x 64,
   // two workgroups per CU).  HSSK_DGEMM_V1=1 forces the latter (A/B runs).
   static const int cus = hssk_rt::cu_count();
   const bool force_v1 = [] { const char* e = std::getenv("HSSK_DGEMM_V1"); return e && std::atoi(e) != 0; }();
-  const bool v2 = aligned && !force_v1 && k > 0 && n >= BN2 && sketch_prepare(BM);
+  const bool v2 = aligned && (gen || !force_v1) && k > 0 && n >= BN2 && sketch_prepare(BM);
+  if (gen && !v2) {
+    // a generated operand outside the eight-wave form's reach (ragged k, odd sample counts, narrow outputs): blocks of
+    // columns are written out and multiplied as stored operands
+    const long long nb_max = std::max<long long>(64, std::min<long long>(1024, (long long)(size_t(1) << 28) / std::max<long long>(k, 1)));
+    const long long ldg = k + (k & 1);
+    for (long long c0 = 0; c0 < n; c0 += nb_max) {
+      const long long nb = std::min(nb_max, n - c0);
+      double* G = ctx->gen_block(sizeof(double) * (size_t)ldg * nb);
+      if (hssk_gen_fill(ctx, gen, G, k, nb, ldg, 0, jg0 + c0, transB)) throw std::runtime_error(hssk_last_error());
+      dgemm_impl(ctx, 0, m, nb, k, alpha, A, lda, G, ldg, nullptr, 0, beta, C + c0 * ldc, ldc);
+    }
+    return;
+  }
   const int BNt = v2 ? BN2 : BN;
   const unsigned gn_full = aligned ? (unsigned)(n / BNt) : 0u;
   const long long edge_col0 = (long long)gn_full * BNt;                       // the masked kernel starts here (64-column tiles)
@@ -667,10 +732,18 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
     if (g == timed) hssk_rt::event_record(ctx->ev1, ctx->stream);
   };
   auto grid_of = [&](const Group& g) { return dim3((unsigned)g.ntiles, gm, (unsigned)g.nz); };
+  if (gen && gedge.ntiles) {
+    // the ragged rest of a generated operand (< 128 columns) is written out and takes the masked kernel as a stored block
+    const long long ldg = k + (k & 1);
+    double* G = ctx->gen_block(sizeof(double) * (size_t)ldg * gedge.cols);
+    if (hssk_gen_fill(ctx, gen, G, k, gedge.cols, ldg, 0, jg0 + gedge.col0, transB)) throw std::runtime_error(hssk_last_error());
+    const double* Gs = G - gedge.col0 * ldg;   // (the kernel addresses columns by their absolute index)
+    bracket(&gedge, [&] { launch_bm<false, 0>(BM, ctx, 0, grid_of(gedge), m, n, k, A, lda, Gs, ldg, shifted(gedge), ldp, ldp * gedge.cols, gedge.kchunk, (int)(gedge.col0 / BN), nullptr); });
+  } else
   bracket(&gedge, [&] { launch_bm<false, 0>(BM, ctx, transB, grid_of(gedge), m, n, k, A, lda, B, ldb, shifted(gedge), ldp, ldp * gedge.cols, gedge.kchunk, (int)(gedge.col0 / BN), nullptr); });
   if (v2) {
-    bracket(&gtail, [&] { launch_sketch<1>(BM, ctx, transB, grid_of(gtail), n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)(gtail.col0 / BN2), nullptr); });
-    bracket(&gmain, [&] { launch_sketch<0>(BM, ctx, transB, grid_of(gmain), n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)(gmain.col0 / BN2), clk); });
+    bracket(&gtail, [&] { launch_sketch<1>(BM, ctx, transB, grid_of(gtail), n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)(gtail.col0 / BN2), nullptr, gen, jg0); });
+    bracket(&gmain, [&] { launch_sketch<0>(BM, ctx, transB, grid_of(gmain), n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)(gmain.col0 / BN2), clk, gen, jg0); });
   } else {
     bracket(&gtail, [&] { launch_bm<true, 1>(BM, ctx, transB, grid_of(gtail), m, n, k, A, lda, B, ldb, shifted(gtail), ldp, ldp * gtail.cols, gtail.kchunk, (int)(gtail.col0 / BN), nullptr); });
     bracket(&gmain, [&] { launch_bm<true, 0>(BM, ctx, transB, grid_of(gmain), m, n, k, A, lda, B, ldb, shifted(gmain), ldp, ldp * gmain.cols, gmain.kchunk, (int)(gmain.col0 / BN), clk); });
@@ -689,5 +762,21 @@ extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long lo
       HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
   }
   hssk_rt::check_launch();
+}
+
+extern "C" int hssk_dgemm(hssk_ctx* ctx, int transB, int m, long long n, long long k, double alpha,
+                          const double* A, long long lda, const double* B, long long ldb, double beta,
+                          double* C, long long ldc) {
+  HSSK_API_BEGIN
+  dgemm_impl(ctx, transB, m, n, k, alpha, A, lda, B, ldb, nullptr, 0, beta, C, ldc);
+  HSSK_API_END
+}
+
+extern "C" int hssk_sketch_gen(hssk_ctx* ctx, const hssk_gen* g, int transG, int m, long long n, long long k, long long j0,
+                               double alpha, const double* A, long long lda, double beta, double* C, long long ldc) {
+  HSSK_API_BEGIN
+  if (!g || (g->kind != HSSK_GEN_TOEPLITZ && g->kind != HSSK_GEN_TOEPLITZ_UPPER)) throw std::invalid_argument("hssk_sketch_gen: unknown generator kind");
+  if (k > 0x7fffffffLL || j0 + n > 0x7fffffffLL) throw std::invalid_argument("hssk_sketch_gen: indices beyond 2^31");
+  dgemm_impl(ctx, transG, m, n, k, alpha, A, lda, nullptr, 0, g, j0, beta, C, ldc);
   HSSK_API_END
 }

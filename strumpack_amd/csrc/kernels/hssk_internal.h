@@ -129,6 +129,18 @@ struct hssk_ctx {
     }
     return d_aux;
   }
+  // written-out column blocks of a generated operand (hssk_sketch_gen: ragged rest columns, shapes outside the fused kernel)
+  double* d_gen = nullptr;
+  size_t gen_bytes = 0;
+  double* gen_block(size_t bytes) {
+    if (bytes > gen_bytes) {
+      sync_all();
+      hssk_rt::dev_free(d_gen);
+      d_gen = (double*)hssk_rt::dev_malloc(bytes);
+      gen_bytes = bytes;
+    }
+    return d_gen;
+  }
   double* scratch(size_t bytes) {
     if (bytes > scratch_bytes) {
       sync_all();

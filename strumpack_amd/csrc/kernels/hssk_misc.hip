@@ -3,6 +3,7 @@
 // addresses of the column-major operands wherever the access pattern allows it.
 #include "hssk_device.h"
 #include "hssk_internal.h"
+#include "hssk_gen.h"
 
 #include <vector>
 
@@ -14,12 +15,10 @@ namespace {
 __global__ void fill_toeplitz_kernel(double* __restrict__ A, int rows, long long lda, int upper, int i0, int j0) {
   // grid: (ceil(rows/256), cols): blockIdx.y = column, x covers rows -> coalesced column writes
   const int jl = blockIdx.y, j = j0 + jl;
+  hssk_gen g;
+  g.kind = upper ? HSSK_GEN_TOEPLITZ_UPPER : HSSK_GEN_TOEPLITZ;
   for (int il = blockIdx.x * blockDim.x + threadIdx.x; il < rows; il += gridDim.x * blockDim.x) {
-    const int i = i0 + il;
-    int dij = i > j ? i - j : j - i;
-    double v = 1.0 / (1.0 + (double)dij);
-    if (upper && i > j) v = 0.;
-    A[il + (size_t)jl * lda] = v;
+    A[il + (size_t)jl * lda] = hssk_gen_eval(g, i0 + il, j);
   }
 }
 
@@ -117,6 +116,30 @@ __global__ void gather_elems_kernel(const hssk_elem_desc* __restrict__ descs, co
       else p.B[i + (size_t)j * p.ldb] = v;
     }
   }
+}
+
+// the same with the matrix given by a formula: B(i,j) = G(I[i], J[j])
+__global__ void gen_elems_kernel(hssk_gen g, const hssk_elem_desc* __restrict__ descs, const Work2* __restrict__ work) {
+  const Work2 w = work[blockIdx.x];
+  const hssk_elem_desc p = descs[w.prob];
+  int jend = min(p.n, (w.chunk + 1) * COLS_PER_WG);
+  for (int j = w.chunk * COLS_PER_WG; j < jend; j++) {
+    long long gj = p.J ? p.J[j] : (p.j0 + j);
+    const bool cin = p.chi <= p.clo || (gj >= p.clo && gj < p.chi);
+    for (int i = threadIdx.x; i < p.m; i += blockDim.x) {
+      long long gi = p.I ? p.I[i] : (p.i0 + i);
+      const bool rin = p.rhi <= p.rlo || (gi >= p.rlo && gi < p.rhi);
+      double v = (cin && rin) ? hssk_gen_eval(g, (int)gi, (int)gj) : 0.;
+      if (p.transpose) p.B[j + (size_t)i * p.ldb] = v;
+      else p.B[i + (size_t)j * p.ldb] = v;
+    }
+  }
+}
+// a dense block of it: A(il, jl) = trans ? G(j0 + jl, i0 + il) : G(i0 + il, j0 + jl); grid (row chunks, columns)
+__global__ void gen_fill_kernel(hssk_gen g, double* __restrict__ A, long long rows, long long lda, long long i0, long long j0, int trans) {
+  const long long jl = blockIdx.y;
+  for (long long il = (long long)blockIdx.x * blockDim.x + threadIdx.x; il < rows; il += (long long)gridDim.x * blockDim.x)
+    A[il + jl * lda] = trans ? hssk_gen_eval(g, (int)(j0 + jl), (int)(i0 + il)) : hssk_gen_eval(g, (int)(i0 + il), (int)(j0 + jl));
 }
 
 // real image of a block of another scalar type (hssk_expand_image): grid (row chunks, columns), a thread per scalar
@@ -346,6 +369,35 @@ int hssk_gather_elems(hssk_ctx* ctx, const hssk_elem_desc* descs, int count) {
   auto* dd = (const hssk_elem_desc*)ctx->stage(descs, sizeof(*descs) * count);
   auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
   HSSK_LAUNCH(gather_elems_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+static void check_gen(const hssk_gen* g) {
+  if (!g || (g->kind != HSSK_GEN_TOEPLITZ && g->kind != HSSK_GEN_TOEPLITZ_UPPER)) throw std::invalid_argument("hssk_gen: unknown generator kind");
+}
+int hssk_gen_elems(hssk_ctx* ctx, const hssk_gen* g, const hssk_elem_desc* descs, int count) {
+  HSSK_API_BEGIN
+  check_gen(g);
+  auto w = make_work2(descs, count, [](const hssk_elem_desc& d) { return d.m > 0 ? d.n : 0; });
+  if (w.empty()) return 0;
+  auto* dd = (const hssk_elem_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dw = (const Work2*)ctx->stage(w.data(), sizeof(Work2) * w.size());
+  HSSK_LAUNCH(gen_elems_kernel, dim3((unsigned)w.size()), dim3(256), 0, ctx->stream, *g, dd, dw);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+int hssk_gen_fill(hssk_ctx* ctx, const hssk_gen* g, double* A, long long rows, long long cols, long long lda, long long i0,
+                  long long j0, int trans) {
+  HSSK_API_BEGIN
+  check_gen(g);
+  if (rows <= 0 || cols <= 0) return 0;
+  if (i0 + rows > 0x7fffffffLL || j0 + cols > 0x7fffffffLL) throw std::invalid_argument("hssk_gen_fill: indices beyond 2^31");
+  for (long long c0 = 0; c0 < cols; c0 += 65535) {   // (grid.y limit)
+    const long long nc = std::min<long long>(65535, cols - c0);
+    dim3 grid((unsigned)std::min<long long>(64, (rows + 255) / 256), (unsigned)nc);
+    HSSK_LAUNCH(gen_fill_kernel, grid, dim3(256), 0, ctx->stream, *g, A + c0 * lda, rows, lda, i0, j0 + c0, trans);
+  }
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -144,6 +144,24 @@ def from_blocks_device(lib, d_rows, ldr, d_cols, ldc, n, opts, hss, comm=None, e
     return capi.StructuredMatrix(lib, h, n)
 
 
+def from_generator(lib, n, kind, opts, hss, comm=None, exchange_cb=None, world=None, rank=None):
+    """HSS construction of a matrix given by one of the library's formulas (kind 1: Toeplitz, 2: its upper triangle): no rank
+    holds any part of the operand.  `comm` = NativeComm, or an all-gather callback (gloo tests), or neither (one process)."""
+    h = C.c_void_p()
+    if comm is not None:
+        rc = lib.SPX_d_struct_from_generator_comm(C.byref(h), n, kind, C.byref(opts), C.byref(hss), comm.h)
+    elif exchange_cb is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size() if world is None else world
+        rank = dist.get_rank() if rank is None else rank
+        rc = lib.SPX_d_struct_from_generator_sharded(C.byref(h), n, kind, C.byref(opts), C.byref(hss), world, rank, exchange_cb, None)
+    else:
+        rc = lib.SPX_d_struct_from_generator(C.byref(h), n, kind, C.byref(opts), C.byref(hss))
+    if rc:
+        raise RuntimeError("SPX_d_struct_from_generator failed")
+    return capi.StructuredMatrix(lib, h, n)
+
+
 def from_dense_device_comm(lib, dptr, n, lda, opts, hss, comm):
     """replicated operand, native communicator"""
     h = C.c_void_p()

@@ -122,6 +122,11 @@ class ShiftDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("n", C.c_int), ("lda", C.c_int)]
 
 
+class Gen(C.Structure):
+    """hssk_gen: a matrix given by a formula (kind 1: Toeplitz 1/(1+|i-j|), 2: its upper triangle)"""
+    _fields_ = [("kind", C.c_int), ("reserved", C.c_int), ("p", C.c_double * 4)]
+
+
 HSSK_SYMBOLS = [
     "hssk_ctx_create", "hssk_ctx_destroy", "hssk_ctx_stream", "hssk_sync", "hssk_last_error",
     "hssk_malloc", "hssk_free", "hssk_memcpy_h2d", "hssk_memcpy_d2h", "hssk_last_dgemm_ms", "hssk_last_dgemm_flops", "hssk_last_dgemm_trace",
@@ -134,6 +139,7 @@ HSSK_SYMBOLS = [
     "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict", "hssk_copy_triu",
     "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_h2d_bytes_async", "hssk_expand_image", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
+    "hssk_sketch_gen", "hssk_gen_elems", "hssk_gen_fill",
 ]
 
 
@@ -231,6 +237,11 @@ class Hssk:
                      "hssk_sumsq_vbatched", "hssk_leaf_update_vbatched", "hssk_formq_vbatched",
                      "hssk_id_xsolve_vbatched", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hssk_sketch_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
+                                      C.c_double, C.c_void_p, C.c_longlong, C.c_double, C.c_void_p, C.c_longlong]
+        L.hssk_gen_elems.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.hssk_gen_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong,
+                                    C.c_longlong, C.c_int]
         L.hssk_id_solves_inline.argtypes = [C.c_int, C.c_int]
         L.hssk_shift_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         L.hssk_kernel_eval_vbatched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]

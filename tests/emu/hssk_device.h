@@ -101,6 +101,10 @@ inline void hssk_flag_raise(int* f) { __atomic_store_n(f, 1, __ATOMIC_RELAXED); 
 inline double hssk_cload(const double* p, size_t off) { double v; __atomic_load((const double*)(p + off), &v, __ATOMIC_ACQUIRE); return v; }
 inline void hssk_cstore(double* p, size_t off, double v) { __atomic_store(p + off, &v, __ATOMIC_RELEASE); }
 inline void hssk_sched_barrier() {}
+#define HSSK_SG_MFMA 0x008
+#define HSSK_SG_VALU 0x002
+#define HSSK_SG_DSWRITE 0x200
+template <int MASK, int N> inline void hssk_sched_group() {}
 inline unsigned hssk_fbits(float v) { unsigned b; std::memcpy(&b, &v, 4); return b; }
 inline unsigned long long hssk_bits(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; }
 inline double hssk_from_bits(unsigned long long b) { double v; std::memcpy(&v, &b, 8); return v; }

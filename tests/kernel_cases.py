@@ -800,3 +800,55 @@ def case_upload_two_threads(hk):
         t.join()
     hk2.close()
     assert not errs, errs
+
+
+def case_sketch_gen(hk, m, n, k, j0, trans, kind=1, alpha=1.0, beta=0.0, lda_pad=0, seed=2):
+    """hssk_sketch_gen (op(B) evaluated inside the kernel from a formula) against hssk_dgemm on the written-out block of the
+    same matrix: BITWISE equal (same tiles, K-split and summation order), and equal to numpy to rounding.
+    Generated block: op(G)(kk, j) = trans ? G(j0 + j, kk) : G(kk, j0 + j), G = the Toeplitz test matrix."""
+    r = rng(seed)
+    A = r.standard_normal((m + lda_pad, k))
+    C0 = r.standard_normal((m + 2, n))
+    g = K.Gen(kind, 0, (C.c_double * 4)(0, 0, 0, 0))
+    ii, jj = np.arange(k)[:, None], (j0 + np.arange(n))[None, :]
+    G = 1.0 / (1.0 + np.abs(ii - jj))          # G(kk, j0 + j): symmetric unless kind 2
+    if kind == 2:
+        G = np.where((jj > ii) if trans else (ii > jj), 0.0, G)   # upper triangle: G(i, j) = 0 for i > j
+    # the stored block through the library's own fill (also checked against numpy)
+    ldb = k + (k & 1)
+    dB = hk.array(np.zeros((ldb, n)))
+    hk.check(hk.lib.hssk_gen_fill(hk.ctx, C.byref(g), dB.ptr, k, n, ldb, 0, j0, int(trans)))
+    hk.sync()
+    assert np.array_equal(dB.get()[:k], G), "gen_fill"
+    dA, dC1, dC2 = hk.array(A), hk.array(C0), hk.array(C0)
+    hk.check(hk.lib.hssk_sketch_gen(hk.ctx, C.byref(g), int(trans), m, n, k, j0, alpha, dA.ptr, A.shape[0], beta, dC1.ptr, C0.shape[0]))
+    hk.check(hk.lib.hssk_dgemm(hk.ctx, 0, m, n, k, alpha, dA.ptr, A.shape[0], dB.ptr, ldb, beta, dC2.ptr, C0.shape[0]))
+    hk.sync()
+    got, dense = dC1.get(), dC2.get()
+    ref = C0.copy()
+    ref[:m] = alpha * (A[:m] @ G) + (beta * C0[:m] if beta != 0 else 0)
+    assert np.abs(got - ref).max() <= 1e-13 * max(k, 1) * max(1.0, np.abs(ref).max()), f"sketch_gen m={m} n={n} k={k}"
+    return np.array_equal(got, dense)
+
+
+def case_gen_elems(hk, seed=4):
+    r = rng(seed)
+    n = 500
+    I = r.permutation(n)[:37].astype(np.int32)
+    J = r.permutation(n)[:29].astype(np.int32)
+    for kind in (1, 2):
+        g = K.Gen(kind, 0, (C.c_double * 4)(0, 0, 0, 0))
+        dI, dJ = hk.array(I), hk.array(J)
+        dB, dBt, dD = hk.array(np.zeros((40, 29))), hk.array(np.zeros((29, 37))), hk.array(np.zeros((50, 50)))
+        descs = [K.ElemDesc(None, 0, dI.ptr, dJ.ptr, 0, 0, dB.ptr, 37, 29, 40, 0, 0, 0, 0, 0),
+                 K.ElemDesc(None, 0, dI.ptr, dJ.ptr, 0, 0, dBt.ptr, 37, 29, 29, 1, 0, 0, 0, 0),
+                 K.ElemDesc(None, 0, None, None, 100, 120, dD.ptr, 50, 50, 50, 0, 0, 0, 0, 0)]
+        arr = (K.ElemDesc * len(descs))(*descs)
+        hk.check(hk.lib.hssk_gen_elems(hk.ctx, C.byref(g), arr, len(descs)))
+        hk.sync()
+        T = 1.0 / (1.0 + np.abs(np.arange(n)[:, None] - np.arange(n)[None, :]))
+        if kind == 2:
+            T = np.triu(T)
+        assert np.array_equal(dB.get()[:37], T[np.ix_(I, J)])
+        assert np.array_equal(dBt.get(), T[np.ix_(I, J)].T)
+        assert np.array_equal(dD.get(), T[100:150, 120:170])

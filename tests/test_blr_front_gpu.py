@@ -31,6 +31,15 @@ def test_front_against_reference_star_and_comb(L, name):
     BC.check_front_schedules(L, name)
 
 
+@pytest.mark.parametrize("la", [1, 2, 3])
+@pytest.mark.parametrize("name", ("p40_weak", "p64_weak"))
+def test_front_lookahead_depths(L, name, la, monkeypatch):
+    # the trailing array is updated once per block of `la` block steps (left-looking inside the block): depth 1 is the
+    # right-looking schedule as written; every depth must reproduce the reference's tile table and Schur complement
+    monkeypatch.setenv("STRUMPACK_AMD_BLR_LOOKAHEAD", str(la))
+    BC.check_front(L, name)
+
+
 def test_front_api(L):
     BC.check_front_api(L)
 

@@ -81,6 +81,29 @@ for (n, leaf, d0, dd, algo, with_rows) in BCASES[world]:
         print("rank", rank, "block case", n, leaf, algo, with_rows, same_tree, e_mult, e_multT, e_solve, flush=True)
     ok = ok and good
     H.destroy(); H1.destroy()
+# generated operand (the library's Toeplitz formula evaluated inside the sketch kernel): no rank holds any part of the matrix;
+# n = 256 with 64 + 64 samples takes the fused kernel on every rank's 128-column range, the others the written-out blocks
+GCASES = {2: [(256, 32, 64, 64, 1), (120, 16, 16, 8, 2)], 4: [(512, 32, 64, 64, 1), (140, 16, 8, 8, 1)], 3: [(90, 16, 16, 8, 1)]}
+for (n, leaf, d0, dd, kind) in GCASES[world]:
+    A = O.toeplitz(n) if kind == 1 else np.triu(O.toeplitz(n))
+    dA = hk.array(A)
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd)
+    ex = sdist.make_exchange(L, world, rank)
+    H = sdist.from_generator(L, n, kind, o, h, exchange_cb=ex)
+    H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
+    B = np.random.default_rng(5).standard_normal((n, 2))
+    same_tree = np.array_equal(H.node_info(), H1.node_info())
+    y, y1 = H.mult(B), H1.mult(B)
+    H.factor(); H1.factor()
+    x, x1 = H.solve(B), H1.solve(B)
+    e_mult = np.linalg.norm(y - y1) / np.linalg.norm(y1)
+    e_solve = np.linalg.norm(x - x1) / np.linalg.norm(x1)
+    good = same_tree and e_mult < 1e-11 and e_solve < 1e-9
+    if not good:
+        print("rank", rank, "generator case", n, leaf, kind, same_tree, e_mult, e_solve, flush=True)
+    ok = ok and good
+    H.destroy(); H1.destroy()
 # kernel-matrix front end: subtree ownership (natural / kd trees are balanced -> cut exists), replicated otherwise
 KCASES = {2: [(100, 16, "kdtree", "Gauss")], 4: [(100, 16, "natural", "Laplace")], 3: []}
 for (n, leaf, clus, kern) in KCASES[world]:

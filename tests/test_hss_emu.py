@@ -103,3 +103,13 @@ def test_multi_rhs_matrix_core_sweeps_rank_56(L):
 
 def test_blr_dense_slice(L):
     HC.check_blr(L, max_n=1000)
+
+
+@pytest.mark.parametrize("n,leaf,kind,d0,dd", [(1536, 64, 1, 64, 64), (1024, 128, 2, 128, 64), (700, 64, 1, 64, 32)])
+def test_generated_operand_fused_sketch(L, n, leaf, kind, d0, dd):
+    # the operand is a formula evaluated inside the sketch kernel (n a multiple of 16 and 64-aligned sample counts: the fused
+    # kernel; n = 700: the written-out blocks) -- bitwise the compression of the stored matrix
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(emu_lib.build())
+    HC.check_generator(L, hk, n, leaf, kind, d0=d0, dd=dd)
+    hk.close()

@@ -422,3 +422,40 @@ def test_native_rccl_two_ranks(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "RCCL_OK" in outs[0], "\n".join(outs)
+
+
+@pytest.mark.parametrize("n,leaf,kind,d0,dd,engine", [(8192, 128, 1, 128, 64, "philox"), (4096, 256, 2, 128, 64, "linear"),
+                                                       (3000, 128, 1, 64, 32, "linear")])
+def test_generated_operand_fused_sketch(L, n, leaf, kind, d0, dd, engine):
+    # the operand is a formula evaluated inside the sketch kernel: bitwise the compression of the stored matrix
+    hk = K.Hssk(_loader.lib_path())
+    HC.check_generator(L, hk, n, leaf, kind, rel_tol=1e-5, d0=d0, dd=dd, engine=engine)
+    hk.close()
+
+
+def test_generated_operand_beyond_hbm():
+    """N = 250000: the stored matrix would be 500 GB -- more than the GPU holds; generated inside the sketch kernel it is
+    compressed, factored and solved like any other (size-independent checks: residual against the compressed matrix, sampled
+    entries and a sampled product against the formula)."""
+    L = capi.load(_loader.lib_path())
+    n = 250000
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=256)
+    H = capi.StructuredMatrix.from_generator(L, n, 1, o, capi.StructuredMatrix.hss_options(L, random_engine="philox"))
+    assert H.is_compressed() and 30 <= H.rank() <= 100   # (41 at N = 1e5; 68 measured here)
+    r = np.random.default_rng(9)
+    b = r.standard_normal(n)
+    H.factor()
+    x = H.solve(b)[:, 0]
+    assert np.linalg.norm(H.mult(x)[:, 0] - b) <= 1e-12 * np.linalg.norm(b)
+    # rows of H x against the formula on a sample of rows: (A x)_i = sum_j x_j / (1 + |i - j|)
+    rows = r.choice(n, 64, replace=False)
+    jj = np.arange(n)
+    Ax = np.array([np.dot(1.0 / (1.0 + np.abs(i - jj)), x) for i in rows])
+    assert np.linalg.norm(Ax - b[rows]) <= 5e-3 * np.linalg.norm(b[rows])
+    I = [np.sort(r.choice(n, 8, replace=False)) for _ in range(50)]
+    J = [np.sort(r.choice(n, 8, replace=False)) for _ in range(50)]
+    blocks = H.extract_blocks(I, J)
+    for bi, (ii, jc) in enumerate(zip(I, J)):
+        ref = 1.0 / (1.0 + np.abs(ii[:, None] - jc[None, :]))
+        assert np.abs(blocks[bi] - ref).max() <= 1e-3
+    H.destroy()

@@ -70,6 +70,24 @@ def test_dgemm_lds_dma_form(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-0.5, beta=2.0, lda_pad=4, ldb_pad=2)
 
 
+@pytest.mark.parametrize("m,n,k,j0,tr,kind", [(192, 260, 64, 0, 0, 1), (192, 260, 64, 37, 1, 2), (128, 128, 32, 5, 0, 2),
+                                               (64, 400, 3200, 100, 1, 1), (192, 384, 16, 0, 0, 1)])
+def test_sketch_gen_fused(hk, m, n, k, j0, tr, kind):
+    # the operand evaluated inside the eight-wave kernel: bitwise the stored-operand result
+    assert KC.case_sketch_gen(hk, m, n, k, j0, tr, kind)
+    assert KC.case_sketch_gen(hk, m, n, k, j0, tr, kind, alpha=-0.5, beta=2.0, lda_pad=4)
+
+
+@pytest.mark.parametrize("m,n,k,j0,tr,kind", [(100, 130, 33, 3, 0, 1), (192, 70, 40, 0, 1, 2), (192, 300, 50, 10, 0, 1)])
+def test_sketch_gen_written_out_blocks(hk, m, n, k, j0, tr, kind):
+    # shapes outside the fused kernel (ragged k, odd sample counts, narrow outputs): column blocks are written out
+    KC.case_sketch_gen(hk, m, n, k, j0, tr, kind, alpha=1.5, beta=0.5, lda_pad=1)
+
+
+def test_gen_elems(hk):
+    KC.case_gen_elems(hk)
+
+
 def test_dgemm_splitk(hk):
     KC.case_dgemm(hk, 24, 70, 3000, 1)
 

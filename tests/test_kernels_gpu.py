@@ -63,6 +63,23 @@ def test_dgemm_lds_dma_form(hk, m, n, k, tb):
     KC.case_dgemm(hk, m, n, k, tb, alpha=-0.5, beta=2.0, lda_pad=4, ldb_pad=2)
 
 
+@pytest.mark.parametrize("m,n,k,j0,tr,kind", [(192, 3000, 4096, 0, 0, 1), (192, 3000, 4096, 517, 1, 2), (128, 1280, 2048, 5, 0, 2),
+                                               (64, 4000, 32000, 100, 1, 1), (192, 33000, 20000, 1000, 0, 1)])
+def test_sketch_gen_fused(hk, m, n, k, j0, tr, kind):
+    # the operand evaluated inside the eight-wave kernel: bitwise the stored-operand result
+    assert KC.case_sketch_gen(hk, m, n, k, j0, tr, kind)
+    assert KC.case_sketch_gen(hk, m, n, k, j0, tr, kind, alpha=-0.5, beta=2.0, lda_pad=4)
+
+
+@pytest.mark.parametrize("m,n,k,j0,tr,kind", [(100, 130, 33, 3, 0, 1), (192, 70, 40, 0, 1, 2), (192, 3000, 5001, 10, 0, 1)])
+def test_sketch_gen_written_out_blocks(hk, m, n, k, j0, tr, kind):
+    KC.case_sketch_gen(hk, m, n, k, j0, tr, kind, alpha=1.5, beta=0.5, lda_pad=1)
+
+
+def test_gen_elems(hk):
+    KC.case_gen_elems(hk)
+
+
 def test_leaf_update(hk):
     KC.case_leaf_update(hk, [(24, 20), (192, 45), (64, 33), (2, 1)])
     KC.case_leaf_update(hk, [(192, 195), (192, 196)] * 8 + [(64, 390)], seed=13)
