@@ -39,11 +39,18 @@ def parse():
     p.add_argument("--rel-tol", type=float, default=1e-4)
     p.add_argument("--nrhs", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-factor-ahead", action="store_true", help="toeplitz workload: factor only when told to (no overlap of the "
+                   "factorization's levels with the compression's)")
     p.add_argument("--cpu-n", type=int, default=32768)
     p.add_argument("--sketch", choices=["gaussian", "sjlt"], default="gaussian",
                    help="gaussian = the reference's default (BASELINE's metric is quoted on it); sjlt = its "
                         "--hss_compression_sketch SJLT option (nnz = 4), a separate, HBM-bound workload")
     p.add_argument("--front-n", type=int, default=64, help="blr_front: the separator is an n x n plane (dsep = n^2, dupd = 2 n^2)")
+    p.add_argument("--front-ny", type=int, default=0, help="blr_front: separator = a front-n x front-ny plane (0: square); "
+                   "the 200^3 problem's root front is 200 x 200 with --front-upd none, its second-level fronts 200 x 100 with both update planes")
+    p.add_argument("--front-upd", choices=["both", "none"], default="both", help="blr_front: update planes of the front")
+    p.add_argument("--front-device", action="store_true", help="blr_front: build the front on the GPU and leave it there (forced above 30000 rows: "
+                   "the host generator and its dense checks are for the fixture-sized fronts)")
     p.add_argument("--front-leaf", type=int, default=256, help="blr_front: tile size (the reference's BLR default)")
     p.add_argument("--front-lra", choices=["rrqr", "aca"], default="rrqr",
                    help="blr_front: tile compression (--blr_low_rank_algorithm; the reference's default and BASELINE's: RRQR)")
@@ -223,6 +230,9 @@ def blr_front_workload(a, L, hk, torch):
     import blr_fronts as BF
     from strumpack_amd import capi
     n, leaf = a.front_n, a.front_leaf
+    ny = a.front_ny or n
+    if a.front_device or a.front_ny or a.front_upd != "both" or n * ny * (3 if a.front_upd == "both" else 1) > 30000:
+        return blr_front_device_workload(a, L, hk, torch, BF, n, ny, leaf)
 
     def mm(A, B):   # setup only: the closed-form blocks are products with the 2D sine basis
         return (torch.from_numpy(np.ascontiguousarray(A)).cuda() @ torch.from_numpy(np.ascontiguousarray(B)).cuda()).cpu().numpy()
@@ -313,6 +323,112 @@ def blr_front_workload(a, L, hk, torch):
                                              "%.3f s, max rank %d (same flop count as the GPU line)" % (ref["stats"][0], int(ref["stats"][4]))}
         except Exception as e:
             out["cpu_baseline"] = {"error": str(e)[:200]}
+    print(json.dumps(out))
+    F.destroy()
+
+
+def blr_front_device_workload(a, L, hk, torch, BF, nx, ny, leaf):
+    """Fronts of the 200^3 problem's own size (BASELINE configs[4]: root front 200 x 200, dsep 40000; second level 200 x 100,
+    dsep 20000 + dupd 40000): built on the GPU and left there (tests/blr_fronts.py: poisson_front_device), checked there --
+    B11 \\ b against F11, the Schur complement against sampled dense algebra (F22 R - F21 F11^{-1} F12 R with a dense solve).
+    torch is setup / checking plumbing only; the timed step is the library's partial factorization + solve phases."""
+    import numpy as np
+    from strumpack_amd import capi, dist as sdist
+    fr = BF.poisson_front_device(torch, nx, ny, 8, 8, leaf, upd=a.front_upd)
+    ds, du = fr["ds"], fr["du"]
+    rtol, atol = 1e-4, 1e-12 * fr["norm"]
+    o = capi.StructuredMatrix.options(L, rel_tol=rtol, abs_tol=atol, type=capi.SP_TYPE_BLR)
+    if L.SPX_blr_low_rank_algorithm(1 if a.front_lra == "aca" else 0):
+        raise SystemExit("SPX_blr_low_rank_algorithm failed")
+    ptr = lambda k: fr[k].data_ptr() if k in fr else None
+    rng = np.random.default_rng(5)
+    b, bu = rng.standard_normal((ds, 1)), (rng.standard_normal((du, 1)) if du else None)
+    torch.cuda.synchronize()
+
+    def step():
+        F = capi.BLRFront.factor_device(L, ds, du, ptr("F11"), ds, ptr("F12cm"), ds, ptr("F21cm"), max(du, 1), ptr("F22"), max(du, 1),
+                                        fr["tiles1"], fr["tiles2"], o)
+        ys, yu = F.forward(b, bu)
+        x = F.backward(ys, np.zeros_like(bu) if du else None)
+        return F, x
+
+    F = None
+    for _ in range(a.warmup):
+        if F is not None:
+            F.destroy()
+        F, x = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sts = []
+    for _ in range(a.steps):
+        if F is not None:
+            F.destroy()
+        F, x = step()
+        sts.append(F.stats())
+    torch.cuda.synchronize()
+    elapsed = (time.perf_counter() - t0) / a.steps
+    st = sts[-1]
+    med = lambda k: sorted(s_[k] for s_ in sts)[len(sts) // 2]
+    # phases on the device clock: ONE extra step outside the timed region with the stopwatches on
+    L.SPX_d_blr_front_time_phases(1)
+    F.destroy()
+    F, x = step()
+    ph = F.stats()
+    L.SPX_d_blr_front_time_phases(0)
+    # ---- checks, on the device
+    dev = fr["F11"].device
+    xt = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    bt = torch.from_numpy(b).to(dev)
+    resid = float(torch.linalg.norm(fr["F11"] @ xt - bt) / torch.linalg.norm(bt))     # (F11 symmetric: row-major == column-major)
+    schur_err = None
+    if du:
+        R = torch.from_numpy(rng.standard_normal((du, 8))).to(dev)
+        sp, ld = F.schur_device()
+        St = sdist._tensor(sp, ld * du, True).view(du, ld)[:, :du]        # St[j, i] = S(i, j)
+        SR = St.t() @ R
+        F12 = fr["F12cm"].t()      # the (du x ds) row-major stack of symmetric blocks IS the column-major ds x du block
+        F21 = fr["F21cm"].t()      # the (ds x du) row-major array IS the column-major du x ds block
+        ref = fr["F22"] @ R - F21 @ torch.linalg.solve(fr["F11"], F12 @ R)
+        schur_err = float(torch.linalg.norm(SR - ref) / torch.linalg.norm(ref))
+        del St, SR, ref, F12, F21
+    rk = F.tile_ranks()
+    lr = rk[rk >= 0]
+    phases = {"lu_diag": ph["ms_lu"], "compress_tiles": ph["ms_compress"], "trsm": ph["ms_trsm"], "schur_gemm": ph["ms_schur"]}
+    ms_schur = ph["ms_schur"]
+    ach = st["f_schur"] / (ms_schur * 1e-3) * 1e-12 if ms_schur > 0 else 0.0
+    gbs = st["b_schur"] / (ms_schur * 1e-3) * 1e-9 if ms_schur > 0 else 0.0
+    hbm_bound = st["b_schur"] / 8000e9 > st["f_schur"] / (PEAK_FP64_MFMA_TFLOPS * 1e12)
+    dominant = max(("compress_tiles", "schur_gemm"), key=lambda k_: phases[k_])
+    if dominant == "schur_gemm":
+        roof = {"kernel": "gemm_vbatched_kernel (Schur updates of the trailing array, deferred over blocks of block steps; v_mfma_f64_16x16x4_f64)",
+                "bound": "hbm" if hbm_bound else "mfma", "achieved": gbs if hbm_bound else ach, "peak": 8000.0 if hbm_bound else PEAK_FP64_MFMA_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gbs / 8000.0) if hbm_bound else (ach / PEAK_FP64_MFMA_TFLOPS), "traffic": None,
+                "phase_ms": ms_schur, "flops_per_step": st["f_schur"], "bytes_per_step": st["b_schur"], "tflops": ach, "mfma_frac": ach / PEAK_FP64_MFMA_TFLOPS}
+    else:
+        # tile compression: truncated pivoted QR of every off-diagonal tile, a chain of dependent Householder steps per tile (its
+        # flops against the FP64 vector rate say how far from any throughput bound a latency chain sits)
+        f_comp = st["f_total"] - st["f_schur"]
+        roof = {"kernel": "id_group_kernel / id_reg_kernel (truncated pivoted QR of the tiles of a block row and column: latency chain of Householder steps)",
+                "bound": "mfma", "achieved": f_comp / (phases["compress_tiles"] * 1e-3) * 1e-12 if phases["compress_tiles"] > 0 else 0.0,
+                "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None, "phase_ms": phases["compress_tiles"],
+                "note": "flops = everything but the Schur GEMMs (LU, triangular solves and compression: an upper bound of the phase's own)"}
+        roof["frac"] = roof["achieved"] / PEAK_FP64_MFMA_TFLOPS
+    out = {"metric": "blr_front_partial_factor_gflops", "value": st["f_total"] / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4] kernel at the 200^3 problem's own front sizes: BLR partial factorization (RL with look-ahead, "
+                                  + a.front_lra.upper() + " tiles, rel_tol 1e-4, tiles of %d) of an exact 3D 7-point Poisson front: separator %dx%d plane "
+                                  "(dsep=%d), update part dupd=%d, built and resident in HBM; + forward / backward solve phase, 1 rhs" % (leaf, nx, ny, ds, du),
+                      "dsep": ds, "dupd": du, "tiles": [len(fr["tiles1"]), len(fr["tiles2"])], "leaf": leaf, "rel_tol": rtol,
+                      "lookahead": int(os.environ.get("STRUMPACK_AMD_BLR_LOOKAHEAD", "8"))},
+           "phases_ms": {"factor_wall": med("t_factor") * 1e3, "one_stream_device_clock": phases},
+           "flops": {"schur_gemm": st["f_schur"], "total": st["f_total"]},
+           "blr": {"max_rank": int(st["max_rank"]), "mean_rank": float(lr.mean()) if lr.size else 0.0,
+                   "nnz": [st["nnz11"], st["nnz12"], st["nnz21"]], "dense_nnz": [ds * ds, ds * du, du * ds]},
+           "checks": {"schur_err_vs_sampled_dense": schur_err, "B11_solve_resid": resid},
+           "roofline": roof,
+           "cpu_baseline": {"skipped": "the reference's CPU routine needs minutes to hours on a front of this size (87 s on the dsep 4096 front, "
+                                       "profiles/r03_bench_blr_front_n1.json); its line is the fixture-sized front's"}}
     print(json.dumps(out))
     F.destroy()
 
@@ -453,7 +569,10 @@ def main():
         return
 
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
-    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch)
+    # factor_ahead: the step is construct + factor + solve, so the library is told that a factorization follows -- it enqueues
+    # every tree level's ULV factorization on a second stream as soon as the compression has settled the level (all of it
+    # inside the timed region; --no-factor-ahead: the phases one after the other, as in rounds 1-3)
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch, factor_ahead=not a.no_factor_ahead)
     # ---- process group.  Default for N > 1: the library's own RCCL communicator (collectives on the engine's stream) and
     # a SHARDED operand -- every rank generates only its row block and its column block of A (2 x 80 GB / N), never the
     # whole matrix.  STRUMPACK_AMD_BENCH_COMM=torch selects the round-1 path (replicated A, torch.distributed callback).
@@ -624,6 +743,8 @@ def main():
     traffic = tsrc = None
     if rank == 0 and world == 1 and a.sketch == "gaussian" and not os.environ.get("STRUMPACK_AMD_BENCH_INNER"):
         extra = ["--size", str(n), "--leaf", str(a.leaf), "--rel-tol", str(a.rel_tol), "--nrhs", str(a.nrhs), "--operand", a.operand]
+        if a.no_factor_ahead:
+            extra.append("--no-factor-ahead")
         # the MAIN launches of both sketch products: sketch_kernel<rows / 64, transposed?, group 0>
         tmain = measure_traffic(extra, r"sketch_kernel<\d, (true|false), 0, (true|false)>")
         if tmain is not None:
@@ -640,6 +761,7 @@ def main():
                                % (n, n, "Philox samples" if a.sketch == "gaussian" else "SJLT sketch, nnz=4: NOT the configuration of BASELINE's metric",
                                   a.leaf, a.rel_tol, a.nrhs),
                    "sketch": a.sketch, "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
+                   "factor_ahead": (not a.no_factor_ahead),
                    "operand": ("generated: A is the library's Toeplitz formula, its tiles evaluated inside the sketch kernel -- never stored "
                                "(SPX_d_struct_from_generator; bitwise the compression of the stored matrix); NOT BASELINE's configuration, which holds A in HBM"
                                if generated else "resident in HBM before the clock starts"),

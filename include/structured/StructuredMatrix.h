@@ -99,6 +99,9 @@ typedef struct SPXHSSOptions {
   /* sketching matrix (HSS/HSSOptions.hpp:110-133): 0 Gaussian, 1 SJLT (nnz entries +-1 per row); SJLT placement
    * 0 chunk / 1 perm; nonzeros per row in the first d0 + dd columns (nnz0) and in every further dd columns (nnz) */
   int compression_sketch, sjlt_algo, nnz0, nnz;
+  /* the caller will factor: the ULV factorization of each tree level is enqueued on a second stream as soon as the
+   * compression has settled that level; SP_d_struct_factor then only waits for it (0: factor when told to) */
+  int factor_ahead;
 } SPXHSSOptions;
 void SPX_d_struct_default_hss_options(SPXHSSOptions* h);
 /* like SP_d_struct_from_dense, with explicit HSS options (h may be NULL) */

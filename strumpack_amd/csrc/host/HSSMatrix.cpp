@@ -30,6 +30,8 @@ EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
   e.sjlt_algo = o.SJLT_algo() == SJLTAlgo::CHUNK ? 0 : 1;
   e.nnz0 = o.nnz0(); e.nnz = o.nnz();
   e.verbose = o.verbose();
+  e.factor_ahead = o.factor_ahead();
+  if (const char* fa = std::getenv("STRUMPACK_AMD_FACTOR_AHEAD")) e.factor_ahead = std::atoi(fa) != 0;
   if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
   return e;
 }

@@ -61,6 +61,10 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   void set_nnz(int nnz) { assert(nnz > 0); nnz_ = nnz; }
   void set_SJLT_algo(SJLTAlgo a) { sjlt_algo_ = a; }
   void set_user_defined_random(bool u) { user_defined_random_ = u; }
+  // extension: the caller will factor -- the ULV factorization of each tree level is enqueued on a second stream as soon as
+  // the compression has settled the level (DeviceHSS: EngineOptions::factor_ahead); factor() then only waits
+  void set_factor_ahead(bool f) { factor_ahead_ = f; }
+  bool factor_ahead() const { return factor_ahead_; }
   void set_synchronized_compression(bool sync) { sync_ = sync; }
   void set_log_ranks(bool log_ranks) { log_ranks_ = log_ranks; }
   // kernel-matrix construction (reference HSSOptions.hpp:258-283)
@@ -122,6 +126,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
       } else if (match_flag(argc, argv, i, "hss_nnz0", v, true)) set_nnz0(std::atoi(v.c_str()));
       else if (match_flag(argc, argv, i, "hss_nnz", v, true)) set_nnz(std::atoi(v.c_str()));
       else if (match_flag(argc, argv, i, "hss_user_defined_random", v, false)) set_user_defined_random(true);
+      else if (match_flag(argc, argv, i, "hss_factor_ahead", v, false)) set_factor_ahead(true);
       else if (match_flag(argc, argv, i, "hss_enable_sync", v, false)) set_synchronized_compression(true);
       else if (match_flag(argc, argv, i, "hss_disable_sync", v, false)) set_synchronized_compression(false);
       else if (match_flag(argc, argv, i, "hss_log_ranks", v, false)) set_log_ranks(true);
@@ -163,7 +168,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   CompressionSketch compress_sketch_ = CompressionSketch::GAUSSIAN;
   int nnz0_ = 4, nnz_ = 4;
   SJLTAlgo sjlt_algo_ = SJLTAlgo::CHUNK;
-  bool user_defined_random_ = false, sync_ = false, log_ranks_ = false;
+  bool user_defined_random_ = false, sync_ = false, log_ranks_ = false, factor_ahead_ = false;
   ClusteringAlgorithm clustering_algorithm_ = ClusteringAlgorithm::TWO_MEANS;
   int approximate_neighbors_ = 64, ann_iterations_ = 5;
   NeighborSearch neighbor_search_ = NeighborSearch::EXACT;

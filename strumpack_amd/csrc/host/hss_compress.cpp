@@ -24,6 +24,7 @@ void DeviceHSS::reset_compression() {
     nd = Node();
     nd.lo = lo; nd.m = m; nd.lvl = lvl; nd.height = h; nd.c0 = c0; nd.c1 = c1; nd.parent = p;
   }
+  factor_cancel();   // (a factorization running ahead writes into the arenas reset below)
   persist_->reset();
   dev_tree_ = nullptr;
   work_->reset();
@@ -36,6 +37,7 @@ void DeviceHSS::reset_compression() {
 // back to what the sampling produced; the sample arrays themselves are kept
 void DeviceHSS::restart_nodes(int d_have) {
   ck(hssk_sync(ctx_));
+  factor_cancel();
   for (auto& nd : nodes_) {
     int lo = nd.lo, m = nd.m, lvl = nd.lvl, h = nd.height, c0 = nd.c0, c1 = nd.c1, p = nd.parent;
     nd = Node();
@@ -206,7 +208,10 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       stats_.f_sketch += 4.0 * (double)N * (double)N * (sj_pat_ ? sj_nnz_ : dnew);   // SJLT: 2 nnz flops per element and product
       if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
       stats_.rounds++;
-      for (auto& ids : own_by_height_) process_level(src, ids, d, dd, false);
+      for (size_t h = 0; h < own_by_height_.size(); h++) {
+        process_level(src, own_by_height_[h], d, dd, false);
+        factor_ahead_level(h);   // (EngineOptions::factor_ahead: the settled level's ULV factorization, on its own stream)
+      }
       if (dist_subtree_) {
         exchange_cut_compress(d + dd);
         for (auto& ids : top_by_height_) process_level(src, ids, d, dd, false);

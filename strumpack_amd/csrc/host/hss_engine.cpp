@@ -46,6 +46,7 @@ DeviceHSS::DeviceHSS(int n, const EngineOptions& opts, const structured::Cluster
 }
 
 DeviceHSS::~DeviceHSS() {
+  if (fctx_) hssk_sync(fctx_);
   if (ctx_) hssk_sync(ctx_);
   drop_plans();
   plan_arena_.reset();
@@ -55,6 +56,7 @@ DeviceHSS::~DeviceHSS() {
   tmp_.reset();
   comm_arena_.reset();
   schur_.reset();
+  if (fctx_) hssk_ctx_destroy(fctx_);
   hssk_ctx_destroy(ctx_);
 }
 

@@ -39,6 +39,11 @@ struct EngineOptions {
   // the caller's multiplication routine also FILLS the random block (HSSOptions::user_defined_random,
   // HSSMatrix.compress_stable.hpp:110-141; sparse/fronts/FrontHSS.cpp:383-385): nothing is drawn here
   bool user_random = false;
+  // The caller is going to factor: the ULV factorization of every tree level is enqueued -- on a stream of its own -- as soon
+  // as the compression has settled that level, so the latency chain of the factorization's levels runs beside the chain of the
+  // compression's upper levels instead of after it (extension; the reference factors when told to and not before).  factor()
+  // then only waits.  Costs a caller who never factors the memory and the (overlapped) device time of the factors.
+  bool factor_ahead = false;
   bool verbose = false;
   int device = 0;
   // multi-GPU (one process per GPU): `allgather` is an in-place all-gather of a DEVICE buffer of
@@ -356,10 +361,27 @@ class DeviceHSS {
   int sj_nnz_ = 0;
   long long cols_per_rank_ = 0;  // sketch column shard (multi-GPU)
   int* d_ranks_ = nullptr;
+  // a factorization in progress: the state its levels share (hss_factor.cpp).  `ahead` = started by the compression
+  // (EngineOptions::factor_ahead): its launches are on fctx_'s stream, `done` heights of own_by_height_ are enqueued.
+  struct FactorRun {
+    bool active = false, ahead = false, partial = false;
+    int sr = 0;
+    hssk_ctx* cx = nullptr;
+    std::vector<double*> Dh, Vh, Vd;
+    std::vector<hssk_trtri_desc> ti;
+    std::vector<char> is_cut;
+    size_t done = 0;
+  } frun_;
+  hssk_ctx* fctx_ = nullptr;   // second context (stream, descriptor rings) of a factorization that runs ahead
+  void factor_begin(int sr, bool partial, hssk_ctx* cx);
+  void factor_prep(const std::vector<int>& ids);     // dense column bases of these nodes (they depend on the compression only)
+  void factor_level(const std::vector<int>& ids);
+  void factor_ahead_level(size_t h);                  // compression hook: height h has been processed
+  void factor_cancel();                               // waits for a run ahead and forgets it
   bool factored_ = false, partial_factored_ = false, schur_ready_ = false;
   // every way the ULV factors die (shift, recompression, restart, reset): the whole matrix's, a child's (factor_node) and
   // the partial factorization with its Schur factors go together -- a later solve / solve_node / Schur_update must refuse
-  void invalidate_factors() { factored_ = partial_factored_ = schur_ready_ = false; sub_factored_ = -1; }
+  void invalidate_factors() { factor_cancel(); factored_ = partial_factored_ = schur_ready_ = false; sub_factored_ = -1; }
   int sub_factored_ = -1;   // node whose subtree was ULV-factored as a matrix of its own (factor_node), -1: none
   std::unique_ptr<Arena> schur_;
   // device-resident node table of the extraction kernels (persist arena; rebuilt after a compression)

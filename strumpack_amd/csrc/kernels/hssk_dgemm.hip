@@ -261,12 +261,16 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
 //    MFMA sub-step s is pi(s, l4) = 2 s + (l4 & 1) + 8 (l4 >> 1) for BOTH operands (any bijection does: the sum over
 //    k is what it is), which is what lets one 16-byte piece of the k-contiguous operand serve two lane groups.
 //  * GEN: op(B) is not in memory at all -- it is a formula (hssk_gen) of the DIFFERENCE of its indices, G(i, j) = tau(i - j)
-//    (the Toeplitz kinds): the 16 x 128 tile of a stage holds only 143 distinct values, tau on a run of consecutive differences.
-//    That run is the B "image": one entry each for the first 143 threads of the workgroup, evaluated two stages ahead under
-//    the MFMAs, and a lane reads its operand word for (k, j) at position k + 127 - j of the run (a 32-lane read group covers
-//    17 consecutive words: conflict-free).  Only the A panel still travels.  Same tiles, stages and summation order as the
-//    stored operand -- the results are bitwise equal.  (The FP64 vector instructions of the evaluation run on the same
-//    units as the FP64 MFMA: with every thread evaluating its four entries of the full tile the kernel lost 17 %.)
+//    (the Toeplitz kinds).  The 16 x 128 tile of a stage then holds only 143 distinct values -- tau on a run of consecutive
+//    differences -- and the run of the next stage is the same run moved on by 16: the operand of the whole K-chunk is ONE
+//    sliding window, kept in a 256-entry circular buffer in the LDS (entry (d - d_first) mod 256).  A lane reads its operand
+//    word for tile position (k, j) at k + 127 - j (+ 16 per stage) of the window -- a 32-lane read group covers 17
+//    consecutive entries: conflict-free --, and per stage SIXTEEN new entries are evaluated, two stages ahead, by one wave
+//    (the waves take turns; the entries they overwrite left the window long before).  Only the A panel still travels.  Same
+//    tiles, stages and summation order as the stored operand: the results are bitwise equal.  (Why so frugal: the FP64
+//    vector instructions of the evaluation -- an IEEE division -- execute on the units the FP64 MFMA runs on.  Every
+//    thread evaluating its four entries of the full tile cost 17 % of the kernel; a branch around the MFMAs of the
+//    evaluating waves made the compiler copy the accumulators, 30 %.)
 template <int MBLK, bool TRANSB, int TAG = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k, const double* __restrict__ A, long long lda,
                                                         const double* __restrict__ B, long long ldb,
@@ -325,17 +329,13 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     else if (TRANSB) hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (c - MBLK) * 1024 + wave * 128);
     else hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (wave + 8 * (c - MBLK)) * 128);
   };
-  // generated operand: thread e < 143 owns entry e of the stage's run, tau(d0 + e) with d0 = (first k of the stage) - (last
-  // column of the tile) -- the difference k - j of tile position (k, j) is d0 + k + 127 - j; transposed, the formula takes
-  // the negated difference.  Threads 143 .. 159 fill the pad; the stage is clamped like the copies.
-  constexpr int GEN_RUN = 160;
-  const int gen_e = tid < GEN_RUN ? tid : GEN_RUN - 1;
-  const int gen_d = (int)kbeg - ((int)(jg0 + j0) + 127) + gen_e;
-  auto gen_one = [&](int stage, int slot) {
-    if (!GEN) return;
-    const int sc = stage < nst ? stage : nst - 1;
-    const int d = gen_d + sc * BK;
-    lds[slot * SLOT + A_DBL + gen_e] = TRANSB ? hssk_gen_eval(gen, 0, d) : hssk_gen_eval(gen, d, 0);
+  // generated operand: the window of tau over the differences d_first + i, i = 0, 1, ... (d_first = first k of the chunk minus
+  // the last column of the tile; transposed, the formula takes the negated difference), entry i at run[i & 255]
+  double* run = lds + 3 * SLOT;
+  const int gen_dfirst = (int)kbeg - ((int)(jg0 + j0) + 127);
+  auto gen_entry = [&](int i) {
+    const int d = gen_dfirst + i;
+    run[i & 255] = TRANSB ? hssk_gen_eval(gen, 0, d) : hssk_gen_eval(gen, d, 0);
   };
   auto copy_stage = [&](int stage, int slot) {
 #pragma unroll
@@ -353,10 +353,9 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
   for (int b = 0; b < NT; b++) {
     const int jl = wn + b * 16 + l15;
-    if (GEN) {
-      const int o = hssk_opaque(A_DBL + (l4 & 1) + 8 * (l4 >> 1) + 127 - jl);
+    if (GEN) {   // window index of tile position (k of sub-step s, j): k + 127 - j, before the stage's 16 st
 #pragma unroll
-      for (int s = 0; s < 4; s++) offB[b][s] = o + 2 * s;
+      for (int s = 0; s < 4; s++) offB[b][s] = 2 * s + (l4 & 1) + 8 * (l4 >> 1) + 127 - jl;
     } else if (KJ_IMAGE) {
       const int o = hssk_opaque(A_DBL + (jl >> 6) * 1024 + ((l4 & 1) + 8 * (l4 >> 1)) * 64 + ((jl & 63) ^ (16 * (l4 & 1))));
 #pragma unroll
@@ -374,12 +373,12 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
   double af[2][MT], bf[2][NT];
-  auto frags = [&](int slot, int s, int set) {
+  auto frags = [&](int slot, int s, int set, int stq) {
     const double* base = lds + slot * SLOT;
 #pragma unroll
     for (int a = 0; a < MT; a++) af[set][a] = base[offA[a] + s * 128];
 #pragma unroll
-    for (int b = 0; b < NT; b++) bf[set][b] = base[offB[b][s]];
+    for (int b = 0; b < NT; b++) bf[set][b] = GEN ? run[(offB[b][s] + 16 * stq) & 255] : base[offB[b][s]];
   };
   auto mfmas = [&](int set) {
 #pragma unroll
@@ -388,36 +387,22 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
       for (int b = 0; b < NT; b++)  // swapped operands: lane holds C[i = l15][j = l4 + 4r]
         acc[a][b] = hssk_mfma_f64_16x16x4(bf[set][b], af[set][a], acc[a][b]);
   };
-  // twelve MFMAs and, for a generated operand, one entry of the tile two stages ahead, interleaved by the compiler on request
-  auto mfmas_gen = [&](int set, int stage2, int slot2) {
-    mfmas(set);
-    if (GEN) {
-      gen_one(stage2, slot2);
-#pragma unroll
-      for (int g = 0; g < MT * NT; g++) {
-        hssk_sched_group<HSSK_SG_MFMA, 1>();
-        hssk_sched_group<HSSK_SG_VALU, 3>();
-      }
-    }
-  };
   // one stage out of ring slot S; on entry the fragments of its sub-step 0 are in set 0
   auto stage = [&](int st, auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
     // (scheduling fences: left alone, the compiler hoists the reads of later sub-steps, fuses them into half-rate
     // ds_read2st64_b64 pairs and then waits for ALL of them in front of the next MFMA)
-    // A generated operand's run is evaluated two stages ahead of its use (slot S + 2 was released by the previous barrier
-    // and is read after the next one), by the first three waves only, its ~20 vector instructions dealt out between the
-    // MFMAs of the first sub-step
-    frags(S, 1, 1);
+    frags(S, 1, 1, st);
     hssk_sched_barrier();
-    if (GEN && wave < 3) mfmas_gen(0, st + 2, (S + 2) % 3);
-    else mfmas(0);
+    if (GEN && wave == (st & 3)) gen_entry(159 + 16 * st + l15);   // the window's sixteen entries for stage st + 2 (waves in turn)
     hssk_sched_barrier();
-    frags(S, 2, 0);
+    mfmas(0);
+    hssk_sched_barrier();
+    frags(S, 2, 0, st);
     hssk_sched_barrier();
     mfmas(1);
     hssk_sched_barrier();
-    frags(S, 3, 1);
+    frags(S, 3, 1, st);
     hssk_sched_barrier();
     mfmas(0);
     hssk_sched_barrier();
@@ -432,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
       for (int b = 0; b < NT; b++) acc[a][b] = hssk_mfma_f64_16x16x4(bf[1][b], af[1][a], acc[a][b]);
       hssk_sched_barrier();
-      if (a == 0) frags((S + 1) % 3, 0, 0);
+      if (a == 0) frags((S + 1) % 3, 0, 0, st + 1);
       else if (a - 1 < NCH) copy_one(st + 3, S, a - 1);
       hssk_sched_barrier();
     }
@@ -445,11 +430,10 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     copy_stage(0, 0);
     copy_stage(1, 1);
     copy_stage(2, 2);
-    gen_one(0, 0);   // (stage st evaluates the run of stage st + 2)
-    gen_one(1, 1);
+    if (GEN && tid < 160) gen_entry(tid);   // the window of stages 0 and 1 (stage st adds the entries of stage st + 2)
     hssk_wait_glds<2 * NCH>();
     hssk_wg_barrier();
-    frags(0, 0, 0);
+    frags(0, 0, 0, 0);
     int st = 0;
     for (; st + 3 <= nst; st += 3) {
       stage(st, std::integral_constant<int, 0>());
@@ -559,7 +543,7 @@ void launch_bm(int BM, hssk_ctx* ctx, int transB, dim3 grid, int m, long long n,
 
 // the eight-wave LDS-DMA form (sketch_kernel): BM = 64 MBLK rows, 128 columns per workgroup, three ring stages
 constexpr int BN2 = 128;
-inline size_t sketch_lds_bytes(int mblk) { return sizeof(double) * 3 * (size_t)(64 * mblk + BN2) * BK; }
+inline size_t sketch_lds_bytes(int mblk) { return sizeof(double) * (3 * (size_t)(64 * mblk + BN2) * BK + 256); }   // ring + the generated operand's window
 template <int MBLK, int TAG>
 void launch_sketch_m(hssk_ctx* ctx, int transB, dim3 grid, long long n, long long k, const double* A, long long lda,
                      const double* B, long long ldb, double* P, long long ldp, long long pstride, long long kchunk,

@@ -20,15 +20,17 @@ separator's graph the same way, sparse/fronts/FrontBLR.cpp:622-640); the update 
 import numpy as np
 
 
-def plane_order(n, leaf):
-    """recursive coordinate bisection of the n x n plane: permutation (new -> old, old = ix * n + iy) and the tile sizes"""
+def plane_order(n, leaf, ny=None):
+    """recursive coordinate bisection of the n x ny plane (ny = n by default): permutation (new -> old, old = ix * ny + iy) and
+    the tile sizes"""
+    ny = n if ny is None else ny
     perm, tiles, boxes = [], [], []
 
     def rec(x0, x1, y0, y1):
         cnt = (x1 - x0) * (y1 - y0)
         if cnt <= leaf or cnt <= 1:
             xs, ys = np.meshgrid(np.arange(x0, x1), np.arange(y0, y1), indexing="ij")
-            perm.extend((xs * n + ys).ravel().tolist())
+            perm.extend((xs * ny + ys).ravel().tolist())
             tiles.append(cnt)
             boxes.append((x0, x1, y0, y1))
             return
@@ -41,7 +43,7 @@ def plane_order(n, leaf):
             rec(x0, x1, y0, ym)
             rec(x0, x1, ym, y1)
 
-    rec(0, n, 0, n)
+    rec(0, n, 0, ny)
     return np.array(perm), tiles, boxes
 
 
@@ -53,17 +55,23 @@ def _chain(lmb, p):
     return g11, g1p
 
 
-def poisson_front(n, p_left, p_right, leaf, upd="both", unsym=False, matmul=None):
-    """-> dict(F11, F12, F21, F22 (Fortran order), tiles1, tiles2, boxes); dsep = n^2, dupd = n^2 per update plane.
+def poisson_front(n, p_left, p_right, leaf, upd="both", unsym=False, matmul=None, ny=None):
+    """-> dict(F11, F12, F21, F22 (Fortran order), tiles1, tiles2, boxes); separator = an n x ny plane (ny = n by default),
+    dsep = n ny, dupd = n ny per update plane.
     unsym: rows and columns scaled by two different smooth positive diagonals (same rank structure, F21 != F12^T).
     matmul(A, B): optional replacement of A @ B (bench.py hands in a torch product on the device for large planes)."""
     mm = matmul or (lambda a, b: a @ b)
-    k = np.arange(1, n + 1)
-    S = np.sqrt(2.0 / (n + 1)) * np.sin(np.outer(k, k) * np.pi / (n + 1))
-    Q = np.kron(S, S)
-    c = 2.0 * np.cos(k * np.pi / (n + 1))
-    lmb = (6.0 - c[:, None] - c[None, :]).ravel()
-    perm, tiles1, boxes = plane_order(n, leaf)
+    ny = n if ny is None else ny
+
+    def sine(m):
+        k = np.arange(1, m + 1)
+        return np.sqrt(2.0 / (m + 1)) * np.sin(np.outer(k, k) * np.pi / (m + 1)), 2.0 * np.cos(k * np.pi / (m + 1))
+
+    Sx, cx = sine(n)
+    Sy, cy = sine(ny)
+    Q = np.kron(Sx, Sy)
+    lmb = (6.0 - cx[:, None] - cy[None, :]).ravel()
+    perm, tiles1, boxes = plane_order(n, leaf, ny)
     Qp = np.ascontiguousarray(Q[perm, :])
     fun = lambda f: mm(Qp * f[None, :], Qp.T)
     gl11, gl1p = _chain(lmb, p_left)
@@ -74,7 +82,7 @@ def poisson_front(n, p_left, p_right, leaf, upd="both", unsym=False, matmul=None
     for s in sides:
         blocks12.append(fun(-(gl1p if s == "L" else gr1p)))
         blocks22.append(fun(-(gl11 if s == "L" else gr11)))
-    ds = n * n
+    ds = n * ny
     du = ds * len(sides)
     F12 = np.concatenate(blocks12, axis=1) if sides else np.zeros((ds, 0))
     F22 = np.zeros((du, du))
@@ -90,7 +98,7 @@ def poisson_front(n, p_left, p_right, leaf, upd="both", unsym=False, matmul=None
         F22 = dr[ds:, None] * F22 * dc[None, ds:]
     tiles2 = [leaf] * (du // leaf) + ([du % leaf] if du % leaf else [])
     f = np.asfortranarray
-    return dict(F11=f(F11), F12=f(F12), F21=f(F21), F22=f(F22), tiles1=tiles1, tiles2=tiles2, boxes=boxes, n=n)
+    return dict(F11=f(F11), F12=f(F12), F21=f(F21), F22=f(F22), tiles1=tiles1, tiles2=tiles2, boxes=boxes, n=n, ny=ny)
 
 
 def strong_admissibility(boxes):
@@ -109,3 +117,55 @@ def dense_schur(fr):
     """F22 - F21 F11^{-1} F12 and F11 by dense algebra (the exact answers the compressed factorization approximates)"""
     X = np.linalg.solve(fr["F11"], fr["F12"]) if fr["F12"].shape[1] else fr["F12"]
     return fr["F22"] - fr["F21"] @ X
+
+
+def poisson_front_device(torch, nx, ny, p_left, p_right, leaf, upd="both", device=None):
+    """The same front for an nx x ny separator plane, built and LEFT on the GPU (torch tensors; setup plumbing for fronts of the
+    200^3 problem's own size, where the blocks are tens of GB): dsep = nx ny, dupd = nx ny per update plane.
+    -> dict: F11 (ds x ds), F12cm, F21cm, F22 as tensors whose MEMORY is the column-major block (every block is symmetric or a
+    row of symmetric blocks, so row-major storage of the transpose is the column-major block), tiles1, tiles2, boxes, norm."""
+    dev, dt = device if device is not None else torch.device("cuda", torch.cuda.current_device()), torch.float64
+
+    def sine(n):
+        k = torch.arange(1, n + 1, dtype=dt, device=dev)
+        return np.sqrt(2.0 / (n + 1)) * torch.sin(torch.outer(k, k) * (np.pi / (n + 1))), 2.0 * torch.cos(k * (np.pi / (n + 1)))
+
+    Sx, cx = sine(nx)
+    Sy, cy = sine(ny)
+    lmb = (6.0 - cx[:, None] - cy[None, :]).reshape(-1)
+    perm, tiles1, boxes = plane_order(nx, leaf, ny)
+    Q = torch.kron(Sx, Sy)[torch.as_tensor(perm, device=dev)]
+    del Sx, Sy
+
+    def chain(p):
+        th = torch.acosh(lmb / 2.0)
+        den = 1.0 - torch.exp(-2.0 * (p + 1) * th)
+        return torch.exp(-th) * (1.0 - torch.exp(-2.0 * p * th)) / den, torch.exp(-p * th) * (1.0 - torch.exp(-2.0 * th)) / den
+
+    fun = lambda f: (Q * f[None, :]) @ Q.T
+    gl11, gl1p = chain(p_left)
+    gr11, gr1p = chain(p_right)
+    F11 = fun(lmb - gl11 - gr11)
+    sides = {"both": ("L", "R"), "left": ("L",), "right": ("R",), "none": ()}[upd]
+    ds = nx * ny
+    du = ds * len(sides)
+    out = dict(F11=F11, tiles1=tiles1, boxes=boxes, nx=nx, ny=ny, ds=ds, du=du)
+    n2 = float(torch.linalg.norm(F11)) ** 2
+    if sides:
+        b12 = [fun(-(gl1p if s_ == "L" else gr1p)) for s_ in sides]
+        # column-major ds x du block [B_0 | B_1] == row-major (du x ds) stack of the (symmetric) blocks; F21 = F12^T column-major
+        # (du x ds) == row-major (ds x du) array [B_0 | B_1]
+        out["F12cm"] = torch.cat(b12, dim=0).contiguous()
+        out["F21cm"] = torch.cat(b12, dim=1).contiguous()
+        n2 += 2.0 * sum(float(torch.linalg.norm(b)) ** 2 for b in b12)
+        del b12
+        F22 = torch.zeros((du, du), dtype=dt, device=dev)
+        for q, s_ in enumerate(sides):
+            F22[q * ds:(q + 1) * ds, q * ds:(q + 1) * ds] = fun(-(gl11 if s_ == "L" else gr11))
+        out["F22"] = F22
+    del Q
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    out["norm"] = float(np.sqrt(n2))
+    out["tiles2"] = [leaf] * (du // leaf) + ([du % leaf] if du % leaf else [])
+    return out

@@ -113,3 +113,7 @@ def test_generated_operand_fused_sketch(L, n, leaf, kind, d0, dd):
     hk = K.Hssk(emu_lib.build())
     HC.check_generator(L, hk, n, leaf, kind, d0=d0, dd=dd)
     hk.close()
+
+
+def test_factor_ahead_of_the_compression(L):
+    HC.check_factor_ahead(L)

@@ -459,3 +459,7 @@ def test_generated_operand_beyond_hbm():
         ref = 1.0 / (1.0 + np.abs(ii[:, None] - jc[None, :]))
         assert np.abs(blocks[bi] - ref).max() <= 1e-3
     H.destroy()
+
+
+def test_factor_ahead_of_the_compression(L):
+    HC.check_factor_ahead(L, n=6000, leaf=128)
