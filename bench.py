@@ -420,7 +420,7 @@ def blr_front_device_workload(a, L, hk, torch, BF, nx, ny, leaf):
                                   + a.front_lra.upper() + " tiles, rel_tol 1e-4, tiles of %d) of an exact 3D 7-point Poisson front: separator %dx%d plane "
                                   "(dsep=%d), update part dupd=%d, built and resident in HBM; + forward / backward solve phase, 1 rhs" % (leaf, nx, ny, ds, du),
                       "dsep": ds, "dupd": du, "tiles": [len(fr["tiles1"]), len(fr["tiles2"])], "leaf": leaf, "rel_tol": rtol,
-                      "lookahead": int(os.environ.get("STRUMPACK_AMD_BLR_LOOKAHEAD", "8"))},
+                      "lookahead": os.environ.get("STRUMPACK_AMD_BLR_LOOKAHEAD", "sqrt(block rows left), 4..24")},
            "phases_ms": {"factor_wall": med("t_factor") * 1e3, "one_stream_device_clock": phases},
            "flops": {"schur_gemm": st["f_schur"], "total": st["f_total"]},
            "blr": {"max_rank": int(st["max_rank"]), "mean_rank": float(lr.mean()) if lr.size else 0.0,

@@ -1,9 +1,11 @@
 // DeviceBLR implementation (see blr_engine.hpp for the reference behaviour it follows).
 #include "blr_engine.hpp"
+#include "DevicePool.hpp"
 
 #include <random>
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
@@ -21,17 +23,18 @@ inline double now() {
 }
 }  // namespace
 
-// bump allocator over device chunks (hssk_malloc); rewind() keeps the chunks
+// bump allocator over device chunks from the process-wide pool (DevicePool.hpp); rewind() keeps the chunks
 class Arena2 {
  public:
   explicit Arena2(size_t chunk) : chunk_(chunk) {}
-  ~Arena2() { for (auto& c : chunks_) hssk_free(c.first); }
+  ~Arena2() { for (auto& c : chunks_) DevicePool::get().release(c.first, c.second); }
   void* alloc(size_t bytes) {
     bytes = (std::max<size_t>(bytes, 8) + 255) & ~size_t(255);
     while (bytes > left_) {
       if (next_ < chunks_.size()) { cur_ = (char*)chunks_[next_].first; left_ = chunks_[next_].second; next_++; continue; }
-      const size_t c = std::max(chunk_, bytes);
-      void* p = hssk_malloc((long long)c);
+      const size_t gran = size_t(64) << 20;   // (sizes on a grid: the next factorization of a front this size finds them in the pool)
+      const size_t c = (std::max(chunk_, bytes) + gran - 1) / gran * gran;
+      void* p = DevicePool::get().acquire(c);
       if (!p) throw std::runtime_error(std::string("device allocation failed: ") + hssk_last_error());
       chunks_.emplace_back(p, c);
       next_ = chunks_.size();
@@ -72,14 +75,22 @@ DeviceBLR::~DeviceBLR() {
   store_.reset();
   tmp_.reset();
   blk_.reset();
-  if (dA_) hssk_free(dA_);
+  free_array();
   hssk_ctx_destroy(ctx_);
 }
 
+void DeviceBLR::free_array() {
+  if (dA_) DevicePool::get().release(dA_, dA_bytes_);
+  dA_ = nullptr;
+  dA_bytes_ = 0;
+}
+
 void DeviceBLR::alloc_array() {
-  if (dA_) { hssk_free(dA_); dA_ = nullptr; }
+  free_array();
   ld_ = std::max(m_, 1);
-  dA_ = (double*)hssk_malloc((long long)sizeof(double) * ld_ * std::max(n_, 1));
+  const size_t gran = size_t(64) << 20;
+  dA_bytes_ = (sizeof(double) * (size_t)ld_ * std::max(n_, 1) + gran - 1) / gran * gran;
+  dA_ = (double*)DevicePool::get().acquire(dA_bytes_);
   if (!dA_) throw std::runtime_error("BLR: device allocation of the operand failed");
   store_->rewind();
   tiles_.assign(tiles_.size(), Tile());
@@ -231,8 +242,7 @@ void DeviceBLR::compress_host(const double* A, long long lda, const char* adm) {
     compress_tiles(ij, adm);
   }
   ck(hssk_sync(ctx_));
-  hssk_free(dA_);
-  dA_ = nullptr;
+  free_array();
   compressed_ = true;
   t_compress = now() - t0;
 }
@@ -247,8 +257,7 @@ void DeviceBLR::compress_device(const double* dA, long long lda, const char* adm
     compress_tiles(ij, adm);
   }
   ck(hssk_sync(ctx_));
-  hssk_free(dA_);
-  dA_ = nullptr;
+  free_array();
   compressed_ = true;
   t_compress = now() - t0;
 }
@@ -341,8 +350,13 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
   invU_.assign(rb, nullptr);
   // look-ahead of the Schur updates (below): block steps per deferred update of the trailing array; 1 = every step updates
   // everything (the right-looking schedule as written)
-  const int la = [] { const char* e = std::getenv("STRUMPACK_AMD_BLR_LOOKAHEAD"); return e ? std::max(1, std::atoi(e)) : 8; }();
-  const bool defer = la > 1;
+  // Depth: with nt block rows / columns left, a block of `la` steps reads and writes ~ la (nt) tiles in its strips per step and
+  // nt^2 / la in its deferred update: least near la = sqrt(nt) (measured on the 96 x 96 plane's front, nt = 136: Schur phase
+  // 104 ms at depth 1, 41 ms at 8 and at 16).  STRUMPACK_AMD_BLR_LOOKAHEAD fixes it.
+  const int la_fixed = [] { const char* e = std::getenv("STRUMPACK_AMD_BLR_LOOKAHEAD"); return e ? std::max(1, std::atoi(e)) : 0; }();
+  auto depth = [&](int first) { return la_fixed ? la_fixed : std::max(4, std::min(24, (int)std::lround(std::sqrt((double)(rb - first))))); };
+  int la = depth(0);
+  const bool defer = la_fixed != 1;
   struct Pending { int p; double* T; int ldT; std::vector<int> off; };   // step, its product T_p (rows > p), column offset of tile (p, j) at [j - p - 1]
   std::vector<Pending> pend;
   int b0 = 0, b1 = std::min(la, nsteps);
@@ -422,7 +436,7 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
     // the rest of the array (rows and columns >= b1) receives all `la` updates in ONE product per block column,
     // A(b1:, j) -= [T_b0(:, R_b0,j) | ... | T_b1-1(:, R_b1-1,j)] [V_b0,j | ... | V_b1-1,j]^T: read and written once per block,
     // with an inner dimension la times as long (the same sums in another order: left-looking inside the trailing part).
-    if (i == b1) { b0 = b1; b1 = std::min(b0 + la, nsteps); }
+    if (i == b1) { b0 = b1; la = depth(b0); b1 = std::min(b0 + la, nsteps); }
     (void)b0;
     const int nrest = m_ - roff_[i + 1];
     if (R > 0 && nrest > 0) {

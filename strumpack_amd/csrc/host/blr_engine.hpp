@@ -114,6 +114,7 @@ class DeviceBLR {
   double* blk(int i, int j) const { return dA_ + roff_[i] + (size_t)coff_[j] * ld_; }
   void load(const double* A, long long lda, bool on_device);
   void alloc_array();
+  void free_array();
   void put_block(int r0, int c0, int rows, int cols, const double* src, long long lds, bool on_device);
   void partial_factor(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12, const double* F21,
                       long long ld21, const double* F22, long long ld22, const char* adm11, bool on_device);
@@ -130,7 +131,8 @@ class DeviceBLR {
   BLREngineOptions o_;
   hssk_ctx* ctx_ = nullptr;
   hssk_ctx* ctx2_ = nullptr;   // second stream: the diagonal tile's LU runs next to the compression of its block row / column
-  double* dA_ = nullptr;   // n x n working array / diagonal tiles
+  double* dA_ = nullptr;   // n x n working array / diagonal tiles (a chunk of the process-wide pool)
+  size_t dA_bytes_ = 0;
   long long ld_ = 0;
   int* dpiv_ = nullptr;    // pivots of the diagonal tiles (0-based, local), rows() ints
   std::vector<const double*> invL_, invU_;   // per block step: inverted 64 x 64 diagonal blocks of the tile's L and U (tiles of >= 128 rows; else null)

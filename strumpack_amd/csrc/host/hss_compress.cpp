@@ -201,6 +201,11 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       int dnew = (d == o_.d0) ? d + dd : dd;
       if (c + dnew > dcap) return false;
       fill_random(c, dnew);
+      if (stats_.rounds == 0 && src.extract_before_sample()) {   // the leaves' diagonal blocks: independent of the samples
+        std::vector<int> leaves;
+        for (auto& ids : own_by_height_) for (int id : ids) if (nodes_[id].leaf() && nodes_[id].lvl != 0) leaves.push_back(id);
+        extract_blocks(src, leaves);
+      }
       double t0 = now();
       src.sample(*this, c, dnew);
       ck(hssk_sync(ctx_));
@@ -373,6 +378,7 @@ void DeviceHSS::extract_blocks(Source& src, const std::vector<int>& ids) {
   for (int id : ids) {
     Node& nd = nodes_[id];
     if (nd.leaf()) {
+      if (nd.D) continue;   // (taken out ahead of the sketch: compress_attempt)
       nd.D = persist_->dbl((size_t)nd.m * nd.m);
       reqs.push_back(ElemReq{nullptr, nullptr, nullptr, nullptr, nd.lo, nd.lo, nd.m, nd.m, nd.D, nd.m});
     } else {

@@ -5,6 +5,7 @@
 #include "hss_engine.hpp"
 #include "Comm.hpp"
 #include "LinearNormal.hpp"
+#include "DevicePool.hpp"
 
 #include <unistd.h>
 #include <atomic>
@@ -55,44 +56,6 @@ struct HostRng {
   std::mt19937 mer{0};
   std::normal_distribution<double> nd;
   std::uniform_real_distribution<double> ud;
-};
-
-// process-wide pool of device chunks: arenas return their chunks here instead of hipFree, so that
-// repeated constructions (solver loops, benchmarks) do not pay hipMalloc / hipFree page-table work
-class DevicePool {
- public:
-  static DevicePool& get() { static DevicePool p; return p; }
-  void* acquire(size_t bytes) {
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      auto it = free_.find(bytes);
-      if (it != free_.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); cached_ -= bytes; return p; }
-    }
-    void* p = hssk_malloc((long long)bytes);
-    if (!p) {  // memory pressure: drop the cache and retry once
-      trim();
-      p = hssk_malloc((long long)bytes);
-    }
-    return p;
-  }
-  void release(void* p, size_t bytes) {
-    std::lock_guard<std::mutex> g(mu_);
-    if (cached_ + bytes > limit_) { hssk_free(p); return; }
-    free_[bytes].push_back(p);
-    cached_ += bytes;
-  }
-  void trim() {
-    std::lock_guard<std::mutex> g(mu_);
-    for (auto& kv : free_) for (void* p : kv.second) hssk_free(p);
-    free_.clear();
-    cached_ = 0;
-  }
-  ~DevicePool() { for (auto& kv : free_) for (void* p : kv.second) hssk_free(p); }
-
- private:
-  std::mutex mu_;
-  std::map<size_t, std::vector<void*>> free_;
-  size_t cached_ = 0, limit_ = size_t(8) << 30;
 };
 
 // bump allocator over large device chunks
@@ -236,6 +199,9 @@ struct DeviceHSS::Source {
   // Srt[r0:r0+dn, :] = (A R)^T, Sct[r0:r0+dn, :] = (A^T R)^T for the sample rows [r0, r0+dn) of Rt
   virtual void sample(DeviceHSS& H, int r0, int dn) = 0;
   virtual void extract(DeviceHSS& H, const std::vector<ElemReq>& reqs) = 0;
+  // extract() needs nothing sample() produces or uploads (operand resident on the device, or a formula): the leaves' diagonal
+  // blocks are then taken out BEFORE the sketch instead of behind it -- off the latency chain of the tree levels
+  virtual bool extract_before_sample() const { return false; }
 };
 
 }  // namespace HSS

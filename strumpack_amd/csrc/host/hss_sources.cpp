@@ -9,6 +9,7 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
   const double* dA;
   long long lda;
   DenseDeviceSource(const double* a, long long l) : dA(a), lda(l) {}
+  bool extract_before_sample() const override { return true; }
   void sample(DeviceHSS& H, int r0, int dn) override {
     const long long N = H.n_;
     // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout.
@@ -393,6 +394,7 @@ struct DeviceHSS::CallbackSource : DeviceHSS::Source {
 struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
   hssk_gen g;
   explicit GeneratorSource(const hssk_gen& g_) : g(g_) {}
+  bool extract_before_sample() const override { return true; }
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.sj_pat_) throw std::invalid_argument("generated operand: the SJLT sketch streams a stored matrix; use the Gaussian sketch");
     const long long N = H.n_;
