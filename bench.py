@@ -39,8 +39,10 @@ def parse():
     p.add_argument("--rel-tol", type=float, default=1e-4)
     p.add_argument("--nrhs", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-factor-ahead", action="store_true", help="toeplitz workload: factor only when told to (no overlap of the "
-                   "factorization's levels with the compression's)")
+    p.add_argument("--factor-ahead", action="store_true", help="toeplitz workload: tell the library that a factorization follows -- it enqueues "
+                   "every tree level's ULV factorization on a second stream as soon as the compression has settled the level (SPXHSSOptions::factor_ahead)")
+    p.add_argument("--symmetric", action="store_true", help="toeplitz workload, SECONDARY line: declare the operand symmetric (SPXHSSOptions::symmetric_operand = 2, "
+                   "checked on a sample): A^T R = A R, the second sketch GEMM is a copy; `value` counts the executed flops")
     p.add_argument("--cpu-n", type=int, default=32768)
     p.add_argument("--sketch", choices=["gaussian", "sjlt"], default="gaussian",
                    help="gaussian = the reference's default (BASELINE's metric is quoted on it); sjlt = its "
@@ -569,10 +571,10 @@ def main():
         return
 
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
-    # factor_ahead: the step is construct + factor + solve, so the library is told that a factorization follows -- it enqueues
-    # every tree level's ULV factorization on a second stream as soon as the compression has settled the level (all of it
-    # inside the timed region; --no-factor-ahead: the phases one after the other, as in rounds 1-3)
-    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch, factor_ahead=not a.no_factor_ahead)
+    # --factor-ahead (measured in round 4: no gain -- the leaf level's factorization and the first inner levels of the
+    # compression both want the whole chip): off by default
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch, factor_ahead=a.factor_ahead,
+                                              symmetric=2 if a.symmetric else 0)
     # ---- process group.  Default for N > 1: the library's own RCCL communicator (collectives on the engine's stream) and
     # a SHARDED operand -- every rank generates only its row block and its column block of A (2 x 80 GB / N), never the
     # whole matrix.  STRUMPACK_AMD_BENCH_COMM=torch selects the round-1 path (replicated A, torch.distributed callback).
@@ -743,8 +745,10 @@ def main():
     traffic = tsrc = None
     if rank == 0 and world == 1 and a.sketch == "gaussian" and not os.environ.get("STRUMPACK_AMD_BENCH_INNER"):
         extra = ["--size", str(n), "--leaf", str(a.leaf), "--rel-tol", str(a.rel_tol), "--nrhs", str(a.nrhs), "--operand", a.operand]
-        if a.no_factor_ahead:
-            extra.append("--no-factor-ahead")
+        if a.factor_ahead:
+            extra.append("--factor-ahead")
+        if a.symmetric:
+            extra.append("--symmetric")
         # the MAIN launches of both sketch products: sketch_kernel<rows / 64, transposed?, group 0>
         tmain = measure_traffic(extra, r"sketch_kernel<\d, (true|false), 0, (true|false)>")
         if tmain is not None:
@@ -761,7 +765,9 @@ def main():
                                % (n, n, "Philox samples" if a.sketch == "gaussian" else "SJLT sketch, nnz=4: NOT the configuration of BASELINE's metric",
                                   a.leaf, a.rel_tol, a.nrhs),
                    "sketch": a.sketch, "n": n, "leaf": a.leaf, "rel_tol": a.rel_tol, "nrhs": a.nrhs,
-                   "factor_ahead": (not a.no_factor_ahead),
+                   "factor_ahead": a.factor_ahead,
+                   "symmetric_hint": ("operand declared symmetric and checked on a sample: ONE sketch product, the other a copy -- NOT the general "
+                                      "two-product path of the headline line; value counts executed flops" if a.symmetric else False),
                    "operand": ("generated: A is the library's Toeplitz formula, its tiles evaluated inside the sketch kernel -- never stored "
                                "(SPX_d_struct_from_generator; bitwise the compression of the stored matrix); NOT BASELINE's configuration, which holds A in HBM"
                                if generated else "resident in HBM before the clock starts"),

@@ -102,6 +102,9 @@ typedef struct SPXHSSOptions {
   /* the caller will factor: the ULV factorization of each tree level is enqueued on a second stream as soon as the
    * compression has settled that level; SP_d_struct_factor then only waits for it (0: factor when told to) */
   int factor_ahead;
+  /* the operand is symmetric (0 no claim; 1 trusted; 2 checked on a sample of entries first): with the one random matrix of
+   * both products A^T R = A R, so the second sketch GEMM is a copy of the first (device-resident and generated operands) */
+  int symmetric_operand;
 } SPXHSSOptions;
 void SPX_d_struct_default_hss_options(SPXHSSOptions* h);
 /* like SP_d_struct_from_dense, with explicit HSS options (h may be NULL) */

@@ -17,7 +17,7 @@ class SPXHSSOptions(C.Structure):
     _fields_ = [("d0", C.c_int), ("dd", C.c_int), ("p", C.c_int), ("compression_algorithm", C.c_int),
                 ("random_engine", C.c_int), ("random_distribution", C.c_int),
                 ("compression_sketch", C.c_int), ("sjlt_algo", C.c_int), ("nnz0", C.c_int), ("nnz", C.c_int),
-                ("factor_ahead", C.c_int)]
+                ("factor_ahead", C.c_int), ("symmetric_operand", C.c_int)]
 
 
 SP_SYMBOLS = [
@@ -261,7 +261,7 @@ class StructuredMatrix:
 
     @staticmethod
     def hss_options(lib, d0=None, dd=None, p=None, algorithm=None, random_engine=None, sketch=None, sjlt_algo=None,
-                    nnz0=None, nnz=None, factor_ahead=None):
+                    nnz0=None, nnz=None, factor_ahead=None, symmetric=None):
         h = SPXHSSOptions()
         lib.SPX_d_struct_default_hss_options(C.byref(h))
         if d0 is not None:
@@ -284,6 +284,8 @@ class StructuredMatrix:
             h.nnz = nnz
         if factor_ahead is not None:
             h.factor_ahead = int(bool(factor_ahead))
+        if symmetric is not None:
+            h.symmetric_operand = int(symmetric)
         return h
 
     @classmethod

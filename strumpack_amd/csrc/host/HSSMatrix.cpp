@@ -31,6 +31,7 @@ EngineOptions HSSMatrix<double>::engine_options(const opts_t& o) {
   e.nnz0 = o.nnz0(); e.nnz = o.nnz();
   e.verbose = o.verbose();
   e.factor_ahead = o.factor_ahead();
+  e.symmetric = o.symmetric_operand();
   if (const char* fa = std::getenv("STRUMPACK_AMD_FACTOR_AHEAD")) e.factor_ahead = std::atoi(fa) != 0;
   if (const char* d = std::getenv("STRUMPACK_AMD_DEVICE")) e.device = std::atoi(d);
   return e;

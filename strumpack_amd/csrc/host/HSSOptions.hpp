@@ -63,6 +63,9 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   void set_user_defined_random(bool u) { user_defined_random_ = u; }
   // extension: the caller will factor -- the ULV factorization of each tree level is enqueued on a second stream as soon as
   // the compression has settled the level (DeviceHSS: EngineOptions::factor_ahead); factor() then only waits
+  // extension: the operand is symmetric by the caller's word (1: trusted, 2: checked on a sample): A^T R = A R, one sketch GEMM
+  void set_symmetric_operand(int s) { symmetric_ = s; }
+  int symmetric_operand() const { return symmetric_; }
   void set_factor_ahead(bool f) { factor_ahead_ = f; }
   bool factor_ahead() const { return factor_ahead_; }
   void set_synchronized_compression(bool sync) { sync_ = sync; }
@@ -169,6 +172,7 @@ template <typename scalar_t> class HSSOptions : public structured::StructuredOpt
   int nnz0_ = 4, nnz_ = 4;
   SJLTAlgo sjlt_algo_ = SJLTAlgo::CHUNK;
   bool user_defined_random_ = false, sync_ = false, log_ranks_ = false, factor_ahead_ = false;
+  int symmetric_ = 0;
   ClusteringAlgorithm clustering_algorithm_ = ClusteringAlgorithm::TWO_MEANS;
   int approximate_neighbors_ = 64, ann_iterations_ = 5;
   NeighborSearch neighbor_search_ = NeighborSearch::EXACT;

@@ -57,6 +57,7 @@ HSS::HSSOptions<double> get_hss_options(const CSPOptions* o, const SPXHSSOptions
     if (h->nnz0 > 0) ho.set_nnz0(h->nnz0);
     if (h->nnz > 0) ho.set_nnz(h->nnz);
     ho.set_factor_ahead(h->factor_ahead != 0);
+    ho.set_symmetric_operand(h->symmetric_operand);
   }
   return ho;
 }
@@ -199,6 +200,7 @@ void SPX_d_struct_default_hss_options(SPXHSSOptions* h) {
   h->compression_algorithm = 1; h->random_engine = 0; h->random_distribution = 0;
   h->compression_sketch = 0; h->sjlt_algo = 0; h->nnz0 = d.nnz0(); h->nnz = d.nnz();
   h->factor_ahead = 0;
+  h->symmetric_operand = 0;
 }
 int SPX_d_struct_from_dense_hss(CSPStructMat* S, int rows, int cols, const double* A, int ldA, const CSPOptions* opts,
                                 const SPXHSSOptions* h) {

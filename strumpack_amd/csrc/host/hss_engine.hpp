@@ -44,6 +44,11 @@ struct EngineOptions {
   // compression's upper levels instead of after it (extension; the reference factors when told to and not before).  factor()
   // then only waits.  Costs a caller who never factors the memory and the (overlapped) device time of the factors.
   bool factor_ahead = false;
+  // The operand is SYMMETRIC (a hint of the caller's): with the one random matrix both products use
+  // (compress_stable.hpp:77,139: Rc = Rr), Sc = A^T R is then Sr = A R and the second sketch GEMM is a copy.  1: trusted;
+  // 2: checked first on a sample of 512 x 512 scattered entries against their mirror images (an error if they differ).
+  // A wrong hint with 1 gives a wrong column basis -- a matrix that does not approximate the operand.
+  int symmetric = 0;
   bool verbose = false;
   int device = 0;
   // multi-GPU (one process per GPU): `allgather` is an in-place all-gather of a DEVICE buffer of
@@ -271,6 +276,7 @@ class DeviceHSS {
   struct CallbackSource;
   struct GeneratorSource;
 
+  void check_symmetry(Source& src);
   void build_tree(const structured::ClusterTree* tree);
   void compress(Source& src);
   bool compress_attempt(Source& src, int dcap);

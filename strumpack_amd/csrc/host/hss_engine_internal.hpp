@@ -202,6 +202,8 @@ struct DeviceHSS::Source {
   // extract() needs nothing sample() produces or uploads (operand resident on the device, or a formula): the leaves' diagonal
   // blocks are then taken out BEFORE the sketch instead of behind it -- off the latency chain of the tree levels
   virtual bool extract_before_sample() const { return false; }
+  // sketch products per round that sample() executes (2; 1 when the operand is symmetric by the caller's word: flop count)
+  virtual int products(const DeviceHSS&) const { return 2; }
 };
 
 }  // namespace HSS

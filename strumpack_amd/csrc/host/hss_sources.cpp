@@ -10,6 +10,7 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
   long long lda;
   DenseDeviceSource(const double* a, long long l) : dA(a), lda(l) {}
   bool extract_before_sample() const override { return true; }
+  int products(const DeviceHSS& H) const override { return (H.o_.symmetric && !H.sj_pat_) ? 1 : 2; }
   void sample(DeviceHSS& H, int r0, int dn) override {
     const long long N = H.n_;
     // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout.
@@ -44,10 +45,15 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
       ck(hssk_sync(H.ctx_));
       float ms = hssk_last_dgemm_ms(H.ctx_);
       if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
-      ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0 * lda, lda, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
-      ck(hssk_sync(H.ctx_));
-      ms = hssk_last_dgemm_ms(H.ctx_);
-      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
+      if (H.o_.symmetric) {   // A^T R = A R: the second product is a copy of the first
+        hssk_colgather_desc cp{H.Srt_ + r0 + j0 * H.dcap_, H.Sct_ + r0 + j0 * H.dcap_, nullptr, dn, (int)nloc, H.dcap_, H.dcap_, 0};
+        ck(hssk_gather_cols(H.ctx_, &cp, 1));
+      } else {
+        ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0 * lda, lda, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
+        ck(hssk_sync(H.ctx_));
+        ms = hssk_last_dgemm_ms(H.ctx_);
+        if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
+      }
     }
     if (H.o_.world > 1 && !H.dist_subtree_) {
       const long long bytes = (long long)sizeof(double) * H.dcap_ * H.cols_per_rank_;
@@ -395,6 +401,7 @@ struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
   hssk_gen g;
   explicit GeneratorSource(const hssk_gen& g_) : g(g_) {}
   bool extract_before_sample() const override { return true; }
+  int products(const DeviceHSS& H) const override { return H.o_.symmetric ? 1 : 2; }
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.sj_pat_) throw std::invalid_argument("generated operand: the SJLT sketch streams a stored matrix; use the Gaussian sketch");
     const long long N = H.n_;
@@ -415,8 +422,13 @@ struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
       // Sr(j0:j1, :) = A(j0:j1, :) R  ->  op(G)(k, j) = G(j0 + j, k);   Sc(j0:j1, :) = A(:, j0:j1)^T R  ->  op(G)(k, j) = G(k, j0 + j)
       ck(hssk_sketch_gen(H.ctx_, &g, 1, dn, nloc, N, j0, 1.0, H.Rt_ + r0, H.dcap_, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
       timed();
-      ck(hssk_sketch_gen(H.ctx_, &g, 0, dn, nloc, N, j0, 1.0, H.Rt_ + r0, H.dcap_, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
-      timed();
+      if (H.o_.symmetric) {   // A^T R = A R: the second product is a copy of the first
+        hssk_colgather_desc cp{H.Srt_ + r0 + j0 * H.dcap_, H.Sct_ + r0 + j0 * H.dcap_, nullptr, dn, (int)nloc, H.dcap_, H.dcap_, 0};
+        ck(hssk_gather_cols(H.ctx_, &cp, 1));
+      } else {
+        ck(hssk_sketch_gen(H.ctx_, &g, 0, dn, nloc, N, j0, 1.0, H.Rt_ + r0, H.dcap_, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
+        timed();
+      }
     }
     if (H.o_.world > 1 && !H.dist_subtree_) {
       const long long bytes = (long long)sizeof(double) * H.dcap_ * H.cols_per_rank_;
@@ -438,10 +450,40 @@ struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
 // ---------------------------------------------------------------------------------------------
 void DeviceHSS::compress_generator(const hssk_gen& g) {
   GeneratorSource s(g);
+  check_symmetry(s);
   compress(s);
 }
+// EngineOptions::symmetric == 2: the hint is checked on 512 x 512 scattered entries against their mirror images
+void DeviceHSS::check_symmetry(Source& src) {
+  if (o_.symmetric != 2 || n_ < 2) return;
+  const int q = std::min(512, n_);
+  std::vector<int> I(q), J(q);
+  std::minstd_rand g(12345);
+  for (int i = 0; i < q; i++) { I[i] = (int)(g() % (unsigned)n_); J[i] = (int)(g() % (unsigned)n_); }
+  tmp_->rewind();
+  int* dI = tmp_->ints(q);
+  int* dJ = tmp_->ints(q);
+  double* B1 = tmp_->dbl((size_t)q * q);
+  double* B2 = tmp_->dbl((size_t)q * q);
+  ck(hssk_memcpy_h2d(ctx_, dI, I.data(), (long long)sizeof(int) * q));
+  ck(hssk_memcpy_h2d(ctx_, dJ, J.data(), (long long)sizeof(int) * q));
+  std::vector<ElemReq> rq{ElemReq{dI, dJ, &I, &J, 0, 0, q, q, B1, q}, ElemReq{dJ, dI, &J, &I, 0, 0, q, q, B2, q}};
+  src.extract(*this, rq);
+  std::vector<double> h1((size_t)q * q), h2((size_t)q * q);
+  ck(hssk_memcpy_d2h(ctx_, h1.data(), B1, (long long)sizeof(double) * q * q));
+  ck(hssk_memcpy_d2h(ctx_, h2.data(), B2, (long long)sizeof(double) * q * q));
+  double dmax = 0, amax = 0;
+  for (int j = 0; j < q; j++)
+    for (int i = 0; i < q; i++) {
+      dmax = std::max(dmax, std::abs(h1[i + (size_t)j * q] - h2[j + (size_t)i * q]));
+      amax = std::max(amax, std::abs(h1[i + (size_t)j * q]));
+    }
+  if (dmax > 1e-14 * std::max(amax, 1e-300)) throw std::invalid_argument("compress: the operand was declared symmetric and is not (sampled entries differ from their mirror images)");
+}
+
 void DeviceHSS::compress_dense_device(const double* dA, long long lda) {
   DenseDeviceSource s(dA, lda);
+  check_symmetry(s);
   compress(s);
 }
 void DeviceHSS::compress_dense_host(const double* A, long long lda) {

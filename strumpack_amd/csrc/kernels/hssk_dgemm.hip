@@ -262,15 +262,16 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(int m, long long n, long 
 //    k is what it is), which is what lets one 16-byte piece of the k-contiguous operand serve two lane groups.
 //  * GEN: op(B) is not in memory at all -- it is a formula (hssk_gen) of the DIFFERENCE of its indices, G(i, j) = tau(i - j)
 //    (the Toeplitz kinds).  The 16 x 128 tile of a stage then holds only 143 distinct values -- tau on a run of consecutive
-//    differences -- and the run of the next stage is the same run moved on by 16: the operand of the whole K-chunk is ONE
-//    sliding window, kept in a 256-entry circular buffer in the LDS (entry (d - d_first) mod 256).  A lane reads its operand
-//    word for tile position (k, j) at k + 127 - j (+ 16 per stage) of the window -- a 32-lane read group covers 17
-//    consecutive entries: conflict-free --, and per stage SIXTEEN new entries are evaluated, two stages ahead, by one wave
-//    (the waves take turns; the entries they overwrite left the window long before).  Only the A panel still travels.  Same
-//    tiles, stages and summation order as the stored operand: the results are bitwise equal.  (Why so frugal: the FP64
-//    vector instructions of the evaluation -- an IEEE division -- execute on the units the FP64 MFMA runs on.  Every
-//    thread evaluating its four entries of the full tile cost 17 % of the kernel; a branch around the MFMAs of the
-//    evaluating waves made the compiler copy the accumulators, 30 %.)
+//    differences, tile position (k, j) at entry k + 127 - j (a 32-lane read group covers 17 consecutive entries:
+//    conflict-free) -- and the run of the next stage is the same run moved on by 16.  The run is the B part of a ring
+//    slot: two stages ahead of its use, two waves copy 127 entries from the slot of the stage before (one LDS read, one LDS
+//    write per lane) and a third evaluates the 16 new ones.  Only the A panel still travels.  Same tiles, stages and
+//    summation order as the stored operand: the results are bitwise equal.
+//    (Why so frugal, measured at N = 1e5 against 51.2 ms per launch with the stored operand: every thread evaluating its
+//    four entries of the full tile, 61 ms -- the FP64 vector instructions of an IEEE division run on the units the FP64
+//    MFMA runs on; one entry per thread of the run with a branch around the MFMAs of the evaluating waves, 64 ms -- the
+//    compiler copied the accumulators; a circular window with computed read addresses, 53.4 ms -- two integer
+//    instructions per operand read, issued by both waves of a SIMD at once.)
 template <int MBLK, bool TRANSB, int TAG = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k, const double* __restrict__ A, long long lda,
                                                         const double* __restrict__ B, long long ldb,
@@ -329,13 +330,12 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     else if (TRANSB) hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (c - MBLK) * 1024 + wave * 128);
     else hssk_glds16(srcB[c - MBLK] + sc * stepB, base + A_DBL + (wave + 8 * (c - MBLK)) * 128);
   };
-  // generated operand: the window of tau over the differences d_first + i, i = 0, 1, ... (d_first = first k of the chunk minus
-  // the last column of the tile; transposed, the formula takes the negated difference), entry i at run[i & 255]
-  double* run = lds + 3 * SLOT;
+  // generated operand: entry e of stage s's run is tau(d_first + 16 s + e), d_first = first k of the chunk minus the last
+  // column of the tile (transposed, the formula takes the negated difference); it sits at B-part offset e of the stage's slot
   const int gen_dfirst = (int)kbeg - ((int)(jg0 + j0) + 127);
-  auto gen_entry = [&](int i) {
+  auto gen_tau = [&](int i) {
     const int d = gen_dfirst + i;
-    run[i & 255] = TRANSB ? hssk_gen_eval(gen, 0, d) : hssk_gen_eval(gen, d, 0);
+    return TRANSB ? hssk_gen_eval(gen, 0, d) : hssk_gen_eval(gen, d, 0);
   };
   auto copy_stage = [&](int stage, int slot) {
 #pragma unroll
@@ -353,9 +353,10 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
   for (int b = 0; b < NT; b++) {
     const int jl = wn + b * 16 + l15;
-    if (GEN) {   // window index of tile position (k of sub-step s, j): k + 127 - j, before the stage's 16 st
+    if (GEN) {   // run entry of tile position (k of sub-step s, j): k + 127 - j
+      const int o = hssk_opaque(A_DBL + (l4 & 1) + 8 * (l4 >> 1) + 127 - jl);
 #pragma unroll
-      for (int s = 0; s < 4; s++) offB[b][s] = 2 * s + (l4 & 1) + 8 * (l4 >> 1) + 127 - jl;
+      for (int s = 0; s < 4; s++) offB[b][s] = o + 2 * s;
     } else if (KJ_IMAGE) {
       const int o = hssk_opaque(A_DBL + (jl >> 6) * 1024 + ((l4 & 1) + 8 * (l4 >> 1)) * 64 + ((jl & 63) ^ (16 * (l4 & 1))));
 #pragma unroll
@@ -373,12 +374,12 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
   double af[2][MT], bf[2][NT];
-  auto frags = [&](int slot, int s, int set, int stq) {
+  auto frags = [&](int slot, int s, int set) {
     const double* base = lds + slot * SLOT;
 #pragma unroll
     for (int a = 0; a < MT; a++) af[set][a] = base[offA[a] + s * 128];
 #pragma unroll
-    for (int b = 0; b < NT; b++) bf[set][b] = GEN ? run[(offB[b][s] + 16 * stq) & 255] : base[offB[b][s]];
+    for (int b = 0; b < NT; b++) bf[set][b] = base[offB[b][s]];
   };
   auto mfmas = [&](int set) {
 #pragma unroll
@@ -392,17 +393,23 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     constexpr int S = decltype(slot_tag)::value;
     // (scheduling fences: left alone, the compiler hoists the reads of later sub-steps, fuses them into half-rate
     // ds_read2st64_b64 pairs and then waits for ALL of them in front of the next MFMA)
-    frags(S, 1, 1, st);
-    hssk_sched_barrier();
-    if (GEN && wave == (st & 3)) gen_entry(159 + 16 * st + l15);   // the window's sixteen entries for stage st + 2 (waves in turn)
+    // generated operand: the run of stage st + 2 goes into slot S + 2 (released by the previous barrier, read after the next
+    // one) -- waves 0 and 1 move 127 entries over from the run of stage st + 1 (read here, written after the first group of
+    // MFMAs: the LDS round trip rides them), wave 2 + (st & 1) evaluates the sixteen new ones
+    double gen_moved = 0.;
+    if (GEN && wave < 2 && tid < 127) gen_moved = lds[((S + 1) % 3) * SLOT + A_DBL + tid + 16];
+    frags(S, 1, 1);
     hssk_sched_barrier();
     mfmas(0);
     hssk_sched_barrier();
-    frags(S, 2, 0, st);
+    if (GEN && wave < 2 && tid < 127) lds[((S + 2) % 3) * SLOT + A_DBL + tid] = gen_moved;
+    if (GEN && wave == 2 + (st & 1)) lds[((S + 2) % 3) * SLOT + A_DBL + 127 + l15] = gen_tau(16 * (st + 2) + 127 + l15);
+    hssk_sched_barrier();
+    frags(S, 2, 0);
     hssk_sched_barrier();
     mfmas(1);
     hssk_sched_barrier();
-    frags(S, 3, 1, st);
+    frags(S, 3, 1);
     hssk_sched_barrier();
     mfmas(0);
     hssk_sched_barrier();
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
 #pragma unroll
       for (int b = 0; b < NT; b++) acc[a][b] = hssk_mfma_f64_16x16x4(bf[1][b], af[1][a], acc[a][b]);
       hssk_sched_barrier();
-      if (a == 0) frags((S + 1) % 3, 0, 0, st + 1);
+      if (a == 0) frags((S + 1) % 3, 0, 0);
       else if (a - 1 < NCH) copy_one(st + 3, S, a - 1);
       hssk_sched_barrier();
     }
@@ -430,10 +437,13 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
     copy_stage(0, 0);
     copy_stage(1, 1);
     copy_stage(2, 2);
-    if (GEN && tid < 160) gen_entry(tid);   // the window of stages 0 and 1 (stage st adds the entries of stage st + 2)
+    if (GEN && tid < 143) {   // the runs of stages 0 and 1 (stage st builds the run of stage st + 2)
+      lds[A_DBL + tid] = gen_tau(tid);
+      lds[SLOT + A_DBL + tid] = gen_tau(16 + tid);
+    }
     hssk_wait_glds<2 * NCH>();
     hssk_wg_barrier();
-    frags(0, 0, 0, 0);
+    frags(0, 0, 0);
     int st = 0;
     for (; st + 3 <= nst; st += 3) {
       stage(st, std::integral_constant<int, 0>());
@@ -543,7 +553,7 @@ void launch_bm(int BM, hssk_ctx* ctx, int transB, dim3 grid, int m, long long n,
 
 // the eight-wave LDS-DMA form (sketch_kernel): BM = 64 MBLK rows, 128 columns per workgroup, three ring stages
 constexpr int BN2 = 128;
-inline size_t sketch_lds_bytes(int mblk) { return sizeof(double) * (3 * (size_t)(64 * mblk + BN2) * BK + 256); }   // ring + the generated operand's window
+inline size_t sketch_lds_bytes(int mblk) { return sizeof(double) * 3 * (size_t)(64 * mblk + BN2) * BK; }
 template <int MBLK, int TAG>
 void launch_sketch_m(hssk_ctx* ctx, int transB, dim3 grid, long long n, long long k, const double* A, long long lda,
                      const double* B, long long ldb, double* P, long long ldp, long long pstride, long long kchunk,

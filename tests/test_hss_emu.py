@@ -117,3 +117,10 @@ def test_generated_operand_fused_sketch(L, n, leaf, kind, d0, dd):
 
 def test_factor_ahead_of_the_compression(L):
     HC.check_factor_ahead(L)
+
+
+def test_symmetric_operand_hint(L):
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(emu_lib.build())
+    HC.check_symmetric_hint(L, hk, n=1024, leaf=64)
+    hk.close()

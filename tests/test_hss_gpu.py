@@ -463,3 +463,9 @@ def test_generated_operand_beyond_hbm():
 
 def test_factor_ahead_of_the_compression(L):
     HC.check_factor_ahead(L, n=6000, leaf=128)
+
+
+def test_symmetric_operand_hint(L):
+    hk = K.Hssk(_loader.lib_path())
+    HC.check_symmetric_hint(L, hk, n=8192, leaf=128)
+    hk.close()
