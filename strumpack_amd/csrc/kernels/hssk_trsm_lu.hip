@@ -813,7 +813,10 @@ static bool trsm_blocked(hssk_ctx* ctx, const hssk_trsm_desc* descs, int count, 
   int nblk_max = 0, n_max = 0;
   for (auto& t : tris) { nblk_max = std::max(nblk_max, (t.n + NB - 1) / NB); n_max = std::max(n_max, t.n); }
   static const bool no_fused = [] { const char* e = std::getenv("HSSK_TRSM_NO_FUSED"); return e && e[0] == '1'; }();   // (A/B: one launch per block step and stage)
-  if (n_max <= TF_NMAX && !no_fused) {
+  // (the one-launch form keeps 16 right-hand sides of up to 512 rows in the LDS: 66 KB -- on a device whose workgroups get
+  // less, the block steps below take over)
+  static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
+  if (n_max <= TF_NMAX && !no_fused && sizeof(double) * 16 * (size_t)(nblk_max * NB + 1) <= lds_cap) {
     // all block steps in one launch: a workgroup per 16 right-hand sides
     std::vector<hssk_trsm_desc> sel;
     std::vector<TfWork> work;
@@ -906,9 +909,15 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   for (int i = 0; i < count; i++) nmax = std::max(nmax, descs[i].n);
   static const bool no_wg = [] { const char* e = std::getenv("HSSK_LU_NO_WG"); return e && e[0] == '1'; }();   // (A/B: the first kernel)
   static const bool wg_v1 = [] { const char* e = std::getenv("HSSK_LU_WG_V1"); return e && e[0] == '1'; }();   // (A/B: the first one-workgroup form)
+  // the one-workgroup kernels hold a 32-column panel and a block of U12 in up to 148 KB of LDS: where a workgroup cannot get
+  // that much (gfx90a / gfx942: 64 KB) the global-memory kernels below serve every size
+  static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
+  const bool wg_fits = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * (nmax <= 256 ? LUW_CHW_SMALL : LUW_CH)) <= lds_cap;
   if (nmax <= LU_LDS_N) {
     HSSK_LAUNCH(getrf_lds_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
-  } else if (nmax <= LUW_NMAX && !no_wg && !wg_v1) {
+  } else if (!wg_fits && nmax <= 384) {
+    HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
+  } else if (nmax <= LUW_NMAX && wg_fits && !no_wg && !wg_v1) {
     const int chw = nmax <= 256 ? LUW_CHW_SMALL : LUW_CH;
     const size_t shmem = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * chw);
     if (nmax <= 256) {
@@ -918,7 +927,7 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
       hssk_rt::allow_dynamic_lds(getrf_wg2_kernel<512>, shmem);
       HSSK_LAUNCH(getrf_wg2_kernel<512>, dim3((unsigned)count), dim3(512), shmem, ctx->stream, dd, chw);
     }
-  } else if (nmax <= LUW_NMAX && !no_wg) {
+  } else if (nmax <= LUW_NMAX && wg_fits && !no_wg) {
     const size_t shmem = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * LUW_CH);
     hssk_rt::allow_dynamic_lds(getrf_wg_kernel, shmem);
     HSSK_LAUNCH(getrf_wg_kernel, dim3((unsigned)count), dim3(LUW_T), shmem, ctx->stream, dd);
