@@ -91,14 +91,17 @@ void HSSMatrix<double>::compress(const kernel::Kernel<double>& K, const opts_t& 
 }
 void HSSMatrix<double>::compress_with_neighbors(const kernel::Kernel<double>& K, const opts_t& opts, const int* ann, int k) {
   if (K.n() != rows_) throw std::invalid_argument("compress: kernel size does not match");
-  if (K.device_type() < 0)
-    throw std::invalid_argument("compress(Kernel): user-defined kernel functions cannot be evaluated on the device; "
-                                "use compress(Amult, Aelem) with the kernel's element callback");
   if (K.data().ld() != int(K.d())) throw std::invalid_argument("compress(Kernel): the point matrix must be contiguous");
   make_engine(opts, tree_.get());
   DeviceHSS::KernelSpec ks;
   ks.X = K.data().data(); ks.d = int(K.d()); ks.type = K.device_type(); ks.p = K.degree();
   ks.h = K.width(); ks.lambda = K.lambda(); ks.ann = std::min<int>(int(K.n()), opts.approximate_neighbors());
+  // a user-defined Kernel subclass (kernel/Kernel.hpp:73-170: only its virtual eval is known): blocks evaluated on the host
+  if (K.device_type() < 0) {
+    ks.type = 0;
+    const kernel::Kernel<double>* Kp = &K;
+    ks.eval = [Kp](int i, int j) { return Kp->eval((std::size_t)i, (std::size_t)j); };
+  }
   if (opts.neighbor_search() == NeighborSearch::ANN) {
     const double* X = K.data().data();
     const std::size_t dim = K.d(), n = K.n(), iters = opts.ann_iterations();

@@ -61,10 +61,18 @@ DenseMatrix<double> Kernel<double>::fit_HSS(std::vector<double>& labels, const H
 std::vector<double> Kernel<double>::predict(const DenseMatrix<double>& test, const DenseMatrix<double>& weights) const {
   if (test.rows() != d()) throw std::invalid_argument("predict: test points have the wrong dimension");
   if (weights.rows() != n()) throw std::invalid_argument("predict: one weight per training point expected");
-  if (device_type() < 0) throw std::invalid_argument("predict: user-defined kernel functions cannot be evaluated on the device");
   const int m = int(test.cols()), dim = int(d());
   std::vector<double> prediction(m, 0.);
   if (m == 0) return prediction;
+  if (device_type() < 0) {
+    // a user-defined kernel function (only its virtual evaluation is known): the sums on the host
+    for (int c = 0; c < m; c++) {
+      double s = 0.;
+      for (std::size_t r = 0; r < n(); r++) s += weights(r, 0) * eval_kernel_function(data_.ptr(0, r), test.ptr(0, c));
+      prediction[c] = s;
+    }
+    return prediction;
+  }
   int dev = 0;
   if (const char* e = std::getenv("STRUMPACK_AMD_DEVICE")) dev = std::atoi(e);
   hssk_ctx* ctx = nullptr;

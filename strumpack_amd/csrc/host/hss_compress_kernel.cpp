@@ -135,6 +135,8 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       stats_.t_sketch += now() - tl0;   // host column-set construction (the 'sketch' slot of this path)
       // ---- D (leaves), B01 / B10 (inner nodes), sample panels W = K(cols, rows)  [= S^T]
       std::vector<hssk_keval_desc> ev;
+      struct HostEv { const int* ri; const int* ci; };   // host copies of a request's index lists (null: the range r0 / c0 + a)
+      std::vector<HostEv> hev;
       std::vector<hssk_transpose_desc> tr;
       std::vector<int> idn, which;
       std::vector<double*> Ws;
@@ -144,12 +146,14 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         if (nd.leaf()) {
           nd.D = persist_->dbl((size_t)nd.m * nd.m);
           ev.push_back(hssk_keval_desc{nullptr, nullptr, nd.D, nd.m, nd.m, nd.m, nd.lo, nd.lo});
+          hev.push_back(HostEv{nullptr, nullptr});
         } else {
           Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
           nd.B01 = persist_->dbl((size_t)std::max(a.rU, 1) * std::max(b.rV, 1));
           nd.B10 = persist_->dbl((size_t)std::max(b.rU, 1) * std::max(a.rV, 1));
           if (a.rU > 0 && b.rV > 0) {
             ev.push_back(hssk_keval_desc{a.dIr, b.dIc, nd.B01, a.rU, b.rV, a.rU, 0, 0});
+            hev.push_back(HostEv{a.Ir.data(), b.Ic.data()});
             tr.push_back(hssk_transpose_desc{nd.B01, nd.B10, a.rU, b.rV, a.rU, b.rU});
           }
         }
@@ -158,9 +162,31 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         idn.push_back(ids[q]); which.push_back(0); ds.push_back(d);
         double* W = (m > 0 && d > 0) ? tmp_->dbl((size_t)d * m) : nullptr;
         Ws.push_back(W);
-        if (W) ev.push_back(hssk_keval_desc{didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
+        if (W) {
+          ev.push_back(hssk_keval_desc{didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
+          hev.push_back(HostEv{hidx.data() + coff[q], hidx.data() + roff[q]});
+        }
       }
-      if (!ev.empty()) ck(hssk_kernel_eval_vbatched(ctx_, &spec, ev.data(), (int)ev.size()));
+      if (!ev.empty() && ks.eval) {
+        // user-defined kernel function: the blocks are evaluated on the host's threads, column by column, and uploaded
+        std::vector<size_t> boff(ev.size() + 1, 0);
+        for (size_t e = 0; e < ev.size(); e++) boff[e + 1] = boff[e] + (size_t)ev[e].nr * ev[e].nc;
+        std::vector<double> hb(std::max<size_t>(boff.back(), 1));
+        std::vector<std::pair<int, int>> cols_of;   // (request, column)
+        for (size_t e = 0; e < ev.size(); e++)
+          for (int c = 0; c < ev[e].nc; c++) cols_of.emplace_back((int)e, c);
+        host_parallel_for(cols_of.size(), [&](size_t t) {
+          const int e = cols_of[t].first, c = cols_of[t].second;
+          const hssk_keval_desc& q = ev[e];
+          const int gc = hev[e].ci ? hev[e].ci[c] : q.c0 + c;
+          double* dst = hb.data() + boff[e] + (size_t)c * q.nr;
+          for (int a = 0; a < q.nr; a++) dst[a] = ks.eval(hev[e].ri ? hev[e].ri[a] : q.r0 + a, gc);
+        });
+        for (size_t e = 0; e < ev.size(); e++)
+          if (ev[e].nr > 0 && ev[e].nc > 0)
+            ck(hssk_memcpy2d_h2d(ctx_, ev[e].out, sizeof(double) * ev[e].ldo, hb.data() + boff[e], sizeof(double) * ev[e].nr,
+                                 sizeof(double) * ev[e].nr, ev[e].nc));
+      } else if (!ev.empty()) ck(hssk_kernel_eval_vbatched(ctx_, &spec, ev.data(), (int)ev.size()));
       if (!tr.empty()) ck(hssk_transpose(ctx_, tr.data(), (int)tr.size()));
       if (idn.empty()) return;
       // nodes with an empty column set (d == 0) get rank 0 through a 1 x m zero panel

@@ -154,6 +154,10 @@ class DeviceHSS {
     // optional host neighbour search: fills ann (k x n, ids in cluster order, -1 = none) for the given k; replaces
     // hssk_knn in every round (the reference's randomized search, see NeighborSearch.hpp)
     std::function<void(int k, int* ann)> neighbors;
+    // optional host evaluation of an entry (a user-defined Kernel subclass: kernel/Kernel.hpp:73-170, virtual eval): when set,
+    // every block the compression needs is evaluated on the host's threads and uploaded instead of hssk_kernel_eval_vbatched
+    // (neighbour lists still come from the point coordinates).  Must be callable concurrently.
+    std::function<double(int i, int j)> eval;
   };
   void compress_kernel(const KernelSpec& ks, const int* user_ann = nullptr, int user_k = 0);
 

@@ -116,6 +116,29 @@ def test_write_read_round_trip_gpu(tmp_path_factory):
     assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
 
 
+UK_SRC = os.path.join(ROOT, "tests", "cpp", "test_user_kernel.cpp")
+
+
+def test_user_defined_kernel_emulator(tmp_path_factory):
+    """a subclass of kernel::Kernel<double> that only overrides the virtual evaluation (kernel/Kernel.hpp:73-170): compressed
+    through HSSMatrix(K, opts) with its blocks evaluated on the host, fit_HSS, predict"""
+    import emu_lib
+    emu_lib.build()
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build(os.path.dirname(emu_lib.PATH), "strumpack_amd_emu", str(d / "uk_emu"), UK_SRC)
+    r = subprocess.run([exe, "500", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_user_defined_kernel_gpu(tmp_path_factory):
+    from strumpack_amd import _loader
+    d = tmp_path_factory.mktemp("cpp")
+    exe = build(os.path.dirname(_loader.lib_path()), "strumpack_amd", str(d / "uk"), UK_SRC)
+    r = subprocess.run([exe, "3000", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# exiting" in r.stdout, r.stdout + r.stderr
+
+
 # ---- the reference's OWN drivers, compiled unmodified from where they lie (build container only: /root/reference does not
 # exist on the GPU box) against include/{dense,HSS,structured,kernel,misc}/*.hpp and linked with the emulator library ----
 REF = "/root/reference"

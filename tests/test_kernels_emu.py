@@ -31,6 +31,12 @@ def test_leaf_update(hk):
     KC.case_leaf_update(hk, [(24, 20), (192, 45), (64, 33), (2, 1)])
 
 
+def test_gemm_vbatched_tall_narrow_updates(hk):
+    # the shapes of a BLR front's trailing updates: many rows, a tile's width of columns, A not transposed, B transposed
+    KC.case_gemm_vbatched(hk, [(300, 156, 7, 0, 1, -1.0, 1.0), (256, 256, 40, 0, 1, -1.0, 1.0), (321, 65, 1, 0, 1, 2.0, 0.0),
+                               (700, 200, 33, 0, 1, 0.5, -1.5), (256, 129, 16, 0, 1, 1.0, 1.0)], seed=21)
+
+
 def test_gemm_vbatched_panel_path(hk):
     # m = sample count (even, <= 192), A contiguous and aligned: the 192 x 32 panel kernel
     KC.case_gemm_vbatched(hk, [(192, 45, 45, 0, 1, -1.0, 1.0), (192, 45, 45, 0, 0, -1.0, 1.0), (96, 33, 20, 0, 1, 1.0, 0.0),

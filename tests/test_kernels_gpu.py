@@ -31,6 +31,12 @@ def test_gemm_vbatched_hss_level_shapes(hk):
     KC.case_gemm_vbatched(hk, shapes, seed=11)
 
 
+def test_gemm_vbatched_tall_narrow_updates(hk):
+    # the shapes of a BLR front's trailing updates: many rows, a tile's width of columns, A not transposed, B transposed
+    KC.case_gemm_vbatched(hk, [(30000, 156, 7, 0, 1, -1.0, 1.0), (5000, 256, 96, 0, 1, -1.0, 1.0), (321, 65, 1, 0, 1, 2.0, 0.0),
+                               (7000, 200, 33, 0, 1, 0.5, -1.5), (256, 129, 16, 0, 1, 1.0, 1.0)] + [(2000, 156, 50, 0, 1, -1.0, 1.0)] * 20, seed=21)
+
+
 def test_gemm_vbatched_tall_path(hk):
     # few columns, B resident in the LDS (leaf-level products with many right-hand sides)
     KC.case_gemm_vbatched(hk, [(256, 64, 256, 0, 0, 1.0, 0.0)] * 40 + [(200, 40, 215, 0, 0, -1.0, 1.0), (130, 17, 33, 1, 0, 2.0, 0.5),
