@@ -39,8 +39,11 @@ def parse():
     p.add_argument("--rel-tol", type=float, default=1e-4)
     p.add_argument("--nrhs", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--factor-ahead", action="store_true", help="toeplitz workload: tell the library that a factorization follows -- it enqueues "
-                   "every tree level's ULV factorization on a second stream as soon as the compression has settled the level (SPXHSSOptions::factor_ahead)")
+    p.add_argument("--factor-ahead", action=argparse.BooleanOptionalAction, default=None,
+                   help="toeplitz workload: tell the library that a factorization follows -- it enqueues every tree level's ULV factorization "
+                   "on a second stream as soon as the compression has settled the level (SPXHSSOptions::factor_ahead).  Default: on for "
+                   "N > 1 (a rank's subtree leaves the chip room beside the compression: 18.5 -> 17.7 ms per step in the 8-rank model, "
+                   "profiles/r04_scale_model.json), off at N = 1 (no gain: both phases want the whole chip, DESIGN.md section 9j)")
     p.add_argument("--symmetric", action="store_true", help="toeplitz workload, SECONDARY line: declare the operand symmetric (SPXHSSOptions::symmetric_operand = 2, "
                    "checked on a sample): A^T R = A R, the second sketch GEMM is a copy; `value` counts the executed flops")
     p.add_argument("--cpu-n", type=int, default=32768)
@@ -571,8 +574,10 @@ def main():
         return
 
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
-    # --factor-ahead (measured in round 4: no gain -- the leaf level's factorization and the first inner levels of the
-    # compression both want the whole chip): off by default
+    # --factor-ahead: at N = 1 no gain (the leaf level's factorization and the first inner levels of the compression both
+    # want the whole chip); on a rank's subtree of N > 1 ranks it hides most of the factorization
+    if a.factor_ahead is None:
+        a.factor_ahead = world > 1
     hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch, factor_ahead=a.factor_ahead,
                                               symmetric=2 if a.symmetric else 0)
     # ---- process group.  Default for N > 1: the library's own RCCL communicator (collectives on the engine's stream) and

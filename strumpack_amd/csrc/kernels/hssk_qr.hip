@@ -624,6 +624,131 @@ __global__ void eye_kernel(const EyeDesc* __restrict__ descs) {
   }
 }
 
+// ---- C <- C - V (VT^T C): a compact-WY block reflector (V, VT = V T: rr x nb, nb <= 32) applied to rr x nc columns, FUSED.
+// As two batched GEMMs (W = VT^T C, then C -= V W) the columns cross HBM three times and every product of a 472 x 512 leaf
+// block is a launch of thin tiles (leaf size 512: 15 panels x 2 launches for the factorization and as many for Q, 80 Gflop
+// in 6.3 ms).  Here a workgroup takes NC columns of C into the LDS ([column][row], row stride = 2 mod 32: the 16 columns x
+// 2 rows of a 32-lane operand read fall on distinct banks), forms its 32 x NC block of W from there -- 16 x 16 tiles, the
+// K range of a tile cut over the waves left (NC = 16: two tiles x two halves), VT fragments straight from global memory
+// (L2: the pair is shared by the workgroups of the panel), eight sub-steps ahead --, leaves the partial W's in the LDS and
+// applies V with the accumulators loaded from the LDS copy of C: C is read once and written once.  NC = 16 keeps two
+// workgroups on a CU for 512 rows (66 KB each): one loads while the other multiplies.
+constexpr int WY_T = 256, WY_LDW = 34;
+struct WyDesc {
+  const double* V;    // rr x nb
+  const double* VT;   // rr x nb   (V T)
+  double* C;          // rr x nc
+  int ldv, ldc, rr, nb, nc;
+};
+struct WyWork { int prob, cblock; };
+template <int NC> __global__ __launch_bounds__(WY_T) void wy_apply_kernel(const WyDesc* __restrict__ descs, const WyWork* __restrict__ work) {
+  HSSK_DYN_SHARED(double, wy_lds);
+  constexpr int TILES = 2 * (NC / 16), KP = 4 / TILES;   // W tiles (QB / 16 = 2 row tiles) and the K parts of each
+  const WyWork w = work[blockIdx.x];
+  const WyDesc p = descs[w.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int rr = p.rr, nb = p.nb, j0 = w.cblock * NC, ncb = min(NC, p.nc - j0);
+  const int ldr = ((rr + 31) & ~31) + 2;     // row stride of the LDS copy of C
+  double* Cs = wy_lds;                       // [NC][ldr]
+  double* Ws = wy_lds + NC * ldr;            // [KP][NC][WY_LDW]: part q of W(i, j) at Ws[(q * NC + j) * WY_LDW + i]
+  // ---- C block -> LDS (zeros beyond the block: they feed the MFMAs)
+  const int rpad = (rr + 15) & ~15;
+  for (int c = 0; c < NC; c++)
+    for (int i = tid; i < rpad; i += WY_T)
+      Cs[c * ldr + i] = (i < rr && c < ncb) ? hssk_gload(p.C, (size_t)i + (size_t)(j0 + c) * p.ldc) : 0.;
+  __syncthreads();
+  // ---- W = VT^T C: wave -> (tile, K part); tile = (row tile a of nb, column tile b of the block)
+  {
+    const int tile = wave % TILES, q = wave / TILES, a = tile & 1, b = tile >> 1;
+    hssk_d4 acc = {0., 0., 0., 0.};
+    const int vi = 16 * a + l15;                               // column of VT this lane feeds
+    const double* vt = p.VT + (size_t)min(vi, nb - 1) * p.ldv;
+    const bool vok = vi < nb;
+    const double* cs = Cs + (16 * b + l15) * ldr;
+    constexpr int AH = 8;
+    double va[AH];
+    const int nk = rpad / 4, per = (nk + KP - 1) / KP;         // 4-deep sub-steps (rows of V beyond rr read as zero)
+    const int s_lo = q * per, s_hi = min(nk, s_lo + per);
+#pragma unroll
+    for (int u = 0; u < AH; u++) { const int k = 4 * (s_lo + u) + l4; va[u] = (s_lo + u < s_hi && vok && k < rr) ? hssk_gload(vt, (size_t)k) : 0.; }
+    for (int s0 = s_lo; s0 < s_hi; s0 += AH) {
+#pragma unroll
+      for (int u = 0; u < AH; u++) {
+        const int s = s0 + u;
+        const double av = va[u];
+        const int kn = 4 * (s + AH) + l4;
+        va[u] = (s + AH < s_hi && vok && kn < rr) ? hssk_gload(vt, (size_t)kn) : 0.;
+        if (s < s_hi) acc = hssk_mfma_f64_16x16x4(cs[4 * s + l4], av, acc);   // swapped: lane holds W[i = l15][j = l4 + 4 r]
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
+  }
+  __syncthreads();
+  // ---- C -= V W: 16-row tiles of the block's rows, dealt to the waves; all column tiles of a row tile together
+  const int ntile = rpad / 16;
+  for (int t = wave; t < ntile; t += 4) {
+    const int gi = 16 * t + l15;
+    hssk_d4 c[NC / 16];
+#pragma unroll
+    for (int b = 0; b < NC / 16; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[b][r] = Cs[(16 * b + l4 + 4 * r) * ldr + gi];
+    const bool rok = gi < rr;
+    const double* vrow = p.V + min(gi, rr - 1);
+#pragma unroll
+    for (int ks = 0; ks < QB; ks += 4) {
+      const int k = ks + l4;
+      const double av = (rok && k < nb) ? -hssk_gload(vrow, (size_t)k * p.ldv) : 0.;
+#pragma unroll
+      for (int b = 0; b < NC / 16; b++) {
+        double wv = Ws[(16 * b + l15) * WY_LDW + k];
+#pragma unroll
+        for (int q = 1; q < KP; q++) wv += Ws[(q * NC + 16 * b + l15) * WY_LDW + k];
+        c[b] = hssk_mfma_f64_16x16x4(wv, av, c[b]);   // lane holds C[i = l15][j = l4 + 4 r]
+      }
+    }
+    if (rok) {
+#pragma unroll
+      for (int b = 0; b < NC / 16; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int j = 16 * b + l4 + 4 * r;
+          if (j < ncb) hssk_gstore(p.C, (size_t)gi + (size_t)(j0 + j) * p.ldc, c[b][r]);
+        }
+    }
+  }
+}
+template <int NC> inline size_t wy_lds_bytes(int rr) {
+  return sizeof(double) * ((size_t)NC * (((rr + 31) & ~31) + 2) + (size_t)(4 / (2 * (NC / 16))) * NC * WY_LDW);
+}
+template <int NC> bool wy_apply_nc(hssk_ctx* ctx, const std::vector<WyDesc>& d, int rmax) {
+  static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
+  const size_t shm = wy_lds_bytes<NC>(rmax);
+  if (shm > lds_cap) return false;
+  std::vector<WyWork> wk;
+  for (size_t i = 0; i < d.size(); i++)
+    for (int c = 0; c * NC < d[i].nc; c++) wk.push_back(WyWork{(int)i, c});
+  if (wk.empty()) return true;
+  auto* dd = (const WyDesc*)ctx->stage(d.data(), sizeof(WyDesc) * d.size());
+  auto* dw = (const WyWork*)ctx->stage(wk.data(), sizeof(WyWork) * wk.size());
+  hssk_rt::allow_dynamic_lds(wy_apply_kernel<NC>, shm);
+  HSSK_LAUNCH(wy_apply_kernel<NC>, dim3((unsigned)wk.size()), dim3(WY_T), shm, ctx->stream, dd, dw);
+  return true;
+}
+// the fused application for a batch of (V, VT, C) triples; false if some panel does not fit (the caller then takes the two GEMMs)
+bool wy_apply(hssk_ctx* ctx, const std::vector<WyDesc>& d) {
+  if (d.empty()) return true;
+  static const int mode = [] { const char* e = std::getenv("HSSK_QR_WY"); return e ? std::atoi(e) : 16; }();   // 0: off; 16 / 32: columns per workgroup
+  if (mode == 0) return false;
+  int rmax = 0;
+  for (auto& x : d) {
+    if (x.nb > QB || x.rr <= 0) return false;
+    rmax = std::max(rmax, x.rr);
+  }
+  return mode == 32 ? wy_apply_nc<32>(ctx, d, rmax) : wy_apply_nc<16>(ctx, d, rmax);
+}
+
 void gemm_batch(hssk_ctx* ctx, std::vector<hssk_gemm_desc>& g) {
   if (g.empty()) return;
   if (hssk_gemm_vbatched(ctx, g.data(), (int)g.size())) throw std::runtime_error(hssk_last_error());
@@ -652,8 +777,9 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
   std::vector<hssk_qr_desc> pd;
   std::vector<QPanel> lp;
   std::vector<hssk_gemm_desc> g1, g2;
+  std::vector<WyDesc> wy;
   for (int p = 0; p < std::max(pmax, 1); p++) {
-    pd.clear(); lp.clear(); g1.clear(); g2.clear(); td.clear(); gG.clear(); gVT.clear();
+    pd.clear(); lp.clear(); g1.clear(); g2.clear(); td.clear(); gG.clear(); gVT.clear(); wy.clear();
     const int j0 = p * QB;
     for (int i = 0; i < count; i++) {
       const hssk_qr_desc& d = descs[i];
@@ -683,6 +809,7 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
         double* A2 = Ap + (size_t)nb * d.lda;
         g1.push_back(hssk_gemm_desc{VT, A2, W, nb, nt, rr, d.rows, d.lda, QB, 1, 0, 1.0, 0.0});
         g2.push_back(hssk_gemm_desc{Vc, W, A2, rr, nt, nb, d.rows, QB, d.lda, 0, 0, -1.0, 1.0});
+        wy.push_back(WyDesc{Vc, VT, A2, d.rows, d.lda, rr, nb, nt});
       }
     }
     if (!pd.empty()) {
@@ -707,8 +834,10 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
         else HSSK_LAUNCH(larft_kernel<QB_MAXROWS>, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
       }
     }
-    gemm_batch(ctx, g1);
-    gemm_batch(ctx, g2);
+    if (!wy_apply(ctx, wy)) {
+      gemm_batch(ctx, g1);
+      gemm_batch(ctx, g2);
+    }
   }
   if (!anyq) return;
   std::vector<EyeDesc> ey;
@@ -718,7 +847,7 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
   auto* de = (const EyeDesc*)ctx->stage(ey.data(), sizeof(EyeDesc) * ey.size());
   HSSK_LAUNCH(eye_kernel, dim3((unsigned)ey.size(), 16), dim3(256), 0, ctx->stream, de);
   for (int p = pmax - 1; p >= 0; p--) {
-    g1.clear(); g2.clear();
+    g1.clear(); g2.clear(); wy.clear();
     const int j0 = p * QB;
     for (int i = 0; i < count; i++) {
       const hssk_qr_desc& d = descs[i];
@@ -731,9 +860,12 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
       double* Qb = d.Q + j0 + (size_t)j0 * d.ldq;
       g1.push_back(hssk_gemm_desc{Vc, Qb, W, nb, cq, rr, d.rows, d.ldq, QB, 1, 0, 1.0, 0.0});
       g2.push_back(hssk_gemm_desc{VT, W, Qb, rr, cq, nb, d.rows, QB, d.ldq, 0, 0, -1.0, 1.0});
+      wy.push_back(WyDesc{VT, Vc, Qb, d.rows, d.ldq, rr, nb, cq});   // Q <- Q - (V T)(V^T Q): the roles of the pair swapped
     }
-    gemm_batch(ctx, g1);
-    gemm_batch(ctx, g2);
+    if (!wy_apply(ctx, wy)) {
+      gemm_batch(ctx, g1);
+      gemm_batch(ctx, g2);
+    }
   }
 }
 

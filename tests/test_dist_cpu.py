@@ -59,7 +59,8 @@ BCASES = {2: [(120, 16, 16, 8, "stable", True), (120, 16, 16, 8, "stable", False
 for (n, leaf, d0, dd, algo, with_rows) in BCASES[world]:
     A = O.toeplitz(n) + 0.01 * np.random.default_rng(2).standard_normal((n, n))     # unsymmetric: rows and columns differ
     o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
-    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo)
+    # (factor_ahead on the rank's own levels when the row block is given: the cut exchange and the replicated top follow in factor())
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo, factor_ahead=with_rows)
     lo, hi = sdist.shard_range(L, n, o, world, rank)
     dR = hk.array(np.asfortranarray(A[lo:hi, :])) if with_rows else None
     dC = hk.array(np.asfortranarray(A[:, lo:hi]))

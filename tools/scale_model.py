@@ -38,17 +38,18 @@ def main():
     ap.add_argument("--lat-us", type=float, default=20.0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--lib", default=None, help="library to load (tests: the emulator build)")
+    ap.add_argument("--factor-ahead", action="store_true", help="SPXHSSOptions::factor_ahead: the rank's own levels are factored on a second stream behind the compression")
     a = ap.parse_args()
     libpath = a.lib or _loader.lib_path()
     L = capi.load(libpath)
     L.hssk_is_device_pointer.argtypes = [C.c_void_p]
     n = a.size
     opts = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
-    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox")
+    hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", factor_ahead=a.factor_ahead)
     hk = K.Hssk(libpath)
     hk_lock = threading.Lock()   # (the helper context is shared by the rank threads)
     # single-GPU reference step (whole matrix on one GPU)
-    out = {"n": n, "leaf": a.leaf, "assumed_collective_latency_us": a.lat_us, "ranks": {}}
+    out = {"n": n, "leaf": a.leaf, "assumed_collective_latency_us": a.lat_us, "factor_ahead": a.factor_ahead, "ranks": {}}
 
     def d2h(ptr, nbytes):
         buf = np.empty(nbytes, dtype=np.uint8)
