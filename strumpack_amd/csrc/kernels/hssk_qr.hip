@@ -626,14 +626,16 @@ __global__ void eye_kernel(const EyeDesc* __restrict__ descs) {
 
 // ---- C <- C - V (VT^T C): a compact-WY block reflector (V, VT = V T: rr x nb, nb <= 32) applied to rr x nc columns, FUSED.
 // As two batched GEMMs (W = VT^T C, then C -= V W) the columns cross HBM three times and every product of a 472 x 512 leaf
-// block is a launch of thin tiles (leaf size 512: 15 panels x 2 launches for the factorization and as many for Q, 80 Gflop
-// in 6.3 ms).  Here a workgroup takes NC columns of C into the LDS ([column][row], row stride = 2 mod 32: the 16 columns x
-// 2 rows of a 32-lane operand read fall on distinct banks), forms its 32 x NC block of W from there -- 16 x 16 tiles, the
-// K range of a tile cut over the waves left (NC = 16: two tiles x two halves), VT fragments straight from global memory
-// (L2: the pair is shared by the workgroups of the panel), eight sub-steps ahead --, leaves the partial W's in the LDS and
-// applies V with the accumulators loaded from the LDS copy of C: C is read once and written once.  NC = 16 keeps two
-// workgroups on a CU for 512 rows (66 KB each): one loads while the other multiplies.
-constexpr int WY_T = 256, WY_LDW = 34;
+// block is a launch of thin tiles (leaf size 512: 12 panels x 2 launches for the factorization and as many for Q, 80 Gflop
+// in 4.3 ms; factor phase 7.63 ms).  Here a workgroup takes NC columns of C into the LDS ([column][row], row stride = 2 mod
+// 32: the 16 columns x 2 rows of a 32-lane operand read fall on distinct banks), forms its 32 x NC block of W from there --
+// 16 x 16 tiles, the K range of a tile cut over the waves left (NC = 16, four waves: two tiles x two halves), VT fragments
+// straight from global memory (L2: the pair is shared by the workgroups of the panel), a batch ahead --, leaves the partial
+// W's in the LDS and applies V with the accumulators loaded from the LDS copy of C: C is read once and written once.
+// NC = 16 keeps two workgroups on a CU for 512 rows (74 KB each): one loads while the other multiplies.  Measured (leaf
+// 512, N = 1e5, gpurun_out/r04m): 3.4 ms per step in 26 launches (the largest: 5632 workgroups, 0.74 GB of C in and out,
+// 0.29 ms = 2.6 TB/s), factor phase 6.02 ms.  What is left is traffic: every panel is one pass over the trailing columns.
+constexpr int WY_LDW = 34;
 struct WyDesc {
   const double* V;    // rr x nb
   const double* VT;   // rr x nb   (V T)
@@ -641,90 +643,147 @@ struct WyDesc {
   int ldv, ldc, rr, nb, nc;
 };
 struct WyWork { int prob, cblock; };
-template <int NC> __global__ __launch_bounds__(WY_T) void wy_apply_kernel(const WyDesc* __restrict__ descs, const WyWork* __restrict__ work) {
+template <int NC, int T> __global__ __launch_bounds__(T, T / 128) void wy_apply_kernel(const WyDesc* __restrict__ descs, const WyWork* __restrict__ work) {
   HSSK_DYN_SHARED(double, wy_lds);
-  constexpr int TILES = 2 * (NC / 16), KP = 4 / TILES;   // W tiles (QB / 16 = 2 row tiles) and the K parts of each
+  constexpr int NW = T / 64, TILES = 2 * (NC / 16), KP = NW / TILES;   // W tiles (QB / 16 = 2 row tiles) and the K parts of each
+  constexpr int KS = KP > 2 ? 2 : KP;                                  // partial W's left in the LDS (four parts fold into two first)
+  constexpr int AH = T >= 512 ? 8 : 16, TC = 4, NU = QB / 4;   // (VT fragments in flight per wave: the register budget of four waves per SIMD)
   const WyWork w = work[blockIdx.x];
   const WyDesc p = descs[w.prob];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int rr = p.rr, nb = p.nb, j0 = w.cblock * NC, ncb = min(NC, p.nc - j0);
   const int ldr = ((rr + 31) & ~31) + 2;     // row stride of the LDS copy of C
   double* Cs = wy_lds;                       // [NC][ldr]
-  double* Ws = wy_lds + NC * ldr;            // [KP][NC][WY_LDW]: part q of W(i, j) at Ws[(q * NC + j) * WY_LDW + i]
-  // ---- C block -> LDS (zeros beyond the block: they feed the MFMAs)
-  const int rpad = (rr + 15) & ~15;
-  for (int c = 0; c < NC; c++)
-    for (int i = tid; i < rpad; i += WY_T)
-      Cs[c * ldr + i] = (i < rr && c < ncb) ? hssk_gload(p.C, (size_t)i + (size_t)(j0 + c) * p.ldc) : 0.;
-  __syncthreads();
-  // ---- W = VT^T C: wave -> (tile, K part); tile = (row tile a of nb, column tile b of the block)
-  {
-    const int tile = wave % TILES, q = wave / TILES, a = tile & 1, b = tile >> 1;
-    hssk_d4 acc = {0., 0., 0., 0.};
-    const int vi = 16 * a + l15;                               // column of VT this lane feeds
-    const double* vt = p.VT + (size_t)min(vi, nb - 1) * p.ldv;
-    const bool vok = vi < nb;
-    const double* cs = Cs + (16 * b + l15) * ldr;
-    constexpr int AH = 8;
-    double va[AH];
-    const int nk = rpad / 4, per = (nk + KP - 1) / KP;         // 4-deep sub-steps (rows of V beyond rr read as zero)
-    const int s_lo = q * per, s_hi = min(nk, s_lo + per);
+  double* Ws = wy_lds + NC * ldr;            // [KS][NC][WY_LDW]: part q of W(i, j) at Ws[(q * NC + j) * WY_LDW + i]
+  const int rpad = (rr + 15) & ~15, ntile = rpad / 16;
+  // Every global load of the workgroup is issued before the first product: a workgroup is a chain of four latencies otherwise
+  // (C, the VT fragments batch by batch, V tile by tile) with 3 us of MFMA work in between -- 16 us per workgroup measured.
+  // (1) first VT fragments of this wave's (tile, K part); tile = (row tile a of nb, column tile b of the block)
+  const int tile = wave % TILES, q = wave / TILES, a = tile & 1, b = tile >> 1;
+  const int vi = 16 * a + l15;                               // column of VT this lane feeds
+  const double* vt = p.VT + (size_t)min(vi, nb - 1) * p.ldv;
+  const bool vok = vi < nb;                                  // (rows of W beyond nb: computed from column nb - 1, stored as zeros)
+  // (every load of V / VT is UNCONDITIONAL, from a clamped address, and nothing is selected on the loaded value: the compiler
+  // turns `cond ? load : 0` into a load under a branch, and then waits for ALL loads in flight at the next use -- vmcnt(0)
+  // after every prefetch, 16 us per workgroup.  What a clamped load brings in meets a zero on the other side instead: rows
+  // of C beyond rr are zero in the LDS (row ldr - 1 of every column for the sub-steps beyond the last), rows of W beyond
+  // nb are stored as zeros.)
+  const int nk = rpad / 4, per = ((nk + KP - 1) / KP + AH - 1) / AH * AH;   // 4-deep sub-steps per wave: whole batches
+  const int s_lo = q * per;
+  auto load_vt = [&](int s_) { return hssk_gload(vt, (size_t)min(4 * s_ + l4, rr - 1)); };
+  double va[AH];
 #pragma unroll
-    for (int u = 0; u < AH; u++) { const int k = 4 * (s_lo + u) + l4; va[u] = (s_lo + u < s_hi && vok && k < rr) ? hssk_gload(vt, (size_t)k) : 0.; }
-    for (int s0 = s_lo; s0 < s_hi; s0 += AH) {
+  for (int u = 0; u < AH; u++) va[u] = load_vt(s_lo + u);
+  // (2) C block -> LDS (zeros beyond the block: they feed the MFMAs); the NC loads of a pass are in flight together
+  for (int i0 = 0; i0 < rpad; i0 += T) {
+    const int i = i0 + tid;
+    const double* src = p.C + min(i, rr - 1) + (size_t)j0 * p.ldc;
+    double v[NC];
 #pragma unroll
-      for (int u = 0; u < AH; u++) {
-        const int s = s0 + u;
-        const double av = va[u];
-        const int kn = 4 * (s + AH) + l4;
-        va[u] = (s + AH < s_hi && vok && kn < rr) ? hssk_gload(vt, (size_t)kn) : 0.;
-        if (s < s_hi) acc = hssk_mfma_f64_16x16x4(cs[4 * s + l4], av, acc);   // swapped: lane holds W[i = l15][j = l4 + 4 r]
-      }
+    for (int c = 0; c < NC; c++) v[c] = hssk_gload(src, (size_t)min(c, ncb - 1) * p.ldc);
+    if (i < rpad) {
+#pragma unroll
+      for (int c = 0; c < NC; c++) Cs[c * ldr + i] = (i < rr && c < ncb) ? v[c] : 0.;
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
   }
-  __syncthreads();
-  // ---- C -= V W: 16-row tiles of the block's rows, dealt to the waves; all column tiles of a row tile together
-  const int ntile = rpad / 16;
-  for (int t = wave; t < ntile; t += 4) {
+  if (tid < NC) Cs[tid * ldr + ldr - 1] = 0.;
+  // (3) the V values of this wave's first row tiles of the second product (they arrive under the first one)
+  auto load_v = [&](int t, double (&av)[NU]) {
     const int gi = 16 * t + l15;
-    hssk_d4 c[NC / 16];
-#pragma unroll
-    for (int b = 0; b < NC / 16; b++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) c[b][r] = Cs[(16 * b + l4 + 4 * r) * ldr + gi];
-    const bool rok = gi < rr;
     const double* vrow = p.V + min(gi, rr - 1);
 #pragma unroll
-    for (int ks = 0; ks < QB; ks += 4) {
-      const int k = ks + l4;
-      const double av = (rok && k < nb) ? -hssk_gload(vrow, (size_t)k * p.ldv) : 0.;
+    for (int u = 0; u < NU; u++) {
+      const int k = 4 * u + l4;
+      av[u] = -hssk_gload(vrow, (size_t)min(k, nb - 1) * p.ldv);   // (columns beyond nb meet zero rows of W, rows beyond rr are not stored)
+    }
+  };
+  double avs[TC][NU];
 #pragma unroll
-      for (int b = 0; b < NC / 16; b++) {
-        double wv = Ws[(16 * b + l15) * WY_LDW + k];
+  for (int x = 0; x < TC / 2; x++) load_v(wave + x * NW, avs[x]);   // (the other half once the VT registers are free)
+  __syncthreads();
+  // ---- W = VT^T C
+  {
+    hssk_d4 acc = {0., 0., 0., 0.};
+    const double* cs = Cs + (16 * b + l15) * ldr;
+    for (int s0 = s_lo; s0 < s_lo + per; s0 += AH) {
 #pragma unroll
-        for (int q = 1; q < KP; q++) wv += Ws[(q * NC + 16 * b + l15) * WY_LDW + k];
-        c[b] = hssk_mfma_f64_16x16x4(wv, av, c[b]);   // lane holds C[i = l15][j = l4 + 4 r]
+      for (int u = 0; u < AH; u++) {
+        const int s = s0 + u, k = 4 * s + l4;
+        const double av = va[u];
+        va[u] = load_vt(s + AH);
+        acc = hssk_mfma_f64_16x16x4(cs[k < rpad ? k : ldr - 1], av, acc);   // swapped: lane holds W[i = l15][j = l4 + 4 r]
       }
     }
-    if (rok) {
+    if (!vok) acc = hssk_d4{0., 0., 0., 0.};
 #pragma unroll
-      for (int b = 0; b < NC / 16; b++)
+    for (int x = TC / 2; x < TC; x++) load_v(wave + x * NW, avs[x]);
+    if (KP > KS) {   // parts 2, 3 first; parts 0, 1 add them to their own (same lanes, same addresses: no barrier in between)
+      if (q >= KS) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int j = 16 * b + l4 + 4 * r;
-          if (j < ncb) hssk_gstore(p.C, (size_t)gi + (size_t)(j0 + j) * p.ldc, c[b][r]);
-        }
+        for (int r = 0; r < 4; r++) Ws[((q - KS) * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
+      }
+      __syncthreads();
+      if (q < KS) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] += Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15];
+      }
+    }
+    if (q < KS) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
+    }
+  }
+  __syncthreads();
+  // ---- C -= V W: 16-row tiles of the block's rows, dealt to the waves; all column tiles of a row tile together.  The
+  // fragments of W (parts summed) stay in registers over the wave's tiles.
+  double wf[NC / 16][NU];
+#pragma unroll
+  for (int bb = 0; bb < NC / 16; bb++)
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      double wv = Ws[(16 * bb + l15) * WY_LDW + 4 * u + l4];
+#pragma unroll
+      for (int qq = 1; qq < KS; qq++) wv += Ws[(qq * NC + 16 * bb + l15) * WY_LDW + 4 * u + l4];
+      wf[bb][u] = wv;
+    }
+  for (int t0 = wave; t0 < ntile; t0 += TC * NW) {
+    if (t0 != wave) {
+#pragma unroll
+      for (int x = 0; x < TC; x++) load_v(t0 + x * NW, avs[x]);
+    }
+#pragma unroll
+    for (int x = 0; x < TC; x++) {
+      const int t = t0 + x * NW;
+      if (t >= ntile) break;
+      const int gi = 16 * t + l15;
+      hssk_d4 c[NC / 16];
+#pragma unroll
+      for (int bb = 0; bb < NC / 16; bb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[bb][r] = Cs[(16 * bb + l4 + 4 * r) * ldr + gi];
+#pragma unroll
+      for (int u = 0; u < NU; u++)
+#pragma unroll
+        for (int bb = 0; bb < NC / 16; bb++) c[bb] = hssk_mfma_f64_16x16x4(wf[bb][u], avs[x][u], c[bb]);   // lane holds C[i = l15][j = l4 + 4 r]
+      if (gi < rr) {
+#pragma unroll
+        for (int bb = 0; bb < NC / 16; bb++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int j = 16 * bb + l4 + 4 * r;
+            if (j < ncb) hssk_gstore(p.C, (size_t)gi + (size_t)(j0 + j) * p.ldc, c[bb][r]);
+          }
+      }
     }
   }
 }
-template <int NC> inline size_t wy_lds_bytes(int rr) {
-  return sizeof(double) * ((size_t)NC * (((rr + 31) & ~31) + 2) + (size_t)(4 / (2 * (NC / 16))) * NC * WY_LDW);
+template <int NC, int T> inline size_t wy_lds_bytes(int rr) {
+  constexpr int KP = (T / 64) / (2 * (NC / 16));
+  return sizeof(double) * ((size_t)NC * (((rr + 31) & ~31) + 2) + (size_t)(KP > 2 ? 2 : KP) * NC * WY_LDW);
 }
-template <int NC> bool wy_apply_nc(hssk_ctx* ctx, const std::vector<WyDesc>& d, int rmax) {
+template <int NC, int T> bool wy_apply_nc(hssk_ctx* ctx, const std::vector<WyDesc>& d, int rmax) {
   static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
-  const size_t shm = wy_lds_bytes<NC>(rmax);
+  const size_t shm = wy_lds_bytes<NC, T>(rmax);
   if (shm > lds_cap) return false;
   std::vector<WyWork> wk;
   for (size_t i = 0; i < d.size(); i++)
@@ -732,21 +791,26 @@ template <int NC> bool wy_apply_nc(hssk_ctx* ctx, const std::vector<WyDesc>& d, 
   if (wk.empty()) return true;
   auto* dd = (const WyDesc*)ctx->stage(d.data(), sizeof(WyDesc) * d.size());
   auto* dw = (const WyWork*)ctx->stage(wk.data(), sizeof(WyWork) * wk.size());
-  hssk_rt::allow_dynamic_lds(wy_apply_kernel<NC>, shm);
-  HSSK_LAUNCH(wy_apply_kernel<NC>, dim3((unsigned)wk.size()), dim3(WY_T), shm, ctx->stream, dd, dw);
+  hssk_rt::allow_dynamic_lds(wy_apply_kernel<NC, T>, shm);
+  HSSK_LAUNCH((wy_apply_kernel<NC, T>), dim3((unsigned)wk.size()), dim3(T), shm, ctx->stream, dd, dw);
   return true;
 }
 // the fused application for a batch of (V, VT, C) triples; false if some panel does not fit (the caller then takes the two GEMMs)
 bool wy_apply(hssk_ctx* ctx, const std::vector<WyDesc>& d) {
   if (d.empty()) return true;
-  static const int mode = [] { const char* e = std::getenv("HSSK_QR_WY"); return e ? std::atoi(e) : 16; }();   // 0: off; 16 / 32: columns per workgroup
+  static const int mode = [] { const char* e = std::getenv("HSSK_QR_WY"); return e ? std::atoi(e) : 16; }();   // 0: off; columns per workgroup (16 / 32) + 1000 x threads (256 if none)
   if (mode == 0) return false;
   int rmax = 0;
   for (auto& x : d) {
-    if (x.nb > QB || x.rr <= 0) return false;
+    if (x.nb > QB || x.nb <= 0 || x.rr <= 0) return false;
     rmax = std::max(rmax, x.rr);
   }
-  return mode == 32 ? wy_apply_nc<32>(ctx, d, rmax) : wy_apply_nc<16>(ctx, d, rmax);
+  switch (mode) {
+    case 32: return wy_apply_nc<32, 256>(ctx, d, rmax);
+    case 512016: return wy_apply_nc<16, 512>(ctx, d, rmax);
+    case 512032: return wy_apply_nc<32, 512>(ctx, d, rmax);
+    default: return wy_apply_nc<16, 256>(ctx, d, rmax);   // (leaf 512, factor phase: 6.02 ms; <16, 512> 6.13; <32, 512> 6.79; two GEMMs 7.63)
+  }
 }
 
 void gemm_batch(hssk_ctx* ctx, std::vector<hssk_gemm_desc>& g) {
