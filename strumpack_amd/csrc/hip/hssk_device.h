@@ -154,6 +154,8 @@ __device__ __forceinline__ double hssk_gload(const double* p, size_t off) { retu
 __device__ __forceinline__ hssk_d2 hssk_gload2(const double* p, size_t off) {
   return *(const hssk_d2 HSSK_GLOBAL_AS*)((const double HSSK_GLOBAL_AS*)p + off);
 }
+// the same from an address that is only 8-byte aligned (one 16-byte load all the same: global memory takes unaligned accesses)
+__device__ __forceinline__ hssk_d2 hssk_gload2u(const double* p, size_t off) { return hssk_gload2(p, off); }
 __device__ __forceinline__ void hssk_gstore(double* p, size_t off, double v) { ((double HSSK_GLOBAL_AS*)p)[off] = v; }
 // ---- asynchronous global -> LDS copies (global_load_lds_dwordx4, "LDS DMA") -------------------------------------
 // Every lane names 16 bytes of global memory; lane l's piece lands at lds_base + 16 l (lds_base wave-uniform: it

@@ -17,7 +17,9 @@
 #include <iostream>
 #include <numeric>
 #include <random>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ClusterTree.hpp"
@@ -130,21 +132,45 @@ inline void label_kd(const Points& p, std::vector<int>& label, int nc[2]) {
   for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
 }
 
+// fn(lo, hi) over [0, n) in contiguous pieces, on a few host threads when the range is long (the top levels of a large
+// point set: the two halves of a split only fork BELOW it)
+template <class F> inline void for_pieces(int n, F&& fn) {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int pieces = n >= 32768 ? (int)std::min<unsigned>(8, hw) : 1;
+  if (pieces <= 1) { fn(0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < pieces; t++) th.emplace_back([&, t] { fn((int)((long long)n * t / pieces), (int)((long long)n * (t + 1) / pieces), t); });
+  fn(0, n / pieces, 0);
+  for (auto& x : th) x.join();
+}
+
 // median split by distance from the point farthest from the centroid (CobblePartitioning.cpp:36-78)
 inline void label_cobble(const Points& p, std::vector<int>& label, int nc[2]) {
   const int n = p.n, d = p.d;
   std::vector<double> cen(d, 0.);
-  for (int i = 0; i < n; i++)
+  for (int i = 0; i < n; i++)   // (serial: the sum keeps the reference's order)
     for (int j = 0; j < d; j++) cen[j] += p.pt(i)[j];
   for (int j = 0; j < d; j++) cen[j] /= n;
+  // the farthest point, the FIRST one among equals: per piece, then over the pieces in order
+  int pfirst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double pfar[8] = {-1., -1., -1., -1., -1., -1., -1., -1.};
+  for_pieces(n, [&](int lo, int hi, int t) {
+    int f = lo;
+    double far = -1.;
+    for (int i = lo; i < hi; i++) {
+      const double dd = dist(d, p.pt(i), cen.data());
+      if (dd > far) { far = dd; f = i; }
+    }
+    pfirst[t] = f; pfar[t] = far;
+  });
   int first = 0;
   double far = -1.;
-  for (int i = 0; i < n; i++) {
-    const double dd = dist(d, p.pt(i), cen.data());
-    if (dd > far) { far = dd; first = i; }
-  }
+  for (int t = 0; t < 8; t++)
+    if (pfar[t] > far) { far = pfar[t]; first = pfirst[t]; }
   std::vector<double> ds(n);
-  for (int i = 0; i < n; i++) ds[i] = dist(d, p.pt(i), p.pt(first));
+  for_pieces(n, [&](int lo, int hi, int) {
+    for (int i = lo; i < hi; i++) ds[i] = dist(d, p.pt(i), p.pt(first));
+  });
   std::vector<std::size_t> idx(n);
   std::iota(idx.begin(), idx.end(), 0);
   std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(),
@@ -213,7 +239,11 @@ inline void label_pca(const Points& p, std::vector<int>& label, int nc[2]) {
 
 using labeller_t = std::function<void(const Points&, std::vector<int>&, int*)>;
 
-inline structured::ClusterTree recurse(const Points& p, int cluster_size, int* perm, const labeller_t& lab) {
+// `fork`: levels below this one whose two halves may run on two host threads (the halves of a split share nothing: disjoint
+// ranges of the points and of the permutation; labellers with a state of their own -- the random stream of 2-means --
+// pass 0).  Serial, the 100 000 points of BASELINE configs[3] took 20 ms of the 102 ms step: every level is four passes
+// over all points.
+inline structured::ClusterTree recurse(const Points& p, int cluster_size, int* perm, const labeller_t& lab, int fork = 0) {
   structured::ClusterTree tree(p.n);
   if (p.n < cluster_size) return tree;
   std::vector<int> label;
@@ -222,9 +252,28 @@ inline structured::ClusterTree recurse(const Points& p, int cluster_size, int* p
   group_zero_first(p, label, nc[0], perm);
   if (!nc[0] || !nc[1]) return tree;
   tree.c.resize(2);
-  tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab);
-  tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab);
+  if (fork > 0 && p.n >= 4096) {
+    std::exception_ptr err;
+    std::thread other([&] {
+      try { tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab, fork - 1); }
+      catch (...) { err = std::current_exception(); }
+    });
+    try { tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab, fork - 1); }
+    catch (...) { other.join(); throw; }
+    other.join();
+    if (err) std::rethrow_exception(err);
+  } else {
+    tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab);
+    tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab);
+  }
   return tree;
+}
+// levels to fork: up to the host's hardware threads
+inline int fork_levels() {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  int l = 0;
+  while ((2u << l) <= hw && l < 6) l++;
+  return l;
 }
 
 }  // namespace clustering_detail
@@ -246,16 +295,16 @@ inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, 
       return t;
     }
     case ClusteringAlgorithm::PCA:
-      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_pca);
+      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_pca, cd::fork_levels());
     case ClusteringAlgorithm::TWO_MEANS: {
       std::mt19937 gen(1);  // reproducible, as in the reference
       return cd::recurse(pts, (int)cluster_size, perm.data(),
                          [&gen](const cd::Points& q, std::vector<int>& l, int* nc) { cd::label_two_means(q, l, nc, gen); });
     }
     case ClusteringAlgorithm::KD_TREE:
-      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_kd);
+      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_kd, cd::fork_levels());
     case ClusteringAlgorithm::COBBLE:
-      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_cobble);
+      return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_cobble, cd::fork_levels());
   }
   return structured::ClusterTree(n);
 }

@@ -490,8 +490,12 @@ struct QPanel {
 // product: a single chain waits out an LDS round trip per term); T 23 -> ~2 us -- T^{-1} is KNOWN, the strict upper
 // triangle of V^T V with 1 / tau on the diagonal, so column j of T is one register back substitution per lane
 // (hssk_backsub64; the dlarft recurrence ran 32 dependent steps on one wave); V T 14 -> ~5 us (four products per pass).
-template <int MAXR>
-__global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ descs) {
+// NT threads: the LDS image of a 512-row panel leaves one workgroup per CU, whose four waves spent 50 us per panel waiting
+// on LDS round trips (leaf 512: 12 panels per factorization); more waves share the same loops (from 1024 threads on two per product
+// of G, each half of the rows: a sum of two terms into a zeroed slot does not depend on the order).
+template <int MAXR, int NT>
+__global__ __launch_bounds__(NT) void larft_kernel(const QPanel* __restrict__ descs) {
+  constexpr int PARTS = NT >= 1024 ? 2 : 1;
   constexpr int LDV = MAXR + 1;   // odd: lanes that walk along columns hit distinct LDS banks
   constexpr int LR = HSSK_BACKSUB_LD;
   HSSK_SHARED double s_V[QB * LDV];
@@ -510,33 +514,36 @@ __global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ d
     }
   }
   if (nb == 0) return;
-  for (int e = tid; e < rows * nb; e += 256) {
+  for (int e = tid; e < rows * nb; e += NT) {
     const int i = e % rows, j = e / rows;
     const double v = i < j ? 0. : (i == j ? 1. : hssk_gload(p.A, i + (size_t)j * p.lda));
     s_V[j * LDV + i] = v;
     hssk_gstore(p.Vc, i + (size_t)j * p.ldv, v);
   }
-  for (int e = tid; e < QB * LR; e += 256) s_G[e] = 0.;
+  for (int e = tid; e < QB * LR; e += NT) s_G[e] = 0.;
   // (tau_i == 0: H_i = I, row and column i of T are zero -- a zero "reciprocal" does that in the back substitution)
   if (tid < 64) s_rd[tid] = tid < nb ? p.tau[tid] : 0.;
   __syncthreads();
   // G(a, b) = v_a . v_b for a < b  (v_b is zero above row b): pair e of the nb (nb - 1) / 2, four partial sums
-  for (int e = tid; e < nb * (nb - 1) / 2; e += 256) {
-    int b = 1, rem = e;
-    while (rem >= b) { rem -= b; b++; }   // e = b (b - 1) / 2 + a
+  for (int e = tid; e < PARTS * (nb * (nb - 1) / 2); e += NT) {
+    int b = 1, rem = e / PARTS;
+    const int part = e % PARTS;
+    while (rem >= b) { rem -= b; b++; }   // pair = b (b - 1) / 2 + a
     const int a2 = rem;
     const double* va = s_V + a2 * LDV;
     const double* vb = s_V + b * LDV;
     double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-    int i = b;
-    for (; i + 3 < rows; i += 4) {
+    const int mid = PARTS == 1 ? rows : b + (((rows - b) / 2) & ~3), lo = part ? mid : b, hi = part || PARTS == 1 ? rows : mid;
+    int i = lo;
+    for (; i + 3 < hi; i += 4) {
       s0 += va[i] * vb[i];
       s1 += va[i + 1] * vb[i + 1];
       s2 += va[i + 2] * vb[i + 2];
       s3 += va[i + 3] * vb[i + 3];
     }
-    for (; i < rows; i++) s0 += va[i] * vb[i];
-    s_G[a2 + b * LR] = (s0 + s1) + (s2 + s3);
+    for (; i < hi; i++) s0 += va[i] * vb[i];
+    if (PARTS == 1) s_G[a2 + b * LR] = (s0 + s1) + (s2 + s3);
+    else hssk_lds_add(&s_G[a2 + b * LR], (s0 + s1) + (s2 + s3));
   }
   __syncthreads();
   // T = (striu(G) + diag(1 / tau))^{-1}: lane j of the first wave solves for column j
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256) void larft_kernel(const QPanel* __restrict__ d
   }
   __syncthreads();
   // VT = V T: entry (i, j) = sum_{c <= j} V(i, c) T(c, j); four columns j per pass and thread
-  for (int e = tid; e < rows * (QB / 4); e += 256) {
+  for (int e = tid; e < rows * (QB / 4); e += NT) {
     const int i = e % rows, j0 = 4 * (e / rows);
     if (j0 >= nb) continue;
     double s[4] = {0., 0., 0., 0.};
@@ -627,159 +634,237 @@ __global__ void eye_kernel(const EyeDesc* __restrict__ descs) {
 // ---- C <- C - V (VT^T C): a compact-WY block reflector (V, VT = V T: rr x nb, nb <= 32) applied to rr x nc columns, FUSED.
 // As two batched GEMMs (W = VT^T C, then C -= V W) the columns cross HBM three times and every product of a 472 x 512 leaf
 // block is a launch of thin tiles (leaf size 512: 12 panels x 2 launches for the factorization and as many for Q, 80 Gflop
-// in 4.3 ms; factor phase 7.63 ms).  Here a workgroup takes NC columns of C into the LDS ([column][row], row stride = 2 mod
-// 32: the 16 columns x 2 rows of a 32-lane operand read fall on distinct banks), forms its 32 x NC block of W from there --
-// 16 x 16 tiles, the K range of a tile cut over the waves left (NC = 16, four waves: two tiles x two halves), VT fragments
-// straight from global memory (L2: the pair is shared by the workgroups of the panel), a batch ahead --, leaves the partial
-// W's in the LDS and applies V with the accumulators loaded from the LDS copy of C: C is read once and written once.
-// NC = 16 keeps two workgroups on a CU for 512 rows (74 KB each): one loads while the other multiplies.  Measured (leaf
-// 512, N = 1e5, gpurun_out/r04m): 3.4 ms per step in 26 launches (the largest: 5632 workgroups, 0.74 GB of C in and out,
-// 0.29 ms = 2.6 TB/s), factor phase 6.02 ms.  What is left is traffic: every panel is one pass over the trailing columns.
-constexpr int WY_LDW = 34;
+// in 4.3 ms; factor phase 7.63 ms).  Here a workgroup takes NC columns of C into the LDS (wy_coff below), forms its 32 x NC
+// block of W from there -- 16 x 16 tiles, the K range of a tile cut over the waves left (NC = 16, four waves: two tiles x
+// two halves), VT fragments straight from global memory (L2: the pair is shared by the workgroups of the panel), a batch
+// ahead --, leaves the partial W's in the LDS and applies V with the accumulators loaded from the LDS copy of C: C is read
+// once and written once.  NC = 16 keeps two workgroups on a CU for 512 rows (79 KB each).
+// SEVERAL reflector blocks in one pass (WyDesc::np pairs, applied in order).  The panels of a GROUP (wy_group() of them)
+// are applied right away only to the columns of their own group; the columns beyond receive the whole group in one pass,
+// the block staying in the LDS between the pairs (pair q acts on the rows from roff_q on).  Forming Q walks the groups
+// backwards the same way (a pair meets exact zeros in the columns its panel has not reached: W = 0 there).
+// Measured, leaf 512 at N = 1e5 (196 leaves, 12 panels each; factor phase of bench.py --leaf 512, gpurun_out/r04j .. r04p):
+//   two batched GEMMs per panel                                                   7.63 ms
+//   fused, loads under branches (vmcnt(0) after every prefetch)                   8.17
+//   unconditional loads                                                           6.02   (wy launches 3.3 ms per step)
+//   + groups of four panels (a quarter of the passes over C), T factors on 512 threads, tiled transposed gathers   5.49
+//   + LDS reads in batches, two accumulators, row tiles side by side              5.57   (no change: not bound there)
+//   + VT in 16-byte loads, a 128-byte line per column and 16-row step             5.14   (wy launches 2.8 ms per step)
+// A workgroup-pair of a CU now spends ~16 us per reflector block where its 1024 MFMAs need 6.8: 0.42 of the matrix pipe
+// inside the kernel; the rest is phase changes (two barriers and the reduction of W per block) with two workgroups per CU.
+constexpr int WY_LDW = 34, WY_MAXP = 4;
+struct WyPair {
+  const double* V;    // rows x nb
+  const double* VT;   // rows x nb   (V T)
+  int roff, nb, rows, pad_;   // the pair acts on rows [roff, roff + rows) of the block
+};
 struct WyDesc {
-  const double* V;    // rr x nb
-  const double* VT;   // rr x nb   (V T)
+  WyPair pr[WY_MAXP];
   double* C;          // rr x nc
-  int ldv, ldc, rr, nb, nc;
+  int ldv, ldc, rr, nc, np;
 };
 struct WyWork { int prob, cblock; };
+// LDS copy of the column block: column j at wy_coff(j) = j ldr + 8 (j / 4) + j % 4 with ldr a multiple of 32 -- the 32
+// lanes of an operand read (16 columns x 2 four-row groups: row 16 S + 4 l4 + u) then fall on 32 distinct banks
+__host__ __device__ inline int wy_ldr(int rr) { return (((rr + 15) & ~15) + 1 + 31) & ~31; }   // (room for one zero row past the padded block)
+__host__ __device__ inline int wy_coff(int j, int ldr) { return j * ldr + 8 * (j >> 2) + (j & 3); }
 template <int NC, int T> __global__ __launch_bounds__(T, T / 128) void wy_apply_kernel(const WyDesc* __restrict__ descs, const WyWork* __restrict__ work) {
   HSSK_DYN_SHARED(double, wy_lds);
   constexpr int NW = T / 64, TILES = 2 * (NC / 16), KP = NW / TILES;   // W tiles (QB / 16 = 2 row tiles) and the K parts of each
   constexpr int KS = KP > 2 ? 2 : KP;                                  // partial W's left in the LDS (four parts fold into two first)
-  constexpr int AH = T >= 512 ? 8 : 16, TC = 4, NU = QB / 4;   // (VT fragments in flight per wave: the register budget of four waves per SIMD)
+  constexpr int AHS = T >= 512 ? 2 : 4, TC = 4, NU = QB / 4;   // (16-row steps of VT in flight per wave: the register budget of four waves per SIMD)
   const WyWork w = work[blockIdx.x];
-  const WyDesc p = descs[w.prob];
+  const WyDesc* pd = descs + w.prob;
+  double* const Cg = pd->C;
+  const int ldv = pd->ldv, ldc = pd->ldc, rr = pd->rr, np = pd->np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int rr = p.rr, nb = p.nb, j0 = w.cblock * NC, ncb = min(NC, p.nc - j0);
-  const int ldr = ((rr + 31) & ~31) + 2;     // row stride of the LDS copy of C
-  double* Cs = wy_lds;                       // [NC][ldr]
-  double* Ws = wy_lds + NC * ldr;            // [KS][NC][WY_LDW]: part q of W(i, j) at Ws[(q * NC + j) * WY_LDW + i]
-  const int rpad = (rr + 15) & ~15, ntile = rpad / 16;
-  // Every global load of the workgroup is issued before the first product: a workgroup is a chain of four latencies otherwise
-  // (C, the VT fragments batch by batch, V tile by tile) with 3 us of MFMA work in between -- 16 us per workgroup measured.
-  // (1) first VT fragments of this wave's (tile, K part); tile = (row tile a of nb, column tile b of the block)
-  const int tile = wave % TILES, q = wave / TILES, a = tile & 1, b = tile >> 1;
-  const int vi = 16 * a + l15;                               // column of VT this lane feeds
-  const double* vt = p.VT + (size_t)min(vi, nb - 1) * p.ldv;
-  const bool vok = vi < nb;                                  // (rows of W beyond nb: computed from column nb - 1, stored as zeros)
-  // (every load of V / VT is UNCONDITIONAL, from a clamped address, and nothing is selected on the loaded value: the compiler
-  // turns `cond ? load : 0` into a load under a branch, and then waits for ALL loads in flight at the next use -- vmcnt(0)
-  // after every prefetch, 16 us per workgroup.  What a clamped load brings in meets a zero on the other side instead: rows
-  // of C beyond rr are zero in the LDS (row ldr - 1 of every column for the sub-steps beyond the last), rows of W beyond
-  // nb are stored as zeros.)
-  const int nk = rpad / 4, per = ((nk + KP - 1) / KP + AH - 1) / AH * AH;   // 4-deep sub-steps per wave: whole batches
-  const int s_lo = q * per;
-  auto load_vt = [&](int s_) { return hssk_gload(vt, (size_t)min(4 * s_ + l4, rr - 1)); };
-  double va[AH];
+  const int j0 = w.cblock * NC, ncb = min(NC, pd->nc - j0);
+  const int rpad = (rr + 15) & ~15, ldr = wy_ldr(rr);
+  double* Cs = wy_lds;                                 // column j from wy_coff(j, ldr) on; rows [rr, rpad] zero
+  double* Ws = wy_lds + wy_coff(NC - 1, ldr) + ldr;    // [KS][NC][WY_LDW]: part q of W(i, j) at Ws[(q * NC + j) * WY_LDW + i]
+  const int tile = wave % TILES, q = wave / TILES, a = tile & 1, b = tile >> 1;   // this wave's (tile, K part) of W; tile = (row tile a of nb, column tile b)
+  for (int pi = 0; pi < np; pi++) {
+    const WyPair pr = pd->pr[pi];
+    const int nb = pr.nb, r0 = pr.roff, rrp = pr.rows, rpadp = (rrp + 15) & ~15, ntile = rpadp / 16;   // (roff: a multiple of 16)
+    // Every global load of a pair is issued before its first product: a workgroup is a chain of latencies otherwise (C, the VT
+    // fragments batch by batch, V tile by tile) with 3 us of MFMA work in between.  And no load of V / VT sits under a branch
+    // of its own or feeds a select: the compiler turns `cond ? load : 0` into a load under a branch and then waits for ALL
+    // loads in flight at the next use -- vmcnt(0) after every prefetch, 16 us per workgroup.  What a clamped load brings in
+    // meets a zero on the other side instead: steps beyond the wave's rows read the zero row of the LDS copy, rows of W
+    // beyond nb are stored as zeros.
+    // (1) first VT fragments.  The contraction runs in 16-row steps: lane (column i = l15, group l4) takes rows 16 S + 4 l4
+    // .. + 3 of its column as two 16-byte loads -- a 128-byte line per column and step, where a row per lane and product
+    // (rows 4 s + l4) asked the L1 for 16 lines per product, each a quarter used: the kernel was bound THERE (a pass over C
+    // less per panel and twice the MFMA rate changed nothing).
+    const int vi = 16 * a + l15;                               // column of VT this lane feeds
+    const double* vt = pr.VT + (size_t)min(vi, nb - 1) * ldv;
+    const bool vok = vi < nb;                                  // (rows of W beyond nb: computed from column nb - 1, stored as zeros)
+    const int nfull = rrp >> 4;                                // whole 16-row steps; the rest (< 16 rows) row by row behind them
+    const int perS = nfull ? ((nfull + KP - 1) / KP + AHS - 1) / AHS * AHS : 0;
+    const int S_lo = q * perS;
+    auto load_vt4 = [&](int S, hssk_d2 (&o)[2]) {
+      const size_t off = (size_t)(16 * min(S, nfull - 1) + 4 * l4);
+      o[0] = hssk_gload2u(vt, off);
+      o[1] = hssk_gload2u(vt, off + 2);
+    };
+    hssk_d2 vq[AHS][2];
+    if (nfull) {
 #pragma unroll
-  for (int u = 0; u < AH; u++) va[u] = load_vt(s_lo + u);
-  // (2) C block -> LDS (zeros beyond the block: they feed the MFMAs); the NC loads of a pass are in flight together
-  for (int i0 = 0; i0 < rpad; i0 += T) {
-    const int i = i0 + tid;
-    const double* src = p.C + min(i, rr - 1) + (size_t)j0 * p.ldc;
-    double v[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) v[c] = hssk_gload(src, (size_t)min(c, ncb - 1) * p.ldc);
-    if (i < rpad) {
-#pragma unroll
-      for (int c = 0; c < NC; c++) Cs[c * ldr + i] = (i < rr && c < ncb) ? v[c] : 0.;
+      for (int x = 0; x < AHS; x++) load_vt4(S_lo + x, vq[x]);
     }
-  }
-  if (tid < NC) Cs[tid * ldr + ldr - 1] = 0.;
-  // (3) the V values of this wave's first row tiles of the second product (they arrive under the first one)
-  auto load_v = [&](int t, double (&av)[NU]) {
-    const int gi = 16 * t + l15;
-    const double* vrow = p.V + min(gi, rr - 1);
+    // (2) first pair: C block -> LDS (zeros beyond the block: they feed the MFMAs); the NC loads of a pass are in flight together
+    if (pi == 0) {
+      for (int i0 = 0; i0 < rpad; i0 += T) {
+        const int i = i0 + tid;
+        const double* src = Cg + min(i, rr - 1) + (size_t)j0 * ldc;
+        double v[NC];
 #pragma unroll
-    for (int u = 0; u < NU; u++) {
-      const int k = 4 * u + l4;
-      av[u] = -hssk_gload(vrow, (size_t)min(k, nb - 1) * p.ldv);   // (columns beyond nb meet zero rows of W, rows beyond rr are not stored)
-    }
-  };
-  double avs[TC][NU];
+        for (int c = 0; c < NC; c++) v[c] = hssk_gload(src, (size_t)min(c, ncb - 1) * ldc);
+        if (i < rpad) {
 #pragma unroll
-  for (int x = 0; x < TC / 2; x++) load_v(wave + x * NW, avs[x]);   // (the other half once the VT registers are free)
-  __syncthreads();
-  // ---- W = VT^T C
-  {
-    hssk_d4 acc = {0., 0., 0., 0.};
-    const double* cs = Cs + (16 * b + l15) * ldr;
-    for (int s0 = s_lo; s0 < s_lo + per; s0 += AH) {
-#pragma unroll
-      for (int u = 0; u < AH; u++) {
-        const int s = s0 + u, k = 4 * s + l4;
-        const double av = va[u];
-        va[u] = load_vt(s + AH);
-        acc = hssk_mfma_f64_16x16x4(cs[k < rpad ? k : ldr - 1], av, acc);   // swapped: lane holds W[i = l15][j = l4 + 4 r]
+          for (int c = 0; c < NC; c++) Cs[wy_coff(c, ldr) + i] = (i < rr && c < ncb) ? v[c] : 0.;
+        }
       }
+      if (tid < NC) Cs[wy_coff(tid, ldr) + rpad] = 0.;
     }
-    if (!vok) acc = hssk_d4{0., 0., 0., 0.};
+    // (3) the V values of this wave's first row tiles of the second product (they arrive under the first one)
+    auto load_v = [&](int t, double (&av)[NU]) {
+      const int gi = 16 * t + l15;
+      const double* vrow = pr.V + min(gi, rrp - 1);
 #pragma unroll
-    for (int x = TC / 2; x < TC; x++) load_v(wave + x * NW, avs[x]);
-    if (KP > KS) {   // parts 2, 3 first; parts 0, 1 add them to their own (same lanes, same addresses: no barrier in between)
-      if (q >= KS) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) Ws[((q - KS) * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
+      for (int u = 0; u < NU; u++) {
+        const int k = 4 * u + l4;
+        av[u] = -hssk_gload(vrow, (size_t)min(k, nb - 1) * ldv);   // (columns beyond nb meet zero rows of W, rows beyond the pair's are not stored)
       }
-      __syncthreads();
+    };
+    double avs[TC][NU];
+#pragma unroll
+    for (int x = 0; x < TC / 2; x++) load_v(wave + x * NW, avs[x]);   // (the other half once the VT registers are free)
+    __syncthreads();   // (the block is in the LDS: staged, or left there by the pair before)
+    if (pi == np - 1 && pi > 0 && r0 > 0) {   // rows above the last pair's: final since the pairs before, written out from the LDS
+      for (int c = 0; c < ncb; c++)
+        for (int i = tid; i < r0; i += T) hssk_gstore(Cg, (size_t)i + (size_t)(j0 + c) * ldc, Cs[wy_coff(c, ldr) + i]);
+    }
+    // ---- W = VT^T C
+    {
+      // (a batch of LDS reads, then its products on two accumulators in turn)
+      hssk_d4 acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
+      const double* cs = Cs + wy_coff(16 * b + l15, ldr) + r0;
+      const int zrow = rpad - r0;
+      for (int S0 = S_lo; S0 < S_lo + perS; S0 += AHS) {
+        double cv[AHS][4];
+        hssk_d2 vb[AHS][2];
+#pragma unroll
+        for (int x = 0; x < AHS; x++) {
+          const int S = S0 + x, k = 16 * S + 4 * l4;
+#pragma unroll
+          for (int u = 0; u < 4; u++) cv[x][u] = cs[S < nfull ? k + u : zrow];
+          vb[x][0] = vq[x][0]; vb[x][1] = vq[x][1];
+        }
+#pragma unroll
+        for (int x = 0; x < AHS; x++) load_vt4(S0 + AHS + x, vq[x]);
+#pragma unroll
+        for (int x = 0; x < AHS; x++) {
+          acc = hssk_mfma_f64_16x16x4(cv[x][0], vb[x][0][0], acc);   // swapped: lane holds W[i = l15][j = l4 + 4 r]
+          acc1 = hssk_mfma_f64_16x16x4(cv[x][1], vb[x][0][1], acc1);
+          acc = hssk_mfma_f64_16x16x4(cv[x][2], vb[x][1][0], acc);
+          acc1 = hssk_mfma_f64_16x16x4(cv[x][3], vb[x][1][1], acc1);
+        }
+      }
+      if ((rrp & 15) && q == 0) {   // the rows behind the last whole step: a row per lane and product, clamped (the wait for these loads is the phase's last)
+        double tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) tv[u] = hssk_gload(vt, (size_t)min(16 * nfull + 4 * u + l4, rrp - 1));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = 16 * nfull + 4 * u + l4;
+          acc = hssk_mfma_f64_16x16x4(cs[k < rrp ? k : zrow], tv[u], acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] += acc1[r];
+      if (!vok) acc = hssk_d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int x = TC / 2; x < TC; x++) load_v(wave + x * NW, avs[x]);
+      if (KP > KS) {   // parts 2, 3 first; parts 0, 1 add them to their own (same lanes, same addresses: no barrier in between)
+        if (q >= KS) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) Ws[((q - KS) * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
+        }
+        __syncthreads();
+        if (q < KS) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[r] += Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15];
+        }
+      }
       if (q < KS) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[r] += Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15];
+        for (int r = 0; r < 4; r++) Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
       }
     }
-    if (q < KS) {
+    __syncthreads();
+    // ---- C -= V W: 16-row tiles of the block's rows, dealt to the waves; all column tiles of a row tile together.  The
+    // fragments of W (parts summed) stay in registers over the wave's tiles.  The last pair's result goes to global memory,
+    // the others' back into the LDS.
+    double wf[NC / 16][NU];
 #pragma unroll
-      for (int r = 0; r < 4; r++) Ws[(q * NC + 16 * b + l4 + 4 * r) * WY_LDW + 16 * a + l15] = acc[r];
-    }
-  }
-  __syncthreads();
-  // ---- C -= V W: 16-row tiles of the block's rows, dealt to the waves; all column tiles of a row tile together.  The
-  // fragments of W (parts summed) stay in registers over the wave's tiles.
-  double wf[NC / 16][NU];
+    for (int bb = 0; bb < NC / 16; bb++)
 #pragma unroll
-  for (int bb = 0; bb < NC / 16; bb++)
+      for (int u = 0; u < NU; u++) {
+        double wv = Ws[(16 * bb + l15) * WY_LDW + 4 * u + l4];
 #pragma unroll
-    for (int u = 0; u < NU; u++) {
-      double wv = Ws[(16 * bb + l15) * WY_LDW + 4 * u + l4];
+        for (int qq = 1; qq < KS; qq++) wv += Ws[(qq * NC + 16 * bb + l15) * WY_LDW + 4 * u + l4];
+        wf[bb][u] = wv;
+      }
+    const bool last = pi == np - 1;
+    for (int t0 = wave; t0 < ntile; t0 += TC * NW) {
+      if (t0 != wave) {
 #pragma unroll
-      for (int qq = 1; qq < KS; qq++) wv += Ws[(qq * NC + 16 * bb + l15) * WY_LDW + 4 * u + l4];
-      wf[bb][u] = wv;
-    }
-  for (int t0 = wave; t0 < ntile; t0 += TC * NW) {
-    if (t0 != wave) {
+        for (int x = 0; x < TC; x++) load_v(t0 + x * NW, avs[x]);
+      }
+      // (the chunk's tiles side by side: consecutive products are independent)
+      hssk_d4 c[TC][NC / 16];
 #pragma unroll
-      for (int x = 0; x < TC; x++) load_v(t0 + x * NW, avs[x]);
-    }
-#pragma unroll
-    for (int x = 0; x < TC; x++) {
-      const int t = t0 + x * NW;
-      if (t >= ntile) break;
-      const int gi = 16 * t + l15;
-      hssk_d4 c[NC / 16];
-#pragma unroll
-      for (int bb = 0; bb < NC / 16; bb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) c[bb][r] = Cs[(16 * bb + l4 + 4 * r) * ldr + gi];
-#pragma unroll
-      for (int u = 0; u < NU; u++)
-#pragma unroll
-        for (int bb = 0; bb < NC / 16; bb++) c[bb] = hssk_mfma_f64_16x16x4(wf[bb][u], avs[x][u], c[bb]);   // lane holds C[i = l15][j = l4 + 4 r]
-      if (gi < rr) {
+      for (int x = 0; x < TC; x++) {
+        const int gi = r0 + min(16 * (t0 + x * NW) + l15, rpadp - 1);
 #pragma unroll
         for (int bb = 0; bb < NC / 16; bb++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int j = 16 * bb + l4 + 4 * r;
-            if (j < ncb) hssk_gstore(p.C, (size_t)gi + (size_t)(j0 + j) * p.ldc, c[bb][r]);
+          for (int r = 0; r < 4; r++) c[x][bb][r] = Cs[wy_coff(16 * bb + l4 + 4 * r, ldr) + gi];
+      }
+#pragma unroll
+      for (int u = 0; u < NU; u++)
+#pragma unroll
+        for (int x = 0; x < TC; x++)
+#pragma unroll
+          for (int bb = 0; bb < NC / 16; bb++) c[x][bb] = hssk_mfma_f64_16x16x4(wf[bb][u], avs[x][u], c[x][bb]);   // lane holds C[i = l15][j = l4 + 4 r]
+#pragma unroll
+      for (int x = 0; x < TC; x++) {
+        const int t = t0 + x * NW, gi = r0 + 16 * t + l15;
+        if (t < ntile && 16 * t + l15 < rrp) {
+          if (last) {
+#pragma unroll
+            for (int bb = 0; bb < NC / 16; bb++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int j = 16 * bb + l4 + 4 * r;
+                if (j < ncb) hssk_gstore(Cg, (size_t)gi + (size_t)(j0 + j) * ldc, c[x][bb][r]);
+              }
+          } else {
+#pragma unroll
+            for (int bb = 0; bb < NC / 16; bb++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) Cs[wy_coff(16 * bb + l4 + 4 * r, ldr) + gi] = c[x][bb][r];
           }
+        }
       }
     }
   }
 }
 template <int NC, int T> inline size_t wy_lds_bytes(int rr) {
   constexpr int KP = (T / 64) / (2 * (NC / 16));
-  return sizeof(double) * ((size_t)NC * (((rr + 31) & ~31) + 2) + (size_t)(KP > 2 ? 2 : KP) * NC * WY_LDW);
+  const int ldr = wy_ldr(rr);
+  return sizeof(double) * ((size_t)wy_coff(NC - 1, ldr) + ldr + (size_t)(KP > 2 ? 2 : KP) * NC * WY_LDW);
 }
 template <int NC, int T> bool wy_apply_nc(hssk_ctx* ctx, const std::vector<WyDesc>& d, int rmax) {
   static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
@@ -795,22 +880,38 @@ template <int NC, int T> bool wy_apply_nc(hssk_ctx* ctx, const std::vector<WyDes
   HSSK_LAUNCH((wy_apply_kernel<NC, T>), dim3((unsigned)wk.size()), dim3(T), shm, ctx->stream, dd, dw);
   return true;
 }
-// the fused application for a batch of (V, VT, C) triples; false if some panel does not fit (the caller then takes the two GEMMs)
+inline int wy_mode() {
+  static const int mode = [] { const char* e = std::getenv("HSSK_QR_WY"); return e ? std::atoi(e) : 16; }();   // 0: off (two batched GEMMs per panel)
+  return mode;
+}
+// panels of up to `rows` rows can take the fused application (the LDS holds the column block)
+bool wy_usable(int rows) {
+  static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
+  switch (wy_mode()) {
+    case 0: return false;
+    default: return wy_lds_bytes<16, 256>(rows) <= lds_cap;
+  }
+}
+// panels per group (QB_GROUP above): the columns beyond a group see its panels in ONE pass (HSSK_QR_GROUP = 1: every panel its own)
+inline int wy_group() {
+  static const int g = [] { const char* e = std::getenv("HSSK_QR_GROUP"); return std::max(1, std::min(WY_MAXP, e ? std::atoi(e) : WY_MAXP)); }();
+  return g;
+}
+// the fused application for a batch of (pairs, C); false if some block does not fit (callers ask wy_usable first)
 bool wy_apply(hssk_ctx* ctx, const std::vector<WyDesc>& d) {
   if (d.empty()) return true;
-  static const int mode = [] { const char* e = std::getenv("HSSK_QR_WY"); return e ? std::atoi(e) : 16; }();   // 0: off; columns per workgroup (16 / 32) + 1000 x threads (256 if none)
+  const int mode = wy_mode();
   if (mode == 0) return false;
   int rmax = 0;
   for (auto& x : d) {
-    if (x.nb > QB || x.nb <= 0 || x.rr <= 0) return false;
+    if (x.np < 1 || x.np > WY_MAXP || x.rr <= 0) return false;
+    for (int i = 0; i < x.np; i++)
+      if (x.pr[i].nb > QB || x.pr[i].nb <= 0 || x.pr[i].roff < 0 || x.pr[i].roff % 16 || x.pr[i].rows <= 0 || x.pr[i].roff + x.pr[i].rows > x.rr) return false;
     rmax = std::max(rmax, x.rr);
   }
-  switch (mode) {
-    case 32: return wy_apply_nc<32, 256>(ctx, d, rmax);
-    case 512016: return wy_apply_nc<16, 512>(ctx, d, rmax);
-    case 512032: return wy_apply_nc<32, 512>(ctx, d, rmax);
-    default: return wy_apply_nc<16, 256>(ctx, d, rmax);   // (leaf 512, factor phase: 6.02 ms; <16, 512> 6.13; <32, 512> 6.79; two GEMMs 7.63)
-  }
+  // (32 columns per workgroup, and eight waves on 16, were measured slower in every form: factor phase at leaf 512 6.79 and
+  // 6.13 against 6.02 ms in the first, 7.06 against 5.57 in a later one -- both spill at the register budget of their occupancy)
+  return wy_apply_nc<16, 256>(ctx, d, rmax);
 }
 
 void gemm_batch(hssk_ctx* ctx, std::vector<hssk_gemm_desc>& g) {
@@ -842,9 +943,19 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
   std::vector<QPanel> lp;
   std::vector<hssk_gemm_desc> g1, g2;
   std::vector<WyDesc> wy;
+  int rows_max = 0;
+  for (int i = 0; i < count; i++) rows_max = std::max(rows_max, descs[i].rows);
+  const bool fused = wy_usable(rows_max);
+  const int GP = fused ? wy_group() : 1;
+  auto one_pair = [](const double* V, const double* VT, int nb, int rows, double* C, int ldv, int ldc, int nc) {
+    WyDesc w{};
+    w.pr[0] = WyPair{V, VT, 0, nb, rows, 0};
+    w.C = C; w.ldv = ldv; w.ldc = ldc; w.rr = rows; w.nc = nc; w.np = 1;
+    return w;
+  };
   for (int p = 0; p < std::max(pmax, 1); p++) {
     pd.clear(); lp.clear(); g1.clear(); g2.clear(); td.clear(); gG.clear(); gVT.clear(); wy.clear();
-    const int j0 = p * QB;
+    const int j0 = p * QB, g0 = (p / GP) * GP;
     for (int i = 0; i < count; i++) {
       const hssk_qr_desc& d = descs[i];
       const int kmax = std::min(d.rows, d.cols);
@@ -868,12 +979,29 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
       }
       if (nb == 0 || !factor) continue;
       pd.push_back(hssk_qr_desc{Ap, d.lda, rr, nb, nullptr, 0, 0, rdp, d.work + j0});
-      const int nt = d.cols - (j0 + nb);
+      // the columns of the panel's own group: this panel alone, now
+      const int je = GP > 1 ? (int)std::min<long long>(d.cols, (long long)(g0 + GP) * QB) : d.cols;   // first column beyond the group
+      const int nt = je - (j0 + nb);
       if (nt > 0) {
         double* A2 = Ap + (size_t)nb * d.lda;
-        g1.push_back(hssk_gemm_desc{VT, A2, W, nb, nt, rr, d.rows, d.lda, QB, 1, 0, 1.0, 0.0});
-        g2.push_back(hssk_gemm_desc{Vc, W, A2, rr, nt, nb, d.rows, QB, d.lda, 0, 0, -1.0, 1.0});
-        wy.push_back(WyDesc{Vc, VT, A2, d.rows, d.lda, rr, nb, nt});
+        if (fused) wy.push_back(one_pair(Vc, VT, nb, rr, A2, d.rows, d.lda, nt));
+        else {
+          g1.push_back(hssk_gemm_desc{VT, A2, W, nb, nt, rr, d.rows, d.lda, QB, 1, 0, 1.0, 0.0});
+          g2.push_back(hssk_gemm_desc{Vc, W, A2, rr, nt, nb, d.rows, QB, d.lda, 0, 0, -1.0, 1.0});
+        }
+      }
+      // the columns beyond, once the group (or the matrix) has its last panel: all panels of the group in one pass
+      if (GP > 1 && d.cols > je && (p == g0 + GP - 1 || p == (kmax - 1) / QB)) {
+        WyDesc w{};
+        const int jg = g0 * QB;
+        for (int q = g0; q <= p; q++) {
+          const int jq = q * QB, nbq = std::min(QB, kmax - jq);
+          const int rendq = (d.stair > 0 && d.nq == 0) ? std::min<long long>(d.rows, (long long)d.stair * (jq + nbq)) : d.rows;
+          const double* Vq = ws + offV[i] + jq + (size_t)jq * d.rows;
+          w.pr[w.np++] = WyPair{Vq, Vq + (size_t)d.rows * kmax, jq - jg, nbq, rendq - jq, 0};
+        }
+        w.C = d.A + jg + (size_t)je * d.lda; w.ldv = d.rows; w.ldc = d.lda; w.rr = rend - jg; w.nc = d.cols - je;
+        wy.push_back(w);
       }
     }
     if (!pd.empty()) {
@@ -894,11 +1022,13 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
       } else {
         int lrmax = 0;
         for (auto& q : lp) lrmax = std::max(lrmax, q.rows);
-        if (lrmax <= 256) HSSK_LAUNCH(larft_kernel<256>, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
-        else HSSK_LAUNCH(larft_kernel<QB_MAXROWS>, dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+        if (lrmax <= 256) HSSK_LAUNCH((larft_kernel<256, 256>), dim3((unsigned)lp.size()), dim3(256), 0, ctx->stream, dl);
+        else HSSK_LAUNCH((larft_kernel<QB_MAXROWS, 512>), dim3((unsigned)lp.size()), dim3(512), 0, ctx->stream, dl);   // (1024 threads would leave the back substitution 128 registers: it keeps 64 doubles)
       }
     }
-    if (!wy_apply(ctx, wy)) {
+    if (fused) {
+      if (!wy_apply(ctx, wy)) throw std::runtime_error("hssk_qr: fused block reflector refused a block it had accepted");
+    } else {
       gemm_batch(ctx, g1);
       gemm_batch(ctx, g2);
     }
@@ -910,26 +1040,45 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
   if (ey.empty()) return;
   auto* de = (const EyeDesc*)ctx->stage(ey.data(), sizeof(EyeDesc) * ey.size());
   HSSK_LAUNCH(eye_kernel, dim3((unsigned)ey.size(), 16), dim3(256), 0, ctx->stream, de);
-  for (int p = pmax - 1; p >= 0; p--) {
-    g1.clear(); g2.clear(); wy.clear();
-    const int j0 = p * QB;
-    for (int i = 0; i < count; i++) {
-      const hssk_qr_desc& d = descs[i];
-      const int kmax = std::min(d.rows, d.cols);
-      if (j0 >= kmax || d.nq <= j0) continue;
-      const int nb = std::min(QB, kmax - j0), rr = d.rows - j0, cq = d.nq - j0;
-      double* Vc = ws + offV[i] + j0 + (size_t)j0 * d.rows;
-      double* VT = Vc + (size_t)d.rows * kmax;
-      double* W = ws + offW[i];
-      double* Qb = d.Q + j0 + (size_t)j0 * d.ldq;
-      g1.push_back(hssk_gemm_desc{Vc, Qb, W, nb, cq, rr, d.rows, d.ldq, QB, 1, 0, 1.0, 0.0});
-      g2.push_back(hssk_gemm_desc{VT, W, Qb, rr, cq, nb, d.rows, QB, d.ldq, 0, 0, -1.0, 1.0});
-      wy.push_back(WyDesc{VT, Vc, Qb, d.rows, d.ldq, rr, nb, cq});   // Q <- Q - (V T)(V^T Q): the roles of the pair swapped
-    }
-    if (!wy_apply(ctx, wy)) {
+  // Q = H_0 ... H_k I, the groups backwards; inside a group the panels from the last to the first over the block
+  // Q(j_g:, j_g:) -- a panel finds exact zeros in its rows of the columns it has not reached yet (W = 0 there)
+  for (int g = (pmax - 1) / GP; g >= 0; g--) {
+    wy.clear();
+    const int g0 = g * GP, jg = g0 * QB;
+    for (int ps = std::min(pmax, g0 + GP) - 1; ps >= g0; ps--) {   // (unfused: a pair of products per panel)
+      g1.clear(); g2.clear();
+      const int j0 = ps * QB;
+      for (int i = 0; i < count && !fused; i++) {
+        const hssk_qr_desc& d = descs[i];
+        const int kmax = std::min(d.rows, d.cols);
+        if (j0 >= kmax || d.nq <= j0) continue;
+        const int nb = std::min(QB, kmax - j0), rr = d.rows - j0, cq = d.nq - j0;
+        double* Vc = ws + offV[i] + j0 + (size_t)j0 * d.rows;
+        double* VT = Vc + (size_t)d.rows * kmax;
+        double* W = ws + offW[i];
+        double* Qb = d.Q + j0 + (size_t)j0 * d.ldq;
+        g1.push_back(hssk_gemm_desc{Vc, Qb, W, nb, cq, rr, d.rows, d.ldq, QB, 1, 0, 1.0, 0.0});
+        g2.push_back(hssk_gemm_desc{VT, W, Qb, rr, cq, nb, d.rows, QB, d.ldq, 0, 0, -1.0, 1.0});
+      }
       gemm_batch(ctx, g1);
       gemm_batch(ctx, g2);
     }
+    if (!fused) continue;
+    for (int i = 0; i < count; i++) {
+      const hssk_qr_desc& d = descs[i];
+      const int kmax = std::min(d.rows, d.cols);
+      if (jg >= kmax || d.nq <= jg) continue;
+      WyDesc w{};
+      for (int q = std::min(pmax, g0 + GP) - 1; q >= g0; q--) {
+        const int jq = q * QB;
+        if (jq >= kmax || d.nq <= jq) continue;
+        const double* Vq = ws + offV[i] + jq + (size_t)jq * d.rows;
+        w.pr[w.np++] = WyPair{Vq + (size_t)d.rows * kmax, Vq, jq - jg, std::min(QB, kmax - jq), d.rows - jq, 0};   // Q <- Q - (V T)(V^T Q): the roles of the pair swapped
+      }
+      w.C = d.Q + jg + (size_t)jg * d.ldq; w.ldv = d.rows; w.ldc = d.ldq; w.rr = d.rows - jg; w.nc = d.nq - jg;
+      wy.push_back(w);
+    }
+    if (!wy_apply(ctx, wy)) throw std::runtime_error("hssk_qr: fused block reflector refused a block it had accepted");
   }
 }
 

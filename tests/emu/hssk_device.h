@@ -114,6 +114,7 @@ void hssk_pause();   // emu_runtime.cpp: sched_yield
 #define HSSK_SHARED alignas(16) static thread_local
 inline double hssk_gload(const double* p, size_t off) { return p[off]; }
 inline hssk_d2 hssk_gload2(const double* p, size_t off) { return *reinterpret_cast<const hssk_d2*>(p + off); }
+inline hssk_d2 hssk_gload2u(const double* p, size_t off) { hssk_d2 v; std::memcpy(&v, p + off, sizeof v); return v; }
 inline void hssk_gstore(double* p, size_t off, double v) { p[off] = v; }
 // asynchronous global -> LDS copies: immediate on the emulator (lane l's 16 bytes land at lds_base + 16 l)
 inline void hssk_glds16(const double* gsrc, double* lds_base) { std::memcpy(lds_base + 2 * (threadIdx.x & 63), gsrc, 16); }

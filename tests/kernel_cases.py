@@ -177,6 +177,29 @@ def case_gathers(hk, seed=3):
     assert np.array_equal(dB.get(), src[np.ix_(Ii, Jj)])
     assert np.array_equal(dBt.get(), src[np.ix_(Ii, Jj)].T)
     assert np.array_equal(dBc.get(), src[5:15, 7:19])
+    # large transposed gathers take the tiled kernel (64 x 32 tiles through the LDS): ragged edges, permuted rows, a window
+    big = r.standard_normal((150, 130))
+    dG = hk.array(big)
+    Ib = r.permutation(150)[:101].astype(np.int32)
+    dIb = hk.array(Ib)
+    dT1 = hk.array(np.full((75, 101), 7.0))     # ldb 75 > n = 70
+    dT2 = hk.array(np.zeros((130, 150)))
+    dT3 = hk.array(np.zeros((40, 101)))
+    hk.batch("hssk_gather_elems", [
+        K.ElemDesc(dG.ptr, 150, dIb.ptr, None, 0, 20, dT1.ptr, 101, 70, 75, 1),
+        K.ElemDesc(dG.ptr, 150, None, None, 0, 0, dT2.ptr, 150, 130, 130, 1),
+        K.ElemDesc(dG.ptr, 150, dIb.ptr, None, 0, 33, dT3.ptr, 101, 40, 40, 1, 10, 90, 40, 60),
+        K.ElemDesc(dS.ptr, 37, dIi.ptr, dJj.ptr, 0, 0, dB.ptr, 9, 13, 9, 0)])
+    hk.sync()
+    t1 = dT1.get()
+    assert np.array_equal(t1[:70], big[Ib][:, 20:90].T) and np.all(t1[70:] == 7.0)
+    assert np.array_equal(dT2.get(), big.T)
+    ref3 = big[Ib][:, 33:73].copy()
+    ref3[(Ib < 10) | (Ib >= 90), :] = 0.
+    cols = np.arange(33, 73)
+    ref3[:, (cols < 40) | (cols >= 60)] = 0.
+    assert np.array_equal(dT3.get(), ref3.T)
+    assert np.array_equal(dB.get(), src[np.ix_(Ii, Jj)])
     # transpose
     dT = hk.array(np.zeros((52, 37)))
     hk.batch("hssk_transpose", [K.TransposeDesc(dS.ptr, dT.ptr, 37, 50, 37, 52)])

@@ -26,6 +26,84 @@ def test_clustering_matches_reference(lib, algo):
         assert np.array_equal(Xp, pts[perm - 1])
 
 
+def _serial_tree(X, leaf, split):
+    """Serial restatement of binary_tree_clustering's recursion (host/Clustering.hpp: recurse + group_zero_first) with numpy
+    splits: returns the 1-based permutation and the leaf sizes."""
+    n = len(X)
+    perm = np.arange(1, n + 1)
+    leaves = []
+
+    def rec(lo, hi):
+        m = hi - lo
+        if m < leaf:
+            leaves.append(m)
+            return
+        lab = split(X[perm[lo:hi] - 1])
+        n0 = int((lab == 0).sum())
+        # group_zero_first: the j-th zero-labelled point is swapped into slot j
+        loc = perm[lo:hi].copy()
+        labc = lab.copy()
+        ct = cj = 0
+        for _ in range(n0):
+            while labc[cj] != 0:
+                cj += 1
+            if cj != ct:
+                loc[[cj, ct]] = loc[[ct, cj]]
+                labc[cj] = labc[ct]
+                labc[ct] = 0
+            cj += 1
+            ct += 1
+        perm[lo:hi] = loc
+        if n0 == 0 or n0 == m:
+            leaves.append(m)
+            return
+        rec(lo, lo + n0)
+        rec(lo + n0, hi)
+
+    rec(0, n)
+    return perm, leaves
+
+
+def _median_labels(key):
+    n = len(key)
+    # std::nth_element leaves an implementation-defined arrangement, but WHICH elements fall below the median position is
+    # determined when the keys are distinct
+    order = np.argsort(key, kind="stable")
+    lab = np.zeros(n, dtype=np.int64)
+    lab[order[n // 2:]] = 1
+    return lab
+
+
+def _split_cobble(P):
+    cen = np.zeros(P.shape[1])
+    for j in range(P.shape[1]):
+        cen[j] = np.add.accumulate(P[:, j])[-1] / len(P)       # (left-to-right sum, as the host code)
+    first = int(np.argmax(np.sqrt(((P - cen) ** 2).sum(1))))
+    return _median_labels(np.sqrt(((P - P[first]) ** 2).sum(1)))
+
+
+def _split_kd(P):
+    ext = P.max(0) - P.min(0)
+    return _median_labels(P[:, int(np.argmax(ext))])
+
+
+@pytest.mark.parametrize("algo,split", [("cobble", _split_cobble), ("kdtree", _split_kd)])
+def test_clustering_large_set_on_host_threads(lib, algo, split):
+    """70 000 points: the halves of the top splits run on host threads and the passes of the first levels in pieces
+    (Clustering.hpp: recurse / for_pieces); the tree must be the serial one.  Leaf sets are compared (the order inside the
+    halves of a median split is nth_element's)."""
+    r = np.random.default_rng(11)
+    X = r.random((70000, 5))
+    Xp, perm, leaves = KM.clustering(lib, X, algo, 600)
+    assert np.array_equal(Xp, X[perm - 1]) and sorted(perm.tolist()) == list(range(1, 70001))
+    rperm, rleaves = _serial_tree(X, 600, split)
+    assert leaves.tolist() == rleaves
+    off = 0
+    for m in rleaves:
+        assert set(perm[off:off + m].tolist()) == set(rperm[off:off + m].tolist())
+        off += m
+
+
 def test_pca_clustering_matches_reference_up_to_mirroring(lib):
     """The principal direction comes from LAPACK syevx in the reference: its sign is implementation-defined, so a split
     may come out mirrored; the two halves (as point sets) and the leaf sizes must agree."""
