@@ -953,8 +953,11 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
     w.C = C; w.ldv = ldv; w.ldc = ldc; w.rr = rows; w.nc = nc; w.np = 1;
     return w;
   };
+  // (Q only, from panels factored before: the T factors of all panels depend on nothing -- one launch for all of them)
+  const bool all_larft = !factor && !tall;
   for (int p = 0; p < std::max(pmax, 1); p++) {
-    pd.clear(); lp.clear(); g1.clear(); g2.clear(); td.clear(); gG.clear(); gVT.clear(); wy.clear();
+    pd.clear(); g1.clear(); g2.clear(); td.clear(); gG.clear(); gVT.clear(); wy.clear();
+    if (!all_larft || p == 0) lp.clear();
     const int j0 = p * QB, g0 = (p / GP) * GP;
     for (int i = 0; i < count; i++) {
       const hssk_qr_desc& d = descs[i];
@@ -1009,7 +1012,7 @@ void qr_blocked(hssk_ctx* ctx, const hssk_qr_desc* descs, int count, bool factor
       if (tall) HSSK_LAUNCH(qr_kernel, dim3((unsigned)pd.size()), dim3(QR_THREADS), 0, ctx->stream, dp, 0);   // Level-2 on a 32-column panel
       else HSSK_LAUNCH((qr_reg_kernel<32, 1, 8>), dim3((unsigned)pd.size()), dim3(512), 0, ctx->stream, dp);
     }
-    if (!lp.empty()) {
+    if (!lp.empty() && (!all_larft || p == std::max(pmax, 1) - 1)) {
       auto* dl = (const QPanel*)ctx->stage(lp.data(), sizeof(QPanel) * lp.size());
       if (tall) {
         HSSK_LAUNCH(make_v_kernel, dim3((unsigned)lp.size(), 8), dim3(256), 0, ctx->stream, dl);
@@ -1114,8 +1117,15 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
   else if (cmax <= 160) launch_qr_reg<13, 5, 8>(ctx, dd, count);   // (a step costs per column slot: the 195 x ~160 ULV panels of N = 1e5 need five or
   else if (cmax <= 192) launch_qr_reg<13, 6, 8>(ctx, dd, count);   //  six, not seven)
   else launch_qr_reg<13, 7, 8>(ctx, dd, count);
-  // Q is then formed by a second, barrier-free launch over blocks of 64 columns
-  if (qmax > 0) formq_reg(ctx, dd, descs, count, rmax);
+  // Q is then formed by a second, barrier-free launch over blocks of 64 columns -- or, for the taller panels, from the compact-WY
+  // pairs of 32 reflectors each on the matrix cores (qr_blocked with the factorization skipped: the T factors of all panels in
+  // one launch, then the fused block reflector over the groups of panels; the 512 panels 196 x 155 of the ULV leaves at N =
+  // 1e5: formq_reg 0.70 ms).  HSSK_QR_FORMQ_WY=0: the register form for everything up to 256 rows.
+  static const bool q_wy = [] { const char* e = std::getenv("HSSK_QR_FORMQ_WY"); return !(e && e[0] == '0'); }();
+  if (qmax > 0) {
+    if (q_wy && rmax >= 128 && cmax >= 64 && wy_usable(rmax)) qr_blocked(ctx, descs, count, false);
+    else formq_reg(ctx, dd, descs, count, rmax);
+  }
   hssk_rt::check_launch();
   HSSK_API_END
 }
@@ -1134,8 +1144,12 @@ extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int
   if (force_blocked() || rmax > 256) {
     qr_blocked(ctx, descs, count, false);
   } else {
-    auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
-    formq_reg(ctx, dd, descs, count, rmax);   // rmax <= 256 (taller panels took the blocked path above)
+    static const bool q_wy = [] { const char* e = std::getenv("HSSK_QR_FORMQ_WY"); return !(e && e[0] == '0'); }();
+    if (q_wy && rmax >= 128 && cmax >= 64 && wy_usable(rmax)) qr_blocked(ctx, descs, count, false);
+    else {
+      auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);
+      formq_reg(ctx, dd, descs, count, rmax);   // rmax <= 256 (taller panels took the blocked path above)
+    }
   }
   hssk_rt::check_launch();
   HSSK_API_END
