@@ -213,6 +213,21 @@ int hssk_kernel_eval_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* spec, const
  * of the query range are written -- one process per GPU searches for its own points).  Serves the neighbour lists of
  * HSSMatrix::compress_with_coordinates (HSS/HSSMatrix.compress_kernel.hpp:58-66).  d <= 64. */
 int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx);
+/* Column sets of the kernel-matrix compression (the sorted, duplicate-free ids a node samples its rows on:
+ * HSS/HSSMatrix.compress_kernel.hpp:108-131 for a leaf -- the neighbours of its points outside the leaf --, :159-183 for an
+ * inner node -- the union of its children's sets without the ids inside the node).  out = sorted unique ids of
+ * src0[0:n0] and src1[0:n1] (device ints; src1 may be NULL) that are >= 0 and outside [lo, hi); *count = their number
+ * (out has room for n0 + n1).  universe = number of points (all ids are below it): a workgroup marks a bitmap of that many
+ * bits in its LDS and reads it back in order; returns HSSK_UNSUPPORTED when the bitmap does not fit the LDS. */
+typedef struct hssk_colset_desc {
+  const int* src0;
+  const int* src1;
+  int n0, n1, lo, hi;
+  int* out;
+  int* count;
+} hssk_colset_desc;
+int hssk_colsets(hssk_ctx* ctx, const hssk_colset_desc* descs, int count, int universe);
+long long hssk_colsets_max_universe(void);   /* largest universe hssk_colsets takes on this device */
 /* pred[c] = sum_r w[r] k(x_r, t_c), c < m; T is d x m (device)   (Kernel::predict, kernel/KernelRegression.hpp:112-123) */
 int hssk_kernel_predict(hssk_ctx* ctx, const hssk_kernel_spec* spec, const double* w, const double* T, int m, double* pred);
 

@@ -183,6 +183,10 @@ __device__ __forceinline__ int hssk_opaque(int v) { __asm__ volatile("" : "+v"(v
 __device__ __forceinline__ void hssk_lds_add(double* p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// bits set in an LDS word by many lanes at once
+__device__ __forceinline__ void hssk_lds_or(unsigned* p, unsigned v) {
+  (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // a slot counter in the LDS: returns the value before the increment
 __device__ __forceinline__ int hssk_lds_inc(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // a value known to be the same in every lane of the wave, moved to a scalar register (loads indexed by it become s_load)

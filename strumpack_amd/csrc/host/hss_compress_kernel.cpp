@@ -27,14 +27,23 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     ck(hssk_memcpy_h2d(ctx_, dX, ks.X, (long long)sizeof(double) * dim * N));
     hssk_kernel_spec spec{dX, N, dim, ks.type, ks.p, ks.h, ks.lambda};
     double tk0 = now();
-    std::vector<int> ann((size_t)k * N);
+    // Column sets on the DEVICE (hssk_colsets: sorted unions through an LDS bitmap) when nothing on the host needs them: the
+    // kernel function is one of the library's (a user-defined one is evaluated on the host, with host index lists), the
+    // tree is not shared between processes (the cut nodes' sets travel through the host), the point set fits the bitmap.
+    // The neighbour lists then stay on the device (25.6 MB at N = 1e5, k = 64) and only the SIZES of the sets come back,
+    // one word per node and level; on the host the sets took 5-7 ms of the 102 ms step, most of it the index upload of
+    // every level.  STRUMPACK_AMD_KERNEL_HOST_SETS=1: the host form.
+    static const bool host_sets_env = [] { const char* e = std::getenv("STRUMPACK_AMD_KERNEL_HOST_SETS"); return e && e[0] == '1'; }();
+    const bool dev_sets = !host_sets_env && !ks.eval && !dist_subtree_ && o_.world == 1 && (long long)N <= hssk_colsets_max_universe();
+    int* dann = nullptr;
+    std::vector<int> ann(dev_sets && !user_ann && !ks.neighbors ? 0 : (size_t)k * N);
     if (user_ann && k == user_k) std::copy(user_ann, user_ann + (size_t)k * N, ann.begin());
     else if (ks.neighbors) ks.neighbors(k, ann.data());
     else {
       // one process per GPU: neighbours of this rank's own points only (its subtree's leaves are all that read them)
       int q0 = 0, q1 = N;
       if (dist_subtree_) { const Node& c = nodes_[cut_nodes_[o_.rank]]; q0 = c.lo; q1 = c.lo + c.m; }
-      int* dann = work_->ints((size_t)k * N);
+      dann = work_->ints((size_t)k * N);
       // (the search kernel on the device clock: bench.py --workload kernel reports it against the FP32 vector roof --
       //  3 flops per coordinate and candidate: subtract, multiply, add)
       ck(hssk_watch_start(ctx_, 7));
@@ -47,15 +56,22 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         stats_.sketch_kernel_flops += 3.0 * dim * (double)N * (double)(q1 - q0);
         stats_.sketch_launches += pairs;
       }
-      ck(hssk_memcpy_d2h(ctx_, ann.data() + (size_t)k * q0, dann + (size_t)k * q0, (long long)sizeof(int) * k * (q1 - q0)));
+      if (!dev_sets) ck(hssk_memcpy_d2h(ctx_, ann.data() + (size_t)k * q0, dann + (size_t)k * q0, (long long)sizeof(int) * k * (q1 - q0)));
     }
     if ((user_ann && k == user_k) || ks.neighbors) {
       // lists that come from the caller index the bitmaps below: an id outside [0, N) must not reach them (negative = no neighbour)
       for (size_t q = 0; q < ann.size(); q++)
         if (ann[q] >= N) throw std::invalid_argument("compress_kernel: neighbour id " + std::to_string(ann[q]) + " is not a point (n = " + std::to_string(N) + ")");
     }
+    if (dev_sets && !dann) {   // lists from the caller: to the device once
+      dann = work_->ints((size_t)k * N);
+      ck(hssk_memcpy_h2d(ctx_, dann, ann.data(), (long long)sizeof(int) * k * N));
+    }
     stats_.t_random += now() - tk0;   // neighbour search (reported in the 'random' slot: it replaces the random sketch)
-    std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node
+    std::vector<std::vector<int>> cols(nodes_.size());   // per node: sorted unique column ids outside the node (host form)
+    std::vector<int*> dcols(dev_sets ? nodes_.size() : 0, nullptr);   // device form: the sets and their sizes
+    std::vector<int> dcnt(dev_sets ? nodes_.size() : 0, 0);
+    auto set_size = [&](int id) { return dev_sets ? dcnt[id] : (int)cols[id].size(); };
     bool failed = false;
     auto do_level = [&](const std::vector<int>& ids) {
       if (ids.empty() || failed) return;
@@ -74,7 +90,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
           nd.mU = nd.mV = nd.m;
           rows[q].resize(nd.m);
           for (int i = 0; i < nd.m; i++) rows[q][i] = lo + i;
-          if (nd.lvl > 0) {
+          if (nd.lvl > 0 && !dev_sets) {
             // sorted, duplicate-free ids outside the node: marked in a bitmap over the point set and read back in order
             // (m k ~ 1e4 ids per leaf: cheaper than sorting them)
             std::vector<unsigned long long> bits(((size_t)N + 63) / 64, 0ULL);
@@ -103,7 +119,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
           nd.mU = nd.mV = a.rU + b.rU;
           rows[q] = a.Ir;
           rows[q].insert(rows[q].end(), b.Ir.begin(), b.Ir.end());
-          if (nd.lvl > 0) {
+          if (nd.lvl > 0 && !dev_sets) {
             // union of the children's (sorted, duplicate-free) sets without the ids inside this node
             const std::vector<int>&ca = cols[nd.c0], &cb = cols[nd.c1];
             cs.reserve(ca.size() + cb.size());
@@ -132,6 +148,29 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         }
       int* didx = tmp_->ints(std::max<size_t>(hidx.size(), 1));
       if (!hidx.empty()) ck(hssk_memcpy_h2d(ctx_, didx, hidx.data(), (long long)sizeof(int) * hidx.size()));
+      if (dev_sets) {
+        // the level's sets in one launch (a workgroup per node); their sizes come back in one read
+        std::vector<hssk_colset_desc> cd;
+        std::vector<int> cq;
+        int* dc = tmp_->ints(ids.size());
+        for (size_t q = 0; q < ids.size(); q++) {
+          const Node& nd = nodes_[ids[q]];
+          if (nd.lvl == 0) continue;
+          hssk_colset_desc c{};
+          if (nd.leaf()) { c.src0 = dann + (size_t)nd.lo * k; c.n0 = nd.m * k; }
+          else { c.src0 = dcols[nd.c0]; c.n0 = dcnt[nd.c0]; c.src1 = dcols[nd.c1]; c.n1 = dcnt[nd.c1]; }
+          c.lo = nd.lo; c.hi = nd.lo + nd.m;
+          c.out = dcols[ids[q]] = work_->ints((size_t)std::max(c.n0 + c.n1, 1));
+          c.count = dc + q;
+          cd.push_back(c); cq.push_back((int)q);
+        }
+        if (!cd.empty()) {
+          ck(hssk_colsets(ctx_, cd.data(), (int)cd.size(), N));
+          std::vector<int> hc(ids.size(), 0);
+          ck(hssk_memcpy_d2h(ctx_, hc.data(), dc, (long long)sizeof(int) * ids.size()));
+          for (int q : cq) dcnt[ids[q]] = hc[q];
+        }
+      }
       stats_.t_sketch += now() - tl0;   // host column-set construction (the 'sketch' slot of this path)
       // ---- D (leaves), B01 / B10 (inner nodes), sample panels W = K(cols, rows)  [= S^T]
       std::vector<hssk_keval_desc> ev;
@@ -158,13 +197,13 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
           }
         }
         if (nd.lvl == 0) { nd.Ustate = nd.Vstate = 2; continue; }
-        const int m = nd.mU, d = (int)cols[ids[q]].size();
+        const int m = nd.mU, d = set_size(ids[q]);
         idn.push_back(ids[q]); which.push_back(0); ds.push_back(d);
         double* W = (m > 0 && d > 0) ? tmp_->dbl((size_t)d * m) : nullptr;
         Ws.push_back(W);
         if (W) {
-          ev.push_back(hssk_keval_desc{didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
-          hev.push_back(HostEv{hidx.data() + coff[q], hidx.data() + roff[q]});
+          ev.push_back(hssk_keval_desc{dev_sets ? dcols[ids[q]] : didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
+          hev.push_back(HostEv{hidx.data() + coff[q], hidx.data() + roff[q]});   // (read by the host evaluation only: never with device sets)
         }
       }
       if (!ev.empty() && ks.eval) {
@@ -201,7 +240,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       for (size_t q = 0; q < idn.size(); q++) {
         Node& nd = nodes_[idn[q]];
         nd.rV = nd.rU; nd.XV = nd.XU; nd.permV = nd.permU; nd.hpermV = nd.hpermU; nd.Ic = nd.Ir; nd.dIc = nd.dIr; nd.Vstate = nd.Ustate;
-        const int d = (int)cols[idn[q]].size();
+        const int d = set_size(idn[q]);
         if (!(d >= nd.m || d >= o_.max_rank || nd.rU + o_.p < d)) failed = true;
       }
     };

@@ -386,6 +386,72 @@ extern "C" int hssk_kernel_eval_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* 
   HSSK_API_END
 }
 
+// ---- column sets: sorted unions through a bitmap in the LDS (hssk_colsets) ----------------------------------------
+namespace {
+constexpr int CS_T = 1024;
+__global__ __launch_bounds__(CS_T) void colset_kernel(const hssk_colset_desc* __restrict__ descs, int words) {
+  HSSK_DYN_SHARED(unsigned, cs_lds);
+  unsigned* bits = cs_lds;                 // [words]
+  int* base = (int*)(cs_lds + words);      // [CS_T + 1]: ids before each thread's stretch of the bitmap
+  const hssk_colset_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int w = tid; w < words; w += CS_T) bits[w] = 0u;
+  __syncthreads();
+  for (int s = 0; s < 2; s++) {
+    const int* src = s ? p.src1 : p.src0;
+    const int n = s ? p.n1 : p.n0;
+    if (!src) continue;
+    for (int e = tid; e < n; e += CS_T) {
+      const int g = src[e];
+      if (g >= 0 && (g < p.lo || g >= p.hi)) hssk_lds_or(&bits[g >> 5], 1u << (g & 31));
+    }
+  }
+  __syncthreads();
+  // every thread a contiguous stretch of words: count, exclusive scan over the threads, write in order
+  const int per = (words + CS_T - 1) / CS_T, w0 = min(words, tid * per), w1 = min(words, w0 + per);
+  int cnt = 0;
+  for (int w = w0; w < w1; w++) cnt += __builtin_popcount(bits[w]);
+  base[tid + 1] = cnt;
+  if (tid == 0) base[0] = 0;
+  __syncthreads();
+  // (inclusive scan, Hillis-Steele over CS_T + 1 entries; the slots are re-read after a barrier each round)
+  for (int off = 1; off <= CS_T; off <<= 1) {
+    const int add = tid + 1 >= off ? base[tid + 1 - off] : 0;
+    __syncthreads();
+    base[tid + 1] += add;
+    __syncthreads();
+  }
+  int o = base[tid];
+  for (int w = w0; w < w1; w++) {
+    unsigned b = bits[w];
+    while (b) {
+      const int t = __builtin_ctz(b);
+      p.out[o++] = (w << 5) + t;
+      b &= b - 1;
+    }
+  }
+  if (tid == CS_T - 1) *p.count = base[CS_T];
+}
+}  // namespace
+
+extern "C" long long hssk_colsets_max_universe(void) {
+  const size_t cap = hssk_rt::max_lds_per_workgroup(), fixed = sizeof(int) * (CS_T + 1);
+  return cap > fixed ? (long long)((cap - fixed) / sizeof(unsigned)) * 32 : 0;
+}
+extern "C" int hssk_colsets(hssk_ctx* ctx, const hssk_colset_desc* descs, int count, int universe) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  if (universe <= 0) throw std::invalid_argument("hssk_colsets: empty universe");
+  const int words = (universe + 31) / 32;
+  const size_t shm = sizeof(unsigned) * (size_t)words + sizeof(int) * (CS_T + 1);
+  if (shm > hssk_rt::max_lds_per_workgroup()) HSSK_UNSUPPORTED("column sets over more ids than the LDS has bits");
+  auto* dd = (const hssk_colset_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  hssk_rt::allow_dynamic_lds(colset_kernel, shm);
+  HSSK_LAUNCH(colset_kernel, dim3((unsigned)count), dim3(CS_T), shm, ctx->stream, dd, words);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
 extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx) {
   HSSK_API_BEGIN
   if (n <= 0 || k <= 0 || q1 <= q0) return 0;

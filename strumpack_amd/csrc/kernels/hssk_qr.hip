@@ -1103,7 +1103,9 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
   }
   // register-resident kernels when the largest panel of the batch fits (rows <= 16 RT, cols <= 4 NW CT; the register
   // tiles of the widest variants, 13 x 7 and 16 x 6 doubles per lane, need the 256 VGPRs of an 8-wave workgroup)
-  if (force_blocked() || rmax > 256 || cmax > 224 || (rmax > 208 && cmax > 192)) {
+  // (HSSK_QR_BLOCKED_ROWS: batches whose tallest panel has at least that many rows, and 96 columns, take the blocked path too)
+  static const int blk_rows = [] { const char* e = std::getenv("HSSK_QR_BLOCKED_ROWS"); return e ? std::atoi(e) : 1 << 30; }();
+  if (force_blocked() || rmax > 256 || cmax > 224 || (rmax > 208 && cmax > 192) || (rmax >= blk_rows && cmax >= 96 && wy_usable(rmax))) {
     qr_blocked(ctx, descs, count, true);
     hssk_rt::check_launch();
     return 0;
@@ -1117,11 +1119,13 @@ extern "C" int hssk_qr_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int co
   else if (cmax <= 160) launch_qr_reg<13, 5, 8>(ctx, dd, count);   // (a step costs per column slot: the 195 x ~160 ULV panels of N = 1e5 need five or
   else if (cmax <= 192) launch_qr_reg<13, 6, 8>(ctx, dd, count);   //  six, not seven)
   else launch_qr_reg<13, 7, 8>(ctx, dd, count);
-  // Q is then formed by a second, barrier-free launch over blocks of 64 columns -- or, for the taller panels, from the compact-WY
-  // pairs of 32 reflectors each on the matrix cores (qr_blocked with the factorization skipped: the T factors of all panels in
-  // one launch, then the fused block reflector over the groups of panels; the 512 panels 196 x 155 of the ULV leaves at N =
-  // 1e5: formq_reg 0.70 ms).  HSSK_QR_FORMQ_WY=0: the register form for everything up to 256 rows.
-  static const bool q_wy = [] { const char* e = std::getenv("HSSK_QR_FORMQ_WY"); return !(e && e[0] == '0'); }();
+  // Q is then formed by a second, barrier-free launch over blocks of 64 columns.  HSSK_QR_FORMQ_WY=1: for the taller panels
+  // from the compact-WY pairs of 32 reflectors each on the matrix cores instead (qr_blocked with the factorization skipped:
+  // the T factors of all panels in one launch, then the fused block reflector over the groups of panels) -- measured SLOWER
+  // on the 512 panels 196 x 155 of the ULV leaves at N = 1e5 (T factors 0.28 ms + two launches 0.57 ms against 0.70 ms of
+  // formq_reg; factor phase 2.81 against 2.55 ms, gpurun_out/r04q), as is the whole blocked path from 128 rows on
+  // (HSSK_QR_BLOCKED_ROWS=128: factor 3.37, tree 4.53 against 2.85 ms): off.
+  static const bool q_wy = [] { const char* e = std::getenv("HSSK_QR_FORMQ_WY"); return e && e[0] == '1'; }();
   if (qmax > 0) {
     if (q_wy && rmax >= 128 && cmax >= 64 && wy_usable(rmax)) qr_blocked(ctx, descs, count, false);
     else formq_reg(ctx, dd, descs, count, rmax);
@@ -1144,7 +1148,7 @@ extern "C" int hssk_formq_vbatched(hssk_ctx* ctx, const hssk_qr_desc* descs, int
   if (force_blocked() || rmax > 256) {
     qr_blocked(ctx, descs, count, false);
   } else {
-    static const bool q_wy = [] { const char* e = std::getenv("HSSK_QR_FORMQ_WY"); return !(e && e[0] == '0'); }();
+    static const bool q_wy = [] { const char* e = std::getenv("HSSK_QR_FORMQ_WY"); return e && e[0] == '1'; }();
     if (q_wy && rmax >= 128 && cmax >= 64 && wy_usable(rmax)) qr_blocked(ctx, descs, count, false);
     else {
       auto* dd = (const hssk_qr_desc*)ctx->stage(descs, sizeof(*descs) * count);

@@ -34,6 +34,11 @@ class KevalDesc(C.Structure):
                 ("nr", C.c_int), ("nc", C.c_int), ("ldo", C.c_int), ("r0", C.c_int), ("c0", C.c_int)]
 
 
+class ColsetDesc(C.Structure):
+    _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("n0", C.c_int), ("n1", C.c_int), ("lo", C.c_int), ("hi", C.c_int),
+                ("out", C.c_void_p), ("count", C.c_void_p)]
+
+
 class ColGatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p),
                 ("rows", C.c_int), ("ncols", C.c_int), ("lds", C.c_int), ("ldd", C.c_int),
@@ -139,7 +144,7 @@ HSSK_SYMBOLS = [
     "hssk_kernel_eval_vbatched", "hssk_knn", "hssk_kernel_predict", "hssk_copy_triu",
     "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_h2d_bytes_async", "hssk_expand_image", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
-    "hssk_sketch_gen", "hssk_gen_elems", "hssk_gen_fill",
+    "hssk_sketch_gen", "hssk_gen_elems", "hssk_gen_fill", "hssk_colsets", "hssk_colsets_max_universe",
 ]
 
 
@@ -247,6 +252,9 @@ class Hssk:
         L.hssk_kernel_eval_vbatched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hssk_kernel_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.hssk_colsets.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.hssk_colsets_max_universe.argtypes = []
+        L.hssk_colsets_max_universe.restype = C.c_longlong
         L.hssk_sjlt_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
         L.hssk_sjlt_sketch.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_longlong,
                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong]

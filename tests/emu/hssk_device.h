@@ -122,6 +122,7 @@ template <int N> inline void hssk_wait_glds() {}
 inline void hssk_wg_barrier() { emu::block_barrier(); }
 inline int hssk_opaque(int v) { return v; }
 inline void hssk_lds_add(double* p, double v) { *p += v; }   // fibers are cooperative: a plain update is atomic
+inline void hssk_lds_or(unsigned* p, unsigned v) { *p |= v; }
 inline int hssk_lds_inc(int* p) { return (*p)++; }
 inline int hssk_uniform(int v) { return v; }
 // compile-time only: memory operations are not moved across this point

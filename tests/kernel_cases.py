@@ -875,3 +875,40 @@ def case_gen_elems(hk, seed=4):
         assert np.array_equal(dB.get()[:37], T[np.ix_(I, J)])
         assert np.array_equal(dBt.get(), T[np.ix_(I, J)].T)
         assert np.array_equal(dD.get(), T[100:150, 120:170])
+
+
+def case_colsets(hk, universe=5000, seed=81):
+    """hssk_colsets vs numpy: sorted unique ids of one or two lists, ids inside [lo, hi) and negative ones dropped; leaf form
+    (a k x m block of neighbour ids) and inner form (two sorted sets); empty results; the count word."""
+    r = np.random.default_rng(seed)
+    cases = []
+    ann = r.integers(-1, universe, size=(64 * 300,)).astype(np.int32)          # a leaf of 300 points, 64 neighbours each
+    cases.append((ann, None, 1200, 1500))
+    a = np.unique(r.integers(0, universe, 4000)).astype(np.int32)
+    b = np.unique(r.integers(0, universe, 2500)).astype(np.int32)
+    cases.append((a, b, 1000, 1900))
+    cases.append((a[:7], b[:1], 0, 0))
+    cases.append((np.arange(10, 20, dtype=np.int32), None, 10, 20))           # everything inside: empty
+    cases.append((np.array([universe - 1, 0, universe - 1, 31, 32, 33], dtype=np.int32), np.array([0, 63, 64], dtype=np.int32), 5, 6))
+    descs, keep = [], []
+    for s0, s1, lo, hi in cases:
+        d0 = hk.array(s0)
+        d1 = hk.array(s1) if s1 is not None else None
+        out = hk.array(np.full(len(s0) + (len(s1) if s1 is not None else 0) + 1, -7, dtype=np.int32))
+        cnt = hk.array(np.full(1, -3, dtype=np.int32))
+        keep.append((d0, d1, out, cnt))
+        descs.append(K.ColsetDesc(d0.ptr, d1.ptr if d1 is not None else None, len(s0), len(s1) if s1 is not None else 0, lo, hi, out.ptr, cnt.ptr))
+    arr = (K.ColsetDesc * len(descs))(*descs)
+    hk.check(hk.lib.hssk_colsets(hk.ctx, arr, len(descs), universe))
+    hk.sync()
+    for (s0, s1, lo, hi), (d0, d1, out, cnt) in zip(cases, keep):
+        allv = np.concatenate([s0, s1]) if s1 is not None else s0
+        ref = np.unique(allv[(allv >= 0) & ((allv < lo) | (allv >= hi))])
+        c = int(cnt.get()[0])
+        got = out.get()
+        assert c == len(ref), (c, len(ref))
+        assert np.array_equal(got[:c], ref)
+        assert np.all(got[c:] == -7)
+    # a universe beyond the LDS bitmap is refused, not mis-answered
+    assert hk.lib.hssk_colsets(hk.ctx, arr, 1, 40_000_000) == 2
+

@@ -228,3 +228,9 @@ def test_expand_image(hk):
 
 def test_upload_two_threads(hk):
     KC.case_upload_two_threads(hk)
+
+
+def test_colsets(hk):
+    KC.case_colsets(hk)
+    KC.case_colsets(hk, universe=100000, seed=82)
+
