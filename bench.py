@@ -131,11 +131,22 @@ def kernel_workload(a, torch, dist, world, rank, local):
     # units, 3 flops per coordinate and candidate), HIP events on the engine's stream around its launches (hssk_watch_*)
     if st["sketch_launches"] > 0 and st["sketch_kernel_ms"] > 0:
         ach = st["sketch_kernel_flops"] / (st["sketch_kernel_ms"] * 1e-3) * 1e-12
-        out["roofline"] = {"kernel": "knn_kernel (exact %d nearest neighbours of every point, FP32 distances)" % int(st["d_final"]), "bound": "valu_fp32",
-                           "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+        out["roofline"] = {"kernel": "knn_kernel (exact %d nearest neighbours of every point; differences and squares in FP64 on the vector units, keys rounded to FP32)" % int(st["d_final"]),
+                           "bound": "valu_fp64", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
                            "avg_launch_ms": st["sketch_kernel_ms"] / st["sketch_launches"], "launches_per_step": int(st["sketch_launches"]),
                            "flops_per_launch": st["sketch_kernel_flops"] / st["sketch_launches"],
                            "note": "3 d N^2 flops per search; the kernel is bound by its per-query top-k heaps in LDS (profiles/r02_pmc_knn.md), not by the distance arithmetic"}
+    # dominant PHASE of the step: the row IDs of the sampled blocks -- TSQR of the d x m panels in the register QR kernels
+    # (chunk QRs, then pairwise merges of triangles), the truncated QRCP of the m x m triangles, the kernel evaluations;
+    # flops counted by the engine (Householder counts of the chunks and merges + the ID's), time = the phase on the host clock
+    if st["t_tree"] > 0:
+        fl = st["f_ortho"] + st["f_id"]
+        ach = fl / st["t_tree"] * 1e-12
+        out["phase_roofline"] = {"phase": "blocks + ID (hssk_kernel_eval_vbatched, qr_reg_kernel / tpqr_reg_kernel, id_reg_kernel)", "bound": "valu_fp64",
+                                 "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "ms": st["t_tree"] * 1e3,
+                                 "flops": {"tsqr": st["f_ortho"], "id": st["f_id"]},
+                                 "note": "Level-2 Householder steps on register-resident panels: a step is a reduction, a broadcast and a rank-1 update of ALL "
+                                         "column slots of the tile (the tile does not shrink with the step), one barrier per step"}
     if rank == 0:
         print(json.dumps(out))
     H.destroy()

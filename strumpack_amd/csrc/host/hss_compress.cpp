@@ -533,6 +533,10 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
       double* wk = tmp.dbl((size_t)cr + m);
       qr.push_back(hssk_qr_desc{Ws[k] + r0, d, cr, m, nullptr, 0, 0, nullptr, wk, 0, 0., 0., 1});   // (only R is read again)
       pieces[k].push_back(Piece{Ws[k] + r0, d, std::min(cr, m)});
+      {   // Householder QR of a cr x m chunk, R only: 2 cr m^2 - (2/3) m^3 (cr >= m), 2 m cr^2 - (2/3) cr^3 otherwise
+        const double a_ = std::max(cr, m), b_ = std::min(cr, m);
+        stats_.f_ortho += 2.0 * a_ * b_ * b_ - 2.0 / 3.0 * b_ * b_ * b_;
+      }
     }
     any = true;
   }
@@ -565,6 +569,7 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
         if (cntp == 2 && full && m <= 224 && !pairs_off && tsqr_staircase()) {
           tp.push_back(hssk_tpqr_desc{pc[i].p, pc[i].ld, pc[i + 1].p, pc[i + 1].ld, m});
           next.push_back(pc[i]);
+          stats_.f_ortho += 2.0 / 3.0 * (double)m * m * m;   // structured QR of two stacked triangles
           continue;
         }
         double* dst = tmp.dbl((size_t)rows * m);
@@ -580,6 +585,10 @@ void DeviceHSS::tsqr_reduce(const std::vector<int>& ids, const std::vector<int>&
         double* wk = tmp.dbl((size_t)rows + m);
         qr.push_back(hssk_qr_desc{dst, rows, rows, m, nullptr, 0, 0, nullptr, wk, stair ? (int)cntp : 0, 0., 0., 1});
         next.push_back(Piece{dst, rows, std::min(rows, m)});
+        {   // (counted as the dense QR of the stack; the staircase sweep does about a third of it)
+          const double a_ = std::max(rows, m), b_ = std::min(rows, m);
+          stats_.f_ortho += (2.0 * a_ * b_ * b_ - 2.0 / 3.0 * b_ * b_ * b_) * (stair ? 1.0 / 3.0 : 1.0);
+        }
       }
       pc.swap(next);
       more = more || pc.size() > 1;

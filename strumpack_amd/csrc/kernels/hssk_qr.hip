@@ -377,8 +377,12 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void tpqr_reg_
       double* sv = s_v + (k & 1) * 16 * RT;
       const double alpha = alpha_next;
       const double* st = s_t + (k & 1) * NC * CT;
-      const double trow = (k + 1 < m && tid > k && tid < m) ? hssk_gload(R1, (size_t)(k + 1) + (size_t)tid * p.ld1) : 0.;   // row k + 1, for the next step
-      alpha_next = k + 1 < m ? hssk_gload(R1, (size_t)(k + 1) + (size_t)(k + 1) * p.ld1) : 0.;
+      // row k + 1, for the next step.  UNCONDITIONAL loads from clamped addresses (entries at or left of the diagonal are never
+      // read back): under conditions of their own the compiler cannot count them, and the owner wave's wait for R1(k, k) --
+      // fetched a step ago -- became a wait for everything in flight, the row just asked for included: an L2 round trip per step
+      const int kn = min(k + 1, m - 1);
+      const double trow = hssk_gload(R1, (size_t)kn + (size_t)min(tid, m - 1) * p.ld1);
+      alpha_next = hssk_gload(R1, (size_t)kn + (size_t)kn * p.ld1);
       if (wave == kw) {
         // reflector from [R1(k, k); R2(0:k, k)]
         double s = 0.;

@@ -483,33 +483,50 @@ __global__ __launch_bounds__(T) void getrf_wg2_kernel(const hssk_lu_desc* __rest
           if (i < nb) { s_U[i + c * LU_] = u[i]; hssk_gstore(A, (size_t)(j0 + i) + (size_t)(c0 + c) * lda, u[i]); }
       }
       __syncthreads();
-      // A22(:, c0 .. c0+nc) -= L21 U12 on the matrix cores (transposed accumulator, see above)
+      // A22(:, c0 .. c0+nc) -= L21 U12 on the matrix cores (transposed accumulator, see above).  The tiles of a wave in one
+      // sequence, the NEXT tile's entries of A22 loaded (unconditionally, from clamped addresses: masked at the store) while
+      // the current one is multiplied: with the loads under their own conditions right in front of the products every tile
+      // waited out an L2 round trip -- 25 to 50 tiles per wave and panel.
       if (rws > 0) {
         const int y = lane & 15, kq = lane >> 4;
         const int nrt = (rws + 15) / 16, nct = (nc + 15) / 16;
-        for (int ti = wave; ti < nrt; ti += NW) {
+        const int ntw = wave < nrt ? ((nrt - wave + NW - 1) / NW) * nct : 0;
+        auto load_tile = [&](int t, hssk_d4& v) {
+          const int ti = wave + NW * (t / nct), tj = t % nct;
+          const int rowc = min(ti * 16 + y, rws - 1);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int colc = min(tj * 16 + kq + 4 * r, nc - 1);
+            v[r] = hssk_gload(A, (size_t)(jend + rowc) + (size_t)(c0 + colc) * lda);
+          }
+        };
+        hssk_d4 nxt = {0., 0., 0., 0.};
+        if (ntw) load_tile(0, nxt);
+        // (the LDS operands beyond the panel's columns: read from a clamped index and multiplied by zero -- a select on the
+        // read value puts every read under a branch of its own, with a full wait behind it)
+        double bl[LUW_NB / 4], mk[LUW_NB / 4];
+        int kc[LUW_NB / 4];
+#pragma unroll
+        for (int kk = 0; kk < LUW_NB / 4; kk++) { mk[kk] = kq + 4 * kk < nb ? 1. : 0.; kc[kk] = min(kq + 4 * kk, nb - 1); }
+        for (int t = 0; t < ntw; t++) {
+          const int ti = wave + NW * (t / nct), tj = t % nct;
           const int row = ti * 16 + y, rowc = min(row, rws - 1);
-          double bl[LUW_NB / 4];
+          if (tj == 0) {
 #pragma unroll
-          for (int kk = 0; kk < LUW_NB / 4; kk++) bl[kk] = kq + 4 * kk < nb ? s_P[(nb + rowc) + (kq + 4 * kk) * LP] : 0.;
-          for (int tj = 0; tj < nct; tj++) {
-            const int xc = min(tj * 16 + y, nc - 1);
-            hssk_d4 acc;
+            for (int kk = 0; kk < LUW_NB / 4; kk++) bl[kk] = s_P[(nb + rowc) + kc[kk] * LP] * mk[kk];
+          }
+          hssk_d4 acc = nxt;
+          load_tile(min(t + 1, ntw - 1), nxt);
+          const int xc = min(tj * 16 + y, nc - 1);
+          double au[LUW_NB / 4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int col = tj * 16 + kq + 4 * r;
-              acc[r] = (row < rws && col < nc) ? hssk_gload(A, (size_t)(jend + row) + (size_t)(c0 + col) * lda) : 0.;
-            }
+          for (int kk = 0; kk < LUW_NB / 4; kk++) au[kk] = -s_U[kc[kk] + xc * LU_];   // (bl carries the mask)
 #pragma unroll
-            for (int kk = 0; kk < LUW_NB / 4; kk++) {
-              const double au = kq + 4 * kk < nb ? -s_U[(kq + 4 * kk) + xc * LU_] : 0.;
-              acc = hssk_mfma_f64_16x16x4(au, bl[kk], acc);
-            }
+          for (int kk = 0; kk < LUW_NB / 4; kk++) acc = hssk_mfma_f64_16x16x4(au[kk], bl[kk], acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int col = tj * 16 + kq + 4 * r;
-              if (row < rws && col < nc) hssk_gstore(A, (size_t)(jend + row) + (size_t)(c0 + col) * lda, acc[r]);
-            }
+          for (int r = 0; r < 4; r++) {
+            const int col = tj * 16 + kq + 4 * r;
+            if (row < rws && col < nc) hssk_gstore(A, (size_t)(jend + row) + (size_t)(c0 + col) * lda, acc[r]);
           }
         }
       }
