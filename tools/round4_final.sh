@@ -12,6 +12,19 @@ cp $out/kt/kt_kernel_stats.csv $out/kernel_stats_bench_n100k.csv 2>/dev/null
 [ -f $out/kt/trace_tail.txt ] && cp $out/kt/trace_tail.txt $out/trace_tail.txt
 rm -rf $out/kt
 cd /root/repo
+unset STRUMPACK_AMD_BENCH_NO_PMC
+# secondary lines of the round (no counter passes, no CPU baseline)
+for cfg in "kernel:--workload kernel --steps 4" "leaf512:--leaf 512" "nrhs64:--nrhs 64" "generated:--operand generated" "symmetric:--symmetric"; do
+  STRUMPACK_AMD_BENCH_NO_PMC=1 timeout 300 python bench.py --no-cpu-baseline ${cfg#*:} > $out/bench_${cfg%%:*}_n1.json 2> $out/bench_${cfg%%:*}.err; echo "${cfg%%:*} rc=$?"
+done
+python - $out <<'PY'
+import json,sys,glob
+for f in sorted(glob.glob(sys.argv[1]+"/bench_*_n1.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], "ms %.2f"%d["ms_per_step"], {k:round(v*1e3,3) for k,v in d.get("phases_s",{}).items()}, (d.get("phase_roofline") or {}).get("frac"), (d.get("sweeps") or {}))
+    except Exception as e: print(f, "failed", e)
+PY
 python - $out/bench_n1.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
