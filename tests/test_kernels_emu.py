@@ -147,7 +147,7 @@ def test_qr(hk):
     KC.case_qr(hk, [(195, 128, 128)], seed=9)                       # <4,8,16>
     KC.case_qr(hk, [(195, 160, 195), (130, 100, 130)], seed=10)     # <4,26,8>
     KC.case_qr(hk, [(300, 40, 300), (260, 250, 260), (390, 350, 390), (300, 60, 0), (280, 300, 200)], seed=11)   # blocked (compact WY + batched GEMM)
-    KC.case_qr(hk, [(512, 472, 512), (500, 330, 200), (300, 420, 300)], seed=13)   # panel groups: several groups, a ragged last one, thin Q, columns beyond the last panel
+    KC.case_qr(hk, [(512, 472, 512), (500, 330, 200), (300, 420, 300), (511, 470, 511)], seed=13)   # panel groups: several groups, a ragged last one, thin Q, columns beyond the last panel, odd row counts (unaligned 16-byte loads)
     KC.case_qr(hk, [(600, 20, 30), (700, 90, 100), (530, 70, 0)], seed=12)   # tall blocked path (GEMM-assembled compact WY)
 
 

@@ -145,7 +145,7 @@ def test_qr(hk):
     KC.case_qr(hk, [(40, 12, 12), (30, 30, 30), (33, 20, 33), (10, 1, 10), (70, 10, 0)])
     KC.case_qr(hk, [(390, 350, 390), (390, 128, 128), (256, 240, 256), (54, 24, 54)] * 2, seed=23)
     KC.case_qr(hk, [(1400, 600, 1400), (900, 300, 0), (2100, 130, 130)], seed=24)     # tall blocked path
-    KC.case_qr(hk, [(512, 472, 512), (500, 330, 200), (300, 420, 300), (512, 512, 512)] * 3, seed=26)   # panel groups of the fused block reflector
+    KC.case_qr(hk, [(512, 472, 512), (500, 330, 200), (300, 420, 300), (512, 512, 512), (511, 470, 511), (391, 350, 391)] * 3, seed=26)   # panel groups of the fused block reflector
     KC.case_qr(hk, [(195, 159, 195), (208, 160, 0), (200, 180, 200), (196, 161, 196)], seed=25)   # five- and seven-slot register variants
 
 
