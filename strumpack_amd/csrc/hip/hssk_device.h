@@ -92,6 +92,21 @@ __device__ __forceinline__ double hssk_bcast_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int hssk_bcast_lane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// first arg max over the 64 lanes of the wave, same rule; every lane ends up with the result.  The rows on the DPP network,
+// the four row results through SGPRs (v_readlane): no LDS crossbar.  (The pivot searches of the LU / QRCP kernels ran six
+// stages of three ds_bpermute each per elimination step -- eighteen dependent round trips through the LDS pipeline.)
+__device__ __forceinline__ void hssk_wave_argmax(double& v, int& idx) {
+  hssk_row_argmax(v, idx);
+  double bv = hssk_bcast_lane(v, 0);
+  int bi = hssk_bcast_lane_i(idx, 0);
+#pragma unroll
+  for (int r = 1; r < 4; r++) {
+    const double ov = hssk_bcast_lane(v, 16 * r);
+    const int oi = hssk_bcast_lane_i(idx, 16 * r);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  v = bv; idx = bi;
+}
 // non-zero if `pred` holds in any lane of the wave
 __device__ __forceinline__ int hssk_any(int pred) { return __any(pred); }
 __device__ __forceinline__ double hssk_wave_max(double v) {

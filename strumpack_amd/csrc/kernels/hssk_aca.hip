@@ -26,12 +26,7 @@ struct ArgMax { double v; int i; };
 // the largest v, smallest index among equals (std::max_element); all threads of the workgroup call, all get the result
 __device__ __forceinline__ ArgMax block_argmax(double v, int i, double* s_v, int* s_i) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = hssk_shfl_xor(v, o);
-    const int oi = hssk_shfl_xor(i, o);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
+  hssk_wave_argmax(v, i);
   if (lane == 0) { s_v[wave] = v; s_i[wave] = i; }
   __syncthreads();
   ArgMax r{s_v[0], s_i[0]};

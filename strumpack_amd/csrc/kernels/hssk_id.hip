@@ -65,12 +65,7 @@ __global__ __launch_bounds__(ID_THREADS) void id_kernel(const hssk_id_desc* __re
       double v = vn1[j];
       if (v > bv) { bv = v; bi = j; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      double ov = hssk_shfl_xor(bv, o);
-      int oi = hssk_shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    hssk_wave_argmax(bv, bi);
     if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
@@ -241,12 +236,7 @@ __global__ __launch_bounds__(IDS_T) void id_stream_kernel(const hssk_id_desc* __
         const double v = s_vn1[j];
         if (v > bv) { bv = v; bi = j; }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = hssk_shfl_xor(bv, o);
-        const int oi = hssk_shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
+      hssk_wave_argmax(bv, bi);
       const int pv = bi;
       // ---- 2. swap columns k <-> pv (the new column k stays in registers for the reflector)
       double ck[RL], cp[RL];
@@ -1159,12 +1149,7 @@ __global__ __launch_bounds__(256) void idw_pivot_kernel(const hssk_id_desc* __re
     const double v = vn1[j];
     if (v > bv) { bv = v; bi = j; }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = hssk_shfl_xor(bv, o);
-    const int oi = hssk_shfl_xor(bi, o);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
+  hssk_wave_argmax(bv, bi);
   if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
   __syncthreads();
   if (tid == 0) {

@@ -77,7 +77,7 @@ constexpr int LU_THREADS = 256;
 // wait on LDS instead of L2: the 82 x 82 root of N = 1e5 took 167 us in global memory).
 __device__ __forceinline__ int getrf_body(double* __restrict__ A, int ld, int n, int* __restrict__ piv, double* s_val, int* s_idx, int* s_piv) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int info = 0;
+  int info = 0, mypiv = 0;
   for (int k = 0; k < n; k++) {
     // pivot: first arg max_{i >= k} |A(i, k)|
     double bv = -1.;
@@ -86,12 +86,7 @@ __device__ __forceinline__ int getrf_body(double* __restrict__ A, int ld, int n,
       double v = fabs(A[i + (size_t)k * ld]);
       if (v > bv) { bv = v; bi = i; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      double ov = hssk_shfl_xor(bv, o);
-      int oi = hssk_shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    hssk_wave_argmax(bv, bi);
     if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
@@ -100,10 +95,15 @@ __device__ __forceinline__ int getrf_body(double* __restrict__ A, int ld, int n,
       for (int w = 1; w < LU_THREADS / 64; w++)
         if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
       *s_piv = ix;
-      piv[k] = ix;
     }
     __syncthreads();
     const int pv = *s_piv;
+    // (the pivots go to global memory a workgroup's worth at a time: thread k % LU_THREADS keeps step k's)
+    if (tid == k % LU_THREADS) mypiv = pv;
+    if ((k + 1) % LU_THREADS == 0 || k == n - 1) {
+      const int kb = k - k % LU_THREADS;
+      if (kb + tid <= k) piv[kb + tid] = mypiv;
+    }
     if (pv != k)
       for (int j = tid; j < n; j += LU_THREADS) {
         double a = A[k + (size_t)j * ld], b = A[pv + (size_t)j * ld];
@@ -203,12 +203,7 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       double bv = -1.;
       int bi = 0x7fffffff;
       if (k + tid < mp) { bv = fabs(s_P[(k + tid) + k * LP]); bi = k + tid; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = hssk_shfl_xor(bv, o);
-        const int oi = hssk_shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
+      hssk_wave_argmax(bv, bi);
       if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
       __syncthreads();
       double v = s_val[0];
@@ -378,6 +373,8 @@ __global__ __launch_bounds__(T) void getrf_wg2_kernel(const hssk_lu_desc* __rest
 #pragma unroll
     for (int j = 0; j < LUW_NB; j++) a[j] = (has && j < nb) ? hssk_gload(A, (size_t)(j0 + tid) + (size_t)(j0 + j) * lda) : 0.;
     int pos = tid;
+    int mypiv = 0;   // pivot of step tid of this panel: to global memory once per panel (a store per step in front of the
+                     // step's barrier made the next step wait out its round trip)
     if (tid == 0) s_naff = 0;
 #pragma unroll
     for (int k = 0; k < LUW_NB; k++) {
@@ -385,12 +382,7 @@ __global__ __launch_bounds__(T) void getrf_wg2_kernel(const hssk_lu_desc* __rest
         // ---- pivot: first arg max over the positions >= k
         double bv = (has && pos >= k) ? fabs(a[k]) : -1.;
         int bi = (has && pos >= k) ? pos : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const double ov = hssk_shfl_xor(bv, o);
-          const int oi = hssk_shfl_xor(bi, o);
-          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        hssk_wave_argmax(bv, bi);
         if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
         __syncthreads();
         double v = s_val[0];
@@ -405,8 +397,8 @@ __global__ __launch_bounds__(T) void getrf_wg2_kernel(const hssk_lu_desc* __rest
         if (ispiv) {
 #pragma unroll
           for (int j = k; j < LUW_NB; j++) s_row[j] = a[j];
-          p.piv[j0 + k] = j0 + pp;
         }
+        if (tid == k) mypiv = j0 + pp;
         __syncthreads();
         const double akk = s_row[k];
         if (akk == 0.) {
@@ -419,6 +411,7 @@ __global__ __launch_bounds__(T) void getrf_wg2_kernel(const hssk_lu_desc* __rest
         }
       }
     }
+    if (tid < nb) p.piv[j0 + tid] = mypiv;
     // ---- rows to their positions: LDS (trailing update) and global memory; who moved
     if (has) {
 #pragma unroll
@@ -559,12 +552,7 @@ __global__ __launch_bounds__(LU_THREADS) void getrf_panel_kernel(const hssk_lu_d
       const double v = fabs(A[i + (size_t)k * ld]);
       if (v > bv) { bv = v; bi = i; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = hssk_shfl_xor(bv, o);
-      const int oi = hssk_shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    hssk_wave_argmax(bv, bi);
     if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
     __syncthreads();
     if (tid == 0) {

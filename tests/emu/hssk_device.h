@@ -75,6 +75,13 @@ inline void hssk_row_argmax(double& v, int& idx) {
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
 }
+inline void hssk_wave_argmax(double& v, int& idx) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = hssk_shfl_xor(v, o);
+    const int oi = hssk_shfl_xor(idx, o);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
 template <int N>
 inline void hssk_row_sum_n(double (&v)[N]) {
   for (int i = 0; i < N; i++) v[i] = hssk_row_sum(v[i]);
