@@ -146,7 +146,7 @@ constexpr knn_key_t KNN_EMPTY = ((knn_key_t)0x7f61b1e6u << 32) | 0x7fffffffu;   
 // of heaps), so several waves share a SIMD and cover each other's LDS and FP64 latencies -- with one query per lane the
 // 128 KB of heaps per 256 queries left ONE wave per SIMD, which issues one instruction per 4-cycle slot whatever its type
 // (profiles/r02_pmc_knn.md).  The price is paid in the flush, which takes the LQ lane groups of a query in turn.
-template <int DM, int Q, int LQ>
+template <int DM, int Q, int LQ, bool PIPE = false>
 __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
                                                     const knn_key_t* __restrict__ lb, int* __restrict__ out_idx, int ldo,
                                                     knn_key_t* __restrict__ ub) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
 #pragma unroll
         for (int j = 0; j < DM; j++) b[u][j] = tile[(c + u * LQ + part) * DM + j];
     };
-    if (LQ == 1) {
+    if (LQ == 1 || PIPE) {
       // software pipeline over the tile: the LDS reads of the next trip are in flight while this one computes (one
       // wave per SIMD: nothing else hides their latency)
       double b0[U][DM], b1[U][DM];
@@ -288,7 +288,11 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
         if (hssk_any(cnt > KNN_PEND - U)) flush();
       }
     } else {
-      // (several waves per SIMD: they cover each other, and the second register set is better spent on occupancy)
+      // (several waves per SIMD: they cover each other.  With d <= 8 the LDS holds two workgroups per CU whatever the register
+      // count, so the second register set is free there: PIPE, 18.9 -> 18.2 ms at N = 1e5.  Tried and dropped in round 4: the
+      // page as an unsorted array with its largest key in registers and the four lanes of a query scanning for the next one
+      // together -- 21.0 ms: every lane of the wave runs every insertion step of every query, a scan costs more than the six
+      // levels of the heap it replaces)
       double b0[U][DM];
       for (int c = 0; c < CT; c += TRIP) {
         fetch(c, b0);
@@ -468,7 +472,9 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
     // (queries per workgroup: threads / lanes per query)
     static const bool lq1 = [] { const char* e = std::getenv("HSSK_KNN_LQ"); return e && e[0] == '1'; }();
     const int nqr = q1 - q0;
-    if (d <= 8 && !lq1) HSSK_LAUNCH((knn_kernel<8, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    static const bool pipe = [] { const char* e = std::getenv("HSSK_KNN_PIPE"); return !(e && e[0] == '0'); }();
+    if (d <= 8 && !lq1 && pipe) HSSK_LAUNCH((knn_kernel<8, 256, 4, true>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    else if (d <= 8 && !lq1) HSSK_LAUNCH((knn_kernel<8, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
     else if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256, 1>), dim3((unsigned)((nqr + 255) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
     else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
     else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
