@@ -146,11 +146,14 @@ constexpr knn_key_t KNN_EMPTY = ((knn_key_t)0x7f61b1e6u << 32) | 0x7fffffffu;   
 // of heaps), so several waves share a SIMD and cover each other's LDS and FP64 latencies -- with one query per lane the
 // 128 KB of heaps per 256 queries left ONE wave per SIMD, which issues one instruction per 4-cycle slot whatever its type
 // (profiles/r02_pmc_knn.md).  The price is paid in the flush, which takes the LQ lane groups of a query in turn.
-template <int DM, int Q, int LQ, bool PIPE = false>
+// TILEK / PEND: coordinates per LDS tile and lane, slots of a lane's pending list (the defaults above).  <8, 64, 4, false, 64,
+// 11> is a ONE-WAVE workgroup of 17.5 KB: nine of them per CU, and the 6250 of N = 1e5 are 2.7 rounds of the chip's 2304
+// slots -- the 1563 four-wave workgroups were 3.05 rounds of 512 slots, i.e. FOUR rounds of time for three of work.
+template <int DM, int Q, int LQ, bool PIPE = false, int TILEK = KNN_TILE, int PEND = KNN_PEND>
 __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
                                                     const knn_key_t* __restrict__ lb, int* __restrict__ out_idx, int ldo,
                                                     knn_key_t* __restrict__ ub) {
-  constexpr int TILE = KNN_TILE * LQ;           // coordinates per tile: a tile lasts as many trips whatever LQ
+  constexpr int TILE = TILEK * LQ;              // coordinates per tile: a tile lasts as many trips whatever LQ
   constexpr int CT = TILE / DM;                 // candidates per tile
   constexpr int U = DM <= 16 ? 4 : (DM <= 32 ? 2 : 1);   // candidates per lane and trip (their coordinates sit in registers)
   constexpr int NL = TILE / Q;                  // tile elements per lane
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
   constexpr int TRIP = U * LQ;                  // candidates per trip
   static_assert(TILE % Q == 0 && CT % (2 * TRIP) == 0 && Q % LQ == 0 && 64 % LQ == 0, "tile shape");
   HSSK_SHARED knn_key_t hh[KNN_P * NQ];
-  HSSK_SHARED knn_key_t pend[KNN_PEND * Q];
+  HSSK_SHARED knn_key_t pend[PEND * Q];
   HSSK_SHARED double xc[2 * TILE];          // two tiles: the next one is written while the current one is read
   const int tid = threadIdx.x, ql = tid / LQ, part = tid % LQ;
   const int q = q0 + blockIdx.x * NQ + ql;
@@ -282,10 +285,10 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
       for (int c = 0; c < CT; c += 2 * TRIP) {
         fetch(c + TRIP, b1);
         trip(c, b0);
-        if (hssk_any(cnt > KNN_PEND - U)) flush();
+        if (hssk_any(cnt > PEND - U)) flush();
         if (c + 2 * TRIP < CT) fetch(c + 2 * TRIP, b0);
         trip(c + TRIP, b1);
-        if (hssk_any(cnt > KNN_PEND - U)) flush();
+        if (hssk_any(cnt > PEND - U)) flush();
       }
     } else {
       // (several waves per SIMD: they cover each other.  With d <= 8 the LDS holds two workgroups per CU whatever the register
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
       for (int c = 0; c < CT; c += TRIP) {
         fetch(c, b0);
         trip(c, b0);
-        if (hssk_any(cnt > KNN_PEND - U)) flush();
+        if (hssk_any(cnt > PEND - U)) flush();
       }
     }
   }
@@ -473,6 +476,11 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
     static const bool lq1 = [] { const char* e = std::getenv("HSSK_KNN_LQ"); return e && e[0] == '1'; }();
     const int nqr = q1 - q0;
     static const bool pipe = [] { const char* e = std::getenv("HSSK_KNN_PIPE"); return !(e && e[0] == '0'); }();
+    static const bool w1 = [] { const char* e = std::getenv("HSSK_KNN_W1"); return !(e && e[0] == '0'); }();   // (18.2 -> 17.3 ms at N = 1e5)
+    if (d <= 8 && !lq1 && w1) {
+      HSSK_LAUNCH((knn_kernel<8, 64, 4, false, 64, 11>), dim3((unsigned)((nqr + 15) / 16)), dim3(64), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+      continue;
+    }
     if (d <= 8 && !lq1 && pipe) HSSK_LAUNCH((knn_kernel<8, 256, 4, true>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
     else if (d <= 8 && !lq1) HSSK_LAUNCH((knn_kernel<8, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
     else if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256, 1>), dim3((unsigned)((nqr + 255) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
