@@ -46,12 +46,21 @@ __device__ __forceinline__ double mm_aload(const MatOp& o, int i, int k) {
 // the whole accumulator tuple around each --, k-steps beyond K multiply by zeros read in place of the right-hand sides.)
 template <int NC>
 __device__ __forceinline__ void mm_chunk(const MatOp& o, const double* xb, int k0, const double (&a)[MM_CH], hssk_d4 (&acc)[NC / 16]) {
+  // (all LDS operands of the chunk first, unconditionally and from a clamped row; k-steps beyond K are cancelled by a ZERO
+  // FACTOR on the A fragment.  Written as `k < K ? xr[..] : 0.` every read sat under a branch of its own with a full wait
+  // behind it, right in front of its product: ~230 cycles per MFMA with one wave per SIMD -- round 3's "open" item.)
+  double xv[MM_CH][NC / 16];
 #pragma unroll
   for (int u = 0; u < MM_CH; u++) {
-    const int k = k0 + 4 * u;
-    const double* xr = xb + min(k, o.K - 1) * MM_LDR;
+    const double* xr = xb + min(k0 + 4 * u, o.K - 1) * MM_LDR;
 #pragma unroll
-    for (int ct = 0; ct < NC / 16; ct++) acc[ct] = hssk_mfma_f64_16x16x4(a[u], k < o.K ? xr[ct * 16] : 0., acc[ct]);
+    for (int ct = 0; ct < NC / 16; ct++) xv[u][ct] = xr[ct * 16];
+  }
+#pragma unroll
+  for (int u = 0; u < MM_CH; u++) {
+    const double au = a[u] * (k0 + 4 * u < o.K ? 1. : 0.);
+#pragma unroll
+    for (int ct = 0; ct < NC / 16; ct++) acc[ct] = hssk_mfma_f64_16x16x4(au, xv[u][ct], acc[ct]);
   }
 }
 template <int NC>
