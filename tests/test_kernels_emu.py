@@ -233,4 +233,5 @@ def test_upload_two_threads(hk):
 def test_colsets(hk):
     KC.case_colsets(hk)
     KC.case_colsets(hk, universe=100000, seed=82)
+    KC.case_colsets(hk, universe=1_250_000, seed=83)    # a bitmap of nearly the whole LDS
 
