@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <iostream>
 #include <numeric>
@@ -113,6 +114,34 @@ inline void label_two_means(const Points& p, std::vector<int>& label, int nc[2],
   }
 }
 
+// Labels of a median split: the n / 2 smallest keys get 0, as the reference's
+//   std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(), [&](a, b) { return key[a] < key[b]; })
+// leaves them.  WHICH elements end up below position n / 2 is the same for every selection algorithm unless equal keys
+// straddle that position, so the selection runs on a copy of the keys (contiguous doubles: a third of the time of the
+// indirect comparisons, and the serial part of every level of the clustering); only if the keys below the median value
+// do not number exactly n / 2 is the reference's own call made, whose arrangement then decides the ties.
+inline void median_labels(const std::vector<double>& key, std::vector<int>& label, int nc[2]) {
+  const int n = (int)key.size(), h = n / 2;
+  nc[0] = h; nc[1] = n - h;
+  label.assign(n, 0);
+  if (n < 2) return;
+  // (STRUMPACK_AMD_CLUSTER_EXACT_SELECT=1: always the reference's call -- the tests compare the two)
+  static const bool exact = [] { const char* e = std::getenv("STRUMPACK_AMD_CLUSTER_EXACT_SELECT"); return e && e[0] == '1'; }();
+  std::vector<double> tmp(key);
+  std::nth_element(tmp.begin(), tmp.begin() + h, tmp.end());
+  const double v = tmp[h];
+  int below = 0;
+  for (int i = 0; i < n; i++) below += key[i] < v;
+  if (below == h && !exact) {
+    for (int i = 0; i < n; i++) label[i] = key[i] < v ? 0 : 1;
+    return;
+  }
+  std::vector<std::size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::nth_element(idx.begin(), idx.begin() + h, idx.end(), [&](const std::size_t& a, const std::size_t& b) { return key[a] < key[b]; });
+  for (int i = h; i < n; i++) label[idx[i]] = 1;
+}
+
 // median split along the coordinate of largest extent (KDTree.cpp:36-57, 83-95)
 inline void label_kd(const Points& p, std::vector<int>& label, int nc[2]) {
   const int n = p.n, d = p.d;
@@ -123,13 +152,9 @@ inline void label_kd(const Points& p, std::vector<int>& label, int nc[2]) {
   double ext = mx[0] - mn[0];
   for (int j = 1; j < d; j++)
     if (mx[j] - mn[j] > ext) { ext = mx[j] - mn[j]; dim = j; }
-  std::vector<std::size_t> idx(n);
-  std::iota(idx.begin(), idx.end(), 0);
-  std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(),
-                   [&](const std::size_t& a, const std::size_t& b) { return p.pt((int)a)[dim] < p.pt((int)b)[dim]; });
-  nc[0] = n / 2; nc[1] = n - n / 2;
-  label.assign(n, 0);
-  for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
+  std::vector<double> key(n);
+  for (int i = 0; i < n; i++) key[i] = p.pt(i)[dim];
+  median_labels(key, label, nc);
 }
 
 // fn(lo, hi) over [0, n) in contiguous pieces, on a few host threads when the range is long (the top levels of a large
@@ -171,13 +196,7 @@ inline void label_cobble(const Points& p, std::vector<int>& label, int nc[2]) {
   for_pieces(n, [&](int lo, int hi, int) {
     for (int i = lo; i < hi; i++) ds[i] = dist(d, p.pt(i), p.pt(first));
   });
-  std::vector<std::size_t> idx(n);
-  std::iota(idx.begin(), idx.end(), 0);
-  std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(),
-                   [&](const std::size_t& a, const std::size_t& b) { return ds[a] < ds[b]; });
-  nc[0] = n / 2; nc[1] = n - n / 2;
-  label.assign(n, 0);
-  for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
+  median_labels(ds, label, nc);
 }
 
 // median split along the principal direction of the (uncentred) second-moment matrix p p^T, as the reference does
@@ -229,12 +248,7 @@ inline void label_pca(const Points& p, std::vector<int>& label, int nc[2]) {
   std::vector<double> x(n, 0.);
   for (int i = 0; i < n; i++)
     for (int a = 0; a < d; a++) x[i] += p.pt(i)[a] * z[a];
-  std::vector<std::size_t> idx(n);
-  std::iota(idx.begin(), idx.end(), 0);
-  std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(), [&](const std::size_t& a, const std::size_t& b) { return x[a] < x[b]; });
-  nc[0] = n / 2; nc[1] = n - n / 2;
-  label.assign(n, 0);
-  for (int i = n / 2; i < n; i++) label[idx[i]] = 1;
+  median_labels(x, label, nc);
 }
 
 using labeller_t = std::function<void(const Points&, std::vector<int>&, int*)>;

@@ -104,6 +104,34 @@ def test_clustering_large_set_on_host_threads(lib, algo, split):
         off += m
 
 
+@pytest.mark.parametrize("algo", ["cobble", "kdtree", "pca"])
+def test_median_split_fast_selection_is_the_reference_selection(algo):
+    """The median splits select on a copy of the keys and make the reference's nth_element call only when equal keys straddle
+    the median position (Clustering.hpp: median_labels); with STRUMPACK_AMD_CLUSTER_EXACT_SELECT=1 they always make it.  Same
+    permutations either way, on random points and on a lattice with many duplicated points (a subprocess per mode: the switch
+    is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import emu_lib; from strumpack_amd import kernel as KM\n"
+        "lib = KM.load(emu_lib.build()); r = np.random.default_rng(5)\n"
+        "out = []\n"
+        "for X in (r.random((20000, 6)), r.integers(0, 3, (9000, 4)).astype(float), np.repeat(r.random((700, 3)), 9, axis=0)):\n"
+        "    Xp, perm, leaves = KM.clustering(lib, X, %r, 100)\n"
+        "    out.append(perm.tolist()); out.append(leaves.tolist())\n"
+        "import hashlib, json; print(hashlib.sha256(json.dumps(out).encode()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), algo)
+    digests = []
+    for mode in ("0", "1"):
+        env = dict(os.environ, STRUMPACK_AMD_CLUSTER_EXACT_SELECT=mode)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        digests.append(res.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
+
+
 def test_pca_clustering_matches_reference_up_to_mirroring(lib):
     """The principal direction comes from LAPACK syevx in the reference: its sign is implementation-defined, so a split
     may come out mirrored; the two halves (as point sets) and the leaf sizes must agree."""
