@@ -183,3 +183,41 @@ def test_oracle_kernel_compression_matches_reference(tag):
 @pytest.mark.parametrize("tag", ["gauss_400", "laplace_400", "anova_400"])
 def test_regression_with_reference_neighbours(lib, tag):
     KG.check_regression(KM, lib, tag, inject=True, acc_tol=0.0, rank_tol=0.0, w_tol=1e-7 if tag == "gauss_400" else 1e-6)
+
+
+def test_column_sets_on_device_equal_the_host_form():
+    """compress_kernel builds the nodes' column sets on the device (hssk_colsets) unless STRUMPACK_AMD_KERNEL_HOST_SETS=1
+    asks for the host threads: same sets, hence the same node table (ranks, sizes), permutation and regression weights --
+    with the library's own exact neighbours and with injected lists (a subprocess per mode: the switch is read once)."""
+    import hashlib  # noqa: F401
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import emu_lib; from strumpack_amd import kernel as KM\n"
+        "lib = KM.load(emu_lib.build()); r = np.random.default_rng(9)\n"
+        "X = r.random((900, 4)); y = np.sign(X[:, 0] - 0.5 + 0.1 * r.standard_normal(900))\n"
+        "res = []\n"
+        "for nb in (None, 'inject'):\n"
+        "    m = KM.KernelRegression(lib, h=0.7, lam=2.0, kernel='rbf', argv=['--hss_leaf_size', '64', '--hss_rel_tol', '1e-3', '--hss_approximate_neighbors', '24'])\n"
+        "    if nb is None:\n"
+        "        m.fit(X, y)\n"
+        "    else:\n"
+        "        perm = res[1]\n"
+        "        Xp = X[np.array(perm) - 1]\n"
+        "        D = ((Xp[:, None, :] - Xp[None, :, :]) ** 2).sum(-1); np.fill_diagonal(D, np.inf)\n"
+        "        ann = np.argsort(D, axis=1, kind='stable')[:, :24].astype(np.int32)\n"
+        "        m.fit(X, y, neighbors=ann)\n"
+        "    res += [m.node_info().tolist(), m.permutation().tolist(), np.round(m.weights(), 12).tolist()]\n"
+        "    m.destroy()\n"
+        "import hashlib, json; print(hashlib.sha256(json.dumps(res).encode()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    digests = []
+    for mode in ("0", "1"):
+        env = dict(os.environ, STRUMPACK_AMD_KERNEL_HOST_SETS=mode)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        digests.append(res.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
+
