@@ -43,6 +43,7 @@ int hssk_plan_size(const hssk_plan* plan);
 /* device memory helpers (hipMalloc/hipFree/hipMemcpy wrappers so FFI users need no HIP binding) */
 void* hssk_malloc(long long bytes);
 void hssk_free(void* dptr);
+long long hssk_device_total_bytes(void); /* HBM of the calling thread's current device; 0 if unknown */
 int hssk_memcpy_h2d(hssk_ctx* ctx, void* dst, const void* src, long long bytes);
 int hssk_memcpy_d2h(hssk_ctx* ctx, void* dst, const void* src, long long bytes); /* synchronises */
 /* host -> device without synchronising: src is copied into the context's pinned staging ring first, so the caller's
@@ -154,8 +155,11 @@ typedef struct hssk_gen {
   int kind, reserved;
   double p[4]; /* parameters of later kinds */
 } hssk_gen;
-/* hssk_dgemm with op(B)(kk, j) = transG ? G(j0 + j, kk) : G(kk, j0 + j), kk in [0, k), j in [0, n): same tiles, same
- * K-split and summation order as hssk_dgemm on the stored matrix -- the results are bitwise those of the dense route. */
+/* hssk_dgemm with op(B)(kk, j) = transG ? G(j0 + j, kk) : G(kk, j0 + j), kk in [0, k), j in [0, n).  Shapes the eight-wave
+ * kernel takes (m a multiple of its row block -- 64 / 128 / 192 --, k a multiple of 16, n >= 128, even lda: what the engine's
+ * sketch passes) run the same tiles, K-split and summation order as hssk_dgemm on the stored matrix: bitwise the results of the
+ * dense route.  Other shapes (ragged k, odd m, narrow outputs) are evaluated in blocks of at most 1024 columns that are
+ * multiplied as stored operands, each with the K-split of its own width: equal to the dense route up to rounding only. */
 int hssk_sketch_gen(hssk_ctx* ctx, const hssk_gen* g, int transG, int m, long long n, long long k, long long j0, double alpha,
                     const double* A, long long lda, double beta, double* C, long long ldc);
 /* A(il, jl) = trans ? G(j0 + jl, i0 + il) : G(i0 + il, j0 + jl) for a rows x cols block (leading dimension lda) */

@@ -262,6 +262,14 @@ int SPX_d_blr_front_stats(const SPXBLRFront F, double* out);
 void SPX_d_blr_front_destroy(SPXBLRFront* F);
 /* the hssk kernel context of the matrix (include/hssk.h), for callers that share its stream */
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S);
+/* The library keeps released device chunks in a process-wide cache for reuse (no hipMalloc / hipFree page-table work in solver
+ * loops); the cache is invisible to the other allocators of the process (torch, RCCL).  Default cap: a sixth of the device's memory
+ * (environment STRUMPACK_AMD_POOL_GB overrides).  _trim returns everything cached to the device now; _set_limit_gb changes the cap
+ * (and trims down to it; 0 = cache nothing). */
+long long SPX_device_pool_cached_bytes(void);
+long long SPX_device_pool_limit_bytes(void);
+void SPX_device_pool_trim(void);
+void SPX_device_pool_set_limit_gb(double gb);
 
 #ifdef __cplusplus
 }

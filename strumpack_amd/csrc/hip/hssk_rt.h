@@ -71,6 +71,12 @@ inline int cu_count() {
 }
 // workgroups of one launch that are certain to be resident together (kernels whose workgroups wait for each other)
 inline int coresident_workgroups() { return cu_count(); }
+// total HBM of the current device in bytes (0 if unknown)
+inline size_t device_total_bytes() {
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return tot;
+}
 inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void set_device(int d) { HSSK_CHECK(hipSetDevice(d)); }
 inline bool is_device_pointer(const void* p) {

@@ -11,6 +11,9 @@
 // reference's swap sequence (which also defines the order inside each half), recurse -- so only the labelling
 // differs between them.
 #pragma once
+#include <atomic>
+#include <memory>
+#include <system_error>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -159,14 +162,40 @@ inline void label_kd(const Points& p, std::vector<int>& label, int nc[2]) {
 
 // fn(lo, hi) over [0, n) in contiguous pieces, on a few host threads when the range is long (the top levels of a large
 // point set: the two halves of a split only fork BELOW it)
+// Host threads forked by the clustering at any one time are capped (nested fan-out: the halves of the top splits fork, and
+// each labels its points in pieces): a piece that finds the budget spent, or whose thread cannot be started, runs on the
+// caller's thread instead.  Exceptions of a piece are carried to the caller after every started thread has been joined.
+inline std::atomic<int>& live_threads() { static std::atomic<int> n{0}; return n; }
+inline int thread_budget() { return (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency())); }
+struct ThreadSlot {   // one unit of the budget, held while a forked thread lives
+  bool ok;
+  ThreadSlot() : ok(live_threads().fetch_add(1) < thread_budget()) { if (!ok) live_threads().fetch_sub(1); }
+  ~ThreadSlot() { if (ok) live_threads().fetch_sub(1); }
+};
+
 template <class F> inline void for_pieces(int n, F&& fn) {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const int pieces = n >= 32768 ? (int)std::min<unsigned>(8, hw) : 1;
   if (pieces <= 1) { fn(0, n, 0); return; }
   std::vector<std::thread> th;
-  for (int t = 1; t < pieces; t++) th.emplace_back([&, t] { fn((int)((long long)n * t / pieces), (int)((long long)n * (t + 1) / pieces), t); });
-  fn(0, n / pieces, 0);
+  std::vector<std::unique_ptr<ThreadSlot>> slots;
+  std::vector<std::exception_ptr> err(pieces);
+  auto piece = [&](int t) {
+    try { fn((int)((long long)n * t / pieces), (int)((long long)n * (t + 1) / pieces), t); }
+    catch (...) { err[t] = std::current_exception(); }
+  };
+  std::vector<int> inline_pieces{0};
+  for (int t = 1; t < pieces; t++) {
+    std::unique_ptr<ThreadSlot> sl(new ThreadSlot());
+    bool started = false;
+    if (sl->ok) {
+      try { th.emplace_back(piece, t); started = true; } catch (const std::system_error&) {}
+    }
+    if (started) slots.push_back(std::move(sl)); else inline_pieces.push_back(t);
+  }
+  for (int t : inline_pieces) piece(t);
   for (auto& x : th) x.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 // median split by distance from the point farthest from the centroid (CobblePartitioning.cpp:36-78)
@@ -266,17 +295,27 @@ inline structured::ClusterTree recurse(const Points& p, int cluster_size, int* p
   group_zero_first(p, label, nc[0], perm);
   if (!nc[0] || !nc[1]) return tree;
   tree.c.resize(2);
-  if (fork > 0 && p.n >= 4096) {
+  bool forked = false;
+  std::unique_ptr<ThreadSlot> slot;
+  if (fork > 0 && p.n >= 4096) slot.reset(new ThreadSlot());
+  if (slot && slot->ok) {
     std::exception_ptr err;
-    std::thread other([&] {
-      try { tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab, fork - 1); }
-      catch (...) { err = std::current_exception(); }
-    });
-    try { tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab, fork - 1); }
-    catch (...) { other.join(); throw; }
-    other.join();
-    if (err) std::rethrow_exception(err);
-  } else {
+    std::thread other;
+    try {
+      other = std::thread([&] {
+        try { tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab, fork - 1); }
+        catch (...) { err = std::current_exception(); }
+      });
+      forked = true;
+    } catch (const std::system_error&) {}
+    if (forked) {
+      try { tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab, fork - 1); }
+      catch (...) { other.join(); throw; }
+      other.join();
+      if (err) std::rethrow_exception(err);
+    }
+  }
+  if (!forked) {
     tree.c[0] = recurse(Points{p.x, p.d, nc[0]}, cluster_size, perm, lab);
     tree.c[1] = recurse(Points{p.pt(nc[0]), p.d, nc[1]}, cluster_size, perm + nc[0], lab);
   }

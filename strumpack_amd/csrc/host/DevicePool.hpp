@@ -2,6 +2,7 @@
 // that repeated constructions (solver loops, the fronts of a multifrontal factorization, benchmarks) do not pay hipMalloc /
 // hipFree page-table work -- a free of a multi-gigabyte block is a synchronous call of tens of milliseconds.
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -29,6 +30,7 @@ class DevicePool {
   }
   void release(void* p, size_t bytes) {
     std::lock_guard<std::mutex> g(mu_);
+    ensure_limit();
     if (cached_ + bytes > limit_) { hssk_free(p); return; }
     free_[bytes].push_back(p);
     cached_ += bytes;
@@ -39,14 +41,32 @@ class DevicePool {
     free_.clear();
     cached_ = 0;
   }
+  // bytes currently kept for reuse / the cap on them; set_limit trims down to the new cap
+  size_t cached() { std::lock_guard<std::mutex> g(mu_); return cached_; }
+  size_t limit() { std::lock_guard<std::mutex> g(mu_); ensure_limit(); return limit_; }
+  void set_limit(size_t bytes) {
+    { std::lock_guard<std::mutex> g(mu_); limit_ = bytes; limit_set_ = true; }
+    if (cached() > bytes) trim();
+  }
   ~DevicePool() { for (auto& kv : free_) for (void* p : kv.second) hssk_free(p); }
 
  private:
   std::mutex mu_;
   std::map<size_t, std::vector<void*>> free_;
-  // bytes kept for reuse (STRUMPACK_AMD_POOL_GB; default 48 of the 288 GB: the working array + block products of a
-  // 60000-row BLR front are ~45 GB)
-  size_t cached_ = 0, limit_ = [] { const char* e = std::getenv("STRUMPACK_AMD_POOL_GB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 48) << 30; }();
+  // Bytes kept for reuse.  The cache is only ever trimmed by this library (on its own failed allocation, set_limit, trim), so
+  // what it holds is invisible to the other allocators of the process (torch, RCCL): the default cap is a SIXTH of the device's
+  // memory (48 of the 288 GB of an MI355X -- the working array + block products of a 60000-row BLR front are ~45 GB --, 10 GB of
+  // a 64 GB part), STRUMPACK_AMD_POOL_GB overrides it, SPX_device_pool_trim / SPX_device_pool_set_limit_gb manage it at run time.
+  void ensure_limit() {
+    if (limit_set_) return;
+    limit_set_ = true;
+    const char* e = std::getenv("STRUMPACK_AMD_POOL_GB");
+    if (e) { limit_ = (size_t)std::max(0, std::atoi(e)) << 30; return; }
+    const long long tot = hssk_device_total_bytes();
+    limit_ = tot > 0 ? (size_t)tot / 6 : (size_t)8 << 30;
+  }
+  size_t cached_ = 0, limit_ = 0;
+  bool limit_set_ = false;
 };
 
 namespace HSS { using strumpack::DevicePool; }

@@ -1,5 +1,6 @@
 // C interface SP_d_struct_* (reference structured/StructuredMatrixC.cpp:61-119 handle + error
 // convention, :83-821 entry points) and the SPX_* device-operand extensions.
+#include "DevicePool.hpp"
 #include <complex>
 #include <cstdlib>
 #include <iostream>
@@ -626,5 +627,13 @@ void SPX_d_blr_front_destroy(SPXBLRFront* F) {
 }
 
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S) { return hss(S) ? (void*)hss(S)->engine()->ctx() : nullptr; }
+
+// The process-wide cache of device chunks (DevicePool.hpp): what it holds is free memory only this library can see
+long long SPX_device_pool_cached_bytes(void) { return (long long)strumpack::DevicePool::get().cached(); }
+long long SPX_device_pool_limit_bytes(void) { return (long long)strumpack::DevicePool::get().limit(); }
+void SPX_device_pool_trim(void) { strumpack::DevicePool::get().trim(); }
+void SPX_device_pool_set_limit_gb(double gb) {
+  strumpack::DevicePool::get().set_limit(gb <= 0 ? 0 : (size_t)(gb * 1073741824.0));
+}
 
 }  // extern "C"

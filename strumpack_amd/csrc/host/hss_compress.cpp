@@ -210,7 +210,7 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       src.sample(*this, c, dnew);
       ck(hssk_sync(ctx_));
       stats_.t_sketch += now() - t0;
-      stats_.f_sketch += 2.0 * src.products(*this) * (double)N * (double)N * (sj_pat_ ? sj_nnz_ : dnew);   // per product: 2 N^2 d (SJLT: 2 nnz per element)
+      stats_.f_sketch += src.sketch_flops(*this, dnew);   // per product: 2 N^2 d (SJLT streamed: 2 nnz per element)
       if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
       stats_.rounds++;
       for (size_t h = 0; h < own_by_height_.size(); h++) {
@@ -238,7 +238,7 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       src.sample(*this, d_old, d - d_old);
       ck(hssk_sync(ctx_));
       stats_.t_sketch += now() - t0;
-      stats_.f_sketch += 2.0 * src.products(*this) * (double)N * (double)N * (sj_pat_ ? sj_nnz_ : d - d_old);
+      stats_.f_sketch += src.sketch_flops(*this, d - d_old);
       if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << (o_.algorithm == 2 ? " (original, hard restart)" : " (original)") << std::endl;
       if (o_.algorithm == 2) {   // keep the new samples as drawn
         if (dist_subtree_ || o_.world > 1) throw std::invalid_argument("hard restart is a single-GPU option");

@@ -204,6 +204,10 @@ struct DeviceHSS::Source {
   virtual bool extract_before_sample() const { return false; }
   // sketch products per round that sample() executes (2; 1 when the operand is symmetric by the caller's word: flop count)
   virtual int products(const DeviceHSS&) const { return 2; }
+  // flops of the sample() call just made for dn new samples: per product 2 N^2 dn, or 2 N^2 nnz when the SJLT pattern was
+  // streamed -- decided by the route sample() actually took (a source that multiplies with the dense form of the pattern, or
+  // copies the second product of a symmetric operand, says so here)
+  virtual double sketch_flops(const DeviceHSS& H, int dn) const;
 };
 
 }  // namespace HSS

@@ -202,16 +202,28 @@ void DeviceHSS::factor_ahead_level(size_t h) {
     factor_begin(0, false, fctx_);
     frun_.ahead = true;
   }
-  if (!frun_.ahead || frun_.done != h || h >= own_by_height_.size()) return;
-  const std::vector<int>& ids = own_by_height_[h];
-  for (int id : ids)
-    if (!nodes_[id].compressed()) return;
-  ck(hssk_stream_wait(fctx_, ctx_));
-  factor_prep(ids);
-  factor_level(ids);
-  // (the inverted diagonal blocks of the level's triangles: on this stream a launch per level costs nothing)
-  if (!frun_.ti.empty()) { ck(hssk_trtri_diag_vbatched(fctx_, frun_.ti.data(), (int)frun_.ti.size())); frun_.ti.clear(); }
-  frun_.done = h + 1;
+  if (!frun_.ahead || h >= own_by_height_.size()) return;
+  // every height up to h whose turn has come (a height held back earlier -- see below -- is caught up with here)
+  while (frun_.done <= h) {
+    const std::vector<int>& ids = own_by_height_[frun_.done];
+    // A node's reduced block Dt goes straight into its PARENT's Dh (dt_slot), whose size and offsets are the ranks of BOTH
+    // children: on a tree whose siblings differ in height the taller one is settled later, so the level also waits for the
+    // siblings of its nodes (cut nodes keep a compact Dt of their own and need not).
+    for (int id : ids) {
+      const Node& nd = nodes_[id];
+      if (!nd.compressed()) return;
+      if (nd.parent >= 0 && !frun_.is_cut[id]) {
+        const Node& pa = nodes_[nd.parent];
+        if (!nodes_[pa.c0].compressed() || !nodes_[pa.c1].compressed()) return;
+      }
+    }
+    ck(hssk_stream_wait(fctx_, ctx_));
+    factor_prep(ids);
+    factor_level(ids);
+    // (the inverted diagonal blocks of the level's triangles: on this stream a launch per level costs nothing)
+    if (!frun_.ti.empty()) { ck(hssk_trtri_diag_vbatched(fctx_, frun_.ti.data(), (int)frun_.ti.size())); frun_.ti.clear(); }
+    frun_.done++;
+  }
 }
 
 void DeviceHSS::factor_cancel() {

@@ -5,12 +5,21 @@
 namespace strumpack {
 namespace HSS {
 
+double DeviceHSS::Source::sketch_flops(const DeviceHSS& H, int dn) const {
+  return 2.0 * products(H) * (double)H.n_ * (double)H.n_ * (H.sj_pat_ ? H.sj_nnz_ : dn);
+}
+
 struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
   const double* dA;
   long long lda;
   DenseDeviceSource(const double* a, long long l) : dA(a), lda(l) {}
   bool extract_before_sample() const override { return true; }
-  int products(const DeviceHSS& H) const override { return (H.o_.symmetric && !H.sj_pat_) ? 1 : 2; }
+  int done_products_ = 2;     // what the last sample() executed (the route is chosen there)
+  bool done_sparse_ = false;
+  int products(const DeviceHSS&) const override { return done_products_; }
+  double sketch_flops(const DeviceHSS& H, int dn) const override {
+    return 2.0 * done_products_ * (double)H.n_ * (double)H.n_ * (done_sparse_ ? H.sj_nnz_ : dn);
+  }
   void sample(DeviceHSS& H, int r0, int dn) override {
     const long long N = H.n_;
     // AFunctor::operator()(Rr,Rc,Sr,Sc), HSSExtra.hpp:236-239, in the transposed sample layout.
@@ -27,7 +36,9 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
     // SJLT sketch: stream A once per product instead of a dense GEMM (blocks wider than the kernel's LDS tile, or
     // STRUMPACK_AMD_SJLT_DENSE=1, multiply with the dense form of the pattern)
     static const bool sj_dense = std::getenv("STRUMPACK_AMD_SJLT_DENSE") && std::atoi(std::getenv("STRUMPACK_AMD_SJLT_DENSE"));
-    if (nloc > 0 && H.sj_pat_ && dn <= 1024 && !sj_dense) {
+    done_sparse_ = H.sj_pat_ && dn <= 1024 && !sj_dense;
+    done_products_ = (!done_sparse_ && H.o_.symmetric) ? 1 : 2;
+    if (nloc > 0 && done_sparse_) {
       for (int t = 0; t < 2; t++) {
         const double* Aop = t == 0 ? dA + j0 : dA + j0 * lda;
         double* St = (t == 0 ? H.Srt_ : H.Sct_) + r0 + j0 * H.dcap_;

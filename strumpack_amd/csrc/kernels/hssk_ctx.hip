@@ -414,6 +414,9 @@ void* hssk_malloc(long long bytes) {
   try { return hssk_rt::dev_malloc((size_t)bytes); } catch (const std::exception& e) { hssk_set_error(e.what()); return nullptr; }
 }
 void hssk_free(void* p) { hssk_rt::dev_free(p); }
+long long hssk_device_total_bytes(void) {
+  try { return (long long)hssk_rt::device_total_bytes(); } catch (...) { return 0; }
+}
 
 int hssk_memcpy_h2d(hssk_ctx* c, void* dst, const void* src, long long bytes) {
   HSSK_API_BEGIN

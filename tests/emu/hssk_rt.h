@@ -49,6 +49,7 @@ inline int coresident_workgroups() {
   const int nt = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
   return nt < 16 ? nt : 16;
 }
+inline size_t device_total_bytes() { return (size_t)16 << 30; }
 inline int device_count() { return 1; }
 inline void set_device(int) {}
 inline bool is_device_pointer(const void*) { return false; }
