@@ -7,7 +7,8 @@ double-precision Toeplitz matrix A(i,j) = 1/(1+|i-j|) (test/test_HSS_seq.cpp:75-
 rel_tol 1e-4, d0+dd = 128+64 samples, matrix A already resident in HBM when the clock starts.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: under a launcher -- python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... -- the ranks are the
+    launcher's; without one this process starts the N ranks itself.  WORLD_SIZE and --gpus must agree.)
 
 Prints ONE JSON line (rank 0).  `value` = algorithmic GFLOP/s of compress+factor+solve (flop model of
 SURVEY.md section 8(d): 4 N^2 d for the sketch + the per-node terms) over the max-over-ranks step
@@ -536,8 +537,51 @@ def cpu_baseline(n_small, leaf, rel_tol, n_full=100000):
                     sample="numpy/LAPACK oracle, Toeplitz N=%d (reference library unavailable: %s)" % (n, e))
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits non-zero if any
+    rank does -- so that both spellings of the driver's multi-GPU command measure N ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), STRUMPACK_AMD_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    # a rank that died leaves the others in a collective: give them a moment, then stop exactly the processes started here
+    deadline = time.time() + (30 if rcs[0] == 0 else 5)
+    for q in procs[1:]:
+        try:
+            q.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            q.kill()
+            q.wait()
+        rcs.append(q.returncode)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stdout.write("".join(ln + "\n" for ln in (out0 or "").splitlines() if not ln.startswith("{")))
+        print("bench: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
+        raise SystemExit(next(rc for _, rc in bad if rc) if any(rc and rc > 0 for _, rc in bad) else 1)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_ranks(a)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("bench: --gpus %d but the launcher started WORLD_SIZE=%s ranks; the two must agree" % (a.gpus, os.environ["WORLD_SIZE"]),
+                  file=sys.stderr)
+        raise SystemExit(2)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -174,6 +174,33 @@ def test_bench_rendezvous_dry_run(world):
     assert d["checks"]["solve_resid_H"] < 1e-10 and d["hss"]["levels"] >= 3
 
 
+def test_bench_bare_gpus_spelling_spawns_the_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher (the shape of the driver's one-GPU command with N = 2): bench.py starts the
+    two ranks itself and relays rank 0's line -- n_gpus is 2, not a single rank that ignored the flag.  A launcher whose
+    WORLD_SIZE disagrees with --gpus is refused (exit code 2, no line)."""
+    import json
+    import emu_lib
+    emu_lib.build()
+    env = dict(os.environ, STRUMPACK_AMD_BENCH_DRYRUN_LIB=emu_lib.PATH, HSSK_EMU_THREADS="2", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--size", "1500", "--leaf", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["checks"]["solve_resid_H"] < 1e-10
+    # the native communicator cannot be set up on the emulator: with the default (rccl, no fall-back) every rank exits non-zero,
+    # and so does the parent -- no line
+    r = subprocess.run(cmd, env=dict(env, STRUMPACK_AMD_BENCH_COMM="rccl"), capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout + r.stderr
+
+
 def test_bench_refuses_silent_fallback():
     """With the default process group (the library's RCCL communicator) a multi-rank bench run must not fall back to the torch
     callback path on its own: where RCCL cannot be set up (here: the emulator build, gloo) every rank exits non-zero and no
