@@ -390,6 +390,45 @@ typedef struct hssk_xsolve_desc {
 } hssk_xsolve_desc;
 int hssk_id_xsolve_vbatched(hssk_ctx* ctx, const hssk_xsolve_desc* descs, int count);
 
+/* ---- the inner levels of a compression round as ONE launch (kernels/hssk_tree.hip) ------------------------------------
+ * compress_recursive_stable above the leaves (HSS/HSSMatrix.compress_stable.hpp:165-348, HSS/HSSMatrix.compress.hpp:555-629,
+ * 689-724): coupling blocks, local samples, both interpolative decompositions, reduced samples and skeleton indices of every
+ * inner node, one workgroup per (node, basis), children before parents, ranks never leaving the device.
+ * nodes: DEVICE array, one record per node of the (sub)tree, leaves included.  Leaves (and any node already compressed) are
+ * inputs: S / perm / Rred / I / r as the level-synchronous calls left them, flag = {1, 1}, status = 0.  Inner nodes are
+ * outputs: c0 / c1 / lvl and the storage pointers set, r = m = flag = status = 0; storage sized for ranks <= rcap:
+ *   S[s]: d x 2 rcap (leading dimension lds), Rred[s]: d x rcap (lds), perm[s]: 2 rcap ints, I[s]: rcap ints,
+ *   X[s]: rcap x 2 rcap doubles (written r x (m - r) with leading dimension r), B01 / B10: rcap^2 doubles (written with the
+ *   children's ranks as leading dimensions, as hssk_gather_elems would), W[s]: (2 rcap)^2 doubles of workspace.
+ * s = 0: the row basis U (from the row samples Srt), s = 1: the column basis V.  Rred[0] = V^T Rr (rV columns), Rred[1] =
+ * U^T Rc (rU columns).  lvl = depth of the node (the tolerances of its decompositions are rtol / lvl, atol / lvl); a node
+ * with lvl == 0 is the root: coupling blocks only.
+ * order (HOST, count entries): (node << 1) | s in dispatch order -- every entry after both sides of both its children; the
+ * root once, with s = 0.  res (DEVICE, 4 ints per node, zeroed by the caller): rU, rV, status (1: a rank above rcap or more
+ * rows than samples somewhere below -- nothing of the node is valid; the caller takes the level-synchronous calls).
+ * rcap in {32, 48, 64}, d <= 256; returns 2 otherwise.  hssk_sweep_status() reports a workgroup that gave up waiting. */
+typedef struct hssk_tnode {
+  int c0, c1, lvl, reserved;
+  double* S[2];
+  int* perm[2];
+  double* Rred[2];
+  int* I[2];
+  double* X[2];
+  double *B01, *B10;
+  double* W[2];
+  int r[2], m[2], flag[2];
+  int status, pad;
+} hssk_tnode;
+typedef struct hssk_elem_src {   /* where scattered entries of the operand come from: A(i, j) = A[i + j lda], or the formula */
+  const double* A;
+  long long lda;
+  hssk_gen gen;
+  int use_gen;
+} hssk_elem_src;
+int hssk_tree_inner(hssk_ctx* ctx, hssk_tnode* nodes, const int* order, int count, int d, int lds, int rcap, double rtol,
+                    double atol, int max_rank, const hssk_elem_src* src, int* res);
+int hssk_tree_rcap_max(void);
+
 /* ---- batched Householder QR ------------------------------------------------------------------- */
 /* A (rows x cols, overwritten) = Q R.  nq > 0: the first nq columns of Q are written to Q
  * (rows x nq, ldq).  rdiag (device, 2 doubles, may be NULL) receives max|R_ii|, min|R_ii| over

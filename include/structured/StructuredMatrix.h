@@ -262,6 +262,11 @@ int SPX_d_blr_front_stats(const SPXBLRFront F, double* out);
 void SPX_d_blr_front_destroy(SPXBLRFront* F);
 /* the hssk kernel context of the matrix (include/hssk.h), for callers that share its stream */
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S);
+/* Diagnostics (process-wide counters): compression rounds whose inner tree levels ran as ONE launch (kernels/hssk_tree.hip; the
+ * default wherever the operand's entries can be read on the device; STRUMPACK_AMD_TREE_LAUNCH=0 switches it off), and how many of
+ * those found a rank above the launch's speculated bound and redid the inner levels one by one. */
+long long SPX_tree_pass_launches(void);
+long long SPX_tree_pass_fallbacks(void);
 /* The library keeps released device chunks in a process-wide cache for reuse (no hipMalloc / hipFree page-table work in solver
  * loops); the cache is invisible to the other allocators of the process (torch, RCCL).  Default cap: a sixth of the device's memory
  * (environment STRUMPACK_AMD_POOL_GB overrides).  _trim returns everything cached to the device now; _set_limit_gb changes the cap

@@ -38,6 +38,8 @@ SP_SYMBOLS = [
     "SPX_d_blr_front_factor", "SPX_d_blr_front_factor_device", "SPX_d_blr_front_time_phases", "SPX_blr_low_rank_algorithm", "SPX_d_blr_front_forward",
     "SPX_d_blr_front_backward", "SPX_d_blr_front_schur", "SPX_d_blr_front_schur_device", "SPX_d_blr_front_tile_ranks",
     "SPX_d_blr_front_stats", "SPX_d_blr_front_destroy",
+    "SPX_tree_pass_launches", "SPX_tree_pass_fallbacks",
+    "SPX_device_pool_cached_bytes", "SPX_device_pool_limit_bytes", "SPX_device_pool_trim", "SPX_device_pool_set_limit_gb",
 ]
 ELEM_CB = C.CFUNCTYPE(C.c_double, C.c_int, C.c_int)
 ALLGATHER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_longlong)
@@ -111,6 +113,13 @@ def load(path):
     L.SPX_d_struct_mult_child.argtypes = [vp, C.c_int, C.c_char, C.c_int, dp, ll, dp, ll, C.c_int]
     L.SPX_d_struct_hssk_ctx.argtypes = [vp]
     L.SPX_d_struct_hssk_ctx.restype = vp
+    for f in ("SPX_tree_pass_launches", "SPX_tree_pass_fallbacks", "SPX_device_pool_cached_bytes", "SPX_device_pool_limit_bytes"):
+        getattr(L, f).argtypes = []
+        getattr(L, f).restype = C.c_longlong
+    L.SPX_device_pool_trim.argtypes = []
+    L.SPX_device_pool_trim.restype = None
+    L.SPX_device_pool_set_limit_gb.argtypes = [C.c_double]
+    L.SPX_device_pool_set_limit_gb.restype = None
     ip = C.POINTER(C.c_int)
     L.SPX_d_struct_extract_blocks.argtypes = [vp, C.c_int, ip, ip, ip, ip, C.POINTER(C.c_void_p), ip, C.c_int, C.c_int]
     L.SPX_d_blr_front_factor.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int,

@@ -628,6 +628,10 @@ void SPX_d_blr_front_destroy(SPXBLRFront* F) {
 
 void* SPX_d_struct_hssk_ctx(const CSPStructMat S) { return hss(S) ? (void*)hss(S)->engine()->ctx() : nullptr; }
 
+// compression rounds whose inner tree levels ran as one launch / that fell back after a rank above the launch's bound
+long long SPX_tree_pass_launches(void) { return strumpack::HSS::tree_pass_launches(); }
+long long SPX_tree_pass_fallbacks(void) { return strumpack::HSS::tree_pass_fallbacks(); }
+
 // The process-wide cache of device chunks (DevicePool.hpp): what it holds is free memory only this library can see
 long long SPX_device_pool_cached_bytes(void) { return (long long)strumpack::DevicePool::get().cached(); }
 long long SPX_device_pool_limit_bytes(void) { return (long long)strumpack::DevicePool::get().limit(); }

@@ -214,6 +214,12 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
       if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
       stats_.rounds++;
       for (size_t h = 0; h < own_by_height_.size(); h++) {
+        // above the leaves: every inner level of the round in ONE launch where that applies (hss_compress_tree.cpp); else,
+        // and after a launch that found a rank above its bound, level by level
+        if (h == 1 && tree_pass(src, d, dd)) {
+          for (size_t hh = 1; hh < own_by_height_.size(); hh++) factor_ahead_level(hh);
+          break;
+        }
         process_level(src, own_by_height_[h], d, dd, false);
         factor_ahead_level(h);   // (EngineOptions::factor_ahead: the settled level's ULV factorization, on its own stream)
       }

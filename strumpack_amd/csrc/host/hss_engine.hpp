@@ -82,6 +82,10 @@ using host_mult_t = std::function<void(char trans, int n, int nrhs, const double
 using host_sample_t = std::function<void(int n, int nrhs, double* R, double* Sr, double* Sc)>;
 using host_elem_t = std::function<void(int m, const int* I, int n, const int* J, double* B, int ldb)>;
 class DeviceHSS;
+// compression rounds whose inner levels ran as one launch (hssk_tree_inner) / that fell back to the level-synchronous path after
+// it reported a rank above its bound -- process-wide counters, for the tests
+long long tree_pass_launches();
+long long tree_pass_fallbacks();
 
 struct PhaseStats {
   double t_compress = 0, t_sketch = 0, t_random = 0, t_tree = 0, t_factor = 0, t_solve = 0, t_mult = 0;
@@ -288,6 +292,7 @@ class DeviceHSS {
   void restart_nodes(int d_have);
   void fill_random(int r0, int dn);
   void process_level(Source& src, const std::vector<int>& ids, int d, int dd, bool original);
+  bool tree_pass(Source& src, int d, int dd);   // all inner levels of a round in one launch (hss_compress_tree.cpp)
   void extract_blocks(Source& src, const std::vector<int>& ids);
   void local_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);
   void reduce_samples(const std::vector<int>& ids, const std::vector<int>& r0, const std::vector<int>& dn);

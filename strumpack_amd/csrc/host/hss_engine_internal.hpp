@@ -208,6 +208,9 @@ struct DeviceHSS::Source {
   // streamed -- decided by the route sample() actually took (a source that multiplies with the dense form of the pattern, or
   // copies the second product of a symmetric operand, says so here)
   virtual double sketch_flops(const DeviceHSS& H, int dn) const;
+  // scattered entries of the operand among this rank's OWN nodes straight from device memory or a formula (the single-launch
+  // tree pass gathers its coupling blocks itself, hssk_tree_inner); false: only extract() can serve them
+  virtual bool device_elems(const DeviceHSS&, hssk_elem_src*) const { return false; }
 };
 
 }  // namespace HSS

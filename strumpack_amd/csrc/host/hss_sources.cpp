@@ -14,6 +14,7 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
   long long lda;
   DenseDeviceSource(const double* a, long long l) : dA(a), lda(l) {}
   bool extract_before_sample() const override { return true; }
+  bool device_elems(const DeviceHSS&, hssk_elem_src* e) const override { e->A = dA; e->lda = lda; e->use_gen = 0; return true; }
   int done_products_ = 2;     // what the last sample() executed (the route is chosen there)
   bool done_sparse_ = false;
   int products(const DeviceHSS&) const override { return done_products_; }
@@ -97,6 +98,12 @@ struct DeviceHSS::ShardedDenseSource : DeviceHSS::Source {
   const double* dCols;
   long long ldc;
   ShardedDenseSource(const double* r, long long lr, const double* c, long long lc) : dRows(r), ldr(lr), dCols(c), ldc(lc) {}
+  // (blocks inside the rank's subtree lie in its column block, addressed with global column indices)
+  bool device_elems(const DeviceHSS& H, hssk_elem_src* e) const override {
+    const Node& c = H.nodes_[H.o_.world == 1 ? 0 : H.cut_nodes_[H.o_.rank]];
+    e->A = dCols - (long long)c.lo * ldc; e->lda = ldc; e->use_gen = 0;
+    return true;
+  }
   void sample(DeviceHSS& H, int r0, int dn) override {
     const bool single = H.o_.world == 1;   // one rank: its "shard" is the whole operand (same code path, no collective)
     if (!single && !H.dist_subtree_) throw std::invalid_argument("sharded operand: the tree cannot be cut into one subtree per rank (world must be a power of two and the tree complete down to that depth)");
@@ -412,6 +419,7 @@ struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
   hssk_gen g;
   explicit GeneratorSource(const hssk_gen& g_) : g(g_) {}
   bool extract_before_sample() const override { return true; }
+  bool device_elems(const DeviceHSS&, hssk_elem_src* e) const override { e->A = nullptr; e->lda = 0; e->gen = g; e->use_gen = 1; return true; }
   int products(const DeviceHSS& H) const override { return H.o_.symmetric ? 1 : 2; }
   void sample(DeviceHSS& H, int r0, int dn) override {
     if (H.sj_pat_) throw std::invalid_argument("generated operand: the SJLT sketch streams a stored matrix; use the Gaussian sketch");

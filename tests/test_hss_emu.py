@@ -115,6 +115,13 @@ def test_generated_operand_fused_sketch(L, n, leaf, kind, d0, dd):
     hk.close()
 
 
+def test_inner_levels_in_one_launch(L):
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(emu_lib.build())
+    HC.check_tree_pass(L, hk)
+    hk.close()
+
+
 def test_factor_ahead_of_the_compression(L):
     HC.check_factor_ahead(L)
 

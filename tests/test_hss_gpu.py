@@ -465,6 +465,15 @@ def test_factor_ahead_of_the_compression(L):
     HC.check_factor_ahead(L, n=6000, leaf=128)
 
 
+def test_inner_levels_in_one_launch(L):
+    """hssk_tree_inner on the MI355X (workgroups of one launch polling each other across XCDs) against the level-synchronous
+    path, BASELINE configs[1]'s shape included (N = 32768, leaf 256, rel_tol 1e-4: 8 levels, 254 workgroups)."""
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(_loader.lib_path())
+    HC.check_tree_pass(L, hk, sizes=((3000, 64, 1e-6), (6000, 128, 1e-6), (515, 64, 1e-6), (32768, 256, 1e-4)))
+    hk.close()
+
+
 def test_symmetric_operand_hint(L):
     hk = K.Hssk(_loader.lib_path())
     HC.check_symmetric_hint(L, hk, n=8192, leaf=128)
