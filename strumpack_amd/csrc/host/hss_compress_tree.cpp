@@ -106,15 +106,18 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
   if (rc == 2) return false;
   ck(rc);
   g_tree_launches++;
-  // ---- the ONE read-back of the tree: ranks, statuses, pivoted orders, skeleton indices
+  // ---- the read-back of the tree, in two pieces: the ranks and statuses first (a few KB) -- with them the exact-size blocks of
+  // the matrix are carved and the copies into them enqueued --, then the pivoted orders and skeleton indices for the host's
+  // tables while the device copies
   const size_t nints = (size_t)(inext - iblock);
   std::vector<int> hall(nints);
-  ck(hssk_memcpy_d2h(ctx_, hall.data(), iblock, (long long)(sizeof(int) * nints)));
+  ck(hssk_memcpy_d2h(ctx_, hall.data(), iblock, (long long)(sizeof(int) * 4 * nt)));
   if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("compress: single-launch tree pass: ") + hssk_last_error());
   for (size_t t = 0; t < nt; t++)
     if (hall[4 * t + 2]) { g_tree_fallbacks++; return false; }   // a rank above the bound: the level-synchronous path redoes the inner levels
   // ---- commit: the node table as process_level leaves it
   std::vector<hssk_colgather_desc> cp;
+  cp.reserve(4 * (size_t)ninner);
   auto keep = [&](const double* from, int rows, int cols) -> double* {   // exact-size block of the matrix (leading dimension max(rows, 1))
     double* to = persist_->dbl((size_t)std::max(rows, 1) * std::max(cols, 1));
     if (rows > 0 && cols > 0) cp.push_back(hssk_colgather_desc{from, to, nullptr, rows, cols, rows, rows, 0});
@@ -126,12 +129,14 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
     if (nd.leaf()) continue;
     const hssk_tnode& q = tab[t];
     Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+    if (nd.lvl != 0) {   // (ranks before the parent's blocks are sized: own_by_height_ order has the children first)
+      nd.mU = a.rU + b.rU; nd.mV = a.rV + b.rV;
+      nd.rU = hall[4 * t]; nd.rV = hall[4 * t + 1];
+    }
     nd.B01 = keep(tmpv[t].B01, a.rU, b.rV);
     nd.B10 = keep(tmpv[t].B10, b.rU, a.rV);
     stats_.f_local += 4.0 * ((double)a.rU * b.rV + (double)b.rU * a.rV) * dtot;
     if (nd.lvl == 0) { nd.Ustate = nd.Vstate = 2; continue; }
-    nd.mU = a.rU + b.rU; nd.mV = a.rV + b.rV;
-    nd.rU = hall[4 * t]; nd.rV = hall[4 * t + 1];
     nd.Srt = q.S[0]; nd.Sct = q.S[1];
     nd.Rrt = nd.Rct = nullptr;   // (an inner node's samples are its children's reduced ones, read in place)
     nd.RrtRed = q.Rred[0]; nd.RctRed = q.Rred[1];
@@ -140,10 +145,6 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
     nd.panels = true;
     for (int s = 0; s < 2; s++) {
       const int m = s == 0 ? nd.mU : nd.mV, r = s == 0 ? nd.rU : nd.rV;
-      const int* hp = hall.data() + (q.perm[s] - iblock);
-      const int* hi = hall.data() + (q.I[s] - iblock);
-      (s == 0 ? nd.hpermU : nd.hpermV).assign(hp, hp + m);
-      (s == 0 ? nd.Ir : nd.Ic).assign(hi, hi + r);
       (s == 0 ? nd.XU : nd.XV) = keep(tmpv[t].X[s], r, m - r);
       (s == 0 ? nd.Ustate : nd.Vstate) = 2;
       const int K = (m > r && r > 0) ? m - r : 0;
@@ -152,6 +153,20 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
     }
   }
   if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
+  // the host's copies of the pivoted orders and skeleton indices (extraction, serialization, the exchanges of a distributed tree)
+  ck(hssk_memcpy_d2h(ctx_, hall.data() + 4 * nt, iblock + 4 * nt, (long long)(sizeof(int) * (nints - 4 * nt))));
+  for (size_t t = 0; t < nt; t++) {
+    Node& nd = nodes_[tnodes[t]];
+    if (nd.leaf() || nd.lvl == 0) continue;
+    const hssk_tnode& q = tab[t];
+    for (int s = 0; s < 2; s++) {
+      const int m = s == 0 ? nd.mU : nd.mV, r = s == 0 ? nd.rU : nd.rV;
+      const int* hp = hall.data() + (q.perm[s] - iblock);
+      const int* hi = hall.data() + (q.I[s] - iblock);
+      (s == 0 ? nd.hpermU : nd.hpermV).assign(hp, hp + m);
+      (s == 0 ? nd.Ir : nd.Ic).assign(hi, hi + r);
+    }
+  }
   return true;
 }
 

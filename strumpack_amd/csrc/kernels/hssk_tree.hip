@@ -181,15 +181,21 @@ __global__ __launch_bounds__(TR_T) HSSK_WAVES_PER_SIMD(2) void tree_inner_kernel
         if (k0 + u < K) tr_fma_row<RC>(acc, mk[u], C + (k0 + u) * sk, sj, J);
     }
     const int off = hb == 0 ? 0 : ra[s];
+    // (the gathered columns eight at a time: eight coherent loads in flight, then their stores -- one load per store would be a
+    // memory round trip per column)
 #pragma unroll
     for (int jb = 0; jb < RC / 8; jb++) {
       if (8 * jb < J) {
+        double g[8];
 #pragma unroll
-        for (int j = 8 * jb; j < 8 * jb + 8; j++) {
-          if (live && j < J) {
-            const double g = hssk_cload(G, (size_t)i + (size_t)s_pc[hb][j] * lds);
-            hssk_cstore(S, (size_t)i + (size_t)(off + j) * lds, g - acc[j]);
-          }
+        for (int u = 0; u < 8; u++) {
+          const int j = 8 * jb + u;
+          g[u] = (live && j < J) ? hssk_cload(G, (size_t)i + (size_t)s_pc[hb][j] * lds) : 0.;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = 8 * jb + u;
+          if (live && j < J) hssk_cstore(S, (size_t)i + (size_t)(off + j) * lds, g[u] - acc[j]);
         }
       }
     }
@@ -209,7 +215,10 @@ __global__ __launch_bounds__(TR_T) HSSK_WAVES_PER_SIMD(2) void tree_inner_kernel
     p.max_rank = P.max_rank;
     p.perm = perm; p.rank = nullptr; p.work = nullptr;
     p.src = S; p.lds = lds; p.defer_x = 1;
-    rank = id_reg_body<RT, CT, 8>(p);
+    // (a Householder step costs per column slot of the register tile: panels of up to 64 / 96 columns take the narrower tiles)
+    if (CT >= 3 && m <= 64) rank = id_reg_body<RT, 2, 8>(p);
+    else if (CT >= 4 && m <= 96) rank = id_reg_body<RT, 3, 8>(p);
+    else rank = id_reg_body<RT, CT, 8>(p);
   }
   if (rank > RC) { publish(0, 1); return; }
   // the pivoted order: into the LDS for the steps below, and out again with coherent stores for the parent
@@ -282,12 +291,16 @@ __global__ __launch_bounds__(TR_T) HSSK_WAVES_PER_SIMD(2) void tree_inner_kernel
 #pragma unroll
     for (int jb = 0; jb < JB / 8; jb++) {
       if (8 * jb < J) {
+        double g[8];
 #pragma unroll
-        for (int j = 8 * jb; j < 8 * jb + 8; j++) {
-          if (live && j < J) {
-            const double g = hssk_cload(col(s_perm[j0 + j]), (size_t)i);
-            hssk_cstore(out, (size_t)i + (size_t)(j0 + j) * lds, g + acc[j]);
-          }
+        for (int u = 0; u < 8; u++) {
+          const int j = 8 * jb + u;
+          g[u] = (live && j < J) ? hssk_cload(col(s_perm[j0 + j]), (size_t)i) : 0.;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = 8 * jb + u;
+          if (live && j < J) hssk_cstore(out, (size_t)i + (size_t)(j0 + j) * lds, g[u] + acc[j]);
         }
       }
     }
