@@ -323,12 +323,9 @@ def blr_front_workload(a, L, hk, torch):
            "blr": {"max_rank": int(st["max_rank"]), "mean_rank": float(lr.mean()) if lr.size else 0.0,
                    "nnz": [st["nnz11"], st["nnz12"], st["nnz21"]], "dense_nnz": [ds * ds, ds * du, du * ds]},
            "checks": {"schur_err_vs_dense": err(S, Sx), "B11_solve_resid": err(fr["F11"] @ x, b)},
-           "roofline": {"kernel": "gemm_vbatched_kernel (the three batched GEMMs of a block step's Schur update, v_mfma_f64_16x16x4_f64)",
-                        "bound": "hbm" if hbm_bound else "mfma", "achieved": gbs if hbm_bound else ach, "peak": 8000.0 if hbm_bound else PEAK_FP64_MFMA_TFLOPS,
-                        "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gbs / 8000.0) if hbm_bound else ach / PEAK_FP64_MFMA_TFLOPS,
-                        "traffic": None, "phase_ms": ms_schur, "launches_per_step": int(st["schur_launches"]),
-                        "flops_per_step": st["f_schur"], "bytes_per_step": st["b_schur"], "tflops": ach, "mfma_frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                        "note": "HIP events on the engine's stream around the Schur-update launches of every block step (hssk_watch_*), summed over the step"}}
+           "roofline": blr_roofline({"lu_diag": pmed("ms_lu"), "compress_tiles": pmed("ms_compress"), "trsm": pmed("ms_trsm"), "schur_gemm": ms_schur},
+                                    st, fr["tiles1"], ms_schur, ach, gbs, hbm_bound)}
+    out["roofline"]["note"] = "phases: HIP events on the engine's stream around the launches of each kind in every block step (hssk_watch_*), summed over the step"
     if not a.no_cpu_baseline:
         try:
             from oracle import ref_lib as R
@@ -342,6 +339,42 @@ def blr_front_workload(a, L, hk, torch):
             out["cpu_baseline"] = {"error": str(e)[:200]}
     print(json.dumps(out))
     F.destroy()
+
+
+def blr_roofline(phases, st, tiles1, ms_schur, ach, gbs, hbm_bound):
+    """`roofline` of a BLR front line: that of the LARGEST of the four phases on the one-stream device clock (diagonal LUs, tile
+    compression, triangular solves, Schur GEMMs)."""
+    # the line's roofline is that of the LARGEST of the four phases on the one-stream device clock
+    sizes1 = [int(t_) for t_ in tiles1]
+    f_lu = sum(2.0 / 3.0 * t_ ** 3 for t_ in sizes1)
+    dominant = max(phases, key=lambda k_: phases[k_])
+    if dominant == "schur_gemm":
+        roof = {"kernel": "gemm_vbatched_kernel (Schur updates of the trailing array, deferred over blocks of block steps; v_mfma_f64_16x16x4_f64)",
+                "bound": "hbm" if hbm_bound else "mfma", "achieved": gbs if hbm_bound else ach, "peak": 8000.0 if hbm_bound else PEAK_FP64_MFMA_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gbs / 8000.0) if hbm_bound else (ach / PEAK_FP64_MFMA_TFLOPS), "traffic": None,
+                "phase_ms": ms_schur, "flops_per_step": st["f_schur"], "bytes_per_step": st["b_schur"], "tflops": ach, "mfma_frac": ach / PEAK_FP64_MFMA_TFLOPS}
+    elif dominant == "lu_diag":
+        # LU with partial pivoting of the diagonal tiles, one after the other: a chain of elimination steps on one workgroup each
+        # (getrf_quad_kernel up to 192 rows -- the tile in registers --, getrf_wg2_kernel beyond); priced against the FP64 roof of
+        # the chip to say how far a serial chain sits from any throughput bound
+        a_lu = f_lu / (phases["lu_diag"] * 1e-3) * 1e-12 if phases["lu_diag"] > 0 else 0.0
+        roof = {"kernel": "getrf_quad_kernel / getrf_wg2_kernel + trtri_diag_kernel (LU of the %d diagonal tiles of the separator, a serial chain: "
+                          "%.3f ms per tile)" % (len(sizes1), phases["lu_diag"] / max(len(sizes1), 1)),
+                "bound": "mfma", "achieved": a_lu, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a_lu / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": None, "phase_ms": phases["lu_diag"], "flops_per_step": f_lu}
+    else:
+        # tile compression (truncated pivoted QR of every off-diagonal tile: a chain of dependent Householder steps per tile) or
+        # the triangular solves with the diagonal tile: their flops against the FP64 rate say how far from any throughput bound
+        # a latency chain sits
+        f_rest = max(st["f_total"] - st["f_schur"] - f_lu, 0.0)
+        what = ("id_group_kernel / id_reg_kernel (truncated pivoted QR of the tiles of a block row and column: latency chain of Householder steps)"
+                if dominant == "compress_tiles" else "trsm_fused_kernel / laswp (triangular solves of a block row and column with the diagonal tile)")
+        roof = {"kernel": what, "bound": "mfma", "achieved": f_rest / (phases[dominant] * 1e-3) * 1e-12 if phases[dominant] > 0 else 0.0,
+                "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None, "phase_ms": phases[dominant],
+                "note": "flops = everything but the Schur GEMMs and the diagonal LUs (triangular solves and compression together: an upper bound of the phase's own)"}
+        roof["frac"] = roof["achieved"] / PEAK_FP64_MFMA_TFLOPS
+    roof["dominant_phase"] = dominant
+    return roof
 
 
 def blr_front_device_workload(a, L, hk, torch, BF, nx, ny, leaf):
@@ -415,21 +448,7 @@ def blr_front_device_workload(a, L, hk, torch, BF, nx, ny, leaf):
     ach = st["f_schur"] / (ms_schur * 1e-3) * 1e-12 if ms_schur > 0 else 0.0
     gbs = st["b_schur"] / (ms_schur * 1e-3) * 1e-9 if ms_schur > 0 else 0.0
     hbm_bound = st["b_schur"] / 8000e9 > st["f_schur"] / (PEAK_FP64_MFMA_TFLOPS * 1e12)
-    dominant = max(("compress_tiles", "schur_gemm"), key=lambda k_: phases[k_])
-    if dominant == "schur_gemm":
-        roof = {"kernel": "gemm_vbatched_kernel (Schur updates of the trailing array, deferred over blocks of block steps; v_mfma_f64_16x16x4_f64)",
-                "bound": "hbm" if hbm_bound else "mfma", "achieved": gbs if hbm_bound else ach, "peak": 8000.0 if hbm_bound else PEAK_FP64_MFMA_TFLOPS,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gbs / 8000.0) if hbm_bound else (ach / PEAK_FP64_MFMA_TFLOPS), "traffic": None,
-                "phase_ms": ms_schur, "flops_per_step": st["f_schur"], "bytes_per_step": st["b_schur"], "tflops": ach, "mfma_frac": ach / PEAK_FP64_MFMA_TFLOPS}
-    else:
-        # tile compression: truncated pivoted QR of every off-diagonal tile, a chain of dependent Householder steps per tile (its
-        # flops against the FP64 vector rate say how far from any throughput bound a latency chain sits)
-        f_comp = st["f_total"] - st["f_schur"]
-        roof = {"kernel": "id_group_kernel / id_reg_kernel (truncated pivoted QR of the tiles of a block row and column: latency chain of Householder steps)",
-                "bound": "mfma", "achieved": f_comp / (phases["compress_tiles"] * 1e-3) * 1e-12 if phases["compress_tiles"] > 0 else 0.0,
-                "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None, "phase_ms": phases["compress_tiles"],
-                "note": "flops = everything but the Schur GEMMs (LU, triangular solves and compression: an upper bound of the phase's own)"}
-        roof["frac"] = roof["achieved"] / PEAK_FP64_MFMA_TFLOPS
+    roof = blr_roofline(phases, st, fr["tiles1"], ms_schur, ach, gbs, hbm_bound)
     out = {"metric": "blr_front_partial_factor_gflops", "value": st["f_total"] / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -268,7 +268,7 @@ void* SPX_d_struct_hssk_ctx(const CSPStructMat S);
 long long SPX_tree_pass_launches(void);
 long long SPX_tree_pass_fallbacks(void);
 /* The library keeps released device chunks in a process-wide cache for reuse (no hipMalloc / hipFree page-table work in solver
- * loops); the cache is invisible to the other allocators of the process (torch, RCCL).  Default cap: a sixth of the device's memory
+ * loops); the cache is invisible to the other allocators of the process (torch, RCCL).  Default cap: a fifth of the device's memory
  * (environment STRUMPACK_AMD_POOL_GB overrides).  _trim returns everything cached to the device now; _set_limit_gb changes the cap
  * (and trims down to it; 0 = cache nothing). */
 long long SPX_device_pool_cached_bytes(void);

@@ -107,6 +107,12 @@ __device__ __forceinline__ void hssk_wave_argmax(double& v, int& idx) {
   }
   v = bv; idx = bi;
 }
+// value of `v` in lane Q of the caller's quad (lanes 4 g .. 4 g + 3): one DPP quad_perm move per half
+template <int Q>
+__device__ __forceinline__ double hssk_quad_bcast(double v) { return hssk_dpp_mov0<Q | (Q << 2) | (Q << 4) | (Q << 6), 0xF>(v); }
+// value of `v` in lane Q (0 / 1) of the caller's pair of lanes (2 g, 2 g + 1)
+template <int Q>
+__device__ __forceinline__ double hssk_pair_bcast(double v) { return hssk_dpp_mov0<Q | (Q << 2) | ((2 + Q) << 4) | ((2 + Q) << 6), 0xF>(v); }
 // non-zero if `pred` holds in any lane of the wave
 __device__ __forceinline__ int hssk_any(int pred) { return __any(pred); }
 __device__ __forceinline__ double hssk_wave_max(double v) {

@@ -54,16 +54,16 @@ class DevicePool {
   std::mutex mu_;
   std::map<size_t, std::vector<void*>> free_;
   // Bytes kept for reuse.  The cache is only ever trimmed by this library (on its own failed allocation, set_limit, trim), so
-  // what it holds is invisible to the other allocators of the process (torch, RCCL): the default cap is a SIXTH of the device's
-  // memory (48 of the 288 GB of an MI355X -- the working array + block products of a 60000-row BLR front are ~45 GB --, 10 GB of
-  // a 64 GB part), STRUMPACK_AMD_POOL_GB overrides it, SPX_device_pool_trim / SPX_device_pool_set_limit_gb manage it at run time.
+  // what it holds is invisible to the other allocators of the process (torch, RCCL): the default cap is a FIFTH of the device's
+  // memory (57 of the 288 GB of an MI355X -- the working array + block products of a 60000-row BLR front are ~48 GB: with less,
+  // every factorization of such a front pays a hipFree and a hipMalloc of tens of GB, half a second --, 13 GB of a 64 GB part), STRUMPACK_AMD_POOL_GB overrides it, SPX_device_pool_trim / SPX_device_pool_set_limit_gb manage it at run time.
   void ensure_limit() {
     if (limit_set_) return;
     limit_set_ = true;
     const char* e = std::getenv("STRUMPACK_AMD_POOL_GB");
     if (e) { limit_ = (size_t)std::max(0, std::atoi(e)) << 30; return; }
     const long long tot = hssk_device_total_bytes();
-    limit_ = tot > 0 ? (size_t)tot / 6 : (size_t)8 << 30;
+    limit_ = tot > 0 ? (size_t)tot / 5 : (size_t)8 << 30;
   }
   size_t cached_ = 0, limit_ = 0;
   bool limit_set_ = false;

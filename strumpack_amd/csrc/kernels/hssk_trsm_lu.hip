@@ -906,6 +906,7 @@ int hssk_trsm_vbatched(hssk_ctx* ctx, const hssk_trsm_desc* descs_in, int count)
   HSSK_API_END
 }
 
+bool hssk_getrf_row_launch(hssk_ctx* ctx, const hssk_lu_desc* dd, int count, int nmax);   // hssk_lu_row.hip
 int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
@@ -918,7 +919,9 @@ int hssk_getrf_vbatched(hssk_ctx* ctx, const hssk_lu_desc* descs, int count) {
   // that much (gfx90a / gfx942: 64 KB) the global-memory kernels below serve every size
   static const size_t lds_cap = hssk_rt::max_lds_per_workgroup();
   const bool wg_fits = sizeof(double) * ((size_t)(nmax | 1) * LUW_NB + (size_t)(LUW_NB + 1) * (nmax <= 256 ? LUW_CHW_SMALL : LUW_CH)) <= lds_cap;
-  if (nmax <= LU_LDS_N) {
+  if (hssk_getrf_row_launch(ctx, dd, count, nmax)) {
+    // (up to 192 rows: the whole matrix in the registers of one workgroup, hssk_lu_row.hip)
+  } else if (nmax <= LU_LDS_N) {
     HSSK_LAUNCH(getrf_lds_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);
   } else if (!wg_fits && nmax <= 384) {
     HSSK_LAUNCH(getrf_kernel, dim3((unsigned)count), dim3(LU_THREADS), 0, ctx->stream, dd);

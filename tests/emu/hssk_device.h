@@ -82,6 +82,8 @@ inline void hssk_wave_argmax(double& v, int& idx) {
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
 }
+template <int Q> inline double hssk_quad_bcast(double v) { return emu::wave_xchg(v, (int)((threadIdx.x & 60) | Q)); }
+template <int Q> inline double hssk_pair_bcast(double v) { return emu::wave_xchg(v, (int)((threadIdx.x & 62) | Q)); }
 template <int N>
 inline void hssk_row_sum_n(double (&v)[N]) {
   for (int i = 0; i < N; i++) v[i] = hssk_row_sum(v[i]);

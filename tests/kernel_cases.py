@@ -486,7 +486,8 @@ def case_trsm_lu(hk, seed=9, big_lu=(600, 3), extra_lu=()):
         assert np.allclose(dB.get(), ref, atol=1e-11 * max(1.0, np.abs(ref).max())), f"trsm lower={lower} trans={trans} n={T.shape[0]}"
     # 130 .. 512: one workgroup with the panel in LDS (getrf_wg_kernel: ragged last panel, several 64-column passes over
     # the trailing matrix); the last one takes the multi-launch blocked path (n > 512)
-    for n, nrhs in [(1, 1), (45, 3), (130, 1), (161, 2), (256, 2)] + list(extra_lu) + [big_lu]:
+    # (up to 192 rows: the whole matrix in the registers of one workgroup, getrf_quad_kernel -- every instantiation's edges)
+    for n, nrhs in [(1, 1), (45, 3), (96, 2), (97, 1), (128, 1), (130, 1), (156, 2), (160, 1), (161, 2), (192, 1), (193, 1), (256, 2)] + list(extra_lu) + [big_lu]:
         A = r.standard_normal((n, n))
         B = r.standard_normal((n, nrhs))
         dA, dB = hk.array(A), hk.array(B)
@@ -503,7 +504,7 @@ def case_trsm_lu(hk, seed=9, big_lu=(600, 3), extra_lu=()):
     # and 1, then multiples of 1/2), so their ties are real and the first candidate in the interchanged order must win, as in
     # dgetf2; later steps round (ties there are resolved by the order of the updates, LAPACK's own differs between versions):
     # the factorization is checked as one -- P A = L U, |L| <= 1
-    for n in [140, 256] + [e[0] for e in extra_lu]:
+    for n in [90, 140, 180, 256] + [e[0] for e in extra_lu]:
         A = r.integers(1, 3, size=(n, n)).astype(float) * r.choice([-1.0, 1.0], size=(n, n))
         dA, dpiv, dinfo = hk.array(A), hk.empty((n,), np.int32), hk.empty((1,), np.int32)
         hk.batch("hssk_getrf_vbatched", [K.LuDesc(dA.ptr, n, n, dpiv.ptr, dinfo.ptr)])

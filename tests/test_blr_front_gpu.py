@@ -67,3 +67,64 @@ def test_front_device_operands(L):
     Fd.destroy()
     Fh.destroy()
     hk.close()
+
+
+@pytest.mark.parametrize("nx,ny,upd", [(200, 200, "none"), (200, 100, "both")])
+def test_front_at_the_200cubed_problems_own_sizes(L, nx, ny, upd):
+    """BASELINE configs[4] at ITS front sizes -- what the reference hands to BLRMatrix::construct_and_partial_factor
+    (BLR/BLRMatrix.cpp:740) on the 200^3 Poisson problem: the root separator (a 200 x 200 plane: dsep 40000, no update part)
+    and a second-level front (200 x 100 plane: dsep 20000, dupd 40000).  The reference's routine needs minutes to hours on
+    these, so the checks are the size-independent properties of a partial factorization, on the device (torch is plumbing):
+    F11 (B11 \ b) = b to the compression tolerance; the Schur complement applied to sampled vectors against dense algebra
+    (F22 R - F21 F11^{-1} F12 R with a dense solve); low-rank tiles only where the rank pays (r (m + n) <= m n,
+    BLRMatrix.cpp:568) and ranks that do not grow when the tolerance is loosened."""
+    import torch
+    import blr_fronts as BF
+    from strumpack_amd import dist as sdist
+    leaf = 256
+    fr = BF.poisson_front_device(torch, nx, ny, 8, 8, leaf, upd=upd)
+    ds, du = fr["ds"], fr["du"]
+    ptr = lambda k: fr[k].data_ptr() if k in fr else None
+    rng = np.random.default_rng(5)
+    b, bu = rng.standard_normal((ds, 2)), (rng.standard_normal((du, 2)) if du else None)
+    dev = fr["F11"].device
+    ranks = {}
+    for rtol in (1e-4, 1e-2):
+        o = capi.StructuredMatrix.options(L, rel_tol=rtol, abs_tol=1e-12 * fr["norm"], type=capi.SP_TYPE_BLR)
+        torch.cuda.synchronize()
+        F = capi.BLRFront.factor_device(L, ds, du, ptr("F11"), ds, ptr("F12cm"), ds, ptr("F21cm"), max(du, 1), ptr("F22"), max(du, 1),
+                                        fr["tiles1"], fr["tiles2"], o)
+        rk = F.tile_ranks()
+        ranks[rtol] = rk
+        nt = len(fr["tiles1"]) + len(fr["tiles2"])
+        sizes = np.array(list(fr["tiles1"]) + list(fr["tiles2"]))
+        assert rk.shape == (nt, nt)
+        lr = rk >= 0
+        # (the diagonal is never compressed; a low-rank tile pays for itself)
+        assert not lr[np.arange(nt), np.arange(nt)].any()
+        mm, nn = np.meshgrid(sizes, sizes, indexing="ij")
+        assert (rk[lr] * (mm[lr] + nn[lr]) <= mm[lr] * nn[lr]).all()
+        if rtol == 1e-4:
+            ys, yu = F.forward(b, bu)
+            x = F.backward(ys, np.zeros_like(bu) if du else None)
+            xt, bt = torch.from_numpy(np.ascontiguousarray(x)).to(dev), torch.from_numpy(b).to(dev)
+            resid = float(torch.linalg.norm(fr["F11"] @ xt - bt) / torch.linalg.norm(bt))     # (F11 symmetric: row-major == column-major)
+            assert resid <= 20 * rtol, resid
+            if du:
+                R = torch.from_numpy(rng.standard_normal((du, 4))).to(dev)
+                sp, ld = F.schur_device()
+                St = sdist._tensor(sp, ld * du, True).view(du, ld)[:, :du]        # St[j, i] = S(i, j)
+                SR = St.t() @ R
+                ref = fr["F22"] @ R - fr["F21cm"].t() @ torch.linalg.solve(fr["F11"], fr["F12cm"].t() @ R)
+                err = float(torch.linalg.norm(SR - ref) / torch.linalg.norm(ref))
+                assert err <= 20 * rtol, err
+                del St, SR, ref, R
+        F.destroy()
+    both = (ranks[1e-4] >= 0) & (ranks[1e-2] >= 0)
+    # (tile by tile up to the noise of the running Schur complements -- the two factorizations update with different
+    # approximations --, strictly in the sum and in the largest rank)
+    assert (ranks[1e-2][both] <= ranks[1e-4][both] + 2).all()
+    assert ranks[1e-2][both].sum() < ranks[1e-4][both].sum() and ranks[1e-2].max() <= ranks[1e-4].max()
+    del fr
+    torch.cuda.empty_cache()
+    L.SPX_device_pool_trim()
