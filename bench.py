@@ -44,7 +44,7 @@ def parse():
                    help="toeplitz workload: tell the library that a factorization follows -- it enqueues every tree level's ULV factorization "
                    "on a second stream as soon as the compression has settled the level (SPXHSSOptions::factor_ahead).  Default: on for "
                    "N > 1 (a rank's subtree leaves the chip room beside the compression: 18.5 -> 17.7 ms per step in the 8-rank model, "
-                   "profiles/r04_scale_model.json), off at N = 1 (no gain: both phases want the whole chip, DESIGN.md section 9j)")
+                   "profiles/r04_scale_model.json), off at N = 1 (no gain: both phases want the whole chip, DESIGN.md section 2)")
     p.add_argument("--symmetric", action="store_true", help="toeplitz workload, SECONDARY line: declare the operand symmetric (SPXHSSOptions::symmetric_operand = 2, "
                    "checked on a sample): A^T R = A R, the second sketch GEMM is a copy; `value` counts the executed flops")
     p.add_argument("--cpu-n", type=int, default=32768)
@@ -649,7 +649,7 @@ def main():
 
     opts = capi.StructuredMatrix.options(L, rel_tol=a.rel_tol, abs_tol=1e-8, leaf_size=a.leaf, max_rank=50000)
     # --factor-ahead: at N = 1 no gain (the leaf level's factorization and the first inner levels of the compression both
-    # want the whole chip, DESIGN.md section 9j); on a rank's subtree of N > 1 ranks it hides most of the factorization
+    # want the whole chip, DESIGN.md section 2); on a rank's subtree of N > 1 ranks it hides most of the factorization
     if a.factor_ahead is None:
         a.factor_ahead = world > 1
     hopts = capi.StructuredMatrix.hss_options(L, random_engine="philox", sketch=a.sketch, factor_ahead=a.factor_ahead,

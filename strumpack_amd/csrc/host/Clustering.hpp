@@ -166,7 +166,7 @@ inline void label_kd(const Points& p, std::vector<int>& label, int nc[2]) {
 // each labels its points in pieces): a piece that finds the budget spent, or whose thread cannot be started, runs on the
 // caller's thread instead.  Exceptions of a piece are carried to the caller after every started thread has been joined.
 inline std::atomic<int>& live_threads() { static std::atomic<int> n{0}; return n; }
-inline int thread_budget() { return (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency())); }
+inline int thread_budget() { return (int)std::max(1u, std::min(512u, 2 * std::thread::hardware_concurrency())); }
 struct ThreadSlot {   // one unit of the budget, held while a forked thread lives
   bool ok;
   ThreadSlot() : ok(live_threads().fetch_add(1) < thread_budget()) { if (!ok) live_threads().fetch_sub(1); }

@@ -594,9 +594,6 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
   __syncthreads();
 
   int rank = kmax;
-#ifdef IDG_TIMING
-  long long tacc[5] = {0, 0, 0, 0, 0};
-#endif
   // (one copy of the step for every 16-row register block `rk` -- the register kernel's form -- costs 2800 instructions per
   //  block and, at 256 rows, 350 bytes of spills per lane: 11.4 us per step.  Here rk is a run-time value: the entries of row
   //  k are picked out of the lane's RT registers of a column with compare-selects.)
@@ -604,9 +601,6 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
     for (int k = 0; k < kmax; k++) {
       const int rk = k >> 4, lk = k & 15;
       double* xs = xw + (size_t)k * SW;   // this step's words: [H values][H columns][16 RT reflector rows][tau, stop, |R_kk|]
-#ifdef IDG_TIMING
-      long long tq0 = hssk_wallclock();
-#endif
       // ---- 1. pivot: this workgroup's first arg max over its unused columns ...
       {
         double bv = -1.;
@@ -630,9 +624,6 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         if (lane == 0) { s_val[wave] = wv; s_idx[wave] = wi; }
       }
       __syncthreads();
-#ifdef IDG_TIMING
-      long long tq1 = hssk_wallclock();
-#endif
       double gv = s_val[lane & (NW - 1)];
       int pcol = s_idx[lane & (NW - 1)];
       hssk_row_argmax(gv, pcol);
@@ -647,9 +638,6 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         if (isidx) s_oidx[q] = got; else s_oval[q] = got;
       }
       __syncthreads();
-#ifdef IDG_TIMING
-      long long tq2 = hssk_wallclock();
-#endif
 #pragma unroll
       for (int q = 0; q < H; q++) {
         const double v = s_oval[q];
@@ -724,9 +712,6 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         else if (tid < 16 * RT + 3) s_msg[tid - 16 * RT] = idg_take(xs, (size_t)(2 * H + tid), err);
       }
       __syncthreads();
-#ifdef IDG_TIMING
-      long long tq3 = hssk_wallclock();
-#endif
       if (tid == 0) {
         if (k == 0) s_r00 = s_msg[2];
         s_perm[k] = pcol;
@@ -801,17 +786,8 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void id_group_
         if (act && l16 == 0) s_vn1[lc] = newn1;
       }
       __syncthreads();   // (the step's LDS words are rewritten by the next one)
-#ifdef IDG_TIMING
-      if (tid == 0) {
-        const long long tq4 = hssk_wallclock();
-        tacc[0] += tq1 - tq0; tacc[1] += tq2 - tq1; tacc[2] += tq3 - tq2; tacc[3] += tq4 - tq3; tacc[4] += (h == owner);
-      }
-#endif
     }
   }
-#ifdef IDG_TIMING
-  if (tid == 0) for (int q = 0; q < 5; q++) p.work[8 * h + q] = (double)tacc[q];
-#endif
   // ---- pivoted column positions: skeleton columns first (pivot order), then the rest in index order (every workgroup works
   // the whole table out: the pivots of all steps are known to all)
   __syncthreads();

@@ -186,9 +186,13 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
         if (may_stop && s_stop) { done = true; break; }
         const double tau = s_tau[k];
         if (tau != 0.) {
+          // The reflector is zero above row k: the row registers below rk (static in the unrolled step loop) take no part --
+          // neither in the dot products (their terms are exact zeros: the sums keep their values bit for bit, the even / odd
+          // pairing of the partial sums included) nor in the update.  On the square-ish panels (a 208 x 195 TSQR chunk, the
+          // 195 x 170 panels of the ULV factorization) that is half the arithmetic of the factorization.
           double vr[RT];
 #pragma unroll
-          for (int r = 0; r < RT; r++) vr[r] = sv[l16 + 16 * r];
+          for (int r = 0; r < RT; r++) vr[r] = r >= rk ? sv[l16 + 16 * r] : 0.;
           // all dot products of the wave's slots first, their row sums stage by stage (independent chains in flight)
           double dot[CT];
 #pragma unroll
@@ -196,8 +200,12 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
             double d0 = 0., d1 = 0.;
             if (c >= kc) {
 #pragma unroll
-              for (int r = 0; r + 1 < RT; r += 2) { d0 += vr[r] * a[c][r]; d1 += vr[r + 1] * a[c][r + 1]; }
-              if (RT & 1) d0 += vr[RT - 1] * a[c][RT - 1];
+              for (int r = 0; r < RT; r++) {
+                if (r >= rk) {
+                  if ((r & 1) == 0) d0 += vr[r] * a[c][r];
+                  else d1 += vr[r] * a[c][r];
+                }
+              }
             }
             dot[c] = d0 + d1;
           }
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(NW * 64) HSSK_WAVES_PER_SIMD(NW / 4) void qr_reg_ke
             const int col = grp + NC * c;
             const double f = (col > k && col < cols) ? dot[c] * tau : 0.;
 #pragma unroll
-            for (int r = 0; r < RT; r++) a[c][r] -= f * vr[r];
+            for (int r = 0; r < RT; r++)
+              if (r >= rk) a[c][r] -= f * vr[r];
           }
         }
       }

@@ -183,12 +183,6 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
   const int n = p.n, lda = p.lda;
   double* __restrict__ A = p.A;
   int info = 0;
-#ifdef LUW_TIMING
-  long long tacc[5] = {0, 0, 0, 0, 0}, tq = hssk_wallclock();
-#define LUW_STAMP(q) { __syncthreads(); const long long t_ = hssk_wallclock(); tacc[q] += t_ - tq; tq = t_; }
-#else
-#define LUW_STAMP(q)
-#endif
   for (int j0 = 0; j0 < n; j0 += LUW_NB) {
     const int nb = min(LUW_NB, n - j0), mp = n - j0, LP = mp | 1, jend = j0 + nb;
     double* s_P = s_dyn;                              // mp x nb panel, leading dimension LP
@@ -197,7 +191,6 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       for (int i = tid; i < mp; i += LUW_T) s_P[i + j * LP] = hssk_gload(A, (size_t)(j0 + i) + (size_t)(j0 + j) * lda);
     for (int e = tid; e < mp; e += LUW_T) s_src[e] = e;
     __syncthreads();
-    LUW_STAMP(0)
     for (int k = 0; k < nb; k++) {
       // ---- pivot: first arg max_{i >= k} |P(i, k)|  (one row per thread: mp <= 512)
       double bv = -1.;
@@ -235,7 +228,6 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       }
       __syncthreads();
     }
-    LUW_STAMP(1)
     // ---- L = P(:, k) / pivot below the diagonal; panel back to global memory
     for (int j = 0; j < nb; j++)
       for (int i = tid; i < mp; i += LUW_T) {
@@ -279,7 +271,6 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       }
     }
     __syncthreads();
-    LUW_STAMP(2)
     // ---- trailing matrix, LUW_CH columns at a time
     constexpr int LU_ = LUW_NB + 1;
     for (int c0 = jend; c0 < n; c0 += LUW_CH) {
@@ -324,11 +315,7 @@ __global__ __launch_bounds__(LUW_T) void getrf_wg_kernel(const hssk_lu_desc* __r
       }
       __syncthreads();
     }
-    LUW_STAMP(3)
   }
-#ifdef LUW_TIMING
-  if (tid == 0 && blockIdx.x == 0) printf("getrf_wg n %d: us  panel load %.1f  steps %.1f  write-back + interchange %.1f  trailing %.1f\n", n, tacc[0] / 100., tacc[1] / 100., tacc[2] / 100., tacc[3] / 100.);
-#endif
   if (tid == 0) *p.info = info;
 }
 

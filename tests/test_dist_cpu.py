@@ -54,8 +54,10 @@ for (n, leaf, d0, dd, algo, sketch) in CASES[world]:
     H.destroy(); H1.destroy()
 # sharded operand: every rank passes only its row block + column block, or only its column block (column-sharded operator:
 # the Sr contributions are reduced over the ranks); must reproduce the single-process matrix built from the whole A
-BCASES = {2: [(120, 16, 16, 8, "stable", True), (120, 16, 16, 8, "stable", False), (75, 8, 8, 8, "original", False)],
-          4: [(140, 16, 8, 8, "stable", True), (140, 16, 8, 8, "stable", False)], 3: []}
+# (the cases with 64 + 32 samples take the single-launch tree pass on the rank's own levels -- coupling blocks read from the
+#  rank's column block with global indices --, the others, with too few samples for its rank bound, the level path)
+BCASES = {2: [(120, 16, 16, 8, "stable", True), (120, 16, 16, 8, "stable", False), (75, 8, 8, 8, "original", False), (300, 32, 64, 32, "stable", True)],
+          4: [(140, 16, 8, 8, "stable", True), (140, 16, 8, 8, "stable", False), (600, 32, 64, 32, "stable", False)], 3: []}
 for (n, leaf, d0, dd, algo, with_rows) in BCASES[world]:
     A = O.toeplitz(n) + 0.01 * np.random.default_rng(2).standard_normal((n, n))     # unsymmetric: rows and columns differ
     o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
