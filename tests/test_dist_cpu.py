@@ -60,6 +60,9 @@ BCASES = {2: [(120, 16, 16, 8, "stable", True), (120, 16, 16, 8, "stable", False
           4: [(140, 16, 8, 8, "stable", True), (140, 16, 8, 8, "stable", False), (600, 32, 64, 32, "stable", False)], 3: []}
 for (n, leaf, d0, dd, algo, with_rows) in BCASES[world]:
     A = O.toeplitz(n) + 0.01 * np.random.default_rng(2).standard_normal((n, n))     # unsymmetric: rows and columns differ
+    if d0 + dd >= 96:   # (compressible in one round: an unsymmetric perturbation of rank 3 instead of full-rank noise)
+        g2 = np.random.default_rng(2)
+        A = O.toeplitz(n) + 0.05 * g2.standard_normal((n, 3)) @ g2.standard_normal((3, n))
     o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
     # (factor_ahead on the rank's own levels when the row block is given: the cut exchange and the replicated top follow in factor())
     h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo, factor_ahead=with_rows)
@@ -67,7 +70,11 @@ for (n, leaf, d0, dd, algo, with_rows) in BCASES[world]:
     dR = hk.array(np.asfortranarray(A[lo:hi, :])) if with_rows else None
     dC = hk.array(np.asfortranarray(A[:, lo:hi]))
     ex = sdist.make_exchange(L, world, rank)
+    tl0 = L.SPX_tree_pass_launches()
     H = sdist.from_blocks_device(L, dR.ptr if with_rows else None, hi - lo, dC.ptr, n, n, o, h, exchange_cb=ex)
+    if d0 + dd >= 96 and L.SPX_tree_pass_launches() != tl0 + 1:
+        print("rank", rank, "block case", n, "did not take the single-launch tree pass on its own levels", flush=True)
+        ok = False
     dA = hk.array(A)
     H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
     B = np.random.default_rng(5).standard_normal((n, 2))
