@@ -404,8 +404,9 @@ int hssk_id_xsolve_vbatched(hssk_ctx* ctx, const hssk_xsolve_desc* descs, int co
  * U^T Rc (rU columns).  lvl = depth of the node (the tolerances of its decompositions are rtol / lvl, atol / lvl); a node
  * with lvl == 0 is the root: coupling blocks only.
  * order (HOST, count entries): (node << 1) | s in dispatch order -- every entry after both sides of both its children; the
- * root once, with s = 0.  res (DEVICE, 4 ints per node, zeroed by the caller): rU, rV, status (1: a rank above rcap or more
- * rows than samples somewhere below -- nothing of the node is valid; the caller takes the level-synchronous calls).
+ * root once, with s = 0.  res (DEVICE, 4 ints per node; written for every entry of `order`): rU, rV, status of side 0, status of
+ * side 1 (1: a rank above rcap or more rows than samples somewhere below -- nothing of the node is valid; the caller takes the
+ * level-synchronous calls).
  * rcap in {32, 48, 64}, d <= 256; returns 2 otherwise.  hssk_sweep_status() reports a workgroup that gave up waiting. */
 typedef struct hssk_tnode {
   int c0, c1, lvl, reserved;

@@ -101,20 +101,22 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
   }
   hssk_tnode* dtab = (hssk_tnode*)work_->alloc(sizeof(hssk_tnode) * nt);
   ck(hssk_upload_async(ctx_, dtab, tab.data(), (long long)(sizeof(hssk_tnode) * nt)));
-  ck(hssk_memset_zero(ctx_, iblock, (long long)(sizeof(int) * 4 * nt)));
   int rc = hssk_tree_inner(ctx_, dtab, order.data(), (int)order.size(), dtot, dcap_, rcap, o_.rel_tol, o_.abs_tol, o_.max_rank, &es, ires);
   if (rc == 2) return false;
   ck(rc);
   g_tree_launches++;
-  // ---- the read-back of the tree, in two pieces: the ranks and statuses first (a few KB) -- with them the exact-size blocks of
-  // the matrix are carved and the copies into them enqueued --, then the pivoted orders and skeleton indices for the host's
-  // tables while the device copies
+  // ---- the read-back of the tree: ranks and statuses (a few KB) first -- with them the exact-size blocks of the matrix are
+  // carved and the copies into them enqueued -- and the pivoted orders and skeleton indices for the host's tables while the
+  // device copies; small trees (a rank's subtree of a multi-GPU run) take everything in one piece
   const size_t nints = (size_t)(inext - iblock);
+  const bool one_piece = nints * sizeof(int) <= (size_t(128) << 10);
   std::vector<int> hall(nints);
-  ck(hssk_memcpy_d2h(ctx_, hall.data(), iblock, (long long)(sizeof(int) * 4 * nt)));
+  ck(hssk_memcpy_d2h(ctx_, hall.data(), iblock, (long long)(sizeof(int) * (one_piece ? nints : 4 * nt))));
   if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("compress: single-launch tree pass: ") + hssk_last_error());
-  for (size_t t = 0; t < nt; t++)
-    if (hall[4 * t + 2]) { g_tree_fallbacks++; return false; }   // a rank above the bound: the level-synchronous path redoes the inner levels
+  for (int e : order) {
+    const int t = e >> 1, sd = e & 1;
+    if (hall[4 * (size_t)t + 2 + sd]) { g_tree_fallbacks++; return false; }   // a rank above the bound: the level-synchronous path redoes the inner levels
+  }
   // ---- commit: the node table as process_level leaves it
   std::vector<hssk_colgather_desc> cp;
   cp.reserve(4 * (size_t)ninner);
@@ -154,7 +156,7 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
   }
   if (!cp.empty()) ck(hssk_gather_cols(ctx_, cp.data(), (int)cp.size()));
   // the host's copies of the pivoted orders and skeleton indices (extraction, serialization, the exchanges of a distributed tree)
-  ck(hssk_memcpy_d2h(ctx_, hall.data() + 4 * nt, iblock + 4 * nt, (long long)(sizeof(int) * (nints - 4 * nt))));
+  if (!one_piece) ck(hssk_memcpy_d2h(ctx_, hall.data() + 4 * nt, iblock + 4 * nt, (long long)(sizeof(int) * (nints - 4 * nt))));
   for (size_t t = 0; t < nt; t++) {
     Node& nd = nodes_[tnodes[t]];
     if (nd.leaf() || nd.lvl == 0) continue;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TR_T) HSSK_WAVES_PER_SIMD(2) void tree_inner_kernel
       hssk_flag_store(&nd->m[s], m);
       if (st) hssk_flag_store(&nd->status, st);
       res[4 * id + s] = r;
-      if (st) res[4 * id + 2] = st;
+      res[4 * id + 2 + s] = st;   // (every (node, side) writes its own word: the caller need not clear the array)
       hssk_drain_stores();
       hssk_flag_store(&nd->flag[s], 1);
       if (root) hssk_flag_store(&nd->flag[1], 1);
