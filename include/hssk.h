@@ -505,6 +505,28 @@ int hssk_getrs_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count
  * dense/DenseMatrix.cpp:287-297); LU is not read */
 int hssk_laswp_vbatched(hssk_ctx* ctx, const hssk_lusolve_desc* descs, int count);
 
+/* ---- block substitution with the factors of a BLR front, one right-hand side, ONE launch (kernels/hssk_blr_sweep.hip) --------
+ * BLRMatrix::solve (BLR/BLRMatrix.hpp:118-122), FrontBLR::fwd_solve_phase2 / bwd_solve_phase1 (sparse/fronts/FrontBLR.cpp:525-570).
+ * rows[w] (HOST): block row w of the sweep in dispatch order; it owns X[off, off + m), subtracts its terms
+ * acc -= U (V^T X[src_off, src_off + n)) and -- LU != NULL -- solves with its diagonal tile: mode 0: x = L^{-1} P acc (piv: the
+ * tile's 0-based interchanges; Tinv: hssk_trtri_diag_vbatched mode 2), mode 1: x = U^{-1} acc (Tinv: mode 1).  A term's source is
+ * either an input (src_flag < 0) or the piece of block row src_flag < w of the same launch, waited for.  X: device, one column;
+ * flags: device, nrows ints (cleared by the call).  Tiles of up to 512 rows; returns 2 beyond.  hssk_sweep_status() reports a
+ * workgroup that gave up waiting. */
+typedef struct hssk_blr_term {
+  const double* U;   /* m x r, leading dimension m (the row's) */
+  const double* V;   /* n x r, leading dimension n */
+  int r, n, src_off, src_flag;
+} hssk_blr_term;
+typedef struct hssk_blr_row {
+  int first_term, nterms, off, m;
+  const double* LU;
+  int lda, mode;
+  const int* piv;
+  const double* Tinv;
+} hssk_blr_row;
+int hssk_blr_sweep(hssk_ctx* ctx, const hssk_blr_row* rows, int nrows, const hssk_blr_term* terms, int nterms, double* X, int* flags);
+
 /* ---- single-launch tree sweeps (few right-hand sides) ---------------------------------------------------------
  * The forward / backward ULV sweeps (HSS/HSSMatrix.solve.hpp:69-238) and the mat-vec up / down sweeps
  * (HSS/HSSMatrix.apply.hpp:55-220) of a whole (sub)tree as ONE launch each: one workgroup per node, ordered so that a

@@ -377,9 +377,10 @@ void DeviceBLR::factor_rl(const char* adm, int nsteps) {
     if (lctx != ctx_) ck(hssk_stream_wait(lctx, ctx_));
     watch(0, true);
     if (mi) ck(hssk_getrf_vbatched(lctx, &lu, 1));
-    if (mi >= 128) {
-      // the inverted diagonal blocks of the tile's L and U, once: this step's two triangular solves and every later solve
-      // phase with the tile take them from here (hssk_trsm_desc::Tinv) instead of inverting per call
+    if (mi > 0) {
+      // the inverted diagonal blocks of the tile's L and U, once: this step's two triangular solves (tiles of 128 rows and more)
+      // and every later solve phase with the tile (the single-launch sweeps: any size) take them from here
+      // (hssk_trsm_desc::Tinv, hssk_blr_row::Tinv) instead of inverting per call
       const size_t per = (size_t)((mi + 63) / 64) * 64 * 64;
       double* inv = store_->dbl(2 * per);
       hssk_trtri_desc tt[2] = {{blk(i, i), inv, mi, (int)ld_, 2}, {blk(i, i), inv + per, mi, (int)ld_, 1}};
@@ -616,8 +617,61 @@ int DeviceBLR::rmax() const {
 
 // block forward substitution over the eliminated steps, X (n_ x nrhs, device): x_i <- L_ii^{-1} P_i x_i, then
 // x_k -= U_ki (V_ki^T x_i) for every block row k below -- the rest of the separator AND the update rows (B21)
+// The two substitutions for ONE right-hand side as one launch each (hssk_blr_sweep: a workgroup per block row, waiting for the
+// rows it depends on through its tiles of non-zero rank); false: not applicable (tiles beyond 512 rows, a tile without its
+// inverted diagonal blocks, STRUMPACK_AMD_BLR_SWEEP=0) -- the caller walks the block steps.
+bool DeviceBLR::sweep(double* X, bool backward) const {
+  static const bool off = [] { const char* e = std::getenv("STRUMPACK_AMD_BLR_SWEEP"); return e && e[0] == '0'; }();
+  if (off) return false;
+  const int rb = rowblocks(), ns = nsteps_;
+  std::vector<hssk_blr_row> rows;
+  std::vector<hssk_blr_term> terms;
+  for (int i = 0; i < ns; i++)
+    if (tm(i) > 512 || (tm(i) > 0 && (!invL_[i] || !invU_[i]))) return false;
+  for (int k = ns; k < rb; k++) if (tm(k) > 512) return false;
+  if (!backward) {
+    // block row k = workgroup k: terms (k, i), i < min(k, steps), in ascending order of the step they wait for
+    for (int k = 0; k < rb; k++) {
+      hssk_blr_row r{};
+      r.first_term = (int)terms.size();
+      r.off = roff_[k]; r.m = tm(k);
+      for (int i = 0; i < std::min(k, ns); i++) {
+        const Tile& t = tile(k, i);
+        if (t.r <= 0 || tm(k) == 0 || tm(i) == 0) continue;
+        terms.push_back(hssk_blr_term{t.U, t.V, t.r, tm(i), roff_[i], i});
+      }
+      r.nterms = (int)terms.size() - r.first_term;
+      if (k < ns && r.m > 0) { r.LU = blk(k, k); r.lda = (int)ld_; r.mode = 0; r.piv = dpiv_ + roff_[k]; r.Tinv = invL_[k]; }
+      rows.push_back(r);
+    }
+  } else {
+    // block row i = workgroup steps - 1 - i: terms (i, j), j > i; the update columns are inputs, the separator's come from
+    // the workgroups in front
+    for (int w = 0; w < ns; w++) {
+      const int i = ns - 1 - w;
+      hssk_blr_row r{};
+      r.first_term = (int)terms.size();
+      r.off = roff_[i]; r.m = tm(i);
+      for (int j = rb - 1; j > i; j--) {   // (inputs first, then the rows finished longest ago)
+        const Tile& t = tile(i, j);
+        if (t.r <= 0 || tm(i) == 0 || tn(j) == 0) continue;
+        terms.push_back(hssk_blr_term{t.U, t.V, t.r, tn(j), coff_[j], j < ns ? ns - 1 - j : -1});
+      }
+      r.nterms = (int)terms.size() - r.first_term;
+      if (r.m > 0) { r.LU = blk(i, i); r.lda = (int)ld_; r.mode = 1; r.piv = nullptr; r.Tinv = invU_[i]; }
+      rows.push_back(r);
+    }
+  }
+  int* flags = tmp_->ints(rows.size() + 1);
+  const int rc = hssk_blr_sweep(ctx_, rows.data(), (int)rows.size(), terms.data(), (int)terms.size(), X, flags);
+  if (rc == 2) return false;
+  ck(rc);
+  return true;
+}
+
 void DeviceBLR::fwd(double* X, int nrhs, double* t, int Rmax) const {
   const int rb = rowblocks();
+  if (nrhs == 1 && sweep(X, false)) return;
   for (int i = 0; i < nsteps_; i++) {
     const int mi = tm(i);
     if (!mi) continue;
@@ -644,6 +698,7 @@ void DeviceBLR::fwd(double* X, int nrhs, double* t, int Rmax) const {
 // rest of the separator and the update columns (B12)
 void DeviceBLR::bwd(double* X, int nrhs, double* t, int Rmax) const {
   const int rb = rowblocks();
+  if (nrhs == 1 && sweep(X, true)) return;
   for (int i = nsteps_ - 1; i >= 0; i--) {
     const int mi = tm(i);
     if (!mi) continue;
@@ -684,6 +739,7 @@ void DeviceBLR::solve(int nrhs, double* b, long long ldb) const {
   fwd(X, nrhs, t, Rmax);
   bwd(X, nrhs, t, Rmax);
   ck(hssk_memcpy2d_d2h(ctx_, b, sizeof(double) * ldb, X, sizeof(double) * n_, sizeof(double) * n_, nrhs));
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("BLR solve: ") + hssk_last_error());
 }
 
 // FrontBLR::fwd_solve_phase2 (FrontBLR.cpp:525-547): bsep <- L11^{-1} P bsep, bupd <- bupd - B21 bsep
@@ -703,6 +759,7 @@ void DeviceBLR::front_forward(int nrhs, double* bsep, long long ldb, double* bup
   fwd(X, nrhs, t, Rmax);
   ck(hssk_memcpy2d_d2h(ctx_, bsep, sizeof(double) * ldb, X, sizeof(double) * n_, sizeof(double) * ds, nrhs));
   if (du > 0) ck(hssk_memcpy2d_d2h(ctx_, bupd, sizeof(double) * ldu, X + ds, sizeof(double) * n_, sizeof(double) * du, nrhs));
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("BLR front, forward phase: ") + hssk_last_error());
 }
 
 // FrontBLR::bwd_solve_phase1 (FrontBLR.cpp:550-570): ysep <- U11^{-1} (ysep - B12 yupd)
@@ -721,6 +778,7 @@ void DeviceBLR::front_backward(int nrhs, double* ysep, long long ldy, const doub
   double* t = tmp.dbl((size_t)Rmax * nrhs);
   bwd(X, nrhs, t, Rmax);
   ck(hssk_memcpy2d_d2h(ctx_, ysep, sizeof(double) * ldy, X, sizeof(double) * n_, sizeof(double) * ds, nrhs));
+  if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("BLR front, backward phase: ") + hssk_last_error());
 }
 
 void DeviceBLR::dense(double* A, long long lda) const {

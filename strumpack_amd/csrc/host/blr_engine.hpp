@@ -118,6 +118,7 @@ class DeviceBLR {
   void put_block(int r0, int c0, int rows, int cols, const double* src, long long lds, bool on_device);
   void partial_factor(int sep_blocks, const double* F11, long long ld11, const double* F12, long long ld12, const double* F21,
                       long long ld21, const double* F22, long long ld22, const char* adm11, bool on_device);
+  bool sweep(double* X, bool backward) const;   // one right-hand side: a substitution as ONE launch (hssk_blr_sweep)
   void fwd(double* X, int nrhs, double* t, int Rmax) const;
   void bwd(double* X, int nrhs, double* t, int Rmax) const;
   int rmax() const;
@@ -135,7 +136,7 @@ class DeviceBLR {
   size_t dA_bytes_ = 0;
   long long ld_ = 0;
   int* dpiv_ = nullptr;    // pivots of the diagonal tiles (0-based, local), rows() ints
-  std::vector<const double*> invL_, invU_;   // per block step: inverted 64 x 64 diagonal blocks of the tile's L and U (tiles of >= 128 rows; else null)
+  std::vector<const double*> invL_, invU_;   // per block step: inverted 64 x 64 diagonal blocks of the tile's L and U 
   std::vector<Tile> tiles_;
   std::unique_ptr<Arena2> store_, tmp_, blk_;   // blk_: products kept for a block of steps (deferred Schur updates, factor_rl)
   bool compressed_ = false, factored_ = false;

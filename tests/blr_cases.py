@@ -86,6 +86,14 @@ def check_front(L, name, G=None):
     x = F.solve11(fr["bsep"])
     assert err(x, G[name + "_x11"]) <= 10 * rtol
     assert err(fr["F11"] @ x, fr["bsep"]) <= max(3 * float(G[name + "_x11_resid"]), 10 * rtol)
+    # one right-hand side: each substitution is ONE launch (hssk_blr_sweep: a workgroup per block row, waiting for the rows its
+    # non-zero tiles point at) -- the same factors applied in another order than the block steps above
+    fs1, fu1 = F.forward(fr["bsep"][:, :1], fr["bupd"][:, :1] if du else None)
+    assert err(fs1, fs[:, :1]) <= 1e-11
+    if du:
+        assert err(fu1, fu[:, :1]) <= 1e-11
+    ys1 = F.backward(fr["ysep"][:, :1], fr["yupd"][:, :1] if du else None)
+    assert err(ys1, ys[:, :1]) <= 1e-11
     F.destroy()
     return st
 
