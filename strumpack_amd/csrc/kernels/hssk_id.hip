@@ -836,7 +836,7 @@ void launch_id_reg(hssk_ctx* ctx, const hssk_id_desc* dd, int count) {
   HSSK_LAUNCH((id_reg_kernel<RT, CT, NW>), dim3((unsigned)count), dim3(NW * 64), 0, ctx->stream, dd);
   if (!g_all_deferred) HSSK_LAUNCH(id_xsolve_kernel, dim3((unsigned)count), dim3(XS_T), 0, ctx->stream, dd);
 }
-// panels of d <= 16 RT sample rows and up to 64 / 96 / 128 / 224 columns (a step costs per column slot); 8-wave workgroups (two waves per SIMD: 256 VGPRs
+// panels of d <= 16 RT sample rows and up to 64 / 96 / 128 / 160 / 192 / 224 columns (a step costs per column slot); 8-wave workgroups (two waves per SIMD: 256 VGPRs
 // for the register tile and the unrolled step loop; 16 waves with half the slots issue the same number of instructions
 // per SIMD and step)
 template <int RT>
@@ -844,6 +844,8 @@ bool launch_id_reg_ct(hssk_ctx* ctx, const hssk_id_desc* dd, int count, int mmax
   if (mmax <= 64) launch_id_reg<RT, 2, 8>(ctx, dd, count);
   else if (mmax <= 96) launch_id_reg<RT, 3, 8>(ctx, dd, count);
   else if (mmax <= 128) launch_id_reg<RT, 4, 8>(ctx, dd, count);
+  else if (mmax <= 160) launch_id_reg<RT, 5, 8>(ctx, dd, count);   // (the 156-row tiles of the 200^3 problem's BLR fronts)
+  else if (mmax <= 192) launch_id_reg<RT, 6, 8>(ctx, dd, count);
   else if (mmax <= 224) launch_id_reg<RT, 7, 8>(ctx, dd, count);
   else return false;
   return true;
