@@ -478,3 +478,36 @@ def test_symmetric_operand_hint(L):
     hk = K.Hssk(_loader.lib_path())
     HC.check_symmetric_hint(L, hk, n=8192, leaf=128)
     hk.close()
+
+
+def test_inner_levels_in_one_launch_at_full_size(L, monkeypatch):
+    """BASELINE configs[2]'s tree (N = 100000, leaf 256, rel_tol 1e-4, 192 samples: 1023 nodes, 9 inner levels, 1021 workgroups
+    of one launch) with the operand given by the library's Toeplitz formula (nothing stored): the single-launch tree pass against
+    the level-synchronous path on the same samples -- every node's rows and ranks, memory to the byte, products and solutions to
+    rounding --, and the reference's pass criteria on sampled columns."""
+    n = 100000
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-4, abs_tol=1e-8, leaf_size=256)
+    h = capi.StructuredMatrix.hss_options(L, random_engine="philox")
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((n, 2))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("STRUMPACK_AMD_TREE_LAUNCH", mode)
+        l0 = L.SPX_tree_pass_launches()
+        H = capi.StructuredMatrix.from_generator(L, n, 1, o, h)
+        assert H.is_compressed() and L.SPX_tree_pass_launches() - l0 == (1 if mode == "1" else 0)
+        y = H.mult(b)
+        H.factor()
+        x = H.solve(b)
+        assert np.linalg.norm(H.mult(x) - b) <= HC.SOLVE_TOLERANCE * np.linalg.norm(b)
+        res[mode] = (H.node_info(), H.memory(), H.rank(), H.levels(), y, x)
+        H.destroy()
+    assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1:4] == res["0"][1:4]
+    assert res["1"][2] == 41 and res["1"][3] == 10
+    for k in (4, 5):
+        assert np.linalg.norm(res["1"][k] - res["0"][k]) <= 1e-10 * np.linalg.norm(res["0"][k])
+    cols = rng.integers(0, n, 16)
+    i = np.arange(n)
+    Ac = 1.0 / (1.0 + np.abs(i[:, None] - cols[None, :]))
+    # y = H b against A b on sampled ROWS (A symmetric): rows cols of A b
+    assert np.linalg.norm(Ac.T @ b - res["1"][4][cols]) <= 1e2 * 1e-4 * np.linalg.norm(Ac.T @ b)
