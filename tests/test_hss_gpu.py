@@ -470,7 +470,7 @@ def test_inner_levels_in_one_launch(L):
     path, BASELINE configs[1]'s shape included (N = 32768, leaf 256, rel_tol 1e-4: 8 levels, 254 workgroups)."""
     from strumpack_amd import hssk as K
     hk = K.Hssk(_loader.lib_path())
-    HC.check_tree_pass(L, hk, sizes=((3000, 64, 1e-6), (6000, 128, 1e-6), (515, 64, 1e-6), (32768, 256, 1e-4)))
+    HC.check_tree_pass(L, hk, sizes=((3000, 64, 1e-6), (6000, 128, 1e-6), (1100, 32, 1e-6), (515, 64, 1e-6), (32768, 256, 1e-4)), again=True)
     hk.close()
 
 
