@@ -89,7 +89,13 @@ struct RowOp {
 // A thread's slice of the FIRST pass of gemv_rows (rows [0, SW_T)): row i, K range [k0, k1).  One definition for the pass
 // itself and for rows_prefetch, which loads the slice's matrix elements into registers before the vectors exist.
 constexpr int SW_GRP = 8;    // loads a thread keeps in flight in the streaming part of a pass
-constexpr int SW_PRE = 24;   // prefetched elements per thread and pass (K <= 48 with two K partitions, <= 96 with four)
+// prefetched elements per thread and pass (K <= 24 with two K partitions, <= 48 with four).  Twelve, not more: the slices set
+// the kernels' register count, and with it how many workgroups a CU holds.  At 24 the one-vector mat-vec needed 189 registers
+// and the forward solve 249 -- two workgroups per CU, 512 slots for the 2045 resp. 1023 workgroups of an N = 1e5 tree, so the
+// inner nodes waiting for their turn held the slots the leaves needed and the leaves' D x (84 % of the bytes) only started once
+// the up-sweep had ended; at 12 it is 116 / 153 registers, four / three workgroups per CU (mat-vec 0.089 -> 0.064 ms,
+// profiles/r06_sweeps.md).  Nodes up to rank 48 still find their whole block in the slices.
+constexpr int SW_PRE = 12;
 struct Pre { double v[SW_PRE]; };
 struct RowSlice { int i, part, P, M, M64, k0, k1; bool act; RowOp ro; };
 template <class F>
@@ -185,6 +191,44 @@ __device__ __forceinline__ void gemv_n(const double* __restrict__ A, int lda, in
 }
 __device__ __forceinline__ void gemv_n_prefetch(const double* __restrict__ A, int lda, int M, int K, Pre& pre) {
   rows_prefetch(M, [=](int i) { return RowOp{A + i, lda, K, nullptr, nullptr, 0}; }, pre);
+}
+
+// The same for FEW rows (M <= 32: the interpolation block of a leaf, r x (m - r) with r ~ 10 - 20 and m - r ~ 180): the K range
+// is split over all 256 / M thread groups, every thread's slice is at most a few groups of sixteen loads in flight -- gemv_rows
+// gives such a block four K partitions of 45 columns each on a quarter of the threads, six dependent memory round trips
+// (the leaves' V^T x: 7 -> 4.5 us).
+template <int NR, int LDV>
+__device__ __forceinline__ void gemv_n_few(const double* __restrict__ A, int lda, int M, int K, const double* x, double* out, int nrhs, int op,
+                                           double* s_p) {
+  const int tid = threadIdx.x;
+  const int P = SW_T / M;                        // >= 8
+  const int prt = tid / M, i = tid - prt * M;
+  const bool act = prt < P;
+  const int Kc = (K + P - 1) / P, k0 = prt * Kc, k1 = min(K, k0 + Kc);
+  double acc[NR] = {};
+  if (act)
+    for (int k = k0; k < k1; k += 16) {
+      double t[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) t[u] = hssk_gload(A + i, (size_t)min(k + u, k1 - 1) * lda);
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const double mk = k + u < k1 ? 1. : 0.;
+#pragma unroll
+        for (int c = 0; c < NR; c++) acc[c] += mk * t[u] * x[min(k + u, k1 - 1) + c * LDV];
+      }
+    }
+  // partials: s_p[c * SW_T + prt * M + i]   (P * M <= SW_T)
+  if (act)
+    for (int c = 0; c < nrhs; c++) s_p[c * SW_T + prt * M + i] = acc[c];
+  __syncthreads();
+  if (tid < M)
+    for (int c = 0; c < nrhs; c++) {
+      double v = 0.;
+      for (int q = 0; q < P; q++) v += s_p[c * SW_T + q * M + tid];
+      apply_op(out + tid + c * LDV, v, op);
+    }
+  __syncthreads();
 }
 
 // pull `count` doubles at p towards this XCD's L2 (one load per 128-byte line) while the workgroup still waits for its
@@ -538,7 +582,8 @@ __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict_
         else s_g[(tid - r) + c * LDV] = v;
       }
     __syncthreads();
-    if (m > r && r > 0) gemv_n<NR, LDV>(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p, pre, pf);
+    if (!handed && m > r && r > 0 && r <= 32) gemv_n_few<NR, LDV>(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p);
+    else if (m > r && r > 0) gemv_n<NR, LDV>(p.X, r, r, m - r, s_g, s_o, nrhs, OP_ADD, s_p, pre, pf);
     for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.dst, (e % r) + (size_t)(e / r) * p.ldd, s_o[(e % r) + (e / r) * LDV]);
     return;
   }
