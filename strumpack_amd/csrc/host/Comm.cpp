@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -39,9 +40,19 @@ const Api& api() {
     // a librccl that is already mapped (PyTorch's) must be the one used: two RCCL instances in one process do not share
     // their device bookkeeping
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)
-      if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
     std::string why;   // dlerror() hands out its message once: take it right behind the failing dlopen
+    // STRUMPACK_AMD_RCCL_LIB names the library to bind instead (a differently installed RCCL; the CPU tests' stand-in,
+    // tests/emu/fake_rccl.cpp): that one or none
+    if (const char* forced = std::getenv("STRUMPACK_AMD_RCCL_LIB")) {
+      if (!(h = dlopen(forced, RTLD_NOW | RTLD_LOCAL))) {
+        const char* e = dlerror();
+        err = std::string("cannot load STRUMPACK_AMD_RCCL_LIB = ") + forced + ": " + (e ? e : "?");
+        return;
+      }
+    }
+    if (!h)
+      for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
     if (!h)
       for (const char* n : names) {
         if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;

@@ -160,6 +160,128 @@ def test_distributed_hss(tmp_path, world):
     assert "DIST_OK" in outs[0], "\n".join(outs)
 
 
+NATIVE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import emu_lib
+from strumpack_amd import capi, dist as sdist, hssk as K
+from oracle import hss_oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)     # (only to hand rank 0's unique id to the others)
+L = capi.load(emu_lib.PATH)
+hk = K.Hssk(emu_lib.PATH)
+comm = sdist.NativeComm(L)                                       # csrc/host/Comm.cpp: RcclComm over the library STRUMPACK_AMD_RCCL_LIB names
+ok = L.SPX_comm_selftest(comm.h) == 0 and L.SPX_comm_size(comm.h) == world and L.SPX_comm_rank(comm.h) == rank
+if not ok:
+    print("rank", rank, "selftest failed", flush=True)
+# sharded operand through the native communicator: row block + column block (all-gathers at the cut, all-reduce of the top
+# nodes' coupling blocks), column block only (the Sr contributions reduced to their owners: the grouped ncclReduce)
+CASES = {2: [(120, 16, 16, 8, "stable", True), (120, 16, 16, 8, "stable", False), (300, 32, 64, 32, "stable", True)],
+         4: [(140, 16, 8, 8, "stable", True), (140, 16, 8, 8, "stable", False), (600, 32, 64, 32, "stable", False)]}
+for (n, leaf, d0, dd, algo, with_rows) in CASES[world]:
+    A = O.toeplitz(n) + 0.01 * np.random.default_rng(2).standard_normal((n, n))
+    if d0 + dd >= 96:
+        g2 = np.random.default_rng(2)
+        A = O.toeplitz(n) + 0.05 * g2.standard_normal((n, 3)) @ g2.standard_normal((3, n))
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd, algorithm=algo, factor_ahead=with_rows)
+    lo, hi = sdist.shard_range(L, n, o, world, rank)
+    dR = hk.array(np.asfortranarray(A[lo:hi, :])) if with_rows else None
+    dC = hk.array(np.asfortranarray(A[:, lo:hi]))
+    H = sdist.from_blocks_device(L, dR.ptr if with_rows else None, hi - lo, dC.ptr, n, n, o, h, comm=comm)
+    dA = hk.array(A)
+    H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
+    B = np.random.default_rng(5).standard_normal((n, 2))
+    same_tree = np.array_equal(H.node_info(), H1.node_info())
+    y, y1 = H.mult(B), H1.mult(B)
+    yt, yt1 = H.mult(B, "T"), H1.mult(B, "T")
+    H.factor(); H1.factor()
+    x, x1 = H.solve(B), H1.solve(B)
+    e_mult = np.linalg.norm(y - y1) / np.linalg.norm(y1)
+    e_multT = np.linalg.norm(yt - yt1) / np.linalg.norm(yt1)
+    e_solve = np.linalg.norm(x - x1) / np.linalg.norm(x1)
+    good = same_tree and e_mult < 1e-10 and e_multT < 1e-10 and e_solve < 1e-8
+    if not good:
+        print("rank", rank, "native block case", n, leaf, with_rows, same_tree, e_mult, e_multT, e_solve, flush=True)
+    ok = ok and good
+    H.destroy(); H1.destroy()
+# generated operand, twenty right-hand sides as well
+for (n, leaf, d0, dd) in {2: [(256, 32, 64, 64)], 4: [(512, 32, 64, 64)]}[world]:
+    A = O.toeplitz(n)
+    dA = hk.array(A)
+    o = capi.StructuredMatrix.options(L, rel_tol=1e-6, abs_tol=1e-10, leaf_size=leaf)
+    h = capi.StructuredMatrix.hss_options(L, d0=d0, dd=dd)
+    H = sdist.from_generator(L, n, 1, o, h, comm=comm)
+    H1 = capi.StructuredMatrix.from_dense_device(L, dA.ptr, n, n, o, h)
+    B = np.random.default_rng(5).standard_normal((n, 20))
+    same_tree = np.array_equal(H.node_info(), H1.node_info())
+    y, y1 = H.mult(B), H1.mult(B)
+    H.factor(); H1.factor()
+    x, x1 = H.solve(B), H1.solve(B)
+    good = same_tree and np.linalg.norm(y - y1) < 1e-11 * np.linalg.norm(y1) and np.linalg.norm(x - x1) < 1e-9 * np.linalg.norm(x1)
+    if not good:
+        print("rank", rank, "native generator case", n, same_tree, flush=True)
+    ok = ok and good
+    H.destroy(); H1.destroy()
+comm.close()
+t = torch.tensor([float(ok)])
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
+if rank == 0:
+    print("NATIVE_OK" if t.item() == 1.0 else "NATIVE_FAIL", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def fake_rccl():
+    """tests/emu/fake_rccl.cpp: the nccl* symbols Comm.cpp binds, over shared memory (built with the emulator library)"""
+    import emu_lib
+    emu_lib.build()
+    path = os.path.join(os.path.dirname(emu_lib.PATH), "libfake_rccl.so")
+    assert os.path.exists(path)
+    return path
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_comm_multirank(tmp_path, world):
+    """RcclComm (csrc/host/Comm.cpp) with N > 1 ranks: the in-place all-gather offsets, the all-reduce and the grouped reduce that
+    serves as reduce-scatter, driven by the engine exactly as on the GPUs (SPX_comm_*, from_blocks_device / from_generator with a
+    native communicator), against the single-process matrix.  The collectives run over a stand-in for librccl."""
+    script = tmp_path / "native_worker.py"
+    script.write_text(NATIVE_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29543 + world), HSSK_EMU_THREADS="2",
+               STRUMPACK_AMD_RCCL_LIB=fake_rccl())
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "NATIVE_OK" in outs[0], "\n".join(outs)
+
+
+@pytest.mark.parametrize("world", [2])
+def test_bench_dry_run_native_comm(world):
+    """The multi-GPU bench line's own path -- STRUMPACK_AMD_BENCH_COMM=rccl: native communicator, trial run, sharded operand,
+    no fall-back -- on the emulator with the librccl stand-in: the line must say it ran on the native communicator with
+    `world` ranks."""
+    import json
+    import emu_lib
+    env = dict(os.environ, STRUMPACK_AMD_RCCL_LIB=fake_rccl(), STRUMPACK_AMD_BENCH_DRYRUN_LIB=emu_lib.PATH, HSSK_EMU_THREADS="2",
+               OMP_NUM_THREADS="2", STRUMPACK_AMD_BENCH_COMM="rccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29581 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--size", "1500", "--leaf", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == world and d["config"]["rccl_nranks"] == world
+    assert d["config"]["comm"].startswith("native RCCL communicator") and d["checks"]["solve_resid_H"] < 1e-10
+
+
 @pytest.mark.parametrize("world", [2])
 def test_bench_rendezvous_dry_run(world):
     """bench.py launched exactly as the driver launches its multi-GPU run (python -m torch.distributed.run --nnodes=1
