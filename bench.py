@@ -571,27 +571,37 @@ def spawn_ranks(a):
     rank does -- so that both spellings of the driver's multi-GPU command measure N ranks."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
+    # the rendezvous port: the socket that found it stays open (SO_REUSEADDR) until the ranks have been started, so that no
+    # other process of the box is handed the same number in between
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
     procs = []
+    out0f = tempfile.TemporaryFile(mode="w+")   # (rank 0's stdout: a file, so that no pipe has to be drained while all ranks are watched)
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), STRUMPACK_AMD_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    # a rank that died leaves the others in a collective: give them a moment, then stop exactly the processes started here
-    deadline = time.time() + (30 if rcs[0] == 0 else 5)
-    for q in procs[1:]:
-        try:
-            q.wait(timeout=max(0.1, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            q.kill()
-            q.wait()
-        rcs.append(q.returncode)
+                                      stdout=out0f if r == 0 else subprocess.DEVNULL, text=True))
+    sk.close()
+    # every rank is watched: one that dies (bad device, RCCL set-up) leaves the others in the rendezvous or in a collective until
+    # torch's own time-out, minutes later -- they are given a moment, then exactly the processes started here are stopped
+    first_bad = None
+    while any(q.poll() is None for q in procs):
+        if first_bad is None and any(q.poll() not in (None, 0) for q in procs):
+            first_bad = time.time()
+        if first_bad is not None and time.time() - first_bad > 5:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+        time.sleep(0.05)
+    rcs = [q.wait() for q in procs]
+    out0f.seek(0)
+    out0 = out0f.read()
+    out0f.close()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         sys.stdout.write("".join(ln + "\n" for ln in (out0 or "").splitlines() if not ln.startswith("{")))

@@ -526,6 +526,11 @@ typedef struct hssk_blr_row {
   const double* Tinv;
 } hssk_blr_row;
 int hssk_blr_sweep(hssk_ctx* ctx, const hssk_blr_row* rows, int nrows, const hssk_blr_term* terms, int nterms, double* X, int* flags);
+/* The same with the two tables resident on the device (the factors do not change between solves: the caller uploads them once).
+ * hssk_blr_sweep_check: the checks of hssk_blr_sweep on host tables, nothing issued (0 fine, 2 beyond the kernel, 1 malformed);
+ * hssk_blr_sweep_resident: d_rows / d_terms = device copies of tables that passed it. */
+int hssk_blr_sweep_check(const hssk_blr_row* rows, int nrows, const hssk_blr_term* terms, int nterms);
+int hssk_blr_sweep_resident(hssk_ctx* ctx, const hssk_blr_row* d_rows, int nrows, const hssk_blr_term* d_terms, double* X, int* flags);
 
 /* ---- single-launch tree sweeps (few right-hand sides) ---------------------------------------------------------
  * The forward / backward ULV sweeps (HSS/HSSMatrix.solve.hpp:69-238) and the mat-vec up / down sweeps

@@ -41,12 +41,22 @@ class DevicePool {
     free_.clear();
     cached_ = 0;
   }
-  // bytes currently kept for reuse / the cap on them; set_limit trims down to the new cap
+  // bytes currently kept for reuse / the cap on them; set_limit frees chunks, largest first, until the cache is within the new
+  // cap (the small chunks, which a running solver loop asks for most often, stay)
   size_t cached() { std::lock_guard<std::mutex> g(mu_); return cached_; }
   size_t limit() { std::lock_guard<std::mutex> g(mu_); ensure_limit(); return limit_; }
   void set_limit(size_t bytes) {
-    { std::lock_guard<std::mutex> g(mu_); limit_ = bytes; limit_set_ = true; }
-    if (cached() > bytes) trim();
+    std::lock_guard<std::mutex> g(mu_);
+    limit_ = bytes;
+    limit_set_ = true;
+    while (cached_ > limit_ && !free_.empty()) {
+      auto it = std::prev(free_.end());   // (the map is keyed by chunk size)
+      if (it->second.empty()) { free_.erase(it); continue; }
+      hssk_free(it->second.back());
+      it->second.pop_back();
+      cached_ -= it->first;
+      if (it->second.empty()) free_.erase(it);
+    }
   }
   ~DevicePool() { for (auto& kv : free_) for (void* p : kv.second) hssk_free(p); }
 
@@ -55,7 +65,9 @@ class DevicePool {
   std::map<size_t, std::vector<void*>> free_;
   // Bytes kept for reuse.  The cache is only ever trimmed by this library (on its own failed allocation, set_limit, trim), so
   // what it holds is invisible to the other allocators of the process (torch, RCCL): the default cap is a FIFTH of the device's
-  // memory (57 of the 288 GB of an MI355X -- the working array + block products of a 60000-row BLR front are ~48 GB: with less,
+  // memory -- of the device that is current on the thread that first releases a chunk; the cap is one number for the process,
+  // whichever devices' chunks are cached (one process per GPU is how this library is run; a process that drives several
+  // devices sets the cap itself) -- (57 of the 288 GB of an MI355X -- the working array + block products of a 60000-row BLR front are ~48 GB: with less,
   // every factorization of such a front pays a hipFree and a hipMalloc of tens of GB, half a second --, 13 GB of a 64 GB part), STRUMPACK_AMD_POOL_GB overrides it, SPX_device_pool_trim / SPX_device_pool_set_limit_gb manage it at run time.
   void ensure_limit() {
     if (limit_set_) return;

@@ -93,6 +93,7 @@ void DeviceBLR::alloc_array() {
   dA_ = (double*)DevicePool::get().acquire(dA_bytes_);
   if (!dA_) throw std::runtime_error("BLR: device allocation of the operand failed");
   store_->rewind();
+  sweep_tab_[0] = sweep_tab_[1] = SweepTables();
   tiles_.assign(tiles_.size(), Tile());
   dpiv_ = store_->ints((size_t)std::max(m_, 1) + rowblocks() + 1);
   compressed_ = factored_ = false;
@@ -624,6 +625,15 @@ bool DeviceBLR::sweep(double* X, bool backward) const {
   static const bool off = [] { const char* e = std::getenv("STRUMPACK_AMD_BLR_SWEEP"); return e && e[0] == '0'; }();
   if (off) return false;
   const int rb = rowblocks(), ns = nsteps_;
+  {
+    const SweepTables& T = sweep_tab_[backward ? 1 : 0];
+    if (T.built) {
+      if (!T.ok) return false;
+      int* flags = tmp_->ints((size_t)T.nrows + 1);
+      ck(hssk_blr_sweep_resident(ctx_, T.rows, T.nrows, T.terms, X, flags));
+      return true;
+    }
+  }
   std::vector<hssk_blr_row> rows;
   std::vector<hssk_blr_term> terms;
   for (int i = 0; i < ns; i++)
@@ -662,10 +672,18 @@ bool DeviceBLR::sweep(double* X, bool backward) const {
       rows.push_back(r);
     }
   }
+  // the tables go to the device once per factorization: the factors they describe do not change between solves
+  SweepTables& T = sweep_tab_[backward ? 1 : 0];
+  T.built = true;
+  T.nrows = (int)rows.size();
+  if (hssk_blr_sweep_check(rows.data(), (int)rows.size(), terms.data(), (int)terms.size())) return false;   // (ok stays false)
+  T.rows = (hssk_blr_row*)store_->alloc(sizeof(hssk_blr_row) * std::max<size_t>(rows.size(), 1));
+  T.terms = (hssk_blr_term*)store_->alloc(sizeof(hssk_blr_term) * std::max<size_t>(terms.size(), 1));
+  ck(hssk_memcpy_h2d(ctx_, T.rows, rows.data(), (long long)(sizeof(hssk_blr_row) * rows.size())));
+  if (!terms.empty()) ck(hssk_memcpy_h2d(ctx_, T.terms, terms.data(), (long long)(sizeof(hssk_blr_term) * terms.size())));
+  T.ok = true;
   int* flags = tmp_->ints(rows.size() + 1);
-  const int rc = hssk_blr_sweep(ctx_, rows.data(), (int)rows.size(), terms.data(), (int)terms.size(), X, flags);
-  if (rc == 2) return false;
-  ck(rc);
+  ck(hssk_blr_sweep_resident(ctx_, T.rows, T.nrows, T.terms, X, flags));
   return true;
 }
 

@@ -139,6 +139,9 @@ class DeviceBLR {
   std::vector<const double*> invL_, invU_;   // per block step: inverted 64 x 64 diagonal blocks of the tile's L and U 
   std::vector<Tile> tiles_;
   std::unique_ptr<Arena2> store_, tmp_, blk_;   // blk_: products kept for a block of steps (deferred Schur updates, factor_rl)
+  // row / term tables of the single-launch substitutions (forward, backward), resident in store_ from the first solve on
+  struct SweepTables { bool built = false, ok = false; int nrows = 0; hssk_blr_row* rows = nullptr; hssk_blr_term* terms = nullptr; };
+  mutable SweepTables sweep_tab_[2];
   bool compressed_ = false, factored_ = false;
   int nsteps_ = 0;   // eliminated block steps (== rowblocks() for a full factorization)
 };

@@ -48,18 +48,24 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
   int rcap = ((std::max(32, (5 * lmax + 1) / 2) + 15) / 16) * 16;
   if (const char* e = std::getenv("STRUMPACK_AMD_TREE_RCAP")) rcap = std::atoi(e);   // (tests: force an overflow)
   rcap = std::min(rcap, (dtot / 2) / 16 * 16);
-  if (rcap < 32 || rcap > hssk_tree_rcap_max() || lmax > rcap) return false;
+  // (the kernel's variants: 32 / 48 / 64, as far as the device's LDS goes -- anything else is the level path's, decided HERE,
+  //  before anything is carved from an arena)
+  if ((rcap != 32 && rcap != 48 && rcap != 64) || rcap > hssk_tree_rcap_max() || lmax > rcap) return false;
   const int mcap = 2 * rcap;
 
   // ---- device node table: this rank's nodes, children before parents (own_by_height_ order)
   std::vector<int> tix(nodes_.size(), -1);
   std::vector<int> tnodes;
   for (auto& ids : own_by_height_) for (int id : ids) { tix[id] = (int)tnodes.size(); tnodes.push_back(id); }
+  for (int id : tnodes)
+    if (!nodes_[id].leaf() && (tix[nodes_[id].c0] < 0 || tix[nodes_[id].c1] < 0)) return false;   // a child outside this rank's levels: not a tree this pass knows
   const size_t nt = tnodes.size();
   std::vector<hssk_tnode> tab(nt);
-  // storage of the inner nodes at the rank bound: panels and workspace from the compression's work arena; what the matrix
-  // keeps (X, B01, B10) is copied to exact-size blocks once the ranks are known; the integer arrays stay where they are
-  int* iblock = persist_->ints(4 * nt + (size_t)ninner * (2 * mcap + 2 * rcap));
+  // storage of the inner nodes at the rank bound -- panels, workspace, integer arrays -- from the compression's work arena;
+  // what the matrix keeps is copied out once the ranks are known (X, B01, B10 to exact-size blocks, the integer arrays in one
+  // piece); a pass that ends in the level path gives its storage back (the matrix's own arena is not touched before the commit)
+  const Arena::Mark work_mark = work_->mark();
+  int* iblock = work_->ints(4 * nt + (size_t)ninner * (2 * mcap + 2 * rcap));
   int* ires = iblock;
   int* inext = iblock + 4 * nt;
   struct Tmp { double *X[2], *B01, *B10; };
@@ -82,7 +88,6 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
       continue;
     }
     q.c0 = tix[nd.c0]; q.c1 = tix[nd.c1];
-    if (q.c0 < 0 || q.c1 < 0) return false;   // (a child outside this rank's levels: not a tree this pass knows)
     Tmp& tv = tmpv[t];
     tv.B01 = q.B01 = work_->dbl((size_t)rcap * rcap);
     tv.B10 = q.B10 = work_->dbl((size_t)rcap * rcap);
@@ -102,7 +107,7 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
   hssk_tnode* dtab = (hssk_tnode*)work_->alloc(sizeof(hssk_tnode) * nt);
   ck(hssk_upload_async(ctx_, dtab, tab.data(), (long long)(sizeof(hssk_tnode) * nt)));
   int rc = hssk_tree_inner(ctx_, dtab, order.data(), (int)order.size(), dtot, dcap_, rcap, o_.rel_tol, o_.abs_tol, o_.max_rank, &es, ires);
-  if (rc == 2) return false;
+  if (rc == 2) { work_->rewind(work_mark); return false; }
   ck(rc);
   g_tree_launches++;
   // ---- the read-back of the tree: ranks and statuses (a few KB) first -- with them the exact-size blocks of the matrix are
@@ -115,8 +120,17 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
   if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("compress: single-launch tree pass: ") + hssk_last_error());
   for (int e : order) {
     const int t = e >> 1, sd = e & 1;
-    if (hall[4 * (size_t)t + 2 + sd]) { g_tree_fallbacks++; return false; }   // a rank above the bound: the level-synchronous path redoes the inner levels
+    if (hall[4 * (size_t)t + 2 + sd]) {   // a rank above the bound: the level-synchronous path redoes the inner levels
+      g_tree_fallbacks++;
+      ck(hssk_sync(ctx_));                // (nothing of the launch is in flight when its storage is handed out again)
+      work_->rewind(work_mark);
+      return false;
+    }
   }
+  // the integer arrays the matrix keeps (pivoted orders, skeleton indices: at the rank bound, as the kernel laid them out)
+  int* ikeep = nints > 4 * nt ? persist_->ints(nints - 4 * nt) : nullptr;
+  if (ikeep) ck(hssk_memcpy_d2d(ctx_, ikeep, iblock + 4 * nt, (long long)(sizeof(int) * (nints - 4 * nt))));
+  auto kept = [&](int* p) { return ikeep + (p - (iblock + 4 * nt)); };
   // ---- commit: the node table as process_level leaves it
   std::vector<hssk_colgather_desc> cp;
   cp.reserve(4 * (size_t)ninner);
@@ -142,8 +156,8 @@ bool DeviceHSS::tree_pass(Source& src, int d, int dd) {
     nd.Srt = q.S[0]; nd.Sct = q.S[1];
     nd.Rrt = nd.Rct = nullptr;   // (an inner node's samples are its children's reduced ones, read in place)
     nd.RrtRed = q.Rred[0]; nd.RctRed = q.Rred[1];
-    nd.permU = q.perm[0]; nd.permV = q.perm[1];
-    nd.dIr = q.I[0]; nd.dIc = q.I[1];
+    nd.permU = kept(q.perm[0]); nd.permV = kept(q.perm[1]);
+    nd.dIr = kept(q.I[0]); nd.dIc = kept(q.I[1]);
     nd.panels = true;
     for (int s = 0; s < 2; s++) {
       const int m = s == 0 ? nd.mU : nd.mV, r = s == 0 ? nd.rU : nd.rV;

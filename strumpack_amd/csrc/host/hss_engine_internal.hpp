@@ -168,6 +168,10 @@ class Arena {
   int* ints(size_t count) { return (int*)alloc(sizeof(int) * count); }
   // forget all allocations but keep the chunks (caller guarantees the device is done with them)
   void rewind() { next_ = 0; cur_ = nullptr; left_ = 0; used_ = 0; }
+  // forget the allocations made since mark() (same guarantee; the chunks stay)
+  struct Mark { size_t left, used, next; char* cur; };
+  Mark mark() const { return Mark{left_, used_, next_, cur_}; }
+  void rewind(const Mark& m) { left_ = m.left; used_ = m.used; next_ = m.next; cur_ = m.cur; }
   void reset() {
     for (auto& c : chunks_) DevicePool::get().release(c.first, c.second);
     chunks_.clear();

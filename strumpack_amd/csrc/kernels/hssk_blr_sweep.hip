@@ -143,24 +143,41 @@ __global__ __launch_bounds__(BS_T) void blr_sweep_kernel(const hssk_blr_row* __r
 
 }  // namespace
 
-extern "C" int hssk_blr_sweep(hssk_ctx* ctx, const hssk_blr_row* rows, int nrows, const hssk_blr_term* terms, int nterms, double* X,
-                              int* flags) {
+extern "C" int hssk_blr_sweep_check(const hssk_blr_row* rows, int nrows, const hssk_blr_term* terms, int nterms) {
   HSSK_API_BEGIN
-  if (nrows <= 0) return 0;
   for (int i = 0; i < nrows; i++) {
     if (rows[i].m > BS_MMAX) HSSK_UNSUPPORTED("tile beyond 512 rows");
     if (rows[i].LU && !rows[i].Tinv) HSSK_UNSUPPORTED("diagonal tile without its inverted 64 x 64 blocks");
+    if (rows[i].first_term < 0 || rows[i].nterms < 0 || rows[i].first_term + rows[i].nterms > nterms) throw std::invalid_argument("hssk_blr_sweep: term range outside the table");
     for (int q = 0; q < rows[i].nterms; q++) {
       const hssk_blr_term& t = terms[rows[i].first_term + q];
       if (t.n > BS_MMAX || t.r > BS_MMAX) HSSK_UNSUPPORTED("tile beyond 512 rows / columns");
       if (t.src_flag >= i) throw std::invalid_argument("hssk_blr_sweep: a block row may only depend on rows in front of it");
     }
   }
+  HSSK_API_END
+}
+
+extern "C" int hssk_blr_sweep_resident(hssk_ctx* ctx, const hssk_blr_row* d_rows, int nrows, const hssk_blr_term* d_terms, double* X,
+                                       int* flags) {
+  HSSK_API_BEGIN
+  if (nrows <= 0) return 0;
   if (!ctx->h_sweep_err) { ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64); *ctx->h_sweep_err = 0; }
+  hssk_rt::memset_async(flags, 0, sizeof(int) * (size_t)nrows, ctx->stream);
+  HSSK_LAUNCH(blr_sweep_kernel, dim3((unsigned)nrows), dim3(BS_T), 0, ctx->stream, d_rows, d_terms, X, flags, ctx->h_sweep_err);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
+
+extern "C" int hssk_blr_sweep(hssk_ctx* ctx, const hssk_blr_row* rows, int nrows, const hssk_blr_term* terms, int nterms, double* X,
+                              int* flags) {
+  if (nrows <= 0) return 0;
+  if (const int rc = hssk_blr_sweep_check(rows, nrows, terms, nterms)) return rc;
+  HSSK_API_BEGIN
+  // (tables beyond the staging ring: the caller walks the block steps, as for any operand this launch does not take)
+  if (sizeof(*rows) * (size_t)nrows + sizeof(*terms) * (size_t)std::max(nterms, 1) + 1024 > ctx->ring_bytes) HSSK_UNSUPPORTED("descriptor tables beyond the staging ring");
   auto* dr = (const hssk_blr_row*)ctx->stage(rows, sizeof(*rows) * (size_t)nrows);
   auto* dt = (const hssk_blr_term*)ctx->stage(nterms > 0 ? terms : (const hssk_blr_term*)rows, nterms > 0 ? sizeof(*terms) * (size_t)nterms : 8);
-  hssk_rt::memset_async(flags, 0, sizeof(int) * (size_t)nrows, ctx->stream);
-  HSSK_LAUNCH(blr_sweep_kernel, dim3((unsigned)nrows), dim3(BS_T), 0, ctx->stream, dr, dt, X, flags, ctx->h_sweep_err);
-  hssk_rt::check_launch();
+  return hssk_blr_sweep_resident(ctx, dr, nrows, dt, X, flags);
   HSSK_API_END
 }

@@ -326,7 +326,19 @@ void launch_tree(hssk_ctx* ctx, hssk_tnode* nodes, const int* dorder, int count,
 
 }  // namespace
 
-extern "C" int hssk_tree_rcap_max(void) { return 64; }
+// dynamic LDS of the launch for a rank bound (launch_tree) plus the kernel's static arrays (three register-ID instantiations,
+// tables: ~20 KB): what a workgroup must be able to get
+static size_t tree_lds_bytes(int rcap) {
+  const size_t RC = (size_t)rcap;
+  return sizeof(double) * std::max<size_t>(2 * RC * RC, 64 * HSSK_BACKSUB_LD + 64 + RC * 2 * RC) + (size_t)20 * 1024;
+}
+// largest rank bound whose launch fits the device's LDS (64 on gfx950: 100 KB of 160; a 64 KB part gets 32; 0: none fits)
+extern "C" int hssk_tree_rcap_max(void) {
+  const size_t cap = hssk_rt::max_lds_per_workgroup();
+  for (int rcap : {64, 48, 32})
+    if (tree_lds_bytes(rcap) <= cap) return rcap;
+  return 0;
+}
 
 extern "C" int hssk_tree_inner(hssk_ctx* ctx, hssk_tnode* nodes, const int* order, int count, int d, int lds, int rcap, double rtol,
                                double atol, int max_rank, const hssk_elem_src* src, int* res) {
@@ -335,6 +347,7 @@ extern "C" int hssk_tree_inner(hssk_ctx* ctx, hssk_tnode* nodes, const int* orde
   if (!src || (!src->use_gen && !src->A)) HSSK_UNSUPPORTED("no element source");
   if (d <= 0 || d > 256 || (rcap != 32 && rcap != 48 && rcap != 64)) HSSK_UNSUPPORTED("sample count / rank bound outside the kernel's variants");
   if (src->use_gen && src->gen.kind != HSSK_GEN_TOEPLITZ && src->gen.kind != HSSK_GEN_TOEPLITZ_UPPER) HSSK_UNSUPPORTED("unknown generator kind");
+  if (tree_lds_bytes(rcap) > hssk_rt::max_lds_per_workgroup()) HSSK_UNSUPPORTED("rank bound beyond this device's LDS");   // (the caller takes the level path)
   if (!ctx->h_sweep_err) { ctx->h_sweep_err = (int*)hssk_rt::pinned_malloc(64); *ctx->h_sweep_err = 0; }
   TreeParams P;
   P.d = d; P.lds = lds; P.rcap = rcap; P.max_rank = max_rank; P.rtol = rtol; P.atol = atol;
