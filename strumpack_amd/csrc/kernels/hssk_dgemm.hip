@@ -309,14 +309,18 @@ __global__ __launch_bounds__(512, 2) void sketch_kernel(long long n, long long k
   long long stepB = 0;
   if (GEN) {
   } else if (TRANSB) {
-    srcB[0] = B + j0 + (pos ^ (16 * kk)) + (kbeg + 2 * wave + kk) * ldb;
-    srcB[1] = srcB[0] + 64;
+    // (the RAGGED last tile -- n is not a multiple of 128; the host sends it only when n is even -- reads the last valid pair
+    //  instead of columns beyond n: its surplus columns hold garbage that the reduce pass never folds)
+    const long long jp = j0 + (pos ^ (16 * kk));
+    srcB[0] = B + (jp < n - 2 ? jp : n - 2) + (kbeg + 2 * wave + kk) * ldb;
+    srcB[1] = B + (jp + 64 < n - 2 ? jp + 64 : n - 2) + (kbeg + 2 * wave + kk) * ldb;
     stepB = (long long)BK * ldb;
   } else {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const int j = 8 * (wave + 8 * r) + (lane >> 3), q = lane & 7;
-      srcB[r] = B + (j0 + j) * ldb + kbeg + 2 * (q ^ ((j >> 1) & 7));
+      const long long jc = j0 + j < n - 1 ? j0 + j : n - 1;   // (ragged last tile: the last valid column again)
+      srcB[r] = B + jc * ldb + kbeg + 2 * (q ^ ((j >> 1) & 7));
     }
     stepB = BK;
   }
@@ -635,8 +639,15 @@ static void dgemm_impl(hssk_ctx* ctx, int transB, int m, long long n, long long 
     return;
   }
   const int BNt = v2 ? BN2 : BN;
-  const unsigned gn_full = aligned ? (unsigned)(n / BNt) : 0u;
-  const long long edge_col0 = (long long)gn_full * BNt;                       // the masked kernel starts here (64-column tiles)
+  // The ragged last columns (n not a multiple of the tile width) of the eight-wave form are ONE MORE TILE of its grid, padded: the
+  // kernel reads the last valid columns again instead of columns beyond n, writes the tile's partials (the scratch has the
+  // room) and the reduce pass folds only the valid ones.  They used to be a launch of their own through the masked
+  // four-wave kernel, split 256 ways along K to fill the chip: 1.0 ms for the 32 last columns of N = 1e5 (1.2 TFLOP/s), twice
+  // per round, against 0.07 ms for one more tile.  (An odd n keeps the masked launch: the pair that straddles n would be read.)
+  static const bool no_fold = [] { const char* e = std::getenv("HSSK_DGEMM_NO_FOLD"); return e && std::atoi(e) != 0; }();
+  const bool fold_edge = v2 && !no_fold && n % BNt != 0 && n % 2 == 0;
+  const unsigned gn_full = aligned ? (unsigned)(n / BNt) + (fold_edge ? 1u : 0u) : 0u;
+  const long long edge_col0 = std::min<long long>(n, (long long)gn_full * BNt);   // the masked kernel starts here (64-column tiles)
   const unsigned gn_edge = (unsigned)((n - edge_col0 + BN - 1) / BN);
   // Work decomposition.  The CUs hold `slots` workgroups (two four-wave ones per CU, or one eight-wave one); a grid that is
   // not a multiple of that ends in a partly filled round.  The full tiles are therefore cut into a MAIN group whose grid
@@ -644,7 +655,8 @@ static void dgemm_impl(hssk_ctx* ctx, int transB, int m, long long n, long long 
   // deeper K-split that fills one last round of short workgroups; the ragged edge keeps its own masked launch.  Every
   // group writes K-partials that one deterministic reduce pass per group folds into C.
   const long long slots = v2 ? cus : 2LL * cus;
-  struct Group { long long col0 = 0, ntiles = 0; int split = 1; long long kchunk = BK; int nz = 0; double* P = nullptr; long long cols = 0; };
+  // (cols: columns of the group's tiles, the stride of its partials; vcols: those of them that exist)
+  struct Group { long long col0 = 0, ntiles = 0; int split = 1; long long kchunk = BK; int nz = 0; double* P = nullptr; long long cols = 0, vcols = 0; };
   auto chunk_of = [&](int split) {
     long long c = ((ksteps + split - 1) / split) * BK;
     return c > 0 ? c : (long long)BK;
@@ -700,6 +712,7 @@ static void dgemm_impl(hssk_ctx* ctx, int transB, int m, long long n, long long 
   size_t ptot = 0;
   for (Group* g : {&gmain, &gtail, &gedge}) {
     if (!g->ntiles) continue;
+    g->vcols = std::min(g->cols, n - g->col0);
     g->kchunk = chunk_of(g->split);
     g->nz = (int)std::max<long long>(1, (k + g->kchunk - 1) / g->kchunk);
     ptot += (size_t)ldp * g->cols * g->nz;
@@ -745,15 +758,15 @@ static void dgemm_impl(hssk_ctx* ctx, int transB, int m, long long n, long long 
   ctx->d_clk = gmain.ntiles ? clk : nullptr;
   ctx->dgemm_trace_wgs = (long long)ntrace;
   ctx->dgemm_timed = true;
-  ctx->dgemm_timed_flops = 2.0 * (double)m * (double)timed->cols * (double)k;
+  ctx->dgemm_timed_flops = 2.0 * (double)m * (double)timed->vcols * (double)k;   // (algorithmic: the columns that exist)
   for (const Group* g : {&gmain, &gtail, &gedge}) {
     if (!g->ntiles) continue;
-    long long total = (long long)m * g->cols;
+    long long total = (long long)m * g->vcols;
     unsigned rb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
     if (g->nz >= 32 && total <= 65536)   // too few elements to hide the latency of a serial walk over the partials
-      HSSK_LAUNCH(dgemm_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
+      HSSK_LAUNCH(dgemm_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, ctx->stream, m, g->vcols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
     else
-      HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->cols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
+      HSSK_LAUNCH(dgemm_reduce_kernel, dim3(rb), dim3(256), 0, ctx->stream, m, g->vcols, (const double*)g->P, ldp, ldp * g->cols, g->nz, alpha, beta, C + g->col0 * ldc, ldc);
   }
   hssk_rt::check_launch();
 }
