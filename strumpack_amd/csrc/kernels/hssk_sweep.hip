@@ -313,6 +313,45 @@ __device__ __forceinline__ void gemv_t(const double* __restrict__ A, int lda, in
   gemv_t<NR, LDV>(A, lda, K, N, x, out, nrhs, op, none, false);
 }
 
+// The same for LONG columns (K >= 33 rows: the leaves' D^T x, the rows-below updates of the forward substitution): a WAVE per
+// column, lanes along its rows -- every load instruction is 512 contiguous bytes, where gemv_t's four lanes per column put the
+// 64 lanes of a load on 16 columns, i.e. on 64 different cache lines; the column sums over the DPP network (hssk_wave_sum).  A
+// wave keeps four columns x up to four 64-row pieces in flight; x sits in registers.  K <= 256.  Contains wave collectives and
+// a barrier: every thread must call.  x and out must not alias.
+template <int NR, int LDV>
+__device__ __forceinline__ void gemv_t_wave(const double* __restrict__ A, int lda, int K, int N, const double* x, double* out, int nrhs, int op) {
+  const int lane = threadIdx.x & 63, wave = hssk_uniform((int)(threadIdx.x >> 6));
+  constexpr int NW = SW_T / 64, U = 4;
+  const int nc = (K + 63) >> 6;   // 64-row pieces of a column (<= 4)
+  double xr[4][NR];
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+#pragma unroll
+    for (int q = 0; q < NR; q++) xr[c][q] = (c < nc && lane + 64 * c < K) ? x[lane + 64 * c + q * LDV] : 0.;
+  for (int j0 = wave * U; j0 < N; j0 += NW * U) {
+    double t[U][4];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = min(j0 + u, N - 1);
+#pragma unroll
+      for (int c = 0; c < 4; c++) t[u][c] = c < nc ? hssk_gload(A + (size_t)j * lda, (size_t)min(lane + 64 * c, K - 1)) : 0.;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      double acc[NR] = {};
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int q = 0; q < NR; q++) acc[q] += t[u][c] * xr[c][q];   // (rows beyond K: xr is zero there)
+      for (int q = 0; q < nrhs; q++) {
+        const double v = hssk_wave_sum(acc[q]);
+        if (lane == 0 && j0 + u < N) apply_op(out + j0 + u + q * LDV, v, op);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---- forward ULV sweep ---------------------------------------------------------------------------------------------
 // Right-hand sides beyond SW_NR: blockIdx.y walks groups of SW_NR columns.  The groups are independent chains through the
 // tree that run side by side (a 2-D grid is dispatched x-fastest, so within a group the index order still holds); each
@@ -479,7 +518,8 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
         // column k of R~ (rows b0 .. b0+nb contiguous) for k > b0 + nb;  x = y_b (now final) copied to s_f
         for (int e = tid; e < nb * nrhs; e += SW_T) s_f[(e % nb) + (e / nb) * LDV] = s_y[b0 + (e % nb) + (e / nb) * LDV];
         __syncthreads();
-        gemv_t<NR, LDV>(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
+        if (NR == 1 && nb > 32) gemv_t_wave<NR, LDV>(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
+        else gemv_t<NR, LDV>(p.Rlq + b0 + (size_t)(b0 + nb) * m, m, nb, rest, s_f, s_y + b0 + nb, nrhs, OP_SUB);
       }
     }
     for (int e = tid; e < q * nrhs; e += SW_T) hssk_gstore(p.y, (e % q) + (size_t)(e / q) * q, s_y[(e % q) + (e / q) * LDV]);
@@ -606,7 +646,8 @@ __device__ __forceinline__ void apply_body(const hssk_apply_up_desc* __restrict_
     const int m = p.m;
     for (int e = tid; e < m * nrhs; e += SW_T) s_x[(e % m) + (e / m) * LDV] = hssk_gload(p.x, (e % m) + (size_t)(e / m) * p.ldx);
     __syncthreads();
-    if (p.trans) gemv_t<NR, LDV>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
+    if (p.trans && m > 32) gemv_t_wave<NR, LDV>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
+    else if (p.trans) gemv_t<NR, LDV>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET);
     else gemv_n<NR, LDV>(p.D, m, m, m, s_x, s_o, nrhs, OP_SET, s_p);
     if (p.beta != 0.) {
       for (int e = tid; e < m * nrhs; e += SW_T) s_o[(e % m) + (e / m) * LDV] += p.beta * hssk_gload(p.out, (e % m) + (size_t)(e / m) * p.ldo);

@@ -51,7 +51,7 @@ def main():
         by = st["b_mult"] + 16.0 * n * nrhs
         print("apply %s: median %.4f ms (min %.4f)  %.0f GB/s" % (trans, a_med, a_min, by / a_med * 1e-6))
         y = dY.get().copy()
-        np.save(os.path.join(ROOT, "gpurun_out", "sweep_ab_y%s_%s.npy" % (trans, os.environ.get("SWEEP_AB_TAG", "x"))), y)
+        if nrhs == 1: np.save(os.path.join(ROOT, "gpurun_out", "sweep_ab_y%s_%s.npy" % (trans, os.environ.get("SWEEP_AB_TAG", "x"))), y)
 
     def one_solve():
         hk.check(hk.lib.hssk_memcpy_d2d(hk.ctx, dS.ptr, dB.ptr, 8 * n * nrhs))
@@ -61,7 +61,7 @@ def main():
         H.solve_device(dS.ptr, nrhs)
     one_solve()
     x = dS.get().copy()
-    np.save(os.path.join(ROOT, "gpurun_out", "sweep_ab_x_%s.npy" % os.environ.get("SWEEP_AB_TAG", "x")), x)
+    if nrhs == 1: np.save(os.path.join(ROOT, "gpurun_out", "sweep_ab_x_%s.npy" % os.environ.get("SWEEP_AB_TAG", "x")), x)
     s_med, s_min = dev_ms(only_solve)
     st = H.stats()
     by = st["b_solve"] + 16.0 * n * nrhs
