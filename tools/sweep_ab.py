@@ -1,5 +1,5 @@
-"""Device-clock timing of the apply / solve sweeps alone (N = 1e5 Toeplitz, generated operand: no 80 GB fill), the
-leaves-early launch of the mat-vec against node order, with the two results compared.
+"""Device-clock timing of the apply / solve sweeps alone (N = 1e5 Toeplitz, generated operand: no 80 GB fill); the results go
+to gpurun_out/sweep_ab_{yN,yT,x}_<SWEEP_AB_TAG>.npy for comparisons between builds / environment switches.
 usage: python tools/sweep_ab.py [n] [leaf] [nrhs]   (HSSK_* / STRUMPACK_AMD_* environment switches apply)"""
 import ctypes as C
 import os
@@ -72,14 +72,6 @@ def main():
 
 
 if __name__ == "__main__":
-    if os.environ.get("SWEEP_AB_TAG"):
-        main()
-    else:
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        for tag, env in (("early", {}), ("late", {"HSSK_SWEEP_LEAVES_EARLY": "0"})):
-            print("==", tag, flush=True)
-            subprocess.run([sys.executable, __file__] + sys.argv[1:], env=dict(os.environ, SWEEP_AB_TAG=tag, **env), check=True)
-        for f in ("yN", "yT", "x"):
-            a = np.load(os.path.join(ROOT, "gpurun_out", "sweep_ab_%s_early.npy" % f))
-            b = np.load(os.path.join(ROOT, "gpurun_out", "sweep_ab_%s_late.npy" % f))
-            print("%s: leaves early vs node order  max rel diff %.2e" % (f, np.abs(a - b).max() / np.abs(b).max()))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    os.environ.setdefault("SWEEP_AB_TAG", "x")
+    main()
