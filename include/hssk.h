@@ -562,7 +562,17 @@ typedef struct hssk_sweep_fwd_desc {
   double* xroot;
   int ldf, rU0, rU1, rV0, rV1, ldz_in, m, r, mv, rv, ldp, ldz, ldxr;
   int wait0, wait1;
+  /* chain block of an inner node (optional; hssk_sweep_chain_ok says which shapes the kernels take): the node's whole step as
+   * ONE matrix, [ft1; z] = G [f; zc], G (r + rv) x (m + mv), leading dimension ldg -- what the parent waits for is then one
+   * pass behind the children's vectors instead of five dependent ones; y (not on the chain) follows through the blocks above.
+   * The caller obtains G by running this very sweep on the columns of an identity (DeviceHSS::chain_blocks). */
+  const double* G;
+  int ldg;
 } hssk_sweep_fwd_desc;
+/* 1 if the vector forms of the forward sweep (nrhs <= 4) use a chain block of this shape */
+int hssk_sweep_chain_ok(int m, int r, int mv, int rv);
+/* forward sweeps launched in the chain-block form so far (process-wide; tests) */
+long long hssk_sweep_chain_launches(void);
 int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs);
 /* out (m x nrhs, ldo) = Qt(:, 0:m-r) y + Qt(:, m-r:) xpart */
 typedef struct hssk_sweep_bwd_desc {

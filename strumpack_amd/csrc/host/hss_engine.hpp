@@ -267,6 +267,8 @@ class DeviceHSS {
     // derived factors read by the single-launch solve sweeps: WQ = W1 Q~(:, 0:m-r), Vt0T = Vt0^T, inverted 64 x 64 diagonal blocks of
     // R~^T (non-root) resp. of the root's L and U
     double *WQ = nullptr, *Tinv = nullptr, *TinvU = nullptr, *Vt0T = nullptr;
+    // chain block of the single-vector forward sweep: [ft1; z] = Gc [f; zc], (rU + rV) x (mU + mV) (DeviceHSS::chain_blocks)
+    double* Gc = nullptr;
     double* LU = nullptr;
     int* piv = nullptr;
     bool leaf() const { return c0 < 0; }
@@ -335,6 +337,11 @@ class DeviceHSS {
   struct PlanEntry { int seen = 0; hssk_plan* plan = nullptr; };
   std::map<PlanKey, PlanEntry> plans_;
   std::unique_ptr<Arena> plan_arena_;   // work vectors of the recorded sweeps (never rewound while plans live)
+  // chain blocks of the inner nodes (hssk_sweep_fwd_desc::G): built when a single-vector solve is about to be recorded -- a
+  // caller that solves once never pays for them --, dropped with the factors
+  std::unique_ptr<Arena> chain_arena_;
+  bool chain_built_ = false;
+  void chain_blocks();
   void drop_plans();
   bool plans_enabled() const;
   // ---- multi-GPU: subtree ownership below the cut level, replicated top

@@ -25,7 +25,9 @@ void DeviceHSS::factor_begin(int sr, bool partial, hssk_ctx* cx) {
   drop_plans();   // recorded sweeps reference the old factors
   fact_->reset();
   stats_.f_ulv = 0;
-  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nd.Vt0T = nullptr, nd.piv = nullptr;
+  for (auto& nd : nodes_) nd.Qt = nd.Rlq = nd.W1 = nd.Vt0 = nd.Dt = nd.Vt1 = nd.LU = nd.WQ = nd.Tinv = nd.TinvU = nd.Vt0T = nd.Gc = nullptr, nd.piv = nullptr;
+  chain_built_ = false;
+  if (chain_arena_) chain_arena_->reset();
   const size_t nn = nodes_.size();
   frun_ = FactorRun();
   frun_.active = true;

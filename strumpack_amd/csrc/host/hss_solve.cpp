@@ -27,6 +27,79 @@ void DeviceHSS::backward_solve_node(int node, SolveWork& w, const double* xroot,
   solve_sub(node, w.nrhs, x, ldxo, false, 2, &w);
 }
 
+// Chain blocks (hssk_sweep_fwd_desc::G, kernels/hssk_sweep.hip): for every inner node below the root the matrix G with
+// [ft1; z] = G [f; zc] -- the node's whole forward step (solve.hpp:88-192: coupling products, P^T, E, L^{-1}, W1 Q0, V^*, Vt0^*) as
+// what it is for the parent, one linear map of what the children hand over.  G is not assembled from the factors: the forward
+// sweep ITSELF is run on the columns of an identity, every node on its own (no waits), sixteen columns per launch, and writes G
+// where it would write the hand-off -- whatever arithmetic the sweep does, the block reproduces.  Cost: a dozen small launches
+// and (rU + rV)(mU + mV) doubles per node (57 MB at N = 1e5 against 270 MB of factors), paid when a single-vector solve on a
+// device buffer comes the second time (the call that is recorded for replay); STRUMPACK_AMD_NO_CHAIN=1 keeps the plain sweep.
+void DeviceHSS::chain_blocks() {
+  if (chain_built_) return;
+  chain_built_ = true;
+  static const bool off = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_CHAIN"); return e && e[0] == '1'; }();
+  if (off || o_.world != 1 || dist_subtree_ || !factored_) return;
+  const int CH = 16;
+  auto pad = [&](int k) { return (k + CH - 1) / CH * CH; };
+  std::vector<int> ids;
+  int kmax = 0;
+  for (size_t i = 1; i < nodes_.size(); i++) {
+    const Node& nd = nodes_[i];
+    if (nd.leaf() || nd.mU <= nd.rU || nd.mU > 256 || nd.mV > 256) continue;
+    if (!nd.B01 || !nd.B10 || !nd.Rlq || !nd.Tinv || (nd.rU && !nd.WQ) || (nd.rV && !nd.Vt0T)) continue;
+    if (!hssk_sweep_chain_ok(nd.mU, nd.rU, nd.mV, nd.rV)) continue;
+    ids.push_back((int)i);
+    kmax = std::max(kmax, nd.mU + nd.mV);
+  }
+  if (ids.empty()) return;
+  const int kpad = pad(kmax);
+  if (!chain_arena_) chain_arena_.reset(new Arena());
+  const Arena::Mark mk = tmp_->mark();
+  std::vector<double> eye((size_t)kpad * kpad, 0.);
+  for (int i = 0; i < kpad; i++) eye[(size_t)i * kpad + i] = 1.;
+  double* dI = tmp_->dbl(eye.size());
+  ck(hssk_memcpy_h2d(ctx_, dI, eye.data(), (long long)(sizeof(double) * eye.size())));
+  std::vector<double*> ys(ids.size());
+  for (size_t k = 0; k < ids.size(); k++) {
+    Node& nd = nodes_[ids[k]];
+    nd.Gc = chain_arena_->dbl((size_t)(nd.rU + nd.rV) * pad(nd.mU + nd.mV));
+    ys[k] = tmp_->dbl((size_t)(nd.mU - nd.rU) * CH);
+  }
+  bool ok = true;
+  for (int c0 = 0; c0 < kpad && ok; c0 += CH) {
+    std::vector<hssk_sweep_fwd_desc> fd;
+    for (size_t k = 0; k < ids.size(); k++) {
+      const Node& nd = nodes_[ids[k]];
+      if (c0 >= pad(nd.mU + nd.mV)) continue;
+      const Node &a = nodes_[nd.c0], &c = nodes_[nd.c1];
+      const int ldg = nd.rU + nd.rV;
+      hssk_sweep_fwd_desc d{};
+      d.wait0 = d.wait1 = -1;
+      d.fsrc = dI + (size_t)c0 * kpad; d.ldf = kpad;
+      d.zc = dI + nd.mU + (size_t)c0 * kpad; d.ldz_in = kpad;
+      d.B01 = nd.B01; d.B10 = nd.B10;
+      d.rU0 = a.rU; d.rU1 = c.rU; d.rV0 = a.rV; d.rV1 = c.rV;
+      d.permV = nd.permV; d.XV = nd.XV;
+      d.m = nd.mU; d.r = nd.rU; d.rv = nd.rV; d.mv = nd.mV;
+      d.permU = nd.permU; d.XU = nd.XU; d.Rlq = nd.Rlq; d.Tinv = nd.Tinv; d.WQ = nd.WQ; d.Vt0T = nd.Vt0T;
+      d.ft1 = nd.Gc + (size_t)c0 * ldg; d.ldp = ldg;
+      d.z = nd.Gc + nd.rU + (size_t)c0 * ldg; d.ldz = ldg;
+      d.y = ys[k];
+      fd.push_back(d);
+    }
+    if (fd.empty()) continue;
+    const int rc = hssk_ulv_fwd_sweep(ctx_, fd.data(), (int)fd.size(), CH);
+    if (rc == 2) ok = false;
+    else ck(rc);
+  }
+  ck(hssk_sync(ctx_));
+  tmp_->rewind(mk);
+  if (!ok || hssk_sweep_status(ctx_)) {
+    for (int id : ids) nodes_[id].Gc = nullptr;
+    chain_arena_->reset();
+  }
+}
+
 // sr != 0: the subtree of node sr as a matrix of its own (factor_node): rows of b = the node's rows
 // phase 0: the whole solve; 1: forward half, state kept in *ws; 2: backward half from *ws
 void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device, int phase, SolveWork* ws) {
@@ -63,7 +136,10 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   hssk_plan* rec = nullptr;
   // the first call on a buffer runs normally; the second one is recorded while it runs, later ones replay
   if (plannable && plans_.size() > 32) drop_plans();   // many different buffers: start over rather than grow
-  if (plannable && ++plans_[key].seen == 2) ck(hssk_plan_begin(ctx_, &rec));
+  if (plannable && ++plans_[key].seen == 2) {
+    if (nrhs == 1 && sr == 0 && phase == 0) chain_blocks();   // (before the recording starts: its launches are not the sweep's)
+    ck(hssk_plan_begin(ctx_, &rec));
+  }
   struct EndRec { hssk_ctx* c; hssk_plan* p; bool done = false; ~EndRec() { if (p && !done) { hssk_plan_end(c); hssk_plan_destroy(p); } } } guard{ctx_, rec};
   if (phase == 1) {   // the state of a split solve lives in its own arena until the backward half has run
     ws->arena.reset(new Arena());
@@ -155,6 +231,7 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
           d.z = zc[nd.parent] + (id == pa.c0 ? 0 : nodes_[pa.c0].rV);
           d.ldz = std::max(nodes_[pa.c0].rV + nodes_[pa.c1].rV, 1);
           d.y = y[id];
+          if (nrhs == 1 && sr == 0 && !nd.leaf() && nd.Gc) { d.G = nd.Gc; d.ldg = nd.rU + nd.rV; }
           if (d.m > d.r && (!d.y || !d.Rlq || !d.Tinv || (d.r && !d.WQ) || (d.rv && !d.Vt0T))) return false;
         }
         where[id] = (int)fd.size();

@@ -361,13 +361,27 @@ __device__ __forceinline__ void gemv_t_wave(const double* __restrict__ A, int ld
 // 9-level tree cost sixteen latency chains one after the other -- a group's workgroups hold the slots while they wait --:
 // 0.9 ms for the inner levels of N = 1e5 at nrhs = 64.  In turn, the chain is paid once and the levels pipeline: a parent
 // works on group g while its children are on g + 1.)
+// Chain block of an inner node of the forward sweep (hssk_sweep_fwd_desc::G): what the PARENT waits for -- ft1 and z -- is a
+// linear function of what the children hand over, [ft1; z] = G [f; zc], G (r + rv) x (m + mv).  As written above it, the step is
+// five dependent passes (the coupling products, X^T, the substitution, [WQ; Vt0^T]) with their barriers and partial sums: 6 - 8 us
+// per tree level at N = 1e5, eight levels deep, against 1.6 - 2.4 us for the hand-off itself.  With G the chain is ONE pass whose
+// matrix elements sit in registers before the children's vectors exist (SW_CH per thread: the rows over 256 / (r + rv) K
+// partitions); y, which only the backward sweep reads, follows behind the hand-off through the node's blocks.
+constexpr int SW_CH = 56;
+__host__ __device__ inline bool chain_shape_ok(int m, int r, int mv, int rv, int ldv) {
+  const int M = r + rv, K = m + mv;
+  if (M <= 0 || M > SW_T || K > ldv || m <= r) return false;
+  const int P = SW_T / M;
+  return (K + P - 1) / P <= SW_CH;
+}
+
 template <int NR>
 __device__ __forceinline__ int rhs_group(int nrhs_total, int group, int& c0) {
   c0 = group * NR;
   return min(NR, nrhs_total - c0);
 }
 
-template <int NR, int LDV>
+template <int NR, int LDV, bool CHAIN>
 __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err, int group) {
   // (LDS carved from the launch's dynamic allocation: the NR = 16 instantiation needs more than the 64 KB static limit)
   HSSK_DYN_SHARED(double, s_dyn);
@@ -414,8 +428,20 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
     if (i < r) return RowOp{p.WQ + i, r, q, s_y, s_t + i, OP_SUB};
     return RowOp{p.Vt0T + (i - r), rv, q, s_y, s_z + (i - r), OP_ADD};
   };
-  const bool pf = inner && !p.LU;
+  // (CHAIN: an instantiation of its own, taken when every inner node of the launch has a block -- the slices of a block and the
+  //  four prefetch slices of the plain step do not share registers, whatever the source says: 241 against 153)
+  const bool chain = CHAIN && inner && !p.LU && p.G != nullptr && chain_shape_ok(m, r, mv, rv, LDV);
+  const bool pf = !CHAIN && inner && !p.LU;
+  // the chain block: row ci of G, columns [ck0, ck1)
+  const int cM = chain ? r + rv : 1, cP = SW_T / cM, cpart = tid / cM, ci = tid - cpart * cM;
+  const bool cact = chain && cpart < cP;
+  const int cKc = (m + mv + cP - 1) / cP, ck0 = cpart * cKc, ck1 = min(m + mv, ck0 + cKc);
   Pre pre1, pre2, pre3, pre4;
+  double gpre[CHAIN ? SW_CH : 1];
+  if (CHAIN && chain) {
+#pragma unroll
+    for (int u = 0; u < SW_CH; u++) gpre[CHAIN ? u : 0] = (cact && ck0 + u < ck1) ? hssk_gload(p.G, (size_t)ci + (size_t)(ck0 + u) * p.ldg) : 0.;
+  }
   if (pf) {
     rows_prefetch(m + mz, rows1, pre1);
     if (q > 0) {
@@ -440,11 +466,38 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
   // ---- f = rhs rows (leaf) or [ft1_0; ft1_1] (inner: handed over by the children); zc = stacked children z
   for (int e = tid; e < m * nrhs; e += SW_T) {
     const int i = e % m, c = e / m;
-    s_f[i + c * LDV] = inner ? sweep_take(p.fsrc, i + (size_t)c * p.ldf, err) : hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
+    const double v = inner ? sweep_take(p.fsrc, i + (size_t)c * p.ldf, err) : hssk_gload(p.fsrc, i + (size_t)c * p.ldf);
+    s_f[i + c * LDV] = v;
+    if (chain) s_t[i + c * LDV] = v;   // ([f; zc] in one piece for the chain block)
   }
   if (inner)
-    for (int e = tid; e < mv * nrhs; e += SW_T) s_a[(e % mv) + (e / mv) * LDV] = sweep_take(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in, err);
+    for (int e = tid; e < mv * nrhs; e += SW_T) {
+      const double v = sweep_take(p.zc, (e % mv) + (size_t)(e / mv) * p.ldz_in, err);
+      s_a[(e % mv) + (e / mv) * LDV] = v;
+      if (chain) s_t[m + (e % mv) + (e / mv) * LDV] = v;
+    }
   __syncthreads();
+  if (CHAIN && chain) {
+    // ---- [ft1; z] = G [f; zc]: the hand-off to the parent, one pass on registers and LDS
+    double acc[NR] = {};
+#pragma unroll
+    for (int u = 0; u < SW_CH; u++) {
+      const int k = min(ck0 + u, m + mv - 1);   // (elements beyond the slice are zeros)
+#pragma unroll
+      for (int c = 0; c < NR; c++) acc[c] += gpre[CHAIN ? u : 0] * s_t[k + c * LDV];
+    }
+    if (cact)
+      for (int c = 0; c < nrhs; c++) s_p[(cpart * NR + c) * cM + ci] = acc[c];
+    __syncthreads();
+    if (tid < cM)
+      for (int c = 0; c < nrhs; c++) {
+        double v = 0.;
+        for (int qq = 0; qq < cP; qq++) v += s_p[(qq * NR + c) * cM + tid];
+        if (tid < r) hssk_cstore(p.ft1, tid + (size_t)c * p.ldp, v);
+        else hssk_cstore(p.z, (tid - r) + (size_t)c * p.ldz, v);
+      }
+    __syncthreads();   // (s_p and s_t are written again below)
+  }
   if (inner) {
     if (zpart) {
       // s_z (= s_t2) <- zc(permV[0:rv]);  s_y <- zc(permV[rv:])
@@ -526,6 +579,7 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
     // ---- one pass over [WQ; Vt0^T] (both (.) x q, rows contiguous):  ft1 -= WQ y   and   z += Vt0^T y
     gemv_rows<NR, LDV>(r + rv, rows4, nrhs, s_p, pre4, pf);
   }
+  if (chain) return;   // (ft1 and z left with the chain block)
   for (int e = tid; e < r * nrhs; e += SW_T) hssk_cstore(p.ft1, (e % r) + (size_t)(e / r) * p.ldp, s_t[(e % r) + (e / r) * LDV]);
   for (int e = tid; e < rv * nrhs; e += SW_T) hssk_cstore(p.z, (e % rv) + (size_t)(e / rv) * p.ldz, s_z[(e % rv) + (e / rv) * LDV]);
 }
@@ -533,11 +587,11 @@ __device__ __forceinline__ void ulv_fwd_body(const hssk_sweep_fwd_desc* __restri
 // LOOP: the groups of right-hand sides in turn inside the workgroup (many groups); otherwise one group per workgroup along
 // blockIdx.y -- the few-right-hand-side form keeps the straight-line body (the loop and its closing barrier cost the
 // single-vector solve 15 percent)
-template <int NR, int LDV, bool LOOP>
+template <int NR, int LDV, bool LOOP, bool CHAIN = false>
 __global__ __launch_bounds__(SW_T) void ulv_fwd_sweep_kernel(const hssk_sweep_fwd_desc* __restrict__ descs, int nrhs_total, int* err) {
-  if (!LOOP) { ulv_fwd_body<NR, LDV>(descs, nrhs_total, err, (int)blockIdx.y); return; }
+  if (!LOOP) { ulv_fwd_body<NR, LDV, CHAIN>(descs, nrhs_total, err, (int)blockIdx.y); return; }
   for (int g = blockIdx.y; g * NR < nrhs_total; g += gridDim.y) {
-    ulv_fwd_body<NR, LDV>(descs, nrhs_total, err, g);
+    ulv_fwd_body<NR, LDV, CHAIN>(descs, nrhs_total, err, g);
     __syncthreads();   // (the LDS vectors are reused by the next group)
   }
 }
@@ -782,7 +836,9 @@ int* sweep_err(hssk_ctx* ctx) {
 
 }  // namespace
 
+static std::atomic<long long> chain_launches{0};
 extern "C" long long hssk_sweep_mma_launches(void) { return mma_launches; }
+extern "C" long long hssk_sweep_chain_launches(void) { return chain_launches; }
 extern "C" int hssk_sweep_mma_min_nrhs(void) { return mma_min_nrhs() > 0 ? mma_min_nrhs() : 1 << 30; }
 extern "C" int hssk_sweep_require_mma(hssk_ctx* ctx, int on) { ctx->require_mma = on != 0; return 0; }
 
@@ -805,6 +861,8 @@ extern "C" int hssk_sweep_arm(hssk_ctx* ctx, double* buf, long long count) {
   hssk_rt::check_launch();
   HSSK_API_END
 }
+
+extern "C" int hssk_sweep_chain_ok(int m, int r, int mv, int rv) { return chain_shape_ok(m, r, mv, rv, SW_MAX) ? 1 : 0; }
 
 extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* descs, int count, int nrhs) {
   HSSK_API_BEGIN
@@ -854,7 +912,18 @@ extern "C" int hssk_ulv_fwd_sweep(hssk_ctx* ctx, const hssk_sweep_fwd_desc* desc
   if (nrhs > 64 || ctx->require_mma) HSSK_UNSUPPORTED("operands beyond the matrix-core sweep");
   const unsigned gy = groups_y(nrhs, 1);
   auto lds = [](int nr, int ldv) { return sizeof(double) * ((size_t)5 * ldv * nr + (size_t)SW_T * nr) + sizeof(int) * (size_t)ldv; };
-  if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  // (chain blocks: the instantiation that uses them where every inner node below the root brought one the kernel takes)
+  bool chain = nrhs == 1;
+  int nchain = 0;
+  for (int i = 0; i < count && chain; i++) {
+    const hssk_sweep_fwd_desc& d = descs[i];
+    if (!d.B01 || d.LU || d.m <= d.r) continue;
+    chain = d.G != nullptr && chain_shape_ok(d.m, d.r, d.mv, d.rv, SW_MAX);
+    nchain++;
+  }
+  if (nrhs == 1 && chain && nchain > 0) chain_launches++;
+  if (nrhs == 1 && chain && nchain > 0) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false, true>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
+  else if (nrhs == 1) HSSK_LAUNCH((ulv_fwd_sweep_kernel<1, SW_MAX, false>), dim3((unsigned)count, 1u), dim3(SW_T), lds(1, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
   else if ((int)gy * SW_NR >= nrhs && !wide_ok(nrhs, dmax, 1)) HSSK_LAUNCH((ulv_fwd_sweep_kernel<SW_NR, SW_MAX, false>), dim3((unsigned)count, gy), dim3(SW_T), lds(SW_NR, SW_MAX), ctx->stream, dd, nrhs, sweep_err(ctx));
   else if (wide_ok(nrhs, dmax, 1)) {
     // many right-hand sides, small nodes (the inner levels of the hybrid path): sixteen right-hand sides per pass

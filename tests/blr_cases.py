@@ -19,12 +19,18 @@ CASES = {
     "p64_weak": (64, 8, 8, 256, "both", False, "weak", 1e-4, "gpu"),
     "p64_unsym_strong": (64, 6, 10, 256, "left", True, "strong", 1e-6, "gpu"),
 }
+# fronts with a separator of 10 000 unknowns (a 100 x 100 plane: the size class of the 200^3 problem's upper fronts), GPU tier;
+# fixtures: tests/golden/make_golden_blr_front_10k.py -> blr_front_10k_golden.npz
+BIG_CASES = {
+    "p100_root": (100, 12, 12, 256, "none", False, "weak", 1e-4, "gpu"),
+    "p100_left": (100, 10, 14, 256, "left", False, "weak", 1e-4, "gpu"),
+}
 NRHS = 3
 ACA_CASES = ("p16_weak", "p12_unsym_strong", "p40_weak")   # also recorded with ACA tile compression
 
 
 def build_case(name):
-    n, pl, pr, leaf, upd, unsym, admk, rtol, _ = CASES[name]
+    n, pl, pr, leaf, upd, unsym, admk, rtol, _ = (CASES.get(name) or BIG_CASES[name])
     fr = BF.poisson_front(n, pl, pr, leaf, upd=upd, unsym=unsym)
     # sparse/fronts/FrontBLR.cpp:424-429: the absolute tolerance is scaled by the norm of [F11 F12; F21 0]
     nF = np.sqrt(sum(np.linalg.norm(fr[k]) ** 2 for k in ("F11", "F12", "F21")))
@@ -39,7 +45,11 @@ def build_case(name):
 
 
 def golden():
-    return np.load(os.path.join(HERE, "golden", "blr_front_golden.npz"))
+    G = dict(np.load(os.path.join(HERE, "golden", "blr_front_golden.npz")))
+    big = os.path.join(HERE, "golden", "blr_front_10k_golden.npz")
+    if os.path.exists(big):
+        G.update(np.load(big))
+    return G
 
 
 def err(a, b):

@@ -68,6 +68,13 @@ def test_sweep_plans(L):
     hk.close()
 
 
+def test_chain_blocks(L):
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(emu_lib.PATH)
+    HC.check_chain_blocks(L, hk, n=300, leaf=32)
+    hk.close()
+
+
 def test_float_and_complex_instantiations(L):
     HC.check_scz(L)
 

@@ -88,6 +88,13 @@ def test_sweep_plans(L):
     hk.close()
 
 
+def test_chain_blocks(L):
+    from strumpack_amd import hssk as K
+    hk = K.Hssk(_loader.lib_path())
+    HC.check_chain_blocks(L, hk, n=6000, leaf=64)
+    hk.close()
+
+
 def test_native_code_is_loaded():
     import os
     maps = open("/proc/self/maps").read()
