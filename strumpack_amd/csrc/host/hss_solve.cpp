@@ -100,6 +100,11 @@ void DeviceHSS::chain_blocks() {
   }
 }
 
+static int solve_side_mode() {
+  static const int v = [] { const char* e = std::getenv("STRUMPACK_AMD_SOLVE_SIDE"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
 // sr != 0: the subtree of node sr as a matrix of its own (factor_node): rows of b = the node's rows
 // phase 0: the whole solve; 1: forward half, state kept in *ws; 2: backward half from *ws
 void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_device, int phase, SolveWork* ws) {
@@ -419,7 +424,7 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
   const bool hybrid = fuse && !dist_subtree_ && (nrhs >= hybrid_nrhs() || big_leaves) && lv_height.size() > 1;
   bool fwd_done = phase == 2;   // (the backward half: the forward sweep ran in forward_solve)
   static const bool no_side = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
-  const bool side = hybrid && !no_side && phase == 0;   // (a split solve keeps every launch on the main stream)
+  const bool side = hybrid && !no_side && phase == 0 && solve_side_mode() != 0;   // (a split solve keeps every launch on the main stream)
   std::vector<int> leaf_parents;   // the leaves' parents, whatever their depth: one batch
   if (hybrid)
     for (auto& ids : lv_depth) leaf_parents.insert(leaf_parents.end(), ids.begin(), ids.end());
@@ -434,14 +439,22 @@ void DeviceHSS::solve_sub(int sr, int nrhs, double* b, long long ldb, bool on_de
       leaves_done = fwd_sweep(leaf_level);
     }
     if (!leaves_done) fwd(lv_height[0], true);
-    if (side) {
-      // the leaves' Q~(:, 0:q) y -- most of the backward step, and independent of the levels above -- next to the inner levels
+    // the leaves' Q~(:, 0:q) y -- most of the backward step, and independent of the levels above -- can run on the side stream
+    // next to the inner levels (STRUMPACK_AMD_SOLVE_SIDE=1: next to the forward sweep's, =2: next to the backward sweep's).  Off
+    // since round 6: the product now keeps two workgroups per CU busy (gemm_tall_kernel: 0.16 instead of 0.25 ms) and takes the
+    // memory system from the chain of inner levels -- 0.543 (=1) / 0.570 (=2) against 0.534 ms one after the other at N = 1e5
+    // (gpurun_out/sweeps_n64_a.txt); the mat-vec, whose leaf product needs nothing from the tree, keeps its side stream (0.248
+    // against 0.316 ms).
+    const bool side_early = solve_side_mode() == 1;
+    auto side_leaves = [&] {
       ck(hssk_side_begin(ctx_));
       struct End { hssk_ctx* c; ~End() { hssk_side_end(c); } } end{ctx_};
       bwd(leaf_parents, 3);
-    }
+    };
+    if (side && side_early) side_leaves();
     if (!fwd_sweep(inner))
       for (auto& ids : inner) fwd(ids);
+    if (side && !side_early) side_leaves();
     fwd_done = true;
   }
   if (!fwd_done && !(fuse && fwd_sweep(lv_height)))

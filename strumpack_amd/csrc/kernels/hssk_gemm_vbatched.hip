@@ -427,66 +427,87 @@ inline bool panel_eligible(const hssk_gemm_desc& d) {
 // tiles of B.  The MFMA takes the B fragment first, so a lane holds C[i = l & 15][j = (l >> 4) + 4 r]: sixteen
 // lanes store sixteen consecutive rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int TALL_T = 1024, TALL_M = 256, TALL_N = 64, TALL_LDB = TALL_N + 1, TALL_CH = 16, TALL_KMAX = 256;
+// Round 6: 512 threads and B in the LDS HALF of K at a time.  The first form (1024 threads, all of B: 101 KB for the 195-row
+// leaves of N = 1e5) was one workgroup per CU by registers and by LDS, so the 512 leaves ran as two rounds of workgroups whose
+// phases -- load B, stream A, store C -- had nothing to overlap with: 116 us for the leaves' D X at 64 right-hand sides (2.2 TB/s),
+// 193 - 245 us next to the inner levels' sweep, the longest launch of the mat-vec and of the solve.  Now a wave owns two 16-row
+// tiles (accumulators of both live across the halves), two workgroups share a CU and every leaf is resident at once.
+constexpr int TALL_T = 512, TALL_M = 256, TALL_N = 64, TALL_LDB = TALL_N + 1, TALL_CH = 8, TALL_KMAX = 256, TALL_KH = 128;
 
-__global__ __launch_bounds__(TALL_T) void gemm_tall_kernel(const hssk_gemm_desc* __restrict__ descs, const Tile* __restrict__ tiles) {
+__global__ __launch_bounds__(TALL_T) HSSK_WAVES_PER_SIMD(4) void gemm_tall_kernel(const hssk_gemm_desc* __restrict__ descs, const Tile* __restrict__ tiles) {
   HSSK_DYN_SHARED(double, Bs);
   const Tile t = tiles[blockIdx.x];
   const hssk_gemm_desc p = descs[t.prob];
   const int tid = threadIdx.x, lane = tid & 63, wave = hssk_uniform(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int m = p.m, n = p.n, k = p.k;
-  // B -> LDS (lanes along k: contiguous in memory), zero beyond column n
-  {
-    const int cs = TALL_T / k, kk = tid % k, jq = tid / k;   // k <= 256: cs >= 4 columns per pass
-    if (jq < cs)
-      for (int j = jq; j < TALL_N; j += 8 * cs) {   // eight loads in flight (one at a time: a memory round trip per column)
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = hssk_gload(p.B, (size_t)kk + (size_t)min(j + u * cs, n - 1) * p.ldb);
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (j + u * cs < TALL_N) Bs[kk * TALL_LDB + j + u * cs] = j + u * cs < n ? v[u] : 0.;
-      }
-  }
-  __syncthreads();
-  const int nks = (k + 3) >> 2;
-  const int nch = hssk_uniform((nks + TALL_CH - 1) / TALL_CH);
+  const int nh = (k + TALL_KH - 1) / TALL_KH;
+  const int kc = (((k + nh - 1) / nh) + 3) & ~3;   // rows of B per pass (a multiple of the MFMA's four k)
   const int r0 = t.tm * TALL_M;
-  for (int tl = wave; tl * 16 < TALL_M && r0 + tl * 16 < m; tl += TALL_T / 64) {
-    const int i = r0 + tl * 16 + l15;
-    // A fragment element, indices clamped into the block: no branch around the load and no select behind it (either makes the
-    // compiler wait for the load long before the matrix cores need it).  Rows beyond m are never stored; k-steps beyond k
-    // multiply by zeros read in place of B.
-    auto aload = [&](int kk) -> double {
-      const int ic = min(i, m - 1), kc = min(kk, k - 1);
-      return p.transA ? hssk_gload(p.A, (size_t)kc + (size_t)ic * p.lda) : hssk_gload(p.A, (size_t)ic + (size_t)kc * p.lda);
-    };
-    hssk_d4 acc[4];
+  constexpr int NW = TALL_T / 64, NTL = TALL_M / 16 / NW;   // tiles per wave: wave, wave + NW
+  hssk_d4 acc[NTL][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) acc[ct] = hssk_d4{0., 0., 0., 0.};
-    auto chunk = [&](int k0, const double (&a)[TALL_CH]) {
+  for (int q = 0; q < NTL; q++)
 #pragma unroll
-      for (int u = 0; u < TALL_CH; u++) {
-        const int kk = k0 + 4 * u;
-        const double* xr = Bs + min(kk, k - 1) * TALL_LDB + l15;
+    for (int ct = 0; ct < 4; ct++) acc[q][ct] = hssk_d4{0., 0., 0., 0.};
+  for (int kb = 0; kb < k; kb += kc) {
+    const int kn = min(kc, k - kb);
+    if (kb) __syncthreads();   // (every wave is done with the previous rows of B)
+    // B(kb : kb + kn, :) -> LDS (lanes along k: contiguous in memory), zero beyond column n
+    {
+      const int cs = TALL_T / kn, kk = tid % kn, jq = tid / kn;   // kn <= 128: cs >= 4 columns per pass
+      if (jq < cs)
+        for (int j = jq; j < TALL_N; j += 8 * cs) {   // eight loads in flight (one at a time: a memory round trip per column)
+          double v[8];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) acc[ct] = hssk_mfma_f64_16x16x4(kk < k ? xr[ct * 16] : 0., a[u], acc[ct]);
-      }
-    };
-    // two register sets in turn: the fragments of the next chunk are in flight while the matrix cores work on the current one
-    double a0[TALL_CH], a1[TALL_CH];
+          for (int u = 0; u < 8; u++) v[u] = hssk_gload(p.B, (size_t)(kb + kk) + (size_t)min(j + u * cs, n - 1) * p.ldb);
 #pragma unroll
-    for (int u = 0; u < TALL_CH; u++) a0[u] = aload(4 * u + l4);
-    for (int c = 0; c < nch; c += 2) {
-      const int k0 = 4 * TALL_CH * c + l4;
-#pragma unroll
-      for (int u = 0; u < TALL_CH; u++) a1[u] = aload(k0 + 4 * TALL_CH + 4 * u);
-      chunk(k0, a0);
-#pragma unroll
-      for (int u = 0; u < TALL_CH; u++) a0[u] = aload(k0 + 8 * TALL_CH + 4 * u);
-      chunk(k0 + 4 * TALL_CH, a1);   // (beyond k: zeros on the B side)
+          for (int u = 0; u < 8; u++)
+            if (j + u * cs < TALL_N) Bs[kk * TALL_LDB + j + u * cs] = j + u * cs < n ? v[u] : 0.;
+        }
     }
+    __syncthreads();
+    const int nks = (kn + 3) >> 2;
+    const int nch = hssk_uniform((nks + TALL_CH - 1) / TALL_CH);
+#pragma unroll
+    for (int q = 0; q < NTL; q++) {
+      const int tl = wave + q * NW;
+      if (r0 + tl * 16 >= m) continue;   // (uniform in the wave)
+      const int i = r0 + tl * 16 + l15;
+      // A fragment element, indices clamped into the block: no branch around the load and no select behind it (either makes the
+      // compiler wait for the load long before the matrix cores need it).  Rows beyond m are never stored; k-steps beyond the
+      // pass multiply by zeros read in place of B.
+      auto aload = [&](int kk) -> double {
+        const int ic = min(i, m - 1), kg = kb + min(kk, kn - 1);
+        return p.transA ? hssk_gload(p.A, (size_t)kg + (size_t)ic * p.lda) : hssk_gload(p.A, (size_t)ic + (size_t)kg * p.lda);
+      };
+      auto chunk = [&](int k0, const double (&a)[TALL_CH]) {
+#pragma unroll
+        for (int u = 0; u < TALL_CH; u++) {
+          const int kk = k0 + 4 * u;
+          const double* xr = Bs + min(kk, kn - 1) * TALL_LDB + l15;
+#pragma unroll
+          for (int ct = 0; ct < 4; ct++) acc[q][ct] = hssk_mfma_f64_16x16x4(kk < kn ? xr[ct * 16] : 0., a[u], acc[q][ct]);
+        }
+      };
+      // two register sets in turn: the fragments of the next chunk are in flight while the matrix cores work on the current one
+      double a0[TALL_CH], a1[TALL_CH];
+#pragma unroll
+      for (int u = 0; u < TALL_CH; u++) a0[u] = aload(4 * u + l4);
+      for (int c = 0; c < nch; c += 2) {
+        const int k0 = 4 * TALL_CH * c + l4;
+#pragma unroll
+        for (int u = 0; u < TALL_CH; u++) a1[u] = aload(k0 + 4 * TALL_CH + 4 * u);
+        chunk(k0, a0);
+#pragma unroll
+        for (int u = 0; u < TALL_CH; u++) a0[u] = aload(k0 + 8 * TALL_CH + 4 * u);
+        chunk(k0 + 4 * TALL_CH, a1);   // (beyond the pass: zeros on the B side)
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NTL; q++) {
+    const int i = r0 + (wave + q * NW) * 16 + l15;
     if (i < m) {
 #pragma unroll
       for (int ct = 0; ct < 4; ct++)
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(TALL_T) void gemm_tall_kernel(const hssk_gemm_desc*
         for (int r = 0; r < 4; r++) {
           const int j = ct * 16 + l4 + 4 * r;
           if (j < n) {
-            double v = p.alpha * acc[ct][r];
+            double v = p.alpha * acc[q][ct][r];
             if (p.beta != 0.) v += p.beta * hssk_gload(p.C, (size_t)i + (size_t)j * p.ldc);
             hssk_gstore(p.C, (size_t)i + (size_t)j * p.ldc, v);
           }
@@ -609,7 +630,10 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
     }
     if (tall_eligible(d)) {
       for (int tm = 0; tm * TALL_M < d.m; tm++) ttiles.push_back(Tile{p, tm, 0});
-      kmax_tall = std::max(kmax_tall, d.k);
+      {   // rows of B per pass of this problem (the kernel's own arithmetic): the LDS is sized for the largest
+        const int nh = (d.k + TALL_KH - 1) / TALL_KH;
+        kmax_tall = std::max(kmax_tall, (((d.k + nh - 1) / nh) + 3) & ~3);
+      }
       continue;
     }
     if (panel_eligible(d)) {
@@ -660,7 +684,7 @@ extern "C" int hssk_gemm_vbatched(hssk_ctx* ctx, const hssk_gemm_desc* descs, in
   }
   if (!ttiles.empty()) {
     auto* d_tiles = (const Tile*)ctx->stage(ttiles.data(), sizeof(Tile) * ttiles.size());
-    const size_t lds = sizeof(double) * (size_t)kmax_tall * TALL_LDB;
+    const size_t lds = sizeof(double) * (size_t)kmax_tall * TALL_LDB;   // (the largest pass of any problem)
     hssk_rt::allow_dynamic_lds(gemm_tall_kernel, lds);
     HSSK_LAUNCH(gemm_tall_kernel, dim3((unsigned)ttiles.size()), dim3(TALL_T), lds, ctx->stream, d_descs, d_tiles);
   }
