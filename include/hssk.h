@@ -117,6 +117,11 @@ double hssk_watch_read_ms(hssk_ctx* ctx, int id, int* pairs);
  * the short tail / edge launches and the reduce pass are outside the bracket. */
 float hssk_last_dgemm_ms(hssk_ctx* ctx);
 double hssk_last_dgemm_flops(hssk_ctx* ctx);
+/* the same without a synchronisation behind every product: _defer sets the last launch's bracket aside (hssk_last_dgemm_ms
+ * then has nothing to report until the next product), _collect synchronises once and returns the summed duration (ms),
+ * algorithmic flops and number of the brackets set aside since its last call */
+int hssk_dgemm_timing_defer(hssk_ctx* ctx);
+int hssk_dgemm_timing_collect(hssk_ctx* ctx, double* ms, double* flops, int* launches);
 /* profiling aid: per-workgroup records of that main launch, 4 long long each {start, end (100 MHz ticks), hardware id
  * (XCC_ID << 32 | HW_ID), column tile}; returns the number of records copied (<= max_wgs).  Synchronises. */
 long long hssk_last_dgemm_trace(hssk_ctx* ctx, long long* out, long long max_wgs);

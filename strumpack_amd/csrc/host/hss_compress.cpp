@@ -1,6 +1,7 @@
 // DeviceHSS: the adaptive randomized compression (driver, tree levels, ID / TSQR, stopping test).
 // HSSMatrix.compress_stable.hpp:100-442, HSSMatrix.compress.hpp:100-165,300-368,524-724.
 #include "hss_engine_internal.hpp"
+#include <cstdio>
 
 namespace strumpack {
 namespace HSS {
@@ -76,11 +77,24 @@ void DeviceHSS::compress(Source& src) {
                 // restarted run retraces the same samples and continues past the old capacity)
     if (o_.verbose) std::cout << "# HSS compression: growing the sample capacity to " << dcap << std::endl;
   }
+  static const bool trace_host = [] { const char* e = std::getenv("STRUMPACK_AMD_TRACE_HOST"); return e && e[0] == '1'; }();
+  const double th0 = now();
   if (dist_subtree_) exchange_node_table();
   free_compress_workspace();
   comm_arena_->reset();
+  const double th1 = now();
+  {
+    const double ms = hssk_watch_read_ms(ctx_, 5, nullptr);   // every product of every round and attempt
+    if (ms > 0.) stats_.t_sketch = ms * 1e-3;
+    double kms = 0., kfl = 0.;
+    int kn = 0;
+    ck(hssk_dgemm_timing_collect(ctx_, &kms, &kfl, &kn));     // the main launches of the products (hssk_dgemm_timing_defer)
+    stats_.sketch_kernel_ms += kms; stats_.sketch_kernel_flops += kfl; stats_.sketch_launches += kn;
+  }
   stats_.t_compress = now() - t0;
   stats_.t_tree = stats_.t_compress - stats_.t_sketch - stats_.t_random;
+  stats_.t_mark = now();
+  if (trace_host) std::fprintf(stderr, "# host: compress end: free workspace %.1f us, timers %.1f us\n", (th1 - th0) * 1e6, (now() - th1) * 1e6);
 }
 
 void DeviceHSS::fill_random(int r0, int dn) {
@@ -206,10 +220,12 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
         for (auto& ids : own_by_height_) for (int id : ids) if (nodes_[id].leaf() && nodes_[id].lvl != 0) leaves.push_back(id);
         extract_blocks(src, leaves);
       }
-      double t0 = now();
+      // (the sketch phase is timed on the device clock -- stopwatch 5, read at the end of compress() --: a host clock needs a
+      //  synchronisation behind the products, and the leaf level's first launch then starts a sync return and 512 descriptors
+      //  later, 80 us at N = 1e5; now it is enqueued while the products run)
+      ck(hssk_watch_start(ctx_, 5));
       src.sample(*this, c, dnew);
-      ck(hssk_sync(ctx_));
-      stats_.t_sketch += now() - t0;
+      ck(hssk_watch_stop(ctx_, 5));
       stats_.f_sketch += src.sketch_flops(*this, dnew);   // per product: 2 N^2 d (SJLT streamed: 2 nnz per element)
       if (o_.verbose) std::cout << "# compressing with d+dd = " << d << "+" << dd << " (stable)" << std::endl;
       stats_.rounds++;
@@ -240,10 +256,9 @@ bool DeviceHSS::compress_attempt(Source& src, int dcap) {
     while (!is_compressed()) {
       if (d > dcap) return false;
       fill_random(d_old, d - d_old);
-      double t0 = now();
+      ck(hssk_watch_start(ctx_, 5));
       src.sample(*this, d_old, d - d_old);
-      ck(hssk_sync(ctx_));
-      stats_.t_sketch += now() - t0;
+      ck(hssk_watch_stop(ctx_, 5));
       stats_.f_sketch += src.sketch_flops(*this, d - d_old);
       if (o_.verbose) std::cout << "# compressing with d = " << d - o_.p << " + " << o_.p << (o_.algorithm == 2 ? " (original, hard restart)" : " (original)") << std::endl;
       if (o_.algorithm == 2) {   // keep the new samples as drawn

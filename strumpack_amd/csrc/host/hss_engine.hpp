@@ -94,6 +94,7 @@ struct PhaseStats {
   double sketch_kernel_flops = 0;  // algorithmic flops of those launches
   double sketch_kernel_bytes = 0;  // SJLT sketch: algorithmic HBM bytes of those launches (8 per element of A read)
   int sketch_launches = 0, rounds = 0, d_final = 0;
+  double t_mark = 0;   // host clock at the end of compress() (STRUMPACK_AMD_TRACE_HOST)
   // algorithmic flop model
   double f_sketch = 0, f_local = 0, f_reduce = 0, f_id = 0, f_ortho = 0, f_ulv = 0, f_solve = 0;
   // algorithmic HBM bytes of one solve / one mat-vec: every block the sweep reads, once (vectors not included)

@@ -1,5 +1,6 @@
 // DeviceHSS: ULV factorization (HSSMatrix.factor.hpp:51-147).
 #include "hss_engine_internal.hpp"
+#include <cstdio>
 
 namespace strumpack {
 namespace HSS {
@@ -247,12 +248,27 @@ void DeviceHSS::factor_sub(int sr, bool partial) {
     ck(hssk_sync(ctx_));
     frun_.cx = ctx_;
   } else {
+    static const bool trace_host = [] { const char* e = std::getenv("STRUMPACK_AMD_TRACE_HOST"); return e && e[0] == '1'; }();
+    const double th0 = now();
     factor_cancel();
     ck(hssk_sync(ctx_));
+    const double th1 = now();
     factor_begin(sr, partial, ctx_);
-    // the dense column bases depend on the compression only: one launch for the whole tree instead of one per level
+    const double th2 = now();
+    if (trace_host) std::fprintf(stderr, "# host: factor: entry %.1f us, cancel + sync %.1f us, begin %.1f us\n", (th0 - t0) * 1e6, (th1 - th0) * 1e6, (th2 - th1) * 1e6);
+    // the dense column bases depend on the compression only: one launch for the lowest level -- whose elimination, the bulk of
+    // the factorization, is then enqueued before the host has touched the rest of the tree -- and one for everything above it
+    // instead of one per level
+    if (!levels.empty()) {
+      const double tp0 = now();
+      factor_prep(levels[0]);
+      const double tp1 = now();
+      factor_level(levels[0]);
+      frun_.done = 1;
+      if (trace_host) std::fprintf(stderr, "# host: factor: prep of the lowest level %.1f us, its launches %.1f us; since the end of compress() %.1f us\n", (tp1 - tp0) * 1e6, (now() - tp1) * 1e6, (tp0 - stats_.t_mark) * 1e6);
+    }
     std::vector<int> all;
-    for (auto& ids : levels) all.insert(all.end(), ids.begin(), ids.end());
+    for (size_t h = 1; h < levels.size(); h++) all.insert(all.end(), levels[h].begin(), levels[h].end());
     if (dist_subtree_) for (auto& ids : top_by_height_) all.insert(all.end(), ids.begin(), ids.end());
     factor_prep(all);
   }

@@ -53,18 +53,16 @@ struct DeviceHSS::DenseDeviceSource : DeviceHSS::Source {
         }
       }
     } else if (nloc > 0) {
+      // (the products' kernel timings are set aside and read at the end of compress(): no synchronisation between the products
+      //  nor behind them)
       ck(hssk_dgemm(H.ctx_, 1, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0, lda, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));
-      ck(hssk_sync(H.ctx_));
-      float ms = hssk_last_dgemm_ms(H.ctx_);
-      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
+      ck(hssk_dgemm_timing_defer(H.ctx_));
       if (H.o_.symmetric) {   // A^T R = A R: the second product is a copy of the first
         hssk_colgather_desc cp{H.Srt_ + r0 + j0 * H.dcap_, H.Sct_ + r0 + j0 * H.dcap_, nullptr, dn, (int)nloc, H.dcap_, H.dcap_, 0};
         ck(hssk_gather_cols(H.ctx_, &cp, 1));
       } else {
         ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dA + j0 * lda, lda, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
-        ck(hssk_sync(H.ctx_));
-        ms = hssk_last_dgemm_ms(H.ctx_);
-        if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
+        ck(hssk_dgemm_timing_defer(H.ctx_));
       }
     }
     if (H.o_.world > 1 && !H.dist_subtree_) {
@@ -111,11 +109,7 @@ struct DeviceHSS::ShardedDenseSource : DeviceHSS::Source {
     const long long N = H.n_;
     const Node& c = H.nodes_[single ? 0 : H.cut_nodes_[H.o_.rank]];
     const long long j0 = c.lo, nloc = c.m;
-    auto timed = [&] {
-      ck(hssk_sync(H.ctx_));
-      const float ms = hssk_last_dgemm_ms(H.ctx_);
-      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
-    };
+    auto timed = [&] { ck(hssk_dgemm_timing_defer(H.ctx_)); };   // (read at the end of compress())
     ck(hssk_dgemm(H.ctx_, 0, dn, nloc, N, 1.0, H.Rt_ + r0, H.dcap_, dCols, ldc, 0.0, H.Sct_ + r0 + j0 * H.dcap_, H.dcap_));
     timed();
     if (dRows) {
@@ -432,11 +426,7 @@ struct DeviceHSS::GeneratorSource : DeviceHSS::Source {
       j0 = std::min(N, H.cols_per_rank_ * H.o_.rank); j1 = std::min(N, j0 + H.cols_per_rank_);
     }
     const long long nloc = j1 - j0;
-    auto timed = [&] {
-      ck(hssk_sync(H.ctx_));
-      const float ms = hssk_last_dgemm_ms(H.ctx_);
-      if (ms > 0) { H.stats_.sketch_kernel_ms += ms; H.stats_.sketch_launches++; H.stats_.sketch_kernel_flops += hssk_last_dgemm_flops(H.ctx_); }
-    };
+    auto timed = [&] { ck(hssk_dgemm_timing_defer(H.ctx_)); };   // (read at the end of compress())
     if (nloc > 0) {
       // Sr(j0:j1, :) = A(j0:j1, :) R  ->  op(G)(k, j) = G(j0 + j, k);   Sc(j0:j1, :) = A(:, j0:j1)^T R  ->  op(G)(k, j) = G(k, j0 + j)
       ck(hssk_sketch_gen(H.ctx_, &g, 1, dn, nloc, N, j0, 1.0, H.Rt_ + r0, H.dcap_, 0.0, H.Srt_ + r0 + j0 * H.dcap_, H.dcap_));

@@ -295,6 +295,7 @@ void hssk_ctx_destroy(hssk_ctx* c) {
   delete c->uploader;
   hssk_rt::pinned_free(c->h_sweep_err);
   for (auto& w : c->watch) for (auto& p : w) { hssk_rt::event_destroy(p.first); hssk_rt::event_destroy(p.second); }
+  for (auto& b : c->dgemm_deferred) { hssk_rt::event_destroy(b.a); hssk_rt::event_destroy(b.b); }
   for (auto e : c->watch_free) hssk_rt::event_destroy(e);
   hssk_rt::event_destroy(c->ev0);
   hssk_rt::event_destroy(c->ev_sync);
@@ -524,6 +525,37 @@ double hssk_last_dgemm_flops(hssk_ctx* c) { return c->dgemm_timed ? c->dgemm_tim
 float hssk_last_dgemm_ms(hssk_ctx* c) {
   if (!c->dgemm_timed) return -1.f;
   try { return hssk_rt::event_elapsed_ms(c->ev0, c->ev1); } catch (...) { return -1.f; }
+}
+
+// The bracket of the last timed launch is set aside (the context gets fresh events) instead of being read: reading needs a
+// synchronisation behind the launch, and a caller with more launches to enqueue -- the second sketch product, the leaf level
+// behind it -- would leave the device idle for the sync's return and its own host work (35 - 80 us per product at N = 1e5).
+int hssk_dgemm_timing_defer(hssk_ctx* c) {
+  HSSK_API_BEGIN
+  if (!c->dgemm_timed) return 0;
+  c->dgemm_deferred.push_back(hssk_ctx::TimedBracket{c->ev0, c->ev1, c->dgemm_timed_flops});
+  c->ev0 = watch_event(c);
+  c->ev1 = watch_event(c);
+  c->dgemm_timed = false;
+  HSSK_API_END
+}
+// synchronises; sums and releases the brackets set aside since the last call
+int hssk_dgemm_timing_collect(hssk_ctx* c, double* ms, double* flops, int* launches) {
+  HSSK_API_BEGIN
+  double t = 0., f = 0.;
+  int n = 0;
+  if (!c->dgemm_deferred.empty()) hssk_rt::sync(c->stream);
+  for (auto& b : c->dgemm_deferred) {
+    const float e = hssk_rt::event_elapsed_ms(b.a, b.b);
+    if (e > 0) { t += e; f += b.flops; n++; }
+    c->watch_free.push_back(b.a);
+    c->watch_free.push_back(b.b);
+  }
+  c->dgemm_deferred.clear();
+  if (ms) *ms = t;
+  if (flops) *flops = f;
+  if (launches) *launches = n;
+  HSSK_API_END
 }
 
 }  // extern "C"

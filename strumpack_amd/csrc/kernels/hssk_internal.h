@@ -60,6 +60,9 @@ struct hssk_ctx {
   bool require_mma = false;   // hssk_sweep_require_mma: the sweeps refuse (code 2) what their matrix-core form cannot take
   bool dgemm_timed = false;
   double dgemm_timed_flops = 0.;  // algorithmic flops of the launch bracketed by ev0 / ev1
+  // brackets set aside by hssk_dgemm_timing_defer (read by _collect at the caller's next synchronisation)
+  struct TimedBracket { hssk_rt::event_t a, b; double flops; };
+  std::vector<TimedBracket> dgemm_deferred;
   long long dgemm_trace_wgs = 0;  // workgroups of the last main launch (trace records behind d_clk + 4)
   long long* d_clk = nullptr;   // device: {shader cycles, 100 MHz ticks} of workgroup 0 of the last dgemm
   double* d_scratch = nullptr;  // split-K partials of hssk_dgemm

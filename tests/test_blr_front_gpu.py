@@ -1,6 +1,7 @@
 """GPU parity tests of the BLR frontal-matrix path (BASELINE configs[4]: BLR-compressed fronts of the 3D Poisson problem,
 batched LU) through the C interface SPX_d_blr_front_*: fixtures of the reference's own
-BLRMatrix::construct_and_partial_factor (tests/golden/make_golden_blr_front.py) on fronts with dsep 100 ... 4096."""
+BLRMatrix::construct_and_partial_factor (tests/golden/make_golden_blr_front.py, make_golden_blr_front_10k.py) on fronts with
+dsep 100 ... 10000."""
 import numpy as np
 import pytest
 
@@ -18,6 +19,13 @@ def L():
 
 @pytest.mark.parametrize("name", sorted(BC.CASES))
 def test_front_against_reference(L, name):
+    BC.check_front(L, name)
+
+
+@pytest.mark.parametrize("name", sorted(BC.BIG_CASES))
+def test_front_10k_against_reference(L, name):
+    # separators of 10 000 unknowns (a 100 x 100 plane: the size class of the 200^3 problem's upper fronts), fixtures of the
+    # reference's own run (tests/golden/make_golden_blr_front_10k.py: 277 / 498 s per factorization on eight cores)
     BC.check_front(L, name)
 
 
@@ -71,7 +79,7 @@ def test_front_device_operands(L):
 
 @pytest.mark.parametrize("nx,ny,upd", [(200, 200, "none"), (200, 100, "both")])
 def test_front_at_the_200cubed_problems_own_sizes(L, nx, ny, upd):
-    """BASELINE configs[4] at ITS front sizes -- what the reference hands to BLRMatrix::construct_and_partial_factor
+    r"""BASELINE configs[4] at ITS front sizes -- what the reference hands to BLRMatrix::construct_and_partial_factor
     (BLR/BLRMatrix.cpp:740) on the 200^3 Poisson problem: the root separator (a 200 x 200 plane: dsep 40000, no update part)
     and a second-level front (200 x 100 plane: dsep 20000, dupd 40000).  The reference's routine needs minutes to hours on
     these, so the checks are the size-independent properties of a partial factorization, on the device (torch is plumbing):
