@@ -356,6 +356,31 @@ typedef struct hssk_ulvsplit_desc {
   int ldt;
 } hssk_ulvsplit_desc;
 int hssk_ulv_split(hssk_ctx* ctx, const hssk_ulvsplit_desc* descs, int count);
+/* The whole ULV step of an INNER node as one workgroup (kernels/hssk_ulv_node.hip; HSSMatrix.factor.hpp:65-137): children a, b
+ * with U ranks ra, rb (m = ra + rb rows) and V ranks rva, rvb.
+ *   D-hat (Dh, m x m, ld m: the diagonal blocks -- the children's Dt -- are in place): Dh(0:ra, ra:) = B01 Vt1b^T,
+ *     Dh(ra:, 0:ra) = B10 Vt1a^T      (B01 ra x rvb, B10 rb x rva, Vt1a ra x rva, Vt1b rb x rvb, each ld = max(rows, 1))
+ *   V-hat (Vh, m x rv, ld m) = [Vt1a Vd(0:rva, :); Vt1b Vd(rva:, :)]   (Vd (rva + rvb) x rv, ld rva + rvb; NULL: skipped)
+ * eliminate != 0 (r < m): with the row ID (perm, X: r x (m - r), ld max(r, 1))
+ *   W1 = (P^T Dh)(0:r, :) (ld max(r, 1)), Rlq (m x (m - r), ld m) = QR of W0^T = (P^T Dh)(r:, :)^T - W1^T X with tau (m doubles),
+ *   Qt (m x m, ld m) the explicit Q~, Vt0T = Vh^T Q~(:, 0:q) (rv x q, ld rv), Vt1 = Q~(:, q:)^T Vh (r x rv, ld max(r, 1)),
+ *   Dt = W1 Q~(:, q:) (r x r, ld ldt), WQ = W1 Q~(:, 0:q) (r x q, ld max(r, 1)),  q = m - r.
+ * eliminate == 0: the assembly only (the root, factored by hssk_getrf_vbatched).  Returns 2 (nothing issued) unless
+ * hssk_ulv_node_fits() holds for every node -- the caller then takes the batched steps. */
+typedef struct hssk_ulvnode_desc {
+  const double *B01, *B10, *Vt1a, *Vt1b, *Vd;
+  double *Dh, *Vh;
+  int ra, rb, rva, rvb;
+  int eliminate;
+  const int* perm;
+  const double* X;
+  double *W1, *Rlq, *Qt, *tau, *Vt0T, *Vt1, *Dt, *WQ;
+  int m, r, rv, ldt;
+} hssk_ulvnode_desc;
+int hssk_ulv_node_vbatched(hssk_ctx* ctx, const hssk_ulvnode_desc* descs, int count);
+/* 1 if a node of these dimensions fits the fused step (its blocks next to each other in the LDS) */
+int hssk_ulv_node_fits(int m, int r, int rv, int ra, int rb, int rva, int rvb);
+long long hssk_ulv_node_launches(void);   /* launches so far (process-wide; tests) */
 
 /* ---- batched interpolative decomposition ------------------------------------------------------- */
 /* Truncated column-pivoted Householder QR of W (d x m, column-major, overwritten), i.e. the row ID

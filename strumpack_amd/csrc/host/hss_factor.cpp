@@ -77,6 +77,23 @@ void DeviceHSS::factor_level(const std::vector<int>& ids) {
     const int off = id == pa.c0 ? 0 : nodes_[pa.c0].rU;
     return Dh[nd.parent] + off + (size_t)off * ld;
   };
+  // Inner levels whose nodes fit one workgroup each: the level is ONE launch (hssk_ulv_node_vbatched: assembly, split, QR, Q~
+  // and the products behind it per node) instead of five -- 65 - 75 us per level at N = 1e5 in launches of 10 - 17 us for a few
+  // 80-row blocks.  STRUMPACK_AMD_NO_ULV_NODE=1 keeps the batched steps.
+  static const bool no_node = [] { const char* e = std::getenv("STRUMPACK_AMD_NO_ULV_NODE"); return e && e[0] == '1'; }();
+  bool fused = !no_node;
+  for (int id : ids) {
+    const Node& nd = nodes_[id];
+    if (!fused) break;
+    if (nd.leaf()) { fused = false; break; }
+    const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+    const int mu = a.rU + b.rU;
+    const bool vh = (id != sr || partial) && nd.rV > 0;
+    if (mu <= 0 || !a.Vt1 || !b.Vt1) fused = false;
+    if (id != sr && (nd.mU != mu || nd.mU <= nd.rU)) fused = false;
+    if (fused && !hssk_ulv_node_fits(mu, id == sr ? 0 : nd.rU, vh ? nd.rV : 0, a.rU, b.rU, a.rV, b.rV)) fused = false;
+  }
+  std::vector<hssk_ulvnode_desc> un;
   // ---- assemble Dh (mU x mU) and Vh (mU x rV)
   std::vector<hssk_colgather_desc> cp;
   std::vector<hssk_gemm_desc> g0, g1;
@@ -98,18 +115,37 @@ void DeviceHSS::factor_level(const std::vector<int>& ids) {
         cp.push_back(hssk_colgather_desc{a.Dt, Dh[id], nullptr, a.rU, a.rU, std::max(a.rU, 1), std::max(mu, 1), 0});
         cp.push_back(hssk_colgather_desc{b.Dt, Dh[id] + a.rU + (size_t)a.rU * mu, nullptr, b.rU, b.rU, std::max(b.rU, 1), std::max(mu, 1), 0});
       }
-      g0.push_back(hssk_gemm_desc{nd.B01, b.Vt1, Dh[id] + (size_t)a.rU * mu, a.rU, b.rU, b.rV, std::max(a.rU, 1), std::max(b.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
-      g0.push_back(hssk_gemm_desc{nd.B10, a.Vt1, Dh[id] + a.rU, b.rU, a.rU, a.rV, std::max(b.rU, 1), std::max(a.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
+      if (!fused) {
+        g0.push_back(hssk_gemm_desc{nd.B01, b.Vt1, Dh[id] + (size_t)a.rU * mu, a.rU, b.rU, b.rV, std::max(a.rU, 1), std::max(b.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
+        g0.push_back(hssk_gemm_desc{nd.B10, a.Vt1, Dh[id] + a.rU, b.rU, a.rU, a.rV, std::max(b.rU, 1), std::max(a.rU, 1), std::max(mu, 1), 0, 1, 1.0, 0.0});
+      }
       stats_.f_ulv += 2.0 * a.rU * (double)b.rU * (a.rV + b.rV);
     }
     if ((!root || partial) && !nd.leaf() && nd.rV) {
       Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
       // Vh = [Vt1_0 Vd(0:rV0, :) ; Vt1_1 Vd(rV0:, :)]   (Vd: the node's dense column basis, factor_prep)
-      g1.push_back(hssk_gemm_desc{a.Vt1, Vd[id], Vh[id], a.rU, nd.rV, a.rV, std::max(a.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
-      g1.push_back(hssk_gemm_desc{b.Vt1, Vd[id] + a.rV, Vh[id] + a.rU, b.rU, nd.rV, b.rV, std::max(b.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+      if (!fused) {
+        g1.push_back(hssk_gemm_desc{a.Vt1, Vd[id], Vh[id], a.rU, nd.rV, a.rV, std::max(a.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+        g1.push_back(hssk_gemm_desc{b.Vt1, Vd[id] + a.rV, Vh[id] + a.rU, b.rU, nd.rV, b.rV, std::max(b.rU, 1), nd.mV, nd.mU, 0, 0, 1.0, 0.0});
+      }
       stats_.f_ulv += 2.0 * nd.rV * ((double)a.rU * a.rV + (double)b.rU * b.rV);
     }
   }
+  // the assembly half of a fused node's descriptor
+  auto node_desc = [&](int id) {
+    const Node& nd = nodes_[id];
+    const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+    hssk_ulvnode_desc d{};
+    d.B01 = nd.B01; d.B10 = nd.B10; d.Vt1a = a.Vt1; d.Vt1b = b.Vt1;
+    d.ra = a.rU; d.rb = b.rU; d.rva = a.rV; d.rvb = b.rV;
+    d.m = a.rU + b.rU;
+    d.Dh = Dh[id];
+    const bool vh = (id != sr || partial) && nd.rV > 0;
+    d.Vd = vh ? Vd[id] : nullptr;
+    d.Vh = vh ? Vh[id] : nullptr;
+    d.rv = vh ? nd.rV : 0;
+    return d;
+  };
   if (!cp.empty()) ck(hssk_gather_cols(cx, cp.data(), (int)cp.size()));
   // (the coupling products into Dh and the products that build Vh are independent of each other: one batched launch)
   g0.insert(g0.end(), g1.begin(), g1.end());
@@ -136,6 +172,7 @@ void DeviceHSS::factor_level(const std::vector<int>& ids) {
         f.ti.push_back(hssk_trtri_desc{nd.LU, nd.TinvU, mu, mu, 1});
       }
       stats_.f_ulv += 2.0 / 3.0 * mu * (double)mu * mu;
+      if (fused) un.push_back(node_desc(id));   // (eliminate = 0: the assembly; the LU follows below)
       continue;
     }
     const int m = nd.mU, r = nd.rU, rv = nd.rV;
@@ -147,6 +184,21 @@ void DeviceHSS::factor_level(const std::vector<int>& ids) {
       nd.Vt1 = fact_->dbl((size_t)std::max(r, 1) * std::max(rv, 1));
       int ldt = 1;
       nd.Dt = dt_slot(id, r, ldt);
+      if (fused) {
+        hssk_ulvnode_desc d = node_desc(id);
+        d.eliminate = 1;
+        d.perm = nd.permU; d.X = nd.XU; d.r = r;
+        d.W1 = nd.W1; d.Rlq = nd.Rlq; d.Qt = nd.Qt; d.tau = fact_->dbl((size_t)2 * m);
+        d.Vt1 = nd.Vt1; d.Dt = nd.Dt; d.ldt = ldt;
+        if (rv) { nd.Vt0T = fact_->dbl((size_t)rv * (m - r)); d.Vt0T = nd.Vt0T; }
+        if (r) { nd.WQ = fact_->dbl((size_t)r * (m - r)); d.WQ = nd.WQ; }
+        un.push_back(d);
+        nd.Tinv = fact_->dbl((size_t)((m - r + 63) / 64) * 4096);
+        f.ti.push_back(hssk_trtri_desc{nd.Rlq, nd.Tinv, m - r, m, 0});
+        const double k = m - r;
+        stats_.f_ulv += 2.0 * k * r * m + (2.0 * m * k * k - 2.0 / 3.0 * k * k * k) + (4.0 * m * m * k - 2.0 * m * k * k) / 1.0 * 0.5 + 2.0 * m * m * rv + 2.0 * r * (double)r * m;
+        continue;
+      }
       if (m <= 256) {   // one fused launch (hssk_ulv_split); larger blocks: two row gathers and a product
         us.push_back(hssk_ulvsplit_desc{Dh[id], m, m, r, nd.permU, nd.XU, std::max(r, 1), nd.W1, std::max(r, 1), nd.Rlq, m});
       } else {
@@ -184,6 +236,7 @@ void DeviceHSS::factor_level(const std::vector<int>& ids) {
       if (m) ge.push_back(hssk_elem_desc{Dh[id], m, nd.permU, nullptr, 0, 0, nd.Dt, m, m, ldt, 0});
     }
   }
+  if (!un.empty()) ck(hssk_ulv_node_vbatched(cx, un.data(), (int)un.size()));
   if (!us.empty()) ck(hssk_ulv_split(cx, us.data(), (int)us.size()));
   if (!ge.empty()) ck(hssk_gather_elems(cx, ge.data(), (int)ge.size()));
   if (!g2.empty()) ck(hssk_gemm_vbatched(cx, g2.data(), (int)g2.size()));

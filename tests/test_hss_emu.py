@@ -68,6 +68,10 @@ def test_sweep_plans(L):
     hk.close()
 
 
+def test_ulv_inner_levels_one_launch_each(L):
+    HC.check_ulv_node(L, n=400)
+
+
 def test_chain_blocks(L):
     from strumpack_amd import hssk as K
     hk = K.Hssk(emu_lib.PATH)
