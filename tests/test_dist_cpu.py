@@ -271,8 +271,8 @@ def test_bench_dry_run_native_comm(world):
     env = dict(os.environ, STRUMPACK_AMD_RCCL_LIB=fake_rccl(), STRUMPACK_AMD_BENCH_DRYRUN_LIB=emu_lib.PATH, HSSK_EMU_THREADS="2",
                OMP_NUM_THREADS="2", STRUMPACK_AMD_BENCH_COMM="rccl")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29581 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-           "--size", "1500", "--leaf", "64", "--no-cpu-baseline"]
+           "--master-port", str(29581 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
+           "--size", "800", "--leaf", "64", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

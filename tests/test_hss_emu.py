@@ -129,12 +129,12 @@ def test_generated_operand_fused_sketch(L, n, leaf, kind, d0, dd):
 def test_inner_levels_in_one_launch(L):
     from strumpack_amd import hssk as K
     hk = K.Hssk(emu_lib.build())
-    HC.check_tree_pass(L, hk)
+    HC.check_tree_pass(L, hk, sizes=((1024, 64, 1e-6), (515, 64, 1e-6)))   # (the GPU tier: 515 ... 32768 and the N = 1e5 operand)
     hk.close()
 
 
 def test_factor_ahead_of_the_compression(L):
-    HC.check_factor_ahead(L)
+    HC.check_factor_ahead(L, n=640)   # (the GPU tier: n = 6000, leaf 128)
 
 
 def test_symmetric_operand_hint(L):

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-end GPU call: the GPU test tier and smoke() (what the driver runs), the default bench line with its live counter passes,
+# Round-end GPU call (rounds 5 and 6): the GPU test tier and smoke() (what the driver runs), the default bench line with its live counter passes,
 # its kernel summary and launch-by-launch timeline, the secondary lines, the BLR front lines and the 8-rank cost model.
-#   usage (GPU box, repo root): bash tools/round5_final.sh <tag> [notests]
-tag=${1:-r05_final}; out=/root/repo/gpurun_out/$tag; mkdir -p $out; cd /root/repo
+#   usage (GPU box, repo root): bash tools/round6_final.sh <tag> [notests]
+tag=${1:-r06_final}; out=/root/repo/gpurun_out/$tag; mkdir -p $out; cd /root/repo
 if [ -z "$2" ]; then
   timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -14 $out/pytest.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log
