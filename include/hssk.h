@@ -237,6 +237,14 @@ typedef struct hssk_colset_desc {
 } hssk_colset_desc;
 int hssk_colsets(hssk_ctx* ctx, const hssk_colset_desc* descs, int count, int universe);
 long long hssk_colsets_max_universe(void);   /* largest universe hssk_colsets takes on this device */
+/* Binary-tree clustering of a point set by median splits, on the device (binary_tree_clustering, clustering/Clustering.hpp:143-168,
+ * for the partitioners whose tree does not depend on the data: algo 4 = cobble, clustering/CobblePartitioning.cpp:36-78; algo 2 =
+ * kd, clustering/KDTree.cpp:36-95).  X (d x n, a point per column) and perm (n ints, out, 0-based: new column i is old column
+ * perm[i]) are DEVICE arrays, rearranged in place into cluster order; clusters of >= cluster_size points are halved (n / 2 | n - n / 2).
+ * One launch per tree level.  *status (host, out): 0 = the arrangement is the reference's; non-zero = ties at a median / at the
+ * farthest point or a long displacement chain were met -- X and perm are then NOT to be used and the caller takes the host form
+ * (host/Clustering.hpp).  Returns 2 for an algorithm / dimension this form does not take.  Synchronises. */
+int hssk_cluster_median(hssk_ctx* ctx, double* X, int d, int n, int algo, int cluster_size, int* perm, int* status);
 /* pred[c] = sum_r w[r] k(x_r, t_c), c < m; T is d x m (device)   (Kernel::predict, kernel/KernelRegression.hpp:112-123) */
 int hssk_kernel_predict(hssk_ctx* ctx, const hssk_kernel_spec* spec, const double* w, const double* T, int m, double* pred);
 

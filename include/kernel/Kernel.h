@@ -41,6 +41,12 @@ int SPX_kernel_weights(STRUMPACKKernel K, double* w);
  * 3 pca, 4 cobble; data (d x n) is reordered in place, perm is 1-based; returns the number of leaves and writes
  * at most cap leaf sizes */
 int SPX_clustering(int n, int d, double* data, int algo, int leaf_size, int* perm, int* leaf_sizes, int cap);
+/* the same with the median-split partitioners (2 kdtree, 4 cobble) on the device, one launch per tree level
+ * (hssk_cluster_median); *status: 0 = done; > 0 = ties at a median / at the farthest point or a long displacement chain were
+ * met, -1 = algorithm or dimension not taken by the device form -- data and perm are untouched then and the return value is 0
+ * (SPX_clustering, the host form, decides such point sets).  This is what the kernel-matrix constructors call for point sets
+ * of STRUMPACK_AMD_CLUSTER_DEVICE_MIN (default 8192) points and more, falling back to the host form on a non-zero status. */
+int SPX_clustering_device(int n, int d, double* data, int algo, int leaf_size, int* perm, int* leaf_sizes, int cap, int* status);
 /* find_approximate_neighbors on its own (clustering/NeighborSearch.cpp:324-345, host): ann / scores are k x n, column i =
  * the neighbours of point i, nearest first, the point itself included; scores (squared distances) may be NULL */
 int SPX_approximate_neighbors(int n, int d, const double* data, int iterations, int k, int* ann, double* scores);

@@ -115,6 +115,8 @@ template <int Q>
 __device__ __forceinline__ double hssk_pair_bcast(double v) { return hssk_dpp_mov0<Q | (Q << 2) | ((2 + Q) << 4) | ((2 + Q) << 6), 0xF>(v); }
 // non-zero if `pred` holds in any lane of the wave
 __device__ __forceinline__ int hssk_any(int pred) { return __any(pred); }
+// bit l = lane l's predicate (all 64 lanes of the wave take part)
+__device__ __forceinline__ unsigned long long hssk_ballot(int pred) { return __ballot(pred); }
 __device__ __forceinline__ double hssk_wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, hssk_shfl_xor(v, o));

@@ -28,6 +28,8 @@
 
 #include "ClusterTree.hpp"
 #include "DenseMatrix.hpp"
+#include "DevicePool.hpp"
+#include "hssk.h"
 
 namespace strumpack {
 
@@ -360,6 +362,71 @@ inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, 
       return cd::recurse(pts, (int)cluster_size, perm.data(), cd::label_cobble, cd::fork_levels());
   }
   return structured::ClusterTree(n);
+}
+
+// ---- the device form of the median-split partitioners (cobble, kd): kernels/hssk_cluster.hip ------------------------------
+// The tree of a median split follows from n and the cluster size alone (n / 2 | n - n / 2 while n >= cluster_size).
+inline structured::ClusterTree median_split_tree(int n, int cluster_size) {
+  structured::ClusterTree t(n);
+  if (n < cluster_size || n / 2 == 0) return t;
+  t.c.resize(2);
+  t.c[0] = median_split_tree(n / 2, cluster_size);
+  t.c[1] = median_split_tree(n - n / 2, cluster_size);
+  return t;
+}
+
+// Reorders p and fills perm (1-based) like binary_tree_clustering, one launch per tree level.  Returns 0 when done; -1 when
+// this form does not apply (algorithm, dimension, layout); > 0 when the device met a tie at a median or at the farthest point
+// or a long displacement chain (hssk_cluster_median) -- p and perm are untouched then and the host form decides.
+inline int binary_tree_clustering_device(ClusteringAlgorithm algo, DenseMatrix<double>& p, std::vector<int>& perm,
+                                         std::size_t cluster_size, int device, structured::ClusterTree& tree) {
+  const int n = (int)p.cols(), d = (int)p.rows();
+  if (algo != ClusteringAlgorithm::COBBLE && algo != ClusteringAlgorithm::KD_TREE) return -1;
+  if (n <= 0 || d <= 0 || d > 64 || p.ld() != d || cluster_size < 2 || cluster_size > (std::size_t)n) return -1;
+  hssk_ctx* ctx = nullptr;
+  if (hssk_ctx_create(&ctx, device)) throw std::runtime_error(std::string("binary_tree_clustering: ") + hssk_last_error());
+  const size_t bytes = sizeof(double) * (size_t)d * n + sizeof(int) * (size_t)n;
+  const size_t chunk = ((bytes + (size_t(64) << 20) - 1) >> 26) << 26;   // (the arenas' granularity: the pool hands the block on)
+  void* blk = DevicePool::get().acquire(chunk);
+  if (!blk) { hssk_ctx_destroy(ctx); throw std::runtime_error("binary_tree_clustering: out of device memory"); }
+  double* dX = (double*)blk;
+  int* dperm = (int*)(dX + (size_t)d * n);
+  int status = 0, rc = hssk_memcpy_h2d(ctx, dX, p.data(), (long long)sizeof(double) * d * n);
+  if (!rc) rc = hssk_cluster_median(ctx, dX, d, n, algo == ClusteringAlgorithm::COBBLE ? 4 : 2, (int)cluster_size, dperm, &status);
+  std::vector<int> pm;
+  if (!rc && !status) {
+    pm.resize(n);
+    rc = hssk_memcpy_d2h(ctx, pm.data(), dperm, (long long)sizeof(int) * n);
+    if (!rc) rc = hssk_memcpy_d2h(ctx, p.data(), dX, (long long)sizeof(double) * d * n);
+  }
+  std::string err = rc ? hssk_last_error() : "";
+  DevicePool::get().release(blk, chunk);
+  hssk_ctx_destroy(ctx);
+  if (rc == 2) return -1;
+  if (rc) throw std::runtime_error("binary_tree_clustering (device): " + err);
+  if (status) return status;
+  perm.resize(n);
+  for (int i = 0; i < n; i++) perm[i] = pm[i] + 1;
+  tree = median_split_tree(n, (int)cluster_size);
+  return 0;
+}
+
+// binary_tree_clustering with the median-split partitioners on the device when the point set is large enough to pay for the
+// launches (STRUMPACK_AMD_CLUSTER_DEVICE_MIN points, default 8192; STRUMPACK_AMD_CLUSTER_HOST=1: always the host form).
+// *used_device (may be null): whether the device form produced the result.
+inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, DenseMatrix<double>& p, std::vector<int>& perm,
+                                                      std::size_t cluster_size, int device, bool* used_device = nullptr) {
+  static const bool host_only = [] { const char* e = std::getenv("STRUMPACK_AMD_CLUSTER_HOST"); return e && e[0] == '1'; }();
+  static const long long dev_min = [] { const char* e = std::getenv("STRUMPACK_AMD_CLUSTER_DEVICE_MIN"); return e ? std::atoll(e) : 8192LL; }();
+  if (used_device) *used_device = false;
+  if (!host_only && (long long)p.cols() >= dev_min) {
+    structured::ClusterTree t(0);
+    if (binary_tree_clustering_device(algo, p, perm, cluster_size, device, t) == 0) {
+      if (used_device) *used_device = true;
+      return t;
+    }
+  }
+  return binary_tree_clustering(algo, p, perm, cluster_size);
 }
 
 }  // namespace strumpack

@@ -75,10 +75,12 @@ HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, int 
                              void (*fn)(void*, void*, long long), void* user) : HSSMatrix(K, opts, callback_group(world, rank, fn, user)) {}
 HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, const CommSpec& pg) : rows_(K.n()), cols_(K.n()) {
   auto tc0 = std::chrono::steady_clock::now();
-  auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size());
+  // (cobble / kd of a large point set: on the device, one launch per tree level -- host/Clustering.hpp, kernels/hssk_cluster.hip)
+  bool on_device = false;
+  auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size(), engine_options(opts).device, &on_device);
   K.permute();
   if (opts.verbose())
-    std::cout << "# clustering (" << get_name(opts.clustering_algorithm()) << ") time = "
+    std::cout << "# clustering (" << get_name(opts.clustering_algorithm()) << (on_device ? ", device" : ", host") << ") time = "
               << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count() << std::endl;
   tree_.reset(new structured::ClusterTree(t));
   EngineOptions e = engine_options(opts);

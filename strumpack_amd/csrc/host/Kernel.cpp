@@ -220,4 +220,29 @@ int SPX_clustering(int n, int d, double* data, int algo, int leaf_size, int* per
   } catch (const std::exception& e) { report(e); return -1; }
 }
 
+int SPX_clustering_device(int n, int d, double* data, int algo, int leaf_size, int* perm, int* leaf_sizes, int cap, int* status) {
+  try {
+    DenseMatrix<double> p(d, n, data, d);
+    std::vector<int> pm;
+    static const ClusteringAlgorithm algos[] = {ClusteringAlgorithm::NATURAL, ClusteringAlgorithm::TWO_MEANS, ClusteringAlgorithm::KD_TREE,
+                                                ClusteringAlgorithm::PCA, ClusteringAlgorithm::COBBLE};
+    if (algo < 0 || algo > 4) throw std::invalid_argument("clustering algorithm out of range");
+    int dev = 0;
+    if (const char* e = std::getenv("STRUMPACK_AMD_DEVICE")) dev = std::atoi(e);
+    structured::ClusterTree t(0);
+    const int st = binary_tree_clustering_device(algos[algo], p, pm, (std::size_t)leaf_size, dev, t);
+    if (status) *status = st;
+    if (st) return 0;
+    std::copy(p.data(), p.data() + (size_t)d * n, data);
+    std::copy(pm.begin(), pm.end(), perm);
+    int c = 0;
+    std::function<void(const structured::ClusterTree&)> walk = [&](const structured::ClusterTree& nd) {
+      if (nd.c.empty()) { if (c < cap) leaf_sizes[c] = nd.size; c++; }
+      else for (auto& ch : nd.c) walk(ch);
+    };
+    walk(t);
+    return c;
+  } catch (const std::exception& e) { report(e); return -1; }
+}
+
 }  // extern "C"

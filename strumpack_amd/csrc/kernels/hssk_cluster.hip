@@ -1,0 +1,360 @@
+// Binary-tree clustering of a point set by MEDIAN SPLITS on the device: the row / column ordering and
+// the cluster tree of a kernel matrix, for the two partitioners of the reference whose tree shape does not depend on the
+// data -- cobble (clustering/CobblePartitioning.cpp:36-78: median of the distances from the point farthest from the
+// centroid) and kd (clustering/KDTree.cpp:36-95: median along the coordinate of largest extent) -- driven by
+// clustering/Clustering.hpp:143-168.  A cluster of n >= cluster_size points is split into its n / 2 points of smallest
+// key (in their original order) and the rest (in the order the reference's swap sequence leaves them); the halves are
+// split again on the next level.  One launch per level, one workgroup per cluster, nothing read back between levels.
+//
+// The host form (host/Clustering.hpp) calls libstdc++ on the reference's data to reproduce its permutation exactly; this
+// form reproduces it wherever the answer does not hang on the last bits:
+//   * keys are computed with the host's operations in the host's order (no fused multiply-add: products rounded before
+//     they are added; IEEE square root), so the cobble keys -- distances from ONE data point -- are the host's bit for bit;
+//   * the centroid is a parallel sum (the host adds the points one after the other): it differs from the host's in the
+//     last bits, which only matters when two points are the farthest from it to within rounding -- the workgroup then
+//     raises the status word (so does an exact tie);
+//   * the median is found by selection (a histogram of the keys over 2048 monotone buckets, then ranking inside the
+//     median's bucket); WHICH points lie below it is what std::nth_element leaves unless equal keys straddle the median --
+//     then the reference's own call decides, and the status word is raised;
+//   * the reference moves the n / 2 points labelled 0 to the front with a sequence of swaps: the k-th of them (in index
+//     order) is swapped with whatever stands at position k - 1.  Labelled-0 points therefore keep their order; a point
+//     labelled 1 that stands at position p < n / 2 when position p is filled moves to where that 0-point stood,
+//     z(p) = index of the (p + 1)-th 0-point, and again (z(z(p)), ...) until it lands at or behind n / 2.  These chains are
+//     short unless the labels are 1 0 0 0 ...-like; a chain longer than CL_CHAIN raises the status word.
+// A raised status word means: take the host form (the caller still holds the untouched points).
+#include "hssk_device.h"
+#include "hssk_internal.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int CL_T = 1024;      // threads per workgroup (16 waves)
+constexpr int CL_NB = 2048;     // buckets of the selection histogram
+constexpr int CL_CAP = 4096;    // keys of the median's bucket ranked in the LDS
+constexpr int CL_DMAX = 64;     // largest point dimension
+constexpr int CL_CHAIN = 256;   // longest displacement chain followed
+
+struct ClDesc {
+  int lo, n;
+};
+
+#ifdef HSSK_EMU
+inline double cl_sq_acc(double k, double t) { return k + t * t; }   // (x86-64 baseline: no fused multiply-add)
+#else
+__device__ __forceinline__ double cl_sq_acc(double k, double t) { return __dadd_rn(k, __dmul_rn(t, t)); }
+#endif
+
+// kernel/Metrics.hpp:41-50 followed by sqrt (Euclidean_distance)
+__device__ inline double cl_dist(int d, const double* a, const double* b) {
+  double k = 0.;
+  for (int i = 0; i < d; i++) k = cl_sq_acc(k, a[i] - b[i]);
+  return sqrt(k);
+}
+
+// i = tid, tid + CL_T, ... < n in batches of U: the U loads (or load-and-compute chains) of a batch are independent and in flight
+// together -- the top clusters of a large point set are streamed by ONE workgroup, which a load at a time per thread leaves at
+// the memory latency (1.6 ms for the first split of 1e5 points in R^8)
+template <int U, typename T, class L, class F>
+__device__ __forceinline__ void cl_stream(int tid, int n, L load, F use) {
+  for (int i0 = tid; i0 < n; i0 += U * CL_T) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = load(min(i0 + u * CL_T, n - 1));
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (i0 + u * CL_T < n) use(i0 + u * CL_T, v[u]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cluster_iota_kernel(int* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+// algo 4: cobble, 2: kd.  X, perm: the points (d x n, a point per column) and the permutation so far, rearranged in place;
+// Xt, pt, key, zpos: scratch of the same extents (each workgroup uses its own cluster's stretch).
+__global__ __launch_bounds__(CL_T) void cluster_split_kernel(double* __restrict__ X, double* __restrict__ Xt, int* __restrict__ perm,
+                                                             int* __restrict__ pt, double* __restrict__ key, int* __restrict__ zpos,
+                                                             const ClDesc* __restrict__ cl, int d, int algo, int* status) {
+  HSSK_SHARED double red[CL_T];
+  HSSK_SHARED double red2[CL_T];
+  HSSK_SHARED int ired[CL_T];
+  HSSK_SHARED double cen[CL_DMAX];
+  HSSK_SHARED double ext[2 * CL_DMAX];
+  HSSK_SHARED int hist[CL_NB];
+  HSSK_SHARED double cand[CL_CAP];
+  HSSK_SHARED int wcnt[CL_T / 64];
+  HSSK_SHARED int shi[8];      // 0: farthest point / split coordinate, 1: bucket, 2: keys below the bucket, 3: keys in it,
+                               // 4: gather cursor, 5: keys of the bucket below the median value, 7: give up
+  HSSK_SHARED double shd[4];   // 0: median value, 1: smallest key, 2: largest key
+  const ClDesc c = cl[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = c.lo, n = c.n, h = n / 2;
+  double* P = X + (size_t)lo * d;
+  double* K = key + lo;
+  const int Tp = (CL_T / d) * d;   // threads of the coordinate-wise passes: thread t always meets coordinate t % d
+  if (tid < 8) shi[tid] = 0;
+  __syncthreads();
+  double kmin, kmax;
+  if (algo == 4) {
+    // centroid
+    double s = 0.;
+    if (tid < Tp) {
+      const long long nd = (long long)n * d;
+      for (long long e0 = tid; e0 < nd; e0 += 8LL * Tp) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = P[min(e0 + (long long)u * Tp, nd - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += e0 + (long long)u * Tp < nd ? x[u] : 0.;
+      }
+    }
+    red[tid] = tid < Tp ? s : 0.;
+    __syncthreads();
+    if (tid < d) {
+      double a = 0.;
+      for (int m = tid; m < Tp; m += d) a += red[m];
+      cen[tid] = a / n;
+    }
+    __syncthreads();
+    // the point farthest from it (the first among equals) and the runner-up's distance
+    double v1 = -1., v2 = -1.;
+    int i1 = 0x7fffffff;
+    cl_stream<4, double>(tid, n, [&](int i) { return cl_dist(d, P + (size_t)i * d, cen); }, [&](int i, double dd) {
+      if (dd > v1) { v2 = v1; v1 = dd; i1 = i; }
+      else if (dd > v2) v2 = dd;
+    });
+    red[tid] = v1; red2[tid] = v2; ired[tid] = i1;
+    __syncthreads();
+    for (int s2 = CL_T / 2; s2 > 0; s2 >>= 1) {
+      if (tid < s2) {
+        const double va = red[tid], vb = red[tid + s2], wa = red2[tid], wb = red2[tid + s2];
+        const int ia = ired[tid], ib = ired[tid + s2];
+        if (vb > va || (vb == va && ib < ia)) { red[tid] = vb; ired[tid] = ib; red2[tid] = fmax(va, wb); }
+        else red2[tid] = fmax(vb, wa);
+      }
+      __syncthreads();
+    }
+    const int first = ired[0];
+    const double far = red[0], second = red2[0];
+    if (!(far - second > 1e-10 * far)) {   // a tie to within the centroid's rounding (or NaNs): the host's sum decides
+      if (tid == 0) hssk_flag_store(status, 1);
+      return;
+    }
+    __syncthreads();
+    if (tid < d) cen[tid] = P[(size_t)first * d + tid];
+    __syncthreads();
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+    cl_stream<4, double>(tid, n, [&](int i) { return cl_dist(d, P + (size_t)i * d, cen); }, [&](int i, double dd) {
+      K[i] = dd;
+      mn = fmin(mn, dd); mx = fmax(mx, dd);
+    });
+    red[tid] = mn; red2[tid] = mx;
+    __syncthreads();
+    for (int s2 = CL_T / 2; s2 > 0; s2 >>= 1) {
+      if (tid < s2) { red[tid] = fmin(red[tid], red[tid + s2]); red2[tid] = fmax(red2[tid], red2[tid + s2]); }
+      __syncthreads();
+    }
+    kmin = red[0]; kmax = red2[0];
+  } else {
+    // extent of every coordinate; the first of largest extent
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+    if (tid < Tp) {
+      const long long nd = (long long)n * d;
+      for (long long e0 = tid; e0 < nd; e0 += 8LL * Tp) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = P[min(e0 + (long long)u * Tp, nd - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (e0 + (long long)u * Tp < nd) { mn = fmin(mn, x[u]); mx = fmax(mx, x[u]); }   // (a clamped element is another coordinate's)
+      }
+    }
+    red[tid] = mn; red2[tid] = mx;
+    __syncthreads();
+    if (tid < d) {
+      double a = red[tid], b = red2[tid];
+      for (int m = tid + d; m < Tp; m += d) { a = fmin(a, red[m]); b = fmax(b, red2[m]); }
+      ext[tid] = a; ext[CL_DMAX + tid] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int dim = 0;
+      double e0 = ext[CL_DMAX] - ext[0];
+      for (int j = 1; j < d; j++)
+        if (ext[CL_DMAX + j] - ext[j] > e0) { e0 = ext[CL_DMAX + j] - ext[j]; dim = j; }
+      shi[0] = dim;
+    }
+    __syncthreads();
+    const int dim = shi[0];
+    kmin = ext[dim]; kmax = ext[CL_DMAX + dim];
+    cl_stream<8, double>(tid, n, [&](int i) { return P[(size_t)i * d + dim]; }, [&](int i, double x) { K[i] = x; });
+  }
+  if (!(kmax > kmin)) {   // all keys equal (or NaNs)
+    if (tid == 0) hssk_flag_store(status, 2);
+    return;
+  }
+  // ---- the median: the key of rank h (0-based).  Buckets are a monotone map of the keys, so the bucket of the median is
+  // the one the cumulative counts say; inside it the keys are ranked against each other.
+  for (int b = tid; b < CL_NB; b += CL_T) hist[b] = 0;
+  __syncthreads();
+  const double scale = (CL_NB - 1) / (kmax - kmin);
+  auto bucket = [&](double k) {
+    const int b = (int)((k - kmin) * scale);
+    return min(CL_NB - 1, max(0, b));
+  };
+  cl_stream<8, double>(tid, n, [&](int i) { return K[i]; }, [&](int, double k) { hssk_lds_inc(&hist[bucket(k)]); });
+  __syncthreads();
+  {
+    const int c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+    ired[tid] = c0 + c1;
+    __syncthreads();
+    for (int off = 1; off < CL_T; off <<= 1) {   // inclusive scan over the pairs of buckets
+      const int add = tid >= off ? ired[tid - off] : 0;
+      __syncthreads();
+      ired[tid] += add;
+      __syncthreads();
+    }
+    const int base = ired[tid] - c0 - c1;
+    if (base <= h && h < base + c0) { shi[1] = 2 * tid; shi[2] = base; shi[3] = c0; }
+    else if (base + c0 <= h && h < base + c0 + c1) { shi[1] = 2 * tid + 1; shi[2] = base + c0; shi[3] = c1; }
+  }
+  __syncthreads();
+  const int B = shi[1], below = shi[2], nb = shi[3], r = h - below;
+  if (nb > CL_CAP || nb <= 0) {   // (a pile of near-equal keys)
+    if (tid == 0) hssk_flag_store(status, 3);
+    return;
+  }
+  cl_stream<8, double>(tid, n, [&](int i) { return K[i]; }, [&](int, double k) {
+    if (bucket(k) == B) cand[hssk_lds_inc(&shi[4])] = k;
+  });
+  __syncthreads();
+  for (int a = tid; a < nb; a += CL_T) {
+    const double x = cand[a];
+    int less = 0, eq = 0;
+    for (int j = 0; j < nb; j++) { const double y = cand[j]; less += y < x; eq += y == x; }
+    if (less <= r && r < less + eq) { shd[0] = x; shi[5] = less; }   // (equal keys write equal values)
+  }
+  __syncthreads();
+  const double v = shd[0];
+  if (shi[5] != r) {   // equal keys straddle the median: std::nth_element's arrangement decides (host)
+    if (tid == 0) hssk_flag_store(status, 4);
+    return;
+  }
+  // ---- the points below the median to the front, in order; every wave a contiguous stretch of the cluster
+  const int seg = ((n + CL_T - 1) / CL_T) * 64, i0 = wave * seg, i1 = min(n, i0 + seg);
+  int cnt = 0;
+  for (int b0 = i0; b0 < i1; b0 += 8 * 64) {
+    double k[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) k[u] = K[min(b0 + u * 64 + lane, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) cnt += __builtin_popcountll(hssk_ballot(b0 + u * 64 + lane < i1 && k[u] < v));
+  }
+  if (lane == 0) wcnt[wave] = cnt;
+  __syncthreads();
+  int run = 0;
+  for (int u = 0; u < wave; u++) run += wcnt[u];
+  for (int b0 = i0; b0 < i1; b0 += 4 * 64) {
+    double k[4];
+    int pm[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = min(b0 + u * 64 + lane, n - 1); k[u] = K[i]; pm[u] = perm[lo + i]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = b0 + u * 64 + lane;
+      const int z = i < i1 && k[u] < v;
+      const unsigned long long m = hssk_ballot(z);
+      if (z) {
+        const int rk = run + __builtin_popcountll(m & ((1ULL << lane) - 1ULL));
+        zpos[lo + rk] = i;
+        for (int j = 0; j < d; j++) Xt[(size_t)(lo + rk) * d + j] = P[(size_t)i * d + j];
+        pt[lo + rk] = pm[u];
+      }
+      run += __builtin_popcountll(m);
+    }
+  }
+  __syncthreads();
+  // ---- the others: follow the displacements (see the head of the file)
+  cl_stream<4, int>(tid, n, [&](int i) {
+    if (K[i] < v) return -1;
+    int p = i, steps = 0;
+    while (p < h && steps <= CL_CHAIN) { p = zpos[lo + p]; steps++; }
+    return p;
+  }, [&](int i, int p) {
+    if (p < 0) return;
+    if (p < h) { shi[7] = 1; return; }
+    for (int j = 0; j < d; j++) Xt[(size_t)(lo + p) * d + j] = P[(size_t)i * d + j];
+    pt[lo + p] = perm[lo + i];
+  });
+  __syncthreads();
+  if (shi[7]) {
+    if (tid == 0) hssk_flag_store(status, 5);
+    return;
+  }
+  {
+    const long long nd = (long long)n * d;
+    const double* src = Xt + (size_t)lo * d;
+    for (long long e0 = tid; e0 < nd; e0 += 8LL * CL_T) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = src[min(e0 + (long long)u * CL_T, nd - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (e0 + (long long)u * CL_T < nd) P[e0 + (long long)u * CL_T] = x[u];
+    }
+  }
+  cl_stream<8, int>(tid, n, [&](int i) { return pt[lo + i]; }, [&](int i, int q) { perm[lo + i] = q; });
+}
+
+}  // namespace
+
+// X (d x n, device) and perm (n ints, device; out, 0-based: new column i is old column perm[i]) rearranged into the cluster
+// order of the binary tree whose clusters of >= cluster_size points are halved (n / 2 | n - n / 2).  *status (host, out) is 0
+// when the device form reproduced the reference's arrangement; non-zero: ties or long displacement chains were met and X /
+// perm are not to be used.  algo: 2 kd, 4 cobble (the reference's enumeration order: natural, 2means, kdtree, pca, cobble).
+// Synchronises.
+extern "C" int hssk_cluster_median(hssk_ctx* ctx, double* X, int d, int n, int algo, int cluster_size, int* perm, int* status) {
+  HSSK_API_BEGIN
+  if (algo != 2 && algo != 4) HSSK_UNSUPPORTED("median-split clustering on the device is cobble (4) or kd (2)");
+  if (d <= 0 || d > CL_DMAX) HSSK_UNSUPPORTED("point dimension must be in [1, 64]");
+  if (n <= 0 || cluster_size < 2) throw std::invalid_argument("hssk_cluster_median: empty point set or cluster size < 2");
+  // scratch: Xt | key | pt | zpos | status word
+  const size_t nd = (size_t)n * d;
+  char* base = (char*)ctx->scratch(sizeof(double) * (nd + n) + sizeof(int) * (2 * (size_t)n + 16));
+  double* Xt = (double*)base;
+  double* key = Xt + nd;
+  int* pt = (int*)(key + n);
+  int* zpos = pt + n;
+  int* dstat = zpos + n;
+  hssk_rt::memset_async(dstat, 0, sizeof(int), ctx->stream);
+  HSSK_LAUNCH(cluster_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, perm, n);
+  std::vector<ClDesc> cur{ClDesc{0, n}}, next;
+  while (!cur.empty()) {
+    std::vector<ClDesc> split;
+    next.clear();
+    for (const ClDesc& c : cur) {
+      if (c.n < cluster_size) continue;   // (cluster_size >= 2: both halves non-empty)
+      split.push_back(c);
+      next.push_back(ClDesc{c.lo, c.n / 2});
+      next.push_back(ClDesc{c.lo + c.n / 2, c.n - c.n / 2});
+    }
+    if (!split.empty()) {
+      // (levels of many clusters: the table in pieces the staging ring takes)
+      const size_t piece = 1 << 16;
+      for (size_t o = 0; o < split.size(); o += piece) {
+        const size_t cnt = std::min(piece, split.size() - o);
+        auto* dd = (const ClDesc*)ctx->stage(split.data() + o, sizeof(ClDesc) * cnt);
+        HSSK_LAUNCH(cluster_split_kernel, dim3((unsigned)cnt), dim3(CL_T), 0, ctx->stream, X, Xt, perm, pt, key, zpos, dd, d, algo, dstat);
+      }
+    }
+    cur.swap(next);
+  }
+  hssk_rt::check_launch();
+  int st = 0;
+  hssk_rt::d2h(&st, dstat, sizeof(int), ctx->stream);
+  hssk_rt::sync(ctx->stream);
+  if (status) *status = st;
+  HSSK_API_END
+}

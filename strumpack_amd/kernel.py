@@ -8,7 +8,7 @@ import numpy as np
 KERNEL_SYMBOLS = [
     "STRUMPACK_create_kernel_double", "STRUMPACK_destroy_kernel_double", "STRUMPACK_kernel_fit_HSS_double",
     "STRUMPACK_kernel_predict_double", "SPX_kernel_fit_info", "SPX_kernel_permutation", "SPX_kernel_weights",
-    "SPX_clustering", "SPX_kernel_node_info", "SPX_kernel_set_neighbors", "SPX_approximate_neighbors",
+    "SPX_clustering", "SPX_clustering_device", "SPX_kernel_node_info", "SPX_kernel_set_neighbors", "SPX_approximate_neighbors",
 ]
 KERNEL_TYPES = {"Gauss": 0, "rbf": 0, "Laplace": 1, "ANOVA": 2}
 CLUSTERING = {"natural": 0, "2means": 1, "kdtree": 2, "pca": 3, "cobble": 4}
@@ -30,6 +30,7 @@ def load(path):
     L.SPX_kernel_set_neighbors.argtypes = [vp, C.c_int, vp]
     L.SPX_approximate_neighbors.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     L.SPX_clustering.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.SPX_clustering_device.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]
     return L
 
 
@@ -109,6 +110,20 @@ def clustering(lib, X, algo="2means", leaf_size=512):
     if c < 0:
         raise RuntimeError("SPX_clustering failed")
     return X, perm, ls[:c].copy()
+
+
+def clustering_device(lib, X, algo="cobble", leaf_size=512):
+    """The median-split partitioners on the device (SPX_clustering_device): returns (status, reordered points, 1-based
+    permutation, leaf sizes); status != 0: the device form stood back (ties, long displacement chains) and nothing was moved."""
+    X = np.ascontiguousarray(X, dtype=np.float64).copy()
+    n, d = X.shape
+    perm = np.zeros(n, dtype=np.int32)
+    ls = np.zeros(max(16, 4 * n // max(leaf_size, 1) + 16), dtype=np.int32)
+    st = C.c_int(0)
+    c = lib.SPX_clustering_device(n, d, X.ctypes.data, CLUSTERING[algo], leaf_size, perm.ctypes.data, ls.ctypes.data, len(ls), C.byref(st))
+    if c < 0:
+        raise RuntimeError("SPX_clustering_device failed")
+    return st.value, X, perm, ls[:c].copy()
 
 
 def approximate_neighbors(lib, X, k, iterations=5):

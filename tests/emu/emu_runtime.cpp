@@ -168,6 +168,20 @@ double wave_xchg(double v, int src_lane) {
   return r;
 }
 
+unsigned long long wave_ballot(int pred) {
+  Worker* w = W;
+  int t = w->cur;
+  Wave& wv = w->waves[t / 64];
+  wv.buf[t % 64] = pred ? 1. : 0.;
+  wave_barrier(w, wv);
+  const int T = (int)(w->bdim.x * w->bdim.y * w->bdim.z), lanes = std::min(64, T - (t / 64) * 64);
+  unsigned long long m = 0;
+  for (int l = 0; l < lanes; l++)
+    if (wv.buf[l] != 0.) m |= 1ULL << l;
+  wave_barrier(w, wv);
+  return m;
+}
+
 hssk_d4 mfma_f64_16x16x4(double a, double b, hssk_d4 c) {
   Worker* w = W;
   int t = w->cur, l = t % 64;

@@ -40,6 +40,7 @@ void* dyn_shared();
 void block_barrier();
 double wave_xchg(double v, int src_lane);  // every live lane of the wave must call
 hssk_d4 mfma_f64_16x16x4(double a, double b, hssk_d4 c);
+unsigned long long wave_ballot(int pred);   // every live lane of the wave must call
 }  // namespace emu
 
 inline void __syncthreads() { emu::block_barrier(); }
@@ -82,6 +83,7 @@ inline void hssk_wave_argmax(double& v, int& idx) {
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
 }
+inline unsigned long long hssk_ballot(int pred) { return emu::wave_ballot(pred); }
 template <int Q> inline double hssk_quad_bcast(double v) { return emu::wave_xchg(v, (int)((threadIdx.x & 60) | Q)); }
 template <int Q> inline double hssk_pair_bcast(double v) { return emu::wave_xchg(v, (int)((threadIdx.x & 62) | Q)); }
 template <int N>

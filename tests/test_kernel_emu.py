@@ -104,6 +104,48 @@ def test_clustering_large_set_on_host_threads(lib, algo, split):
         off += m
 
 
+@pytest.mark.parametrize("algo", ["cobble", "kdtree"])
+def test_clustering_device_form(lib, algo):
+    """The median-split partitioners on the device (kernels/hssk_cluster.hip, one launch per tree level): the reference's
+    permutation on its own fixture, the host form's on random points; point sets whose answer hangs on ties (a lattice, all
+    points equal) or on a long chain of displacements are handed back untouched (status != 0)."""
+    J, Z = KG.golden()
+    X = KG.susy()[0]
+    for tag, pts in (("full", X), ("sub1000", X[:1000])):
+        g = J["clustering_%s_%s" % (tag, algo)]
+        st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, g["leaf"])
+        if st == 0:   # (the fixture's own data has duplicated values in some coordinates: kd may stand back)
+            assert np.array_equal(perm, Z["perm_%s_%s" % (tag, algo)])
+            assert leaves.tolist() == g["leaves"]
+            assert np.array_equal(Xp, pts[perm - 1])
+        else:
+            assert algo == "kdtree"
+    r = np.random.default_rng(17)
+    for pts, leaf in ((r.random((9000, 6)), 100), (r.standard_normal((5000, 3)) * 40 - 7, 64), (r.random((257, 2)), 9)):
+        st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, leaf)
+        Xh, ph, lh = KM.clustering(lib, pts, algo, leaf)
+        assert st == 0 and np.array_equal(perm, ph) and np.array_equal(Xp, Xh) and leaves.tolist() == lh.tolist()
+    # ties: the device form stands back and moves nothing
+    for pts in (r.integers(0, 3, (3000, 4)).astype(float), np.ones((500, 3))):
+        st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, 100)
+        assert st > 0 and np.array_equal(Xp, pts) and not perm.any()
+    # the swap sequence: keys ascending (nothing moves), descending (every point of the upper half moves once), and one large
+    # key in front of ascending ones (its point is displaced n / 2 times: beyond what the device follows)
+    key = np.sort(r.random(2000))
+    for k, expect in ((key, 0), (key[::-1].copy(), 0), (np.concatenate([[2.0], key[:-1]]), 5)):
+        pts = np.stack([k, 1e-3 * r.random(2000)], axis=1)
+        if algo == "cobble":   # distances from the farthest point order like the first coordinate when that point is the smallest key
+            pts = pts.copy()
+            pts[:, 0] = 1.0 - pts[:, 0] if expect != 5 else pts[:, 0]
+            pts = np.vstack([pts, [[-50.0, 0.0]]]) if expect != 5 else pts
+        st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, 1500)
+        if algo == "kdtree":
+            assert st == expect
+        if st == 0:
+            Xh, ph, lh = KM.clustering(lib, pts, algo, 1500)
+            assert np.array_equal(perm, ph) and np.array_equal(Xp, Xh)
+
+
 @pytest.mark.parametrize("algo", ["cobble", "kdtree", "pca"])
 def test_median_split_fast_selection_is_the_reference_selection(algo):
     """The median splits select on a copy of the keys and make the reference's nth_element call only when equal keys straddle

@@ -57,6 +57,30 @@ def test_kernel_regression_example_10k(lib):
     print("kernel regression 10k (reference neighbours):", info)
 
 
+@pytest.mark.parametrize("algo", ["cobble", "kdtree"])
+def test_clustering_device_form_is_the_host_form(lib, algo):
+    """Median-split clustering on the device (kernels/hssk_cluster.hip: one launch per tree level) against the host form
+    (libstdc++ calls on the reference's data, host/Clustering.hpp) -- the same permutation element for element, at the
+    reference fixture's size and at BASELINE configs[3]'s; a lattice is handed back untouched."""
+    import numpy as np
+    J, Z = KG.golden()
+    X = KG.susy()[0]
+    g = J["clustering_full_%s" % algo]
+    st, Xp, perm, leaves = KM.clustering_device(lib, X, algo, g["leaf"])
+    if st == 0:
+        assert np.array_equal(perm, Z["perm_full_%s" % algo]) and leaves.tolist() == g["leaves"]
+    else:
+        assert algo == "kdtree"   # (duplicated coordinate values in the data set: a tie at a median)
+    r = np.random.default_rng(2025)
+    for pts, leaf in ((r.random((100000, 8)), 256), (r.standard_normal((70001, 5)), 600)):
+        st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, leaf)
+        Xh, ph, lh = KM.clustering(lib, pts, algo, leaf)
+        assert st == 0 and np.array_equal(perm, ph) and np.array_equal(Xp, Xh) and leaves.tolist() == lh.tolist()
+    lat = r.integers(0, 3, (20000, 4)).astype(float)
+    st, Xp, perm, leaves = KM.clustering_device(lib, lat, algo, 100)
+    assert st > 0 and np.array_equal(Xp, lat)
+
+
 def test_tsqr_staircase_matches_dense_sweep():
     """The TSQR pre-reduction of tall ID panels stacks R factors with interleaved rows and factors only the staircase
     (hssk_qr_desc.stair); the dense sweep of the same stack (STRUMPACK_AMD_TSQR_DENSE=1) must give the same matrix."""
