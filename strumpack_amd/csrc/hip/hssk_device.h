@@ -25,6 +25,15 @@ __device__ __forceinline__ hssk_d4 hssk_mfma_f64_16x16x4(double a, double b, hss
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// D(32x32) += A(32x2) * B(2x32), FP32 matrix core (v_mfma_f32_32x32x2_f32).
+// lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+// lane l receives, in c[r], D[row = 8 (r / 4) + 4 (l >> 5) + r % 4][col = l & 31].
+typedef float hssk_f16v __attribute__((ext_vector_type(16)));
+typedef float hssk_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hssk_f16v hssk_mfma_f32_32x32x2(float a, float b, hssk_f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ double hssk_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int hssk_shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ double hssk_shfl(double v, int src) { return __shfl(v, src, 64); }
@@ -153,6 +162,10 @@ __device__ __forceinline__ void hssk_cstore(double* p, size_t off, double v) {
 __device__ __forceinline__ unsigned long long hssk_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double hssk_from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
 __device__ __forceinline__ unsigned hssk_fbits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ float hssk_from_fbits(unsigned b) { return __uint_as_float(b); }
+// the lanes of a wave exchange data through the LDS without a workgroup barrier: LDS operations of a wave execute in order;
+// this keeps the compiler from moving them across the point (the emulator's lanes are fibers: they meet here)
+__device__ __forceinline__ void hssk_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // instruction-scheduling fence: nothing is moved across it
 __device__ __forceinline__ void hssk_sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
 // request to the instruction scheduler: the next `n` instructions of class MASK of this scheduling region go here

@@ -16,6 +16,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 namespace {
@@ -152,7 +153,7 @@ constexpr knn_key_t KNN_EMPTY = ((knn_key_t)0x7f61b1e6u << 32) | 0x7fffffffu;   
 template <int DM, int Q, int LQ, bool PIPE = false, int TILEK = KNN_TILE, int PEND = KNN_PEND>
 __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, int d, int n, int q0, int q1, int kpage,
                                                     const knn_key_t* __restrict__ lb, int* __restrict__ out_idx, int ldo,
-                                                    knn_key_t* __restrict__ ub) {
+                                                    knn_key_t* __restrict__ ub, int window) {
   constexpr int TILE = TILEK * LQ;              // coordinates per tile: a tile lasts as many trips whatever LQ
   constexpr int CT = TILE / DM;                 // candidates per tile
   constexpr int U = DM <= 16 ? 4 : (DM <= 32 ? 2 : 1);   // candidates per lane and trip (their coordinates sit in registers)
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
   if (LQ > 1) __syncthreads();   // (the heaps are initialised by all lanes of a query)
   // candidate tiles are visited starting at the queries' own position: after the clustering, index neighbours are
   // spatial neighbours, the page threshold tightens at once and later tiles rarely insert (same result set)
+  // window > 0: only the tiles nearest to the queries' own (about `window` candidates) are visited -- the page bound `ub` is
+  // then an UPPER bound of the true one (the filtered search below starts from it); out_idx may be null
   const int ntile = (n + CT - 1) / CT, own = (q0 + blockIdx.x * NQ) / CT;
+  const int nvis = window > 0 ? min(ntile, (window + CT - 1) / CT) : ntile;
   const double inf = __builtin_huge_val();
   // own, own+1, own-1, own+2, own-2, ...: in cluster order index distance tracks spatial distance
   auto tile_start = [&](int t) {
@@ -233,13 +237,13 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
     }
   };
   tile_fetch(0);
-  for (int t = 0; t < ntile; t++) {
+  for (int t = 0; t < nvis; t++) {
     double* tile = xc + (t & 1) * TILE;
 #pragma unroll
     for (int r = 0; r < NL; r++) tile[tid + Q * r] = v[r];
     // one barrier per tile: the buffer written here was last read two tiles ago, before the previous barrier
     __syncthreads();
-    if (t + 1 < ntile) tile_fetch(t + 1);
+    if (t + 1 < nvis) tile_fetch(t + 1);
     const int c0 = tile_start(t);
     // a trip: U candidates per lane (candidate c + u LQ + part: the LQ lanes of a query read neighbouring candidates, whose
     // 64-byte records fall on different LDS banks) against the lane's query, their keys appended to the pending list
@@ -306,10 +310,11 @@ __global__ __launch_bounds__(Q) void knn_kernel(const double* __restrict__ X, in
   }
   flush();
   if (!live) return;
-  for (int s = part; s < kpage; s += LQ) {
-    const knn_key_t K = hh[s * NQ + ql];
-    out_idx[(size_t)q * ldo + s] = K == KNN_EMPTY ? -1 : (int)(K & 0xffffffffu);
-  }
+  if (out_idx)
+    for (int s = part; s < kpage; s += LQ) {
+      const knn_key_t K = hh[s * NQ + ql];
+      out_idx[(size_t)q * ldo + s] = K == KNN_EMPTY ? -1 : (int)(K & 0xffffffffu);
+    }
   if (ub && part == 0) ub[q] = worst;
 }
 
@@ -459,11 +464,10 @@ extern "C" int hssk_colsets(hssk_ctx* ctx, const hssk_colset_desc* descs, int co
   HSSK_API_END
 }
 
-extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx) {
-  HSSK_API_BEGIN
-  if (n <= 0 || k <= 0 || q1 <= q0) return 0;
-  if (q0 < 0 || q1 > n) throw std::invalid_argument("hssk_knn: query range outside the point set");
-  if (d <= 0 || d > KNN_DMAX) throw std::invalid_argument("hssk_knn: point dimension must be in [1, 64]");
+namespace {
+// All pages of the search by the heap kernel.  window > 0: the search over the ~window candidates nearest in index to each
+// query, nothing written but the last page's bound (returned: n keys, indexed by point).
+knn_key_t* knn_exhaustive(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx, int window) {
   const int pages = (k + KNN_P - 1) / KNN_P;
   // page bounds (the largest key of the previous page, per query), ping-pong
   knn_key_t* kb = (knn_key_t*)ctx->scratch(sizeof(knn_key_t) * 2 * (size_t)n + 64);
@@ -471,26 +475,297 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
     const int kp = std::min(KNN_P, k - pg * KNN_P);
     const knn_key_t* lb = pg ? kb + (size_t)((pg - 1) & 1) * n : nullptr;
     knn_key_t* ub = kb + (size_t)(pg & 1) * n;
-    int* oi = out_idx + pg * KNN_P;
+    int* oi = out_idx ? out_idx + pg * KNN_P : nullptr;
     // (queries per workgroup: threads / lanes per query)
     static const bool lq1 = [] { const char* e = std::getenv("HSSK_KNN_LQ"); return e && e[0] == '1'; }();
     const int nqr = q1 - q0;
     static const bool pipe = [] { const char* e = std::getenv("HSSK_KNN_PIPE"); return !(e && e[0] == '0'); }();
     static const bool w1 = [] { const char* e = std::getenv("HSSK_KNN_W1"); return !(e && e[0] == '0'); }();   // (18.2 -> 17.3 ms at N = 1e5)
     if (d <= 8 && !lq1 && w1) {
-      HSSK_LAUNCH((knn_kernel<8, 64, 4, false, 64, 11>), dim3((unsigned)((nqr + 15) / 16)), dim3(64), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+      HSSK_LAUNCH((knn_kernel<8, 64, 4, false, 64, 11>), dim3((unsigned)((nqr + 15) / 16)), dim3(64), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
       continue;
     }
-    if (d <= 8 && !lq1 && pipe) HSSK_LAUNCH((knn_kernel<8, 256, 4, true>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else if (d <= 8 && !lq1) HSSK_LAUNCH((knn_kernel<8, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256, 1>), dim3((unsigned)((nqr + 255) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
-    else HSSK_LAUNCH((knn_kernel<64, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub);
+    if (d <= 8 && !lq1 && pipe) HSSK_LAUNCH((knn_kernel<8, 256, 4, true>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
+    else if (d <= 8 && !lq1) HSSK_LAUNCH((knn_kernel<8, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
+    else if (d <= 8) HSSK_LAUNCH((knn_kernel<8, 256, 1>), dim3((unsigned)((nqr + 255) / 256)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
+    else if (d <= 16) HSSK_LAUNCH((knn_kernel<16, 256, 4>), dim3((unsigned)((nqr + 63) / 64)), dim3(256), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
+    else if (d <= 32) HSSK_LAUNCH((knn_kernel<32, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
+    else HSSK_LAUNCH((knn_kernel<64, 128, 1>), dim3((unsigned)((nqr + 127) / 128)), dim3(128), 0, ctx->stream, X, d, n, q0, q1, kp, lb, oi, k, ub, window);
   }
+  hssk_rt::check_launch();
+  return kb + (size_t)((pages - 1) & 1) * n;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// The filtered search (large point sets).  The heap kernel above spends its time on the per-query heaps, not on the n^2
+// distances.  Here the n^2 part only FILTERS:
+//   * d2(q, c) = |c|^2 + |q|^2 - 2 c.q of all pairs on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: 32 candidates along the
+//     rows, a query per lane, K = d + 2 with the two norms as extra coordinates; points centred on their mean).  A pair
+//     passes when its approximate d2 is <= tau_q + the worst-case error of that arithmetic, tau_q being the float key of the
+//     k-th best candidate the query has met so far -- no true neighbour is lost; the id of a pair that passes is appended to
+//     the query's list (a private cursor per lane: no atomics);
+//   * a list that is nearly full is COMPACTED by the whole wave: exact keys of its entries -- the heap kernel's arithmetic:
+//     FP64 differences, key = (float(d2), id) --, the k smallest kept (bisection on the key bits with ballot counts), tau_q
+//     tightened.  Candidate tiles are visited outwards from the queries' own position (cluster order: index neighbours are
+//     spatial neighbours), so tau_q is close to its final value after the first few tiles and a query lists a few hundred of
+//     the n candidates; lists cannot overflow whatever the data (a loose tau_q only costs compactions);
+//   * a last compaction writes the k ids.
+// The result is the heap kernel's set (the k smallest keys are unique).  One wave per workgroup, 64 queries per wave.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int K2_G = 64;         // workgroups of the mean / norm reductions
+constexpr int K2_SLOTS = 8;      // list entries per lane at a compaction: 64 x 8 = 512 = 2 halves x 256 entries
+
+// partial sums of the coordinates: workgroup g adds the points g, g + G, ... (thread t always meets coordinate t % d)
+__global__ __launch_bounds__(256) void knn2_mean_kernel(const double* __restrict__ X, int d, int n, double* __restrict__ part) {
+  HSSK_SHARED double red[256];
+  const int tid = threadIdx.x, Tp = (256 / d) * d, ppw = Tp / d;   // points per pass of the workgroup
+  double s = 0.;
+  if (tid < Tp) {
+    const int j = tid % d, pl = tid / d;
+    for (long long i = (long long)blockIdx.x * ppw + pl; i < n; i += (long long)K2_G * ppw) s += X[(size_t)i * d + j];
+  }
+  red[tid] = tid < Tp ? s : 0.;
+  __syncthreads();
+  if (tid < d) {
+    double a = 0.;
+    for (int m = tid; m < Tp; m += d) a += red[m];
+    part[blockIdx.x * d + tid] = a;
+  }
+}
+
+// Cf (KP x ldc floats, row k = coordinate k of every candidate): rows 0 .. d-1 = -2 (x - mean), row d = |x - mean|^2, row d + 1 = 1,
+// the rest 0; candidates n .. ldc-1 (padding) get an enormous norm.  nmax[g] = largest norm of workgroup g's points.
+__global__ __launch_bounds__(256) void knn2_prep_kernel(const double* __restrict__ X, int d, int n, int ldc, int KP,
+                                                        const double* __restrict__ part, float* __restrict__ Cf, float* __restrict__ nmax) {
+  HSSK_SHARED double mean[KNN_DMAX];
+  HSSK_SHARED float red[256];
+  const int tid = threadIdx.x;
+  if (tid < d) {
+    double a = 0.;
+    for (int g = 0; g < K2_G; g++) a += part[g * d + tid];
+    mean[tid] = a / n;
+  }
+  __syncthreads();
+  float big = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + tid; i < ldc; i += (long long)gridDim.x * 256) {
+    if (i < n) {
+      double s2 = 0.;
+      for (int j = 0; j < d; j++) {
+        const double c = X[(size_t)i * d + j] - mean[j];
+        s2 += c * c;
+        Cf[(size_t)j * ldc + i] = (float)(-2. * c);
+      }
+      const float nf = (float)s2;
+      Cf[(size_t)d * ldc + i] = nf;
+      Cf[(size_t)(d + 1) * ldc + i] = 1.f;
+      big = fmaxf(big, nf);
+    } else {
+      for (int j = 0; j < d; j++) Cf[(size_t)j * ldc + i] = 0.f;
+      Cf[(size_t)d * ldc + i] = 3.0e38f;
+      Cf[(size_t)(d + 1) * ldc + i] = 1.f;
+    }
+    for (int j = d + 2; j < KP; j++) Cf[(size_t)j * ldc + i] = 0.f;
+  }
+  red[tid] = big;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  if (tid == 0) nmax[blockIdx.x] = red[0];
+}
+
+// KSM k-steps of two coordinates (KP = 2 KSM rows of Cf), TC candidates per LDS tile, CAPH list entries per (query, lane half).
+// Workgroup w = ONE wave: queries q0 + 64 w .. + 63 in two groups of 32 (group g, query l & 31; the lane halves l >> 5 supply the
+// two coordinates of a k-step and receive different candidate rows, so each keeps a list segment of its own).
+template <int KSM, int TC>
+__global__ __launch_bounds__(64) void knn2_scan_kernel(const double* __restrict__ X, const float* __restrict__ Cf, int ldc, int d, int n,
+                                                       int q0, int q1, int k, const float* __restrict__ nmax, int CAPH,
+                                                       int* __restrict__ list, int* __restrict__ out_idx, int ldo) {
+  constexpr int KP = 2 * KSM, NV = (KP * TC / 4 + 63) / 64;
+  HSSK_DYN_SHARED(float, lds2);   // two tiles of KP x TC floats
+  const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
+  const int qbase = q0 + blockIdx.x * 64;
+  float bq[2][KSM], tau[2], marg[2];
+  int cur[2] = {0, 0};
+  int* seg[2];
+  float big = 0.f;
+  for (int g = 0; g < K2_G; g++) big = fmaxf(big, nmax[g]);
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const int q = qbase + 32 * g + l32;
+    const bool live = q < q1;
+    const float nq = live ? Cf[(size_t)d * ldc + q] : 0.f;
+    // the query's side of the product: coordinate k of (x - mean) = -Cf[k] / 2, then 1 (meets the candidate's norm) and its own norm
+#pragma unroll
+    for (int s = 0; s < KSM; s++) {
+      const int kk = 2 * s + half;
+      bq[g][s] = !live ? 0.f : (kk < d ? -0.5f * Cf[(size_t)kk * ldc + q] : (kk == d ? 1.f : (kk == d + 1 ? nq : 0.f)));
+    }
+    // what the FP32 evaluation can be off by: inputs and norms rounded to FP32, K + 2 accumulations of terms bounded by
+    // (|c| + |q|)^2 <= 2 (|c|^2 + |q|^2)
+    marg[g] = 2.02f * ((float)(KP + 6) * 1.1920929e-7f) * (nq + big);
+    tau[g] = live ? 1.0e38f : -1.f;   // (nothing met yet: every candidate passes -- not the padding, whose norm is 3e38; a lane without a query lists nothing)
+    seg[g] = list + ((size_t)(blockIdx.x * 64 + 32 * g + l32) * 2 + half) * CAPH;
+  }
+  // ---- compaction of query j (0 .. 63, uniform) of this wave; fin: the ids go out instead of back into the list
+  auto compact = [&](int j, bool fin) {
+    const int g = j >> 5, j32 = j & 31, q = qbase + j;
+    const int c0 = hssk_shfl(g ? cur[1] : cur[0], j32), c1 = hssk_shfl(g ? cur[1] : cur[0], j32 + 32), m = c0 + c1;
+    const int* s0 = list + ((size_t)(blockIdx.x * 64 + j) * 2) * CAPH;
+    hssk_drain_stores();
+    knn_key_t key[K2_SLOTS];
+    const int nslot = (m + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < K2_SLOTS; i++) {
+      key[i] = KNN_EMPTY;
+      if (i < nslot) {
+        const int e = lane + 64 * i;
+        const int cg = e < m ? hssk_flag_load(e < c0 ? s0 + e : s0 + CAPH + (e - c0)) : q;
+        double s2 = 0.;
+        for (int c = 0; c < d; c++) {
+          const double df = X[(size_t)q * d + c] - X[(size_t)cg * d + c];
+          s2 += df * df;
+        }
+        if (cg != q) key[i] = knn_pack((float)s2, cg);
+      }
+    }
+    // the k-th smallest key: the largest P with fewer than k keys below it, bit by bit (bit 63 is the sign of a distance: clear)
+    knn_key_t P = 0;
+    for (int b = 62; b >= 0; b--) {
+      const knn_key_t cand = P | (1ULL << b);
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < K2_SLOTS; i++)
+        if (i < nslot) c += __builtin_popcountll(hssk_ballot(key[i] < cand));
+      if (c < k) P = cand;
+    }
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < K2_SLOTS; i++)
+      if (i < nslot) {
+        const int keep = key[i] <= P && key[i] != KNN_EMPTY;
+        const unsigned long long mk = hssk_ballot(keep);
+        if (keep) {
+          const int pos = o + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL)), id = (int)(key[i] & 0xffffffffu);
+          if (fin) out_idx[(size_t)q * ldo + pos] = id;
+          else ((int*)s0)[(size_t)(pos & 1) * CAPH + (pos >> 1)] = id;   // alternately into the halves' segments
+        }
+        o += __builtin_popcountll(mk);
+      }
+    if (fin) {
+      for (int s = o + lane; s < k; s += 64) out_idx[(size_t)q * ldo + s] = -1;
+      return;
+    }
+    // the query's lanes: cursors behind what was kept, threshold from the k-th key (once k candidates are known)
+    const float kf = hssk_from_fbits((unsigned)(P >> 32));
+    if (l32 == j32) {
+      const int mine = half ? o / 2 : (o + 1) / 2;
+      if (g) { cur[1] = mine; if (o >= k) tau[1] = kf * (1.f + 4.8e-7f) + marg[1]; }
+      else { cur[0] = mine; if (o >= k) tau[0] = kf * (1.f + 4.8e-7f) + marg[0]; }
+    }
+  };
+  // ---- the scan: tiles outwards from the queries' own
+  const int ntile = ldc / TC, own = min(qbase + 32, n - 1) / TC;
+  auto tile_of = [&](int it) {
+    const int off = (it + 1) >> 1;
+    return ((it & 1) ? own + off : own - off + ntile) % ntile;
+  };
+  hssk_f4 v[NV];
+  auto gfetch = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < NV; r++) {
+      const int e = min(lane + 64 * r, KP * TC / 4 - 1), row = e / (TC / 4), c4 = e % (TC / 4);
+      v[r] = *(const hssk_f4*)(Cf + (size_t)row * ldc + (size_t)t * TC + 4 * c4);
+    }
+  };
+  gfetch(tile_of(0));
+  for (int it = 0; it < ntile; it++) {
+    const int t = tile_of(it);
+    float* tile = lds2 + (it & 1) * KP * TC;
+#pragma unroll
+    for (int r = 0; r < NV; r++)
+      if (lane + 64 * r < KP * TC / 4) *(hssk_f4*)(tile + 4 * (lane + 64 * r)) = v[r];
+    hssk_wave_sync();
+    if (it + 1 < ntile) gfetch(tile_of(it + 1));
+    for (int b = 0; b < TC / 32; b++) {
+      hssk_f16v acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < KSM; s++) {
+        const float a = tile[(2 * s + half) * TC + b * 32 + l32];
+        acc0 = hssk_mfma_f32_32x32x2(a, bq[0][s], acc0);
+        acc1 = hssk_mfma_f32_32x32x2(a, bq[1][s], acc1);
+      }
+      const int cb = t * TC + b * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (acc0[r] <= tau[0]) { seg[0][cur[0]] = cb + 8 * (r / 4) + (r % 4); cur[0]++; }
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (acc1[r] <= tau[1]) { seg[1][cur[1]] = cb + 8 * (r / 4) + (r % 4); cur[1]++; }
+      // a segment takes at most 16 ids per block: compact what could overflow on the next one
+      for (int g = 0; g < 2; g++) {
+        unsigned long long need = hssk_ballot((g ? cur[1] : cur[0]) > CAPH - 16);
+        while (need) {
+          const int j32 = __builtin_ctzll(need) & 31;
+          compact(32 * g + j32, false);
+          need = hssk_ballot((g ? cur[1] : cur[0]) > CAPH - 16);
+        }
+      }
+    }
+    hssk_wave_sync();
+  }
+  for (int j = 0; j < 64 && qbase + j < q1; j++) compact(j, true);
+}
+
+template <int KSM, int TC>
+void knn2_launch_scan(hssk_ctx* ctx, int grid, const double* X, const float* Cf, int ldc, int d, int n, int q0, int q1, int k,
+                      const float* nmax, int CAPH, int* list, int* out_idx) {
+  const size_t shm = sizeof(float) * 2 * (2 * KSM) * TC;
+  hssk_rt::allow_dynamic_lds(knn2_scan_kernel<KSM, TC>, shm);
+  HSSK_LAUNCH((knn2_scan_kernel<KSM, TC>), dim3((unsigned)grid), dim3(64), shm, ctx->stream, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx, k);
+}
+}  // namespace
+
+extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1, int* out_idx) {
+  HSSK_API_BEGIN
+  if (n <= 0 || k <= 0 || q1 <= q0) return 0;
+  if (q0 < 0 || q1 > n) throw std::invalid_argument("hssk_knn: query range outside the point set");
+  if (d <= 0 || d > KNN_DMAX) throw std::invalid_argument("hssk_knn: point dimension must be in [1, 64]");
+  // the filtered search pays from a few thousand points on (HSSK_KNN_FILTER_MIN; HSSK_KNN_FILTER=0: always the heap kernel)
+  static const bool filt = [] { const char* e = std::getenv("HSSK_KNN_FILTER"); return !(e && e[0] == '0'); }();
+  static const int fmin_n = [] { const char* e = std::getenv("HSSK_KNN_FILTER_MIN"); return e ? std::atoi(e) : 8192; }();
+  if (!filt || n < fmin_n || k > 128 || d > 30 || n <= 4 * k) {
+    knn_exhaustive(ctx, X, d, n, k, q0, q1, out_idx, 0);
+    return 0;
+  }
+  const int KSM = d <= 4 ? 3 : (d <= 8 ? 5 : (d <= 16 ? 9 : 16)), KP = 2 * KSM, TC = 256;
+  const int ldc = ((n + TC - 1) / TC) * TC, nq = q1 - q0, nw = (nq + 63) / 64;
+  const int CAPH = k <= 64 ? 128 : 256;   // (2 CAPH = 64 K2_SLOTS at most; a compaction keeps k of 2 CAPH entries)
+  // scratch: Cf | partial means | norms | lists
+  const size_t o_cf = 0, b_cf = sizeof(float) * (size_t)KP * ldc;
+  const size_t o_pm = (o_cf + b_cf + 255) & ~size_t(255), b_pm = sizeof(double) * K2_G * d;
+  const size_t o_nm = (o_pm + b_pm + 255) & ~size_t(255), b_nm = sizeof(float) * K2_G;
+  const size_t o_ls = (o_nm + b_nm + 255) & ~size_t(255), b_ls = sizeof(int) * (size_t)nw * 64 * 2 * CAPH;
+  char* base = (char*)ctx->scratch(o_ls + b_ls + 256);
+  float* Cf = (float*)(base + o_cf);
+  double* part = (double*)(base + o_pm);
+  float* nmax = (float*)(base + o_nm);
+  int* list = (int*)(base + o_ls);
+  HSSK_LAUNCH(knn2_mean_kernel, dim3(K2_G), dim3(256), 0, ctx->stream, X, d, n, part);
+  HSSK_LAUNCH(knn2_prep_kernel, dim3(K2_G), dim3(256), 0, ctx->stream, X, d, n, ldc, KP, part, Cf, nmax);
+  if (KSM == 3) knn2_launch_scan<3, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
+  else if (KSM == 5) knn2_launch_scan<5, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
+  else if (KSM == 9) knn2_launch_scan<9, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
+  else knn2_launch_scan<16, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
   hssk_rt::check_launch();
   HSSK_API_END
 }
+
 
 extern "C" int hssk_kernel_predict(hssk_ctx* ctx, const hssk_kernel_spec* spec, const double* w, const double* T, int m,
                                    double* pred) {

@@ -168,6 +168,24 @@ double wave_xchg(double v, int src_lane) {
   return r;
 }
 
+hssk_f16v mfma_f32_32x32x2(float a, float b, hssk_f16v c) {
+  Worker* w = W;
+  int t = w->cur, l = t % 64;
+  Wave& wv = w->waves[t / 64];
+  wv.buf[l] = a;
+  wv.buf2[l] = b;
+  wave_barrier(w, wv);
+  const int col = l & 31;
+  for (int r = 0; r < 16; r++) {
+    const int row = 8 * (r / 4) + 4 * (l >> 5) + r % 4;
+    float s = c[r];
+    for (int k = 0; k < 2; k++) s = std::fmaf((float)wv.buf[row + 32 * k], (float)wv.buf2[col + 32 * k], s);
+    c[r] = s;
+  }
+  wave_barrier(w, wv);
+  return c;
+}
+
 unsigned long long wave_ballot(int pred) {
   Worker* w = W;
   int t = w->cur;

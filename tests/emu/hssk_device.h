@@ -33,6 +33,8 @@ extern thread_local std::vector<std::function<void()>>* sink;   // non-null whil
 }
 typedef double hssk_d4 __attribute__((vector_size(32)));
 typedef double hssk_d2 __attribute__((vector_size(16)));
+typedef float hssk_f16v __attribute__((vector_size(64)));
+typedef float hssk_f4 __attribute__((vector_size(16)));
 
 namespace emu {
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
@@ -40,6 +42,7 @@ void* dyn_shared();
 void block_barrier();
 double wave_xchg(double v, int src_lane);  // every live lane of the wave must call
 hssk_d4 mfma_f64_16x16x4(double a, double b, hssk_d4 c);
+hssk_f16v mfma_f32_32x32x2(float a, float b, hssk_f16v c);
 unsigned long long wave_ballot(int pred);   // every live lane of the wave must call
 }  // namespace emu
 
@@ -48,6 +51,7 @@ inline void __syncthreads() { emu::block_barrier(); }
 inline hssk_d4 hssk_mfma_f64_16x16x4(double a, double b, hssk_d4 c) {
   return emu::mfma_f64_16x16x4(a, b, c);
 }
+inline hssk_f16v hssk_mfma_f32_32x32x2(float a, float b, hssk_f16v c) { return emu::mfma_f32_32x32x2(a, b, c); }
 inline double hssk_shfl_xor(double v, int mask) {
   return emu::wave_xchg(v, (int)((threadIdx.x & 63) ^ mask));
 }
@@ -117,6 +121,8 @@ inline void hssk_sched_barrier() {}
 #define HSSK_SG_DSWRITE 0x200
 template <int MASK, int N> inline void hssk_sched_group() {}
 inline unsigned hssk_fbits(float v) { unsigned b; std::memcpy(&b, &v, 4); return b; }
+inline float hssk_from_fbits(unsigned b) { float v; std::memcpy(&v, &b, 4); return v; }
+inline void hssk_wave_sync() { (void)emu::wave_ballot(1); }
 inline unsigned long long hssk_bits(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; }
 inline double hssk_from_bits(unsigned long long b) { double v; std::memcpy(&v, &b, 8); return v; }
 inline void hssk_drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
