@@ -511,11 +511,11 @@ knn_key_t* knn_exhaustive(hssk_ctx* ctx, const double* X, int d, int n, int k, i
 //     spatial neighbours), so tau_q is close to its final value after the first few tiles and a query lists a few hundred of
 //     the n candidates; lists cannot overflow whatever the data (a loose tau_q only costs compactions);
 //   * a last compaction writes the k ids.
-// The result is the heap kernel's set (the k smallest keys are unique).  One wave per workgroup, 64 queries per wave.
+// The result is the heap kernel's set (the k smallest keys are unique).  64 queries per wave, four independent waves per workgroup.
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int K2_G = 64;         // workgroups of the mean / norm reductions
-constexpr int K2_SLOTS = 8;      // list entries per lane at a compaction: 64 x 8 = 512 = 2 halves x 256 entries
+constexpr int K2_SLOTS = 6;      // entries per lane at a compaction: 64 x 6 = 384 = 2 halves x 128 listed + 128 kept
 
 // partial sums of the coordinates: workgroup g adds the points g, g + G, ... (thread t always meets coordinate t % d)
 __global__ __launch_bounds__(256) void knn2_mean_kernel(const double* __restrict__ X, int d, int n, double* __restrict__ part) {
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256) void knn2_mean_kernel(const double* __restrict
   }
 }
 
-// Cf (KP x ldc floats, row k = coordinate k of every candidate): rows 0 .. d-1 = -2 (x - mean), row d = |x - mean|^2, row d + 1 = 1,
-// the rest 0; candidates n .. ldc-1 (padding) get an enormous norm.  nmax[g] = largest norm of workgroup g's points.
+// Cf (KP x ldc floats, row k = coordinate k of every candidate): rows 0 .. d-1 = -2 (x - mean), row d = |x - mean|^2, rows d + 1 and
+// d + 2 = 1, the rest 0; candidates n .. ldc-1 (padding) get an enormous norm.  nmax[g] = largest norm of workgroup g's points.
 __global__ __launch_bounds__(256) void knn2_prep_kernel(const double* __restrict__ X, int d, int n, int ldc, int KP,
                                                         const double* __restrict__ part, float* __restrict__ Cf, float* __restrict__ nmax) {
   HSSK_SHARED double mean[KNN_DMAX];
@@ -559,14 +559,14 @@ __global__ __launch_bounds__(256) void knn2_prep_kernel(const double* __restrict
       }
       const float nf = (float)s2;
       Cf[(size_t)d * ldc + i] = nf;
-      Cf[(size_t)(d + 1) * ldc + i] = 1.f;
       big = fmaxf(big, nf);
     } else {
       for (int j = 0; j < d; j++) Cf[(size_t)j * ldc + i] = 0.f;
       Cf[(size_t)d * ldc + i] = 3.0e38f;
-      Cf[(size_t)(d + 1) * ldc + i] = 1.f;
     }
-    for (int j = d + 2; j < KP; j++) Cf[(size_t)j * ldc + i] = 0.f;
+    Cf[(size_t)(d + 1) * ldc + i] = 1.f;   // meets the query's norm
+    Cf[(size_t)(d + 2) * ldc + i] = 1.f;   // meets minus the query's threshold
+    for (int j = d + 3; j < KP; j++) Cf[(size_t)j * ldc + i] = 0.f;
   }
   red[tid] = big;
   __syncthreads();
@@ -577,64 +577,113 @@ __global__ __launch_bounds__(256) void knn2_prep_kernel(const double* __restrict
   if (tid == 0) nmax[blockIdx.x] = red[0];
 }
 
-// KSM k-steps of two coordinates (KP = 2 KSM rows of Cf), TC candidates per LDS tile, CAPH list entries per (query, lane half).
-// Workgroup w = ONE wave: queries q0 + 64 w .. + 63 in two groups of 32 (group g, query l & 31; the lane halves l >> 5 supply the
-// two coordinates of a k-step and receive different candidate rows, so each keeps a list segment of its own).
+// KSM k-steps of two coordinates (KP = 2 KSM >= d + 3 rows of Cf), TC candidates per LDS tile.  A wave: queries
+// q0 + 64 w .. + 63 in two groups of 32 (group g, query l & 31; the lane halves l >> 5 supply the two coordinates of a k-step and
+// receive different candidate rows, so each half keeps a list of its own).  Row d + 2 of the product is 1 x (-tau_q): the
+// accumulator IS d2 - tau_q and its sign bit the verdict; a lane shifts the 16 sign bits of a block into one word and appends
+// (block, bits) to its list when any is set -- two instructions per pair and one predicated store per lane, group and block.
+constexpr int K2_CAPH = 128;     // ids a lane half lists between two compactions of its query (and the words that hold them)
 template <int KSM, int TC>
-__global__ __launch_bounds__(64) void knn2_scan_kernel(const double* __restrict__ X, const float* __restrict__ Cf, int ldc, int d, int n,
-                                                       int q0, int q1, int k, const float* __restrict__ nmax, int CAPH,
-                                                       int* __restrict__ list, int* __restrict__ out_idx, int ldo) {
+__global__ __launch_bounds__(256) void knn2_scan_kernel(const double* __restrict__ X, const float* __restrict__ Cf, int ldc, int d, int n,
+                                                        int q0, int q1, int k, const float* __restrict__ nmax,
+                                                        unsigned* __restrict__ list, int* __restrict__ kept, int* __restrict__ out_idx, int ldo,
+                                                        long long* dbg) {
   constexpr int KP = 2 * KSM, NV = (KP * TC / 4 + 63) / 64;
-  HSSK_DYN_SHARED(float, lds2);   // two tiles of KP x TC floats
-  const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
-  const int qbase = q0 + blockIdx.x * 64;
-  float bq[2][KSM], tau[2], marg[2];
-  int cur[2] = {0, 0};
-  int* seg[2];
+  HSSK_DYN_SHARED(float, lds_all);   // per wave: a tile of KP x TC floats, then 512 ids (the entries of a compaction)
+  // (four independent waves per workgroup: they never meet at a barrier)
+  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31, wv = threadIdx.x >> 6, wid = blockIdx.x * 4 + wv;
+  float* tile = lds_all + wv * (KP * TC + 512);
+  int* ent = (int*)(tile + KP * TC);
+  const int qbase = q0 + wid * 64;
+  if (qbase >= q1) return;
+  long long dbg_comp = 0, dbg_listed = 0;
+  float bq[2][KSM], marg[2];
+  int nw[2] = {0, 0}, nh[2] = {0, 0}, kc[2] = {0, 0};   // words / ids listed since the query's last compaction, ids it kept
+  unsigned* seg[2];
   float big = 0.f;
   for (int g = 0; g < K2_G; g++) big = fmaxf(big, nmax[g]);
+  const int trow = d + 2;   // the threshold's row: supplied by the lanes of half trow & 1 in k-step trow / 2
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     const int q = qbase + 32 * g + l32;
-    const bool live = q < q1;
+    const bool live = q < q1 && !(dbg && dbg[2] == 1);
     const float nq = live ? Cf[(size_t)d * ldc + q] : 0.f;
-    // the query's side of the product: coordinate k of (x - mean) = -Cf[k] / 2, then 1 (meets the candidate's norm) and its own norm
+    // the query's side of the product: coordinate k of (x - mean) = -Cf[k] / 2, then 1 (meets the candidate's norm), its own norm,
+    // and minus the threshold: nothing met yet = every candidate passes (not the padding, whose norm is 3e38); a lane without a
+    // query lists nothing
 #pragma unroll
     for (int s = 0; s < KSM; s++) {
       const int kk = 2 * s + half;
-      bq[g][s] = !live ? 0.f : (kk < d ? -0.5f * Cf[(size_t)kk * ldc + q] : (kk == d ? 1.f : (kk == d + 1 ? nq : 0.f)));
+      bq[g][s] = kk == trow ? (live ? -1.0e38f : 1.f)
+                            : (!live ? 0.f : (kk < d ? -0.5f * Cf[(size_t)kk * ldc + q] : (kk == d ? 1.f : (kk == d + 1 ? nq : 0.f))));
     }
     // what the FP32 evaluation can be off by: inputs and norms rounded to FP32, K + 2 accumulations of terms bounded by
     // (|c| + |q|)^2 <= 2 (|c|^2 + |q|^2)
-    marg[g] = 2.02f * ((float)(KP + 6) * 1.1920929e-7f) * (nq + big);
-    tau[g] = live ? 1.0e38f : -1.f;   // (nothing met yet: every candidate passes -- not the padding, whose norm is 3e38; a lane without a query lists nothing)
-    seg[g] = list + ((size_t)(blockIdx.x * 64 + 32 * g + l32) * 2 + half) * CAPH;
+    marg[g] = fmaxf(2.02f * ((float)(KP + 6) * 1.1920929e-7f) * (nq + big), 1.0e-30f);
+    seg[g] = list + ((size_t)(wid * 64 + 32 * g + l32) * 2 + half) * K2_CAPH;
   }
-  // ---- compaction of query j (0 .. 63, uniform) of this wave; fin: the ids go out instead of back into the list
+  // ---- compaction of query j (0 .. 63, uniform) of this wave; fin: the ids go out instead of into the kept list
   auto compact = [&](int j, bool fin) {
     const int g = j >> 5, j32 = j & 31, q = qbase + j;
-    const int c0 = hssk_shfl(g ? cur[1] : cur[0], j32), c1 = hssk_shfl(g ? cur[1] : cur[0], j32 + 32), m = c0 + c1;
-    const int* s0 = list + ((size_t)(blockIdx.x * 64 + j) * 2) * CAPH;
+    const int w0 = hssk_shfl(g ? nw[1] : nw[0], j32), w1 = hssk_shfl(g ? nw[1] : nw[0], j32 + 32), nk = hssk_shfl(g ? kc[1] : kc[0], j32);
+    const unsigned* s0 = list + ((size_t)(wid * 64 + j) * 2) * K2_CAPH;
+    int* kq = kept + (size_t)(wid * 64 + j) * 128;
     hssk_drain_stores();
+    // the listed words back into ids: ent[0 .. m)
+    int m = 0;
+    for (int i0 = 0; i0 < w0 + w1; i0 += 64) {
+      const int i = i0 + lane;
+      const unsigned w = i < w0 + w1 ? (unsigned)hssk_flag_load((const int*)(i < w0 ? s0 + i : s0 + K2_CAPH + (i - w0))) : 0u;
+      const int hf = i < w0 ? 0 : 1;
+      int cnt = __builtin_popcount(w & 0xffffu), pre = cnt;
+      for (int off = 1; off < 64; off <<= 1) {   // inclusive prefix sum over the lanes
+        const int o = hssk_shfl(pre, max(lane - off, 0));
+        if (lane >= off) pre += o;
+      }
+      int pos = m + pre - cnt;
+      unsigned bits = w & 0xffffu;
+      const int cb = (int)(w >> 16) * 32 + 4 * hf;
+      while (bits) {
+        const int bp = 31 - __builtin_clz(bits), r = 15 - bp;   // (register r of the block went into bit 15 - r)
+        ent[pos++] = cb + 8 * (r / 4) + (r % 4);
+        bits &= ~(1u << bp);
+      }
+      m += hssk_shfl(pre, 63);
+    }
+    for (int i = lane; i < nk; i += 64) ent[m + i] = hssk_flag_load(kq + i);
+    m += nk;
+    dbg_comp++; dbg_listed += m;
+    hssk_wave_sync();
+    // exact keys, the heap kernel's arithmetic
+    // (all slots' coordinates are fetched side by side -- an empty slot reads the query's own: a compaction is a chain of memory
+    //  round trips, not arithmetic)
     knn_key_t key[K2_SLOTS];
     const int nslot = (m + 63) / 64;
+    int cg[K2_SLOTS];
+    double s2[K2_SLOTS];
 #pragma unroll
     for (int i = 0; i < K2_SLOTS; i++) {
-      key[i] = KNN_EMPTY;
-      if (i < nslot) {
-        const int e = lane + 64 * i;
-        const int cg = e < m ? hssk_flag_load(e < c0 ? s0 + e : s0 + CAPH + (e - c0)) : q;
-        double s2 = 0.;
-        for (int c = 0; c < d; c++) {
-          const double df = X[(size_t)q * d + c] - X[(size_t)cg * d + c];
-          s2 += df * df;
-        }
-        if (cg != q) key[i] = knn_pack((float)s2, cg);
+      const int e = lane + 64 * i;
+      cg[i] = e < m ? ent[e] : q;
+      s2[i] = 0.;
+    }
+#pragma unroll 4
+    for (int c = 0; c < d; c++) {
+      const double xq = X[(size_t)q * d + c];
+#pragma unroll
+      for (int i = 0; i < K2_SLOTS; i++) {
+        const double df = xq - X[(size_t)cg[i] * d + c];
+        s2[i] += df * df;
       }
     }
-    // the k-th smallest key: the largest P with fewer than k keys below it, bit by bit (bit 63 is the sign of a distance: clear)
+#pragma unroll
+    for (int i = 0; i < K2_SLOTS; i++) key[i] = cg[i] != q ? knn_pack((float)s2[i], cg[i]) : KNN_EMPTY;
+    hssk_wave_sync();
+    // the k-th smallest key: the largest P with fewer than k keys below it, bit by bit (bit 63 is the sign of a distance: clear;
+    // the bits of the low word above the largest id are clear in every key, so they are clear in P)
     knn_key_t P = 0;
     for (int b = 62; b >= 0; b--) {
+      if (b == 31) b = 31 - __builtin_clz((unsigned)n);
       const knn_key_t cand = P | (1ULL << b);
       int c = 0;
 #pragma unroll
@@ -651,7 +700,7 @@ __global__ __launch_bounds__(64) void knn2_scan_kernel(const double* __restrict_
         if (keep) {
           const int pos = o + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL)), id = (int)(key[i] & 0xffffffffu);
           if (fin) out_idx[(size_t)q * ldo + pos] = id;
-          else ((int*)s0)[(size_t)(pos & 1) * CAPH + (pos >> 1)] = id;   // alternately into the halves' segments
+          else kq[pos] = id;
         }
         o += __builtin_popcountll(mk);
       }
@@ -659,12 +708,17 @@ __global__ __launch_bounds__(64) void knn2_scan_kernel(const double* __restrict_
       for (int s = o + lane; s < k; s += 64) out_idx[(size_t)q * ldo + s] = -1;
       return;
     }
-    // the query's lanes: cursors behind what was kept, threshold from the k-th key (once k candidates are known)
+    // the query's lanes: empty lists, the threshold from the k-th key (once k candidates are known)
     const float kf = hssk_from_fbits((unsigned)(P >> 32));
     if (l32 == j32) {
-      const int mine = half ? o / 2 : (o + 1) / 2;
-      if (g) { cur[1] = mine; if (o >= k) tau[1] = kf * (1.f + 4.8e-7f) + marg[1]; }
-      else { cur[0] = mine; if (o >= k) tau[0] = kf * (1.f + 4.8e-7f) + marg[0]; }
+      if (g) { nw[1] = 0; nh[1] = 0; kc[1] = o; }
+      else { nw[0] = 0; nh[0] = 0; kc[0] = o; }
+      if (o >= k && half == (trow & 1)) {
+        const float t = -(kf * (1.f + 4.8e-7f) + (g ? marg[1] : marg[0]));
+#pragma unroll
+        for (int s = 0; s < KSM; s++)
+          if (s == trow / 2) { if (g) bq[1][s] = t; else bq[0][s] = t; }
+      }
     }
   };
   // ---- the scan: tiles outwards from the queries' own
@@ -684,7 +738,7 @@ __global__ __launch_bounds__(64) void knn2_scan_kernel(const double* __restrict_
   gfetch(tile_of(0));
   for (int it = 0; it < ntile; it++) {
     const int t = tile_of(it);
-    float* tile = lds2 + (it & 1) * KP * TC;
+    hssk_wave_sync();   // (the tile is this wave's alone: its reads of the previous one are issued)
 #pragma unroll
     for (int r = 0; r < NV; r++)
       if (lane + 64 * r < KP * TC / 4) *(hssk_f4*)(tile + 4 * (lane + 64 * r)) = v[r];
@@ -700,34 +754,39 @@ __global__ __launch_bounds__(64) void knn2_scan_kernel(const double* __restrict_
         acc0 = hssk_mfma_f32_32x32x2(a, bq[0][s], acc0);
         acc1 = hssk_mfma_f32_32x32x2(a, bq[1][s], acc1);
       }
-      const int cb = t * TC + b * 32 + 4 * half;
+      unsigned m0 = 0, m1 = 0;
 #pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (acc0[r] <= tau[0]) { seg[0][cur[0]] = cb + 8 * (r / 4) + (r % 4); cur[0]++; }
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (acc1[r] <= tau[1]) { seg[1][cur[1]] = cb + 8 * (r / 4) + (r % 4); cur[1]++; }
-      // a segment takes at most 16 ids per block: compact what could overflow on the next one
+      for (int r = 0; r < 16; r++) {
+        m0 = (m0 << 1) | (hssk_fbits(acc0[r]) >> 31);
+        m1 = (m1 << 1) | (hssk_fbits(acc1[r]) >> 31);
+      }
+      const unsigned blk = (unsigned)(t * (TC / 32) + b) << 16;
+      if (m0) { seg[0][nw[0]] = blk | m0; nw[0]++; nh[0] += __builtin_popcount(m0); }
+      if (m1) { seg[1][nw[1]] = blk | m1; nw[1]++; nh[1] += __builtin_popcount(m1); }
+      // a lane half lists at most 16 ids per block: compact what could overflow on the next one
       for (int g = 0; g < 2; g++) {
-        unsigned long long need = hssk_ballot((g ? cur[1] : cur[0]) > CAPH - 16);
+        unsigned long long need = hssk_ballot((g ? nh[1] : nh[0]) > K2_CAPH - 16);
         while (need) {
-          const int j32 = __builtin_ctzll(need) & 31;
-          compact(32 * g + j32, false);
-          need = hssk_ballot((g ? cur[1] : cur[0]) > CAPH - 16);
+          compact(32 * g + (__builtin_ctzll(need) & 31), false);
+          need = hssk_ballot((g ? nh[1] : nh[0]) > K2_CAPH - 16);
         }
       }
     }
-    hssk_wave_sync();
   }
   for (int j = 0; j < 64 && qbase + j < q1; j++) compact(j, true);
+  if (dbg && lane == 0) {   // (HSSK_KNN_DEBUG: compactions and the entries they met, summed over the waves)
+    hssk_gadd_ll(dbg, dbg_comp);
+    hssk_gadd_ll(dbg + 1, dbg_listed);
+  }
 }
 
 template <int KSM, int TC>
-void knn2_launch_scan(hssk_ctx* ctx, int grid, const double* X, const float* Cf, int ldc, int d, int n, int q0, int q1, int k,
-                      const float* nmax, int CAPH, int* list, int* out_idx) {
-  const size_t shm = sizeof(float) * 2 * (2 * KSM) * TC;
+void knn2_launch_scan(hssk_ctx* ctx, int nwaves, const double* X, const float* Cf, int ldc, int d, int n, int q0, int q1, int k,
+                      const float* nmax, unsigned* list, int* kept, int* out_idx, long long* dbg) {
+  const size_t shm = 4 * (sizeof(float) * (2 * KSM) * TC + sizeof(int) * 512);
   hssk_rt::allow_dynamic_lds(knn2_scan_kernel<KSM, TC>, shm);
-  HSSK_LAUNCH((knn2_scan_kernel<KSM, TC>), dim3((unsigned)grid), dim3(64), shm, ctx->stream, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx, k);
+  HSSK_LAUNCH((knn2_scan_kernel<KSM, TC>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), shm, ctx->stream, X, Cf, ldc, d, n, q0, q1, k, nmax,
+              list, kept, out_idx, k, dbg);
 }
 }  // namespace
 
@@ -736,36 +795,50 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
   if (n <= 0 || k <= 0 || q1 <= q0) return 0;
   if (q0 < 0 || q1 > n) throw std::invalid_argument("hssk_knn: query range outside the point set");
   if (d <= 0 || d > KNN_DMAX) throw std::invalid_argument("hssk_knn: point dimension must be in [1, 64]");
-  // the filtered search pays from a few thousand points on (HSSK_KNN_FILTER_MIN; HSSK_KNN_FILTER=0: always the heap kernel)
+  // the filtered search pays from a few thousand points on (HSSK_KNN_FILTER_MIN; HSSK_KNN_FILTER=0: always the heap kernel);
+  // its lists name a candidate by (block of 32, bit): 2^16 blocks
   static const bool filt = [] { const char* e = std::getenv("HSSK_KNN_FILTER"); return !(e && e[0] == '0'); }();
   static const int fmin_n = [] { const char* e = std::getenv("HSSK_KNN_FILTER_MIN"); return e ? std::atoi(e) : 8192; }();
-  if (!filt || n < fmin_n || k > 128 || d > 30 || n <= 4 * k) {
+  if (!filt || n < fmin_n || k > 128 || d > 29 || n <= 4 * k || n > (1 << 21) - 256) {
     knn_exhaustive(ctx, X, d, n, k, q0, q1, out_idx, 0);
     return 0;
   }
-  const int KSM = d <= 4 ? 3 : (d <= 8 ? 5 : (d <= 16 ? 9 : 16)), KP = 2 * KSM, TC = 256;
+  const int KSM = d <= 3 ? 3 : (d <= 9 ? 6 : (d <= 17 ? 10 : 16)), KP = 2 * KSM, TC = 128;
   const int ldc = ((n + TC - 1) / TC) * TC, nq = q1 - q0, nw = (nq + 63) / 64;
-  const int CAPH = k <= 64 ? 128 : 256;   // (2 CAPH = 64 K2_SLOTS at most; a compaction keeps k of 2 CAPH entries)
-  // scratch: Cf | partial means | norms | lists
+  // scratch: Cf | partial means | norms | lists (words) | kept ids
   const size_t o_cf = 0, b_cf = sizeof(float) * (size_t)KP * ldc;
   const size_t o_pm = (o_cf + b_cf + 255) & ~size_t(255), b_pm = sizeof(double) * K2_G * d;
   const size_t o_nm = (o_pm + b_pm + 255) & ~size_t(255), b_nm = sizeof(float) * K2_G;
-  const size_t o_ls = (o_nm + b_nm + 255) & ~size_t(255), b_ls = sizeof(int) * (size_t)nw * 64 * 2 * CAPH;
-  char* base = (char*)ctx->scratch(o_ls + b_ls + 256);
+  const size_t o_ls = (o_nm + b_nm + 255) & ~size_t(255), b_ls = sizeof(unsigned) * (size_t)nw * 64 * 2 * K2_CAPH;
+  const size_t o_kp = (o_ls + b_ls + 255) & ~size_t(255), b_kp = sizeof(int) * (size_t)nw * 64 * 128;
+  char* base = (char*)ctx->scratch(o_kp + b_kp + 256);
   float* Cf = (float*)(base + o_cf);
   double* part = (double*)(base + o_pm);
   float* nmax = (float*)(base + o_nm);
-  int* list = (int*)(base + o_ls);
+  unsigned* list = (unsigned*)(base + o_ls);
+  int* kept = (int*)(base + o_kp);
+  static const bool dbg_on = [] { const char* e = std::getenv("HSSK_KNN_DEBUG"); return e && e[0] == '1'; }();
+  long long* dbg = nullptr;
+  if (dbg_on) {
+    dbg = (long long*)(base + o_kp + b_kp);
+    hssk_rt::memset_async(dbg, 0, 32, ctx->stream);
+    if (const char* e = std::getenv("HSSK_KNN_DRY")) { long long m = std::atoll(e); hssk_rt::h2d(dbg + 2, &m, 8, ctx->stream); hssk_rt::sync(ctx->stream); }
+  }
   HSSK_LAUNCH(knn2_mean_kernel, dim3(K2_G), dim3(256), 0, ctx->stream, X, d, n, part);
   HSSK_LAUNCH(knn2_prep_kernel, dim3(K2_G), dim3(256), 0, ctx->stream, X, d, n, ldc, KP, part, Cf, nmax);
-  if (KSM == 3) knn2_launch_scan<3, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
-  else if (KSM == 5) knn2_launch_scan<5, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
-  else if (KSM == 9) knn2_launch_scan<9, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
-  else knn2_launch_scan<16, 256>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, CAPH, list, out_idx);
+  if (KSM == 3) knn2_launch_scan<3, 128>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, list, kept, out_idx, dbg);
+  else if (KSM == 6) knn2_launch_scan<6, 128>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, list, kept, out_idx, dbg);
+  else if (KSM == 10) knn2_launch_scan<10, 128>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, list, kept, out_idx, dbg);
+  else knn2_launch_scan<16, 128>(ctx, nw, X, Cf, ldc, d, n, q0, q1, k, nmax, list, kept, out_idx, dbg);
   hssk_rt::check_launch();
+  if (dbg) {
+    long long h[2] = {0, 0};
+    hssk_rt::d2h(h, dbg, 16, ctx->stream);
+    hssk_rt::sync(ctx->stream);
+    std::fprintf(stderr, "hssk_knn filtered: per query %.2f compactions over %.1f entries (%d kept by each)\n", (double)h[0] / nq, (double)h[1] / nq, k);
+  }
   HSSK_API_END
 }
-
 
 extern "C" int hssk_kernel_predict(hssk_ctx* ctx, const hssk_kernel_spec* spec, const double* w, const double* T, int m,
                                    double* pred) {
