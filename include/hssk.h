@@ -427,6 +427,35 @@ typedef struct hssk_xsolve_desc {
   int ldx, solved;
 } hssk_xsolve_desc;
 int hssk_id_xsolve_vbatched(hssk_ctx* ctx, const hssk_xsolve_desc* descs, int count);
+/* The same ID for TALL panels W (d x m, d >> m), from the Gram matrix G = W^T W (m x m, both triangles; the caller forms it on the
+ * matrix cores: hssk_gemm_vbatched over K chunks + hssk_sum_partials): a diagonally pivoted Cholesky factorization of G is the
+ * column-pivoted QR of W -- same pivots, same |R_kk|, same stopping rule (dgeqp3tol.f:225-232) -- in `rank` steps of O(k m).
+ * G resolves singular values down to ~1e-8 of the largest: for tolerances >= 1e-6 only (the caller's choice).
+ * Outputs: perm[0..m) as hssk_id_desc (skeleton columns in pivot order, then the rest in index order); *rank, or -1 when the
+ * rank reached min(ldr, hssk_pchol_id_rank_cap(m)) rows without meeting the tolerance (the caller then takes the QR path);
+ * R(0:rank, 0:m) = [R11 R12] in pivoted column order (leading dimension ldr), for hssk_id_xsolve_vbatched.  m <= 256. */
+typedef struct hssk_pchol_desc {
+  const double* G;
+  int ldg, m;
+  double rtol, atol;
+  int max_rank;
+  int* perm; /* device, m ints */
+  int* rank; /* device, 1 int */
+  double* R;
+  int ldr;
+} hssk_pchol_desc;
+int hssk_pchol_id_vbatched(hssk_ctx* ctx, const hssk_pchol_desc* descs, int count);
+int hssk_pchol_id_max_m(void);
+int hssk_pchol_id_rank_cap(int m); /* rows of R the kernel can hold for a panel of m columns */
+/* out[0..n) = P[0..n) + P[stride .. stride + n) + ... (count terms, added in this order): the K-split partial products of a
+ * long inner dimension, summed deterministically */
+typedef struct hssk_sum_desc {
+  const double* P;
+  long long stride, n;
+  int count;
+  double* out;
+} hssk_sum_desc;
+int hssk_sum_partials(hssk_ctx* ctx, const hssk_sum_desc* descs, int count);
 
 /* ---- the inner levels of a compression round as ONE launch (kernels/hssk_tree.hip) ------------------------------------
  * compress_recursive_stable above the leaves (HSS/HSSMatrix.compress_stable.hpp:165-348, HSS/HSSMatrix.compress.hpp:555-629,

@@ -657,7 +657,58 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       srcs = nullptr;
     }
   }
-  tsqr_reduce(ids, which, Ws, ds);
+  // ---- tall panels at loose tolerances: the ID from the Gram matrix W^T W (kernels/hssk_pchol.hip) -- the d-long part of the
+  // work as a product on the matrix cores, then `rank` steps of a pivoted Cholesky factorization, instead of the TSQR's
+  // Householder sweeps (36 of the 48 ms of the blocks + ID phase of a 1e5-point kernel matrix).  STRUMPACK_AMD_ID_GRAM=0: off.
+  static const bool gram_on = [] { const char* e = std::getenv("STRUMPACK_AMD_ID_GRAM"); return !(e && e[0] == '0'); }();
+  std::vector<char> gram(cnt, 0);
+  std::vector<double*> gramR(cnt, nullptr);
+  std::vector<int> gramLd(cnt, 0);
+  std::vector<hssk_pchol_desc> pcd;
+  std::vector<size_t> pck;
+  if (gram_on && !srcs) {
+    std::vector<hssk_gemm_desc> gd;
+    std::vector<hssk_sum_desc> sd;
+    size_t tiles_total = 0;
+    for (size_t k = 0; k < cnt; k++) {
+      const Node& nd = nodes_[ids[k]];
+      const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
+      if (m <= 0 || m > hssk_pchol_id_max_m() || !Ws[k] || d <= std::max(256, 2 * m) || o_.rel_tol / nd.lvl < 1e-6) continue;
+      gram[k] = 1;
+      tiles_total += (size_t)((m + 63) / 64) * ((m + 63) / 64);
+    }
+    for (size_t k = 0; k < cnt; k++) {
+      if (!gram[k]) continue;
+      const Node& nd = nodes_[ids[k]];
+      const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
+      // K chunks: enough 64 x 64 tiles over the level to fill the chip, chunks of >= 512 rows
+      const int want = (int)std::max<size_t>(1, (2048 + tiles_total - 1) / tiles_total);
+      const int chunks = std::max(1, std::min(want, (d + 511) / 512)), rows = ((d + chunks - 1) / chunks + 15) & ~15;
+      const int nch = (d + rows - 1) / rows;
+      double* G = tmp.dbl((size_t)m * m);
+      double* P = nch > 1 ? tmp.dbl((size_t)nch * m * m) : G;
+      for (int c = 0; c < nch; c++) {
+        const int r0 = c * rows, kr = std::min(rows, d - r0);
+        gd.push_back(hssk_gemm_desc{Ws[k] + r0, Ws[k] + r0, P + (size_t)c * m * m, m, m, kr, d, d, m, 1, 0, 1., 0.});
+      }
+      if (nch > 1) sd.push_back(hssk_sum_desc{P, (long long)m * m, (long long)m * m, nch, G});
+      const int cap = std::max(1, std::min(m, hssk_pchol_id_rank_cap(m)));
+      gramR[k] = tmp.dbl((size_t)cap * m);
+      gramLd[k] = cap;
+      pcd.push_back(hssk_pchol_desc{G, m, m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, nullptr, nullptr, gramR[k], cap});
+      pck.push_back(k);
+      stats_.f_ortho += 2.0 * d * (double)m * m;
+    }
+    if (!gd.empty()) ck(hssk_gemm_vbatched(ctx_, gd.data(), (int)gd.size()));
+    if (!sd.empty()) ck(hssk_sum_partials(ctx_, sd.data(), (int)sd.size()));
+  }
+  {
+    // (the TSQR takes what the Gram form does not)
+    std::vector<double*> Wt(Ws);
+    for (size_t k = 0; k < cnt; k++) if (gram[k]) Wt[k] = nullptr;
+    tsqr_reduce(ids, which, Wt, ds);
+    for (size_t k = 0; k < cnt; k++) if (!gram[k]) Ws[k] = Wt[k];
+  }
   std::vector<hssk_id_desc> idd;
   int id_dmax = 0, id_mmax = 0;
   std::vector<int*> perms(cnt, nullptr);
@@ -673,6 +724,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     perms[k] = perm_block + poff;
     poff += m;
     if (m == 0) continue;
+    if (gram[k]) continue;   // (its descriptor is completed below)
     double* wk = tmp.dbl(3 * (size_t)m);
     // (defer_x: X = R11^{-1} R12 is computed behind the read-back of the ranks, straight into its final place)
     idd.push_back(hssk_id_desc{Ws[k], ds[k], ds[k], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk,
@@ -681,9 +733,36 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     id_mmax = std::max(id_mmax, m);
   }
   if (!idd.empty()) ck(hssk_id_vbatched(ctx_, idd.data(), (int)idd.size()));
+  for (size_t q = 0; q < pcd.size(); q++) { pcd[q].perm = perms[pck[q]]; pcd[q].rank = rank_block + pck[q]; }
+  if (!pcd.empty()) ck(hssk_pchol_id_vbatched(ctx_, pcd.data(), (int)pcd.size()));
   const int x_solved = hssk_id_solves_inline(id_dmax, id_mmax);
   std::vector<int> hall(cnt + std::max<size_t>(perm_total, 1));
   ck(hssk_memcpy_d2h(ctx_, hall.data(), rank_block, (long long)sizeof(int) * (cnt + perm_total)));
+  {
+    // Gram panels whose rank outgrew the kernel's rows (-1): the Householder path for those, and one more read-back
+    std::vector<int> rid, rwh, rds;
+    std::vector<double*> rW;
+    std::vector<size_t> rk_;
+    for (size_t k = 0; k < cnt; k++)
+      if (gram[k] && hall[k] < 0) { rid.push_back(ids[k]); rwh.push_back(which[k]); rW.push_back(Ws[k]); rds.push_back(ds[k]); rk_.push_back(k); }
+    if (!rid.empty()) {
+      tsqr_reduce(rid, rwh, rW, rds);
+      std::vector<hssk_id_desc> rdd;
+      int dmx = 0, mmx = 0;
+      for (size_t q = 0; q < rid.size(); q++) {
+        const size_t k = rk_[q];
+        const Node& nd = nodes_[ids[k]];
+        const int m = which[k] == 0 ? nd.mU : nd.mV;
+        double* wk = tmp.dbl(3 * (size_t)m);
+        rdd.push_back(hssk_id_desc{rW[q], rds[q], rds[q], m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, perms[k], rank_block + k, wk, nullptr, 0, 0});
+        dmx = std::max(dmx, rds[q]); mmx = std::max(mmx, m);
+        gram[k] = 2;   // (X solved by the ID kernel itself: defer_x = 0)
+        Ws[k] = rW[q]; ds[k] = rds[q];
+      }
+      ck(hssk_id_vbatched(ctx_, rdd.data(), (int)rdd.size()));
+      ck(hssk_memcpy_d2h(ctx_, hall.data(), rank_block, (long long)sizeof(int) * (cnt + perm_total)));
+    }
+  }
   // (the cooperative ID's workgroups poll each other with a bounded spin; a timeout must not pass as a rank)
   if (hssk_sweep_status(ctx_)) throw std::runtime_error(std::string("compress: interpolative decomposition: ") + hssk_last_error());
   const int* hranks = hall.data();
@@ -699,14 +778,14 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     Node& nd = nodes_[ids[k]];
     const int w = which[k];
     const int m = w == 0 ? nd.mU : nd.mV;
-    const int dtot = ds[k];
+    const int dtot = gram[k] == 1 ? gramLd[k] : ds[k];
     const int r = m ? hranks[k] : 0;
     perm_off[k] = poff;
     poff += m;
     idx_off[k] = idx_total;
     idx_total += r;
     double* X = persist_->dbl((size_t)std::max(r, 1) * std::max(m - r, 1));
-    if (r > 0 && m > r) xc.push_back(hssk_xsolve_desc{Ws[k], dtot, r, m, X, r, x_solved});
+    if (r > 0 && m > r) xc.push_back(hssk_xsolve_desc{gram[k] == 1 ? gramR[k] : Ws[k], dtot, r, m, X, r, gram[k] == 1 ? 0 : (gram[k] == 2 ? 1 : x_solved)});
     if (w == 0) { nd.rU = r; nd.XU = X; nd.permU = perms[k]; nd.Ustate = 2; }
     else { nd.rV = r; nd.XV = X; nd.permV = perms[k]; nd.Vstate = 2; }
     stats_.f_id += 2.0 * (4.0 * m * (double)dtot * r - 2.0 * (m + dtot) * (double)r * r + 4.0 * r * (double)r * r / 3.0 + (double)r * r * (m - r));
