@@ -456,6 +456,16 @@ typedef struct hssk_sum_desc {
   double* out;
 } hssk_sum_desc;
 int hssk_sum_partials(hssk_ctx* ctx, const hssk_sum_desc* descs, int count);
+/* G (m x m, leading dimension ldg, both triangles written) = W^T W for tall panels W (rows x m, leading dimension ldw, rows >= 2):
+ * 128 x 128 blocks on and above the diagonal on the FP64 matrix cores, mirrored below it.  The K-split of a long panel is the
+ * caller's: one descriptor per row chunk into its own G, then hssk_sum_partials. */
+typedef struct hssk_gram_desc {
+  const double* W;
+  int ldw, rows, m;
+  double* G;
+  int ldg;
+} hssk_gram_desc;
+int hssk_gram_vbatched(hssk_ctx* ctx, const hssk_gram_desc* descs, int count);
 
 /* ---- the inner levels of a compression round as ONE launch (kernels/hssk_tree.hip) ------------------------------------
  * compress_recursive_stable above the leaves (HSS/HSSMatrix.compress_stable.hpp:165-348, HSS/HSSMatrix.compress.hpp:555-629,

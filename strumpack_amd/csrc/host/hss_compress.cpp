@@ -667,7 +667,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   std::vector<hssk_pchol_desc> pcd;
   std::vector<size_t> pck;
   if (gram_on && !srcs) {
-    std::vector<hssk_gemm_desc> gd;
+    std::vector<hssk_gram_desc> gd;
     std::vector<hssk_sum_desc> sd;
     size_t tiles_total = 0;
     for (size_t k = 0; k < cnt; k++) {
@@ -675,21 +675,21 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
       if (m <= 0 || m > hssk_pchol_id_max_m() || !Ws[k] || d <= std::max(256, 2 * m) || o_.rel_tol / nd.lvl < 1e-6) continue;
       gram[k] = 1;
-      tiles_total += (size_t)((m + 63) / 64) * ((m + 63) / 64);
+      tiles_total += (size_t)((m + 127) / 128) * ((m + 127) / 128 + 1) / 2;
     }
     for (size_t k = 0; k < cnt; k++) {
       if (!gram[k]) continue;
       const Node& nd = nodes_[ids[k]];
       const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
-      // K chunks: enough 64 x 64 tiles over the level to fill the chip, chunks of >= 512 rows
-      const int want = (int)std::max<size_t>(1, (2048 + tiles_total - 1) / tiles_total);
+      // K chunks: enough 128 x 128 blocks over the level to fill the chip, chunks of >= 512 rows
+      const int want = (int)std::max<size_t>(1, (1024 + tiles_total - 1) / tiles_total);
       const int chunks = std::max(1, std::min(want, (d + 511) / 512)), rows = ((d + chunks - 1) / chunks + 15) & ~15;
       const int nch = (d + rows - 1) / rows;
       double* G = tmp.dbl((size_t)m * m);
       double* P = nch > 1 ? tmp.dbl((size_t)nch * m * m) : G;
       for (int c = 0; c < nch; c++) {
         const int r0 = c * rows, kr = std::min(rows, d - r0);
-        gd.push_back(hssk_gemm_desc{Ws[k] + r0, Ws[k] + r0, P + (size_t)c * m * m, m, m, kr, d, d, m, 1, 0, 1., 0.});
+        gd.push_back(hssk_gram_desc{Ws[k] + r0, d, kr, m, P + (size_t)c * m * m, m});
       }
       if (nch > 1) sd.push_back(hssk_sum_desc{P, (long long)m * m, (long long)m * m, nch, G});
       const int cap = std::max(1, std::min(m, hssk_pchol_id_rank_cap(m)));
@@ -697,9 +697,9 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       gramLd[k] = cap;
       pcd.push_back(hssk_pchol_desc{G, m, m, o_.rel_tol / nd.lvl, o_.abs_tol / nd.lvl, o_.max_rank, nullptr, nullptr, gramR[k], cap});
       pck.push_back(k);
-      stats_.f_ortho += 2.0 * d * (double)m * m;
+      stats_.f_ortho += (double)d * m * (m + 1.0);   // the triangle of W^T W
     }
-    if (!gd.empty()) ck(hssk_gemm_vbatched(ctx_, gd.data(), (int)gd.size()));
+    if (!gd.empty()) ck(hssk_gram_vbatched(ctx_, gd.data(), (int)gd.size()));
     if (!sd.empty()) ck(hssk_sum_partials(ctx_, sd.data(), (int)sd.size()));
   }
   {

@@ -158,3 +158,123 @@ extern "C" int hssk_sum_partials(hssk_ctx* ctx, const hssk_sum_desc* descs, int 
   hssk_rt::check_launch();
   HSSK_API_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// G = W^T W for tall panels W (rows x m, column-major: K runs along the contiguous direction), FP64 matrix cores.
+// A workgroup (4 waves) owns a 128 x 128 block (I, J >= I) of G for one panel, a wave a 64 x 64 quadrant = 4 x 4 MFMA tiles;
+// quadrants and tiles outside the panel's columns or below the diagonal are skipped, off-diagonal tiles are written on both
+// sides of it.  Both operands are column blocks of W staged through the LDS as [column][k] (17 doubles per column: a lane
+// group of 16 columns falls on 16 banks), the next stage's loads in flight under the products of the current one.
+// Bound: MFMA (a 128 x 128 block takes 16 KB of operands per 16 k-rows = 64 MFMAs per wave).
+namespace {
+constexpr int GR_B = 128, GR_K = 16, GR_KP = GR_K + 1;
+struct GramTile { int prob, bi, bj; };
+
+__global__ __launch_bounds__(256) void gram_kernel(const hssk_gram_desc* __restrict__ descs, const GramTile* __restrict__ tiles) {
+  HSSK_DYN_SHARED(double, gr_lds);   // As[2][128 x 17] | Bs[2][128 x 17]
+  const GramTile t = tiles[blockIdx.x];
+  const hssk_gram_desc p = descs[t.prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = t.bi * GR_B, j0 = t.bj * GR_B, wi = i0 + (wave & 1) * 64, wj = j0 + (wave >> 1) * 64;
+  const bool diag = t.bi == t.bj;
+  // 16 x 16 tiles of this wave that lie inside the panel and on or above the diagonal
+  bool on[4][4];
+  bool any = false;
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      on[a][b] = wi + 16 * a < p.m && wj + 16 * b < p.m && wi + 16 * a <= wj + 16 * b;
+      any = any || on[a][b];
+    }
+  hssk_d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = hssk_d4{0., 0., 0., 0.};
+  // stage loads: thread -> k pair 2 (tid & 7), columns (tid >> 3) + 32 r
+  const int ks = 2 * (tid & 7), cb = tid >> 3;
+  hssk_d2 ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = cb + 32 * r;
+      const int ga = min(i0 + c, p.m - 1), gb = min(j0 + c, p.m - 1), gk = min(k0 + ks, max(p.rows - 2, 0));
+      hssk_d2 va = hssk_gload2u(p.W, (size_t)gk + (size_t)ga * p.ldw);
+      hssk_d2 vb = diag ? va : hssk_gload2u(p.W, (size_t)gk + (size_t)gb * p.ldw);
+      // (rows beyond the panel's: zero; the clamped pair may straddle the end -- a panel has at least two rows)
+      const bool k0ok = k0 + ks < p.rows, k1ok = k0 + ks + 1 < p.rows, shifted = k0 + ks > gk;
+      const double a0 = shifted ? va[1] : va[0], b0 = shifted ? vb[1] : vb[0];
+      ra[r] = hssk_d2{(k0ok && i0 + c < p.m) ? a0 : 0., (k1ok && i0 + c < p.m) ? va[1] : 0.};
+      rb[r] = hssk_d2{(k0ok && j0 + c < p.m) ? b0 : 0., (k1ok && j0 + c < p.m) ? vb[1] : 0.};
+    }
+  };
+  fetch(0);
+  int buf = 0;
+  for (int k0 = 0; k0 < p.rows; k0 += GR_K, buf ^= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = cb + 32 * r;
+      double* Aw = gr_lds + buf * GR_B * GR_KP;
+      double* Bw = gr_lds + (2 + buf) * GR_B * GR_KP;
+      Aw[c * GR_KP + ks] = ra[r][0]; Aw[c * GR_KP + ks + 1] = ra[r][1];
+      if (!diag) { Bw[c * GR_KP + ks] = rb[r][0]; Bw[c * GR_KP + ks + 1] = rb[r][1]; }
+    }
+    __syncthreads();   // (one barrier per stage: the buffer written here was last read two stages ago)
+    if (k0 + GR_K < p.rows) fetch(k0 + GR_K);
+    if (any) {
+      const double* Ab = gr_lds + buf * GR_B * GR_KP + ((wave & 1) * 64) * GR_KP;
+      const double* Bb = gr_lds + ((diag ? 0 : 2) + buf) * GR_B * GR_KP + ((wave >> 1) * 64) * GR_KP;
+#pragma unroll
+      for (int kk = 0; kk < GR_K; kk += 4) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) av[a] = Ab[(16 * a + l15) * GR_KP + kk + l4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) bv[b] = Bb[(16 * b + l15) * GR_KP + kk + l4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if (on[a][b]) acc[a][b] = hssk_mfma_f64_16x16x4(av[a], bv[b], acc[a][b]);
+      }
+    }
+  }
+  // ---- G(i, j) and G(j, i): lane l holds rows (l >> 4) + 4 r, column l & 15 of its tiles
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      if (!on[a][b]) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = wi + 16 * a + l4 + 4 * r, gj = wj + 16 * b + l15;
+        if (gi < p.m && gj < p.m) {
+          hssk_gstore(p.G, (size_t)gi + (size_t)gj * p.ldg, acc[a][b][r]);
+          if (wi + 16 * a != wj + 16 * b) hssk_gstore(p.G, (size_t)gj + (size_t)gi * p.ldg, acc[a][b][r]);
+        }
+      }
+    }
+}
+}  // namespace
+
+extern "C" int hssk_gram_vbatched(hssk_ctx* ctx, const hssk_gram_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  std::vector<GramTile> tiles;
+  for (int q = 0; q < count; q++) {
+    if (descs[q].m <= 0) continue;
+    if (descs[q].rows < 2) throw std::invalid_argument("hssk_gram_vbatched: a panel has at least two rows");
+    const int nb = (descs[q].m + GR_B - 1) / GR_B;
+    for (int bi = 0; bi < nb; bi++)
+      for (int bj = bi; bj < nb; bj++) tiles.push_back(GramTile{q, bi, bj});
+  }
+  if (tiles.empty()) return 0;
+  auto* dd = (const hssk_gram_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  auto* dt = (const GramTile*)ctx->stage(tiles.data(), sizeof(GramTile) * tiles.size());
+  const size_t shm = sizeof(double) * 4 * GR_B * GR_KP;
+  hssk_rt::allow_dynamic_lds(gram_kernel, shm);
+  HSSK_LAUNCH(gram_kernel, dim3((unsigned)tiles.size()), dim3(256), shm, ctx->stream, dd, dt);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}
