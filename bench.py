@@ -128,26 +128,32 @@ def kernel_workload(a, torch, dist, world, rank, local):
                         "blocks_id": st["t_tree"], "factor": st["t_factor"], "solve": st["t_solve"]},
            "hss": {"rank": H.rank(), "levels": H.levels(), "memory_MB": H.memory() / 1e6, "neighbours": int(st["d_final"])},
            "checks": {"solve_resid_H": resid}}
-    # dominant kernel of this workload: the exact nearest-neighbour search (knn_kernel: FP32 distance evaluations on the vector
-    # units, 3 flops per coordinate and candidate), HIP events on the engine's stream around its launches (hssk_watch_*)
+    # a dominant kernel of this workload: the exact nearest-neighbour search -- since round 6 a filter on the FP32 matrix cores
+    # (knn2_scan_kernel: d2 - threshold of all pairs as a product with K = d + 3, v_mfma_f32_32x32x2_f32) with exact FP64 selection
+    # of what passes; HIP events on the engine's stream around its launches (hssk_watch_*).  Priced against the dense FP32 MFMA
+    # peak (MI355X_MICROARCH.md: 157.3 TFLOP/s); the Gram products of the row IDs (gram_kernel, FP64 MFMA) take as long.
     if st["sketch_launches"] > 0 and st["sketch_kernel_ms"] > 0:
-        ach = st["sketch_kernel_flops"] / (st["sketch_kernel_ms"] * 1e-3) * 1e-12
-        out["roofline"] = {"kernel": "knn_kernel (exact %d nearest neighbours of every point; differences and squares in FP64 on the vector units, keys rounded to FP32)" % int(st["d_final"]),
-                           "bound": "valu_fp64", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
+        dim = X.shape[1]
+        fl = 2.0 * (dim + 3) * float(n) * float(n)
+        ach = fl * st["sketch_launches"] / (st["sketch_kernel_ms"] * 1e-3) * 1e-12
+        out["roofline"] = {"kernel": "knn2_scan_kernel (exact %d nearest neighbours of every point: all pairs' squared distances minus the query's threshold on the FP32 matrix cores, "
+                                     "v_mfma_f32_32x32x2_f32, K = d + 3; candidates that pass are re-evaluated in FP64 and the k smallest keys kept)" % int(st["d_final"]),
+                           "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                            "avg_launch_ms": st["sketch_kernel_ms"] / st["sketch_launches"], "launches_per_step": int(st["sketch_launches"]),
-                           "flops_per_launch": st["sketch_kernel_flops"] / st["sketch_launches"],
-                           "note": "3 d N^2 flops per search; the kernel is bound by its per-query top-k heaps in LDS (profiles/r02_pmc_knn.md), not by the distance arithmetic"}
+                           "flops_per_launch": fl,
+                           "note": "2 (d + 3) N^2 flops per search; the launch includes the compactions of the candidate lists (3.3 per query: exact keys + bisection), "
+                                   "which take about as long as the products (matrix pipe busy 0.41 in the scan alone: gpurun_out/r06knn_pmc)"}
     # dominant PHASE of the step: the row IDs of the sampled blocks -- TSQR of the d x m panels in the register QR kernels
     # (chunk QRs, then pairwise merges of triangles), the truncated QRCP of the m x m triangles, the kernel evaluations;
     # flops counted by the engine (Householder counts of the chunks and merges + the ID's), time = the phase on the host clock
     if st["t_tree"] > 0:
         fl = st["f_ortho"] + st["f_id"]
         ach = fl / st["t_tree"] * 1e-12
-        out["phase_roofline"] = {"phase": "blocks + ID (hssk_kernel_eval_vbatched, qr_reg_kernel / tpqr_reg_kernel, id_reg_kernel)", "bound": "valu_fp64",
+        out["phase_roofline"] = {"phase": "blocks + ID (hssk_kernel_eval_vbatched, gram_kernel, pchol_id_kernel)", "bound": "mfma",
                                  "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "ms": st["t_tree"] * 1e3,
-                                 "flops": {"tsqr": st["f_ortho"], "id": st["f_id"]},
-                                 "note": "Level-2 Householder steps on register-resident panels: a step is a reduction, a broadcast and a rank-1 update of ALL "
-                                         "column slots of the tile (the tile does not shrink with the step), one barrier per step"}
+                                 "flops": {"gram": st["f_ortho"], "id": st["f_id"]},
+                                 "note": "row IDs of the tall sample panels from their Gram matrices: W^T W (triangles) on the FP64 matrix cores, then a diagonally "
+                                         "pivoted Cholesky factorization in `rank` steps (DESIGN.md 8); the kernel evaluations (one exp per entry) are a quarter of the phase"}
     if rank == 0:
         print(json.dumps(out))
     H.destroy()

@@ -666,7 +666,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   std::vector<int> gramLd(cnt, 0);
   std::vector<hssk_pchol_desc> pcd;
   std::vector<size_t> pck;
-  if (gram_on && !srcs) {
+  if (gram_on && id_gram_ && !srcs) {
     std::vector<hssk_gram_desc> gd;
     std::vector<hssk_sum_desc> sd;
     size_t tiles_total = 0;

@@ -16,6 +16,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
   OpGuard op_guard(op_mu_);
   double t0 = now();
   stats_ = PhaseStats();
+  struct GramScope { bool& f; explicit GramScope(bool& b) : f(b) { f = true; } ~GramScope() { f = false; } } gram_scope(id_gram_);
   const int N = n_, dim = ks.d;
   if (dim <= 0 || !ks.X) throw std::invalid_argument("compress_kernel: no points");
   int k = std::min(N, std::max(1, user_ann ? user_k : ks.ann));

@@ -308,6 +308,9 @@ class DeviceHSS {
     bool active = false;
   } book_;
   bool defer_book_ = false;
+  // the row ID of tall panels may be taken from their Gram matrices (id_panels): set by the kernel-matrix compression only --
+  // its panels are thousands of rows tall and its tolerances loose; the sketch-based compression keeps the Householder forms
+  bool id_gram_ = false;
   void finish_id_bookkeeping();
   void id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
                  const std::vector<int>& ds, const std::vector<const double*>* srcs = nullptr, int ldsrc = 0);

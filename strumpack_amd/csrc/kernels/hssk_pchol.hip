@@ -24,7 +24,7 @@ namespace {
 constexpr int PC_T = 256;
 constexpr size_t PC_LDS = 150 * 1024;
 
-__global__ __launch_bounds__(PC_T) void pchol_id_kernel(const hssk_pchol_desc* __restrict__ descs, int cap_rows_max) {
+__global__ __launch_bounds__(PC_T) void pchol_id_kernel(const hssk_pchol_desc* __restrict__ descs, int lds_doubles) {
   HSSK_DYN_SHARED(double, Lr);   // [cap][mp] rows of R (original column order)
   HSSK_SHARED double s_v[4];
   HSSK_SHARED int s_i[4];
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(PC_T) void pchol_id_kernel(const hssk_pchol_desc* _
   const hssk_pchol_desc p = descs[blockIdx.x];
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int m = p.m, mp = (m + 7) & ~7;
-  const int cap = min(min(cap_rows_max, (int)(PC_LDS / (sizeof(double) * (size_t)mp))), p.ldr);
+  const int cap = min(lds_doubles / mp, p.ldr);   // rows of R this panel may take
   const bool col = j < m;
   double dj = col ? hssk_gload(p.G, (size_t)j + (size_t)j * p.ldg) : -1.;   // remaining squared norm of column j
   bool alive = col;
@@ -133,16 +133,18 @@ extern "C" int hssk_pchol_id_vbatched(hssk_ctx* ctx, const hssk_pchol_desc* desc
     if (descs[i].ldr < 1) throw std::invalid_argument("hssk_pchol_id_vbatched: ldr < 1");
     mmax = std::max(mmax, descs[i].m);
   }
-  const int mp = (mmax + 7) & ~7;
-  int cap = 0;
-  for (int i = 0; i < count; i++) cap = std::max(cap, std::min(descs[i].ldr, descs[i].m));
+  // LDS of the launch: what the panel with the largest (rows it may take) x (padded columns) needs, within the device's
   const size_t lds_max = std::min(PC_LDS, hssk_rt::max_lds_per_workgroup() > 8192 ? hssk_rt::max_lds_per_workgroup() - 8192 : 0);
-  cap = (int)std::min<size_t>((size_t)cap, lds_max / (sizeof(double) * (size_t)mp));
-  if (cap < 1) HSSK_UNSUPPORTED("no LDS for a row of R");
-  const size_t shm = sizeof(double) * (size_t)cap * mp;
+  size_t need = 0;
+  for (int i = 0; i < count; i++) {
+    const size_t mp = (size_t)((descs[i].m + 7) & ~7);
+    need = std::max(need, sizeof(double) * mp * (size_t)std::min(descs[i].ldr, descs[i].m));
+  }
+  const size_t shm = std::min(need, lds_max);
+  if (shm < sizeof(double) * (size_t)((mmax + 7) & ~7)) HSSK_UNSUPPORTED("no LDS for a row of R");
   auto* dd = (const hssk_pchol_desc*)ctx->stage(descs, sizeof(*descs) * count);
   hssk_rt::allow_dynamic_lds(pchol_id_kernel, shm);
-  HSSK_LAUNCH(pchol_id_kernel, dim3((unsigned)count), dim3(PC_T), shm, ctx->stream, dd, cap);
+  HSSK_LAUNCH(pchol_id_kernel, dim3((unsigned)count), dim3(PC_T), shm, ctx->stream, dd, (int)(shm / sizeof(double)));
   hssk_rt::check_launch();
   HSSK_API_END
 }

@@ -91,6 +91,19 @@ class XsolveDesc(C.Structure):
                 ("X", C.c_void_p), ("ldx", C.c_int), ("solved", C.c_int)]
 
 
+class PcholDesc(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("ldg", C.c_int), ("m", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
+                ("max_rank", C.c_int), ("perm", C.c_void_p), ("rank", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int)]
+
+
+class SumDesc(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("stride", C.c_longlong), ("n", C.c_longlong), ("count", C.c_int), ("out", C.c_void_p)]
+
+
+class GramDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("rows", C.c_int), ("m", C.c_int), ("G", C.c_void_p), ("ldg", C.c_int)]
+
+
 class QrDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("rows", C.c_int), ("cols", C.c_int),
                 ("Q", C.c_void_p), ("ldq", C.c_int), ("nq", C.c_int),
@@ -145,6 +158,7 @@ HSSK_SYMBOLS = [
     "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_h2d_bytes_async", "hssk_expand_image", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
     "hssk_sketch_gen", "hssk_gen_elems", "hssk_gen_fill", "hssk_colsets", "hssk_colsets_max_universe",
+    "hssk_cluster_median", "hssk_pchol_id_vbatched", "hssk_pchol_id_max_m", "hssk_pchol_id_rank_cap", "hssk_sum_partials", "hssk_gram_vbatched",
 ]
 
 
@@ -253,6 +267,10 @@ class Hssk:
         L.hssk_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hssk_kernel_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.hssk_colsets.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.hssk_cluster_median.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        for fn in ("hssk_pchol_id_vbatched", "hssk_sum_partials", "hssk_gram_vbatched"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hssk_pchol_id_rank_cap.argtypes = [C.c_int]
         L.hssk_colsets_max_universe.argtypes = []
         L.hssk_colsets_max_universe.restype = C.c_longlong
         L.hssk_sjlt_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]

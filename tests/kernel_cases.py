@@ -305,6 +305,87 @@ def case_id(hk, problems, seed=5, deferred=False):
         assert X.size == 0 or np.abs(X).max() < 1e3
 
 
+def case_gram_pchol_id(hk, problems, seed=41):
+    """The ID of tall panels from their Gram matrix: hssk_gram_vbatched over row chunks + hssk_sum_partials give W^T W
+    (against numpy), hssk_pchol_id_vbatched the pivots / rank / [R11 R12] of the column-pivoted QR with the reference's
+    stopping rule (against LAPACK's QRCP of W itself), hssk_id_xsolve_vbatched the interpolation matrix.
+    problems: list of (d, m, rtol, atol, max_rank, numerical_rank or None, chunks)."""
+    r = rng(seed)
+    gd, sd, pd, keep = [], [], [], []
+    for (d, m, rtol, atol, mr, nr, chunks) in problems:
+        Wm = r.standard_normal((d, m)) if nr is None else _lowrank(r, d, m, nr) + 1e-9 * r.standard_normal((d, m))
+        ldw = d + 3
+        Wp = np.full((ldw, m), 5.0)
+        Wp[:d] = Wm
+        dW = hk.array(Wp)
+        rows = -(-d // chunks)
+        nch = -(-d // rows)
+        dP = hk.array(np.full((m * m * nch,), np.nan))
+        dG = hk.array(np.full((m + 2, m), np.nan))
+        for c in range(nch):
+            kr = min(rows, d - c * rows)
+            gd.append(K.GramDesc(dW.ptr + 8 * c * rows, ldw, kr, m, dP.ptr + 8 * c * m * m, m))
+        cap = int(hk.lib.hssk_pchol_id_rank_cap(m))
+        dperm, drank, dR = hk.empty((m,), np.int32), hk.empty((1,), np.int32), hk.array(np.full((cap, m), -3.0))
+        keep.append((Wm, dW, dP, dG, dperm, drank, dR, cap, nch))
+    hk.batch("hssk_gram_vbatched", gd)
+    hk.sync()
+    # the partial products, then their sum into a contiguous m x m matrix per problem
+    sums, outs = [], []
+    for (prob, kp) in zip(problems, keep):
+        d, m = prob[0], prob[1]
+        Wm, dW, dP, dG, dperm, drank, dR, cap, nch = kp
+        dGc = hk.array(np.full((m * m,), np.nan))
+        outs.append(dGc)
+        sums.append(K.SumDesc(dP.ptr, m * m, m * m, nch, dGc.ptr))
+    hk.batch("hssk_sum_partials", sums)
+    hk.sync()
+    for (prob, kp, dGc) in zip(problems, keep, outs):
+        d, m, rtol, atol, mr, nr, chunks = prob
+        Wm, dW, dP, dG, dperm, drank, dR, cap, nch = kp
+        G = dGc.get().reshape(m, m, order="F")
+        Gref = Wm.T @ Wm
+        assert np.allclose(G, Gref, rtol=1e-12, atol=1e-12 * np.abs(Gref).max()), "Gram matrix"
+        assert np.array_equal(G, G.T), "both triangles carry the same sums"
+        pd.append(K.PcholDesc(dGc.ptr, m, m, rtol, atol, mr, dperm.ptr, drank.ptr, dR.ptr, cap))
+    hk.batch("hssk_pchol_id_vbatched", pd)
+    hk.sync()
+    for (prob, kp) in zip(problems, keep):
+        d, m, rtol, atol, mr, nr, chunks = prob
+        Wm, dW, dP, dG, dperm, drank, dR, cap, nch = kp
+        assert np.array_equal(dW.get()[:d], Wm), "the panel was modified"
+        rank, perm = int(drank.get()[0]), dperm.get()
+        Rq, jp = sla.qr(Wm, mode="r", pivoting=True)
+        dg = np.abs(np.diag(Rq))
+        rr = min(d, m)
+        for c in range(min(d, m)):
+            if dg[c] / dg[0] <= rtol or dg[c] <= atol:
+                rr = c
+                break
+        if rr > cap:
+            assert rank == -1, "a rank beyond the kernel's rows is reported, not truncated"
+            continue
+        rr = min(rr, mr)
+        assert sorted(perm.tolist()) == list(range(m)), "perm is not a permutation"
+        assert abs(rank - rr) <= (1 if rr > 0 else 0), f"rank {rank} vs LAPACK {rr} for {prob}"
+        assert np.all(np.diff(perm[rank:]) > 0), "columns behind the skeleton keep their order"
+        if rank == 0 or rank == m:
+            continue
+        R = dR.get()[:rank]
+        # R^T R reproduces the Gram matrix on the skeleton rows; R11 upper triangular with the pivots' decreasing diagonal
+        assert np.allclose(np.tril(R[:, :rank], -1), 0.)
+        dd = np.diag(R[:, :rank])
+        assert np.all(dd > 0) and np.all(np.diff(dd) <= 1e-12 * dd[0])
+        assert np.allclose(dd, dg[:rank], rtol=1e-6)
+        dX = hk.array(np.full((rank + 1, m - rank), -3.0))
+        hk.batch("hssk_id_xsolve_vbatched", [K.XsolveDesc(dR.ptr, cap, rank, m, dX.ptr, rank + 1, 0)])
+        hk.sync()
+        X = dX.get()[:rank]
+        err = np.linalg.norm(Wm[:, perm[rank:]] - Wm[:, perm[:rank]] @ X) / np.linalg.norm(Wm)
+        bound = max(rtol * dg[0], atol, dg[min(rank, min(d, m) - 1)]) * np.sqrt(m) * 4 / np.linalg.norm(Wm)
+        assert err <= max(bound, 1e-7), f"ID residual {err} > {bound} for {prob}"
+
+
 def case_qr(hk, shapes, seed=7):
     r = rng(seed)
     descs, keep = [], []

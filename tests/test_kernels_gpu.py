@@ -173,6 +173,11 @@ def test_kernel_matrix_entries(hk):
     KC.case_kernel_eval(hk, n=300)
 
 
+def test_gram_pchol_id(hk):
+    KC.case_gram_pchol_id(hk, [(5000, 195, 1e-3, 1e-12, 1000, 40, 4), (3000, 256, 1e-2, 1e-10, 1000, None, 3), (1520, 100, 1e-4, 1e-12, 17, 30, 2), (2600, 130, 1e-8, 1e-14, 1000, None, 1),
+                              (777, 1, 1e-2, 1e-12, 10, None, 1), (600, 255, 1e-12, 1e-14, 1000, None, 2), (40001, 82, 1e-3, 1e-12, 1000, 25, 16)])
+
+
 def test_knn(hk):
     KC.case_knn(hk, n=2000, d=8, k=64)
     KC.case_knn(hk, n=300, d=3, k=150, seed=24)
