@@ -675,14 +675,14 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
       if (m <= 0 || m > hssk_pchol_id_max_m() || !Ws[k] || d <= std::max(256, 2 * m) || o_.rel_tol / nd.lvl < 1e-6) continue;
       gram[k] = 1;
-      tiles_total += (size_t)((m + 127) / 128) * ((m + 127) / 128 + 1) / 2;
+      tiles_total++;   // (a workgroup per panel and row chunk: hssk_gram_vbatched)
     }
     for (size_t k = 0; k < cnt; k++) {
       if (!gram[k]) continue;
       const Node& nd = nodes_[ids[k]];
       const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
-      // K chunks: enough 128 x 128 blocks over the level to fill the chip, chunks of >= 512 rows
-      const int want = (int)std::max<size_t>(1, (1024 + tiles_total - 1) / tiles_total);
+      // K chunks: enough workgroups over the level to fill the chip twice, chunks of >= 512 rows
+      const int want = (int)std::max<size_t>(1, (768 + tiles_total - 1) / tiles_total);
       const int chunks = std::max(1, std::min(want, (d + 511) / 512)), rows = ((d + chunks - 1) / chunks + 15) & ~15;
       const int nch = (d + rows - 1) / rows;
       double* G = tmp.dbl((size_t)m * m);

@@ -17,6 +17,7 @@
 #include "hssk_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -260,9 +261,119 @@ __global__ __launch_bounds__(256) void gram_kernel(const hssk_gram_desc* __restr
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// The same product with ONE workgroup (8 waves) per panel and row chunk: the 16 x 16 tiles on and above the diagonal of the
+// whole m x m matrix are dealt to the waves in row-major runs (91 tiles for the 195-column panels of a leaf: 11 or 12 per wave --
+// the 128 x 128 blocks above left their waves 16, 16, 10 and 0 tiles of the same panel), every column of the chunk is staged once.
+// m <= 256 (NT tiles per wave: 5 up to 96 columns, 12 up to 208, 17 up to 256).
+namespace {
+constexpr int G2_K = 16, G2_KP = G2_K + 1, G2_T = 512;
+
+template <int NT>
+__global__ __launch_bounds__(G2_T) void gram_panel_kernel(const hssk_gram_desc* __restrict__ descs) {
+  HSSK_DYN_SHARED(double, g2_lds);   // two stages of [mp columns][17]
+  const hssk_gram_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = hssk_uniform(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
+  const int m = p.m, nb = (m + 15) / 16, ntile = nb * (nb + 1) / 2, mp = nb * 16;
+  // this wave's tiles: t0 .. t0 + cnt of the row-major list of (a, b >= a)
+  const int per = (ntile + 7) / 8, t0 = wave * per, cnt = max(0, min(per, ntile - t0));
+  int ta[NT], tb[NT];
+  {
+    int a = 0, rem = t0;   // row of tile t0: rows have nb, nb - 1, ... tiles
+    while (a < nb && rem >= nb - a) { rem -= nb - a; a++; }
+    int b = a + rem;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      ta[i] = min(a, nb - 1); tb[i] = min(b, nb - 1);
+      b++;
+      if (b >= nb) { a++; b = a; }
+    }
+  }
+  hssk_d4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = hssk_d4{0., 0., 0., 0.};
+  // stage loads: thread -> k pair 2 (tid & 7), columns (tid >> 3) + 64 r
+  const int ks = 2 * (tid & 7), cb = tid >> 3;
+  hssk_d2 rv[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = cb + 64 * r;
+      if (64 * r < mp) {
+        const int gc = min(c, m - 1), gk = min(k0 + ks, max(p.rows - 2, 0));
+        const hssk_d2 v = hssk_gload2u(p.W, (size_t)gk + (size_t)gc * p.ldw);
+        const bool k0ok = k0 + ks < p.rows, k1ok = k0 + ks + 1 < p.rows, shifted = k0 + ks > gk;
+        rv[r] = hssk_d2{(k0ok && c < m) ? (shifted ? v[1] : v[0]) : 0., (k1ok && c < m) ? v[1] : 0.};
+      }
+    }
+  };
+  fetch(0);
+  int buf = 0;
+  for (int k0 = 0; k0 < p.rows; k0 += G2_K, buf ^= 1) {
+    double* S = g2_lds + (size_t)buf * mp * G2_KP;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = cb + 64 * r;
+      if (c < mp) { S[c * G2_KP + ks] = rv[r][0]; S[c * G2_KP + ks + 1] = rv[r][1]; }
+    }
+    __syncthreads();   // (one barrier per stage: the buffer written here was last read two stages ago)
+    if (k0 + G2_K < p.rows) fetch(k0 + G2_K);
+#pragma unroll
+    for (int kk = 0; kk < G2_K; kk += 4) {
+      double av = 0.;
+      int arow = -1;
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+        if (i < cnt) {
+          if (ta[i] != arow) { arow = ta[i]; av = S[(16 * arow + l15) * G2_KP + kk + l4]; }
+          const double bv = S[(16 * tb[i] + l15) * G2_KP + kk + l4];
+          acc[i] = hssk_mfma_f64_16x16x4(av, bv, acc[i]);
+        }
+    }
+  }
+  // ---- G(i, j) and G(j, i): lane l holds rows (l >> 4) + 4 r, column l & 15 of its tiles
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+    if (i < cnt) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = 16 * ta[i] + l4 + 4 * r, gj = 16 * tb[i] + l15;
+        if (gi < m && gj < m) {
+          hssk_gstore(p.G, (size_t)gi + (size_t)gj * p.ldg, acc[i][r]);
+          if (ta[i] != tb[i]) hssk_gstore(p.G, (size_t)gj + (size_t)gi * p.ldg, acc[i][r]);
+        }
+      }
+    }
+}
+
+template <int NT> void gram_panel_launch(hssk_ctx* ctx, const hssk_gram_desc* descs, int count, int mmax) {
+  const int mp = ((mmax + 15) / 16) * 16;
+  const size_t shm = sizeof(double) * 2 * (size_t)mp * G2_KP;
+  auto* dd = (const hssk_gram_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  hssk_rt::allow_dynamic_lds(gram_panel_kernel<NT>, shm);
+  HSSK_LAUNCH(gram_panel_kernel<NT>, dim3((unsigned)count), dim3(G2_T), shm, ctx->stream, dd);
+}
+}  // namespace
+
 extern "C" int hssk_gram_vbatched(hssk_ctx* ctx, const hssk_gram_desc* descs, int count) {
   HSSK_API_BEGIN
   if (count <= 0) return 0;
+  // panels of up to 256 columns: a workgroup per panel (HSSK_GRAM_BLOCKS=1: the 128 x 128 blocks for everything)
+  static const bool blocks_only = [] { const char* e = std::getenv("HSSK_GRAM_BLOCKS"); return e && e[0] == '1'; }();
+  int mmax = 0;
+  bool ok = !blocks_only;
+  for (int q = 0; q < count; q++) {
+    mmax = std::max(mmax, descs[q].m);
+    ok = ok && descs[q].m > 0 && descs[q].m <= 256 && descs[q].rows >= 2;
+  }
+  if (ok && sizeof(double) * 2 * (size_t)(((mmax + 15) / 16) * 16) * G2_KP <= hssk_rt::max_lds_per_workgroup()) {
+    const int nb = (mmax + 15) / 16, per = (nb * (nb + 1) / 2 + 7) / 8;
+    if (per <= 5) gram_panel_launch<5>(ctx, descs, count, mmax);
+    else if (per <= 12) gram_panel_launch<12>(ctx, descs, count, mmax);
+    else gram_panel_launch<17>(ctx, descs, count, mmax);
+    hssk_rt::check_launch();
+    return 0;
+  }
   std::vector<GramTile> tiles;
   for (int q = 0; q < count; q++) {
     if (descs[q].m <= 0) continue;
