@@ -125,6 +125,20 @@ def test_clustering_device_form(lib, algo):
         st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, leaf)
         Xh, ph, lh = KM.clustering(lib, pts, algo, leaf)
         assert st == 0 and np.array_equal(perm, ph) and np.array_equal(Xp, Xh) and leaves.tolist() == lh.tolist()
+    # large clusters are split by several workgroups (a launch per step: hssk_cluster.hip, cluster_wide_kernel) -- here from
+    # 3000 points on, so that two levels take that form
+    import os
+    os.environ["HSSK_CLUSTER_WIDE_MIN"] = "3000"
+    try:
+        for pts, leaf in ((r.random((13001, 5)), 200), (r.standard_normal((9000, 3)) * 40 - 7, 64)):
+            st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, leaf)
+            Xh, ph, lh = KM.clustering(lib, pts, algo, leaf)
+            assert st == 0 and np.array_equal(perm, ph) and np.array_equal(Xp, Xh) and leaves.tolist() == lh.tolist()
+        lat = r.integers(0, 3, (8000, 4)).astype(float)
+        st, Xp, perm, leaves = KM.clustering_device(lib, lat, algo, 100)
+        assert st > 0 and np.array_equal(Xp, lat)
+    finally:
+        os.environ.pop("HSSK_CLUSTER_WIDE_MIN")
     # ties: the device form stands back and moves nothing
     for pts in (r.integers(0, 3, (3000, 4)).astype(float), np.ones((500, 3))):
         st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, 100)

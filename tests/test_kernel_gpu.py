@@ -71,11 +71,19 @@ def test_clustering_device_form_is_the_host_form(lib, algo):
         assert np.array_equal(perm, Z["perm_full_%s" % algo]) and leaves.tolist() == g["leaves"]
     else:
         assert algo == "kdtree"   # (duplicated coordinate values in the data set: a tie at a median)
+    import os
     r = np.random.default_rng(2025)
     for pts, leaf in ((r.random((100000, 8)), 256), (r.standard_normal((70001, 5)), 600)):
-        st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, leaf)
         Xh, ph, lh = KM.clustering(lib, pts, algo, leaf)
-        assert st == 0 and np.array_equal(perm, ph) and np.array_equal(Xp, Xh) and leaves.tolist() == lh.tolist()
+        # large clusters by several workgroups (the default from 16384 points), by one workgroup each, and from 5000 points
+        for wide in (None, "0", "5000"):
+            if wide is not None:
+                os.environ["HSSK_CLUSTER_WIDE_MIN"] = wide
+            try:
+                st, Xp, perm, leaves = KM.clustering_device(lib, pts, algo, leaf)
+            finally:
+                os.environ.pop("HSSK_CLUSTER_WIDE_MIN", None)
+            assert st == 0 and np.array_equal(perm, ph) and np.array_equal(Xp, Xh) and leaves.tolist() == lh.tolist()
     lat = r.integers(0, 3, (20000, 4)).astype(float)
     st, Xp, perm, leaves = KM.clustering_device(lib, lat, algo, 100)
     assert st > 0 and np.array_equal(Xp, lat)
