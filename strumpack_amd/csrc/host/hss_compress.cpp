@@ -681,14 +681,16 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       if (!gram[k]) continue;
       const Node& nd = nodes_[ids[k]];
       const int m = which[k] == 0 ? nd.mU : nd.mV, d = ds[k];
-      // K chunks: enough workgroups over the level to fill the chip twice, chunks of >= 512 rows
-      const int want = (int)std::max<size_t>(1, (768 + tiles_total - 1) / tiles_total);
-      const int chunks = std::max(1, std::min(want, (d + 511) / 512)), rows = ((d + chunks - 1) / chunks + 15) & ~15;
-      const int nch = (d + rows - 1) / rows;
+      // K chunks: enough workgroups over the level to fill the chip (STRUMPACK_AMD_GRAM_WGS, default 768: more and shorter chunks measured slower), chunks of >= 256 rows
+      static const int wgs = [] { const char* e = std::getenv("STRUMPACK_AMD_GRAM_WGS"); return e ? std::max(1, std::atoi(e)) : 768; }();
+      const int want = (int)std::max<size_t>(1, ((size_t)wgs + tiles_total - 1) / tiles_total);
+      const int chunks = std::max(1, std::min(want, (d + 255) / 256)), rows = ((d + chunks - 1) / chunks + 15) & ~15;
+      int nch = (d + rows - 1) / rows;
+      if (nch > 1 && d - (nch - 1) * rows < 16) nch--;   // (a last chunk of a few rows joins its predecessor: a chunk has at least two)
       double* G = tmp.dbl((size_t)m * m);
       double* P = nch > 1 ? tmp.dbl((size_t)nch * m * m) : G;
       for (int c = 0; c < nch; c++) {
-        const int r0 = c * rows, kr = std::min(rows, d - r0);
+        const int r0 = c * rows, kr = c == nch - 1 ? d - r0 : rows;
         gd.push_back(hssk_gram_desc{Ws[k] + r0, d, kr, m, P + (size_t)c * m * m, m});
       }
       if (nch > 1) sd.push_back(hssk_sum_desc{P, (long long)m * m, (long long)m * m, nch, G});
