@@ -111,6 +111,52 @@ def test_tsqr_staircase_matches_dense_sweep():
     assert np.linalg.norm(res[0][1] - res[1][1]) <= 1e-10 * np.linalg.norm(res[0][1])
 
 
+@pytest.mark.parametrize("kern,h,dim,clus,rtol", [("Gauss", 1.3, 8, "cobble", 1e-2), ("Laplace", 2.0, 3, "kdtree", 1e-3), ("Gauss", 3.0, 20, "cobble", 1e-2)])
+def test_round6_front_end_against_the_forms_it_replaced(kern, h, dim, clus, rtol):
+    """30000 points through the round-6 front end -- clustering on the device, the filtered neighbour search, the row ID from Gram
+    matrices -- against the forms they replaced in a second process (host clustering, heap search, TSQR + register QRCP:
+    STRUMPACK_AMD_CLUSTER_HOST / HSSK_KNN_FILTER / STRUMPACK_AMD_ID_GRAM): the same permutation, the same tree, ranks equal
+    (one off tolerated on a twentieth of the nodes), products equal to the compression tolerance; and sampled rows of the kernel
+    matrix itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    import kernel_cases as KC
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from strumpack_amd import _loader, capi, dist as sdist\n"
+        "L = capi.load(_loader.lib_path()); n, d = 30000, %d\n"
+        "X = np.random.default_rng(77).random((n, d))\n"
+        "o = capi.StructuredMatrix.options(L, rel_tol=%g, abs_tol=1e-10, leaf_size=256, max_rank=50000)\n"
+        "H, Xp, perm = sdist.from_kernel(L, X, o, kernel=%r, h=%g, lam=2.5, clustering=%r, neighbors=64)\n"
+        "b = np.linspace(-1, 1, n); y = H.mult(b)[:, 0]; H.factor(); x = H.solve(b)[:, 0]\n"
+        "res = float(np.linalg.norm(H.mult(x)[:, 0] - b) / np.linalg.norm(b))\n"
+        "np.savez(sys.argv[1], perm=perm, info=H.node_info(), y=y, Xp=Xp, res=res)\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), dim, rtol, kern, h, clus)
+    out = []
+    for mode, env in (("new", {}), ("old", {"STRUMPACK_AMD_CLUSTER_HOST": "1", "HSSK_KNN_FILTER": "0", "STRUMPACK_AMD_ID_GRAM": "0"})):
+        f = "/tmp/r06_front_%s_%s_%d.npz" % (mode, kern, dim)
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(np.load(f))
+    new, old = out
+    assert np.array_equal(new["perm"], old["perm"]), "device clustering differs from the host form"
+    assert np.array_equal(new["info"][:, [0, 1, 5]], old["info"][:, [0, 1, 5]]), "tree"
+    dr = np.abs(new["info"][:, 3:5] - old["info"][:, 3:5])
+    assert dr.max() <= 1 and (dr > 0).mean() <= 0.05, (int(dr.max()), float((dr > 0).mean()))
+    assert np.linalg.norm(new["y"] - old["y"]) <= 10 * rtol * np.linalg.norm(old["y"])
+    assert float(new["res"]) <= 1e-10 and float(old["res"]) <= 1e-10
+    # sampled rows of the kernel matrix against the compressed one
+    n = len(new["y"])
+    I = np.random.default_rng(3).integers(0, n, 16)
+    KI = KC.kernel_np(new["Xp"], I, np.arange(n), {"Gauss": 0, "Laplace": 1}[kern], h, 2.5)
+    b = np.linspace(-1, 1, n)
+    err = np.linalg.norm(new["y"][I] - KI @ b) / np.linalg.norm(KI @ b)
+    assert err <= 1e2 * rtol, err
+
+
 def test_full_size_properties_100k():
     """BASELINE configs[3] size (N = 100000 points in R^8, Gauss kernel, h = 1.3, lambda = 3.11) through size-independent
     properties: sampled rows of K against the compressed matrix, symmetry (V = U, B10 = B01^T), linearity, ULV residual."""
