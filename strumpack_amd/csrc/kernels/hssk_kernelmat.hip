@@ -10,8 +10,9 @@
 // n^2 d flops are a few milliseconds on this machine -- which only improves the column sample the
 // compression draws from them.
 //
-// Bounds: kernel_eval is exp-throughput / HBM-write bound (one exp per output double); knn is LDS-bandwidth
-// bound (two LDS reads per squared difference); both are far from the sketch's MFMA bound and run once.
+// Bounds: kernel_eval is exp-throughput / HBM-write bound (one exp per output double); the heap form of the neighbour search
+// is LDS-bandwidth bound (two LDS reads per squared difference), the filtered form (large point sets, round 6) runs its n^2
+// part on the FP32 matrix cores.
 #include "hssk_device.h"
 #include "hssk_internal.h"
 

@@ -1,3 +1,6 @@
+"""Median-split clustering (cobble, kd) of 1e5 points in R^8, leaf 256: the device form (hssk_cluster_median through
+SPX_clustering_device, copies included) against the host form (SPX_clustering) -- times and whether the permutations are equal.
+usage (GPU box): python tools/cluster_ab.py   (HSSK_CLUSTER_WIDE_MIN=0: large clusters by one workgroup each)"""
 import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np, time
 from strumpack_amd import _loader
