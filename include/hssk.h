@@ -466,6 +466,21 @@ typedef struct hssk_gram_desc {
   int ldg;
 } hssk_gram_desc;
 int hssk_gram_vbatched(hssk_ctx* ctx, const hssk_gram_desc* descs, int count);
+/* The same for panels that are blocks of a kernel matrix, W(k, c) = K(x_row(k), x_col(c)) with rows = ri[0..rows) (device ints) or the
+ * range r0 + k, columns = ci[0..m) or c0 + c (as hssk_keval_desc, no diagonal shift: the two point sets are disjoint): the
+ * entries are evaluated while they are staged, the panel itself never exists.  Gauss / Laplace kernels, point dimension <= 16,
+ * m <= 256 (hssk_gram_gen_supported); returns 2 otherwise. */
+typedef struct hssk_gramgen_desc {
+  const int* ri;
+  int r0;
+  const int* ci;
+  int c0;
+  int rows, m;
+  double* G;
+  int ldg;
+} hssk_gramgen_desc;
+int hssk_gram_gen_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* spec, const hssk_gramgen_desc* descs, int count);
+int hssk_gram_gen_supported(const hssk_kernel_spec* spec, int mmax);
 
 /* ---- the inner levels of a compression round as ONE launch (kernels/hssk_tree.hip) ------------------------------------
  * compress_recursive_stable above the leaves (HSS/HSSMatrix.compress_stable.hpp:165-348, HSS/HSSMatrix.compress.hpp:555-629,

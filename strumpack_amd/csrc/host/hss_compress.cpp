@@ -666,8 +666,17 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
   std::vector<int> gramLd(cnt, 0);
   std::vector<hssk_pchol_desc> pcd;
   std::vector<size_t> pck;
+  const std::vector<hssk_keval_desc>* gen = id_gen_;   // panels not evaluated yet (kernel matrices)
+  std::vector<char> evaluated(cnt, gen ? 0 : 1);
+  auto evaluate = [&](const std::vector<size_t>& ks_) {
+    std::vector<hssk_keval_desc> ev;
+    for (size_t k : ks_)
+      if (!evaluated[k] && (*gen)[k].out) { ev.push_back((*gen)[k]); evaluated[k] = 1; }
+    if (!ev.empty()) ck(hssk_kernel_eval_vbatched(ctx_, &id_gen_spec_, ev.data(), (int)ev.size()));
+  };
   if (gram_on && id_gram_ && !srcs) {
     std::vector<hssk_gram_desc> gd;
+    std::vector<hssk_gramgen_desc> gg;
     std::vector<hssk_sum_desc> sd;
     size_t tiles_total = 0;
     for (size_t k = 0; k < cnt; k++) {
@@ -689,10 +698,15 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       if (nch > 1 && d - (nch - 1) * rows < 16) nch--;   // (a last chunk of a few rows joins its predecessor: a chunk has at least two)
       double* G = tmp.dbl((size_t)m * m);
       double* P = nch > 1 ? tmp.dbl((size_t)nch * m * m) : G;
+      const bool fused = gen && (*gen)[k].out == Ws[k] && hssk_gram_gen_supported(&id_gen_spec_, m);
       for (int c = 0; c < nch; c++) {
         const int r0 = c * rows, kr = c == nch - 1 ? d - r0 : rows;
-        gd.push_back(hssk_gram_desc{Ws[k] + r0, d, kr, m, P + (size_t)c * m * m, m});
+        if (fused) {
+          const hssk_keval_desc& kd = (*gen)[k];
+          gg.push_back(hssk_gramgen_desc{kd.ri ? kd.ri + r0 : nullptr, kd.r0 + r0, kd.ci, kd.c0, kr, m, P + (size_t)c * m * m, m});
+        } else gd.push_back(hssk_gram_desc{Ws[k] + r0, d, kr, m, P + (size_t)c * m * m, m});
       }
+      if (!fused && gen) evaluate({k});
       if (nch > 1) sd.push_back(hssk_sum_desc{P, (long long)m * m, (long long)m * m, nch, G});
       const int cap = std::max(1, std::min(m, hssk_pchol_id_rank_cap(m)));
       gramR[k] = tmp.dbl((size_t)cap * m);
@@ -702,12 +716,18 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
       stats_.f_ortho += (double)d * m * (m + 1.0);   // the triangle of W^T W
     }
     if (!gd.empty()) ck(hssk_gram_vbatched(ctx_, gd.data(), (int)gd.size()));
+    if (!gg.empty()) ck(hssk_gram_gen_vbatched(ctx_, &id_gen_spec_, gg.data(), (int)gg.size()));
     if (!sd.empty()) ck(hssk_sum_partials(ctx_, sd.data(), (int)sd.size()));
   }
   {
     // (the TSQR takes what the Gram form does not)
     std::vector<double*> Wt(Ws);
     for (size_t k = 0; k < cnt; k++) if (gram[k]) Wt[k] = nullptr;
+    if (gen) {   // (what the Gram form does not take is evaluated now)
+      std::vector<size_t> rest;
+      for (size_t k = 0; k < cnt; k++) if (!gram[k]) rest.push_back(k);
+      evaluate(rest);
+    }
     tsqr_reduce(ids, which, Wt, ds);
     for (size_t k = 0; k < cnt; k++) if (!gram[k]) Ws[k] = Wt[k];
   }
@@ -748,6 +768,7 @@ void DeviceHSS::id_panels(const std::vector<int>& ids, const std::vector<int>& w
     for (size_t k = 0; k < cnt; k++)
       if (gram[k] && hall[k] < 0) { rid.push_back(ids[k]); rwh.push_back(which[k]); rW.push_back(Ws[k]); rds.push_back(ds[k]); rk_.push_back(k); }
     if (!rid.empty()) {
+      if (gen) evaluate(rk_);
       tsqr_reduce(rid, rwh, rW, rds);
       std::vector<hssk_id_desc> rdd;
       int dmx = 0, mmx = 0;

@@ -74,6 +74,9 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     std::vector<int> dcnt(dev_sets ? nodes_.size() : 0, 0);
     auto set_size = [&](int id) { return dev_sets ? dcnt[id] : (int)cols[id].size(); };
     bool failed = false;
+    // sample panels evaluated inside the Gram products of their IDs (STRUMPACK_AMD_ID_GRAM_GEN=0: evaluated here, as before)
+    static const bool gen_env = [] { const char* e = std::getenv("STRUMPACK_AMD_ID_GRAM_GEN"); return !(e && e[0] == '0'); }();
+    const bool gen_panels = gen_env && !ks.eval && hssk_gram_gen_supported(&spec, 1);
     auto do_level = [&](const std::vector<int>& ids) {
       if (ids.empty() || failed) return;
       tmp_->rewind();
@@ -181,6 +184,7 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       std::vector<int> idn, which;
       std::vector<double*> Ws;
       std::vector<int> ds;
+      std::vector<hssk_keval_desc> wgen;   // per ID panel: its description as a block of the kernel matrix (gen_panels)
       for (size_t q = 0; q < ids.size(); q++) {
         Node& nd = nodes_[ids[q]];
         if (nd.leaf()) {
@@ -202,9 +206,15 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         idn.push_back(ids[q]); which.push_back(0); ds.push_back(d);
         double* W = (m > 0 && d > 0) ? tmp_->dbl((size_t)d * m) : nullptr;
         Ws.push_back(W);
+        wgen.push_back(hssk_keval_desc{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0});
         if (W) {
-          ev.push_back(hssk_keval_desc{dev_sets ? dcols[ids[q]] : didx + coff[q], didx + roff[q], W, d, m, d, 0, 0});
-          hev.push_back(HostEv{hidx.data() + coff[q], hidx.data() + roff[q]});   // (read by the host evaluation only: never with device sets)
+          const hssk_keval_desc wd{dev_sets ? dcols[ids[q]] : didx + coff[q], didx + roff[q], W, d, m, d, 0, 0};
+          // (the sample panels of a library kernel are evaluated where they are used: id_panels, DeviceHSS::id_gen_)
+          if (gen_panels) wgen.back() = wd;
+          else {
+            ev.push_back(wd);
+            hev.push_back(HostEv{hidx.data() + coff[q], hidx.data() + roff[q]});   // (read by the host evaluation only: never with device sets)
+          }
         }
       }
       if (!ev.empty() && ks.eval) {
@@ -236,7 +246,10 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
           ck(hssk_memset_zero(ctx_, Ws[q], (long long)sizeof(double) * nodes_[idn[q]].mU));
           ds[q] = 1;
         }
-      id_panels(idn, which, Ws, ds);
+      id_gen_ = gen_panels ? &wgen : nullptr;
+      id_gen_spec_ = spec;
+      try { id_panels(idn, which, Ws, ds); } catch (...) { id_gen_ = nullptr; throw; }
+      id_gen_ = nullptr;
       // symmetric: V = U; acceptance test of compute_U_V_bases_ann (:262-272)
       for (size_t q = 0; q < idn.size(); q++) {
         Node& nd = nodes_[idn[q]];

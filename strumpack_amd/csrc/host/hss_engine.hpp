@@ -311,6 +311,11 @@ class DeviceHSS {
   // the row ID of tall panels may be taken from their Gram matrices (id_panels): set by the kernel-matrix compression only --
   // its panels are thousands of rows tall and its tolerances loose; the sketch-based compression keeps the Householder forms
   bool id_gram_ = false;
+  // kernel matrices: the panels id_panels receives have NOT been evaluated -- entry k describes panel k as a block of the kernel
+  // matrix (out = the panel's place): the Gram form evaluates the entries while it multiplies (hssk_gram_gen_vbatched), every
+  // other route evaluates its panels first
+  const std::vector<hssk_keval_desc>* id_gen_ = nullptr;
+  hssk_kernel_spec id_gen_spec_{};
   void finish_id_bookkeeping();
   void id_panels(const std::vector<int>& ids, const std::vector<int>& which, const std::vector<double*>& Ws,
                  const std::vector<int>& ds, const std::vector<const double*>* srcs = nullptr, int ldsrc = 0);

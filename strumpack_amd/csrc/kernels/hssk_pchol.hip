@@ -391,3 +391,150 @@ extern "C" int hssk_gram_vbatched(hssk_ctx* ctx, const hssk_gram_desc* descs, in
   hssk_rt::check_launch();
   HSSK_API_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same product for panels that are blocks of a KERNEL matrix, W(k, c) = K(x_row(k), x_col(c)) (Gauss / Laplace): the entries
+// are evaluated from the points' coordinates while they are staged -- the panel (8 GB per compression at N = 1e5) is neither
+// written by hssk_kernel_eval_vbatched nor read back here.  Columns' points sit in the LDS for the whole chunk, a stage's 16
+// row points are fetched one stage ahead; a thread evaluates up to eight entries per stage under the products of the previous one.
+// Point dimension <= 16.
+namespace {
+constexpr int GG_DP = 17;   // doubles per point in the LDS (16 coordinates + 1: lanes of consecutive points on different banks)
+
+template <int NT>
+__global__ __launch_bounds__(G2_T) void gram_gen_panel_kernel(hssk_kernel_spec ks, const hssk_gramgen_desc* __restrict__ descs) {
+  HSSK_DYN_SHARED(double, gg_lds);   // two stages of [mp columns][17] | column points [mp][17] | row points of a stage [16][17]
+  const hssk_gramgen_desc p = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = hssk_uniform(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
+  const int m = p.m, nb = (m + 15) / 16, ntile = nb * (nb + 1) / 2, mp = nb * 16, d = ks.d;
+  double* Xc = gg_lds + 2 * (size_t)mp * G2_KP;
+  double* Xr = Xc + (size_t)mp * GG_DP;
+  const int per = (ntile + 7) / 8, t0 = wave * per, cnt = max(0, min(per, ntile - t0));
+  int ta[NT], tb[NT];
+  {
+    int a = 0, rem = t0;
+    while (a < nb && rem >= nb - a) { rem -= nb - a; a++; }
+    int b = a + rem;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      ta[i] = min(a, nb - 1); tb[i] = min(b, nb - 1);
+      b++;
+      if (b >= nb) { a++; b = a; }
+    }
+  }
+  hssk_d4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = hssk_d4{0., 0., 0., 0.};
+  // the columns' points (W's column c = point ci[c] or c0 + c)
+  for (int e = tid; e < mp * d; e += G2_T) {
+    const int c = e / d, j = e % d;
+    const int g = c < m ? (p.ci ? p.ci[c] : p.c0 + c) : 0;
+    Xc[c * GG_DP + j] = c < m ? hssk_gload(ks.X, (size_t)g * d + j) : 0.;
+  }
+  // a stage's row points: thread t < 16 d fetches coordinate t % d of row k0 + t / d (one stage ahead, through a register)
+  auto fetch_rows = [&](int k0) {
+    double x = 0.;
+    if (tid < 16 * d) {
+      const int k = k0 + tid / d;
+      const int g = k < p.rows ? (p.ri ? p.ri[k] : p.r0 + k) : 0;
+      x = hssk_gload(ks.X, (size_t)g * d + tid % d);
+    }
+    return x;
+  };
+  const double scale = ks.type == 0 ? -1. / (2. * ks.h * ks.h) : -1. / ks.h;
+  // entries of stage k0 this thread evaluates: k = tid & 15, columns (tid >> 4) + 32 r
+  const int kt = tid & 15, ct = tid >> 4;
+  double gv[8];
+  auto generate = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int c = ct + 32 * r;
+      gv[r] = 0.;
+      if (32 * r < mp) {
+        double a = 0.;
+        for (int j = 0; j < d; j++) {
+          const double df = Xr[kt * GG_DP + j] - Xc[min(c, mp - 1) * GG_DP + j];
+          a += ks.type == 0 ? df * df : fabs(df);
+        }
+        gv[r] = (k0 + kt < p.rows && c < m) ? exp(a * scale) : 0.;
+      }
+    }
+  };
+  double xr = fetch_rows(0);
+  if (tid < 16 * d) Xr[(tid / d) * GG_DP + tid % d] = xr;
+  __syncthreads();
+  generate(0);
+  xr = fetch_rows(G2_K);
+  __syncthreads();   // (the first stage's row points are replaced at the top of the loop: every wave has evaluated its entries)
+  int buf = 0;
+  for (int k0 = 0; k0 < p.rows; k0 += G2_K, buf ^= 1) {
+    double* S = gg_lds + (size_t)buf * mp * G2_KP;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int c = ct + 32 * r;
+      if (c < mp) S[c * G2_KP + kt] = gv[r];
+    }
+    if (tid < 16 * d) Xr[(tid / d) * GG_DP + tid % d] = xr;   // (the row points of stage k0 were last read before the previous barrier)
+    __syncthreads();
+    if (k0 + G2_K < p.rows) {
+      generate(k0 + G2_K);
+      xr = fetch_rows(k0 + 2 * G2_K);
+    }
+#pragma unroll
+    for (int kk = 0; kk < G2_K; kk += 4) {
+      double av = 0.;
+      int arow = -1;
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+        if (i < cnt) {
+          if (ta[i] != arow) { arow = ta[i]; av = S[(16 * arow + l15) * G2_KP + kk + l4]; }
+          const double bv = S[(16 * tb[i] + l15) * G2_KP + kk + l4];
+          acc[i] = hssk_mfma_f64_16x16x4(av, bv, acc[i]);
+        }
+    }
+    __syncthreads();   // (the row points are replaced at the top of the next stage: every wave has evaluated its entries)
+  }
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+    if (i < cnt) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = 16 * ta[i] + l4 + 4 * r, gj = 16 * tb[i] + l15;
+        if (gi < m && gj < m) {
+          hssk_gstore(p.G, (size_t)gi + (size_t)gj * p.ldg, acc[i][r]);
+          if (ta[i] != tb[i]) hssk_gstore(p.G, (size_t)gj + (size_t)gi * p.ldg, acc[i][r]);
+        }
+      }
+    }
+}
+
+template <int NT> void gram_gen_launch(hssk_ctx* ctx, const hssk_kernel_spec& ks, const hssk_gramgen_desc* descs, int count, int mmax) {
+  const int mp = ((mmax + 15) / 16) * 16;
+  const size_t shm = sizeof(double) * (2 * (size_t)mp * G2_KP + (size_t)mp * GG_DP + 16 * GG_DP);
+  auto* dd = (const hssk_gramgen_desc*)ctx->stage(descs, sizeof(*descs) * count);
+  hssk_rt::allow_dynamic_lds(gram_gen_panel_kernel<NT>, shm);
+  HSSK_LAUNCH(gram_gen_panel_kernel<NT>, dim3((unsigned)count), dim3(G2_T), shm, ctx->stream, ks, dd);
+}
+}  // namespace
+
+extern "C" int hssk_gram_gen_supported(const hssk_kernel_spec* spec, int mmax) {
+  return spec && (spec->type == 0 || spec->type == 1) && spec->d >= 1 && spec->d <= 16 && mmax >= 1 && mmax <= 256 &&
+         sizeof(double) * (2 * (size_t)(((mmax + 15) / 16) * 16) * G2_KP + (size_t)(((mmax + 15) / 16) * 16) * GG_DP + 16 * GG_DP) <= hssk_rt::max_lds_per_workgroup();
+}
+
+extern "C" int hssk_gram_gen_vbatched(hssk_ctx* ctx, const hssk_kernel_spec* spec, const hssk_gramgen_desc* descs, int count) {
+  HSSK_API_BEGIN
+  if (count <= 0) return 0;
+  int mmax = 0;
+  for (int q = 0; q < count; q++) {
+    if (descs[q].m <= 0 || descs[q].rows <= 0) throw std::invalid_argument("hssk_gram_gen_vbatched: empty panel");
+    mmax = std::max(mmax, descs[q].m);
+  }
+  if (!hssk_gram_gen_supported(spec, mmax)) HSSK_UNSUPPORTED("Gauss / Laplace kernels over points of at most 16 coordinates, panels of at most 256 columns");
+  const int nb = (mmax + 15) / 16, per = (nb * (nb + 1) / 2 + 7) / 8;
+  if (per <= 5) gram_gen_launch<5>(ctx, *spec, descs, count, mmax);
+  else if (per <= 12) gram_gen_launch<12>(ctx, *spec, descs, count, mmax);
+  else gram_gen_launch<17>(ctx, *spec, descs, count, mmax);
+  hssk_rt::check_launch();
+  HSSK_API_END
+}

@@ -104,6 +104,11 @@ class GramDesc(C.Structure):
     _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("rows", C.c_int), ("m", C.c_int), ("G", C.c_void_p), ("ldg", C.c_int)]
 
 
+class GramGenDesc(C.Structure):
+    _fields_ = [("ri", C.c_void_p), ("r0", C.c_int), ("ci", C.c_void_p), ("c0", C.c_int), ("rows", C.c_int), ("m", C.c_int),
+                ("G", C.c_void_p), ("ldg", C.c_int)]
+
+
 class QrDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("rows", C.c_int), ("cols", C.c_int),
                 ("Q", C.c_void_p), ("ldq", C.c_int), ("nq", C.c_int),
@@ -158,7 +163,7 @@ HSSK_SYMBOLS = [
     "hssk_laswp_vbatched", "hssk_shift_diag_cplx", "hssk_upload_async", "hssk_h2d_block_async", "hssk_h2d_bytes_async", "hssk_expand_image", "hssk_copy_fence", "hssk_compute_fence", "hssk_compute_mark", "hssk_copy_wait", "hssk_id_xsolve_vbatched", "hssk_id_solves_inline", "hssk_gather_combine", "hssk_ulv_split", "hssk_tpqr_vbatched", "hssk_fill_toeplitz_block", "hssk_sum_slabs", "hssk_ulv_fwd_sweep", "hssk_ulv_bwd_sweep", "hssk_apply_sweep", "hssk_sweep_status", "hssk_sweep_arm", "hssk_trtri_diag_vbatched", "hssk_sjlt_dense", "hssk_sjlt_sketch",
     "hssk_plan_begin", "hssk_plan_end", "hssk_plan_replay", "hssk_plan_destroy", "hssk_plan_size",
     "hssk_sketch_gen", "hssk_gen_elems", "hssk_gen_fill", "hssk_colsets", "hssk_colsets_max_universe",
-    "hssk_cluster_median", "hssk_pchol_id_vbatched", "hssk_pchol_id_max_m", "hssk_pchol_id_rank_cap", "hssk_sum_partials", "hssk_gram_vbatched",
+    "hssk_cluster_median", "hssk_pchol_id_vbatched", "hssk_pchol_id_max_m", "hssk_pchol_id_rank_cap", "hssk_sum_partials", "hssk_gram_vbatched", "hssk_gram_gen_vbatched", "hssk_gram_gen_supported",
 ]
 
 
@@ -271,6 +276,8 @@ class Hssk:
         for fn in ("hssk_pchol_id_vbatched", "hssk_sum_partials", "hssk_gram_vbatched"):
             getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hssk_pchol_id_rank_cap.argtypes = [C.c_int]
+        L.hssk_gram_gen_vbatched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.hssk_gram_gen_supported.argtypes = [C.c_void_p, C.c_int]
         L.hssk_colsets_max_universe.argtypes = []
         L.hssk_colsets_max_universe.restype = C.c_longlong
         L.hssk_sjlt_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]

@@ -386,6 +386,42 @@ def case_gram_pchol_id(hk, problems, seed=41):
         assert err <= max(bound, 1e-7), f"ID residual {err} > {bound} for {prob}"
 
 
+def case_gram_gen(hk, n=700, d=6, seed=43):
+    """hssk_gram_gen_vbatched: W^T W of blocks W = K(rows, cols) of a kernel matrix, evaluated while they are multiplied, against
+    numpy (index lists and ranges, row counts that are no multiple of the stage, Gauss and Laplace)."""
+    r = rng(seed)
+    X = r.standard_normal((n, d))
+    dX = hk.array(X.T)
+    for (ktype, h) in ((0, 1.7), (1, 2.2)):
+        spec = K.KernelSpec(dX.ptr, n, d, ktype, 1, h, 3.0)
+        assert hk.lib.hssk_gram_gen_supported(C.byref(spec), 256) == 1
+        probs, descs, keep = [], [], []
+        for (rows, m, lists) in ((333, 70, True), (64, 130, False), (17, 1, True), (500, 195, True), (2, 16, False)):
+            ri = r.permutation(n)[:rows].astype(np.int32)
+            ci = r.permutation(n)[:m].astype(np.int32)
+            r0, c0 = int(r.integers(0, n - rows)), int(r.integers(0, n - m))
+            dG = hk.array(np.full((m + 1, m), np.nan))
+            if lists:
+                dri, dci = hk.array(ri), hk.array(ci)
+                keep.append((dri, dci))
+                descs.append(K.GramGenDesc(dri.ptr, 0, dci.ptr, 0, rows, m, dG.ptr, m + 1))
+                rr, cc = ri, ci
+            else:
+                descs.append(K.GramGenDesc(None, r0, None, c0, rows, m, dG.ptr, m + 1))
+                rr, cc = np.arange(r0, r0 + rows), np.arange(c0, c0 + m)
+            probs.append((rr, cc, dG, m))
+        arr = (K.GramGenDesc * len(descs))(*descs)
+        hk.check(hk.lib.hssk_gram_gen_vbatched(hk.ctx, C.byref(spec), arr, len(descs)))
+        hk.sync()
+        for (rr, cc, dG, m) in probs:
+            W = kernel_np(X, rr, cc, ktype, h, 0.0)
+            G = dG.get()[:m]
+            assert np.allclose(G, W.T @ W, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(W.T @ W).max())), (ktype, len(rr), m)
+            assert np.array_equal(G, G.T)
+    spec = K.KernelSpec(dX.ptr, n, d, 2, 2, 1.0, 0.0)
+    assert hk.lib.hssk_gram_gen_supported(C.byref(spec), 100) == 0   # (ANOVA: evaluated by hssk_kernel_eval_vbatched)
+
+
 def case_qr(hk, shapes, seed=7):
     r = rng(seed)
     descs, keep = [], []

@@ -179,6 +179,10 @@ def test_gram_pchol_id(hk):
     KC.case_gram_pchol_id(hk, [(300, 40, 1e-3, 1e-12, 1000, 12, 1), (700, 70, 1e-2, 1e-10, 1000, None, 3), (520, 33, 1e-4, 1e-12, 5, 9, 2), (260, 130, 1e-8, 1e-14, 1000, None, 1)])
 
 
+def test_gram_gen(hk):
+    KC.case_gram_gen(hk)
+
+
 def test_knn(hk):
     KC.case_knn(hk, n=150, d=8, k=10)
     KC.case_knn(hk, n=90, d=3, k=70, seed=24)     # two pages

@@ -178,6 +178,10 @@ def test_gram_pchol_id(hk):
                               (777, 1, 1e-2, 1e-12, 10, None, 1), (600, 255, 1e-12, 1e-14, 1000, None, 2), (40001, 82, 1e-3, 1e-12, 1000, 25, 16)])
 
 
+def test_gram_gen(hk):
+    KC.case_gram_gen(hk)
+
+
 def test_knn(hk):
     KC.case_knn(hk, n=2000, d=8, k=64)
     KC.case_knn(hk, n=300, d=3, k=150, seed=24)
