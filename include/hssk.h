@@ -227,13 +227,18 @@ int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int q0, int q1
  * inner node -- the union of its children's sets without the ids inside the node).  out = sorted unique ids of
  * src0[0:n0] and src1[0:n1] (device ints; src1 may be NULL) that are >= 0 and outside [lo, hi); *count = their number
  * (out has room for n0 + n1).  universe = number of points (all ids are below it): a workgroup marks a bitmap of that many
- * bits in its LDS and reads it back in order; returns HSSK_UNSUPPORTED when the bitmap does not fit the LDS. */
+ * bits in its LDS and reads it back in order; returns HSSK_UNSUPPORTED when the bitmap does not fit the LDS.
+ * n0_dev / n1_dev (device ints, may be NULL): when given, the lengths of src0 / src1 are read from there -- the counts an earlier
+ * launch wrote -- and n0 / n1 are only their upper bounds (out has room for n0 + n1): the levels of a tree are then launched
+ * back to back without reading a count back in between. */
 typedef struct hssk_colset_desc {
   const int* src0;
   const int* src1;
   int n0, n1, lo, hi;
   int* out;
   int* count;
+  const int* n0_dev;
+  const int* n1_dev;
 } hssk_colset_desc;
 int hssk_colsets(hssk_ctx* ctx, const hssk_colset_desc* descs, int count, int universe);
 long long hssk_colsets_max_universe(void);   /* largest universe hssk_colsets takes on this device */

@@ -77,6 +77,41 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     // sample panels evaluated inside the Gram products of their IDs (STRUMPACK_AMD_ID_GRAM_GEN=0: evaluated here, as before)
     static const bool gen_env = [] { const char* e = std::getenv("STRUMPACK_AMD_ID_GRAM_GEN"); return !(e && e[0] == '0'); }();
     const bool gen_panels = gen_env && !ks.eval && hssk_gram_gen_supported(&spec, 1);
+    // Column sets on the device: one launch per level (a workgroup per node).  They depend on the children's SETS only, not on
+    // their IDs, and a parent reads its children's counts on the device (hssk_colset_desc::n0_dev), its own room being the bound
+    // min(children's bounds, points outside the node): all levels are launched back to back before the first block is evaluated
+    // and every count comes back in ONE read (a read per level in the middle of the stream cost ~0.1 ms each).
+    if (dev_sets) {
+      const double tc0 = now();
+      int* dcount = work_->ints(nodes_.size());
+      std::vector<int> bound(nodes_.size(), 0);
+      for (auto& ids : own_by_height_) {
+        std::vector<hssk_colset_desc> cd;
+        for (size_t q = 0; q < ids.size(); q++) {
+          const int id = ids[q];
+          const Node& nd = nodes_[id];
+          if (nd.lvl == 0) continue;
+          hssk_colset_desc c{};
+          if (nd.leaf()) { c.src0 = dann + (size_t)nd.lo * k; c.n0 = nd.m * k; }
+          else {
+            c.src0 = dcols[nd.c0]; c.n0 = bound[nd.c0]; c.n0_dev = dcount + nd.c0;
+            c.src1 = dcols[nd.c1]; c.n1 = bound[nd.c1]; c.n1_dev = dcount + nd.c1;
+          }
+          c.lo = nd.lo; c.hi = nd.lo + nd.m;
+          bound[id] = (int)std::min<long long>((long long)c.n0 + c.n1, (long long)N - nd.m);
+          c.out = dcols[id] = work_->ints((size_t)std::max(c.n0 + c.n1, 1));
+          c.count = dcount + id;
+          cd.push_back(c);
+        }
+        if (!cd.empty()) ck(hssk_colsets(ctx_, cd.data(), (int)cd.size(), N));
+      }
+      std::vector<int> hc(nodes_.size(), 0);
+      ck(hssk_memcpy_d2h(ctx_, hc.data(), dcount, (long long)sizeof(int) * nodes_.size()));
+      for (auto& ids : own_by_height_)
+        for (int id : ids)
+          if (nodes_[id].lvl > 0) dcnt[id] = hc[id];
+      stats_.t_sketch += now() - tc0;
+    }
     auto do_level = [&](const std::vector<int>& ids) {
       if (ids.empty() || failed) return;
       tmp_->rewind();
@@ -152,29 +187,6 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         }
       int* didx = tmp_->ints(std::max<size_t>(hidx.size(), 1));
       if (!hidx.empty()) ck(hssk_memcpy_h2d(ctx_, didx, hidx.data(), (long long)sizeof(int) * hidx.size()));
-      if (dev_sets) {
-        // the level's sets in one launch (a workgroup per node); their sizes come back in one read
-        std::vector<hssk_colset_desc> cd;
-        std::vector<int> cq;
-        int* dc = tmp_->ints(ids.size());
-        for (size_t q = 0; q < ids.size(); q++) {
-          const Node& nd = nodes_[ids[q]];
-          if (nd.lvl == 0) continue;
-          hssk_colset_desc c{};
-          if (nd.leaf()) { c.src0 = dann + (size_t)nd.lo * k; c.n0 = nd.m * k; }
-          else { c.src0 = dcols[nd.c0]; c.n0 = dcnt[nd.c0]; c.src1 = dcols[nd.c1]; c.n1 = dcnt[nd.c1]; }
-          c.lo = nd.lo; c.hi = nd.lo + nd.m;
-          c.out = dcols[ids[q]] = work_->ints((size_t)std::max(c.n0 + c.n1, 1));
-          c.count = dc + q;
-          cd.push_back(c); cq.push_back((int)q);
-        }
-        if (!cd.empty()) {
-          ck(hssk_colsets(ctx_, cd.data(), (int)cd.size(), N));
-          std::vector<int> hc(ids.size(), 0);
-          ck(hssk_memcpy_d2h(ctx_, hc.data(), dc, (long long)sizeof(int) * ids.size()));
-          for (int q : cq) dcnt[ids[q]] = hc[q];
-        }
-      }
       stats_.t_sketch += now() - tl0;   // host column-set construction (the 'sketch' slot of this path)
       // ---- D (leaves), B01 / B10 (inner nodes), sample panels W = K(cols, rows)  [= S^T]
       std::vector<hssk_keval_desc> ev;

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(CS_T) void colset_kernel(const hssk_colset_desc* __
   __syncthreads();
   for (int s = 0; s < 2; s++) {
     const int* src = s ? p.src1 : p.src0;
-    const int n = s ? p.n1 : p.n0;
+    const int* nd = s ? p.n1_dev : p.n0_dev;
+    const int n = nd ? min(*nd, s ? p.n1 : p.n0) : (s ? p.n1 : p.n0);   // (a count an earlier launch left on the device)
     if (!src) continue;
     for (int e = tid; e < n; e += CS_T) {
       const int g = src[e];

@@ -36,7 +36,7 @@ class KevalDesc(C.Structure):
 
 class ColsetDesc(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("n0", C.c_int), ("n1", C.c_int), ("lo", C.c_int), ("hi", C.c_int),
-                ("out", C.c_void_p), ("count", C.c_void_p)]
+                ("out", C.c_void_p), ("count", C.c_void_p), ("n0_dev", C.c_void_p), ("n1_dev", C.c_void_p)]
 
 
 class ColGatherDesc(C.Structure):
