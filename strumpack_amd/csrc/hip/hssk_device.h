@@ -227,6 +227,8 @@ __device__ __forceinline__ void hssk_lds_or(unsigned* p, unsigned v) {
 __device__ __forceinline__ int hssk_lds_inc(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // a value known to be the same in every lane of the wave, moved to a scalar register (loads indexed by it become s_load)
 // device-wide counter (statistics)
+// k + t * t with the product rounded before the addition (what a host compiler without fused multiply-add computes)
+__device__ __forceinline__ double hssk_sq_acc_rn(double k, double t) { return __dadd_rn(k, __dmul_rn(t, t)); }
 __device__ __forceinline__ int hssk_gadd_i(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void hssk_gadd_ll(long long* p, long long v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int hssk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -40,16 +40,10 @@ struct ClDesc {
   int lo, n;
 };
 
-#ifdef HSSK_EMU
-inline double cl_sq_acc(double k, double t) { return k + t * t; }   // (x86-64 baseline: no fused multiply-add)
-#else
-__device__ __forceinline__ double cl_sq_acc(double k, double t) { return __dadd_rn(k, __dmul_rn(t, t)); }
-#endif
-
 // kernel/Metrics.hpp:41-50 followed by sqrt (Euclidean_distance)
 __device__ inline double cl_dist(int d, const double* a, const double* b) {
   double k = 0.;
-  for (int i = 0; i < d; i++) k = cl_sq_acc(k, a[i] - b[i]);
+  for (int i = 0; i < d; i++) k = hssk_sq_acc_rn(k, a[i] - b[i]);   // (the product rounded before it is added: the host's arithmetic)
   return sqrt(k);
 }
 

@@ -141,6 +141,7 @@ inline int hssk_opaque(int v) { return v; }
 inline void hssk_lds_add(double* p, double v) { *p += v; }   // fibers are cooperative: a plain update is atomic
 inline void hssk_lds_or(unsigned* p, unsigned v) { *p |= v; }
 inline int hssk_lds_inc(int* p) { return (*p)++; }
+inline double hssk_sq_acc_rn(double k, double t) { volatile double p = t * t; return k + p; }   // (the product rounded on its own)
 inline int hssk_gadd_i(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline void hssk_gadd_ll(long long* p, long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline int hssk_uniform(int v) { return v; }
