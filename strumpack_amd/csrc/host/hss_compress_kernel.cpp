@@ -120,11 +120,20 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
       std::vector<int> hidx;
       std::vector<size_t> roff(ids.size()), coff(ids.size());
       std::vector<std::vector<int>> rows(ids.size());
-      // the nodes of a level are independent: host threads build their row / column sets side by side
-      host_parallel_for(ids.size(), [&](size_t q) {
+      // With the column sets on the device a panel's rows need no list from the host either: a leaf's are a range, an inner
+      // node's the skeleton indices of its children, which the ID of their level left next to each other on the device
+      // (DeviceHSS::finish_id_bookkeeping: one block per level, in the level's order -- siblings are neighbours in it).
+      std::vector<const int*> drows(ids.size(), nullptr);
+      std::vector<char> fast(ids.size(), 0);
+      auto rows_of = [&](size_t q) {
         Node& nd = nodes_[ids[q]];
         std::vector<int>& cs = cols[ids[q]];
         const int lo = nd.lo, hi = nd.lo + nd.m;
+        if (dev_sets) {
+          if (nd.leaf()) { nd.mU = nd.mV = nd.m; fast[q] = 1; return; }
+          const Node &a = nodes_[nd.c0], &b = nodes_[nd.c1];
+          if (a.dIr && (b.rU == 0 || a.dIr + a.rU == b.dIr)) { nd.mU = nd.mV = a.rU + b.rU; drows[q] = a.dIr; fast[q] = 1; return; }
+        }
         if (nd.leaf()) {
           nd.mU = nd.mV = nd.m;
           rows[q].resize(nd.m);
@@ -173,7 +182,11 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
             while (j < cb.size()) keep(cb[j++]);
           }
         }
-      });
+      };
+      // the nodes of a level are independent: host threads build their row / column sets side by side (nothing to build with the
+      // sets and rows on the device: not worth waking the threads)
+      if (dev_sets) for (size_t q = 0; q < ids.size(); q++) rows_of(q);
+      else host_parallel_for(ids.size(), rows_of);
       for (size_t q = 0; q < ids.size(); q++) {
         const std::vector<int>& cs = cols[ids[q]];
         roff[q] = hidx.size(); hidx.insert(hidx.end(), rows[q].begin(), rows[q].end());
@@ -220,7 +233,8 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
         Ws.push_back(W);
         wgen.push_back(hssk_keval_desc{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0});
         if (W) {
-          const hssk_keval_desc wd{dev_sets ? dcols[ids[q]] : didx + coff[q], didx + roff[q], W, d, m, d, 0, 0};
+          // (rows: the leaf's range, the children's device-resident skeleton indices, or the uploaded list)
+          const hssk_keval_desc wd{dev_sets ? dcols[ids[q]] : didx + coff[q], fast[q] ? drows[q] : didx + roff[q], W, d, m, d, 0, fast[q] && !drows[q] ? nd.lo : 0};
           // (the sample panels of a library kernel are evaluated where they are used: id_panels, DeviceHSS::id_gen_)
           if (gen_panels) wgen.back() = wd;
           else {
