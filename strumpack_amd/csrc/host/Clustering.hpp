@@ -378,8 +378,17 @@ inline structured::ClusterTree median_split_tree(int n, int cluster_size) {
 // Reorders p and fills perm (1-based) like binary_tree_clustering, one launch per tree level.  Returns 0 when done; -1 when
 // this form does not apply (algorithm, dimension, layout); > 0 when the device met a tie at a median or at the farthest point
 // or a long displacement chain (hssk_cluster_median) -- p and perm are untouched then and the host form decides.
+// A device block handed on by the clustering: the reordered points (d x n doubles at its start) stay on the device for the
+// compression that follows; release() gives the block back to the pool.
+struct DevicePoints {
+  void* block = nullptr;
+  std::size_t bytes = 0;
+  const double* X() const { return (const double*)block; }
+  void release() { if (block) DevicePool::get().release(block, bytes); block = nullptr; bytes = 0; }
+};
+
 inline int binary_tree_clustering_device(ClusteringAlgorithm algo, DenseMatrix<double>& p, std::vector<int>& perm,
-                                         std::size_t cluster_size, int device, structured::ClusterTree& tree) {
+                                         std::size_t cluster_size, int device, structured::ClusterTree& tree, DevicePoints* keep = nullptr) {
   const int n = (int)p.cols(), d = (int)p.rows();
   if (algo != ClusteringAlgorithm::COBBLE && algo != ClusteringAlgorithm::KD_TREE) return -1;
   if (n <= 0 || d <= 0 || d > 64 || p.ld() != d || cluster_size < 2 || cluster_size > (std::size_t)n) return -1;
@@ -400,7 +409,8 @@ inline int binary_tree_clustering_device(ClusteringAlgorithm algo, DenseMatrix<d
     if (!rc) rc = hssk_memcpy_d2h(ctx, p.data(), dX, (long long)sizeof(double) * d * n);
   }
   std::string err = rc ? hssk_last_error() : "";
-  DevicePool::get().release(blk, chunk);
+  if (keep && !rc && !status) { keep->block = blk; keep->bytes = chunk; }   // (the caller's, with the points in cluster order)
+  else DevicePool::get().release(blk, chunk);
   hssk_ctx_destroy(ctx);
   if (rc == 2) return -1;
   if (rc) throw std::runtime_error("binary_tree_clustering (device): " + err);
@@ -415,13 +425,14 @@ inline int binary_tree_clustering_device(ClusteringAlgorithm algo, DenseMatrix<d
 // launches (STRUMPACK_AMD_CLUSTER_DEVICE_MIN points, default 8192; STRUMPACK_AMD_CLUSTER_HOST=1: always the host form).
 // *used_device (may be null): whether the device form produced the result.
 inline structured::ClusterTree binary_tree_clustering(ClusteringAlgorithm algo, DenseMatrix<double>& p, std::vector<int>& perm,
-                                                      std::size_t cluster_size, int device, bool* used_device = nullptr) {
+                                                      std::size_t cluster_size, int device, bool* used_device = nullptr,
+                                                      DevicePoints* keep = nullptr) {
   static const bool host_only = [] { const char* e = std::getenv("STRUMPACK_AMD_CLUSTER_HOST"); return e && e[0] == '1'; }();
   static const long long dev_min = [] { const char* e = std::getenv("STRUMPACK_AMD_CLUSTER_DEVICE_MIN"); return e ? std::atoll(e) : 8192LL; }();
   if (used_device) *used_device = false;
   if (!host_only && (long long)p.cols() >= dev_min) {
     structured::ClusterTree t(0);
-    if (binary_tree_clustering_device(algo, p, perm, cluster_size, device, t) == 0) {
+    if (binary_tree_clustering_device(algo, p, perm, cluster_size, device, t, keep) == 0) {
       if (used_device) *used_device = true;
       return t;
     }

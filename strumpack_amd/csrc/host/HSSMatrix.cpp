@@ -77,7 +77,9 @@ HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, cons
   auto tc0 = std::chrono::steady_clock::now();
   // (cobble / kd of a large point set: on the device, one launch per tree level -- host/Clustering.hpp, kernels/hssk_cluster.hip)
   bool on_device = false;
-  auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size(), engine_options(opts).device, &on_device);
+  DevicePoints dpts;   // (the points the device clustering reordered stay there for the compression: no second upload)
+  struct Release { DevicePoints& d; ~Release() { d.release(); } } release_dpts{dpts};
+  auto t = binary_tree_clustering(opts.clustering_algorithm(), K.data(), K.permutation(), opts.leaf_size(), engine_options(opts).device, &on_device, &dpts);
   K.permute();
   if (opts.verbose())
     std::cout << "# clustering (" << get_name(opts.clustering_algorithm()) << (on_device ? ", device" : ", host") << ") time = "
@@ -86,7 +88,9 @@ HSSMatrix<double>::HSSMatrix(kernel::Kernel<double>& K, const opts_t& opts, cons
   EngineOptions e = engine_options(opts);
   pg.apply(e);
   eng_.reset(new DeviceHSS(int(rows_), e, tree_.get()));
-  compress(K, opts);
+  device_points_ = dpts.X();
+  try { compress(K, opts); } catch (...) { device_points_ = nullptr; throw; }
+  device_points_ = nullptr;
 }
 void HSSMatrix<double>::compress(const kernel::Kernel<double>& K, const opts_t& opts) {
   compress_with_neighbors(K, opts, K.neighbors(), K.neighbor_count());
@@ -96,7 +100,7 @@ void HSSMatrix<double>::compress_with_neighbors(const kernel::Kernel<double>& K,
   if (K.data().ld() != int(K.d())) throw std::invalid_argument("compress(Kernel): the point matrix must be contiguous");
   make_engine(opts, tree_.get());
   DeviceHSS::KernelSpec ks;
-  ks.X = K.data().data(); ks.d = int(K.d()); ks.type = K.device_type(); ks.p = K.degree();
+  ks.X = K.data().data(); ks.dX = device_points_; ks.d = int(K.d()); ks.type = K.device_type(); ks.p = K.degree();
   ks.h = K.width(); ks.lambda = K.lambda(); ks.ann = std::min<int>(int(K.n()), opts.approximate_neighbors());
   // a user-defined Kernel subclass (kernel/Kernel.hpp:73-170: only its virtual eval is known): blocks evaluated on the host
   if (K.device_type() < 0) {

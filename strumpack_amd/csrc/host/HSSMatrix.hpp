@@ -72,6 +72,7 @@ template <> class HSSMatrix<double> : public structured::StructuredMatrix<double
   void compress(const kernel::Kernel<double>& K, const opts_t& opts);
   // extension (tests): the neighbour lists of the first round are given (k x n, 0-based, column i = point i)
   void compress_with_neighbors(const kernel::Kernel<double>& K, const opts_t& opts, const int* ann, int k);
+  const double* device_points_ = nullptr;   // set while the kernel constructor compresses: the points the device clustering left on the device
   // extension: A resident in HBM
   void compress_device(const double* dA, long long lda, const opts_t& opts);
   // extension: one process per GPU (subtree ownership below the cut level, replicated top);

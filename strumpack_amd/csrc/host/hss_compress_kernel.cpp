@@ -24,8 +24,8 @@ void DeviceHSS::compress_kernel(const KernelSpec& ks, const int* user_ann, int u
     reset_compression();
     stats_.rounds++;
     // points and neighbour lists
-    double* dX = work_->dbl((size_t)dim * N);
-    ck(hssk_memcpy_h2d(ctx_, dX, ks.X, (long long)sizeof(double) * dim * N));
+    double* dX = ks.dX ? const_cast<double*>(ks.dX) : work_->dbl((size_t)dim * N);
+    if (!ks.dX) ck(hssk_memcpy_h2d(ctx_, dX, ks.X, (long long)sizeof(double) * dim * N));
     hssk_kernel_spec spec{dX, N, dim, ks.type, ks.p, ks.h, ks.lambda};
     double tk0 = now();
     // Column sets on the DEVICE (hssk_colsets: sorted unions through an LDS bitmap) when nothing on the host needs them: the

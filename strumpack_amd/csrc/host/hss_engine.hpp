@@ -154,6 +154,7 @@ class DeviceHSS {
   // device nearest-neighbour search of the first round (tests pin the compression against the reference's lists)
   struct KernelSpec {
     const double* X = nullptr;
+    const double* dX = nullptr;   // the same points already on the engine's device (the clustering left them there): no upload
     int d = 0, type = 0, p = 1, ann = 64;
     double h = 1., lambda = 0.;
     // optional host neighbour search: fills ann (k x n, ids in cluster order, -1 = none) for the given k; replaces
