@@ -800,7 +800,8 @@ extern "C" int hssk_knn(hssk_ctx* ctx, const double* X, int d, int n, int k, int
   // the filtered search pays from a few thousand points on (HSSK_KNN_FILTER_MIN; HSSK_KNN_FILTER=0: always the heap kernel);
   // its lists name a candidate by (block of 32, bit): 2^16 blocks
   static const bool filt = [] { const char* e = std::getenv("HSSK_KNN_FILTER"); return !(e && e[0] == '0'); }();
-  static const int fmin_n = [] { const char* e = std::getenv("HSSK_KNN_FILTER_MIN"); return e ? std::atoi(e) : 8192; }();
+  const char* fmin_env = std::getenv("HSSK_KNN_FILTER_MIN");   // (read per call: the tests take both searches in one process)
+  const int fmin_n = fmin_env ? std::atoi(fmin_env) : 8192;
   if (!filt || n < fmin_n || k > 128 || d > 29 || n <= 4 * k || n > (1 << 21) - 256) {
     knn_exhaustive(ctx, X, d, n, k, q0, q1, out_idx, 0);
     return 0;

@@ -183,6 +183,21 @@ def test_gram_gen(hk):
     KC.case_gram_gen(hk)
 
 
+def test_knn_filtered(hk):
+    """The filtered search (FP32 matrix-core filter + exact FP64 selection: large point sets) on small sets, against numpy --
+    the same checks as the heap search: exactly a set of k nearest by the float keys, ties by index."""
+    import os
+    os.environ["HSSK_KNN_FILTER_MIN"] = "600"
+    try:
+        KC.case_knn(hk, n=700, d=8, k=10)
+        KC.case_knn(hk, n=900, d=3, k=20, seed=24)
+        KC.case_knn(hk, n=1100, d=12, k=70, seed=25)                  # the kept list longer than a page of the heap search
+        KC.case_knn(hk, n=800, d=20, k=8, seed=26)
+        KC.case_knn(hk, n=900, d=4, k=12, seed=27, lattice=True)      # exact ties, duplicates
+    finally:
+        os.environ.pop("HSSK_KNN_FILTER_MIN")
+
+
 def test_knn(hk):
     KC.case_knn(hk, n=150, d=8, k=10)
     KC.case_knn(hk, n=90, d=3, k=70, seed=24)     # two pages

@@ -182,6 +182,22 @@ def test_gram_gen(hk):
     KC.case_gram_gen(hk)
 
 
+def test_knn_filtered(hk):
+    """The filtered search (FP32 matrix-core filter + exact FP64 selection: large point sets) on small sets, against numpy --
+    the same checks as the heap search: exactly a set of k nearest by the float keys, ties by index."""
+    import os
+    os.environ["HSSK_KNN_FILTER_MIN"] = "600"
+    try:
+        KC.case_knn(hk, n=2000, d=8, k=64)
+        KC.case_knn(hk, n=900, d=3, k=20, seed=24)
+        KC.case_knn(hk, n=1100, d=12, k=70, seed=25)
+        KC.case_knn(hk, n=1300, d=8, k=128, seed=28)
+        KC.case_knn(hk, n=800, d=20, k=8, seed=26)
+        KC.case_knn(hk, n=900, d=4, k=70, seed=27, lattice=True)      # exact ties, duplicates
+    finally:
+        os.environ.pop("HSSK_KNN_FILTER_MIN")
+
+
 def test_knn(hk):
     KC.case_knn(hk, n=2000, d=8, k=64)
     KC.case_knn(hk, n=300, d=3, k=150, seed=24)
