@@ -18,7 +18,13 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $out/ktk -o kt --output-format c
 cp $out/ktk/kt_kernel_stats.csv $out/kernel_stats_bench_kernel.csv 2>/dev/null; rm -rf $out/ktk
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/ktb -o kt --output-format csv -- python /root/repo/bench.py --no-cpu-baseline --workload blr_front --front-n 200 --front-upd none --steps 2 --warmup 1 > $out/bench_blr_root_under_rocprof.json 2> $out/ktb.err
 cp $out/ktb/kt_kernel_stats.csv $out/kernel_stats_bench_blr_front_200x200_root.csv 2>/dev/null; rm -rf $out/ktb
+# launch-by-launch timeline of a kernel-matrix step; the new front end against the forms it replaced on awkward point sets
+timeout 300 rocprofv3 --kernel-trace -d $out/ktl -o kt --output-format csv -- python /root/repo/bench.py --no-cpu-baseline --workload kernel --steps 2 --warmup 1 > /dev/null 2> $out/ktl.err
+python /root/repo/tools/trace_tail.py $out/ktl > /dev/null 2>&1; [ -f $out/ktl/trace_tail.txt ] && cp $out/ktl/trace_tail.txt $out/kernel_timeline.txt; rm -rf $out/ktl
 cd /root/repo
+timeout 600 python tools/kernel_robust.py > $out/kernel_robust.txt 2>&1; grep -c "perm equal True" $out/kernel_robust.txt
+timeout 300 python tools/knn_ab.py > $out/knn_ab.txt 2>&1; tail -2 $out/knn_ab.txt
+timeout 300 python tools/cluster_ab.py > $out/cluster_ab.txt 2>&1; tail -2 $out/cluster_ab.txt
 # secondary lines of the round (no counter passes, no CPU baseline)
 for cfg in "kernel:--workload kernel --steps 4" "leaf512:--leaf 512" "nrhs64:--nrhs 64" "generated:--operand generated" "symmetric:--symmetric" "factor_ahead:--factor-ahead" \
            "blr_front_200x200_root:--workload blr_front --front-n 200 --front-upd none --steps 3 --warmup 1" "blr_front_200x100:--workload blr_front --front-n 200 --front-ny 100 --steps 2 --warmup 1"; do
